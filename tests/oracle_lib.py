@@ -1,0 +1,111 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so) — test infrastructure only.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_KDTREE_SO = os.path.join(ORACLE_DIR, "_ref", "libkdtree_ref.so")
+
+_lib = None
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        _lib = ctypes.CDLL(ORACLE_SO)
+        _declare(_lib)
+    return _lib
+
+
+def have_ref_kdtree():
+    return os.path.exists(REF_KDTREE_SO)
+
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def _declare(L):
+    L.oracle_dbscan.argtypes = [_dp, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32, _i32p, _u32p, _u32p, _u32p]
+    L.oracle_dbscan.restype = ctypes.c_int
+    L.oracle_dbscan_kdapi.argtypes = [ctypes.c_char_p] + L.oracle_dbscan.argtypes
+    L.oracle_dbscan_kdapi.restype = ctypes.c_int
+    L.oracle_range_query_all.argtypes = [_dp, ctypes.c_uint32, ctypes.c_double, _u64p, _u32p, ctypes.c_uint64]
+    L.oracle_range_query_all.restype = ctypes.c_long
+    L.oracle_range_query_all_kdapi.argtypes = [ctypes.c_char_p] + L.oracle_range_query_all.argtypes
+    L.oracle_range_query_all_kdapi.restype = ctypes.c_long
+    L.oracle_dbscan_batch.argtypes = [_dp, _u32p, _u32p, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32, _i32p, _u32p]
+    L.oracle_dbscan_batch.restype = ctypes.c_int
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def dbscan(xy, eps, minpts, kdapi=False, with_members=False):
+    """One DBSCAN::Run().  Returns (rc, labels[int32 n], n_clusters[, clusters list])."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    n = xy.shape[0]
+    labels = np.full(max(n, 1), -1, dtype=np.int32)
+    nc = ctypes.c_uint32(0)
+    members = np.zeros(max(n, 1), dtype=np.uint32)
+    moff = np.zeros(n + 2, dtype=np.uint32)
+    args = [_p(xy, _dp), n, float(eps), int(minpts), _p(labels, _i32p), ctypes.byref(nc), _p(members, _u32p),
+            _p(moff, _u32p)]
+    if kdapi:
+        rc = lib().oracle_dbscan_kdapi(REF_KDTREE_SO.encode(), *args)
+    else:
+        rc = lib().oracle_dbscan(*args)
+    labels = labels[:n]
+    if with_members:
+        cl = [members[moff[c]:moff[c + 1]].copy() for c in range(nc.value)]
+        return rc, labels, nc.value, cl
+    return rc, labels, nc.value
+
+
+def range_query_all(xy, eps, kdapi=False):
+    """CSR (off, idx) of every point's raw range query (self included, list order)."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    n = xy.shape[0]
+    cap = max(16, n * 64)
+    while True:
+        off = np.zeros(n + 1, dtype=np.uint64)
+        idx = np.zeros(cap, dtype=np.uint32)
+        if kdapi:
+            r = lib().oracle_range_query_all_kdapi(REF_KDTREE_SO.encode(), _p(xy, _dp), n, float(eps),
+                                                   _p(off, _u64p), _p(idx, _u32p), cap)
+        else:
+            r = lib().oracle_range_query_all(_p(xy, _dp), n, float(eps), _p(off, _u64p), _p(idx, _u32p), cap)
+        if r == -2:
+            cap *= 4
+            continue
+        if r < 0:
+            raise RuntimeError("oracle range query failed: %d" % r)
+        return off, idx[:r]
+
+
+def dbscan_batch(xy, seg_off, seg_cnt, eps, minpts):
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    seg_off = np.ascontiguousarray(seg_off, dtype=np.uint32)
+    seg_cnt = np.ascontiguousarray(seg_cnt, dtype=np.uint32)
+    S = seg_off.shape[0]
+    labels = np.full(max(xy.shape[0], 1), -1, dtype=np.int32)
+    ncl = np.zeros(max(S, 1), dtype=np.uint32)
+    lib().oracle_dbscan_batch(_p(xy, _dp), _p(seg_off, _u32p), _p(seg_cnt, _u32p), S, float(eps), int(minpts),
+                              _p(labels, _i32p), _p(ncl, _u32p))
+    return labels[:xy.shape[0]], ncl[:S]
