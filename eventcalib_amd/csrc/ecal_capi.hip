@@ -1,0 +1,90 @@
+// Context lifecycle and shared helpers of libecal.so.
+#include "ecal_ctx.hpp"
+
+int ecal_ensure(ecal_ctx *ctx, ecal_devbuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return ECAL_OK;
+    if (b.ptr) {
+        hipError_t e = hipFree(b.ptr);
+        b.ptr = nullptr;
+        b.cap = 0;
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("hipFree: ") + hipGetErrorString(e);
+            return ECAL_ERR_HIP;
+        }
+    }
+    // grow geometrically so that a stream of slowly growing batches does not re-allocate each time
+    size_t want = bytes + bytes / 4;
+    want = (want + 255) & ~(size_t) 255;
+    hipError_t e = hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) {
+        want = (bytes + 255) & ~(size_t) 255;
+        e = hipMalloc(&b.ptr, want);
+    }
+    if (e != hipSuccess) {
+        b.ptr = nullptr;
+        ctx->last_error = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+        return ECAL_ERR_NOMEM;
+    }
+    b.cap = want;
+    return ECAL_OK;
+}
+
+extern "C" int ecal_abi_version(void) { return ECAL_ABI_VERSION; }
+
+extern "C" const char *ecal_strerror(int status) {
+    switch (status) {
+        case ECAL_OK: return "ok";
+        case ECAL_ERR_INVALID: return "invalid argument";
+        case ECAL_ERR_NO_DEVICE: return "no usable HIP device";
+        case ECAL_ERR_HIP: return "HIP runtime error";
+        case ECAL_ERR_NOMEM: return "out of memory";
+        case ECAL_ERR_UNSORTED: return "event timestamps not sorted";
+        case ECAL_ERR_RANGE: return "size out of range";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char *ecal_last_error(const ecal_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+extern "C" int ecal_init(int device, ecal_ctx **out) {
+    if (!out) return ECAL_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ECAL_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return ECAL_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return ECAL_ERR_NO_DEVICE;
+    ecal_ctx *ctx = new (std::nothrow) ecal_ctx;
+    if (!ctx) return ECAL_ERR_NOMEM;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ECAL_ERR_HIP;
+    }
+    *out = ctx;
+    return ECAL_OK;
+}
+
+static void release(ecal_devbuf &b) {
+    if (b.ptr) (void) hipFree(b.ptr);
+    b.ptr = nullptr;
+    b.cap = 0;
+}
+
+extern "C" void ecal_destroy(ecal_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void) hipStreamSynchronize(ctx->stream);
+        (void) hipStreamDestroy(ctx->stream);
+    }
+    for (ecal_devbuf *b : ctx->all_bufs()) release(*b);
+    delete ctx;
+}
+
+extern "C" int ecal_sync(ecal_ctx *ctx) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ECAL_OK;
+}

@@ -1,0 +1,43 @@
+// Host-side context shared by the C-ABI translation units (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include <new>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/ecal.h"
+
+struct ecal_devbuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct ecal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    // grow-only device scratch (never shrinks; sized for 288 GB parts: keep and reuse)
+    ecal_devbuf in_xy, in_off, in_cnt, out_labels, out_ncl;  // staging for the host-pointer API
+    ecal_devbuf big_slot, big_anc, big_cur;                 // global-scratch tier of DBSCAN
+    bool attrs_set = false;
+    std::vector<ecal_devbuf *> all_bufs() {
+        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur};
+    }
+};
+
+#define ECAL_HIP_TRY(ctx, call)                                                                       \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e__);                   \
+            return (e__ == hipErrorOutOfMemory) ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;                      \
+        }                                                                                             \
+    } while (0)
+
+// ensure a scratch buffer of at least `bytes` (contents are NOT preserved)
+int ecal_ensure(ecal_ctx *ctx, ecal_devbuf &b, size_t bytes);

@@ -1,0 +1,226 @@
+// DBSCAN kernels (one workgroup per segment) and their launchers.  gfx950 only.
+// Build with -ffp-contract=off: the ball predicate must be the reference's mul/add sequence.
+#include "ecal_ctx.hpp"
+#include "dbscan_device.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ecal {
+
+// ---- LDS carve for an LDS tier of capacity CAP (all offsets multiples of 16) ----
+template <int CAP>
+struct TierLayout {
+    static constexpr size_t c_off = 0;
+    static constexpr size_t slot_off = c_off + sizeof(double) * 2 * CAP;
+    static constexpr size_t anc_off = slot_off + sizeof(uint32_t) * (2 * CAP + 4);
+    static constexpr size_t cur_off = anc_off + sizeof(uint16_t) * 4 * CAP;
+    static constexpr size_t red_off = cur_off + sizeof(uint16_t) * CAP;
+    static constexpr size_t bytes = red_off + sizeof(uint32_t) * 32;
+    static_assert(slot_off % 16 == 0 && anc_off % 16 == 0 && cur_off % 16 == 0 && red_off % 16 == 0, "align");
+};
+
+template <int V>
+struct Log2 {
+    static constexpr uint32_t value = 1 + Log2<V / 2>::value;
+};
+template <>
+struct Log2<1> {
+    static constexpr uint32_t value = 0;
+};
+
+// Segments with lo_excl < n <= CAP are handled here; the others exit at once.
+// The tier with lo_excl == 0 also writes n_clusters = 0 for empty segments.
+template <int CAP, int T>
+__global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict__ xy,
+                                                       const uint32_t *__restrict__ seg_off,
+                                                       const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
+                                                       double eps, uint32_t minpts, int32_t *__restrict__ labels,
+                                                       uint32_t *__restrict__ n_clusters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t s = blockIdx.x;
+    const uint32_t n = seg_cnt[s];
+    if (n == 0) {
+        if (lo_excl == 0 && threadIdx.x == 0) n_clusters[s] = 0;
+        return;
+    }
+    if (n <= lo_excl || n > (uint32_t) CAP) return;
+    using L = TierLayout<CAP>;
+    DbWork<uint16_t> w;
+    double2 *pts = reinterpret_cast<double2 *>(smem + L::c_off);
+    w.c = reinterpret_cast<const double *>(pts);
+    w.slot = reinterpret_cast<uint32_t *>(smem + L::slot_off);
+    w.anc = reinterpret_cast<uint16_t *>(smem + L::anc_off);
+    w.cur = reinterpret_cast<uint16_t *>(smem + L::cur_off);
+    w.red = reinterpret_cast<uint32_t *>(smem + L::red_off);
+
+    const size_t base = seg_off[s];
+    const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
+    for (uint32_t i = threadIdx.x; i < n; i += T) pts[i] = src[i];
+    __syncthreads();
+    const uint32_t total = dbscan_segment<T, false, uint16_t>(w, n, eps, minpts, Log2<CAP>::value, labels + base);
+    if (threadIdx.x == 0) n_clusters[s] = total;
+}
+
+constexpr int BIG_T = 1024;
+
+// Segments with n > lo_excl: workspace in global scratch, indexed by the segment's point offset.
+__global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restrict__ xy,
+                                                           const uint32_t *__restrict__ seg_off,
+                                                           const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
+                                                           double eps, uint32_t minpts, int32_t *__restrict__ labels,
+                                                           uint32_t *__restrict__ n_clusters, uint32_t *gslot,
+                                                           uint32_t *ganc, uint32_t *gcur) {
+    __shared__ uint32_t red[32];
+    const uint32_t s = blockIdx.x;
+    const uint32_t n = seg_cnt[s];
+    if (n <= lo_excl) return;
+    const size_t base = seg_off[s];
+    DbWork<uint32_t> w;
+    w.c = xy + 2 * base;  // the caller's interleaved points are used in place
+    w.slot = gslot + 2 * base;
+    w.anc = ganc + 4 * base;
+    w.cur = gcur + base;
+    w.red = red;
+    // nb = largest power of two <= n/2 (>= 2048 here) so that label[n] + 1 + cursor[nb] fits slot[2n]
+    uint32_t nb_log = 31u - (uint32_t) __clz((int) (n >> 1));
+    if (nb_log > 20u) nb_log = 20u;
+    const uint32_t total = dbscan_segment<BIG_T, true, uint32_t>(w, n, eps, minpts, nb_log, labels + base);
+    if (threadIdx.x == 0) n_clusters[s] = total;
+}
+
+}  // namespace ecal
+
+using namespace ecal;
+
+static constexpr int CAP0 = 1024, CAP1 = 2048, CAP2 = 4096;
+
+static int set_attrs(ecal_ctx *ctx) {
+    if (ctx->attrs_set) return ECAL_OK;
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP0, CAP0 / 4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP0>::bytes));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP1, CAP1 / 4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP1>::bytes));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP2, CAP2 / 4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP2>::bytes));
+    ctx->attrs_set = true;
+    return ECAL_OK;
+}
+
+extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off,
+                                     const uint32_t *d_seg_cnt, uint32_t S, uint32_t n_points, uint32_t max_seg_points,
+                                     double eps, uint32_t minpts, int32_t *d_labels, uint32_t *d_n_clusters,
+                                     void *stream) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (minpts < 1) {
+        ctx->last_error = "minpts < 1 (DBSCAN::Run returns FAILED)";
+        return ECAL_ERR_INVALID;
+    }
+    if (S == 0) return ECAL_OK;
+    if (!d_seg_off || !d_seg_cnt || !d_n_clusters || (n_points && (!d_xy || !d_labels))) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = set_attrs(ctx);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
+
+    hipLaunchKernelGGL((dbscan_lds_kernel<CAP0, CAP0 / 4>), dim3(S), dim3(CAP0 / 4), TierLayout<CAP0>::bytes, st, d_xy,
+                       d_seg_off, d_seg_cnt, 0u, eps, minpts, d_labels, d_n_clusters);
+    if (mx > (uint32_t) CAP0)
+        hipLaunchKernelGGL((dbscan_lds_kernel<CAP1, CAP1 / 4>), dim3(S), dim3(CAP1 / 4), TierLayout<CAP1>::bytes, st,
+                           d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP0, eps, minpts, d_labels, d_n_clusters);
+    if (mx > (uint32_t) CAP1)
+        hipLaunchKernelGGL((dbscan_lds_kernel<CAP2, CAP2 / 4>), dim3(S), dim3(CAP2 / 4), TierLayout<CAP2>::bytes, st,
+                           d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP1, eps, minpts, d_labels, d_n_clusters);
+    if (mx > (uint32_t) CAP2) {
+        const size_t np = n_points;
+        if ((rc = ecal_ensure(ctx, ctx->big_slot, (2 * np + 4) * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_anc, 4 * np * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_cur, np * sizeof(uint32_t)))) return rc;
+        hipLaunchKernelGGL(dbscan_big_kernel, dim3(S), dim3(BIG_T), 0, st, d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP2,
+                           eps, minpts, d_labels, d_n_clusters, (uint32_t *) ctx->big_slot.ptr, (uint32_t *) ctx->big_anc.ptr,
+                           (uint32_t *) ctx->big_cur.ptr);
+    }
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}
+
+extern "C" int ecal_dbscan_batch(ecal_ctx *ctx, const double *xy, const uint32_t *slice_off, uint32_t S, double eps,
+                                 uint32_t minpts, int32_t *labels, uint32_t *n_clusters) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (minpts < 1) {
+        ctx->last_error = "minpts < 1 (DBSCAN::Run returns FAILED)";
+        return ECAL_ERR_INVALID;
+    }
+    if (S == 0) return ECAL_OK;
+    if (!slice_off || !n_clusters) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    for (uint32_t s = 0; s < S; s++) {
+        if (slice_off[s + 1] < slice_off[s]) {
+            ctx->last_error = "slice_off must be non-decreasing";
+            return ECAL_ERR_INVALID;
+        }
+    }
+    const uint32_t base0 = slice_off[0];
+    const size_t N = (size_t) slice_off[S] - base0;
+    if (N && (!xy || !labels)) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ecal_ensure(ctx, ctx->in_xy, (N + 1) * 2 * sizeof(double)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->in_off, (size_t) S * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->in_cnt, (size_t) S * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->out_labels, (N + 1) * sizeof(int32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->out_ncl, (size_t) S * sizeof(uint32_t)))) return rc;
+    uint32_t *h = (uint32_t *) malloc(2 * (size_t) S * sizeof(uint32_t));
+    if (!h) return ECAL_ERR_NOMEM;
+    uint32_t mx = 1;
+    for (uint32_t s = 0; s < S; s++) {
+        h[s] = slice_off[s] - base0;
+        h[S + s] = slice_off[s + 1] - slice_off[s];
+        if (h[S + s] > mx) mx = h[S + s];
+    }
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    if (N) e = hipMemcpyAsync(ctx->in_xy.ptr, xy + 2 * (size_t) base0, N * 2 * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->in_off.ptr, h, S * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->in_cnt.ptr, h + S, S * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);  // h is pageable: make sure it was consumed
+    free(h);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("H2D: ") + hipGetErrorString(e);
+        return ECAL_ERR_HIP;
+    }
+    rc = ecal_dbscan_batch_dev(ctx, (const double *) ctx->in_xy.ptr, (const uint32_t *) ctx->in_off.ptr,
+                               (const uint32_t *) ctx->in_cnt.ptr, S, (uint32_t) N, mx, eps, minpts,
+                               (int32_t *) ctx->out_labels.ptr, (uint32_t *) ctx->out_ncl.ptr, st);
+    if (rc) return rc;
+    // results land in temporaries first: caller buffers are written only on success
+    int32_t *tl = N ? (int32_t *) malloc(N * sizeof(int32_t)) : nullptr;
+    uint32_t *tn = (uint32_t *) malloc((size_t) S * sizeof(uint32_t));
+    if ((N && !tl) || !tn) {
+        free(tl);
+        free(tn);
+        return ECAL_ERR_NOMEM;
+    }
+    if (N) e = hipMemcpyAsync(tl, ctx->out_labels.ptr, N * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(tn, ctx->out_ncl.ptr, S * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        free(tl);
+        free(tn);
+        ctx->last_error = std::string("dbscan/D2H: ") + hipGetErrorString(e);
+        return ECAL_ERR_HIP;
+    }
+    if (N) memcpy(labels + base0, tl, N * sizeof(int32_t));
+    memcpy(n_clusters, tn, (size_t) S * sizeof(uint32_t));
+    free(tl);
+    free(tn);
+    return ECAL_OK;
+}

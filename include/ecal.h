@@ -1,0 +1,81 @@
+/*
+ * ecal.h — C ABI of the MI355X-native EventCalib hot path (libecal.so).
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference tree, MobilePerceptionLab/EventCalib).
+ * The reference has no FFI layer of its own; its seams are the C++ class APIs listed here, and
+ * the C++ shims in eventcalib_amd/csrc/host/ (same class names and members) sit on top of this
+ * ABI so that unit_test_eventCameraCalib-style callers can switch with a re-link
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions: returns ECAL_OK (0) or a negative ecal_status; never throws; all buffers are
+ * caller-owned; outputs are written only on success.  Entry points ending in _dev take DEVICE
+ * pointers and enqueue asynchronously on `stream` (a hipStream_t passed as void*, NULL = the
+ * context's own stream); the others take HOST pointers and return when the result is in place.
+ * One ecal_ctx per host thread (matches the reference's one-DBSCAN-instance-per-worker use,
+ * event_camera_calib/test/eventCameraCalib.cpp:181-190).
+ */
+#ifndef ECAL_H_
+#define ECAL_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECAL_ABI_VERSION 1
+
+typedef enum ecal_status {
+    ECAL_OK = 0,
+    ECAL_ERR_INVALID = -1,    /* bad argument (NULL pointer, minpts < 1, ...) */
+    ECAL_ERR_NO_DEVICE = -2,  /* no usable HIP device / HIP runtime failure at init */
+    ECAL_ERR_HIP = -3,        /* a HIP call failed; ecal_last_error() has the text */
+    ECAL_ERR_NOMEM = -4,      /* device or host allocation failed */
+    ECAL_ERR_UNSORTED = -5,   /* event timestamps are not non-decreasing */
+    ECAL_ERR_RANGE = -6       /* a size exceeds what the ABI can index (2^32-1 points) */
+} ecal_status;
+
+typedef struct ecal_ctx ecal_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int ecal_abi_version(void);
+int ecal_init(int device, ecal_ctx **out);
+void ecal_destroy(ecal_ctx *ctx);
+const char *ecal_strerror(int status);
+const char *ecal_last_error(const ecal_ctx *ctx);
+/* blocks until everything enqueued on the context's own stream has finished */
+int ecal_sync(ecal_ctx *ctx);
+
+/* ---- DBSCAN ------------------------------------------------------------------------------
+ * Replaces DBSCAN<Eigen::Vector2d,double>::Run(&V, 2, eps, minpts)
+ *   (dbscan/include/dbscan.h:115-177, regionQuery :198-227, expandCluster :229-259) and the
+ *   kd-tree underneath it (dbscan/src/kdtree.cpp:106-179, 344-365), called twice per
+ *   time-slice from CirclesEventFrame::extractFeatures (event_camera_calib/src/CirclesEventFrame.cpp:66-72).
+ *
+ * One Run() per slice s over the points xy[slice_off[s] .. slice_off[s+1]) (pid = index inside
+ * the slice, dim = 2).  labels[i] = index into the reference's `Clusters` vector for that slice
+ * (clusters are numbered in order of their smallest member pid, dbscan.h:154-155), or -1 for a
+ * member of `Noise`.  Only core points (>= minpts neighbours, self excluded, dbscan.h:151,218,247)
+ * are ever assigned; border points are Noise exactly as in the reference.  The neighbour
+ * relation reproduces the reference kd-tree's inclusive-ball / strict-plane-pruning behaviour
+ * bit for bit (DESIGN.md "the quirk").  Empty slices give n_clusters[s] = 0 (Run would return
+ * FAILED, dbscan.h:121); minpts < 1 is ECAL_ERR_INVALID (Run's FAILED, dbscan.h:123).
+ */
+int ecal_dbscan_batch(ecal_ctx *ctx, const double *xy /*[N][2]*/, const uint32_t *slice_off /*[S+1]*/,
+                      uint32_t S, double eps, uint32_t minpts, int32_t *labels /*[N]*/,
+                      uint32_t *n_clusters /*[S]*/);
+
+/* Device-resident form: segment s is d_xy[d_seg_off[s] .. d_seg_off[s]+d_seg_cnt[s]) (segments
+ * may leave gaps but must not overlap); n_points = upper bound on any d_seg_off+d_seg_cnt
+ * (size of d_xy/d_labels in points).  max_seg_points: upper bound on any d_seg_cnt, or 0 if
+ * unknown (then every size tier is launched). */
+int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                          uint32_t S, uint32_t n_points, uint32_t max_seg_points, double eps, uint32_t minpts,
+                          int32_t *d_labels, uint32_t *d_n_clusters, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECAL_H_ */

@@ -1,0 +1,107 @@
+"""GPU parity: HIP DBSCAN (through the C ABI) vs the oracle, bit-exact labels."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import eventcalib_amd
+    c = eventcalib_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _check(ctx, xy, off, eps, minpts):
+    labels, ncl = ctx.dbscan_batch(xy, off, eps, minpts)
+    ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)
+    bad = np.nonzero(labels != ref_l)[0]
+    assert bad.size == 0, "%d/%d labels differ (first at %d: got %d want %d)" % (
+        bad.size, labels.size, bad[0], labels[bad[0]], ref_l[bad[0]])
+    assert (ncl == ref_n).all()
+
+
+def test_golden_fixtures(ctx):
+    files = sorted(glob.glob(os.path.join(GOLDEN, "dbscan_*.npz")))
+    assert files
+    for f in files:
+        z = np.load(f)
+        labels, ncl = ctx.dbscan_batch(z["xy"], z["off"], float(z["eps"]), int(z["minpts"]))
+        assert (labels == z["labels"]).all(), f
+        assert (ncl == z["n_clusters"]).all(), f
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.1, 0.5, 2.0])
+def test_arc_slices(ctx, noise):
+    rng = np.random.default_rng(int(noise * 10) + 1)
+    xy, off = synth.arc_slices(rng, 64, noise)
+    _check(ctx, xy, off, 4.0, 2)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_lattices_quirk(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    xy, off, lattice = synth.random_segments(rng, 200, max_n=400)
+    for eps in (4.0, 3.0, 5.0, 2.5, 1.7, 4.5, 0.3):
+        for minpts in (1, 2, 5):
+            _check(ctx, xy, off, eps, minpts)
+
+
+def test_edge_cases(ctx):
+    # n = 1, all-noise, one giant cluster, duplicates only, empty slices at both ends
+    parts = [np.zeros((0, 2)), np.array([[3.0, 3.0]]), np.array([[0.0, 0.0], [100.0, 100.0], [200.0, 0.0]]),
+             np.stack([np.arange(300.0), np.zeros(300)], 1), np.tile(np.array([[5.0, 5.0]]), (40, 1)),
+             np.zeros((0, 2))]
+    off = np.zeros(len(parts) + 1, np.uint32)
+    off[1:] = np.cumsum([p.shape[0] for p in parts])
+    xy = np.concatenate(parts)
+    for minpts in (1, 2, 5):
+        _check(ctx, xy, off, 4.0, minpts)
+    labels, ncl = ctx.dbscan_batch(xy, off, 4.0, 2)
+    assert ncl.tolist() == [0, 0, 0, 1, 1, 0]
+
+
+def test_size_tiers_and_big_path(ctx):
+    """Segments that land in every tier: <=1024, <=2048, <=4096 (LDS) and > 4096 (global scratch)."""
+    rng = np.random.default_rng(77)
+    sizes = [1000, 1024, 1025, 2048, 2049, 4096, 4097, 9000, 30]
+    parts = []
+    for n in sizes:
+        span = int(np.sqrt(n) * 3) + 4
+        parts.append(rng.integers(0, span, size=(n, 2)).astype(np.float64))
+    off = np.zeros(len(parts) + 1, np.uint32)
+    off[1:] = np.cumsum(sizes)
+    xy = np.concatenate(parts)
+    _check(ctx, xy, off, 4.0, 2)
+    _check(ctx, xy, off, 3.0, 5)
+
+
+def test_degenerate_orders_and_coordinates(ctx):
+    rng = np.random.default_rng(3)
+    # row-major sorted input: the insertion-order tree degenerates to depth O(n)
+    g = np.stack(np.meshgrid(np.arange(40.0), np.arange(20.0)), -1).reshape(-1, 2)
+    keep = rng.random(g.shape[0]) < 0.5
+    sorted_pts = g[keep]
+    # huge coordinates: the cell hash is unusable -> brute-force candidate scan
+    far = rng.integers(0, 50, size=(200, 2)).astype(np.float64) + 1.0e13
+    neg = rng.integers(-60, 60, size=(300, 2)).astype(np.float64)
+    parts = [sorted_pts, far, neg]
+    off = np.zeros(len(parts) + 1, np.uint32)
+    off[1:] = np.cumsum([p.shape[0] for p in parts])
+    _check(ctx, np.concatenate(parts), off, 4.0, 2)
+
+
+def test_invalid_arguments(ctx):
+    import eventcalib_amd
+    with pytest.raises(eventcalib_amd.EcalError):
+        ctx.dbscan_batch(np.zeros((3, 2)), np.array([0, 3], np.uint32), 4.0, 0)   # Run() FAILED: min < 1
+    labels, ncl = ctx.dbscan_batch(np.zeros((0, 2)), np.array([0], np.uint32), 4.0, 2)
+    assert labels.size == 0 and ncl.size == 0
