@@ -12,6 +12,7 @@ _LIB = None
 EXPORTED_SYMBOLS = [
     "ecal_abi_version", "ecal_init", "ecal_destroy", "ecal_strerror", "ecal_last_error", "ecal_sync",
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
+    "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
 ]
 
 
@@ -51,6 +52,13 @@ def load_library():
     L.ecal_dbscan_batch.restype = i32
     L.ecal_dbscan_batch_dev.argtypes = [vp, vp, vp, vp, u32, u32, u32, f64, u32, vp, vp, vp]
     L.ecal_dbscan_batch_dev.restype = i32
+    u64 = ctypes.c_uint64
+    L.ecal_window_bounds_dev.argtypes = [vp, vp, u64, vp, vp, u32, vp, vp, vp, vp]
+    L.ecal_window_bounds_dev.restype = i32
+    L.ecal_check_sorted_dev.argtypes = [vp, vp, u64, vp, vp]
+    L.ecal_check_sorted_dev.restype = i32
+    L.ecal_slice_events_dev.argtypes = [vp, vp, u64, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
+    L.ecal_slice_events_dev.restype = i32
     _LIB = L
     return L
 
@@ -117,3 +125,17 @@ class Context:
         self._check(self._L.ecal_dbscan_batch_dev(self._h, d_xy, d_seg_off, d_seg_cnt, int(S), int(n_points),
                                                   int(max_seg_points), float(eps), int(minpts), d_labels,
                                                   d_n_clusters, stream))
+
+    # ---- ingest + slicing (device buffers, raw pointers) ----
+    def window_bounds_dev(self, d_events, n_events, d_t0, d_t1, S, d_win_lo, d_win_hi, d_win_base, stream=0):
+        self._check(self._L.ecal_window_bounds_dev(self._h, d_events, int(n_events), d_t0, d_t1, int(S), d_win_lo,
+                                                   d_win_hi, d_win_base, stream))
+
+    def check_sorted_dev(self, d_events, n_events, d_flag, stream=0):
+        self._check(self._L.ecal_check_sorted_dev(self._h, d_events, int(n_events), d_flag, stream))
+
+    def slice_events_dev(self, d_events, n_events, d_win_lo, d_win_hi, d_win_base, S, max_win_events, cap_points,
+                         d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, stream=0):
+        self._check(self._L.ecal_slice_events_dev(self._h, d_events, int(n_events), d_win_lo, d_win_hi, d_win_base,
+                                                  int(S), int(max_win_events), int(cap_points), d_xy, d_seg_off,
+                                                  d_seg_cnt, d_event_point, d_overflow, stream))

@@ -1,0 +1,440 @@
+// Ingest + time-slicing kernels: packed 25-byte event records -> per-window unique pixel sets.
+//
+// Replaces (reference paths):
+//   event/include/opengv2/event/Event.hpp:41-47           record decode (f64 t, f64 x, f64 y, u8 p)
+//   event_camera_calib/test/eventCameraCalib.cpp:154-163  multimap<double,Event_loc_pol> fill
+//   event/src/EventFrame.cpp:10-36                        window [t0,t1], per-polarity unique pixel
+//                                                         sets, erase pixels present in both
+// One workgroup owns one window: its records are decoded straight out of the packed stream,
+// bucketed by a hash of the pixel, de-duplicated inside the bucket, and compacted in
+// first-occurrence order (the build's canonical pid order).
+#include "ecal_ctx.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ecal {
+
+constexpr int RECORD_BYTES = 25;
+
+__device__ __forceinline__ double load_f64_unaligned(const uint8_t *p) {
+    double v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// ---------------- window bounds: lower_bound(t0) / upper_bound(t1) on the record stream -----------
+__global__ void window_bounds_kernel(const uint8_t *__restrict__ rec, uint64_t n, const double *__restrict__ t0,
+                                     const double *__restrict__ t1, uint32_t S, uint32_t *__restrict__ lo_out,
+                                     uint32_t *__restrict__ hi_out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const double a0 = t0[s], a1 = t1[s];
+    uint64_t a = 0, b = n;
+    while (a < b) {
+        const uint64_t m = (a + b) >> 1;
+        if (load_f64_unaligned(rec + m * RECORD_BYTES) < a0) a = m + 1; else b = m;
+    }
+    const uint64_t lo = a;
+    b = n;
+    while (a < b) {
+        const uint64_t m = (a + b) >> 1;
+        if (load_f64_unaligned(rec + m * RECORD_BYTES) <= a1) a = m + 1; else b = m;
+    }
+    lo_out[s] = (uint32_t) lo;
+    hi_out[s] = (uint32_t) (a < lo ? lo : a);
+}
+
+// exclusive scan of (hi - lo) over the windows; base[S] = total.  One block, S is small (<= ~1e6).
+__global__ __launch_bounds__(1024) void window_base_kernel(const uint32_t *__restrict__ lo,
+                                                           const uint32_t *__restrict__ hi, uint32_t S,
+                                                           uint32_t *__restrict__ base) {
+    __shared__ uint32_t red[17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0; s0 < S; s0 += 1024) {
+        const uint32_t s = s0 + threadIdx.x;
+        const uint32_t v = (s < S) ? hi[s] - lo[s] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) red[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t x = red[w];
+            if (w < wave) pre += x;
+            tot += x;
+        }
+        if (s < S) base[s] = carry + pre + inc - v;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[S] = carry;
+}
+
+// flag[0] = 1 if some record's timestamp is smaller than its predecessor's
+__global__ void check_sorted_kernel(const uint8_t *__restrict__ rec, uint64_t n, int *flag) {
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (i >= n) return;
+    if (load_f64_unaligned(rec + i * RECORD_BYTES) < load_f64_unaligned(rec + (i - 1) * RECORD_BYTES)) *flag = 1;
+}
+
+// ---------------- per-window slicing ----------------
+template <typename Idx>
+struct SliceWork {
+    double2 *pts;    // [n] decoded (x, y)
+    uint8_t *pol;    // [n] 1 = positive
+    uint32_t *bend;  // [nb + 1] bucket cursors / ends
+    Idx *sorted;     // [n] event ids grouped by bucket
+    Idx *rep;        // [n] representative event of this event's (pixel, polarity), NONE if erased
+    uint32_t *pos;   // [n] packed exclusive counts: low 16/.. see below (LDS) or two words (global)
+    uint32_t *red;   // block-scan scratch (LDS)
+};
+
+__device__ __forceinline__ uint32_t pixel_hash(double x, double y) {
+    // operator== semantics: -0.0 and +0.0 are the same pixel -> canonicalise before hashing
+    const uint64_t xb = (uint64_t) __double_as_longlong(x + 0.0), yb = (uint64_t) __double_as_longlong(y + 0.0);
+    uint32_t h = ((uint32_t) (xb >> 32) ^ (uint32_t) xb) * 0x9E3779B1u;
+    h ^= (((uint32_t) (yb >> 32) ^ (uint32_t) yb) * 0x85EBCA77u) + (h >> 13);
+    h ^= h >> 16;
+    h *= 0xC2B2AE3Du;
+    h ^= h >> 15;
+    return h;
+}
+
+template <int T>
+__device__ __forceinline__ void block_exscan2(uint32_t a, uint32_t b, uint32_t *red, uint32_t *ea, uint32_t *eb,
+                                              uint32_t *ta, uint32_t *tb) {
+    // two independent exclusive scans (64-bit packed) in one pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long v = ((unsigned long long) b << 32) | a, inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    unsigned long long *r64 = reinterpret_cast<unsigned long long *>(red);
+    if (lane == 63) r64[wave] = inc;
+    __syncthreads();
+    unsigned long long pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; w++) {
+        const unsigned long long x = r64[w];
+        if (w < wave) pre += x;
+        tot += x;
+    }
+    __syncthreads();
+    const unsigned long long ex = pre + inc - v;
+    *ea = (uint32_t) ex;
+    *eb = (uint32_t) (ex >> 32);
+    *ta = (uint32_t) tot;
+    *tb = (uint32_t) (tot >> 32);
+}
+
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t ld_word(const uint32_t *p) {
+    if constexpr (GLOBAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+
+// EventFrame constructor for the records [lo, lo+n) of the stream.
+template <int T, bool GLOBAL, typename Idx>
+__device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint8_t *__restrict__ rec, uint32_t lo,
+                                             uint32_t n, uint32_t nb_log, double *__restrict__ xy_out,
+                                             int32_t *__restrict__ event_point, uint32_t *n_pos_out,
+                                             uint32_t *n_neg_out) {
+    constexpr uint32_t NONE = (sizeof(Idx) == 2) ? 0xFFFFu : 0xFFFFFFFFu;
+    const uint32_t tid = threadIdx.x;
+    double2 *const pts = wk.pts;
+    uint8_t *const pol = wk.pol;
+    uint32_t *const bend = wk.bend;
+    Idx *const sorted = wk.sorted;
+    Idx *const rep = wk.rep;
+    uint32_t *const pos = wk.pos;
+    const uint32_t nb = 1u << nb_log, mask = nb - 1u;
+
+    // a. decode (Event.hpp:41-47)
+    for (uint32_t b = tid; b <= nb; b += T) bend[b] = 0;
+    for (uint32_t k = tid; k < n; k += T) {
+        const uint8_t *r = rec + (uint64_t) (lo + k) * RECORD_BYTES;
+        double2 p;
+        p.x = load_f64_unaligned(r + 8);
+        p.y = load_f64_unaligned(r + 16);
+        pts[k] = p;
+        pol[k] = r[24] ? 1 : 0;
+    }
+    __syncthreads();
+    // b/c. counting sort of the events by pixel-hash bucket
+    for (uint32_t k = tid; k < n; k += T) atomicAdd(&bend[pixel_hash(pts[k].x, pts[k].y) & mask], 1u);
+    __syncthreads();
+    {
+        const uint32_t per = (nb + T - 1) / T, b0 = tid * per;
+        uint32_t sum = 0;
+        for (uint32_t b = b0; b < b0 + per && b < nb; b++) sum += ld_word<GLOBAL>(&bend[b]);
+        uint32_t ex, dummy0, tot, dummy1;
+        block_exscan2<T>(sum, 0u, wk.red, &ex, &dummy0, &tot, &dummy1);
+        for (uint32_t b = b0; b < b0 + per && b < nb; b++) {
+            const uint32_t c = ld_word<GLOBAL>(&bend[b]);
+            bend[b] = ex;
+            ex += c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < n; k += T) {
+        const uint32_t at = atomicAdd(&bend[pixel_hash(pts[k].x, pts[k].y) & mask], 1u);
+        sorted[at] = (Idx) k;
+    }
+    __syncthreads();
+    // d. first occurrence per (pixel, polarity); erase pixels that fired with both polarities
+    uint32_t cntP = 0, cntN = 0;  // this thread's representatives (blocked ownership below)
+    for (uint32_t k = tid; k < n; k += T) {
+        const double2 p = pts[k];
+        const uint32_t b = pixel_hash(p.x, p.y) & mask;
+        uint32_t m = b ? ld_word<GLOBAL>(&bend[b - 1]) : 0u;
+        const uint32_t e = ld_word<GLOBAL>(&bend[b]);
+        uint32_t minP = NONE, minN = NONE;
+        for (; m < e; m++) {
+            const uint32_t j = sorted[m];
+            const double2 q = pts[j];
+            if (q.x == p.x && q.y == p.y) {  // std::equal_to<> on Vector2d (EventFrame.cpp:12-13)
+                if (pol[j]) minP = min(minP, j); else minN = min(minN, j);
+            }
+        }
+        const bool erased = (minP != NONE) && (minN != NONE);  // EventFrame.cpp:24-32
+        rep[k] = (Idx) (erased ? NONE : (pol[k] ? minP : minN));
+    }
+    __syncthreads();
+    // e. ranks of the representatives in event order (blocked ownership: contiguous k per thread)
+    const uint32_t per = (n + T - 1) / T, k0 = tid * per;
+    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
+        if (rep[k] == k) { if (pol[k]) cntP++; else cntN++; }
+    }
+    uint32_t exP, exN, nP, nN;
+    block_exscan2<T>(cntP, cntN, wk.red, &exP, &exN, &nP, &nN);
+    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
+        if (rep[k] == k) pos[k] = pol[k] ? exP++ : exN++;
+    }
+    __syncthreads();
+    // f. outputs: positives first, then negatives (canonical order = first occurrence)
+    double2 *out2 = reinterpret_cast<double2 *>(xy_out);
+    for (uint32_t k = tid; k < n; k += T) {
+        const uint32_t r = rep[k];
+        if (r == NONE) {
+            event_point[k] = -1;
+        } else {
+            const uint32_t at = pos[r];
+            event_point[k] = (int32_t) at;
+            if (r == k) out2[pol[k] ? at : nP + at] = pts[k];
+        }
+    }
+    *n_pos_out = nP;
+    *n_neg_out = nN;
+}
+
+template <int CAP>
+struct SliceLayout {
+    static constexpr size_t pts_off = 0;
+    static constexpr size_t bend_off = pts_off + sizeof(double2) * CAP;
+    static constexpr size_t pos_off = bend_off + sizeof(uint32_t) * (CAP + 4);
+    static constexpr size_t sorted_off = pos_off + sizeof(uint32_t) * CAP;
+    static constexpr size_t rep_off = sorted_off + sizeof(uint16_t) * CAP;
+    static constexpr size_t pol_off = rep_off + sizeof(uint16_t) * CAP;
+    static constexpr size_t red_off = pol_off + ((CAP + 15) / 16) * 16;
+    static constexpr size_t bytes = red_off + 16 * sizeof(unsigned long long);
+    static_assert(bend_off % 16 == 0 && pos_off % 16 == 0 && sorted_off % 16 == 0 && rep_off % 16 == 0 &&
+                  pol_off % 16 == 0 && red_off % 16 == 0, "align");
+};
+
+template <int V>
+struct Log2c {
+    static constexpr uint32_t value = 1 + Log2c<V / 2>::value;
+};
+template <>
+struct Log2c<1> {
+    static constexpr uint32_t value = 0;
+};
+
+template <int CAP, int NB, int T>
+__global__ __launch_bounds__(T) void slice_lds_kernel(const uint8_t *__restrict__ rec,
+                                                      const uint32_t *__restrict__ win_lo,
+                                                      const uint32_t *__restrict__ win_hi,
+                                                      const uint32_t *__restrict__ win_base, uint32_t lo_excl,
+                                                      uint32_t cap_points, double *__restrict__ xy_out,
+                                                      uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt,
+                                                      int32_t *__restrict__ event_point, int *overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t s = blockIdx.x;
+    const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
+    if (n == 0) {
+        if (lo_excl == 0 && threadIdx.x == 0) {
+            seg_off[2 * s] = base < cap_points ? base : 0;
+            seg_off[2 * s + 1] = seg_off[2 * s];
+            seg_cnt[2 * s] = 0;
+            seg_cnt[2 * s + 1] = 0;
+        }
+        return;
+    }
+    if (n <= lo_excl || n > (uint32_t) CAP) return;
+    if ((uint64_t) base + n > cap_points) {  // caller's buffers too small: report, emit empty segments
+        if (threadIdx.x == 0) {
+            *overflow = 1;
+            seg_off[2 * s] = seg_off[2 * s + 1] = 0;
+            seg_cnt[2 * s] = seg_cnt[2 * s + 1] = 0;
+        }
+        return;
+    }
+    using L = SliceLayout<CAP>;
+    SliceWork<uint16_t> w;
+    w.pts = reinterpret_cast<double2 *>(smem + L::pts_off);
+    w.bend = reinterpret_cast<uint32_t *>(smem + L::bend_off);
+    w.pos = reinterpret_cast<uint32_t *>(smem + L::pos_off);
+    w.sorted = reinterpret_cast<uint16_t *>(smem + L::sorted_off);
+    w.rep = reinterpret_cast<uint16_t *>(smem + L::rep_off);
+    w.pol = reinterpret_cast<uint8_t *>(smem + L::pol_off);
+    w.red = reinterpret_cast<uint32_t *>(smem + L::red_off);
+    uint32_t nP, nN;
+    slice_window<T, false, uint16_t>(w, rec, lo, n, Log2c<NB>::value, xy_out + 2 * (size_t) base, event_point + base,
+                                     &nP, &nN);
+    if (threadIdx.x == 0) {
+        seg_off[2 * s] = base;
+        seg_cnt[2 * s] = nP;
+        seg_off[2 * s + 1] = base + nP;
+        seg_cnt[2 * s + 1] = nN;
+    }
+}
+
+constexpr int SLICE_BIG_T = 1024;
+
+__global__ __launch_bounds__(SLICE_BIG_T) void slice_big_kernel(
+    const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
+    const uint32_t *__restrict__ win_base, uint32_t lo_excl, uint32_t cap_points, double *__restrict__ xy_out,
+    uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
+    double2 *g_pts, uint8_t *g_pol, uint32_t *g_bend, uint32_t *g_sorted, uint32_t *g_rep, uint32_t *g_pos) {
+    __shared__ unsigned long long red64[16];
+    const uint32_t s = blockIdx.x;
+    const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
+    if (n <= lo_excl) return;
+    if ((uint64_t) base + n > cap_points) {
+        if (threadIdx.x == 0) {
+            *overflow = 1;
+            seg_off[2 * s] = seg_off[2 * s + 1] = 0;
+            seg_cnt[2 * s] = seg_cnt[2 * s + 1] = 0;
+        }
+        return;
+    }
+    SliceWork<uint32_t> w;
+    w.pts = g_pts + base;
+    w.pol = g_pol + base;
+    w.bend = g_bend + base + s;  // nb + 1 <= n + 1 words per window
+    w.sorted = g_sorted + base;
+    w.rep = g_rep + base;
+    w.pos = g_pos + base;
+    w.red = reinterpret_cast<uint32_t *>(red64);
+    uint32_t nb_log = 31u - (uint32_t) __clz((int) n);  // largest power of two <= n
+    if (nb_log > 20u) nb_log = 20u;
+    uint32_t nP, nN;
+    slice_window<SLICE_BIG_T, true, uint32_t>(w, rec, lo, n, nb_log, xy_out + 2 * (size_t) base, event_point + base, &nP,
+                                              &nN);
+    if (threadIdx.x == 0) {
+        seg_off[2 * s] = base;
+        seg_cnt[2 * s] = nP;
+        seg_off[2 * s + 1] = base + nP;
+        seg_cnt[2 * s + 1] = nN;
+    }
+}
+
+}  // namespace ecal
+
+using namespace ecal;
+
+static constexpr int SCAP0 = 2048, SCAP1 = 5120;
+
+extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_t0,
+                                      const double *d_t1, uint32_t S, uint32_t *d_win_lo, uint32_t *d_win_hi,
+                                      uint32_t *d_win_base, void *stream) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (n_events > 0xFFFFFFFFull) {
+        ctx->last_error = "more than 2^32-1 events in one stream";
+        return ECAL_ERR_RANGE;
+    }
+    if (S == 0) return ECAL_OK;
+    if ((n_events && !d_events) || !d_t0 || !d_t1 || !d_win_lo || !d_win_hi || !d_win_base) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    hipLaunchKernelGGL(window_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d_events, n_events, d_t0, d_t1, S,
+                       d_win_lo, d_win_hi);
+    hipLaunchKernelGGL(window_base_kernel, dim3(1), dim3(1024), 0, st, d_win_lo, d_win_hi, S, d_win_base);
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}
+
+extern "C" int ecal_check_sorted_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, int *d_flag,
+                                     void *stream) {
+    if (!ctx || !d_flag || (n_events && !d_events)) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    if (n_events > 1) {
+        const uint64_t blocks = (n_events - 1 + 255) / 256;
+        hipLaunchKernelGGL(check_sorted_kernel, dim3((uint32_t) blocks), dim3(256), 0, st, d_events, n_events, d_flag);
+        ECAL_HIP_TRY(ctx, hipGetLastError());
+    }
+    return ECAL_OK;
+}
+
+extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events,
+                                     const uint32_t *d_win_lo, const uint32_t *d_win_hi, const uint32_t *d_win_base,
+                                     uint32_t S, uint32_t max_win_events, uint32_t cap_points, double *d_xy,
+                                     uint32_t *d_seg_off, uint32_t *d_seg_cnt, int32_t *d_event_point, int *d_overflow,
+                                     void *stream) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (S == 0) return ECAL_OK;
+    if ((n_events && !d_events) || !d_win_lo || !d_win_hi || !d_win_base || !d_seg_off || !d_seg_cnt || !d_overflow ||
+        (cap_points && (!d_xy || !d_event_point))) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    if (!ctx->slice_attrs_set) {
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_lds_kernel<SCAP0, 2048, 256>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int) SliceLayout<SCAP0>::bytes));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_lds_kernel<SCAP1, 4096, 512>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int) SliceLayout<SCAP1>::bytes));
+        ctx->slice_attrs_set = true;
+    }
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
+    const uint32_t mx = max_win_events ? max_win_events : 0xFFFFFFFFu;
+    hipLaunchKernelGGL((slice_lds_kernel<SCAP0, 2048, 256>), dim3(S), dim3(256), SliceLayout<SCAP0>::bytes, st, d_events,
+                       d_win_lo, d_win_hi, d_win_base, 0u, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point,
+                       d_overflow);
+    if (mx > (uint32_t) SCAP0)
+        hipLaunchKernelGGL((slice_lds_kernel<SCAP1, 4096, 512>), dim3(S), dim3(512), SliceLayout<SCAP1>::bytes, st,
+                           d_events, d_win_lo, d_win_hi, d_win_base, (uint32_t) SCAP0, cap_points, d_xy, d_seg_off,
+                           d_seg_cnt, d_event_point, d_overflow);
+    if (mx > (uint32_t) SCAP1) {
+        const size_t w = cap_points;
+        int rc;
+        if ((rc = ecal_ensure(ctx, ctx->sl_pts, w * sizeof(double2)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->sl_pol, w))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->sl_bend, (w + S + 4) * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->sl_sorted, w * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->sl_rep, w * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->sl_pos, w * sizeof(uint32_t)))) return rc;
+        hipLaunchKernelGGL(slice_big_kernel, dim3(S), dim3(SLICE_BIG_T), 0, st, d_events, d_win_lo, d_win_hi, d_win_base,
+                           (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
+                           (double2 *) ctx->sl_pts.ptr, (uint8_t *) ctx->sl_pol.ptr, (uint32_t *) ctx->sl_bend.ptr,
+                           (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr);
+    }
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}

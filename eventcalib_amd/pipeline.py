@@ -1,0 +1,69 @@
+"""Device-resident detection pipeline: packed event stream -> windows -> unique pixel sets ->
+DBSCAN labels (-> circle candidates), every stage a HIP kernel behind the C ABI.
+
+torch is plumbing only here: it owns the HBM buffers and the stream; all compute goes through
+libecal.so (eventcalib_amd.capi).  Mirrors the per-piece loop of the reference driver
+(event_camera_calib/test/eventCameraCalib.cpp:49-62) for a whole batch of windows at once.
+"""
+import numpy as np
+import torch
+
+from .capi import Context
+
+RECORD = 25
+
+
+class DetectPipeline:
+    """Buffers are sized once (grow-only) so a timed loop performs no allocation."""
+
+    def __init__(self, ctx: Context, device=None):
+        self.ctx = ctx
+        self.dev = torch.device("cuda", ctx.device) if device is None else device
+        self._cap_windows = 0
+        self._cap_slots = 0
+
+    def _ensure(self, S, slots):
+        dev = self.dev
+        if S > self._cap_windows:
+            self.win_lo = torch.empty(S, dtype=torch.int32, device=dev)
+            self.win_hi = torch.empty(S, dtype=torch.int32, device=dev)
+            self.win_base = torch.empty(S + 1, dtype=torch.int32, device=dev)
+            self.seg_off = torch.empty(2 * S, dtype=torch.int32, device=dev)
+            self.seg_cnt = torch.empty(2 * S, dtype=torch.int32, device=dev)
+            self.n_clusters = torch.empty(2 * S, dtype=torch.int32, device=dev)
+            self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+            self._cap_windows = S
+        if slots > self._cap_slots:
+            self.xy = torch.empty(slots, 2, dtype=torch.float64, device=dev)
+            self.event_point = torch.empty(slots, dtype=torch.int32, device=dev)
+            self.labels = torch.empty(slots, dtype=torch.int32, device=dev)
+            self._cap_slots = slots
+
+    def set_windows(self, t0, t1):
+        """Inclusive windows [t0[s], t1[s]] (numpy float64 or torch)."""
+        self.t0 = torch.as_tensor(np.asarray(t0, dtype=np.float64)).to(self.dev)
+        self.t1 = torch.as_tensor(np.asarray(t1, dtype=np.float64)).to(self.dev)
+        self.S = int(self.t0.numel())
+
+    def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0):
+        """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN on the
+        current torch stream; results stay in HBM (self.xy / seg_off / seg_cnt / labels / n_clusters)."""
+        assert events.is_cuda and events.dtype == torch.uint8
+        n = events.numel() // RECORD
+        S = self.S
+        slots = n if slots is None else slots
+        self._ensure(S, slots)
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        c = self.ctx
+        c.window_bounds_dev(events.data_ptr(), n, self.t0.data_ptr(), self.t1.data_ptr(), S, self.win_lo.data_ptr(),
+                            self.win_hi.data_ptr(), self.win_base.data_ptr(), st)
+        c.slice_events_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(),
+                           self.win_base.data_ptr(), S, max_win_events, slots, self.xy.data_ptr(),
+                           self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),
+                           self.flags.data_ptr(), st)
+        c.dbscan_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots,
+                           max_seg_points, eps, minpts, self.labels.data_ptr(), self.n_clusters.data_ptr(), st)
+        return self
+
+    def overflowed(self):
+        return bool(self.flags[0].item())

@@ -75,6 +75,39 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
                           uint32_t S, uint32_t n_points, uint32_t max_seg_points, double eps, uint32_t minpts,
                           int32_t *d_labels, uint32_t *d_n_clusters, void *stream);
 
+/* ---- ingest + time-slicing ----------------------------------------------------------------
+ * The event stream is the reference's .bin image: packed 25-byte little-endian records
+ * {f64 t_sec, f64 x, f64 y, u8 polarity} (event/include/opengv2/event/Event.hpp:41-47,
+ * README.md:7-13), time-sorted as the reference's std::multimap<double,Event_loc_pol> keeps them
+ * (event_camera_calib/test/eventCameraCalib.cpp:154-163).  At most 2^32-1 events per stream.
+ *
+ * ecal_window_bounds_dev: for every window s the index range [lo, hi) of the events with
+ *   t0[s] <= t <= t1[s] — container.lower_bound(duration.first) .. upper_bound(duration.second)
+ *   of EventFrame::EventFrame (event/src/EventFrame.cpp:14-15) — and win_base[s] = sum of the
+ *   sizes of the windows before s (win_base[S] = total), the slot where window s writes.
+ * ecal_check_sorted_dev: *d_flag = 1 if some timestamp is smaller than its predecessor.
+ * ecal_slice_events_dev: the rest of the EventFrame constructor (EventFrame.cpp:10-36) for all
+ *   windows at once: per polarity the set of unique pixel locations (operator== on the doubles),
+ *   minus every location present in both sets.  Window s owns slots [win_base[s], win_base[s+1])
+ *   of d_xy / d_event_point (capacity cap_points slots):
+ *     segment 2s   = positiveEvents_ : d_xy[d_seg_off[2s]   ..+d_seg_cnt[2s]]
+ *     segment 2s+1 = negativeEvents_ : d_xy[d_seg_off[2s+1] ..+d_seg_cnt[2s+1]]
+ *   in the build's canonical order (ascending first occurrence inside the window; the reference's
+ *   order is libstdc++ unordered_set iteration order, an implementation artefact — DESIGN.md §2).
+ *   d_event_point[win_base[s]+k] = index of event k's pixel inside its polarity's segment, or -1
+ *   if the pixel was erased.  The segment arrays feed ecal_dbscan_batch_dev directly (S' = 2S).
+ *   *d_overflow = 1 if some window did not fit cap_points (its segments are then empty).
+ *   max_win_events: upper bound on any window size, 0 = unknown.
+ */
+int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_t0,
+                           const double *d_t1, uint32_t S, uint32_t *d_win_lo, uint32_t *d_win_hi,
+                           uint32_t *d_win_base /*[S+1]*/, void *stream);
+int ecal_check_sorted_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, int *d_flag, void *stream);
+int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const uint32_t *d_win_lo,
+                          const uint32_t *d_win_hi, const uint32_t *d_win_base, uint32_t S, uint32_t max_win_events,
+                          uint32_t cap_points, double *d_xy, uint32_t *d_seg_off /*[2S]*/,
+                          uint32_t *d_seg_cnt /*[2S]*/, int32_t *d_event_point, int *d_overflow, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

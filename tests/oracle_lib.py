@@ -109,3 +109,57 @@ def dbscan_batch(xy, seg_off, seg_cnt, eps, minpts):
     lib().oracle_dbscan_batch(_p(xy, _dp), _p(seg_off, _u32p), _p(seg_cnt, _u32p), S, float(eps), int(minpts),
                               _p(labels, _i32p), _p(ncl, _u32p))
     return labels[:xy.shape[0]], ncl[:S]
+
+
+# ---- ingest + slicing (oracle/event_oracle.cpp) ----
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+
+
+def _declare_events(L):
+    L.oracle_window_bounds.argtypes = [_u8p, ctypes.c_uint64, ctypes.c_double, ctypes.c_double, _u64p, _u64p]
+    L.oracle_window_bounds.restype = ctypes.c_int
+    L.oracle_check_sorted.argtypes = [_u8p, ctypes.c_uint64]
+    L.oracle_check_sorted.restype = ctypes.c_int
+    L.oracle_event_frame.argtypes = [_u8p, ctypes.c_uint64, ctypes.c_uint64, _dp, _u32p, _u32p, _i32p]
+    L.oracle_event_frame.restype = ctypes.c_int
+
+
+def window_bounds(rec, t0, t1):
+    L = lib()
+    _declare_events(L)
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    lo, hi = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    L.oracle_window_bounds(_p(rec, _u8p), rec.size // 25, float(t0), float(t1), ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+def check_sorted(rec):
+    L = lib()
+    _declare_events(L)
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    return L.oracle_check_sorted(_p(rec, _u8p), rec.size // 25)
+
+
+def event_frame(rec, lo, hi):
+    """EventFrame ctor on events [lo,hi): (xy_pos [nP,2], xy_neg [nN,2], event_point int32 [hi-lo])."""
+    L = lib()
+    _declare_events(L)
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    n = hi - lo
+    xy = np.zeros((max(n, 1), 2), dtype=np.float64)
+    ep = np.full(max(n, 1), -1, dtype=np.int32)
+    npos, nneg = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    L.oracle_event_frame(_p(rec, _u8p), lo, hi, _p(xy, _dp), ctypes.byref(npos), ctypes.byref(nneg), _p(ep, _i32p))
+    return xy[:npos.value].copy(), xy[npos.value:npos.value + nneg.value].copy(), ep[:n]
+
+
+def pack_events(t, x, y, p):
+    """numpy arrays -> packed 25-byte records (uint8 [n*25])."""
+    t = np.asarray(t, np.float64)
+    n = t.shape[0]
+    rec = np.zeros((n, 25), dtype=np.uint8)
+    rec[:, 0:8] = t.view(np.uint8).reshape(n, 8)
+    rec[:, 8:16] = np.asarray(x, np.float64).view(np.uint8).reshape(n, 8)
+    rec[:, 16:24] = np.asarray(y, np.float64).view(np.uint8).reshape(n, 8)
+    rec[:, 24] = np.asarray(p, np.uint8)
+    return rec.reshape(-1)

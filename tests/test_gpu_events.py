@@ -1,0 +1,126 @@
+"""GPU parity: window bounds + EventFrame slicing + DBSCAN on the sliced sets, vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth_stream as SS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    yield ctx, DetectPipeline(ctx), torch
+    ctx.close()
+
+
+def _compare(pipe, torch, rec_np, t0, t1, eps=4.0, minpts=2, check_labels=True):
+    S = len(t0)
+    lo = pipe.win_lo[:S].cpu().numpy().astype(np.int64)
+    hi = pipe.win_hi[:S].cpu().numpy().astype(np.int64)
+    base = pipe.win_base[:S + 1].cpu().numpy().astype(np.int64)
+    seg_off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
+    seg_cnt = pipe.seg_cnt[:2 * S].cpu().numpy().astype(np.int64)
+    xy = pipe.xy.cpu().numpy()
+    ep = pipe.event_point.cpu().numpy()
+    labels = pipe.labels.cpu().numpy()
+    ncl = pipe.n_clusters[:2 * S].cpu().numpy()
+    assert not pipe.overflowed()
+    run = 0
+    for s in range(S):
+        olo, ohi = O.window_bounds(rec_np, t0[s], t1[s])
+        assert (lo[s], hi[s]) == (olo, ohi), "window %d bounds" % s
+        assert base[s] == run
+        run += ohi - olo
+        pos, neg, oep = O.event_frame(rec_np, olo, ohi)
+        assert seg_cnt[2 * s] == pos.shape[0] and seg_cnt[2 * s + 1] == neg.shape[0], "window %d counts" % s
+        if ohi > olo:
+            assert seg_off[2 * s] == base[s] and seg_off[2 * s + 1] == base[s] + pos.shape[0]
+        gp = xy[seg_off[2 * s]:seg_off[2 * s] + seg_cnt[2 * s]]
+        gn = xy[seg_off[2 * s + 1]:seg_off[2 * s + 1] + seg_cnt[2 * s + 1]]
+        assert np.array_equal(gp, pos) and np.array_equal(gn, neg), "window %d points" % s
+        assert np.array_equal(ep[base[s]:base[s] + (ohi - olo)], oep), "window %d event_point" % s
+        if check_labels:
+            for k, pts in ((0, pos), (1, neg)):
+                if pts.shape[0] == 0:
+                    assert ncl[2 * s + k] == 0
+                    continue
+                rc, ol, onc = O.dbscan(pts, eps, minpts)
+                o = seg_off[2 * s + k]
+                assert np.array_equal(labels[o:o + pts.shape[0]], ol), "window %d pol %d labels" % (s, k)
+                assert ncl[2 * s + k] == onc
+    assert base[S] == run
+
+
+def test_tiled_windows_on_synthetic_stream(env):
+    ctx, pipe, torch = env
+    buf = SS.make_stream(60000, device="cpu")
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    pipe.set_windows(t0, t1)
+    pipe.run(buf.cuda())
+    torch.cuda.synchronize()
+    _compare(pipe, torch, buf.numpy(), t0, t1)
+
+
+def test_overlapping_empty_and_growing_windows(env):
+    """The reference's adaptive policy produces overlapping windows of 3..9 steps (eventCameraCalib.cpp:49-81)."""
+    ctx, pipe, torch = env
+    buf = SS.make_stream(40000, device="cpu", seed=7)
+    t, _, _ = SS.unpack_records(buf)
+    ts, te = float(t[0]), float(t[-1])
+    step = 5e-4
+    t0 = [ts, ts + step, ts + 2 * step, ts - 1.0, te + 1.0, ts + 10 * step, ts + 3 * step, ts]
+    t1 = [ts + 3 * step, ts + 5 * step, ts + 11 * step, ts - 0.5, te + 2.0, ts + 10 * step, ts + 3 * step + 1e-7, te]
+    pipe.set_windows(t0, t1)
+    pipe.run(buf.cuda(), slots=200000)
+    torch.cuda.synchronize()
+    _compare(pipe, torch, buf.numpy(), t0, t1)
+
+
+def test_slice_size_tiers_and_duplicates(env):
+    """Windows in every slicer tier (<=2048, <=5120 LDS; > 5120 global scratch), heavy duplication,
+    +/- cancellation, non-integer and negative-zero coordinates."""
+    ctx, pipe, torch = env
+    rng = np.random.default_rng(5)
+    n = 30000
+    t = np.sort(rng.uniform(0, 1, n))
+    x = rng.integers(0, 60, n).astype(np.float64) * rng.choice([1.0, 0.5], n)
+    y = rng.integers(0, 40, n).astype(np.float64)
+    x[rng.random(n) < 0.01] = -0.0
+    p = (rng.random(n) < 0.5).astype(np.uint8) * rng.integers(1, 255, n).astype(np.uint8)
+    rec = O.pack_events(t, x, y, p)
+    q = [0.0, t[1500], t[1501], t[5000], t[5001], t[12000], t[12001], t[29999]]
+    t0 = [q[0], q[2], q[4], q[6], 0.0]
+    t1 = [q[1], q[3], q[5], q[7], 1.0]
+    pipe.set_windows(t0, t1)
+    pipe.run(torch.from_numpy(rec).cuda(), slots=80000)
+    torch.cuda.synchronize()
+    _compare(pipe, torch, rec, t0, t1, check_labels=True)
+
+
+def test_overflow_is_reported(env):
+    ctx, pipe, torch = env
+    buf = SS.make_stream(5000, device="cpu")
+    t, _, _ = SS.unpack_records(buf)
+    pipe.set_windows([float(t[0])], [float(t[-1])])
+    pipe._cap_slots = 0
+    pipe.run(buf.cuda(), slots=100)
+    torch.cuda.synchronize()
+    assert pipe.overflowed()
+    assert int(pipe.seg_cnt[0]) == 0 and int(pipe.seg_cnt[1]) == 0
+
+
+def test_check_sorted(env):
+    ctx, pipe, torch = env
+    buf = SS.make_stream(5000, device="cpu").cuda()
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx.check_sorted_dev(buf.data_ptr(), 5000, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(flag.item()) == 0
+    rec = buf.reshape(5000, 25).flip(0).contiguous().reshape(-1)
+    ctx.check_sorted_dev(rec.data_ptr(), 5000, flag.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert int(flag.item()) == 1
