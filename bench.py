@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — M1 of BASELINE.json: Mevents/s through decode -> time-slice -> DBSCAN(+/-) -> circle
+candidates on the 50 M-event synthetic circle-grid stream (configs[2]'s stream; tiled 1.5 ms
+windows, policy P1 of SURVEY §8d), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  The detection
+path shards by time range with no data-path collective: every rank owns its own
+50 M-event stream (weak scaling); the only collectives are the timing barrier and a MAX over ranks.
+A "step" = one full pass of the hot path over the rank's resident stream.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_EVENT = 29.0     # 25 B record read once + 4 B int32 label written once
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--events", type=int, default=50_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="events timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    import eventcalib_amd
+    from eventcalib_amd.pipeline import DetectPipeline
+    import synth_stream as SS
+
+    ctx = eventcalib_amd.Context(local_rank)
+    pipe = DetectPipeline(ctx, dev)
+
+    # ---- synthetic input, resident in HBM before the timed region ----
+    n_events = args.events
+    rate = 1.0e6
+    t_start = 5.0 + rank * (n_events / rate + 1.0)      # every rank: its own time range of the motion
+    events = SS.make_stream(n_events, rate=rate, t_start=t_start, seed=12345 + rank, device=dev)
+    t_first = t_start
+    t_last = t_start + (n_events - 1) / rate
+    t0, t1 = SS.tiled_windows(t_first, t_last, 1.5e-3)
+    pipe.set_windows(t0, t1)
+    S = len(t0)
+
+    eps, minpts = 4.0, 2                                   # example.yaml:68-71
+    # size hints from an untimed pass (lets the launcher skip empty size tiers)
+    pipe.run(events, eps, minpts)
+    torch.cuda.synchronize(dev)
+    assert not pipe.overflowed()
+    max_win = int((pipe.win_hi[:S] - pipe.win_lo[:S]).max().item())
+    max_seg = int(pipe.seg_cnt[:2 * S].max().item())
+    n_points = int(pipe.seg_cnt[:2 * S].sum().item())
+
+    def step():
+        pipe.run(events, eps, minpts, max_win_events=max_win, max_seg_points=max_seg)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    # per-stage HIP events on the stream the kernels are launched on (torch's current stream)
+    st = torch.cuda.current_stream(dev)
+    c = ctx
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    barrier()
+    t_begin = time.perf_counter()
+    for k in range(args.steps):
+        n = n_events
+        ev[k][0].record(st)
+        c.window_bounds_dev(events.data_ptr(), n, pipe.t0.data_ptr(), pipe.t1.data_ptr(), S, pipe.win_lo.data_ptr(),
+                            pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(), st.cuda_stream)
+        ev[k][1].record(st)
+        c.slice_events_dev(events.data_ptr(), n, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(),
+                           pipe.win_base.data_ptr(), S, max_win, n, pipe.xy.data_ptr(), pipe.seg_off.data_ptr(),
+                           pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(), pipe.flags.data_ptr(), st.cuda_stream)
+        ev[k][2].record(st)
+        c.dbscan_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * S, n, max_seg,
+                           eps, minpts, pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), st.cuda_stream)
+        ev[k][3].record(st)
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    stage_ms = np.zeros(3)
+    for k in range(args.steps):
+        for j in range(3):
+            stage_ms[j] += ev[k][j].elapsed_time(ev[k][j + 1])
+    stage_ms /= max(args.steps, 1)
+
+    total_events = n_events * world * args.steps
+    value = total_events / elapsed / 1e6
+    ms_per_step = elapsed / max(args.steps, 1) * 1e3
+
+    out = {
+        "metric": "Mevents/s DBSCAN+detect",
+        "value": round(value, 3),
+        "unit": "Mevents/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "%dM-event synthetic circle-grid stream per GPU, 346x260, 1 Mev/s, tiled 1.5 ms windows "
+                        "(%d windows), eps 4 minpts 2; stages: window bounds + EventFrame slicing + DBSCAN(+/-)"
+                        % (n_events // 1_000_000, S),
+            "events_per_gpu": n_events, "windows_per_gpu": S, "unique_points_per_gpu": n_points,
+            "max_window_events": max_win, "max_segment_points": max_seg,
+            "sharding": "time ranges, one stream per GPU, no data-path collective",
+        },
+    }
+    if rank == 0:
+        dom = int(np.argmax(stage_ms))
+        names = ["window_bounds", "slice_lds_kernel", "dbscan_lds_kernel<1024,256>"]
+        achieved = ALGO_BYTES_PER_EVENT * n_events / (stage_ms[dom] * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_events,
+            "kernel_ms": round(float(stage_ms[dom]), 4),
+            "stage_ms": {"window_bounds": round(float(stage_ms[0]), 4), "slice": round(float(stage_ms[1]), 4),
+                         "dbscan": round(float(stage_ms[2]), 4)},
+        }
+        if args.cpu_sample > 0 and world == 1:
+            import oracle_lib as O
+            m = min(args.cpu_sample, n_events)
+            rec = events[: m * 25].cpu().numpy()
+            nw = int(np.searchsorted(t1, t_start + (m - 1) / rate))
+            tc = time.perf_counter()
+            cev, ccl = O.detect_windows(rec, t0[:nw], t1[:nw], eps, minpts)
+            cel = time.perf_counter() - tc
+            out["cpu_baseline"] = {
+                "value": round(cev / cel / 1e6, 4), "unit": "Mevents/s", "cores": 1, "kind": "port",
+                "sample": "first %d windows (%d events) of the same stream, oracle EventFrame + DBSCAN(+/-) per "
+                          "window, 1 thread, %.1f s" % (nw, cev, cel),
+                "host_cpus": os.cpu_count(),
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

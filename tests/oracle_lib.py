@@ -163,3 +163,18 @@ def pack_events(t, x, y, p):
     rec[:, 16:24] = np.asarray(y, np.float64).view(np.uint8).reshape(n, 8)
     rec[:, 24] = np.asarray(p, np.uint8)
     return rec.reshape(-1)
+
+
+def detect_windows(rec, t0, t1, eps, minpts):
+    """CPU baseline loop (oracle/pipeline_oracle.cpp): returns (events covered, total clusters)."""
+    L = lib()
+    L.oracle_detect_windows.argtypes = [_u8p, ctypes.c_uint64, _dp, _dp, ctypes.c_uint32, ctypes.c_double,
+                                        ctypes.c_uint32, _u64p]
+    L.oracle_detect_windows.restype = ctypes.c_uint64
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    t0 = np.ascontiguousarray(t0, dtype=np.float64)
+    t1 = np.ascontiguousarray(t1, dtype=np.float64)
+    ncl = ctypes.c_uint64(0)
+    ev = L.oracle_detect_windows(_p(rec, _u8p), rec.size // 25, _p(t0, _dp), _p(t1, _dp), t0.shape[0], float(eps),
+                                 int(minpts), ctypes.byref(ncl))
+    return int(ev), int(ncl.value)
