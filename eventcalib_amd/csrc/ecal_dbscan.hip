@@ -123,7 +123,7 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = set_attrs(ctx);
     if (rc) return rc;
-    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    hipStream_t st = (hipStream_t) stream;
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
 
     hipLaunchKernelGGL((dbscan_lds_kernel<CAP0, CAP0 / 4>), dim3(S), dim3(CAP0 / 4), TierLayout<CAP0>::bytes, st, d_xy,

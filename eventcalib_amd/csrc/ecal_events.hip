@@ -367,7 +367,7 @@ extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, ui
         return ECAL_ERR_INVALID;
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    hipStream_t st = (hipStream_t) stream;
     hipLaunchKernelGGL(window_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d_events, n_events, d_t0, d_t1, S,
                        d_win_lo, d_win_hi);
     hipLaunchKernelGGL(window_base_kernel, dim3(1), dim3(1024), 0, st, d_win_lo, d_win_hi, S, d_win_base);
@@ -379,7 +379,7 @@ extern "C" int ecal_check_sorted_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
                                      void *stream) {
     if (!ctx || !d_flag || (n_events && !d_events)) return ECAL_ERR_INVALID;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    hipStream_t st = (hipStream_t) stream;
     ECAL_HIP_TRY(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), st));
     if (n_events > 1) {
         const uint64_t blocks = (n_events - 1 + 255) / 256;
@@ -402,7 +402,7 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         return ECAL_ERR_INVALID;
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = stream ? (hipStream_t) stream : ctx->stream;
+    hipStream_t st = (hipStream_t) stream;
     if (!ctx->slice_attrs_set) {
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_lds_kernel<SCAP0, 2048, 256>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize,

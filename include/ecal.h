@@ -10,8 +10,9 @@
  *
  * Conventions: returns ECAL_OK (0) or a negative ecal_status; never throws; all buffers are
  * caller-owned; outputs are written only on success.  Entry points ending in _dev take DEVICE
- * pointers and enqueue asynchronously on `stream` (a hipStream_t passed as void*, NULL = the
- * context's own stream); the others take HOST pointers and return when the result is in place.
+ * pointers and enqueue asynchronously on `stream` (a hipStream_t passed as void*; NULL is HIP's
+ * default stream, exactly as in a kernel launch); the others take HOST pointers, run on the
+ * context's own stream and return when the result is in place.
  * One ecal_ctx per host thread (matches the reference's one-DBSCAN-instance-per-worker use,
  * event_camera_calib/test/eventCameraCalib.cpp:181-190).
  */
