@@ -23,11 +23,11 @@ struct ecal_ctx {
     std::string last_error;
     // grow-only device scratch (never shrinks; sized for 288 GB parts: keep and reuse)
     ecal_devbuf in_xy, in_off, in_cnt, out_labels, out_ncl;  // staging for the host-pointer API
-    ecal_devbuf big_slot, big_anc, big_cur;                 // global-scratch tier of DBSCAN
+    ecal_devbuf big_slot, big_anc, big_cur, big_inv, big_cs, big_flags;    // global-scratch tier of DBSCAN
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
     bool attrs_set = false, slice_attrs_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
-        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur,
+        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos};
     }
 };

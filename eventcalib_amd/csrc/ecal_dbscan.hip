@@ -12,11 +12,15 @@ template <int CAP>
 struct TierLayout {
     static constexpr size_t c_off = 0;
     static constexpr size_t slot_off = c_off + sizeof(double) * 2 * CAP;
-    static constexpr size_t anc_off = slot_off + sizeof(uint32_t) * (2 * CAP + 4);
+    static constexpr size_t anc_off = slot_off + sizeof(uint32_t) * (2 * CAP + 8);
     static constexpr size_t cur_off = anc_off + sizeof(uint16_t) * 4 * CAP;
-    static constexpr size_t red_off = cur_off + sizeof(uint16_t) * CAP;
-    static constexpr size_t bytes = red_off + sizeof(uint32_t) * 32;
-    static_assert(slot_off % 16 == 0 && anc_off % 16 == 0 && cur_off % 16 == 0 && red_off % 16 == 0, "align");
+    static constexpr size_t inv_off = cur_off + sizeof(uint16_t) * CAP;
+    static constexpr size_t red_off = inv_off + sizeof(uint16_t) * CAP;
+    static constexpr size_t edges_off = red_off + sizeof(uint32_t) * 48;
+    static constexpr size_t sflags_off = edges_off + sizeof(uint32_t) * 2 * EDGE_CAP;
+    static constexpr size_t bytes = sflags_off + ((CAP + 15) / 16) * 16;
+    static_assert(slot_off % 16 == 0 && anc_off % 16 == 0 && cur_off % 16 == 0 && inv_off % 16 == 0 &&
+                  red_off % 16 == 0 && edges_off % 16 == 0, "align");
 };
 
 template <int V>
@@ -26,6 +30,12 @@ struct Log2 {
 template <>
 struct Log2<1> {
     static constexpr uint32_t value = 0;
+};
+
+// bucket count of a tier = largest power of two <= CAP (label[n] + 1 + starts[nb + 2] must fit slot[2 CAP + 8])
+template <int CAP>
+struct NbLog {
+    static constexpr uint32_t value = Log2<CAP>::value;  // Log2 rounds down
 };
 
 // Segments with lo_excl < n <= CAP are handled here; the others exit at once.
@@ -45,19 +55,65 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
     }
     if (n <= lo_excl || n > (uint32_t) CAP) return;
     using L = TierLayout<CAP>;
-    DbWork<uint16_t> w;
-    double2 *pts = reinterpret_cast<double2 *>(smem + L::c_off);
-    w.c = reinterpret_cast<const double *>(pts);
-    w.slot = reinterpret_cast<uint32_t *>(smem + L::slot_off);
-    w.anc = reinterpret_cast<uint16_t *>(smem + L::anc_off);
-    w.cur = reinterpret_cast<uint16_t *>(smem + L::cur_off);
-    w.red = reinterpret_cast<uint32_t *>(smem + L::red_off);
-
+    constexpr int PPT = CAP / T;
     const size_t base = seg_off[s];
     const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
-    for (uint32_t i = threadIdx.x; i < n; i += T) pts[i] = src[i];
+    uint32_t *const red = reinterpret_cast<uint32_t *>(smem + L::red_off);
+
+    // A. load the segment; pixel-like data (integers, |v| <= 16383) takes the exact int16 path
+    double2 mine[PPT];
+    bool fits = true;
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+        const uint32_t i = threadIdx.x + u * T;
+        if (i < n) {
+            mine[u] = src[i];
+            fits = fits && GeoI16::fits(mine[u]);
+        }
+    }
+    if (threadIdx.x < 3) red[40 + threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t total = dbscan_segment<T, false, uint16_t>(w, n, eps, minpts, Log2<CAP>::value, labels + base);
+    uint32_t round = 0;
+    const bool int_mode = !block_any(!fits, red + 40, round);
+
+    uint32_t total;
+    if (int_mode) {
+        DbWork<uint16_t, GeoI16> w;
+        uint32_t *pts = reinterpret_cast<uint32_t *>(smem + L::c_off);
+        w.p = pts;
+        w.cs = pts;  // bucket-ordered points overwrite the pid-ordered copy once B and the count pass are done
+        w.slot = reinterpret_cast<uint32_t *>(smem + L::slot_off);
+        w.anc = reinterpret_cast<uint16_t *>(smem + L::anc_off);
+        w.pid_s = reinterpret_cast<uint16_t *>(smem + L::cur_off);
+        w.inv = reinterpret_cast<uint16_t *>(smem + L::inv_off);
+        w.red = red;
+        w.edges = reinterpret_cast<uint32_t *>(smem + L::edges_off);
+        w.sflags = reinterpret_cast<uint8_t *>(smem + L::sflags_off);
+        w.pflags = nullptr;
+#pragma unroll
+        for (int u = 0; u < PPT; u++)
+            if (threadIdx.x + u * T < n) pts[threadIdx.x + u * T] = GeoI16::pack(mine[u]);
+        __syncthreads();
+        total = dbscan_segment<T, false, uint16_t, PPT, GeoI16>(w, src, n, eps, minpts, NbLog<CAP>::value, labels + base);
+    } else {
+        DbWork<uint16_t, GeoF64> w;
+        double2 *pts = reinterpret_cast<double2 *>(smem + L::c_off);
+        w.p = pts;
+        w.cs = pts;
+        w.slot = reinterpret_cast<uint32_t *>(smem + L::slot_off);
+        w.anc = reinterpret_cast<uint16_t *>(smem + L::anc_off);
+        w.pid_s = reinterpret_cast<uint16_t *>(smem + L::cur_off);
+        w.inv = reinterpret_cast<uint16_t *>(smem + L::inv_off);
+        w.red = red;
+        w.edges = reinterpret_cast<uint32_t *>(smem + L::edges_off);
+        w.sflags = reinterpret_cast<uint8_t *>(smem + L::sflags_off);
+        w.pflags = nullptr;
+#pragma unroll
+        for (int u = 0; u < PPT; u++)
+            if (threadIdx.x + u * T < n) pts[threadIdx.x + u * T] = mine[u];
+        __syncthreads();
+        total = dbscan_segment<T, false, uint16_t, PPT, GeoF64>(w, src, n, eps, minpts, NbLog<CAP>::value, labels + base);
+    }
     if (threadIdx.x == 0) n_clusters[s] = total;
 }
 
@@ -69,22 +125,30 @@ __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restr
                                                            const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
                                                            double eps, uint32_t minpts, int32_t *__restrict__ labels,
                                                            uint32_t *__restrict__ n_clusters, uint32_t *gslot,
-                                                           uint32_t *ganc, uint32_t *gcur) {
-    __shared__ uint32_t red[32];
+                                                           uint32_t *ganc, uint32_t *gcur, uint32_t *ginv,
+                                                           double2 *gcs, uint8_t *gflags) {
+    __shared__ uint32_t red[48];
+    __shared__ uint32_t edges[2 * EDGE_CAP];
     const uint32_t s = blockIdx.x;
     const uint32_t n = seg_cnt[s];
     if (n <= lo_excl) return;
     const size_t base = seg_off[s];
-    DbWork<uint32_t> w;
-    w.c = xy + 2 * base;  // the caller's interleaved points are used in place
-    w.slot = gslot + 2 * base;
+    DbWork<uint32_t, GeoF64> w;
+    const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
+    w.p = src;  // the caller's interleaved points are read in place
+    w.cs = gcs + base;
+    w.slot = gslot + 2 * base + 4 * (size_t) s;
     w.anc = ganc + 4 * base;
-    w.cur = gcur + base;
+    w.pid_s = gcur + base;
+    w.inv = ginv + base;
     w.red = red;
+    w.edges = edges;
+    w.sflags = gflags + 2 * base;
+    w.pflags = gflags + 2 * base + n;
     // nb = largest power of two <= n/2 (>= 2048 here) so that label[n] + 1 + cursor[nb] fits slot[2n]
     uint32_t nb_log = 31u - (uint32_t) __clz((int) (n >> 1));
     if (nb_log > 20u) nb_log = 20u;
-    const uint32_t total = dbscan_segment<BIG_T, true, uint32_t>(w, n, eps, minpts, nb_log, labels + base);
+    const uint32_t total = dbscan_segment<BIG_T, true, uint32_t, 0, GeoF64>(w, src, n, eps, minpts, nb_log, labels + base);
     if (threadIdx.x == 0) n_clusters[s] = total;
 }
 
@@ -92,6 +156,9 @@ __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restr
 
 using namespace ecal;
 
+// size tiers: capacity CAP points, CAP/4 threads; LDS ~39 B/point -> 4 / 2 / 1 workgroups per CU.
+// (Smaller tiers — 640 points on 128 threads, 768 on 256 — were measured and are not faster: the
+// kernel is bound by instructions issued per point, not by occupancy; profiles/r01_notes.md.)
 static constexpr int CAP0 = 1024, CAP1 = 2048, CAP2 = 4096;
 
 static int set_attrs(ecal_ctx *ctx) {
@@ -115,6 +182,10 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
         ctx->last_error = "minpts < 1 (DBSCAN::Run returns FAILED)";
         return ECAL_ERR_INVALID;
     }
+    if (!(eps > 0.0) || !(eps < 1.0e300)) {
+        ctx->last_error = "eps must be a positive finite number";
+        return ECAL_ERR_INVALID;
+    }
     if (S == 0) return ECAL_OK;
     if (!d_seg_off || !d_seg_cnt || !d_n_clusters || (n_points && (!d_xy || !d_labels))) {
         ctx->last_error = "null pointer";
@@ -136,12 +207,16 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
                            d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP1, eps, minpts, d_labels, d_n_clusters);
     if (mx > (uint32_t) CAP2) {
         const size_t np = n_points;
-        if ((rc = ecal_ensure(ctx, ctx->big_slot, (2 * np + 4) * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_slot, (2 * np + 4 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_inv, np * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_cs, np * 2 * sizeof(double)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_flags, 2 * np + 16))) return rc;
         if ((rc = ecal_ensure(ctx, ctx->big_anc, 4 * np * sizeof(uint32_t)))) return rc;
         if ((rc = ecal_ensure(ctx, ctx->big_cur, np * sizeof(uint32_t)))) return rc;
         hipLaunchKernelGGL(dbscan_big_kernel, dim3(S), dim3(BIG_T), 0, st, d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP2,
                            eps, minpts, d_labels, d_n_clusters, (uint32_t *) ctx->big_slot.ptr, (uint32_t *) ctx->big_anc.ptr,
-                           (uint32_t *) ctx->big_cur.ptr);
+                           (uint32_t *) ctx->big_cur.ptr, (uint32_t *) ctx->big_inv.ptr, (double2 *) ctx->big_cs.ptr,
+                           (uint8_t *) ctx->big_flags.ptr);
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
@@ -152,6 +227,10 @@ extern "C" int ecal_dbscan_batch(ecal_ctx *ctx, const double *xy, const uint32_t
     if (!ctx) return ECAL_ERR_INVALID;
     if (minpts < 1) {
         ctx->last_error = "minpts < 1 (DBSCAN::Run returns FAILED)";
+        return ECAL_ERR_INVALID;
+    }
+    if (!(eps > 0.0) || !(eps < 1.0e300)) {
+        ctx->last_error = "eps must be a positive finite number";
         return ECAL_ERR_INVALID;
     }
     if (S == 0) return ECAL_OK;
@@ -224,3 +303,14 @@ extern "C" int ecal_dbscan_batch(ecal_ctx *ctx, const double *xy, const uint32_t
     free(tn);
     return ECAL_OK;
 }
+
+#ifdef ECAL_PHASE_PROF
+extern "C" int ecal_debug_phase_cycles(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_phase_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -103,5 +103,8 @@ def test_invalid_arguments(ctx):
     import eventcalib_amd
     with pytest.raises(eventcalib_amd.EcalError):
         ctx.dbscan_batch(np.zeros((3, 2)), np.array([0, 3], np.uint32), 4.0, 0)   # Run() FAILED: min < 1
+    for bad_eps in (0.0, -4.0, float("nan"), float("inf")):
+        with pytest.raises(eventcalib_amd.EcalError):
+            ctx.dbscan_batch(np.zeros((3, 2)), np.array([0, 3], np.uint32), bad_eps, 2)
     labels, ncl = ctx.dbscan_batch(np.zeros((0, 2)), np.array([0], np.uint32), 4.0, 2)
     assert labels.size == 0 and ncl.size == 0
