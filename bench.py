@@ -76,6 +76,8 @@ def main():
     max_win = int((pipe.win_hi[:S] - pipe.win_lo[:S]).max().item())
     max_seg = int(pipe.seg_cnt[:2 * S].max().item())
     n_points = int(pipe.seg_cnt[:2 * S].sum().item())
+    n_ok = int((pipe.win_info[:S, 3] == 0).sum().item())
+    n_cand = int(pipe.win_info[:S, 0].sum().item())
 
     def step():
         pipe.run(events, eps, minpts, max_win_events=max_win, max_seg_points=max_seg)
@@ -90,7 +92,8 @@ def main():
     # per-stage HIP events on the stream the kernels are launched on (torch's current stream)
     st = torch.cuda.current_stream(dev)
     c = ctx
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    pipe.set_detect_params(5, 36, ctx.circle_radius_threshold(346, 260, 9, 4, True, 5.5, 1.75))
     barrier()
     t_begin = time.perf_counter()
     for k in range(args.steps):
@@ -106,6 +109,11 @@ def main():
         c.dbscan_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * S, n, max_seg,
                            eps, minpts, pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), st.cuda_stream)
         ev[k][3].record(st)
+        c.extract_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
+                            pipe.n_clusters.data_ptr(), S, n, pipe.det[0], pipe.det[1], pipe.det[2],
+                            pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
+                            pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream)
+        ev[k][4].record(st)
     barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
@@ -113,9 +121,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    stage_ms = np.zeros(3)
+    stage_ms = np.zeros(4)
     for k in range(args.steps):
-        for j in range(3):
+        for j in range(4):
             stage_ms[j] += ev[k][j].elapsed_time(ev[k][j + 1])
     stage_ms /= max(args.steps, 1)
 
@@ -138,16 +146,17 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%dM-event synthetic circle-grid stream per GPU, 346x260, 1 Mev/s, tiled 1.5 ms windows "
-                        "(%d windows), eps 4 minpts 2; stages: window bounds + EventFrame slicing + DBSCAN(+/-)"
+                        "(%d windows), eps 4 minpts 2; stages: window bounds + EventFrame slicing + DBSCAN(+/-) + circle candidates"
                         % (n_events // 1_000_000, S),
             "events_per_gpu": n_events, "windows_per_gpu": S, "unique_points_per_gpu": n_points,
             "max_window_events": max_win, "max_segment_points": max_seg,
+            "windows_reaching_pairing": n_ok, "circle_candidates": n_cand,
             "sharding": "time ranges, one stream per GPU, no data-path collective",
         },
     }
     if rank == 0:
         dom = int(np.argmax(stage_ms))
-        names = ["window_bounds", "slice_lds_kernel", "dbscan_lds_kernel<1024,256>"]
+        names = ["window_bounds", "slice_lds_kernel", "dbscan_lds_kernel<1024,256>", "extract_kernel"]
         achieved = ALGO_BYTES_PER_EVENT * n_events / (stage_ms[dom] * 1e-3) / 1e9
         out["roofline"] = {
             "bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
@@ -155,7 +164,7 @@ def main():
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_events,
             "kernel_ms": round(float(stage_ms[dom]), 4),
             "stage_ms": {"window_bounds": round(float(stage_ms[0]), 4), "slice": round(float(stage_ms[1]), 4),
-                         "dbscan": round(float(stage_ms[2]), 4)},
+                         "dbscan": round(float(stage_ms[2]), 4), "extract": round(float(stage_ms[3]), 4)},
         }
         if args.cpu_sample > 0 and world == 1:
             import oracle_lib as O
@@ -167,8 +176,8 @@ def main():
             cel = time.perf_counter() - tc
             out["cpu_baseline"] = {
                 "value": round(cev / cel / 1e6, 4), "unit": "Mevents/s", "cores": 1, "kind": "port",
-                "sample": "first %d windows (%d events) of the same stream, oracle EventFrame + DBSCAN(+/-) per "
-                          "window, 1 thread, %.1f s" % (nw, cev, cel),
+                "sample": "first %d windows (%d events) of the same stream, oracle EventFrame + extractFeatures "
+                          "(DBSCAN +/-, filter, medians, pairing) per window, 1 thread, %.1f s" % (nw, cev, cel),
                 "host_cpus": os.cpu_count(),
             }
         print(json.dumps(out), flush=True)

@@ -13,6 +13,7 @@ EXPORTED_SYMBOLS = [
     "ecal_abi_version", "ecal_init", "ecal_destroy", "ecal_strerror", "ecal_last_error", "ecal_sync",
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
+    "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
 ]
 
 
@@ -59,6 +60,10 @@ def load_library():
     L.ecal_check_sorted_dev.restype = i32
     L.ecal_slice_events_dev.argtypes = [vp, vp, u64, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp, vp]
     L.ecal_slice_events_dev.restype = i32
+    L.ecal_circle_radius_threshold.argtypes = [f64, f64, i32, i32, i32, f64, f64]
+    L.ecal_circle_radius_threshold.restype = f64
+    L.ecal_extract_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f64, vp, vp, vp, vp, vp, vp]
+    L.ecal_extract_batch_dev.restype = i32
     _LIB = L
     return L
 
@@ -139,3 +144,16 @@ class Context:
         self._check(self._L.ecal_slice_events_dev(self._h, d_events, int(n_events), d_win_lo, d_win_hi, d_win_base,
                                                   int(S), int(max_win_events), int(cap_points), d_xy, d_seg_off,
                                                   d_seg_cnt, d_event_point, d_overflow, stream))
+
+    # ---- circle-candidate extraction ----
+    def circle_radius_threshold(self, width, height, rows, cols, asymmetric, square_size, circle_radius):
+        return self._L.ecal_circle_radius_threshold(float(width), float(height), int(rows), int(cols),
+                                                    int(bool(asymmetric)), float(square_size), float(circle_radius))
+
+    def extract_batch_dev(self, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min,
+                          need_clusters, radius_threshold, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
+                          stream=0):
+        self._check(self._L.ecal_extract_batch_dev(self._h, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters,
+                                                   int(S), int(n_points), int(cluster_min), int(need_clusters),
+                                                   float(radius_threshold), d_win_info, d_cand_pair, d_cand_xyr,
+                                                   d_kept_labels, d_rep, stream))

@@ -25,10 +25,12 @@ struct ecal_ctx {
     ecal_devbuf in_xy, in_off, in_cnt, out_labels, out_ncl;  // staging for the host-pointer API
     ecal_devbuf big_slot, big_anc, big_cur, big_inv, big_cs, big_flags;    // global-scratch tier of DBSCAN
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
+    ecal_devbuf det_members, det_koff, det_ksize;  // detection stage scratch
     bool attrs_set = false, slice_attrs_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
-                &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos};
+                &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos,
+                &det_members, &det_koff, &det_ksize};
     }
 };
 

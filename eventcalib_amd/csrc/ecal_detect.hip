@@ -1,0 +1,287 @@
+// Circle-candidate extraction per time-slice: DBSCAN labels of the + and - pixel sets -> filtered
+// clusters -> median representatives -> mutually nearest +/- pairs -> candidate circles.
+//
+// Replaces CirclesEventFrame::extractFeatures between its two DBSCAN::Run calls and the
+// findCirclesGrid call (event_camera_calib/src/CirclesEventFrame.cpp:89-312, fitCircle == 0 path
+// :283-311) and the radius gate of :16-33.  One workgroup owns one window.
+//
+// Order conventions: a cluster's members are processed in ascending pid; its
+// representative is the member of rank size/2 in the order (norm, pid) — the reference takes
+// std::nth_element by norm over its BFS member order, which picks the same pixel unless two members
+// tie in norm at that rank; 1-NN ties go to the smallest cluster index.
+#include "ecal_ctx.hpp"
+#include "block_utils.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ecal {
+
+constexpr int DET_T = 256;
+constexpr uint32_t DET_MAXC = 2048;  // DBSCAN clusters per polarity handled in LDS
+
+struct DetectParams {
+    uint32_t cluster_min;    // clusterMinSample
+    uint32_t need_clusters;  // rows * cols
+    double four_thr2;        // 4 * circleRadiusThreshold_^2
+};
+
+__device__ __forceinline__ double norm_of(double2 p) { return __dsqrt_rn(p.x * p.x + p.y * p.y); }  // Vector2d::norm()
+
+__global__ __launch_bounds__(DET_T) void extract_kernel(
+    const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+    const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
+    uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
+    int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
+    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize) {
+    __shared__ uint32_t csize[DET_MAXC];  // members per DBSCAN cluster; later a scatter cursor
+    __shared__ uint32_t newid[DET_MAXC];  // renumbered id of a kept cluster
+    __shared__ uint32_t coff[DET_MAXC];   // first member slot of a kept cluster
+    __shared__ unsigned long long red[DET_T / 64];
+    __shared__ uint32_t nk_sh[2];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const double2 *pts = reinterpret_cast<const double2 *>(xy);
+    uint32_t *info = win_info + 4 * (size_t) s;
+    const uint32_t o_pol[2] = {seg_off[2 * s], seg_off[2 * s + 1]};
+    const uint32_t n_pol[2] = {seg_cnt[2 * s], seg_cnt[2 * s + 1]};
+
+    if (n_pol[0] == 0 || n_pol[1] == 0) {  // CirclesEventFrame.cpp:62-64
+        for (int pol = 0; pol < 2; pol++)
+            for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) kept_labels[o_pol[pol] + i] = -1;
+        if (tid == 0) {
+            info[0] = 0;
+            info[1] = 0;
+            info[2] = 0;
+            info[3] = 1;
+        }
+        return;
+    }
+    if (n_clusters[2 * s] > DET_MAXC || n_clusters[2 * s + 1] > DET_MAXC) {
+        for (int pol = 0; pol < 2; pol++)
+            for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) kept_labels[o_pol[pol] + i] = -1;
+        if (tid == 0) {
+            info[0] = 0;
+            info[1] = 0;
+            info[2] = 0;
+            info[3] = 4;  // capacity exceeded (more than DET_MAXC clusters in one polarity)
+        }
+        return;
+    }
+
+    for (int pol = 0; pol < 2; pol++) {
+        const uint32_t o = o_pol[pol], n = n_pol[pol], nc = n_clusters[2 * s + pol];
+        const int32_t *lab = labels + o;
+        for (uint32_t c = tid; c < nc; c += DET_T) csize[c] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += DET_T) {
+            const int32_t l = lab[i];
+            if (l >= 0) atomicAdd(&csize[l], 1u);
+        }
+        __syncthreads();
+        // kept clusters (:89-117): renumber, and lay their member lists out back to back
+        {
+            const uint32_t per = (nc + DET_T - 1) / DET_T, c0 = tid * per;
+            uint32_t k = 0, m = 0;
+            for (uint32_t c = c0; c < c0 + per && c < nc; c++) {
+                if (csize[c] >= prm.cluster_min) {
+                    k++;
+                    m += csize[c];
+                }
+            }
+            uint32_t ek, em, tk, tm;
+            block_exscan_pair<DET_T>(k, m, red, &ek, &em, &tk, &tm);
+            for (uint32_t c = c0; c < c0 + per && c < nc; c++) {
+                if (csize[c] >= prm.cluster_min) {
+                    newid[c] = ek;
+                    coff[c] = em;
+                    koff[o + ek] = em;
+                    ksize[o + ek] = csize[c];
+                    ek++;
+                    em += csize[c];
+                } else {
+                    newid[c] = 0xFFFFFFFFu;
+                }
+            }
+            if (tid == 0) nk_sh[pol] = tk;
+        }
+        __syncthreads();
+        // per-point renumbered label; member lists (arbitrary order first)
+        for (uint32_t i = tid; i < n; i += DET_T) {
+            const int32_t l = lab[i];
+            int32_t kl = -1;
+            if (l >= 0 && newid[l] != 0xFFFFFFFFu) {
+                kl = (int32_t) newid[l];
+                const uint32_t at = atomicSub(&csize[l], 1u) - 1u;
+                members[o + coff[l] + at] = i;
+            }
+            kept_labels[o + i] = kl;
+        }
+        __syncthreads();
+    }
+    const uint32_t nk[2] = {nk_sh[0], nk_sh[1]};
+    if (nk[0] < prm.need_clusters || nk[1] < prm.need_clusters) {  // :127-129
+        if (tid == 0) {
+            info[0] = 0;
+            info[1] = nk[0];
+            info[2] = nk[1];
+            info[3] = 1;
+        }
+        return;
+    }
+    // representative of every kept cluster (:136-147): rank size/2 in the order (norm, pid).
+    // members, kept_labels, koff, ksize were written by this workgroup: visible after the barrier.
+    for (int pol = 0; pol < 2; pol++) {
+        const uint32_t o = o_pol[pol], n = n_pol[pol];
+        for (uint32_t i = tid; i < n; i += DET_T) {
+            const int32_t kl = kept_labels[o + i];
+            if (kl < 0) continue;
+            const uint32_t m = ksize[o + kl];
+            const uint32_t *mem = members + o + koff[o + kl];
+            const double ni = norm_of(pts[o + i]);
+            uint32_t rank = 0;
+            for (uint32_t t = 0; t < m; t++) {
+                const uint32_t j = mem[t];
+                const double nj = norm_of(pts[o + j]);
+                rank += (nj < ni || (nj == ni && j < i)) ? 1u : 0u;
+            }
+            if (rank == m / 2) rep[o + kl] = i;
+        }
+    }
+    __syncthreads();
+    // mutual nearest +/- representatives and the circle test (:283-311); candidates in + cluster order
+    uint32_t carry = 0;
+    for (uint32_t p0 = 0; p0 < nk[0]; p0 += DET_T) {
+        const uint32_t pi = p0 + tid;
+        bool ok = false;
+        uint32_t ni_best = 0;
+        double cx = 0, cy = 0, r = 0;
+        if (pi < nk[0]) {
+            const double2 pc = pts[o_pol[0] + rep[o_pol[0] + pi]];
+            double bd = 1.79769313486231570e308;
+            for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
+                const double2 c = pts[o_pol[1] + rep[o_pol[1] + k]];
+                const double dx = pc.x - c.x, dy = pc.y - c.y;
+                const double d = dx * dx + dy * dy;
+                if (d < bd) {
+                    bd = d;
+                    ni_best = k;
+                }
+            }
+            if (!(bd > prm.four_thr2)) {  // :286
+                const double2 nc = pts[o_pol[1] + rep[o_pol[1] + ni_best]];
+                double bd2 = 1.79769313486231570e308;
+                uint32_t back = 0;
+                for (uint32_t k = 0; k < nk[0]; k++) {
+                    const double2 c = pts[o_pol[0] + rep[o_pol[0] + k]];
+                    const double dx = nc.x - c.x, dy = nc.y - c.y;
+                    const double d = dx * dx + dy * dy;
+                    if (d < bd2) {
+                        bd2 = d;
+                        back = k;
+                    }
+                }
+                if (back == pi) {
+                    cx = (pc.x + nc.x) / 2;
+                    cy = (pc.y + nc.y) / 2;
+                    const double ddx = pc.x - nc.x, ddy = pc.y - nc.y;
+                    r = __dsqrt_rn(ddx * ddx + ddy * ddy) / 2;
+                    double fit = 0;
+                    uint32_t cnt = 0;
+                    for (int pol = 0; pol < 2; pol++) {
+                        const uint32_t o = o_pol[pol], kk = pol ? ni_best : pi;
+                        const uint32_t m = ksize[o + kk];
+                        const uint32_t *mem = members + o + koff[o + kk];
+                        // ascending pid without sorting: m is small, pick the next larger pid each time
+                        uint32_t prev = 0;
+                        bool first = true;
+                        for (uint32_t t = 0; t < m; t++) {
+                            uint32_t nxt = 0xFFFFFFFFu;
+                            for (uint32_t u = 0; u < m; u++) {
+                                const uint32_t j = mem[u];
+                                if ((first || j > prev) && j < nxt) nxt = j;
+                            }
+                            const double2 e = pts[o + nxt];
+                            const double ex = e.x - cx, ey = e.y - cy;
+                            fit += fabs(__dsqrt_rn(ex * ex + ey * ey) - r);
+                            prev = nxt;
+                            first = false;
+                        }
+                        cnt += m;
+                    }
+                    fit /= (double) cnt * r;
+                    ok = fit < 10 / r;
+                }
+            }
+        }
+        uint32_t ex, dummy, tot, dummy2;
+        block_exscan_pair<DET_T>(ok ? 1u : 0u, 0u, red, &ex, &dummy, &tot, &dummy2);
+        if (ok) {
+            const size_t at = (size_t) o_pol[0] + carry + ex;
+            cand_pair[2 * at] = pi;
+            cand_pair[2 * at + 1] = ni_best;
+            cand_xyr[3 * at] = cx;
+            cand_xyr[3 * at + 1] = cy;
+            cand_xyr[3 * at + 2] = r;
+        }
+        carry += tot;
+    }
+    if (tid == 0) {
+        info[0] = carry;
+        info[1] = nk[0];
+        info[2] = nk[1];
+        info[3] = 0;
+    }
+}
+
+}  // namespace ecal
+
+using namespace ecal;
+
+extern "C" double ecal_circle_radius_threshold(double width, double height, int rows, int cols, int asymmetric,
+                                               double square_size, double circle_radius) {
+    const double lo = width < height ? width : height, hi = width < height ? height : width;
+    int a, b;
+    if (asymmetric) {
+        a = rows > 2 * cols ? rows : 2 * cols;
+        b = rows < 2 * cols ? rows : 2 * cols;
+    } else {
+        a = rows > cols ? rows : cols;
+        b = rows < cols ? rows : cols;
+    }
+    const double m1 = hi / a, m2 = lo / b;
+    return (m1 < m2 ? m1 : m2) / square_size * circle_radius * 1.5;
+}
+
+extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off,
+                                      const uint32_t *d_seg_cnt, const int32_t *d_labels,
+                                      const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points,
+                                      uint32_t cluster_min, uint32_t need_clusters, double radius_threshold,
+                                      uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
+                                      int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (S == 0) return ECAL_OK;
+    if (!d_seg_off || !d_seg_cnt || !d_n_clusters || !d_win_info ||
+        (n_points && (!d_xy || !d_labels || !d_cand_pair || !d_cand_xyr || !d_kept_labels || !d_rep))) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    if (!(radius_threshold >= 0.0)) {
+        ctx->last_error = "radius_threshold must be >= 0";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t np = (size_t) n_points + 16;
+    if ((rc = ecal_ensure(ctx, ctx->det_members, np * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->det_koff, np * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->det_ksize, np * sizeof(uint32_t)))) return rc;
+    DetectParams prm;
+    prm.cluster_min = cluster_min;
+    prm.need_clusters = need_clusters;
+    prm.four_thr2 = 4 * radius_threshold * radius_threshold;
+    hipLaunchKernelGGL(extract_kernel, dim3(S), dim3(DET_T), 0, (hipStream_t) stream, d_xy, d_seg_off, d_seg_cnt,
+                       d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
+                       (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
+                       (uint32_t *) ctx->det_ksize.ptr);
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}

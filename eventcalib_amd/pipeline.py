@@ -32,11 +32,16 @@ class DetectPipeline:
             self.seg_cnt = torch.empty(2 * S, dtype=torch.int32, device=dev)
             self.n_clusters = torch.empty(2 * S, dtype=torch.int32, device=dev)
             self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+            self.win_info = torch.empty(S, 4, dtype=torch.int32, device=dev)
             self._cap_windows = S
         if slots > self._cap_slots:
             self.xy = torch.empty(slots, 2, dtype=torch.float64, device=dev)
             self.event_point = torch.empty(slots, dtype=torch.int32, device=dev)
             self.labels = torch.empty(slots, dtype=torch.int32, device=dev)
+            self.kept_labels = torch.empty(slots, dtype=torch.int32, device=dev)
+            self.rep = torch.empty(slots, dtype=torch.int32, device=dev)
+            self.cand_pair = torch.empty(slots, 2, dtype=torch.int32, device=dev)
+            self.cand_xyr = torch.empty(slots, 3, dtype=torch.float64, device=dev)
             self._cap_slots = slots
 
     def set_windows(self, t0, t1):
@@ -45,9 +50,14 @@ class DetectPipeline:
         self.t1 = torch.as_tensor(np.asarray(t1, dtype=np.float64)).to(self.dev)
         self.S = int(self.t0.numel())
 
-    def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0):
-        """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN on the
-        current torch stream; results stay in HBM (self.xy / seg_off / seg_cnt / labels / n_clusters)."""
+    def set_detect_params(self, cluster_min=5, need_clusters=36, radius_threshold=15.511363636363637):
+        """clusterMinSample, rows*cols and circleRadiusThreshold_ (defaults: example.yaml, 346x260 sensor)."""
+        self.det = (int(cluster_min), int(need_clusters), float(radius_threshold))
+
+    def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True):
+        """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN -> candidate
+        extraction on the current torch stream; results stay in HBM (self.xy / seg_off / seg_cnt /
+        labels / n_clusters / win_info / cand_pair / cand_xyr / kept_labels / rep)."""
         assert events.is_cuda and events.dtype == torch.uint8
         n = events.numel() // RECORD
         S = self.S
@@ -63,6 +73,13 @@ class DetectPipeline:
                            self.flags.data_ptr(), st)
         c.dbscan_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots,
                            max_seg_points, eps, minpts, self.labels.data_ptr(), self.n_clusters.data_ptr(), st)
+        if detect:
+            if not hasattr(self, "det"):
+                self.set_detect_params()
+            c.extract_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(),
+                                self.labels.data_ptr(), self.n_clusters.data_ptr(), S, slots, self.det[0], self.det[1],
+                                self.det[2], self.win_info.data_ptr(), self.cand_pair.data_ptr(),
+                                self.cand_xyr.data_ptr(), self.kept_labels.data_ptr(), self.rep.data_ptr(), st)
         return self
 
     def overflowed(self):

@@ -109,6 +109,38 @@ int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
                           uint32_t cap_points, double *d_xy, uint32_t *d_seg_off /*[2S]*/,
                           uint32_t *d_seg_cnt /*[2S]*/, int32_t *d_event_point, int *d_overflow, void *stream);
 
+/* ---- circle-candidate extraction -----------------------------------------------------------
+ * Replaces CirclesEventFrame::extractFeatures between its DBSCAN::Run calls and cv::findCirclesGrid
+ * (event_camera_calib/src/CirclesEventFrame.cpp:89-312, fitCircle == 0 path :283-311) for all
+ * windows at once.  Inputs are the outputs of ecal_slice_events_dev and ecal_dbscan_batch_dev with
+ * S' = 2S segments (2s = positive, 2s+1 = negative polarity of window s).
+ *
+ * ecal_circle_radius_threshold: circleRadiusThreshold_ (CirclesEventFrame.cpp:16-33); pure host math.
+ * ecal_extract_batch_dev, per window s (all outputs indexed like the points: window s owns the
+ *   slots from d_seg_off[2s] on):
+ *     d_kept_labels[slot of point] = cluster id after erasing clusters with fewer than cluster_min
+ *        (clusterMinSample) members and renumbering (:89-117), or -1  (= pClusters_/nClusters_)
+ *     d_rep[d_seg_off[2s+pol] + k]  = pid of the representative of kept cluster k: the member of
+ *        rank size/2 ordered by (Vector2d::norm(), pid)  (:136-147; the reference's nth_element
+ *        picks the same pixel unless two members tie in norm at that rank)
+ *     candidates j = 0..n-1 in + cluster order (:283-311): d_cand_pair[2*(d_seg_off[2s]+j)..] =
+ *        (+ cluster, - cluster), d_cand_xyr[3*(d_seg_off[2s]+j)..] = centre x, centre y, radius
+ *     d_win_info[4s..] = { n candidates, kept + clusters, kept - clusters, status } with status
+ *        0 = ok, 1 = extractFeatures would return false before pairing (an empty polarity :62-64
+ *        or fewer than need_clusters = rows*cols kept clusters :127-129), 4 = more than 2048 DBSCAN
+ *        clusters in one polarity (not handled; no candidates)
+ *   The ordering of the candidates into the pattern grid (cv::findCirclesGrid, :332-353) is not
+ *   part of this entry point.
+ */
+double ecal_circle_radius_threshold(double width, double height, int rows, int cols, int asymmetric,
+                                    double square_size, double circle_radius);
+int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                           const int32_t *d_labels, const uint32_t *d_n_clusters, uint32_t S /*windows*/,
+                           uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters, double radius_threshold,
+                           uint32_t *d_win_info /*[S][4]*/, uint32_t *d_cand_pair /*[n_points][2]*/,
+                           double *d_cand_xyr /*[n_points][3]*/, int32_t *d_kept_labels /*[n_points]*/,
+                           uint32_t *d_rep /*[n_points]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

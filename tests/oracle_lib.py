@@ -165,16 +165,64 @@ def pack_events(t, x, y, p):
     return rec.reshape(-1)
 
 
-def detect_windows(rec, t0, t1, eps, minpts):
-    """CPU baseline loop (oracle/pipeline_oracle.cpp): returns (events covered, total clusters)."""
+def detect_windows(rec, t0, t1, eps, minpts, cluster_min=5, need_clusters=36, radius_thr=15.511363636363637):
+    """CPU baseline loop (oracle/pipeline_oracle.cpp): returns (events covered, total kept clusters)."""
     L = lib()
     L.oracle_detect_windows.argtypes = [_u8p, ctypes.c_uint64, _dp, _dp, ctypes.c_uint32, ctypes.c_double,
-                                        ctypes.c_uint32, _u64p]
+                                        ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, _u64p]
     L.oracle_detect_windows.restype = ctypes.c_uint64
     rec = np.ascontiguousarray(rec, dtype=np.uint8)
     t0 = np.ascontiguousarray(t0, dtype=np.float64)
     t1 = np.ascontiguousarray(t1, dtype=np.float64)
     ncl = ctypes.c_uint64(0)
     ev = L.oracle_detect_windows(_p(rec, _u8p), rec.size // 25, _p(t0, _dp), _p(t1, _dp), t0.shape[0], float(eps),
-                                 int(minpts), ctypes.byref(ncl))
+                                 int(minpts), int(cluster_min), int(need_clusters), float(radius_thr),
+                                 ctypes.byref(ncl))
     return int(ev), int(ncl.value)
+
+
+# ---- circle-candidate extraction (oracle/detect_oracle.cpp) ----
+def circle_radius_threshold(width, height, rows, cols, asymmetric, square, radius):
+    L = lib()
+    L.oracle_circle_radius_threshold.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    L.oracle_circle_radius_threshold.restype = ctypes.c_double
+    return L.oracle_circle_radius_threshold(width, height, rows, cols, int(asymmetric), square, radius)
+
+
+def extract_candidates(pos, neg, eps, minpts, cluster_min, need_clusters, radius_thr):
+    """extractFeatures up to the candidate list (fitCircle == 0).  Returns a dict."""
+    L = lib()
+    L.oracle_extract_candidates.argtypes = [_dp, ctypes.c_uint32, _dp, ctypes.c_uint32, ctypes.c_double,
+                                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double,
+                                            _u32p, _u32p, _dp, _i32p, _i32p, _u32p, _u32p]
+    L.oracle_extract_candidates.restype = ctypes.c_int
+    pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 2)
+    neg = np.ascontiguousarray(neg, np.float64).reshape(-1, 2)
+    npos, nneg = pos.shape[0], neg.shape[0]
+    info = np.zeros(4, np.uint32)
+    m = max(npos, nneg, 1)
+    pair = np.zeros((m, 2), np.uint32)
+    xyr = np.zeros((m, 3), np.float64)
+    kp = np.full(max(npos, 1), -1, np.int32)
+    kn = np.full(max(nneg, 1), -1, np.int32)
+    rp = np.zeros(max(npos, 1), np.uint32)
+    rn = np.zeros(max(nneg, 1), np.uint32)
+    L.oracle_extract_candidates(_p(pos, _dp), npos, _p(neg, _dp), nneg, float(eps), int(minpts), int(cluster_min),
+                                int(need_clusters), float(radius_thr), _p(info, _u32p), _p(pair, _u32p), _p(xyr, _dp),
+                                _p(kp, _i32p), _p(kn, _i32p), _p(rp, _u32p), _p(rn, _u32p))
+    nc = int(info[0])
+    return dict(n=nc, nk_pos=int(info[1]), nk_neg=int(info[2]), status=int(info[3]) & 1, tie=bool(info[3] & 2),
+                pair=pair[:nc], xyr=xyr[:nc], kept_pos=kp[:npos], kept_neg=kn[:nneg], rep_pos=rp[:int(info[1])],
+                rep_neg=rn[:int(info[2])])
+
+
+def fit_circle(a, b):
+    L = lib()
+    L.oracle_fit_circle.argtypes = [_dp, ctypes.c_uint32, _dp, ctypes.c_uint32, _dp, _dp]
+    a = np.ascontiguousarray(a, np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(b, np.float64).reshape(-1, 2)
+    c = np.zeros(2)
+    r = ctypes.c_double(0)
+    L.oracle_fit_circle(_p(a, _dp), a.shape[0], _p(b, _dp), b.shape[0], _p(c, _dp), ctypes.byref(r))
+    return c, r.value

@@ -1,0 +1,103 @@
+"""GPU parity: candidate extraction (through the C ABI) vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth_stream as SS
+
+pytestmark = pytest.mark.gpu
+THR = 15.511363636363637
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    yield ctx, DetectPipeline(ctx), torch
+    ctx.close()
+
+
+def test_radius_threshold_kat(env):
+    ctx, pipe, torch = env
+    assert ctx.circle_radius_threshold(346, 260, 9, 4, True, 5.5, 1.75) == THR
+    assert ctx.circle_radius_threshold(346, 260, 9, 4, True, 5.5, 1.75) == O.circle_radius_threshold(346.0, 260.0, 9, 4,
+                                                                                                    True, 5.5, 1.75)
+    assert ctx.circle_radius_threshold(640, 480, 5, 7, False, 3.0, 1.0) == O.circle_radius_threshold(640.0, 480.0, 5, 7,
+                                                                                                     False, 3.0, 1.0)
+
+
+def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr):
+    S = len(t0)
+    info = pipe.win_info[:S].cpu().numpy().astype(np.int64)
+    seg_off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
+    seg_cnt = pipe.seg_cnt[:2 * S].cpu().numpy().astype(np.int64)
+    xy = pipe.xy.cpu().numpy()
+    kept = pipe.kept_labels.cpu().numpy()
+    rep = pipe.rep.cpu().numpy()
+    pair = pipe.cand_pair.cpu().numpy()
+    xyr = pipe.cand_xyr.cpu().numpy()
+    exact = tied = 0
+    for s in range(S):
+        op, on = seg_off[2 * s], seg_off[2 * s + 1]
+        pos = xy[op:op + seg_cnt[2 * s]]
+        neg = xy[on:on + seg_cnt[2 * s + 1]]
+        ref = O.extract_candidates(pos, neg, 4.0, 2, cluster_min, need, thr)
+        assert info[s, 3] == ref["status"], "window %d status" % s
+        assert np.array_equal(kept[op:op + len(pos)], ref["kept_pos"]), "window %d kept +" % s
+        assert np.array_equal(kept[on:on + len(neg)], ref["kept_neg"]), "window %d kept -" % s
+        if len(pos) and len(neg):
+            assert info[s, 1] == ref["nk_pos"] and info[s, 2] == ref["nk_neg"]
+        if ref["status"]:
+            assert info[s, 0] == 0
+            continue
+        if ref["tie"]:
+            # some cluster's median is order dependent in the reference: representatives may differ
+            # by a pixel of equal norm; the GPU's choice must still have the oracle's norm
+            tied += 1
+            gp = pos[rep[op:op + ref["nk_pos"]]]
+            rp = pos[ref["rep_pos"]]
+            assert np.array_equal(np.sqrt((gp ** 2).sum(1)), np.sqrt((rp ** 2).sum(1)))
+            continue
+        exact += 1
+        assert np.array_equal(rep[op:op + ref["nk_pos"]], ref["rep_pos"]), "window %d rep +" % s
+        assert np.array_equal(rep[on:on + ref["nk_neg"]], ref["rep_neg"]), "window %d rep -" % s
+        n = ref["n"]
+        assert info[s, 0] == n, "window %d candidate count" % s
+        assert np.array_equal(pair[op:op + n], ref["pair"]), "window %d pairs" % s
+        assert np.array_equal(xyr[op:op + n], ref["xyr"]), "window %d circles" % s   # same arithmetic: bitwise
+    return exact, tied
+
+
+@pytest.mark.parametrize("rate", [1.0e6, 2.0e6, 4.0e6])
+def test_synthetic_stream(env, rate):
+    ctx, pipe, torch = env
+    buf = SS.make_stream(90000, rate=rate, device="cpu", seed=31)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR)
+    pipe.run(buf.cuda())
+    torch.cuda.synchronize()
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)
+    assert exact + tied > 0 or rate < 2.0e6      # sparse 1 Mev/s windows may all fail the 36-cluster test
+    if rate >= 2.0e6:
+        assert exact >= 3
+
+
+def test_small_need_and_cluster_min(env):
+    """Looser parameters so every window reaches the pairing stage; also windows with an empty polarity."""
+    ctx, pipe, torch = env
+    buf = SS.make_stream(40000, rate=1.0e6, device="cpu", seed=5)
+    t, xy, p = SS.unpack_records(buf)
+    ts, te = float(t[0]), float(t[-1])
+    t0, t1 = SS.tiled_windows(ts, te)
+    t0 = list(t0) + [ts - 1.0]
+    t1 = list(t1) + [ts - 0.5]
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(3, 10, 40.0)
+    pipe.run(buf.cuda())
+    torch.cuda.synchronize()
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 3, 10, 40.0)
+    assert exact >= 5
