@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = [
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
+    "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_detect_batch",
 ]
 
 

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
     uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
-    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize) {
+    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
+    double *__restrict__ norms) {
     __shared__ uint32_t csize[DET_MAXC];  // members per DBSCAN cluster; later a scatter cursor
     __shared__ uint32_t newid[DET_MAXC];  // renumbered id of a kept cluster
     __shared__ uint32_t coff[DET_MAXC];   // first member slot of a kept cluster
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
                 kl = (int32_t) newid[l];
                 const uint32_t at = atomicSub(&csize[l], 1u) - 1u;
                 members[o + coff[l] + at] = i;
+                norms[o + i] = norm_of(pts[o + i]);
             }
             kept_labels[o + i] = kl;
         }
@@ -127,23 +129,27 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         }
         return;
     }
-    // representative of every kept cluster (:136-147): rank size/2 in the order (norm, pid).
-    // members, kept_labels, koff, ksize were written by this workgroup: visible after the barrier.
+    // One scan of its cluster per kept point gives (a) its rank in the order (norm, pid): rank
+    // size/2 is the representative (:136-147), and (b) its position in ascending-pid order, which
+    // turns the scattered member list into a sorted one.
+    // members, kept_labels, koff, ksize, norms were written by this workgroup: visible after the barrier.
     for (int pol = 0; pol < 2; pol++) {
         const uint32_t o = o_pol[pol], n = n_pol[pol];
         for (uint32_t i = tid; i < n; i += DET_T) {
             const int32_t kl = kept_labels[o + i];
             if (kl < 0) continue;
-            const uint32_t m = ksize[o + kl];
-            const uint32_t *mem = members + o + koff[o + kl];
-            const double ni = norm_of(pts[o + i]);
-            uint32_t rank = 0;
+            const uint32_t m = ksize[o + kl], first = o + koff[o + kl];
+            const uint32_t *mem = members + first;
+            const double ni = norms[o + i];
+            uint32_t rank = 0, at = 0;
             for (uint32_t t = 0; t < m; t++) {
                 const uint32_t j = mem[t];
-                const double nj = norm_of(pts[o + j]);
+                const double nj = norms[o + j];
                 rank += (nj < ni || (nj == ni && j < i)) ? 1u : 0u;
+                at += (j < i) ? 1u : 0u;
             }
             if (rank == m / 2) rep[o + kl] = i;
+            sorted[first + at] = i;
         }
     }
     __syncthreads();
@@ -189,21 +195,11 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
                     for (int pol = 0; pol < 2; pol++) {
                         const uint32_t o = o_pol[pol], kk = pol ? ni_best : pi;
                         const uint32_t m = ksize[o + kk];
-                        const uint32_t *mem = members + o + koff[o + kk];
-                        // ascending pid without sorting: m is small, pick the next larger pid each time
-                        uint32_t prev = 0;
-                        bool first = true;
+                        const uint32_t *mem = sorted + o + koff[o + kk];  // ascending pid
                         for (uint32_t t = 0; t < m; t++) {
-                            uint32_t nxt = 0xFFFFFFFFu;
-                            for (uint32_t u = 0; u < m; u++) {
-                                const uint32_t j = mem[u];
-                                if ((first || j > prev) && j < nxt) nxt = j;
-                            }
-                            const double2 e = pts[o + nxt];
+                            const double2 e = pts[o + mem[t]];
                             const double ex = e.x - cx, ey = e.y - cy;
                             fit += fabs(__dsqrt_rn(ex * ex + ey * ey) - r);
-                            prev = nxt;
-                            first = false;
                         }
                         cnt += m;
                     }
@@ -274,6 +270,8 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
     if ((rc = ecal_ensure(ctx, ctx->det_members, np * sizeof(uint32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->det_koff, np * sizeof(uint32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->det_ksize, np * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->det_sorted, np * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->det_norms, np * sizeof(double)))) return rc;
     DetectParams prm;
     prm.cluster_min = cluster_min;
     prm.need_clusters = need_clusters;
@@ -281,7 +279,8 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
     hipLaunchKernelGGL(extract_kernel, dim3(S), dim3(DET_T), 0, (hipStream_t) stream, d_xy, d_seg_off, d_seg_cnt,
                        d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
                        (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
-                       (uint32_t *) ctx->det_ksize.ptr);
+                       (uint32_t *) ctx->det_ksize.ptr, (uint32_t *) ctx->det_sorted.ptr,
+                       (double *) ctx->det_norms.ptr);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

@@ -141,6 +141,45 @@ int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_
                            double *d_cand_xyr /*[n_points][3]*/, int32_t *d_kept_labels /*[n_points]*/,
                            uint32_t *d_rep /*[n_points]*/, void *stream);
 
+/* ---- host-buffer conveniences (what the C++ shims in eventcalib_amd/csrc/host/ call) ----------
+ * ecal_stream: the event stream uploaded once and kept in HBM — the counterpart of the reference's
+ *   EventContainer (event/include/opengv2/event/EventContainer.hpp:25-30), filled once by the driver
+ *   (event_camera_calib/test/eventCameraCalib.cpp:154-163) and shared read-only by all workers.
+ *   `events` = packed 25-byte records in time order (ECAL_ERR_UNSORTED otherwise).
+ * ecal_detect_batch: for every window [t0[s], t1[s]] the EventFrame constructor followed by
+ *   extractFeatures up to the candidate circles (the four device entry points above, in order) and
+ *   copies the requested results to host memory.  Every pointer of ecal_detect_result may be NULL
+ *   (not copied); the layouts are those documented at the device entry points; cap_points must be
+ *   >= the total number of events covered by the windows (ECAL_ERR_RANGE otherwise).
+ */
+typedef struct ecal_stream ecal_stream;
+typedef struct ecal_detect_params {
+    double dbscan_eps;               /* example.yaml: dbscan_eps */
+    uint32_t dbscan_min_samples;     /* dbscan_startMinSample */
+    uint32_t cluster_min_sample;     /* clusterMinSample */
+    uint32_t need_clusters;          /* BoardSize_Rows * BoardSize_Cols */
+    double circle_radius_threshold;  /* ecal_circle_radius_threshold(...) */
+} ecal_detect_params;
+typedef struct ecal_detect_result {
+    uint32_t *win_lo, *win_hi; /* [S] */
+    uint32_t *win_base;        /* [S+1] */
+    double *xy;                /* [cap_points][2] */
+    uint32_t *seg_off, *seg_cnt; /* [2S] */
+    int32_t *event_point;      /* [cap_points] */
+    int32_t *labels;           /* [cap_points] */
+    uint32_t *n_clusters;      /* [2S] */
+    int32_t *kept_labels;      /* [cap_points] */
+    uint32_t *rep;             /* [cap_points] */
+    uint32_t *win_info;        /* [S][4] */
+    uint32_t *cand_pair;       /* [cap_points][2] */
+    double *cand_xyr;          /* [cap_points][3] */
+} ecal_detect_result;
+int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t n_events, ecal_stream **out);
+void ecal_stream_destroy(ecal_stream *s);
+uint64_t ecal_stream_size(const ecal_stream *s);
+int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const double *t0, const double *t1, uint32_t S,
+                      const ecal_detect_params *prm, uint32_t cap_points, ecal_detect_result *res);
+
 #ifdef __cplusplus
 }
 #endif

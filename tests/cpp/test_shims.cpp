@@ -1,0 +1,88 @@
+// Exercises the C++ shims the way the reference's callers use the original classes
+// (CirclesEventFrame.cpp:66-72 for DBSCAN; eventCameraCalib.cpp:138-163,49-56 for the stream,
+// container and frames).  Built and run by tests/test_gpu_shims.py on the GPU box.
+//   usage: test_shims events.bin
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../eventcalib_amd/csrc/host/circles_event_frame.hpp"
+
+#define CHECK(c)                                                        \
+    do {                                                                \
+        if (!(c)) {                                                     \
+            std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            return 1;                                                   \
+        }                                                               \
+    } while (0)
+
+int main(int argc, char **argv) {
+    using namespace opengv2;
+    // --- DBSCAN: the survey's 3-point demo (order dependent pruning quirk) ---
+    {
+        std::vector<Vector2d> v = {{{4, 5}}, {{4, 0}}, {{0, 0}}};
+        DBSCAN<Vector2d, double> db;
+        CHECK(db.Run(&v, 2, 4.0, 1) == 0);
+        CHECK(db.Clusters.size() == 1 && db.Clusters[0].size() == 1 && db.Clusters[0][0] == 1);
+        CHECK(db.Noise.size() == 2 && db.Noise[0] == 0 && db.Noise[1] == 2);
+        std::vector<Vector2d> w = {{{4, 0}}, {{0, 0}}, {{4, 5}}};
+        CHECK(db.Run(&w, 2, 4.0, 1) == 0);
+        CHECK(db.Clusters.size() == 1 && db.Clusters[0].size() == 2 && db.Noise.size() == 1 && db.Noise[0] == 2);
+        std::vector<Vector2d> empty;
+        CHECK(db.Run(&empty, 2, 4.0, 1) == 1);   // FAILED, dbscan.h:121
+        CHECK(db.Run(&v, 2, 4.0, 0) == 1);       // FAILED, dbscan.h:123
+        CHECK(db.Run(&v, 0, 4.0, 1) == 1);       // FAILED, dbscan.h:122
+    }
+    if (argc < 2) {
+        std::printf("shims ok (dbscan only)\n");
+        return 0;
+    }
+    // --- stream -> container -> frames, as the reference driver does ---
+    EventStream es(argv[1]);
+    auto container = std::make_shared<EventContainer>();
+    while (!es.isEnd()) {
+        container->emplace(es.current());
+        es.next();
+    }
+    es.close();
+    CHECK(container->size() > 1000);
+    bool threw = false;
+    try {
+        EventStream missing("/nonexistent/file.bin");
+    } catch (const std::invalid_argument &) {
+        threw = true;
+    }
+    CHECK(threw);
+    const double t0 = container->firstTime();
+    auto pattern = std::make_shared<CirclePatternParameters>();
+    CirclesEventFrame frame(container, {t0, t0 + 1.5e-3}, pattern);
+    CHECK(frame.circleRadiusThreshold() == 15.511363636363637);
+    const bool ok = frame.extractFeatures();
+    const FrameDetection &d = frame.detection();
+    CHECK(frame.eventsNum() == (int) (d.positive.size() + d.negative.size()));
+    CHECK(d.positive.size() > 100 && d.negative.size() > 100);
+    // the DBSCAN shim on the frame's pixel sets must reproduce the pipeline's labels
+    DBSCAN<Vector2d, double> db;
+    std::vector<Vector2d> pos = d.positive;
+    CHECK(db.Run(&pos, 2, 4.0, 2) == 0);
+    CHECK(db.Clusters.size() == d.nClustersPos);
+    for (size_t c = 0; c < db.Clusters.size(); c++)
+        for (uint pid : db.Clusters[c]) CHECK(d.labelsPos[pid] == (int32_t) c);
+    for (uint pid : db.Noise) CHECK(d.labelsPos[pid] == -1);
+    std::printf("shims ok: %zu events, window: %zu + / %zu - pixels, %u/%u clusters, %zu candidates, extract=%d\n",
+                container->size(), d.positive.size(), d.negative.size(), d.nClustersPos, d.nClustersNeg,
+                d.candidates.size(), (int) ok);
+    // batch of overlapping windows through detect_windows
+    std::vector<std::pair<double, double>> wins;
+    for (int k = 0; k < 6; k++) wins.push_back({t0 + k * 5e-4, t0 + k * 5e-4 + 1.5e-3});
+    std::vector<FrameDetection> out;
+    ecal_detect_params prm;
+    prm.dbscan_eps = 4;
+    prm.dbscan_min_samples = 2;
+    prm.cluster_min_sample = 5;
+    prm.need_clusters = 36;
+    prm.circle_radius_threshold = frame.circleRadiusThreshold();
+    detect_windows(*container, wins, prm, out);
+    CHECK(out.size() == 6 && out[0].positive.size() == d.positive.size());
+    return 0;
+}
