@@ -15,6 +15,9 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_detect_batch",
+    "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
+    "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
+    "ecal_solver_solve", "ecal_inverse_radial_distortion",
 ]
 
 
@@ -158,3 +161,162 @@ class Context:
                                                    int(S), int(n_points), int(cluster_min), int(need_clusters),
                                                    float(radius_threshold), d_win_info, d_cand_pair, d_cand_xyr,
                                                    d_kept_labels, d_rep, stream))
+
+
+# ---- continuous-time calibration solve ----
+class _SplineProblem(ctypes.Structure):
+    _fields_ = [("n_segments", ctypes.c_uint32), ("seg_cp_off", ctypes.c_void_p), ("knots", ctypes.c_void_p),
+                ("n_res", ctypes.c_uint64), ("obs", ctypes.c_void_p), ("time", ctypes.c_void_p),
+                ("lm_id", ctypes.c_void_p), ("seg_id", ctypes.c_void_p), ("n_landmarks", ctypes.c_uint32),
+                ("landmarks", ctypes.c_void_p), ("circle_radius", ctypes.c_double), ("huber_a", ctypes.c_double)]
+
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+
+class LmOptions(ctypes.Structure):
+    _fields_ = [("max_num_iterations", ctypes.c_int), ("function_tolerance", ctypes.c_double),
+                ("gradient_tolerance", ctypes.c_double), ("parameter_tolerance", ctypes.c_double),
+                ("initial_trust_region_radius", ctypes.c_double), ("max_trust_region_radius", ctypes.c_double),
+                ("min_relative_decrease", ctypes.c_double), ("min_lm_diagonal", ctypes.c_double),
+                ("max_lm_diagonal", ctypes.c_double), ("jacobi_scaling", ctypes.c_int),
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p)]
+
+
+class LmSummary(ctypes.Structure):
+    _fields_ = [("iterations", ctypes.c_int), ("successful_steps", ctypes.c_int), ("unsuccessful_steps", ctypes.c_int),
+                ("jacobian_evaluations", ctypes.c_int), ("cost_evaluations", ctypes.c_int),
+                ("termination", ctypes.c_int), ("initial_cost", ctypes.c_double), ("final_cost", ctypes.c_double),
+                ("seconds", ctypes.c_double)]
+
+
+def _declare_solver(L):
+    vp, i32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    L.ecal_solver_create.argtypes = [vp, ctypes.POINTER(_SplineProblem), ctypes.POINTER(vp)]
+    L.ecal_solver_create.restype = i32
+    L.ecal_solver_destroy.argtypes = [vp]
+    L.ecal_solver_destroy.restype = None
+    for f in (L.ecal_solver_param_size, L.ecal_solver_normal_size):
+        f.argtypes = [vp]
+        f.restype = ctypes.c_size_t
+    L.ecal_solver_num_chunks.argtypes = [vp]
+    L.ecal_solver_num_chunks.restype = ctypes.c_uint32
+    L.ecal_solver_evaluate_dev.argtypes = [vp, vp, i32, vp, vp]
+    L.ecal_solver_evaluate_dev.restype = i32
+    L.ecal_solver_evaluate.argtypes = [vp, vp, i32, vp]
+    L.ecal_solver_evaluate.restype = i32
+    L.ecal_lm_default_options.argtypes = [ctypes.POINTER(LmOptions)]
+    L.ecal_lm_default_options.restype = None
+    L.ecal_solver_solve.argtypes = [vp, vp, ctypes.POINTER(LmOptions), ctypes.POINTER(LmSummary)]
+    L.ecal_solver_solve.restype = i32
+    L.ecal_inverse_radial_distortion.argtypes = [vp, vp]
+    L.ecal_inverse_radial_distortion.restype = None
+
+
+def inverse_radial_distortion(k4):
+    L = load_library()
+    _declare_solver(L)
+    k = np.ascontiguousarray(k4, np.float64)
+    b = np.zeros(5)
+    L.ecal_inverse_radial_distortion(_ptr(k), _ptr(b))
+    return b
+
+
+class Solver:
+    """ecal_solver: residual records + spline layout resident on the GPU.
+
+    problem: dict with seg_cp_off [G+1] u32, knots f64, obs [M,2], time [M], lm_id [M] u32,
+    seg_id [M] u32 or None, landmarks [L,3], circle_radius, huber_a.
+    Parameter vector layout: [intr 9 | q n_cp x 4 (xyzw) | t n_cp x 3]."""
+
+    def __init__(self, ctx: Context, problem):
+        self.ctx = ctx
+        L = ctx._L
+        _declare_solver(L)
+        keep = {}
+
+        def arr(name, dt):
+            a = np.ascontiguousarray(problem[name], dtype=dt)
+            keep[name] = a
+            return ctypes.c_void_p(a.ctypes.data)
+
+        P = _SplineProblem()
+        P.seg_cp_off = arr("seg_cp_off", np.uint32)
+        P.n_segments = keep["seg_cp_off"].shape[0] - 1
+        P.knots = arr("knots", np.float64)
+        P.obs = arr("obs", np.float64)
+        P.time = arr("time", np.float64)
+        P.lm_id = arr("lm_id", np.uint32)
+        P.n_res = keep["time"].shape[0]
+        P.seg_id = arr("seg_id", np.uint32) if problem.get("seg_id") is not None else None
+        P.landmarks = arr("landmarks", np.float64)
+        P.n_landmarks = keep["landmarks"].reshape(-1, 3).shape[0]
+        P.circle_radius = float(problem["circle_radius"])
+        P.huber_a = float(problem["huber_a"])
+        h = ctypes.c_void_p()
+        ctx._check(L.ecal_solver_create(ctx._h, ctypes.byref(P), ctypes.byref(h)))
+        self._h = h
+        self.n_params = int(L.ecal_solver_param_size(h))
+        self.n_normal = int(L.ecal_solver_normal_size(h))
+        self.n_cp = (self.n_params - 9) // 7
+        self.n_chunks = int(L.ecal_solver_num_chunks(h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._L.ecal_solver_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def evaluate(self, params, with_jacobian=True):
+        p = np.ascontiguousarray(params, np.float64)
+        assert p.shape[0] == self.n_params
+        acc = np.zeros(self.n_normal if with_jacobian else 1)
+        self.ctx._check(self.ctx._L.ecal_solver_evaluate(self._h, _ptr(p), int(with_jacobian), _ptr(acc)))
+        return acc
+
+    def evaluate_dev(self, d_params, with_jacobian, d_accum, stream=0):
+        self.ctx._check(self.ctx._L.ecal_solver_evaluate_dev(self._h, d_params, int(with_jacobian), d_accum, stream))
+
+    def default_options(self):
+        o = LmOptions()
+        self.ctx._L.ecal_lm_default_options(ctypes.byref(o))
+        return o
+
+    def solve(self, params, options=None):
+        p = np.array(params, dtype=np.float64, copy=True)
+        s = LmSummary()
+        o = options if options is not None else self.default_options()
+        self.ctx._check(self.ctx._L.ecal_solver_solve(self._h, _ptr(p), ctypes.byref(o), ctypes.byref(s)))
+        return p, s
+
+
+def unpack_normal(acc, n_cp):
+    """Normal-equation buffer -> (cost, g [9+6 n_cp], H dense symmetric) in the order [intr | cp0 (rot3, trans3) | ...]."""
+    n = 9 + 6 * n_cp
+    g = np.zeros(n)
+    H = np.zeros((n, n))
+    g[:9] = acc[1:10]
+    Hi = acc[10:91].reshape(9, 9)
+    H[:9, :9] = np.triu(Hi) + np.triu(Hi, 1).T
+    for c in range(n_cp):
+        b = acc[91 + 204 * c: 91 + 204 * (c + 1)]
+        r0 = 9 + 6 * c
+        g[r0:r0 + 6] = b[:6]
+        H[r0:r0 + 6, :9] = b[6:60].reshape(6, 9)
+        H[:9, r0:r0 + 6] = H[r0:r0 + 6, :9].T
+        for d in range(4):
+            if c + d >= n_cp:
+                break
+            blk = b[60 + 36 * d: 96 + 36 * d].reshape(6, 6)
+            c1 = 9 + 6 * (c + d)
+            if d == 0:
+                H[r0:r0 + 6, r0:r0 + 6] = np.triu(blk) + np.triu(blk, 1).T
+            else:
+                H[r0:r0 + 6, c1:c1 + 6] = blk
+                H[c1:c1 + 6, r0:r0 + 6] = blk.T
+    return acc[0], g, H

@@ -1,0 +1,661 @@
+// Continuous-time calibration solve: per-event residual / Jacobian and the stacked normal equations
+// on the GPU, Levenberg-Marquardt and the block-banded arrow Cholesky on the host.
+//
+// Replaces, for the quaternion-spline variant (useSO3 = 0, the shipped default):
+//   EventCalibSpline::optimize's Ceres problem (event_camera_calib/src/EventCalibSpline.cpp:196-247):
+//     one residual block [9,4,4,4,4,3,3,3,3] per associated event, HuberLoss(0.2 R),
+//     EigenQuaternionParameterization, SPARSE_NORMAL_CHOLESKY, tolerances 1e-10, 50 iterations;
+//   CalibReprojectionError::operator() (EventCalibSpline.hpp:158-229) — see spline_residual.hpp.
+// Residuals are sorted by (segment, time); a "chunk" is a run of residuals inside one knot span, so all
+// its rows share the same 33 columns and J^T J of the chunk is one dense 34x34 (33 + residual) Gram
+// matrix.  It is accumulated with register-tiled FP64 FMAs (4x4 tiles): on gfx950 the FP64 MFMA peak
+// equals the FP64 vector peak and the 16x16x4 shape would pad 34 to 48 (2x the flops), so matrix
+// cores buy nothing here.
+#include "ecal_ctx.hpp"
+#include "spline_residual.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <vector>
+
+namespace ecal {
+
+struct ResRecord {  // 32 bytes per residual: the algorithmic traffic unit of SURVEY §8(d)
+    double u, v, t;
+    uint32_t lm, seg;
+};
+struct Chunk {
+    uint32_t start, count, seg, span;
+};
+
+constexpr int NE_T = 256;   // threads per workgroup = rows per batch
+constexpr int NE_LD = 36;   // padded row: 33 Jacobian entries, the residual, 2 zeros
+constexpr int NE_TILES = 45;  // 4x4 tiles of the upper triangle of a 9x9 tile grid
+constexpr int NE_GROUPS = 5;  // row groups (5 * 45 = 225 accumulating threads)
+constexpr uint32_t NE_CHUNK = 4096;
+
+// accumulation buffer: [0] cost | [1..9] g_intr | [10..90] H_intr (9x9, upper) | per control point c at
+// 91 + 204 c: g_c[6] | H_c,intr[6][9] | H_c,c+d[4][6][6] (d = 0..3; d = 0 upper only)
+constexpr size_t ACC_HEAD = 91, ACC_PER_CP = 204;
+
+__device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_intr, uint32_t &cp, uint32_t &comp) {
+    if (li < 9) {
+        is_intr = true;
+        cp = 0;
+        comp = (uint32_t) li;
+    } else if (li < 21) {
+        is_intr = false;
+        cp = c0 + (uint32_t) (li - 9) / 3u;
+        comp = (uint32_t) (li - 9) % 3u;
+    } else {
+        is_intr = false;
+        cp = c0 + (uint32_t) (li - 21) / 3u;
+        comp = 3u + (uint32_t) (li - 21) % 3u;
+    }
+}
+
+__global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__restrict__ rec,
+                                                         const Chunk *__restrict__ chunks,
+                                                         const double *__restrict__ knots,
+                                                         const uint32_t *__restrict__ knot_off,
+                                                         const uint32_t *__restrict__ cp_off,
+                                                         const double *__restrict__ params, uint32_t n_cp_total,
+                                                         const double *__restrict__ landmarks, double radius,
+                                                         double huber_a, int with_jac, double *__restrict__ accum) {
+    extern __shared__ __attribute__((aligned(16))) double rows[];  // [NE_T][NE_LD] when with_jac
+    __shared__ double red[NE_T / 64];
+    const Chunk ch = chunks[blockIdx.x];
+    const int tid = threadIdx.x;
+    const double *kn = knots + knot_off[ch.seg];
+    const uint32_t c0 = cp_off[ch.seg] + ch.span - 3;
+    const double *intr = params;
+    const double *qall = params + 9;
+    const double *tall = params + 9 + 4 * (size_t) n_cp_total;
+    double q[4][4], t[4][3], pin[9];
+    for (int i = 0; i < 9; i++) pin[i] = intr[i];
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 4; k++) q[j][k] = qall[4 * (size_t) (c0 + j) + k];
+        for (int k = 0; k < 3; k++) t[j][k] = tall[3 * (size_t) (c0 + j) + k];
+    }
+    // tile owned by this thread in the accumulation phase
+    int ti = 0, tj = 0;
+    {
+        int rem = tid % NE_TILES;
+        for (ti = 0; ti < 9; ti++) {
+            if (rem < 9 - ti) break;
+            rem -= 9 - ti;
+        }
+        tj = ti + rem;
+    }
+    const int grp = tid / NE_TILES;
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0;
+    double cost = 0.0;
+
+    for (uint32_t b0 = 0; b0 < ch.count; b0 += NE_T) {
+        const uint32_t k = b0 + tid;
+        double J[RES_NJ];
+        double r = 0.0, sc = 0.0;
+        if (k < ch.count) {
+            const ResRecord e = rec[ch.start + k];
+            ResidualInput in;
+            in.u = e.u;
+            in.v = e.v;
+            in.lmx = landmarks[3 * (size_t) e.lm];
+            in.lmy = landmarks[3 * (size_t) e.lm + 1];
+            in.lmz = landmarks[3 * (size_t) e.lm + 2];
+            in.radius = radius;
+            spline_basis(kn, ch.span, e.t, in.b);
+            r = spline_residual(in, pin, q, t, with_jac ? J : nullptr);
+            double hr;
+            sc = huber_scale(r, huber_a, &hr);
+            cost += hr;
+        }
+        if (with_jac) {
+            double *row = rows + (size_t) tid * NE_LD;
+            if (k < ch.count) {
+#pragma unroll
+                for (int i = 0; i < RES_NJ; i++) row[i] = J[i] * sc;
+                row[33] = r * sc;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 34; i++) row[i] = 0.0;
+            }
+            row[34] = 0.0;
+            row[35] = 0.0;
+            __syncthreads();
+            if (grp < NE_GROUPS) {
+                const uint32_t nrow = min((uint32_t) NE_T, ch.count - b0);
+                for (uint32_t rk = grp; rk < nrow; rk += NE_GROUPS) {
+                    const double *rw = rows + (size_t) rk * NE_LD;
+                    const double2 a01 = *reinterpret_cast<const double2 *>(rw + 4 * ti);
+                    const double2 a23 = *reinterpret_cast<const double2 *>(rw + 4 * ti + 2);
+                    const double2 b01 = *reinterpret_cast<const double2 *>(rw + 4 * tj);
+                    const double2 b23 = *reinterpret_cast<const double2 *>(rw + 4 * tj + 2);
+                    const double a[4] = {a01.x, a01.y, a23.x, a23.y}, bb[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+#pragma unroll
+                        for (int y = 0; y < 4; y++) acc[4 * x + y] += a[x] * bb[y];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // cost: block reduction, one atomic per workgroup
+    for (int o = 32; o > 0; o >>= 1) cost += __shfl_down(cost, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = cost;
+    __syncthreads();
+    if (tid == 0) {
+        double c = 0;
+        for (int w = 0; w < NE_T / 64; w++) c += red[w];
+        atomicAdd(&accum[0], c);
+    }
+    if (!with_jac || grp >= NE_GROUPS) return;
+    // flush this thread's tile into the global block storage
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const int li = 4 * ti + x, lj = 4 * tj + y;
+            if (li > lj || lj >= 34 || li >= 33) continue;
+            const double v = acc[4 * x + y];
+            if (v == 0.0) continue;
+            bool ia, ib;
+            uint32_t ca, ka, cb, kb;
+            local_to_unknown(li, c0, ia, ca, ka);
+            if (lj == 33) {  // gradient J^T r
+                if (ia) atomicAdd(&accum[1 + ka], v);
+                else atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) ca + ka], v);
+                continue;
+            }
+            local_to_unknown(lj, c0, ib, cb, kb);
+            if (ia && ib) {
+                atomicAdd(&accum[10 + 9 * ka + kb], v);
+            } else if (ia) {  // intrinsics x control point
+                atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) cb + 6 + 9 * kb + ka], v);
+            } else {
+                if (ca > cb || (ca == cb && ka > kb)) {  // keep blocks (c, c+d), d >= 0; diagonal upper
+                    const uint32_t tc = ca, tk = ka;
+                    ca = cb;
+                    ka = kb;
+                    cb = tc;
+                    kb = tk;
+                }
+                atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) ca + 60 + 36 * (cb - ca) + 6 * ka + kb], v);
+            }
+        }
+    }
+}
+
+}  // namespace ecal
+
+using namespace ecal;
+
+struct ecal_solver {
+    ecal_ctx *ctx = nullptr;
+    uint64_t n_res = 0;
+    uint32_t n_cp = 0, n_seg = 0, n_chunks = 0;
+    double radius = 0, huber_a = 0;
+    std::vector<uint32_t> cp_off, knot_off;
+    std::vector<double> knots;
+    ResRecord *d_rec = nullptr;
+    Chunk *d_chunks = nullptr;
+    double *d_knots = nullptr, *d_landmarks = nullptr, *d_params = nullptr, *d_accum = nullptr;
+    uint32_t *d_knot_off = nullptr, *d_cp_off = nullptr;
+    size_t n_params() const { return 9 + 7 * (size_t) n_cp; }
+    size_t n_accum() const { return ACC_HEAD + ACC_PER_CP * (size_t) n_cp; }
+};
+
+extern "C" void ecal_solver_destroy(ecal_solver *s) {
+    if (!s) return;
+    (void) hipSetDevice(s->ctx->device);
+    void *ptrs[] = {s->d_rec, s->d_chunks, s->d_knots, s->d_landmarks, s->d_params, s->d_accum, s->d_knot_off, s->d_cp_off};
+    for (void *p : ptrs)
+        if (p) (void) hipFree(p);
+    delete s;
+}
+
+extern "C" size_t ecal_solver_normal_size(const ecal_solver *s) { return s ? s->n_accum() : 0; }
+extern "C" size_t ecal_solver_param_size(const ecal_solver *s) { return s ? s->n_params() : 0; }
+extern "C" uint32_t ecal_solver_num_chunks(const ecal_solver *s) { return s ? s->n_chunks : 0; }
+
+extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, ecal_solver **out) {
+    if (!ctx || !p || !out) return ECAL_ERR_INVALID;
+    *out = nullptr;
+    if (p->n_segments < 1 || !p->seg_cp_off || !p->knots || !p->landmarks || (p->n_res && (!p->obs || !p->time || !p->lm_id))) {
+        ctx->last_error = "null pointer / no segment";
+        return ECAL_ERR_INVALID;
+    }
+    if (p->n_res > 0xFFFFFFFFull) return ECAL_ERR_RANGE;
+    ecal_solver *s = new (std::nothrow) ecal_solver;
+    if (!s) return ECAL_ERR_NOMEM;
+    s->ctx = ctx;
+    s->n_res = p->n_res;
+    s->n_seg = p->n_segments;
+    s->radius = p->circle_radius;
+    s->huber_a = p->huber_a;
+    s->cp_off.assign(p->seg_cp_off, p->seg_cp_off + p->n_segments + 1);
+    s->n_cp = s->cp_off[p->n_segments];
+    s->knot_off.resize(p->n_segments + 1);
+    for (uint32_t g = 0; g <= p->n_segments; g++) s->knot_off[g] = s->cp_off[g] + 4 * g;
+    s->knots.assign(p->knots, p->knots + s->knot_off[p->n_segments]);
+    for (uint32_t g = 0; g < p->n_segments; g++) {
+        if (s->cp_off[g + 1] - s->cp_off[g] < 4) {
+            ctx->last_error = "a spline segment needs at least degree + 1 = 4 control points";
+            delete s;
+            return ECAL_ERR_INVALID;
+        }
+    }
+    // chunk table: residuals are sorted by (segment, time); cut at knot-span boundaries
+    std::vector<ResRecord> recs(p->n_res);
+    std::vector<Chunk> chunks;
+    uint64_t i = 0;
+    for (uint32_t g = 0; g < p->n_segments; g++) {
+        const double *kn = s->knots.data() + s->knot_off[g];
+        const uint32_t ncp = s->cp_off[g + 1] - s->cp_off[g];
+        uint64_t e = i;
+        while (e < p->n_res && (p->seg_id ? p->seg_id[e] : 0u) == g) e++;
+        for (uint64_t k = i; k < e; k++) {
+            if ((k > i && p->time[k] < p->time[k - 1]) || p->time[k] < kn[3] || p->time[k] > kn[ncp]) {
+                ctx->last_error = "residual times must be sorted inside a segment and lie inside its knot range";
+                delete s;
+                return ECAL_ERR_INVALID;
+            }
+            if (p->lm_id[k] >= p->n_landmarks) {
+                ctx->last_error = "landmark id out of range";
+                delete s;
+                return ECAL_ERR_INVALID;
+            }
+        }
+        uint64_t a = i;
+        for (uint32_t span = 3; span < ncp && a < e; span++) {
+            uint64_t b;
+            if (span == ncp - 1) {
+                b = e;
+            } else {
+                b = std::lower_bound(p->time + a, p->time + e, kn[span + 1]) - p->time;  // [u_span, u_span+1)
+            }
+            for (uint64_t c = a; c < b; c += NE_CHUNK)
+                chunks.push_back(Chunk{(uint32_t) c, (uint32_t) std::min<uint64_t>(NE_CHUNK, b - c), g, span});
+            a = b;
+        }
+        i = e;
+    }
+    if (i != p->n_res) {
+        ctx->last_error = "seg_id must be non-decreasing and < n_segments";
+        delete s;
+        return ECAL_ERR_INVALID;
+    }
+    for (uint64_t k = 0; k < p->n_res; k++) {
+        recs[k].u = p->obs[2 * k];
+        recs[k].v = p->obs[2 * k + 1];
+        recs[k].t = p->time[k];
+        recs[k].lm = p->lm_id[k];
+        recs[k].seg = p->seg_id ? p->seg_id[k] : 0u;
+    }
+    s->n_chunks = (uint32_t) chunks.size();
+    hipError_t e = hipSetDevice(ctx->device);
+    auto up = [&](void **dst, const void *src, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(dst, bytes ? bytes : 16);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    up((void **) &s->d_rec, recs.data(), recs.size() * sizeof(ResRecord));
+    up((void **) &s->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk));
+    up((void **) &s->d_knots, s->knots.data(), s->knots.size() * sizeof(double));
+    up((void **) &s->d_landmarks, p->landmarks, 3 * (size_t) p->n_landmarks * sizeof(double));
+    up((void **) &s->d_knot_off, s->knot_off.data(), s->knot_off.size() * sizeof(uint32_t));
+    up((void **) &s->d_cp_off, s->cp_off.data(), s->cp_off.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_params, s->n_params() * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_accum, s->n_accum() * sizeof(double));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("ecal_solver_create: ") + hipGetErrorString(e);
+        ecal_solver_destroy(s);
+        return e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
+    }
+    *out = s;
+    return ECAL_OK;
+}
+
+extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum,
+                                        void *stream) {
+    if (!s || !d_params || !d_accum) return ECAL_ERR_INVALID;
+    ecal_ctx *ctx = s->ctx;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t) stream;
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, (with_jacobian ? s->n_accum() : 1) * sizeof(double), st));
+    if (s->n_chunks) {
+        const size_t lds = with_jacobian ? NE_T * NE_LD * sizeof(double) : 0;
+        hipLaunchKernelGGL(normal_eq_kernel, dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks, s->d_knots,
+                           s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a,
+                           with_jacobian, d_accum);
+        ECAL_HIP_TRY(ctx, hipGetLastError());
+    }
+    return ECAL_OK;
+}
+
+extern "C" int ecal_solver_evaluate(ecal_solver *s, const double *params, int with_jacobian, double *accum) {
+    if (!s || !params || !accum) return ECAL_ERR_INVALID;
+    ecal_ctx *ctx = s->ctx;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(s->d_params, params, s->n_params() * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = ecal_solver_evaluate_dev(s, s->d_params, with_jacobian, s->d_accum, st);
+    if (rc) return rc;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(accum, s->d_accum, (with_jacobian ? s->n_accum() : 1) * sizeof(double),
+                                     hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ECAL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side: block-banded arrow system and Levenberg-Marquardt (Ceres 1.x trust-region loop restated)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int BW = 24;  // scalar half-bandwidth + 1 of the control-point part (4 blocks of 6)
+
+struct ArrowSystem {
+    size_t nc = 0;                // 6 * n_cp
+    std::vector<double> band;     // [nc][BW]: band[i][k] = A(i, i-k), lower band
+    std::vector<double> border;   // [nc][9]:  A(i, intr j)
+    double corner[81];            // A(intr, intr)
+    std::vector<double> gc;       // [nc]
+    double gi[9];
+};
+
+// unpack the accumulation buffer (upper blocks) into the symmetric arrow system
+void unpack(const double *acc, uint32_t n_cp, ArrowSystem &A) {
+    A.nc = 6 * (size_t) n_cp;
+    A.band.assign(A.nc * BW, 0.0);
+    A.border.assign(A.nc * 9, 0.0);
+    A.gc.assign(A.nc, 0.0);
+    for (int i = 0; i < 9; i++) {
+        A.gi[i] = acc[1 + i];
+        for (int j = i; j < 9; j++) A.corner[9 * i + j] = A.corner[9 * j + i] = acc[10 + 9 * i + j];
+    }
+    for (uint32_t c = 0; c < n_cp; c++) {
+        const double *b = acc + ACC_HEAD + ACC_PER_CP * (size_t) c;
+        for (int k = 0; k < 6; k++) {
+            A.gc[6 * c + k] = b[k];
+            for (int j = 0; j < 9; j++) A.border[(6 * c + k) * 9 + j] = b[6 + 9 * k + j];
+        }
+        for (uint32_t d = 0; d < 4 && c + d < n_cp; d++) {
+            const double *blk = b + 60 + 36 * d;
+            for (int ka = 0; ka < 6; ka++)
+                for (int kb = 0; kb < 6; kb++) {
+                    if (d == 0 && kb < ka) continue;  // diagonal block: upper stored
+                    const size_t row = 6 * (size_t) (c + d) + kb, col = 6 * (size_t) c + ka;  // row >= col
+                    A.band[row * BW + (row - col)] = blk[6 * ka + kb];
+                }
+        }
+    }
+}
+
+// Solve (S A S + diag(dd)) y = -S g for the arrow system; returns false if not positive definite.
+// scale: Jacobi column scaling S (nc + 9); dd: LM diagonal added to the scaled system (nc + 9).
+bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const std::vector<double> &dd,
+                 std::vector<double> &y) {
+    const size_t nc = A.nc;
+    std::vector<double> L(nc * BW), Yb(nc * 9), rhs(nc);
+    for (size_t i = 0; i < nc; i++) {
+        for (int k = 0; k < BW && (size_t) k <= i; k++) L[i * BW + k] = A.band[i * BW + k] * scale[i] * scale[i - k];
+        L[i * BW] += dd[i];
+        for (int j = 0; j < 9; j++) Yb[i * 9 + j] = A.border[i * 9 + j] * scale[i] * scale[nc + j];
+        rhs[i] = -A.gc[i] * scale[i];
+    }
+    // banded Cholesky (lower), in place
+    for (size_t i = 0; i < nc; i++) {
+        for (int k = std::min<size_t>(BW - 1, i); k >= 0; k--) {
+            const size_t j = i - k;  // column
+            double v = L[i * BW + k];
+            const int mmax = std::min<size_t>(BW - 1 - k, j);
+            for (int m = 1; m <= mmax; m++) v -= L[i * BW + k + m] * L[j * BW + m];
+            if (k == 0) {
+                if (!(v > 0.0)) return false;
+                L[i * BW] = std::sqrt(v);
+            } else {
+                L[i * BW + k] = v / L[j * BW];
+            }
+        }
+    }
+    // forward substitution: L Z = [border | rhs]
+    for (size_t i = 0; i < nc; i++) {
+        const int kmax = std::min<size_t>(BW - 1, i);
+        for (int j = 0; j < 9; j++) {
+            double v = Yb[i * 9 + j];
+            for (int k = 1; k <= kmax; k++) v -= L[i * BW + k] * Yb[(i - k) * 9 + j];
+            Yb[i * 9 + j] = v / L[i * BW];
+        }
+        double v = rhs[i];
+        for (int k = 1; k <= kmax; k++) v -= L[i * BW + k] * rhs[i - k];
+        rhs[i] = v / L[i * BW];
+    }
+    // Schur complement on the 9 intrinsics
+    double S[81], b[9];
+    for (int i = 0; i < 9; i++) {
+        for (int j = 0; j < 9; j++) {
+            double v = A.corner[9 * i + j] * scale[nc + i] * scale[nc + j];
+            if (i == j) v += dd[nc + i];
+            for (size_t r = 0; r < nc; r++) v -= Yb[r * 9 + i] * Yb[r * 9 + j];
+            S[9 * i + j] = v;
+        }
+        double v = -A.gi[i] * scale[nc + i];
+        for (size_t r = 0; r < nc; r++) v -= Yb[r * 9 + i] * rhs[r];
+        b[i] = v;
+    }
+    // dense Cholesky 9x9
+    for (int i = 0; i < 9; i++) {
+        for (int j = 0; j <= i; j++) {
+            double v = S[9 * i + j];
+            for (int k = 0; k < j; k++) v -= S[9 * i + k] * S[9 * j + k];
+            if (i == j) {
+                if (!(v > 0.0)) return false;
+                S[9 * i + i] = std::sqrt(v);
+            } else {
+                S[9 * i + j] = v / S[9 * j + j];
+            }
+        }
+    }
+    double yi[9];
+    for (int i = 0; i < 9; i++) {
+        double v = b[i];
+        for (int k = 0; k < i; k++) v -= S[9 * i + k] * yi[k];
+        yi[i] = v / S[9 * i + i];
+    }
+    for (int i = 8; i >= 0; i--) {
+        double v = yi[i];
+        for (int k = i + 1; k < 9; k++) v -= S[9 * k + i] * yi[k];
+        yi[i] = v / S[9 * i + i];
+    }
+    // back substitution for the control points: L^T y_c = rhs - Yb yi
+    y.assign(nc + 9, 0.0);
+    for (int j = 0; j < 9; j++) y[nc + j] = yi[j];
+    for (size_t ii = nc; ii-- > 0;) {
+        double v = rhs[ii];
+        for (int j = 0; j < 9; j++) v -= Yb[ii * 9 + j] * yi[j];
+        const int kmax = std::min<size_t>(BW - 1, nc - 1 - ii);
+        for (int k = 1; k <= kmax; k++) v -= L[(ii + k) * BW + k] * y[ii + k];
+        y[ii] = v / L[ii * BW];
+    }
+    return true;
+}
+
+// y^T A y and g^T y on the unscaled system (for the model cost change)
+void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd, double *dHd) {
+    const size_t nc = A.nc;
+    double g = 0, h = 0;
+    for (size_t i = 0; i < nc; i++) {
+        g += A.gc[i] * d[i];
+        double row = A.band[i * BW] * d[i];
+        const int kmax = std::min<size_t>(BW - 1, i);
+        for (int k = 1; k <= kmax; k++) row += 2.0 * A.band[i * BW + k] * d[i - k];
+        h += d[i] * row;
+        for (int j = 0; j < 9; j++) h += 2.0 * d[i] * A.border[i * 9 + j] * d[nc + j];
+    }
+    for (int i = 0; i < 9; i++) {
+        g += A.gi[i] * d[nc + i];
+        for (int j = 0; j < 9; j++) h += d[nc + i] * A.corner[9 * i + j] * d[nc + j];
+    }
+    *gTd = g;
+    *dHd = h;
+}
+
+// x (+) delta: intrinsics and translations add, quaternions take exp(delta) (x) q
+void plus(const double *x, const std::vector<double> &d, uint32_t n_cp, double *out) {
+    const size_t nc = 6 * (size_t) n_cp;
+    for (int i = 0; i < 9; i++) out[i] = x[i] + d[nc + i];
+    for (uint32_t c = 0; c < n_cp; c++) {
+        quaternion_plus(x + 9 + 4 * (size_t) c, &d[6 * (size_t) c], out + 9 + 4 * (size_t) c);
+        for (int k = 0; k < 3; k++)
+            out[9 + 4 * (size_t) n_cp + 3 * (size_t) c + k] = x[9 + 4 * (size_t) n_cp + 3 * (size_t) c + k] + d[6 * (size_t) c + 3 + k];
+    }
+}
+
+}  // namespace
+
+extern "C" void ecal_lm_default_options(ecal_lm_options *o) {
+    if (!o) return;
+    o->max_num_iterations = 50;             // Ceres default, not overridden at EventCalibSpline.cpp:238-243
+    o->function_tolerance = 1e-10;          // Sophus::Constants<double>::epsilon(), EventCalibSpline.cpp:240
+    o->gradient_tolerance = 1e-10;          // :239
+    o->parameter_tolerance = 1e-8;          // Ceres default
+    o->initial_trust_region_radius = 1e4;   // Ceres defaults below
+    o->max_trust_region_radius = 1e16;
+    o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6;
+    o->max_lm_diagonal = 1e32;
+    o->jacobi_scaling = 1;
+    o->allreduce = nullptr;
+    o->allreduce_user = nullptr;
+}
+
+extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_options *opt_in,
+                                 ecal_lm_summary *sum) {
+    if (!s || !params) return ECAL_ERR_INVALID;
+    ecal_lm_options opt;
+    if (opt_in) opt = *opt_in; else ecal_lm_default_options(&opt);
+    ecal_ctx *ctx = s->ctx;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t np = s->n_params(), na = s->n_accum(), nc = 6 * (size_t) s->n_cp, nt = nc + 9;
+    std::vector<double> acc(na), x(params, params + np), xc(np), delta, scale(nt, 1.0), dd(nt);
+    ArrowSystem A;
+    const auto t_begin = std::chrono::steady_clock::now();
+
+    auto evaluate = [&](const double *xp, int with_jac, double *cost) -> int {
+        hipError_t e = hipMemcpyAsync(s->d_params, xp, np * sizeof(double), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return ECAL_ERR_HIP;
+        int rc = ecal_solver_evaluate_dev(s, s->d_params, with_jac, s->d_accum, st);
+        if (rc) return rc;
+        const size_t n = with_jac ? na : 1;
+        if (opt.allreduce) {  // per-GPU partials summed over ranks (RCCL all-reduce supplied by the caller)
+            rc = opt.allreduce(opt.allreduce_user, s->d_accum, n, st);
+            if (rc) return ECAL_ERR_HIP;
+        }
+        e = hipMemcpyAsync(acc.data(), s->d_accum, n * sizeof(double), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("solver evaluate: ") + hipGetErrorString(e);
+            return ECAL_ERR_HIP;
+        }
+        *cost = acc[0];
+        return ECAL_OK;
+    };
+
+    ecal_lm_summary S;
+    memset(&S, 0, sizeof(S));
+    double cost = 0, radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
+    int rc = evaluate(x.data(), 1, &cost);
+    if (rc) return rc;
+    S.jacobian_evaluations = 1;
+    S.initial_cost = cost;
+    unpack(acc.data(), s->n_cp, A);
+    if (opt.jacobi_scaling) {  // computed once from the initial Jacobian, as Ceres does
+        for (size_t i = 0; i < nc; i++) scale[i] = 1.0 / (1.0 + std::sqrt(A.band[i * BW]));
+        for (int i = 0; i < 9; i++) scale[nc + i] = 1.0 / (1.0 + std::sqrt(A.corner[10 * i]));
+    }
+    S.termination = 1;  // NO_CONVERGENCE unless a test fires
+    auto gmax = [&]() {
+        double m = 0;
+        for (size_t i = 0; i < nc; i++) m = std::max(m, std::fabs(A.gc[i]));
+        for (int i = 0; i < 9; i++) m = std::max(m, std::fabs(A.gi[i]));
+        return m;
+    };
+    if (gmax() <= opt.gradient_tolerance) S.termination = 0;
+    while (S.termination == 1 && S.iterations < opt.max_num_iterations) {
+        S.iterations++;
+        // Levenberg-Marquardt diagonal on the scaled system
+        for (size_t i = 0; i < nt; i++) {
+            const double h = (i < nc ? A.band[i * BW] : A.corner[10 * (i - nc)]) * scale[i] * scale[i];
+            dd[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
+        }
+        bool ok = solve_arrow(A, scale, dd, delta);
+        double model_change = 0;
+        if (ok) {
+            for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
+            double gTd, dHd;
+            quad_forms(A, delta, &gTd, &dHd);
+            model_change = -gTd - 0.5 * dHd;
+            ok = model_change > 0.0;
+        }
+        if (!ok) {  // invalid step: shrink the region
+            radius /= decrease_factor;
+            decrease_factor *= 2.0;
+            S.unsuccessful_steps++;
+            continue;
+        }
+        plus(x.data(), delta, s->n_cp, xc.data());
+        double new_cost;
+        rc = evaluate(xc.data(), 0, &new_cost);
+        if (rc) return rc;
+        S.cost_evaluations++;
+        const double rel = (cost - new_cost) / model_change;
+        double step2 = 0, x2 = 0;
+        for (size_t i = 0; i < nt; i++) step2 += delta[i] * delta[i];
+        for (size_t i = 0; i < np; i++) x2 += x[i] * x[i];
+        if (rel > opt.min_relative_decrease) {
+            const double cost_change = cost - new_cost;
+            x.swap(xc);
+            const double prev = cost;
+            rc = evaluate(x.data(), 1, &cost);
+            if (rc) return rc;
+            S.jacobian_evaluations++;
+            unpack(acc.data(), s->n_cp, A);
+            S.successful_steps++;
+            const double t = 2.0 * rel - 1.0;
+            radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+            decrease_factor = 2.0;
+            if (gmax() <= opt.gradient_tolerance) S.termination = 0;
+            else if (std::fabs(cost_change) <= opt.function_tolerance * prev) S.termination = 0;
+        } else {
+            radius /= decrease_factor;
+            decrease_factor *= 2.0;
+            S.unsuccessful_steps++;
+        }
+        if (S.termination == 1 && std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(x2) + opt.parameter_tolerance))
+            S.termination = 0;
+    }
+    S.final_cost = cost;
+    S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    memcpy(params, x.data(), np * sizeof(double));
+    if (sum) *sum = S;
+    return ECAL_OK;
+}
+
+// closed form of PinholeCamera::inverseRadialDistortion (core/sensor/src/PinholeCamera.cpp:69-95)
+extern "C" void ecal_inverse_radial_distortion(const double *k4, double *b5) {
+    const double k1 = k4[0], k2 = k4[1], k3 = k4[2], k4v = k4[3];
+    const double k1_2 = k1 * k1, k1_3 = k1_2 * k1, k1_4 = k1_3 * k1, k1_5 = k1_4 * k1;
+    b5[0] = -k1;
+    b5[1] = 3 * k1_2 - k2;
+    b5[2] = -12 * k1_3 + 8 * k1 * k2 - k3;
+    b5[3] = 55 * k1_4 - 55 * k1_2 * k2 + 5 * k2 * k2 + 10 * k1 * k3 - k4v;
+    b5[4] = -273 * k1_5 + 364 * k1_3 * k2 - 78 * k1 * k2 * k2 - 78 * k1_2 * k3 + 12 * k2 * k3 + 12 * k1 * k4v;
+}

@@ -1,0 +1,189 @@
+// Per-event reprojection residual of the continuous-time calibration and its analytic gradient.
+//
+// Replaces the Ceres autodiff functor CalibReprojectionError::operator()
+// (event_camera_calib/include/opengv2/event_camera_calib/EventCalibSpline.hpp:158-229, unDistort
+// :36-63) together with ceres::EigenQuaternionParameterization (used at EventCalibSpline.cpp:116-135)
+// and the degree-3 B-spline basis of core/spline/include/opengv2/spline/BsplineReal.hpp:107-145,
+// 208-231 (NURBS book A2.1/A2.2).  Plain functions, usable from HIP kernels and host C++.
+//
+// Residual (B.2 of SURVEY): v = sum_j b_j q_j (xyzw), q = v/|v|, T = sum_j b_j t_j;
+//   x = (u-cx)/fx, y = (v-cy)/fy, r2 = x^2+y^2, c = 1 + k1 r2 + .. + k5 r2^5, p = (x c, y c, 1);
+//   Y = R(q) p, Xw = T - T_z * Y / Y_z   (ray / plane z = 0 intersection: depth = -T_z / (R3 . p));
+//   res = |Xw - lm| - Rc.
+// The Jacobian row has 33 entries in tangent space:
+//   [0..8]   intrinsics fx fy cx cy k1..k5
+//   [9+3j..] rotation control point j (j = 0..3): delta of  q_j <- exp(delta) (x) q_j
+//   [21+3j..] translation control point j
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define ECAL_HD __host__ __device__ __forceinline__
+#else
+#define ECAL_HD inline
+#endif
+
+namespace ecal {
+
+constexpr int RES_NJ = 33;  // tangent-space width of one residual's Jacobian row
+
+// knot span index for u in a clamped knot vector with n_cp control points, degree 3
+// (BsplineReal.hpp:208-231; u == last knot -> last span)
+ECAL_HD uint32_t spline_find_span(const double *knots, uint32_t n_cp, double u) {
+    const uint32_t n = n_cp - 1;
+    if (u == knots[n + 1]) return n;
+    uint32_t low = 3, high = n + 1, mid = (low + high) / 2;
+    while (u < knots[mid] || u >= knots[mid + 1]) {
+        if (u < knots[mid]) high = mid; else low = mid;
+        mid = (low + high) / 2;
+    }
+    return mid;
+}
+
+// the four non-zero cubic basis functions N_{span-3..span,3}(u) (BsplineReal.hpp:107-145, ders[0])
+ECAL_HD void spline_basis(const double *knots, uint32_t span, double u, double b[4]) {
+    double left[4], right[4], ndu[4][4];
+    ndu[0][0] = 1.0;
+    for (int j = 1; j <= 3; j++) {
+        left[j] = u - knots[span + 1 - j];
+        right[j] = knots[span + j] - u;
+        double saved = 0.0;
+        for (int r = 0; r < j; r++) {
+            ndu[j][r] = right[r + 1] + left[j - r];
+            const double temp = ndu[r][j - 1] / ndu[j][r];
+            ndu[r][j] = saved + right[r + 1] * temp;
+            saved = left[j - r] * temp;
+        }
+        ndu[j][j] = saved;
+    }
+    for (int j = 0; j <= 3; j++) b[j] = ndu[j][3];
+}
+
+struct ResidualInput {
+    double u, v;          // observed pixel
+    double lmx, lmy, lmz; // landmark (circle centre on the board, z = 0)
+    double radius;        // circle radius (world units)
+    double b[4];          // basis values (same for the rotation and the translation spline)
+};
+
+// intr[9]; q[4][4] rotation control points (x y z w); t[4][3] translation control points.
+// Returns the residual; if J != nullptr fills the 33 tangent-space partials.
+ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, const double (*q)[4], const double (*t)[3],
+                               double *J) {
+    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+    // pose at the event time
+    double vq[4] = {0, 0, 0, 0}, T[3] = {0, 0, 0};
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 4; k++) vq[k] += in.b[j] * q[j][k];
+        for (int k = 0; k < 3; k++) T[k] += in.b[j] * t[j][k];
+    }
+    const double vn = sqrt(vq[0] * vq[0] + vq[1] * vq[1] + vq[2] * vq[2] + vq[3] * vq[3]);
+    const double ux = vq[0] / vn, uy = vq[1] / vn, uz = vq[2] / vn, w = vq[3] / vn;
+    // undistorted ray
+    const double x = (in.u - cx) / fx, y = (in.v - cy) / fy;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
+    const double c = 1.0 + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    const double px = x * c, py = y * c, pz = 1.0;
+    // Y = p + 2 w (u x p) + 2 (u (u.p) - p (u.u))
+    const double cxp0 = uy * pz - uz * py, cxp1 = uz * px - ux * pz, cxp2 = ux * py - uy * px;  // u x p
+    const double udp = ux * px + uy * py + uz * pz, udu = ux * ux + uy * uy + uz * uz;
+    const double Y0 = px + 2 * w * cxp0 + 2 * (ux * udp - px * udu);
+    const double Y1 = py + 2 * w * cxp1 + 2 * (uy * udp - py * udu);
+    const double Y2 = pz + 2 * w * cxp2 + 2 * (uz * udp - pz * udu);
+    const double s = -T[2] / Y2;  // depth
+    const double Xw0 = T[0] + s * Y0, Xw1 = T[1] + s * Y1, Xw2 = T[2] + s * Y2;
+    const double d0 = Xw0 - in.lmx, d1 = Xw1 - in.lmy, d2 = Xw2 - in.lmz;
+    const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const double res = dist - in.radius;
+    if (!J) return res;
+
+    const double e0 = d0 / dist, e1 = d1 / dist, e2 = d2 / dist;  // d res / d Xw
+    const double eY = e0 * Y0 + e1 * Y1 + e2 * Y2;
+    // Xw = T - T_z Y / Y_z
+    const double gT0 = e0, gT1 = e1, gT2 = e2 - eY / Y2;
+    const double k = -T[2] / Y2;  // = s
+    const double gY0 = k * e0, gY1 = k * e1, gY2 = k * e2 - k * eY / Y2;
+    // d Y / d p = R(q) = I + 2 w [u]x + 2 (u u^T - (u.u) I);   g_p = R^T g_Y = g_Y - 2 w (u x g_Y) + 2 (u (u.g_Y) - g_Y (u.u))
+    const double udg = ux * gY0 + uy * gY1 + uz * gY2;
+    const double cxg0 = uy * gY2 - uz * gY1, cxg1 = uz * gY0 - ux * gY2;
+    const double gp0 = gY0 - 2 * w * cxg0 + 2 * (ux * udg - gY0 * udu);
+    const double gp1 = gY1 - 2 * w * cxg1 + 2 * (uy * udg - gY1 * udu);
+    // intrinsics
+    const double cp = intr[4] + 2 * intr[5] * r2 + 3 * intr[6] * r4 + 4 * intr[7] * r6 + 5 * intr[8] * r8;  // dc/dr2
+    const double gx = gp0 * (c + 2 * x * x * cp) + gp1 * (2 * x * y * cp);
+    const double gy = gp0 * (2 * x * y * cp) + gp1 * (c + 2 * y * y * cp);
+    J[0] = -gx * x / fx;
+    J[1] = -gy * y / fy;
+    J[2] = -gx / fx;
+    J[3] = -gy / fy;
+    const double gk = gp0 * x + gp1 * y;
+    J[4] = gk * r2;
+    J[5] = gk * r4;
+    J[6] = gk * r6;
+    J[7] = gk * r8;
+    J[8] = gk * r10;
+    // unit quaternion: g_w = 2 (u x p).g_Y ;  g_u = 2 w (p x g_Y) + 2 ((u.p) g_Y + p (u.g_Y) - 2 u (p.g_Y))
+    const double pdg = px * gY0 + py * gY1 + pz * gY2;
+    const double pxg0 = py * gY2 - pz * gY1, pxg1 = pz * gY0 - px * gY2, pxg2 = px * gY1 - py * gY0;
+    double gq[4];
+    gq[0] = 2 * w * pxg0 + 2 * (udp * gY0 + px * udg - 2 * ux * pdg);
+    gq[1] = 2 * w * pxg1 + 2 * (udp * gY1 + py * udg - 2 * uy * pdg);
+    gq[2] = 2 * w * pxg2 + 2 * (udp * gY2 + pz * udg - 2 * uz * pdg);
+    gq[3] = 2 * (cxp0 * gY0 + cxp1 * gY1 + cxp2 * gY2);
+    // through the normalisation q = v / |v|
+    const double qdg = ux * gq[0] + uy * gq[1] + uz * gq[2] + w * gq[3];
+    const double gv[4] = {(gq[0] - ux * qdg) / vn, (gq[1] - uy * qdg) / vn, (gq[2] - uz * qdg) / vn,
+                          (gq[3] - w * qdg) / vn};
+    for (int j = 0; j < 4; j++) {
+        const double bj = in.b[j];
+        // EigenQuaternionParameterization: q_j <- exp(delta) (x) q_j ; d/d delta at 0 (4x3, xyzw rows)
+        //   [ w  z -y ; -z  w  x ;  y -x  w ; -x -y -z ]
+        const double qx = q[j][0], qy = q[j][1], qz = q[j][2], qw = q[j][3];
+        J[9 + 3 * j + 0] = bj * (gv[0] * qw - gv[1] * qz + gv[2] * qy - gv[3] * qx);
+        J[9 + 3 * j + 1] = bj * (gv[0] * qz + gv[1] * qw - gv[2] * qx - gv[3] * qy);
+        J[9 + 3 * j + 2] = bj * (-gv[0] * qy + gv[1] * qx + gv[2] * qw - gv[3] * qz);
+        J[21 + 3 * j + 0] = bj * gT0;
+        J[21 + 3 * j + 1] = bj * gT1;
+        J[21 + 3 * j + 2] = bj * gT2;
+    }
+    return res;
+}
+
+// ceres::HuberLoss(a) + Corrector for a scalar residual (Ceres 1.x loss_function.cc / corrector.cc):
+// s = r^2; rho(s) = s (s <= a^2) or 2 a sqrt(s) - a^2; rho'' <= 0, so residual and Jacobian row are
+// both scaled by sqrt(rho'); cost contribution = rho / 2.
+ECAL_HD double huber_scale(double r, double a, double *half_rho) {
+    const double s = r * r, b = a * a;
+    if (s <= b) {
+        *half_rho = 0.5 * s;
+        return 1.0;
+    }
+    const double rt = sqrt(s);
+    *half_rho = 0.5 * (2.0 * a * rt - b);
+    const double rho1 = a / rt;
+    return sqrt(rho1 > 0 ? rho1 : 0.0);  // max(min, a / r), Ceres clamps with DBL_MIN
+}
+
+// q <- exp(delta) (x) q   (EigenQuaternionParameterization::Plus, xyzw storage)
+ECAL_HD void quaternion_plus(const double q[4], const double d[3], double out[4]) {
+    const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    double dq[4];
+    if (nd > 0.0) {
+        const double sn = sin(nd) / nd;
+        dq[0] = sn * d[0];
+        dq[1] = sn * d[1];
+        dq[2] = sn * d[2];
+        dq[3] = cos(nd);
+    } else {
+        dq[0] = dq[1] = dq[2] = 0.0;
+        dq[3] = 1.0;
+    }
+    // Hamilton product dq (x) q
+    out[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
+    out[1] = dq[3] * q[1] - dq[0] * q[2] + dq[1] * q[3] + dq[2] * q[0];
+    out[2] = dq[3] * q[2] + dq[0] * q[1] - dq[1] * q[0] + dq[2] * q[3];
+    out[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
+}
+
+}  // namespace ecal

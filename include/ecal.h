@@ -180,6 +180,72 @@ uint64_t ecal_stream_size(const ecal_stream *s);
 int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const double *t0, const double *t1, uint32_t S,
                       const ecal_detect_params *prm, uint32_t cap_points, ecal_detect_result *res);
 
+/* ---- continuous-time calibration solve ---------------------------------------------------------
+ * Replaces the Ceres problem of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
+ * 196-247) for the quaternion-spline variant (useSO3 = 0): one residual per associated event,
+ *   r = | Xw(event pixel; intrinsics, pose(t)) - landmark | - circle_radius
+ * (CalibReprojectionError::operator(), EventCalibSpline.hpp:158-229; unDistort :36-63), HuberLoss(huber_a)
+ * with huber_a = 0.2 * circle_radius (:205), EigenQuaternionParameterization on the rotation control
+ * points (:116-135), Levenberg-Marquardt with the options of :238-243.
+ *
+ * Parameter vector (doubles): [ fx fy cx cy k1..k5 | q_c (x y z w) for c < n_cp | t_c (x y z) for c < n_cp ],
+ * n_cp = seg_cp_off[n_segments] control points; segment g owns control points
+ * [seg_cp_off[g], seg_cp_off[g+1]) and the clamped knot vector knots[seg_cp_off[g] + 4g ..] of
+ * n_cp_g + 4 entries (degree 3: BsplineReal<4>/<3> of one segment share it, EventCalibSpline.cpp:68-91).
+ * Residual records (the output of the association step, EventCalibSpline.cpp:158-192) must be sorted
+ * by (segment, time); 32 bytes each on the device (obs 16 + time 8 + landmark 4 + segment 4): spans and
+ * basis values are recomputed from the time (BsplineReal.hpp:107-145,208-231).
+ *
+ * Normal-equation buffer of ecal_solver_evaluate[_dev] (ecal_solver_normal_size doubles, tangent space,
+ * Huber-corrected, SUMS over this process's residuals — ranks add theirs with an all-reduce):
+ *   [0] cost = sum rho/2 | [1..9] (J^T r)_intr | [10..90] (J^T J)_intr,intr (9x9 row-major, upper part)
+ *   then per control point c, 204 doubles: (J^T r)_c [6: d_rot 3, d_trans 3] | (J^T J)_c,intr [6][9] |
+ *   (J^T J)_c,c+d [4][6][6] for d = 0..3 (d = 0: upper part).  with_jacobian = 0 fills only [0].
+ */
+typedef struct ecal_solver ecal_solver;
+typedef struct ecal_spline_problem {
+    uint32_t n_segments;
+    const uint32_t *seg_cp_off; /* [n_segments + 1] */
+    const double *knots;        /* [n_cp + 4 n_segments] */
+    uint64_t n_res;
+    const double *obs;          /* [n_res][2] event pixel */
+    const double *time;         /* [n_res] */
+    const uint32_t *lm_id;      /* [n_res] index into landmarks */
+    const uint32_t *seg_id;     /* [n_res] or NULL (= all segment 0) */
+    uint32_t n_landmarks;
+    const double *landmarks;    /* [n_landmarks][3] */
+    double circle_radius;       /* Circles_Radius */
+    double huber_a;             /* 0.2 * circle_radius in the reference */
+} ecal_spline_problem;
+typedef int (*ecal_allreduce_fn)(void *user, double *d_buf, size_t n_doubles, void *stream);
+typedef struct ecal_lm_options {
+    int max_num_iterations;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_trust_region_radius, max_trust_region_radius, min_relative_decrease;
+    double min_lm_diagonal, max_lm_diagonal;
+    int jacobi_scaling;
+    ecal_allreduce_fn allreduce; /* NULL on one GPU; sums d_buf over ranks in place (RCCL) otherwise */
+    void *allreduce_user;
+} ecal_lm_options;
+typedef struct ecal_lm_summary {
+    int iterations, successful_steps, unsuccessful_steps, jacobian_evaluations, cost_evaluations;
+    int termination; /* 0 = converged (a tolerance fired), 1 = max_num_iterations reached */
+    double initial_cost, final_cost, seconds;
+} ecal_lm_summary;
+int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *problem, ecal_solver **out);
+void ecal_solver_destroy(ecal_solver *s);
+size_t ecal_solver_param_size(const ecal_solver *s);
+size_t ecal_solver_normal_size(const ecal_solver *s);
+uint32_t ecal_solver_num_chunks(const ecal_solver *s);
+int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum, void *stream);
+int ecal_solver_evaluate(ecal_solver *s, const double *params, int with_jacobian, double *accum);
+void ecal_lm_default_options(ecal_lm_options *opt);
+int ecal_solver_solve(ecal_solver *s, double *params /*in: start, out: solution*/, const ecal_lm_options *opt,
+                      ecal_lm_summary *summary);
+/* PinholeCamera::inverseRadialDistortion (core/sensor/src/PinholeCamera.cpp:69-95): (k1,k2,k3,k4) -> the
+ * five inverse-polynomial coefficients that initialise k1..k5 (EventCalibSpline.cpp:101-105). */
+void ecal_inverse_radial_distortion(const double *k4, double *b5);
+
 #ifdef __cplusplus
 }
 #endif

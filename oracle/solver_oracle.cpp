@@ -1,0 +1,223 @@
+// TEST INFRASTRUCTURE ONLY — CPU oracle for the continuous-time calibration solve (see
+// dbscan_oracle.cpp for the rules: only tests/, smoke() and bench.py's cpu_baseline may use this).
+//
+// Restates (reference paths):
+//   * event_camera_calib/include/opengv2/event_camera_calib/EventCalibSpline.hpp:36-63 (unDistort)
+//     and :158-229 (CalibReprojectionError::operator(), quaternion spline variant, useSO3 = 0), as a
+//     template over the scalar type exactly like the reference, differentiated here with a small
+//     forward-mode dual number (what ceres::AutoDiffCostFunction<...,1,9,4,4,4,4,3,3,3,3> does,
+//     EventCalibSpline.hpp:237-239);
+//   * core/spline/include/opengv2/spline/BsplineReal.hpp:107-145 (basis, ders[0]) and :208-231
+//     (findSpan); :87-100 knot placement is NOT restated (the spline fit is a "next" row);
+//   * core/sensor/src/PinholeCamera.cpp:69-95 inverseRadialDistortion (closed form of
+//     Drap & Lefevre), used to initialise k1..k5 at EventCalibSpline.cpp:101-105.
+// Third-party arithmetic restated from its published algorithm (source not in the reference tree,
+// no version pinned — CMakeLists.txt:45 only says find_package(Ceres)): Ceres 1.x HuberLoss +
+// Corrector (rho'' <= 0 branch), EigenQuaternionParameterization (Plus and its 4x3 Jacobian) and the
+// Levenberg-Marquardt trust-region loop with Jacobi scaling (trust_region_minimizer.cc,
+// levenberg_marquardt_strategy.cc).  Parity of the minimiser is therefore UNPINNED; tests check
+// convergence to the same minimum as the product path and to the synthetic ground truth.
+
+#include <cstdint>
+#include <cstddef>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+
+namespace {
+
+constexpr int NP = 37;  // 9 + 4*4 + 4*3 ambient parameters of one residual block
+
+struct Jet {
+    double a;
+    double v[NP];
+    Jet() : a(0) { for (int i = 0; i < NP; i++) v[i] = 0; }
+    Jet(double x) : a(x) { for (int i = 0; i < NP; i++) v[i] = 0; }
+    static Jet var(double x, int k) {
+        Jet j(x);
+        j.v[k] = 1;
+        return j;
+    }
+};
+inline Jet operator+(const Jet &x, const Jet &y) { Jet r; r.a = x.a + y.a; for (int i = 0; i < NP; i++) r.v[i] = x.v[i] + y.v[i]; return r; }
+inline Jet operator-(const Jet &x, const Jet &y) { Jet r; r.a = x.a - y.a; for (int i = 0; i < NP; i++) r.v[i] = x.v[i] - y.v[i]; return r; }
+inline Jet operator-(const Jet &x) { Jet r; r.a = -x.a; for (int i = 0; i < NP; i++) r.v[i] = -x.v[i]; return r; }
+inline Jet operator*(const Jet &x, const Jet &y) { Jet r; r.a = x.a * y.a; for (int i = 0; i < NP; i++) r.v[i] = x.a * y.v[i] + x.v[i] * y.a; return r; }
+inline Jet operator/(const Jet &x, const Jet &y) { Jet r; r.a = x.a / y.a; for (int i = 0; i < NP; i++) r.v[i] = (x.v[i] - r.a * y.v[i]) / y.a; return r; }
+inline Jet sqrt(const Jet &x) { Jet r; r.a = std::sqrt(x.a); for (int i = 0; i < NP; i++) r.v[i] = x.v[i] / (2 * r.a); return r; }
+inline Jet &operator*=(Jet &x, const Jet &y) { x = x * y; return x; }
+inline double sqrt_(double x) { return std::sqrt(x); }
+inline Jet sqrt_(const Jet &x) { return sqrt(x); }
+
+// EventCalibSpline.hpp:158-229 with T = double or Jet.  Quaternion rotation of a vector follows
+// Eigen's QuaternionBase::_transformVector (v + w*2(u x v) + u x 2(u x v)).
+template <typename T>
+T residual_functor(const T *intr, const T (*rq)[4], const T (*tp)[3], const double *rb, const double *tb,
+                   const double obs[2], const double lm[3], double radius) {
+    T q[4], t[3];
+    for (int k = 0; k < 4; k++) q[k] = T(rb[0]) * rq[0][k] + T(rb[1]) * rq[1][k] + T(rb[2]) * rq[2][k] + T(rb[3]) * rq[3][k];
+    const T nrm = sqrt_(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);  // Qwb_v.normalize()
+    for (int k = 0; k < 4; k++) q[k] = q[k] / nrm;
+    for (int k = 0; k < 3; k++) t[k] = T(tb[0]) * tp[0][k] + T(tb[1]) * tp[1][k] + T(tb[2]) * tp[2][k] + T(tb[3]) * tp[3][k];
+    // unDistort (:36-63)
+    T Xc[3];
+    Xc[0] = (T(obs[0]) - intr[2]) / intr[0];
+    Xc[1] = (T(obs[1]) - intr[3]) / intr[1];
+    Xc[2] = T(1.0);
+    const T xx = Xc[0] * Xc[0], yy = Xc[1] * Xc[1];
+    const T r2 = xx + yy, r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
+    const T coeff = T(1.0) + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    Xc[0] *= coeff;
+    Xc[1] *= coeff;
+    // :213-224
+    const T tx = T(2.0) * q[0], ty = T(2.0) * q[1], tz = T(2.0) * q[2];
+    const T twx = tx * q[3], twy = ty * q[3], txx = tx * q[0], txz = tz * q[0], tyy = ty * q[1], tyz = tz * q[1];
+    const T r2row[3] = {txz - twy, tyz + twx, T(1.0) - (txx + tyy)};
+    const T depth = -t[2] / (r2row[0] * Xc[0] + r2row[1] * Xc[1] + r2row[2] * Xc[2]);
+    for (int k = 0; k < 3; k++) Xc[k] *= depth;
+    // Xw = Qws * Xc + tws
+    T uv[3] = {q[1] * Xc[2] - q[2] * Xc[1], q[2] * Xc[0] - q[0] * Xc[2], q[0] * Xc[1] - q[1] * Xc[0]};
+    for (int k = 0; k < 3; k++) uv[k] = uv[k] + uv[k];
+    const T c2[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
+    T Xw[3];
+    for (int k = 0; k < 3; k++) Xw[k] = Xc[k] + q[3] * uv[k] + c2[k] + t[k];
+    const T d0 = Xw[0] - T(lm[0]), d1 = Xw[1] - T(lm[1]), d2 = Xw[2] - T(lm[2]);
+    return sqrt_(d0 * d0 + d1 * d1 + d2 * d2) - T(radius);
+}
+
+}  // namespace
+
+extern "C" {
+
+// BsplineReal::findSpan (:208-231) for a clamped knot vector with n_cp control points, degree 3
+uint32_t oracle_find_span(const double *knots, uint32_t n_cp, double u) {
+    const size_t degree = 3;
+    const size_t n = (n_cp + degree + 1) - 2 - degree;
+    if (u == knots[n + 1]) return (uint32_t) n;
+    size_t low = degree, high = n + 1, mid = (low + high) / 2;
+    while (u < knots[mid] || u >= knots[mid + 1]) {
+        if (u < knots[mid]) high = mid; else low = mid;
+        mid = (low + high) / 2;
+    }
+    return (uint32_t) mid;
+}
+
+// BsplineReal::dersBasisFuns(u, span, 0, ders) -> ders[0][0..3]  (:107-145)
+void oracle_basis(const double *knots, uint32_t span, double u, double *b4) {
+    const int degree = 3;
+    double ndu[4][4], left[4], right[4];
+    ndu[0][0] = 1;
+    for (int j = 1; j <= degree; j++) {
+        left[j] = u - knots[span + 1 - j];
+        right[j] = knots[span + j] - u;
+        double saved = 0.0;
+        for (int r = 0; r < j; ++r) {
+            ndu[j][r] = right[r + 1] + left[j - r];
+            double temp = ndu[r][j - 1] / ndu[j][r];
+            ndu[r][j] = saved + right[r + 1] * temp;
+            saved = left[j - r] * temp;
+        }
+        ndu[j][j] = saved;
+    }
+    for (int j = 0; j <= degree; j++) b4[j] = ndu[j][degree];
+}
+
+// residual and its Jacobian: J37 = ambient partials [intr 9 | q0..q3 (4 each) | t0..t3 (3 each)] as
+// Ceres' autodiff would return them; J33 = after EigenQuaternionParameterization (tangent space)
+// [intr 9 | delta_0..delta_3 (3 each) | t0..t3].  Either may be NULL.
+double oracle_residual(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                       const double *obs2, const double *lm3, double radius, double *J37, double *J33) {
+    Jet ji[9], jq[4][4], jt[4][3];
+    for (int i = 0; i < 9; i++) ji[i] = Jet::var(intr[i], i);
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 4; k++) jq[j][k] = Jet::var(q4x4[4 * j + k], 9 + 4 * j + k);
+        for (int k = 0; k < 3; k++) jt[j][k] = Jet::var(t4x3[3 * j + k], 25 + 3 * j + k);
+    }
+    const Jet r = residual_functor<Jet>(ji, jq, jt, basis4, basis4, obs2, lm3, radius);
+    if (J37) for (int i = 0; i < NP; i++) J37[i] = r.v[i];
+    if (J33) {
+        for (int i = 0; i < 9; i++) J33[i] = r.v[i];
+        for (int j = 0; j < 4; j++) {
+            const double *x = q4x4 + 4 * j;
+            const double *g = r.v + 9 + 4 * j;
+            // EigenQuaternionParameterization::ComputeJacobian (4x3, row-major, xyzw):
+            //   [ w  z -y ; -z  w  x ;  y -x  w ; -x -y -z ]
+            J33[9 + 3 * j + 0] = g[0] * x[3] - g[1] * x[2] + g[2] * x[1] - g[3] * x[0];
+            J33[9 + 3 * j + 1] = g[0] * x[2] + g[1] * x[3] - g[2] * x[0] - g[3] * x[1];
+            J33[9 + 3 * j + 2] = -g[0] * x[1] + g[1] * x[0] + g[2] * x[3] - g[3] * x[2];
+            for (int k = 0; k < 3; k++) J33[21 + 3 * j + k] = r.v[25 + 3 * j + k];
+        }
+    }
+    return r.a;
+}
+
+double oracle_residual_value(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                             const double *obs2, const double *lm3, double radius) {
+    double q[4][4], t[4][3];
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 4; k++) q[j][k] = q4x4[4 * j + k];
+        for (int k = 0; k < 3; k++) t[j][k] = t4x3[3 * j + k];
+    }
+    return residual_functor<double>(intr, q, t, basis4, basis4, obs2, lm3, radius);
+}
+
+// PinholeCamera::inverseRadialDistortion (PinholeCamera.cpp:69-95): (k1,k2,k3,k4) -> b1..b5
+void oracle_inverse_radial(const double *k4, double *b5) {
+    const double k1 = k4[0], k2 = k4[1], k3 = k4[2], k4_ = k4[3];
+    b5[0] = -k1;
+    b5[1] = 3 * k1 * k1 - k2;
+    b5[2] = -12 * k1 * k1 * k1 + 8 * k1 * k2 - k3;
+    b5[3] = 55 * k1 * k1 * k1 * k1 - 55 * k1 * k1 * k2 + 5 * k2 * k2 + 10 * k1 * k3 - k4_;
+    b5[4] = -273 * k1 * k1 * k1 * k1 * k1 + 364 * k1 * k1 * k1 * k2 - 78 * k1 * k2 * k2 - 78 * k1 * k1 * k3 +
+            12 * k2 * k3 + 12 * k1 * k4_;
+}
+
+// ---- whole-problem evaluation on the CPU (the solver cpu_baseline and the checker of the GPU
+// normal equations).  Layout of a problem: intr[9]; n_cp control points (q [n_cp][4], t [n_cp][3])
+// of ONE spline segment with knots[n_cp + 4]; M residual records: obs [M][2], time [M], lm id [M];
+// landmarks [L][3].  Outputs (any may be NULL): cost = sum rho/2; g[9 + 6 n_cp] = J^T r in tangent
+// order [intr | (delta_c, t_c) per control point]; H dense [(9+6n_cp)^2] row-major (small problems).
+double oracle_evaluate(const double *intr, uint32_t n_cp, const double *q, const double *t, const double *knots,
+                       uint64_t M, const double *obs, const double *time, const uint32_t *lm_id,
+                       const double *landmarks, double radius, double huber_a, double *g, double *H) {
+    const size_t N = 9 + 6 * (size_t) n_cp;
+    if (g) std::fill(g, g + N, 0.0);
+    if (H) std::fill(H, H + N * N, 0.0);
+    double cost = 0;
+    for (uint64_t m = 0; m < M; m++) {
+        const double u = time[m];
+        const uint32_t span = oracle_find_span(knots, n_cp, u);
+        double b[4], J[33];
+        oracle_basis(knots, span, u, b);
+        const uint32_t c0 = span - 3;
+        double r = oracle_residual(intr, q + 4 * (size_t) c0, t + 3 * (size_t) c0, b, obs + 2 * m,
+                                   landmarks + 3 * (size_t) lm_id[m], radius, nullptr, (g || H) ? J : nullptr);
+        // HuberLoss + Corrector
+        const double s = r * r, a2 = huber_a * huber_a;
+        double rho, scale;
+        if (s <= a2) {
+            rho = s;
+            scale = 1.0;
+        } else {
+            const double rt = std::sqrt(s);
+            rho = 2 * huber_a * rt - a2;
+            scale = std::sqrt(huber_a / rt);
+        }
+        cost += 0.5 * rho;
+        if (!(g || H)) continue;
+        r *= scale;
+        size_t idx[33];
+        for (int i = 0; i < 9; i++) idx[i] = i;
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++) {
+                idx[9 + 3 * j + k] = 9 + 6 * (size_t) (c0 + j) + k;
+                idx[21 + 3 * j + k] = 9 + 6 * (size_t) (c0 + j) + 3 + k;
+            }
+        for (int i = 0; i < 33; i++) J[i] *= scale;
+        if (g) for (int i = 0; i < 33; i++) g[idx[i]] += J[i] * r;
+        if (H) for (int i = 0; i < 33; i++) for (int j = 0; j < 33; j++) H[idx[i] * N + idx[j]] += J[i] * J[j];
+    }
+    return cost;
+}
+
+}  // extern "C"

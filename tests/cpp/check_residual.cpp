@@ -1,0 +1,55 @@
+// CPU check (g++): the product's analytic residual/Jacobian (eventcalib_amd/csrc/spline_residual.hpp)
+// against the oracle's dual-number differentiation of the reference functor.  Test harness only.
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <random>
+#include "../../eventcalib_amd/csrc/spline_residual.hpp"
+
+extern "C" double oracle_residual(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                                  const double *obs2, const double *lm3, double radius, double *J37, double *J33);
+extern "C" uint32_t oracle_find_span(const double *knots, uint32_t n_cp, double u);
+extern "C" void oracle_basis(const double *knots, uint32_t span, double u, double *b4);
+
+int main() {
+    std::mt19937_64 rng(1234);
+    std::uniform_real_distribution<double> U(-1, 1);
+    double worst_r = 0, worst_j = 0;
+    for (int trial = 0; trial < 20000; trial++) {
+        double intr[9] = {359.67525 + 20 * U(rng), 359.67525 + 20 * U(rng), 172.5 + 5 * U(rng), 129.5 + 5 * U(rng),
+                          0.35 + 0.05 * U(rng), 0.38 + 0.05 * U(rng), -0.04 + 0.02 * U(rng), -1.16 + 0.1 * U(rng),
+                          -4.1 + 0.3 * U(rng)};
+        double q[4][4], t[4][3], b[4];
+        double base[4] = {0.05 * U(rng), 0.05 * U(rng), 0.7 + 0.05 * U(rng), 0.7 + 0.05 * U(rng)};
+        for (int j = 0; j < 4; j++) {
+            double n = 0;
+            for (int k = 0; k < 4; k++) { q[j][k] = base[k] + 0.02 * U(rng); n += q[j][k] * q[j][k]; }
+            n = std::sqrt(n) * (1.0 + 0.01 * U(rng));   // control points are only approximately unit
+            for (int k = 0; k < 4; k++) q[j][k] /= n;
+            t[j][0] = 19 + 3 * U(rng); t[j][1] = 22 + 3 * U(rng); t[j][2] = -66 + 5 * U(rng);
+        }
+        // a clamped knot vector with 7 control points and a random parameter
+        double knots[11] = {0, 0, 0, 0, 0.21, 0.48, 0.77, 1, 1, 1, 1};
+        const double u = 0.5 * (U(rng) + 1.0);
+        const uint32_t span = ecal::spline_find_span(knots, 7, u);
+        if (span != oracle_find_span(knots, 7, u)) { std::printf("span mismatch\n"); return 1; }
+        double ob[4];
+        ecal::spline_basis(knots, span, u, b);
+        oracle_basis(knots, span, u, ob);
+        for (int k = 0; k < 4; k++) if (b[k] != ob[k]) { std::printf("basis mismatch\n"); return 1; }
+        double obs[2] = {173 + 150 * U(rng), 130 + 110 * U(rng)};
+        double lm[3] = {19 + 18 * U(rng), 22 + 20 * U(rng), 0};
+        ecal::ResidualInput in;
+        in.u = obs[0]; in.v = obs[1]; in.lmx = lm[0]; in.lmy = lm[1]; in.lmz = lm[2]; in.radius = 1.75;
+        for (int k = 0; k < 4; k++) in.b[k] = b[k];
+        double J[33], Jo[33];
+        const double r = ecal::spline_residual(in, intr, q, t, J);
+        const double ro = oracle_residual(intr, &q[0][0], &t[0][0], b, obs, lm, 1.75, nullptr, Jo);
+        worst_r = std::fmax(worst_r, std::fabs(r - ro) / (1.0 + std::fabs(ro)));
+        double nj = 0;
+        for (int i = 0; i < 33; i++) nj = std::fmax(nj, std::fabs(Jo[i]));
+        for (int i = 0; i < 33; i++) worst_j = std::fmax(worst_j, std::fabs(J[i] - Jo[i]) / (1e-12 + nj));
+    }
+    std::printf("max rel residual err %.3e  max rel jacobian err %.3e\n", worst_r, worst_j);
+    return (worst_r < 1e-12 && worst_j < 1e-10) ? 0 : 2;
+}

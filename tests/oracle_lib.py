@@ -226,3 +226,39 @@ def fit_circle(a, b):
     r = ctypes.c_double(0)
     L.oracle_fit_circle(_p(a, _dp), a.shape[0], _p(b, _dp), b.shape[0], _p(c, _dp), ctypes.byref(r))
     return c, r.value
+
+
+# ---- solver oracle (oracle/solver_oracle.cpp) ----
+def solver_evaluate(problem, x, want_H=True):
+    """Dense CPU evaluation of one-segment problems: (cost, g, H) in tangent order [intr | cp (rot3, trans3)]."""
+    L = lib()
+    L.oracle_evaluate.argtypes = [_dp, ctypes.c_uint32, _dp, _dp, _dp, ctypes.c_uint64, _dp, _dp, _u32p, _dp,
+                                  ctypes.c_double, ctypes.c_double, _dp, _dp]
+    L.oracle_evaluate.restype = ctypes.c_double
+    n_cp = int(problem["seg_cp_off"][-1])
+    assert len(problem["seg_cp_off"]) == 2, "oracle_evaluate handles one segment"
+    x = np.ascontiguousarray(x, np.float64)
+    intr = x[:9].copy()
+    q = x[9:9 + 4 * n_cp].copy()
+    t = x[9 + 4 * n_cp:].copy()
+    kn = np.ascontiguousarray(problem["knots"], np.float64)
+    obs = np.ascontiguousarray(problem["obs"], np.float64)
+    tm = np.ascontiguousarray(problem["time"], np.float64)
+    lm = np.ascontiguousarray(problem["lm_id"], np.uint32)
+    lms = np.ascontiguousarray(problem["landmarks"], np.float64)
+    n = 9 + 6 * n_cp
+    g = np.zeros(n)
+    H = np.zeros((n, n)) if want_H else None
+    cost = L.oracle_evaluate(_p(intr, _dp), n_cp, _p(q, _dp), _p(t, _dp), _p(kn, _dp), tm.shape[0], _p(obs, _dp),
+                             _p(tm, _dp), _p(lm, _u32p), _p(lms, _dp), float(problem["circle_radius"]),
+                             float(problem["huber_a"]), _p(g, _dp), _p(H, _dp) if want_H else None)
+    return cost, g, H
+
+
+def inverse_radial(k4):
+    L = lib()
+    L.oracle_inverse_radial.argtypes = [_dp, _dp]
+    k = np.ascontiguousarray(k4, np.float64)
+    b = np.zeros(5)
+    L.oracle_inverse_radial(_p(k, _dp), _p(b, _dp))
+    return b

@@ -1,0 +1,112 @@
+"""GPU parity: residual / Jacobian / normal equations and the LM solve vs the oracle.
+Floating point (f64): tolerances are stated per assertion."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_lm
+import synth_solver as SV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import eventcalib_amd
+    c = eventcalib_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _dense(acc, n_cp):
+    from eventcalib_amd.capi import unpack_normal
+    return unpack_normal(acc, n_cp)
+
+
+@pytest.mark.parametrize("n_res,n_cp", [(500, 6), (3000, 9), (20000, 5)])
+def test_normal_equations_match_oracle(ctx, n_res, n_cp):
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(n_res)
+    prob, x = SV.make_problem(n_res, n_cp=n_cp, seed=n_res, pixel_noise=0.5)
+    y = SV.perturb(x, n_cp, rng, intr_rel=0.01, rot=0.005, trans=0.2)   # large enough to put residuals on the Huber tail
+    s = Solver(ctx, prob)
+    acc = s.evaluate(y, True)
+    cost, g, H = _dense(acc, n_cp)
+    oc, og, oH = O.solver_evaluate(prob, y)
+    # f64 sums of ~n_res terms in a different order (atomics) and FMA contraction: relative 1e-11
+    assert abs(cost - oc) <= 1e-11 * abs(oc)
+    assert np.abs(g - og).max() <= 1e-10 * np.abs(og).max()
+    assert np.abs(H - oH).max() <= 1e-10 * np.abs(oH).max()
+    assert abs(s.evaluate(y, False)[0] - oc) <= 1e-11 * abs(oc)
+    if n_res == 20000:
+        assert s.n_chunks > n_cp - 3      # spans with more than 4096 residuals are split into several chunks
+    s.close()
+
+
+def test_two_segments(ctx):
+    from eventcalib_amd.capi import Solver
+    prob, x = SV.make_problem(1200, n_cp=6, seed=9, n_segments=2, pixel_noise=0.2)
+    s = Solver(ctx, prob)
+    acc = s.evaluate(x, True)
+    cost, g, H = _dense(acc, 12)
+    # the oracle handles one segment: evaluate each segment separately (shared intrinsics) and add
+    tot_c, tot_g, tot_H = 0.0, np.zeros_like(g), np.zeros_like(H)
+    for seg in range(2):
+        m = prob["seg_id"] == seg
+        p1 = dict(prob, seg_cp_off=np.array([0, 6], np.uint32), knots=prob["knots"][10 * seg: 10 * seg + 10], obs=prob["obs"][m],
+                  time=prob["time"][m], lm_id=prob["lm_id"][m], seg_id=None)
+        x1 = np.concatenate([x[:9], x[9 + 24 * seg: 9 + 24 * seg + 24], x[9 + 48 + 18 * seg: 9 + 48 + 18 * seg + 18]])
+        c1, g1, H1 = O.solver_evaluate(p1, x1)
+        idx = np.concatenate([np.arange(9), 9 + 36 * seg + np.arange(36)])
+        tot_c += c1
+        tot_g[idx] += g1
+        tot_H[np.ix_(idx, idx)] += H1
+    assert abs(cost - tot_c) <= 1e-11 * abs(tot_c) + 1e-20
+    assert np.abs(g - tot_g).max() <= 1e-10 * np.abs(tot_g).max()
+    assert np.abs(H - tot_H).max() <= 1e-10 * np.abs(tot_H).max()
+    # no coupling between the control points of different segments
+    assert np.abs(H[9:45, 45:81]).max() == 0.0
+    s.close()
+
+
+def test_lm_recovers_ground_truth_and_matches_reference_loop(ctx):
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(4)
+    n_cp = 8
+    prob, x_gt = SV.make_problem(4000, n_cp=n_cp, seed=4)
+    x0 = SV.perturb(x_gt, n_cp, rng)
+    s = Solver(ctx, prob)
+    x, summ = s.solve(x0)
+    assert summ.termination == 0 and summ.final_cost < 1e-12 * summ.initial_cost + 1e-16
+    # intrinsics back to the ground truth: relative 1e-6 (noise-free data; the gauge is fixed by the board)
+    assert np.abs(x[:4] / x_gt[:4] - 1).max() < 1e-6
+    assert np.abs(x[4:9] - x_gt[4:9]).max() < 1e-5
+    # same minimiser as the dense numpy loop on the oracle: iterates agree closely
+    xr, hist, it = ref_lm.solve(prob, x0)
+    assert np.abs(x[:9] - xr[:9]).max() <= 1e-7 * np.abs(xr[:9]).max()
+    assert abs(summ.successful_steps + 1 - len(hist)) <= 2
+    s.close()
+
+
+def test_lm_with_noise_and_outliers(ctx):
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(6)
+    n_cp = 7
+    prob, x_gt = SV.make_problem(6000, n_cp=n_cp, seed=6, pixel_noise=0.4)
+    bad = rng.random(6000) < 0.05
+    prob["obs"][bad] += rng.normal(0, 15, size=(int(bad.sum()), 2))      # outliers -> Huber region
+    x0 = SV.perturb(x_gt, n_cp, rng)
+    s = Solver(ctx, prob)
+    x, summ = s.solve(x0)
+    xr, hist, it = ref_lm.solve(prob, x0)
+    assert summ.final_cost <= hist[-1] * (1 + 1e-6)
+    # focal lengths within 1 % of truth despite noise/outliers; agreement with the oracle loop to 1e-5
+    assert np.abs(x[:2] / x_gt[:2] - 1).max() < 1e-2
+    assert np.abs(x[:9] - xr[:9]).max() <= 1e-5 * np.abs(xr[:9]).max()
+    s.close()
+
+
+def test_inverse_radial(ctx):
+    from eventcalib_amd.capi import inverse_radial_distortion
+    b = inverse_radial_distortion([-0.34991902, -0.014698517, 0.59684463, 0.0])
+    assert np.array_equal(b, O.inverse_radial([-0.34991902, -0.014698517, 0.59684463, 0.0]))
