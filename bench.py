@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--events", type=int, default=50_000_000)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="events timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--solver-iters", type=int, default=8, help="LM iterations timed for M2 (0 = skip the solver leg)")
+    ap.add_argument("--solver-cpu-sample", type=int, default=300_000, help="residuals timed on the CPU oracle")
     args = ap.parse_args()
 
     import numpy as np
@@ -180,10 +182,127 @@ def main():
                           "(DBSCAN +/-, filter, medians, pairing) per window, 1 thread, %.1f s" % (nw, cev, cel),
                 "host_cpus": os.cpu_count(),
             }
+    # ------------------------------------------------------------------------------------------
+    # M2: Levenberg-Marquardt iterations/s of the continuous-time solve on the same stream
+    # (configs[2]: 50 M events -> ~45 M associated residuals, control point every 50 steps = 25 ms)
+    # ------------------------------------------------------------------------------------------
+    if args.solver_iters > 0:
+        del events
+        pipe = None
+        torch.cuda.empty_cache()
+        out_solver = solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np)
+        if rank == 0:
+            out["solver"] = out_solver
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+
+
+def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np):
+    import synth_solver_torch as ST
+    import synth_solver as SV
+    from eventcalib_amd.capi import Solver, make_allreduce_hook
+    step = 5e-4                                               # MotionTimeStep, example.yaml:14
+    duration = n_events / rate
+    n_cp = max(4, int(duration / (50 * step)))                # EventCalibSpline.cpp:81
+    n_res = int(0.9 * n_events)                               # the edge events; noise fails findCenter's gate
+    # every rank owns one spline segment (its time range); intrinsics are shared by all ranks
+    t0, t1 = t_start, t_start + duration
+    prob, x_seg = ST.make_problem(n_res, n_cp, t0, t1, seed=777 + rank, device=dev, round_pixels=True)
+    rngp = np.random.default_rng(99)                           # same perturbation of the shared intrinsics everywhere
+    intr0 = x_seg[:9].copy()
+    intr0[:4] *= 1 + 0.01 * rngp.uniform(-1, 1, 4)
+    intr0[4:9] += 0.01 * rngp.uniform(-1, 1, 5)
+    if world > 1:
+        seg_cp_off = (np.arange(world + 1) * n_cp).astype(np.uint32)
+        knots = np.concatenate([ST.uniform_knots(n_cp, t_start_r, t_start_r + duration) for t_start_r in
+                                [5.0 + r * (duration + 1.0) for r in range(world)]])
+        prob = dict(prob, seg_cp_off=seg_cp_off, knots=knots, seg_id=np.full(n_res, rank, np.uint32))
+        # full parameter vector: every rank needs all control points (others' blocks only get reduced sums)
+        q_all = np.concatenate([SV.gt_control_points(n_cp, 5.0 + r * (duration + 1.0), 5.0 + r * (duration + 1.0) + duration)[0]
+                                for r in range(world)])
+        t_all = np.concatenate([SV.gt_control_points(n_cp, 5.0 + r * (duration + 1.0), 5.0 + r * (duration + 1.0) + duration)[1]
+                                for r in range(world)])
+        x0 = np.concatenate([intr0, q_all.ravel(), t_all.ravel()])
+    else:
+        x0 = np.concatenate([intr0, x_seg[9:]])
+    solver = Solver(ctx, prob)
+    del prob
+    opt = solver.default_options()
+    hook = make_allreduce_hook(ctx, world)
+    if world > 1:
+        opt.allreduce = hook
+    # warm-up: two iterations
+    opt.max_num_iterations = 2
+    solver.solve(x0, opt)
+    # kernel-level timing of one Jacobian evaluation and one cost evaluation (HIP events on the launch stream)
+    st = torch.cuda.current_stream(dev)
+    d_x = torch.as_tensor(x0, device=dev)
+    d_acc = torch.empty(solver.n_normal, dtype=torch.float64, device=dev)
+    reps = 5
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    solver.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize(dev)
+    ev[0].record(st)
+    for _ in range(reps):
+        solver.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
+    ev[1].record(st)
+    for _ in range(reps):
+        solver.evaluate_dev(d_x.data_ptr(), 0, d_acc.data_ptr(), st.cuda_stream)
+    ev[2].record(st)
+    torch.cuda.synchronize(dev)
+    jac_ms = ev[0].elapsed_time(ev[1]) / reps
+    cost_ms = ev[1].elapsed_time(ev[2]) / reps
+    # timed solve
+    opt.max_num_iterations = args.solver_iters
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    tb = time.perf_counter()
+    x, summ = solver.solve(x0, opt)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - tb
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    iters = int(summ.iterations)
+    res_total = n_res * world
+    FLOP_JAC = 2100.0            # per residual and Jacobian evaluation: ~700 residual+gradient, 45 tiles x 16 FMA x 2
+    out = {
+        "metric": "LM solver iterations/s", "value": round(iters / el, 3), "unit": "iterations/s",
+        "iterations": iters, "seconds": round(el, 4), "successful_steps": int(summ.successful_steps),
+        "jacobian_evaluations": int(summ.jacobian_evaluations), "cost_evaluations": int(summ.cost_evaluations),
+        "initial_cost": float(summ.initial_cost), "final_cost": float(summ.final_cost),
+        "residuals": res_total, "control_points": int(solver.n_cp), "unknowns": int(9 + 6 * solver.n_cp),
+        "intrinsics_rel_err_after": float(np.abs(x[:4] / SV.GT_INTR[:4] - 1).max()),
+        "kernel_ms": {"normal_equations": round(jac_ms, 4), "cost_only": round(cost_ms, 4)},
+        "roofline_hbm": {"algorithmic_bytes_per_residual_iteration": 64, "achieved_GBs":
+                         round(64.0 * n_res * (iters / el) / 1e9, 2), "peak_GBs": HBM_PEAK_GBS},
+        "roofline_fp64": {"kernel": "normal_eq_kernel", "flop_per_residual": FLOP_JAC,
+                          "achieved_TFLOPs": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 1e12, 3), "peak_TFLOPs": 78.6,
+                          "frac": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 78.6e12, 4)},
+        "sharding": "one spline segment (time range) per GPU, shared intrinsics, all-reduce of the normal-equation "
+                    "buffer per evaluation" if world > 1 else "single GPU",
+    }
+    if rank == 0 and args.solver_cpu_sample > 0 and world == 1:
+        import oracle_lib as O
+        m = min(args.solver_cpu_sample, n_res)
+        small, xs = ST.make_problem(m, 40, t0, t0 + 1.0, seed=5, device="cpu")
+        tc = time.perf_counter()
+        O.solver_evaluate(small, xs, want_H=False)
+        cel = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": round(m / cel, 1), "unit": "residual Jacobian evaluations/s", "cores": 1,
+                               "kind": "port", "sample": "%d residuals, dual-number Jacobian + gradient accumulation, "
+                               "1 thread, %.1f s" % (m, cel),
+                               "implied_iterations_per_s_on_this_problem": round(m / cel / (2 * n_res), 6)}
+    solver.close()
+    return out
+
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
-    "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_detect_batch",
+    "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
@@ -68,6 +68,8 @@ def load_library():
     L.ecal_circle_radius_threshold.restype = f64
     L.ecal_extract_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f64, vp, vp, vp, vp, vp, vp]
     L.ecal_extract_batch_dev.restype = i32
+    L.ecal_copy_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, i32]
+    L.ecal_copy_dev.restype = i32
     _LIB = L
     return L
 
@@ -320,3 +322,31 @@ def unpack_normal(acc, n_cp):
                 H[r0:r0 + 6, c1:c1 + 6] = blk
                 H[c1:c1 + 6, r0:r0 + 6] = blk.T
     return acc[0], g, H
+
+
+def make_allreduce_hook(ctx: Context, world_size):
+    """ALLREDUCE_FN for LmOptions.allreduce: sums the solver's device buffer over ranks with
+    torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" works for CPU-side tests of the
+    plumbing).  The buffer is staged through a torch tensor; full synchronisation on both sides keeps the
+    solver's private stream and torch's collective stream ordered."""
+    import torch
+    import torch.distributed as dist
+    state = {}
+
+    def hook(user, d_buf, n, stream):
+        try:
+            if world_size <= 1:
+                return 0
+            t = state.get(n)
+            if t is None:
+                t = state[n] = torch.empty(n, dtype=torch.float64, device=torch.device("cuda", ctx.device))
+            ctx._check(ctx._L.ecal_copy_dev(ctx._h, t.data_ptr(), d_buf, n * 8, stream, 1))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize(t.device)
+            ctx._check(ctx._L.ecal_copy_dev(ctx._h, d_buf, t.data_ptr(), n * 8, stream, 1))
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("allreduce hook failed:", e)
+            return 1
+
+    return ALLREDUCE_FN(hook)

@@ -134,3 +134,13 @@ extern "C" int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const dou
     }
     return ECAL_OK;
 }
+
+// device-to-device copy on a stream (lets the Python all-reduce hook move the solver's buffer in and
+// out of a torch tensor without any other HIP binding)
+extern "C" int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream, int sync) {
+    if (!ctx || (bytes && (!d_dst || !d_src))) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (bytes) ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream));
+    if (sync) ECAL_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t) stream));
+    return ECAL_OK;
+}

@@ -177,6 +177,8 @@ typedef struct ecal_detect_result {
 int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t n_events, ecal_stream **out);
 void ecal_stream_destroy(ecal_stream *s);
 uint64_t ecal_stream_size(const ecal_stream *s);
+/* device-to-device copy on `stream` (optionally followed by a stream synchronise) */
+int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream, int sync);
 int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const double *t0, const double *t1, uint32_t S,
                       const ecal_detect_params *prm, uint32_t cap_points, ecal_detect_result *res);
 
