@@ -160,9 +160,21 @@ def main():
         dom = int(np.argmax(stage_ms))
         names = ["window_bounds", "slice_lds_kernel", "dbscan_lds_kernel<1024,256>", "extract_kernel"]
         achieved = ALGO_BYTES_PER_EVENT * n_events / (stage_ms[dom] * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
+        # committed profile (tools/pmc_traffic.py over two rocprofv3 --pmc passes of this same command) is
+        # quoted when it was taken on the same workload size, else null
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            key = {2: "ecal::dbscan_lds_kernel<1024, 256>", 1: "ecal::slice_lds_kernel<2048, 2048, 256>",
+                   3: "ecal::extract_kernel"}.get(dom)
+            if tr.get("events") == n_events and key in tr["kernels"]:
+                traffic = tr["kernels"][key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out["roofline"] = {
             "bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_events,
             "kernel_ms": round(float(stage_ms[dom]), 4),
             "stage_ms": {"window_bounds": round(float(stage_ms[0]), 4), "slice": round(float(stage_ms[1]), 4),
