@@ -1,0 +1,182 @@
+// Event -> (keyframe, circle) association that builds the solver's residual records.
+//
+// Replaces the loop of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:158-192):
+// for every event with spline.front <= t <= spline.back, the keyframe nearest in time (1-D nanoflann
+// tree, :140-154,166) accepted if dt^2 < (5 * MotionTimeStep)^2 (:168), then
+// CirclesEventFrame::findCenter (include/.../CirclesEventFrame.hpp:50-65): nearest circle centre of that
+// keyframe, accepted if |dist - radius| < 5 px; the event then becomes one residual (pixel, time,
+// landmark of that circle).  Output order = event (time) order, as relationContainer_ (:181-183).
+// Ties (equidistant keyframes / centres) go to the smaller index; nanoflann's choice is unpinned.
+#include "ecal_ctx.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ecal {
+
+constexpr int AS_T = 256;
+constexpr int AS_PER = 4;  // events per thread -> 1024 events per block
+
+__device__ __forceinline__ double load_f64_u(const uint8_t *p) {
+    double v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// returns the circle index or -1
+__device__ __forceinline__ int associate_one(double t, double x, double y, const double *kf_time, const double *circles,
+                                             uint32_t K, uint32_t n_circ, double t_min, double t_max, double max_dt2,
+                                             double edge_tol) {
+    if (!(t >= t_min && t <= t_max) || K == 0) return -1;
+    // nearest keyframe in time: first index with kf_time >= t, compare with its predecessor
+    uint32_t a = 0, b = K;
+    while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (kf_time[m] < t) a = m + 1; else b = m;
+    }
+    uint32_t k = a;
+    if (a == K) k = K - 1;
+    else if (a > 0) {
+        const double d0 = t - kf_time[a - 1], d1 = kf_time[a] - t;
+        if (d0 * d0 <= d1 * d1) k = a - 1;
+    }
+    const double dt = t - kf_time[k];
+    if (!(dt * dt < max_dt2)) return -1;
+    const double *c = circles + 3 * (size_t) k * n_circ;
+    double best = 1.79769313486231570e308;
+    int bi = -1;
+    for (uint32_t i = 0; i < n_circ; i++) {
+        const double dx = x - c[3 * i], dy = y - c[3 * i + 1];
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < best) {
+            best = d2;
+            bi = (int) i;
+        }
+    }
+    if (bi < 0) return -1;
+    const double dis = __dsqrt_rn(best);
+    return (fabs(dis - c[3 * bi + 2]) < edge_tol) ? bi : -1;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(AS_T) void associate_kernel(const uint8_t *__restrict__ rec, uint64_t n,
+                                                         const double *__restrict__ kf_time,
+                                                         const double *__restrict__ circles, uint32_t K,
+                                                         uint32_t n_circ, double t_min, double t_max, double max_dt2,
+                                                         double edge_tol, uint32_t *__restrict__ block_cnt,
+                                                         const uint32_t *__restrict__ block_off,
+                                                         double *__restrict__ obs, double *__restrict__ time,
+                                                         uint32_t *__restrict__ lm) {
+    __shared__ uint32_t wsum[AS_T / 64];
+    const uint64_t base = (uint64_t) blockIdx.x * (AS_T * AS_PER) + (uint64_t) threadIdx.x * AS_PER;
+    int hit[AS_PER];
+    double tt[AS_PER], xx[AS_PER], yy[AS_PER];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < AS_PER; e++) {
+        hit[e] = -1;
+        const uint64_t i = base + e;
+        if (i < n) {
+            const uint8_t *r = rec + i * 25;
+            tt[e] = load_f64_u(r);
+            xx[e] = load_f64_u(r + 8);
+            yy[e] = load_f64_u(r + 16);
+            hit[e] = associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, t_min, t_max, max_dt2, edge_tol);
+            mine += hit[e] >= 0 ? 1u : 0u;
+        }
+    }
+    // exclusive scan of `mine` over the block (thread order = event order)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (int w = 0; w < AS_T / 64; w++) {
+        if (w < wave) pre += wsum[w];
+        tot += wsum[w];
+    }
+    if (!WRITE) {
+        if (threadIdx.x == 0) block_cnt[blockIdx.x] = tot;
+        return;
+    }
+    uint64_t at = (uint64_t) block_off[blockIdx.x] + pre + inc - mine;
+#pragma unroll
+    for (int e = 0; e < AS_PER; e++) {
+        if (hit[e] >= 0) {
+            obs[2 * at] = xx[e];
+            obs[2 * at + 1] = yy[e];
+            time[at] = tt[e];
+            lm[at] = (uint32_t) hit[e];
+            at++;
+        }
+    }
+}
+
+// exclusive scan of the per-block counts; off[n_blocks] = total.  One workgroup.
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__restrict__ cnt, uint32_t nb,
+                                                           uint32_t *__restrict__ off) {
+    __shared__ uint32_t red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < nb ? cnt[b] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) red[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) pre += red[w];
+            tot += red[w];
+        }
+        if (b < nb) off[b] = carry + pre + inc - v;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nb] = carry;
+}
+
+}  // namespace ecal
+
+using namespace ecal;
+
+extern "C" int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
+                                  const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, double t_min,
+                                  double t_max, double max_dt, double edge_tol, double *d_obs, double *d_time,
+                                  uint32_t *d_lm_id, uint32_t *d_count, void *stream) {
+    if (!ctx || !d_count) return ECAL_ERR_INVALID;
+    if (n_events > 0xFFFFFFFFull) return ECAL_ERR_RANGE;
+    if (n_events && (!d_events || !d_obs || !d_time || !d_lm_id)) return ECAL_ERR_INVALID;
+    if (n_keyframes && (!d_kf_time || !d_kf_circles)) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t) stream;
+    const uint32_t nb = (uint32_t) ((n_events + AS_T * AS_PER - 1) / (AS_T * AS_PER));
+    if (nb == 0) {
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
+        return ECAL_OK;
+    }
+    int rc;
+    if ((rc = ecal_ensure(ctx, ctx->as_cnt, (size_t) nb * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->as_off, ((size_t) nb + 1) * sizeof(uint32_t)))) return rc;
+    uint32_t *cnt = (uint32_t *) ctx->as_cnt.ptr, *off = (uint32_t *) ctx->as_off.ptr;
+    const double md2 = max_dt * max_dt;
+    hipLaunchKernelGGL((associate_kernel<false>), dim3(nb), dim3(AS_T), 0, st, d_events, n_events, d_kf_time,
+                       d_kf_circles, n_keyframes, n_circles, t_min, t_max, md2, edge_tol, cnt, off, d_obs, d_time,
+                       d_lm_id);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, cnt, nb, off);
+    hipLaunchKernelGGL((associate_kernel<true>), dim3(nb), dim3(AS_T), 0, st, d_events, n_events, d_kf_time,
+                       d_kf_circles, n_keyframes, n_circles, t_min, t_max, md2, edge_tol, cnt, off, d_obs, d_time,
+                       d_lm_id);
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_count, off + nb, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}

@@ -26,12 +26,13 @@ struct ecal_ctx {
     ecal_devbuf big_slot, big_anc, big_cur, big_inv, big_cs, big_flags;    // global-scratch tier of DBSCAN
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
     ecal_devbuf det_members, det_koff, det_ksize, det_sorted, det_norms;  // detection stage scratch
+    ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
     bool attrs_set = false, slice_attrs_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos,
-                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms,
+                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &as_cnt, &as_off,
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
                 &host_pipe[6], &host_pipe[7], &host_pipe[8], &host_pipe[9], &host_pipe[10], &host_pipe[11],
                 &host_pipe[12], &host_pipe[13], &host_pipe[14], &host_pipe[15], &host_pipe[16]};

@@ -182,6 +182,20 @@ int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, v
 int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const double *t0, const double *t1, uint32_t S,
                       const ecal_detect_params *prm, uint32_t cap_points, ecal_detect_result *res);
 
+/* ---- event -> residual association ----------------------------------------------------------------
+ * Replaces the association loop of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
+ * 140-192) and CirclesEventFrame::findCenter (include/opengv2/event_camera_calib/CirclesEventFrame.hpp:50-65):
+ * every event with t_min <= t <= t_max (the spline's range) looks up the keyframe nearest in time
+ * (d_kf_time ascending, accepted if |dt| < max_dt = 5 * MotionTimeStep) and that keyframe's nearest circle
+ * centre (d_kf_circles [K][n_circles][3] = cx, cy, radius in pixels, grid order), accepted if
+ * | |pixel - centre| - radius | < edge_tol (5 px).  Accepted events are written in event order:
+ * d_obs[j] = pixel, d_time[j] = t, d_lm_id[j] = circle index (= landmark index); *d_count = how many
+ * (outputs need room for n_events entries).  These arrays are ecal_spline_problem's obs/time/lm_id. */
+int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
+                       const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, double t_min, double t_max,
+                       double max_dt, double edge_tol, double *d_obs, double *d_time, uint32_t *d_lm_id,
+                       uint32_t *d_count, void *stream);
+
 /* ---- continuous-time calibration solve ---------------------------------------------------------
  * Replaces the Ceres problem of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
  * 196-247) for the quaternion-spline variant (useSO3 = 0): one residual per associated event,

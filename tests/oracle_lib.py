@@ -262,3 +262,23 @@ def inverse_radial(k4):
     b = np.zeros(5)
     L.oracle_inverse_radial(_p(k, _dp), _p(b, _dp))
     return b
+
+
+def associate(rec, kf_time, circles, t_min, t_max, max_dt, edge_tol):
+    """EventCalibSpline association: returns (obs [m,2], time [m], lm_id [m])."""
+    L = lib()
+    L.oracle_associate.argtypes = [_u8p, ctypes.c_uint64, _dp, _dp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double,
+                                   ctypes.c_double, ctypes.c_double, ctypes.c_double, _dp, _dp, _u32p]
+    L.oracle_associate.restype = ctypes.c_uint64
+    rec = np.ascontiguousarray(rec, np.uint8)
+    n = rec.size // 25
+    kf = np.ascontiguousarray(kf_time, np.float64)
+    ci = np.ascontiguousarray(circles, np.float64)
+    K = kf.shape[0]
+    nc = ci.reshape(K, -1, 3).shape[1] if K else 0
+    obs = np.zeros((max(n, 1), 2))
+    tm = np.zeros(max(n, 1))
+    lm = np.zeros(max(n, 1), np.uint32)
+    m = L.oracle_associate(_p(rec, _u8p), n, _p(kf, _dp), _p(ci, _dp), K, nc, float(t_min), float(t_max), float(max_dt),
+                           float(edge_tol), _p(obs, _dp), _p(tm, _dp), _p(lm, _u32p))
+    return obs[:m].copy(), tm[:m].copy(), lm[:m].copy()
