@@ -16,9 +16,23 @@ struct TierLayout {
     static constexpr size_t cur_off = anc_off + sizeof(uint16_t) * 4 * CAP;
     static constexpr size_t inv_off = cur_off + sizeof(uint16_t) * CAP;
     static constexpr size_t red_off = inv_off + sizeof(uint16_t) * CAP;
-    static constexpr size_t edges_off = red_off + sizeof(uint32_t) * 48;
+    static constexpr size_t edges_off = red_off + sizeof(uint32_t) * 48;  // red: 32 scan, 36 edge count, 40-42 any flags, 44-47 bbox
     static constexpr size_t sflags_off = edges_off + sizeof(uint32_t) * 2 * EDGE_CAP;
-    static constexpr size_t bytes = sflags_off + ((CAP + 15) / 16) * 16;
+    // pixel bitmap of the int16 path: only the 1024-point tier carries it (the larger tiers would lose
+    // a workgroup per CU to the extra LDS; their segments take the grid path).  In the int16 path the
+    // points take 4 of the 16 bytes per point of the coordinate region; its tail holds the bitmap's
+    // per-word prefix counts, the row starts, the one-way edge list and the per-point flags, and the
+    // bitmap itself starts where the f64 path keeps its edge list and flags.
+    static constexpr bool has_bitmap = CAP <= 1024;
+    static constexpr size_t f64_end = sflags_off + ((CAP + 15) / 16) * 16;
+    static constexpr size_t wpre_off = c_off + sizeof(uint32_t) * CAP;
+    static constexpr size_t rowstart_off = wpre_off + sizeof(uint16_t) * BM_WORDS;
+    static constexpr size_t i16_edges_off = rowstart_off + sizeof(uint16_t) * 512;
+    static constexpr size_t i16_sflags_off = i16_edges_off + sizeof(uint32_t) * 2 * EDGE_CAP;
+    static constexpr size_t bm_off = edges_off;
+    static constexpr size_t i16_end = bm_off + sizeof(uint32_t) * BM_WORDS;
+    static constexpr size_t bytes = (has_bitmap && i16_end > f64_end) ? i16_end : f64_end;
+    static_assert(!has_bitmap || i16_sflags_off + CAP <= slot_off, "int16 side tables must fit the coordinate region");
     static_assert(slot_off % 16 == 0 && anc_off % 16 == 0 && cur_off % 16 == 0 && inv_off % 16 == 0 &&
                   red_off % 16 == 0 && edges_off % 16 == 0, "align");
 };
@@ -87,9 +101,12 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
         w.pid_s = reinterpret_cast<uint16_t *>(smem + L::cur_off);
         w.inv = reinterpret_cast<uint16_t *>(smem + L::inv_off);
         w.red = red;
-        w.edges = reinterpret_cast<uint32_t *>(smem + L::edges_off);
-        w.sflags = reinterpret_cast<uint8_t *>(smem + L::sflags_off);
+        w.edges = reinterpret_cast<uint32_t *>(smem + (L::has_bitmap ? L::i16_edges_off : L::edges_off));
+        w.sflags = reinterpret_cast<uint8_t *>(smem + (L::has_bitmap ? L::i16_sflags_off : L::sflags_off));
         w.pflags = nullptr;
+        w.bm = L::has_bitmap ? reinterpret_cast<uint32_t *>(smem + L::bm_off) : nullptr;
+        w.wpre = reinterpret_cast<uint16_t *>(smem + L::wpre_off);
+        w.rowstart = reinterpret_cast<uint16_t *>(smem + L::rowstart_off);
 #pragma unroll
         for (int u = 0; u < PPT; u++)
             if (threadIdx.x + u * T < n) pts[threadIdx.x + u * T] = GeoI16::pack(mine[u]);
@@ -108,6 +125,9 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
         w.edges = reinterpret_cast<uint32_t *>(smem + L::edges_off);
         w.sflags = reinterpret_cast<uint8_t *>(smem + L::sflags_off);
         w.pflags = nullptr;
+        w.bm = nullptr;
+        w.wpre = nullptr;
+        w.rowstart = nullptr;
 #pragma unroll
         for (int u = 0; u < PPT; u++)
             if (threadIdx.x + u * T < n) pts[threadIdx.x + u * T] = mine[u];
@@ -145,6 +165,9 @@ __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restr
     w.edges = edges;
     w.sflags = gflags + 2 * base;
     w.pflags = gflags + 2 * base + n;
+    w.bm = nullptr;
+    w.wpre = nullptr;
+    w.rowstart = nullptr;
     // nb = largest power of two <= n/2 (>= 2048 here) so that label[n] + 1 + cursor[nb] fits slot[2n]
     uint32_t nb_log = 31u - (uint32_t) __clz((int) (n >> 1));
     if (nb_log > 20u) nb_log = 20u;

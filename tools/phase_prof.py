@@ -6,8 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 src = os.path.join(ROOT, "eventcalib_amd", "csrc")
 out = "/tmp/libecal_prof.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                       "-DECAL_PHASE_PROF", "-shared", "-o", out] + [os.path.join(src, f) for f in
-                       ("ecal_capi.hip", "ecal_dbscan.hip", "ecal_events.hip")])
+                       "-DECAL_PHASE_PROF", "-shared", "-o", out] + sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith(".hip")))
 import numpy as np, torch
 import eventcalib_amd.capi as capi
 capi.lib_path = lambda: out
@@ -26,9 +25,9 @@ L.ecal_debug_phase_cycles(buf, 1)
 pipe.run(ev, max_win_events=2000, max_seg_points=1000); torch.cuda.synchronize()
 L.ecal_debug_phase_cycles(buf, 1)
 v = list(buf); wg = max(v[10], 1)
-names = ["B kd-bounds", "C cell sort", "D count", "E labels", "F rank"]
-tot = sum(v[:5])
+names = ["B kd-bounds", "C cell sort / bitmap build", "D count", "E labels (grid E.1 + E.2/3)", "F rank", "bitmap ranks", "bitmap E.1"]
+tot = sum(v[:7])
 for i, nm in enumerate(names):
-    print("%-12s %10.0f cycles/WG  %5.1f %%" % (nm, v[i] / wg, 100.0 * v[i] / tot))
+    print("%-28s %10.0f cycles/WG  %5.1f %%" % (nm, v[i] / wg, 100.0 * v[i] / tot))
 print("D: candidate visits/WG %.0f (per point %.1f)   wave-steps/WG %.0f (x64 = %.0f lane slots)" % (v[12]/wg, v[12]/wg/578.0, v[13]/wg, 64*v[13]/wg))
 print("levels/WG %.1f  sweeps/WG %.2f  WGs %d  total cycles/WG %.0f" % (v[8] / wg, v[9] / wg, wg, tot / wg))
