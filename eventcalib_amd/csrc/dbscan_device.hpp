@@ -686,6 +686,7 @@ __device__ __forceinline__ uint32_t dbscan_segment(const DbWork<Idx, G> wk, cons
             }
         }
         __syncthreads();
+        ECAL_PHASE_MARK(12);  // init + B.0
         // B.1 every later point walks down the finished top tree (reads only) to its first free slot
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
@@ -715,6 +716,7 @@ __device__ __forceinline__ uint32_t dbscan_segment(const DbWork<Idx, G> wk, cons
             if (i < n && i >= KTOP) atomicMin(&slot[2 * (st[u] & R::MASK) + ((st[u] & R::SIDE) ? 1u : 0u)], i);
         }
         __syncthreads();
+        ECAL_PHASE_MARK(13);  // B.1 walk + first bids
         // B.2 level-synchronous bidding below the top tree
         for (;;) {
             bool active = false;
@@ -727,6 +729,7 @@ __device__ __forceinline__ uint32_t dbscan_segment(const DbWork<Idx, G> wk, cons
 #endif
             if (!block_any(active, anyf, any_round)) break;
         }
+        ECAL_PHASE_MARK(14);  // B.2
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
             const uint32_t i = tid + u * T;

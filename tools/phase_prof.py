@@ -26,8 +26,9 @@ pipe.run(ev, max_win_events=2000, max_seg_points=1000); torch.cuda.synchronize()
 L.ecal_debug_phase_cycles(buf, 1)
 v = list(buf); wg = max(v[10], 1)
 names = ["B kd-bounds", "C cell sort / bitmap build", "D count", "E labels (grid E.1 + E.2/3)", "F rank", "bitmap ranks", "bitmap E.1"]
-tot = sum(v[:7])
+tot = sum(v[:7]) + v[12] + v[13] + v[14]
 for i, nm in enumerate(names):
     print("%-28s %10.0f cycles/WG  %5.1f %%" % (nm, v[i] / wg, 100.0 * v[i] / tot))
+print("B split: init+B.0 %.0f  B.1 %.0f  B.2 %.0f  (rest = anc/flags)" % (v[12]/wg, v[13]/wg, v[14]/wg))
 print("D: candidate visits/WG %.0f (per point %.1f)   wave-steps/WG %.0f (x64 = %.0f lane slots)" % (v[12]/wg, v[12]/wg/578.0, v[13]/wg, 64*v[13]/wg))
 print("levels/WG %.1f  sweeps/WG %.2f  WGs %d  total cycles/WG %.0f" % (v[8] / wg, v[9] / wg, wg, tot / wg))
