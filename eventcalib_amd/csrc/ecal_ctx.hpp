@@ -28,7 +28,7 @@ struct ecal_ctx {
     ecal_devbuf det_members, det_koff, det_ksize, det_sorted, det_norms;  // detection stage scratch
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
-    bool attrs_set = false, slice_attrs_set = false;
+    bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos,

@@ -17,7 +17,9 @@
 namespace ecal {
 
 constexpr int DET_T = 256;
-constexpr uint32_t DET_MAXC = 2048;  // DBSCAN clusters per polarity handled in LDS
+constexpr uint32_t DET_MAXC = 2048;       // DBSCAN clusters per polarity the kernel handles at all
+constexpr uint32_t DET_LDS_PTS = 1408;    // points per window (both polarities) staged in LDS (3 workgroups/CU) ...
+constexpr uint32_t DET_LDS_MAXC = 1024;   // ... when neither polarity has more DBSCAN clusters than this
 
 struct DetectParams {
     uint32_t cluster_min;    // clusterMinSample
@@ -27,50 +29,37 @@ struct DetectParams {
 
 __device__ __forceinline__ double norm_of(double2 p) { return __dsqrt_rn(p.x * p.x + p.y * p.y); }  // Vector2d::norm()
 
-__global__ __launch_bounds__(DET_T) void extract_kernel(
-    const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
-    const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
-    uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
-    int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
-    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
-    double *__restrict__ norms) {
-    __shared__ uint32_t csize[DET_MAXC];  // members per DBSCAN cluster; later a scatter cursor
-    __shared__ uint32_t newid[DET_MAXC];  // renumbered id of a kept cluster
-    __shared__ uint32_t coff[DET_MAXC];   // first member slot of a kept cluster
-    __shared__ unsigned long long red[DET_T / 64];
-    __shared__ uint32_t nk_sh[2];
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
-    const double2 *pts = reinterpret_cast<const double2 *>(xy);
-    uint32_t *info = win_info + 4 * (size_t) s;
-    const uint32_t o_pol[2] = {seg_off[2 * s], seg_off[2 * s + 1]};
-    const uint32_t n_pol[2] = {seg_cnt[2 * s], seg_cnt[2 * s + 1]};
+// Per-window working set: either staged in LDS (16-bit indices, points copied in) or in global scratch.
+// All indices are window-local: point i of polarity pol lives at base[pol] + i, kept cluster k likewise.
+struct DetGlobal {
+    const double2 *pts;  // + window slot offset applied by the caller
+    uint32_t *members, *sorted, *koff, *ksize, *rep;
+    int32_t *kept;
+    double *norms;
+    __device__ __forceinline__ double2 pt(uint32_t li) const { return pts[li]; }
+    __device__ __forceinline__ double norm(uint32_t li) const { return norms[li]; }
+    __device__ __forceinline__ void set_norm(uint32_t li, double v) const { norms[li] = v; }
+};
+struct DetLds {
+    double2 *pts;
+    uint16_t *members, *sorted, *koff, *ksize, *rep;
+    int16_t *kept;
+    __device__ __forceinline__ double2 pt(uint32_t li) const { return pts[li]; }
+    __device__ __forceinline__ double norm(uint32_t li) const { return norm_of(pts[li]); }
+    __device__ __forceinline__ void set_norm(uint32_t, double) const {}
+};
 
-    if (n_pol[0] == 0 || n_pol[1] == 0) {  // CirclesEventFrame.cpp:62-64
-        for (int pol = 0; pol < 2; pol++)
-            for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) kept_labels[o_pol[pol] + i] = -1;
-        if (tid == 0) {
-            info[0] = 0;
-            info[1] = 0;
-            info[2] = 0;
-            info[3] = 1;
-        }
-        return;
-    }
-    if (n_clusters[2 * s] > DET_MAXC || n_clusters[2 * s + 1] > DET_MAXC) {
-        for (int pol = 0; pol < 2; pol++)
-            for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) kept_labels[o_pol[pol] + i] = -1;
-        if (tid == 0) {
-            info[0] = 0;
-            info[1] = 0;
-            info[2] = 0;
-            info[3] = 4;  // capacity exceeded (more than DET_MAXC clusters in one polarity)
-        }
-        return;
-    }
-
+// base[pol]: window-local offset of the polarity's points (and of its kept-cluster arrays).
+template <typename ST>
+__device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&base)[2], const uint32_t (&n_pol)[2],
+                                               const int32_t *lab0, const int32_t *lab1, const uint32_t (&nc_pol)[2],
+                                               const DetectParams &prm, uint32_t *csize, uint32_t *newid, uint32_t *coff,
+                                               unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
+                                               uint32_t *cand_pair, double *cand_xyr) {
+    const uint32_t tid = threadIdx.x;
     for (int pol = 0; pol < 2; pol++) {
-        const uint32_t o = o_pol[pol], n = n_pol[pol], nc = n_clusters[2 * s + pol];
-        const int32_t *lab = labels + o;
+        const uint32_t o = base[pol], n = n_pol[pol], nc = nc_pol[pol];
+        const int32_t *lab = pol ? lab1 : lab0;
         for (uint32_t c = tid; c < nc; c += DET_T) csize[c] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < n; i += DET_T) {
@@ -94,8 +83,8 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
                 if (csize[c] >= prm.cluster_min) {
                     newid[c] = ek;
                     coff[c] = em;
-                    koff[o + ek] = em;
-                    ksize[o + ek] = csize[c];
+                    st.koff[o + ek] = em;
+                    st.ksize[o + ek] = csize[c];
                     ek++;
                     em += csize[c];
                 } else {
@@ -112,10 +101,10 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
             if (l >= 0 && newid[l] != 0xFFFFFFFFu) {
                 kl = (int32_t) newid[l];
                 const uint32_t at = atomicSub(&csize[l], 1u) - 1u;
-                members[o + coff[l] + at] = i;
-                norms[o + i] = norm_of(pts[o + i]);
+                st.members[o + coff[l] + at] = i;
+                st.set_norm(o + i, norm_of(st.pt(o + i)));
             }
-            kept_labels[o + i] = kl;
+            st.kept[o + i] = kl;
         }
         __syncthreads();
     }
@@ -132,24 +121,22 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     // One scan of its cluster per kept point gives (a) its rank in the order (norm, pid): rank
     // size/2 is the representative (:136-147), and (b) its position in ascending-pid order, which
     // turns the scattered member list into a sorted one.
-    // members, kept_labels, koff, ksize, norms were written by this workgroup: visible after the barrier.
     for (int pol = 0; pol < 2; pol++) {
-        const uint32_t o = o_pol[pol], n = n_pol[pol];
+        const uint32_t o = base[pol], n = n_pol[pol];
         for (uint32_t i = tid; i < n; i += DET_T) {
-            const int32_t kl = kept_labels[o + i];
+            const int32_t kl = st.kept[o + i];
             if (kl < 0) continue;
-            const uint32_t m = ksize[o + kl], first = o + koff[o + kl];
-            const uint32_t *mem = members + first;
-            const double ni = norms[o + i];
+            const uint32_t m = st.ksize[o + kl], first = o + st.koff[o + kl];
+            const double ni = st.norm(o + i);
             uint32_t rank = 0, at = 0;
             for (uint32_t t = 0; t < m; t++) {
-                const uint32_t j = mem[t];
-                const double nj = norms[o + j];
+                const uint32_t j = st.members[first + t];
+                const double nj = st.norm(o + j);
                 rank += (nj < ni || (nj == ni && j < i)) ? 1u : 0u;
                 at += (j < i) ? 1u : 0u;
             }
-            if (rank == m / 2) rep[o + kl] = i;
-            sorted[first + at] = i;
+            if (rank == m / 2) st.rep[o + kl] = i;
+            st.sorted[first + at] = i;
         }
     }
     __syncthreads();
@@ -161,10 +148,10 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         uint32_t ni_best = 0;
         double cx = 0, cy = 0, r = 0;
         if (pi < nk[0]) {
-            const double2 pc = pts[o_pol[0] + rep[o_pol[0] + pi]];
+            const double2 pc = st.pt(base[0] + st.rep[base[0] + pi]);
             double bd = 1.79769313486231570e308;
             for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
-                const double2 c = pts[o_pol[1] + rep[o_pol[1] + k]];
+                const double2 c = st.pt(base[1] + st.rep[base[1] + k]);
                 const double dx = pc.x - c.x, dy = pc.y - c.y;
                 const double d = dx * dx + dy * dy;
                 if (d < bd) {
@@ -173,11 +160,11 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
                 }
             }
             if (!(bd > prm.four_thr2)) {  // :286
-                const double2 nc = pts[o_pol[1] + rep[o_pol[1] + ni_best]];
+                const double2 nc = st.pt(base[1] + st.rep[base[1] + ni_best]);
                 double bd2 = 1.79769313486231570e308;
                 uint32_t back = 0;
                 for (uint32_t k = 0; k < nk[0]; k++) {
-                    const double2 c = pts[o_pol[0] + rep[o_pol[0] + k]];
+                    const double2 c = st.pt(base[0] + st.rep[base[0] + k]);
                     const double dx = nc.x - c.x, dy = nc.y - c.y;
                     const double d = dx * dx + dy * dy;
                     if (d < bd2) {
@@ -193,11 +180,10 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
                     double fit = 0;
                     uint32_t cnt = 0;
                     for (int pol = 0; pol < 2; pol++) {
-                        const uint32_t o = o_pol[pol], kk = pol ? ni_best : pi;
-                        const uint32_t m = ksize[o + kk];
-                        const uint32_t *mem = sorted + o + koff[o + kk];  // ascending pid
-                        for (uint32_t t = 0; t < m; t++) {
-                            const double2 e = pts[o + mem[t]];
+                        const uint32_t o = base[pol], kk = pol ? ni_best : pi;
+                        const uint32_t m = st.ksize[o + kk], first = o + st.koff[o + kk];
+                        for (uint32_t t = 0; t < m; t++) {  // ascending pid
+                            const double2 e = st.pt(o + st.sorted[first + t]);
                             const double ex = e.x - cx, ey = e.y - cy;
                             fit += fabs(__dsqrt_rn(ex * ex + ey * ey) - r);
                         }
@@ -211,7 +197,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         uint32_t ex, dummy, tot, dummy2;
         block_exscan_pair<DET_T>(ok ? 1u : 0u, 0u, red, &ex, &dummy, &tot, &dummy2);
         if (ok) {
-            const size_t at = (size_t) o_pol[0] + carry + ex;
+            const size_t at = (size_t) carry + ex;
             cand_pair[2 * at] = pi;
             cand_pair[2 * at + 1] = ni_best;
             cand_xyr[3 * at] = cx;
@@ -227,6 +213,89 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         info[3] = 0;
     }
 }
+
+__global__ __launch_bounds__(DET_T) void extract_kernel(
+    const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+    const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
+    uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
+    int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
+    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
+    double *__restrict__ norms) {
+    // csize: members per DBSCAN cluster, later a scatter cursor; newid: renumbered id of a kept cluster;
+    // coff: first member slot of a kept cluster.  Sized for the global path; the LDS path uses the first
+    // DET_LDS_MAXC entries and the rest of the block for its staged arrays.
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long red[DET_T / 64];
+    __shared__ uint32_t nk_sh[2];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const double2 *pts = reinterpret_cast<const double2 *>(xy);
+    uint32_t *info = win_info + 4 * (size_t) s;
+    const uint32_t o_pol[2] = {seg_off[2 * s], seg_off[2 * s + 1]};
+    const uint32_t n_pol[2] = {seg_cnt[2 * s], seg_cnt[2 * s + 1]};
+    const uint32_t nc_pol[2] = {n_clusters[2 * s], n_clusters[2 * s + 1]};
+
+    if (n_pol[0] == 0 || n_pol[1] == 0 || nc_pol[0] > DET_MAXC || nc_pol[1] > DET_MAXC) {
+        // empty polarity: CirclesEventFrame.cpp:62-64; otherwise capacity exceeded (status 4)
+        for (int pol = 0; pol < 2; pol++)
+            for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) kept_labels[o_pol[pol] + i] = -1;
+        if (tid == 0) {
+            info[0] = 0;
+            info[1] = 0;
+            info[2] = 0;
+            info[3] = (n_pol[0] == 0 || n_pol[1] == 0) ? 1 : 4;
+        }
+        return;
+    }
+    // the window's slots are contiguous: positives then negatives (ecal_slice_events_dev layout) — if not,
+    // or if the window is too large, work in global scratch
+    const bool contiguous = o_pol[1] == o_pol[0] + n_pol[0];
+    const uint32_t n_all = n_pol[0] + n_pol[1];
+    const bool staged = contiguous && n_all <= DET_LDS_PTS && nc_pol[0] <= DET_LDS_MAXC && nc_pol[1] <= DET_LDS_MAXC;
+    uint32_t *csize = reinterpret_cast<uint32_t *>(smem);
+    if (staged) {
+        uint16_t *u16 = reinterpret_cast<uint16_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t));
+        DetLds st;
+        st.members = u16;
+        st.sorted = u16 + DET_LDS_PTS;
+        st.koff = u16 + 2 * DET_LDS_PTS;
+        st.ksize = u16 + 3 * DET_LDS_PTS;
+        st.rep = u16 + 4 * DET_LDS_PTS;
+        st.kept = reinterpret_cast<int16_t *>(u16 + 5 * DET_LDS_PTS);
+        st.pts = reinterpret_cast<double2 *>(u16 + 6 * DET_LDS_PTS);
+        for (uint32_t i = tid; i < n_all; i += DET_T) st.pts[i] = pts[o_pol[0] + i];
+        __syncthreads();
+        const uint32_t base[2] = {0u, n_pol[0]};
+        extract_window(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_LDS_MAXC,
+                       csize + 2 * DET_LDS_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
+                       cand_xyr + 3 * (size_t) o_pol[0]);
+        __syncthreads();
+        for (uint32_t i = tid; i < n_all; i += DET_T) kept_labels[o_pol[0] + i] = st.kept[i];
+        if (nk_sh[0] >= prm.need_clusters && nk_sh[1] >= prm.need_clusters) {  // representatives exist only then
+            for (int pol = 0; pol < 2; pol++)
+                for (uint32_t k = tid; k < nk_sh[pol]; k += DET_T) rep[o_pol[pol] + k] = st.rep[base[pol] + k];
+        }
+    } else {
+        DetGlobal st;
+        const uint32_t w0 = o_pol[0] < o_pol[1] ? o_pol[0] : o_pol[1];  // window-local indices relative to w0
+        st.pts = pts + w0;
+        st.members = members + w0;
+        st.sorted = sorted + w0;
+        st.koff = koff + w0;
+        st.ksize = ksize + w0;
+        st.rep = rep + w0;
+        st.kept = kept_labels + w0;
+        st.norms = norms + w0;
+        const uint32_t base[2] = {o_pol[0] - w0, o_pol[1] - w0};
+        extract_window(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_MAXC,
+                       csize + 2 * DET_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
+                       cand_xyr + 3 * (size_t) o_pol[0]);
+    }
+}
+
+constexpr size_t DET_LDS_BYTES_GLOBAL = 3 * DET_MAXC * sizeof(uint32_t);
+constexpr size_t DET_LDS_BYTES_STAGED = 3 * DET_LDS_MAXC * sizeof(uint32_t) + 6 * DET_LDS_PTS * sizeof(uint16_t) +
+                                        DET_LDS_PTS * sizeof(double2);
+constexpr size_t DET_LDS_BYTES = DET_LDS_BYTES_STAGED > DET_LDS_BYTES_GLOBAL ? DET_LDS_BYTES_STAGED : DET_LDS_BYTES_GLOBAL;
 
 }  // namespace ecal
 
@@ -276,7 +345,12 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
     prm.cluster_min = cluster_min;
     prm.need_clusters = need_clusters;
     prm.four_thr2 = 4 * radius_threshold * radius_threshold;
-    hipLaunchKernelGGL(extract_kernel, dim3(S), dim3(DET_T), 0, (hipStream_t) stream, d_xy, d_seg_off, d_seg_cnt,
+    if (!ctx->det_attr_set) {
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
+        ctx->det_attr_set = true;
+    }
+    hipLaunchKernelGGL(extract_kernel, dim3(S), dim3(DET_T), DET_LDS_BYTES, (hipStream_t) stream, d_xy, d_seg_off, d_seg_cnt,
                        d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
                        (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
                        (uint32_t *) ctx->det_ksize.ptr, (uint32_t *) ctx->det_sorted.ptr,

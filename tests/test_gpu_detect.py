@@ -101,3 +101,19 @@ def test_small_need_and_cluster_min(env):
     torch.cuda.synchronize()
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 3, 10, 40.0)
     assert exact >= 5
+
+
+def test_large_windows_use_the_global_scratch_path(env):
+    """Windows with more than 1408 unique pixels do not fit the LDS staging of extract_kernel."""
+    ctx, pipe, torch = env
+    buf = SS.make_stream(60000, rate=2.0e6, device="cpu", seed=12)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]), 3.0e-3)
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR)
+    pipe.run(buf.cuda())
+    torch.cuda.synchronize()
+    S = len(t0)
+    assert int((pipe.seg_cnt[:2 * S:2] + pipe.seg_cnt[1:2 * S:2]).max()) > 1408
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)
+    assert exact + tied >= 3
