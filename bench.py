@@ -287,7 +287,8 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
     FLOP_JAC = 2100.0            # per residual and Jacobian evaluation: ~700 residual+gradient, 45 tiles x 16 FMA x 2
     out = {
         "metric": "LM solver iterations/s", "value": round(iters / el, 3), "unit": "iterations/s",
-        "iterations": iters, "seconds": round(el, 4), "successful_steps": int(summ.successful_steps),
+        "iterations": iters, "seconds": round(el, 4), "seconds_evaluate": round(float(summ.seconds_evaluate), 4),
+        "seconds_linear_solve_host": round(float(summ.seconds_linear_solve), 4), "successful_steps": int(summ.successful_steps),
         "jacobian_evaluations": int(summ.jacobian_evaluations), "cost_evaluations": int(summ.cost_evaluations),
         "initial_cost": float(summ.initial_cost), "final_cost": float(summ.final_cost),
         "residuals": res_total, "control_points": int(solver.n_cp), "unknowns": int(9 + 6 * solver.n_cp),

@@ -199,7 +199,8 @@ class LmSummary(ctypes.Structure):
     _fields_ = [("iterations", ctypes.c_int), ("successful_steps", ctypes.c_int), ("unsuccessful_steps", ctypes.c_int),
                 ("jacobian_evaluations", ctypes.c_int), ("cost_evaluations", ctypes.c_int),
                 ("termination", ctypes.c_int), ("initial_cost", ctypes.c_double), ("final_cost", ctypes.c_double),
-                ("seconds", ctypes.c_double)]
+                ("seconds", ctypes.c_double), ("seconds_evaluate", ctypes.c_double),
+                ("seconds_linear_solve", ctypes.c_double)]
 
 
 def _declare_solver(L):

@@ -33,7 +33,8 @@ constexpr int NE_T = 256;   // threads per workgroup = rows per batch
 constexpr int NE_LD = 36;   // padded row: 33 Jacobian entries, the residual, 2 zeros
 constexpr int NE_TILES = 45;  // 4x4 tiles of the upper triangle of a 9x9 tile grid
 constexpr int NE_GROUPS = 5;  // row groups (5 * 45 = 225 accumulating threads)
-constexpr uint32_t NE_CHUNK = 4096;
+constexpr uint32_t NE_CHUNK = 16384;  // residuals per workgroup (one span): few, long chunks keep the FP64 atomics rare
+constexpr uint32_t NE_REPL = 64;      // replicas of the shared head (cost, intrinsics block) that the chunks add into
 
 // accumulation buffer: [0] cost | [1..9] g_intr | [10..90] H_intr (9x9, upper) | per control point c at
 // 91 + 204 c: g_c[6] | H_c,intr[6][9] | H_c,c+d[4][6][6] (d = 0..3; d = 0 upper only)
@@ -62,11 +63,14 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
                                                          const uint32_t *__restrict__ cp_off,
                                                          const double *__restrict__ params, uint32_t n_cp_total,
                                                          const double *__restrict__ landmarks, double radius,
-                                                         double huber_a, int with_jac, double *__restrict__ accum) {
+                                                         double huber_a, int with_jac, double *__restrict__ accum,
+                                                         double *__restrict__ heads) {
     extern __shared__ __attribute__((aligned(16))) double rows[];  // [NE_T][NE_LD] when with_jac
     __shared__ double red[NE_T / 64];
     const Chunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x;
+    // every chunk touches the cost and the 9x9 intrinsics block: spread those adds over NE_REPL copies
+    double *const head = heads + (size_t) (blockIdx.x % NE_REPL) * ACC_HEAD;
     const double *kn = knots + knot_off[ch.seg];
     const uint32_t c0 = cp_off[ch.seg] + ch.span - 3;
     const double *intr = params;
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
     if (tid == 0) {
         double c = 0;
         for (int w = 0; w < NE_T / 64; w++) c += red[w];
-        atomicAdd(&accum[0], c);
+        atomicAdd(&head[0], c);
     }
     if (!with_jac || grp >= NE_GROUPS) return;
     // flush this thread's tile into the global block storage
@@ -167,13 +171,13 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
             uint32_t ca, ka, cb, kb;
             local_to_unknown(li, c0, ia, ca, ka);
             if (lj == 33) {  // gradient J^T r
-                if (ia) atomicAdd(&accum[1 + ka], v);
+                if (ia) atomicAdd(&head[1 + ka], v);
                 else atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) ca + ka], v);
                 continue;
             }
             local_to_unknown(lj, c0, ib, cb, kb);
             if (ia && ib) {
-                atomicAdd(&accum[10 + 9 * ka + kb], v);
+                atomicAdd(&head[10 + 9 * ka + kb], v);
             } else if (ia) {  // intrinsics x control point
                 atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) cb + 6 + 9 * kb + ka], v);
             } else {
@@ -190,6 +194,15 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
     }
 }
 
+// accum[0..91) = sum over the replicas
+__global__ void reduce_heads_kernel(const double *__restrict__ heads, double *__restrict__ accum, uint32_t n_out) {
+    const uint32_t i = threadIdx.x;
+    if (i >= n_out) return;
+    double v = 0.0;
+    for (uint32_t r = 0; r < NE_REPL; r++) v += heads[(size_t) r * ACC_HEAD + i];
+    accum[i] = v;
+}
+
 }  // namespace ecal
 
 using namespace ecal;
@@ -203,7 +216,7 @@ struct ecal_solver {
     std::vector<double> knots;
     ResRecord *d_rec = nullptr;
     Chunk *d_chunks = nullptr;
-    double *d_knots = nullptr, *d_landmarks = nullptr, *d_params = nullptr, *d_accum = nullptr;
+    double *d_knots = nullptr, *d_landmarks = nullptr, *d_params = nullptr, *d_accum = nullptr, *d_heads = nullptr;
     uint32_t *d_knot_off = nullptr, *d_cp_off = nullptr;
     size_t n_params() const { return 9 + 7 * (size_t) n_cp; }
     size_t n_accum() const { return ACC_HEAD + ACC_PER_CP * (size_t) n_cp; }
@@ -212,7 +225,7 @@ struct ecal_solver {
 extern "C" void ecal_solver_destroy(ecal_solver *s) {
     if (!s) return;
     (void) hipSetDevice(s->ctx->device);
-    void *ptrs[] = {s->d_rec, s->d_chunks, s->d_knots, s->d_landmarks, s->d_params, s->d_accum, s->d_knot_off, s->d_cp_off};
+    void *ptrs[] = {s->d_rec, s->d_chunks, s->d_knots, s->d_landmarks, s->d_params, s->d_accum, s->d_heads, s->d_knot_off, s->d_cp_off};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
     delete s;
@@ -311,6 +324,7 @@ extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, e
     up((void **) &s->d_cp_off, s->cp_off.data(), s->cp_off.size() * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **) &s->d_params, s->n_params() * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **) &s->d_accum, s->n_accum() * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_heads, NE_REPL * ACC_HEAD * sizeof(double));
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
@@ -330,11 +344,14 @@ extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, 
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
     ECAL_HIP_TRY(ctx, hipMemsetAsync(d_accum, 0, (with_jacobian ? s->n_accum() : 1) * sizeof(double), st));
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(s->d_heads, 0, NE_REPL * ACC_HEAD * sizeof(double), st));
     if (s->n_chunks) {
         const size_t lds = with_jacobian ? NE_T * NE_LD * sizeof(double) : 0;
         hipLaunchKernelGGL(normal_eq_kernel, dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks, s->d_knots,
                            s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a,
-                           with_jacobian, d_accum);
+                           with_jacobian, d_accum, s->d_heads);
+        hipLaunchKernelGGL(reduce_heads_kernel, dim3(1), dim3(128), 0, st, s->d_heads, d_accum,
+                           with_jacobian ? (uint32_t) ACC_HEAD : 1u);
         ECAL_HIP_TRY(ctx, hipGetLastError());
     }
     return ECAL_OK;
@@ -400,58 +417,74 @@ void unpack(const double *acc, uint32_t n_cp, ArrowSystem &A) {
 
 // Solve (S A S + diag(dd)) y = -S g for the arrow system; returns false if not positive definite.
 // scale: Jacobi column scaling S (nc + 9); dd: LM diagonal added to the scaled system (nc + 9).
+// ws: caller-owned workspace (reused across iterations).  The border and the right-hand side are kept
+// as 10 contiguous columns so that the substitution loops vectorise.
+struct ArrowWorkspace {
+    std::vector<double> L, Z;  // [nc][BW] factor; [nc][10] = L^-1 [border | rhs]
+};
+
 bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const std::vector<double> &dd,
-                 std::vector<double> &y) {
+                 std::vector<double> &y, ArrowWorkspace &ws) {
     const size_t nc = A.nc;
-    std::vector<double> L(nc * BW), Yb(nc * 9), rhs(nc);
+    ws.L.resize(nc * BW);
+    ws.Z.resize(nc * 10);
+    double *__restrict__ L = ws.L.data();
+    double *__restrict__ Z = ws.Z.data();
+    const double *__restrict__ sc = scale.data();
     for (size_t i = 0; i < nc; i++) {
-        for (int k = 0; k < BW && (size_t) k <= i; k++) L[i * BW + k] = A.band[i * BW + k] * scale[i] * scale[i - k];
+        const double si = sc[i];
+        const size_t kmax = std::min<size_t>(BW - 1, i);
+        for (size_t k = 0; k <= kmax; k++) L[i * BW + k] = A.band[i * BW + k] * si * sc[i - k];
+        for (size_t k = kmax + 1; k < (size_t) BW; k++) L[i * BW + k] = 0.0;
         L[i * BW] += dd[i];
-        for (int j = 0; j < 9; j++) Yb[i * 9 + j] = A.border[i * 9 + j] * scale[i] * scale[nc + j];
-        rhs[i] = -A.gc[i] * scale[i];
+        for (int j = 0; j < 9; j++) Z[i * 10 + j] = A.border[i * 9 + j] * si * sc[nc + j];
+        Z[i * 10 + 9] = -A.gc[i] * si;
     }
-    // banded Cholesky (lower), in place
+    // banded Cholesky (lower, row-wise) fused with the forward substitution of the 10 columns
     for (size_t i = 0; i < nc; i++) {
-        for (int k = std::min<size_t>(BW - 1, i); k >= 0; k--) {
-            const size_t j = i - k;  // column
-            double v = L[i * BW + k];
-            const int mmax = std::min<size_t>(BW - 1 - k, j);
-            for (int m = 1; m <= mmax; m++) v -= L[i * BW + k + m] * L[j * BW + m];
-            if (k == 0) {
-                if (!(v > 0.0)) return false;
-                L[i * BW] = std::sqrt(v);
-            } else {
-                L[i * BW + k] = v / L[j * BW];
-            }
+        double *__restrict__ Li = L + i * BW;
+        const int kmax = (int) std::min<size_t>(BW - 1, i);
+        for (int k = kmax; k >= 1; k--) {
+            const double *__restrict__ Lj = L + (i - k) * BW;  // row of column j = i - k
+            const int mmax = std::min(BW - 1 - k, (int) (i - k));
+            double v = Li[k];
+            for (int m = 1; m <= mmax; m++) v -= Li[k + m] * Lj[m];
+            Li[k] = v / Lj[0];
+        }
+        double d = Li[0];
+        for (int m = 1; m <= kmax; m++) d -= Li[m] * Li[m];
+        if (!(d > 0.0)) return false;
+        d = std::sqrt(d);
+        Li[0] = d;
+        double acc10[10];
+        for (int j = 0; j < 10; j++) acc10[j] = Z[i * 10 + j];
+        for (int k = 1; k <= kmax; k++) {
+            const double l = Li[k];
+            const double *__restrict__ Zk = Z + (i - k) * 10;
+            for (int j = 0; j < 10; j++) acc10[j] -= l * Zk[j];
+        }
+        const double inv = 1.0 / d;
+        for (int j = 0; j < 10; j++) Z[i * 10 + j] = acc10[j] * inv;
+    }
+    // Schur complement on the 9 intrinsics: S = C - Zb^T Zb, b = -g_i - Zb^T z
+    double S[81], bvec[9], G[10 * 10];
+    for (int i = 0; i < 100; i++) G[i] = 0.0;
+    for (size_t r = 0; r < nc; r++) {
+        const double *__restrict__ z = Z + r * 10;
+        for (int i = 0; i < 10; i++) {
+            const double zi = z[i];
+            for (int j = i; j < 10; j++) G[10 * i + j] += zi * z[j];
         }
     }
-    // forward substitution: L Z = [border | rhs]
-    for (size_t i = 0; i < nc; i++) {
-        const int kmax = std::min<size_t>(BW - 1, i);
-        for (int j = 0; j < 9; j++) {
-            double v = Yb[i * 9 + j];
-            for (int k = 1; k <= kmax; k++) v -= L[i * BW + k] * Yb[(i - k) * 9 + j];
-            Yb[i * 9 + j] = v / L[i * BW];
-        }
-        double v = rhs[i];
-        for (int k = 1; k <= kmax; k++) v -= L[i * BW + k] * rhs[i - k];
-        rhs[i] = v / L[i * BW];
-    }
-    // Schur complement on the 9 intrinsics
-    double S[81], b[9];
     for (int i = 0; i < 9; i++) {
         for (int j = 0; j < 9; j++) {
-            double v = A.corner[9 * i + j] * scale[nc + i] * scale[nc + j];
+            double v = A.corner[9 * i + j] * sc[nc + i] * sc[nc + j] - (i <= j ? G[10 * i + j] : G[10 * j + i]);
             if (i == j) v += dd[nc + i];
-            for (size_t r = 0; r < nc; r++) v -= Yb[r * 9 + i] * Yb[r * 9 + j];
             S[9 * i + j] = v;
         }
-        double v = -A.gi[i] * scale[nc + i];
-        for (size_t r = 0; r < nc; r++) v -= Yb[r * 9 + i] * rhs[r];
-        b[i] = v;
+        bvec[i] = -A.gi[i] * sc[nc + i] - G[10 * i + 9];
     }
-    // dense Cholesky 9x9
-    for (int i = 0; i < 9; i++) {
+    for (int i = 0; i < 9; i++) {  // dense Cholesky 9x9
         for (int j = 0; j <= i; j++) {
             double v = S[9 * i + j];
             for (int k = 0; k < j; k++) v -= S[9 * i + k] * S[9 * j + k];
@@ -465,7 +498,7 @@ bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const s
     }
     double yi[9];
     for (int i = 0; i < 9; i++) {
-        double v = b[i];
+        double v = bvec[i];
         for (int k = 0; k < i; k++) v -= S[9 * i + k] * yi[k];
         yi[i] = v / S[9 * i + i];
     }
@@ -474,15 +507,17 @@ bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const s
         for (int k = i + 1; k < 9; k++) v -= S[9 * k + i] * yi[k];
         yi[i] = v / S[9 * i + i];
     }
-    // back substitution for the control points: L^T y_c = rhs - Yb yi
+    // back substitution for the control points: L^T y_c = z - Zb yi
     y.assign(nc + 9, 0.0);
     for (int j = 0; j < 9; j++) y[nc + j] = yi[j];
+    double *__restrict__ yc = y.data();
     for (size_t ii = nc; ii-- > 0;) {
-        double v = rhs[ii];
-        for (int j = 0; j < 9; j++) v -= Yb[ii * 9 + j] * yi[j];
-        const int kmax = std::min<size_t>(BW - 1, nc - 1 - ii);
-        for (int k = 1; k <= kmax; k++) v -= L[(ii + k) * BW + k] * y[ii + k];
-        y[ii] = v / L[ii * BW];
+        const double *__restrict__ z = Z + ii * 10;
+        double v = z[9];
+        for (int j = 0; j < 9; j++) v -= z[j] * yi[j];
+        const int kmax = (int) std::min<size_t>(BW - 1, nc - 1 - ii);
+        for (int k = 1; k <= kmax; k++) v -= L[(ii + k) * BW + k] * yc[ii + k];
+        yc[ii] = v / L[ii * BW];
     }
     return true;
 }
@@ -545,12 +580,34 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const size_t np = s->n_params(), na = s->n_accum(), nc = 6 * (size_t) s->n_cp, nt = nc + 9;
-    std::vector<double> acc(na), x(params, params + np), xc(np), delta, scale(nt, 1.0), dd(nt);
+    std::vector<double> x(params, params + np), xc(np), delta, scale(nt, 1.0), dd(nt);
     ArrowSystem A;
+    ArrowWorkspace ws;
     const auto t_begin = std::chrono::steady_clock::now();
+    // pinned staging: the 3 MB buffer comes back every evaluation
+    double *acc = nullptr, *xpin = nullptr;
+    ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &acc, na * sizeof(double), hipHostMallocDefault));
+    if (hipHostMalloc((void **) &xpin, np * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        (void) hipHostFree(acc);
+        return ECAL_ERR_NOMEM;
+    }
+    struct Free {
+        double *a, *b;
+        ~Free() {
+            (void) hipHostFree(a);
+            (void) hipHostFree(b);
+        }
+    } free_guard{acc, xpin};
+    double t_eval = 0, t_lin = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
 
     auto evaluate = [&](const double *xp, int with_jac, double *cost) -> int {
-        hipError_t e = hipMemcpyAsync(s->d_params, xp, np * sizeof(double), hipMemcpyHostToDevice, st);
+        const auto te = now();
+        memcpy(xpin, xp, np * sizeof(double));
+        hipError_t e = hipMemcpyAsync(s->d_params, xpin, np * sizeof(double), hipMemcpyHostToDevice, st);
         if (e != hipSuccess) return ECAL_ERR_HIP;
         int rc = ecal_solver_evaluate_dev(s, s->d_params, with_jac, s->d_accum, st);
         if (rc) return rc;
@@ -559,13 +616,14 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             rc = opt.allreduce(opt.allreduce_user, s->d_accum, n, st);
             if (rc) return ECAL_ERR_HIP;
         }
-        e = hipMemcpyAsync(acc.data(), s->d_accum, n * sizeof(double), hipMemcpyDeviceToHost, st);
+        e = hipMemcpyAsync(acc, s->d_accum, n * sizeof(double), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             ctx->last_error = std::string("solver evaluate: ") + hipGetErrorString(e);
             return ECAL_ERR_HIP;
         }
         *cost = acc[0];
+        t_eval += secs(te, now());
         return ECAL_OK;
     };
 
@@ -576,7 +634,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     if (rc) return rc;
     S.jacobian_evaluations = 1;
     S.initial_cost = cost;
-    unpack(acc.data(), s->n_cp, A);
+    unpack(acc, s->n_cp, A);
     if (opt.jacobi_scaling) {  // computed once from the initial Jacobian, as Ceres does
         for (size_t i = 0; i < nc; i++) scale[i] = 1.0 / (1.0 + std::sqrt(A.band[i * BW]));
         for (int i = 0; i < 9; i++) scale[nc + i] = 1.0 / (1.0 + std::sqrt(A.corner[10 * i]));
@@ -596,7 +654,8 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             const double h = (i < nc ? A.band[i * BW] : A.corner[10 * (i - nc)]) * scale[i] * scale[i];
             dd[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
         }
-        bool ok = solve_arrow(A, scale, dd, delta);
+        const auto tl = now();
+        bool ok = solve_arrow(A, scale, dd, delta, ws);
         double model_change = 0;
         if (ok) {
             for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
@@ -605,6 +664,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             model_change = -gTd - 0.5 * dHd;
             ok = model_change > 0.0;
         }
+        t_lin += secs(tl, now());
         if (!ok) {  // invalid step: shrink the region
             radius /= decrease_factor;
             decrease_factor *= 2.0;
@@ -627,7 +687,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             rc = evaluate(x.data(), 1, &cost);
             if (rc) return rc;
             S.jacobian_evaluations++;
-            unpack(acc.data(), s->n_cp, A);
+            unpack(acc, s->n_cp, A);
             S.successful_steps++;
             const double t = 2.0 * rel - 1.0;
             radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
@@ -644,6 +704,8 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     }
     S.final_cost = cost;
     S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    S.seconds_evaluate = t_eval;
+    S.seconds_linear_solve = t_lin;
     memcpy(params, x.data(), np * sizeof(double));
     if (sum) *sum = S;
     return ECAL_OK;

@@ -247,6 +247,8 @@ typedef struct ecal_lm_summary {
     int iterations, successful_steps, unsuccessful_steps, jacobian_evaluations, cost_evaluations;
     int termination; /* 0 = converged (a tolerance fired), 1 = max_num_iterations reached */
     double initial_cost, final_cost, seconds;
+    double seconds_evaluate;     /* H2D parameters + kernels + all-reduce + D2H buffer, summed */
+    double seconds_linear_solve; /* banded-arrow Cholesky + model change on the host, summed */
 } ecal_lm_summary;
 int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *problem, ecal_solver **out);
 void ecal_solver_destroy(ecal_solver *s);

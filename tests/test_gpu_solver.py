@@ -23,7 +23,7 @@ def _dense(acc, n_cp):
     return unpack_normal(acc, n_cp)
 
 
-@pytest.mark.parametrize("n_res,n_cp", [(500, 6), (3000, 9), (20000, 5)])
+@pytest.mark.parametrize("n_res,n_cp", [(500, 6), (3000, 9), (40000, 4)])
 def test_normal_equations_match_oracle(ctx, n_res, n_cp):
     from eventcalib_amd.capi import Solver
     rng = np.random.default_rng(n_res)
@@ -38,8 +38,8 @@ def test_normal_equations_match_oracle(ctx, n_res, n_cp):
     assert np.abs(g - og).max() <= 1e-10 * np.abs(og).max()
     assert np.abs(H - oH).max() <= 1e-10 * np.abs(oH).max()
     assert abs(s.evaluate(y, False)[0] - oc) <= 1e-11 * abs(oc)
-    if n_res == 20000:
-        assert s.n_chunks > n_cp - 3      # spans with more than 4096 residuals are split into several chunks
+    if n_res == 40000:
+        assert s.n_chunks > n_cp - 3      # a span with more than 16384 residuals is split into several chunks
     s.close()
 
 
