@@ -1,0 +1,113 @@
+"""GPU, BASELINE config sizes (10 M events = configs[1]): size-independent properties of the detection path,
+plus oracle spot checks on a random sample of windows (bounded CPU time)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth_stream as SS
+
+pytestmark = pytest.mark.gpu
+N_EVENTS = 10_000_000
+
+
+@pytest.fixture(scope="module")
+def run():
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    pipe = DetectPipeline(ctx)
+    ev = SS.make_stream(N_EVENTS, device="cuda")
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (N_EVENTS - 1) / 1e6)
+    pipe.set_windows(t0, t1)
+    pipe.run(ev)
+    torch.cuda.synchronize()
+    yield ctx, pipe, ev, t0, t1, torch
+    ctx.close()
+
+
+def test_structure_invariants(run):
+    ctx, pipe, ev, t0, t1, torch = run
+    S = len(t0)
+    assert not pipe.overflowed()
+    lo, hi, base = pipe.win_lo[:S].long(), pipe.win_hi[:S].long(), pipe.win_base[:S + 1].long()
+    # tiled windows: every event in exactly one window, in order
+    assert int(lo[0]) == 0 and int(hi[-1]) == N_EVENTS and bool((lo[1:] == hi[:-1]).all())
+    assert bool((base[1:] - base[:-1] == hi - lo).all()) and int(base[-1]) == N_EVENTS
+    off, cnt = pipe.seg_off[:2 * S].long(), pipe.seg_cnt[:2 * S].long()
+    assert bool((off[0::2] == base[:-1]).all()) and bool((off[1::2] == off[0::2] + cnt[0::2]).all())
+    assert bool((cnt[0::2] + cnt[1::2] <= hi - lo).all())
+    # labels: -1 or in [0, n_clusters) of their segment, and every cluster id is used
+    seg_of = torch.repeat_interleave(torch.arange(2 * S, device="cuda"), cnt)
+    slot = torch.repeat_interleave(off, cnt) + (torch.arange(int(cnt.sum()), device="cuda") -
+                                               torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt))
+    lab = pipe.labels[slot].long()
+    ncl = pipe.n_clusters[:2 * S].long()
+    assert bool((lab >= -1).all()) and bool((lab < ncl[seg_of]).all())
+    mx = torch.full((2 * S,), -1, dtype=torch.long, device="cuda").scatter_reduce(0, seg_of, lab, reduce="amax")
+    assert bool((mx == ncl - 1).all())
+    # a cluster's id is the rank of its smallest pid: first occurrence of each label increases with the label
+    pid = slot - off[seg_of]
+    key = seg_of * 4096 + lab.clamp(min=0)
+    first = torch.full((2 * S * 4096,), 1 << 30, dtype=torch.long, device="cuda").scatter_reduce(
+        0, key[lab >= 0], pid[lab >= 0], reduce="amin").view(2 * S, 4096)
+    valid = torch.arange(4096, device="cuda")[None, :] < ncl[:, None]
+    inc = (first[:, 1:] > first[:, :-1]) | ~valid[:, 1:]
+    assert bool(inc.all())
+    # event -> point map: -1 or a valid index of its polarity's segment
+    ep = pipe.event_point[:N_EVENTS].long()
+    pol = ev.view(-1, 25)[:, 24].long()
+    win = torch.repeat_interleave(torch.arange(S, device="cuda"), hi - lo)
+    lim = torch.where(pol > 0, cnt[2 * win], cnt[2 * win + 1])
+    assert bool((ep >= -1).all()) and bool((ep < lim).all())
+    # kept labels are a renumbering of labels; candidates never exceed kept + clusters
+    info = pipe.win_info[:S].long()
+    assert bool((info[:, 0] <= info[:, 1]).all()) and bool(((info[:, 3] == 0) | (info[:, 0] == 0)).all())
+
+
+def test_partition_property(run):
+    """Processing the two halves of the window list separately gives the same per-window results
+    (no cross-window state): compare labels / candidates of windows in the second half."""
+    ctx, pipe, ev, t0, t1, torch = run
+    from eventcalib_amd.pipeline import DetectPipeline
+    S = len(t0)
+    h = S // 2
+    p2 = DetectPipeline(ctx)
+    p2.set_windows(t0[h:], t1[h:])
+    p2.run(ev, slots=N_EVENTS)
+    torch.cuda.synchronize()
+    S2 = S - h
+    assert torch.equal(p2.seg_cnt[:2 * S2], pipe.seg_cnt[2 * h:2 * S])
+    assert torch.equal(p2.n_clusters[:2 * S2], pipe.n_clusters[2 * h:2 * S])
+    assert torch.equal(p2.win_info[:S2], pipe.win_info[h:S])
+    b0 = int(pipe.win_base[h])
+    m = int(p2.win_base[S2])
+    assert m == N_EVENTS - b0
+    # per-slot arrays agree where slots are defined (positive+negative points of each window)
+    cnt = p2.seg_cnt[:2 * S2].long()
+    off = p2.seg_off[:2 * S2].long()
+    slot = torch.repeat_interleave(off, cnt) + (torch.arange(int(cnt.sum()), device="cuda") -
+                                               torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt))
+    assert torch.equal(p2.labels[slot], pipe.labels[slot + b0])
+    assert torch.equal(p2.kept_labels[slot], pipe.kept_labels[slot + b0])
+    assert torch.equal(p2.xy[slot], pipe.xy[slot + b0])
+
+
+def test_oracle_spot_checks(run):
+    ctx, pipe, ev, t0, t1, torch = run
+    S = len(t0)
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(S, 40, replace=False))
+    lo = pipe.win_lo[:S].cpu().numpy().astype(np.int64)
+    hi = pipe.win_hi[:S].cpu().numpy().astype(np.int64)
+    off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
+    cnt = pipe.seg_cnt[:2 * S].cpu().numpy().astype(np.int64)
+    for s in pick:
+        rec = ev[25 * lo[s]: 25 * hi[s]].cpu().numpy()
+        pos, neg, ep = O.event_frame(rec, 0, hi[s] - lo[s])
+        for k, pts in ((0, pos), (1, neg)):
+            o, n = off[2 * s + k], cnt[2 * s + k]
+            assert n == pts.shape[0]
+            assert np.array_equal(pipe.xy[o:o + n].cpu().numpy(), pts)
+            rc, lab, nc = O.dbscan(pts, 4.0, 2)
+            assert np.array_equal(pipe.labels[o:o + n].cpu().numpy(), lab)
