@@ -121,7 +121,8 @@ def main():
         c.extract_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
                             pipe.n_clusters.data_ptr(), S, n, pipe.det[0], pipe.det[1], pipe.det[2],
                             pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
-                            pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream)
+                            pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream, fit_circle=pipe.det[3],
+                            knn_num=pipe.det[4])
         ev[k][4].record(st)
     barrier()
     elapsed = time.perf_counter() - t_begin

@@ -67,7 +67,7 @@ def load_library():
     L.ecal_slice_events_dev.restype = i32
     L.ecal_circle_radius_threshold.argtypes = [f64, f64, i32, i32, i32, f64, f64]
     L.ecal_circle_radius_threshold.restype = f64
-    L.ecal_extract_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f64, vp, vp, vp, vp, vp, vp]
+    L.ecal_extract_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f64, i32, u32, vp, vp, vp, vp, vp, vp]
     L.ecal_extract_batch_dev.restype = i32
     L.ecal_associate_dev.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, u32, u32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
     L.ecal_associate_dev.restype = i32
@@ -168,11 +168,11 @@ class Context:
 
     def extract_batch_dev(self, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min,
                           need_clusters, radius_threshold, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
-                          stream=0):
+                          stream=0, fit_circle=False, knn_num=3):
         self._check(self._L.ecal_extract_batch_dev(self._h, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters,
                                                    int(S), int(n_points), int(cluster_min), int(need_clusters),
-                                                   float(radius_threshold), d_win_info, d_cand_pair, d_cand_xyr,
-                                                   d_kept_labels, d_rep, stream))
+                                                   float(radius_threshold), int(bool(fit_circle)), int(knn_num),
+                                                   d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, stream))
 
 
 # ---- continuous-time calibration solve ----

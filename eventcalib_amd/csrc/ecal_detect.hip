@@ -25,7 +25,11 @@ struct DetectParams {
     uint32_t cluster_min;    // clusterMinSample
     uint32_t need_clusters;  // rows * cols
     double four_thr2;        // 4 * circleRadiusThreshold_^2
+    double thr;              // circleRadiusThreshold_
+    uint32_t fit_circle;     // Params::fitCircle
+    uint32_t knn;            // Params::knn_num (<= DET_KNN_MAX)
 };
+constexpr uint32_t DET_KNN_MAX = 8;
 
 __device__ __forceinline__ double norm_of(double2 p) { return __dsqrt_rn(p.x * p.x + p.y * p.y); }  // Vector2d::norm()
 
@@ -48,6 +52,125 @@ struct DetLds {
     __device__ __forceinline__ double norm(uint32_t li) const { return norm_of(pts[li]); }
     __device__ __forceinline__ void set_norm(uint32_t, double) const {}
 };
+
+struct CircleFit {
+    double err, radius, cx, cy;
+};
+
+// CirclesEventFrame::fitCircle (:361-415) over the + cluster kp and the - cluster kn (members in
+// ascending pid; the reference sums in its BFS member order — last-bit differences only), then the
+// error of :202-219.  3x3 system solved by Gaussian elimination with partial pivoting (Eigen's lu()).
+template <typename ST>
+__device__ __forceinline__ CircleFit fit_pair(const ST &st, const uint32_t (&base)[2], uint32_t kp, uint32_t kn,
+                                              double thr) {
+    double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0, sxxx = 0, syyy = 0, sxyy = 0, sxxy = 0;
+    uint32_t cnt = 0;
+    for (int pol = 0; pol < 2; pol++) {
+        const uint32_t o = base[pol], kk = pol ? kn : kp;
+        const uint32_t m = st.ksize[o + kk], first = o + st.koff[o + kk];
+        for (uint32_t t = 0; t < m; t++) {
+            const double2 e = st.pt(o + st.sorted[first + t]);
+            sx += e.x;
+            sy += e.y;
+            const double xx = e.x * e.x, yy = e.y * e.y, xy = e.x * e.y;
+            sxx += xx;
+            syy += yy;
+            sxy += xy;
+            sxxx += xx * e.x;
+            syyy += yy * e.y;
+            sxyy += xy * e.y;
+            sxxy += e.x * xy;
+        }
+        cnt += m;
+    }
+    double A[3][4] = {{2 * sx, 2 * sy, (double) cnt, sxx + syy},
+                      {2 * sxx, 2 * sxy, sx, sxxx + sxyy},
+                      {2 * sxy, 2 * syy, sy, sxxy + syyy}};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        int piv = c;
+#pragma unroll
+        for (int r = c + 1; r < 3; r++)
+            if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double a = A[c][k], b = A[piv][k];
+            A[c][k] = b;
+            A[piv][k] = (piv == c) ? b : a;
+        }
+#pragma unroll
+        for (int r = c + 1; r < 3; r++) {
+            const double f = A[r][c] / A[c][c];
+#pragma unroll
+            for (int k = c; k < 4; k++) A[r][k] -= f * A[c][k];
+        }
+    }
+    double x[3];
+    x[2] = A[2][3] / A[2][2];
+    x[1] = (A[1][3] - A[1][2] * x[2]) / A[1][1];
+    x[0] = (A[0][3] - A[0][1] * x[1] - A[0][2] * x[2]) / A[0][0];
+    CircleFit f;
+    f.cx = x[0];
+    f.cy = x[1];
+    f.radius = __dsqrt_rn(x[0] * x[0] + x[1] * x[1] + x[2]);
+    f.err = 0.0;
+    const double2 pr = st.pt(base[0] + st.rep[base[0] + kp]), nr = st.pt(base[1] + st.rep[base[1] + kn]);
+    const double ax = pr.x - nr.x, ay = pr.y - nr.y;
+    const double approx = __dsqrt_rn(ax * ax + ay * ay) / 2;
+    if (f.radius > thr || f.radius > 2 * approx) {
+        f.err = 1.79769313486231570e308;  // std::numeric_limits<double>::max(), :207
+        return f;
+    }
+    for (int pol = 0; pol < 2; pol++) {
+        const uint32_t o = base[pol], kk = pol ? kn : kp;
+        const uint32_t m = st.ksize[o + kk], first = o + st.koff[o + kk];
+        for (uint32_t t = 0; t < m; t++) {
+            const double2 e = st.pt(o + st.sorted[first + t]);
+            const double ex = e.x - f.cx, ey = e.y - f.cy;
+            f.err += fabs(__dsqrt_rn(ex * ex + ey * ey) - f.radius);
+        }
+    }
+    f.err /= (double) cnt * f.radius;
+    return f;
+}
+
+// the k nearest representatives of polarity `pol` to q, ascending squared distance, ties to the smaller
+// cluster index (nanoflann's order among ties is unpinned); returns how many survive the gates of
+// :187-193 (d > 4 d0 or d > 4 thr^2 cuts the list)
+template <typename ST>
+__device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, uint32_t nk, double2 q, uint32_t K,
+                                              double gate, uint32_t (&idx)[DET_KNN_MAX]) {
+    double d2[DET_KNN_MAX];
+    for (uint32_t i = 0; i < DET_KNN_MAX; i++) {
+        d2[i] = 1.79769313486231570e308;
+        idx[i] = 0;
+    }
+    uint32_t have = 0;
+    for (uint32_t k = 0; k < nk; k++) {
+        const double2 c = st.pt(base_pol + st.rep[base_pol + k]);
+        const double dx = q.x - c.x, dy = q.y - c.y;
+        const double d = dx * dx + dy * dy;
+        // insertion into the sorted top-K (strict <: equal distances keep the earlier index first)
+        uint32_t pos = have < K ? have : K;
+        while (pos > 0 && d < d2[pos - 1]) pos--;
+        if (pos < K) {
+            for (uint32_t m = (have < K ? have : K - 1); m > pos; m--) {
+                d2[m] = d2[m - 1];
+                idx[m] = idx[m - 1];
+            }
+            d2[pos] = d;
+            idx[pos] = k;
+            if (have < K) have++;
+        }
+    }
+    uint32_t real = K;
+    for (uint32_t oi = 0; oi < K; oi++)
+        if (d2[oi] > d2[0] * 4 || d2[oi] > gate) {
+            real = oi;
+            break;
+        }
+    return real;
+}
 
 // base[pol]: window-local offset of the polarity's points (and of its kept-cluster arrays).
 template <typename ST>
@@ -147,7 +270,45 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         bool ok = false;
         uint32_t ni_best = 0;
         double cx = 0, cy = 0, r = 0;
-        if (pi < nk[0]) {
+        if (pi < nk[0] && prm.fit_circle) {  // :180-281
+            uint32_t n_idx[DET_KNN_MAX], p_idx[DET_KNN_MAX];
+            uint32_t real = knn_gated(st, base[1], nk[1], st.pt(base[0] + st.rep[base[0] + pi]), prm.knn, prm.four_thr2,
+                                      n_idx);
+            if (real > 0) {
+                CircleFit best = fit_pair(st, base, pi, n_idx[0], prm.thr);
+                uint32_t nmin = 0;
+                for (uint32_t j = 1; j < real; j++) {
+                    const CircleFit f = fit_pair(st, base, pi, n_idx[j], prm.thr);
+                    if (f.err < best.err) {  // std::min_element: first minimum
+                        best = f;
+                        nmin = j;
+                    }
+                }
+                if (best.err < 2 / best.radius) {  // :229-230
+                    const uint32_t nsel = n_idx[nmin];
+                    real = knn_gated(st, base[0], nk[0], st.pt(base[1] + st.rep[base[1] + nsel]), prm.knn, prm.four_thr2,
+                                     p_idx);
+                    if (real > 0) {
+                        CircleFit bb = fit_pair(st, base, p_idx[0], nsel, prm.thr);
+                        uint32_t pmin = 0;
+                        for (uint32_t i = 1; i < real; i++) {
+                            const CircleFit f = fit_pair(st, base, p_idx[i], nsel, prm.thr);
+                            if (f.err < bb.err) {
+                                bb = f;
+                                pmin = i;
+                            }
+                        }
+                        if (p_idx[pmin] == pi) {  // :275
+                            ok = true;
+                            ni_best = nsel;
+                            cx = bb.cx;
+                            cy = bb.cy;
+                            r = bb.radius;
+                        }
+                    }
+                }
+            }
+        } else if (pi < nk[0]) {
             const double2 pc = st.pt(base[0] + st.rep[base[0] + pi]);
             double bd = 1.79769313486231570e308;
             for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
@@ -320,7 +481,7 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
                                       const uint32_t *d_seg_cnt, const int32_t *d_labels,
                                       const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points,
                                       uint32_t cluster_min, uint32_t need_clusters, double radius_threshold,
-                                      uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
+                                      int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
                                       int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
@@ -345,6 +506,13 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
     prm.cluster_min = cluster_min;
     prm.need_clusters = need_clusters;
     prm.four_thr2 = 4 * radius_threshold * radius_threshold;
+    prm.thr = radius_threshold;
+    prm.fit_circle = fit_circle ? 1u : 0u;
+    prm.knn = knn_num;
+    if (fit_circle && (knn_num < 1 || knn_num > DET_KNN_MAX)) {
+        ctx->last_error = "knn_num must be in 1..8 when fitCircle is set";
+        return ECAL_ERR_INVALID;
+    }
     if (!ctx->det_attr_set) {
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));

@@ -28,7 +28,7 @@ public:
         int dbscan_startMinSample;
         int clusterMinSample;
         int knn_num;
-        bool fitCircle;             // only false (the shipped example.yaml value) is on the GPU path
+        bool fitCircle;             // false: midpoint circles (:283-311); true: algebraic fit + knn (:180-281)
     };
 
     CirclesEventFrame(EventContainer::Ptr container, const std::pair<double, double> &duration,
@@ -43,7 +43,6 @@ public:
     // in either polarity (CirclesEventFrame.cpp:62-64,127-129), or when fewer than rows*cols
     // candidate circles are found (the reference's findCirclesGrid cannot succeed with fewer).
     bool extractFeatures() {
-        if (params_.fitCircle) throw std::logic_error("fitCircle = 1 is not on the GPU path yet");
         ensure();
         if (det_.status != 0) return false;
         return det_.candidates.size() >= (size_t) (pattern_->rows * pattern_->cols);
@@ -63,6 +62,8 @@ protected:
         p.cluster_min_sample = (uint32_t) params_.clusterMinSample;
         p.need_clusters = (uint32_t) (pattern_->rows * pattern_->cols);
         p.circle_radius_threshold = circleRadiusThreshold_;
+        p.fit_circle = params_.fitCircle ? 1 : 0;
+        p.knn_num = (uint32_t) params_.knn_num;
         return p;
     }
     CirclePatternParameters::Ptr pattern_;

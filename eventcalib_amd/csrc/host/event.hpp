@@ -265,6 +265,8 @@ protected:
         p.cluster_min_sample = 5;
         p.need_clusters = 36;
         p.circle_radius_threshold = ecal_circle_radius_threshold(346, 260, 9, 4, 1, 5.5, 1.75);
+        p.fit_circle = 0;
+        p.knn_num = 3;
         return p;
     }
     void ensure() {

@@ -50,9 +50,10 @@ class DetectPipeline:
         self.t1 = torch.as_tensor(np.asarray(t1, dtype=np.float64)).to(self.dev)
         self.S = int(self.t0.numel())
 
-    def set_detect_params(self, cluster_min=5, need_clusters=36, radius_threshold=15.511363636363637):
-        """clusterMinSample, rows*cols and circleRadiusThreshold_ (defaults: example.yaml, 346x260 sensor)."""
-        self.det = (int(cluster_min), int(need_clusters), float(radius_threshold))
+    def set_detect_params(self, cluster_min=5, need_clusters=36, radius_threshold=15.511363636363637, fit_circle=False,
+                          knn_num=3):
+        """clusterMinSample, rows*cols, circleRadiusThreshold_, fitCircle, knn_num (defaults: example.yaml, 346x260)."""
+        self.det = (int(cluster_min), int(need_clusters), float(radius_threshold), bool(fit_circle), int(knn_num))
 
     def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True):
         """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN -> candidate
@@ -79,7 +80,8 @@ class DetectPipeline:
             c.extract_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(),
                                 self.labels.data_ptr(), self.n_clusters.data_ptr(), S, slots, self.det[0], self.det[1],
                                 self.det[2], self.win_info.data_ptr(), self.cand_pair.data_ptr(),
-                                self.cand_xyr.data_ptr(), self.kept_labels.data_ptr(), self.rep.data_ptr(), st)
+                                self.cand_xyr.data_ptr(), self.kept_labels.data_ptr(), self.rep.data_ptr(), st,
+                                fit_circle=self.det[3], knn_num=self.det[4])
         return self
 
     def overflowed(self):

@@ -111,8 +111,9 @@ int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
 
 /* ---- circle-candidate extraction -----------------------------------------------------------
  * Replaces CirclesEventFrame::extractFeatures between its DBSCAN::Run calls and cv::findCirclesGrid
- * (event_camera_calib/src/CirclesEventFrame.cpp:89-312, fitCircle == 0 path :283-311) for all
- * windows at once.  Inputs are the outputs of ecal_slice_events_dev and ecal_dbscan_batch_dev with
+ * (event_camera_calib/src/CirclesEventFrame.cpp:89-312) for all windows at once: fit_circle == 0 is the
+ * mutual-nearest / midpoint path of :283-311 (the shipped example.yaml), fit_circle != 0 the knn_num-nearest
+ * / algebraic CirclesEventFrame::fitCircle (:361-415) / double-direction path of :180-281 (knn_num <= 8).  Inputs are the outputs of ecal_slice_events_dev and ecal_dbscan_batch_dev with
  * S' = 2S segments (2s = positive, 2s+1 = negative polarity of window s).
  *
  * ecal_circle_radius_threshold: circleRadiusThreshold_ (CirclesEventFrame.cpp:16-33); pure host math.
@@ -137,7 +138,7 @@ double ecal_circle_radius_threshold(double width, double height, int rows, int c
 int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
                            const int32_t *d_labels, const uint32_t *d_n_clusters, uint32_t S /*windows*/,
                            uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters, double radius_threshold,
-                           uint32_t *d_win_info /*[S][4]*/, uint32_t *d_cand_pair /*[n_points][2]*/,
+                           int fit_circle, uint32_t knn_num, uint32_t *d_win_info /*[S][4]*/, uint32_t *d_cand_pair /*[n_points][2]*/,
                            double *d_cand_xyr /*[n_points][3]*/, int32_t *d_kept_labels /*[n_points]*/,
                            uint32_t *d_rep /*[n_points]*/, void *stream);
 
@@ -159,6 +160,8 @@ typedef struct ecal_detect_params {
     uint32_t cluster_min_sample;     /* clusterMinSample */
     uint32_t need_clusters;          /* BoardSize_Rows * BoardSize_Cols */
     double circle_radius_threshold;  /* ecal_circle_radius_threshold(...) */
+    int fit_circle;                  /* fitCircle */
+    uint32_t knn_num;                /* knn_num (used when fit_circle != 0) */
 } ecal_detect_params;
 typedef struct ecal_detect_result {
     uint32_t *win_lo, *win_hi; /* [S] */

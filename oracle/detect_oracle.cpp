@@ -93,6 +93,63 @@ size_t nearest(const Side &s, const Pt &q, double *d2_out) {
     return best;
 }
 
+// k nearest centres, ascending squared distance (ties: smaller index first — nanoflann unpinned)
+void knn(const Side &s, const Pt &q, size_t k, std::vector<size_t> &idx, std::vector<double> &d2) {
+    std::vector<std::pair<double, size_t>> all;
+    for (size_t i = 0; i < s.centres.size(); i++) {
+        const Pt &c = s.pts[s.centres[i]];
+        const double dx = q.x - c.x, dy = q.y - c.y;
+        all.emplace_back(dx * dx + dy * dy, i);
+    }
+    std::stable_sort(all.begin(), all.end(), [](auto &a, auto &b) { return a.first < b.first; });
+    idx.assign(k, 0);
+    d2.assign(k, 0.0);
+    for (size_t i = 0; i < k && i < all.size(); i++) {
+        idx[i] = all[i].second;
+        d2[i] = all[i].first;
+    }
+}
+
+struct Fit {
+    double err, radius, cx, cy;
+};
+
+extern "C" int oracle_fit_circle(const double *a_xy, uint32_t na, const double *b_xy, uint32_t nb, double *centre_xy,
+                                 double *radius);
+
+// fitCircle + the error of :202-219 for the pair (+ cluster pc, - cluster nc)
+Fit fit_pair(const Side &P, size_t pc, const Side &N, size_t nc, double thr) {
+    std::vector<double> a, b;
+    for (uint32_t e : P.clusters[pc]) {
+        a.push_back(P.pts[e].x);
+        a.push_back(P.pts[e].y);
+    }
+    for (uint32_t e : N.clusters[nc]) {
+        b.push_back(N.pts[e].x);
+        b.push_back(N.pts[e].y);
+    }
+    double c[2], r;
+    oracle_fit_circle(a.data(), (uint32_t) P.clusters[pc].size(), b.data(), (uint32_t) N.clusters[nc].size(), c, &r);
+    Fit f{0.0, r, c[0], c[1]};
+    const Pt pr = P.pts[P.centres[pc]], nr = N.pts[N.centres[nc]];
+    const double ax = pr.x - nr.x, ay = pr.y - nr.y;
+    const double approx = std::sqrt(ax * ax + ay * ay) / 2;
+    if (r > thr || r > 2 * approx) {  // also false for a NaN radius, as in the reference
+        f.err = std::numeric_limits<double>::max();
+        return f;
+    }
+    for (uint32_t e : P.clusters[pc]) {
+        const double ex = P.pts[e].x - c[0], ey = P.pts[e].y - c[1];
+        f.err += std::abs(std::sqrt(ex * ex + ey * ey) - r);
+    }
+    for (uint32_t e : N.clusters[nc]) {
+        const double ex = N.pts[e].x - c[0], ey = N.pts[e].y - c[1];
+        f.err += std::abs(std::sqrt(ex * ex + ey * ey) - r);
+    }
+    f.err /= (P.clusters[pc].size() + N.clusters[nc].size()) * r;
+    return f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -111,10 +168,27 @@ double oracle_circle_radius_threshold(double width, double height, int rows, int
 // clusters :127-129 or an empty polarity :62-64; +2 = some cluster has a norm tie at its median)}; cand_pair[2j..] = (+ cluster, - cluster) in
 // kept numbering; cand_xyr[3j..] = centre x, centre y, radius; kept_pos/kept_neg per point;
 // rep_pos/rep_neg = representative pid per kept cluster (sized n_pos / n_neg).
+int oracle_extract_candidates_mode(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
+                                   double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
+                                   double radius_thr, int fit_circle, uint32_t knn_num, uint32_t *info,
+                                   uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
+                                   uint32_t *rep_pos, uint32_t *rep_neg);
+
 int oracle_extract_candidates(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg, double eps,
                               uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters, double radius_thr,
                               uint32_t *info, uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos,
                               int32_t *kept_neg, uint32_t *rep_pos, uint32_t *rep_neg) {
+    return oracle_extract_candidates_mode(pos_xy, n_pos, neg_xy, n_neg, eps, minpts, cluster_min, need_clusters,
+                                          radius_thr, 0, 1, info, cand_pair, cand_xyr, kept_pos, kept_neg, rep_pos,
+                                          rep_neg);
+}
+
+// fit_circle == 0: the :283-311 path; fit_circle != 0: the :180-281 path with knn_num neighbours.
+int oracle_extract_candidates_mode(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
+                                   double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
+                                   double radius_thr, int fit_circle, uint32_t knn_num, uint32_t *info,
+                                   uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
+                                   uint32_t *rep_pos, uint32_t *rep_neg) {
     info[0] = info[1] = info[2] = 0;
     info[3] = 1;
     for (uint32_t i = 0; i < n_pos; i++) kept_pos[i] = -1;
@@ -135,6 +209,51 @@ int oracle_extract_candidates(const double *pos_xy, uint32_t n_pos, const double
     for (size_t i = 0; i < P.centres.size(); i++) rep_pos[i] = P.centres[i];
     for (size_t i = 0; i < N.centres.size(); i++) rep_neg[i] = N.centres[i];
     uint32_t nc = 0;
+    if (fit_circle) {  // :180-281
+        const size_t K = knn_num;
+        const double gate = 4 * radius_thr * radius_thr;
+        std::vector<size_t> n_idx, p_idx;
+        std::vector<double> d2;
+        for (size_t pi = 0; pi < P.centres.size(); pi++) {
+            size_t real = K;
+            knn(N, P.pts[P.centres[pi]], K, n_idx, d2);
+            for (size_t oi = 0; oi < K; oi++)
+                if (d2[oi] > d2[0] * 4 || d2[oi] > gate) {
+                    real = oi;
+                    break;
+                }
+            if (real == 0) continue;
+            std::vector<Fit> fits(real);
+            for (size_t j = 0; j < real; j++) fits[j] = fit_pair(P, pi, N, n_idx[j], radius_thr);
+            size_t nmin = 0;
+            for (size_t j = 1; j < real; j++)
+                if (fits[j].err < fits[nmin].err) nmin = j;  // std::min_element: first minimum
+            if (!(fits[nmin].err < 2 / fits[nmin].radius)) continue;
+            real = K;
+            knn(P, N.pts[N.centres[n_idx[nmin]]], K, p_idx, d2);
+            for (size_t oi = 0; oi < K; oi++)
+                if (d2[oi] > d2[0] * 4 || d2[oi] > gate) {
+                    real = oi;
+                    break;
+                }
+            if (real == 0) continue;
+            std::vector<Fit> back(real);
+            for (size_t i = 0; i < real; i++) back[i] = fit_pair(P, p_idx[i], N, n_idx[nmin], radius_thr);
+            size_t pmin = 0;
+            for (size_t i = 1; i < real; i++)
+                if (back[i].err < back[pmin].err) pmin = i;
+            if (p_idx[pmin] == pi) {
+                cand_pair[2 * nc] = (uint32_t) pi;
+                cand_pair[2 * nc + 1] = (uint32_t) n_idx[nmin];
+                cand_xyr[3 * nc] = back[pmin].cx;
+                cand_xyr[3 * nc + 1] = back[pmin].cy;
+                cand_xyr[3 * nc + 2] = back[pmin].radius;
+                nc++;
+            }
+        }
+        info[0] = nc;
+        return 0;
+    }
     for (size_t pi = 0; pi < P.centres.size(); pi++) {  // :283-311
         double d2;
         const Pt pc = P.pts[P.centres[pi]];

@@ -82,6 +82,8 @@ int main(int argc, char **argv) {
     prm.cluster_min_sample = 5;
     prm.need_clusters = 36;
     prm.circle_radius_threshold = frame.circleRadiusThreshold();
+    prm.fit_circle = 0;
+    prm.knn_num = 3;
     detect_windows(*container, wins, prm, out);
     CHECK(out.size() == 6 && out[0].positive.size() == d.positive.size());
     return 0;

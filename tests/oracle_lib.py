@@ -190,13 +190,14 @@ def circle_radius_threshold(width, height, rows, cols, asymmetric, square, radiu
     return L.oracle_circle_radius_threshold(width, height, rows, cols, int(asymmetric), square, radius)
 
 
-def extract_candidates(pos, neg, eps, minpts, cluster_min, need_clusters, radius_thr):
-    """extractFeatures up to the candidate list (fitCircle == 0).  Returns a dict."""
+def extract_candidates(pos, neg, eps, minpts, cluster_min, need_clusters, radius_thr, fit_circle=False, knn_num=3):
+    """extractFeatures up to the candidate list (both fitCircle paths).  Returns a dict."""
     L = lib()
-    L.oracle_extract_candidates.argtypes = [_dp, ctypes.c_uint32, _dp, ctypes.c_uint32, ctypes.c_double,
-                                            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double,
-                                            _u32p, _u32p, _dp, _i32p, _i32p, _u32p, _u32p]
-    L.oracle_extract_candidates.restype = ctypes.c_int
+    L.oracle_extract_candidates_mode.argtypes = [_dp, ctypes.c_uint32, _dp, ctypes.c_uint32, ctypes.c_double,
+                                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double,
+                                                 ctypes.c_int, ctypes.c_uint32, _u32p, _u32p, _dp, _i32p, _i32p,
+                                                 _u32p, _u32p]
+    L.oracle_extract_candidates_mode.restype = ctypes.c_int
     pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 2)
     neg = np.ascontiguousarray(neg, np.float64).reshape(-1, 2)
     npos, nneg = pos.shape[0], neg.shape[0]
@@ -208,9 +209,10 @@ def extract_candidates(pos, neg, eps, minpts, cluster_min, need_clusters, radius
     kn = np.full(max(nneg, 1), -1, np.int32)
     rp = np.zeros(max(npos, 1), np.uint32)
     rn = np.zeros(max(nneg, 1), np.uint32)
-    L.oracle_extract_candidates(_p(pos, _dp), npos, _p(neg, _dp), nneg, float(eps), int(minpts), int(cluster_min),
-                                int(need_clusters), float(radius_thr), _p(info, _u32p), _p(pair, _u32p), _p(xyr, _dp),
-                                _p(kp, _i32p), _p(kn, _i32p), _p(rp, _u32p), _p(rn, _u32p))
+    L.oracle_extract_candidates_mode(_p(pos, _dp), npos, _p(neg, _dp), nneg, float(eps), int(minpts), int(cluster_min),
+                                     int(need_clusters), float(radius_thr), int(bool(fit_circle)), int(knn_num),
+                                     _p(info, _u32p), _p(pair, _u32p), _p(xyr, _dp), _p(kp, _i32p), _p(kn, _i32p),
+                                     _p(rp, _u32p), _p(rn, _u32p))
     nc = int(info[0])
     return dict(n=nc, nk_pos=int(info[1]), nk_neg=int(info[2]), status=int(info[3]) & 1, tie=bool(info[3] & 2),
                 pair=pair[:nc], xyr=xyr[:nc], kept_pos=kp[:npos], kept_neg=kn[:nneg], rep_pos=rp[:int(info[1])],

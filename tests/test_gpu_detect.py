@@ -28,7 +28,7 @@ def test_radius_threshold_kat(env):
                                                                                                      False, 3.0, 1.0)
 
 
-def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr):
+def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=False, knn_num=3):
     S = len(t0)
     info = pipe.win_info[:S].cpu().numpy().astype(np.int64)
     seg_off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
@@ -43,7 +43,7 @@ def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr):
         op, on = seg_off[2 * s], seg_off[2 * s + 1]
         pos = xy[op:op + seg_cnt[2 * s]]
         neg = xy[on:on + seg_cnt[2 * s + 1]]
-        ref = O.extract_candidates(pos, neg, 4.0, 2, cluster_min, need, thr)
+        ref = O.extract_candidates(pos, neg, 4.0, 2, cluster_min, need, thr, fit_circle, knn_num)
         assert info[s, 3] == ref["status"], "window %d status" % s
         assert np.array_equal(kept[op:op + len(pos)], ref["kept_pos"]), "window %d kept +" % s
         assert np.array_equal(kept[on:on + len(neg)], ref["kept_neg"]), "window %d kept -" % s
@@ -66,7 +66,12 @@ def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr):
         n = ref["n"]
         assert info[s, 0] == n, "window %d candidate count" % s
         assert np.array_equal(pair[op:op + n], ref["pair"]), "window %d pairs" % s
-        assert np.array_equal(xyr[op:op + n], ref["xyr"]), "window %d circles" % s   # same arithmetic: bitwise
+        if fit_circle:
+            # the nine running sums of fitCircle are accumulated in ascending pid here and in the reference's
+            # BFS member order in the oracle: f64 rounding differs in the last digits, stated tolerance 1e-9
+            assert np.allclose(xyr[op:op + n], ref["xyr"], rtol=1e-9, atol=1e-9), "window %d circles" % s
+        else:
+            assert np.array_equal(xyr[op:op + n], ref["xyr"]), "window %d circles" % s   # same arithmetic: bitwise
     return exact, tied
 
 
@@ -117,3 +122,19 @@ def test_large_windows_use_the_global_scratch_path(env):
     assert int((pipe.seg_cnt[:2 * S:2] + pipe.seg_cnt[1:2 * S:2]).max()) > 1408
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)
     assert exact + tied >= 3
+
+
+@pytest.mark.parametrize("knn_num", [1, 3])
+def test_fit_circle_path(env, knn_num):
+    """fitCircle == 1 (CirclesEventFrame.cpp:180-281): knn candidates, algebraic circle fit, double-direction check."""
+    ctx, pipe, torch = env
+    buf = SS.make_stream(90000, rate=2.0e6, device="cpu", seed=77)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR, fit_circle=True, knn_num=knn_num)
+    pipe.run(buf.cuda())
+    torch.cuda.synchronize()
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, True, knn_num)
+    assert exact >= 5
+    pipe.set_detect_params(5, 36, THR)

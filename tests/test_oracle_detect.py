@@ -41,6 +41,11 @@ def test_two_half_arcs_make_one_candidate():
     d = np.linalg.norm(out["xyr"][:, None, :2] - (centres[None] - 0.5), axis=2).min(1)
     # centre = midpoint of the two norm-median pixels: a crude estimate by design (refined by rectifyFeatures)
     assert (d < 8.0).all() and (np.abs(out["xyr"][:, 2] - r) < 4.0).all()
+    # fitCircle == 1 path (:180-281): the algebraic fit recovers the true centres / radius much more closely
+    fit = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.5, fit_circle=True, knn_num=3)
+    assert fit["status"] == 0 and fit["n"] == 36
+    d = np.linalg.norm(fit["xyr"][:, None, :2] - (centres[None] - 0.5), axis=2).min(1)
+    assert (d < 0.8).all() and (np.abs(fit["xyr"][:, 2] - r) < 0.8).all()
     # too few clusters -> extractFeatures returns false (:127-129)
     out = O.extract_candidates(pos[:200], neg, 4.0, 2, 5, 36, 15.5)
     assert out["status"] == 1 and out["n"] == 0
