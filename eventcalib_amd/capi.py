@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_detect_batch", "ecal_copy_dev",
-    "ecal_associate_dev",
+    "ecal_grid_order_dev", "ecal_associate_dev",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
@@ -69,6 +69,8 @@ def load_library():
     L.ecal_circle_radius_threshold.restype = f64
     L.ecal_extract_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, f64, i32, u32, vp, vp, vp, vp, vp, vp]
     L.ecal_extract_batch_dev.restype = i32
+    L.ecal_grid_order_dev.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp]
+    L.ecal_grid_order_dev.restype = i32
     L.ecal_associate_dev.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, u32, u32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
     L.ecal_associate_dev.restype = i32
     L.ecal_copy_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, i32]
@@ -153,6 +155,11 @@ class Context:
         self._check(self._L.ecal_slice_events_dev(self._h, d_events, int(n_events), d_win_lo, d_win_hi, d_win_base,
                                                   int(S), int(max_win_events), int(cap_points), d_xy, d_seg_off,
                                                   d_seg_cnt, d_event_point, d_overflow, stream))
+
+    # ---- grid ordering ----
+    def grid_order_dev(self, d_win_info, d_seg_off, d_cand_xyr, S, rows, cols, d_order, d_found, stream=0):
+        self._check(self._L.ecal_grid_order_dev(self._h, d_win_info, d_seg_off, d_cand_xyr, int(S), int(rows), int(cols),
+                                                d_order, d_found, stream))
 
     # ---- event -> residual association ----
     def associate_dev(self, d_events, n_events, d_kf_time, d_kf_circles, n_keyframes, n_circles, t_min, t_max,

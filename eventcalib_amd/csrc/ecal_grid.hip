@@ -1,0 +1,235 @@
+// Ordering of the candidate circles into the asymmetric pattern grid.
+//
+// Replaces what the reference gets from its vendored, patched OpenCV finder —
+// cv::findCirclesGrid(points, Size(cols, rows), centers, CALIB_CB_ASYMMETRIC_GRID [| CLUSTERING]) at
+// event_camera_calib/src/CirclesEventFrame.cpp:332-336 (cv_calib/src/cv_calib.cpp:7-87,
+// cv_calib/src/circlesgrid.cpp) followed by the nearest-candidate lookup of :340-353 — with a
+// deterministic lattice walk (the reference's finder runs kmeans with random centres, x100 attempts).
+// Output convention = the reference's (circlesgrid.cpp:1258-1291): grid index i*cols + j is the model
+// point ((2j + i%2) s, i s) (EventCalibIni.cpp:102-106).  For rows x cols = 9 x 4 the pattern has no
+// orientation-preserving self-symmetry, so a complete grid has exactly one valid assignment; the walk
+// assumes the board is seen from its front (model -> image mapping with positive determinant).
+// Parity with OpenCV's finder is NOT pinned (third-party algorithm, random by construction); tests check
+// the ordering against synthetic ground truth.
+//
+// One wave (64 lanes) per window: lanes share the nearest-candidate searches, lane-uniform control flow
+// does the breadth-first walk over the centred-square lattice (neighbours along the two diagonals).
+#include "ecal_ctx.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ecal {
+
+constexpr int GR_T = 64;
+constexpr uint32_t GR_MAXC = 128;  // candidates per window handled
+constexpr int GR_L = 32;           // lattice coordinate window (u, v in [-16, 15])
+constexpr uint32_t GR_MAXM = 128;  // pattern points handled (rows * cols)
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long pack_key(double d2, uint32_t idx) {
+    // non-negative doubles order like their bit patterns; low 8 bits carry the index (ties: smaller index)
+    return (((unsigned long long) __double_as_longlong(d2)) & ~0xFFull) | (idx & 0xFFu);
+}
+
+__global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__restrict__ win_info,
+                                                          const uint32_t *__restrict__ seg_off,
+                                                          const double *__restrict__ cand_xyr, uint32_t rows,
+                                                          uint32_t cols, double tol_frac, int32_t *__restrict__ order,
+                                                          uint32_t *__restrict__ found) {
+    __shared__ double px[GR_MAXC], py[GR_MAXC];
+    __shared__ double e1x[GR_MAXC], e1y[GR_MAXC], e2x[GR_MAXC], e2y[GR_MAXC];  // local lattice basis per node
+    __shared__ int8_t cu[GR_MAXC], cv[GR_MAXC];
+    __shared__ uint8_t assigned[GR_MAXC], queue[GR_MAXC];
+    __shared__ uint8_t occ[GR_L * GR_L];  // lattice cell -> candidate index + 1
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = win_info[4 * (size_t) s], M = rows * cols;
+    int32_t *out = order + (size_t) s * M;
+    for (uint32_t m = lane; m < M; m += GR_T) out[m] = -1;
+    if (lane == 0) found[s] = 0;
+    if (win_info[4 * (size_t) s + 3] != 0 || n < M || n > GR_MAXC || M > GR_MAXM) return;
+    const double *c = cand_xyr + 3 * (size_t) seg_off[2 * s];
+    for (uint32_t i = lane; i < n; i += GR_T) {
+        px[i] = c[3 * i];
+        py[i] = c[3 * i + 1];
+        assigned[i] = 0;
+    }
+    for (uint32_t k = lane; k < GR_L * GR_L; k += GR_T) occ[k] = 0;
+    __syncthreads();
+
+    // nearest candidate to (qx, qy) among those passing `want`; returns packed (dist^2, index)
+    auto nearest = [&](double qx, double qy, bool only_free, uint32_t skip) -> unsigned long long {
+        unsigned long long best = ~0ull;
+        for (uint32_t i = lane; i < n; i += GR_T) {
+            if (i == skip || (only_free && assigned[i])) continue;
+            const double dx = px[i] - qx, dy = py[i] - qy;
+            const unsigned long long k = pack_key(dx * dx + dy * dy, i);
+            best = k < best ? k : best;
+        }
+        return wave_min_u64(best);
+    };
+
+    // seed: the candidate closest to the centroid (an interior circle has all four diagonal neighbours)
+    double sx = 0, sy = 0;
+    for (uint32_t i = lane; i < n; i += GR_T) {
+        sx += px[i];
+        sy += py[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o, 64);
+        sy += __shfl_xor(sy, o, 64);
+    }
+    const uint32_t seed = (uint32_t) (nearest(sx / n, sy / n, false, 0xFFFFFFFFu) & 0xFFu);
+    // its four nearest neighbours give the two diagonal steps
+    uint32_t nb[4];
+    {
+        if (lane == 0) assigned[seed] = 1;
+        __syncthreads();
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long r = nearest(px[seed], py[seed], true, seed);
+            nb[k] = (uint32_t) (r & 0xFFu);
+            if (lane == 0) assigned[nb[k]] = 1;
+            __syncthreads();
+        }
+        if (lane == 0)
+            for (int k = 0; k < 4; k++) assigned[nb[k]] = 0;
+        __syncthreads();
+    }
+    double ax = px[nb[0]] - px[seed], ay = py[nb[0]] - py[seed];
+    double bx = 0, by = 0, bestperp = -1.0;
+    for (int k = 1; k < 4; k++) {
+        const double dx = px[nb[k]] - px[seed], dy = py[nb[k]] - py[seed];
+        const double cr = fabs(ax * dy - ay * dx), nn = sqrt((ax * ax + ay * ay) * (dx * dx + dy * dy));
+        const double perp = nn > 0 ? cr / nn : 0.0;
+        if (perp > bestperp) {
+            bestperp = perp;
+            bx = dx;
+            by = dy;
+        }
+    }
+    const double la = sqrt(ax * ax + ay * ay), lb = sqrt(bx * bx + by * by);
+    if (!(bestperp > 0.5) || !(lb > 0.5 * la && lb < 2.0 * la)) return;  // no usable lattice around the seed
+    if (ax * by - ay * bx < 0) {  // right-handed (u, v) in image coordinates
+        bx = -bx;
+        by = -by;
+    }
+    // breadth-first walk
+    uint32_t qh = 0, qt = 0;
+    if (lane == 0) {
+        assigned[seed] = 1;
+        cu[seed] = 0;
+        cv[seed] = 0;
+        e1x[seed] = ax;
+        e1y[seed] = ay;
+        e2x[seed] = bx;
+        e2y[seed] = by;
+        occ[(GR_L / 2) * GR_L + GR_L / 2] = (uint8_t) (seed + 1);
+        queue[0] = (uint8_t) seed;
+    }
+    qt = 1;
+    __syncthreads();
+    while (qh < qt) {
+        const uint32_t cur = queue[qh++];
+        const int u0 = cu[cur], v0 = cv[cur];
+        const double b1x = e1x[cur], b1y = e1y[cur], b2x = e2x[cur], b2y = e2y[cur];
+        for (int dir = 0; dir < 4; dir++) {
+            const int du = dir == 0 ? 1 : (dir == 1 ? -1 : 0), dv = dir == 2 ? 1 : (dir == 3 ? -1 : 0);
+            const int u = u0 + du, v = v0 + dv;
+            if (u < -GR_L / 2 || u >= GR_L / 2 || v < -GR_L / 2 || v >= GR_L / 2) continue;
+            if (occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)]) continue;
+            const double sxp = du * b1x + dv * b2x, syp = du * b1y + dv * b2y;
+            const double tx = px[cur] + sxp, ty = py[cur] + syp;
+            const unsigned long long r = nearest(tx, ty, true, 0xFFFFFFFFu);
+            if (r == ~0ull) continue;
+            const uint32_t j = (uint32_t) (r & 0xFFu);
+            const double ddx = px[j] - tx, ddy = py[j] - ty;
+            const double lim = tol_frac * tol_frac * (sxp * sxp + syp * syp);
+            if (ddx * ddx + ddy * ddy > lim) continue;
+            if (lane == 0) {
+                assigned[j] = 1;
+                cu[j] = (int8_t) u;
+                cv[j] = (int8_t) v;
+                // the step actually taken refreshes the matching basis vector (perspective / distortion drift)
+                const double mx = px[j] - px[cur], my = py[j] - py[cur];
+                e1x[j] = du ? du * mx : b1x;
+                e1y[j] = du ? du * my : b1y;
+                e2x[j] = dv ? dv * mx : b2x;
+                e2y[j] = dv ? dv * my : b2y;
+                occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] = (uint8_t) (j + 1);
+                queue[qt] = (uint8_t) j;
+            }
+            qt++;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (qt < M) return;
+    // match the pattern: model point (x, y) = ((2j + i%2), i) has lattice coordinates U = (x+y)/2,
+    // V = (y-x)/2 in the right-handed basis E1 = (1,1), E2 = (-1,1); try the four rotations of the
+    // image lattice and every visited node as the image of model point 0
+    const uint32_t combos = 4 * qt;
+    uint32_t win = 0xFFFFFFFFu;
+    for (uint32_t cb = lane; cb < combos; cb += GR_T) {
+        const uint32_t rot = cb / qt, a = queue[cb % qt];
+        bool ok = true;
+        for (uint32_t m = 0; m < M && ok; m++) {
+            const int i = (int) (m / cols), jj = (int) (m % cols);
+            const int x = 2 * jj + (i & 1), y = i;
+            const int U = (x + y) / 2, V = (y - x) / 2;  // relative to model point 0 = (0, 0)
+            int ru, rv;
+            switch (rot) {
+                case 0: ru = U; rv = V; break;
+                case 1: ru = -V; rv = U; break;
+                case 2: ru = -U; rv = -V; break;
+                default: ru = V; rv = -U; break;
+            }
+            const int u = cu[a] + ru, v = cv[a] + rv;
+            ok = u >= -GR_L / 2 && u < GR_L / 2 && v >= -GR_L / 2 && v < GR_L / 2 &&
+                 occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] != 0;
+        }
+        if (ok) win = min(win, cb);
+    }
+    for (int o = 32; o > 0; o >>= 1) win = min(win, (uint32_t) __shfl_xor((int) win, o, 64));
+    if (win == 0xFFFFFFFFu) return;
+    const uint32_t rot = win / qt, a = queue[win % qt];
+    for (uint32_t m = lane; m < M; m += GR_T) {
+        const int i = (int) (m / cols), jj = (int) (m % cols);
+        const int x = 2 * jj + (i & 1), y = i;
+        const int U = (x + y) / 2, V = (y - x) / 2;
+        int ru, rv;
+        switch (rot) {
+            case 0: ru = U; rv = V; break;
+            case 1: ru = -V; rv = U; break;
+            case 2: ru = -U; rv = -V; break;
+            default: ru = V; rv = -U; break;
+        }
+        out[m] = (int32_t) occ[(cv[a] + rv + GR_L / 2) * GR_L + (cu[a] + ru + GR_L / 2)] - 1;
+    }
+    if (lane == 0) found[s] = 1;
+}
+
+}  // namespace ecal
+
+using namespace ecal;
+
+extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off,
+                                   const double *d_cand_xyr, uint32_t S, uint32_t rows, uint32_t cols,
+                                   int32_t *d_order, uint32_t *d_found, void *stream) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (S == 0) return ECAL_OK;
+    if (!d_win_info || !d_seg_off || !d_cand_xyr || !d_order || !d_found || rows * cols < 4 || rows * cols > GR_MAXM) {
+        ctx->last_error = "null pointer or unsupported pattern size";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(grid_order_kernel, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
+                       d_cand_xyr, rows, cols, 0.4, d_order, d_found);
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}

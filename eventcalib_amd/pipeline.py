@@ -33,6 +33,8 @@ class DetectPipeline:
             self.n_clusters = torch.empty(2 * S, dtype=torch.int32, device=dev)
             self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
             self.win_info = torch.empty(S, 4, dtype=torch.int32, device=dev)
+            self.grid_order = torch.empty(S, 128, dtype=torch.int32, device=dev)
+            self.grid_found = torch.empty(S, dtype=torch.int32, device=dev)
             self._cap_windows = S
         if slots > self._cap_slots:
             self.xy = torch.empty(slots, 2, dtype=torch.float64, device=dev)
@@ -83,6 +85,14 @@ class DetectPipeline:
                                 self.cand_xyr.data_ptr(), self.kept_labels.data_ptr(), self.rep.data_ptr(), st,
                                 fit_circle=self.det[3], knn_num=self.det[4])
         return self
+
+    def order_grid(self, rows=9, cols=4):
+        """cv::findCirclesGrid's job on the candidates of the last run(): self.grid_found[s], self.grid_order[s, :rows*cols]."""
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        order = self.grid_order[: self.S].view(-1)[: self.S * rows * cols]
+        self.ctx.grid_order_dev(self.win_info.data_ptr(), self.seg_off.data_ptr(), self.cand_xyr.data_ptr(), self.S, rows,
+                                cols, order.data_ptr(), self.grid_found.data_ptr(), st)
+        return order.view(self.S, rows * cols), self.grid_found[: self.S]
 
     def overflowed(self):
         return bool(self.flags[0].item())

@@ -185,6 +185,21 @@ int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, v
 int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const double *t0, const double *t1, uint32_t S,
                       const ecal_detect_params *prm, uint32_t cap_points, ecal_detect_result *res);
 
+/* ---- grid ordering of the candidates -----------------------------------------------------------------
+ * Replaces cv::findCirclesGrid(points, Size(cols, rows), centers, CALIB_CB_ASYMMETRIC_GRID[|CLUSTERING]) and the
+ * nearest-candidate lookup after it (event_camera_calib/src/CirclesEventFrame.cpp:332-353; the finder is the
+ * reference's vendored OpenCV code, cv_calib/src/circlesgrid.cpp) for all windows at once.
+ * Inputs: d_win_info / d_seg_off / d_cand_xyr as written by ecal_extract_batch_dev.  Per window s:
+ *   d_found[s] = 1 and d_order[s*rows*cols + i*cols + j] = index (into the window's candidate list) of the
+ *   circle at model point ((2j + i%2) s, i s, 0) (EventCalibIni.cpp:102-106) — the reference's orderIdxs —
+ *   or d_found[s] = 0 and -1 entries when no complete grid is found (extractFeatures returns false).
+ * Deterministic lattice walk, not OpenCV's randomised (kmeans) search: same ordering whenever a complete
+ * grid is present and seen from its front; parity with the third-party finder is otherwise unpinned.
+ * Up to 128 candidates per window, rows*cols <= 128. */
+int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off, const double *d_cand_xyr,
+                        uint32_t S, uint32_t rows, uint32_t cols, int32_t *d_order /*[S][rows*cols]*/,
+                        uint32_t *d_found /*[S]*/, void *stream);
+
 /* ---- event -> residual association ----------------------------------------------------------------
  * Replaces the association loop of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
  * 140-192) and CirclesEventFrame::findCenter (include/opengv2/event_camera_calib/CirclesEventFrame.hpp:50-65):
