@@ -28,6 +28,7 @@ struct ecal_ctx {
     ecal_devbuf det_members, det_koff, det_ksize, det_sorted, det_norms;  // detection stage scratch
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
+    ecal_devbuf host_grid_order, host_grid_found;
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
@@ -35,7 +36,8 @@ struct ecal_ctx {
                 &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &as_cnt, &as_off,
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
                 &host_pipe[6], &host_pipe[7], &host_pipe[8], &host_pipe[9], &host_pipe[10], &host_pipe[11],
-                &host_pipe[12], &host_pipe[13], &host_pipe[14], &host_pipe[15], &host_pipe[16]};
+                &host_pipe[12], &host_pipe[13], &host_pipe[14], &host_pipe[15], &host_pipe[16],
+                &host_grid_order, &host_grid_found};
     }
 };
 

@@ -115,6 +115,21 @@ extern "C" int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const dou
                                      (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr,
                                      (uint32_t *) B[12].ptr, st)))
         return rc;
+    const uint32_t M = prm->rows * prm->cols;
+    if (M > 0) {
+        if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S,
+                                      prm->rows, prm->cols, (int32_t *) ctx->host_grid_order.ptr,
+                                      (uint32_t *) ctx->host_grid_found.ptr, st)))
+            return rc;
+        if (res->grid_order)
+            ECAL_HIP_TRY(ctx, hipMemcpyAsync(res->grid_order, ctx->host_grid_order.ptr, (size_t) S * M * sizeof(int32_t),
+                                             hipMemcpyDeviceToHost, st));
+        if (res->grid_found)
+            ECAL_HIP_TRY(ctx, hipMemcpyAsync(res->grid_found, ctx->host_grid_found.ptr, (size_t) S * sizeof(uint32_t),
+                                             hipMemcpyDeviceToHost, st));
+    }
     int overflow = 0;
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(&overflow, B[16].ptr, sizeof(int), hipMemcpyDeviceToHost, st));
     const Out outs[] = {{res->win_lo, &B[2], S * 4ul},        {res->win_hi, &B[3], S * 4ul},

@@ -2,10 +2,10 @@
 // (event_camera_calib/include/opengv2/event_camera_calib/CirclesEventFrame.hpp,
 //  event_camera_calib/src/CirclesEventFrame.cpp) on top of libecal.so.
 //
-// extractFeatures() runs the reference's extraction up to the candidate circles on the GPU.  The
-// last step of the reference — cv::findCirclesGrid ordering the candidates into the pattern grid
-// (:332-353) — is not part of this round: candidates() exposes the candidate list, and
-// extractFeatures() returns whether the frame reached a full candidate set (>= rows*cols).
+// extractFeatures() runs the whole reference function on the GPU: DBSCAN x2, cluster filter, medians,
+// pairing / circle fit, and the ordering of the candidates into the pattern grid (a deterministic lattice
+// walk in place of the vendored cv::findCirclesGrid, ecal_grid_order_dev); features() are the circles in
+// grid order, index i*cols + j <-> landmark ((2j + i%2) s, i s, 0).
 #ifndef ECAL_HOST_CIRCLES_EVENT_FRAME_HPP_
 #define ECAL_HOST_CIRCLES_EVENT_FRAME_HPP_
 
@@ -39,14 +39,23 @@ public:
                                                               pattern_->squareSize, pattern_->circleRadius);
     }
 
-    // false when a polarity is empty, when fewer than rows*cols clusters survive the size filter
-    // in either polarity (CirclesEventFrame.cpp:62-64,127-129), or when fewer than rows*cols
-    // candidate circles are found (the reference's findCirclesGrid cannot succeed with fewer).
+    struct CalibCircle {  // event_camera_calib/include/opengv2/event_camera_calib/CalibCircle.hpp
+        Vector2d location;
+        double radius;
+    };
+
+    // false when a polarity is empty, when fewer than rows*cols clusters survive the size filter in either
+    // polarity (CirclesEventFrame.cpp:62-64,127-129), or when no complete grid is found among the candidates
+    // (findCirclesGrid's isFound, :332-336,358).
     bool extractFeatures() {
         ensure();
-        if (det_.status != 0) return false;
-        return det_.candidates.size() >= (size_t) (pattern_->rows * pattern_->cols);
+        features_.clear();
+        if (det_.status != 0 || !det_.gridFound) return false;
+        for (size_t idx : det_.orderIdxs)  // :350-353
+            features_.push_back(CalibCircle{det_.candidateCenters[idx], det_.candidatesRadius[idx]});
+        return true;
     }
+    const std::vector<CalibCircle> &features() const { return features_; }
 
     const FrameDetection &detection() {
         ensure();
@@ -64,11 +73,14 @@ protected:
         p.circle_radius_threshold = circleRadiusThreshold_;
         p.fit_circle = params_.fitCircle ? 1 : 0;
         p.knn_num = (uint32_t) params_.knn_num;
+        p.rows = (uint32_t) pattern_->rows;
+        p.cols = (uint32_t) pattern_->cols;
         return p;
     }
     CirclePatternParameters::Ptr pattern_;
     Params params_;
     double circleRadiusThreshold_;
+    std::vector<CalibCircle> features_;
 };
 
 }  // namespace opengv2

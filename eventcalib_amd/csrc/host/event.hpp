@@ -160,6 +160,8 @@ struct FrameDetection {
     std::vector<std::pair<size_t, size_t>> candidates;  // (+ cluster, - cluster), kept numbering
     std::vector<Vector2d> candidateCenters;
     std::vector<double> candidatesRadius;
+    bool gridFound = false;            // cv::findCirclesGrid's isFound (CirclesEventFrame.cpp:332-336)
+    std::vector<size_t> orderIdxs;     // candidate index per grid position i*cols + j (:343-348)
 };
 
 inline void detect_windows(EventContainer &c, const std::vector<std::pair<double, double>> &durations,
@@ -180,6 +182,9 @@ inline void detect_windows(EventContainer &c, const std::vector<std::pair<double
     probe.win_base = base.data();
     size_t cap = c.size();
     std::vector<double> xy;
+    const uint32_t M = prm.rows * prm.cols;
+    std::vector<int32_t> gorder((size_t) S * (M ? M : 1));
+    std::vector<uint32_t> gfound(S, 0);
     std::vector<uint32_t> seg_off(2 * S), seg_cnt(2 * S), ncl(2 * S), info(4 * S), pair;
     std::vector<int32_t> labels, kept;
     std::vector<double> xyr;
@@ -201,6 +206,8 @@ inline void detect_windows(EventContainer &c, const std::vector<std::pair<double
         r.win_info = info.data();
         r.cand_pair = pair.data();
         r.cand_xyr = xyr.data();
+        r.grid_order = gorder.data();
+        r.grid_found = gfound.data();
         const int rc = ecal_detect_batch(ctx, c.device(), t0.data(), t1.data(), S, &prm, (uint32_t) cap, &r);
         if (rc == ECAL_OK) break;
         if (rc == ECAL_ERR_RANGE && attempt == 0) {  // overlapping windows cover more slots than events
@@ -230,6 +237,9 @@ inline void detect_windows(EventContainer &c, const std::vector<std::pair<double
             f.candidateCenters.push_back(Vector2d{{xyr[3 * (op + j)], xyr[3 * (op + j) + 1]}});
             f.candidatesRadius.push_back(xyr[3 * (op + j) + 2]);
         }
+        f.gridFound = M > 0 && gfound[s] != 0;
+        if (f.gridFound)
+            for (uint32_t m = 0; m < M; m++) f.orderIdxs.push_back((size_t) gorder[(size_t) s * M + m]);
     }
 }
 
@@ -267,6 +277,8 @@ protected:
         p.circle_radius_threshold = ecal_circle_radius_threshold(346, 260, 9, 4, 1, 5.5, 1.75);
         p.fit_circle = 0;
         p.knn_num = 3;
+        p.rows = 0;
+        p.cols = 0;
         return p;
     }
     void ensure() {

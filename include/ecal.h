@@ -162,6 +162,7 @@ typedef struct ecal_detect_params {
     double circle_radius_threshold;  /* ecal_circle_radius_threshold(...) */
     int fit_circle;                  /* fitCircle */
     uint32_t knn_num;                /* knn_num (used when fit_circle != 0) */
+    uint32_t rows, cols;             /* BoardSize_Rows / BoardSize_Cols: grid ordering runs when both are > 0 */
 } ecal_detect_params;
 typedef struct ecal_detect_result {
     uint32_t *win_lo, *win_hi; /* [S] */
@@ -176,6 +177,8 @@ typedef struct ecal_detect_result {
     uint32_t *win_info;        /* [S][4] */
     uint32_t *cand_pair;       /* [cap_points][2] */
     double *cand_xyr;          /* [cap_points][3] */
+    int32_t *grid_order;       /* [S][rows*cols] (ecal_grid_order_dev), when params.rows * params.cols > 0 */
+    uint32_t *grid_found;      /* [S] */
 } ecal_detect_result;
 int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t n_events, ecal_stream **out);
 void ecal_stream_destroy(ecal_stream *s);

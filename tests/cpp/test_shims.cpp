@@ -6,7 +6,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../eventcalib_amd/csrc/host/circles_event_frame.hpp"
+#include "../../eventcalib_amd/csrc/host/multi_process.hpp"
 
 #define CHECK(c)                                                        \
     do {                                                                \
@@ -84,7 +84,25 @@ int main(int argc, char **argv) {
     prm.circle_radius_threshold = frame.circleRadiusThreshold();
     prm.fit_circle = 0;
     prm.knn_num = 3;
+    prm.rows = 9;
+    prm.cols = 4;
     detect_windows(*container, wins, prm, out);
     CHECK(out.size() == 6 && out[0].positive.size() == d.positive.size());
+    if (ok) {  // ordered features: 36 circles, neighbours in a row are ~2 squares apart and ordered consistently
+        CHECK(frame.features().size() == 36);
+        CHECK(d.gridFound && d.orderIdxs.size() == 36);
+    }
+    // the driver's adaptive windowing + keyframe gate (eventCameraCalib.cpp:34-97, EventCalibIni.cpp:23-97)
+    CirclesEventFrame::Params fp;
+    const double step = 5e-4;
+    std::vector<KeyFrame> kfs = detect_keyframes(*container, pattern, fp, step, 4000, 4, t0, container->lastTime());
+    std::printf("adaptive windowing: %zu keyframes\n", kfs.size());
+    CHECK(kfs.size() >= 2);
+    for (size_t k = 0; k < kfs.size(); k++) {
+        CHECK(kfs[k].features.size() == 36);
+        CHECK(kfs[k].duration.second - kfs[k].duration.first >= 3 * step - 1e-12);
+        CHECK(kfs[k].duration.second - kfs[k].duration.first <= 10 * step + 1e-9);
+        if (k) CHECK(kfs[k].timeStamp > kfs[k - 1].timeStamp);
+    }
     return 0;
 }
