@@ -15,11 +15,19 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_detect_batch", "ecal_copy_dev",
-    "ecal_grid_order_dev", "ecal_associate_dev",
+    "ecal_grid_order_dev", "ecal_associate_dev", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
 ]
+
+
+class RectifyParams(ctypes.Structure):
+    """ecal_rectify_params (include/ecal.h)."""
+    _fields_ = [("fx", ctypes.c_double), ("fy", ctypes.c_double), ("cx", ctypes.c_double), ("cy", ctypes.c_double),
+                ("dist", ctypes.c_double * 5), ("width", ctypes.c_double), ("height", ctypes.c_double),
+                ("rows", ctypes.c_uint32), ("cols", ctypes.c_uint32), ("asymmetric", ctypes.c_int),
+                ("circle_radius", ctypes.c_double), ("fit_circle", ctypes.c_int)]
 
 
 class EcalError(RuntimeError):
@@ -71,6 +79,9 @@ def load_library():
     L.ecal_extract_batch_dev.restype = i32
     L.ecal_grid_order_dev.argtypes = [vp, vp, vp, vp, u32, u32, u32, vp, vp, vp]
     L.ecal_grid_order_dev.restype = i32
+    L.ecal_rectify_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u32, vp, ctypes.POINTER(RectifyParams),
+                                         vp, vp, vp, vp]
+    L.ecal_rectify_batch_dev.restype = i32
     L.ecal_associate_dev.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, u32, u32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
     L.ecal_associate_dev.restype = i32
     L.ecal_copy_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, i32]
@@ -160,6 +171,13 @@ class Context:
     def grid_order_dev(self, d_win_info, d_seg_off, d_cand_xyr, S, rows, cols, d_order, d_found, stream=0):
         self._check(self._L.ecal_grid_order_dev(self._h, d_win_info, d_seg_off, d_cand_xyr, int(S), int(rows), int(cols),
                                                 d_order, d_found, stream))
+
+    # ---- re-detection around predicted projections ----
+    def rectify_batch_dev(self, d_xy, d_seg_off, d_seg_cnt, d_kept_labels, d_win_info, d_frame_window, d_pose, F,
+                          d_landmarks, params, d_feat_xyr, d_feat_valid, d_frame_info, stream=0):
+        self._check(self._L.ecal_rectify_batch_dev(self._h, d_xy, d_seg_off, d_seg_cnt, d_kept_labels, d_win_info,
+                                                   d_frame_window, d_pose, int(F), d_landmarks, ctypes.byref(params),
+                                                   d_feat_xyr, d_feat_valid, d_frame_info, stream))
 
     # ---- event -> residual association ----
     def associate_dev(self, d_events, n_events, d_kf_time, d_kf_circles, n_keyframes, n_circles, t_min, t_max,

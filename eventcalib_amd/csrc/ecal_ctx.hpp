@@ -29,11 +29,14 @@ struct ecal_ctx {
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
     ecal_devbuf host_grid_order, host_grid_found;
+    ecal_devbuf host_rect[11];  // staging of ecal_rectify_batch
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos,
                 &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &as_cnt, &as_off,
+                &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
+                &host_rect[7], &host_rect[8], &host_rect[9], &host_rect[10],
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
                 &host_pipe[6], &host_pipe[7], &host_pipe[8], &host_pipe[9], &host_pipe[10], &host_pipe[11],
                 &host_pipe[12], &host_pipe[13], &host_pipe[14], &host_pipe[15], &host_pipe[16],

@@ -160,3 +160,57 @@ extern "C" int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size
     if (sync) ECAL_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t) stream));
     return ECAL_OK;
 }
+
+// Host-buffer form of ecal_rectify_batch_dev (what CirclesEventFrame::rectifyFeatures in host/ calls): keyframe f
+// owns segments 2f (positiveEvents_) and 2f+1 (negativeEvents_) of xy / kept_labels.
+extern "C" int ecal_rectify_batch(ecal_ctx *ctx, const double *xy, const uint32_t *seg_off, const uint32_t *seg_cnt,
+                                  const int32_t *kept_labels, uint32_t n_points, const double *pose, uint32_t F,
+                                  const double *landmarks, const ecal_rectify_params *prm, double *feat_xyr,
+                                  uint32_t *feat_valid, uint32_t *frame_info) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (F == 0) return ECAL_OK;
+    if (!seg_off || !seg_cnt || !pose || !landmarks || !prm || !feat_xyr || !feat_valid || !frame_info ||
+        (n_points && (!xy || !kept_labels))) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    const uint32_t n = prm->rows * prm->cols;
+    std::vector<uint32_t> info(4 * (size_t) F, 0), window(F);
+    for (uint32_t f = 0; f < F; f++) {
+        window[f] = f;
+        for (int pol = 0; pol < 2; pol++) {
+            const uint32_t o = seg_off[2 * f + pol], c = seg_cnt[2 * f + pol];
+            if ((uint64_t) o + c > n_points) {
+                ctx->last_error = "segment outside the point array";
+                return ECAL_ERR_RANGE;
+            }
+            int32_t mx = -1;
+            for (uint32_t i = 0; i < c; i++) mx = std::max(mx, kept_labels[o + i]);
+            info[4 * (size_t) f + 1 + pol] = (uint32_t) (mx + 1);
+        }
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t np = n_points ? n_points : 1;
+    const size_t bytes[11] = {np * 16, (size_t) F * 8, (size_t) F * 8, np * 4, (size_t) F * 16, (size_t) F * 4,
+                              (size_t) F * 96, (size_t) n * 24, (size_t) F * n * 24, (size_t) F * n * 4, (size_t) F * 8};
+    for (int i = 0; i < 11; i++)
+        if (int rc = ecal_ensure(ctx, ctx->host_rect[i], bytes[i])) return rc;
+    void *dp[11];
+    for (int i = 0; i < 11; i++) dp[i] = ctx->host_rect[i].ptr;
+    hipStream_t st = ctx->stream;
+    const void *src[8] = {xy, seg_off, seg_cnt, kept_labels, info.data(), window.data(), pose, landmarks};
+    for (int i = 0; i < 8; i++) {
+        if ((i == 0 || i == 3) && n_points == 0) continue;
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(dp[i], src[i], bytes[i], hipMemcpyHostToDevice, st));
+    }
+    if (int rc = ecal_rectify_batch_dev(ctx, (const double *) dp[0], (const uint32_t *) dp[1], (const uint32_t *) dp[2],
+                                        (const int32_t *) dp[3], (const uint32_t *) dp[4], (const uint32_t *) dp[5],
+                                        (const double *) dp[6], F, (const double *) dp[7], prm, (double *) dp[8],
+                                        (uint32_t *) dp[9], (uint32_t *) dp[10], st))
+        return rc;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(feat_xyr, dp[8], bytes[8], hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(feat_valid, dp[9], bytes[9], hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(frame_info, dp[10], bytes[10], hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ECAL_OK;
+}

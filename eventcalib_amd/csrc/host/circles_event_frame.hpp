@@ -9,6 +9,8 @@
 #ifndef ECAL_HOST_CIRCLES_EVENT_FRAME_HPP_
 #define ECAL_HOST_CIRCLES_EVENT_FRAME_HPP_
 
+#include <unordered_set>
+
 #include "event.hpp"
 
 namespace opengv2 {
@@ -57,6 +59,66 @@ public:
     }
     const std::vector<CalibCircle> &features() const { return features_; }
 
+    // camera model rectifyFeatures projects with (the reference reads it from sensor_: PinholeCamera K, distCoeffs
+    // k1 k2 p1 p2 k3 and size(), CirclesEventFrame.cpp:426-433)
+    struct Camera {
+        double fx, fy, cx, cy;
+        double distCoeffs[5];
+    };
+
+    // CirclesEventFrame::rectifyFeatures (:417-638) after extractFeatures() succeeded: every feature is re-found
+    // around the projection of its landmark under the pose (Rcw row-major, tcw); erased features leave
+    // features_ (their grid index is kept in featureLandmark()), false = discard the frame.  `outlierIdxs` is
+    // unused, as in the reference.
+    bool rectifyFeatures(const std::unordered_set<int> & /*outlierIdxs*/, const double (&Rcw)[9], const double (&tcw)[3],
+                         const Camera &camera) {
+        ensure();
+        const uint32_t n = (uint32_t) (pattern_->rows * pattern_->cols);
+        if (features_.size() != n) return false;
+        std::vector<double> xy, lm(3 * (size_t) n), feat(3 * (size_t) n);
+        std::vector<int32_t> kept;
+        for (const auto &p : det_.positive) xy.push_back(p[0]), xy.push_back(p[1]);
+        for (const auto &p : det_.negative) xy.push_back(p[0]), xy.push_back(p[1]);
+        kept.insert(kept.end(), det_.keptPos.begin(), det_.keptPos.end());
+        kept.insert(kept.end(), det_.keptNeg.begin(), det_.keptNeg.end());
+        const uint32_t off[2] = {0, (uint32_t) det_.positive.size()};
+        const uint32_t cnt[2] = {(uint32_t) det_.positive.size(), (uint32_t) det_.negative.size()};
+        for (int i = 0; i < pattern_->rows; i++)      // EventCalibIni::calcBoardCornerPositions (:98-112), cv::Point3f
+            for (int j = 0; j < pattern_->cols; j++) {
+                double *o = &lm[3 * (size_t) (i * pattern_->cols + j)];
+                o[0] = (float) ((pattern_->isAsymmetric ? (2 * j + i % 2) : j) * pattern_->squareSize);
+                o[1] = (float) (i * pattern_->squareSize);
+                o[2] = 0;
+            }
+        double pose[12];
+        for (int i = 0; i < 9; i++) pose[i] = Rcw[i];
+        for (int i = 0; i < 3; i++) pose[9 + i] = tcw[i];
+        ecal_rectify_params prm;
+        prm.fx = camera.fx, prm.fy = camera.fy, prm.cx = camera.cx, prm.cy = camera.cy;
+        for (int i = 0; i < 5; i++) prm.dist[i] = camera.distCoeffs[i];
+        prm.width = container_->cameraSize[0], prm.height = container_->cameraSize[1];
+        prm.rows = (uint32_t) pattern_->rows, prm.cols = (uint32_t) pattern_->cols;
+        prm.asymmetric = pattern_->isAsymmetric ? 1 : 0;
+        prm.circle_radius = pattern_->circleRadius;
+        prm.fit_circle = params_.fitCircle ? 1 : 0;
+        std::vector<uint32_t> valid(n);
+        uint32_t info[2] = {0, 0};
+        const int rc = ecal_rectify_batch(ecal_host::thread_ctx(), xy.data(), off, cnt, kept.data(),
+                                          (uint32_t) kept.size(), pose, 1, lm.data(), &prm, feat.data(), valid.data(), info);
+        if (rc != ECAL_OK)
+            throw std::runtime_error(std::string("ecal_rectify_batch: ") + ecal_last_error(ecal_host::thread_ctx()));
+        features_.clear();
+        featureLandmark_.clear();
+        for (uint32_t k = 0; k < n; k++)
+            if (valid[k]) {
+                features_.push_back(CalibCircle{Vector2d{{feat[3 * k], feat[3 * k + 1]}}, feat[3 * k + 2]});
+                featureLandmark_.push_back((int) k);
+            }
+        return info[0] != 0;
+    }
+    // landmark (grid) index of features()[i] after rectifyFeatures (the reference keeps f->landmark())
+    const std::vector<int> &featureLandmark() const { return featureLandmark_; }
+
     const FrameDetection &detection() {
         ensure();
         return det_;
@@ -81,6 +143,7 @@ protected:
     Params params_;
     double circleRadiusThreshold_;
     std::vector<CalibCircle> features_;
+    std::vector<int> featureLandmark_;
 };
 
 }  // namespace opengv2

@@ -203,6 +203,41 @@ int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_
                         uint32_t S, uint32_t rows, uint32_t cols, int32_t *d_order /*[S][rows*cols]*/,
                         uint32_t *d_found /*[S]*/, void *stream);
 
+/* ---- re-detection of the circles around their predicted projections ---------------------------------
+ * Replaces CirclesEventFrame::rectifyFeatures(outlierIdxs, Rcw, tcw) (event_camera_calib/src/
+ * CirclesEventFrame.cpp:417-638; caller EventCalibIni.cpp:294) for F keyframes at once.  Keyframe f is window
+ * d_frame_window[f] of the slicing / DBSCAN / extraction outputs (d_xy, d_seg_off, d_seg_cnt, d_kept_labels =
+ * pClusters_/nClusters_ membership, d_win_info); d_pose[12f..] = Rcw row-major (9) then tcw (3), the pose
+ * solvePnPRansac gave it (EventCalibIni.cpp:258-272); d_landmarks [rows*cols][3] = landmark positions in grid
+ * order (EventCalibIni.cpp:102-106; narrowed to float as the reference's cv::Point3f).  Per circle k:
+ *   d_feat_valid[f*n + k] = 0 if the reference erases the feature (projection outside the image :457-461, fewer
+ *   than 5 events of either polarity :560-563, refit too far from the prediction :572-576), else 1 and
+ *   d_feat_xyr[3(f*n + k)..] = rectified centre x, y, radius (NaN when erased).
+ *   d_frame_info[2f..] = { return value of rectifyFeatures (border score :587-622 with fit_circle == 0, 20 % rule
+ *   :625-627), number of erased features }.
+ * The outlierIdxs argument of the reference is unused there and has no counterpart.  d_feat_xyr of the accepted
+ * keyframes is what ecal_associate_dev takes as d_kf_circles (NaN rows never match an event).
+ * cv::projectPoints (OpenCV, third party) is restated: 5 distortion coefficients k1 k2 p1 p2 k3. */
+typedef struct ecal_rectify_params {
+    double fx, fy, cx, cy;     /* camera->K() */
+    double dist[5];            /* camera->distCoeffs(): k1 k2 p1 p2 k3 */
+    double width, height;      /* camera->size() */
+    uint32_t rows, cols;       /* BoardSize_Rows / BoardSize_Cols, rows*cols <= 128 */
+    int asymmetric;            /* pattern_->isAsymmetric */
+    double circle_radius;      /* Circles_Radius (world units) */
+    int fit_circle;            /* params_.fitCircle: != 0 skips the border-score test */
+} ecal_rectify_params;
+int ecal_rectify_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                           const int32_t *d_kept_labels, const uint32_t *d_win_info, const uint32_t *d_frame_window /*[F]*/,
+                           const double *d_pose /*[F][12]*/, uint32_t F, const double *d_landmarks /*[rows*cols][3]*/,
+                           const ecal_rectify_params *prm, double *d_feat_xyr /*[F][rows*cols][3]*/,
+                           uint32_t *d_feat_valid /*[F][rows*cols]*/, uint32_t *d_frame_info /*[F][2]*/, void *stream);
+/* host-buffer form: keyframe f owns segments 2f (positiveEvents_) and 2f+1 (negativeEvents_) of xy / kept_labels */
+int ecal_rectify_batch(ecal_ctx *ctx, const double *xy /*[n_points][2]*/, const uint32_t *seg_off /*[2F]*/,
+                       const uint32_t *seg_cnt /*[2F]*/, const int32_t *kept_labels /*[n_points]*/, uint32_t n_points,
+                       const double *pose /*[F][12]*/, uint32_t F, const double *landmarks, const ecal_rectify_params *prm,
+                       double *feat_xyr, uint32_t *feat_valid, uint32_t *frame_info);
+
 /* ---- event -> residual association ----------------------------------------------------------------
  * Replaces the association loop of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
  * 140-192) and CirclesEventFrame::findCenter (include/opengv2/event_camera_calib/CirclesEventFrame.hpp:50-65):

@@ -2,6 +2,7 @@
 // (CirclesEventFrame.cpp:66-72 for DBSCAN; eventCameraCalib.cpp:138-163,49-56 for the stream,
 // container and frames).  Built and run by tests/test_gpu_shims.py on the GPU box.
 //   usage: test_shims events.bin
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -91,6 +92,34 @@ int main(int argc, char **argv) {
     if (ok) {  // ordered features: 36 circles, neighbours in a row are ~2 squares apart and ordered consistently
         CHECK(frame.features().size() == 36);
         CHECK(d.gridFound && d.orderIdxs.size() == 36);
+    }
+    // rectifyFeatures (CirclesEventFrame.cpp:417-638) with the pose of the window's mid time (argv[2]: rows of
+    // t + Rcw row-major + tcw) and with a pose 5 cm off
+    if (ok && argc > 2) {
+        std::ifstream pf(argv[2], std::ios::binary);
+        std::vector<double> row(13), best(13);
+        double bd = 1e300;
+        const double tm = t0 + 0.75e-3;
+        while (pf.read(reinterpret_cast<char *>(row.data()), 13 * sizeof(double)))
+            if (std::fabs(row[0] - tm) < bd) bd = std::fabs(row[0] - tm), best = row;
+        CHECK(bd < 1e-3);
+        double R[9], tc[3], tbad[3];
+        for (int i = 0; i < 9; i++) R[i] = best[1 + i];
+        for (int i = 0; i < 3; i++) tc[i] = best[10 + i], tbad[i] = best[10 + i] + (i == 0 ? 5.0 : 0.0);
+        const CirclesEventFrame::Camera cam{359.67525, 359.67525, 172.5, 129.5, {-0.34991902, -0.014698517, 0, 0, 0.59684463}};
+        CirclesEventFrame good(container, {t0, t0 + 1.5e-3}, pattern), bad(container, {t0, t0 + 1.5e-3}, pattern);
+        CHECK(good.extractFeatures() && bad.extractFeatures());
+        const std::vector<CirclesEventFrame::CalibCircle> before = good.features();
+        CHECK(good.rectifyFeatures({}, R, tc, cam));
+        CHECK(good.features().size() >= 30 && good.features().size() == good.featureLandmark().size());
+        for (size_t i = 0; i < good.features().size(); i++) {   // refit centres stay near the midpoint candidates
+            const auto &a = good.features()[i];
+            const auto &b = before[(size_t) good.featureLandmark()[i]];
+            CHECK(std::hypot(a.location[0] - b.location[0], a.location[1] - b.location[1]) < 12.0);
+        }
+        CHECK(!bad.rectifyFeatures({}, R, tbad, cam));
+        std::printf("rectify: %zu of 36 features kept with the true pose, frame rejected with the shifted pose\n",
+                    good.features().size());
     }
     // the driver's adaptive windowing + keyframe gate (eventCameraCalib.cpp:34-97, EventCalibIni.cpp:23-97)
     CirclesEventFrame::Params fp;

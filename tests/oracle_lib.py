@@ -284,3 +284,30 @@ def associate(rec, kf_time, circles, t_min, t_max, max_dt, edge_tol):
     m = L.oracle_associate(_p(rec, _u8p), n, _p(kf, _dp), _p(ci, _dp), K, nc, float(t_min), float(t_max), float(max_dt),
                            float(edge_tol), _p(obs, _dp), _p(tm, _dp), _p(lm, _u32p))
     return obs[:m].copy(), tm[:m].copy(), lm[:m].copy()
+
+
+def rectify(pos, neg, kept_pos, kept_neg, pose, camera, dist, width, height, landmarks, rows, cols, asymmetric,
+            circle_radius, fit_circle=False):
+    """CirclesEventFrame::rectifyFeatures for one keyframe -> (feat_xyr [n,3], valid [n], ok, erased)."""
+    L = lib()
+    L.oracle_rectify.restype = ctypes.c_int
+    pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 2)
+    neg = np.ascontiguousarray(neg, np.float64).reshape(-1, 2)
+    kp = np.ascontiguousarray(kept_pos, np.int32)
+    kn = np.ascontiguousarray(kept_neg, np.int32)
+    pose = np.ascontiguousarray(pose, np.float64).reshape(12)
+    camera = np.ascontiguousarray(camera, np.float64).reshape(4)
+    dist = np.ascontiguousarray(dist, np.float64).reshape(5)
+    lm = np.ascontiguousarray(landmarks, np.float64).reshape(-1, 3)
+    n = rows * cols
+    feat = np.zeros((n, 3), np.float64)
+    valid = np.zeros(n, np.uint32)
+    info = np.zeros(2, np.uint32)
+    vp = ctypes.c_void_p
+    L.oracle_rectify(vp(pos.ctypes.data), ctypes.c_uint32(len(pos)), vp(neg.ctypes.data), ctypes.c_uint32(len(neg)),
+                     vp(kp.ctypes.data), vp(kn.ctypes.data), vp(pose.ctypes.data), vp(camera.ctypes.data),
+                     vp(dist.ctypes.data), ctypes.c_double(width), ctypes.c_double(height), vp(lm.ctypes.data),
+                     ctypes.c_uint32(rows), ctypes.c_uint32(cols), ctypes.c_int(int(asymmetric)),
+                     ctypes.c_double(circle_radius), ctypes.c_int(int(fit_circle)), vp(feat.ctypes.data),
+                     vp(valid.ctypes.data), vp(info.ctypes.data))
+    return feat, valid, int(info[0]), int(info[1])

@@ -18,6 +18,11 @@ def test_cpp_shims(tmp_path):
                            "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"])
     binf = str(tmp_path / "events.bin")
     SS.make_stream(60000, rate=2.0e6, device="cpu").numpy().tofile(binf)
-    out = subprocess.run([exe, binf], capture_output=True, text=True, timeout=300)
+    import numpy as np
+    import synth_rectify as SR
+    times = 5.0 + np.arange(0, 400) * 1e-4
+    posef = str(tmp_path / "poses.bin")
+    np.concatenate([times[:, None], SR.poses_cw(times)], axis=1).astype(np.float64).tofile(posef)
+    out = subprocess.run([exe, binf, posef], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "shims ok" in out.stdout
+    assert "shims ok" in out.stdout and "rectify:" in out.stdout
