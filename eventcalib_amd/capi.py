@@ -205,7 +205,8 @@ class _SplineProblem(ctypes.Structure):
     _fields_ = [("n_segments", ctypes.c_uint32), ("seg_cp_off", ctypes.c_void_p), ("knots", ctypes.c_void_p),
                 ("n_res", ctypes.c_uint64), ("obs", ctypes.c_void_p), ("time", ctypes.c_void_p),
                 ("lm_id", ctypes.c_void_p), ("seg_id", ctypes.c_void_p), ("n_landmarks", ctypes.c_uint32),
-                ("landmarks", ctypes.c_void_p), ("circle_radius", ctypes.c_double), ("huber_a", ctypes.c_double)]
+                ("landmarks", ctypes.c_void_p), ("circle_radius", ctypes.c_double), ("huber_a", ctypes.c_double),
+                ("use_so3", ctypes.c_int)]
 
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -264,7 +265,7 @@ class Solver:
     """ecal_solver: residual records + spline layout resident on the GPU.
 
     problem: dict with seg_cp_off [G+1] u32, knots f64, obs [M,2], time [M], lm_id [M] u32,
-    seg_id [M] u32 or None, landmarks [L,3], circle_radius, huber_a.
+    seg_id [M] u32 or None, landmarks [L,3], circle_radius, huber_a, use_so3 (optional, default False).
     Parameter vector layout: [intr 9 | q n_cp x 4 (xyzw) | t n_cp x 3]."""
 
     def __init__(self, ctx: Context, problem):
@@ -291,6 +292,7 @@ class Solver:
         P.n_landmarks = keep["landmarks"].reshape(-1, 3).shape[0]
         P.circle_radius = float(problem["circle_radius"])
         P.huber_a = float(problem["huber_a"])
+        P.use_so3 = int(bool(problem.get("use_so3", False)))
         h = ctypes.c_void_p()
         ctx._check(L.ecal_solver_create(ctx._h, ctypes.byref(P), ctypes.byref(h)))
         self._h = h

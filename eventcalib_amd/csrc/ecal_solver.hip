@@ -56,6 +56,7 @@ __device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_i
     }
 }
 
+template <bool SO3>
 __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__restrict__ rec,
                                                          const Chunk *__restrict__ chunks,
                                                          const double *__restrict__ knots,
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
             in.lmz = landmarks[3 * (size_t) e.lm + 2];
             in.radius = radius;
             spline_basis(kn, ch.span, e.t, in.b);
-            r = spline_residual(in, pin, q, t, with_jac ? J : nullptr);
+            r = SO3 ? spline_residual_so3(in, pin, q, t, with_jac ? J : nullptr)
+                    : spline_residual(in, pin, q, t, with_jac ? J : nullptr);
             double hr;
             sc = huber_scale(r, huber_a, &hr);
             cost += hr;
@@ -212,6 +214,7 @@ struct ecal_solver {
     uint64_t n_res = 0;
     uint32_t n_cp = 0, n_seg = 0, n_chunks = 0;
     double radius = 0, huber_a = 0;
+    bool use_so3 = false;  // cumulative SO3 spline + LocalParameterizationSO3 instead of the quaternion spline
     std::vector<uint32_t> cp_off, knot_off;
     std::vector<double> knots;
     ResRecord *d_rec = nullptr;
@@ -250,6 +253,7 @@ extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, e
     s->n_seg = p->n_segments;
     s->radius = p->circle_radius;
     s->huber_a = p->huber_a;
+    s->use_so3 = p->use_so3 != 0;
     s->cp_off.assign(p->seg_cp_off, p->seg_cp_off + p->n_segments + 1);
     s->n_cp = s->cp_off[p->n_segments];
     s->knot_off.resize(p->n_segments + 1);
@@ -326,7 +330,10 @@ extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, e
     if (e == hipSuccess) e = hipMalloc((void **) &s->d_accum, s->n_accum() * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **) &s->d_heads, NE_REPL * ACC_HEAD * sizeof(double));
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
     if (e != hipSuccess) {
         ctx->last_error = std::string("ecal_solver_create: ") + hipGetErrorString(e);
@@ -347,9 +354,14 @@ extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, 
     ECAL_HIP_TRY(ctx, hipMemsetAsync(s->d_heads, 0, NE_REPL * ACC_HEAD * sizeof(double), st));
     if (s->n_chunks) {
         const size_t lds = with_jacobian ? NE_T * NE_LD * sizeof(double) : 0;
-        hipLaunchKernelGGL(normal_eq_kernel, dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks, s->d_knots,
-                           s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a,
-                           with_jacobian, d_accum, s->d_heads);
+        if (s->use_so3)
+            hipLaunchKernelGGL(normal_eq_kernel<true>, dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks,
+                               s->d_knots, s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius,
+                               s->huber_a, with_jacobian, d_accum, s->d_heads);
+        else
+            hipLaunchKernelGGL(normal_eq_kernel<false>, dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks,
+                               s->d_knots, s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius,
+                               s->huber_a, with_jacobian, d_accum, s->d_heads);
         hipLaunchKernelGGL(reduce_heads_kernel, dim3(1), dim3(128), 0, st, s->d_heads, d_accum,
                            with_jacobian ? (uint32_t) ACC_HEAD : 1u);
         ECAL_HIP_TRY(ctx, hipGetLastError());
@@ -543,11 +555,14 @@ void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd,
 }
 
 // x (+) delta: intrinsics and translations add, quaternions take exp(delta) (x) q
-void plus(const double *x, const std::vector<double> &d, uint32_t n_cp, double *out) {
+void plus(const double *x, const std::vector<double> &d, uint32_t n_cp, bool so3, double *out) {
     const size_t nc = 6 * (size_t) n_cp;
     for (int i = 0; i < 9; i++) out[i] = x[i] + d[nc + i];
     for (uint32_t c = 0; c < n_cp; c++) {
-        quaternion_plus(x + 9 + 4 * (size_t) c, &d[6 * (size_t) c], out + 9 + 4 * (size_t) c);
+        if (so3)
+            so3_plus(x + 9 + 4 * (size_t) c, &d[6 * (size_t) c], out + 9 + 4 * (size_t) c);
+        else
+            quaternion_plus(x + 9 + 4 * (size_t) c, &d[6 * (size_t) c], out + 9 + 4 * (size_t) c);
         for (int k = 0; k < 3; k++)
             out[9 + 4 * (size_t) n_cp + 3 * (size_t) c + k] = x[9 + 4 * (size_t) n_cp + 3 * (size_t) c + k] + d[6 * (size_t) c + 3 + k];
     }
@@ -671,7 +686,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             S.unsuccessful_steps++;
             continue;
         }
-        plus(x.data(), delta, s->n_cp, xc.data());
+        plus(x.data(), delta, s->n_cp, s->use_so3, xc.data());
         double new_cost;
         rc = evaluate(xc.data(), 0, &new_cost);
         if (rc) return rc;

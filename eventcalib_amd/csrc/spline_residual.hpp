@@ -67,19 +67,11 @@ struct ResidualInput {
     double b[4];          // basis values (same for the rotation and the translation spline)
 };
 
-// intr[9]; q[4][4] rotation control points (x y z w); t[4][3] translation control points.
-// Returns the residual; if J != nullptr fills the 33 tangent-space partials.
-ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, const double (*q)[4], const double (*t)[3],
-                               double *J) {
+// Shared tail of both rotation parameterisations: residual for the unit quaternion (ux,uy,uz,w) and translation T;
+// when J != nullptr fills J[0..8] (intrinsics), gq = d res / d (unit quaternion, ambient xyzw) and gT = d res / d T.
+ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double ux, double uy, double uz, double w,
+                             const double T[3], double *J, double gq[4], double gT[3]) {
     const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
-    // pose at the event time
-    double vq[4] = {0, 0, 0, 0}, T[3] = {0, 0, 0};
-    for (int j = 0; j < 4; j++) {
-        for (int k = 0; k < 4; k++) vq[k] += in.b[j] * q[j][k];
-        for (int k = 0; k < 3; k++) T[k] += in.b[j] * t[j][k];
-    }
-    const double vn = sqrt(vq[0] * vq[0] + vq[1] * vq[1] + vq[2] * vq[2] + vq[3] * vq[3]);
-    const double ux = vq[0] / vn, uy = vq[1] / vn, uz = vq[2] / vn, w = vq[3] / vn;
     // undistorted ray
     const double x = (in.u - cx) / fx, y = (in.v - cy) / fy;
     const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
@@ -101,7 +93,9 @@ ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, cons
     const double e0 = d0 / dist, e1 = d1 / dist, e2 = d2 / dist;  // d res / d Xw
     const double eY = e0 * Y0 + e1 * Y1 + e2 * Y2;
     // Xw = T - T_z Y / Y_z
-    const double gT0 = e0, gT1 = e1, gT2 = e2 - eY / Y2;
+    gT[0] = e0;
+    gT[1] = e1;
+    gT[2] = e2 - eY / Y2;
     const double k = -T[2] / Y2;  // = s
     const double gY0 = k * e0, gY1 = k * e1, gY2 = k * e2 - k * eY / Y2;
     // d Y / d p = R(q) = I + 2 w [u]x + 2 (u u^T - (u.u) I);   g_p = R^T g_Y = g_Y - 2 w (u x g_Y) + 2 (u (u.g_Y) - g_Y (u.u))
@@ -126,11 +120,28 @@ ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, cons
     // unit quaternion: g_w = 2 (u x p).g_Y ;  g_u = 2 w (p x g_Y) + 2 ((u.p) g_Y + p (u.g_Y) - 2 u (p.g_Y))
     const double pdg = px * gY0 + py * gY1 + pz * gY2;
     const double pxg0 = py * gY2 - pz * gY1, pxg1 = pz * gY0 - px * gY2, pxg2 = px * gY1 - py * gY0;
-    double gq[4];
     gq[0] = 2 * w * pxg0 + 2 * (udp * gY0 + px * udg - 2 * ux * pdg);
     gq[1] = 2 * w * pxg1 + 2 * (udp * gY1 + py * udg - 2 * uy * pdg);
     gq[2] = 2 * w * pxg2 + 2 * (udp * gY2 + pz * udg - 2 * uz * pdg);
     gq[3] = 2 * (cxp0 * gY0 + cxp1 * gY1 + cxp2 * gY2);
+    return res;
+}
+
+// intr[9]; q[4][4] rotation control points (x y z w); t[4][3] translation control points.
+// Returns the residual; if J != nullptr fills the 33 tangent-space partials.
+ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, const double (*q)[4], const double (*t)[3],
+                               double *J) {
+    // pose at the event time
+    double vq[4] = {0, 0, 0, 0}, T[3] = {0, 0, 0};
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 4; k++) vq[k] += in.b[j] * q[j][k];
+        for (int k = 0; k < 3; k++) T[k] += in.b[j] * t[j][k];
+    }
+    const double vn = sqrt(vq[0] * vq[0] + vq[1] * vq[1] + vq[2] * vq[2] + vq[3] * vq[3]);
+    const double ux = vq[0] / vn, uy = vq[1] / vn, uz = vq[2] / vn, w = vq[3] / vn;
+    double gq[4], gT[3];
+    const double res = residual_core(in, intr, ux, uy, uz, w, T, J, gq, gT);
+    if (!J) return res;
     // through the normalisation q = v / |v|
     const double qdg = ux * gq[0] + uy * gq[1] + uz * gq[2] + w * gq[3];
     const double gv[4] = {(gq[0] - ux * qdg) / vn, (gq[1] - uy * qdg) / vn, (gq[2] - uz * qdg) / vn,
@@ -143,10 +154,166 @@ ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, cons
         J[9 + 3 * j + 0] = bj * (gv[0] * qw - gv[1] * qz + gv[2] * qy - gv[3] * qx);
         J[9 + 3 * j + 1] = bj * (gv[0] * qz + gv[1] * qw - gv[2] * qx - gv[3] * qy);
         J[9 + 3 * j + 2] = bj * (-gv[0] * qy + gv[1] * qx + gv[2] * qw - gv[3] * qz);
-        J[21 + 3 * j + 0] = bj * gT0;
-        J[21 + 3 * j + 1] = bj * gT1;
-        J[21 + 3 * j + 2] = bj * gT2;
+        J[21 + 3 * j + 0] = bj * gT[0];
+        J[21 + 3 * j + 1] = bj * gT[1];
+        J[21 + 3 * j + 2] = bj * gT[2];
     }
+    return res;
+}
+
+// ---- cumulative SO3 spline (useSO3 = 1) ------------------------------------------------------------------------
+// CalibReprojectionError_SO3::operator() (EventCalibSpline.hpp:65-135) with LocalParameterizationSO3
+// (core/spline/include/opengv2/spline/BsplineSO3.hpp:190-221: r_cp <- r_cp * exp(delta)):
+//   R = R_0 A_1 A_2 A_3,  A_j = Exp(beta_j d_j),  d_j = Log(R_{j-1}^T R_j),  beta = cumulative basis
+//   (BsplineSO3.cpp:88-94: beta_3 = N_3, beta_2 = N_3 + N_2, beta_1 = N_3 + N_2 + N_1).
+// Analytic tangent Jacobian instead of the reference's autodiff through Sophus: with g_w = d res / d omega for
+// R <- R Exp(omega),  v_3 = g_w, v_{j-1} = A_j v_j (so v_0 = A_1 A_2 A_3 g_w),  m_j = beta_j Jl(beta_j d_j) v_j,
+//   d res / d delta_0 = v_0 - Jr^-1(d_1) m_1,   d res / d delta_i = Jl^-1(d_i) m_i - Jr^-1(d_{i+1}) m_{i+1},
+//   d res / d delta_3 = Jl^-1(d_3) m_3
+// (Jr/Jl = right/left Jacobians of SO(3), Jl(x) = Jr(x)^T).  Rotations are handled as rotation vectors / matrices
+// applied to vectors; quaternions are (x, y, z, w), q and -q denote the same rotation.
+
+ECAL_HD void so3_cross(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// out = (I + a [phi]x + b [phi]x^2) v
+ECAL_HD void so3_apply(double a, double b, const double phi[3], const double v[3], double out[3]) {
+    double c1[3], c2[3];
+    so3_cross(phi, v, c1);
+    so3_cross(phi, c1, c2);
+    for (int k = 0; k < 3; k++) out[k] = v[k] + a * c1[k] + b * c2[k];
+}
+
+// Exp(phi) v  (Rodrigues)
+ECAL_HD void so3_rotate(const double phi[3], const double v[3], double out[3]) {
+    const double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    double a, b;
+    if (t2 < 1e-12) {
+        a = 1.0 - t2 / 6.0;
+        b = 0.5 - t2 / 24.0;
+    } else {
+        const double th = sqrt(t2);
+        a = sin(th) / th;
+        b = (1.0 - cos(th)) / t2;
+    }
+    so3_apply(a, b, phi, v, out);
+}
+
+// Jl(phi) v = (I + (1 - cos t)/t^2 [phi]x + (t - sin t)/t^3 [phi]x^2) v
+ECAL_HD void so3_jl(const double phi[3], const double v[3], double out[3]) {
+    const double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    double a, b;
+    if (t2 < 1e-8) {
+        a = 0.5 - t2 / 24.0;
+        b = 1.0 / 6.0 - t2 / 120.0;
+    } else {
+        const double th = sqrt(t2);
+        a = (1.0 - cos(th)) / t2;
+        b = (th - sin(th)) / (t2 * th);
+    }
+    so3_apply(a, b, phi, v, out);
+}
+
+// Jl^-1(phi) v (sign = +1) or Jr^-1(phi) v (sign = -1):  (I -/+ 1/2 [phi]x + (1/t^2 - (1 + cos t)/(2 t sin t)) [phi]x^2) v
+ECAL_HD void so3_jinv(const double phi[3], double sign, const double v[3], double out[3]) {
+    const double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    double b;
+    if (t2 < 1e-8) {
+        b = 1.0 / 12.0 + t2 / 720.0;
+    } else {
+        const double th = sqrt(t2);
+        b = 1.0 / t2 - (1.0 + cos(th)) / (2.0 * th * sin(th));
+    }
+    so3_apply(-0.5 * sign, b, phi, v, out);
+}
+
+// Hamilton product (xyzw)
+ECAL_HD void quat_mul(const double a[4], const double b[4], double o[4]) {
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+// Sophus SO3::log of a unit quaternion: rotation vector with angle 2 atan(|v| / w) (in (-pi, pi))
+ECAL_HD void so3_log(const double q[4], double phi[3]) {
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2], w = q[3];
+    double f;
+    if (n2 < 1e-20) {
+        f = 2.0 / w - (2.0 / 3.0) * n2 / (w * w * w);
+    } else {
+        const double n = sqrt(n2);
+        f = fabs(w) < 1e-10 ? (w > 0 ? M_PI : -M_PI) / n : 2.0 * atan(n / w) / n;
+    }
+    phi[0] = f * q[0];
+    phi[1] = f * q[1];
+    phi[2] = f * q[2];
+}
+
+// Sophus SO3::exp: rotation vector -> unit quaternion
+ECAL_HD void so3_exp(const double phi[3], double q[4]) {
+    const double t2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+    double im, re;
+    if (t2 < 1e-20) {
+        im = 0.5 - t2 / 48.0;
+        re = 1.0 - t2 / 8.0;
+    } else {
+        const double th = sqrt(t2);
+        im = sin(0.5 * th) / th;
+        re = cos(0.5 * th);
+    }
+    q[0] = im * phi[0];
+    q[1] = im * phi[1];
+    q[2] = im * phi[2];
+    q[3] = re;
+}
+
+// q[4][4]: SO3 control points as unit quaternions (x y z w); in.b = the four N values (the cumulative basis is
+// formed here).  J layout as spline_residual, rotation columns = delta of r_cp_j <- r_cp_j * exp(delta).
+ECAL_HD double spline_residual_so3(const ResidualInput &in, const double *intr, const double (*q)[4],
+                                   const double (*t)[3], double *J) {
+    double beta[3];
+    beta[2] = in.b[3];
+    beta[1] = beta[2] + in.b[2];
+    beta[0] = beta[1] + in.b[1];
+    double d[3][3], bd[3][3], Q[4] = {q[0][0], q[0][1], q[0][2], q[0][3]}, T[3] = {0, 0, 0};
+    for (int j = 1; j <= 3; j++) {
+        const double inv[4] = {-q[j - 1][0], -q[j - 1][1], -q[j - 1][2], q[j - 1][3]};
+        double rel[4], e[4], nq[4];
+        quat_mul(inv, q[j], rel);
+        so3_log(rel, d[j - 1]);
+        for (int k = 0; k < 3; k++) bd[j - 1][k] = beta[j - 1] * d[j - 1][k];
+        so3_exp(bd[j - 1], e);
+        quat_mul(Q, e, nq);
+        for (int k = 0; k < 4; k++) Q[k] = nq[k];
+    }
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 3; k++) T[k] += in.b[j] * t[j][k];
+    double gq[4], gT[3];
+    const double res = residual_core(in, intr, Q[0], Q[1], Q[2], Q[3], T, J, gq, gT);
+    if (!J) return res;
+    // g_w: R <- R Exp(omega) is Q <- Q (x) (omega/2, 1)
+    double v[3], m[3], a[3], n[3];
+    v[0] = 0.5 * (gq[0] * Q[3] + gq[1] * Q[2] - gq[2] * Q[1] - gq[3] * Q[0]);
+    v[1] = 0.5 * (-gq[0] * Q[2] + gq[1] * Q[3] + gq[2] * Q[0] - gq[3] * Q[1]);
+    v[2] = 0.5 * (gq[0] * Q[1] - gq[1] * Q[0] + gq[2] * Q[3] - gq[3] * Q[2]);
+    double p_next[3] = {0, 0, 0};  // Jl^-1(d_{j}) m_{j} of the factor processed last (j = 3 first)
+    for (int j = 3; j >= 1; j--) {
+        so3_jl(bd[j - 1], v, m);
+        for (int k = 0; k < 3; k++) m[k] *= beta[j - 1];
+        so3_jinv(d[j - 1], +1.0, m, a);   // Jl^-1(d_j) m_j  -> column block of control point j
+        so3_jinv(d[j - 1], -1.0, m, n);   // Jr^-1(d_j) m_j  -> subtracted from control point j-1
+        for (int k = 0; k < 3; k++) J[9 + 3 * j + k] = a[k] - (j < 3 ? p_next[k] : 0.0);
+        for (int k = 0; k < 3; k++) p_next[k] = n[k];
+        so3_rotate(bd[j - 1], v, a);      // v_{j-1} = A_j v_j
+        for (int k = 0; k < 3; k++) v[k] = a[k];
+    }
+    for (int k = 0; k < 3; k++) J[9 + k] = v[k] - p_next[k];
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 3; k++) J[21 + 3 * j + k] = in.b[j] * gT[k];
     return res;
 }
 
@@ -163,6 +330,13 @@ ECAL_HD double huber_scale(double r, double a, double *half_rho) {
     *half_rho = 0.5 * (2.0 * a * rt - b);
     const double rho1 = a / rt;
     return sqrt(rho1 > 0 ? rho1 : 0.0);  // max(min, a / r), Ceres clamps with DBL_MIN
+}
+
+// q <- q (x) exp(delta)   (LocalParameterizationSO3::Plus, BsplineSO3.hpp:196-203)
+ECAL_HD void so3_plus(const double q[4], const double d[3], double out[4]) {
+    double e[4];
+    so3_exp(d, e);
+    quat_mul(q, e, out);
 }
 
 // q <- exp(delta) (x) q   (EigenQuaternionParameterization::Plus, xyzw storage)

@@ -254,7 +254,7 @@ int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events
 
 /* ---- continuous-time calibration solve ---------------------------------------------------------
  * Replaces the Ceres problem of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
- * 196-247) for the quaternion-spline variant (useSO3 = 0): one residual per associated event,
+ * 196-247) for both rotation-spline variants (ecal_spline_problem.use_so3): one residual per associated event,
  *   r = | Xw(event pixel; intrinsics, pose(t)) - landmark | - circle_radius
  * (CalibReprojectionError::operator(), EventCalibSpline.hpp:158-229; unDistort :36-63), HuberLoss(huber_a)
  * with huber_a = 0.2 * circle_radius (:205), EigenQuaternionParameterization on the rotation control
@@ -288,6 +288,9 @@ typedef struct ecal_spline_problem {
     const double *landmarks;    /* [n_landmarks][3] */
     double circle_radius;       /* Circles_Radius */
     double huber_a;             /* 0.2 * circle_radius in the reference */
+    int use_so3;                /* useSO3 (eventCameraCalib.cpp:204-208): 0 = quaternion spline + EigenQuaternion-
+                                   Parameterization; 1 = cumulative SO3 spline (CalibReprojectionError_SO3,
+                                   EventCalibSpline.hpp:65-135) + LocalParameterizationSO3 (q <- q * exp(delta)) */
 } ecal_spline_problem;
 typedef int (*ecal_allreduce_fn)(void *user, double *d_buf, size_t n_doubles, void *stream);
 typedef struct ecal_lm_options {

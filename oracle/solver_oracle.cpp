@@ -48,6 +48,14 @@ inline Jet sqrt(const Jet &x) { Jet r; r.a = std::sqrt(x.a); for (int i = 0; i <
 inline Jet &operator*=(Jet &x, const Jet &y) { x = x * y; return x; }
 inline double sqrt_(double x) { return std::sqrt(x); }
 inline Jet sqrt_(const Jet &x) { return sqrt(x); }
+inline double sin_(double x) { return std::sin(x); }
+inline double cos_(double x) { return std::cos(x); }
+inline double atan_(double x) { return std::atan(x); }
+inline Jet sin_(const Jet &x) { Jet r; r.a = std::sin(x.a); const double c = std::cos(x.a); for (int i = 0; i < NP; i++) r.v[i] = c * x.v[i]; return r; }
+inline Jet cos_(const Jet &x) { Jet r; r.a = std::cos(x.a); const double s = -std::sin(x.a); for (int i = 0; i < NP; i++) r.v[i] = s * x.v[i]; return r; }
+inline Jet atan_(const Jet &x) { Jet r; r.a = std::atan(x.a); const double d = 1.0 / (1.0 + x.a * x.a); for (int i = 0; i < NP; i++) r.v[i] = d * x.v[i]; return r; }
+inline double val(double x) { return x; }
+inline double val(const Jet &x) { return x.a; }
 
 // EventCalibSpline.hpp:158-229 with T = double or Jet.  Quaternion rotation of a vector follows
 // Eigen's QuaternionBase::_transformVector (v + w*2(u x v) + u x 2(u x v)).
@@ -81,6 +89,99 @@ T residual_functor(const T *intr, const T (*rq)[4], const T (*tp)[3], const doub
     const T c2[3] = {q[1] * uv[2] - q[2] * uv[1], q[2] * uv[0] - q[0] * uv[2], q[0] * uv[1] - q[1] * uv[0]};
     T Xw[3];
     for (int k = 0; k < 3; k++) Xw[k] = Xc[k] + q[3] * uv[k] + c2[k] + t[k];
+    const T d0 = Xw[0] - T(lm[0]), d1 = Xw[1] - T(lm[1]), d2 = Xw[2] - T(lm[2]);
+    return sqrt_(d0 * d0 + d1 * d1 + d2 * d2) - T(radius);
+}
+
+// ---- SO3 spline variant (useSO3 = 1): CalibReprojectionError_SO3::operator() (EventCalibSpline.hpp:65-135).
+// Sophus (third party, CMakeLists.txt:46, no version pinned) is restated from its published so3.hpp:
+// SO3::exp / expAndTheta, SO3::log / logAndTheta (with their small-angle series, epsilon 1e-10), inverse =
+// conjugate, product = Hamilton product (Sophus' first-order renormalisation of a product — a factor
+// 2/(1+|q|^2) that is 1 to rounding for unit inputs — is not replayed).  Quaternions are (x, y, z, w).
+constexpr double kSophusEps = 1e-10;
+
+template <typename T>
+void quat_mul(const T a[4], const T b[4], T out[4]) {
+    out[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    out[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+    out[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+    out[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+template <typename T>
+void so3_exp(const T w[3], T q[4]) {
+    const T theta_sq = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    T imag, real;
+    if (val(theta_sq) < kSophusEps * kSophusEps) {
+        const T theta_po4 = theta_sq * theta_sq;
+        imag = T(0.5) - T(1.0 / 48.0) * theta_sq + T(1.0 / 3840.0) * theta_po4;
+        real = T(1.0) - T(1.0 / 8.0) * theta_sq + T(1.0 / 384.0) * theta_po4;
+    } else {
+        const T theta = sqrt_(theta_sq), half = T(0.5) * theta;
+        imag = sin_(half) / theta;
+        real = cos_(half);
+    }
+    q[0] = imag * w[0];
+    q[1] = imag * w[1];
+    q[2] = imag * w[2];
+    q[3] = real;
+}
+
+template <typename T>
+void so3_log(const T q[4], T w[3]) {
+    const T squared_n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+    const T qw = q[3];
+    T two_atan;
+    if (val(squared_n) < kSophusEps * kSophusEps) {
+        const T squared_w = qw * qw;
+        two_atan = T(2.0) / qw - T(2.0 / 3.0) * squared_n / (qw * squared_w);
+    } else {
+        const T n = sqrt_(squared_n);
+        if (std::abs(val(qw)) < kSophusEps)
+            two_atan = (val(qw) > 0 ? T(M_PI) : T(-M_PI)) / n;
+        else
+            two_atan = T(2.0) * atan_(n / qw) / n;
+    }
+    for (int k = 0; k < 3; k++) w[k] = two_atan * q[k];
+}
+
+template <typename T>
+T residual_functor_so3(const T *intr, const T (*rq)[4], const T (*tp)[3], const double *rb, const double *tb,
+                       const double obs[2], const double lm[3], double radius) {
+    // :103-108  Qwb = r_cp0 * prod_j exp(beta_j log(r_cp{j-1}^-1 r_cp{j}));  rb = cumulative basis (3 values)
+    T Q[4] = {rq[0][0], rq[0][1], rq[0][2], rq[0][3]};
+    for (int j = 1; j <= 3; j++) {
+        const T inv[4] = {-rq[j - 1][0], -rq[j - 1][1], -rq[j - 1][2], rq[j - 1][3]};
+        T rel[4], d[3], e[4], nq[4];
+        quat_mul(inv, rq[j], rel);
+        so3_log(rel, d);
+        for (int k = 0; k < 3; k++) d[k] = T(rb[j - 1]) * d[k];
+        so3_exp(d, e);
+        quat_mul(Q, e, nq);
+        for (int k = 0; k < 4; k++) Q[k] = nq[k];
+    }
+    T t[3];
+    for (int k = 0; k < 3; k++) t[k] = T(tb[0]) * tp[0][k] + T(tb[1]) * tp[1][k] + T(tb[2]) * tp[2][k] + T(tb[3]) * tp[3][k];
+    // unDistort (:36-63) and the ray / plane intersection (:118-131), as in the quaternion functor
+    T Xc[3];
+    Xc[0] = (T(obs[0]) - intr[2]) / intr[0];
+    Xc[1] = (T(obs[1]) - intr[3]) / intr[1];
+    Xc[2] = T(1.0);
+    const T r2 = Xc[0] * Xc[0] + Xc[1] * Xc[1];
+    const T r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
+    const T coeff = T(1.0) + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    Xc[0] *= coeff;
+    Xc[1] *= coeff;
+    const T tx = T(2.0) * Q[0], ty = T(2.0) * Q[1], tz = T(2.0) * Q[2];
+    const T twx = tx * Q[3], twy = ty * Q[3], txx = tx * Q[0], txz = tz * Q[0], tyy = ty * Q[1], tyz = tz * Q[1];
+    const T r2row[3] = {txz - twy, tyz + twx, T(1.0) - (txx + tyy)};
+    const T depth = -t[2] / (r2row[0] * Xc[0] + r2row[1] * Xc[1] + r2row[2] * Xc[2]);
+    for (int k = 0; k < 3; k++) Xc[k] *= depth;
+    T uv[3] = {Q[1] * Xc[2] - Q[2] * Xc[1], Q[2] * Xc[0] - Q[0] * Xc[2], Q[0] * Xc[1] - Q[1] * Xc[0]};
+    for (int k = 0; k < 3; k++) uv[k] = uv[k] + uv[k];
+    const T c2[3] = {Q[1] * uv[2] - Q[2] * uv[1], Q[2] * uv[0] - Q[0] * uv[2], Q[0] * uv[1] - Q[1] * uv[0]};
+    T Xw[3];
+    for (int k = 0; k < 3; k++) Xw[k] = Xc[k] + Q[3] * uv[k] + c2[k] + t[k];
     const T d0 = Xw[0] - T(lm[0]), d1 = Xw[1] - T(lm[1]), d2 = Xw[2] - T(lm[2]);
     return sqrt_(d0 * d0 + d1 * d1 + d2 * d2) - T(radius);
 }
@@ -151,6 +252,39 @@ double oracle_residual(const double *intr, const double *q4x4, const double *t4x
     return r.a;
 }
 
+// SO3 variant: basis4 = the four N values; the cumulative basis of BsplineSO3::derBasisFuns
+// (core/spline/src/BsplineSO3.cpp:88-94) is formed here.  J33 = ambient partials times
+// Sophus::SO3::Dx_this_mul_exp_x_at_0 (LocalParameterizationSO3::ComputeJacobian, BsplineSO3.hpp:209-216):
+// the tangent of  r_cp <- r_cp * exp(delta).
+double oracle_residual_so3(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                           const double *obs2, const double *lm3, double radius, double *J37, double *J33) {
+    double beta[3];
+    beta[2] = basis4[3];
+    beta[1] = beta[2] + basis4[2];
+    beta[0] = beta[1] + basis4[1];
+    Jet ji[9], jq[4][4], jt[4][3];
+    for (int i = 0; i < 9; i++) ji[i] = Jet::var(intr[i], i);
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 4; k++) jq[j][k] = Jet::var(q4x4[4 * j + k], 9 + 4 * j + k);
+        for (int k = 0; k < 3; k++) jt[j][k] = Jet::var(t4x3[3 * j + k], 25 + 3 * j + k);
+    }
+    const Jet r = residual_functor_so3<Jet>(ji, jq, jt, beta, basis4, obs2, lm3, radius);
+    if (J37) for (int i = 0; i < NP; i++) J37[i] = r.v[i];
+    if (J33) {
+        for (int i = 0; i < 9; i++) J33[i] = r.v[i];
+        for (int j = 0; j < 4; j++) {
+            const double *x = q4x4 + 4 * j;
+            const double *g = r.v + 9 + 4 * j;
+            // Dx_this_mul_exp_x_at_0 (4x3, xyzw rows): 0.5 * [ w -z  y ;  z  w -x ; -y  x  w ; -x -y -z ]
+            J33[9 + 3 * j + 0] = 0.5 * (g[0] * x[3] + g[1] * x[2] - g[2] * x[1] - g[3] * x[0]);
+            J33[9 + 3 * j + 1] = 0.5 * (-g[0] * x[2] + g[1] * x[3] + g[2] * x[0] - g[3] * x[1]);
+            J33[9 + 3 * j + 2] = 0.5 * (g[0] * x[1] - g[1] * x[0] + g[2] * x[3] - g[3] * x[2]);
+            for (int k = 0; k < 3; k++) J33[21 + 3 * j + k] = r.v[25 + 3 * j + k];
+        }
+    }
+    return r.a;
+}
+
 double oracle_residual_value(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
                              const double *obs2, const double *lm3, double radius) {
     double q[4][4], t[4][3];
@@ -177,9 +311,20 @@ void oracle_inverse_radial(const double *k4, double *b5) {
 // of ONE spline segment with knots[n_cp + 4]; M residual records: obs [M][2], time [M], lm id [M];
 // landmarks [L][3].  Outputs (any may be NULL): cost = sum rho/2; g[9 + 6 n_cp] = J^T r in tangent
 // order [intr | (delta_c, t_c) per control point]; H dense [(9+6n_cp)^2] row-major (small problems).
+double oracle_evaluate_mode(const double *intr, uint32_t n_cp, const double *q, const double *t, const double *knots,
+                            uint64_t M, const double *obs, const double *time, const uint32_t *lm_id,
+                            const double *landmarks, double radius, double huber_a, int use_so3, double *g, double *H);
+
 double oracle_evaluate(const double *intr, uint32_t n_cp, const double *q, const double *t, const double *knots,
                        uint64_t M, const double *obs, const double *time, const uint32_t *lm_id,
                        const double *landmarks, double radius, double huber_a, double *g, double *H) {
+    return oracle_evaluate_mode(intr, n_cp, q, t, knots, M, obs, time, lm_id, landmarks, radius, huber_a, 0, g, H);
+}
+
+// use_so3 != 0: the cumulative SO3 spline (CalibReprojectionError_SO3 + LocalParameterizationSO3)
+double oracle_evaluate_mode(const double *intr, uint32_t n_cp, const double *q, const double *t, const double *knots,
+                            uint64_t M, const double *obs, const double *time, const uint32_t *lm_id,
+                            const double *landmarks, double radius, double huber_a, int use_so3, double *g, double *H) {
     const size_t N = 9 + 6 * (size_t) n_cp;
     if (g) std::fill(g, g + N, 0.0);
     if (H) std::fill(H, H + N * N, 0.0);
@@ -190,8 +335,9 @@ double oracle_evaluate(const double *intr, uint32_t n_cp, const double *q, const
         double b[4], J[33];
         oracle_basis(knots, span, u, b);
         const uint32_t c0 = span - 3;
-        double r = oracle_residual(intr, q + 4 * (size_t) c0, t + 3 * (size_t) c0, b, obs + 2 * m,
-                                   landmarks + 3 * (size_t) lm_id[m], radius, nullptr, (g || H) ? J : nullptr);
+        double r = (use_so3 ? oracle_residual_so3 : oracle_residual)(intr, q + 4 * (size_t) c0, t + 3 * (size_t) c0, b,
+                                                                     obs + 2 * m, landmarks + 3 * (size_t) lm_id[m],
+                                                                     radius, nullptr, (g || H) ? J : nullptr);
         // HuberLoss + Corrector
         const double s = r * r, a2 = huber_a * huber_a;
         double rho, scale;

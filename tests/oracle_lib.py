@@ -234,9 +234,9 @@ def fit_circle(a, b):
 def solver_evaluate(problem, x, want_H=True):
     """Dense CPU evaluation of one-segment problems: (cost, g, H) in tangent order [intr | cp (rot3, trans3)]."""
     L = lib()
-    L.oracle_evaluate.argtypes = [_dp, ctypes.c_uint32, _dp, _dp, _dp, ctypes.c_uint64, _dp, _dp, _u32p, _dp,
-                                  ctypes.c_double, ctypes.c_double, _dp, _dp]
-    L.oracle_evaluate.restype = ctypes.c_double
+    L.oracle_evaluate_mode.argtypes = [_dp, ctypes.c_uint32, _dp, _dp, _dp, ctypes.c_uint64, _dp, _dp, _u32p, _dp,
+                                       ctypes.c_double, ctypes.c_double, ctypes.c_int, _dp, _dp]
+    L.oracle_evaluate_mode.restype = ctypes.c_double
     n_cp = int(problem["seg_cp_off"][-1])
     assert len(problem["seg_cp_off"]) == 2, "oracle_evaluate handles one segment"
     x = np.ascontiguousarray(x, np.float64)
@@ -251,9 +251,10 @@ def solver_evaluate(problem, x, want_H=True):
     n = 9 + 6 * n_cp
     g = np.zeros(n)
     H = np.zeros((n, n)) if want_H else None
-    cost = L.oracle_evaluate(_p(intr, _dp), n_cp, _p(q, _dp), _p(t, _dp), _p(kn, _dp), tm.shape[0], _p(obs, _dp),
-                             _p(tm, _dp), _p(lm, _u32p), _p(lms, _dp), float(problem["circle_radius"]),
-                             float(problem["huber_a"]), _p(g, _dp), _p(H, _dp) if want_H else None)
+    cost = L.oracle_evaluate_mode(_p(intr, _dp), n_cp, _p(q, _dp), _p(t, _dp), _p(kn, _dp), tm.shape[0], _p(obs, _dp),
+                                  _p(tm, _dp), _p(lm, _u32p), _p(lms, _dp), float(problem["circle_radius"]),
+                                  float(problem["huber_a"]), int(bool(problem.get("use_so3", False))), _p(g, _dp),
+                                  _p(H, _dp) if want_H else None)
     return cost, g, H
 
 

@@ -16,11 +16,21 @@ def quat_plus(q, d):
                      a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
 
 
-def plus(x, d, n_cp):
+def so3_plus(q, d):
+    """LocalParameterizationSO3::Plus: q (x) exp(d), exp with the half angle (Sophus)."""
+    nd = np.linalg.norm(d)
+    e = np.concatenate([np.sin(nd / 2) / nd * d, [np.cos(nd / 2)]]) if nd > 0 else np.array([0.0, 0.0, 0.0, 1.0])
+    a, b = q, e
+    return np.array([a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1], a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0],
+                     a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3], a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2]])
+
+
+def plus(x, d, n_cp, use_so3=False):
     y = x.copy()
     y[:9] += d[:9]
+    rot_plus = so3_plus if use_so3 else quat_plus
     for c in range(n_cp):
-        y[9 + 4 * c: 13 + 4 * c] = quat_plus(x[9 + 4 * c: 13 + 4 * c], d[9 + 6 * c: 12 + 6 * c])
+        y[9 + 4 * c: 13 + 4 * c] = rot_plus(x[9 + 4 * c: 13 + 4 * c], d[9 + 6 * c: 12 + 6 * c])
         y[9 + 4 * n_cp + 3 * c: 12 + 4 * n_cp + 3 * c] += d[12 + 6 * c: 15 + 6 * c]
     return y
 
@@ -50,7 +60,7 @@ def solve(problem, x0, max_iter=50, ftol=1e-10, gtol=1e-10, ptol=1e-8):
             radius /= dec
             dec *= 2
             continue
-        xn = plus(x, d, n_cp)
+        xn = plus(x, d, n_cp, bool(problem.get("use_so3", False)))
         new_cost = O.solver_evaluate(problem, xn, want_H=False)[0]
         rel = (cost - new_cost) / model
         if rel > 1e-3:

@@ -43,6 +43,43 @@ def test_normal_equations_match_oracle(ctx, n_res, n_cp):
     s.close()
 
 
+@pytest.mark.parametrize("n_res,n_cp", [(600, 6), (20000, 5)])
+def test_so3_normal_equations_match_oracle(ctx, n_res, n_cp):
+    """useSO3 = 1: cumulative SO3 spline + LocalParameterizationSO3 (EventCalibSpline.hpp:65-135, BsplineSO3.hpp:190-221)."""
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(n_res + 1)
+    prob, x = SV.make_problem(n_res, n_cp=n_cp, seed=n_res + 1, pixel_noise=0.5, use_so3=True)
+    y = SV.perturb(x, n_cp, rng, intr_rel=0.01, rot=0.005, trans=0.2)
+    s = Solver(ctx, prob)
+    acc = s.evaluate(y, True)
+    cost, g, H = _dense(acc, n_cp)
+    oc, og, oH = O.solver_evaluate(prob, y)
+    assert abs(cost - oc) <= 1e-11 * abs(oc)
+    assert np.abs(g - og).max() <= 1e-9 * np.abs(og).max()
+    assert np.abs(H - oH).max() <= 1e-9 * np.abs(oH).max()
+    # and it is a different function from the quaternion-blend variant
+    qc = O.solver_evaluate(dict(prob, use_so3=False), y, want_H=False)[0]
+    assert abs(qc - oc) > 1e-9 * abs(oc)
+    s.close()
+
+
+def test_so3_lm_recovers_ground_truth(ctx):
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(14)
+    n_cp = 8
+    prob, x_gt = SV.make_problem(4000, n_cp=n_cp, seed=14, use_so3=True)
+    x0 = SV.perturb(x_gt, n_cp, rng)
+    s = Solver(ctx, prob)
+    x, summ = s.solve(x0)
+    assert summ.termination == 0 and summ.final_cost < 1e-12 * summ.initial_cost + 1e-16
+    assert np.abs(x[:4] / x_gt[:4] - 1).max() < 1e-6
+    assert np.abs(x[4:9] - x_gt[4:9]).max() < 1e-5
+    assert np.abs(np.linalg.norm(x[9:9 + 4 * n_cp].reshape(n_cp, 4), axis=1) - 1).max() < 1e-12   # stays on the manifold
+    xr, hist, it = ref_lm.solve(prob, x0)
+    assert np.abs(x[:9] - xr[:9]).max() <= 1e-7 * np.abs(xr[:9]).max()
+    s.close()
+
+
 def test_two_segments(ctx):
     from eventcalib_amd.capi import Solver
     prob, x = SV.make_problem(1200, n_cp=6, seed=9, n_segments=2, pixel_noise=0.2)
