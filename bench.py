@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="events timed on the CPU oracle (0 = skip)")
     ap.add_argument("--solver-iters", type=int, default=8, help="LM iterations timed for M2 (0 = skip the solver leg)")
     ap.add_argument("--solver-cpu-sample", type=int, default=300_000, help="residuals timed on the CPU oracle")
+    ap.add_argument("--p2-pieces", type=int, default=1024,
+                    help="pieces of the adaptive-window policy P2 (SURVEY 8d) measured after M1 (0 = skip)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe upload timing")
     args = ap.parse_args()
 
     import numpy as np
@@ -202,6 +205,39 @@ def main():
                           "(DBSCAN +/-, filter, medians, pairing) per window, 1 thread, %.1f s" % (nw, cev, cel),
                 "host_cpus": os.cpu_count(),
             }
+    # ---- reported beside the contract number (rank 0, one GPU): PCIe upload and the reference's window policy ----
+    if rank == 0 and world == 1 and not args.no_h2d:
+        host = torch.empty(events.numel(), dtype=torch.uint8, pin_memory=True)
+        host.copy_(events)
+        dst = torch.empty_like(events)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        dst.copy_(host, non_blocking=True)
+        e1.record(st)
+        torch.cuda.synchronize(dev)
+        h2d_ms = e0.elapsed_time(e1)
+        del host, dst
+        out["h2d"] = {"bytes": int(events.numel()), "ms": round(h2d_ms, 3),
+                      "GBs": round(events.numel() / h2d_ms / 1e6, 2),
+                      "Mevents_per_s_including_upload": round(n_events / ((h2d_ms + ms_per_step) * 1e-3) / 1e6, 1),
+                      "note": "pinned host -> HBM copy of the packed stream, once per stream; never part of `value`"}
+    if rank == 0 and world == 1 and args.p2_pieces > 0:
+        # policy P2 of SURVEY 8d: the reference driver's adaptive success / slide / grow windows per piece
+        # (eventCameraCalib.cpp:49-95) + keyframe gate, lock-step over all pieces; counted as the reference
+        # would: all events of the stream / wall time, although the policy skips frameGap after every keyframe
+        from eventcalib_amd.adaptive import detect_keyframes
+        torch.cuda.synchronize(dev)
+        tp = time.perf_counter()
+        kf = detect_keyframes(pipe, events, 5e-4, 4000, args.p2_pieces, t_first, t_last, eps, minpts)
+        torch.cuda.synchronize(dev)
+        p2_s = time.perf_counter() - tp
+        out["policy_p2"] = {"value": round(n_events / p2_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2_s, 4),
+                            "pieces": args.p2_pieces, "lockstep_passes": kf["steps"], "windows_evaluated": kf["windows"],
+                            "keyframes": int(len(kf["time"])),
+                            "note": "adaptive windows + grid ordering + keyframe gate, host-driven (one D2H of the "
+                                    "verdicts per pass); the reference uses 5*(hw threads - 2) pieces"}
+        pipe.set_windows(t0, t1)
     # ------------------------------------------------------------------------------------------
     # M2: Levenberg-Marquardt iterations/s of the continuous-time solve on the same stream
     # (configs[2]: 50 M events -> ~45 M associated residuals, control point every 50 steps = 25 ms)

@@ -1,0 +1,104 @@
+"""The reference driver's adaptive windowing + keyframe gate over a device-resident stream.
+
+Python mirror of eventcalib_amd/csrc/host/multi_process.hpp (detect_keyframes), i.e. of
+  MultiProcess::process     event_camera_calib/test/eventCameraCalib.cpp:34-97
+  piece construction        event_camera_calib/test/eventCameraCalib.cpp:168-179
+  EventCalibIni::track      event_camera_calib/src/EventCalibIni.cpp:23-97
+Every piece advances in lockstep; one step = one batched pass of the detection pipeline (bounds -> slice ->
+DBSCAN -> candidates -> grid order) over the current window of every active piece, then a small D2H copy of
+the per-window verdicts drives the reference's success / slide / grow rule on the host.
+"""
+import numpy as np
+import torch
+
+from .pipeline import DetectPipeline
+
+
+def _row_directions(feat, rows, cols):
+    """feat [n, rows*cols, 2] -> unit directions [n, rows, 2] of the total-least-squares line through each
+    pattern row (right singular vector of [x y 1] with the smallest singular value, EventCalibIni.cpp:46-57),
+    oriented from the row's first to its last circle."""
+    n = feat.shape[0]
+    p = feat.reshape(n, rows, cols, 2)
+    A = np.concatenate([p, np.ones((n, rows, cols, 1))], axis=3)
+    _, _, vt = np.linalg.svd(A, full_matrices=False)
+    line = vt[:, :, -1, :]                                   # (A, B, C)
+    d = np.stack([line[:, :, 1], -line[:, :, 0]], axis=2)
+    span = p[:, :, -1, :] - p[:, :, 0, :]
+    sign = np.where((d * span).sum(axis=2) < 0, -1.0, 1.0)
+    return d * sign[:, :, None]
+
+
+def orientation_gate(ref_feat, ref_t, cur_feat, cur_t, rows, cols, motion_time_step):
+    """EventCalibIni::track's test for n frame pairs: median angle between corresponding pattern rows divided by the
+    time distance below (5e-4 pi) / MotionTimeStep rad/s."""
+    a, b = _row_directions(ref_feat, rows, cols), _row_directions(cur_feat, rows, cols)
+    c = (a * b).sum(axis=2) / (np.linalg.norm(a, axis=2) * np.linalg.norm(b, axis=2))
+    theta = np.arccos(np.clip(c, -1.0, 1.0))
+    med = np.partition(theta, rows // 2, axis=1)[:, rows // 2]
+    return med / np.abs(cur_t - ref_t) < (5e-4 * np.pi) / motion_time_step
+
+
+def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event_num_threshold, piece_num,
+                     start_time, end_time, eps=4.0, minpts=2, rows=9, cols=4, max_steps=1_000_000):
+    """Returns dict(time [K], duration [K,2], events_num [K], features [K, rows*cols, 3]) sorted by time, plus
+    `steps` and `windows` (how many batched passes / windows were evaluated)."""
+    ln, gap = 3 * motion_time_step, 5 * motion_time_step
+    step = (end_time - start_time) / piece_num
+    k = np.arange(piece_num)
+    bound_hi = end_time - step * k
+    first = end_time - step * (k + 1)
+    second = first + ln
+    active = second < bound_hi
+    have_ref = np.zeros(piece_num, bool)
+    ref_feat = np.zeros((piece_num, rows * cols, 2))
+    ref_t = np.zeros(piece_num)
+    keys = []
+    n = rows * cols
+    steps = windows = 0
+    while active.any() and steps < max_steps:
+        idx = np.nonzero(active)[0]
+        S = len(idx)
+        pipe.set_windows(first[idx], second[idx])
+        pipe.run(events, eps, minpts)
+        order, found = pipe.order_grid(rows, cols)
+        info = pipe.win_info[:S].cpu().numpy()
+        found = found.cpu().numpy().astype(bool)
+        cnt = pipe.seg_cnt[: 2 * S].cpu().numpy().reshape(S, 2).sum(axis=1)          # EventFrame::eventsNum()
+        ok = (info[:, 3] == 0) & found
+        accepted = np.zeros(S, bool)
+        if ok.any():
+            w = np.nonzero(ok)[0]
+            wt = torch.as_tensor(w, device=order.device)
+            base = pipe.seg_off[: 2 * S: 2][wt].long()
+            gi = base[:, None] + order[wt].long()
+            feat = pipe.cand_xyr[gi.reshape(-1)].reshape(len(w), n, 3).cpu().numpy()
+            t_mid = (first[idx[w]] + second[idx[w]]) / 2
+            pw = idx[w]
+            acc = ~have_ref[pw]
+            chk = np.nonzero(have_ref[pw])[0]
+            if len(chk):
+                acc[chk] = orientation_gate(ref_feat[pw[chk]], ref_t[pw[chk]], feat[chk, :, :2], t_mid[chk], rows, cols,
+                                            motion_time_step)
+            for j in np.nonzero(acc)[0]:
+                keys.append((t_mid[j], first[pw[j]], second[pw[j]], int(cnt[w[j]]), feat[j]))
+            a = pw[acc]
+            have_ref[a] = True
+            ref_feat[a] = feat[acc, :, :2]
+            ref_t[a] = t_mid[acc]
+            accepted[w[acc]] = True
+        # eventCameraCalib.cpp:61-62 (success), :67-69,75-77 (slide), :70-71,78-79 (grow)
+        f, s2 = first[idx], second[idx]
+        slide = ~accepted & ((cnt > frame_event_num_threshold) | ((s2 - f) > 3 * ln))
+        grow = ~accepted & ~slide
+        nf = np.where(accepted, s2 + gap, np.where(slide, f + motion_time_step, f))
+        ns = np.where(grow, s2 + motion_time_step, nf + ln)
+        first[idx], second[idx] = nf, ns
+        active[idx] = ns < bound_hi[idx]
+        steps += 1
+        windows += S
+    keys.sort(key=lambda r: r[0])
+    K = len(keys)
+    return dict(time=np.array([r[0] for r in keys]), duration=np.array([[r[1], r[2]] for r in keys]).reshape(K, 2),
+                events_num=np.array([r[3] for r in keys], np.int64),
+                features=np.stack([r[4] for r in keys]) if K else np.zeros((0, n, 3)), steps=steps, windows=windows)

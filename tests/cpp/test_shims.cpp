@@ -132,6 +132,8 @@ int main(int argc, char **argv) {
         CHECK(kfs[k].duration.second - kfs[k].duration.first >= 3 * step - 1e-12);
         CHECK(kfs[k].duration.second - kfs[k].duration.first <= 10 * step + 1e-9);
         if (k) CHECK(kfs[k].timeStamp > kfs[k - 1].timeStamp);
+        std::printf("kf %.12f %.12f %d %.9f %.9f\n", kfs[k].duration.first, kfs[k].duration.second, kfs[k].eventsNum,
+                    kfs[k].features[0].location[0], kfs[k].features[35].radius);
     }
     return 0;
 }

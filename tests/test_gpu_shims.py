@@ -26,3 +26,18 @@ def test_cpp_shims(tmp_path):
     out = subprocess.run([exe, binf, posef], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "shims ok" in out.stdout and "rectify:" in out.stdout
+    # the Python mirror of the adaptive windowing (eventcalib_amd/adaptive.py) must select the same keyframes
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.adaptive import detect_keyframes
+    from eventcalib_amd.pipeline import DetectPipeline
+    buf = torch.from_numpy(np.fromfile(binf, dtype=np.uint8))
+    t, _, _ = SS.unpack_records(buf)
+    ctx = eventcalib_amd.Context(0)
+    kf = detect_keyframes(DetectPipeline(ctx), buf.cuda(), 5e-4, 4000, 4, float(t[0]), float(t[-1]))
+    rows = [ln.split()[1:] for ln in out.stdout.splitlines() if ln.startswith("kf ")]
+    assert len(rows) == len(kf["time"]) >= 2
+    for r, d, n, f in zip(rows, kf["duration"], kf["events_num"], kf["features"]):
+        assert abs(float(r[0]) - d[0]) < 1e-9 and abs(float(r[1]) - d[1]) < 1e-9 and int(r[2]) == n
+        assert abs(float(r[3]) - f[0, 0]) < 1e-6 and abs(float(r[4]) - f[35, 2]) < 1e-6
+    ctx.close()
