@@ -50,9 +50,6 @@ __device__ unsigned long long g_phase_cycles[16];
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t EDGE_CAP = 256;  // one-way edges kept per segment before falling back to sweeps
 constexpr uint32_t KTOP = 64;       // insertions replayed by wave 0 alone (the top of the kd-tree)
-constexpr uint32_t BM_WORDS = 3520; // bitmap capacity: 346x260 sensor + 2*4 padding needs 268 rows x 13 words
-constexpr uint32_t BM_ROWS = 472;   // rowstart[BM_ROWS + 1 + 39]: 512 u16
-constexpr int BM_RMAX = 15;         // largest disc radius (pixels) the bitmap path takes
 
 template <typename Idx>
 struct IdxBits;
@@ -133,10 +130,6 @@ struct DbWork {
     uint8_t *pflags;             // [n] global tier only: the same bits by pid until the scatter
     uint32_t *red;               // [48] block-scan scratch, edge counter, block_any flags (always LDS)
     uint32_t *edges;             // [2*EDGE_CAP] one-way edges (src pid, dst pid) (always LDS)
-    // pixel-bitmap path (int16 geometry, LDS tiers): nullptr where unavailable
-    uint32_t *bm;                // [BM_WORDS] occupancy bits, row-major, rows padded by the disc radius
-    uint16_t *wpre;              // [BM_WORDS] points of the row before each word
-    uint16_t *rowstart;          // [BM_ROWS + 1] points before each row; the last 40 entries hold the disc half-widths
 };
 
 template <bool GLOBAL>
@@ -362,249 +355,6 @@ __device__ __forceinline__ bool kd_level_settle(uint32_t *slot, uint32_t i, type
     return true;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Pixel-bitmap form of phases C/D/E.1 for integer pixel data (GeoI16): the segment's points become
-// bits of an LDS bitmap (bounding box padded by the disc radius R = floor(eps)); points are ranked in
-// raster order by row starts + per-word prefix counts (no sort, no atomics besides the bit sets);
-//   D: #neighbours = sum over the 2R+1 rows of popcount(row window & disc row) - 1;
-//   E: two-way edges = set bits of the rows above and of the left half of the own row.
-// The only neighbours that can be pruned sit at exactly (+-eps, 0) / (0, +-eps) and carry a filter bit,
-// so the exact replay (pruned_dim) runs for at most two bits per point.  Returns false — leaving
-// P, anc and the flags untouched — when the segment does not qualify (bounding box too large, duplicate
-// pixels, eps too large, edge list overflow): the caller then runs the general grid path.
-template <int T, typename Idx, int PPT>
-__device__ __forceinline__ bool bitmap_core_and_edges(const DbWork<Idx, GeoI16> &wk, const GeoI16 &geo, uint32_t n,
-                                                      double eps, uint32_t minpts, const uint32_t (&myflags)[PPT],
-                                                      uint32_t *parent, uint32_t *n_edges, uint32_t *edges,
-                                                      uint32_t *anyf, uint32_t &any_round) {
-    using G = GeoI16;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t *const P = wk.p;
-    uint32_t *const bm = wk.bm;
-    uint16_t *const wpre = wk.wpre;
-    uint16_t *const rowstart = wk.rowstart;
-    uint16_t *const hw = wk.rowstart + BM_ROWS + 1;  // disc half-width per row offset dy + R
-    int *const bbox = reinterpret_cast<int *>(wk.red + 44);  // min x, min y, -max x, -max y (4 words of red)
-    Idx *const pid_s = wk.pid_s;
-    Idx *const inv = wk.inv;
-    uint8_t *const sflags = wk.sflags;
-    const Idx *const anc = wk.anc;
-
-#ifdef ECAL_PHASE_PROF
-    unsigned long long phase_t__ = __builtin_readcyclecounter();
-#endif
-    // disc radius and eligibility that does not depend on the data
-    int R = (int) floor(sqrt((double) geo.e2i));
-    while ((long long) (R + 1) * (R + 1) <= (long long) geo.e2i) R++;
-    while ((long long) R * R > (long long) geo.e2i) R--;
-    if (R > BM_RMAX || !(eps < 1073741824.0)) return false;  // (eps >= 2^30: the filter bits are no longer exact)
-    // 1. bounding box
-    if (tid < 4) bbox[tid] = 0x7FFFFFFF;
-    __syncthreads();
-    {
-        int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mxy = -0x7FFFFFFF;
-        for (uint32_t i = tid; i < n; i += T) {
-            const uint32_t p = P[i];
-            const int x = G::sx(p), y = G::sy(p);
-            mnx = min(mnx, x);
-            mny = min(mny, y);
-            mxx = max(mxx, x);
-            mxy = max(mxy, y);
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            mnx = min(mnx, __shfl_xor(mnx, o, 64));
-            mny = min(mny, __shfl_xor(mny, o, 64));
-            mxx = max(mxx, __shfl_xor(mxx, o, 64));
-            mxy = max(mxy, __shfl_xor(mxy, o, 64));
-        }
-        if ((tid & 63) == 0) {
-            atomicMin(&bbox[0], mnx);
-            atomicMin(&bbox[1], mny);
-            atomicMin(&bbox[2], -mxx);
-            atomicMin(&bbox[3], -mxy);
-        }
-    }
-    __syncthreads();
-    const int ox = bbox[0] - R, oy = bbox[1] - R;
-    const uint32_t W = (uint32_t) (-bbox[2] - bbox[0] + 1 + 2 * R), H = (uint32_t) (-bbox[3] - bbox[1] + 1 + 2 * R);
-    const uint32_t RW = ((W + 31u) >> 5) + 1u;  // one spare word: 64-bit window fetches never leave the row
-    if (H > BM_ROWS || (uint64_t) H * RW > BM_WORDS) return false;
-    // 2. occupancy bits (a second hit on a set bit = duplicate pixel -> not representable)
-    for (uint32_t k = tid; k < H * RW; k += T) bm[k] = 0;
-    if (tid <= (uint32_t) (2 * R)) {
-        const int dy = (int) tid - R;
-        int w = (int) floor(sqrt((double) (geo.e2i - dy * dy)));
-        while ((long long) (w + 1) * (w + 1) + (long long) dy * dy <= (long long) geo.e2i) w++;
-        while ((long long) w * w + (long long) dy * dy > (long long) geo.e2i) w--;
-        hw[tid] = (uint16_t) w;
-    }
-    __syncthreads();
-    bool dup = false;
-    for (uint32_t i = tid; i < n; i += T) {
-        const uint32_t p = P[i];
-        const uint32_t cx = (uint32_t) (G::sx(p) - ox), yy = (uint32_t) (G::sy(p) - oy);
-        const uint32_t bit = 1u << (cx & 31u);
-        if (atomicOr(&bm[yy * RW + (cx >> 5)], bit) & bit) dup = true;
-    }
-    if (block_any(dup, anyf, any_round)) return false;
-    ECAL_PHASE_MARK(1);  // bbox + bit sets
-    // 3. raster ranks: per-word prefix inside each row, then row starts
-    for (uint32_t r = tid; r < H; r += T) {
-        uint32_t acc = 0;
-        for (uint32_t w = 0; w < RW; w++) {
-            wpre[r * RW + w] = (uint16_t) acc;
-            acc += (uint32_t) __popc(bm[r * RW + w]);
-        }
-        rowstart[r] = (uint16_t) acc;  // row count for now
-    }
-    __syncthreads();
-    {
-        const uint32_t per = (H + T - 1) / T, r0 = tid * per;
-        uint32_t sum = 0;
-        for (uint32_t r = r0; r < r0 + per && r < H; r++) sum += rowstart[r];
-        uint32_t total;
-        uint32_t run = block_exscan<T>(sum, wk.red, &total);
-        for (uint32_t r = r0; r < r0 + per && r < H; r++) {
-            const uint32_t c = rowstart[r];
-            rowstart[r] = (uint16_t) run;
-            run += c;
-        }
-    }
-    __syncthreads();
-    auto rank_of = [&](uint32_t cx, uint32_t yy) -> uint32_t {
-        const uint32_t w = yy * RW + (cx >> 5);
-        return (uint32_t) rowstart[yy] + (uint32_t) wpre[w] + (uint32_t) __popc(bm[w] & ((1u << (cx & 31u)) - 1u));
-    };
-    auto window = [&](uint32_t row, uint32_t lo, uint32_t nbits) -> uint32_t {  // nbits <= 31 bits from column lo
-        const uint32_t w = row * RW + (lo >> 5);
-        const unsigned long long two = ((unsigned long long) bm[w + 1] << 32) | bm[w];
-        return (uint32_t) (two >> (lo & 31u)) & ((1u << nbits) - 1u);
-    };
-#pragma unroll
-    for (int u = 0; u < PPT; u++) {
-        const uint32_t i = tid + u * T;
-        if (i < n) {
-            const uint32_t p = P[i];
-            const uint32_t rk = rank_of((uint32_t) (G::sx(p) - ox), (uint32_t) (G::sy(p) - oy));
-            pid_s[rk] = (Idx) i;
-            inv[i] = (Idx) rk;
-            sflags[rk] = (uint8_t) myflags[u];
-        }
-    }
-    __syncthreads();
-    ECAL_PHASE_MARK(5);  // ranks
-    const bool eps_int = geo.epsi <= R;  // |delta| == eps is possible only for an integral eps (then epsi == R)
-    // 4. D: neighbour counts
-    for (uint32_t i = tid; i < n; i += T) {
-        const uint32_t p = P[i];
-        const int x = G::sx(p), y = G::sy(p);
-        const uint32_t cx = (uint32_t) (x - ox), yy = (uint32_t) (y - oy);
-        uint32_t cnt = 0;
-        for (int dy = -R; dy <= R; dy++) {
-            const uint32_t w = hw[dy + R];
-            cnt += (uint32_t) __popc(window(yy + dy, cx - w, 2u * w + 1u));
-        }
-        cnt -= 1u;  // the point itself
-        if (eps_int && cnt >= minpts) {
-            // neighbours at (+eps, 0) / (0, +eps) whose filter bit is set may be invisible from here
-            const uint32_t e = (uint32_t) geo.epsi;
-            if (bm[yy * RW + ((cx + e) >> 5)] >> ((cx + e) & 31u) & 1u) {
-                const uint32_t rk = rank_of(cx + e, yy);
-                if ((sflags[rk] & 1u) && pruned_dim<G>(P, (const Idx *) nullptr, anc, pid_s[rk], 0u, (double) x, eps)) cnt--;
-            }
-            if (bm[(yy + e) * RW + (cx >> 5)] >> (cx & 31u) & 1u) {
-                const uint32_t rk = rank_of(cx, yy + e);
-                if ((sflags[rk] & 2u) && pruned_dim<G>(P, (const Idx *) nullptr, anc, pid_s[rk], 1u, (double) y, eps)) cnt--;
-            }
-        }
-        parent[i] = (cnt >= minpts) ? i : NONE32;
-        if (cnt >= minpts) sflags[inv[i]] |= 16u;
-    }
-    __syncthreads();
-    ECAL_PHASE_MARK(2);  // D
-    // 5. E.1: every pair once, from its later point in raster order (rows above, own row to the left).
-    // The neighbour bits of the R+1 row windows are first gathered into one per-lane list (row offset
-    // and column packed in a byte each), so that the loop over neighbours runs max-over-lanes of the
-    // TOTAL neighbour count instead of the sum over rows of the per-row maxima.
-    for (uint32_t i = tid; i < n; i += T) {
-        if (parent[i] == NONE32) continue;  // written by this thread in D
-        const uint32_t p = P[i];
-        const int x = G::sx(p), y = G::sy(p);
-        const uint32_t cx = (uint32_t) (x - ox), yy = (uint32_t) (y - oy);
-        const uint32_t fi = sflags[inv[i]];
-        unsigned long long list = 0;  // up to 8 neighbours: (dy + R) << 5 | bit index, 1-based via +1 on the byte
-        uint32_t nlist = 0;
-        bool overflow = false;
-        for (int dy = -R; dy <= 0; dy++) {
-            const uint32_t w = hw[dy + R];
-            uint32_t m = window(yy + dy, cx - w, dy == 0 ? w : 2u * w + 1u);  // own row: strictly left of the point
-            while (m) {
-                const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
-                m &= m - 1u;
-                if (nlist < 8u) list |= (unsigned long long) ((((uint32_t) (dy + R)) << 5 | b) & 0xFFu) << (8u * nlist);
-                else overflow = true;
-                nlist++;
-            }
-        }
-        uint32_t ri = i;  // current root of i's component
-        auto link = [&](int dy, uint32_t b) {
-            const uint32_t w = hw[dy + R];
-            const uint32_t nx = cx - w + b, ny = yy + dy;
-            const uint32_t rk = rank_of(nx, ny);
-            if (!(sflags[rk] & 16u)) return;
-            const uint32_t pj = pid_s[rk];
-            // seen from j the delta to i is (+eps,0) or (0,+eps) exactly when i carries the filter bit
-            const bool sus = eps_int && ((dy == 0 && cx - nx == (uint32_t) geo.epsi && (fi & 1u)) ||
-                                         (nx == cx && dy == -geo.epsi && (fi & 2u)));
-            bool both = true;
-            if (sus) {
-                bool fwd, bwd;  // i -> j, j -> i
-                edge_dirs<G>(P, (const Idx *) nullptr, anc, i, pj, G::unpack(p), G::unpack(P[pj]), eps, fwd, bwd);
-                both = fwd && bwd;
-                if (!both && (fwd || bwd)) {
-                    const uint32_t at = atomicAdd(n_edges, 1u);
-                    if (at < EDGE_CAP) {
-                        edges[2 * at] = fwd ? i : pj;
-                        edges[2 * at + 1] = fwd ? pj : i;
-                    }
-                }
-            }
-            if (both) {  // union(ri, pj), keeping i's root in a register
-                uint32_t rj = uf_find<false>(parent, pj);
-                for (;;) {
-                    ri = uf_find<false>(parent, ri);
-                    if (ri == rj) break;
-                    const uint32_t hi = max(ri, rj), lo = min(ri, rj);
-                    if (atomicCAS(&parent[hi], hi, lo) == hi) {
-                        ri = lo;
-                        break;
-                    }
-                    rj = uf_find<false>(parent, rj);
-                }
-            }
-        };
-        if (!overflow) {
-            for (uint32_t k = 0; k < nlist; k++) {
-                const uint32_t e = (uint32_t) (list >> (8u * k)) & 0xFFu;
-                link((int) (e >> 5) - R, e & 31u);
-            }
-        } else {  // more than 8 earlier neighbours: walk the windows again
-            for (int dy = -R; dy <= 0; dy++) {
-                const uint32_t w = hw[dy + R];
-                uint32_t m = window(yy + dy, cx - w, dy == 0 ? w : 2u * w + 1u);
-                while (m) {
-                    const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
-                    m &= m - 1u;
-                    link(dy, b);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    ECAL_PHASE_MARK(6);  // E.1
-    return *n_edges <= EDGE_CAP;
-}
-
 // The whole pipeline for one segment.  Preconditions: wk.p holds the n points (pid order, already
 // in G's storage format), src is the same data in global memory, all threads of the block call
 // this with identical arguments, n >= 1, minpts >= 1, eps > 0 finite.  PPT = points per thread
@@ -800,20 +550,6 @@ __device__ __forceinline__ uint32_t dbscan_segment(const DbWork<Idx, G> wk, cons
     ECAL_PHASE_COUNT(8, levels__);
 
     uint32_t *const parent = slot;       // [n]  D/E: union-find parent by pid (NONE32 = not core)
-    bool bitmap_done = false;
-    if constexpr (PPT > 0 && sizeof(typename G::Store) == 4) {
-        if (wk.bm) {
-            bitmap_done = bitmap_core_and_edges<T, Idx, PPT>(wk, geo, n, eps, minpts, myflags, parent, n_edges, edges,
-                                                             anyf, any_round);
-#ifdef ECAL_PHASE_PROF
-            phase_t__ = __builtin_readcyclecounter();
-#endif
-            if (!bitmap_done) {  // not eligible (or edge list overflow): start over on the grid path
-                __syncthreads();
-                if (tid == 0) *n_edges = 0;
-            }
-        }
-    }
     uint32_t *const arr = slot + n + 1;  // [nb + 2]
     uint32_t *const bstart = arr + 1;    // bstart[b] = first bucket position of bucket b; bstart[nb] = n
     const uint32_t nb = 1u << nb_log;
@@ -822,7 +558,7 @@ __device__ __forceinline__ uint32_t dbscan_segment(const DbWork<Idx, G> wk, cons
     g.bx_mask = (1u << g.bx_log) - 1u;
     g.by_mask = (1u << (nb_log - g.bx_log)) - 1u;
     bool use_grid = false;
-    if (!bitmap_done) {
+    {
     // ---------------- C: torus cell hash + counting sort ----------------
     bool bad = !geo.usable();
     for (uint32_t b = tid; b < nb + 2; b += T) arr[b] = 0;
@@ -951,7 +687,7 @@ __device__ __forceinline__ uint32_t dbscan_segment(const DbWork<Idx, G> wk, cons
                 return true;
             });
     }
-    }  // !bitmap_done
+    }
     __syncthreads();
     const uint32_t m_edges = *n_edges;
     if (m_edges <= EDGE_CAP) {

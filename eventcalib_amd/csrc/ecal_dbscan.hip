@@ -2,6 +2,7 @@
 // Build with -ffp-contract=off: the ball predicate must be the reference's mul/add sequence.
 #include "ecal_ctx.hpp"
 #include "dbscan_device.hpp"
+#include "dbscan_pixel.hpp"
 
 #pragma clang fp contract(off)
 
@@ -18,21 +19,7 @@ struct TierLayout {
     static constexpr size_t red_off = inv_off + sizeof(uint16_t) * CAP;
     static constexpr size_t edges_off = red_off + sizeof(uint32_t) * 48;  // red: 32 scan, 36 edge count, 40-42 any flags, 44-47 bbox
     static constexpr size_t sflags_off = edges_off + sizeof(uint32_t) * 2 * EDGE_CAP;
-    // pixel bitmap of the int16 path: only the 1024-point tier carries it (the larger tiers would lose
-    // a workgroup per CU to the extra LDS; their segments take the grid path).  In the int16 path the
-    // points take 4 of the 16 bytes per point of the coordinate region; its tail holds the bitmap's
-    // per-word prefix counts, the row starts, the one-way edge list and the per-point flags, and the
-    // bitmap itself starts where the f64 path keeps its edge list and flags.
-    static constexpr bool has_bitmap = CAP <= 1024;
-    static constexpr size_t f64_end = sflags_off + ((CAP + 15) / 16) * 16;
-    static constexpr size_t wpre_off = c_off + sizeof(uint32_t) * CAP;
-    static constexpr size_t rowstart_off = wpre_off + sizeof(uint16_t) * BM_WORDS;
-    static constexpr size_t i16_edges_off = rowstart_off + sizeof(uint16_t) * 512;
-    static constexpr size_t i16_sflags_off = i16_edges_off + sizeof(uint32_t) * 2 * EDGE_CAP;
-    static constexpr size_t bm_off = edges_off;
-    static constexpr size_t i16_end = bm_off + sizeof(uint32_t) * BM_WORDS;
-    static constexpr size_t bytes = (has_bitmap && i16_end > f64_end) ? i16_end : f64_end;
-    static_assert(!has_bitmap || i16_sflags_off + CAP <= slot_off, "int16 side tables must fit the coordinate region");
+    static constexpr size_t bytes = sflags_off + ((CAP + 15) / 16) * 16;
     static_assert(slot_off % 16 == 0 && anc_off % 16 == 0 && cur_off % 16 == 0 && inv_off % 16 == 0 &&
                   red_off % 16 == 0 && edges_off % 16 == 0, "align");
 };
@@ -55,13 +42,11 @@ struct NbLog {
 // Segments with lo_excl < n <= CAP are handled here; the others exit at once.
 // The tier with lo_excl == 0 also writes n_clusters = 0 for empty segments.
 template <int CAP, int T>
-__global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict__ xy,
-                                                       const uint32_t *__restrict__ seg_off,
-                                                       const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
-                                                       double eps, uint32_t minpts, int32_t *__restrict__ labels,
-                                                       uint32_t *__restrict__ n_clusters) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t s = blockIdx.x;
+__device__ __forceinline__ void tier_segment(unsigned char *smem, uint32_t s, const double *__restrict__ xy,
+                                             const uint32_t *__restrict__ seg_off,
+                                             const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl, double eps,
+                                             uint32_t minpts, int32_t *__restrict__ labels,
+                                             uint32_t *__restrict__ n_clusters) {
     const uint32_t n = seg_cnt[s];
     if (n == 0) {
         if (lo_excl == 0 && threadIdx.x == 0) n_clusters[s] = 0;
@@ -101,12 +86,9 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
         w.pid_s = reinterpret_cast<uint16_t *>(smem + L::cur_off);
         w.inv = reinterpret_cast<uint16_t *>(smem + L::inv_off);
         w.red = red;
-        w.edges = reinterpret_cast<uint32_t *>(smem + (L::has_bitmap ? L::i16_edges_off : L::edges_off));
-        w.sflags = reinterpret_cast<uint8_t *>(smem + (L::has_bitmap ? L::i16_sflags_off : L::sflags_off));
+        w.edges = reinterpret_cast<uint32_t *>(smem + L::edges_off);
+        w.sflags = reinterpret_cast<uint8_t *>(smem + L::sflags_off);
         w.pflags = nullptr;
-        w.bm = L::has_bitmap ? reinterpret_cast<uint32_t *>(smem + L::bm_off) : nullptr;
-        w.wpre = reinterpret_cast<uint16_t *>(smem + L::wpre_off);
-        w.rowstart = reinterpret_cast<uint16_t *>(smem + L::rowstart_off);
 #pragma unroll
         for (int u = 0; u < PPT; u++)
             if (threadIdx.x + u * T < n) pts[threadIdx.x + u * T] = GeoI16::pack(mine[u]);
@@ -125,9 +107,6 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
         w.edges = reinterpret_cast<uint32_t *>(smem + L::edges_off);
         w.sflags = reinterpret_cast<uint8_t *>(smem + L::sflags_off);
         w.pflags = nullptr;
-        w.bm = nullptr;
-        w.wpre = nullptr;
-        w.rowstart = nullptr;
 #pragma unroll
         for (int u = 0; u < PPT; u++)
             if (threadIdx.x + u * T < n) pts[threadIdx.x + u * T] = mine[u];
@@ -135,6 +114,24 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
         total = dbscan_segment<T, false, uint16_t, PPT, GeoF64>(w, src, n, eps, minpts, NbLog<CAP>::value, labels + base);
     }
     if (threadIdx.x == 0) n_clusters[s] = total;
+}
+
+// todo == nullptr: workgroup b handles segment b (gridDim.x == S).  Otherwise the workgroups share the list of
+// segments the pixel kernel left over (todo[0 .. *todo_count)), usually empty.
+template <int CAP, int T>
+__global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict__ xy,
+                                                       const uint32_t *__restrict__ seg_off,
+                                                       const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
+                                                       double eps, uint32_t minpts, int32_t *__restrict__ labels,
+                                                       uint32_t *__restrict__ n_clusters, uint32_t S,
+                                                       const uint32_t *__restrict__ todo,
+                                                       const uint32_t *__restrict__ todo_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t count = todo ? *todo_count : S;
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        tier_segment<CAP, T>(smem, todo ? todo[k] : k, xy, seg_off, seg_cnt, lo_excl, eps, minpts, labels, n_clusters);
+        __syncthreads();
+    }
 }
 
 constexpr int BIG_T = 1024;
@@ -165,9 +162,6 @@ __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restr
     w.edges = edges;
     w.sflags = gflags + 2 * base;
     w.pflags = gflags + 2 * base + n;
-    w.bm = nullptr;
-    w.wpre = nullptr;
-    w.rowstart = nullptr;
     // nb = largest power of two <= n/2 (>= 2048 here) so that label[n] + 1 + cursor[nb] fits slot[2n]
     uint32_t nb_log = 31u - (uint32_t) __clz((int) (n >> 1));
     if (nb_log > 20u) nb_log = 20u;
@@ -179,15 +173,26 @@ __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restr
 
 using namespace ecal;
 
-// size tiers: capacity CAP points, CAP/4 threads; LDS ~39 B/point -> 4 / 2 / 1 workgroups per CU.
-// (Smaller tiers — 640 points on 128 threads, 768 on 256 — were measured and are not faster: the
-// kernel is bound by instructions issued per point, not by occupancy; profiles/r01_notes.md.)
+// general size tiers: capacity CAP points, CAP/4 threads; LDS ~36 B/point -> 4 / 2 / 1 workgroups per CU
 static constexpr int CAP0 = 1024, CAP1 = 2048, CAP2 = 4096;
+
+// profiling knobs only (tools/occupancy_probe.sh): ECAL_DBSCAN_LDS_PAD = extra dynamic LDS of the pixel kernel, to lower
+// its occupancy; ECAL_DBSCAN_NO_PIXEL = general kernels only
+static size_t tier0_pad() {
+    static const size_t pad = [] {
+        const char *e = getenv("ECAL_DBSCAN_LDS_PAD");
+        return e ? (size_t) strtoul(e, nullptr, 10) : (size_t) 0;
+    }();
+    return pad;
+}
 
 static int set_attrs(ecal_ctx *ctx) {
     if (ctx->attrs_set) return ECAL_OK;
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP0, CAP0 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP0>::bytes));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int) (PixelLayout::bytes + tier0_pad())));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP1, CAP1 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP1>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP2, CAP2 / 4>),
@@ -220,14 +225,31 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
     hipStream_t st = (hipStream_t) stream;
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
 
-    hipLaunchKernelGGL((dbscan_lds_kernel<CAP0, CAP0 / 4>), dim3(S), dim3(CAP0 / 4), TierLayout<CAP0>::bytes, st, d_xy,
-                       d_seg_off, d_seg_cnt, 0u, eps, minpts, d_labels, d_n_clusters);
+    // event pixels (integer coordinates, eps < 16): the lean pixel kernel takes every segment it can and lists
+    // the others; the general tiers then work that list off with a small grid (it is normally empty)
+    const bool pixel = eps < (double) (PX_RMAX + 1) && !getenv("ECAL_DBSCAN_NO_PIXEL");
+    const uint32_t *todo = nullptr, *todo_count = nullptr;
+    uint32_t grid = S;
+    if (pixel) {
+        if ((rc = ecal_ensure(ctx, ctx->px_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
+        uint32_t *cnt = (uint32_t *) ctx->px_todo.ptr, *list = cnt + 4;
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(dbscan_pixel_kernel, dim3(S), dim3(PX_T), PixelLayout::bytes + tier0_pad(), st, d_xy, d_seg_off,
+                           d_seg_cnt, eps, minpts, d_labels, d_n_clusters, list, cnt);
+        todo = list;
+        todo_count = cnt;
+        grid = S < 1024u ? S : 1024u;
+    }
+    hipLaunchKernelGGL((dbscan_lds_kernel<CAP0, CAP0 / 4>), dim3(grid), dim3(CAP0 / 4), TierLayout<CAP0>::bytes, st, d_xy,
+                       d_seg_off, d_seg_cnt, 0u, eps, minpts, d_labels, d_n_clusters, S, todo, todo_count);
     if (mx > (uint32_t) CAP0)
-        hipLaunchKernelGGL((dbscan_lds_kernel<CAP1, CAP1 / 4>), dim3(S), dim3(CAP1 / 4), TierLayout<CAP1>::bytes, st,
-                           d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP0, eps, minpts, d_labels, d_n_clusters);
+        hipLaunchKernelGGL((dbscan_lds_kernel<CAP1, CAP1 / 4>), dim3(grid), dim3(CAP1 / 4), TierLayout<CAP1>::bytes, st,
+                           d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP0, eps, minpts, d_labels, d_n_clusters, S, todo,
+                           todo_count);
     if (mx > (uint32_t) CAP1)
-        hipLaunchKernelGGL((dbscan_lds_kernel<CAP2, CAP2 / 4>), dim3(S), dim3(CAP2 / 4), TierLayout<CAP2>::bytes, st,
-                           d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP1, eps, minpts, d_labels, d_n_clusters);
+        hipLaunchKernelGGL((dbscan_lds_kernel<CAP2, CAP2 / 4>), dim3(grid), dim3(CAP2 / 4), TierLayout<CAP2>::bytes, st,
+                           d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP1, eps, minpts, d_labels, d_n_clusters, S, todo,
+                           todo_count);
     if (mx > (uint32_t) CAP2) {
         const size_t np = n_points;
         if ((rc = ecal_ensure(ctx, ctx->big_slot, (2 * np + 4 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
