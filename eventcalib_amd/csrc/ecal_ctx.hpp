@@ -24,6 +24,7 @@ struct ecal_ctx {
     // grow-only device scratch (never shrinks; sized for 288 GB parts: keep and reuse)
     ecal_devbuf in_xy, in_off, in_cnt, out_labels, out_ncl;  // staging for the host-pointer API
     ecal_devbuf big_slot, big_anc, big_cur, big_inv, big_cs, big_flags;    // global-scratch tier of DBSCAN
+    ecal_devbuf pxs_todo;  // same for the pixel slicer
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
     ecal_devbuf det_members, det_koff, det_ksize, det_sorted, det_norms;  // detection stage scratch
@@ -33,7 +34,7 @@ struct ecal_ctx {
     ecal_devbuf host_rect[11];  // staging of ecal_rectify_batch
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
-        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
+        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos,
                 &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
