@@ -399,7 +399,10 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
     for (uint32_t k = tid; k < n; k += T) {
         const uint8_t *r = rec + (uint64_t) (lo + k) * RECORD_BYTES;
         const double x = load_f64_unaligned(r + 8), y = load_f64_unaligned(r + 16);
-        bad = bad || !(x == floor(x) && y == floor(y) && fabs(x) <= 16383.0 && fabs(y) <= 16383.0);
+        // (-0.0 is a valid pixel for operator==, but the emitted element keeps its sign bit: general path)
+        bad = bad || !(x == floor(x) && y == floor(y) && fabs(x) <= 16383.0 && fabs(y) <= 16383.0) ||
+              __double_as_longlong(x) == (long long) 0x8000000000000000ull ||
+              __double_as_longlong(y) == (long long) 0x8000000000000000ull;
         const uint32_t kx = (uint32_t) (int) x & 0x7FFFu, ky = (uint32_t) (int) y & 0x7FFFu;
         key[k] = kx | (ky << 15) | (r[24] ? 0x40000000u : 0u);
     }

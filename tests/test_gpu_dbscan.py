@@ -108,3 +108,37 @@ def test_invalid_arguments(ctx):
             ctx.dbscan_batch(np.zeros((3, 2)), np.array([0, 3], np.uint32), bad_eps, 2)
     labels, ncl = ctx.dbscan_batch(np.zeros((0, 2)), np.array([0], np.uint32), 4.0, 2)
     assert labels.size == 0 and ncl.size == 0
+
+
+def test_pixel_and_general_kernels_agree(ctx):
+    """Integer pixel segments take the lean pixel kernel (dbscan_pixel.hpp); with ECAL_DBSCAN_NO_PIXEL the general
+    tiers do the same segments.  Both must equal the oracle — including the pruning quirk (integral eps), duplicate
+    pixels (pixel kernel bails), a bounding box too large for its bitmap, and segments above its 1024-point capacity."""
+    rng = np.random.default_rng(77)
+    segs = []
+    for k in range(40):                                   # dense lattice patches: many exactly-eps pairs
+        n = int(rng.integers(20, 900))
+        segs.append(np.stack([rng.integers(0, 60, n), rng.integers(0, 45, n)], 1).astype(np.float64))
+        segs[-1] = np.unique(segs[-1], axis=0)[rng.permutation(len(np.unique(segs[-1], axis=0)))]
+    dup = np.stack([rng.integers(0, 30, 300), rng.integers(0, 30, 300)], 1).astype(np.float64)   # duplicates
+    segs.append(dup)
+    wide = np.stack([rng.integers(-8000, 8000, 500), rng.integers(-8000, 8000, 500)], 1).astype(np.float64)
+    wide[:200] = np.stack([rng.integers(0, 40, 200), rng.integers(0, 40, 200)], 1)                # bbox too large
+    segs.append(wide)
+    big = np.unique(np.stack([rng.integers(0, 120, 3000), rng.integers(0, 90, 3000)], 1), axis=0).astype(np.float64)
+    segs.append(big[rng.permutation(len(big))][:1500])                                            # > 1024 points
+    row = np.stack([np.arange(300), np.full(300, 7)], 1).astype(np.float64)                        # > 255 points in a row
+    segs.append(row[rng.permutation(300)])
+    xy = np.concatenate(segs)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint32)
+    for eps, minpts in ((4.0, 2), (3.0, 1), (5.0, 5), (4.5, 2), (15.0, 3), (16.0, 2)):
+        os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+        la, na = ctx.dbscan_batch(xy, off, eps, minpts)
+        os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
+        try:
+            lb, nb = ctx.dbscan_batch(xy, off, eps, minpts)
+        finally:
+            os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+        assert np.array_equal(la, lb) and np.array_equal(na, nb), (eps, minpts)
+        ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)
+        assert np.array_equal(la, ref_l) and np.array_equal(na, ref_n), (eps, minpts)
