@@ -1,4 +1,4 @@
-"""ctypes binding of libecal.so (include/ecal.h).  No torch import here: device pointers are
+"""ctypes binding of libecal.so (include/ecal.h).  No torch objects cross this layer: device pointers are
 passed as integers (``tensor.data_ptr()``), streams as ``torch.cuda.current_stream().cuda_stream``."""
 import ctypes
 import os
@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
+    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_calibrate_views",
 ]
 
 
@@ -49,6 +50,13 @@ def load_library():
     if not os.path.exists(p):
         raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C eventcalib_amd/csrc`). There is no CPU fallback." % p)
+    # torch wheels bundle their own libamdhip64 under the same soname: whichever HIP runtime is mapped first serves
+    # the whole process, and torch cannot find a GPU through the system one.  Let torch (when present) map its
+    # runtime first; libecal.so then binds to that already-loaded library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(p)
     vp, u32, i32, f64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_double
     L.ecal_abi_version.restype = i32
@@ -388,3 +396,73 @@ def make_allreduce_hook(ctx: Context, world_size):
             return 1
 
     return ALLREDUCE_FN(hook)
+
+
+# ---- init calibration on calibration views ----
+CALIB_FIX_ASPECT_RATIO, CALIB_FIX_PRINCIPAL_POINT, CALIB_ZERO_TANGENT_DIST = 1 << 0, 1 << 1, 1 << 2
+CALIB_FIX_K1, CALIB_FIX_K2, CALIB_FIX_K3, CALIB_FIX_K4, CALIB_FIX_K5, CALIB_FIX_K6 = (1 << 3, 1 << 4, 1 << 5, 1 << 6,
+                                                                                      1 << 7, 1 << 8)
+CALIB_FIX_SKEW, CALIB_RECOMPUTE_EXTRINSIC = 1 << 9, 1 << 10
+CALIB_BLOCK_DOUBLES = 272
+
+
+class CalibOptions(ctypes.Structure):
+    """ecal_calib_options (include/ecal.h)."""
+    _fields_ = [("model", ctypes.c_int), ("flags", ctypes.c_uint32), ("aspect_ratio", ctypes.c_double),
+                ("max_iter", ctypes.c_int), ("eps", ctypes.c_double), ("allreduce", ALLREDUCE_FN),
+                ("allreduce_user", ctypes.c_void_p)]
+
+
+class CalibResult(ctypes.Structure):
+    _fields_ = [("intr", ctypes.c_double * 12), ("rms", ctypes.c_double), ("iterations", ctypes.c_int),
+                ("jacobian_evaluations", ctypes.c_int), ("error_evaluations", ctypes.c_int), ("seconds", ctypes.c_double)]
+
+
+def _declare_calib(L):
+    vp, i32, u32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_double
+    L.ecal_calib_default_options.argtypes = [ctypes.POINTER(CalibOptions)]
+    L.ecal_calib_default_options.restype = None
+    L.ecal_calib_view_blocks_dev.argtypes = [vp, vp, u32, vp, u32, i32, u32, f64, vp, vp, i32, vp, vp]
+    L.ecal_calib_view_blocks_dev.restype = i32
+    L.ecal_pnp_batch_dev.argtypes = [vp, vp, u32, vp, vp, u32, i32, vp, f64, i32, i32, vp, vp, vp, vp, vp]
+    L.ecal_pnp_batch_dev.restype = i32
+    L.ecal_calibrate_views.argtypes = [vp, vp, u32, vp, u32, f64, f64, ctypes.POINTER(CalibOptions),
+                                       ctypes.POINTER(CalibResult), vp, vp, vp]
+    L.ecal_calibrate_views.restype = i32
+
+
+def calibrate_views(ctx: Context, obj, img, width, height, model=0, flags=0, aspect_ratio=1.0, max_iter=0, eps=0.0,
+                    allreduce=None):
+    """ecal_calibrate_views: obj [n][3], img [V][n][2] (this rank's views).  Returns a dict."""
+    L = ctx._L
+    _declare_calib(L)
+    obj = np.ascontiguousarray(obj, np.float64)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, obj.shape[0], 2)
+    V = img.shape[0]
+    opt = CalibOptions()
+    L.ecal_calib_default_options(ctypes.byref(opt))
+    opt.model, opt.flags, opt.aspect_ratio, opt.max_iter, opt.eps = int(model), int(flags), float(aspect_ratio), int(max_iter), float(eps)
+    if allreduce is not None:
+        opt.allreduce = allreduce
+    res = CalibResult()
+    rv, tv, pe = np.zeros((V, 3)), np.zeros((V, 3)), np.zeros(V)
+    ctx._check(L.ecal_calibrate_views(ctx._h, _ptr(obj), obj.shape[0], _ptr(img) if V else None, V, float(width), float(height),
+                                      ctypes.byref(opt), ctypes.byref(res), _ptr(rv) if V else None, _ptr(tv) if V else None,
+                                      _ptr(pe) if V else None))
+    return {"intr": np.array(res.intr[:]), "rms": res.rms, "iterations": res.iterations, "rvecs": rv, "tvecs": tv,
+            "per_view_err": pe, "jacobian_evaluations": res.jacobian_evaluations,
+            "error_evaluations": res.error_evaluations, "seconds": res.seconds}
+
+
+def calib_view_blocks_dev(ctx: Context, d_obj, n_pts, d_img, n_views, model, flags, aspect_ratio, d_intr, d_view_params,
+                          with_jacobian, d_blocks, stream=0):
+    _declare_calib(ctx._L)
+    ctx._check(ctx._L.ecal_calib_view_blocks_dev(ctx._h, d_obj, n_pts, d_img, n_views, model, flags, aspect_ratio, d_intr,
+                                                 d_view_params, int(with_jacobian), d_blocks, stream))
+
+
+def pnp_batch_dev(ctx: Context, d_obj, n_pts, d_img, d_valid, n_frames, model, d_intr, reproj_thresh, rounds, refine_iters,
+                  d_pose, d_inlier=None, d_err=None, d_ok=None, stream=0):
+    _declare_calib(ctx._L)
+    ctx._check(ctx._L.ecal_pnp_batch_dev(ctx._h, d_obj, n_pts, d_img, d_valid, n_frames, model, d_intr, float(reproj_thresh),
+                                         int(rounds), int(refine_iters), d_pose, d_inlier, d_err, d_ok, stream))

@@ -78,6 +78,7 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
         (void) hipStreamSynchronize(ctx->stream);
         (void) hipStreamDestroy(ctx->stream);
     }
+    if (ctx->calib_pinned) (void) hipHostFree(ctx->calib_pinned);
     for (ecal_devbuf *b : ctx->all_bufs()) release(*b);
     delete ctx;
 }

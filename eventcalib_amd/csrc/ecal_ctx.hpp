@@ -32,6 +32,8 @@ struct ecal_ctx {
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
     ecal_devbuf host_grid_order, host_grid_found;
     ecal_devbuf host_rect[11];  // staging of ecal_rectify_batch
+    ecal_devbuf calib_scratch;  // ecal_calibrate_views: views, blocks, reduced records
+    double *calib_pinned = nullptr;  // pinned host landing zone of the reduced record
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
@@ -42,7 +44,7 @@ struct ecal_ctx {
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
                 &host_pipe[6], &host_pipe[7], &host_pipe[8], &host_pipe[9], &host_pipe[10], &host_pipe[11],
                 &host_pipe[12], &host_pipe[13], &host_pipe[14], &host_pipe[15], &host_pipe[16],
-                &host_grid_order, &host_grid_found};
+                &host_grid_order, &host_grid_found, &calib_scratch};
     }
 };
 

@@ -323,6 +323,75 @@ int ecal_solver_solve(ecal_solver *s, double *params /*in: start, out: solution*
  * five inverse-polynomial coefficients that initialise k1..k5 (EventCalibSpline.cpp:101-105). */
 void ecal_inverse_radial_distortion(const double *k4, double *b5);
 
+/* ---- init calibration on calibration views ---------------------------------------------------------
+ * Replaces the OpenCV calls of EventCalibIni::cvCalibration (event_camera_calib/src/EventCalibIni.cpp:149-347):
+ *   cv::calibrateCamera(objectPoints, imagePoints, imageSize, K, dist(8), rvecs, tvecs, flag | CALIB_USE_LU)  :198-199
+ *   cv::fisheye::calibrate(objectPoints, imagePoints, imageSize, K, dist(4), rvecs, tvecs, flag)              :188
+ *   cv::solvePnPRansac(objectPoints[0], imageP, K, dist, rvec, tvec, false, 50, 4.0, 0.99, inliers, IPPE)     :258-259
+ * with the flag word assembled as in parameters.hpp:48-69.  OpenCV is third party (not in the reference tree):
+ * the algorithms are restated (oracle/calib_oracle.py lists them), parity with OpenCV itself is unpinned.
+ *
+ * Intrinsics slots (12 doubles): model 0 = fx fy cx cy k1 k2 p1 p2 k3 k4 k5 k6 (cv::calibrateCamera's K and its
+ * 8 distortion coefficients in OpenCV's order), model 1 = fx fy cx cy alpha k1 k2 k3 k4 (cv::fisheye).
+ * A view = the n_pts circle centres of one keyframe in grid order (CirclesEventFrame::features()); the board
+ * points obj [n_pts][3] are calcBoardCornerPositions (EventCalibIni.cpp:99-115) and must have z == 0.
+ * Pose of a view: rvec (cv::Rodrigues vector) and tvec, camera <- board.
+ *
+ * ecal_calib_view_blocks_dev: the data-parallel piece — per view v the normal-equation blocks of its
+ *   2 n_pts reprojection residuals r = projected - measured with the analytic Jacobian J (columns of fixed
+ *   intrinsics zeroed; with FIX_ASPECT_RATIO fx is tied to aspect_ratio * fy and its column folded into fy's):
+ *   d_blocks[272 v ..] = Hii [12][12] | Hiv [12][6] | Hvv [6][6] | gi = (J^T r)_intr [12] | gv [6] | cost = r^T r | pad.
+ *   with_jacobian = 0 writes only cost (slot 270).  Blocks of different views are independent: views shard across
+ *   GPUs and only Schur-reduced 12 x 12 records are summed (ecal_calibrate_views below).
+ * ecal_pnp_batch_dev: planar pose of F frames at once — undistort, homography, IPPE (both solutions, the one with
+ *   the smaller reprojection error), `rounds` consensus rounds with inliers = reprojection error <= reproj_thresh
+ *   px (0 = none; a deterministic stand-in for the RANSAC loop), then refine_iters Levenberg-Marquardt iterations
+ *   on the pose (0 = none, as solvePnPRansac's final SOLVEPNP_IPPE call; 20 = cvFindExtrinsicCameraParams2).
+ *   d_valid [F][n_pts] (or NULL) masks missing circles.  d_pose [F][6] = rvec, tvec; d_inlier [F][n_pts];
+ *   d_err [F] = sum of squared reprojection errors over the inliers; d_ok [F] = 0 if no pose was found.
+ * ecal_calibrate_views: the whole calibration for this process's views (host pointers).  With options.allreduce
+ *   set, every rank passes its own shard of the views (n_views may differ, 0 allowed) and all ranks return the
+ *   same intrinsics; rvecs / tvecs / per_view_err are those of the local views.
+ */
+#define ECAL_CALIB_FIX_ASPECT_RATIO    (1u << 0)  /* cv::CALIB_FIX_ASPECT_RATIO: fx = aspect_ratio * fy */
+#define ECAL_CALIB_FIX_PRINCIPAL_POINT (1u << 1)  /* cv::CALIB_FIX_PRINCIPAL_POINT / fisheye::CALIB_FIX_PRINCIPAL_POINT */
+#define ECAL_CALIB_ZERO_TANGENT_DIST   (1u << 2)  /* cv::CALIB_ZERO_TANGENT_DIST */
+#define ECAL_CALIB_FIX_K1              (1u << 3)
+#define ECAL_CALIB_FIX_K2              (1u << 4)
+#define ECAL_CALIB_FIX_K3              (1u << 5)
+#define ECAL_CALIB_FIX_K4              (1u << 6)
+#define ECAL_CALIB_FIX_K5              (1u << 7)
+#define ECAL_CALIB_FIX_K6              (1u << 8)
+#define ECAL_CALIB_FIX_SKEW            (1u << 9)  /* cv::fisheye::CALIB_FIX_SKEW */
+#define ECAL_CALIB_RECOMPUTE_EXTRINSIC (1u << 10) /* cv::fisheye::CALIB_RECOMPUTE_EXTRINSIC */
+#define ECAL_CALIB_BLOCK_DOUBLES 272
+typedef struct ecal_calib_options {
+    int model;            /* 0 = pinhole (Calibrate_UseFisheyeModel: 0), 1 = fisheye */
+    uint32_t flags;       /* ECAL_CALIB_* */
+    double aspect_ratio;  /* Calibrate_FixAspectRatio (used with ECAL_CALIB_FIX_ASPECT_RATIO) */
+    int max_iter;         /* 0 = OpenCV's default TermCriteria: 30 (calibrateCamera) / 100 (fisheye) */
+    double eps;           /* 0 = DBL_EPSILON */
+    ecal_allreduce_fn allreduce; /* NULL on one GPU; sums a small device buffer over ranks in place (RCCL) */
+    void *allreduce_user;
+} ecal_calib_options;
+typedef struct ecal_calib_result {
+    double intr[12];
+    double rms;           /* sqrt(sum of squared reprojection errors / number of points), all ranks' views */
+    int iterations, jacobian_evaluations, error_evaluations;
+    double seconds;
+} ecal_calib_result;
+void ecal_calib_default_options(ecal_calib_options *opt);
+int ecal_calib_view_blocks_dev(ecal_ctx *ctx, const double *d_obj /*[n_pts][3]*/, uint32_t n_pts, const double *d_img /*[V][n_pts][2]*/,
+                               uint32_t n_views, int model, uint32_t flags, double aspect_ratio, const double *d_intr /*[12]*/,
+                               const double *d_view_params /*[V][6]*/, int with_jacobian, double *d_blocks /*[V][272]*/, void *stream);
+int ecal_pnp_batch_dev(ecal_ctx *ctx, const double *d_obj, uint32_t n_pts, const double *d_img /*[F][n_pts][2]*/,
+                       const uint32_t *d_valid /*[F][n_pts] or NULL*/, uint32_t n_frames, int model, const double *d_intr /*[12]*/,
+                       double reproj_thresh, int rounds, int refine_iters, double *d_pose /*[F][6]*/, uint32_t *d_inlier /*or NULL*/,
+                       double *d_err /*or NULL*/, uint32_t *d_ok /*or NULL*/, void *stream);
+int ecal_calibrate_views(ecal_ctx *ctx, const double *obj /*[n_pts][3]*/, uint32_t n_pts, const double *img /*[V][n_pts][2]*/,
+                         uint32_t n_views, double width, double height, const ecal_calib_options *opt, ecal_calib_result *res,
+                         double *rvecs /*[V][3] or NULL*/, double *tvecs /*[V][3] or NULL*/, double *per_view_err /*[V] or NULL*/);
+
 #ifdef __cplusplus
 }
 #endif
