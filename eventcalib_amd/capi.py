@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
-    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_calibrate_views",
+    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views",
 ]
 
 

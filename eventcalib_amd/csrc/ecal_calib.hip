@@ -834,6 +834,47 @@ extern "C" int ecal_pnp_batch_dev(ecal_ctx *ctx, const double *d_obj, uint32_t n
     return ECAL_OK;
 }
 
+// host-buffer form of ecal_pnp_batch_dev (what host/event_calib_ini.hpp calls)
+extern "C" int ecal_pnp_batch(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const double *img, const uint32_t *valid, uint32_t n_frames,
+                              int model, const double *intr, double reproj_thresh, int rounds, int refine_iters, double *pose,
+                              uint32_t *inlier, double *err, uint32_t *ok) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (!obj || !img || !intr || !pose || n_pts < 4 || n_pts > CB_MAXPTS) {
+        ctx->last_error = "ecal_pnp_batch: bad argument";
+        return ECAL_ERR_INVALID;
+    }
+    if (n_frames == 0) return ECAL_OK;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t F = n_frames, n = n_pts;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) / 256 * 256;
+        return o;
+    };
+    const size_t o_obj = carve(3 * n * 8), o_img = carve(2 * n * F * 8), o_valid = carve(n * F * 4), o_intr = carve(CB_NI * 8),
+                 o_pose = carve(6 * F * 8), o_inl = carve(n * F * 4), o_err = carve(F * 8), o_ok = carve(F * 4);
+    int rc = ecal_ensure(ctx, ctx->calib_scratch, off);
+    if (rc) return rc;
+    char *base = (char *) ctx->calib_scratch.ptr;
+    hipStream_t st = ctx->stream;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_obj, obj, 3 * n * 8, hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_img, img, 2 * n * F * 8, hipMemcpyHostToDevice, st));
+    if (valid) ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_valid, valid, n * F * 4, hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_intr, intr, CB_NI * 8, hipMemcpyHostToDevice, st));
+    rc = ecal_pnp_batch_dev(ctx, (const double *) (base + o_obj), n_pts, (const double *) (base + o_img),
+                            valid ? (const uint32_t *) (base + o_valid) : nullptr, n_frames, model, (const double *) (base + o_intr),
+                            reproj_thresh, rounds, refine_iters, (double *) (base + o_pose), (uint32_t *) (base + o_inl),
+                            (double *) (base + o_err), (uint32_t *) (base + o_ok), st);
+    if (rc) return rc;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(pose, base + o_pose, 6 * F * 8, hipMemcpyDeviceToHost, st));
+    if (inlier) ECAL_HIP_TRY(ctx, hipMemcpyAsync(inlier, base + o_inl, n * F * 4, hipMemcpyDeviceToHost, st));
+    if (err) ECAL_HIP_TRY(ctx, hipMemcpyAsync(err, base + o_err, F * 8, hipMemcpyDeviceToHost, st));
+    if (ok) ECAL_HIP_TRY(ctx, hipMemcpyAsync(ok, base + o_ok, F * 4, hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ECAL_OK;
+}
+
 extern "C" void ecal_calib_default_options(ecal_calib_options *o) {
     if (!o) return;
     memset(o, 0, sizeof(*o));

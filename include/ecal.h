@@ -388,6 +388,10 @@ int ecal_pnp_batch_dev(ecal_ctx *ctx, const double *d_obj, uint32_t n_pts, const
                        const uint32_t *d_valid /*[F][n_pts] or NULL*/, uint32_t n_frames, int model, const double *d_intr /*[12]*/,
                        double reproj_thresh, int rounds, int refine_iters, double *d_pose /*[F][6]*/, uint32_t *d_inlier /*or NULL*/,
                        double *d_err /*or NULL*/, uint32_t *d_ok /*or NULL*/, void *stream);
+/* host-buffer form of ecal_pnp_batch_dev */
+int ecal_pnp_batch(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const double *img, const uint32_t *valid /*or NULL*/,
+                   uint32_t n_frames, int model, const double *intr /*[12]*/, double reproj_thresh, int rounds, int refine_iters,
+                   double *pose /*[F][6]*/, uint32_t *inlier /*or NULL*/, double *err /*or NULL*/, uint32_t *ok /*or NULL*/);
 int ecal_calibrate_views(ecal_ctx *ctx, const double *obj /*[n_pts][3]*/, uint32_t n_pts, const double *img /*[V][n_pts][2]*/,
                          uint32_t n_views, double width, double height, const ecal_calib_options *opt, ecal_calib_result *res,
                          double *rvecs /*[V][3] or NULL*/, double *tvecs /*[V][3] or NULL*/, double *per_view_err /*[V] or NULL*/);

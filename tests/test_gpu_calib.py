@@ -91,13 +91,13 @@ def test_pnp_recovers_pose_and_flags_outliers(ctx, model):
         r_o, t_o, inl_o = CO.pnp_consensus(model, gt, obj, img[f])
         assert (inl_o == inl[f].astype(bool)).all()
         assert np.abs(pose[f, :3] - r_o).max() < 1e-9 and np.abs(pose[f, 3:] - t_o).max() < 1e-8
-    # with refinement the ML pose of the clean frames is exact
+    # with refinement the ML pose of the clean frames is exact up to the FLT_EPSILON parameter-change stop
     capi.pnp_batch_dev(ctx, d_obj.data_ptr(), obj.shape[0], d_img.data_ptr(), None, F, model, d_intr.data_ptr(), 4.0, 3, 20,
                        d_pose.data_ptr(), d_inl.data_ptr(), d_err.data_ptr(), d_ok.data_ptr(),
                        torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     pose = d_pose.cpu().numpy()
-    assert np.abs(pose[:, :3] - rv).max() < 1e-9 and np.abs(pose[:, 3:] - tv).max() < 1e-7
+    assert np.abs(pose[:, :3] - rv).max() < 1e-7 and np.abs(pose[:, 3:] - tv).max() < 1e-5
 
 
 @pytest.mark.parametrize("model,flags,aspect,V", [(0, SC.FLAGS_EXAMPLE, 1.0, 24), (0, CO.FIX_K4 | CO.FIX_K5 | CO.FIX_K6, 0.0, 24),

@@ -41,3 +41,36 @@ def test_cpp_shims(tmp_path):
         assert abs(float(r[0]) - d[0]) < 1e-9 and abs(float(r[1]) - d[1]) < 1e-9 and int(r[2]) == n
         assert abs(float(r[3]) - f[0, 0]) < 1e-6 and abs(float(r[4]) - f[35, 2]) < 1e-6
     ctx.close()
+
+
+@pytest.mark.parametrize("fisheye", [0, 1])
+def test_cpp_event_calib_ini(tmp_path, fisheye):
+    """EventCalibIni::cvCalibration shim: frame selection (step = frames / NumOfFrameToUse), calibration, batched PnP,
+    checkPose and the rectify hook, on synthetic keyframes with known camera and poses."""
+    import numpy as np
+    import synth_calib as SC
+    import calib_oracle as CO
+    exe = str(tmp_path / "test_calib_shim")
+    lib_dir = os.path.join(ROOT, "eventcalib_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_calib_shim.cpp"),
+                           "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"])
+    V = 50
+    obj, img, rv, tv = SC.make_views(V, fisheye, seed=31)
+    ts = 5.0 + 1.0 * np.arange(V)             # far apart in time: every pose passes checkPose
+    ts[10] = ts[9] + 1e-4                     # ... except one implausibly fast jump
+    vf = str(tmp_path / "views.bin")
+    np.concatenate([[V, obj.shape[0], fisheye], img.ravel(), ts]).astype(np.float64).tofile(vf)
+    out = subprocess.run([exe, vf], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    head = lines[0].split()
+    gt = SC.GT_FISHEYE if fisheye else SC.GT_PINHOLE
+    assert head[1] == "1" and float(head[3]) < 1e-4 and int(head[5]) == 20        # float-narrowed pixels: rms ~1e-5
+    K = np.array([float(x) for x in lines[1].split()[1:]])
+    assert np.abs(K / gt[:4] - 1).max() < 1e-5
+    dist = np.array([float(x) for x in lines[2].split()[1:]])
+    assert np.abs(dist - (gt[5:9] if fisheye else gt[4:12])).max() < 1e-3
+    n_check, n_rect, n_acc = int(head[9]), int(head[11]), int(head[7])
+    assert n_check == 1 and n_rect == (V - 1) // 7 and n_acc == V - n_check - n_rect
+    p0 = [float(x) for x in lines[3].split()[1:]]
+    assert np.abs(np.array(p0[:3]) - tv[0]).max() < 5e-3 and abs(p0[3] - CO.rodrigues(rv[0])[0, 0]) < 1e-4
