@@ -162,6 +162,20 @@ def view_blocks(model, flags, aspect, p, obj, img, v):
     return H[:NI, :NI], H[:NI, NI:], H[NI:, NI:], g[:NI], g[NI:], float(r @ r)
 
 
+def reduced_record(model, flags, aspect, p, obj, img, views, lam):
+    """Schur-reduced record of a shard of views in the layout ranks all-reduce (ecal_calibrate_views):
+    S [12][12] = sum_v Hii - Hiv (Hvv + lam diag Hvv)^-1 Hvi | g [12] | diag(sum Hii) [12] | cost | points."""
+    S, g, d, cost = np.zeros((NI, NI)), np.zeros(NI), np.zeros(NI), 0.0
+    for v in views:
+        Hii, Hiv, Hvv, gi, gv, c = view_blocks(model, flags, aspect, p, obj, img, v)
+        W = Hiv @ np.linalg.inv(Hvv + lam * np.diag(np.diag(Hvv)))
+        S += Hii - W @ Hiv.T
+        g += gi - W @ gv
+        d += np.diag(Hii)
+        cost += c
+    return np.concatenate([S.ravel(), g, d, [cost, float(len(views) * obj.shape[0])]])
+
+
 def homography(src, dst):
     """Least-squares homography dst ~ H src (Hartley-normalised DLT, h22 = 1)."""
     def norm(pts):

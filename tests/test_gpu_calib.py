@@ -3,8 +3,12 @@ numpy oracle (oracle/calib_oracle.py) and synthetic ground truth.  Floating poin
 import numpy as np
 import pytest
 
-import synth_calib as SC
-import calib_oracle as CO
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import synth_calib as SC  # noqa: E402
+import calib_oracle as CO  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 

@@ -72,6 +72,60 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _calib_worker(rank, world, port, q):
+    """Init calibration, views sharded over ranks: the all-reduced 170-double Schur records give every rank the
+    step the dense (12 + 6V)^2 system gives (what cv::calibrateCamera solves)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import calib_oracle as CO
+    import synth_calib as SC
+    try:
+        V, lam = 6, 1e-3
+        obj, img, rv, tv = SC.make_views(V, 0, seed=9, noise_px=0.3)
+        flags, aspect = SC.FLAGS_EXAMPLE, 1.0
+        p = np.concatenate([SC.GT_PINHOLE * (1 + 1e-3)] + [np.concatenate([rv[v], tv[v]]) for v in range(V)])
+        lo, hi = (V * rank) // world, (V * (rank + 1)) // world
+        rec = torch.from_numpy(CO.reduced_record(0, flags, aspect, p, obj, img, range(lo, hi), lam))
+        assert rec.numel() == 170
+        dist.all_reduce(rec)
+        rec = rec.numpy()
+        assert rec[169] == V * obj.shape[0]
+        free = np.flatnonzero(CO.free_mask(0, flags))
+        A = rec[:144].reshape(12, 12)[np.ix_(free, free)] + lam * np.diag(rec[156:168][free])
+        x_red = np.linalg.solve(A, rec[144:156][free])
+        # dense reference: the whole arrow system with the (1 + lambda) diagonal, as CvLevMarq::step
+        fm = np.concatenate([CO.free_mask(0, flags), np.ones(6 * V)])
+        J = CO.jacobian_fd(0, flags, aspect, p, obj, img) * fm
+        r = CO.residuals(0, flags, aspect, p, obj, img)
+        idx = np.flatnonzero(fm)
+        H = (J.T @ J)[np.ix_(idx, idx)]
+        H[np.diag_indices_from(H)] *= 1 + lam
+        x_full = np.linalg.solve(H, (J.T @ r)[idx])
+        assert np.allclose(x_red, x_full[:len(free)], rtol=1e-6, atol=1e-9), (x_red, x_full[:len(free)])
+        assert abs(rec[168] - r @ r) < 1e-9
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "FAIL: %r" % (e,)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_calibration_views():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_calib_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
 def test_world_size_2_gloo():
     world = 2
     ctx = mp.get_context("spawn")
