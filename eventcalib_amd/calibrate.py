@@ -1,0 +1,233 @@
+"""The reference driver end to end over a device-resident event stream.
+
+Python mirror of unit_test_eventCameraCalib's main (event_camera_calib/test/eventCameraCalib.cpp:99-233) and of the
+C++ shims in eventcalib_amd/csrc/host/ (multi_process.hpp, event_calib_ini.hpp, event_calib_spline.hpp):
+
+  1. keyframe search: adaptive windows + grid ordering + orientation gate          eventCameraCalib.cpp:168-190
+  2. EventCalibIni::cvCalibration: frame selection, calibrateCamera, solvePnPRansac for every keyframe, checkPose,
+     rectifyFeatures                                                              EventCalibIni.cpp:149-325
+  3. EventCalibSpline: gap segmentation, spline initialisation, event association, the continuous-time solve,
+     updateMap                                                                    EventCalibSpline.cpp:14-317
+  4. SystemBase::saveKeyFrameTrajectoryTUM                                        SystemBase.cpp:122-150
+
+Every numeric stage is a libecal.so entry point (HIP kernels or, for the two tiny banded fits, host C++); this
+module is orchestration only — torch owns HBM buffers, numpy carries the small per-keyframe tables.
+"""
+import numpy as np
+import torch
+
+from . import capi
+from .adaptive import detect_keyframes
+from .pipeline import DetectPipeline
+
+EXAMPLE_FLAGS = (capi.CALIB_FIX_ASPECT_RATIO | capi.CALIB_FIX_PRINCIPAL_POINT | capi.CALIB_ZERO_TANGENT_DIST |
+                 capi.CALIB_FIX_K4 | capi.CALIB_FIX_K5 | capi.CALIB_FIX_K6)       # parameters.hpp:47-58 on example.yaml
+
+
+def board_points(rows=9, cols=4, square=5.5, asymmetric=True):
+    """EventCalibIni::calcBoardCornerPositions (EventCalibIni.cpp:99-115), narrowed to float like cv::Point3f."""
+    pts = [(((2 * j + i % 2) if asymmetric else j) * square, i * square, 0.0) for i in range(rows) for j in range(cols)]
+    return np.array(pts, np.float32).astype(np.float64)
+
+
+def rodrigues(rv):
+    """[n,3] rotation vectors -> [n,3,3] (cv::Rodrigues)."""
+    rv = np.asarray(rv, np.float64).reshape(-1, 3)
+    th = np.linalg.norm(rv, axis=1)
+    k = rv / np.maximum(th, 1e-300)[:, None]
+    K = np.zeros((len(rv), 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -k[:, 2], k[:, 1], k[:, 2], -k[:, 0], -k[:, 1], k[:, 0]
+    return (np.cos(th)[:, None, None] * np.eye(3) + (1 - np.cos(th))[:, None, None] * k[:, :, None] * k[:, None, :] +
+            np.sin(th)[:, None, None] * K)
+
+
+def quat_from_matrix(R):
+    """[n,3,3] -> [n,4] x y z w (Eigen::Quaterniond(Matrix3d)'s branches)."""
+    out = np.zeros((len(R), 4))
+    for n, m in enumerate(R):
+        t = np.trace(m)
+        if t > 0:
+            t = np.sqrt(t + 1.0)
+            out[n, 3] = 0.5 * t
+            t = 0.5 / t
+            out[n, :3] = (m[2, 1] - m[1, 2]) * t, (m[0, 2] - m[2, 0]) * t, (m[1, 0] - m[0, 1]) * t
+        else:
+            i = 0
+            if m[1, 1] > m[0, 0]:
+                i = 1
+            if m[2, 2] > m[i, i]:
+                i = 2
+            j, k = (i + 1) % 3, (i + 2) % 3
+            t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0)
+            out[n, i] = 0.5 * t
+            t = 0.5 / t
+            out[n, 3] = (m[k, j] - m[j, k]) * t
+            out[n, j] = (m[j, i] + m[i, j]) * t
+            out[n, k] = (m[k, i] + m[i, k]) * t
+    return out
+
+
+def check_pose(R_ref, twb_ref, t_ref, R_cur, twb_cur, t_cur, step):
+    """EventCalibIni::checkPose (EventCalibIni.cpp:327-347)."""
+    dt = t_cur - t_ref
+    v_t = np.linalg.norm(twb_cur - twb_ref) / dt
+    c = (np.trace(R_cur @ R_ref.T) - 1) * 0.5
+    v_r = abs(np.arccos(min(1.0, max(-1.0, c))) / dt)
+    return v_t < (2.5e-1 / step) * 2 and v_r < (5e-4 * np.pi) * 2 / step
+
+
+def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, frame_event_num_threshold=4000, piece_num=30,
+                     frames_to_use=200, width=346.0, height=260.0, rows=9, cols=4, square=5.5, circle_radius=1.75,
+                     flags=EXAMPLE_FLAGS, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2):
+    """events: uint8 CUDA tensor of packed 25-byte records.  Returns a dict with the initial calibration, the refined
+    intrinsics [fx fy cx cy k1..k5 (inverse radial polynomial)] and the keyframe trajectory."""
+    dev = events.device
+    st = torch.cuda.current_stream(dev).cuda_stream
+    step = motion_time_step
+    n_circ = rows * cols
+    pipe = DetectPipeline(ctx, dev)
+    # -- 1. keyframes
+    kf = detect_keyframes(pipe, events, step, frame_event_num_threshold, piece_num, t_first, t_last, eps, minpts, rows, cols)
+    K = len(kf["time"])
+    out = {"keyframes": K}
+    if K == 0:
+        raise RuntimeError("no keyframe found")
+    # -- 2. init calibration on a subset (EventCalibIni.cpp:163-181), image points narrowed to float like cv::Point2f
+    use = frames_to_use
+    sel_step = K // use
+    if sel_step == 0:
+        use, sel_step = K, 1
+    sel = np.arange(use) * sel_step
+    obj = board_points(rows, cols, square)
+    feat32 = kf["features"][:, :, :2].astype(np.float32).astype(np.float64)
+    ini = capi.calibrate_views(ctx, obj, feat32[sel], width, height, 0, flags, aspect_ratio)
+    intr0 = ini["intr"]
+    out["init"] = {"intr": intr0, "rms": ini["rms"], "iterations": ini["iterations"], "views": use}
+    # solvePnPRansac on every keyframe, one batched launch
+    d_obj = torch.as_tensor(obj, device=dev)
+    d_img = torch.as_tensor(np.ascontiguousarray(feat32), device=dev)
+    d_intr = torch.as_tensor(intr0, device=dev)
+    d_pose = torch.empty(K, 6, dtype=torch.float64, device=dev)
+    d_inl = torch.empty(K, n_circ, dtype=torch.int32, device=dev)
+    d_ok = torch.empty(K, dtype=torch.int32, device=dev)
+    capi.pnp_batch_dev(ctx, d_obj.data_ptr(), n_circ, d_img.data_ptr(), None, K, 0, d_intr.data_ptr(), 4.0, 3, 0, d_pose.data_ptr(),
+                       d_inl.data_ptr(), None, d_ok.data_ptr(), st)
+    pose = d_pose.cpu().numpy()
+    ok = d_ok.cpu().numpy().astype(bool)
+    Rsw = rodrigues(pose[:, :3])
+    tsw = pose[:, 3:]
+    twb = -np.einsum("nji,nj->ni", Rsw, tsw)
+    # rectifyFeatures for all keyframes at once: their windows go through the detection pipeline again
+    pipe.set_windows(kf["duration"][:, 0], kf["duration"][:, 1])
+    pipe.run(events, eps, minpts)
+    prm = capi.RectifyParams()
+    prm.fx, prm.fy, prm.cx, prm.cy = intr0[:4]
+    for i in range(5):
+        prm.dist[i] = intr0[4 + i]                         # k1 k2 p1 p2 k3
+    prm.width, prm.height, prm.rows, prm.cols, prm.asymmetric = width, height, rows, cols, 1
+    prm.circle_radius, prm.fit_circle = circle_radius, int(pipe.det[3])
+    d_frames = torch.arange(K, dtype=torch.int32, device=dev)
+    d_rpose = torch.as_tensor(np.concatenate([Rsw.reshape(K, 9), tsw], axis=1), device=dev)
+    d_feat = torch.empty(K, n_circ, 3, dtype=torch.float64, device=dev)
+    d_valid = torch.empty(K, n_circ, dtype=torch.int32, device=dev)
+    d_info = torch.empty(K, 2, dtype=torch.int32, device=dev)
+    ctx.rectify_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.kept_labels.data_ptr(),
+                          pipe.win_info.data_ptr(), d_frames.data_ptr(), d_rpose.data_ptr(), K, d_obj.data_ptr(), prm,
+                          d_feat.data_ptr(), d_valid.data_ptr(), d_info.data_ptr(), st)
+    rect_ok = d_info[:, 0].cpu().numpy().astype(bool)
+    circles = d_feat.cpu().numpy()
+    # the sequential gates of EventCalibIni.cpp:281-302 (checkPose against the last accepted keyframe, then rectify)
+    acc, last, n_check, n_rect = [], -1, 0, 0
+    for f in range(K):
+        if not ok[f] or (last >= 0 and not check_pose(Rsw[last], twb[last], kf["time"][last], Rsw[f], twb[f], kf["time"][f], step)):
+            n_check += 1
+            continue
+        if not rect_ok[f]:
+            n_rect += 1
+            continue
+        acc.append(f)
+        last = f
+    out["init"].update(accepted=len(acc), discarded_by_check_pose=n_check, discarded_by_rectify=n_rect)
+    acc = np.array(acc, np.int64)
+    if len(acc) <= 10:
+        raise RuntimeError("too few frames in the map.")     # EventCalibSpline.cpp:26-28
+    # -- 3. splines: a gap of more than 50 steps starts a new one; fewer than 4 frames -> dropped (:318-345)
+    times = kf["time"][acc]
+    cuts = np.nonzero(np.diff(times) > 50 * step)[0] + 1
+    segs = [s for s in np.split(np.arange(len(acc)), cuts) if len(s) >= 4]
+    if not segs:
+        raise RuntimeError("sampleSets not filtered")
+    Qwb = quat_from_matrix(np.transpose(Rsw[acc], (0, 2, 1)))
+    seg_cp_off, knots, cq, ct, ranges = [0], [], [], [], []
+    for s in segs:
+        u = times[s].copy()
+        u[0] -= 3 * step
+        u[-1] += 3 * step
+        cp_num = int(np.floor((u[-1] - u[0]) / (50 * step)))
+        if cp_num > len(u):
+            cp_num = len(u) - 1
+        cp_num = max(cp_num, 4)
+        kn, c_t = capi.spline_fit(u, twb[acc][s], cp_num)
+        _, c_q = capi.spline_fit(u, Qwb[s], cp_num)
+        if use_so3:
+            c_q /= np.linalg.norm(c_q, axis=1, keepdims=True)
+        knots.append(kn)
+        cq.append(c_q)
+        ct.append(c_t)
+        seg_cp_off.append(seg_cp_off[-1] + cp_num)
+        ranges.append((u[0], u[-1]))
+    keep = np.concatenate(segs)
+    kf_idx = acc[keep]
+    # association (EventCalibSpline.cpp:140-192): every event against the nearest keyframe's rectified circles
+    n_events = events.numel() // 25
+    d_kt = torch.as_tensor(kf["time"][kf_idx], device=dev)
+    d_kc = torch.as_tensor(np.ascontiguousarray(circles[kf_idx]), device=dev)
+    d_o = torch.empty(n_events, 2, dtype=torch.float64, device=dev)
+    d_t = torch.empty(n_events, dtype=torch.float64, device=dev)
+    d_l = torch.empty(n_events, dtype=torch.int32, device=dev)
+    d_c = torch.zeros(1, dtype=torch.int32, device=dev)
+    obs, tm, lm, sid = [], [], [], []
+    for i, (a, b) in enumerate(ranges):
+        ctx.associate_dev(events.data_ptr(), n_events, d_kt.data_ptr(), d_kc.data_ptr(), len(kf_idx), n_circ, a, b, 5 * step, 5.0,
+                          d_o.data_ptr(), d_t.data_ptr(), d_l.data_ptr(), d_c.data_ptr(), st)
+        m = int(d_c.item())
+        obs.append(d_o[:m].cpu().numpy())
+        tm.append(d_t[:m].cpu().numpy())
+        lm.append(d_l[:m].cpu().numpy())
+        sid.append(np.full(m, i, np.uint32))
+    obs, tm, lm, sid = np.concatenate(obs), np.concatenate(tm), np.concatenate(lm), np.concatenate(sid)
+    # intrinsics: K + the inverse radial polynomial of (k1, k2, k3) (:93-105)
+    b5 = capi.inverse_radial_distortion([intr0[4], intr0[5], intr0[8], 0.0])
+    x0 = np.concatenate([intr0[:4], b5, np.concatenate(cq).ravel(), np.concatenate(ct).ravel()])
+    prob = dict(seg_cp_off=np.array(seg_cp_off, np.uint32), knots=np.concatenate(knots), obs=obs, time=tm, lm_id=lm.astype(np.uint32),
+                seg_id=sid, landmarks=board_points(rows, cols, square).astype(np.float64), circle_radius=circle_radius,
+                huber_a=0.2 * circle_radius, use_so3=bool(use_so3))
+    solver = capi.Solver(ctx, prob)
+    opt = solver.default_options()
+    opt.max_num_iterations = max_num_iterations
+    x, summ = solver.solve(x0, opt)
+    solver.close()
+    out["spline"] = {"splines": len(segs), "control_points": int(seg_cp_off[-1]), "residuals": int(len(tm)),
+                     "iterations": int(summ.iterations), "initial_cost": float(summ.initial_cost),
+                     "final_cost": float(summ.final_cost)}
+    out["intrinsics"] = x[:9].copy()
+    # updateMap (:253-317): keyframe poses re-read from the optimised splines
+    n_cp = seg_cp_off[-1]
+    q_all, t_all = x[9:9 + 4 * n_cp].reshape(n_cp, 4), x[9 + 4 * n_cp:].reshape(n_cp, 3)
+    traj = []
+    for i, s in enumerate(segs):
+        a, b = seg_cp_off[i], seg_cp_off[i + 1]
+        tt = times[s]
+        q = capi.spline_eval(knots[i], q_all[a:b], tt)
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        traj.append(np.concatenate([tt[:, None], capi.spline_eval(knots[i], t_all[a:b], tt), q], axis=1))
+    out["trajectory"] = np.concatenate(traj)                 # timestamp tx ty tz qx qy qz qw (TUM)
+    out["init_trajectory"] = np.concatenate([times[keep][:, None], twb[kf_idx], Qwb[keep]], axis=1)
+    return out
+
+
+def save_trajectory_tum(path, traj):
+    """SystemBase::saveKeyFrameTrajectoryTUM's format: fixed, 10 digits, one keyframe per line."""
+    with open(path, "w") as f:
+        for r in traj:
+            f.write(" ".join("%.10f" % v for v in r) + "\n")

@@ -14,12 +14,12 @@ EXPORTED_SYMBOLS = [
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
-    "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_detect_batch", "ecal_copy_dev",
-    "ecal_grid_order_dev", "ecal_associate_dev", "ecal_rectify_batch_dev", "ecal_rectify_batch",
+    "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
+    "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
-    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views",
+    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval",
 ]
 
 
@@ -466,3 +466,29 @@ def pnp_batch_dev(ctx: Context, d_obj, n_pts, d_img, d_valid, n_frames, model, d
     _declare_calib(ctx._L)
     ctx._check(ctx._L.ecal_pnp_batch_dev(ctx._h, d_obj, n_pts, d_img, d_valid, n_frames, model, d_intr, float(reproj_thresh),
                                          int(rounds), int(refine_iters), d_pose, d_inlier, d_err, d_ok, stream))
+
+
+def spline_fit(u, data, n_cp):
+    """ecal_spline_fit: returns (knots [n_cp + 4], control points [n_cp][dim])."""
+    L = load_library()
+    u = np.ascontiguousarray(u, np.float64)
+    data = np.ascontiguousarray(data, np.float64).reshape(len(u), -1)
+    knots, cp = np.zeros(n_cp + 4), np.zeros((n_cp, data.shape[1]))
+    L.ecal_spline_fit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                  ctypes.c_void_p, ctypes.c_void_p]
+    st = L.ecal_spline_fit(_ptr(u), _ptr(data), len(u), data.shape[1], n_cp, _ptr(knots), _ptr(cp))
+    if st != 0:
+        raise EcalError(st, L.ecal_strerror(st).decode())
+    return knots, cp
+
+
+def spline_eval(knots, cp, u):
+    L = load_library()
+    knots, cp, u = (np.ascontiguousarray(a, np.float64) for a in (knots, cp, u))
+    out = np.zeros((len(u), cp.shape[1]))
+    L.ecal_spline_eval.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p,
+                                   ctypes.c_uint32, ctypes.c_void_p]
+    st = L.ecal_spline_eval(_ptr(knots), _ptr(cp), cp.shape[0], cp.shape[1], _ptr(u), len(u), _ptr(out))
+    if st != 0:
+        raise EcalError(st, L.ecal_strerror(st).decode())
+    return out

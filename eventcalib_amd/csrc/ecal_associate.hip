@@ -180,3 +180,44 @@ extern "C" int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
+
+// host-buffer form (what host/event_calib_spline.hpp calls): the event stream stays in HBM (ecal_stream), the
+// keyframe tables go up, the accepted records come back.  obs / time / lm_id need room for `capacity` records;
+// *count is the number found (ECAL_ERR_RANGE and nothing copied if it exceeds capacity).
+extern "C" int ecal_associate(ecal_ctx *ctx, const ecal_stream *es, const double *kf_time, const double *kf_circles,
+                              uint32_t n_keyframes, uint32_t n_circles, double t_min, double t_max, double max_dt, double edge_tol,
+                              uint64_t capacity, double *obs, double *time, uint32_t *lm_id, uint64_t *count) {
+    if (!ctx || !es || !count) return ECAL_ERR_INVALID;
+    const uint64_t n = ecal_stream_size(es);
+    *count = 0;
+    if (n == 0 || n_keyframes == 0) return ECAL_OK;
+    if (!kf_time || !kf_circles) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t kb = (size_t) n_keyframes * 8, cb = (size_t) n_keyframes * n_circles * 24;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_kt = 0, o_kc = up(kb), o_obs = o_kc + up(cb), o_tm = o_obs + up(n * 16), o_lm = o_tm + up(n * 8),
+                 o_cnt = o_lm + up(n * 4), total = o_cnt + 256;
+    int rc = ecal_ensure(ctx, ctx->as_host, total);
+    if (rc) return rc;
+    char *base = (char *) ctx->as_host.ptr;
+    hipStream_t st = ctx->stream;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_kt, kf_time, kb, hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_kc, kf_circles, cb, hipMemcpyHostToDevice, st));
+    rc = ecal_associate_dev(ctx, ecal_stream_data(es), n, (const double *) (base + o_kt), (const double *) (base + o_kc), n_keyframes,
+                            n_circles, t_min, t_max, max_dt, edge_tol, (double *) (base + o_obs), (double *) (base + o_tm),
+                            (uint32_t *) (base + o_lm), (uint32_t *) (base + o_cnt), st);
+    if (rc) return rc;
+    uint32_t cnt = 0;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(&cnt, base + o_cnt, 4, hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    *count = cnt;
+    if (cnt > capacity) return ECAL_ERR_RANGE;
+    if (cnt) {
+        if (!obs || !time || !lm_id) return ECAL_ERR_INVALID;
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(obs, base + o_obs, (size_t) cnt * 16, hipMemcpyDeviceToHost, st));
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(time, base + o_tm, (size_t) cnt * 8, hipMemcpyDeviceToHost, st));
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(lm_id, base + o_lm, (size_t) cnt * 4, hipMemcpyDeviceToHost, st));
+        ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    }
+    return ECAL_OK;
+}

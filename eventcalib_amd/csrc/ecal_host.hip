@@ -9,6 +9,8 @@ struct ecal_stream {
     uint64_t n_events;
 };
 
+extern "C" const uint8_t *ecal_stream_data(const ecal_stream *s) { return s ? s->d_events : nullptr; }
+
 extern "C" int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t n_events, ecal_stream **out) {
     if (!ctx || !out || (n_events && !events)) return ECAL_ERR_INVALID;
     *out = nullptr;

@@ -183,6 +183,8 @@ typedef struct ecal_detect_result {
 int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t n_events, ecal_stream **out);
 void ecal_stream_destroy(ecal_stream *s);
 uint64_t ecal_stream_size(const ecal_stream *s);
+/* DEVICE pointer of the packed records (what the _dev entry points take as d_events) */
+const uint8_t *ecal_stream_data(const ecal_stream *s);
 /* device-to-device copy on `stream` (optionally followed by a stream synchronise) */
 int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream, int sync);
 int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const double *t0, const double *t1, uint32_t S,
@@ -251,6 +253,12 @@ int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events
                        const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, double t_min, double t_max,
                        double max_dt, double edge_tol, double *d_obs, double *d_time, uint32_t *d_lm_id,
                        uint32_t *d_count, void *stream);
+
+/* host-buffer form: events from an ecal_stream (resident in HBM), keyframe tables and results in host memory;
+ * obs/time/lm_id need room for `capacity` records, *count = records found (ECAL_ERR_RANGE if more than capacity) */
+int ecal_associate(ecal_ctx *ctx, const ecal_stream *es, const double *kf_time, const double *kf_circles, uint32_t n_keyframes,
+                   uint32_t n_circles, double t_min, double t_max, double max_dt, double edge_tol, uint64_t capacity, double *obs,
+                   double *time, uint32_t *lm_id, uint64_t *count);
 
 /* ---- continuous-time calibration solve ---------------------------------------------------------
  * Replaces the Ceres problem of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
@@ -395,6 +403,23 @@ int ecal_pnp_batch(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const doubl
 int ecal_calibrate_views(ecal_ctx *ctx, const double *obj /*[n_pts][3]*/, uint32_t n_pts, const double *img /*[V][n_pts][2]*/,
                          uint32_t n_views, double width, double height, const ecal_calib_options *opt, ecal_calib_result *res,
                          double *rvecs /*[V][3] or NULL*/, double *tvecs /*[V][3] or NULL*/, double *per_view_err /*[V] or NULL*/);
+
+/* ---- initial spline fit + evaluation (host; no GPU involved) -------------------------------------------
+ * ecal_spline_fit: BsplineReal<dim>(3, Q, controlPointsNum, u) (core/spline/include/opengv2/spline/
+ *   BsplineReal.hpp:17-100,329-449) as EventCalibSpline builds twbSplines_ / QwbSplines_ from the keyframe poses
+ *   (event_camera_calib/src/EventCalibSpline.cpp:61-91), and BsplineSO3's knotSpacing + initialGuess
+ *   (core/spline/src/BsplineSO3.cpp:60-72,198-279; its Ceres refinement optimizeCP is not restated — the
+ *   calibration solve refines the same control points).  u [m] ascending sample parameters (timestamps, first and
+ *   last already widened by 3 steps as :63-66), data [m][dim]; outputs the clamped knot vector [n_cp + 4]
+ *   (NURBS book 9.68) — the layout ecal_spline_problem.knots takes — and the control points [n_cp][dim]: first and
+ *   last interpolate, the interior ones minimise the squared distance at the interior samples.
+ *   ECAL_ERR_INVALID if n_cp < 4, m < 2 or a control point has no supporting sample.
+ * ecal_spline_eval: BsplineReal::evaluate(u, 0, ..) (:454-470) at m parameters (updateMap, EventCalibSpline.cpp:
+ *   253-317); ECAL_ERR_RANGE outside the knot range. */
+int ecal_spline_fit(const double *u, const double *data, uint32_t m, uint32_t dim, uint32_t n_cp, double *knots /*[n_cp+4]*/,
+                    double *cp /*[n_cp][dim]*/);
+int ecal_spline_eval(const double *knots, const double *cp, uint32_t n_cp, uint32_t dim, const double *u, uint32_t m,
+                     double *out /*[m][dim]*/);
 
 #ifdef __cplusplus
 }

@@ -34,8 +34,34 @@ def landmarks(device="cpu"):
     return torch.tensor(pts, dtype=torch.float64, device=device)
 
 
+TRAJECTORY = "hover"   # "hover": the benchmark stream (near fronto-parallel); "orbit": tilted views (see pose_orbit)
+
+
+def _rot(axis, a):
+    c, s, z, o = torch.cos(a), torch.sin(a), torch.zeros_like(a), torch.ones_like(a)
+    rows = {0: [o, z, z, z, c, -s, z, s, c], 1: [c, z, s, z, o, z, -s, z, c], 2: [c, -s, z, s, c, z, z, z, o]}[axis]
+    return torch.stack(rows, dim=1).reshape(-1, 3, 3)
+
+
+def pose_orbit(t):
+    """Calibration-style motion: the camera orbits the board centre with its optical axis on it, tilting up to
+    ~25 degrees about both board axes (a fronto-parallel sequence leaves the focal length unobservable for
+    calibrateCamera), distance 72 +- 5 cm, |omega| ~ 1 rad/s, |v| ~ 80 cm/s (inside the reference's keyframe and
+    checkPose gates, EventCalibIni.cpp:82,342-343)."""
+    ax = 0.40 * torch.sin(2 * math.pi * 0.43 * t + 0.3) + 0.06 * torch.sin(2 * math.pi * 1.3 * t)
+    ay = 0.35 * torch.sin(2 * math.pi * 0.31 * t + 1.7) + 0.06 * torch.sin(2 * math.pi * 1.1 * t + 0.5)
+    az = 0.5 * math.pi + 0.10 * torch.sin(2 * math.pi * 0.23 * t + 2.1)
+    R = _rot(0, ax) @ _rot(1, ay) @ _rot(2, az)
+    dist = 72.0 + 5.0 * torch.sin(2 * math.pi * 0.19 * t + 0.7)
+    B = torch.tensor([3.5 * SQUARE, 4.0 * SQUARE, 0.0], dtype=t.dtype, device=t.device)
+    C = B[None, :] - dist[:, None] * R[:, :, 2]
+    return R, C
+
+
 def pose(t):
     """Camera-to-world rotation R_wc [n,3,3] and camera centre C [n,3] (cm) at times t [n] (s)."""
+    if TRAJECTORY == "orbit":
+        return pose_orbit(t)
     # centre: hovering ~65 cm in front of the board (board plane z = 0, camera on the -z side)
     bx, by = 3.5 * SQUARE, 4.0 * SQUARE
     C = torch.stack([

@@ -1,0 +1,66 @@
+"""GPU: the reference driver end to end on one synthetic .bin stream with tilted views — adaptive keyframe search ->
+init calibration (calibrateCamera's role) -> PnP / checkPose / rectifyFeatures -> spline initialisation -> event
+association -> continuous-time solve -> intrinsics + trajectory (eventCameraCalib.cpp:99-233).  Ground truth is the
+generating camera and motion; tolerances are stated per assertion (events are floored to integer pixels, so the
+principal point comes back ~0.5 px low, as it would for the reference)."""
+import numpy as np
+import pytest
+
+import synth_stream as SS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def result():
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.calibrate import calibrate_stream
+    SS.TRAJECTORY = "orbit"
+    try:
+        n = 3_000_000
+        buf = SS.make_stream(n, rate=1.0e6, t_start=5.0, device="cuda", seed=21)
+        ctx = eventcalib_amd.Context(0)
+        out = {so3: calibrate_stream(ctx, buf, 5.0, 5.0 + (n - 1) / 1e6, use_so3=so3) for so3 in (False, True)}
+        t = torch.tensor(out[False]["trajectory"][:, 0])
+        R, C = SS.pose(t)
+        out["gt_C"], out["gt_R"] = C.numpy(), R.numpy()
+        ctx.close()
+        return out
+    finally:
+        SS.TRAJECTORY = "hover"
+
+
+def test_init_calibration_from_detected_keyframes(result):
+    ini = result[False]["init"]
+    assert result[False]["keyframes"] > 300 and ini["views"] == 200
+    assert abs(ini["intr"][0] / SS.FX - 1) < 5e-3 and ini["intr"][0] == ini["intr"][1]        # fixed aspect ratio
+    assert (ini["intr"][2], ini["intr"][3]) == ((346 - 1) / 2, (260 - 1) / 2)                  # fixed principal point
+    assert abs(ini["intr"][4] - SS.K1) < 0.05 and ini["rms"] < 5.0                             # midpoint circles: ~3 px
+    assert ini["accepted"] > 200 and ini["discarded_by_rectify"] < 20
+
+
+@pytest.mark.parametrize("so3", [False, True])
+def test_refined_intrinsics_and_trajectory(result, so3):
+    r = result[so3]
+    fx, fy, cx, cy = r["intrinsics"][:4]
+    assert abs(fx / SS.FX - 1) < 2e-3 and abs(fy / SS.FY - 1) < 2e-3
+    assert abs(cx - (SS.CX - 0.5)) < 0.3 and abs(cy - (SS.CY - 0.5)) < 0.3
+    assert r["spline"]["final_cost"] < r["spline"]["initial_cost"] and r["spline"]["residuals"] > 1_000_000
+    # trajectory: camera centres within 3 mm of the generating motion (the PnP initialisation is centimetres off)
+    tr, ini = r["trajectory"], r["init_trajectory"]
+    assert np.abs(tr[:, 1:4] - result["gt_C"]).max() < 0.3
+    assert np.abs(ini[:, 1:4] - result["gt_C"]).max() > 1.0
+    # orientation: |q . q_gt| ~ 1
+    from scipy.spatial.transform import Rotation
+    qg = Rotation.from_matrix(result["gt_R"]).as_quat()
+    assert (1 - np.abs((tr[:, 4:8] * qg).sum(1))).max() < 1e-5
+
+
+def test_tum_writer_roundtrip(result, tmp_path):
+    from eventcalib_amd.calibrate import save_trajectory_tum
+    p = str(tmp_path / "TrajectoryByEvent.txt")
+    save_trajectory_tum(p, result[False]["trajectory"])
+    back = np.loadtxt(p)
+    assert back.shape == result[False]["trajectory"].shape and np.abs(back - result[False]["trajectory"]).max() < 1e-9
+    assert len(open(p).readline().split()) == 8 and len(open(p).readline().split()[0].split(".")[1]) == 10

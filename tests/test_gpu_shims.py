@@ -49,7 +49,6 @@ def test_cpp_event_calib_ini(tmp_path, fisheye):
     checkPose and the rectify hook, on synthetic keyframes with known camera and poses."""
     import numpy as np
     import synth_calib as SC
-    import calib_oracle as CO
     exe = str(tmp_path / "test_calib_shim")
     lib_dir = os.path.join(ROOT, "eventcalib_amd")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_calib_shim.cpp"),
@@ -73,4 +72,41 @@ def test_cpp_event_calib_ini(tmp_path, fisheye):
     n_check, n_rect, n_acc = int(head[9]), int(head[11]), int(head[7])
     assert n_check == 1 and n_rect == (V - 1) // 7 and n_acc == V - n_check - n_rect
     p0 = [float(x) for x in lines[3].split()[1:]]
-    assert np.abs(np.array(p0[:3]) - tv[0]).max() < 5e-3 and abs(p0[3] - CO.rodrigues(rv[0])[0, 0]) < 1e-4
+    assert np.abs(np.array(p0[:3]) - tv[0]).max() < 5e-3 and abs(p0[3] - SC.rodrigues(rv[0])[0, 0]) < 1e-4
+
+
+def test_cpp_driver_chain(tmp_path):
+    """The whole reference driver on the C++ shims (keyframes -> cvCalibration + rectify -> EventCalibSpline -> TUM file)
+    agrees with the Python mirror (eventcalib_amd/calibrate.py) on the same .bin file and recovers the camera."""
+    import numpy as np
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.calibrate import calibrate_stream
+    exe = str(tmp_path / "test_calib_chain")
+    lib_dir = os.path.join(ROOT, "eventcalib_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_calib_chain.cpp"),
+                           "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"])
+    SS.TRAJECTORY = "orbit"
+    try:
+        n = 2_000_000
+        buf = SS.make_stream(n, rate=1.0e6, t_start=5.0, device="cpu", seed=21)
+    finally:
+        SS.TRAJECTORY = "hover"
+    binf = str(tmp_path / "events.bin")
+    buf.numpy().tofile(binf)
+    out = subprocess.run([exe, binf, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.splitlines()
+    init = lines[1].split()
+    ref = [float(v) for v in lines[2].split()[1:10]]
+    ctx = eventcalib_amd.Context(0)
+    py = calibrate_stream(ctx, buf.cuda(), 5.0, 5.0 + (n - 1) / 1e6)
+    ctx.close()
+    assert int(lines[0].split()[1]) == py["keyframes"]
+    assert abs(float(init[2]) - py["init"]["intr"][0]) < 1e-6 * py["init"]["intr"][0]           # same init calibration
+    assert int(init[9]) == py["init"]["accepted"]
+    assert np.abs(np.array(ref[:4]) - py["intrinsics"][:4]).max() < 1e-3                         # same refined camera
+    assert abs(ref[0] / SS.FX - 1) < 2e-3 and abs(ref[2] - (SS.CX - 0.5)) < 0.3
+    traj = np.loadtxt(str(tmp_path / "TrajectoryByEvent.txt"))
+    assert traj.shape[1] == 8 and len(traj) == len(py["trajectory"])
+    assert np.abs(traj - py["trajectory"]).max() < 1e-3
