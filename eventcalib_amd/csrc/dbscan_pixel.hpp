@@ -51,22 +51,26 @@ struct PixelLayout {
     static constexpr size_t bytes = red_off + 4 * 48;
 };
 
+// child-slot word: pid << 22 | x' << 11 | y'  (x', y' = bitmap coordinates < 2048).  ds_min_u32 orders the bids by
+// pid, and the winner's coordinates come back with its id: one dependent LDS read per tree level instead of two.
+__device__ __forceinline__ uint32_t px_word(uint32_t pid, uint32_t cx, uint32_t cy) { return (pid << 22) | (cx << 11) | cy; }
+__device__ __forceinline__ uint32_t px_wx(uint32_t w) { return (w >> 11) & 0x7FFu; }
+__device__ __forceinline__ uint32_t px_wy(uint32_t w) { return w & 0x7FFu; }
+
 // one tree level for one unplaced point (register state); returns true while unplaced
-__device__ __forceinline__ bool px_level_step(const uint32_t *P, uint32_t *slot, uint32_t i, uint32_t self,
-                                              uint32_t &st, uint32_t &f) {
+__device__ __forceinline__ bool px_level_step(uint32_t *slot, uint32_t i, uint32_t self, uint32_t &st, uint32_t &f) {
     using R = IdxBits<uint32_t>;
-    using G = GeoI16;
-    const uint32_t child = slot[2 * (st & R::MASK) + ((st & R::SIDE) ? 1u : 0u)];
+    const uint32_t cw = slot[2 * (st & R::MASK) + ((st & R::SIDE) ? 1u : 0u)];
+    const uint32_t child = cw >> 22;
     if (child == i) {
         st = R::PLACED;
         return false;
     }
-    const uint32_t pc = P[child];
     const uint32_t nd = (st & R::DIR) ? 0u : 1u;
-    const int sv = nd ? G::sy(self) : G::sx(self), cv = nd ? G::sy(pc) : G::sx(pc);
+    const uint32_t sv = nd ? px_wy(self) : px_wx(self), cv = nd ? px_wy(cw) : px_wx(cw);
     const uint32_t ns = sv < cv ? 0u : 1u;  // kdtree.cpp:128-131: left iff strictly smaller
     f |= (sv == cv) ? (1u << nd) : 0u;      // `child` becomes an ancestor splitting on nd at my coordinate
-    atomicMin(&slot[2 * child + ns], i);
+    atomicMin(&slot[2 * child + ns], self);
     st = child | (nd ? R::DIR : 0u) | (ns ? R::SIDE : 0u);
     return true;
 }
@@ -93,7 +97,6 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
         return;
     }
-    uint32_t *const P = reinterpret_cast<uint32_t *>(px_smem + L::p_off);
     uint16_t *const pid_s = reinterpret_cast<uint16_t *>(px_smem + L::pid_off);
     uint8_t *const sflags = reinterpret_cast<uint8_t *>(px_smem + L::sflags_off);
     uint32_t *const edges = reinterpret_cast<uint32_t *>(px_smem + L::edges_off);
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     uint8_t *const wpre = reinterpret_cast<uint8_t *>(px_smem + L::wpre_off);
     uint32_t *const red = reinterpret_cast<uint32_t *>(px_smem + L::red_off);
     uint32_t *const n_edges = red + 36;
+    uint32_t *const rootw = red + 37;
     uint32_t *const anyf = red + 40;
     int *const bbox = reinterpret_cast<int *>(red + 44);  // min x, min y, -max x, -max y
     uint32_t any_round = 0;
@@ -137,7 +141,6 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                 const double2 v = src[i];
                 fits = fits && G::fits(v);
                 pp[u] = G::pack(v);
-                P[i] = pp[u];
                 slot[2 * i] = NONE32;
                 slot[2 * i + 1] = NONE32;
                 const int x = G::sx(pp[u]), y = G::sy(pp[u]);
@@ -173,7 +176,15 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     // 64-bit window fetches may read the first word of the next row (or the spare word after the last row):
     // those bits are always masked off
     const uint32_t RW = (W + 31u) >> 5;
-    if (H > PX_ROWS || (uint64_t) H * RW > PX_WORDS) PX_BAIL();
+    if (H > PX_ROWS || (uint64_t) H * RW > PX_WORDS || W > 2047u) PX_BAIL();
+    uint32_t mcx[PPT], myy[PPT], me[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+        mcx[u] = (uint32_t) (G::sx(pp[u]) - ox);
+        myy[u] = (uint32_t) (G::sy(pp[u]) - oy);
+        me[u] = px_word(tid + u * T, mcx[u] & 0x7FFu, myy[u] & 0x7FFu);
+    }
+    if (tid == 0) *rootw = me[0];
 
     // ---------------- B: kd_insert replay -> prune bits ----------------
     uint32_t st[PPT], f[PPT];
@@ -182,22 +193,23 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         st[u] = R::PLACED;
         f[u] = 0;
     }
-    const int x0 = G::sx(P[0]);
     // B.0: wave 0 alone replays the first KTOP insertions (wave-synchronous, no block barrier)
     if (tid < KTOP) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t x0 = px_wx(*rootw);
         const uint32_t i = tid;
         if (i > 0 && i < n) {
-            const int x = G::sx(pp[0]);
-            const uint32_t side = (x < x0) ? 0u : 1u;
-            f[0] |= (x == x0) ? 1u : 0u;
-            atomicMin(&slot[side], i);
+            const uint32_t side = (mcx[0] < x0) ? 0u : 1u;
+            f[0] |= (mcx[0] == x0) ? 1u : 0u;
+            atomicMin(&slot[side], me[0]);
             st[0] = side ? R::SIDE : 0u;
         }
         for (;;) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bool act = false;
-            if (!(st[0] & R::PLACED)) act = px_level_step(P, slot, i, pp[0], st[0], f[0]);
+            if (!(st[0] & R::PLACED)) act = px_level_step(slot, i, me[0], st[0], f[0]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (!__any(act)) break;
@@ -208,6 +220,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     // B.1: every later point walks the finished top tree (reads only); the walks of a thread's points advance
     // together so their LDS round trips overlap
     {
+        const uint32_t x0 = px_wx(*rootw);
         uint32_t a[PPT], d[PPT], side[PPT];
         bool go[PPT];
 #pragma unroll
@@ -216,30 +229,26 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             go[u] = i < n && i >= KTOP;
             a[u] = 0;
             d[u] = 0;
-            const int x = G::sx(pp[u]);
-            side[u] = (x < x0) ? 0u : 1u;
-            if (go[u]) f[u] |= (x == x0) ? 1u : 0u;
+            side[u] = (mcx[u] < x0) ? 0u : 1u;
+            if (go[u]) f[u] |= (mcx[u] == x0) ? 1u : 0u;
         }
         for (;;) {
-            uint32_t child[PPT];
+            uint32_t cw[PPT];
             bool any = false;
 #pragma unroll
-            for (int u = 0; u < PPT; u++) child[u] = slot[go[u] ? 2 * a[u] + side[u] : 0u];
+            for (int u = 0; u < PPT; u++) cw[u] = slot[go[u] ? 2 * a[u] + side[u] : 0u];
 #pragma unroll
             for (int u = 0; u < PPT; u++) {
-                go[u] = go[u] && child[u] != NONE32;
+                go[u] = go[u] && cw[u] != NONE32;
                 any = any || go[u];
             }
             if (!any) break;
-            uint32_t pc[PPT];
-#pragma unroll
-            for (int u = 0; u < PPT; u++) pc[u] = P[go[u] ? child[u] : 0u];
 #pragma unroll
             for (int u = 0; u < PPT; u++) {
                 if (go[u]) {
-                    a[u] = child[u];
+                    a[u] = cw[u] >> 22;
                     d[u] ^= 1u;
-                    const int sv = d[u] ? G::sy(pp[u]) : G::sx(pp[u]), cv = d[u] ? G::sy(pc[u]) : G::sx(pc[u]);
+                    const uint32_t sv = d[u] ? myy[u] : mcx[u], cv = d[u] ? px_wy(cw[u]) : px_wx(cw[u]);
                     side[u] = sv < cv ? 0u : 1u;
                     f[u] |= (sv == cv) ? (1u << d[u]) : 0u;
                 }
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         const uint32_t i = tid + u * T;
-        if (i < n && i >= KTOP) atomicMin(&slot[2 * (st[u] & R::MASK) + ((st[u] & R::SIDE) ? 1u : 0u)], i);
+        if (i < n && i >= KTOP) atomicMin(&slot[2 * (st[u] & R::MASK) + ((st[u] & R::SIDE) ? 1u : 0u)], me[u]);
     }
     __syncthreads();
     ECAL_PHASE_MARK(13);
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         bool active = false;
 #pragma unroll
         for (int u = 0; u < PPT; u++)
-            if (!(st[u] & R::PLACED)) active |= px_level_step(P, slot, tid + u * T, pp[u], st[u], f[u]);
+            if (!(st[u] & R::PLACED)) active |= px_level_step(slot, tid + u * T, me[u], st[u], f[u]);
 #ifdef ECAL_PHASE_PROF
         levels__++;
 #endif
@@ -285,12 +294,9 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     }
     __syncthreads();
     bool bad = false;
-    uint32_t mcx[PPT], myy[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         const uint32_t i = tid + u * T;
-        mcx[u] = (uint32_t) (G::sx(pp[u]) - ox);
-        myy[u] = (uint32_t) (G::sy(pp[u]) - oy);
         if (i < n) {
             const uint32_t bit = 1u << (mcx[u] & 31u);
             if (atomicOr(&bm[myy[u] * RW + (mcx[u] >> 5)], bit) & bit) bad = true;  // duplicate pixel: not representable
@@ -369,12 +375,11 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             }
             core[u] = cnt >= minpts;
             parent[i] = core[u] ? i : NONE32;
+            // the core bit joins the flag byte right away: concurrent readers of this phase only look at bits 0-1,
+            // which are the same in the old and the new byte
+            if (core[u]) sflags[myrk[u]] = (uint8_t) (f[u] | 16u);
         }
     }
-    __syncthreads();  // all filter bits were read: the core bit may join them
-#pragma unroll
-    for (int u = 0; u < PPT; u++)
-        if (core[u]) sflags[myrk[u]] = (uint8_t) (f[u] | 16u);
     __syncthreads();
     ECAL_PHASE_MARK(2);
     // ---------------- E.1: union-find over the half disc (rows above, own row to the left) ----------------
@@ -399,6 +404,11 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             }
         }
         uint32_t ri = i;  // current root of i's component
+        // Chain rule: within one row of the disc, a core neighbour at most R to the right of the previous core
+        // neighbour (and not at exactly eps from it, where the quirk may cut the edge) is already joined to it by
+        // its own scan of its row, so joining i with the first of such a run joins i with all of it.
+        int prev_dy = 1;
+        uint32_t prev_x = 0;
         auto link = [&](int dy, uint32_t b) {
             const uint32_t w = hw[dy + Rd];
             const uint32_t nx = cx - w + b, ny = yy + dy;
@@ -416,6 +426,13 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                     edges[2 * at + 1] = pj;
                 }
                 return;
+            }
+            {
+                const uint32_t dx = nx - prev_x;
+                const bool chained = dy == prev_dy && dx <= (uint32_t) Rd && !(eps_int && dx == (uint32_t) geo.epsi);
+                prev_dy = dy;
+                prev_x = nx;
+                if (chained) return;
             }
             uint32_t rj = uf_find<false>(parent, pj);
             for (;;) {

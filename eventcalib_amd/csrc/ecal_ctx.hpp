@@ -35,6 +35,7 @@ struct ecal_ctx {
     ecal_devbuf host_rect[11];  // staging of ecal_rectify_batch
     ecal_devbuf calib_scratch;  // ecal_calibrate_views: views, blocks, reduced records
     double *calib_pinned = nullptr;  // pinned host landing zone of the reduced record
+    uint32_t n_cu = 256;  // compute units of the device (grid size of the persistent kernels)
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,

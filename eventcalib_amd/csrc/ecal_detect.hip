@@ -16,10 +16,27 @@
 
 namespace ecal {
 
+#ifdef ECAL_PHASE_PROF
+__device__ unsigned long long g_det_cycles[16];
+#define DET_MARK(idx)                                                                    \
+    do {                                                                                 \
+        if (threadIdx.x == 0) {                                                          \
+            const unsigned long long now__ = __builtin_readcyclecounter();               \
+            atomicAdd(&g_det_cycles[idx], now__ - det_t__);                              \
+            det_t__ = now__;                                                             \
+        }                                                                                \
+    } while (0)
+#define DET_T0() unsigned long long det_t__ = __builtin_readcyclecounter()
+#else
+#define DET_MARK(idx) do { } while (0)
+#define DET_T0() do { } while (0)
+#endif
+
 constexpr int DET_T = 256;
 constexpr uint32_t DET_MAXC = 2048;       // DBSCAN clusters per polarity the kernel handles at all
-constexpr uint32_t DET_LDS_PTS = 1408;    // points per window (both polarities) staged in LDS (3 workgroups/CU) ...
-constexpr uint32_t DET_LDS_MAXC = 1024;   // ... when neither polarity has more DBSCAN clusters than this
+constexpr uint32_t DET_LDS_PTS = 1408;    // points per window (both polarities) staged in LDS, packed to 4 bytes (5 workgroups/CU) ...
+constexpr uint32_t DET_LDS_MAXC = 512;    // ... when neither polarity has more DBSCAN clusters than this and every
+                                          // coordinate is an integer of |v| <= 32767 (event pixels)
 
 struct DetectParams {
     uint32_t cluster_min;    // clusterMinSample
@@ -42,14 +59,25 @@ struct DetGlobal {
     double *norms;
     __device__ __forceinline__ double2 pt(uint32_t li) const { return pts[li]; }
     __device__ __forceinline__ double norm(uint32_t li) const { return norms[li]; }
+    __device__ __forceinline__ double key(uint32_t li) const { return norms[li]; }  // ordering key of the median
     __device__ __forceinline__ void set_norm(uint32_t li, double v) const { norms[li] = v; }
 };
 struct DetLds {
-    double2 *pts;
+    uint32_t *pts;  // x | y << 16, two's complement int16 each (exact: the staged path is taken for integer pixels only)
     uint16_t *members, *sorted, *koff, *ksize, *rep;
     int16_t *kept;
-    __device__ __forceinline__ double2 pt(uint32_t li) const { return pts[li]; }
-    __device__ __forceinline__ double norm(uint32_t li) const { return norm_of(pts[li]); }
+    __device__ __forceinline__ double2 pt(uint32_t li) const {
+        const uint32_t w = pts[li];
+        return make_double2((double) (int) (short) (w & 0xFFFFu), (double) (((int) w) >> 16));
+    }
+    __device__ __forceinline__ double norm(uint32_t li) const { return norm_of(pt(li)); }
+    // ordering key of the median: for integer pixels x^2 + y^2 (< 2^31, exact) orders exactly like Vector2d::norm() —
+    // sqrt is monotone and two different integers below 2^53 never round to the same double root
+    __device__ __forceinline__ uint32_t key(uint32_t li) const {
+        const uint32_t w = pts[li];
+        const int x = (int) (short) (w & 0xFFFFu), y = ((int) w) >> 16;
+        return (uint32_t) (x * x + y * y);
+    }
     __device__ __forceinline__ void set_norm(uint32_t, double) const {}
 };
 
@@ -180,6 +208,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                                                unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
                                                uint32_t *cand_pair, double *cand_xyr) {
     const uint32_t tid = threadIdx.x;
+    DET_T0();
     for (int pol = 0; pol < 2; pol++) {
         const uint32_t o = base[pol], n = n_pol[pol], nc = nc_pol[pol];
         const int32_t *lab = pol ? lab1 : lab0;
@@ -231,6 +260,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         }
         __syncthreads();
     }
+    DET_MARK(1);
     const uint32_t nk[2] = {nk_sh[0], nk_sh[1]};
     if (nk[0] < prm.need_clusters || nk[1] < prm.need_clusters) {  // :127-129
         if (tid == 0) {
@@ -250,11 +280,11 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
             const int32_t kl = st.kept[o + i];
             if (kl < 0) continue;
             const uint32_t m = st.ksize[o + kl], first = o + st.koff[o + kl];
-            const double ni = st.norm(o + i);
+            const auto ni = st.key(o + i);
             uint32_t rank = 0, at = 0;
             for (uint32_t t = 0; t < m; t++) {
                 const uint32_t j = st.members[first + t];
-                const double nj = st.norm(o + j);
+                const auto nj = st.key(o + j);
                 rank += (nj < ni || (nj == ni && j < i)) ? 1u : 0u;
                 at += (j < i) ? 1u : 0u;
             }
@@ -263,7 +293,10 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         }
     }
     __syncthreads();
+    DET_MARK(2);
     // mutual nearest +/- representatives and the circle test (:283-311); candidates in + cluster order
+    // (Dealing the ~40 + clusters of a window round-robin over the four waves was tried: 0.93 -> 1.06 ms.  The kernel
+    // is issue bound, and four waves with 10 active lanes issue four times the instructions of one wave with 40.)
     uint32_t carry = 0;
     for (uint32_t p0 = 0; p0 < nk[0]; p0 += DET_T) {
         const uint32_t pi = p0 + tid;
@@ -367,6 +400,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         }
         carry += tot;
     }
+    DET_MARK(3);
     if (tid == 0) {
         info[0] = carry;
         info[1] = nk[0];
@@ -411,8 +445,20 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     // or if the window is too large, work in global scratch
     const bool contiguous = o_pol[1] == o_pol[0] + n_pol[0];
     const uint32_t n_all = n_pol[0] + n_pol[1];
-    const bool staged = contiguous && n_all <= DET_LDS_PTS && nc_pol[0] <= DET_LDS_MAXC && nc_pol[1] <= DET_LDS_MAXC;
+    bool staged = contiguous && n_all <= DET_LDS_PTS && nc_pol[0] <= DET_LDS_MAXC && nc_pol[1] <= DET_LDS_MAXC;
     uint32_t *csize = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *const lds_pts = reinterpret_cast<uint32_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t) + 6 * DET_LDS_PTS * sizeof(uint16_t));
+    DET_T0();
+    if (staged) {  // stage the points packed; a coordinate that does not pack exactly sends the window to the global path
+        bool fits = true;
+        for (uint32_t i = tid; i < n_all; i += DET_T) {
+            const double2 v = pts[o_pol[0] + i];
+            fits = fits && v.x == floor(v.x) && v.y == floor(v.y) && fabs(v.x) <= 32767.0 && fabs(v.y) <= 32767.0;
+            lds_pts[i] = ((uint32_t) (int) v.x & 0xFFFFu) | ((uint32_t) (int) v.y << 16);
+        }
+        staged = !__syncthreads_or(!fits);
+        DET_MARK(0);
+    }
     if (staged) {
         uint16_t *u16 = reinterpret_cast<uint16_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t));
         DetLds st;
@@ -422,18 +468,25 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         st.ksize = u16 + 3 * DET_LDS_PTS;
         st.rep = u16 + 4 * DET_LDS_PTS;
         st.kept = reinterpret_cast<int16_t *>(u16 + 5 * DET_LDS_PTS);
-        st.pts = reinterpret_cast<double2 *>(u16 + 6 * DET_LDS_PTS);
-        for (uint32_t i = tid; i < n_all; i += DET_T) st.pts[i] = pts[o_pol[0] + i];
-        __syncthreads();
+        st.pts = lds_pts;
         const uint32_t base[2] = {0u, n_pol[0]};
         extract_window(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_LDS_MAXC,
                        csize + 2 * DET_LDS_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
         __syncthreads();
+#ifdef ECAL_PHASE_PROF
+        det_t__ = __builtin_readcyclecounter();
+#endif
         for (uint32_t i = tid; i < n_all; i += DET_T) kept_labels[o_pol[0] + i] = st.kept[i];
         if (nk_sh[0] >= prm.need_clusters && nk_sh[1] >= prm.need_clusters) {  // representatives exist only then
             for (int pol = 0; pol < 2; pol++)
                 for (uint32_t k = tid; k < nk_sh[pol]; k += DET_T) rep[o_pol[pol] + k] = st.rep[base[pol] + k];
+        }
+        DET_MARK(4);
+        if (tid == 0) {
+#ifdef ECAL_PHASE_PROF
+            atomicAdd(&g_det_cycles[8], 1ull);
+#endif
         }
     } else {
         DetGlobal st;
@@ -455,12 +508,23 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
 
 constexpr size_t DET_LDS_BYTES_GLOBAL = 3 * DET_MAXC * sizeof(uint32_t);
 constexpr size_t DET_LDS_BYTES_STAGED = 3 * DET_LDS_MAXC * sizeof(uint32_t) + 6 * DET_LDS_PTS * sizeof(uint16_t) +
-                                        DET_LDS_PTS * sizeof(double2);
+                                        DET_LDS_PTS * sizeof(uint32_t);
 constexpr size_t DET_LDS_BYTES = DET_LDS_BYTES_STAGED > DET_LDS_BYTES_GLOBAL ? DET_LDS_BYTES_STAGED : DET_LDS_BYTES_GLOBAL;
 
 }  // namespace ecal
 
 using namespace ecal;
+
+#ifdef ECAL_PHASE_PROF
+extern "C" int ecal_debug_det_cycles(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_det_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_det_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" double ecal_circle_radius_threshold(double width, double height, int rows, int cols, int asymmetric,
                                                double square_size, double circle_radius) {
