@@ -662,6 +662,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         return m;
     };
     if (gmax() <= opt.gradient_tolerance) S.termination = 0;
+    bool last_step_ok = true;
     while (S.termination == 1 && S.iterations < opt.max_num_iterations) {
         S.iterations++;
         // Levenberg-Marquardt diagonal on the scaled system
@@ -688,9 +689,14 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         }
         plus(x.data(), delta, s->n_cp, s->use_so3, xc.data());
         double new_cost;
-        rc = evaluate(xc.data(), 0, &new_cost);
+        // After a successful step the next one is usually successful too: evaluate the candidate WITH its normal
+        // equations in one pass (4.8 ms) instead of a cost-only pass (1.0 ms + a host round trip) followed, on
+        // acceptance, by the full pass at the same point.  After a rejected step fall back to the cost-only probe.
+        const bool speculate = last_step_ok;
+        rc = evaluate(xc.data(), speculate ? 1 : 0, &new_cost);
         if (rc) return rc;
-        S.cost_evaluations++;
+        if (speculate) S.jacobian_evaluations++;
+        else S.cost_evaluations++;
         const double rel = (cost - new_cost) / model_change;
         double step2 = 0, x2 = 0;
         for (size_t i = 0; i < nt; i++) step2 += delta[i] * delta[i];
@@ -699,11 +705,16 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             const double cost_change = cost - new_cost;
             x.swap(xc);
             const double prev = cost;
-            rc = evaluate(x.data(), 1, &cost);
-            if (rc) return rc;
-            S.jacobian_evaluations++;
+            if (speculate) {
+                cost = new_cost;  // the buffer of the speculative pass is the one to unpack
+            } else {
+                rc = evaluate(x.data(), 1, &cost);
+                if (rc) return rc;
+                S.jacobian_evaluations++;
+            }
             unpack(acc, s->n_cp, A);
             S.successful_steps++;
+            last_step_ok = true;
             const double t = 2.0 * rel - 1.0;
             radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
             decrease_factor = 2.0;
@@ -713,6 +724,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             radius /= decrease_factor;
             decrease_factor *= 2.0;
             S.unsuccessful_steps++;
+            last_step_ok = false;
         }
         if (S.termination == 1 && std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(x2) + opt.parameter_tolerance))
             S.termination = 0;
