@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--p2-pieces", type=int, default=1024,
                     help="pieces of the adaptive-window policy P2 (SURVEY 8d) measured after M1 (0 = skip)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe upload timing")
+    ap.add_argument("--ingest-events", type=int, default=50_000_000,
+                    help="events of the double-buffered ingest leg (configs[4]; host-resident stream; 0 = skip)")
     ap.add_argument("--calib-views", type=int, default=64,
                     help="views of the init calibration leg (configs[3]: 64 views sharded over the GPUs; 0 = skip)")
     ap.add_argument("--calib-cpu-views", type=int, default=8, help="views timed on the numpy oracle (0 = skip)")
@@ -252,6 +254,8 @@ def main():
         out_solver = solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np)
         if rank == 0:
             out["solver"] = out_solver
+    if args.ingest_events > 0 and rank == 0 and world == 1:
+        out["ingest"] = ingest_leg(args, ctx, dev, torch, np, rate)
     if args.calib_views > 0:
         out_calib = calib_leg(args, ctx, dev, world, rank, dist, torch, np)
         if rank == 0:
@@ -366,6 +370,32 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
                                "implied_iterations_per_s_on_this_problem": round(m / cel / (2 * n_res), 6)}
     solver.close()
     return out
+
+def ingest_leg(args, ctx, dev, torch, np, rate):
+    """configs[4]: the stream starts in (pinned) HOST memory; chunks are uploaded with hipMemcpyAsync on a copy stream
+    while the previous chunk is detected (ecal_detect_stream_tiled) — PCIe-inclusive events/s, reported beside M1."""
+    import synth_stream as SS
+    from eventcalib_amd import capi
+    n = args.ingest_events
+    host = torch.empty(n * 25, dtype=torch.uint8, pin_memory=True)
+    host.copy_(SS.make_stream(n, rate=rate, t_start=5.0, seed=4242, device=dev))
+    torch.cuda.synchronize(dev)
+    S = int(np.floor((n - 1) / rate / 1.5e-3)) + 1
+    res = {}
+    for wpc in (2048, S + 1):                       # double-buffered chunks vs one chunk (upload, then detect)
+        capi.detect_stream_tiled(ctx, host.data_ptr(), n, 5.0, 1.5e-3, wpc, S + 8, want_features=False)   # warm-up (allocations)
+        tb = time.perf_counter()
+        info, found, _, st = capi.detect_stream_tiled(ctx, host.data_ptr(), n, 5.0, 1.5e-3, wpc, S + 8, want_features=False)
+        el = time.perf_counter() - tb
+        res[wpc] = (el, st["chunks"], int((found != 0).sum()))
+    (e2, c2, f2), (e1, c1, f1) = res[2048], res[S + 1]
+    return {"metric": "Mevents/s including the PCIe upload", "value": round(n / e2 / 1e6, 1), "unit": "Mevents/s", "events": n,
+            "windows": S, "chunks": c2, "seconds": round(e2, 4), "grids_found": f2,
+            "single_chunk_seconds": round(e1, 4), "single_chunk_Mevents_per_s": round(n / e1 / 1e6, 1),
+            "pcie_floor_seconds_at_57GBs": round(n * 25 / 57e9, 4),
+            "note": "stages: window bounds + slicing + DBSCAN + candidates + grid ordering per chunk of 2048 windows; the copy of "
+                    "chunk k+1 overlaps the kernels of chunk k; never part of `value`"}
+
 
 def calib_leg(args, ctx, dev, world, rank, dist, torch, np):
     """configs[3]: the init calibration (cv::calibrateCamera's role, EventCalibIni.cpp:198-199) on 64 views sharded

@@ -15,7 +15,8 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
-    "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_rectify_batch_dev", "ecal_rectify_batch",
+    "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
+    "ecal_detect_stream_tiled", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
@@ -492,3 +493,39 @@ def spline_eval(knots, cp, u):
     if st != 0:
         raise EcalError(st, L.ecal_strerror(st).decode())
     return out
+
+
+# ---- double-buffered ingest ----
+class DetectParams(ctypes.Structure):
+    """ecal_detect_params (include/ecal.h)."""
+    _fields_ = [("dbscan_eps", ctypes.c_double), ("dbscan_min_samples", ctypes.c_uint32), ("cluster_min_sample", ctypes.c_uint32),
+                ("need_clusters", ctypes.c_uint32), ("circle_radius_threshold", ctypes.c_double), ("fit_circle", ctypes.c_int),
+                ("knn_num", ctypes.c_uint32), ("rows", ctypes.c_uint32), ("cols", ctypes.c_uint32)]
+
+
+class IngestStats(ctypes.Structure):
+    _fields_ = [("chunks", ctypes.c_uint32), ("max_chunk_events", ctypes.c_uint64), ("bytes_uploaded", ctypes.c_uint64),
+                ("seconds", ctypes.c_double)]
+
+
+def detect_stream_tiled(ctx: Context, host_ptr, n_events, t_start, window_len, windows_per_chunk, max_windows, eps=4.0, minpts=2,
+                        cluster_min=5, rows=9, cols=4, radius_threshold=15.511363636363637, want_features=True):
+    """ecal_detect_stream_tiled over packed records at host address `host_ptr` (pinned for overlap).  Returns
+    (win_info [S,4], grid_found [S], features [S, rows*cols, 3] or None, stats dict)."""
+    L = ctx._L
+    vp, u32, f64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_double
+    L.ecal_detect_stream_tiled.argtypes = [vp, vp, ctypes.c_uint64, f64, f64, u32, ctypes.POINTER(DetectParams), u32, vp, vp, vp,
+                                           ctypes.POINTER(u32), ctypes.POINTER(IngestStats)]
+    L.ecal_detect_stream_tiled.restype = ctypes.c_int
+    prm = DetectParams(float(eps), int(minpts), int(cluster_min), int(rows * cols), float(radius_threshold), 0, 3, int(rows), int(cols))
+    info = np.zeros((max_windows, 4), np.uint32)
+    found = np.zeros(max_windows, np.uint32)
+    feat = np.zeros((max_windows, rows * cols, 3)) if want_features else None
+    nw = u32(0)
+    st = IngestStats()
+    ctx._check(L.ecal_detect_stream_tiled(ctx._h, host_ptr, int(n_events), float(t_start), float(window_len), int(windows_per_chunk),
+                                          ctypes.byref(prm), int(max_windows), _ptr(info), _ptr(found),
+                                          _ptr(feat) if want_features else None, ctypes.byref(nw), ctypes.byref(st)))
+    S = nw.value
+    return info[:S], found[:S], (feat[:S] if want_features else None), {"chunks": st.chunks, "max_chunk_events": st.max_chunk_events,
+                                                                      "bytes_uploaded": st.bytes_uploaded, "seconds": st.seconds}

@@ -79,6 +79,11 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
         (void) hipStreamDestroy(ctx->stream);
     }
     if (ctx->calib_pinned) (void) hipHostFree(ctx->calib_pinned);
+    if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->ev_uploaded[k]) (void) hipEventDestroy(ctx->ev_uploaded[k]);
+        if (ctx->ev_consumed[k]) (void) hipEventDestroy(ctx->ev_consumed[k]);
+    }
     for (ecal_devbuf *b : ctx->all_bufs()) release(*b);
     delete ctx;
 }

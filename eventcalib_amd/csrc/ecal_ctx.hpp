@@ -30,6 +30,9 @@ struct ecal_ctx {
     ecal_devbuf det_members, det_koff, det_ksize, det_sorted, det_norms;  // detection stage scratch
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
     ecal_devbuf as_host;         // staging of ecal_associate
+    ecal_devbuf ingest_ev[2], ingest_feat;  // ecal_detect_stream_tiled: ping-pong event chunks, gathered features
+    hipStream_t copy_stream = nullptr;      // uploads of the double-buffered ingest
+    hipEvent_t ev_uploaded[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
     ecal_devbuf host_grid_order, host_grid_found;
     ecal_devbuf host_rect[11];  // staging of ecal_rectify_batch
@@ -46,7 +49,7 @@ struct ecal_ctx {
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
                 &host_pipe[6], &host_pipe[7], &host_pipe[8], &host_pipe[9], &host_pipe[10], &host_pipe[11],
                 &host_pipe[12], &host_pipe[13], &host_pipe[14], &host_pipe[15], &host_pipe[16],
-                &host_grid_order, &host_grid_found, &calib_scratch, &as_host};
+                &host_grid_order, &host_grid_found, &calib_scratch, &as_host, &ingest_ev[0], &ingest_ev[1], &ingest_feat};
     }
 };
 

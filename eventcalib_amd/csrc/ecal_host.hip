@@ -1,6 +1,9 @@
 // Host-pointer conveniences on top of the device entry points: a device-resident event stream and
 // one call that runs bounds -> slicing -> DBSCAN -> candidate extraction for a batch of windows and
 // copies back whatever the caller asks for.  Used by the C++ shims (host/*.hpp).
+#include <chrono>
+#include <algorithm>
+#include <math.h>
 #include "ecal_ctx.hpp"
 
 struct ecal_stream {
@@ -148,6 +151,182 @@ extern "C" int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const dou
     ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
     if (overflow) {
         ctx->last_error = "cap_points is smaller than the number of events covered by the windows";
+        return ECAL_ERR_RANGE;
+    }
+    return ECAL_OK;
+}
+
+// ---- double-buffered ingest ------------------------------------------------------------------------------
+// The event file does not have to be resident before detection starts: chunks of whole windows are uploaded on a
+// copy stream (hipMemcpyAsync from pinned host memory) into one of two device buffers while the detection kernels
+// of the previous chunk run on the context's stream.  Tiled windows (policy P1 of SURVEY 8d): window s =
+// [t_start + s len, nextafter(t_start + (s + 1) len, -inf)], so every event is in exactly one window.
+namespace {
+__global__ void gather_features_kernel(const uint32_t *win_info, const uint32_t *seg_off, const double *cand_xyr,
+                                       const int32_t *order, const uint32_t *found, uint32_t S, uint32_t M, double *feat) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * M) return;
+    const uint32_t s = i / M;
+    double x = NAN, y = NAN, r = NAN;
+    if (win_info[4 * s + 3] == 0 && found[s]) {
+        const size_t c = (size_t) seg_off[2 * s] + (uint32_t) order[i];
+        x = cand_xyr[3 * c];
+        y = cand_xyr[3 * c + 1];
+        r = cand_xyr[3 * c + 2];
+    }
+    feat[3 * (size_t) i] = x;
+    feat[3 * (size_t) i + 1] = y;
+    feat[3 * (size_t) i + 2] = r;
+}
+inline double rec_time(const uint8_t *events, uint64_t i) {
+    double t;
+    memcpy(&t, events + 25 * i, 8);
+    return t;
+}
+}  // namespace
+
+extern "C" int ecal_pin_host(ecal_ctx *ctx, void *ptr, size_t bytes) {
+    if (!ctx || !ptr) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ECAL_HIP_TRY(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return ECAL_OK;
+}
+extern "C" int ecal_unpin_host(ecal_ctx *ctx, void *ptr) {
+    if (!ctx || !ptr) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipHostUnregister(ptr));
+    return ECAL_OK;
+}
+
+extern "C" int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events, uint64_t n_events, double t_start, double window_len,
+                                        uint32_t windows_per_chunk, const ecal_detect_params *prm, uint32_t max_windows,
+                                        uint32_t *win_info, uint32_t *grid_found, double *features, uint32_t *n_windows,
+                                        ecal_ingest_stats *stats) {
+    if (!ctx || !prm || !n_windows || (n_events && !events) || !(window_len > 0) || windows_per_chunk == 0) return ECAL_ERR_INVALID;
+    *n_windows = 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (n_events == 0) return ECAL_OK;
+    if (n_events > 0xFFFFFFFFull) return ECAL_ERR_RANGE;
+    const double t_last = rec_time(events, n_events - 1);
+    if (!(t_last >= t_start)) return ECAL_OK;
+    const uint64_t S64 = (uint64_t) floor((t_last - t_start) / window_len) + 1;
+    if (S64 > max_windows) {
+        ctx->last_error = "ecal_detect_stream_tiled: more windows than max_windows";
+        return ECAL_ERR_RANGE;
+    }
+    const uint32_t S = (uint32_t) S64, M = prm->rows * prm->cols;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (!ctx->copy_stream) ECAL_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    hipStream_t cs = ctx->copy_stream;
+    for (int k = 0; k < 2; k++) {
+        if (!ctx->ev_uploaded[k]) ECAL_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_uploaded[k], hipEventDisableTiming));
+        if (!ctx->ev_consumed[k]) ECAL_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_consumed[k], hipEventDisableTiming));
+    }
+    const auto wall0 = std::chrono::steady_clock::now();
+    auto first_at_or_after = [&](double t) {  // lower_bound on the packed timestamps (host)
+        uint64_t lo = 0, hi = n_events;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (rec_time(events, mid) < t) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t n_chunks = (S + windows_per_chunk - 1) / windows_per_chunk;
+    std::vector<uint64_t> c_lo(n_chunks), c_hi(n_chunks);
+    uint64_t max_ev = 0;
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        c_lo[c] = first_at_or_after(t_start + window_len * ((double) c * windows_per_chunk));
+        const uint32_t w_end = std::min<uint64_t>(S, (uint64_t) (c + 1) * windows_per_chunk);
+        c_hi[c] = w_end == S ? n_events : first_at_or_after(t_start + window_len * (double) w_end);
+        max_ev = std::max(max_ev, c_hi[c] - c_lo[c]);
+    }
+    int rc;
+    for (int k = 0; k < 2; k++)
+        if ((rc = ecal_ensure(ctx, ctx->ingest_ev[k], max_ev * 25 + 32))) return rc;
+    const uint32_t Wc = windows_per_chunk;
+    const size_t cap = (size_t) max_ev + 16;
+    ecal_devbuf *B = ctx->host_pipe;  // same roles as in ecal_detect_batch
+    const size_t sizes[17] = {Wc * sizeof(double), Wc * sizeof(double), Wc * 4ul, Wc * 4ul, (Wc + 1) * 4ul, cap * 16, 2ul * Wc * 4,
+                              2ul * Wc * 4, cap * 4, cap * 4, 2ul * Wc * 4, cap * 4, cap * 4, 4ul * Wc * 4, cap * 8, cap * 24, 16};
+    for (int i = 0; i < 17; i++)
+        if ((rc = ecal_ensure(ctx, B[i], sizes[i]))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) Wc * (M ? M : 1) * sizeof(int32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) Wc * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->ingest_feat, (size_t) Wc * (M ? M : 1) * 24))) return rc;
+    std::vector<double> t0(Wc), t1(Wc);
+    auto upload = [&](uint32_t c) -> int {
+        const int k = c & 1;
+        if (c >= 2) ECAL_HIP_TRY(ctx, hipStreamWaitEvent(cs, ctx->ev_consumed[k], 0));  // buffer k is free again
+        const uint64_t nb = (c_hi[c] - c_lo[c]) * 25;
+        if (nb) ECAL_HIP_TRY(ctx, hipMemcpyAsync(ctx->ingest_ev[k].ptr, events + 25 * c_lo[c], nb, hipMemcpyHostToDevice, cs));
+        ECAL_HIP_TRY(ctx, hipEventRecord(ctx->ev_uploaded[k], cs));
+        return ECAL_OK;
+    };
+    if ((rc = upload(0))) return rc;
+    for (uint32_t c = 0; c < n_chunks; c++) {
+        if (c + 1 < n_chunks && (rc = upload(c + 1))) return rc;  // next chunk's copy overlaps this chunk's kernels
+        const int k = c & 1;
+        const uint32_t w0 = c * Wc, nw = std::min<uint64_t>(S, (uint64_t) (c + 1) * Wc) - w0;
+        const uint64_t ne = c_hi[c] - c_lo[c];
+        const uint8_t *d_ev = (const uint8_t *) ctx->ingest_ev[k].ptr;
+        for (uint32_t w = 0; w < nw; w++) {
+            t0[w] = t_start + window_len * (double) (w0 + w);
+            t1[w] = nextafter(t_start + window_len * (double) (w0 + w + 1), -INFINITY);
+        }
+        // the host vectors are reused per chunk: wait until the previous chunk's copies of them were taken
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(B[0].ptr, t0.data(), nw * sizeof(double), hipMemcpyHostToDevice, st));
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(B[1].ptr, t1.data(), nw * sizeof(double), hipMemcpyHostToDevice, st));
+        ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));  // also bounds the host's run-ahead to one chunk
+        ECAL_HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_uploaded[k], 0));
+        if ((rc = ecal_window_bounds_dev(ctx, d_ev, ne, (double *) B[0].ptr, (double *) B[1].ptr, nw, (uint32_t *) B[2].ptr,
+                                         (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, st)))
+            return rc;
+        if ((rc = ecal_slice_events_dev(ctx, d_ev, ne, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, nw, 0,
+                                        (uint32_t) max_ev, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
+                                        (int32_t *) B[8].ptr, (int *) B[16].ptr, st)))
+            return rc;
+        ECAL_HIP_TRY(ctx, hipEventRecord(ctx->ev_consumed[k], st));  // the packed records are not read after slicing
+        if ((rc = ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * nw,
+                                        (uint32_t) max_ev, 0, prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr,
+                                        (uint32_t *) B[10].ptr, st)))
+            return rc;
+        if ((rc = ecal_extract_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
+                                         (uint32_t *) B[10].ptr, nw, (uint32_t) max_ev, prm->cluster_min_sample, prm->need_clusters,
+                                         prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
+                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr,
+                                         st)))
+            return rc;
+        if (win_info) ECAL_HIP_TRY(ctx, hipMemcpyAsync(win_info + 4 * (size_t) w0, B[13].ptr, 4ul * nw * 4, hipMemcpyDeviceToHost, st));
+        if (M > 0) {
+            if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, nw, prm->rows,
+                                          prm->cols, (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
+                return rc;
+            if (grid_found)
+                ECAL_HIP_TRY(ctx, hipMemcpyAsync(grid_found + w0, ctx->host_grid_found.ptr, nw * 4ul, hipMemcpyDeviceToHost, st));
+            if (features) {
+                const uint32_t tot = nw * M;
+                hipLaunchKernelGGL(gather_features_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, (const uint32_t *) B[13].ptr,
+                                   (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
+                                   (const uint32_t *) ctx->host_grid_found.ptr, nw, M, (double *) ctx->ingest_feat.ptr);
+                ECAL_HIP_TRY(ctx, hipMemcpyAsync(features + 3 * (size_t) w0 * M, ctx->ingest_feat.ptr, (size_t) tot * 24,
+                                                 hipMemcpyDeviceToHost, st));
+            }
+        }
+    }
+    int overflow = 0;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(&overflow, B[16].ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(cs));
+    *n_windows = S;
+    if (stats) {
+        stats->chunks = n_chunks;
+        stats->max_chunk_events = max_ev;
+        stats->bytes_uploaded = n_events ? (c_hi[n_chunks - 1] - c_lo[0]) * 25 : 0;
+        stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
+    }
+    if (overflow) {
+        ctx->last_error = "ecal_detect_stream_tiled: internal capacity overflow";
         return ECAL_ERR_RANGE;
     }
     return ECAL_OK;

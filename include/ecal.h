@@ -190,6 +190,28 @@ int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, v
 int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const double *t0, const double *t1, uint32_t S,
                       const ecal_detect_params *prm, uint32_t cap_points, ecal_detect_result *res);
 
+/* ---- double-buffered ingest (BASELINE configs[4]: hipMemcpyAsync double-buffered ingest) -----------------
+ * ecal_detect_stream_tiled: detection over a HOST-resident event file without uploading it first.  Tiled windows
+ *   s = [t_start + s len, nextafter(t_start + (s + 1) len, -inf)] (policy P1 of SURVEY 8d: every event in exactly one
+ *   window; the reference's piece loop `eventCameraCalib.cpp:172-190` with non-overlapping frames).  Chunks of
+ *   windows_per_chunk windows are uploaded with hipMemcpyAsync on a copy stream into one of two device buffers while
+ *   the detection kernels (bounds -> slice -> DBSCAN -> candidates -> grid order) of the previous chunk run; pass pinned
+ *   host memory (ecal_pin_host, or any hipHostMalloc'ed buffer) — pageable memory makes the copies synchronous.
+ *   Outputs (host, any may be NULL): win_info [S][4] as ecal_extract_batch_dev, grid_found [S], features
+ *   [S][rows*cols][3] = the ordered circles (centre x, y, radius; NaN where no grid was found).
+ *   *n_windows = S = floor((t_last - t_start) / len) + 1 (ECAL_ERR_RANGE if > max_windows). */
+typedef struct ecal_ingest_stats {
+    uint32_t chunks;
+    uint64_t max_chunk_events, bytes_uploaded;
+    double seconds;   /* wall time of the whole call */
+} ecal_ingest_stats;
+int ecal_pin_host(ecal_ctx *ctx, void *ptr, size_t bytes);   /* hipHostRegister */
+int ecal_unpin_host(ecal_ctx *ctx, void *ptr);
+int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events /*host*/, uint64_t n_events, double t_start, double window_len,
+                             uint32_t windows_per_chunk, const ecal_detect_params *prm, uint32_t max_windows,
+                             uint32_t *win_info, uint32_t *grid_found, double *features, uint32_t *n_windows,
+                             ecal_ingest_stats *stats);
+
 /* ---- grid ordering of the candidates -----------------------------------------------------------------
  * Replaces cv::findCirclesGrid(points, Size(cols, rows), centers, CALIB_CB_ASYMMETRIC_GRID[|CLUSTERING]) and the
  * nearest-candidate lookup after it (event_camera_calib/src/CirclesEventFrame.cpp:332-353; the finder is the

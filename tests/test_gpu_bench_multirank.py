@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(nproc, extra):
     env = dict(os.environ, ECAL_BENCH_SINGLE_DEVICE="1", ECAL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--events", "2000000", "--cpu-sample", "0",
-            "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0"] + extra
+            "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0", "--ingest-events", "0"] + extra
     if nproc == 1:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
