@@ -4,7 +4,9 @@
 // eventCameraCalib.cpp:49-56 -> EventFrame.cpp:10-36 -> CirclesEventFrame.cpp:61-312) on the
 // oracle restatements, without the findCirclesGrid call.  Single thread.  Used by bench.py's
 // cpu_baseline leg and by the parity tests as a batch checker.
+#include <atomic>
 #include <cstdint>
+#include <thread>
 #include <vector>
 #include <cstddef>
 
@@ -49,5 +51,36 @@ uint64_t oracle_detect_windows(const uint8_t *rec, uint64_t n, const double *t0,
     }
     *n_clusters_total = clusters;
     return events;
+}
+
+// The reference driver's threading (event_camera_calib/test/eventCameraCalib.cpp:172-190): T = hardware threads - 2
+// workers, the time range cut into 5 T pieces, every worker runs whole pieces.  Here the tiled windows are cut into
+// 5 T contiguous pieces handed out from an atomic counter (the reference hands piece k to thread k % T).
+uint64_t oracle_detect_windows_mt(const uint8_t *rec, uint64_t n, const double *t0, const double *t1, uint32_t S, double eps,
+                                  uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters, double radius_thr,
+                                  uint32_t n_threads, uint64_t *n_clusters_total) {
+    if (n_threads < 1) n_threads = 1;
+    const uint32_t pieces = 5 * n_threads;
+    std::atomic<uint32_t> next{0};
+    std::atomic<uint64_t> events{0}, clusters{0};
+    auto work = [&]() {
+        for (;;) {
+            const uint32_t k = next.fetch_add(1);
+            if (k >= pieces) return;
+            const uint32_t lo = (uint32_t) ((uint64_t) S * k / pieces), hi = (uint32_t) ((uint64_t) S * (k + 1) / pieces);
+            if (hi == lo) continue;
+            uint64_t c = 0;
+            const uint64_t e = oracle_detect_windows(rec, n, t0 + lo, t1 + lo, hi - lo, eps, minpts, cluster_min, need_clusters,
+                                                     radius_thr, &c);
+            events += e;
+            clusters += c;
+        }
+    };
+    std::vector<std::thread> th;
+    for (uint32_t t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+    *n_clusters_total = clusters.load();
+    return events.load();
 }
 }

@@ -181,6 +181,21 @@ def detect_windows(rec, t0, t1, eps, minpts, cluster_min=5, need_clusters=36, ra
     return int(ev), int(ncl.value)
 
 
+def detect_windows_mt(rec, t0, t1, eps, minpts, n_threads, cluster_min=5, need_clusters=36, radius_thr=15.511363636363637):
+    """The same loop on n_threads workers over 5 n_threads pieces (the reference driver's threading)."""
+    L = lib()
+    L.oracle_detect_windows_mt.argtypes = [_u8p, ctypes.c_uint64, _dp, _dp, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32,
+                                           ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32, _u64p]
+    L.oracle_detect_windows_mt.restype = ctypes.c_uint64
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    t0 = np.ascontiguousarray(t0, dtype=np.float64)
+    t1 = np.ascontiguousarray(t1, dtype=np.float64)
+    ncl = ctypes.c_uint64(0)
+    ev = L.oracle_detect_windows_mt(_p(rec, _u8p), rec.size // 25, _p(t0, _dp), _p(t1, _dp), t0.shape[0], float(eps), int(minpts),
+                                    int(cluster_min), int(need_clusters), float(radius_thr), int(n_threads), ctypes.byref(ncl))
+    return int(ev), int(ncl.value)
+
+
 # ---- circle-candidate extraction (oracle/detect_oracle.cpp) ----
 def circle_radius_threshold(width, height, rows, cols, asymmetric, square, radius):
     L = lib()
