@@ -435,7 +435,7 @@ struct ArrowWorkspace {
     std::vector<double> L, Z;  // [nc][BW] factor; [nc][10] = L^-1 [border | rhs]
 };
 
-bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const std::vector<double> &dd,
+__attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const std::vector<double> &dd,
                  std::vector<double> &y, ArrowWorkspace &ws) {
     const size_t nc = A.nc;
     ws.L.resize(nc * BW);
@@ -452,31 +452,31 @@ bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const s
         for (int j = 0; j < 9; j++) Z[i * 10 + j] = A.border[i * 9 + j] * si * sc[nc + j];
         Z[i * 10 + 9] = -A.gc[i] * si;
     }
-    // banded Cholesky (lower, row-wise) fused with the forward substitution of the 10 columns
-    for (size_t i = 0; i < nc; i++) {
-        double *__restrict__ Li = L + i * BW;
-        const int kmax = (int) std::min<size_t>(BW - 1, i);
-        for (int k = kmax; k >= 1; k--) {
-            const double *__restrict__ Lj = L + (i - k) * BW;  // row of column j = i - k
-            const int mmax = std::min(BW - 1 - k, (int) (i - k));
-            double v = Li[k];
-            for (int m = 1; m <= mmax; m++) v -= Li[k + m] * Lj[m];
-            Li[k] = v / Lj[0];
-        }
-        double d = Li[0];
-        for (int m = 1; m <= kmax; m++) d -= Li[m] * Li[m];
+    // banded Cholesky, right-looking: once column j is final, its rank-1 update goes into the (at most BW-1) rows
+    // below it and into their 10 border / right-hand-side columns.  The inner loops run over contiguous pieces of a
+    // row's band and of a small copy of the column, with fixed short trip counts: they vectorise (this function is
+    // compiled for AVX2 + FMA), which the row-wise dot-product form did not.
+    for (size_t j = 0; j < nc; j++) {
+        double d = L[j * BW];
         if (!(d > 0.0)) return false;
         d = std::sqrt(d);
-        Li[0] = d;
-        double acc10[10];
-        for (int j = 0; j < 10; j++) acc10[j] = Z[i * 10 + j];
-        for (int k = 1; k <= kmax; k++) {
-            const double l = Li[k];
-            const double *__restrict__ Zk = Z + (i - k) * 10;
-            for (int j = 0; j < 10; j++) acc10[j] -= l * Zk[j];
-        }
         const double inv = 1.0 / d;
-        for (int j = 0; j < 10; j++) Z[i * 10 + j] = acc10[j] * inv;
+        L[j * BW] = d;
+        double *__restrict__ Zj = Z + j * 10;
+        for (int c = 0; c < 10; c++) Zj[c] *= inv;
+        const int rmax = (int) std::min<size_t>(BW - 1, nc - 1 - j);
+        double col[BW];  // col[r] = L(j + r, j)
+        for (int r = 1; r <= rmax; r++) {
+            col[r] = L[(j + r) * BW + r] * inv;
+            L[(j + r) * BW + r] = col[r];
+        }
+        for (int r = 1; r <= rmax; r++) {
+            const double lr = col[r];
+            double *__restrict__ Lr = L + (j + r) * BW;  // row j + r: entry (j + r, j + c) sits at band offset r - c
+            for (int c = 1; c <= r; c++) Lr[r - c] -= lr * col[c];
+            double *__restrict__ Zr = Z + (j + r) * 10;
+            for (int c = 0; c < 10; c++) Zr[c] -= lr * Zj[c];
+        }
     }
     // Schur complement on the 9 intrinsics: S = C - Zb^T Zb, b = -g_i - Zb^T z
     double S[81], bvec[9], G[10 * 10];
