@@ -77,8 +77,10 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
     const double *intr = params;
     const double *qall = params + 9;
     const double *tall = params + 9 + 4 * (size_t) n_cp_total;
-    double q[4][4], t[4][3], pin[9];
+    double q[4][4], t[4][3], pin[9], binv[6];
     for (int i = 0; i < 9; i++) pin[i] = intr[i];
+    spline_span_inverses(kn, ch.span, binv);           // uniform over the chunk: 6 + 2 divisions per thread, not per residual
+    const double ifx = 1.0 / pin[0], ify = 1.0 / pin[1];
     for (int j = 0; j < 4; j++) {
         for (int k = 0; k < 4; k++) q[j][k] = qall[4 * (size_t) (c0 + j) + k];
         for (int k = 0; k < 3; k++) t[j][k] = tall[3 * (size_t) (c0 + j) + k];
@@ -112,7 +114,9 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
             in.lmy = landmarks[3 * (size_t) e.lm + 1];
             in.lmz = landmarks[3 * (size_t) e.lm + 2];
             in.radius = radius;
-            spline_basis(kn, ch.span, e.t, in.b);
+            in.ifx = ifx;
+            in.ify = ify;
+            spline_basis_inv(kn, ch.span, binv, e.t, in.b);
             r = SO3 ? spline_residual_so3(in, pin, q, t, with_jac ? J : nullptr)
                     : spline_residual(in, pin, q, t, with_jac ? J : nullptr);
             double hr;

@@ -60,20 +60,49 @@ ECAL_HD void spline_basis(const double *knots, uint32_t span, double u, double b
     for (int j = 0; j <= 3; j++) b[j] = ndu[j][3];
 }
 
+// The six denominators of the cubic basis recursion are knot differences — constants of the span, not of u:
+// ndu[j][r] = right[r+1] + left[j-r] = knots[span+r+1] - knots[span+1-j+r].  A chunk of residuals shares its span, so
+// the kernel takes their reciprocals once and the per-residual basis costs no division.
+ECAL_HD void spline_span_inverses(const double *knots, uint32_t span, double inv[6]) {
+    int o = 0;
+    for (int j = 1; j <= 3; j++)
+        for (int r = 0; r < j; r++) inv[o++] = 1.0 / (knots[span + r + 1] - knots[span + 1 - j + r]);
+}
+ECAL_HD void spline_basis_inv(const double *knots, uint32_t span, const double inv[6], double u, double b[4]) {
+    double left[4], right[4], N[4];
+    N[0] = 1.0;
+    int o = 0;
+    for (int j = 1; j <= 3; j++) {
+        left[j] = u - knots[span + 1 - j];
+        right[j] = knots[span + j] - u;
+        double saved = 0.0;
+        for (int r = 0; r < j; r++) {
+            const double temp = N[r] * inv[o++];
+            N[r] = saved + right[r + 1] * temp;
+            saved = left[j - r] * temp;
+        }
+        N[j] = saved;
+    }
+    for (int j = 0; j <= 3; j++) b[j] = N[j];
+}
+
 struct ResidualInput {
     double u, v;          // observed pixel
     double lmx, lmy, lmz; // landmark (circle centre on the board, z = 0)
     double radius;        // circle radius (world units)
     double b[4];          // basis values (same for the rotation and the translation spline)
+    double ifx, ify;      // 1 / fx, 1 / fy (the kernel hoists them out of its residual loop); 0 = compute here
 };
 
 // Shared tail of both rotation parameterisations: residual for the unit quaternion (ux,uy,uz,w) and translation T;
 // when J != nullptr fills J[0..8] (intrinsics), gq = d res / d (unit quaternion, ambient xyzw) and gT = d res / d T.
 ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double ux, double uy, double uz, double w,
                              const double T[3], double *J, double gq[4], double gT[3]) {
-    const double fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+    const double cx = intr[2], cy = intr[3];
+    // divisions are reciprocal + multiply: one rcp each for fx, fy (hoisted by the kernel), Y_z, |Xw - lm|
+    const double ifx = in.ifx != 0.0 ? in.ifx : 1.0 / intr[0], ify = in.ify != 0.0 ? in.ify : 1.0 / intr[1];
     // undistorted ray
-    const double x = (in.u - cx) / fx, y = (in.v - cy) / fy;
+    const double x = (in.u - cx) * ifx, y = (in.v - cy) * ify;
     const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
     const double c = 1.0 + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
     const double px = x * c, py = y * c, pz = 1.0;
@@ -83,21 +112,23 @@ ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double
     const double Y0 = px + 2 * w * cxp0 + 2 * (ux * udp - px * udu);
     const double Y1 = py + 2 * w * cxp1 + 2 * (uy * udp - py * udu);
     const double Y2 = pz + 2 * w * cxp2 + 2 * (uz * udp - pz * udu);
-    const double s = -T[2] / Y2;  // depth
+    const double iY2 = 1.0 / Y2;
+    const double s = -T[2] * iY2;  // depth
     const double Xw0 = T[0] + s * Y0, Xw1 = T[1] + s * Y1, Xw2 = T[2] + s * Y2;
     const double d0 = Xw0 - in.lmx, d1 = Xw1 - in.lmy, d2 = Xw2 - in.lmz;
     const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
     const double res = dist - in.radius;
     if (!J) return res;
 
-    const double e0 = d0 / dist, e1 = d1 / dist, e2 = d2 / dist;  // d res / d Xw
+    const double idist = 1.0 / dist;
+    const double e0 = d0 * idist, e1 = d1 * idist, e2 = d2 * idist;  // d res / d Xw
     const double eY = e0 * Y0 + e1 * Y1 + e2 * Y2;
     // Xw = T - T_z Y / Y_z
     gT[0] = e0;
     gT[1] = e1;
-    gT[2] = e2 - eY / Y2;
-    const double k = -T[2] / Y2;  // = s
-    const double gY0 = k * e0, gY1 = k * e1, gY2 = k * e2 - k * eY / Y2;
+    gT[2] = e2 - eY * iY2;
+    const double k = s;
+    const double gY0 = k * e0, gY1 = k * e1, gY2 = k * e2 - k * eY * iY2;
     // d Y / d p = R(q) = I + 2 w [u]x + 2 (u u^T - (u.u) I);   g_p = R^T g_Y = g_Y - 2 w (u x g_Y) + 2 (u (u.g_Y) - g_Y (u.u))
     const double udg = ux * gY0 + uy * gY1 + uz * gY2;
     const double cxg0 = uy * gY2 - uz * gY1, cxg1 = uz * gY0 - ux * gY2;
@@ -107,10 +138,10 @@ ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double
     const double cp = intr[4] + 2 * intr[5] * r2 + 3 * intr[6] * r4 + 4 * intr[7] * r6 + 5 * intr[8] * r8;  // dc/dr2
     const double gx = gp0 * (c + 2 * x * x * cp) + gp1 * (2 * x * y * cp);
     const double gy = gp0 * (2 * x * y * cp) + gp1 * (c + 2 * y * y * cp);
-    J[0] = -gx * x / fx;
-    J[1] = -gy * y / fy;
-    J[2] = -gx / fx;
-    J[3] = -gy / fy;
+    J[0] = -gx * x * ifx;
+    J[1] = -gy * y * ify;
+    J[2] = -gx * ifx;
+    J[3] = -gy * ify;
     const double gk = gp0 * x + gp1 * y;
     J[4] = gk * r2;
     J[5] = gk * r4;
@@ -138,14 +169,15 @@ ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, cons
         for (int k = 0; k < 3; k++) T[k] += in.b[j] * t[j][k];
     }
     const double vn = sqrt(vq[0] * vq[0] + vq[1] * vq[1] + vq[2] * vq[2] + vq[3] * vq[3]);
-    const double ux = vq[0] / vn, uy = vq[1] / vn, uz = vq[2] / vn, w = vq[3] / vn;
+    const double ivn = 1.0 / vn;
+    const double ux = vq[0] * ivn, uy = vq[1] * ivn, uz = vq[2] * ivn, w = vq[3] * ivn;
     double gq[4], gT[3];
     const double res = residual_core(in, intr, ux, uy, uz, w, T, J, gq, gT);
     if (!J) return res;
     // through the normalisation q = v / |v|
     const double qdg = ux * gq[0] + uy * gq[1] + uz * gq[2] + w * gq[3];
-    const double gv[4] = {(gq[0] - ux * qdg) / vn, (gq[1] - uy * qdg) / vn, (gq[2] - uz * qdg) / vn,
-                          (gq[3] - w * qdg) / vn};
+    const double gv[4] = {(gq[0] - ux * qdg) * ivn, (gq[1] - uy * qdg) * ivn, (gq[2] - uz * qdg) * ivn,
+                          (gq[3] - w * qdg) * ivn};
     for (int j = 0; j < 4; j++) {
         const double bj = in.b[j];
         // EigenQuaternionParameterization: q_j <- exp(delta) (x) q_j ; d/d delta at 0 (4x3, xyzw rows)

@@ -42,6 +42,7 @@ int main() {
         double obs[2] = {173 + 150 * U(rng), 130 + 110 * U(rng)};
         double lm[3] = {19 + 18 * U(rng), 22 + 20 * U(rng), 0};
         ecal::ResidualInput in;
+        in.ifx = in.ify = 0.0;  // computed inside
         in.u = obs[0]; in.v = obs[1]; in.lmx = lm[0]; in.lmy = lm[1]; in.lmz = lm[2]; in.radius = 1.75;
         for (int k = 0; k < 4; k++) in.b[k] = b[k];
         double J[33], Jo[33];
@@ -80,6 +81,7 @@ int main() {
         double obs[2] = {173 + 150 * U(rng), 130 + 110 * U(rng)};
         double lm[3] = {19 + 18 * U(rng), 22 + 20 * U(rng), 0};
         ecal::ResidualInput in;
+        in.ifx = in.ify = 0.0;  // computed inside
         in.u = obs[0]; in.v = obs[1]; in.lmx = lm[0]; in.lmy = lm[1]; in.lmz = lm[2]; in.radius = 1.75;
         for (int k = 0; k < 4; k++) in.b[k] = b[k];
         double J[33], Jo[33];
