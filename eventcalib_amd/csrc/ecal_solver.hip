@@ -31,8 +31,15 @@ struct Chunk {
 
 constexpr int NE_T = 256;   // threads per workgroup = rows per batch
 constexpr int NE_LD = 36;   // padded row: 33 Jacobian entries, the residual, 2 zeros
-constexpr int NE_TILES = 45;  // 4x4 tiles of the upper triangle of a 9x9 tile grid
-constexpr int NE_GROUPS = 5;  // row groups (5 * 45 = 225 accumulating threads)
+// Register tiles of the Gram accumulation: TW x TW doubles per thread over the padded 36 columns.  TW = 6 (21 tiles of
+// the upper triangle x 12 row groups = 252 threads, 2.7 LDS bytes per FMA) for the quaternion variant; the SO3 variant's
+// residual code needs the registers, so it keeps TW = 4 (45 tiles x 5 row groups = 225 threads, 4 bytes per FMA).
+template <int TW>
+struct NeTiles {
+    static constexpr int TG = NE_LD / TW;
+    static constexpr int TILES = TG * (TG + 1) / 2;
+    static constexpr int GROUPS = NE_T / TILES;
+};
 constexpr uint32_t NE_CHUNK = 16384;  // residuals per workgroup (one span): few, long chunks keep the FP64 atomics rare
 constexpr uint32_t NE_REPL = 64;      // replicas of the shared head (cost, intrinsics block) that the chunks add into
 
@@ -57,7 +64,7 @@ __device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_i
 }
 
 template <bool SO3>
-__global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__restrict__ rec,
+__global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResRecord *__restrict__ rec,
                                                          const Chunk *__restrict__ chunks,
                                                          const double *__restrict__ knots,
                                                          const uint32_t *__restrict__ knot_off,
@@ -66,6 +73,8 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
                                                          const double *__restrict__ landmarks, double radius,
                                                          double huber_a, int with_jac, double *__restrict__ accum,
                                                          double *__restrict__ heads) {
+    constexpr int NE_TW = SO3 ? 4 : 6;
+    constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES, NE_GROUPS = NeTiles<NE_TW>::GROUPS;
     extern __shared__ __attribute__((aligned(16))) double rows[];  // [NE_T][NE_LD] when with_jac
     __shared__ double red[NE_T / 64];
     const Chunk ch = chunks[blockIdx.x];
@@ -89,16 +98,16 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
     int ti = 0, tj = 0;
     {
         int rem = tid % NE_TILES;
-        for (ti = 0; ti < 9; ti++) {
-            if (rem < 9 - ti) break;
-            rem -= 9 - ti;
+        for (ti = 0; ti < NE_TG; ti++) {
+            if (rem < NE_TG - ti) break;
+            rem -= NE_TG - ti;
         }
         tj = ti + rem;
     }
     const int grp = tid / NE_TILES;
-    double acc[16];
+    double acc[NE_TW * NE_TW];
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.0;
+    for (int i = 0; i < NE_TW * NE_TW; i++) acc[i] = 0.0;
     double cost = 0.0;
 
     for (uint32_t b0 = 0; b0 < ch.count; b0 += NE_T) {
@@ -140,15 +149,20 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
                 const uint32_t nrow = min((uint32_t) NE_T, ch.count - b0);
                 for (uint32_t rk = grp; rk < nrow; rk += NE_GROUPS) {
                     const double *rw = rows + (size_t) rk * NE_LD;
-                    const double2 a01 = *reinterpret_cast<const double2 *>(rw + 4 * ti);
-                    const double2 a23 = *reinterpret_cast<const double2 *>(rw + 4 * ti + 2);
-                    const double2 b01 = *reinterpret_cast<const double2 *>(rw + 4 * tj);
-                    const double2 b23 = *reinterpret_cast<const double2 *>(rw + 4 * tj + 2);
-                    const double a[4] = {a01.x, a01.y, a23.x, a23.y}, bb[4] = {b01.x, b01.y, b23.x, b23.y};
+                    double a[NE_TW], bb[NE_TW];
 #pragma unroll
-                    for (int x = 0; x < 4; x++)
+                    for (int x = 0; x < NE_TW; x += 2) {  // 16-byte LDS reads (tile starts are 48-byte aligned)
+                        const double2 av = *reinterpret_cast<const double2 *>(rw + NE_TW * ti + x);
+                        const double2 bv = *reinterpret_cast<const double2 *>(rw + NE_TW * tj + x);
+                        a[x] = av.x;
+                        a[x + 1] = av.y;
+                        bb[x] = bv.x;
+                        bb[x + 1] = bv.y;
+                    }
 #pragma unroll
-                        for (int y = 0; y < 4; y++) acc[4 * x + y] += a[x] * bb[y];
+                    for (int x = 0; x < NE_TW; x++)
+#pragma unroll
+                        for (int y = 0; y < NE_TW; y++) acc[NE_TW * x + y] += a[x] * bb[y];
                 }
             }
             __syncthreads();
@@ -166,12 +180,12 @@ __global__ __launch_bounds__(NE_T) void normal_eq_kernel(const ResRecord *__rest
     if (!with_jac || grp >= NE_GROUPS) return;
     // flush this thread's tile into the global block storage
 #pragma unroll
-    for (int x = 0; x < 4; x++) {
+    for (int x = 0; x < NE_TW; x++) {
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            const int li = 4 * ti + x, lj = 4 * tj + y;
+        for (int y = 0; y < NE_TW; y++) {
+            const int li = NE_TW * ti + x, lj = NE_TW * tj + y;
             if (li > lj || lj >= 34 || li >= 33) continue;
-            const double v = acc[4 * x + y];
+            const double v = acc[NE_TW * x + y];
             if (v == 0.0) continue;
             bool ia, ib;
             uint32_t ca, ka, cb, kb;
