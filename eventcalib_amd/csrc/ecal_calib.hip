@@ -261,13 +261,18 @@ __global__ __launch_bounds__(CBK_T) void calib_costrec_kernel(const double *bloc
         R[e] = e == CRO_COST ? blocks[(size_t) v * CB_BLOCK + CBO_COST] : (e == CRO_NPTS ? (double) n : 0.0);
 }
 
-// out[e] = sum over views in view order (deterministic)
-__global__ __launch_bounds__(192) void calib_reduce_kernel(const double *view_red, uint32_t V, double *out) {
-    const int e = threadIdx.x;
-    if (e >= CB_RED) return;
+// out[e] = sum over views: four interleaved partial sums per entry (views v = q mod 4, each in view order), combined
+// in the fixed order q = 0..3 — deterministic, and a quarter of the dependent-load chain of a single running sum
+constexpr int CB_RED_Q = 4;
+__global__ __launch_bounds__(CB_RED_STRIDE * CB_RED_Q) void calib_reduce_kernel(const double *view_red, uint32_t V, double *out) {
+    __shared__ double part[CB_RED_Q][CB_RED_STRIDE];
+    const int e = threadIdx.x % CB_RED_STRIDE, q = threadIdx.x / CB_RED_STRIDE;
     double s = 0;
-    for (uint32_t v = 0; v < V; v++) s += view_red[(size_t) v * CB_RED_STRIDE + e];
-    out[e] = s;
+    if (e < CB_RED)
+        for (uint32_t v = q; v < V; v += CB_RED_Q) s += view_red[(size_t) v * CB_RED_STRIDE + e];
+    part[q][e] = s;
+    __syncthreads();
+    if (q == 0 && e < CB_RED) out[e] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
 }
 
 // back-substitution of one view: x_v = (Hvv')^-1 (g_v - Hvi x_i); cand = prev - scale * x_v
@@ -727,7 +732,7 @@ int launch_eval(CalibWork &w, const double *intr, int which_view, int which_bloc
 
 // view_red -> red (+ all-reduce over ranks) -> host
 int reduce_to_host(CalibWork &w) {
-    hipLaunchKernelGGL(calib_reduce_kernel, dim3(1), dim3(192), 0, w.st, w.d_view_red, w.V, w.d_red);
+    hipLaunchKernelGGL(calib_reduce_kernel, dim3(1), dim3(CB_RED_STRIDE * CB_RED_Q), 0, w.st, w.d_view_red, w.V, w.d_red);
     if (w.opt->allreduce) {
         if (w.opt->allreduce(w.opt->allreduce_user, w.d_red, CB_RED, w.st) != 0) {
             w.ctx->last_error = "all-reduce hook failed";

@@ -36,7 +36,9 @@ def test_two_ranks_match_one_rank():
     # the sharded init calibration lands on the single-rank answer (same 64 views, Schur records summed over ranks)
     c1, c2 = one["init_calibration"], two["init_calibration"]
     assert c1["views_per_gpu"] == 64 and c2["views_per_gpu"] == 32
-    assert abs(c1["rms_px"] - c2["rms_px"]) < 1e-9 and c1["lm_iterations"] == c2["lm_iterations"]
+    # same minimum; the stop test (relative parameter change below DBL_EPSILON) sits on rounding, and the sharded sum
+    # adds the Schur records in a different order, so the count may differ by an iteration
+    assert abs(c1["rms_px"] - c2["rms_px"]) < 1e-9 and abs(c1["lm_iterations"] - c2["lm_iterations"]) <= 1
     assert c1["fx_rel_err"] < 2e-3 and c2["fx_rel_err"] < 2e-3
     # the solver's shared intrinsics move towards the truth in both layouts (start: 1 % off; 3 iterations only)
     assert two["solver"]["intrinsics_rel_err_after"] < 8e-3 and one["solver"]["intrinsics_rel_err_after"] < 8e-3
