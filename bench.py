@@ -293,25 +293,27 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
     intr0 = x_seg[:9].copy()
     intr0[:4] *= 1 + 0.01 * rngp.uniform(-1, 1, 4)
     intr0[4:9] += 0.01 * rngp.uniform(-1, 1, 5)
-    if world > 1:
-        seg_cp_off = (np.arange(world + 1) * n_cp).astype(np.uint32)
-        knots = np.concatenate([ST.uniform_knots(n_cp, t_start_r, t_start_r + duration) for t_start_r in
-                                [5.0 + r * (duration + 1.0) for r in range(world)]])
-        prob = dict(prob, seg_cp_off=seg_cp_off, knots=knots, seg_id=np.full(n_res, rank, np.uint32))
-        # full parameter vector: every rank needs all control points (others' blocks only get reduced sums)
-        q_all = np.concatenate([SV.gt_control_points(n_cp, 5.0 + r * (duration + 1.0), 5.0 + r * (duration + 1.0) + duration)[0]
-                                for r in range(world)])
-        t_all = np.concatenate([SV.gt_control_points(n_cp, 5.0 + r * (duration + 1.0), 5.0 + r * (duration + 1.0) + duration)[1]
-                                for r in range(world)])
-        x0 = np.concatenate([intr0, q_all.ravel(), t_all.ravel()])
-    else:
-        x0 = np.concatenate([intr0, x_seg[9:]])
+    # N > 1: every rank keeps its OWN segment in its own solver (distributed segments, include/ecal.h): what crosses
+    # xGMI per evaluation is the 91-double head, per linear solve 101 + N doubles, per step 4 — never the control points
+    x0 = np.concatenate([intr0, x_seg[9:]])
+    combined = None
+    if world > 1 and os.environ.get("ECAL_BENCH_SOLVER_CHECK") and rank == 0:
+        # test hook: the same problem as ONE solver over all segments, solved by rank 0 alone — the reference result
+        parts = [ST.make_problem(n_res, n_cp, 5.0 + r * (duration + 1.0), 5.0 + r * (duration + 1.0) + duration, seed=777 + r,
+                                 device=dev, round_pixels=True) for r in range(world)]
+        combined = (dict(parts[0][0], seg_cp_off=(np.arange(world + 1) * n_cp).astype(np.uint32),
+                         knots=np.concatenate([p[0]["knots"] for p in parts]),
+                         obs=np.concatenate([p[0]["obs"] for p in parts]), time=np.concatenate([p[0]["time"] for p in parts]),
+                         lm_id=np.concatenate([p[0]["lm_id"] for p in parts]),
+                         seg_id=np.concatenate([np.full(n_res, r, np.uint32) for r in range(world)])),
+                    np.concatenate([intr0] + [p[1][9:9 + 4 * n_cp] for p in parts] + [p[1][9 + 4 * n_cp:] for p in parts]))
     solver = Solver(ctx, prob)
     del prob
     opt = solver.default_options()
     hook = make_allreduce_hook(ctx, world)
     if world > 1:
         opt.allreduce = hook
+        opt.distributed, opt.rank, opt.world_size = 1, rank, world
     # warm-up: two iterations
     opt.max_num_iterations = 2
     solver.solve(x0, opt)
@@ -357,7 +359,7 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
         "seconds_linear_solve_host": round(float(summ.seconds_linear_solve), 4), "successful_steps": int(summ.successful_steps),
         "jacobian_evaluations": int(summ.jacobian_evaluations), "cost_evaluations": int(summ.cost_evaluations),
         "initial_cost": float(summ.initial_cost), "final_cost": float(summ.final_cost),
-        "residuals": res_total, "control_points": int(solver.n_cp), "unknowns": int(9 + 6 * solver.n_cp),
+        "residuals": res_total, "control_points": int(solver.n_cp) * world, "unknowns": int(9 + 6 * solver.n_cp * world),
         "intrinsics_rel_err_after": float(np.abs(x[:4] / SV.GT_INTR[:4] - 1).max()),
         "kernel_ms": {"normal_equations": round(jac_ms, 4), "cost_only": round(cost_ms, 4)},
         "roofline_hbm": {"algorithmic_bytes_per_residual_iteration": 64, "achieved_GBs":
@@ -365,9 +367,19 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
         "roofline_fp64": {"kernel": "normal_eq_kernel", "flop_per_residual": FLOP_JAC,
                           "achieved_TFLOPs": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 1e12, 3), "peak_TFLOPs": 78.6,
                           "frac": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 78.6e12, 4)},
-        "sharding": "one spline segment (time range) per GPU, shared intrinsics, all-reduce of the normal-equation "
-                    "buffer per evaluation" if world > 1 else "single GPU",
+        "sharding": "one spline segment (time range) per GPU in its own solver, shared intrinsics: 91 doubles all-reduced per "
+                    "evaluation, 101 + N per linear solve, 4 per step" if world > 1 else "single GPU",
     }
+    if combined is not None:
+        ref = Solver(ctx, combined[0])
+        o2 = ref.default_options()
+        o2.max_num_iterations = args.solver_iters
+        xr, sr = ref.solve(combined[1], o2)
+        ref.close()
+        out["check_vs_single_solver"] = {"intrinsics_rel_diff": float(np.abs(x[:9] / xr[:9] - 1).max()),
+                                         "final_cost_rel_diff": float(abs(summ.final_cost / sr.final_cost - 1)),
+                                         "own_control_points_abs_diff": float(np.abs(x[9:9 + 4 * n_cp] - xr[9:9 + 4 * n_cp]).max()),
+                                         "iterations": [iters, int(sr.iterations)]}
     if rank == 0 and args.solver_cpu_sample > 0 and world == 1:
         import oracle_lib as O
         m = min(args.solver_cpu_sample, n_res)

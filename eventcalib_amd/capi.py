@@ -227,7 +227,8 @@ class LmOptions(ctypes.Structure):
                 ("initial_trust_region_radius", ctypes.c_double), ("max_trust_region_radius", ctypes.c_double),
                 ("min_relative_decrease", ctypes.c_double), ("min_lm_diagonal", ctypes.c_double),
                 ("max_lm_diagonal", ctypes.c_double), ("jacobi_scaling", ctypes.c_int),
-                ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p)]
+                ("allreduce", ALLREDUCE_FN), ("allreduce_user", ctypes.c_void_p),
+                ("distributed", ctypes.c_int), ("rank", ctypes.c_int), ("world_size", ctypes.c_int)]
 
 
 class LmSummary(ctypes.Structure):

@@ -11,6 +11,8 @@
 // matrix.  It is accumulated with register-tiled FP64 FMAs (4x4 tiles): on gfx950 the FP64 MFMA peak
 // equals the FP64 vector peak and the 16x16x4 shape would pad 34 to 48 (2x the flops), so matrix
 // cores buy nothing here.
+#include <functional>
+#include <limits>
 #include "ecal_ctx.hpp"
 #include "spline_residual.hpp"
 
@@ -451,6 +453,8 @@ void unpack(const double *acc, uint32_t n_cp, ArrowSystem &A) {
 // as 10 contiguous columns so that the substitution loops vectorise.
 struct ArrowWorkspace {
     std::vector<double> L, Z;  // [nc][BW] factor; [nc][10] = L^-1 [border | rhs]
+    double G[100];             // [Zb z]^T [Zb z]
+    std::function<bool(double *)> reduce_G;  // distributed mode: sums G over ranks in place; false = some rank failed
 };
 
 __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const std::vector<double> &dd,
@@ -474,9 +478,13 @@ __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const
     // below it and into their 10 border / right-hand-side columns.  The inner loops run over contiguous pieces of a
     // row's band and of a small copy of the column, with fixed short trip counts: they vectorise (this function is
     // compiled for AVX2 + FMA), which the row-wise dot-product form did not.
+    bool pd = true;
     for (size_t j = 0; j < nc; j++) {
         double d = L[j * BW];
-        if (!(d > 0.0)) return false;
+        if (!(d > 0.0)) {
+            pd = false;
+            break;
+        }
         d = std::sqrt(d);
         const double inv = 1.0 / d;
         L[j * BW] = d;
@@ -496,9 +504,18 @@ __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const
             for (int c = 0; c < 10; c++) Zr[c] -= lr * Zj[c];
         }
     }
-    // Schur complement on the 9 intrinsics: S = C - Zb^T Zb, b = -g_i - Zb^T z
-    double S[81], bvec[9], G[10 * 10];
+    // Schur complement on the 9 intrinsics: S = C - Zb^T Zb, b = -g_i - Zb^T z.  G = [Zb z]^T [Zb z] is a sum over the
+    // control-point rows: with the segments sharded over ranks it is the one thing the linear solve has to all-reduce.
+    double S[81], bvec[9];
+    double *G = ws.G;
     for (int i = 0; i < 100; i++) G[i] = 0.0;
+    if (!pd) {
+        if (ws.reduce_G) {  // every rank must take part in the collective
+            G[99] = std::numeric_limits<double>::quiet_NaN();
+            (void) ws.reduce_G(G);
+        }
+        return false;
+    }
     for (size_t r = 0; r < nc; r++) {
         const double *__restrict__ z = Z + r * 10;
         for (int i = 0; i < 10; i++) {
@@ -506,6 +523,7 @@ __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const
             for (int j = i; j < 10; j++) G[10 * i + j] += zi * z[j];
         }
     }
+    if (ws.reduce_G && !ws.reduce_G(G)) return false;  // sum over ranks (also carries "some rank failed")
     for (int i = 0; i < 9; i++) {
         for (int j = 0; j < 9; j++) {
             double v = A.corner[9 * i + j] * sc[nc + i] * sc[nc + j] - (i <= j ? G[10 * i + j] : G[10 * j + i]);
@@ -553,7 +571,8 @@ __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const
 }
 
 // y^T A y and g^T y on the unscaled system (for the model cost change)
-void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd, double *dHd) {
+// skip_shared: distributed mode, ranks other than 0 — the intrinsics-only terms are counted once
+void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd, double *dHd, bool skip_shared = false) {
     const size_t nc = A.nc;
     double g = 0, h = 0;
     for (size_t i = 0; i < nc; i++) {
@@ -564,7 +583,7 @@ void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd,
         h += d[i] * row;
         for (int j = 0; j < 9; j++) h += 2.0 * d[i] * A.border[i * 9 + j] * d[nc + j];
     }
-    for (int i = 0; i < 9; i++) {
+    for (int i = 0; i < 9 && !skip_shared; i++) {
         g += A.gi[i] * d[nc + i];
         for (int j = 0; j < 9; j++) h += d[nc + i] * A.corner[9 * i + j] * d[nc + j];
     }
@@ -602,6 +621,9 @@ extern "C" void ecal_lm_default_options(ecal_lm_options *o) {
     o->jacobi_scaling = 1;
     o->allreduce = nullptr;
     o->allreduce_user = nullptr;
+    o->distributed = 0;
+    o->rank = 0;
+    o->world_size = 1;
 }
 
 extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_options *opt_in,
@@ -632,6 +654,37 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         }
     } free_guard{acc, xpin};
     double t_eval = 0, t_lin = 0;
+    // Distributed segments (ecal_lm_options.distributed): every rank owns its own spline segments in its own
+    // ecal_solver; only the 9 intrinsics are shared.  Per evaluation the 91-double head is all-reduced; per linear solve
+    // the 10 x 10 Schur sums (+ a failure flag and one slot per rank for the gradient max-norm); per step four scalars.
+    const bool dist_mode = opt.distributed != 0 && opt.allreduce != nullptr;
+    const int world = dist_mode ? std::max(1, opt.world_size) : 1, my_rank = dist_mode ? opt.rank : 0;
+    if (dist_mode && (my_rank < 0 || my_rank >= world || world > 1024)) return ECAL_ERR_INVALID;
+    double *d_small = nullptr, *h_small = nullptr;
+    const size_t n_small = 128 + (size_t) world;
+    if (dist_mode) {
+        ECAL_HIP_TRY(ctx, hipMalloc((void **) &d_small, n_small * sizeof(double)));
+        if (hipHostMalloc((void **) &h_small, n_small * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+            (void) hipFree(d_small);
+            return ECAL_ERR_NOMEM;
+        }
+    }
+    struct FreeSmall {
+        double *d, *h;
+        ~FreeSmall() {
+            if (d) (void) hipFree(d);
+            if (h) (void) hipHostFree(h);
+        }
+    } free_small{d_small, h_small};
+    auto reduce_small = [&](double *v, size_t n) -> bool {  // sum v[0..n) over ranks in place
+        memcpy(h_small, v, n * sizeof(double));
+        if (hipMemcpyAsync(d_small, h_small, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+        if (opt.allreduce(opt.allreduce_user, d_small, n, st) != 0) return false;
+        if (hipMemcpyAsync(h_small, d_small, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+        if (hipStreamSynchronize(st) != hipSuccess) return false;
+        memcpy(v, h_small, n * sizeof(double));
+        return true;
+    };
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double>(b - a).count();
@@ -646,7 +699,8 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         if (rc) return rc;
         const size_t n = with_jac ? na : 1;
         if (opt.allreduce) {  // per-GPU partials summed over ranks (RCCL all-reduce supplied by the caller)
-            rc = opt.allreduce(opt.allreduce_user, s->d_accum, n, st);
+            // distributed segments: only the head (cost, intrinsics gradient and block) is shared between ranks
+            rc = opt.allreduce(opt.allreduce_user, s->d_accum, dist_mode ? std::min(n, (size_t) ACC_HEAD) : n, st);
             if (rc) return ECAL_ERR_HIP;
         }
         e = hipMemcpyAsync(acc, s->d_accum, n * sizeof(double), hipMemcpyDeviceToHost, st);
@@ -676,9 +730,30 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     auto gmax = [&]() {
         double m = 0;
         for (size_t i = 0; i < nc; i++) m = std::max(m, std::fabs(A.gc[i]));
+        if (dist_mode) {  // one slot per rank, summed: a max over ranks without a max collective
+            std::vector<double> v((size_t) world, 0.0);
+            v[(size_t) my_rank] = m;
+            if (reduce_small(v.data(), v.size()))
+                for (double x : v) m = std::max(m, x);
+        }
         for (int i = 0; i < 9; i++) m = std::max(m, std::fabs(A.gi[i]));
         return m;
     };
+    if (dist_mode)
+        ws.reduce_G = [&](double *G) -> bool {
+            double buf[101];
+            bool bad = false;
+            for (int i = 0; i < 100; i++) {
+                buf[i] = G[i];
+                bad = bad || !std::isfinite(G[i]);
+            }
+            buf[100] = bad ? 1.0 : 0.0;
+            if (bad)
+                for (int i = 0; i < 100; i++) buf[i] = 0.0;
+            if (!reduce_small(buf, 101)) return false;
+            for (int i = 0; i < 100; i++) G[i] = buf[i];
+            return buf[100] == 0.0;
+        };
     if (gmax() <= opt.gradient_tolerance) S.termination = 0;
     bool last_step_ok = true;
     while (S.termination == 1 && S.iterations < opt.max_num_iterations) {
@@ -694,10 +769,16 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         if (ok) {
             for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
             double gTd, dHd;
-            quad_forms(A, delta, &gTd, &dHd);
+            quad_forms(A, delta, &gTd, &dHd, dist_mode && my_rank != 0);
+            if (dist_mode) {
+                double two[2] = {gTd, dHd};
+                if (!reduce_small(two, 2)) return ECAL_ERR_HIP;
+                gTd = two[0];
+                dHd = two[1];
+            }
             model_change = -gTd - 0.5 * dHd;
             ok = model_change > 0.0;
-        }
+        }  // (a failed factorisation was agreed on through reduce_G: every rank skips the reduction above together)
         t_lin += secs(tl, now());
         if (!ok) {  // invalid step: shrink the region
             radius /= decrease_factor;
@@ -717,8 +798,19 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         else S.cost_evaluations++;
         const double rel = (cost - new_cost) / model_change;
         double step2 = 0, x2 = 0;
-        for (size_t i = 0; i < nt; i++) step2 += delta[i] * delta[i];
-        for (size_t i = 0; i < np; i++) x2 += x[i] * x[i];
+        if (dist_mode) {  // own control points from every rank, the shared intrinsics once
+            for (size_t i = 0; i < nc; i++) step2 += delta[i] * delta[i];
+            for (size_t i = 9; i < np; i++) x2 += x[i] * x[i];
+            double two[2] = {step2, x2};
+            if (!reduce_small(two, 2)) return ECAL_ERR_HIP;
+            step2 = two[0];
+            x2 = two[1];
+            for (size_t i = nc; i < nt; i++) step2 += delta[i] * delta[i];
+            for (size_t i = 0; i < 9; i++) x2 += x[i] * x[i];
+        } else {
+            for (size_t i = 0; i < nt; i++) step2 += delta[i] * delta[i];
+            for (size_t i = 0; i < np; i++) x2 += x[i] * x[i];
+        }
         if (rel > opt.min_relative_decrease) {
             const double cost_change = cost - new_cost;
             x.swap(xc);

@@ -331,6 +331,14 @@ typedef struct ecal_lm_options {
     int jacobi_scaling;
     ecal_allreduce_fn allreduce; /* NULL on one GPU; sums d_buf over ranks in place (RCCL) otherwise */
     void *allreduce_user;
+    /* distributed != 0 (needs allreduce): every rank owns its OWN spline segments in its own ecal_solver (its residuals,
+     * its control points) and only the 9 intrinsics are shared.  Exchanged per evaluation: the 91-double head (cost,
+     * intrinsics gradient and block); per linear solve: the 10 x 10 Schur sums of the rank's banded factorisation + a
+     * failure flag + one slot per rank (gradient max-norm); per step: four scalars.  Every rank factorises only its own
+     * band and returns its own control points; all ranks return the same intrinsics, cost and summary.
+     * distributed == 0 with allreduce set: every rank holds the whole parameter vector and the whole normal-equation
+     * buffer is summed (residuals of one segment may then be spread over ranks). */
+    int distributed, rank, world_size;
 } ecal_lm_options;
 typedef struct ecal_lm_summary {
     int iterations, successful_steps, unsuccessful_steps, jacobian_evaluations, cost_evaluations;

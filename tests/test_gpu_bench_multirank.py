@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(nproc, extra):
-    env = dict(os.environ, ECAL_BENCH_SINGLE_DEVICE="1", ECAL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, ECAL_BENCH_SINGLE_DEVICE="1", ECAL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               ECAL_BENCH_SOLVER_CHECK="1")
     args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--events", "2000000", "--cpu-sample", "0",
             "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0", "--ingest-events", "0"] + extra
     if nproc == 1:
@@ -44,3 +45,8 @@ def test_two_ranks_match_one_rank():
     assert two["solver"]["intrinsics_rel_err_after"] < 8e-3 and one["solver"]["intrinsics_rel_err_after"] < 8e-3
     assert two["solver"]["final_cost"] < two["solver"]["initial_cost"]
     assert two["solver"]["residuals"] == 2 * one["solver"]["residuals"]
+    # distributed segments (each rank factorises its own band, 91 / 101 + N / 4 doubles exchanged) == one solver over both
+    # segments: same iterates up to the summation order
+    chk = two["solver"]["check_vs_single_solver"]
+    assert chk["iterations"][0] == chk["iterations"][1]
+    assert chk["intrinsics_rel_diff"] < 1e-8 and chk["final_cost_rel_diff"] < 1e-9 and chk["own_control_points_abs_diff"] < 1e-7

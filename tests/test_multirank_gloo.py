@@ -65,6 +65,25 @@ def _worker(rank, world, port, q):
         # cross-segment control-point blocks stay zero
         Hr = pack[1 + n:].reshape(n, n)
         assert np.abs(Hr[9:9 + 6 * n_cp, 9 + 6 * n_cp:]).max() == 0.0
+        # ---- distributed segments (ecal_lm_options.distributed): every rank eliminates its own control points; only the
+        #      head (intrinsics gradient / block) and the 9 x 10 Schur sums are all-reduced.  Step == dense solve. ----
+        gi_loc, Hii_loc = g[:9], H[:9, :9]
+        Hcc, Hci, gc = H[9:, 9:], H[9:, :9], g[9:]
+        lam = 1e-3
+        Acc = Hcc + lam * np.diag(np.diag(Hcc))
+        W = np.linalg.solve(Acc, np.concatenate([Hci, gc[:, None]], axis=1))          # Acc^-1 [B | g_c]
+        piece = torch.from_numpy(np.concatenate([(Hci.T @ W).ravel(), gi_loc, Hii_loc.ravel()]))   # 90 + 9 + 81
+        dist.all_reduce(piece)
+        piece = piece.numpy()
+        P, gi_all, Hii_all = piece[:90].reshape(9, 10), piece[90:99], piece[99:].reshape(9, 9)
+        Sred = Hii_all + lam * np.diag(np.diag(Hii_all)) - P[:, :9]
+        step_i = np.linalg.solve(Sred, -(gi_all - P[:, 9]))
+        step_c = -np.linalg.solve(Acc, gc + Hci @ step_i)                             # own control points only
+        Hs = Hr + lam * np.diag(np.diag(Hr))
+        full = np.linalg.solve(Hs, -pack[1:1 + n])
+        assert np.allclose(step_i, full[:9], rtol=1e-7, atol=1e-12)
+        own = slice(9 + 6 * n_cp * rank, 9 + 6 * n_cp * (rank + 1))
+        assert np.allclose(step_c, full[own], rtol=1e-6, atol=1e-10)
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, "FAIL: %r" % (e,)))
