@@ -88,6 +88,10 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     using R = IdxBits<uint32_t>;
     constexpr int T = PX_T, PPT = PX_PPT;
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
+#ifdef ECAL_PHASE_PROF
+    unsigned long long phase_t__ = __builtin_readcyclecounter(), d7__ = 0;
+    uint32_t levels__ = 0;
+#endif
     const uint32_t n = seg_cnt[s];
     if (n == 0) {
         if (tid == 0) n_clusters[s] = 0;
@@ -114,16 +118,28 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     uint32_t any_round = 0;
     const size_t base = seg_off[s];
     const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
+#ifdef ECAL_PHASE_PROF
+    if (tid == 0) {  // scalar loads done (count, offset)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long now__ = __builtin_readcyclecounter();
+        d7__ = now__ - phase_t__ + (base & 0);  // added to the counters later: an atomic here would sit in vmcnt
+        phase_t__ = now__;
+    }
+#endif
+#ifdef ECAL_PHASE_PROF
+    if (tid == 0) {  // scalar loads done (count, offset)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long now__ = __builtin_readcyclecounter();
+        d7__ = now__ - phase_t__ + (base & 0);  // added to the counters later: an atomic here would sit in vmcnt
+        phase_t__ = now__;
+    }
+#endif
 #define PX_BAIL()                                                  \
     do {                                                           \
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;         \
         return;                                                    \
     } while (0)
 
-#ifdef ECAL_PHASE_PROF
-    unsigned long long phase_t__ = __builtin_readcyclecounter();
-    uint32_t levels__ = 0;
-#endif
     // ---------------- A: load, pack, bounding box ----------------
     if (tid < 3) anyf[tid] = 0;
     if (tid < 4) bbox[tid] = 0x7FFFFFFF;
@@ -133,12 +149,18 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     bool fits = true;
     {
         int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mxy = -0x7FFFFFFF;
+        // all of the thread's loads are issued before the first is used (index clamped instead of a branch around the
+        // load): with the load inside `if (i < n)` the compiler waited for each one in turn — up to four serial HBM
+        // round trips at the head of every workgroup
+        double2 vin[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) vin[u] = src[min(tid + u * T, n - 1u)];
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
             const uint32_t i = tid + u * T;
             pp[u] = 0;
             if (i < n) {
-                const double2 v = src[i];
+                const double2 v = vin[u];
                 fits = fits && G::fits(v);
                 pp[u] = G::pack(v);
                 slot[2 * i] = NONE32;
@@ -150,6 +172,15 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                 mxy = max(mxy, y);
             }
         }
+#ifdef ECAL_PHASE_PROF
+        if (tid == 0) {  // own points arrived
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long now__ = __builtin_readcyclecounter();
+            atomicAdd(&g_phase_cycles[7], d7__);
+            atomicAdd(&g_phase_cycles[9], now__ - phase_t__);
+            phase_t__ = now__;
+        }
+#endif
         for (int o = 32; o > 0; o >>= 1) {
             mnx = min(mnx, __shfl_xor(mnx, o, 64));
             mny = min(mny, __shfl_xor(mny, o, 64));

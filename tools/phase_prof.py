@@ -32,7 +32,7 @@ for i, nm in enumerate(names):
 print("B split: init+B.0 %.0f  B.1 %.0f  B.2 %.0f  (rest = anc/flags)" % (v[12]/wg, v[13]/wg, v[14]/wg))
 print("D: candidate visits/WG %.0f (per point %.1f)   wave-steps/WG %.0f (x64 = %.0f lane slots)" % (v[12]/wg, v[12]/wg/578.0, v[13]/wg, 64*v[13]/wg))
 print("levels/WG %.1f  sweeps/WG %.2f  WGs %d  total cycles/WG %.0f" % (v[8] / wg, v[9] / wg, wg, tot / wg))
-print("pixel kernel: load + bbox %.0f  (of init+B.0 %.0f)" % (v[15] / wg, v[12] / wg))
+print("pixel kernel: count/offset loads %.0f  points arrive %.0f  bbox + first barriers %.0f   (then init+B.0 %.0f)" % (v[7] / wg, v[9] / wg, v[15] / wg, v[12] / wg))
 d = (ctypes.c_ulonglong * 16)()
 L.ecal_debug_det_cycles(d, 0)
 d = list(d); dw = max(d[8], 1) / 2      # two timed runs accumulated? (reset only DBSCAN's) -> per call counts included
