@@ -11,6 +11,7 @@ the per-window verdicts drives the reference's success / slide / grow rule on th
 import numpy as np
 import torch
 
+from . import capi
 from .pipeline import DetectPipeline
 
 
@@ -40,12 +41,53 @@ def orientation_gate(ref_feat, ref_t, cur_feat, cur_t, rows, cols, motion_time_s
 
 
 def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event_num_threshold, piece_num,
-                     start_time, end_time, eps=4.0, minpts=2, rows=9, cols=4, max_steps=1_000_000):
+                     start_time, end_time, eps=4.0, minpts=2, rows=9, cols=4, max_steps=1_000_000, n_threads=1):
     """Returns dict(time [K], duration [K,2], events_num [K], features [K, rows*cols, 3]) sorted by time, plus
-    `steps` and `windows` (how many batched passes / windows were evaluated)."""
+    `steps` and `windows` (how many batched passes / windows were evaluated).
+
+    n_threads > 1: the pieces are dealt round-robin to that many host threads, each with its OWN ecal_ctx (own stream
+    and scratch — the ABI's one-context-per-thread rule, as the reference gives every worker its own DBSCAN instance):
+    a pass is a ~0.4 ms chain of small launches that leaves the GPU mostly idle, so several chains run side by side.
+    The result does not depend on n_threads (pieces are independent)."""
+    if n_threads > 1:
+        import threading
+        from .capi import Context
+        ctxs = [Context(pipe.ctx.device) for _ in range(n_threads)]
+        outs = [None] * n_threads
+
+        def work(t):
+            outs[t] = _detect_pieces(ctxs[t], events, motion_time_step, frame_event_num_threshold, piece_num,
+                                     np.arange(t, piece_num, n_threads), start_time, end_time, eps, minpts, rows, cols, max_steps)
+        th = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        for c in ctxs:
+            c.close()
+        keys = [r for o in outs for r in o[0]]
+        steps, windows = max(o[1] for o in outs), sum(o[2] for o in outs)
+    else:
+        keys, steps, windows = _detect_pieces(pipe.ctx, events, motion_time_step, frame_event_num_threshold, piece_num,
+                                              np.arange(piece_num), start_time, end_time, eps, minpts, rows, cols, max_steps)
+    n = rows * cols
+    keys.sort(key=lambda r: r[0])
+    K = len(keys)
+    return dict(time=np.array([r[0] for r in keys]), duration=np.array([[r[1], r[2]] for r in keys]).reshape(K, 2),
+                events_num=np.array([r[3] for r in keys], np.int64),
+                features=np.stack([r[4] for r in keys]) if K else np.zeros((0, n, 3)), steps=steps, windows=windows)
+
+
+def _detect_pieces(ctx, events, motion_time_step, frame_event_num_threshold, piece_num, which, start_time, end_time, eps, minpts,
+                   rows, cols, max_steps):
+    """The lock-step loop over the pieces `which` (indices into the piece_num pieces of [start_time, end_time])."""
+    n_ev = events.numel() // 25
     ln, gap = 3 * motion_time_step, 5 * motion_time_step
+    # windows grow to at most 10 steps: twice the mean event count of such a span, to start with
+    per_window = int(2 * 10 * motion_time_step * n_ev / max(end_time - start_time, 1e-9)) + 1024
     step = (end_time - start_time) / piece_num
-    k = np.arange(piece_num)
+    k = np.asarray(which)
+    piece_num = len(k)
     bound_hi = end_time - step * k
     first = end_time - step * (k + 1)
     second = first + ln
@@ -59,20 +101,22 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
     while active.any() and steps < max_steps:
         idx = np.nonzero(active)[0]
         S = len(idx)
-        pipe.set_windows(first[idx], second[idx])
-        pipe.run(events, eps, minpts)
-        order, found = pipe.order_grid(rows, cols)
-        info = pipe.win_info[:S].cpu().numpy()
-        found = found.cpu().numpy().astype(bool)
-        cnt = pipe.seg_cnt[: 2 * S].cpu().numpy().reshape(S, 2).sum(axis=1)          # EventFrame::eventsNum()
-        ok = (info[:, 3] == 0) & found
+        # one C call per pass (ecal_detect_pass): bounds upload, five stages + grid ordering, one packed download
+        while True:   # slots for the pass: windows x (a bound on the events of one window); doubled if a window was denser
+            try:
+                packed = capi.detect_pass(ctx, events.data_ptr(), n_ev, first[idx], second[idx], min(n_ev, S * per_window), eps,
+                                          minpts, 5, rows, cols)
+                break
+            except capi.EcalError as e:
+                if e.status != -6 or S * per_window >= n_ev:
+                    raise
+                per_window *= 2
+        status, found, cnt = packed[:, 0].astype(np.int64), packed[:, 1] != 0, packed[:, 2].astype(np.int64)   # cnt = EventFrame::eventsNum()
+        ok = (status == 0) & found
         accepted = np.zeros(S, bool)
         if ok.any():
             w = np.nonzero(ok)[0]
-            wt = torch.as_tensor(w, device=order.device)
-            base = pipe.seg_off[: 2 * S: 2][wt].long()
-            gi = base[:, None] + order[wt].long()
-            feat = pipe.cand_xyr[gi.reshape(-1)].reshape(len(w), n, 3).cpu().numpy()
+            feat = packed[w, 3:].reshape(len(w), n, 3)
             t_mid = (first[idx[w]] + second[idx[w]]) / 2
             pw = idx[w]
             acc = ~have_ref[pw]
@@ -97,8 +141,4 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
         active[idx] = ns < bound_hi[idx]
         steps += 1
         windows += S
-    keys.sort(key=lambda r: r[0])
-    K = len(keys)
-    return dict(time=np.array([r[0] for r in keys]), duration=np.array([[r[1], r[2]] for r in keys]).reshape(K, 2),
-                events_num=np.array([r[3] for r in keys], np.int64),
-                features=np.stack([r[4] for r in keys]) if K else np.zeros((0, n, 3)), steps=steps, windows=windows)
+    return keys, steps, windows

@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = [
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
-    "ecal_detect_stream_tiled", "ecal_rectify_batch_dev", "ecal_rectify_batch",
+    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
@@ -530,3 +530,19 @@ def detect_stream_tiled(ctx: Context, host_ptr, n_events, t_start, window_len, w
     S = nw.value
     return info[:S], found[:S], (feat[:S] if want_features else None), {"chunks": st.chunks, "max_chunk_events": st.max_chunk_events,
                                                                       "bytes_uploaded": st.bytes_uploaded, "seconds": st.seconds}
+
+
+def detect_pass(ctx: Context, d_events, n_events, t0, t1, cap_points, eps=4.0, minpts=2, cluster_min=5, rows=9, cols=4,
+                radius_threshold=15.511363636363637):
+    """ecal_detect_pass: packed [S, 3 + 3 rows cols] = status, ok, unique pixels, ordered circles of every window."""
+    L = ctx._L
+    vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+    L.ecal_detect_pass.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, u32, ctypes.POINTER(DetectParams), u32, vp]
+    L.ecal_detect_pass.restype = ctypes.c_int
+    t0 = np.ascontiguousarray(t0, np.float64)
+    t1 = np.ascontiguousarray(t1, np.float64)
+    S = t0.shape[0]
+    prm = DetectParams(float(eps), int(minpts), int(cluster_min), int(rows * cols), float(radius_threshold), 0, 3, int(rows), int(cols))
+    out = np.empty((S, 3 + 3 * rows * cols))
+    ctx._check(L.ecal_detect_pass(ctx._h, d_events, int(n_events), _ptr(t0), _ptr(t1), S, ctypes.byref(prm), int(cap_points), _ptr(out)))
+    return out

@@ -80,6 +80,7 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     }
     if (ctx->calib_pinned) (void) hipHostFree(ctx->calib_pinned);
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_uploaded[k]) (void) hipEventDestroy(ctx->ev_uploaded[k]);
         if (ctx->ev_consumed[k]) (void) hipEventDestroy(ctx->ev_consumed[k]);

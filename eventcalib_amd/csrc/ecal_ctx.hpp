@@ -32,6 +32,8 @@ struct ecal_ctx {
     ecal_devbuf as_host;         // staging of ecal_associate
     ecal_devbuf ingest_ev[2], ingest_feat;  // ecal_detect_stream_tiled: ping-pong event chunks, gathered features
     hipStream_t copy_stream = nullptr;      // uploads of the double-buffered ingest
+    double *pass_pinned = nullptr;          // ecal_detect_pass: pinned window bounds in, packed verdicts out
+    size_t pass_pinned_cap = 0;
     hipEvent_t ev_uploaded[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
     ecal_devbuf host_grid_order, host_grid_found;

@@ -185,6 +185,117 @@ inline double rec_time(const uint8_t *events, uint64_t i) {
 }
 }  // namespace
 
+// ordered circles of every window on the device: d_feat[s][k] = candidate d_order[s][k] of window s (centre x, y,
+// radius), NaN where the window has no complete grid — the keyframe features without a host round trip per window
+extern "C" int ecal_gather_features_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off, const double *d_cand_xyr,
+                                        const int32_t *d_order, const uint32_t *d_found, uint32_t S, uint32_t M, double *d_feat,
+                                        void *stream) {
+    if (!ctx || (S && M && (!d_win_info || !d_seg_off || !d_cand_xyr || !d_order || !d_found || !d_feat))) return ECAL_ERR_INVALID;
+    if (S == 0 || M == 0) return ECAL_OK;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const uint32_t tot = S * M;
+    hipLaunchKernelGGL(gather_features_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t) stream, d_win_info, d_seg_off,
+                       d_cand_xyr, d_order, d_found, S, M, d_feat);
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}
+
+// ---- one lock-step pass of the adaptive-window driver ------------------------------------------------------------
+namespace {
+__global__ void pack_pass_kernel(const uint32_t *win_info, const uint32_t *seg_off, const uint32_t *seg_cnt, const double *cand_xyr,
+                                 const int32_t *order, const uint32_t *found, uint32_t S, uint32_t M, double *out) {
+    const uint32_t W = 3 + 3 * M;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * (M + 1)) return;
+    const uint32_t s = i / (M + 1), k = i % (M + 1);
+    const bool ok = win_info[4 * s + 3] == 0 && found[s];
+    double *o = out + (size_t) s * W;
+    if (k == M) {  // header: status, grid flag, EventFrame::eventsNum()
+        o[0] = (double) win_info[4 * s + 3];
+        o[1] = ok ? 1.0 : 0.0;
+        o[2] = (double) (seg_cnt[2 * s] + seg_cnt[2 * s + 1]);
+        return;
+    }
+    double x = NAN, y = NAN, r = NAN;
+    if (ok) {
+        const size_t c = (size_t) seg_off[2 * s] + (uint32_t) order[(size_t) s * M + k];
+        x = cand_xyr[3 * c];
+        y = cand_xyr[3 * c + 1];
+        r = cand_xyr[3 * c + 2];
+    }
+    o[3 + 3 * k] = x;
+    o[4 + 3 * k] = y;
+    o[5 + 3 * k] = r;
+}
+}  // namespace
+
+extern "C" int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *t0, const double *t1,
+                                uint32_t S, const ecal_detect_params *prm, uint32_t cap_points, double *packed) {
+    if (!ctx || !prm || !packed || (S && (!t0 || !t1)) || (n_events && !d_events)) return ECAL_ERR_INVALID;
+    const uint32_t M = prm->rows * prm->cols;
+    if (S == 0) return ECAL_OK;
+    if (M == 0 || M > 128) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    const size_t cap = (size_t) cap_points + 16, W = 3 + 3 * (size_t) M;
+    ecal_devbuf *B = ctx->host_pipe;  // roles as in ecal_detect_batch; 0 holds t0 and t1 back to back
+    const size_t sizes[17] = {2ul * S * sizeof(double), 16, S * 4ul, S * 4ul, (S + 1) * 4ul, cap * 16, 2ul * S * 4, 2ul * S * 4, cap * 4,
+                              cap * 4, 2ul * S * 4, cap * 4, cap * 4, 4ul * S * 4, cap * 8, cap * 24, 16};
+    for (int i = 0; i < 17; i++)
+        if ((rc = ecal_ensure(ctx, B[i], sizes[i]))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->ingest_feat, (size_t) S * W * sizeof(double)))) return rc;
+    const size_t pin_need = 2ul * S * sizeof(double) + (size_t) S * W * sizeof(double) + 16;
+    if (ctx->pass_pinned_cap < pin_need) {
+        if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
+        ctx->pass_pinned = nullptr;
+        ctx->pass_pinned_cap = 0;
+        ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &ctx->pass_pinned, pin_need + pin_need / 2, hipHostMallocDefault));
+        ctx->pass_pinned_cap = pin_need + pin_need / 2;
+    }
+    double *h_t = ctx->pass_pinned, *h_out = ctx->pass_pinned + 2 * (size_t) S;
+    memcpy(h_t, t0, S * sizeof(double));
+    memcpy(h_t + S, t1, S * sizeof(double));
+    double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_t0, h_t, 2ul * S * sizeof(double), hipMemcpyHostToDevice, st));
+    if ((rc = ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
+                                     (uint32_t *) B[4].ptr, st)))
+        return rc;
+    if ((rc = ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, S, 0,
+                                    cap_points, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[8].ptr,
+                                    (int *) B[16].ptr, st)))
+        return rc;
+    if ((rc = ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * S, cap_points, 0,
+                                    prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, st)))
+        return rc;
+    if ((rc = ecal_extract_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
+                                     (uint32_t *) B[10].ptr, S, cap_points, prm->cluster_min_sample, prm->need_clusters,
+                                     prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
+                                     (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st)))
+        return rc;
+    if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
+                                  (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
+        return rc;
+    const uint32_t tot = S * (M + 1);
+    hipLaunchKernelGGL(pack_pass_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr,
+                       (const uint32_t *) B[7].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
+                       (const uint32_t *) ctx->host_grid_found.ptr, S, M, (double *) ctx->ingest_feat.ptr);
+    // the overflow flag lands in the pinned block too: a copy into pageable memory would take the runtime's synchronous path
+    int *h_flag = reinterpret_cast<int *>(h_out + (size_t) S * W);
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(h_out, ctx->ingest_feat.ptr, (size_t) S * W * sizeof(double), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(h_flag, B[16].ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    const int overflow = *h_flag;
+    if (overflow) {
+        ctx->last_error = "cap_points is smaller than the number of events covered by the windows";
+        return ECAL_ERR_RANGE;
+    }
+    memcpy(packed, h_out, (size_t) S * W * sizeof(double));
+    return ECAL_OK;
+}
+
 extern "C" int ecal_pin_host(ecal_ctx *ctx, void *ptr, size_t bytes) {
     if (!ctx || !ptr) return ECAL_ERR_INVALID;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));

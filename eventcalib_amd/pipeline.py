@@ -48,8 +48,8 @@ class DetectPipeline:
 
     def set_windows(self, t0, t1):
         """Inclusive windows [t0[s], t1[s]] (numpy float64 or torch)."""
-        self.t0 = torch.as_tensor(np.asarray(t0, dtype=np.float64)).to(self.dev)
-        self.t1 = torch.as_tensor(np.asarray(t1, dtype=np.float64)).to(self.dev)
+        both = torch.as_tensor(np.stack([np.asarray(t0, dtype=np.float64), np.asarray(t1, dtype=np.float64)])).to(self.dev)
+        self.t0, self.t1 = both[0], both[1]          # one upload for both bounds
         self.S = int(self.t0.numel())
 
     def set_detect_params(self, cluster_min=5, need_clusters=36, radius_threshold=15.511363636363637, fit_circle=False,
@@ -93,6 +93,23 @@ class DetectPipeline:
         self.ctx.grid_order_dev(self.win_info.data_ptr(), self.seg_off.data_ptr(), self.cand_xyr.data_ptr(), self.S, rows,
                                 cols, order.data_ptr(), self.grid_found.data_ptr(), st)
         return order.view(self.S, rows * cols), self.grid_found[: self.S]
+
+    def gather_features(self, rows=9, cols=4):
+        """Ordered circles [S, rows*cols, 3] of the last run() + order_grid() (NaN rows where no grid was found), on device."""
+        import ctypes
+        st = torch.cuda.current_stream(self.dev).cuda_stream
+        M = rows * cols
+        if getattr(self, "_feat_cap", 0) < self.S * M:
+            self.feat = torch.empty(self.S * M * 3, dtype=torch.float64, device=self.dev)
+            self._feat_cap = self.S * M
+        L = self.ctx._L
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        L.ecal_gather_features_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, vp, vp]
+        L.ecal_gather_features_dev.restype = ctypes.c_int
+        self.ctx._check(L.ecal_gather_features_dev(self.ctx._h, self.win_info.data_ptr(), self.seg_off.data_ptr(),
+                                                   self.cand_xyr.data_ptr(), self.grid_order.data_ptr(), self.grid_found.data_ptr(),
+                                                   self.S, M, self.feat.data_ptr(), st))
+        return self.feat[: self.S * M * 3].view(self.S, M, 3)
 
     def overflowed(self):
         return bool(self.flags[0].item())

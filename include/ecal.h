@@ -205,6 +205,18 @@ typedef struct ecal_ingest_stats {
     uint64_t max_chunk_events, bytes_uploaded;
     double seconds;   /* wall time of the whole call */
 } ecal_ingest_stats;
+/* d_feat [S][M][3] = the ordered circles of every window (candidate d_order[s][k] of window s: centre x, y, radius),
+ * NaN where status != 0 or no grid was found; inputs as written by ecal_extract_batch_dev / ecal_grid_order_dev */
+int ecal_gather_features_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off, const double *d_cand_xyr,
+                             const int32_t *d_order /*[S][M]*/, const uint32_t *d_found, uint32_t S, uint32_t M /*rows*cols*/,
+                             double *d_feat, void *stream);
+/* ecal_detect_pass: one lock-step pass of the adaptive-window driver (MultiProcess::process, event_camera_calib/test/
+ * eventCameraCalib.cpp:49-95, for every active piece at once): the five detection stages + grid ordering over S windows of a
+ * DEVICE-resident stream, one upload of the window bounds and ONE download of what the driver's control flow needs:
+ * packed [S][3 + 3 rows*cols] doubles = { status (win_info[3]), 1 if extractFeatures() would return true, unique pixels
+ * (EventFrame::eventsNum()), then the ordered circles x y r (NaN if none) }.  Synchronous. */
+int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *t0, const double *t1, uint32_t S,
+                     const ecal_detect_params *prm, uint32_t cap_points, double *packed);
 int ecal_pin_host(ecal_ctx *ctx, void *ptr, size_t bytes);   /* hipHostRegister */
 int ecal_unpin_host(ecal_ctx *ctx, void *ptr);
 int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events /*host*/, uint64_t n_events, double t_start, double window_len,

@@ -40,6 +40,9 @@ def test_cpp_shims(tmp_path):
     for r, d, n, f in zip(rows, kf["duration"], kf["events_num"], kf["features"]):
         assert abs(float(r[0]) - d[0]) < 1e-9 and abs(float(r[1]) - d[1]) < 1e-9 and int(r[2]) == n
         assert abs(float(r[3]) - f[0, 0]) < 1e-6 and abs(float(r[4]) - f[35, 2]) < 1e-6
+    # the pieces are independent: several host threads with their own contexts select the same keyframes
+    kf4 = detect_keyframes(DetectPipeline(ctx), buf.cuda(), 5e-4, 4000, 4, float(t[0]), float(t[-1]), n_threads=3)
+    assert np.array_equal(kf4["time"], kf["time"]) and np.array_equal(kf4["features"], kf["features"])
     ctx.close()
 
 
