@@ -6,9 +6,10 @@
 // by the disc radius fits a 3232-word bitmap (a 346x260 sensor does) and eps < 16.  Anything else is appended
 // to a to-do list that the general kernels work off.
 //
-// What makes it small and why that matters: the kernel is latency bound — a workgroup's ~40 us are chains of
-// dependent LDS operations, the same at 1 or 3 workgroups per CU (profiles/r01_notes.md) — so throughput
-// is proportional to the workgroups a CU can hold, i.e. to 160 KB / LDS per workgroup.  For integer pixels the
+// What makes it small and why that matters: the kernel is latency bound — a workgroup is a ~45 us chain of
+// dependent LDS operations and barriers, and kernel time is ~ 1 / (workgroups per CU) from 1 to 6
+// (tools/occupancy_probe.sh, profiles/r01_notes.md) — so throughput is proportional to the workgroups a CU can
+// hold, i.e. to 160 KB / LDS per workgroup.  For integer pixels the
 // closed form of the pruning quirk collapses to two bits per point,
 //     f_d(j) = "an ancestor of j in the insertion-order kd-tree splits on d at j's own d-coordinate",
 // and  i -> j is pruned  <=>  j = i + eps * e_d exactly  and  f_d(j)   (integral eps only),
