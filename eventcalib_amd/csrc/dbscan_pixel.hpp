@@ -26,7 +26,10 @@
 
 namespace ecal {
 
-constexpr int PX_T = 256;
+#ifndef ECAL_PX_T
+#define ECAL_PX_T 256
+#endif
+constexpr int PX_T = ECAL_PX_T;
 constexpr int PX_CAP = 1024;
 constexpr int PX_PPT = PX_CAP / PX_T;
 constexpr uint32_t PX_WORDS = 3232;    // bitmap words: 346x260 padded by 2*4 = 354x268 bits = 268 rows x 12 words = 3216
@@ -127,20 +130,27 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         phase_t__ = now__;
     }
 #endif
-#ifdef ECAL_PHASE_PROF
-    if (tid == 0) {  // scalar loads done (count, offset)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long now__ = __builtin_readcyclecounter();
-        d7__ = now__ - phase_t__ + (base & 0);  // added to the counters later: an atomic here would sit in vmcnt
-        phase_t__ = now__;
-    }
-#endif
 #define PX_BAIL()                                                  \
     do {                                                           \
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;         \
         return;                                                    \
     } while (0)
 
+    // debug builds (-DECAL_PX_STOP=k, tools/px_stop_probe.sh): leave after phase k with the phase's results written
+    // out, so that instruction counters can be attributed to phases
+#ifdef ECAL_PX_STOP
+#define PX_STOP(k, expr)                                                                  \
+    if (ECAL_PX_STOP == (k)) {                                                            \
+        _Pragma("unroll") for (int u = 0; u < PPT; u++) {                                 \
+            const uint32_t i = tid + u * T;                                               \
+            if (i < n) labels[base + i] = (int32_t) (expr);                               \
+        }                                                                                 \
+        if (tid == 0) n_clusters[s] = 0;                                                  \
+        return;                                                                           \
+    }
+#else
+#define PX_STOP(k, expr)
+#endif
     // ---------------- A: load, pack, bounding box ----------------
     if (tid < 3) anyf[tid] = 0;
     if (tid < 4) bbox[tid] = 0x7FFFFFFF;
@@ -217,6 +227,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         me[u] = px_word(tid + u * T, mcx[u] & 0x7FFu, myy[u] & 0x7FFu);
     }
     if (tid == 0) *rootw = me[0];
+    PX_STOP(1, me[u] + W + H);
 
     // ---------------- B: kd_insert replay -> prune bits ----------------
     uint32_t st[PPT], f[PPT];
@@ -292,6 +303,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             if (i < n && i >= KTOP) st[u] = a[u] | (d[u] ? R::DIR : 0u) | (side[u] ? R::SIDE : 0u);
         }
     }
+    PX_STOP(2, st[u] ^ (f[u] << 28));
     __syncthreads();  // every walk is done before the first bid changes a slot
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
@@ -312,6 +324,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         if (!block_any(active, anyf, any_round)) break;
     }
     ECAL_PHASE_MARK(14);
+    PX_STOP(3, st[u] ^ (f[u] << 28));
     ECAL_PHASE_MARK(0);
     ECAL_PHASE_COUNT(8, levels__);
 
@@ -382,6 +395,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     }
     __syncthreads();
     ECAL_PHASE_MARK(5);
+    PX_STOP(4, myrk[u] + pid_s[i] + sflags[i]);
     const bool eps_int = geo.epsi <= Rd;  // |delta| == eps needs an integral eps (then epsi == R)
     // ---------------- D: core test ----------------
     bool core[PPT];
@@ -414,6 +428,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     }
     __syncthreads();
     ECAL_PHASE_MARK(2);
+    PX_STOP(5, parent[i] + sflags[i]);
     // ---------------- E.1: union-find over the half disc (rows above, own row to the left) ----------------
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
@@ -497,6 +512,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     }
     __syncthreads();
     ECAL_PHASE_MARK(6);
+    PX_STOP(6, parent[i] + *n_edges);
     const uint32_t m_edges = *n_edges;
     if (m_edges > PX_EDGE_CAP) PX_BAIL();
     // ---------------- E.2 flatten; E.3 one-way edges to the fix-point ----------------
@@ -553,6 +569,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     if (tid == 0) n_clusters[s] = total;
     ECAL_PHASE_MARK(4);
 #undef PX_BAIL
+#undef PX_STOP
 }
 
 }  // namespace ecal
