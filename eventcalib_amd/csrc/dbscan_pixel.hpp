@@ -22,6 +22,7 @@
 // E union-find over the set bits of the half disc (each pair once), one-way edges to a list + fix-point;
 // F seeds ranked in pid order = the reference's cluster ids.
 #pragma once
+#include <type_traits>
 #include "dbscan_device.hpp"
 
 namespace ecal {
@@ -33,27 +34,58 @@ constexpr int PX_T = ECAL_PX_T;
 constexpr int PX_CAP = 1024;
 constexpr int PX_PPT = PX_CAP / PX_T;
 constexpr uint32_t PX_WORDS = 3232;    // bitmap words: 346x260 padded by 2*4 = 354x268 bits = 268 rows x 12 words = 3216
-constexpr uint32_t PX_ROWS = 472;      // rowstart[PX_ROWS + 1 + 39]: 512 u16 (tail = disc half-widths)
+constexpr uint32_t PX_ROWS = 472;      // rowstart[PX_ROWS + 1]: 512 u16
 constexpr uint32_t PX_EDGE_CAP = 128;  // one-way edges kept (more: left to the general kernel)
 constexpr int PX_RMAX = 15;
 
+// Everything the kernel needs to know about eps, worked out once on the host (the f64 square roots used to run in
+// every thread).  dmask[k] = row dy = k - Rd of the closed eps-disc as bits of the (2 Rd + 1)-wide window that starts
+// at column cx - Rd: one 64-bit fetch per row serves every row of the disc, the row's shape is an AND.
+struct PxGeom {
+    int e2i;           // floor(eps^2): d2 <= eps^2  <=>  d2 <= e2i for integer deltas
+    int Rd;            // floor(eps) = the disc's radius in pixels, <= PX_RMAX
+    uint32_t eps_int;  // eps is integral (== Rd): only then |delta| == eps exists and the pruning quirk can bite
+    uint32_t dmask[2 * PX_RMAX + 1];
+};
+
+__host__ __device__ constexpr int px_isqrt(int v) {
+    int r = 0;
+    while ((long long) (r + 1) * (r + 1) <= (long long) v) r++;
+    return r;
+}
+__host__ __device__ constexpr uint32_t px_disc_mask(int e2i, int Rd, int k) {
+    const int dy = k - Rd;
+    const int w = px_isqrt(e2i - dy * dy);
+    return ((w >= 15 ? 0x7FFFFFFFu : ((1u << (2 * w + 1)) - 1u)) << (Rd - w));
+}
+// false: eps is outside what the pixel kernel represents (the general tiers take the launch)
+inline bool px_geometry(double eps, PxGeom *g) {
+    if (!(eps > 0.0) || !(eps < (double) (PX_RMAX + 1))) return false;
+    const double e2 = eps * eps;  // GeoI16::init
+    g->e2i = (int) floor(e2);
+    g->Rd = px_isqrt(g->e2i);
+    g->eps_int = (eps == floor(eps)) ? 1u : 0u;
+    for (int k = 0; k < 2 * PX_RMAX + 1; k++) g->dmask[k] = (k <= 2 * g->Rd) ? px_disc_mask(g->e2i, g->Rd, k) : 0u;
+    return g->Rd >= 0 && g->Rd <= PX_RMAX;
+}
+
 struct PixelLayout {
-    // region A: points (pid order) during A/B and the bit sets; then rank -> pid, flags by rank, edge list
-    static constexpr size_t p_off = 0;
-    static constexpr size_t pid_off = 0;                                    // u16[1024]
-    static constexpr size_t sflags_off = pid_off + 2 * PX_CAP;              // u8[1024]
-    static constexpr size_t edges_off = sflags_off + PX_CAP;                // u32[2 * PX_EDGE_CAP]
-    static_assert(edges_off + 8 * PX_EDGE_CAP <= 4 * PX_CAP, "rank tables must fit the point region");
-    // region B: kd child slots during B; then the bitmap; after E.1: component labels (E.3)
-    static constexpr size_t slot_off = 4 * PX_CAP;                          // u32[2 * 1024]
+    // region A (from the rank phase on): rank -> pid | f << 10 | core << 12, the one-way edge list, the disc masks
+    static constexpr size_t pf_off = 0;                                     // u16[1024]
+    static constexpr size_t edges_off = pf_off + 2 * PX_CAP;                // u32[2 * PX_EDGE_CAP]
+    static constexpr size_t dm_off = edges_off + 8 * PX_EDGE_CAP;           // u32[32]
+    // region B: kd child slots during B (+ one dummy word that stays NONE); then the bitmap; after E.1: component labels
+    static constexpr size_t slot_off = dm_off + 128;                        // u32[2 * 1024 + 1]
     static constexpr size_t bm_off = slot_off;                              // u32[PX_WORDS]
-    static_assert(4 * PX_WORDS >= 8 * PX_CAP, "child slots must fit the bitmap region");
+    static_assert(4 * PX_WORDS >= 8 * PX_CAP + 4, "child slots must fit the bitmap region");
     static constexpr size_t parent_off = bm_off + 4 * PX_WORDS + 16;        // u32[1024] (after one spare bitmap word)
     static constexpr size_t rowstart_off = parent_off + 4 * PX_CAP;         // u16[512]
     static constexpr size_t wpre_off = rowstart_off + 1024;                 // u8[PX_WORDS]
     static constexpr size_t red_off = wpre_off + PX_WORDS;                  // u32[48]
     static constexpr size_t bytes = red_off + 4 * 48;
 };
+constexpr uint32_t PX_PF_CORE = 0x1000u, PX_PF_PID = 0x3FFu;
+constexpr uint32_t PX_DUMMY_SLOT = 8u * PX_CAP;  // byte offset of the child-slot word nobody bids for
 
 // child-slot word: pid << 22 | x' << 11 | y'  (x', y' = bitmap coordinates < 2048).  ds_min_u32 orders the bids by
 // pid, and the winner's coordinates come back with its id: one dependent LDS read per tree level instead of two.
@@ -61,27 +93,30 @@ __device__ __forceinline__ uint32_t px_word(uint32_t pid, uint32_t cx, uint32_t 
 __device__ __forceinline__ uint32_t px_wx(uint32_t w) { return (w >> 11) & 0x7FFu; }
 __device__ __forceinline__ uint32_t px_wy(uint32_t w) { return w & 0x7FFu; }
 
-// one tree level for one unplaced point (register state); returns true while unplaced
-__device__ __forceinline__ bool px_level_step(uint32_t *slot, uint32_t i, uint32_t self, uint32_t &st, uint32_t &f) {
-    using R = IdxBits<uint32_t>;
-    const uint32_t cw = slot[2 * (st & R::MASK) + ((st & R::SIDE) ? 1u : 0u)];
+// One tree level for one unplaced point (register state).  sl = byte offset of the child slot the point bid for
+// (~0 = placed), sh = bit offset of the coordinate the winner of that slot splits on (11 = x, 0 = y), fb = the prune
+// bit of that dimension.  Returns true while unplaced.
+__device__ __forceinline__ bool px_level_step(unsigned char *slotb, uint32_t i, uint32_t self, uint32_t &sl, uint32_t &sh,
+                                              uint32_t &fb, uint32_t &f) {
+    const uint32_t cw = *reinterpret_cast<const uint32_t *>(slotb + sl);
     const uint32_t child = cw >> 22;
     if (child == i) {
-        st = R::PLACED;
+        sl = ~0u;
         return false;
     }
-    const uint32_t nd = (st & R::DIR) ? 0u : 1u;
-    const uint32_t sv = nd ? px_wy(self) : px_wx(self), cv = nd ? px_wy(cw) : px_wx(cw);
-    const uint32_t ns = sv < cv ? 0u : 1u;  // kdtree.cpp:128-131: left iff strictly smaller
-    f |= (sv == cv) ? (1u << nd) : 0u;      // `child` becomes an ancestor splitting on nd at my coordinate
-    atomicMin(&slot[2 * child + ns], self);
-    st = child | (nd ? R::DIR : 0u) | (ns ? R::SIDE : 0u);
+    const uint32_t sv = __builtin_amdgcn_ubfe(self, sh, 11u), cv = __builtin_amdgcn_ubfe(cw, sh, 11u);
+    f |= (sv == cv) ? fb : 0u;                    // `child` becomes an ancestor splitting at my coordinate
+    sl = (child << 3) | (sv < cv ? 0u : 4u);      // kdtree.cpp:128-131: left iff strictly smaller
+    atomicMin(reinterpret_cast<uint32_t *>(slotb + sl), self);
+    sh ^= 11u;
+    fb ^= 3u;
     return true;
 }
 
+template <int E2I>
 __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__restrict__ xy,
                                                             const uint32_t *__restrict__ seg_off,
-                                                            const uint32_t *__restrict__ seg_cnt, double eps,
+                                                            const uint32_t *__restrict__ seg_cnt, const PxGeom geom,
                                                             uint32_t minpts, int32_t *__restrict__ labels,
                                                             uint32_t *__restrict__ n_clusters,
                                                             uint32_t *__restrict__ todo,
@@ -89,7 +124,6 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
     using L = PixelLayout;
     using G = GeoI16;
-    using R = IdxBits<uint32_t>;
     constexpr int T = PX_T, PPT = PX_PPT;
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
 #ifdef ECAL_PHASE_PROF
@@ -105,14 +139,18 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
         return;
     }
-    uint16_t *const pid_s = reinterpret_cast<uint16_t *>(px_smem + L::pid_off);
-    uint8_t *const sflags = reinterpret_cast<uint8_t *>(px_smem + L::sflags_off);
+    // E2I > 0: the disc is a compile-time constant (masks become literals, the row loops unroll)
+    const int Rd = E2I > 0 ? px_isqrt(E2I) : geom.Rd;
+    const int e2i = E2I > 0 ? E2I : geom.e2i;
+    const bool eps_int = geom.eps_int != 0;  // then eps == Rd
+    uint16_t *const pf = reinterpret_cast<uint16_t *>(px_smem + L::pf_off);
     uint32_t *const edges = reinterpret_cast<uint32_t *>(px_smem + L::edges_off);
+    uint32_t *const dm = reinterpret_cast<uint32_t *>(px_smem + L::dm_off);
+    unsigned char *const slotb = px_smem + L::slot_off;
     uint32_t *const slot = reinterpret_cast<uint32_t *>(px_smem + L::slot_off);
     uint32_t *const bm = reinterpret_cast<uint32_t *>(px_smem + L::bm_off);
     uint32_t *const parent = reinterpret_cast<uint32_t *>(px_smem + L::parent_off);
     uint16_t *const rowstart = reinterpret_cast<uint16_t *>(px_smem + L::rowstart_off);
-    uint16_t *const hw = rowstart + PX_ROWS + 1;  // disc half-width per row offset dy + R
     uint8_t *const wpre = reinterpret_cast<uint8_t *>(px_smem + L::wpre_off);
     uint32_t *const red = reinterpret_cast<uint32_t *>(px_smem + L::red_off);
     uint32_t *const n_edges = red + 36;
@@ -122,6 +160,8 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     uint32_t any_round = 0;
     const size_t base = seg_off[s];
     const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
+    // first point of this wave's u-th batch: batches that start at or after n are skipped with a scalar branch
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(tid);
 #ifdef ECAL_PHASE_PROF
     if (tid == 0) {  // scalar loads done (count, offset)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -135,7 +175,6 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;         \
         return;                                                    \
     } while (0)
-
     // debug builds (-DECAL_PX_STOP=k, tools/px_stop_probe.sh): leave after phase k with the phase's results written
     // out, so that instruction counters can be attributed to phases
 #ifdef ECAL_PX_STOP
@@ -154,12 +193,17 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     // ---------------- A: load, pack, bounding box ----------------
     if (tid < 3) anyf[tid] = 0;
     if (tid < 4) bbox[tid] = 0x7FFFFFFF;
-    if (tid == 0) *n_edges = 0;
+    if (tid == 0) {
+        *n_edges = 0;
+        slot[PX_DUMMY_SLOT / 4] = NONE32;
+    }
+    if (E2I == 0 && tid < (uint32_t) (2 * PX_RMAX + 1)) dm[tid] = geom.dmask[tid];
     __syncthreads();
     uint32_t pp[PPT];
     bool fits = true;
     {
-        int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mxx = -0x7FFFFFFF, mxy = -0x7FFFFFFF;
+        typedef short short2v __attribute__((ext_vector_type(2)));
+        short2v mn = {0x7FFF, 0x7FFF}, mx = {-0x7FFF, -0x7FFF};
         // all of the thread's loads are issued before the first is used (index clamped instead of a branch around the
         // load): with the load inside `if (i < n)` the compiler waited for each one in turn — up to four serial HBM
         // round trips at the head of every workgroup
@@ -176,11 +220,9 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                 pp[u] = G::pack(v);
                 slot[2 * i] = NONE32;
                 slot[2 * i + 1] = NONE32;
-                const int x = G::sx(pp[u]), y = G::sy(pp[u]);
-                mnx = min(mnx, x);
-                mny = min(mny, y);
-                mxx = max(mxx, x);
-                mxy = max(mxy, y);
+                const short2v c = {(short) G::sx(pp[u]), (short) G::sy(pp[u])};
+                mn = __builtin_elementwise_min(mn, c);  // v_pk_min_i16: both coordinates at once
+                mx = __builtin_elementwise_max(mx, c);
             }
         }
 #ifdef ECAL_PHASE_PROF
@@ -193,26 +235,19 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         }
 #endif
         for (int o = 32; o > 0; o >>= 1) {
-            mnx = min(mnx, __shfl_xor(mnx, o, 64));
-            mny = min(mny, __shfl_xor(mny, o, 64));
-            mxx = max(mxx, __shfl_xor(mxx, o, 64));
-            mxy = max(mxy, __shfl_xor(mxy, o, 64));
+            const int a = __shfl_xor(__builtin_bit_cast(int, mn), o, 64), b = __shfl_xor(__builtin_bit_cast(int, mx), o, 64);
+            mn = __builtin_elementwise_min(mn, __builtin_bit_cast(short2v, a));
+            mx = __builtin_elementwise_max(mx, __builtin_bit_cast(short2v, b));
         }
-        if ((tid & 63) == 0 && mnx != 0x7FFFFFFF) {
-            atomicMin(&bbox[0], mnx);
-            atomicMin(&bbox[1], mny);
-            atomicMin(&bbox[2], -mxx);
-            atomicMin(&bbox[3], -mxy);
+        if ((tid & 63) == 0 && mn.x != 0x7FFF) {
+            atomicMin(&bbox[0], (int) mn.x);
+            atomicMin(&bbox[1], (int) mn.y);
+            atomicMin(&bbox[2], -(int) mx.x);
+            atomicMin(&bbox[3], -(int) mx.y);
         }
     }
     if (block_any(!fits, anyf, any_round)) PX_BAIL();
-    G geo;
-    geo.init(eps);
-    int Rr = (int) floor(sqrt((double) geo.e2i));
-    while ((long long) (Rr + 1) * (Rr + 1) <= (long long) geo.e2i) Rr++;
-    while ((long long) Rr * Rr > (long long) geo.e2i) Rr--;
-    const int Rd = Rr;
-    if (Rd > PX_RMAX || !(eps < 1073741824.0)) PX_BAIL();
+    if (Rd > PX_RMAX) PX_BAIL();
     const int ox = bbox[0] - Rd, oy = bbox[1] - Rd;
     const uint32_t W = (uint32_t) (-bbox[2] - bbox[0] + 1 + 2 * Rd), H = (uint32_t) (-bbox[3] - bbox[1] + 1 + 2 * Rd);
     // 64-bit window fetches may read the first word of the next row (or the spare word after the last row):
@@ -230,10 +265,12 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     PX_STOP(1, me[u] + W + H);
 
     // ---------------- B: kd_insert replay -> prune bits ----------------
-    uint32_t st[PPT], f[PPT];
+    uint32_t sl[PPT], sh[PPT], fb[PPT], f[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
-        st[u] = R::PLACED;
+        sl[u] = ~0u;
+        sh[u] = 0;
+        fb[u] = 2;
         f[u] = 0;
     }
     // B.0: wave 0 alone replays the first KTOP insertions (wave-synchronous, no block barrier)
@@ -243,16 +280,15 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         const uint32_t x0 = px_wx(*rootw);
         const uint32_t i = tid;
         if (i > 0 && i < n) {
-            const uint32_t side = (mcx[0] < x0) ? 0u : 1u;
             f[0] |= (mcx[0] == x0) ? 1u : 0u;
-            atomicMin(&slot[side], me[0]);
-            st[0] = side ? R::SIDE : 0u;
+            sl[0] = (mcx[0] < x0) ? 0u : 4u;  // children of the root split on y: sh = 0, fb = 2
+            atomicMin(reinterpret_cast<uint32_t *>(slotb + sl[0]), me[0]);
         }
         for (;;) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bool act = false;
-            if (!(st[0] & R::PLACED)) act = px_level_step(slot, i, me[0], st[0], f[0]);
+            if (sl[0] != ~0u) act = px_level_step(slotb, i, me[0], sl[0], sh[0], fb[0], f[0]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (!__any(act)) break;
@@ -260,55 +296,65 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     }
     __syncthreads();
     ECAL_PHASE_MARK(12);
-    // B.1: every later point walks the finished top tree (reads only); the walks of a thread's points advance
-    // together so their LDS round trips overlap
+    // B.1: every later point walks the finished top tree (reads only).  All walks start at the root together and
+    // go down one level per step, so the splitting dimension is the same for the whole wave (no per-lane selects);
+    // the walks of a thread's points advance together so their LDS round trips overlap; a walk that has ended keeps
+    // reading its empty slot (nobody writes during B.1).
     {
         const uint32_t x0 = px_wx(*rootw);
-        uint32_t a[PPT], d[PPT], side[PPT];
-        bool go[PPT];
+        uint32_t a2[PPT], dl[PPT], fcx[PPT], fcy[PPT];
+        bool ulive[PPT];
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
             const uint32_t i = tid + u * T;
-            go[u] = i < n && i >= KTOP;
-            a[u] = 0;
-            d[u] = 0;
-            side[u] = (mcx[u] < x0) ? 0u : 1u;
-            if (go[u]) f[u] |= (mcx[u] == x0) ? 1u : 0u;
+            const bool go = i < n && i >= KTOP;
+            ulive[u] = wbase + u * T < n && wbase + u * T + 63u >= KTOP;
+            a2[u] = go ? ((mcx[u] < x0) ? 0u : 4u) : PX_DUMMY_SLOT;
+            dl[u] = 0;
+            fcx[u] = (go && mcx[u] == x0) ? 1u : 0u;
+            fcy[u] = 0;
         }
-        for (;;) {
+        auto walk = [&](auto dim) -> bool {
+            constexpr int D = decltype(dim)::value;
             uint32_t cw[PPT];
             bool any = false;
 #pragma unroll
-            for (int u = 0; u < PPT; u++) cw[u] = slot[go[u] ? 2 * a[u] + side[u] : 0u];
+            for (int u = 0; u < PPT; u++)
+                if (ulive[u]) cw[u] = *reinterpret_cast<const uint32_t *>(slotb + a2[u]);
 #pragma unroll
             for (int u = 0; u < PPT; u++) {
-                go[u] = go[u] && cw[u] != NONE32;
-                any = any || go[u];
-            }
-            if (!any) break;
-#pragma unroll
-            for (int u = 0; u < PPT; u++) {
-                if (go[u]) {
-                    a[u] = cw[u] >> 22;
-                    d[u] ^= 1u;
-                    const uint32_t sv = d[u] ? myy[u] : mcx[u], cv = d[u] ? px_wy(cw[u]) : px_wx(cw[u]);
-                    side[u] = sv < cv ? 0u : 1u;
-                    f[u] |= (sv == cv) ? (1u << d[u]) : 0u;
+                if (ulive[u] && cw[u] != NONE32) {
+                    any = true;
+                    const uint32_t sv = D ? myy[u] : mcx[u], cv = D ? px_wy(cw[u]) : px_wx(cw[u]);
+                    if (D) fcy[u] += (sv == cv) ? 1u : 0u;
+                    else fcx[u] += (sv == cv) ? 1u : 0u;
+                    a2[u] = ((cw[u] >> 22) << 3) | (sv < cv ? 0u : 4u);
+                    dl[u] = D;
                 }
             }
+            return any;
+        };
+        for (;;) {
+            if (!walk(std::integral_constant<int, 1>())) break;
+            if (!walk(std::integral_constant<int, 0>())) break;
         }
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
             const uint32_t i = tid + u * T;
-            if (i < n && i >= KTOP) st[u] = a[u] | (d[u] ? R::DIR : 0u) | (side[u] ? R::SIDE : 0u);
+            if (i < n && i >= KTOP) {
+                f[u] |= (fcx[u] ? 1u : 0u) | (fcy[u] ? 2u : 0u);
+                sl[u] = a2[u];                // the empty slot under the last top-tree node: bid for it
+                sh[u] = dl[u] ? 11u : 0u;     // its winner splits on the other dimension
+                fb[u] = dl[u] ? 1u : 2u;
+            }
         }
     }
-    PX_STOP(2, st[u] ^ (f[u] << 28));
+    PX_STOP(2, sl[u] ^ (f[u] << 28) ^ sh[u]);
     __syncthreads();  // every walk is done before the first bid changes a slot
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         const uint32_t i = tid + u * T;
-        if (i < n && i >= KTOP) atomicMin(&slot[2 * (st[u] & R::MASK) + ((st[u] & R::SIDE) ? 1u : 0u)], me[u]);
+        if (i < n && i >= KTOP) atomicMin(reinterpret_cast<uint32_t *>(slotb + sl[u]), me[u]);
     }
     __syncthreads();
     ECAL_PHASE_MARK(13);
@@ -317,26 +363,19 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         bool active = false;
 #pragma unroll
         for (int u = 0; u < PPT; u++)
-            if (!(st[u] & R::PLACED)) active |= px_level_step(slot, tid + u * T, me[u], st[u], f[u]);
+            if (sl[u] != ~0u) active |= px_level_step(slotb, tid + u * T, me[u], sl[u], sh[u], fb[u], f[u]);
 #ifdef ECAL_PHASE_PROF
         levels__++;
 #endif
         if (!block_any(active, anyf, any_round)) break;
     }
     ECAL_PHASE_MARK(14);
-    PX_STOP(3, st[u] ^ (f[u] << 28));
     ECAL_PHASE_MARK(0);
     ECAL_PHASE_COUNT(8, levels__);
+    PX_STOP(3, sl[u] ^ (f[u] << 28));
 
     // ---------------- bitmap of the points (the child slots are dead: same LDS) ----------------
     for (uint32_t k = tid; k < H * RW; k += T) bm[k] = 0;
-    if (tid <= (uint32_t) (2 * Rd)) {
-        const int dy = (int) tid - Rd;
-        int w = (int) floor(sqrt((double) (geo.e2i - dy * dy)));
-        while ((long long) (w + 1) * (w + 1) + (long long) dy * dy <= (long long) geo.e2i) w++;
-        while ((long long) w * w + (long long) dy * dy > (long long) geo.e2i) w--;
-        hw[tid] = (uint16_t) w;
-    }
     __syncthreads();
     bool bad = false;
 #pragma unroll
@@ -375,13 +414,11 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     __syncthreads();
     auto rank_of = [&](uint32_t cx, uint32_t yy) -> uint32_t {
         const uint32_t w = yy * RW + (cx >> 5);
-        return (uint32_t) rowstart[yy] + (uint32_t) wpre[w] + (uint32_t) __popc(bm[w] & ((1u << (cx & 31u)) - 1u));
+        return (uint32_t) rowstart[yy] + (uint32_t) wpre[w] + (uint32_t) __popc(__builtin_amdgcn_ubfe(bm[w], 0u, cx & 31u));
     };
-    auto window = [&](uint32_t row, uint32_t lo, uint32_t nbits) -> uint32_t {  // nbits <= 31 bits from column lo
-        const uint32_t w = row * RW + (lo >> 5);
-        const unsigned long long two = ((unsigned long long) bm[w + 1] << 32) | bm[w];
-        return (uint32_t) (two >> (lo & 31u)) & ((1u << nbits) - 1u);
-    };
+    // the 2 Rd + 1 columns from c0 of one bitmap row (word index a = row * RW + (c0 >> 5), sh5 = c0 & 31)
+    auto window = [&](uint32_t a, uint32_t sh5) -> uint32_t { return __builtin_amdgcn_alignbit(bm[a + 1], bm[a], sh5); };
+    auto mask_of = [&](int k) -> uint32_t { return E2I > 0 ? px_disc_mask(E2I, px_isqrt(E2I), k) : dm[k]; };
     uint32_t myrk[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
@@ -389,97 +426,120 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         myrk[u] = 0;
         if (i < n) {
             myrk[u] = rank_of(mcx[u], myy[u]);
-            pid_s[myrk[u]] = (uint16_t) i;
-            sflags[myrk[u]] = (uint8_t) f[u];
+            pf[myrk[u]] = (uint16_t) (i | (f[u] << 10));
         }
     }
     __syncthreads();
     ECAL_PHASE_MARK(5);
-    PX_STOP(4, myrk[u] + pid_s[i] + sflags[i]);
-    const bool eps_int = geo.epsi <= Rd;  // |delta| == eps needs an integral eps (then epsi == R)
+    PX_STOP(4, myrk[u] + pf[i]);
     // ---------------- D: core test ----------------
     bool core[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         const uint32_t i = tid + u * T;
         core[u] = false;
-        if (i < n) {
-            const uint32_t cx = mcx[u], yy = myy[u];
-            uint32_t cnt = 0;
-            for (int dy = -Rd; dy <= Rd; dy++) {
-                const uint32_t w = hw[dy + Rd];
-                cnt += (uint32_t) __popc(window(yy + dy, cx - w, 2u * w + 1u));
+        if (wbase + u * T < n && i < n) {
+            const uint32_t cx = mcx[u], yy = myy[u], c0 = cx - (uint32_t) Rd, sh5 = c0 & 31u;
+            uint32_t a = (yy - (uint32_t) Rd) * RW + (c0 >> 5);
+            uint32_t cnt = 0, vmid = 0, vlast = 0;
+            if constexpr (E2I > 0) {
+#pragma unroll
+                for (int k = 0; k <= 2 * px_isqrt(E2I); k++) {
+                    const uint32_t v = window(a, sh5);
+                    cnt += (uint32_t) __popc(v & mask_of(k));
+                    if (k == px_isqrt(E2I)) vmid = v;
+                    if (k == 2 * px_isqrt(E2I)) vlast = v;
+                    a += RW;
+                }
+            } else {
+                for (int k = 0; k <= 2 * Rd; k++) {
+                    const uint32_t v = window(a, sh5);
+                    cnt += (uint32_t) __popc(v & mask_of(k));
+                    vmid = (k == Rd) ? v : vmid;
+                    vlast = v;
+                    a += RW;
+                }
             }
             cnt -= 1u;  // the point itself
             if (eps_int && cnt >= minpts) {
                 // a neighbour at exactly (+eps, 0) / (0, +eps) carrying the matching bit is invisible from here
-                const uint32_t e = (uint32_t) geo.epsi;
-                if (bm[yy * RW + ((cx + e) >> 5)] >> ((cx + e) & 31u) & 1u)
-                    if (sflags[rank_of(cx + e, yy)] & 1u) cnt--;
-                if (bm[(yy + e) * RW + (cx >> 5)] >> (cx & 31u) & 1u)
-                    if (sflags[rank_of(cx, yy + e)] & 2u) cnt--;
+                if ((vmid >> (2 * Rd)) & 1u)
+                    if (pf[rank_of(cx + (uint32_t) Rd, yy)] & (1u << 10)) cnt--;
+                if ((vlast >> Rd) & 1u)
+                    if (pf[rank_of(cx, yy + (uint32_t) Rd)] & (2u << 10)) cnt--;
             }
             core[u] = cnt >= minpts;
             parent[i] = core[u] ? i : NONE32;
-            // the core bit joins the flag byte right away: concurrent readers of this phase only look at bits 0-1,
-            // which are the same in the old and the new byte
-            if (core[u]) sflags[myrk[u]] = (uint8_t) (f[u] | 16u);
+            // the core bit joins the table entry right away: concurrent readers of this phase only look at the f
+            // bits, which are the same in the old and the new value
+            if (core[u]) pf[myrk[u]] = (uint16_t) (i | (f[u] << 10) | PX_PF_CORE);
         }
     }
     __syncthreads();
     ECAL_PHASE_MARK(2);
-    PX_STOP(5, parent[i] + sflags[i]);
+    PX_STOP(5, parent[i] + pf[i]);
     // ---------------- E.1: union-find over the half disc (rows above, own row to the left) ----------------
+    // d2 <= tlim  <=>  two core points are joined by a two-way edge (in the ball, and not an exactly-eps pair that the
+    // quirk may have cut one way)
+    const int tlim = eps_int ? e2i - 1 : e2i;
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         const uint32_t i = tid + u * T;
-        if (!core[u]) continue;
-        const uint32_t cx = mcx[u], yy = myy[u];
+        if (!(wbase + u * T < n) || !core[u]) continue;
+        const uint32_t cx = mcx[u], yy = myy[u], c0 = cx - (uint32_t) Rd, sh5 = c0 & 31u;
+        const uint32_t a0 = (yy - (uint32_t) Rd) * RW + (c0 >> 5);
         const uint32_t fi = f[u];
-        unsigned long long list = 0;  // up to 8 neighbours: (dy + R) << 5 | bit index, one byte each
+        unsigned long long list = 0;  // up to 8 neighbours: k << 5 | bit index, one byte each (k = dy + Rd <= 7)
         uint32_t nlist = 0;
-        bool overflow = false;
-        for (int dy = -Rd; dy <= 0; dy++) {
-            const uint32_t w = hw[dy + Rd];
-            uint32_t m = window(yy + dy, cx - w, dy == 0 ? w : 2u * w + 1u);  // own row: strictly left of the point
-            while (m) {
-                const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
-                m &= m - 1u;
-                if (nlist < 8u) list |= (unsigned long long) ((((uint32_t) (dy + Rd)) << 5 | b) & 0xFFu) << (8u * nlist);
-                else overflow = true;
-                nlist++;
+        bool overflow = Rd > 7;
+        if (!overflow) {
+            uint32_t a = a0;
+            auto row = [&](int k) {
+                uint32_t m = window(a, sh5) & mask_of(k);
+                if (k == Rd) m &= (1u << Rd) - 1u;  // own row: strictly left of the point
+                while (m) {
+                    const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
+                    m &= m - 1u;
+                    if (nlist < 8u) list |= (unsigned long long) (((uint32_t) k << 5) | b) << (8u * nlist);
+                    else overflow = true;
+                    nlist++;
+                }
+                a += RW;
+            };
+            if constexpr (E2I > 0) {
+#pragma unroll
+                for (int k = 0; k <= px_isqrt(E2I); k++) row(k);
+            } else {
+                for (int k = 0; k <= Rd; k++) row(k);
             }
         }
         uint32_t ri = i;  // current root of i's component
-        // Chain rule: within one row of the disc, a core neighbour at most R to the right of the previous core
-        // neighbour (and not at exactly eps from it, where the quirk may cut the edge) is already joined to it by
-        // its own scan of its row, so joining i with the first of such a run joins i with all of it.
-        int prev_dy = 1;
-        uint32_t prev_x = 0;
-        auto link = [&](int dy, uint32_t b) {
-            const uint32_t w = hw[dy + Rd];
-            const uint32_t nx = cx - w + b, ny = yy + dy;
-            const uint32_t rk = rank_of(nx, ny);
-            if (!(sflags[rk] & 16u)) return;
-            const uint32_t pj = pid_s[rk];
+        // Anchors = neighbours already joined with i (offsets from i).  A neighbour j within a two-way edge of an
+        // anchor a needs no union and not even a look at its table entry: if j is core, a and j are joined by the scan
+        // of whichever of the two comes later in raster order (induction on that order), and a is joined with i.
+        int ax0 = 4096, ay0 = 4096, ax1 = 4096, ay1 = 4096;
+        auto link = [&](int k, uint32_t b) {
+            const int ddx = (int) b - Rd, ddy = k - Rd;
+            {
+                const int ex0 = ddx - ax0, ey0 = ddy - ay0, ex1 = ddx - ax1, ey1 = ddy - ay1;
+                if (__mul24(ex0, ex0) + __mul24(ey0, ey0) <= tlim || __mul24(ex1, ex1) + __mul24(ey1, ey1) <= tlim) return;
+            }
+            const uint32_t nx = c0 + b, ny = yy - (uint32_t) Rd + (uint32_t) k;
+            const uint32_t pfj = pf[rank_of(nx, ny)];
+            if (!(pfj & PX_PF_CORE)) return;
+            const uint32_t pj = pfj & PX_PF_PID;
             // j = i - eps e_d: the query from j misses i exactly when i carries bit d; the query from i always
             // finds j (pruning only hides neighbours on the + side) -> one-way edge i -> j
-            const bool one_way = eps_int && ((dy == 0 && cx - nx == (uint32_t) geo.epsi && (fi & 1u)) ||
-                                             (nx == cx && dy == -geo.epsi && (fi & 2u)));
-            if (one_way) {
-                const uint32_t at = atomicAdd(n_edges, 1u);
-                if (at < PX_EDGE_CAP) {
-                    edges[2 * at] = i;
-                    edges[2 * at + 1] = pj;
+            if (eps_int && fi) {
+                const bool one_way = (k == Rd && b == 0u && (fi & 1u)) || (k == 0 && b == (uint32_t) Rd && (fi & 2u));
+                if (one_way) {
+                    const uint32_t at = atomicAdd(n_edges, 1u);
+                    if (at < PX_EDGE_CAP) {
+                        edges[2 * at] = i;
+                        edges[2 * at + 1] = pj;
+                    }
+                    return;
                 }
-                return;
-            }
-            {
-                const uint32_t dx = nx - prev_x;
-                const bool chained = dy == prev_dy && dx <= (uint32_t) Rd && !(eps_int && dx == (uint32_t) geo.epsi);
-                prev_dy = dy;
-                prev_x = nx;
-                if (chained) return;
             }
             uint32_t rj = uf_find<false>(parent, pj);
             for (;;) {
@@ -492,21 +552,27 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                 }
                 rj = uf_find<false>(parent, rj);
             }
+            ax1 = ax0;
+            ay1 = ay0;
+            ax0 = ddx;
+            ay0 = ddy;
         };
         if (!overflow) {
-            for (uint32_t k = 0; k < nlist; k++) {
-                const uint32_t e = (uint32_t) (list >> (8u * k)) & 0xFFu;
-                link((int) (e >> 5) - Rd, e & 31u);
+            for (uint32_t q = 0; q < nlist; q++) {
+                const uint32_t e = (uint32_t) (list >> (8u * q)) & 0xFFu;
+                link((int) (e >> 5), e & 31u);
             }
-        } else {  // more than 8 earlier neighbours: walk the windows again
-            for (int dy = -Rd; dy <= 0; dy++) {
-                const uint32_t w = hw[dy + Rd];
-                uint32_t m = window(yy + dy, cx - w, dy == 0 ? w : 2u * w + 1u);
+        } else {  // more than 8 earlier neighbours (or a wide disc): walk the windows again
+            uint32_t a = a0;
+            for (int k = 0; k <= Rd; k++) {
+                uint32_t m = window(a, sh5) & mask_of(k);
+                if (k == Rd) m &= (1u << Rd) - 1u;
                 while (m) {
                     const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
                     m &= m - 1u;
-                    link(dy, b);
+                    link(k, b);
                 }
+                a += RW;
             }
         }
     }
@@ -546,7 +612,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     ECAL_PHASE_COUNT(11, m_edges);
     // ---------------- F: seeds ranked in pid order = reference cluster ids ----------------
     const uint32_t *const label = parent;
-    uint16_t *const rank = pid_s;  // rank -> pid table is dead
+    uint16_t *const rank = pf;  // rank -> pid table is dead
     uint32_t total;
     {
         const uint32_t per = (n + T - 1) / T, i0 = tid * per;

@@ -190,7 +190,10 @@ static int set_attrs(ecal_ctx *ctx) {
     if (ctx->attrs_set) return ECAL_OK;
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP0, CAP0 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP0>::bytes));
-    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel),
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int) (PixelLayout::bytes + tier0_pad())));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int) (PixelLayout::bytes + tier0_pad())));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP1, CAP1 / 4>),
@@ -227,15 +230,21 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
 
     // event pixels (integer coordinates, eps < 16): the lean pixel kernel takes every segment it can and lists
     // the others; the general tiers then work that list off with a small grid (it is normally empty)
-    const bool pixel = eps < (double) (PX_RMAX + 1) && !getenv("ECAL_DBSCAN_NO_PIXEL");
+    PxGeom geom;
+    const bool pixel = px_geometry(eps, &geom) && !getenv("ECAL_DBSCAN_NO_PIXEL");
     const uint32_t *todo = nullptr, *todo_count = nullptr;
     uint32_t grid = S;
     if (pixel) {
         if ((rc = ecal_ensure(ctx, ctx->px_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
         uint32_t *cnt = (uint32_t *) ctx->px_todo.ptr, *list = cnt + 4;
         ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(dbscan_pixel_kernel, dim3(S), dim3(PX_T), PixelLayout::bytes + tier0_pad(), st, d_xy, d_seg_off,
-                           d_seg_cnt, eps, minpts, d_labels, d_n_clusters, list, cnt);
+        // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
+        if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC"))
+            hipLaunchKernelGGL(dbscan_pixel_kernel<16>, dim3(S), dim3(PX_T), PixelLayout::bytes + tier0_pad(), st, d_xy,
+                               d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
+        else
+            hipLaunchKernelGGL(dbscan_pixel_kernel<0>, dim3(S), dim3(PX_T), PixelLayout::bytes + tier0_pad(), st, d_xy,
+                               d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
         todo = list;
         todo_count = cnt;
         grid = S < 1024u ? S : 1024u;
