@@ -46,12 +46,35 @@ struct PxGeom {
     int Rd;            // floor(eps) = the disc's radius in pixels, <= PX_RMAX
     uint32_t eps_int;  // eps is integral (== Rd): only then |delta| == eps exists and the pruning quirk can bite
     uint32_t dmask[2 * PX_RMAX + 1];
+    // the half disc (rows above + own row to the left) packed row after row into one word (radius <= 4: 24 bits):
+    // hd_code[p] = k << 5 | b of packed position p (k = dy + Rd, b = column - (cx - Rd))
+    uint8_t hd_code[32];
 };
 
 __host__ __device__ constexpr int px_isqrt(int v) {
     int r = 0;
     while ((long long) (r + 1) * (r + 1) <= (long long) v) r++;
     return r;
+}
+// half-disc row k as a field of its window: lowest column, width, position in the packed word
+__host__ __device__ constexpr int px_hd_low(int e2i, int Rd, int k) { return k == Rd ? 0 : Rd - px_isqrt(e2i - (k - Rd) * (k - Rd)); }
+__host__ __device__ constexpr int px_hd_width(int e2i, int Rd, int k) {
+    return k == Rd ? Rd : 2 * px_isqrt(e2i - (k - Rd) * (k - Rd)) + 1;
+}
+__host__ __device__ constexpr int px_hd_pos(int e2i, int Rd, int k) {
+    int p = 0;
+    for (int j = 0; j < k; j++) p += px_hd_width(e2i, Rd, j);
+    return p;
+}
+// nibble |dy| of the result = 1 + the largest |dx| with dx^2 + dy^2 <= lim (0: none), for |dy| <= 7
+__host__ __device__ constexpr uint32_t px_reach_table(int lim) {
+    uint32_t c = 0;
+    for (int dy = 0; dy < 8; dy++) {
+        const int r = lim - dy * dy;
+        const uint32_t v = r < 0 ? 0u : (uint32_t) (px_isqrt(r) + 1);
+        c |= (v > 15u ? 15u : v) << (4 * dy);
+    }
+    return c;
 }
 __host__ __device__ constexpr uint32_t px_disc_mask(int e2i, int Rd, int k) {
     const int dy = k - Rd;
@@ -66,6 +89,11 @@ inline bool px_geometry(double eps, PxGeom *g) {
     g->Rd = px_isqrt(g->e2i);
     g->eps_int = (eps == floor(eps)) ? 1u : 0u;
     for (int k = 0; k < 2 * PX_RMAX + 1; k++) g->dmask[k] = (k <= 2 * g->Rd) ? px_disc_mask(g->e2i, g->Rd, k) : 0u;
+    for (int p = 0; p < 32; p++) g->hd_code[p] = 0;
+    if (g->Rd <= 4 && px_hd_pos(g->e2i, g->Rd, g->Rd + 1) <= 32)  // only a half disc that fits one word is ever packed
+        for (int k = 0, p = 0; k <= g->Rd; k++)
+            for (int b = px_hd_low(g->e2i, g->Rd, k); b < px_hd_low(g->e2i, g->Rd, k) + px_hd_width(g->e2i, g->Rd, k); b++)
+                g->hd_code[p++] = (uint8_t) (k << 5 | b);
     return g->Rd >= 0 && g->Rd <= PX_RMAX;
 }
 
@@ -74,8 +102,9 @@ struct PixelLayout {
     static constexpr size_t pf_off = 0;                                     // u16[1024]
     static constexpr size_t edges_off = pf_off + 2 * PX_CAP;                // u32[2 * PX_EDGE_CAP]
     static constexpr size_t dm_off = edges_off + 8 * PX_EDGE_CAP;           // u32[32]
+    static constexpr size_t hd_off = dm_off + 128;                          // u8[32]
     // region B: kd child slots during B (+ one dummy word that stays NONE); then the bitmap; after E.1: component labels
-    static constexpr size_t slot_off = dm_off + 128;                        // u32[2 * 1024 + 1]
+    static constexpr size_t slot_off = hd_off + 32;                         // u32[2 * 1024 + 1]
     static constexpr size_t bm_off = slot_off;                              // u32[PX_WORDS]
     static_assert(4 * PX_WORDS >= 8 * PX_CAP + 4, "child slots must fit the bitmap region");
     static constexpr size_t parent_off = bm_off + 4 * PX_WORDS + 16;        // u32[1024] (after one spare bitmap word)
@@ -146,6 +175,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     uint16_t *const pf = reinterpret_cast<uint16_t *>(px_smem + L::pf_off);
     uint32_t *const edges = reinterpret_cast<uint32_t *>(px_smem + L::edges_off);
     uint32_t *const dm = reinterpret_cast<uint32_t *>(px_smem + L::dm_off);
+    uint8_t *const hd = px_smem + L::hd_off;
     unsigned char *const slotb = px_smem + L::slot_off;
     uint32_t *const slot = reinterpret_cast<uint32_t *>(px_smem + L::slot_off);
     uint32_t *const bm = reinterpret_cast<uint32_t *>(px_smem + L::bm_off);
@@ -198,6 +228,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         slot[PX_DUMMY_SLOT / 4] = NONE32;
     }
     if (E2I == 0 && tid < (uint32_t) (2 * PX_RMAX + 1)) dm[tid] = geom.dmask[tid];
+    if (E2I > 0 && tid < 32u) hd[tid] = geom.hd_code[tid];
     __syncthreads();
     uint32_t pp[PPT];
     bool fits = true;
@@ -489,49 +520,30 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         const uint32_t cx = mcx[u], yy = myy[u], c0 = cx - (uint32_t) Rd, sh5 = c0 & 31u;
         const uint32_t a0 = (yy - (uint32_t) Rd) * RW + (c0 >> 5);
         const uint32_t fi = f[u];
-        unsigned long long list = 0;  // up to 8 neighbours: k << 5 | bit index, one byte each (k = dy + Rd <= 7)
-        uint32_t nlist = 0;
-        bool overflow = Rd > 7;
-        if (!overflow) {
-            uint32_t a = a0;
-            auto row = [&](int k) {
-                uint32_t m = window(a, sh5) & mask_of(k);
-                if (k == Rd) m &= (1u << Rd) - 1u;  // own row: strictly left of the point
-                while (m) {
-                    const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
-                    m &= m - 1u;
-                    if (nlist < 8u) list |= (unsigned long long) (((uint32_t) k << 5) | b) << (8u * nlist);
-                    else overflow = true;
-                    nlist++;
-                }
-                a += RW;
-            };
-            if constexpr (E2I > 0) {
-#pragma unroll
-                for (int k = 0; k <= px_isqrt(E2I); k++) row(k);
-            } else {
-                for (int k = 0; k <= Rd; k++) row(k);
-            }
-        }
         uint32_t ri = i;  // current root of i's component
-        // Anchors = neighbours already joined with i (offsets from i).  A neighbour j within a two-way edge of an
-        // anchor a needs no union and not even a look at its table entry: if j is core, a and j are joined by the scan
-        // of whichever of the two comes later in raster order (induction on that order), and a is joined with i.
-        int ax0 = 4096, ay0 = 4096, ax1 = 4096, ay1 = 4096;
-        auto link = [&](int k, uint32_t b) {
-            const int ddx = (int) b - Rd, ddy = k - Rd;
-            {
-                const int ex0 = ddx - ax0, ey0 = ddy - ay0, ex1 = ddx - ax1, ey1 = ddy - ay1;
+        // Anchors = neighbours already joined with i (as k, b).  A neighbour j within a two-way edge of an anchor a
+        // needs no union and not even a look at its table entry: if j is core, a and j are joined by the scan of
+        // whichever of the two comes later in raster order (induction on that order), and a is joined with i.
+        uint32_t ab0 = 4096, ak0 = 0, ab1 = 4096, ak1 = 0;
+        auto link = [&](uint32_t k, uint32_t b) {
+            if constexpr (E2I > 0) {
+                // |dx| < 1 + reach(|dy|): the two-way-edge test without multiplies
+                const uint32_t reach = eps_int ? px_reach_table(E2I - 1) : px_reach_table(E2I);
+                if (__sad(b, ab0, 0u) < __builtin_amdgcn_ubfe(reach, 4u * __sad(k, ak0, 0u), 4u) ||
+                    __sad(b, ab1, 0u) < __builtin_amdgcn_ubfe(reach, 4u * __sad(k, ak1, 0u), 4u))
+                    return;
+            } else {
+                const int ex0 = (int) b - (int) ab0, ey0 = (int) k - (int) ak0, ex1 = (int) b - (int) ab1, ey1 = (int) k - (int) ak1;
                 if (__mul24(ex0, ex0) + __mul24(ey0, ey0) <= tlim || __mul24(ex1, ex1) + __mul24(ey1, ey1) <= tlim) return;
             }
-            const uint32_t nx = c0 + b, ny = yy - (uint32_t) Rd + (uint32_t) k;
+            const uint32_t nx = c0 + b, ny = yy - (uint32_t) Rd + k;
             const uint32_t pfj = pf[rank_of(nx, ny)];
             if (!(pfj & PX_PF_CORE)) return;
             const uint32_t pj = pfj & PX_PF_PID;
             // j = i - eps e_d: the query from j misses i exactly when i carries bit d; the query from i always
             // finds j (pruning only hides neighbours on the + side) -> one-way edge i -> j
             if (eps_int && fi) {
-                const bool one_way = (k == Rd && b == 0u && (fi & 1u)) || (k == 0 && b == (uint32_t) Rd && (fi & 2u));
+                const bool one_way = (k == (uint32_t) Rd && b == 0u && (fi & 1u)) || (k == 0u && b == (uint32_t) Rd && (fi & 2u));
                 if (one_way) {
                     const uint32_t at = atomicAdd(n_edges, 1u);
                     if (at < PX_EDGE_CAP) {
@@ -552,27 +564,63 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                 }
                 rj = uf_find<false>(parent, rj);
             }
-            ax1 = ax0;
-            ay1 = ay0;
-            ax0 = ddx;
-            ay0 = ddy;
+            ab1 = ab0;
+            ak1 = ak0;
+            ab0 = b;
+            ak0 = k;
         };
-        if (!overflow) {
-            for (uint32_t q = 0; q < nlist; q++) {
-                const uint32_t e = (uint32_t) (list >> (8u * q)) & 0xFFu;
-                link((int) (e >> 5), e & 31u);
-            }
-        } else {  // more than 8 earlier neighbours (or a wide disc): walk the windows again
-            uint32_t a = a0;
-            for (int k = 0; k <= Rd; k++) {
-                uint32_t m = window(a, sh5) & mask_of(k);
-                if (k == Rd) m &= (1u << Rd) - 1u;
-                while (m) {
-                    const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
-                    m &= m - 1u;
-                    link(k, b);
-                }
+        if constexpr (E2I > 0) {
+            // the whole half disc as one packed word: a field per row, one loop over its set bits
+            constexpr int RD = px_isqrt(E2I);
+            static_assert(RD <= 4 && px_hd_pos(E2I, RD, RD + 1) <= 32, "the packed half disc must fit 32 bits");
+            uint32_t nm = 0, a = a0;
+#pragma unroll
+            for (int k = 0; k <= RD; k++) {
+                nm |= __builtin_amdgcn_ubfe(window(a, sh5), (uint32_t) px_hd_low(E2I, RD, k), (uint32_t) px_hd_width(E2I, RD, k))
+                      << px_hd_pos(E2I, RD, k);
                 a += RW;
+            }
+            while (nm) {
+                const uint32_t e = hd[__ffs((int) nm) - 1];
+                nm &= nm - 1u;
+                link(e >> 5, e & 31u);
+            }
+        } else {
+            unsigned long long list = 0;  // up to 8 neighbours: k << 5 | bit index, one byte each (k = dy + Rd <= 7)
+            uint32_t nlist = 0;
+            bool overflow = Rd > 7;
+            if (!overflow) {
+                uint32_t a = a0;
+                for (int k = 0; k <= Rd; k++) {
+                    uint32_t m = window(a, sh5) & mask_of(k);
+                    if (k == Rd) m &= (1u << Rd) - 1u;  // own row: strictly left of the point
+                    while (m) {
+                        const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
+                        m &= m - 1u;
+                        if (nlist < 8u) list |= (unsigned long long) (((uint32_t) k << 5) | b) << (8u * nlist);
+                        else overflow = true;
+                        nlist++;
+                    }
+                    a += RW;
+                }
+            }
+            if (!overflow) {
+                for (uint32_t q = 0; q < nlist; q++) {
+                    const uint32_t e = (uint32_t) (list >> (8u * q)) & 0xFFu;
+                    link(e >> 5, e & 31u);
+                }
+            } else {  // more than 8 earlier neighbours (or a wide disc): walk the windows again
+                uint32_t a = a0;
+                for (int k = 0; k <= Rd; k++) {
+                    uint32_t m = window(a, sh5) & mask_of(k);
+                    if (k == Rd) m &= (1u << Rd) - 1u;
+                    while (m) {
+                        const uint32_t b = (uint32_t) __ffs((int) m) - 1u;
+                        m &= m - 1u;
+                        link((uint32_t) k, b);
+                    }
+                    a += RW;
+                }
             }
         }
     }

@@ -142,3 +142,30 @@ def test_pixel_and_general_kernels_agree(ctx):
         assert np.array_equal(la, lb) and np.array_equal(na, nb), (eps, minpts)
         ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)
         assert np.array_equal(la, ref_l) and np.array_equal(na, ref_n), (eps, minpts)
+
+
+def test_compiled_and_generic_disc_agree(ctx):
+    """floor(eps^2) == 16 (the shipped eps = 4) runs the pixel kernel with the disc compiled in (packed half-disc word,
+    multiply-free anchor test); ECAL_DBSCAN_GENERIC_DISC forces the run-time disc on the same input.  Sparse noise
+    around dense arcs gives core points with non-core neighbours; eps = 4.1 has the same disc without the quirk."""
+    rng = np.random.default_rng(5)
+    segs = []
+    for k in range(60):
+        n = int(rng.integers(50, 1000))
+        dense = np.stack([rng.integers(0, 50, n), rng.integers(0, 40, n)], 1)
+        sparse = np.stack([rng.integers(0, 340, n // 3 + 1), rng.integers(0, 250, n // 3 + 1)], 1)
+        p = np.unique(np.concatenate([dense, sparse]), axis=0).astype(np.float64)
+        segs.append(p[rng.permutation(len(p))][:1024])
+    xy = np.concatenate(segs)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint32)
+    for eps, minpts in ((4.0, 2), (4.0, 1), (4.0, 5), (4.1, 2)):
+        os.environ.pop("ECAL_DBSCAN_GENERIC_DISC", None)
+        la, na = ctx.dbscan_batch(xy, off, eps, minpts)
+        os.environ["ECAL_DBSCAN_GENERIC_DISC"] = "1"
+        try:
+            lb, nb = ctx.dbscan_batch(xy, off, eps, minpts)
+        finally:
+            os.environ.pop("ECAL_DBSCAN_GENERIC_DISC", None)
+        assert np.array_equal(la, lb) and np.array_equal(na, nb), (eps, minpts)
+        ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)
+        assert np.array_equal(la, ref_l) and np.array_equal(na, ref_n), (eps, minpts)

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for k in 1 2 3 4 5 6 full; do
+for k in ${PX_STOPS:-1 2 3 4 5 6 full}; do
   lib=$ROOT/build_ab/libecal_stop$k.so
   [ "$k" = full ] && lib=$ROOT/eventcalib_amd/libecal.so
   export ECAL_LIB=$lib
