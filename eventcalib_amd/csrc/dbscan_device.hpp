@@ -298,6 +298,20 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t v) {
     return v;
 }
 
+// Root of v without touching the forest.  The flatten pass (E.2) must use this one: with path halving, a thread that
+// read parent[v] before another thread stored v's root there would overwrite that root with a mere ancestor, and v
+// would come out of the pass unflattened (seen as a wrong label in ~1 of 10^5 segments).  Without the halving stores
+// every store of the pass is a true root, and a walk that meets one simply gets there sooner.
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t uf_root(const uint32_t *parent, uint32_t v) {
+    uint32_t p = ld_shared_word<GLOBAL>(&parent[v]);
+    while (p != v) {
+        v = p;
+        p = ld_shared_word<GLOBAL>(&parent[p]);
+    }
+    return v;
+}
+
 template <bool GLOBAL>
 __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
     for (;;) {
@@ -693,7 +707,7 @@ __device__ __forceinline__ uint32_t dbscan_segment(const DbWork<Idx, G> wk, cons
     if (m_edges <= EDGE_CAP) {
         // E.2 flatten: parent[p] = root of p's two-way component (= its smallest pid)
         for (uint32_t i = tid; i < n; i += T) {
-            if (ld_shared_word<GLOBAL>(&parent[i]) != NONE32) parent[i] = uf_find<GLOBAL>(parent, i);
+            if (ld_shared_word<GLOBAL>(&parent[i]) != NONE32) parent[i] = uf_root<GLOBAL>(parent, i);
         }
         __syncthreads();
         if (m_edges > 0) {

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     // ---------------- E.2 flatten; E.3 one-way edges to the fix-point ----------------
 #pragma unroll
     for (int u = 0; u < PPT; u++)
-        if (core[u]) parent[tid + u * T] = uf_find<false>(parent, tid + u * T);
+        if (core[u]) parent[tid + u * T] = uf_root<false>(parent, tid + u * T);  // read-only walk: see uf_root
     __syncthreads();
     if (m_edges > 0) {
         uint32_t *const comp = bm;  // the bitmap is dead

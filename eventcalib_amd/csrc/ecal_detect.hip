@@ -31,6 +31,11 @@ __device__ unsigned long long g_det_cycles[16];
 #define DET_MARK(idx) do { } while (0)
 #define DET_T0() do { } while (0)
 #endif
+// debug builds (-DECAL_DET_STOP=k, tools/px_stop_probe.sh): leave extract_window after phase k so that instruction
+// counters can be attributed to phases (results stay in LDS / scratch; nothing downstream may run)
+#ifndef ECAL_DET_STOP
+#define ECAL_DET_STOP 0
+#endif
 
 constexpr int DET_T = 256;
 constexpr uint32_t DET_MAXC = 2048;       // DBSCAN clusters per polarity the kernel handles at all
@@ -61,11 +66,21 @@ struct DetGlobal {
     __device__ __forceinline__ double norm(uint32_t li) const { return norms[li]; }
     __device__ __forceinline__ double key(uint32_t li) const { return norms[li]; }  // ordering key of the median
     __device__ __forceinline__ void set_norm(uint32_t li, double v) const { norms[li] = v; }
+    static constexpr bool INT_PIXELS = false;
+    __device__ __forceinline__ bool composite() const { return false; }
+    __device__ __forceinline__ uint32_t member_word(uint32_t, uint32_t i) const { return i; }
+    __device__ __forceinline__ uint32_t ipt(uint32_t) const { return 0; }
 };
 struct DetLds {
     uint32_t *pts;  // x | y << 16, two's complement int16 each (exact: the staged path is taken for integer pixels only)
-    uint16_t *members, *sorted, *koff, *ksize, *rep;
+    uint32_t *members;  // member lists; when `small`: key << 11 | point index (one compare orders by (norm, pid))
+    uint16_t *sorted, *koff, *ksize, *rep;
     int16_t *kept;
+    bool small;  // every |coordinate| <= 1023: x^2 + y^2 < 2^21 leaves 11 bits for the window-local index (< 1408)
+    static constexpr bool INT_PIXELS = true;
+    __device__ __forceinline__ bool composite() const { return small; }
+    __device__ __forceinline__ uint32_t member_word(uint32_t li, uint32_t i) const { return small ? (key(li) << 11) | i : i; }
+    __device__ __forceinline__ uint32_t ipt(uint32_t li) const { return pts[li]; }
     __device__ __forceinline__ double2 pt(uint32_t li) const {
         const uint32_t w = pts[li];
         return make_double2((double) (int) (short) (w & 0xFFFFu), (double) (((int) w) >> 16));
@@ -201,7 +216,7 @@ __device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, u
 }
 
 // base[pol]: window-local offset of the polarity's points (and of its kept-cluster arrays).
-template <typename ST>
+template <bool FIT, typename ST>
 __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&base)[2], const uint32_t (&n_pol)[2],
                                                const int32_t *lab0, const int32_t *lab1, const uint32_t (&nc_pol)[2],
                                                const DetectParams &prm, uint32_t *csize, uint32_t *newid, uint32_t *coff,
@@ -253,7 +268,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
             if (l >= 0 && newid[l] != 0xFFFFFFFFu) {
                 kl = (int32_t) newid[l];
                 const uint32_t at = atomicSub(&csize[l], 1u) - 1u;
-                st.members[o + coff[l] + at] = i;
+                st.members[o + coff[l] + at] = st.member_word(o + i, i);
                 st.set_norm(o + i, norm_of(st.pt(o + i)));
             }
             st.kept[o + i] = kl;
@@ -261,6 +276,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         __syncthreads();
     }
     DET_MARK(1);
+    if (ECAL_DET_STOP == 2) return;
     const uint32_t nk[2] = {nk_sh[0], nk_sh[1]};
     if (nk[0] < prm.need_clusters || nk[1] < prm.need_clusters) {  // :127-129
         if (tid == 0) {
@@ -274,26 +290,36 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     // One scan of its cluster per kept point gives (a) its rank in the order (norm, pid): rank
     // size/2 is the representative (:136-147), and (b) its position in ascending-pid order, which
     // turns the scattered member list into a sorted one.
-    for (int pol = 0; pol < 2; pol++) {
-        const uint32_t o = base[pol], n = n_pol[pol];
-        for (uint32_t i = tid; i < n; i += DET_T) {
-            const int32_t kl = st.kept[o + i];
-            if (kl < 0) continue;
-            const uint32_t m = st.ksize[o + kl], first = o + st.koff[o + kl];
+    // (Both polarities in one loop: 2 x ~580 points leave fewer idle lanes in the last round than 580 twice.)
+    for (uint32_t idx = tid; idx < n_pol[0] + n_pol[1]; idx += DET_T) {
+        const int pol = idx >= n_pol[0] ? 1 : 0;
+        const uint32_t o = base[pol], i = idx - (pol ? n_pol[0] : 0u);
+        const int32_t kl = st.kept[o + i];
+        if (kl < 0) continue;
+        const uint32_t m = st.ksize[o + kl], first = o + st.koff[o + kl];
+        uint32_t rank = 0, at = 0;
+        if (st.composite()) {
+            const uint32_t wi = st.member_word(o + i, i);
+            for (uint32_t t = 0; t < m; t++) {
+                const uint32_t wj = st.members[first + t];
+                rank += (wj < wi) ? 1u : 0u;
+                at += ((wj & 2047u) < i) ? 1u : 0u;
+            }
+        } else {
             const auto ni = st.key(o + i);
-            uint32_t rank = 0, at = 0;
             for (uint32_t t = 0; t < m; t++) {
                 const uint32_t j = st.members[first + t];
                 const auto nj = st.key(o + j);
                 rank += (nj < ni || (nj == ni && j < i)) ? 1u : 0u;
                 at += (j < i) ? 1u : 0u;
             }
-            if (rank == m / 2) st.rep[o + kl] = i;
-            st.sorted[first + at] = i;
         }
+        if (rank == m / 2) st.rep[o + kl] = i;
+        st.sorted[first + at] = i;
     }
     __syncthreads();
     DET_MARK(2);
+    if (ECAL_DET_STOP == 3) return;
     // mutual nearest +/- representatives and the circle test (:283-311); candidates in + cluster order
     // (Dealing the ~40 + clusters of a window round-robin over the four waves was tried: 0.93 -> 1.06 ms.  The kernel
     // is issue bound, and four waves with 10 active lanes issue four times the instructions of one wave with 40.)
@@ -303,7 +329,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         bool ok = false;
         uint32_t ni_best = 0;
         double cx = 0, cy = 0, r = 0;
-        if (pi < nk[0] && prm.fit_circle) {  // :180-281
+        if (FIT && pi < nk[0]) {  // :180-281
             uint32_t n_idx[DET_KNN_MAX], p_idx[DET_KNN_MAX];
             uint32_t real = knn_gated(st, base[1], nk[1], st.pt(base[0] + st.rep[base[0] + pi]), prm.knn, prm.four_thr2,
                                       n_idx);
@@ -344,28 +370,67 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         } else if (pi < nk[0]) {
             const double2 pc = st.pt(base[0] + st.rep[base[0] + pi]);
             double bd = 1.79769313486231570e308;
-            for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
-                const double2 c = st.pt(base[1] + st.rep[base[1] + k]);
-                const double dx = pc.x - c.x, dy = pc.y - c.y;
-                const double d = dx * dx + dy * dy;
-                if (d < bd) {
-                    bd = d;
-                    ni_best = k;
-                }
-            }
-            if (!(bd > prm.four_thr2)) {  // :286
-                const double2 nc = st.pt(base[1] + st.rep[base[1] + ni_best]);
-                double bd2 = 1.79769313486231570e308;
-                uint32_t back = 0;
-                for (uint32_t k = 0; k < nk[0]; k++) {
-                    const double2 c = st.pt(base[0] + st.rep[base[0] + k]);
-                    const double dx = nc.x - c.x, dy = nc.y - c.y;
-                    const double d = dx * dx + dy * dy;
-                    if (d < bd2) {
-                        bd2 = d;
-                        back = k;
+            uint32_t back = 0;
+            bool near = false;
+            bool int_nn = false;
+            if constexpr (ST::INT_PIXELS) int_nn = st.composite();  // |v| <= 1023: no 32-bit overflow below
+            if (int_nn) {
+                // integer pixels: dx^2 + dy^2 is exact in 32-bit integers and orders like the reference's doubles
+                const uint32_t pw = st.ipt(base[0] + st.rep[base[0] + pi]);
+                const int px = (int) (short) (pw & 0xFFFFu), py = ((int) pw) >> 16;
+                uint32_t bi = 0xFFFFFFFFu;
+                for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
+                    const uint32_t cw = st.ipt(base[1] + st.rep[base[1] + k]);
+                    const int dx = px - (int) (short) (cw & 0xFFFFu), dy = py - (((int) cw) >> 16);
+                    const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
+                    if (d < bi) {
+                        bi = d;
+                        ni_best = k;
                     }
                 }
+                if (bi != 0xFFFFFFFFu) bd = (double) bi;
+                if (!(bd > prm.four_thr2)) {  // :286
+                    near = true;
+                    const uint32_t nw = st.ipt(base[1] + st.rep[base[1] + ni_best]);
+                    const int nx = (int) (short) (nw & 0xFFFFu), ny = ((int) nw) >> 16;
+                    uint32_t bi2 = 0xFFFFFFFFu;
+                    for (uint32_t k = 0; k < nk[0]; k++) {
+                        const uint32_t cw = st.ipt(base[0] + st.rep[base[0] + k]);
+                        const int dx = nx - (int) (short) (cw & 0xFFFFu), dy = ny - (((int) cw) >> 16);
+                        const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
+                        if (d < bi2) {
+                            bi2 = d;
+                            back = k;
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
+                    const double2 c = st.pt(base[1] + st.rep[base[1] + k]);
+                    const double dx = pc.x - c.x, dy = pc.y - c.y;
+                    const double d = dx * dx + dy * dy;
+                    if (d < bd) {
+                        bd = d;
+                        ni_best = k;
+                    }
+                }
+                if (!(bd > prm.four_thr2)) {  // :286
+                    near = true;
+                    const double2 nc = st.pt(base[1] + st.rep[base[1] + ni_best]);
+                    double bd2 = 1.79769313486231570e308;
+                    for (uint32_t k = 0; k < nk[0]; k++) {
+                        const double2 c = st.pt(base[0] + st.rep[base[0] + k]);
+                        const double dx = nc.x - c.x, dy = nc.y - c.y;
+                        const double d = dx * dx + dy * dy;
+                        if (d < bd2) {
+                            bd2 = d;
+                            back = k;
+                        }
+                    }
+                }
+            }
+            if (near) {
+                const double2 nc = st.pt(base[1] + st.rep[base[1] + ni_best]);
                 if (back == pi) {
                     cx = (pc.x + nc.x) / 2;
                     cy = (pc.y + nc.y) / 2;
@@ -409,6 +474,9 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     }
 }
 
+// FIT = Params::fitCircle: the algebraic-fit pairing keeps two 3x4 systems in registers; compiled apart so that the
+// default path (fitCircle == 0) stays below 96 VGPRs = five workgroups per CU
+template <bool FIT>
 __global__ __launch_bounds__(DET_T) void extract_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
@@ -447,30 +515,45 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     const uint32_t n_all = n_pol[0] + n_pol[1];
     bool staged = contiguous && n_all <= DET_LDS_PTS && nc_pol[0] <= DET_LDS_MAXC && nc_pol[1] <= DET_LDS_MAXC;
     uint32_t *csize = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *const lds_pts = reinterpret_cast<uint32_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t) + 6 * DET_LDS_PTS * sizeof(uint16_t));
+    uint32_t *const lds_pts = reinterpret_cast<uint32_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t) + 5 * DET_LDS_PTS * sizeof(uint16_t) +
+                                                           DET_LDS_PTS * sizeof(uint32_t));
     DET_T0();
+    bool small_px = false;
     if (staged) {  // stage the points packed; a coordinate that does not pack exactly sends the window to the global path
-        bool fits = true;
+        bool fits = true, large = false;
         for (uint32_t i = tid; i < n_all; i += DET_T) {
             const double2 v = pts[o_pol[0] + i];
             fits = fits && v.x == floor(v.x) && v.y == floor(v.y) && fabs(v.x) <= 32767.0 && fabs(v.y) <= 32767.0;
+            large = large || !(fabs(v.x) <= 1023.0 && fabs(v.y) <= 1023.0);
             lds_pts[i] = ((uint32_t) (int) v.x & 0xFFFFu) | ((uint32_t) (int) v.y << 16);
         }
-        staged = !__syncthreads_or(!fits);
+        // bit 0: some coordinate does not pack; bit 1: some coordinate is beyond the composite-key range
+        if (tid == 0) nk_sh[0] = 0;
+        __syncthreads();
+        if (!fits || large) atomicOr(&nk_sh[0], (fits ? 0u : 1u) | (large ? 2u : 0u));
+        __syncthreads();
+        const uint32_t verdict = nk_sh[0];
+        staged = !(verdict & 1);
+        small_px = !(verdict & 2);
         DET_MARK(0);
+        if (ECAL_DET_STOP == 1) {
+            for (uint32_t i = tid; i < n_all; i += DET_T) kept_labels[o_pol[0] + i] = (int32_t) lds_pts[i];
+            return;
+        }
     }
     if (staged) {
         uint16_t *u16 = reinterpret_cast<uint16_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t));
         DetLds st;
-        st.members = u16;
-        st.sorted = u16 + DET_LDS_PTS;
-        st.koff = u16 + 2 * DET_LDS_PTS;
-        st.ksize = u16 + 3 * DET_LDS_PTS;
-        st.rep = u16 + 4 * DET_LDS_PTS;
-        st.kept = reinterpret_cast<int16_t *>(u16 + 5 * DET_LDS_PTS);
+        st.sorted = u16;
+        st.koff = u16 + DET_LDS_PTS;
+        st.ksize = u16 + 2 * DET_LDS_PTS;
+        st.rep = u16 + 3 * DET_LDS_PTS;
+        st.kept = reinterpret_cast<int16_t *>(u16 + 4 * DET_LDS_PTS);
+        st.members = reinterpret_cast<uint32_t *>(u16 + 5 * DET_LDS_PTS);
         st.pts = lds_pts;
+        st.small = small_px;
         const uint32_t base[2] = {0u, n_pol[0]};
-        extract_window(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_LDS_MAXC,
+        extract_window<FIT>(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_LDS_MAXC,
                        csize + 2 * DET_LDS_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
         __syncthreads();
@@ -500,15 +583,16 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         st.kept = kept_labels + w0;
         st.norms = norms + w0;
         const uint32_t base[2] = {o_pol[0] - w0, o_pol[1] - w0};
-        extract_window(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_MAXC,
+        extract_window<FIT>(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_MAXC,
                        csize + 2 * DET_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
     }
 }
 
 constexpr size_t DET_LDS_BYTES_GLOBAL = 3 * DET_MAXC * sizeof(uint32_t);
-constexpr size_t DET_LDS_BYTES_STAGED = 3 * DET_LDS_MAXC * sizeof(uint32_t) + 6 * DET_LDS_PTS * sizeof(uint16_t) +
-                                        DET_LDS_PTS * sizeof(uint32_t);
+constexpr size_t DET_LDS_BYTES_STAGED = 3 * DET_LDS_MAXC * sizeof(uint32_t) + 5 * DET_LDS_PTS * sizeof(uint16_t) +
+                                        2 * DET_LDS_PTS * sizeof(uint32_t);
+static_assert(DET_LDS_BYTES_STAGED + 64 <= 32768, "five workgroups per CU");
 constexpr size_t DET_LDS_BYTES = DET_LDS_BYTES_STAGED > DET_LDS_BYTES_GLOBAL ? DET_LDS_BYTES_STAGED : DET_LDS_BYTES_GLOBAL;
 
 }  // namespace ecal
@@ -578,15 +662,24 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
         return ECAL_ERR_INVALID;
     }
     if (!ctx->det_attr_set) {
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel),
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
         ctx->det_attr_set = true;
     }
-    hipLaunchKernelGGL(extract_kernel, dim3(S), dim3(DET_T), DET_LDS_BYTES, (hipStream_t) stream, d_xy, d_seg_off, d_seg_cnt,
-                       d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
-                       (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
-                       (uint32_t *) ctx->det_ksize.ptr, (uint32_t *) ctx->det_sorted.ptr,
-                       (double *) ctx->det_norms.ptr);
+    if (prm.fit_circle)
+        hipLaunchKernelGGL(extract_kernel<true>, dim3(S), dim3(DET_T), DET_LDS_BYTES, (hipStream_t) stream, d_xy, d_seg_off,
+                           d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
+                           (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
+                           (uint32_t *) ctx->det_ksize.ptr, (uint32_t *) ctx->det_sorted.ptr,
+                           (double *) ctx->det_norms.ptr);
+    else
+        hipLaunchKernelGGL(extract_kernel<false>, dim3(S), dim3(DET_T), DET_LDS_BYTES, (hipStream_t) stream, d_xy, d_seg_off,
+                           d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
+                           (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
+                           (uint32_t *) ctx->det_ksize.ptr, (uint32_t *) ctx->det_sorted.ptr,
+                           (double *) ctx->det_norms.ptr);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

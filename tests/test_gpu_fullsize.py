@@ -111,3 +111,31 @@ def test_oracle_spot_checks(run):
             assert np.array_equal(pipe.xy[o:o + n].cpu().numpy(), pts)
             rc, lab, nc = O.dbscan(pts, 4.0, 2)
             assert np.array_equal(pipe.labels[o:o + n].cpu().numpy(), lab)
+
+
+def test_pixel_kernel_equals_general_tiers_repeatedly(run):
+    """The pixel DBSCAN kernel against the general tiers (ECAL_DBSCAN_NO_PIXEL) on every segment of the stream, eight
+    runs: 13 k segments x 8 is what it takes to see a one-in-10^5 ordering race between workgroup threads (the
+    flatten pass once lost a root to a concurrent path-halving store)."""
+    import os
+    ctx, pipe, ev, t0, t1, torch = run
+    from eventcalib_amd.pipeline import DetectPipeline
+    S = len(t0)
+    p2 = DetectPipeline(ctx)
+    p2.set_windows(t0, t1)
+    os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
+    try:
+        p2.run(ev, detect=False)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+    ref_l, ref_n = p2.labels.clone(), p2.n_clusters[:2 * S].clone()
+    off, cnt = p2.seg_off[:2 * S].long(), p2.seg_cnt[:2 * S].long()
+    used = torch.repeat_interleave(off, cnt) + (torch.arange(int(cnt.sum()), device="cuda") -
+                                               torch.repeat_interleave(torch.cumsum(cnt, 0) - cnt, cnt))
+    for rep in range(8):
+        p2.labels.fill_(-7)
+        p2.run(ev, detect=False)
+        torch.cuda.synchronize()
+        assert torch.equal(p2.n_clusters[:2 * S], ref_n), rep
+        assert torch.equal(p2.labels[used], ref_l[used]), rep
