@@ -39,8 +39,8 @@ __device__ unsigned long long g_det_cycles[16];
 
 constexpr int DET_T = 256;
 constexpr uint32_t DET_MAXC = 2048;       // DBSCAN clusters per polarity the kernel handles at all
-constexpr uint32_t DET_LDS_PTS = 1408;    // points per window (both polarities) staged in LDS, packed to 4 bytes (5 workgroups/CU) ...
-constexpr uint32_t DET_LDS_MAXC = 512;    // ... when neither polarity has more DBSCAN clusters than this and every
+constexpr uint32_t DET_LDS_PTS = 1408;    // points per window (both polarities) staged in LDS, packed to 4 bytes (6 workgroups/CU) ...
+constexpr uint32_t DET_LDS_MAXC = 384;    // ... when neither polarity has more DBSCAN clusters than this and every
                                           // coordinate is an integer of |v| <= 32767 (event pixels)
 
 struct DetectParams {
@@ -67,6 +67,8 @@ struct DetGlobal {
     __device__ __forceinline__ double key(uint32_t li) const { return norms[li]; }  // ordering key of the median
     __device__ __forceinline__ void set_norm(uint32_t li, double v) const { norms[li] = v; }
     static constexpr bool INT_PIXELS = false;
+    using CIdx = uint32_t;  // renumbered cluster id / first member slot of a DBSCAN cluster
+    static constexpr CIdx CNONE = 0xFFFFFFFFu;
     __device__ __forceinline__ bool composite() const { return false; }
     __device__ __forceinline__ uint32_t member_word(uint32_t, uint32_t i) const { return i; }
     __device__ __forceinline__ uint32_t ipt(uint32_t) const { return 0; }
@@ -78,6 +80,8 @@ struct DetLds {
     int16_t *kept;
     bool small;  // every |coordinate| <= 1023: x^2 + y^2 < 2^21 leaves 11 bits for the window-local index (< 1408)
     static constexpr bool INT_PIXELS = true;
+    using CIdx = uint16_t;
+    static constexpr CIdx CNONE = 0xFFFFu;
     __device__ __forceinline__ bool composite() const { return small; }
     __device__ __forceinline__ uint32_t member_word(uint32_t li, uint32_t i) const { return small ? (key(li) << 11) | i : i; }
     __device__ __forceinline__ uint32_t ipt(uint32_t li) const { return pts[li]; }
@@ -104,13 +108,13 @@ struct CircleFit {
 // ascending pid; the reference sums in its BFS member order — last-bit differences only), then the
 // error of :202-219.  3x3 system solved by Gaussian elimination with partial pivoting (Eigen's lu()).
 template <typename ST>
-__device__ __forceinline__ CircleFit fit_pair(const ST &st, const uint32_t (&base)[2], uint32_t kp, uint32_t kn,
-                                              double thr) {
+__device__ __forceinline__ CircleFit fit_pair(const ST &st, const uint32_t (&base)[2], const uint32_t (&kb)[2], uint32_t kp,
+                                              uint32_t kn, double thr) {
     double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0, sxxx = 0, syyy = 0, sxyy = 0, sxxy = 0;
     uint32_t cnt = 0;
     for (int pol = 0; pol < 2; pol++) {
         const uint32_t o = base[pol], kk = pol ? kn : kp;
-        const uint32_t m = st.ksize[o + kk], first = o + st.koff[o + kk];
+        const uint32_t m = st.ksize[kb[pol] + kk], first = o + st.koff[kb[pol] + kk];
         for (uint32_t t = 0; t < m; t++) {
             const double2 e = st.pt(o + st.sorted[first + t]);
             sx += e.x;
@@ -157,7 +161,7 @@ __device__ __forceinline__ CircleFit fit_pair(const ST &st, const uint32_t (&bas
     f.cy = x[1];
     f.radius = __dsqrt_rn(x[0] * x[0] + x[1] * x[1] + x[2]);
     f.err = 0.0;
-    const double2 pr = st.pt(base[0] + st.rep[base[0] + kp]), nr = st.pt(base[1] + st.rep[base[1] + kn]);
+    const double2 pr = st.pt(base[0] + st.rep[kb[0] + kp]), nr = st.pt(base[1] + st.rep[kb[1] + kn]);
     const double ax = pr.x - nr.x, ay = pr.y - nr.y;
     const double approx = __dsqrt_rn(ax * ax + ay * ay) / 2;
     if (f.radius > thr || f.radius > 2 * approx) {
@@ -166,7 +170,7 @@ __device__ __forceinline__ CircleFit fit_pair(const ST &st, const uint32_t (&bas
     }
     for (int pol = 0; pol < 2; pol++) {
         const uint32_t o = base[pol], kk = pol ? kn : kp;
-        const uint32_t m = st.ksize[o + kk], first = o + st.koff[o + kk];
+        const uint32_t m = st.ksize[kb[pol] + kk], first = o + st.koff[kb[pol] + kk];
         for (uint32_t t = 0; t < m; t++) {
             const double2 e = st.pt(o + st.sorted[first + t]);
             const double ex = e.x - f.cx, ey = e.y - f.cy;
@@ -181,7 +185,7 @@ __device__ __forceinline__ CircleFit fit_pair(const ST &st, const uint32_t (&bas
 // cluster index (nanoflann's order among ties is unpinned); returns how many survive the gates of
 // :187-193 (d > 4 d0 or d > 4 thr^2 cuts the list)
 template <typename ST>
-__device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, uint32_t nk, double2 q, uint32_t K,
+__device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, uint32_t kb_pol, uint32_t nk, double2 q, uint32_t K,
                                               double gate, uint32_t (&idx)[DET_KNN_MAX]) {
     double d2[DET_KNN_MAX];
     for (uint32_t i = 0; i < DET_KNN_MAX; i++) {
@@ -190,7 +194,7 @@ __device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, u
     }
     uint32_t have = 0;
     for (uint32_t k = 0; k < nk; k++) {
-        const double2 c = st.pt(base_pol + st.rep[base_pol + k]);
+        const double2 c = st.pt(base_pol + st.rep[kb_pol + k]);
         const double dx = q.x - c.x, dy = q.y - c.y;
         const double d = dx * dx + dy * dy;
         // insertion into the sorted top-K (strict <: equal distances keep the earlier index first)
@@ -217,15 +221,16 @@ __device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, u
 
 // base[pol]: window-local offset of the polarity's points (and of its kept-cluster arrays).
 template <bool FIT, typename ST>
-__device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&base)[2], const uint32_t (&n_pol)[2],
-                                               const int32_t *lab0, const int32_t *lab1, const uint32_t (&nc_pol)[2],
-                                               const DetectParams &prm, uint32_t *csize, uint32_t *newid, uint32_t *coff,
+__device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&base)[2], const uint32_t (&kb)[2],
+                                               const uint32_t (&n_pol)[2], const int32_t *lab0, const int32_t *lab1,
+                                               const uint32_t (&nc_pol)[2], const DetectParams &prm, uint32_t *csize,
+                                               typename ST::CIdx *newid, typename ST::CIdx *coff,
                                                unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
                                                uint32_t *cand_pair, double *cand_xyr) {
     const uint32_t tid = threadIdx.x;
     DET_T0();
     for (int pol = 0; pol < 2; pol++) {
-        const uint32_t o = base[pol], n = n_pol[pol], nc = nc_pol[pol];
+        const uint32_t o = base[pol], ko = kb[pol], n = n_pol[pol], nc = nc_pol[pol];
         const int32_t *lab = pol ? lab1 : lab0;
         for (uint32_t c = tid; c < nc; c += DET_T) csize[c] = 0;
         __syncthreads();
@@ -248,14 +253,14 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
             block_exscan_pair<DET_T>(k, m, red, &ek, &em, &tk, &tm);
             for (uint32_t c = c0; c < c0 + per && c < nc; c++) {
                 if (csize[c] >= prm.cluster_min) {
-                    newid[c] = ek;
-                    coff[c] = em;
-                    st.koff[o + ek] = em;
-                    st.ksize[o + ek] = csize[c];
+                    newid[c] = (typename ST::CIdx) ek;
+                    coff[c] = (typename ST::CIdx) em;
+                    st.koff[ko + ek] = em;
+                    st.ksize[ko + ek] = csize[c];
                     ek++;
                     em += csize[c];
                 } else {
-                    newid[c] = 0xFFFFFFFFu;
+                    newid[c] = ST::CNONE;
                 }
             }
             if (tid == 0) nk_sh[pol] = tk;
@@ -265,7 +270,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         for (uint32_t i = tid; i < n; i += DET_T) {
             const int32_t l = lab[i];
             int32_t kl = -1;
-            if (l >= 0 && newid[l] != 0xFFFFFFFFu) {
+            if (l >= 0 && newid[l] != ST::CNONE) {
                 kl = (int32_t) newid[l];
                 const uint32_t at = atomicSub(&csize[l], 1u) - 1u;
                 st.members[o + coff[l] + at] = st.member_word(o + i, i);
@@ -296,7 +301,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         const uint32_t o = base[pol], i = idx - (pol ? n_pol[0] : 0u);
         const int32_t kl = st.kept[o + i];
         if (kl < 0) continue;
-        const uint32_t m = st.ksize[o + kl], first = o + st.koff[o + kl];
+        const uint32_t m = st.ksize[kb[pol] + kl], first = o + st.koff[kb[pol] + kl];
         uint32_t rank = 0, at = 0;
         if (st.composite()) {
             const uint32_t wi = st.member_word(o + i, i);
@@ -314,7 +319,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 at += (j < i) ? 1u : 0u;
             }
         }
-        if (rank == m / 2) st.rep[o + kl] = i;
+        if (rank == m / 2) st.rep[kb[pol] + kl] = i;
         st.sorted[first + at] = i;
     }
     __syncthreads();
@@ -331,13 +336,13 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         double cx = 0, cy = 0, r = 0;
         if (FIT && pi < nk[0]) {  // :180-281
             uint32_t n_idx[DET_KNN_MAX], p_idx[DET_KNN_MAX];
-            uint32_t real = knn_gated(st, base[1], nk[1], st.pt(base[0] + st.rep[base[0] + pi]), prm.knn, prm.four_thr2,
+            uint32_t real = knn_gated(st, base[1], kb[1], nk[1], st.pt(base[0] + st.rep[kb[0] + pi]), prm.knn, prm.four_thr2,
                                       n_idx);
             if (real > 0) {
-                CircleFit best = fit_pair(st, base, pi, n_idx[0], prm.thr);
+                CircleFit best = fit_pair(st, base, kb, pi, n_idx[0], prm.thr);
                 uint32_t nmin = 0;
                 for (uint32_t j = 1; j < real; j++) {
-                    const CircleFit f = fit_pair(st, base, pi, n_idx[j], prm.thr);
+                    const CircleFit f = fit_pair(st, base, kb, pi, n_idx[j], prm.thr);
                     if (f.err < best.err) {  // std::min_element: first minimum
                         best = f;
                         nmin = j;
@@ -345,13 +350,13 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
                 if (best.err < 2 / best.radius) {  // :229-230
                     const uint32_t nsel = n_idx[nmin];
-                    real = knn_gated(st, base[0], nk[0], st.pt(base[1] + st.rep[base[1] + nsel]), prm.knn, prm.four_thr2,
+                    real = knn_gated(st, base[0], kb[0], nk[0], st.pt(base[1] + st.rep[kb[1] + nsel]), prm.knn, prm.four_thr2,
                                      p_idx);
                     if (real > 0) {
-                        CircleFit bb = fit_pair(st, base, p_idx[0], nsel, prm.thr);
+                        CircleFit bb = fit_pair(st, base, kb, p_idx[0], nsel, prm.thr);
                         uint32_t pmin = 0;
                         for (uint32_t i = 1; i < real; i++) {
-                            const CircleFit f = fit_pair(st, base, p_idx[i], nsel, prm.thr);
+                            const CircleFit f = fit_pair(st, base, kb, p_idx[i], nsel, prm.thr);
                             if (f.err < bb.err) {
                                 bb = f;
                                 pmin = i;
@@ -368,7 +373,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
             }
         } else if (pi < nk[0]) {
-            const double2 pc = st.pt(base[0] + st.rep[base[0] + pi]);
+            const double2 pc = st.pt(base[0] + st.rep[kb[0] + pi]);
             double bd = 1.79769313486231570e308;
             uint32_t back = 0;
             bool near = false;
@@ -376,11 +381,11 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
             if constexpr (ST::INT_PIXELS) int_nn = st.composite();  // |v| <= 1023: no 32-bit overflow below
             if (int_nn) {
                 // integer pixels: dx^2 + dy^2 is exact in 32-bit integers and orders like the reference's doubles
-                const uint32_t pw = st.ipt(base[0] + st.rep[base[0] + pi]);
+                const uint32_t pw = st.ipt(base[0] + st.rep[kb[0] + pi]);
                 const int px = (int) (short) (pw & 0xFFFFu), py = ((int) pw) >> 16;
                 uint32_t bi = 0xFFFFFFFFu;
                 for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
-                    const uint32_t cw = st.ipt(base[1] + st.rep[base[1] + k]);
+                    const uint32_t cw = st.ipt(base[1] + st.rep[kb[1] + k]);
                     const int dx = px - (int) (short) (cw & 0xFFFFu), dy = py - (((int) cw) >> 16);
                     const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
                     if (d < bi) {
@@ -391,11 +396,11 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 if (bi != 0xFFFFFFFFu) bd = (double) bi;
                 if (!(bd > prm.four_thr2)) {  // :286
                     near = true;
-                    const uint32_t nw = st.ipt(base[1] + st.rep[base[1] + ni_best]);
+                    const uint32_t nw = st.ipt(base[1] + st.rep[kb[1] + ni_best]);
                     const int nx = (int) (short) (nw & 0xFFFFu), ny = ((int) nw) >> 16;
                     uint32_t bi2 = 0xFFFFFFFFu;
                     for (uint32_t k = 0; k < nk[0]; k++) {
-                        const uint32_t cw = st.ipt(base[0] + st.rep[base[0] + k]);
+                        const uint32_t cw = st.ipt(base[0] + st.rep[kb[0] + k]);
                         const int dx = nx - (int) (short) (cw & 0xFFFFu), dy = ny - (((int) cw) >> 16);
                         const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
                         if (d < bi2) {
@@ -406,7 +411,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
             } else {
                 for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
-                    const double2 c = st.pt(base[1] + st.rep[base[1] + k]);
+                    const double2 c = st.pt(base[1] + st.rep[kb[1] + k]);
                     const double dx = pc.x - c.x, dy = pc.y - c.y;
                     const double d = dx * dx + dy * dy;
                     if (d < bd) {
@@ -416,10 +421,10 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
                 if (!(bd > prm.four_thr2)) {  // :286
                     near = true;
-                    const double2 nc = st.pt(base[1] + st.rep[base[1] + ni_best]);
+                    const double2 nc = st.pt(base[1] + st.rep[kb[1] + ni_best]);
                     double bd2 = 1.79769313486231570e308;
                     for (uint32_t k = 0; k < nk[0]; k++) {
-                        const double2 c = st.pt(base[0] + st.rep[base[0] + k]);
+                        const double2 c = st.pt(base[0] + st.rep[kb[0] + k]);
                         const double dx = nc.x - c.x, dy = nc.y - c.y;
                         const double d = dx * dx + dy * dy;
                         if (d < bd2) {
@@ -430,7 +435,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
             }
             if (near) {
-                const double2 nc = st.pt(base[1] + st.rep[base[1] + ni_best]);
+                const double2 nc = st.pt(base[1] + st.rep[kb[1] + ni_best]);
                 if (back == pi) {
                     cx = (pc.x + nc.x) / 2;
                     cy = (pc.y + nc.y) / 2;
@@ -440,7 +445,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                     uint32_t cnt = 0;
                     for (int pol = 0; pol < 2; pol++) {
                         const uint32_t o = base[pol], kk = pol ? ni_best : pi;
-                        const uint32_t m = st.ksize[o + kk], first = o + st.koff[o + kk];
+                        const uint32_t m = st.ksize[kb[pol] + kk], first = o + st.koff[kb[pol] + kk];
                         for (uint32_t t = 0; t < m; t++) {  // ascending pid
                             const double2 e = st.pt(o + st.sorted[first + t]);
                             const double ex = e.x - cx, ey = e.y - cy;
@@ -473,6 +478,22 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         info[3] = 0;
     }
 }
+
+// LDS of the staged path: per DBSCAN cluster (csize u32: atomics; newid, coff), per kept cluster and polarity (koff,
+// ksize, rep), per point (sorted, kept, members, pts)
+struct DetLdsLayout {
+    static constexpr size_t csize_off = 0;                                          // u32[MAXC]
+    static constexpr size_t newid_off = csize_off + 4 * DET_LDS_MAXC;              // u16[MAXC]
+    static constexpr size_t coff_off = newid_off + 2 * DET_LDS_MAXC;               // u16[MAXC]
+    static constexpr size_t koff_off = coff_off + 2 * DET_LDS_MAXC;                // u16[2 * MAXC]
+    static constexpr size_t ksize_off = koff_off + 4 * DET_LDS_MAXC;               // u16[2 * MAXC]
+    static constexpr size_t rep_off = ksize_off + 4 * DET_LDS_MAXC;                // u16[2 * MAXC]
+    static constexpr size_t sorted_off = rep_off + 4 * DET_LDS_MAXC;               // u16[PTS]
+    static constexpr size_t kept_off = sorted_off + 2 * DET_LDS_PTS;               // i16[PTS]
+    static constexpr size_t members_off = kept_off + 2 * DET_LDS_PTS;              // u32[PTS]
+    static constexpr size_t pts_off = members_off + 4 * DET_LDS_PTS;               // u32[PTS]
+    static constexpr size_t bytes = pts_off + 4 * DET_LDS_PTS;
+};
 
 // FIT = Params::fitCircle: the algebraic-fit pairing keeps two 3x4 systems in registers; compiled apart so that the
 // default path (fitCircle == 0) stays below 96 VGPRs = five workgroups per CU
@@ -515,8 +536,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     const uint32_t n_all = n_pol[0] + n_pol[1];
     bool staged = contiguous && n_all <= DET_LDS_PTS && nc_pol[0] <= DET_LDS_MAXC && nc_pol[1] <= DET_LDS_MAXC;
     uint32_t *csize = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *const lds_pts = reinterpret_cast<uint32_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t) + 5 * DET_LDS_PTS * sizeof(uint16_t) +
-                                                           DET_LDS_PTS * sizeof(uint32_t));
+    uint32_t *const lds_pts = reinterpret_cast<uint32_t *>(smem + DetLdsLayout::pts_off);
     DET_T0();
     bool small_px = false;
     if (staged) {  // stage the points packed; a coordinate that does not pack exactly sends the window to the global path
@@ -542,19 +562,20 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         }
     }
     if (staged) {
-        uint16_t *u16 = reinterpret_cast<uint16_t *>(smem + 3 * DET_LDS_MAXC * sizeof(uint32_t));
         DetLds st;
-        st.sorted = u16;
-        st.koff = u16 + DET_LDS_PTS;
-        st.ksize = u16 + 2 * DET_LDS_PTS;
-        st.rep = u16 + 3 * DET_LDS_PTS;
-        st.kept = reinterpret_cast<int16_t *>(u16 + 4 * DET_LDS_PTS);
-        st.members = reinterpret_cast<uint32_t *>(u16 + 5 * DET_LDS_PTS);
+        using LL = DetLdsLayout;
+        st.sorted = reinterpret_cast<uint16_t *>(smem + LL::sorted_off);
+        st.koff = reinterpret_cast<uint16_t *>(smem + LL::koff_off);
+        st.ksize = reinterpret_cast<uint16_t *>(smem + LL::ksize_off);
+        st.rep = reinterpret_cast<uint16_t *>(smem + LL::rep_off);
+        st.kept = reinterpret_cast<int16_t *>(smem + LL::kept_off);
+        st.members = reinterpret_cast<uint32_t *>(smem + LL::members_off);
         st.pts = lds_pts;
         st.small = small_px;
         const uint32_t base[2] = {0u, n_pol[0]};
-        extract_window<FIT>(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_LDS_MAXC,
-                       csize + 2 * DET_LDS_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
+        const uint32_t kb[2] = {0u, DET_LDS_MAXC};  // per-cluster arrays: one block of DET_LDS_MAXC per polarity
+        extract_window<FIT>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize,
+                       reinterpret_cast<uint16_t *>(smem + LL::newid_off), reinterpret_cast<uint16_t *>(smem + LL::coff_off), red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
         __syncthreads();
 #ifdef ECAL_PHASE_PROF
@@ -563,7 +584,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         for (uint32_t i = tid; i < n_all; i += DET_T) kept_labels[o_pol[0] + i] = st.kept[i];
         if (nk_sh[0] >= prm.need_clusters && nk_sh[1] >= prm.need_clusters) {  // representatives exist only then
             for (int pol = 0; pol < 2; pol++)
-                for (uint32_t k = tid; k < nk_sh[pol]; k += DET_T) rep[o_pol[pol] + k] = st.rep[base[pol] + k];
+                for (uint32_t k = tid; k < nk_sh[pol]; k += DET_T) rep[o_pol[pol] + k] = st.rep[kb[pol] + k];
         }
         DET_MARK(4);
         if (tid == 0) {
@@ -583,16 +604,15 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         st.kept = kept_labels + w0;
         st.norms = norms + w0;
         const uint32_t base[2] = {o_pol[0] - w0, o_pol[1] - w0};
-        extract_window<FIT>(st, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_MAXC,
+        extract_window<FIT>(st, base, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_MAXC,
                        csize + 2 * DET_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
     }
 }
 
 constexpr size_t DET_LDS_BYTES_GLOBAL = 3 * DET_MAXC * sizeof(uint32_t);
-constexpr size_t DET_LDS_BYTES_STAGED = 3 * DET_LDS_MAXC * sizeof(uint32_t) + 5 * DET_LDS_PTS * sizeof(uint16_t) +
-                                        2 * DET_LDS_PTS * sizeof(uint32_t);
-static_assert(DET_LDS_BYTES_STAGED + 64 <= 32768, "five workgroups per CU");
+constexpr size_t DET_LDS_BYTES_STAGED = DetLdsLayout::bytes;
+static_assert(DET_LDS_BYTES_STAGED + 64 <= 26624, "six workgroups per CU");
 constexpr size_t DET_LDS_BYTES = DET_LDS_BYTES_STAGED > DET_LDS_BYTES_GLOBAL ? DET_LDS_BYTES_STAGED : DET_LDS_BYTES_GLOBAL;
 
 }  // namespace ecal

@@ -138,3 +138,23 @@ def test_fit_circle_path(env, knn_num):
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, True, knn_num)
     assert exact >= 5
     pipe.set_detect_params(5, 36, THR)
+
+
+def test_translated_pixels_take_the_plain_key_path(env):
+    """Coordinates beyond 1023 do not fit the composite (norm, pid) member word of extract_kernel (x^2 + y^2 must stay
+    below 2^21): such windows are still staged in LDS but rank their cluster members by key and index separately,
+    and search the nearest representative in doubles."""
+    ctx, pipe, torch = env
+    buf = SS.make_stream(60000, rate=2.0e6, device="cpu", seed=44)
+    rec = buf.numpy().reshape(-1, 25)
+    xy = rec[:, 8:24].copy().view(np.float64)
+    xy += np.array([3000.0, 1200.0])
+    rec[:, 8:24] = xy.view(np.uint8)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR)
+    pipe.run(buf.cuda())
+    torch.cuda.synchronize()
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)
+    assert exact + tied >= 3
