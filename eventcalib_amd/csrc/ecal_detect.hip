@@ -263,7 +263,10 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                     newid[c] = ST::CNONE;
                 }
             }
-            if (tid == 0) nk_sh[pol] = tk;
+            if (tid == 0) {
+                nk_sh[pol] = tk;
+                nk_sh[2 + pol] = tm;  // members of kept clusters
+            }
         }
         __syncthreads();
         // per-point renumbered label; member lists (arbitrary order first)
@@ -295,16 +298,19 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     // One scan of its cluster per kept point gives (a) its rank in the order (norm, pid): rank
     // size/2 is the representative (:136-147), and (b) its position in ascending-pid order, which
     // turns the scattered member list into a sorted one.
-    // (Both polarities in one loop: 2 x ~580 points leave fewer idle lanes in the last round than 580 twice.)
-    for (uint32_t idx = tid; idx < n_pol[0] + n_pol[1]; idx += DET_T) {
-        const int pol = idx >= n_pol[0] ? 1 : 0;
-        const uint32_t o = base[pol], i = idx - (pol ? n_pol[0] : 0u);
+    // The loop runs over the member lists, not over the points: neighbouring lanes then work on the same cluster —
+    // equal trip counts (a wave pays for its longest scan) and broadcast LDS reads.  Both polarities in one loop.
+    const uint32_t tm0 = nk_sh[2], tm1 = nk_sh[3];
+    for (uint32_t idx = tid; idx < tm0 + tm1; idx += DET_T) {
+        const int pol = idx >= tm0 ? 1 : 0;
+        const uint32_t o = base[pol];
+        const uint32_t wq = st.members[o + idx - (pol ? tm0 : 0u)];
+        const uint32_t i = st.composite() ? (wq & 2047u) : wq;
         const int32_t kl = st.kept[o + i];
-        if (kl < 0) continue;
         const uint32_t m = st.ksize[kb[pol] + kl], first = o + st.koff[kb[pol] + kl];
         uint32_t rank = 0, at = 0;
         if (st.composite()) {
-            const uint32_t wi = st.member_word(o + i, i);
+            const uint32_t wi = wq;
             for (uint32_t t = 0; t < m; t++) {
                 const uint32_t wj = st.members[first + t];
                 rank += (wj < wi) ? 1u : 0u;
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     // DET_LDS_MAXC entries and the rest of the block for its staged arrays.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
-    __shared__ uint32_t nk_sh[2];
+    __shared__ uint32_t nk_sh[4];  // kept clusters per polarity, their members per polarity
     const uint32_t s = blockIdx.x, tid = threadIdx.x;
     const double2 *pts = reinterpret_cast<const double2 *>(xy);
     uint32_t *info = win_info + 4 * (size_t) s;
