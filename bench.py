@@ -246,7 +246,7 @@ def main():
         # would: all events of the stream / wall time, although the policy skips frameGap after every keyframe.
         # The number of pieces is a property of the HOST in the reference (5 * (hardware threads - 2)); the chain of
         # dependent windows inside a piece is what serialises, so the GPU wants many short pieces.
-        from eventcalib_amd.adaptive import detect_keyframes
+        from eventcalib_amd.adaptive import detect_keyframes, detect_keyframes_device
         ref_pieces = 5 * max(1, (os.cpu_count() or 3) - 2)
         runs = [ref_pieces, 4096] if args.p2_pieces < 0 else [args.p2_pieces]
         out["policy_p2"] = []
@@ -261,8 +261,21 @@ def main():
             out["policy_p2"].append({"value": round(n_events / p2_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2_s, 4),
                                      "pieces": pieces, "host_threads": nth, "lockstep_passes": kf["steps"], "windows_evaluated": kf["windows"],
                                      "keyframes": int(len(kf["time"])),
+                                     "driver": "host",
                                      "note": "adaptive windows + grid ordering + keyframe gate, host-driven (one H2D of the window "
                                              "bounds and one D2H of verdicts + ordered circles per pass)"})
+            # the same policy with the rule on the device (ecal_detect_keyframes): no per-pass host round trip
+            detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts)   # warm-up
+            torch.cuda.synchronize(dev)
+            tp = time.perf_counter()
+            kd = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts)
+            p2d_s = time.perf_counter() - tp
+            out["policy_p2"].append({"value": round(n_events / p2d_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2d_s, 4),
+                                     "pieces": pieces, "host_threads": 1, "lockstep_passes": kd["steps"], "windows_evaluated": kd["windows"],
+                                     "keyframes": int(len(kd["time"])), "driver": "device",
+                                     "same_keyframes_as_host_driver": bool(np.array_equal(kd["time"], kf["time"])),
+                                     "note": "the same policy in one call: five stages + grid ordering + one policy kernel per pass, "
+                                             "enqueued back to back; the host reads a 4-byte counter every 8 passes"})
         pipe.set_windows(t0, t1)
     # ------------------------------------------------------------------------------------------
     # M2: Levenberg-Marquardt iterations/s of the continuous-time solve on the same stream

@@ -78,6 +78,28 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
                 features=np.stack([r[4] for r in keys]) if K else np.zeros((0, n, 3)), steps=steps, windows=windows)
 
 
+def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps=4.0,
+                            minpts=2, rows=9, cols=4, max_passes=0):
+    """Same result as detect_keyframes, with the policy on the device (ecal_detect_keyframes): no per-pass host round trip.
+    Slots and the keyframe capacity are estimated and doubled when the library reports them too small."""
+    n_ev = events.numel() // 25
+    span = max(end_time - start_time, 1e-9)
+    # a pass covers one window of <= 10 steps per piece: twice the mean event count of such spans, to start with
+    cap = int(min(n_ev, piece_num * (2 * 10 * motion_time_step * n_ev / span + 1024)))
+    max_keys = int(span / (8 * motion_time_step)) + piece_num + 64   # one keyframe per window + gap at the very most
+    while True:
+        try:
+            t, d, e, f, passes, windows = capi.detect_keyframes_dev(ctx, events.data_ptr(), n_ev, motion_time_step,
+                                                                    frame_event_num_threshold, piece_num, start_time, end_time, cap,
+                                                                    max_keys, eps, minpts, 5, rows, cols, max_passes=max_passes)
+            break
+        except capi.EcalError as err:
+            if err.status != -6 or (cap >= n_ev and max_keys > 4 * n_ev):
+                raise
+            cap, max_keys = min(n_ev, 2 * cap), 2 * max_keys
+    return dict(time=t, duration=d, events_num=e, features=f, steps=passes, windows=windows)
+
+
 def _detect_pieces(ctx, events, motion_time_step, frame_event_num_threshold, piece_num, which, start_time, end_time, eps, minpts,
                    rows, cols, max_steps):
     """The lock-step loop over the pieces `which` (indices into the piece_num pieces of [start_time, end_time])."""

@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = [
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
-    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_rectify_batch_dev", "ecal_rectify_batch",
+    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
@@ -530,6 +530,38 @@ def detect_stream_tiled(ctx: Context, host_ptr, n_events, t_start, window_len, w
     S = nw.value
     return info[:S], found[:S], (feat[:S] if want_features else None), {"chunks": st.chunks, "max_chunk_events": st.max_chunk_events,
                                                                       "bytes_uploaded": st.bytes_uploaded, "seconds": st.seconds}
+
+
+class AdaptiveParams(ctypes.Structure):
+    _fields_ = [("motion_time_step", ctypes.c_double), ("frame_event_num_threshold", ctypes.c_uint32), ("piece_num", ctypes.c_uint32),
+                ("start_time", ctypes.c_double), ("end_time", ctypes.c_double), ("max_passes", ctypes.c_uint32),
+                ("check_every", ctypes.c_uint32)]
+
+
+def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time,
+                         end_time, cap_points, max_keyframes, eps=4.0, minpts=2, cluster_min=5, rows=9, cols=4,
+                         radius_threshold=15.511363636363637, max_passes=0, check_every=0):
+    """ecal_detect_keyframes (policy on the device).  Returns (time [K], duration [K,2], events_num [K], features [K, rows cols, 3],
+    passes, windows); raises EcalError(-6) when cap_points or max_keyframes is too small."""
+    L = ctx._L
+    vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+    L.ecal_detect_keyframes.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(AdaptiveParams), ctypes.POINTER(DetectParams), u32, u32,
+                                        vp, vp, vp, vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_uint64)]
+    L.ecal_detect_keyframes.restype = ctypes.c_int
+    ap = AdaptiveParams(float(motion_time_step), int(frame_event_num_threshold), int(piece_num), float(start_time), float(end_time),
+                        int(max_passes), int(check_every))
+    prm = DetectParams(float(eps), int(minpts), int(cluster_min), int(rows * cols), float(radius_threshold), 0, 3, int(rows), int(cols))
+    M = rows * cols
+    t = np.empty(max_keyframes)
+    d = np.empty((max_keyframes, 2))
+    e = np.empty(max_keyframes, np.int32)
+    f = np.empty((max_keyframes, M, 3))
+    nk, ps, nw = u32(0), u32(0), ctypes.c_uint64(0)
+    ctx._check(L.ecal_detect_keyframes(ctx._h, d_events, int(n_events), ctypes.byref(ap), ctypes.byref(prm), int(cap_points),
+                                       int(max_keyframes), _ptr(t), _ptr(d), _ptr(e), _ptr(f), ctypes.byref(nk), ctypes.byref(ps),
+                                       ctypes.byref(nw)))
+    K = nk.value
+    return t[:K].copy(), d[:K].copy(), e[:K].astype(np.int64), f[:K].copy(), ps.value, nw.value
 
 
 def detect_pass(ctx: Context, d_events, n_events, t0, t1, cap_points, eps=4.0, minpts=2, cluster_min=5, rows=9, cols=4,

@@ -1,0 +1,317 @@
+// The reference driver's adaptive windowing + keyframe gate with the policy ON THE DEVICE.
+//   MultiProcess::process     event_camera_calib/test/eventCameraCalib.cpp:34-97  (success / slide / grow rule :49-95)
+//   piece construction        event_camera_calib/test/eventCameraCalib.cpp:168-179
+//   EventCalibIni::track      event_camera_calib/src/EventCalibIni.cpp:23-97      (row-line directions :46-57, gate :82)
+// Same deterministic per-piece policy as host/multi_process.hpp and eventcalib_amd/adaptive.py, which drive one
+// ecal_detect_pass per lock-step pass from the host (upload of the window bounds, download of verdicts + circles, the
+// rule in host code: ~2 ms per pass, of which the GPU works ~0.5).  Here a pass is the five detection stages + grid
+// ordering + ONE policy kernel (a thread per piece: gate, keyframe record, next window), all enqueued back to back on
+// one stream; the host only reads a 4-byte "pieces still active" counter every few passes.  Every pass covers ALL
+// pieces: a finished piece has the empty window (+inf, -inf), which every stage skips.
+#include "ecal_ctx.hpp"
+
+#include <math.h>
+
+#include <algorithm>
+#include <numeric>
+
+namespace {
+
+constexpr int AD_MAX_ROWS = 32;
+
+// direction (B, -A) of the total-least-squares line A x + B y + C = 0 through the row's circle centres: eigenvector of the
+// 3x3 Gram matrix of [x y 1] with the smallest eigenvalue (= the right singular vector of EventCalibIni.cpp:46-57), cyclic
+// Jacobi as in host/multi_process.hpp; oriented from the first to the last circle
+__device__ void row_direction(const double *xyr, const int32_t *order, uint32_t cols, double &dx_out, double &dy_out) {
+    double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (uint32_t j = 0; j < cols; j++) {
+        const double r[3] = {xyr[3 * (size_t) order[j]], xyr[3 * (size_t) order[j] + 1], 1.0};
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) M[a][b] += r[a] * r[b];
+    }
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+        for (int a = 0; a < 3; a++)
+            for (int b = a + 1; b < 3; b++) off += M[a][b] * M[a][b];
+        if (off < 1e-300) break;
+        for (int a = 0; a < 3; a++)
+            for (int b = a + 1; b < 3; b++) {
+                if (M[a][b] == 0.0) continue;
+                const double th = 0.5 * atan2(2 * M[a][b], M[b][b] - M[a][a]);
+                const double c = cos(th), s = sin(th);
+                for (int k = 0; k < 3; k++) {
+                    const double mka = M[k][a], mkb = M[k][b];
+                    M[k][a] = c * mka - s * mkb;
+                    M[k][b] = s * mka + c * mkb;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double mak = M[a][k], mbk = M[b][k];
+                    M[a][k] = c * mak - s * mbk;
+                    M[b][k] = s * mak + c * mbk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    const double vka = V[k][a], vkb = V[k][b];
+                    V[k][a] = c * vka - s * vkb;
+                    V[k][b] = s * vka + c * vkb;
+                }
+            }
+    }
+    int m = 0;
+    for (int a = 1; a < 3; a++)
+        if (M[a][a] < M[m][m]) m = a;
+    double dx = V[1][m], dy = -V[0][m];
+    const double sx = xyr[3 * (size_t) order[cols - 1]] - xyr[3 * (size_t) order[0]];
+    const double sy = xyr[3 * (size_t) order[cols - 1] + 1] - xyr[3 * (size_t) order[0] + 1];
+    if (dx * sx + dy * sy < 0) {
+        dx = -dx;
+        dy = -dy;
+    }
+    dx_out = dx;
+    dy_out = dy;
+}
+
+struct AdaptiveArrays {
+    double *first, *second, *bound_hi, *ref_t, *ref_dir;  // [P], [P], [P], [P], [P][rows][2]
+    uint32_t *active, *have_ref;                          // [P]
+    uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: unused
+    unsigned long long *windows;                          // windows evaluated
+};
+
+__global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_time, double ln, AdaptiveArrays st, double *t0, double *t1) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) {
+        st.counters[0] = st.counters[1] = st.counters[2] = st.counters[3] = 0;
+        *st.windows = 0;
+    }
+    if (k >= P) return;
+    const double step = (end_time - start_time) / (double) P;  // eventCameraCalib.cpp:168-179
+    const double hi = end_time - step * (double) k, first = end_time - step * (double) (k + 1), second = first + ln;
+    st.bound_hi[k] = hi;
+    st.first[k] = first;
+    st.second[k] = second;
+    const bool act = second < hi;
+    st.active[k] = act ? 1u : 0u;
+    st.have_ref[k] = 0;
+    st.ref_t[k] = 0;
+    t0[k] = act ? first : INFINITY;
+    t1[k] = act ? second : -INFINITY;
+}
+
+// one thread per piece: verdict of the pass -> gate -> keyframe record -> next window
+__global__ void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t pass, const uint32_t *__restrict__ win_info,
+                                     const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+                                     const double *__restrict__ cand_xyr, const int32_t *__restrict__ order,
+                                     const uint32_t *__restrict__ found, AdaptiveArrays st, double mts, uint32_t thr_events,
+                                     uint32_t max_keys, double *__restrict__ kf_time, double *__restrict__ kf_dur,
+                                     int32_t *__restrict__ kf_events, double *__restrict__ kf_feat, double *__restrict__ t0,
+                                     double *__restrict__ t1) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P || !st.active[k]) return;
+    const uint32_t M = rows * cols;
+    const double ln = 3 * mts, gap = 5 * mts;
+    const double f = st.first[k], s2 = st.second[k];
+    const uint32_t cnt = seg_cnt[2 * k] + seg_cnt[2 * k + 1];  // EventFrame::eventsNum()
+    const bool ok = win_info[4 * k + 3] == 0 && found[k];     // extractFeatures() == true
+    bool accepted = false;
+    if (ok) {
+        const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * k];
+        const int32_t *ord = order + (size_t) k * M;
+        const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
+        double dir[AD_MAX_ROWS][2];
+        for (uint32_t i = 0; i < rows; i++) row_direction(xyr, ord + i * cols, cols, dir[i][0], dir[i][1]);
+        accepted = true;
+        if (st.have_ref[k]) {  // EventCalibIni::track: median row angle / time distance
+            double theta[AD_MAX_ROWS];
+            const double *rd = st.ref_dir + (size_t) k * rows * 2;
+            for (uint32_t i = 0; i < rows; i++) {
+                const double c = (rd[2 * i] * dir[i][0] + rd[2 * i + 1] * dir[i][1]) /
+                                 (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[i][0], dir[i][1]));
+                theta[i] = acos(fmax(-1.0, fmin(1.0, c)));
+            }
+            double med = theta[0];
+            for (uint32_t i = 0; i < rows; i++) {  // order statistic rows / 2 (std::nth_element)
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < rows; j++) rank += (theta[j] < theta[i] || (theta[j] == theta[i] && j < i)) ? 1u : 0u;
+                if (rank == rows / 2) med = theta[i];
+            }
+            accepted = med / fabs(t_mid - st.ref_t[k]) < (5e-4 * M_PI) / mts;
+        }
+        if (accepted) {
+            const uint32_t at = atomicAdd(&st.counters[1], 1u);
+            if (at < max_keys) {
+                kf_time[at] = t_mid;
+                kf_dur[2 * at] = f;
+                kf_dur[2 * at + 1] = s2;
+                kf_events[at] = (int32_t) cnt;
+                for (uint32_t c = 0; c < M; c++) {
+                    kf_feat[3 * ((size_t) at * M + c)] = xyr[3 * (size_t) ord[c]];
+                    kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[3 * (size_t) ord[c] + 1];
+                    kf_feat[3 * ((size_t) at * M + c) + 2] = xyr[3 * (size_t) ord[c] + 2];
+                }
+            }
+            st.have_ref[k] = 1;
+            st.ref_t[k] = t_mid;
+            double *rd = st.ref_dir + (size_t) k * rows * 2;
+            for (uint32_t i = 0; i < rows; i++) {
+                rd[2 * i] = dir[i][0];
+                rd[2 * i + 1] = dir[i][1];
+            }
+        }
+    }
+    // eventCameraCalib.cpp:61-62 (success), :67-69,75-77 (slide), :70-71,78-79 (grow)
+    double nf, ns;
+    if (accepted) {
+        nf = s2 + gap;
+        ns = nf + ln;
+    } else if (cnt > thr_events || (s2 - f) > 3 * ln) {
+        nf = f + mts;
+        ns = nf + ln;
+    } else {
+        nf = f;
+        ns = s2 + mts;
+    }
+    st.first[k] = nf;
+    st.second[k] = ns;
+    const bool act = ns < st.bound_hi[k];  // :50
+    st.active[k] = act ? 1u : 0u;
+    t0[k] = act ? nf : INFINITY;
+    t1[k] = act ? ns : -INFINITY;
+    if (act) atomicAdd(&st.counters[0], 1u);
+    atomicMax(&st.counters[2], pass + 1u);
+    atomicAdd(st.windows, 1ull);
+}
+
+}  // namespace
+
+extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                                     const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                                     double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                                     uint32_t *passes, uint64_t *windows) {
+    if (!ctx || !ap || !prm || !n_keyframes || (n_events && !d_events)) return ECAL_ERR_INVALID;
+    *n_keyframes = 0;
+    if (passes) *passes = 0;
+    if (windows) *windows = 0;
+    const uint32_t P = ap->piece_num, M = prm->rows * prm->cols;
+    if (P == 0 || M == 0 || M > 128 || prm->rows > (uint32_t) AD_MAX_ROWS || !(ap->motion_time_step > 0) ||
+        !(ap->end_time > ap->start_time) || (max_keyframes && (!kf_time || !kf_duration || !kf_events_num || !kf_features))) {
+        ctx->last_error = "ecal_detect_keyframes: invalid parameters";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    const uint32_t S = P;
+    const size_t cap = (size_t) cap_points + 16;
+    ecal_devbuf *B = ctx->host_pipe;  // roles as in ecal_detect_pass; 0 holds t0 and t1 back to back
+    const size_t sizes[17] = {2ul * S * sizeof(double), 16, S * 4ul, S * 4ul, (S + 1) * 4ul, cap * 16, 2ul * S * 4, 2ul * S * 4, cap * 4,
+                              cap * 4, 2ul * S * 4, cap * 4, cap * 4, 4ul * S * 4, cap * 8, cap * 24, 16};
+    for (int i = 0; i < 17; i++)
+        if ((rc = ecal_ensure(ctx, B[i], sizes[i]))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
+    const size_t state_bytes = (size_t) P * (4 * 8 + 2 * 8 * prm->rows + 2 * 4) + 64;
+    if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
+    const size_t key_stride = 8 + 16 + 8 + 24 * (size_t) M;  // time, duration, events (padded), features
+    if ((rc = ecal_ensure(ctx, ctx->adaptive_keys, (size_t) max_keyframes * key_stride + 64))) return rc;
+    if (ctx->pass_pinned_cap < 64) {
+        if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
+        ctx->pass_pinned = nullptr;
+        ctx->pass_pinned_cap = 0;
+        ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &ctx->pass_pinned, 4096, hipHostMallocDefault));
+        ctx->pass_pinned_cap = 4096;
+    }
+    AdaptiveArrays a;
+    {
+        unsigned char *p = (unsigned char *) ctx->adaptive_state.ptr;
+        a.windows = (unsigned long long *) p;
+        a.counters = (uint32_t *) (p + 16);
+        p += 64;
+        a.first = (double *) p;
+        a.second = a.first + P;
+        a.bound_hi = a.second + P;
+        a.ref_t = a.bound_hi + P;
+        a.ref_dir = a.ref_t + P;
+        a.active = (uint32_t *) (a.ref_dir + (size_t) P * prm->rows * 2);
+        a.have_ref = a.active + P;
+    }
+    double *d_kt = (double *) ctx->adaptive_keys.ptr, *d_kd = d_kt + max_keyframes, *d_kf = d_kd + 2 * (size_t) max_keyframes;
+    int32_t *d_ke = (int32_t *) (d_kf + 3 * (size_t) max_keyframes * M);
+    double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
+    const double ln = 3 * ap->motion_time_step;
+    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, ap->start_time, ap->end_time, ln, a, d_t0, d_t1);
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(B[16].ptr, 0, sizeof(int), st));
+    uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..3] counters, [4] overflow flag
+    const uint32_t check_every = ap->check_every ? ap->check_every : 8u;
+    const uint32_t max_passes = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
+    for (uint32_t pass = 0; pass < max_passes; pass++) {
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st));  // pieces active after this pass
+        if ((rc = ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
+                                         (uint32_t *) B[4].ptr, st)))
+            return rc;
+        if ((rc = ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, S, 0,
+                                        cap_points, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
+                                        (int32_t *) B[8].ptr, (int *) B[16].ptr, st)))
+            return rc;
+        if ((rc = ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * S, cap_points, 0,
+                                        prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, st)))
+            return rc;
+        if ((rc = ecal_extract_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
+                                         (uint32_t *) B[10].ptr, S, cap_points, prm->cluster_min_sample, prm->need_clusters,
+                                         prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
+                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st)))
+            return rc;
+        if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
+                                      (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
+            return rc;
+        hipLaunchKernelGGL(adaptive_step_kernel, dim3((P + 127) / 128), dim3(128), 0, st, P, prm->rows, prm->cols, pass,
+                           (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
+                           (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
+                           (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
+                           max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1);
+        if (pass % check_every == check_every - 1 || pass + 1 == max_passes) {
+            ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            ECAL_HIP_TRY(ctx, hipMemcpyAsync(h + 4, B[16].ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+            ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+            if (h[4]) {
+                ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
+                return ECAL_ERR_RANGE;
+            }
+            if (h[0] == 0) break;
+        }
+    }
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    unsigned long long nwin = 0;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(&nwin, a.windows, sizeof(nwin), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint32_t K = h[1];
+    if (passes) *passes = h[2];
+    if (windows) *windows = nwin;
+    if (K > max_keyframes) {
+        *n_keyframes = K;
+        ctx->last_error = "ecal_detect_keyframes: more keyframes than max_keyframes (n_keyframes holds the count)";
+        return ECAL_ERR_RANGE;
+    }
+    *n_keyframes = K;
+    if (K == 0) return ECAL_OK;
+    // the records arrive in completion order: sort by time stamp (the reference's keyframe map is ordered by time)
+    std::vector<double> t(K), d(2 * (size_t) K), ft(3 * (size_t) K * M);
+    std::vector<int32_t> e(K);
+    ECAL_HIP_TRY(ctx, hipMemcpy(t.data(), d_kt, K * sizeof(double), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(d.data(), d_kd, 2ul * K * sizeof(double), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(ft.data(), d_kf, 3ul * K * M * sizeof(double), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(e.data(), d_ke, K * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> perm(K);
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return t[x] < t[y] || (t[x] == t[y] && d[2 * x] < d[2 * y]); });
+    for (uint32_t i = 0; i < K; i++) {
+        const uint32_t j = perm[i];
+        kf_time[i] = t[j];
+        kf_duration[2 * i] = d[2 * j];
+        kf_duration[2 * i + 1] = d[2 * j + 1];
+        kf_events_num[i] = e[j];
+        memcpy(kf_features + 3 * (size_t) i * M, ft.data() + 3 * (size_t) j * M, 3 * M * sizeof(double));
+    }
+    return ECAL_OK;
+}

@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <stdexcept>
+#include <string>
 
 #include "circles_event_frame.hpp"
 
@@ -170,6 +172,68 @@ inline std::vector<KeyFrame> detect_keyframes(EventContainer &container, CircleP
     for (auto &pc : pieces)
         for (auto &k : pc.keys) all.push_back(std::move(k));
     std::sort(all.begin(), all.end(), [](const KeyFrame &a, const KeyFrame &b) { return a.timeStamp < b.timeStamp; });
+    return all;
+}
+
+// The same search with the policy ON THE DEVICE (ecal_detect_keyframes): the passes are enqueued back to back, nothing
+// but a 4-byte counter crosses PCIe until the keyframes come back.  Same keyframes as detect_keyframes above.
+inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, CirclePatternParameters::Ptr pattern,
+                                                     const CirclesEventFrame::Params &params, double motionTimeStep,
+                                                     int frameEventNumThreshold, int pieceNum, double startTime, double endTime) {
+    ecal_detect_params prm;
+    prm.dbscan_eps = params.dbscan_eps;
+    prm.dbscan_min_samples = (uint32_t) params.dbscan_startMinSample;
+    prm.cluster_min_sample = (uint32_t) params.clusterMinSample;
+    prm.need_clusters = (uint32_t) (pattern->rows * pattern->cols);
+    prm.circle_radius_threshold = ecal_circle_radius_threshold(container.cameraSize[0], container.cameraSize[1], pattern->rows,
+                                                               pattern->cols, pattern->isAsymmetric, pattern->squareSize,
+                                                               pattern->circleRadius);
+    prm.fit_circle = params.fitCircle ? 1 : 0;
+    prm.knn_num = (uint32_t) params.knn_num;
+    prm.rows = (uint32_t) pattern->rows;
+    prm.cols = (uint32_t) pattern->cols;
+    ecal_adaptive_params ap;
+    ap.motion_time_step = motionTimeStep;
+    ap.frame_event_num_threshold = (uint32_t) frameEventNumThreshold;
+    ap.piece_num = (uint32_t) pieceNum;
+    ap.start_time = startTime;
+    ap.end_time = endTime;
+    ap.max_passes = 0;
+    ap.check_every = 0;
+    const ecal_stream *es = container.device();
+    const uint64_t n = ecal_stream_size(es);
+    const size_t M = (size_t) prm.rows * prm.cols;
+    const double span = std::max(endTime - startTime, 1e-9);
+    // a pass covers one window of <= 10 steps per piece; doubled on ECAL_ERR_RANGE
+    uint64_t cap = std::min<uint64_t>(n, (uint64_t) (pieceNum * (20.0 * motionTimeStep * (double) n / span + 1024.0)));
+    uint32_t max_keys = (uint32_t) (span / (8 * motionTimeStep)) + (uint32_t) pieceNum + 64;
+    std::vector<double> t, d, f;
+    std::vector<int32_t> e;
+    uint32_t K = 0;
+    for (;;) {
+        t.resize(max_keys);
+        d.resize(2 * (size_t) max_keys);
+        e.resize(max_keys);
+        f.resize(3 * M * max_keys);
+        const int rc = ecal_detect_keyframes(ecal_host::thread_ctx(), ecal_stream_data(es), n, &ap, &prm, (uint32_t) cap, max_keys,
+                                             t.data(), d.data(), e.data(), f.data(), &K, nullptr, nullptr);
+        if (rc == ECAL_OK) break;
+        if (rc != ECAL_ERR_RANGE || (cap >= n && max_keys > (1u << 30)))
+            throw std::runtime_error(std::string("ecal_detect_keyframes: ") + ecal_strerror(rc) + " — " +
+                                     ecal_last_error(ecal_host::thread_ctx()));
+        cap = std::min<uint64_t>(n, 2 * cap);
+        max_keys *= 2;
+    }
+    std::vector<KeyFrame> all(K);
+    for (uint32_t k = 0; k < K; k++) {
+        all[k].timeStamp = t[k];
+        all[k].duration = {d[2 * k], d[2 * k + 1]};
+        all[k].eventsNum = e[k];
+        for (size_t c = 0; c < M; c++) {
+            const double *p = f.data() + 3 * (k * M + c);
+            all[k].features.push_back(CirclesEventFrame::CalibCircle{Vector2d{{p[0], p[1]}}, p[2]});
+        }
+    }
     return all;
 }
 

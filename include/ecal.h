@@ -217,6 +217,29 @@ int ecal_gather_features_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const ui
  * (EventFrame::eventsNum()), then the ordered circles x y r (NaN if none) }.  Synchronous. */
 int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *t0, const double *t1, uint32_t S,
                      const ecal_detect_params *prm, uint32_t cap_points, double *packed);
+/* ecal_detect_keyframes: the whole adaptive-window driver with the policy on the device — the reference's worker loop
+ * (MultiProcess::process, event_camera_calib/test/eventCameraCalib.cpp:34-97: success / slide / grow rule :49-95) over
+ * piece_num pieces of [start_time, end_time] (:168-179) with the keyframe gate of EventCalibIni::track (event_camera_calib/
+ * src/EventCalibIni.cpp:23-97) against the previous keyframe of the window's own piece (the deterministic policy of
+ * host/multi_process.hpp).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over the current
+ * window of every piece + one policy kernel, enqueued back to back; the host reads a 4-byte counter every check_every
+ * passes.  d_events: DEVICE-resident stream.  cap_points >= the events covered by the windows of any one pass
+ * (ECAL_ERR_RANGE otherwise: call again with more).  Outputs (host), sorted by time stamp: kf_time [K], kf_duration
+ * [K][2], kf_events_num [K] (EventFrame::eventsNum()), kf_features [K][rows*cols][3] (x, y, radius in grid order);
+ * *n_keyframes = K (ECAL_ERR_RANGE with the needed count if K > max_keyframes); *passes = lock-step passes that
+ * evaluated a window, *windows = windows evaluated.  Synchronous. */
+typedef struct ecal_adaptive_params {
+    double motion_time_step;             /* MotionTimeStep: window = 3 steps, gap after a keyframe = 5 steps */
+    uint32_t frame_event_num_threshold;  /* FrameEventNumThreshold */
+    uint32_t piece_num;                  /* the reference: 5 * (hardware threads - 2) */
+    double start_time, end_time;         /* StartTime / EndTime */
+    uint32_t max_passes;                 /* 0 = unlimited */
+    uint32_t check_every;                /* passes between two looks at the active-piece counter (0 = 8) */
+} ecal_adaptive_params;
+int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                          const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                          double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                          uint32_t *passes, uint64_t *windows);
 int ecal_pin_host(ecal_ctx *ctx, void *ptr, size_t bytes);   /* hipHostRegister */
 int ecal_unpin_host(ecal_ctx *ctx, void *ptr);
 int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events /*host*/, uint64_t n_events, double t_start, double window_len,

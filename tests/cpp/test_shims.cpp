@@ -135,5 +135,15 @@ int main(int argc, char **argv) {
         std::printf("kf %.12f %.12f %d %.9f %.9f\n", kfs[k].duration.first, kfs[k].duration.second, kfs[k].eventsNum,
                     kfs[k].features[0].location[0], kfs[k].features[35].radius);
     }
+    // the same search with the policy on the device: identical keyframes
+    std::vector<KeyFrame> kfd = detect_keyframes_device(*container, pattern, fp, step, 4000, 4, t0, container->lastTime());
+    CHECK(kfd.size() == kfs.size());
+    for (size_t k = 0; k < kfd.size() && k < kfs.size(); k++) {
+        CHECK(kfd[k].timeStamp == kfs[k].timeStamp && kfd[k].duration == kfs[k].duration && kfd[k].eventsNum == kfs[k].eventsNum);
+        for (int c = 0; c < 36; c++)
+            CHECK(kfd[k].features[c].location[0] == kfs[k].features[c].location[0] &&
+                  kfd[k].features[c].location[1] == kfs[k].features[c].location[1] && kfd[k].features[c].radius == kfs[k].features[c].radius);
+    }
+    std::printf("device policy: %zu keyframes, identical\n", kfd.size());
     return 0;
 }

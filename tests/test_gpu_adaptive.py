@@ -1,0 +1,52 @@
+"""GPU: the adaptive-window driver with the policy on the device (ecal_detect_keyframes) against the host-driven
+lock-step driver (eventcalib_amd.adaptive.detect_keyframes over ecal_detect_pass): same keyframes, same windows."""
+import numpy as np
+import pytest
+
+import synth_stream as SS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    ev = SS.make_stream(3_000_000, rate=2.0e6, device="cuda", seed=77)
+    yield ctx, DetectPipeline(ctx), ev, torch
+    ctx.close()
+
+
+@pytest.mark.parametrize("pieces", [1, 7, 64, 500])
+def test_device_policy_equals_host_policy(env, pieces):
+    from eventcalib_amd.adaptive import detect_keyframes, detect_keyframes_device
+    ctx, pipe, ev, torch = env
+    t_first, t_last = 5.0, 5.0 + (3_000_000 - 1) / 2.0e6
+    host = detect_keyframes(pipe, ev, 5e-4, 4000, pieces, t_first, t_last)
+    dev = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last)
+    assert dev["steps"] == host["steps"] and dev["windows"] == host["windows"]
+    assert len(host["time"]) >= 5 or pieces == 1
+    # the gate compares an angle rate with a threshold; host (numpy SVD) and device (Jacobi) agree to ~1e-13 in the angle,
+    # so the accepted set is the same unless a frame sits on the threshold (none does on this stream)
+    assert np.array_equal(dev["time"], host["time"])
+    assert np.array_equal(dev["duration"], host["duration"])
+    assert np.array_equal(dev["events_num"], host["events_num"])
+    assert np.array_equal(dev["features"], host["features"])      # the same candidate circles, bit for bit
+
+
+def test_capacity_errors_and_limits(env):
+    import eventcalib_amd.capi as capi
+    ctx, pipe, ev, torch = env
+    n = ev.numel() // 25
+    with pytest.raises(capi.EcalError) as e:   # slots for one pass too small
+        capi.detect_keyframes_dev(ctx, ev.data_ptr(), n, 5e-4, 4000, 64, 5.0, 6.0, 1000, 4096)
+    assert e.value.status == -6
+    with pytest.raises(capi.EcalError) as e:   # keyframe capacity too small
+        capi.detect_keyframes_dev(ctx, ev.data_ptr(), n, 5e-4, 4000, 64, 5.0, 6.0, n, 2)
+    assert e.value.status == -6
+    t, d, e_, f, passes, windows = capi.detect_keyframes_dev(ctx, ev.data_ptr(), n, 5e-4, 4000, 64, 5.0, 6.0, n, 4096, max_passes=3)
+    assert passes <= 3 and windows <= 3 * 64
+    with pytest.raises(capi.EcalError):        # invalid: no pieces
+        capi.detect_keyframes_dev(ctx, ev.data_ptr(), n, 5e-4, 4000, 0, 5.0, 6.0, n, 16)
