@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import capi
-from .adaptive import detect_keyframes
+from .adaptive import detect_keyframes_device
 from .pipeline import DetectPipeline
 
 EXAMPLE_FLAGS = (capi.CALIB_FIX_ASPECT_RATIO | capi.CALIB_FIX_PRINCIPAL_POINT | capi.CALIB_ZERO_TANGENT_DIST |
@@ -87,7 +87,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     n_circ = rows * cols
     pipe = DetectPipeline(ctx, dev)
     # -- 1. keyframes
-    kf = detect_keyframes(pipe, events, step, frame_event_num_threshold, piece_num, t_first, t_last, eps, minpts, rows, cols)
+    kf = detect_keyframes_device(pipe.ctx, events, step, frame_event_num_threshold, piece_num, t_first, t_last, eps, minpts, rows, cols)
     K = len(kf["time"])
     out = {"keyframes": K}
     if K == 0:

@@ -21,7 +21,7 @@ int main(int argc, char **argv) {
     cs->validate();
     auto pattern = cs->circlePatternParameters;
     CirclesEventFrame::Params fp;
-    std::vector<KeyFrame> kfs = detect_keyframes(*container, pattern, fp, step, 4000, 30, container->firstTime(), container->lastTime());
+    std::vector<KeyFrame> kfs = detect_keyframes_device(*container, pattern, fp, step, 4000, 30, container->firstTime(), container->lastTime());
     std::printf("keyframes %zu\n", kfs.size());
     EventCalibIni ini(cs, step);
     EventCalibIni::Result res;
