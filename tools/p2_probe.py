@@ -3,7 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, eventcalib_amd, synth_stream as SS
-from eventcalib_amd.adaptive import detect_keyframes
+from eventcalib_amd.adaptive import detect_keyframes, detect_keyframes_device
 from eventcalib_amd.pipeline import DetectPipeline
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 pieces = int(sys.argv[2]) if len(sys.argv) > 2 else 254
@@ -11,8 +11,13 @@ nth = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = eventcalib_amd.Context(0)
 ev = SS.make_stream(n, device="cuda")
 pipe = DetectPipeline(ctx)
-detect_keyframes(pipe, ev, 5e-4, 4000, pieces, 5.0, 5.5, n_threads=nth)
+dev = len(sys.argv) > 4 and sys.argv[4] == "dev"     # policy on the device (ecal_detect_keyframes)
+if dev:
+    run = lambda a, b: detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, a, b)
+else:
+    run = lambda a, b: detect_keyframes(pipe, ev, 5e-4, 4000, pieces, a, b, n_threads=nth)
+run(5.0, 5.5)
 torch.cuda.synchronize(); t = time.perf_counter()
-kf = detect_keyframes(pipe, ev, 5e-4, 4000, pieces, 5.0, 5.0 + (n - 1) / 1e6, n_threads=nth)
+kf = run(5.0, 5.0 + (n - 1) / 1e6)
 torch.cuda.synchronize(); el = time.perf_counter() - t
 print("threads %d " % nth + "P2: %d events, %d pieces, %.3f s, %d passes (%.3f ms each), %d windows, %d keyframes" % (n, pieces, el, kf["steps"], el / kf["steps"] * 1e3, kf["windows"], len(kf["time"])))
