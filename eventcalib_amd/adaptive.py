@@ -49,6 +49,7 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
     and scratch — the ABI's one-context-per-thread rule, as the reference gives every worker its own DBSCAN instance):
     a pass is a ~0.4 ms chain of small launches that leaves the GPU mostly idle, so several chains run side by side.
     The result does not depend on n_threads (pieces are independent)."""
+    torch.cuda.synchronize(events.device)   # the passes run on the context's own stream: `events` must be complete
     if n_threads > 1:
         import threading
         from .capi import Context
@@ -82,6 +83,7 @@ def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_thres
                             minpts=2, rows=9, cols=4, max_passes=0):
     """Same result as detect_keyframes, with the policy on the device (ecal_detect_keyframes): no per-pass host round trip.
     Slots and the keyframe capacity are estimated and doubled when the library reports them too small."""
+    torch.cuda.synchronize(events.device)   # the passes run on the context's own stream: `events` must be complete
     n_ev = events.numel() // 25
     span = max(end_time - start_time, 1e-9)
     # a pass covers one window of <= 10 steps per piece: twice the mean event count of such spans, to start with

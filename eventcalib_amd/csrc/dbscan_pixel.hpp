@@ -31,8 +31,8 @@ namespace ecal {
 #define ECAL_PX_T 256
 #endif
 constexpr int PX_T = ECAL_PX_T;
-constexpr int PX_CAP = 1024;
-constexpr int PX_PPT = PX_CAP / PX_T;
+constexpr int PX_CAP = 1024;   // points per segment of the first pass (four per thread)
+constexpr int PX_CAP2 = 2048;  // second pass over the segments the first one left: eight per thread, 10-bit bitmap coordinates
 constexpr uint32_t PX_WORDS = 3232;    // bitmap words: 346x260 padded by 2*4 = 354x268 bits = 268 rows x 12 words = 3216
 constexpr uint32_t PX_ROWS = 472;      // rowstart[PX_ROWS + 1]: 512 u16
 constexpr uint32_t PX_EDGE_CAP = 128;  // one-way edges kept (more: left to the general kernel)
@@ -97,64 +97,74 @@ inline bool px_geometry(double eps, PxGeom *g) {
     return g->Rd >= 0 && g->Rd <= PX_RMAX;
 }
 
+template <int CAP>
 struct PixelLayout {
-    // region A (from the rank phase on): rank -> pid | f << 10 | core << 12, the one-way edge list, the disc masks
-    static constexpr size_t pf_off = 0;                                     // u16[1024]
-    static constexpr size_t edges_off = pf_off + 2 * PX_CAP;                // u32[2 * PX_EDGE_CAP]
+    // region A (from the rank phase on): rank -> pid | f << PB | core << (PB + 2), the one-way edge list, the disc masks
+    static constexpr size_t pf_off = 0;                                     // u16[CAP]
+    static constexpr size_t edges_off = pf_off + 2 * CAP;                   // u32[2 * PX_EDGE_CAP]
     static constexpr size_t dm_off = edges_off + 8 * PX_EDGE_CAP;           // u32[32]
     static constexpr size_t hd_off = dm_off + 128;                          // u8[32]
-    // region B: kd child slots during B (+ one dummy word that stays NONE); then the bitmap; after E.1: component labels
-    static constexpr size_t slot_off = hd_off + 32;                         // u32[2 * 1024 + 1]
+    // region B: kd child slots during B (+ one dummy word that stays NONE) — they may run on into parent[], which
+    // phase D is the first to use; then the bitmap; after E.1: component labels
+    static constexpr size_t slot_off = hd_off + 32;                         // u32[2 * CAP + 1]
     static constexpr size_t bm_off = slot_off;                              // u32[PX_WORDS]
-    static_assert(4 * PX_WORDS >= 8 * PX_CAP + 4, "child slots must fit the bitmap region");
-    static constexpr size_t parent_off = bm_off + 4 * PX_WORDS + 16;        // u32[1024] (after one spare bitmap word)
-    static constexpr size_t rowstart_off = parent_off + 4 * PX_CAP;         // u16[512]
+    static constexpr size_t parent_off = bm_off + 4 * PX_WORDS + 16;        // u32[CAP] (after one spare bitmap word)
+    static_assert(4 * PX_WORDS + 16 + 4 * CAP >= 8 * CAP + 4, "child slots must fit bitmap + parent");
+    static_assert(PX_WORDS >= (uint32_t) CAP, "component labels (E.3) must fit the bitmap region");
+    static constexpr size_t rowstart_off = parent_off + 4 * CAP;            // u16[512]
     static constexpr size_t wpre_off = rowstart_off + 1024;                 // u8[PX_WORDS]
     static constexpr size_t red_off = wpre_off + PX_WORDS;                  // u32[48]
     static constexpr size_t bytes = red_off + 4 * 48;
 };
-constexpr uint32_t PX_PF_CORE = 0x1000u, PX_PF_PID = 0x3FFu;
-constexpr uint32_t PX_DUMMY_SLOT = 8u * PX_CAP;  // byte offset of the child-slot word nobody bids for
 
-// child-slot word: pid << 22 | x' << 11 | y'  (x', y' = bitmap coordinates < 2048).  ds_min_u32 orders the bids by
-// pid, and the winner's coordinates come back with its id: one dependent LDS read per tree level instead of two.
-__device__ __forceinline__ uint32_t px_word(uint32_t pid, uint32_t cx, uint32_t cy) { return (pid << 22) | (cx << 11) | cy; }
-__device__ __forceinline__ uint32_t px_wx(uint32_t w) { return (w >> 11) & 0x7FFu; }
-__device__ __forceinline__ uint32_t px_wy(uint32_t w) { return w & 0x7FFu; }
+// Word formats by capacity.  Child-slot word: pid << 2 CB | x' << CB | y' (x', y' = bitmap coordinates < 2^CB - 1):
+// ds_min_u32 orders the bids by pid, and the winner's coordinates come back with its id — one dependent LDS read per
+// tree level instead of two.  Rank table entry (u16): pid | f << PB | core << (PB + 2).
+template <int CAP>
+struct PxFmt {
+    static constexpr uint32_t PB = CAP > 1024 ? 11u : 10u;   // pid bits
+    static constexpr uint32_t CB = (32u - PB) / 2u;          // coordinate bits: 11 (CAP 1024) or 10 (CAP 2048)
+    static constexpr uint32_t CMASK = (1u << CB) - 1u;
+    static constexpr uint32_t PF_PID = (1u << PB) - 1u, PF_CORE = 1u << (PB + 2u);
+    static constexpr uint32_t DUMMY_SLOT = 8u * CAP;         // byte offset of the child-slot word nobody bids for
+    static __device__ __forceinline__ uint32_t word(uint32_t pid, uint32_t cx, uint32_t cy) { return (pid << (2u * CB)) | (cx << CB) | cy; }
+    static __device__ __forceinline__ uint32_t wx(uint32_t w) { return (w >> CB) & CMASK; }
+    static __device__ __forceinline__ uint32_t wy(uint32_t w) { return w & CMASK; }
+};
 
 // One tree level for one unplaced point (register state).  sl = byte offset of the child slot the point bid for
-// (~0 = placed), sh = bit offset of the coordinate the winner of that slot splits on (11 = x, 0 = y), fb = the prune
+// (~0 = placed), sh = bit offset of the coordinate the winner of that slot splits on (CB = x, 0 = y), fb = the prune
 // bit of that dimension.  Returns true while unplaced.
+template <int CAP>
 __device__ __forceinline__ bool px_level_step(unsigned char *slotb, uint32_t i, uint32_t self, uint32_t &sl, uint32_t &sh,
                                               uint32_t &fb, uint32_t &f) {
+    using F = PxFmt<CAP>;
     const uint32_t cw = *reinterpret_cast<const uint32_t *>(slotb + sl);
-    const uint32_t child = cw >> 22;
+    const uint32_t child = cw >> (2u * F::CB);
     if (child == i) {
         sl = ~0u;
         return false;
     }
-    const uint32_t sv = __builtin_amdgcn_ubfe(self, sh, 11u), cv = __builtin_amdgcn_ubfe(cw, sh, 11u);
+    const uint32_t sv = __builtin_amdgcn_ubfe(self, sh, F::CB), cv = __builtin_amdgcn_ubfe(cw, sh, F::CB);
     f |= (sv == cv) ? fb : 0u;                    // `child` becomes an ancestor splitting at my coordinate
     sl = (child << 3) | (sv < cv ? 0u : 4u);      // kdtree.cpp:128-131: left iff strictly smaller
     atomicMin(reinterpret_cast<uint32_t *>(slotb + sl), self);
-    sh ^= 11u;
+    sh ^= F::CB;
     fb ^= 3u;
     return true;
 }
 
-template <int E2I>
-__global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__restrict__ xy,
-                                                            const uint32_t *__restrict__ seg_off,
-                                                            const uint32_t *__restrict__ seg_cnt, const PxGeom geom,
-                                                            uint32_t minpts, int32_t *__restrict__ labels,
-                                                            uint32_t *__restrict__ n_clusters,
-                                                            uint32_t *__restrict__ todo,
-                                                            uint32_t *__restrict__ todo_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
-    using L = PixelLayout;
+template <int E2I, int CAP>
+__device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_t s, const double *__restrict__ xy,
+                                           const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+                                           const PxGeom &geom, uint32_t minpts, int32_t *__restrict__ labels,
+                                           uint32_t *__restrict__ n_clusters, uint32_t *__restrict__ todo,
+                                           uint32_t *__restrict__ todo_count) {
+    using L = PixelLayout<CAP>;
+    using F = PxFmt<CAP>;
     using G = GeoI16;
-    constexpr int T = PX_T, PPT = PX_PPT;
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    constexpr int T = PX_T, PPT = CAP / PX_T;
+    const uint32_t tid = threadIdx.x;
 #ifdef ECAL_PHASE_PROF
     unsigned long long phase_t__ = __builtin_readcyclecounter(), d7__ = 0;
     uint32_t levels__ = 0;
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         if (tid == 0) n_clusters[s] = 0;
         return;
     }
-    if (n > (uint32_t) PX_CAP) {
+    if (n > (uint32_t) CAP) {
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
         return;
     }
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     if (tid < 4) bbox[tid] = 0x7FFFFFFF;
     if (tid == 0) {
         *n_edges = 0;
-        slot[PX_DUMMY_SLOT / 4] = NONE32;
+        slot[F::DUMMY_SLOT / 4] = NONE32;
     }
     if (E2I == 0 && tid < (uint32_t) (2 * PX_RMAX + 1)) dm[tid] = geom.dmask[tid];
     if (E2I > 0 && tid < 32u) hd[tid] = geom.hd_code[tid];
@@ -284,13 +294,13 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     // 64-bit window fetches may read the first word of the next row (or the spare word after the last row):
     // those bits are always masked off
     const uint32_t RW = (W + 31u) >> 5;
-    if (H > PX_ROWS || (uint64_t) H * RW > PX_WORDS || W > 2047u) PX_BAIL();
+    if (H > PX_ROWS || (uint64_t) H * RW > PX_WORDS || W > F::CMASK || H > F::CMASK) PX_BAIL();
     uint32_t mcx[PPT], myy[PPT], me[PPT];
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         mcx[u] = (uint32_t) (G::sx(pp[u]) - ox);
         myy[u] = (uint32_t) (G::sy(pp[u]) - oy);
-        me[u] = px_word(tid + u * T, mcx[u] & 0x7FFu, myy[u] & 0x7FFu);
+        me[u] = F::word(tid + u * T, mcx[u] & F::CMASK, myy[u] & F::CMASK);
     }
     if (tid == 0) *rootw = me[0];
     PX_STOP(1, me[u] + W + H);
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     if (tid < KTOP) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint32_t x0 = px_wx(*rootw);
+        const uint32_t x0 = F::wx(*rootw);
         const uint32_t i = tid;
         if (i > 0 && i < n) {
             f[0] |= (mcx[0] == x0) ? 1u : 0u;
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             bool act = false;
-            if (sl[0] != ~0u) act = px_level_step(slotb, i, me[0], sl[0], sh[0], fb[0], f[0]);
+            if (sl[0] != ~0u) act = px_level_step<CAP>(slotb, i, me[0], sl[0], sh[0], fb[0], f[0]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (!__any(act)) break;
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     // the walks of a thread's points advance together so their LDS round trips overlap; a walk that has ended keeps
     // reading its empty slot (nobody writes during B.1).
     {
-        const uint32_t x0 = px_wx(*rootw);
+        const uint32_t x0 = F::wx(*rootw);
         uint32_t a2[PPT], dl[PPT], fcx[PPT], fcy[PPT];
         bool ulive[PPT];
 #pragma unroll
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             const uint32_t i = tid + u * T;
             const bool go = i < n && i >= KTOP;
             ulive[u] = wbase + u * T < n && wbase + u * T + 63u >= KTOP;
-            a2[u] = go ? ((mcx[u] < x0) ? 0u : 4u) : PX_DUMMY_SLOT;
+            a2[u] = go ? ((mcx[u] < x0) ? 0u : 4u) : F::DUMMY_SLOT;
             dl[u] = 0;
             fcx[u] = (go && mcx[u] == x0) ? 1u : 0u;
             fcy[u] = 0;
@@ -356,10 +366,10 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             for (int u = 0; u < PPT; u++) {
                 if (ulive[u] && cw[u] != NONE32) {
                     any = true;
-                    const uint32_t sv = D ? myy[u] : mcx[u], cv = D ? px_wy(cw[u]) : px_wx(cw[u]);
+                    const uint32_t sv = D ? myy[u] : mcx[u], cv = D ? F::wy(cw[u]) : F::wx(cw[u]);
                     if (D) fcy[u] += (sv == cv) ? 1u : 0u;
                     else fcx[u] += (sv == cv) ? 1u : 0u;
-                    a2[u] = ((cw[u] >> 22) << 3) | (sv < cv ? 0u : 4u);
+                    a2[u] = ((cw[u] >> (2u * F::CB)) << 3) | (sv < cv ? 0u : 4u);
                     dl[u] = D;
                 }
             }
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             if (i < n && i >= KTOP) {
                 f[u] |= (fcx[u] ? 1u : 0u) | (fcy[u] ? 2u : 0u);
                 sl[u] = a2[u];                // the empty slot under the last top-tree node: bid for it
-                sh[u] = dl[u] ? 11u : 0u;     // its winner splits on the other dimension
+                sh[u] = dl[u] ? F::CB : 0u;     // its winner splits on the other dimension
                 fb[u] = dl[u] ? 1u : 2u;
             }
         }
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         bool active = false;
 #pragma unroll
         for (int u = 0; u < PPT; u++)
-            if (sl[u] != ~0u) active |= px_level_step(slotb, tid + u * T, me[u], sl[u], sh[u], fb[u], f[u]);
+            if (sl[u] != ~0u) active |= px_level_step<CAP>(slotb, tid + u * T, me[u], sl[u], sh[u], fb[u], f[u]);
 #ifdef ECAL_PHASE_PROF
         levels__++;
 #endif
@@ -457,7 +467,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
         myrk[u] = 0;
         if (i < n) {
             myrk[u] = rank_of(mcx[u], myy[u]);
-            pf[myrk[u]] = (uint16_t) (i | (f[u] << 10));
+            pf[myrk[u]] = (uint16_t) (i | (f[u] << F::PB));
         }
     }
     __syncthreads();
@@ -495,15 +505,15 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             if (eps_int && cnt >= minpts) {
                 // a neighbour at exactly (+eps, 0) / (0, +eps) carrying the matching bit is invisible from here
                 if ((vmid >> (2 * Rd)) & 1u)
-                    if (pf[rank_of(cx + (uint32_t) Rd, yy)] & (1u << 10)) cnt--;
+                    if (pf[rank_of(cx + (uint32_t) Rd, yy)] & (1u << F::PB)) cnt--;
                 if ((vlast >> Rd) & 1u)
-                    if (pf[rank_of(cx, yy + (uint32_t) Rd)] & (2u << 10)) cnt--;
+                    if (pf[rank_of(cx, yy + (uint32_t) Rd)] & (2u << F::PB)) cnt--;
             }
             core[u] = cnt >= minpts;
             parent[i] = core[u] ? i : NONE32;
             // the core bit joins the table entry right away: concurrent readers of this phase only look at the f
             // bits, which are the same in the old and the new value
-            if (core[u]) pf[myrk[u]] = (uint16_t) (i | (f[u] << 10) | PX_PF_CORE);
+            if (core[u]) pf[myrk[u]] = (uint16_t) (i | (f[u] << F::PB) | F::PF_CORE);
         }
     }
     __syncthreads();
@@ -538,8 +548,8 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
             }
             const uint32_t nx = c0 + b, ny = yy - (uint32_t) Rd + k;
             const uint32_t pfj = pf[rank_of(nx, ny)];
-            if (!(pfj & PX_PF_CORE)) return;
-            const uint32_t pj = pfj & PX_PF_PID;
+            if (!(pfj & F::PF_CORE)) return;
+            const uint32_t pj = pfj & F::PF_PID;
             // j = i - eps e_d: the query from j misses i exactly when i carries bit d; the query from i always
             // finds j (pruning only hides neighbours on the + side) -> one-way edge i -> j
             if (eps_int && fi) {
@@ -684,6 +694,39 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
     ECAL_PHASE_MARK(4);
 #undef PX_BAIL
 #undef PX_STOP
+}
+
+// first pass: workgroup b handles segment b; what it cannot take goes to todo / todo_count
+template <int E2I, int CAP>
+__global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__restrict__ xy,
+                                                            const uint32_t *__restrict__ seg_off,
+                                                            const uint32_t *__restrict__ seg_cnt, const PxGeom geom,
+                                                            uint32_t minpts, int32_t *__restrict__ labels,
+                                                            uint32_t *__restrict__ n_clusters,
+                                                            uint32_t *__restrict__ todo,
+                                                            uint32_t *__restrict__ todo_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
+    px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count);
+}
+
+// second pass (CAP = PX_CAP2): the workgroups share the list of segments the first pass left over
+// (in_list[0 .. *in_count)); what this pass cannot take either goes to todo / todo_count for the general tiers
+template <int E2I, int CAP>
+__global__ __launch_bounds__(PX_T) void dbscan_pixel_list_kernel(const double *__restrict__ xy,
+                                                                 const uint32_t *__restrict__ seg_off,
+                                                                 const uint32_t *__restrict__ seg_cnt, const PxGeom geom,
+                                                                 uint32_t minpts, int32_t *__restrict__ labels,
+                                                                 uint32_t *__restrict__ n_clusters,
+                                                                 uint32_t *__restrict__ todo,
+                                                                 uint32_t *__restrict__ todo_count,
+                                                                 const uint32_t *__restrict__ in_list,
+                                                                 const uint32_t *__restrict__ in_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
+    const uint32_t count = *in_count;
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        px_segment<E2I, CAP>(px_smem, in_list[k], xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count);
+        __syncthreads();
+    }
 }
 
 }  // namespace ecal

@@ -190,12 +190,16 @@ static int set_attrs(ecal_ctx *ctx) {
     if (ctx->attrs_set) return ECAL_OK;
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP0, CAP0 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP0>::bytes));
-    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<0>),
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<0, PX_CAP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int) (PixelLayout::bytes + tier0_pad())));
-    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<16>),
+                                          (int) (PixelLayout<PX_CAP>::bytes + tier0_pad())));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<16, PX_CAP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int) (PixelLayout::bytes + tier0_pad())));
+                                          (int) (PixelLayout<PX_CAP>::bytes + tier0_pad())));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_list_kernel<0, PX_CAP2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixelLayout<PX_CAP2>::bytes));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_list_kernel<16, PX_CAP2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixelLayout<PX_CAP2>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP1, CAP1 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP1>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP2, CAP2 / 4>),
@@ -227,6 +231,7 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
     if (rc) return rc;
     hipStream_t st = (hipStream_t) stream;
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
+    const bool second_pass = mx > (uint32_t) PX_CAP && !getenv("ECAL_DBSCAN_NO_SECOND_PASS");  // debug switch
 
     // event pixels (integer coordinates, eps < 16): the lean pixel kernel takes every segment it can and lists
     // the others; the general tiers then work that list off with a small grid (it is normally empty)
@@ -235,18 +240,34 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
     const uint32_t *todo = nullptr, *todo_count = nullptr;
     uint32_t grid = S;
     if (pixel) {
-        if ((rc = ecal_ensure(ctx, ctx->px_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
-        uint32_t *cnt = (uint32_t *) ctx->px_todo.ptr, *list = cnt + 4;
-        ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+        // two to-do lists: what the first pass (<= 1024 points) leaves, and what the second (<= 2048 points) leaves of that
+        if ((rc = ecal_ensure(ctx, ctx->px_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
+        uint32_t *cnt = (uint32_t *) ctx->px_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+        const uint32_t grid2 = S < 1024u ? S : 1024u;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
-        if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC"))
-            hipLaunchKernelGGL(dbscan_pixel_kernel<16>, dim3(S), dim3(PX_T), PixelLayout::bytes + tier0_pad(), st, d_xy,
-                               d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
-        else
-            hipLaunchKernelGGL(dbscan_pixel_kernel<0>, dim3(S), dim3(PX_T), PixelLayout::bytes + tier0_pad(), st, d_xy,
-                               d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
-        todo = list;
-        todo_count = cnt;
+        if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC")) {
+            hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
+                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
+            if (second_pass)
+                hipLaunchKernelGGL((dbscan_pixel_list_kernel<16, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
+                                   d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
+                                   (const uint32_t *) list, (const uint32_t *) cnt);
+        } else {
+            hipLaunchKernelGGL((dbscan_pixel_kernel<0, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
+                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
+            if (second_pass)
+                hipLaunchKernelGGL((dbscan_pixel_list_kernel<0, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
+                                   d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
+                                   (const uint32_t *) list, (const uint32_t *) cnt);
+        }
+        if (second_pass) {
+            todo = list2;
+            todo_count = cnt2;
+        } else {
+            todo = list;
+            todo_count = cnt;
+        }
         grid = S < 1024u ? S : 1024u;
     }
     hipLaunchKernelGGL((dbscan_lds_kernel<CAP0, CAP0 / 4>), dim3(grid), dim3(CAP0 / 4), TierLayout<CAP0>::bytes, st, d_xy,

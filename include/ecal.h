@@ -227,7 +227,8 @@ int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, 
  * (ECAL_ERR_RANGE otherwise: call again with more).  Outputs (host), sorted by time stamp: kf_time [K], kf_duration
  * [K][2], kf_events_num [K] (EventFrame::eventsNum()), kf_features [K][rows*cols][3] (x, y, radius in grid order);
  * *n_keyframes = K (ECAL_ERR_RANGE with the needed count if K > max_keyframes); *passes = lock-step passes that
- * evaluated a window, *windows = windows evaluated.  Synchronous. */
+ * evaluated a window, *windows = windows evaluated.  Synchronous; runs on the context's own stream: d_events must be
+ * complete when the call is made (no pending writes on other streams). */
 typedef struct ecal_adaptive_params {
     double motion_time_step;             /* MotionTimeStep: window = 3 steps, gap after a keyframe = 5 steps */
     uint32_t frame_event_num_threshold;  /* FrameEventNumThreshold */

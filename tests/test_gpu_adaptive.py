@@ -15,6 +15,7 @@ def env():
     from eventcalib_amd.pipeline import DetectPipeline
     ctx = eventcalib_amd.Context(0)
     ev = SS.make_stream(3_000_000, rate=2.0e6, device="cuda", seed=77)
+    torch.cuda.synchronize()   # the library works on its own stream
     yield ctx, DetectPipeline(ctx), ev, torch
     ctx.close()
 

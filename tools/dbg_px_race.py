@@ -7,9 +7,11 @@ import eventcalib_amd
 from eventcalib_amd.pipeline import DetectPipeline
 import synth_stream as SS
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000_000
+rate = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0e6
+wlen = float(sys.argv[3]) if len(sys.argv) > 3 else 1.5e-3
 ctx = eventcalib_amd.Context(0); pipe = DetectPipeline(ctx)
-ev = SS.make_stream(n, device="cuda")
-t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 1e6)
+ev = SS.make_stream(n, rate=rate, device="cuda")
+t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / rate, wlen)
 pipe.set_windows(t0, t1)
 S = len(t0)
 os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
