@@ -23,25 +23,67 @@ __device__ __forceinline__ double load_f64_unaligned(const uint8_t *p) {
 }
 
 // ---------------- window bounds: lower_bound(t0) / upper_bound(t1) on the record stream -----------
+// First index whose time stamp is not < t (STRICT = false: std::lower_bound) or not <= t (STRICT = true:
+// std::upper_bound).  Time stamps grow roughly linearly with the index, so the search starts from the interpolated
+// position, gallops to a bracket and bisects inside it: ~8 dependent loads instead of log2(n) = 26 for 50 M events.
+template <bool STRICT>
+__device__ __forceinline__ uint64_t bound_search(const uint8_t *__restrict__ rec, uint64_t n, double t, double t_first, double t_last) {
+    auto below = [&](uint64_t i) {  // true: the answer lies beyond i
+        const double v = load_f64_unaligned(rec + i * RECORD_BYTES);
+        return STRICT ? (v <= t) : (v < t);
+    };
+    if (n == 0) return 0;
+    const double f = (t - t_first) / (t_last - t_first);  // NaN (one record, or t = NaN) compares false: g = 0
+    uint64_t g = f >= 1.0 ? n - 1 : (f > 0.0 ? (uint64_t) (f * (double) (n - 1)) : 0);
+    if (g > n - 1) g = n - 1;
+    uint64_t lo, hi;  // the answer is in [lo, hi]
+    if (below(g)) {
+        lo = g + 1;
+        hi = n;
+        for (uint64_t w = 32;; w *= 2) {
+            const uint64_t p = g + w;
+            if (p >= n) break;
+            if (!below(p)) {
+                hi = p;
+                break;
+            }
+            lo = p + 1;
+        }
+    } else {
+        hi = g;
+        lo = 0;
+        for (uint64_t w = 32;; w *= 2) {
+            if (g < w) break;
+            const uint64_t p = g - w;
+            if (below(p)) {
+                lo = p + 1;
+                break;
+            }
+            hi = p;
+        }
+    }
+    while (lo < hi) {
+        const uint64_t m = (lo + hi) >> 1;
+        if (below(m)) lo = m + 1; else hi = m;
+    }
+    return lo;
+}
+
 __global__ void window_bounds_kernel(const uint8_t *__restrict__ rec, uint64_t n, const double *__restrict__ t0,
                                      const double *__restrict__ t1, uint32_t S, uint32_t *__restrict__ lo_out,
                                      uint32_t *__restrict__ hi_out) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     const double a0 = t0[s], a1 = t1[s];
-    uint64_t a = 0, b = n;
-    while (a < b) {
-        const uint64_t m = (a + b) >> 1;
-        if (load_f64_unaligned(rec + m * RECORD_BYTES) < a0) a = m + 1; else b = m;
+    double t_first = 0, t_last = 0;
+    if (n) {
+        t_first = load_f64_unaligned(rec);
+        t_last = load_f64_unaligned(rec + (n - 1) * RECORD_BYTES);
     }
-    const uint64_t lo = a;
-    b = n;
-    while (a < b) {
-        const uint64_t m = (a + b) >> 1;
-        if (load_f64_unaligned(rec + m * RECORD_BYTES) <= a1) a = m + 1; else b = m;
-    }
+    const uint64_t lo = bound_search<false>(rec, n, a0, t_first, t_last);   // EventFrame.cpp:14
+    const uint64_t up = bound_search<true>(rec, n, a1, t_first, t_last);    // EventFrame.cpp:15
     lo_out[s] = (uint32_t) lo;
-    hi_out[s] = (uint32_t) (a < lo ? lo : a);
+    hi_out[s] = (uint32_t) (up < lo ? lo : up);
 }
 
 // exclusive scan of (hi - lo) over the windows; base[S] = total.  One block, S is small (<= ~1e6).

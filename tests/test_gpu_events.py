@@ -161,3 +161,39 @@ def test_pixel_and_general_slicers_agree(env):
     n_pts = int(outs[0][2].sum())
     assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][0][:n_pts].view(np.int64), outs[1][0][:n_pts].view(np.int64))
+
+
+def test_window_bounds_search_edge_cases(env):
+    """ecal_window_bounds_dev interpolates the start of its searches (time grows ~linearly with the index), gallops to a
+    bracket and bisects: against numpy's searchsorted on streams whose rate is far from constant (bursts, long pauses,
+    runs of equal time stamps), for windows before / after / across the stream, inverted, infinite and NaN."""
+    import torch
+    ctx = env[0]
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 5, 1000, 200_000):
+        gaps = rng.exponential(1.0, n) * rng.choice([1e-6, 1e-6, 1e-3, 0.0, 5.0], n, p=[0.5, 0.2, 0.1, 0.19, 0.01])
+        t = 7.0 + np.cumsum(gaps)
+        rec = np.zeros((n, 25), np.uint8)
+        rec[:, 0:8] = t.view(np.uint8).reshape(n, 8)
+        ev = torch.from_numpy(rec.reshape(-1)).cuda()
+        S = 4000
+        a = rng.choice(t, S) + rng.choice([0.0, 0.0, 1e-9, -1e-9, 1e-3, -1e-3], S)
+        b = a + rng.choice([0.0, 1e-6, 1e-3, 1.0, -1e-3], S)
+        a[:8] = [-np.inf, np.inf, t[0] - 1, t[-1] + 1, t[0], t[-1], np.nan, -np.inf]
+        b[:8] = [np.inf, -np.inf, t[0] - 0.5, t[-1] + 2, t[0], t[-1], t[-1], np.nan]
+        d_a, d_b = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        lo = torch.zeros(S, dtype=torch.int32, device="cuda")
+        hi = torch.zeros(S, dtype=torch.int32, device="cuda")
+        base = torch.zeros(S + 1, dtype=torch.int32, device="cuda")
+        ctx.window_bounds_dev(ev.data_ptr(), n, d_a.data_ptr(), d_b.data_ptr(), S, lo.data_ptr(), hi.data_ptr(), base.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ok = ~(np.isnan(a) | np.isnan(b))
+        want_lo = np.searchsorted(t, a, side="left")       # std::lower_bound(t0), EventFrame.cpp:14
+        want_hi = np.maximum(np.searchsorted(t, b, side="right"), want_lo)   # std::upper_bound(t1), :15
+        assert np.array_equal(lo.cpu().numpy()[ok], want_lo[ok]), n
+        assert np.array_equal(hi.cpu().numpy()[ok], want_hi[ok]), n
+        # NaN bounds: every comparison is false -> both searches end at 0, the window is empty (as the bisection they replace)
+        got_lo, got_hi = lo.cpu().numpy(), hi.cpu().numpy()
+        assert got_lo[6] == 0 and got_hi[7] == got_lo[7]
+        assert np.array_equal(base.cpu().numpy(), np.concatenate([[0], np.cumsum(got_hi.astype(np.int64) - got_lo)]).astype(np.int32))
