@@ -335,7 +335,125 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     // (Dealing the ~40 + clusters of a window round-robin over the four waves was tried: 0.93 -> 1.06 ms.  The kernel
     // is issue bound, and four waves with 10 active lanes issue four times the instructions of one wave with 40.)
     uint32_t carry = 0;
-    for (uint32_t p0 = 0; p0 < nk[0]; p0 += DET_T) {
+    auto emit = [&](uint32_t pi, bool ok, uint32_t ni_best, double cx, double cy, double r) {
+        uint32_t ex, dummy, tot, dummy2;
+        block_exscan_pair<DET_T>(ok ? 1u : 0u, 0u, red, &ex, &dummy, &tot, &dummy2);
+        if (ok) {
+            const size_t at = (size_t) carry + ex;
+            cand_pair[2 * at] = pi;
+            cand_pair[2 * at + 1] = ni_best;
+            cand_xyr[3 * at] = cx;
+            cand_xyr[3 * at + 1] = cy;
+            cand_xyr[3 * at + 2] = r;
+        }
+        carry += tot;
+    };
+    bool paired = false;
+    if constexpr (!FIT && ST::INT_PIXELS) {
+        // Staged integer pixels, <= 64 + clusters (the usual window): the searches stay on wave 0 (a lane per + cluster),
+        // but the circle test's |distance - r| terms — a correctly rounded f64 square root per member, ~900 instructions
+        // when one lane walks both clusters of its pair — are computed by all four waves, a term per point, and only
+        // their summation (in the reference's order: + members, then - members, ascending pid) goes back to the lane.
+        // The terms take the place of members[] and pts[], which nothing reads after this.
+        if (st.composite() && nk[0] <= 64u) {
+            paired = true;
+            static_assert(4 * DET_LDS_MAXC >= 64 * 3 * sizeof(double), "the pair circles take the place of csize[]");
+            double *const circ = reinterpret_cast<double *>(csize);          // [64][3]: cx, cy, r of + cluster pi's pair
+            typename ST::CIdx *const pair_p = newid, *const pair_n = coff;   // cluster -> its pair (+ cluster index) or none
+            double *const term = reinterpret_cast<double *>(st.members);     // [n_all]
+            for (uint32_t k = tid; k < nk[0]; k += DET_T) pair_p[k] = ST::CNONE;
+            for (uint32_t k = tid; k < nk[1]; k += DET_T) pair_n[k] = ST::CNONE;
+            __syncthreads();
+            const uint32_t pi = tid;
+            bool cand = false;
+            uint32_t ni_best = 0;
+            double cx = 0, cy = 0, r = 0;
+            if (pi < nk[0]) {
+                const uint32_t pw = st.ipt(base[0] + st.rep[kb[0] + pi]);
+                const int px = (int) (short) (pw & 0xFFFFu), py = ((int) pw) >> 16;
+                uint32_t bi = 0xFFFFFFFFu;
+                for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
+                    const uint32_t cw = st.ipt(base[1] + st.rep[kb[1] + k]);
+                    const int dx = px - (int) (short) (cw & 0xFFFFu), dy = py - (((int) cw) >> 16);
+                    const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
+                    if (d < bi) {
+                        bi = d;
+                        ni_best = k;
+                    }
+                }
+                if (bi != 0xFFFFFFFFu && !((double) bi > prm.four_thr2)) {  // :286
+                    const uint32_t nw = st.ipt(base[1] + st.rep[kb[1] + ni_best]);
+                    const int nx = (int) (short) (nw & 0xFFFFu), ny = ((int) nw) >> 16;
+                    uint32_t bi2 = 0xFFFFFFFFu, back = 0;
+                    for (uint32_t k = 0; k < nk[0]; k++) {
+                        const uint32_t cw = st.ipt(base[0] + st.rep[kb[0] + k]);
+                        const int dx = nx - (int) (short) (cw & 0xFFFFu), dy = ny - (((int) cw) >> 16);
+                        const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
+                        if (d < bi2) {
+                            bi2 = d;
+                            back = k;
+                        }
+                    }
+                    if (back == pi) {
+                        cand = true;
+                        const double2 pc = st.pt(base[0] + st.rep[kb[0] + pi]), nc = st.pt(base[1] + st.rep[kb[1] + ni_best]);
+                        cx = (pc.x + nc.x) / 2;
+                        cy = (pc.y + nc.y) / 2;
+                        const double ddx = pc.x - nc.x, ddy = pc.y - nc.y;
+                        r = __dsqrt_rn(ddx * ddx + ddy * ddy) / 2;
+                        circ[3 * pi] = cx;
+                        circ[3 * pi + 1] = cy;
+                        circ[3 * pi + 2] = r;
+                        pair_p[pi] = (typename ST::CIdx) pi;
+                        pair_n[ni_best] = (typename ST::CIdx) pi;
+                    }
+                }
+            }
+            __syncthreads();
+            constexpr int J = (DET_LDS_PTS + DET_T - 1) / DET_T;
+            const uint32_t n_all = n_pol[0] + n_pol[1];
+            double tv[J];
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const uint32_t li = tid + j * DET_T;   // staged: base = {0, n_pol[0]}, so li is the window-local point index
+                tv[j] = 0.0;
+                if (li < n_all) {
+                    const int pol = li >= n_pol[0] ? 1 : 0;
+                    const int32_t kl = st.kept[li];
+                    if (kl >= 0) {
+                        const uint32_t pr = pol ? pair_n[kl] : pair_p[kl];
+                        if (pr != ST::CNONE) {
+                            const double2 e = st.pt(li);
+                            const double ex = e.x - circ[3 * pr], ey = e.y - circ[3 * pr + 1];
+                            tv[j] = fabs(__dsqrt_rn(ex * ex + ey * ey) - circ[3 * pr + 2]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();  // every point has been read: the terms may take the place of members[] and pts[]
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const uint32_t li = tid + j * DET_T;
+                if (li < n_all) term[li] = tv[j];
+            }
+            __syncthreads();
+            bool ok = false;
+            if (cand) {
+                double fit = 0;
+                uint32_t cnt = 0;
+                for (int pol = 0; pol < 2; pol++) {
+                    const uint32_t o = base[pol], kk = pol ? ni_best : pi;
+                    const uint32_t m = st.ksize[kb[pol] + kk], first = o + st.koff[kb[pol] + kk];
+                    for (uint32_t t = 0; t < m; t++) fit += term[o + st.sorted[first + t]];  // ascending pid
+                    cnt += m;
+                }
+                fit /= (double) cnt * r;
+                ok = fit < 10 / r;
+            }
+            emit(pi, ok, ni_best, cx, cy, r);
+        }
+    }
+    for (uint32_t p0 = 0; !paired && p0 < nk[0]; p0 += DET_T) {
         const uint32_t pi = p0 + tid;
         bool ok = false;
         uint32_t ni_best = 0;
@@ -464,17 +582,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
             }
         }
-        uint32_t ex, dummy, tot, dummy2;
-        block_exscan_pair<DET_T>(ok ? 1u : 0u, 0u, red, &ex, &dummy, &tot, &dummy2);
-        if (ok) {
-            const size_t at = (size_t) carry + ex;
-            cand_pair[2 * at] = pi;
-            cand_pair[2 * at + 1] = ni_best;
-            cand_xyr[3 * at] = cx;
-            cand_xyr[3 * at + 1] = cy;
-            cand_xyr[3 * at + 2] = r;
-        }
-        carry += tot;
+        emit(pi, ok, ni_best, cx, cy, r);
     }
     DET_MARK(3);
     if (tid == 0) {
