@@ -355,25 +355,32 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         // when one lane walks both clusters of its pair — are computed by all four waves, a term per point, and only
         // their summation (in the reference's order: + members, then - members, ascending pid) goes back to the lane.
         // The terms take the place of members[] and pts[], which nothing reads after this.
-        if (st.composite() && nk[0] <= 64u) {
+        if (st.composite() && nk[0] <= 64u && nk[1] <= 64u) {
             paired = true;
             static_assert(4 * DET_LDS_MAXC >= 64 * 3 * sizeof(double), "the pair circles take the place of csize[]");
             double *const circ = reinterpret_cast<double *>(csize);          // [64][3]: cx, cy, r of + cluster pi's pair
             typename ST::CIdx *const pair_p = newid, *const pair_n = coff;   // cluster -> its pair (+ cluster index) or none
             double *const term = reinterpret_cast<double *>(st.members);     // [n_all]
-            for (uint32_t k = tid; k < nk[0]; k += DET_T) pair_p[k] = ST::CNONE;
-            for (uint32_t k = tid; k < nk[1]; k += DET_T) pair_n[k] = ST::CNONE;
+            uint32_t *const rp = st.members;  // until the terms arrive: the representatives' packed pixels, [0..63] +, [64..127] -
+            for (uint32_t k = tid; k < nk[0]; k += DET_T) {
+                pair_p[k] = ST::CNONE;
+                rp[k] = st.ipt(base[0] + st.rep[kb[0] + k]);
+            }
+            for (uint32_t k = tid; k < nk[1]; k += DET_T) {
+                pair_n[k] = ST::CNONE;
+                rp[64 + k] = st.ipt(base[1] + st.rep[kb[1] + k]);
+            }
             __syncthreads();
             const uint32_t pi = tid;
             bool cand = false;
             uint32_t ni_best = 0;
             double cx = 0, cy = 0, r = 0;
             if (pi < nk[0]) {
-                const uint32_t pw = st.ipt(base[0] + st.rep[kb[0] + pi]);
+                const uint32_t pw = rp[pi];
                 const int px = (int) (short) (pw & 0xFFFFu), py = ((int) pw) >> 16;
                 uint32_t bi = 0xFFFFFFFFu;
                 for (uint32_t k = 0; k < nk[1]; k++) {  // nanoflann 1-NN, metric_L2_Simple
-                    const uint32_t cw = st.ipt(base[1] + st.rep[kb[1] + k]);
+                    const uint32_t cw = rp[64 + k];
                     const int dx = px - (int) (short) (cw & 0xFFFFu), dy = py - (((int) cw) >> 16);
                     const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
                     if (d < bi) {
@@ -382,11 +389,11 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                     }
                 }
                 if (bi != 0xFFFFFFFFu && !((double) bi > prm.four_thr2)) {  // :286
-                    const uint32_t nw = st.ipt(base[1] + st.rep[kb[1] + ni_best]);
+                    const uint32_t nw = rp[64 + ni_best];
                     const int nx = (int) (short) (nw & 0xFFFFu), ny = ((int) nw) >> 16;
                     uint32_t bi2 = 0xFFFFFFFFu, back = 0;
                     for (uint32_t k = 0; k < nk[0]; k++) {
-                        const uint32_t cw = st.ipt(base[0] + st.rep[kb[0] + k]);
+                        const uint32_t cw = rp[k];
                         const int dx = nx - (int) (short) (cw & 0xFFFFu), dy = ny - (((int) cw) >> 16);
                         const uint32_t d = (uint32_t) (dx * dx) + (uint32_t) (dy * dy);
                         if (d < bi2) {
