@@ -72,6 +72,7 @@ struct DetGlobal {
     __device__ __forceinline__ bool composite() const { return false; }
     __device__ __forceinline__ uint32_t member_word(uint32_t, uint32_t i) const { return i; }
     __device__ __forceinline__ uint32_t ipt(uint32_t) const { return 0; }
+    __device__ __forceinline__ int32_t label(uint32_t, const int32_t *lab, uint32_t i) const { return lab[i]; }  // DBSCAN label
 };
 struct DetLds {
     uint32_t *pts;  // x | y << 16, two's complement int16 each (exact: the staged path is taken for integer pixels only)
@@ -85,6 +86,9 @@ struct DetLds {
     __device__ __forceinline__ bool composite() const { return small; }
     __device__ __forceinline__ uint32_t member_word(uint32_t li, uint32_t i) const { return small ? (key(li) << 11) | i : i; }
     __device__ __forceinline__ uint32_t ipt(uint32_t li) const { return pts[li]; }
+    // the DBSCAN labels were staged into kept[] with the points (one trip to HBM instead of four); the renumbered
+    // label replaces the raw one in place
+    __device__ __forceinline__ int32_t label(uint32_t li, const int32_t *, uint32_t) const { return kept[li]; }
     __device__ __forceinline__ double2 pt(uint32_t li) const {
         const uint32_t w = pts[li];
         return make_double2((double) (int) (short) (w & 0xFFFFu), (double) (((int) w) >> 16));
@@ -235,7 +239,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         for (uint32_t c = tid; c < nc; c += DET_T) csize[c] = 0;
         __syncthreads();
         for (uint32_t i = tid; i < n; i += DET_T) {
-            const int32_t l = lab[i];
+            const int32_t l = st.label(o + i, lab, i);
             if (l >= 0) atomicAdd(&csize[l], 1u);
         }
         __syncthreads();
@@ -271,7 +275,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         __syncthreads();
         // per-point renumbered label; member lists (arbitrary order first)
         for (uint32_t i = tid; i < n; i += DET_T) {
-            const int32_t l = lab[i];
+            const int32_t l = st.label(o + i, lab, i);
             int32_t kl = -1;
             if (l >= 0 && newid[l] != ST::CNONE) {
                 kl = (int32_t) newid[l];
@@ -667,6 +671,8 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
             fits = fits && v.x == floor(v.x) && v.y == floor(v.y) && fabs(v.x) <= 32767.0 && fabs(v.y) <= 32767.0;
             large = large || !(fabs(v.x) <= 1023.0 && fabs(v.y) <= 1023.0);
             lds_pts[i] = ((uint32_t) (int) v.x & 0xFFFFu) | ((uint32_t) (int) v.y << 16);
+            // labels < DET_LDS_MAXC (checked above) or -1: they fit the int16 table that later holds the renumbered ones
+            reinterpret_cast<int16_t *>(smem + DetLdsLayout::kept_off)[i] = (int16_t) labels[o_pol[0] + i];
         }
         // bit 0: some coordinate does not pack; bit 1: some coordinate is beyond the composite-key range
         if (tid == 0) nk_sh[0] = 0;
