@@ -170,6 +170,8 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     uint32_t levels__ = 0;
 #endif
     const uint32_t n = seg_cnt[s];
+    const uint32_t base32 = seg_off[s];  // asked for together with the count: one trip to memory instead of two in a row
+    asm volatile("" ::"s"(base32));     // (a use right here, or the compiler sinks the load below the branches on n)
     if (n == 0) {
         if (tid == 0) n_clusters[s] = 0;
         return;
@@ -198,7 +200,7 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     uint32_t *const anyf = red + 40;
     int *const bbox = reinterpret_cast<int *>(red + 44);  // min x, min y, -max x, -max y
     uint32_t any_round = 0;
-    const size_t base = seg_off[s];
+    const size_t base = base32;
     const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
     // first point of this wave's u-th batch: batches that start at or after n are skipped with a scalar branch
     const uint32_t wbase = __builtin_amdgcn_readfirstlane(tid);
@@ -237,8 +239,6 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
         *n_edges = 0;
         slot[F::DUMMY_SLOT / 4] = NONE32;
     }
-    if (E2I == 0 && tid < (uint32_t) (2 * PX_RMAX + 1)) dm[tid] = geom.dmask[tid];
-    if (E2I > 0 && tid < 32u) hd[tid] = geom.hd_code[tid];
     __syncthreads();
     uint32_t pp[PPT];
     bool fits = true;
@@ -287,6 +287,9 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
             atomicMin(&bbox[3], -(int) mx.y);
         }
     }
+    // the disc tables (read from phase D on; here, behind the point loads, their trip to the kernel arguments is free)
+    if (E2I == 0 && tid < (uint32_t) (2 * PX_RMAX + 1)) dm[tid] = geom.dmask[tid];
+    if (E2I > 0 && tid < 32u) hd[tid] = geom.hd_code[tid];
     if (block_any(!fits, anyf, any_round)) PX_BAIL();
     if (Rd > PX_RMAX) PX_BAIL();
     const int ox = bbox[0] - Rd, oy = bbox[1] - Rd;
