@@ -373,6 +373,9 @@ __global__ __launch_bounds__(T) void slice_lds_kernel(const uint8_t *__restrict_
 // pixels; -0.0 == +0.0 as operator== has it): an event is one 31-bit key (x 15 | y 15 | polarity), the workspace is
 // 24 KB of LDS instead of 58 KB, so a CU holds six windows instead of two — the kernel is a chain of dependent LDS
 // operations (latency bound), throughput follows the workgroups in flight.  Anything else goes to the to-do list.
+#ifndef ECAL_SL_STOP
+#define ECAL_SL_STOP 0   // debug builds: leave slice_pixel_kernel after phase k (tools/px_stop_probe.sh)
+#endif
 constexpr int PXS_T = 256;
 constexpr int PXS_CAP = 2048;
 constexpr uint32_t PXS_NB_LOG = 11;
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
         return;
     }
+    if (ECAL_SL_STOP == 1) return;
     {
         constexpr uint32_t per = NB / T;
         const uint32_t b0 = tid * per;
@@ -480,6 +484,7 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
         sorted[at] = (uint16_t) k;
     }
     __syncthreads();
+    if (ECAL_SL_STOP == 2) return;
     // d. first occurrence per (pixel, polarity); erase pixels that fired with both polarities (EventFrame.cpp:24-32)
     for (uint32_t k = tid; k < n; k += T) {
         const uint32_t p = key[k];
@@ -498,6 +503,7 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
         rep[k] = (uint16_t) (erased ? NONE : ((p & 0x40000000u) ? minP : minN));
     }
     __syncthreads();  // bend is dead from here: pos takes its place
+    if (ECAL_SL_STOP == 3) return;
     // e. ranks of the representatives in event order (blocked ownership: contiguous k per thread)
     const uint32_t per = (n + T - 1) / T, k0 = tid * per;
     uint32_t cntP = 0, cntN = 0;
@@ -510,6 +516,7 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
         if (rep[k] == k) pos[k] = (uint16_t) ((key[k] & 0x40000000u) ? exP++ : exN++);
     }
     __syncthreads();
+    if (ECAL_SL_STOP == 4) return;
     // f. outputs: positives first, then negatives (canonical order = first occurrence)
     double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
     int32_t *ep = event_point + base;
@@ -526,6 +533,207 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
                 v.x = (double) (((int) (p << 17)) >> 17);
                 v.y = (double) (((int) (p << 2)) >> 17);
                 out2[(p & 0x40000000u) ? at : nP + at] = v;
+            }
+        }
+    }
+    if (tid == 0) {
+        seg_off[2 * s] = base;
+        seg_cnt[2 * s] = nP;
+        seg_off[2 * s + 1] = base + nP;
+        seg_cnt[2 * s + 1] = nN;
+    }
+}
+
+// ---------------- pixel windows, hash-table form: the kernel of the hot path ------------------------------------------
+// Same semantics again for windows of <= 2047 events whose coordinates are sensor pixels, 0 <= x <= 2047, 0 <= y <= 1023
+// (+0.0 only).  The counting sort + per-event scan of a hash bucket of slice_pixel_kernel spent 58 % of the kernel's
+// VALU instructions in the bucket loops (trip count = the fullest bucket of the wave).  Here each polarity has an
+// open-addressing table of 2048 words  pixel << 11 | event index : an event claims its pixel's slot with a CAS or lowers
+// the index there with ds_min_u32 — first occurrence = smallest index, exactly what the sort delivered — and after a
+// barrier looks its pixel up in the OTHER polarity's table (present: the pixel is erased, EventFrame.cpp:24-32).  Load
+// factor ~0.3: 1.2 probes on average.  The representative's index rides in the upper 11 bits of the event's key word, the
+// polarities are a bit array: 24 KB of LDS as before.
+constexpr int PXH_T = 256;
+constexpr uint32_t PXH_CAP = 2047;    // events per window: indices 0 .. 2046, 2047 = "erased"
+constexpr uint32_t PXH_SLOTS = 2048;  // per polarity
+constexpr int PXH_PER = 8;            // events per thread at most
+
+struct PixHashLayout {
+    static constexpr size_t key_off = 0;                                   // u32[2048]: pixel (21 bits) | representative << 21
+    static constexpr size_t tab_off = key_off + 4 * 2048;                  // u32[2][2048]; later pos u16[2048]
+    static constexpr size_t pol_off = tab_off + 8 * PXH_SLOTS;             // u32[64]: polarity bits
+    static constexpr size_t red_off = pol_off + 256;                       // 16 x u64 + 4 x u32 flags
+    static constexpr size_t bytes = red_off + 16 * 8 + 16;
+};
+
+__device__ __forceinline__ uint32_t pxh_slot(uint32_t pix) { return (pix * 0x9E3779B1u) >> 21; }
+
+__global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__restrict__ rec,
+                                                           const uint32_t *__restrict__ win_lo,
+                                                           const uint32_t *__restrict__ win_hi,
+                                                           const uint32_t *__restrict__ win_base, uint32_t cap_points,
+                                                           double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
+                                                           uint32_t *__restrict__ seg_cnt,
+                                                           int32_t *__restrict__ event_point, int *overflow,
+                                                           uint32_t *__restrict__ todo,
+                                                           uint32_t *__restrict__ todo_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using L = PixHashLayout;
+    constexpr int T = PXH_T;
+    constexpr uint32_t NONE = 2047u, EMPTY = 0xFFFFFFFFu;
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
+    if (n == 0) {
+        if (tid == 0) {
+            seg_off[2 * s] = base < cap_points ? base : 0;
+            seg_off[2 * s + 1] = seg_off[2 * s];
+            seg_cnt[2 * s] = 0;
+            seg_cnt[2 * s + 1] = 0;
+        }
+        return;
+    }
+    if (n > PXH_CAP) {
+        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+        return;
+    }
+    if ((uint64_t) base + n > cap_points) {  // caller's buffers too small: report, emit empty segments
+        if (tid == 0) {
+            *overflow = 1;
+            seg_off[2 * s] = seg_off[2 * s + 1] = 0;
+            seg_cnt[2 * s] = seg_cnt[2 * s + 1] = 0;
+        }
+        return;
+    }
+    uint32_t *const key = reinterpret_cast<uint32_t *>(smem + L::key_off);
+    uint32_t *const tab = reinterpret_cast<uint32_t *>(smem + L::tab_off);  // [0 .. 2047] negative, [2048 .. 4095] positive
+    uint16_t *const pos = reinterpret_cast<uint16_t *>(smem + L::tab_off);
+    uint32_t *const polbits = reinterpret_cast<uint32_t *>(smem + L::pol_off);
+    uint32_t *const red = reinterpret_cast<uint32_t *>(smem + L::red_off);
+    uint32_t *const badf = red + 32;
+
+    // a. decode (Event.hpp:41-47); the records' loads are all issued before the tables are cleared behind them
+    double vx[PXH_PER], vy[PXH_PER];
+    uint32_t vp[PXH_PER];
+#pragma unroll
+    for (int j = 0; j < PXH_PER; j++) {
+        const uint32_t k = tid + j * T;
+        vx[j] = 0;
+        vy[j] = 0;
+        vp[j] = 0;
+        if (k < n) {
+            const uint8_t *r = rec + (uint64_t) (lo + k) * RECORD_BYTES;
+            vx[j] = load_f64_unaligned(r + 8);
+            vy[j] = load_f64_unaligned(r + 16);
+            vp[j] = r[24];
+        }
+    }
+    {
+        uint4 *t4 = reinterpret_cast<uint4 *>(tab);
+        for (uint32_t q = tid; q < 2 * PXH_SLOTS / 4; q += T) t4[q] = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+    }
+    bool bad = false;
+    uint32_t pix[PXH_PER];
+#pragma unroll
+    for (int j = 0; j < PXH_PER; j++) {
+        const uint32_t k = tid + j * T;
+        const double x = vx[j], y = vy[j];
+        // the sign bit rejects negative coordinates and -0.0 (a valid pixel for operator==, but the emitted element keeps
+        // its sign: general path); the upper bounds are what the table word holds
+        const bool okc = x == floor(x) && y == floor(y) && x <= 2047.0 && y <= 1023.0 && __double_as_longlong(x) >= 0 &&
+                         __double_as_longlong(y) >= 0;
+        bad = bad || (k < n && !okc);
+        pix[j] = (((uint32_t) (int) x & 0x7FFu) << 10) | ((uint32_t) (int) y & 0x3FFu);
+        const unsigned long long pb = __ballot(k < n && vp[j] != 0);   // events tid + j T of this wave: 64 consecutive indices
+        if ((tid & 63u) == 0 && (tid & ~63u) + j * T < n) {
+            polbits[((tid & ~63u) + j * T) >> 5] = (uint32_t) pb;
+            polbits[(((tid & ~63u) + j * T) >> 5) + 1] = (uint32_t) (pb >> 32);
+        }
+    }
+    const bool wave_bad = __any(bad);
+    if ((tid & 63) == 0) badf[tid >> 6] = wave_bad ? 1u : 0u;   // one flag word per wave
+    __syncthreads();
+    if (badf[0] | badf[1] | badf[2] | badf[3]) {
+        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+        return;
+    }
+    // b. every event into its polarity's table: the slot of its pixel ends up holding the smallest event index
+    uint32_t hs[PXH_PER];
+#pragma unroll
+    for (int j = 0; j < PXH_PER; j++) {
+        const uint32_t k = tid + j * T;
+        hs[j] = 0;
+        if (k < n) {
+            uint32_t *const t = tab + (vp[j] ? PXH_SLOTS : 0u);
+            const uint32_t mine = (pix[j] << 11) | k;
+            uint32_t h = pxh_slot(pix[j]);
+            for (;;) {
+                uint32_t w = t[h];
+                if (w == EMPTY) w = atomicCAS(&t[h], EMPTY, mine);   // EMPTY back: the slot is mine
+                if (w == EMPTY) break;
+                if ((w >> 11) == pix[j]) {
+                    atomicMin(&t[h], mine);
+                    break;
+                }
+                h = (h + 1u) & (PXH_SLOTS - 1u);
+            }
+            hs[j] = h;
+        }
+    }
+    __syncthreads();
+    // c. representative = first occurrence of the pixel with this polarity, unless the pixel also fired with the other one
+#pragma unroll
+    for (int j = 0; j < PXH_PER; j++) {
+        const uint32_t k = tid + j * T;
+        if (k < n) {
+            const uint32_t first = tab[(vp[j] ? PXH_SLOTS : 0u) + hs[j]] & 2047u;
+            const uint32_t *const o = tab + (vp[j] ? 0u : PXH_SLOTS);
+            uint32_t h = pxh_slot(pix[j]);
+            bool both = false;
+            for (;;) {
+                const uint32_t w = o[h];
+                if (w == EMPTY) break;
+                if ((w >> 11) == pix[j]) {
+                    both = true;
+                    break;
+                }
+                h = (h + 1u) & (PXH_SLOTS - 1u);
+            }
+            key[k] = pix[j] | ((both ? NONE : first) << 21);
+        }
+    }
+    __syncthreads();  // the tables are dead from here: pos takes their place
+    if (ECAL_SL_STOP == 3) return;
+    // d. ranks of the representatives in event order (blocked ownership: contiguous k per thread)
+    const uint32_t per = (n + T - 1) / T, k0 = tid * per;
+    uint32_t cntP = 0, cntN = 0;
+    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
+        if ((key[k] >> 21) == k) { if ((polbits[k >> 5] >> (k & 31u)) & 1u) cntP++; else cntN++; }
+    }
+    uint32_t exP, exN, nP, nN;
+    block_exscan2<T>(cntP, cntN, red, &exP, &exN, &nP, &nN);
+    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
+        if ((key[k] >> 21) == k) pos[k] = (uint16_t) (((polbits[k >> 5] >> (k & 31u)) & 1u) ? exP++ : exN++);
+    }
+    __syncthreads();
+    // e. outputs: positives first, then negatives (canonical order = first occurrence)
+    double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
+    int32_t *ep = event_point + base;
+#pragma unroll
+    for (int j = 0; j < PXH_PER; j++) {
+        const uint32_t k = tid + j * T;
+        if (k < n) {
+            const uint32_t r = key[k] >> 21;
+            if (r == NONE) {
+                ep[k] = -1;
+            } else {
+                const uint32_t at = pos[r];
+                ep[k] = (int32_t) at;
+                if (r == k) {
+                    double2 v;
+                    v.x = (double) (pix[j] >> 10);
+                    v.y = (double) (pix[j] & 0x3FFu);
+                    out2[vp[j] ? at : nP + at] = v;
+                }
             }
         }
     }
@@ -652,8 +860,12 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_ensure(ctx, ctx->pxs_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
         uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 4;
         ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
-        hipLaunchKernelGGL(slice_pixel_kernel, dim3(S), dim3(PXS_T), PixSliceLayout::bytes, st, d_events, d_win_lo, d_win_hi,
-                           d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+        if (!getenv("ECAL_SLICE_SORT_KERNEL"))   // (debug switch: the counting-sort form, which also takes negative pixels)
+            hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHashLayout::bytes, st, d_events, d_win_lo, d_win_hi,
+                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+        else
+            hipLaunchKernelGGL(slice_pixel_kernel, dim3(S), dim3(PXS_T), PixSliceLayout::bytes, st, d_events, d_win_lo, d_win_hi,
+                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
         todo = list;
         todo_count = cnt;
         grid = S < 512u ? S : 512u;

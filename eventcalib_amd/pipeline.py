@@ -57,7 +57,7 @@ class DetectPipeline:
         """clusterMinSample, rows*cols, circleRadiusThreshold_, fitCircle, knn_num (defaults: example.yaml, 346x260)."""
         self.det = (int(cluster_min), int(need_clusters), float(radius_threshold), bool(fit_circle), int(knn_num))
 
-    def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True):
+    def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True, slice_only=False):
         """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN -> candidate
         extraction on the current torch stream; results stay in HBM (self.xy / seg_off / seg_cnt /
         labels / n_clusters / win_info / cand_pair / cand_xyr / kept_labels / rep)."""
@@ -74,6 +74,8 @@ class DetectPipeline:
                            self.win_base.data_ptr(), S, max_win_events, slots, self.xy.data_ptr(),
                            self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),
                            self.flags.data_ptr(), st)
+        if slice_only:          # profiling aid: bounds + slicing only
+            return self
         c.dbscan_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots,
                            max_seg_points, eps, minpts, self.labels.data_ptr(), self.n_clusters.data_ptr(), st)
         if detect:

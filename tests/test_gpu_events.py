@@ -197,3 +197,47 @@ def test_window_bounds_search_edge_cases(env):
         got_lo, got_hi = lo.cpu().numpy(), hi.cpu().numpy()
         assert got_lo[6] == 0 and got_hi[7] == got_lo[7]
         assert np.array_equal(base.cpu().numpy(), np.concatenate([[0], np.cumsum(got_hi.astype(np.int64) - got_lo)]).astype(np.int32))
+
+
+def test_single_odd_event_sends_the_window_to_the_general_slicer(env):
+    """One event with a non-integer / negative / -0.0 / out-of-range coordinate anywhere in a window (any lane of any
+    wave) must take the window off the pixel fast path; the result equals the general slicer's."""
+    import os
+    import torch
+    ctx = env[0]
+    from eventcalib_amd.pipeline import DetectPipeline
+    buf = SS.make_stream(60000, rate=1.0e6, device="cpu", seed=9)
+    rec = buf.numpy().reshape(-1, 25)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    rng = np.random.default_rng(1)
+    odd = [0.5, -3.0, -0.0, 2048.0, 1.0e300]
+    for w in range(len(t0)):                      # one odd event per window, at a random position
+        idx = np.nonzero((t.numpy() >= t0[w]) & (t.numpy() <= t1[w]))[0]
+        if len(idx) == 0:
+            continue
+        k = int(rng.choice(idx))
+        xy = rec[k, 8:24].copy().view(np.float64)
+        xy[w % 2] = odd[w % len(odd)]
+        rec[k, 8:24] = xy.view(np.uint8)
+    ev = buf.cuda()
+    outs = []
+    for no_pixel in (False, True):
+        if no_pixel:
+            os.environ["ECAL_SLICE_NO_PIXEL"] = "1"
+        try:
+            p = DetectPipeline(ctx)
+            p.set_windows(t0, t1)
+            p.run(ev, slice_only=True)
+            torch.cuda.synchronize()
+            S = len(t0)
+            outs.append((p.seg_off[:2 * S].cpu().numpy().copy(), p.seg_cnt[:2 * S].cpu().numpy().copy(),
+                         p.event_point[:60000].cpu().numpy().copy(), p.xy[:60000].cpu().numpy().copy()))
+        finally:
+            os.environ.pop("ECAL_SLICE_NO_PIXEL", None)
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    used = np.zeros(60000, bool)
+    for o, c in zip(a[0], a[1]):
+        used[o:o + c] = True
+    assert np.array_equal(a[3][used].view(np.uint64), b[3][used].view(np.uint64))   # bitwise, -0.0 included

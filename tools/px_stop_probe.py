@@ -17,7 +17,7 @@ ev = SS.make_stream(n, device="cuda")
 t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 1e6)
 pipe.set_windows(t0, t1)
 for _ in range(3):
-    pipe.run(ev, detect=bool(os.environ.get("ECAL_PROBE_DETECT")))
+    pipe.run(ev, detect=bool(os.environ.get("ECAL_PROBE_DETECT")), slice_only=bool(os.environ.get("ECAL_PROBE_SLICE_ONLY")))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 print("ok")
