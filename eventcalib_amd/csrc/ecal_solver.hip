@@ -490,7 +490,9 @@ __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const
         L[j * BW] = d;
         double *__restrict__ Zj = Z + j * 10;
         for (int c = 0; c < 10; c++) Zj[c] *= inv;
-        const int rmax = (int) std::min<size_t>(BW - 1, nc - 1 - j);
+        // the band is a BLOCK band (4 blocks of 6): column j of block column J reaches down to row 6 (J + 3) + 5 only, and
+        // Cholesky fill stays inside that envelope — the rows beyond hold exact zeros
+        const int rmax = (int) std::min<size_t>(BW - 1 - j % 6, nc - 1 - j);
         double col[BW];  // col[r] = L(j + r, j)
         for (int r = 1; r <= rmax; r++) {
             col[r] = L[(j + r) * BW + r] * inv;
@@ -563,7 +565,7 @@ __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const
         const double *__restrict__ z = Z + ii * 10;
         double v = z[9];
         for (int j = 0; j < 9; j++) v -= z[j] * yi[j];
-        const int kmax = (int) std::min<size_t>(BW - 1, nc - 1 - ii);
+        const int kmax = (int) std::min<size_t>(BW - 1 - ii % 6, nc - 1 - ii);
         for (int k = 1; k <= kmax; k++) v -= L[(ii + k) * BW + k] * yc[ii + k];
         yc[ii] = v / L[ii * BW];
     }
