@@ -553,35 +553,38 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
 // barrier looks its pixel up in the OTHER polarity's table (present: the pixel is erased, EventFrame.cpp:24-32).  Load
 // factor ~0.3: 1.2 probes on average.  The representative's index rides in the upper 11 bits of the event's key word, the
 // polarities are a bit array: 24 KB of LDS as before.
+// LOGC = 11: the first pass (<= 2047 events, x <= 2047, y <= 1023; 24 KB of LDS, six windows per CU);
+// LOGC = 12: the second pass over the windows the first one lists (<= 4095 events, x, y <= 1023; 49 KB, three per CU).
 constexpr int PXH_T = 256;
-constexpr uint32_t PXH_CAP = 2047;    // events per window: indices 0 .. 2046, 2047 = "erased"
-constexpr uint32_t PXH_SLOTS = 2048;  // per polarity
-constexpr int PXH_PER = 8;            // events per thread at most
-
-struct PixHashLayout {
-    static constexpr size_t key_off = 0;                                   // u32[2048]: pixel (21 bits) | representative << 21
-    static constexpr size_t tab_off = key_off + 4 * 2048;                  // u32[2][2048]; later pos u16[2048]
-    static constexpr size_t pol_off = tab_off + 8 * PXH_SLOTS;             // u32[64]: polarity bits
-    static constexpr size_t red_off = pol_off + 256;                       // 16 x u64 + 4 x u32 flags
+template <int LOGC>
+struct PixHash {
+    static constexpr uint32_t SLOTS = 1u << LOGC;        // per polarity
+    static constexpr uint32_t CAP = SLOTS - 1u;          // events per window: indices 0 .. CAP - 1, CAP = "erased"
+    static constexpr int PER = (int) (SLOTS / PXH_T);    // events per thread at most
+    static constexpr uint32_t PIXB = 32u - LOGC;         // pixel bits: x << 10 | y
+    static constexpr double XMAX = (double) ((1u << (PIXB - 10u)) - 1u), YMAX = 1023.0;
+    static constexpr size_t key_off = 0;                                   // u32[SLOTS]: pixel | representative << PIXB
+    static constexpr size_t tab_off = key_off + 4 * SLOTS;                 // u32[2][SLOTS]; later pos u16[SLOTS]
+    static constexpr size_t pol_off = tab_off + 8 * SLOTS;                 // u32[SLOTS / 32]: polarity bits
+    static constexpr size_t red_off = pol_off + SLOTS / 8;                 // 16 x u64 + 4 x u32 flags
     static constexpr size_t bytes = red_off + 16 * 8 + 16;
+    static __device__ __forceinline__ uint32_t slot(uint32_t pix) { return (pix * 0x9E3779B1u) >> (32u - LOGC); }
 };
 
-__device__ __forceinline__ uint32_t pxh_slot(uint32_t pix) { return (pix * 0x9E3779B1u) >> 21; }
-
-__global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__restrict__ rec,
-                                                           const uint32_t *__restrict__ win_lo,
-                                                           const uint32_t *__restrict__ win_hi,
-                                                           const uint32_t *__restrict__ win_base, uint32_t cap_points,
-                                                           double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
-                                                           uint32_t *__restrict__ seg_cnt,
-                                                           int32_t *__restrict__ event_point, int *overflow,
-                                                           uint32_t *__restrict__ todo,
-                                                           uint32_t *__restrict__ todo_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using L = PixHashLayout;
+template <int LOGC>
+__device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uint32_t s, const uint8_t *__restrict__ rec,
+                                                  const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
+                                                  const uint32_t *__restrict__ win_base, uint32_t cap_points,
+                                                  double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
+                                                  uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point,
+                                                  int *overflow, uint32_t *__restrict__ todo,
+                                                  uint32_t *__restrict__ todo_count) {
+    using L = PixHash<LOGC>;
     constexpr int T = PXH_T;
-    constexpr uint32_t NONE = 2047u, EMPTY = 0xFFFFFFFFu;
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    constexpr uint32_t PXH_CAP = L::CAP, PXH_SLOTS = L::SLOTS, IDXM = L::CAP, PIXB = L::PIXB;
+    constexpr int PXH_PER = L::PER;
+    constexpr uint32_t NONE = L::CAP, EMPTY = 0xFFFFFFFFu;
+    const uint32_t tid = threadIdx.x;
     const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
     if (n == 0) {
         if (tid == 0) {
@@ -639,10 +642,10 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
         const double x = vx[j], y = vy[j];
         // the sign bit rejects negative coordinates and -0.0 (a valid pixel for operator==, but the emitted element keeps
         // its sign: general path); the upper bounds are what the table word holds
-        const bool okc = x == floor(x) && y == floor(y) && x <= 2047.0 && y <= 1023.0 && __double_as_longlong(x) >= 0 &&
+        const bool okc = x == floor(x) && y == floor(y) && x <= L::XMAX && y <= L::YMAX && __double_as_longlong(x) >= 0 &&
                          __double_as_longlong(y) >= 0;
         bad = bad || (k < n && !okc);
-        pix[j] = (((uint32_t) (int) x & 0x7FFu) << 10) | ((uint32_t) (int) y & 0x3FFu);
+        pix[j] = (((uint32_t) (int) x << 10) | ((uint32_t) (int) y & 0x3FFu)) & ((1u << PIXB) - 1u);
         const unsigned long long pb = __ballot(k < n && vp[j] != 0);   // events tid + j T of this wave: 64 consecutive indices
         if ((tid & 63u) == 0 && (tid & ~63u) + j * T < n) {
             polbits[((tid & ~63u) + j * T) >> 5] = (uint32_t) pb;
@@ -664,13 +667,13 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
         hs[j] = 0;
         if (k < n) {
             uint32_t *const t = tab + (vp[j] ? PXH_SLOTS : 0u);
-            const uint32_t mine = (pix[j] << 11) | k;
-            uint32_t h = pxh_slot(pix[j]);
+            const uint32_t mine = (pix[j] << LOGC) | k;
+            uint32_t h = L::slot(pix[j]);
             for (;;) {
                 uint32_t w = t[h];
                 if (w == EMPTY) w = atomicCAS(&t[h], EMPTY, mine);   // EMPTY back: the slot is mine
                 if (w == EMPTY) break;
-                if ((w >> 11) == pix[j]) {
+                if ((w >> LOGC) == pix[j]) {
                     atomicMin(&t[h], mine);
                     break;
                 }
@@ -685,20 +688,20 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
     for (int j = 0; j < PXH_PER; j++) {
         const uint32_t k = tid + j * T;
         if (k < n) {
-            const uint32_t first = tab[(vp[j] ? PXH_SLOTS : 0u) + hs[j]] & 2047u;
+            const uint32_t first = tab[(vp[j] ? PXH_SLOTS : 0u) + hs[j]] & IDXM;
             const uint32_t *const o = tab + (vp[j] ? 0u : PXH_SLOTS);
-            uint32_t h = pxh_slot(pix[j]);
+            uint32_t h = L::slot(pix[j]);
             bool both = false;
             for (;;) {
                 const uint32_t w = o[h];
                 if (w == EMPTY) break;
-                if ((w >> 11) == pix[j]) {
+                if ((w >> LOGC) == pix[j]) {
                     both = true;
                     break;
                 }
                 h = (h + 1u) & (PXH_SLOTS - 1u);
             }
-            key[k] = pix[j] | ((both ? NONE : first) << 21);
+            key[k] = pix[j] | ((both ? NONE : first) << PIXB);
         }
     }
     __syncthreads();  // the tables are dead from here: pos takes their place
@@ -707,12 +710,12 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
     const uint32_t per = (n + T - 1) / T, k0 = tid * per;
     uint32_t cntP = 0, cntN = 0;
     for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if ((key[k] >> 21) == k) { if ((polbits[k >> 5] >> (k & 31u)) & 1u) cntP++; else cntN++; }
+        if ((key[k] >> PIXB) == k) { if ((polbits[k >> 5] >> (k & 31u)) & 1u) cntP++; else cntN++; }
     }
     uint32_t exP, exN, nP, nN;
     block_exscan2<T>(cntP, cntN, red, &exP, &exN, &nP, &nN);
     for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if ((key[k] >> 21) == k) pos[k] = (uint16_t) (((polbits[k >> 5] >> (k & 31u)) & 1u) ? exP++ : exN++);
+        if ((key[k] >> PIXB) == k) pos[k] = (uint16_t) (((polbits[k >> 5] >> (k & 31u)) & 1u) ? exP++ : exN++);
     }
     __syncthreads();
     // e. outputs: positives first, then negatives (canonical order = first occurrence)
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
     for (int j = 0; j < PXH_PER; j++) {
         const uint32_t k = tid + j * T;
         if (k < n) {
-            const uint32_t r = key[k] >> 21;
+            const uint32_t r = key[k] >> PIXB;
             if (r == NONE) {
                 ep[k] = -1;
             } else {
@@ -742,6 +745,41 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
         seg_cnt[2 * s] = nP;
         seg_off[2 * s + 1] = base + nP;
         seg_cnt[2 * s + 1] = nN;
+    }
+}
+
+// first pass: workgroup b handles window b; what it cannot take goes to todo / todo_count
+__global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__restrict__ rec,
+                                                           const uint32_t *__restrict__ win_lo,
+                                                           const uint32_t *__restrict__ win_hi,
+                                                           const uint32_t *__restrict__ win_base, uint32_t cap_points,
+                                                           double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
+                                                           uint32_t *__restrict__ seg_cnt,
+                                                           int32_t *__restrict__ event_point, int *overflow,
+                                                           uint32_t *__restrict__ todo,
+                                                           uint32_t *__restrict__ todo_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    slice_hash_window<11>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
+                          todo, todo_count);
+}
+
+// second pass: the workgroups share the list the first pass left (in_list[0 .. *in_count)); windows of up to 4095 events
+__global__ __launch_bounds__(PXH_T) void slice_hash_list_kernel(const uint8_t *__restrict__ rec,
+                                                                const uint32_t *__restrict__ win_lo,
+                                                                const uint32_t *__restrict__ win_hi,
+                                                                const uint32_t *__restrict__ win_base, uint32_t cap_points,
+                                                                double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
+                                                                uint32_t *__restrict__ seg_cnt,
+                                                                int32_t *__restrict__ event_point, int *overflow,
+                                                                uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
+                                                                const uint32_t *__restrict__ in_list,
+                                                                const uint32_t *__restrict__ in_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t count = *in_count;
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        slice_hash_window<12>(smem, in_list[k], rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point,
+                              overflow, todo, todo_count);
+        __syncthreads();
     }
 }
 
@@ -848,6 +886,8 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_lds_kernel<SCAP1, 4096, 512>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int) SliceLayout<SCAP1>::bytes));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_list_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixHash<12>::bytes));
         ctx->slice_attrs_set = true;
     }
     ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
@@ -857,17 +897,26 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
     uint32_t grid = S;
     if (!getenv("ECAL_SLICE_NO_PIXEL")) {
         int rc;
-        if ((rc = ecal_ensure(ctx, ctx->pxs_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
-        uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 4;
-        ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
-        if (!getenv("ECAL_SLICE_SORT_KERNEL"))   // (debug switch: the counting-sort form, which also takes negative pixels)
-            hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHashLayout::bytes, st, d_events, d_win_lo, d_win_hi,
-                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
-        else
-            hipLaunchKernelGGL(slice_pixel_kernel, dim3(S), dim3(PXS_T), PixSliceLayout::bytes, st, d_events, d_win_lo, d_win_hi,
-                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+        if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
+        uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
         todo = list;
         todo_count = cnt;
+        if (!getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)
+            hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
+                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+            if (mx > PixHash<11>::CAP && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
+                const uint32_t grid2 = S < 768u ? S : 768u;
+                hipLaunchKernelGGL(slice_hash_list_kernel, dim3(grid2), dim3(PXH_T), PixHash<12>::bytes, st, d_events, d_win_lo,
+                                   d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
+                                   cnt2, (const uint32_t *) list, (const uint32_t *) cnt);
+                todo = list2;
+                todo_count = cnt2;
+            }
+        } else {
+            hipLaunchKernelGGL(slice_pixel_kernel, dim3(S), dim3(PXS_T), PixSliceLayout::bytes, st, d_events, d_win_lo, d_win_hi,
+                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+        }
         grid = S < 512u ? S : 512u;
     }
     hipLaunchKernelGGL((slice_lds_kernel<SCAP0, 2048, 256>), dim3(grid), dim3(256), SliceLayout<SCAP0>::bytes, st, d_events,

@@ -241,3 +241,44 @@ def test_single_odd_event_sends_the_window_to_the_general_slicer(env):
     for o, c in zip(a[0], a[1]):
         used[o:o + c] = True
     assert np.array_equal(a[3][used].view(np.uint64), b[3][used].view(np.uint64))   # bitwise, -0.0 included
+
+
+def test_hash_slicer_second_pass_equals_general_slicer(env):
+    """Windows of 2048 ... 4095 events are taken by the second pass of the hash-table slicer (4096-slot tables, 12-bit event
+    indices); its result must equal the general slicer's, and the oracle's on a sample of windows."""
+    import os
+    import torch
+    ctx = env[0]
+    from eventcalib_amd.pipeline import DetectPipeline
+    n = 120000
+    buf = SS.make_stream(n, rate=2.0e6, device="cpu", seed=21)
+    t, _, _ = SS.unpack_records(buf)
+    t0a, t1a = SS.tiled_windows(float(t[0]), float(t[-1]), 1.5e-3)      # ~3000 events
+    t0b, t1b = SS.tiled_windows(float(t[0]), float(t[-1]), 2.0e-3)      # ~4000 events
+    t0, t1 = np.concatenate([t0a, t0b]), np.concatenate([t1a, t1b])
+    ev = buf.cuda()
+    outs = []
+    for no_pixel in (False, True):
+        if no_pixel:
+            os.environ["ECAL_SLICE_NO_PIXEL"] = "1"
+        try:
+            p = DetectPipeline(ctx)
+            p.set_windows(t0, t1)
+            p.run(ev, slots=2 * n + 8192, slice_only=True)
+            torch.cuda.synchronize()
+            S = len(t0)
+            assert not p.overflowed()
+            outs.append((p.win_lo[:S].cpu().numpy().copy(), p.win_hi[:S].cpu().numpy().copy(), p.seg_off[:2 * S].cpu().numpy().copy(),
+                         p.seg_cnt[:2 * S].cpu().numpy().copy(), p.event_point.cpu().numpy().copy(), p.xy.cpu().numpy().copy(),
+                         p.win_base[:S + 1].cpu().numpy().copy()))
+        finally:
+            os.environ.pop("ECAL_SLICE_NO_PIXEL", None)
+    a, b = outs
+    assert int((a[1] - a[0]).max()) > 2048 and int((a[1] - a[0]).max()) < 4096
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for s in range(len(t0)):
+        lo, hi, base = int(a[0][s]), int(a[1][s]), int(a[6][s])
+        assert np.array_equal(a[4][base:base + hi - lo], b[4][base:base + hi - lo]), s
+        for pol in range(2):
+            o, c = int(a[2][2 * s + pol]), int(a[3][2 * s + pol])
+            assert np.array_equal(a[5][o:o + c], b[5][o:o + c]), (s, pol)
