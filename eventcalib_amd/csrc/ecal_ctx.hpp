@@ -28,6 +28,7 @@ struct ecal_ctx {
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
     ecal_devbuf det_members, det_koff, det_ksize, det_sorted, det_norms;  // detection stage scratch
+    ecal_devbuf det_todo;  // [4 + S] u32: count, then the windows the first extraction pass left to the second
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
     ecal_devbuf as_host;         // staging of ecal_associate
     ecal_devbuf ingest_ev[2], ingest_feat;  // ecal_detect_stream_tiled: ping-pong event chunks, gathered features
@@ -46,7 +47,7 @@ struct ecal_ctx {
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos,
-                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &as_cnt, &as_off,
+                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
                 &host_rect[7], &host_rect[8], &host_rect[9], &host_rect[10],
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],

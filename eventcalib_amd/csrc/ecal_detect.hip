@@ -41,6 +41,7 @@ constexpr int DET_T = 256;
 constexpr uint32_t DET_MAXC = 2048;       // DBSCAN clusters per polarity the kernel handles at all
 constexpr uint32_t DET_LDS_PTS = 1408;    // points per window (both polarities) staged in LDS, packed to 4 bytes (6 workgroups/CU) ...
 constexpr uint32_t DET_LDS_MAXC = 384;    // ... when neither polarity has more DBSCAN clusters than this and every
+constexpr uint32_t DET_LDS_PTS2 = 2816, DET_LDS_MAXC2 = 512;   // second pass over the windows the first one lists (44 KB of LDS)
                                           // coordinate is an integer of |v| <= 32767 (event pixels)
 
 struct DetectParams {
@@ -67,6 +68,9 @@ struct DetGlobal {
     __device__ __forceinline__ double key(uint32_t li) const { return norms[li]; }  // ordering key of the median
     __device__ __forceinline__ void set_norm(uint32_t li, double v) const { norms[li] = v; }
     static constexpr bool INT_PIXELS = false;
+    static constexpr uint32_t IDX_MASK = 0xFFFFFFFFu;
+    static constexpr int J = 1;
+    static constexpr uint32_t MAXC = 0;
     using CIdx = uint32_t;  // renumbered cluster id / first member slot of a DBSCAN cluster
     static constexpr CIdx CNONE = 0xFFFFFFFFu;
     __device__ __forceinline__ bool composite() const { return false; }
@@ -74,17 +78,22 @@ struct DetGlobal {
     __device__ __forceinline__ uint32_t ipt(uint32_t) const { return 0; }
     __device__ __forceinline__ int32_t label(uint32_t, const int32_t *lab, uint32_t i) const { return lab[i]; }  // DBSCAN label
 };
-struct DetLds {
+template <uint32_t PTS_, uint32_t MAXC_>
+struct DetLdsT {
+    static constexpr uint32_t IDXB = PTS_ > 2048u ? 12u : 11u;   // bits of the window-local point index in a member word
+    static constexpr uint32_t IDX_MASK = (1u << IDXB) - 1u;
+    static constexpr int J = (int) ((PTS_ + 255u) / 256u);        // points per thread at most
+    static constexpr uint32_t MAXC = MAXC_;
     uint32_t *pts;  // x | y << 16, two's complement int16 each (exact: the staged path is taken for integer pixels only)
-    uint32_t *members;  // member lists; when `small`: key << 11 | point index (one compare orders by (norm, pid))
+    uint32_t *members;  // member lists; when `small`: key << IDXB | point index (one compare orders by (norm, pid))
     uint16_t *sorted, *koff, *ksize, *rep;
     int16_t *kept;
-    bool small;  // every |coordinate| <= 1023: x^2 + y^2 < 2^21 leaves 11 bits for the window-local index (< 1408)
+    bool small;  // every |coordinate| <= 1023 (723 in the second pass): x^2 + y^2 < 2^(32 - IDXB) leaves IDXB bits for the index
     static constexpr bool INT_PIXELS = true;
     using CIdx = uint16_t;
     static constexpr CIdx CNONE = 0xFFFFu;
     __device__ __forceinline__ bool composite() const { return small; }
-    __device__ __forceinline__ uint32_t member_word(uint32_t li, uint32_t i) const { return small ? (key(li) << 11) | i : i; }
+    __device__ __forceinline__ uint32_t member_word(uint32_t li, uint32_t i) const { return small ? (key(li) << IDXB) | i : i; }
     __device__ __forceinline__ uint32_t ipt(uint32_t li) const { return pts[li]; }
     // the DBSCAN labels were staged into kept[] with the points (one trip to HBM instead of four); the renumbered
     // label replaces the raw one in place
@@ -309,7 +318,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         const int pol = idx >= tm0 ? 1 : 0;
         const uint32_t o = base[pol];
         const uint32_t wq = st.members[o + idx - (pol ? tm0 : 0u)];
-        const uint32_t i = st.composite() ? (wq & 2047u) : wq;
+        const uint32_t i = st.composite() ? (wq & ST::IDX_MASK) : wq;
         const int32_t kl = st.kept[o + i];
         const uint32_t m = st.ksize[kb[pol] + kl], first = o + st.koff[kb[pol] + kl];
         uint32_t rank = 0, at = 0;
@@ -318,7 +327,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
             for (uint32_t t = 0; t < m; t++) {
                 const uint32_t wj = st.members[first + t];
                 rank += (wj < wi) ? 1u : 0u;
-                at += ((wj & 2047u) < i) ? 1u : 0u;
+                at += ((wj & ST::IDX_MASK) < i) ? 1u : 0u;
             }
         } else {
             const auto ni = st.key(o + i);
@@ -361,7 +370,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         // The terms take the place of members[] and pts[], which nothing reads after this.
         if (st.composite() && nk[0] <= 64u && nk[1] <= 64u) {
             paired = true;
-            static_assert(4 * DET_LDS_MAXC >= 64 * 3 * sizeof(double), "the pair circles take the place of csize[]");
+            static_assert(4 * ST::MAXC >= 64 * 3 * sizeof(double), "the pair circles take the place of csize[]");
             double *const circ = reinterpret_cast<double *>(csize);          // [64][3]: cx, cy, r of + cluster pi's pair
             typename ST::CIdx *const pair_p = newid, *const pair_n = coff;   // cluster -> its pair (+ cluster index) or none
             double *const term = reinterpret_cast<double *>(st.members);     // [n_all]
@@ -421,7 +430,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
             }
             __syncthreads();
-            constexpr int J = (DET_LDS_PTS + DET_T - 1) / DET_T;
+            constexpr int J = ST::J;
             const uint32_t n_all = n_pol[0] + n_pol[1];
             double tv[J];
 #pragma unroll
@@ -606,37 +615,36 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
 
 // LDS of the staged path: per DBSCAN cluster (csize u32: atomics; newid, coff), per kept cluster and polarity (koff,
 // ksize, rep), per point (sorted, kept, members, pts)
-struct DetLdsLayout {
+template <uint32_t PTS, uint32_t MAXC>
+struct DetLdsLayoutT {
     static constexpr size_t csize_off = 0;                                          // u32[MAXC]
-    static constexpr size_t newid_off = csize_off + 4 * DET_LDS_MAXC;              // u16[MAXC]
-    static constexpr size_t coff_off = newid_off + 2 * DET_LDS_MAXC;               // u16[MAXC]
-    static constexpr size_t koff_off = coff_off + 2 * DET_LDS_MAXC;                // u16[2 * MAXC]
-    static constexpr size_t ksize_off = koff_off + 4 * DET_LDS_MAXC;               // u16[2 * MAXC]
-    static constexpr size_t rep_off = ksize_off + 4 * DET_LDS_MAXC;                // u16[2 * MAXC]
-    static constexpr size_t sorted_off = rep_off + 4 * DET_LDS_MAXC;               // u16[PTS]
-    static constexpr size_t kept_off = sorted_off + 2 * DET_LDS_PTS;               // i16[PTS]
-    static constexpr size_t members_off = kept_off + 2 * DET_LDS_PTS;              // u32[PTS]
-    static constexpr size_t pts_off = members_off + 4 * DET_LDS_PTS;               // u32[PTS]
-    static constexpr size_t bytes = pts_off + 4 * DET_LDS_PTS;
+    static constexpr size_t newid_off = csize_off + 4 * MAXC;              // u16[MAXC]
+    static constexpr size_t coff_off = newid_off + 2 * MAXC;               // u16[MAXC]
+    static constexpr size_t koff_off = coff_off + 2 * MAXC;                // u16[2 * MAXC]
+    static constexpr size_t ksize_off = koff_off + 4 * MAXC;               // u16[2 * MAXC]
+    static constexpr size_t rep_off = ksize_off + 4 * MAXC;                // u16[2 * MAXC]
+    static constexpr size_t sorted_off = rep_off + 4 * MAXC;               // u16[PTS]
+    static constexpr size_t kept_off = sorted_off + 2 * PTS;               // i16[PTS]
+    static constexpr size_t members_off = kept_off + 2 * PTS;              // u32[PTS]
+    static constexpr size_t pts_off = members_off + 4 * PTS;               // u32[PTS]
+    static constexpr size_t bytes = pts_off + 4 * PTS;
 };
 
-// FIT = Params::fitCircle: the algebraic-fit pairing keeps two 3x4 systems in registers; compiled apart so that the
-// default path (fitCircle == 0) stays below 96 VGPRs = five workgroups per CU
-template <bool FIT>
-__global__ __launch_bounds__(DET_T) void extract_kernel(
-    const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
-    const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
-    uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
-    int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
-    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
-    double *__restrict__ norms) {
+// One window.  PTS / MAXC: capacity of the LDS staging.  FIRST: the first pass hands windows that do not fit its staging but
+// fit the second pass's (DET_LDS_PTS2 points, DET_LDS_MAXC2 clusters) to the to-do list instead of taking the global path.
+template <bool FIT, uint32_t PTS, uint32_t MAXC, bool FIRST>
+__device__ __forceinline__ void extract_one(
+    unsigned char *smem, unsigned long long *red, uint32_t *nk_sh, const uint32_t s, const double *__restrict__ xy,
+    const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt, const int32_t *__restrict__ labels,
+    const uint32_t *__restrict__ n_clusters, const DetectParams &prm, uint32_t *__restrict__ win_info,
+    uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr, int32_t *__restrict__ kept_labels,
+    uint32_t *__restrict__ rep, uint32_t *__restrict__ members, uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize,
+    uint32_t *__restrict__ sorted, double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count) {
+    using LL = DetLdsLayoutT<PTS, MAXC>;
     // csize: members per DBSCAN cluster, later a scatter cursor; newid: renumbered id of a kept cluster;
     // coff: first member slot of a kept cluster.  Sized for the global path; the LDS path uses the first
     // DET_LDS_MAXC entries and the rest of the block for its staged arrays.
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned long long red[DET_T / 64];
-    __shared__ uint32_t nk_sh[4];  // kept clusters per polarity, their members per polarity
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const double2 *pts = reinterpret_cast<const double2 *>(xy);
     uint32_t *info = win_info + 4 * (size_t) s;
     const uint32_t o_pol[2] = {seg_off[2 * s], seg_off[2 * s + 1]};
@@ -659,20 +667,26 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     // or if the window is too large, work in global scratch
     const bool contiguous = o_pol[1] == o_pol[0] + n_pol[0];
     const uint32_t n_all = n_pol[0] + n_pol[1];
-    bool staged = contiguous && n_all <= DET_LDS_PTS && nc_pol[0] <= DET_LDS_MAXC && nc_pol[1] <= DET_LDS_MAXC;
+    bool staged = contiguous && n_all <= PTS && nc_pol[0] <= MAXC && nc_pol[1] <= MAXC;
+    if (FIRST && !staged && contiguous && n_all <= DET_LDS_PTS2 && nc_pol[0] <= DET_LDS_MAXC2 && nc_pol[1] <= DET_LDS_MAXC2 && todo) {
+        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;   // the second pass stages it in LDS
+        return;
+    }
     uint32_t *csize = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *const lds_pts = reinterpret_cast<uint32_t *>(smem + DetLdsLayout::pts_off);
+    uint32_t *const lds_pts = reinterpret_cast<uint32_t *>(smem + LL::pts_off);
     DET_T0();
     bool small_px = false;
+    // the composite member word holds key = x^2 + y^2 in 32 - IDXB bits
+    constexpr double KEY_LIM = PTS > 2048u ? 723.0 : 1023.0;
     if (staged) {  // stage the points packed; a coordinate that does not pack exactly sends the window to the global path
         bool fits = true, large = false;
         for (uint32_t i = tid; i < n_all; i += DET_T) {
             const double2 v = pts[o_pol[0] + i];
             fits = fits && v.x == floor(v.x) && v.y == floor(v.y) && fabs(v.x) <= 32767.0 && fabs(v.y) <= 32767.0;
-            large = large || !(fabs(v.x) <= 1023.0 && fabs(v.y) <= 1023.0);
+            large = large || !(fabs(v.x) <= KEY_LIM && fabs(v.y) <= KEY_LIM);
             lds_pts[i] = ((uint32_t) (int) v.x & 0xFFFFu) | ((uint32_t) (int) v.y << 16);
             // labels < DET_LDS_MAXC (checked above) or -1: they fit the int16 table that later holds the renumbered ones
-            reinterpret_cast<int16_t *>(smem + DetLdsLayout::kept_off)[i] = (int16_t) labels[o_pol[0] + i];
+            reinterpret_cast<int16_t *>(smem + LL::kept_off)[i] = (int16_t) labels[o_pol[0] + i];
         }
         // bit 0: some coordinate does not pack; bit 1: some coordinate is beyond the composite-key range
         if (tid == 0) nk_sh[0] = 0;
@@ -689,8 +703,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         }
     }
     if (staged) {
-        DetLds st;
-        using LL = DetLdsLayout;
+        DetLdsT<PTS, MAXC> st;
         st.sorted = reinterpret_cast<uint16_t *>(smem + LL::sorted_off);
         st.koff = reinterpret_cast<uint16_t *>(smem + LL::koff_off);
         st.ksize = reinterpret_cast<uint16_t *>(smem + LL::ksize_off);
@@ -700,7 +713,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         st.pts = lds_pts;
         st.small = small_px;
         const uint32_t base[2] = {0u, n_pol[0]};
-        const uint32_t kb[2] = {0u, DET_LDS_MAXC};  // per-cluster arrays: one block of DET_LDS_MAXC per polarity
+        const uint32_t kb[2] = {0u, MAXC};  // per-cluster arrays: one block of MAXC per polarity
         extract_window<FIT>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize,
                        reinterpret_cast<uint16_t *>(smem + LL::newid_off), reinterpret_cast<uint16_t *>(smem + LL::coff_off), red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
@@ -737,9 +750,50 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     }
 }
 
+// FIT = Params::fitCircle: the algebraic-fit pairing keeps two 3x4 systems in registers; compiled apart so that the default
+// path (fitCircle == 0) stays below 72 VGPRs.  First pass: workgroup b takes window b.
+template <bool FIT>
+__global__ __launch_bounds__(DET_T) void extract_kernel(
+    const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+    const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
+    uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
+    int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
+    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
+    double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long red[DET_T / 64];
+    __shared__ uint32_t nk_sh[4];  // kept clusters per polarity, their members per polarity
+    extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true>(smem, red, nk_sh, blockIdx.x, xy, seg_off, seg_cnt, labels, n_clusters, prm,
+                                                      win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff, ksize, sorted,
+                                                      norms, todo, todo_count);
+}
+
+// second pass: the workgroups share the list of windows of DET_LDS_PTS + 1 ... DET_LDS_PTS2 points the first pass left
+template <bool FIT>
+__global__ __launch_bounds__(DET_T) void extract_list_kernel(
+    const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+    const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
+    uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
+    int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
+    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
+    double *__restrict__ norms, const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long red[DET_T / 64];
+    __shared__ uint32_t nk_sh[4];
+    const uint32_t count = *in_count;
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        extract_one<FIT, DET_LDS_PTS2, DET_LDS_MAXC2, false>(smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters,
+                                                             prm, win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff,
+                                                             ksize, sorted, norms, nullptr, nullptr);
+        __syncthreads();
+    }
+}
+
 constexpr size_t DET_LDS_BYTES_GLOBAL = 3 * DET_MAXC * sizeof(uint32_t);
-constexpr size_t DET_LDS_BYTES_STAGED = DetLdsLayout::bytes;
+constexpr size_t DET_LDS_BYTES_STAGED = DetLdsLayoutT<DET_LDS_PTS, DET_LDS_MAXC>::bytes;
 static_assert(DET_LDS_BYTES_STAGED + 64 <= 26624, "six workgroups per CU");
+constexpr size_t DET_LDS_BYTES2 = DetLdsLayoutT<DET_LDS_PTS2, DET_LDS_MAXC2>::bytes > DET_LDS_BYTES_GLOBAL
+                                      ? DetLdsLayoutT<DET_LDS_PTS2, DET_LDS_MAXC2>::bytes : DET_LDS_BYTES_GLOBAL;
 constexpr size_t DET_LDS_BYTES = DET_LDS_BYTES_STAGED > DET_LDS_BYTES_GLOBAL ? DET_LDS_BYTES_STAGED : DET_LDS_BYTES_GLOBAL;
 
 }  // namespace ecal
@@ -813,20 +867,39 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_list_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES2));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_list_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES2));
         ctx->det_attr_set = true;
     }
-    if (prm.fit_circle)
-        hipLaunchKernelGGL(extract_kernel<true>, dim3(S), dim3(DET_T), DET_LDS_BYTES, (hipStream_t) stream, d_xy, d_seg_off,
-                           d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
-                           (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
-                           (uint32_t *) ctx->det_ksize.ptr, (uint32_t *) ctx->det_sorted.ptr,
-                           (double *) ctx->det_norms.ptr);
-    else
-        hipLaunchKernelGGL(extract_kernel<false>, dim3(S), dim3(DET_T), DET_LDS_BYTES, (hipStream_t) stream, d_xy, d_seg_off,
-                           d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep,
-                           (uint32_t *) ctx->det_members.ptr, (uint32_t *) ctx->det_koff.ptr,
-                           (uint32_t *) ctx->det_ksize.ptr, (uint32_t *) ctx->det_sorted.ptr,
-                           (double *) ctx->det_norms.ptr);
+    // windows too large for the first pass's LDS staging but not for the second's are listed by the first pass
+    if ((rc = ecal_ensure(ctx, ctx->det_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
+    uint32_t *cnt = (uint32_t *) ctx->det_todo.ptr, *list = cnt + 4;
+    const bool second = !getenv("ECAL_EXTRACT_NO_SECOND_PASS");
+    hipStream_t st = (hipStream_t) stream;
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+    uint32_t *mem = (uint32_t *) ctx->det_members.ptr, *ko = (uint32_t *) ctx->det_koff.ptr, *ks = (uint32_t *) ctx->det_ksize.ptr,
+             *so = (uint32_t *) ctx->det_sorted.ptr;
+    double *no = (double *) ctx->det_norms.ptr;
+    const uint32_t grid2 = S < 768u ? S : 768u;
+    if (prm.fit_circle) {
+        hipLaunchKernelGGL(extract_kernel<true>, dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,
+                           d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,
+                           second ? list : nullptr, cnt);
+        if (second)
+            hipLaunchKernelGGL(extract_list_kernel<true>, dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,
+                               d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks,
+                               so, no, (const uint32_t *) list, (const uint32_t *) cnt);
+    } else {
+        hipLaunchKernelGGL(extract_kernel<false>, dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,
+                           d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,
+                           second ? list : nullptr, cnt);
+        if (second)
+            hipLaunchKernelGGL(extract_list_kernel<false>, dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,
+                               d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks,
+                               so, no, (const uint32_t *) list, (const uint32_t *) cnt);
+    }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
