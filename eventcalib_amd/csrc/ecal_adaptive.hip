@@ -74,7 +74,7 @@ __device__ void row_direction(const double *xyr, const int32_t *order, uint32_t 
 struct AdaptiveArrays {
     double *first, *second, *bound_hi, *ref_t, *ref_dir;  // [P], [P], [P], [P], [P][rows][2]
     uint32_t *active, *have_ref;                          // [P]
-    uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: unused
+    uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: slots overflowed
     unsigned long long *windows;                          // windows evaluated
 };
 
@@ -105,8 +105,9 @@ __global__ void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, u
                                      const uint32_t *__restrict__ found, AdaptiveArrays st, double mts, uint32_t thr_events,
                                      uint32_t max_keys, double *__restrict__ kf_time, double *__restrict__ kf_dur,
                                      int32_t *__restrict__ kf_events, double *__restrict__ kf_feat, double *__restrict__ t0,
-                                     double *__restrict__ t1) {
+                                     double *__restrict__ t1, const int *__restrict__ overflow) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && *overflow) st.counters[3] = 1;  // the slicer clears its flag at every call: keep it until the host looks
     if (k >= P || !st.active[k]) return;
     const uint32_t M = rows * cols;
     const double ln = 3 * mts, gap = 5 * mts;
@@ -268,12 +269,11 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
                            (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
                            (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                            (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
-                           max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1);
+                           max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1, (const int *) B[16].ptr);
         if (pass % check_every == check_every - 1 || pass + 1 == max_passes) {
             ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            ECAL_HIP_TRY(ctx, hipMemcpyAsync(h + 4, B[16].ptr, sizeof(int), hipMemcpyDeviceToHost, st));
             ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
-            if (h[4]) {
+            if (h[3]) {
                 ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
                 return ECAL_ERR_RANGE;
             }
