@@ -478,10 +478,12 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     PX_STOP(4, myrk[u] + pf[i]);
     // ---------------- D: core test ----------------
     bool core[PPT];
+    uint32_t hdw[PPT];  // compiled-in disc: the half disc of the point as one packed word, taken from the windows phase D reads anyway
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         const uint32_t i = tid + u * T;
         core[u] = false;
+        hdw[u] = 0;
         if (wbase + u * T < n && i < n) {
             const uint32_t cx = mcx[u], yy = myy[u], c0 = cx - (uint32_t) Rd, sh5 = c0 & 31u;
             uint32_t a = (yy - (uint32_t) Rd) * RW + (c0 >> 5);
@@ -493,6 +495,9 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
                     cnt += (uint32_t) __popc(v & mask_of(k));
                     if (k == px_isqrt(E2I)) vmid = v;
                     if (k == 2 * px_isqrt(E2I)) vlast = v;
+                    if (k <= px_isqrt(E2I) && px_hd_pos(E2I, px_isqrt(E2I), px_isqrt(E2I) + 1) <= 32)
+                        hdw[u] |= __builtin_amdgcn_ubfe(v, (uint32_t) px_hd_low(E2I, px_isqrt(E2I), k), (uint32_t) px_hd_width(E2I, px_isqrt(E2I), k))
+                                  << px_hd_pos(E2I, px_isqrt(E2I), k);
                     a += RW;
                 }
             } else {
@@ -586,13 +591,7 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
             // the whole half disc as one packed word: a field per row, one loop over its set bits
             constexpr int RD = px_isqrt(E2I);
             static_assert(RD <= 4 && px_hd_pos(E2I, RD, RD + 1) <= 32, "the packed half disc must fit 32 bits");
-            uint32_t nm = 0, a = a0;
-#pragma unroll
-            for (int k = 0; k <= RD; k++) {
-                nm |= __builtin_amdgcn_ubfe(window(a, sh5), (uint32_t) px_hd_low(E2I, RD, k), (uint32_t) px_hd_width(E2I, RD, k))
-                      << px_hd_pos(E2I, RD, k);
-                a += RW;
-            }
+            uint32_t nm = hdw[u];  // (the bitmap has not changed since phase D)
             while (nm) {
                 const uint32_t e = hd[__ffs((int) nm) - 1];
                 nm &= nm - 1u;
