@@ -340,56 +340,44 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     }
     __syncthreads();
     ECAL_PHASE_MARK(12);
-    // B.1: every later point walks the finished top tree (reads only).  All walks start at the root together and
-    // go down one level per step, so the splitting dimension is the same for the whole wave (no per-lane selects);
-    // the walks of a thread's points advance together so their LDS round trips overlap; a walk that has ended keeps
-    // reading its empty slot (nobody writes during B.1).
+    // B.1: every later point walks the finished top tree (reads only; nobody writes during B.1).  The 64 walks of a
+    // batch (u, wave) start at the root together and go down one level per step, so the splitting dimension is the same
+    // for the whole wave (no per-lane selects); a walk that has ended keeps reading its empty slot.  One batch after the
+    // other: each loop runs to the depth of ITS deepest walk — interleaving a thread's batches in one loop made every level
+    // cost the deepest of all of them, and the kernel is bound by VALU issue, not by these LDS round trips.
     {
         const uint32_t x0 = F::wx(*rootw);
-        uint32_t a2[PPT], dl[PPT], fcx[PPT], fcy[PPT];
-        bool ulive[PPT];
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
+            if (!(wbase + u * T < n && wbase + u * T + 63u >= KTOP)) continue;   // batch without a point to walk (wave-uniform)
             const uint32_t i = tid + u * T;
             const bool go = i < n && i >= KTOP;
-            ulive[u] = wbase + u * T < n && wbase + u * T + 63u >= KTOP;
-            a2[u] = go ? ((mcx[u] < x0) ? 0u : 4u) : F::DUMMY_SLOT;
-            dl[u] = 0;
-            fcx[u] = (go && mcx[u] == x0) ? 1u : 0u;
-            fcy[u] = 0;
-        }
-        auto walk = [&](auto dim) -> bool {
-            constexpr int D = decltype(dim)::value;
-            uint32_t cw[PPT];
-            bool any = false;
-#pragma unroll
-            for (int u = 0; u < PPT; u++)
-                if (ulive[u]) cw[u] = *reinterpret_cast<const uint32_t *>(slotb + a2[u]);
-#pragma unroll
-            for (int u = 0; u < PPT; u++) {
-                if (ulive[u] && cw[u] != NONE32) {
-                    any = true;
-                    const uint32_t sv = D ? myy[u] : mcx[u], cv = D ? F::wy(cw[u]) : F::wx(cw[u]);
-                    if (D) fcy[u] += (sv == cv) ? 1u : 0u;
-                    else fcx[u] += (sv == cv) ? 1u : 0u;
-                    a2[u] = ((cw[u] >> (2u * F::CB)) << 3) | (sv < cv ? 0u : 4u);
-                    dl[u] = D;
+            uint32_t a2 = go ? ((mcx[u] < x0) ? 0u : 4u) : F::DUMMY_SLOT, dl = 0;
+            uint32_t fcx = (go && mcx[u] == x0) ? 1u : 0u, fcy = 0;
+            for (;;) {  // two levels per turn: y, then x
+                uint32_t cw = *reinterpret_cast<const uint32_t *>(slotb + a2);
+                bool live = cw != NONE32;
+                if (live) {
+                    const uint32_t cv = F::wy(cw);
+                    fcy += (myy[u] == cv) ? 1u : 0u;
+                    a2 = ((cw >> (2u * F::CB)) << 3) | (myy[u] < cv ? 0u : 4u);
+                    dl = 1;
+                    cw = *reinterpret_cast<const uint32_t *>(slotb + a2);
+                    live = cw != NONE32;
+                    if (live) {
+                        const uint32_t cx2 = F::wx(cw);
+                        fcx += (mcx[u] == cx2) ? 1u : 0u;
+                        a2 = ((cw >> (2u * F::CB)) << 3) | (mcx[u] < cx2 ? 0u : 4u);
+                        dl = 0;
+                    }
                 }
+                if (!__any(live)) break;
             }
-            return any;
-        };
-        for (;;) {
-            if (!walk(std::integral_constant<int, 1>())) break;
-            if (!walk(std::integral_constant<int, 0>())) break;
-        }
-#pragma unroll
-        for (int u = 0; u < PPT; u++) {
-            const uint32_t i = tid + u * T;
-            if (i < n && i >= KTOP) {
-                f[u] |= (fcx[u] ? 1u : 0u) | (fcy[u] ? 2u : 0u);
-                sl[u] = a2[u];                // the empty slot under the last top-tree node: bid for it
-                sh[u] = dl[u] ? F::CB : 0u;     // its winner splits on the other dimension
-                fb[u] = dl[u] ? 1u : 2u;
+            if (go) {
+                f[u] |= (fcx ? 1u : 0u) | (fcy ? 2u : 0u);
+                sl[u] = a2;               // the empty slot under the last top-tree node: bid for it
+                sh[u] = dl ? F::CB : 0u;  // its winner splits on the other dimension
+                fb[u] = dl ? 1u : 2u;
             }
         }
     }
