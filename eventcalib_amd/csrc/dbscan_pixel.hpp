@@ -630,11 +630,17 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     const uint32_t m_edges = *n_edges;
     if (m_edges > PX_EDGE_CAP) PX_BAIL();
     // ---------------- E.2 flatten; E.3 one-way edges to the fix-point ----------------
+    uint32_t root[PPT];  // label of the point = smallest pid of its cluster (NONE32: not a core point)
 #pragma unroll
-    for (int u = 0; u < PPT; u++)
-        if (core[u]) parent[tid + u * T] = uf_root<false>(parent, tid + u * T);  // read-only walk: see uf_root
-    __syncthreads();
+    for (int u = 0; u < PPT; u++) {
+        root[u] = NONE32;
+        if (core[u]) {
+            root[u] = uf_root<false>(parent, tid + u * T);  // read-only walk: see uf_root
+            parent[tid + u * T] = root[u];
+        }
+    }
     if (m_edges > 0) {
+        __syncthreads();
         uint32_t *const comp = bm;  // the bitmap is dead
         for (uint32_t i = tid; i < n; i += T) comp[i] = i;
         __syncthreads();
@@ -652,33 +658,51 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
         }
 #pragma unroll
         for (int u = 0; u < PPT; u++)
-            if (core[u]) parent[tid + u * T] = comp[parent[tid + u * T]];
-        __syncthreads();
+            if (core[u]) root[u] = comp[root[u]];
     }
     ECAL_PHASE_MARK(3);
     ECAL_PHASE_COUNT(10, 1);
     ECAL_PHASE_COUNT(11, m_edges);
     // ---------------- F: seeds ranked in pid order = reference cluster ids ----------------
-    const uint32_t *const label = parent;
+    // A seed is a point that is its own label.  Batch (u, wave) holds 64 consecutive pids and the batches ascend in
+    // pid: a seed's rank = seeds in the batches before + seeds on the lanes below (ballot + mbcnt; the labels are
+    // still in registers, so no sweep over the label array and no block scan).
     uint16_t *const rank = pf;  // rank -> pid table is dead
-    uint32_t total;
+    uint32_t *const bcount = red;  // [PPT * T / 64] seeds per batch
+    uint32_t below[PPT];
+    bool seed[PPT];
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+        seed[u] = core[u] && root[u] == tid + u * T;
+        const unsigned long long m = __ballot(seed[u]);
+        below[u] = (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) bcount[u * (T / 64) + wave] = (uint32_t) __popcll(m);
+    }
+    __syncthreads();  // (also: every read of pf / comp above is done before rank[] is written)
+    uint32_t total = 0;
     {
-        const uint32_t per = (n + T - 1) / T, i0 = tid * per;
-        uint32_t mine = 0;
-        for (uint32_t i = i0; i < i0 + per && i < n; i++) mine += (label[i] == i) ? 1u : 0u;
-        uint32_t run = block_exscan<T>(mine, red, &total);
-        for (uint32_t i = i0; i < i0 + per && i < n; i++)
-            if (label[i] == i) rank[i] = (uint16_t) (run++);
+        uint32_t before[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) before[u] = 0;
+#pragma unroll
+        for (int q = 0; q < PPT * (T / 64); q++) {
+            const uint32_t c = bcount[q];
+#pragma unroll
+            for (int u = 0; u < PPT; u++)
+                if ((uint32_t) q < u * (T / 64) + wave) before[u] += c;
+            total += c;
+        }
+#pragma unroll
+        for (int u = 0; u < PPT; u++)
+            if (seed[u]) rank[tid + u * T] = (uint16_t) (before[u] + below[u]);
     }
     __syncthreads();
     int32_t *const out = labels + base;
 #pragma unroll
     for (int u = 0; u < PPT; u++) {
         const uint32_t i = tid + u * T;
-        if (i < n) {
-            const uint32_t Lb = label[i];
-            out[i] = (Lb == NONE32) ? -1 : (int32_t) rank[Lb];
-        }
+        if (i < n) out[i] = (root[u] == NONE32) ? -1 : (int32_t) rank[root[u]];
     }
     if (tid == 0) n_clusters[s] = total;
     ECAL_PHASE_MARK(4);
