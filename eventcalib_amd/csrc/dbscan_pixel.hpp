@@ -49,6 +49,9 @@ struct PxGeom {
     // the half disc (rows above + own row to the left) packed row after row into one word (radius <= 4: 24 bits):
     // hd_code[p] = k << 5 | b of packed position p (k = dy + Rd, b = column - (cx - Rd))
     uint8_t hd_code[32];
+    // hd_cover[p] = the packed positions within a two-way edge of position p (d2 <= floor(eps^2), minus the exactly-eps
+    // pairs when eps is integral): once p is joined, these need no union of their own
+    uint32_t hd_cover[32];
 };
 
 __host__ __device__ constexpr int px_isqrt(int v) {
@@ -89,11 +92,21 @@ inline bool px_geometry(double eps, PxGeom *g) {
     g->Rd = px_isqrt(g->e2i);
     g->eps_int = (eps == floor(eps)) ? 1u : 0u;
     for (int k = 0; k < 2 * PX_RMAX + 1; k++) g->dmask[k] = (k <= 2 * g->Rd) ? px_disc_mask(g->e2i, g->Rd, k) : 0u;
-    for (int p = 0; p < 32; p++) g->hd_code[p] = 0;
+    for (int p = 0; p < 32; p++) {
+        g->hd_code[p] = 0;
+        g->hd_cover[p] = 0;
+    }
+    int np = 0;  // packed positions
     if (g->Rd <= 4 && px_hd_pos(g->e2i, g->Rd, g->Rd + 1) <= 32)  // only a half disc that fits one word is ever packed
-        for (int k = 0, p = 0; k <= g->Rd; k++)
+        for (int k = 0; k <= g->Rd; k++)
             for (int b = px_hd_low(g->e2i, g->Rd, k); b < px_hd_low(g->e2i, g->Rd, k) + px_hd_width(g->e2i, g->Rd, k); b++)
-                g->hd_code[p++] = (uint8_t) (k << 5 | b);
+                g->hd_code[np++] = (uint8_t) (k << 5 | b);
+    const int tlim = g->eps_int ? g->e2i - 1 : g->e2i;
+    for (int p = 0; p < np; p++)
+        for (int q = 0; q < np; q++) {
+            const int dx = (g->hd_code[p] & 31) - (g->hd_code[q] & 31), dy = (g->hd_code[p] >> 5) - (g->hd_code[q] >> 5);
+            if (dx * dx + dy * dy <= tlim) g->hd_cover[p] |= 1u << q;
+        }
     return g->Rd >= 0 && g->Rd <= PX_RMAX;
 }
 
@@ -289,7 +302,10 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     }
     // the disc tables (read from phase D on; here, behind the point loads, their trip to the kernel arguments is free)
     if (E2I == 0 && tid < (uint32_t) (2 * PX_RMAX + 1)) dm[tid] = geom.dmask[tid];
-    if (E2I > 0 && tid < 32u) hd[tid] = geom.hd_code[tid];
+    if (E2I > 0 && tid < 32u) {
+        hd[tid] = geom.hd_code[tid];
+        dm[tid] = geom.hd_cover[tid];  // (the run-time disc masks are not needed when the disc is compiled in)
+    }
     if (block_any(!fits, anyf, any_round)) PX_BAIL();
     if (Rd > PX_RMAX) PX_BAIL();
     const int ox = bbox[0] - Rd, oy = bbox[1] - Rd;
@@ -530,21 +546,17 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
         // Anchors = neighbours already joined with i (as k, b).  A neighbour j within a two-way edge of an anchor a
         // needs no union and not even a look at its table entry: if j is core, a and j are joined by the scan of
         // whichever of the two comes later in raster order (induction on that order), and a is joined with i.
+        // (Compiled-in disc: the positions an anchor settles are a precomputed mask, hd_cover, cleared from the packed word.)
         uint32_t ab0 = 4096, ak0 = 0, ab1 = 4096, ak1 = 0;
-        auto link = [&](uint32_t k, uint32_t b) {
-            if constexpr (E2I > 0) {
-                // |dx| < 1 + reach(|dy|): the two-way-edge test without multiplies
-                const uint32_t reach = eps_int ? px_reach_table(E2I - 1) : px_reach_table(E2I);
-                if (__sad(b, ab0, 0u) < __builtin_amdgcn_ubfe(reach, 4u * __sad(k, ak0, 0u), 4u) ||
-                    __sad(b, ab1, 0u) < __builtin_amdgcn_ubfe(reach, 4u * __sad(k, ak1, 0u), 4u))
-                    return;
-            } else {
+        // returns true when neighbour (k, b) is a core point now joined with i by a two-way edge
+        auto link = [&](uint32_t k, uint32_t b) -> bool {
+            if constexpr (E2I == 0) {   // run-time disc: the anchors are tested here; the compiled-in disc clears them from its word
                 const int ex0 = (int) b - (int) ab0, ey0 = (int) k - (int) ak0, ex1 = (int) b - (int) ab1, ey1 = (int) k - (int) ak1;
-                if (__mul24(ex0, ex0) + __mul24(ey0, ey0) <= tlim || __mul24(ex1, ex1) + __mul24(ey1, ey1) <= tlim) return;
+                if (__mul24(ex0, ex0) + __mul24(ey0, ey0) <= tlim || __mul24(ex1, ex1) + __mul24(ey1, ey1) <= tlim) return false;
             }
             const uint32_t nx = c0 + b, ny = yy - (uint32_t) Rd + k;
             const uint32_t pfj = pf[rank_of(nx, ny)];
-            if (!(pfj & F::PF_CORE)) return;
+            if (!(pfj & F::PF_CORE)) return false;
             const uint32_t pj = pfj & F::PF_PID;
             // j = i - eps e_d: the query from j misses i exactly when i carries bit d; the query from i always
             // finds j (pruning only hides neighbours on the + side) -> one-way edge i -> j
@@ -556,7 +568,7 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
                         edges[2 * at] = i;
                         edges[2 * at + 1] = pj;
                     }
-                    return;
+                    return false;
                 }
             }
             uint32_t rj = uf_find<false>(parent, pj);
@@ -574,6 +586,7 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
             ak1 = ak0;
             ab0 = b;
             ak0 = k;
+            return true;
         };
         if constexpr (E2I > 0) {
             // the whole half disc as one packed word: a field per row, one loop over its set bits
@@ -581,9 +594,10 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
             static_assert(RD <= 4 && px_hd_pos(E2I, RD, RD + 1) <= 32, "the packed half disc must fit 32 bits");
             uint32_t nm = hdw[u];  // (the bitmap has not changed since phase D)
             while (nm) {
-                const uint32_t e = hd[__ffs((int) nm) - 1];
+                const uint32_t p = (uint32_t) __ffs((int) nm) - 1u;
                 nm &= nm - 1u;
-                link(e >> 5, e & 31u);
+                const uint32_t e = hd[p];
+                if (link(e >> 5, e & 31u)) nm &= ~dm[p];   // joined: everything within a two-way edge of it is settled
             }
         } else {
             unsigned long long list = 0;  // up to 8 neighbours: k << 5 | bit index, one byte each (k = dy + Rd <= 7)
