@@ -123,6 +123,7 @@ struct PixelLayout {
     static constexpr size_t bm_off = slot_off;                              // u32[PX_WORDS]
     static constexpr size_t parent_off = bm_off + 4 * PX_WORDS + 16;        // u32[CAP] (after one spare bitmap word)
     static_assert(4 * PX_WORDS + 16 + 4 * CAP >= 8 * CAP + 4, "child slots must fit bitmap + parent");
+    static_assert(slot_off % 16 == 0 && PX_WORDS % 4 == 0, "the bitmap is cleared with 16-byte stores");
     static_assert(PX_WORDS >= (uint32_t) CAP, "component labels (E.3) must fit the bitmap region");
     static constexpr size_t rowstart_off = parent_off + 4 * CAP;            // u16[512]
     static constexpr size_t wpre_off = rowstart_off + 1024;                 // u8[PX_WORDS]
@@ -423,7 +424,10 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     PX_STOP(3, sl[u] ^ (f[u] << 28));
 
     // ---------------- bitmap of the points (the child slots are dead: same LDS) ----------------
-    for (uint32_t k = tid; k < H * RW; k += T) bm[k] = 0;
+    {   // 16 bytes per store (the region is 16-byte aligned and PX_WORDS + 4 words long: rounding up stays inside)
+        uint4 *const bm4 = reinterpret_cast<uint4 *>(bm);
+        for (uint32_t k = tid; k < (H * RW + 3u) / 4u; k += T) bm4[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
     bool bad = false;
 #pragma unroll
