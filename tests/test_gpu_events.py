@@ -126,29 +126,33 @@ def test_check_sorted(env):
     assert int(flag.item()) == 1
 
 
-def test_pixel_and_general_slicers_agree(env):
-    """Integer-pixel windows take slice_pixel_kernel; ECAL_SLICE_NO_PIXEL sends them through the general tiers.
-    Same outputs, and both equal the oracle (negative coordinates, -0.0, both-polarity cancellation, a window with
-    one non-integer coordinate, a window above the pixel kernel's 2048-event capacity)."""
+@pytest.mark.parametrize("shift", [0.0, 25.0])
+def test_pixel_and_general_slicers_agree(env, shift):
+    """Sensor-pixel windows take slice_hash_kernel (its second pass above 2047 events); ECAL_SLICE_SORT_KERNEL selects the
+    counting-sort pixel kernel instead (it also takes negative pixels), ECAL_SLICE_NO_PIXEL sends everything through the
+    general tiers.  Same outputs, and all equal the oracle.  shift = 0: negative coordinates and -0.0 (hash kernel bails,
+    sort kernel does not); shift = 25: all coordinates >= 0.  Both: both-polarity cancellation, a window with one
+    non-integer coordinate, a window above the first pass's capacity."""
     import os
     ctx, pipe, torch = env
     rng = np.random.default_rng(15)
     n = 12000
     t = np.sort(rng.uniform(0, 1, n))
-    x = rng.integers(-20, 60, n).astype(np.float64)
-    y = rng.integers(-10, 40, n).astype(np.float64)
-    x[rng.random(n) < 0.01] = -0.0
+    x = rng.integers(-20, 60, n).astype(np.float64) + shift
+    y = rng.integers(-10, 40, n).astype(np.float64) + shift
+    if shift == 0.0:
+        x[rng.random(n) < 0.01] = -0.0
     x[7000] = 12.5                                         # one fractional coordinate -> that window is not "pixels"
     p = (rng.random(n) < 0.5).astype(np.uint8)
     rec = O.pack_events(t, x, y, p)
-    cuts = [0, 1500, 3100, 5000, 6900, 8400, 12000]        # 1500, 1600, 1900, 1900, 1500 (fractional), 3600 (> 2048)
+    cuts = [0, 1500, 3100, 5000, 6900, 8400, 12000]        # 1500, 1600, 1900, 1900, 1500 (fractional), 3600 (> 2047)
     t0 = [t[a] for a in cuts[:-1]]
     t1 = [t[b - 1] for b in cuts[1:]]
     d = torch.from_numpy(rec).cuda()
     outs = []
-    for flag in (None, "1"):
-        if flag:
-            os.environ["ECAL_SLICE_NO_PIXEL"] = flag
+    for var in (None, "ECAL_SLICE_SORT_KERNEL", "ECAL_SLICE_NO_PIXEL"):
+        if var:
+            os.environ[var] = "1"
         try:
             pipe.set_windows(t0, t1)
             pipe.run(d, slots=20000)
@@ -157,10 +161,12 @@ def test_pixel_and_general_slicers_agree(env):
             outs.append((pipe.xy[:12000].cpu().numpy().copy(), pipe.event_point[:12000].cpu().numpy().copy(),
                          pipe.seg_cnt[:12].cpu().numpy().copy()))
         finally:
-            os.environ.pop("ECAL_SLICE_NO_PIXEL", None)
+            if var:
+                os.environ.pop(var, None)
     n_pts = int(outs[0][2].sum())
-    assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][0][:n_pts].view(np.int64), outs[1][0][:n_pts].view(np.int64))
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][2], o[2]) and np.array_equal(outs[0][1], o[1])
+        assert np.array_equal(outs[0][0][:n_pts].view(np.int64), o[0][:n_pts].view(np.int64))
 
 
 def test_window_bounds_search_edge_cases(env):
