@@ -680,13 +680,29 @@ __device__ __forceinline__ void extract_one(
     constexpr double KEY_LIM = PTS > 2048u ? 723.0 : 1023.0;
     if (staged) {  // stage the points packed; a coordinate that does not pack exactly sends the window to the global path
         bool fits = true, large = false;
-        for (uint32_t i = tid; i < n_all; i += DET_T) {
-            const double2 v = pts[o_pol[0] + i];
-            fits = fits && v.x == floor(v.x) && v.y == floor(v.y) && fabs(v.x) <= 32767.0 && fabs(v.y) <= 32767.0;
-            large = large || !(fabs(v.x) <= KEY_LIM && fabs(v.y) <= KEY_LIM);
-            lds_pts[i] = ((uint32_t) (int) v.x & 0xFFFFu) | ((uint32_t) (int) v.y << 16);
-            // labels < DET_LDS_MAXC (checked above) or -1: they fit the int16 table that later holds the renumbered ones
-            reinterpret_cast<int16_t *>(smem + LL::kept_off)[i] = (int16_t) labels[o_pol[0] + i];
+        // all of the thread's loads are issued before the first is used (index clamped instead of a branch around the load):
+        // inside `if (i < n_all)` the compiler waits for each one in turn — five trips to HBM in a row at the head of every
+        // workgroup instead of one
+        constexpr int JS = (int) ((PTS + DET_T - 1) / DET_T);
+        double2 vin[JS];
+        int32_t lin[JS];
+#pragma unroll
+        for (int j = 0; j < JS; j++) {
+            const uint32_t i = min(tid + j * DET_T, n_all - 1u);
+            vin[j] = pts[o_pol[0] + i];
+            lin[j] = labels[o_pol[0] + i];
+        }
+#pragma unroll
+        for (int j = 0; j < JS; j++) {
+            const uint32_t i = tid + j * DET_T;
+            if (i < n_all) {
+                const double2 v = vin[j];
+                fits = fits && v.x == floor(v.x) && v.y == floor(v.y) && fabs(v.x) <= 32767.0 && fabs(v.y) <= 32767.0;
+                large = large || !(fabs(v.x) <= KEY_LIM && fabs(v.y) <= KEY_LIM);
+                lds_pts[i] = ((uint32_t) (int) v.x & 0xFFFFu) | ((uint32_t) (int) v.y << 16);
+                // labels < MAXC (checked above) or -1: they fit the int16 table that later holds the renumbered ones
+                reinterpret_cast<int16_t *>(smem + LL::kept_off)[i] = (int16_t) lin[j];
+            }
         }
         // bit 0: some coordinate does not pack; bit 1: some coordinate is beyond the composite-key range
         if (tid == 0) nk_sh[0] = 0;
