@@ -659,49 +659,69 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
         return;
     }
+    if (ECAL_SL_STOP == 1) return;
     // b. every event into its polarity's table: the slot of its pixel ends up holding the smallest event index
+    // (The first probe of all of a thread's events is read before any is looked at: the probes of different events are
+    // independent, a loop per event would pay one LDS latency after the other; only the ~15 % of events whose first slot
+    // holds another pixel go on probing.)
     uint32_t hs[PXH_PER];
+    {
+        uint32_t w0[PXH_PER];
 #pragma unroll
-    for (int j = 0; j < PXH_PER; j++) {
-        const uint32_t k = tid + j * T;
-        hs[j] = 0;
-        if (k < n) {
-            uint32_t *const t = tab + (vp[j] ? PXH_SLOTS : 0u);
-            const uint32_t mine = (pix[j] << LOGC) | k;
-            uint32_t h = L::slot(pix[j]);
-            for (;;) {
-                uint32_t w = t[h];
-                if (w == EMPTY) w = atomicCAS(&t[h], EMPTY, mine);   // EMPTY back: the slot is mine
-                if (w == EMPTY) break;
-                if ((w >> LOGC) == pix[j]) {
-                    atomicMin(&t[h], mine);
-                    break;
+        for (int j = 0; j < PXH_PER; j++) {
+            hs[j] = L::slot(pix[j]);
+            w0[j] = tab[(vp[j] ? PXH_SLOTS : 0u) + hs[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            if (k < n) {
+                uint32_t *const t = tab + (vp[j] ? PXH_SLOTS : 0u);
+                const uint32_t mine = (pix[j] << LOGC) | k;
+                uint32_t h = hs[j], w = w0[j];
+                for (;;) {
+                    if (w == EMPTY) w = atomicCAS(&t[h], EMPTY, mine);   // EMPTY back: the slot is mine
+                    if (w == EMPTY) break;
+                    if ((w >> LOGC) == pix[j]) {
+                        atomicMin(&t[h], mine);
+                        break;
+                    }
+                    h = (h + 1u) & (PXH_SLOTS - 1u);
+                    w = t[h];
                 }
-                h = (h + 1u) & (PXH_SLOTS - 1u);
+                hs[j] = h;
             }
-            hs[j] = h;
         }
     }
     __syncthreads();
+    if (ECAL_SL_STOP == 2) return;
     // c. representative = first occurrence of the pixel with this polarity, unless the pixel also fired with the other one
+    {
+        uint32_t fw[PXH_PER], ow[PXH_PER];
 #pragma unroll
-    for (int j = 0; j < PXH_PER; j++) {
-        const uint32_t k = tid + j * T;
-        if (k < n) {
-            const uint32_t first = tab[(vp[j] ? PXH_SLOTS : 0u) + hs[j]] & IDXM;
-            const uint32_t *const o = tab + (vp[j] ? 0u : PXH_SLOTS);
-            uint32_t h = L::slot(pix[j]);
-            bool both = false;
-            for (;;) {
-                const uint32_t w = o[h];
-                if (w == EMPTY) break;
-                if ((w >> LOGC) == pix[j]) {
-                    both = true;
-                    break;
+        for (int j = 0; j < PXH_PER; j++) {   // own slot and first probe of the other table: all reads first
+            fw[j] = tab[(vp[j] ? PXH_SLOTS : 0u) + hs[j]];
+            ow[j] = tab[(vp[j] ? 0u : PXH_SLOTS) + L::slot(pix[j])];
+        }
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            if (k < n) {
+                const uint32_t first = fw[j] & IDXM;
+                const uint32_t *const o = tab + (vp[j] ? 0u : PXH_SLOTS);
+                uint32_t h = L::slot(pix[j]), w = ow[j];
+                bool both = false;
+                for (;;) {
+                    if (w == EMPTY) break;
+                    if ((w >> LOGC) == pix[j]) {
+                        both = true;
+                        break;
+                    }
+                    h = (h + 1u) & (PXH_SLOTS - 1u);
+                    w = o[h];
                 }
-                h = (h + 1u) & (PXH_SLOTS - 1u);
+                key[k] = pix[j] | ((both ? NONE : first) << PIXB);
             }
-            key[k] = pix[j] | ((both ? NONE : first) << PIXB);
         }
     }
     __syncthreads();  // the tables are dead from here: pos takes their place
@@ -718,6 +738,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         if ((key[k] >> PIXB) == k) pos[k] = (uint16_t) (((polbits[k >> 5] >> (k & 31u)) & 1u) ? exP++ : exN++);
     }
     __syncthreads();
+    if (ECAL_SL_STOP == 4) return;
     // e. outputs: positives first, then negatives (canonical order = first occurrence)
     double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
     int32_t *ep = event_point + base;
