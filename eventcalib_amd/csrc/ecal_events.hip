@@ -551,8 +551,8 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
 // open-addressing table of 2048 words  pixel << 11 | event index : an event claims its pixel's slot with a CAS or lowers
 // the index there with ds_min_u32 — first occurrence = smallest index, exactly what the sort delivered — and after a
 // barrier looks its pixel up in the OTHER polarity's table (present: the pixel is erased, EventFrame.cpp:24-32).  Load
-// factor ~0.3: 1.2 probes on average.  The representative's index rides in the upper 11 bits of the event's key word, the
-// polarities are a bit array: 24 KB of LDS as before.
+// factor ~0.3: 1.2 probes on average.  An event's pixel, polarity and representative stay in the registers of its thread
+// from decode to output: the tables are all the LDS there is (16 KB).
 // LOGC = 11: the first pass (<= 2047 events, x <= 2047, y <= 1023; 24 KB of LDS, six windows per CU);
 // LOGC = 12: the second pass over the windows the first one lists (<= 4095 events, x, y <= 1023; 49 KB, three per CU).
 constexpr int PXH_T = 256;
@@ -563,10 +563,8 @@ struct PixHash {
     static constexpr int PER = (int) (SLOTS / PXH_T);    // events per thread at most
     static constexpr uint32_t PIXB = 32u - LOGC;         // pixel bits: x << 10 | y
     static constexpr double XMAX = (double) ((1u << (PIXB - 10u)) - 1u), YMAX = 1023.0;
-    static constexpr size_t key_off = 0;                                   // u32[SLOTS]: pixel | representative << PIXB
-    static constexpr size_t tab_off = key_off + 4 * SLOTS;                 // u32[2][SLOTS]; later pos u16[SLOTS]
-    static constexpr size_t pol_off = tab_off + 8 * SLOTS;                 // u32[SLOTS / 32]: polarity bits
-    static constexpr size_t red_off = pol_off + SLOTS / 8;                 // 16 x u64 + 4 x u32 flags
+    static constexpr size_t tab_off = 0;                                   // u32[2][SLOTS]; later pos u16[SLOTS] + batch counts
+    static constexpr size_t red_off = tab_off + 8 * SLOTS;                 // 16 x u64 + 4 x u32 flags
     static constexpr size_t bytes = red_off + 16 * 8 + 16;
     static __device__ __forceinline__ uint32_t slot(uint32_t pix) { return (pix * 0x9E3779B1u) >> (32u - LOGC); }
 };
@@ -607,10 +605,8 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         }
         return;
     }
-    uint32_t *const key = reinterpret_cast<uint32_t *>(smem + L::key_off);
     uint32_t *const tab = reinterpret_cast<uint32_t *>(smem + L::tab_off);  // [0 .. 2047] negative, [2048 .. 4095] positive
     uint16_t *const pos = reinterpret_cast<uint16_t *>(smem + L::tab_off);
-    uint32_t *const polbits = reinterpret_cast<uint32_t *>(smem + L::pol_off);
     uint32_t *const red = reinterpret_cast<uint32_t *>(smem + L::red_off);
     uint32_t *const badf = red + 32;
 
@@ -646,11 +642,6 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                          __double_as_longlong(y) >= 0;
         bad = bad || (k < n && !okc);
         pix[j] = (((uint32_t) (int) x << 10) | ((uint32_t) (int) y & 0x3FFu)) & ((1u << PIXB) - 1u);
-        const unsigned long long pb = __ballot(k < n && vp[j] != 0);   // events tid + j T of this wave: 64 consecutive indices
-        if ((tid & 63u) == 0 && (tid & ~63u) + j * T < n) {
-            polbits[((tid & ~63u) + j * T) >> 5] = (uint32_t) pb;
-            polbits[(((tid & ~63u) + j * T) >> 5) + 1] = (uint32_t) (pb >> 32);
-        }
     }
     const bool wave_bad = __any(bad);
     if ((tid & 63) == 0) badf[tid >> 6] = wave_bad ? 1u : 0u;   // one flag word per wave
@@ -696,6 +687,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
     __syncthreads();
     if (ECAL_SL_STOP == 2) return;
     // c. representative = first occurrence of the pixel with this polarity, unless the pixel also fired with the other one
+    uint32_t repk[PXH_PER];  // representative of event tid + j T (NONE: erased)
     {
         uint32_t fw[PXH_PER], ow[PXH_PER];
 #pragma unroll
@@ -720,22 +712,51 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     h = (h + 1u) & (PXH_SLOTS - 1u);
                     w = o[h];
                 }
-                key[k] = pix[j] | ((both ? NONE : first) << PIXB);
+                repk[j] = both ? NONE : first;
+            } else {
+                repk[j] = NONE;
             }
         }
     }
     __syncthreads();  // the tables are dead from here: pos takes their place
     if (ECAL_SL_STOP == 3) return;
-    // d. ranks of the representatives in event order (blocked ownership: contiguous k per thread)
-    const uint32_t per = (n + T - 1) / T, k0 = tid * per;
-    uint32_t cntP = 0, cntN = 0;
-    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if ((key[k] >> PIXB) == k) { if ((polbits[k >> 5] >> (k & 31u)) & 1u) cntP++; else cntN++; }
+    // d. ranks of the representatives in event order.  Batch (j, wave) holds 64 consecutive events and the batches ascend in
+    // event index: rank = representatives of the same polarity in the batches before + on the lanes below (ballots; the
+    // per-batch counts, both polarities packed in one word, are scanned by wave 0).
+    constexpr uint32_t NBATCH = (uint32_t) PXH_PER * (T / 64);
+    uint32_t *const bcnt = tab + PXH_SLOTS;  // [NBATCH] counts, then exclusive prefixes; [NBATCH]: totals (the tables are dead)
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t below[PXH_PER];
+#pragma unroll
+    for (int j = 0; j < PXH_PER; j++) {
+        const uint32_t k = tid + j * T;
+        const bool isrep = k < n && repk[j] == k;
+        const unsigned long long mP = __ballot(isrep && vp[j] != 0), mN = __ballot(isrep && vp[j] == 0);
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        below[j] = (uint32_t) __popcll((vp[j] ? mP : mN) & lower);
+        if (lane == 0) bcnt[j * (T / 64) + wave] = (uint32_t) __popcll(mP) | ((uint32_t) __popcll(mN) << 16);
     }
-    uint32_t exP, exN, nP, nN;
-    block_exscan2<T>(cntP, cntN, red, &exP, &exN, &nP, &nN);
-    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if ((key[k] >> PIXB) == k) pos[k] = (uint16_t) (((polbits[k >> 5] >> (k & 31u)) & 1u) ? exP++ : exN++);
+    __syncthreads();
+    if (tid < 64u) {
+        const uint32_t v = tid < NBATCH ? bcnt[tid] : 0u;   // NBATCH <= 64; the packed fields stay below 2^16 (<= 4095 events)
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= (uint32_t) d) inc += o;
+        }
+        if (tid < NBATCH) bcnt[tid] = inc - v;
+        if (tid == 63u) bcnt[NBATCH] = inc;
+    }
+    __syncthreads();
+    const uint32_t totals = bcnt[NBATCH], nP = totals & 0xFFFFu, nN = totals >> 16;
+#pragma unroll
+    for (int j = 0; j < PXH_PER; j++) {
+        const uint32_t k = tid + j * T;
+        if (k < n && repk[j] == k) {
+            const uint32_t ex = bcnt[j * (T / 64) + wave];
+            pos[k] = (uint16_t) ((vp[j] ? (ex & 0xFFFFu) : (ex >> 16)) + below[j]);
+        }
     }
     __syncthreads();
     if (ECAL_SL_STOP == 4) return;
@@ -746,7 +767,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
     for (int j = 0; j < PXH_PER; j++) {
         const uint32_t k = tid + j * T;
         if (k < n) {
-            const uint32_t r = key[k] >> PIXB;
+            const uint32_t r = repk[j];
             if (r == NONE) {
                 ep[k] = -1;
             } else {
