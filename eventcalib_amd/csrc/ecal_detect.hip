@@ -263,7 +263,8 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 }
             }
             uint32_t ek, em, tk, tm;
-            block_exscan_pair<DET_T>(k, m, red, &ek, &em, &tk, &tm);
+            if constexpr (ST::INT_PIXELS) block_exscan_pair16<DET_T>(k, m, red, &ek, &em, &tk, &tm);   // staged: <= 2816 points, <= 512 clusters
+            else block_exscan_pair<DET_T>(k, m, red, &ek, &em, &tk, &tm);
             for (uint32_t c = c0; c < c0 + per && c < nc; c++) {
                 if (csize[c] >= prm.cluster_min) {
                     newid[c] = (typename ST::CIdx) ek;
@@ -350,7 +351,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     uint32_t carry = 0;
     auto emit = [&](uint32_t pi, bool ok, uint32_t ni_best, double cx, double cy, double r) {
         uint32_t ex, dummy, tot, dummy2;
-        block_exscan_pair<DET_T>(ok ? 1u : 0u, 0u, red, &ex, &dummy, &tot, &dummy2);
+        block_exscan_pair16<DET_T>(ok ? 1u : 0u, 0u, red, &ex, &dummy, &tot, &dummy2);   // <= 256 candidates per batch
         if (ok) {
             const size_t at = (size_t) carry + ex;
             cand_pair[2 * at] = pi;
