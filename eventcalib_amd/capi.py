@@ -13,6 +13,7 @@ EXPORTED_SYMBOLS = [
     "ecal_abi_version", "ecal_init", "ecal_destroy", "ecal_strerror", "ecal_last_error", "ecal_sync",
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
+    "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
@@ -76,6 +77,14 @@ def load_library():
     L.ecal_dbscan_batch_dev.argtypes = [vp, vp, vp, vp, u32, u32, u32, f64, u32, vp, vp, vp]
     L.ecal_dbscan_batch_dev.restype = i32
     u64 = ctypes.c_uint64
+    L.ecal_set_point_order.argtypes = [vp, i32]
+    L.ecal_set_point_order.restype = i32
+    L.ecal_get_point_order.argtypes = [vp]
+    L.ecal_get_point_order.restype = i32
+    L.ecal_ref_bucket_step.argtypes = [i32]
+    L.ecal_ref_bucket_step.restype = u64
+    L.ecal_ref_pixel_hash.argtypes = [f64, f64]
+    L.ecal_ref_pixel_hash.restype = u64
     L.ecal_window_bounds_dev.argtypes = [vp, vp, u64, vp, vp, u32, vp, vp, vp, vp]
     L.ecal_window_bounds_dev.restype = i32
     L.ecal_check_sorted_dev.argtypes = [vp, vp, u64, vp, vp]
@@ -163,6 +172,16 @@ class Context:
                                                   d_n_clusters, stream))
 
     # ---- ingest + slicing (device buffers, raw pointers) ----
+    ORDER_REFERENCE, ORDER_FIRST_OCCURRENCE = 0, 1
+
+    def set_point_order(self, order):
+        """Element order of the pixel sets: "reference" (EventFrame.cpp:34-35 on libstdc++; default) or "first"."""
+        code = {"reference": 0, "first": 1, 0: 0, 1: 1}[order]
+        self._check(self._L.ecal_set_point_order(self._h, code))
+
+    def point_order(self):
+        return {0: "reference", 1: "first"}[self._L.ecal_get_point_order(self._h)]
+
     def window_bounds_dev(self, d_events, n_events, d_t0, d_t1, S, d_win_lo, d_win_hi, d_win_base, stream=0):
         self._check(self._L.ecal_window_bounds_dev(self._h, d_events, int(n_events), d_t0, d_t1, int(S), d_win_lo,
                                                    d_win_hi, d_win_base, stream))

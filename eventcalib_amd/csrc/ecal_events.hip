@@ -9,6 +9,7 @@
 // bucketed by a hash of the pixel, de-duplicated inside the bucket, and compacted in
 // first-occurrence order (the build's canonical pid order).
 #include "ecal_ctx.hpp"
+#include "slice_order.hpp"
 
 #pragma clang fp contract(off)
 
@@ -183,13 +184,15 @@ __device__ __forceinline__ uint32_t ld_word(const uint32_t *p) {
     else return *p;
 }
 
-// EventFrame constructor for the records [lo, lo+n) of the stream.
+// EventFrame constructor for the records [lo, lo+n) of the stream.  ord == nullptr: the canonical element order (first
+// occurrence); else the reference's (slice_order.hpp) with *ord as this workgroup's scratch (ord->h .. ord->fa and evk sized
+// for n keys).
 template <int T, bool GLOBAL, typename Idx>
 __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint8_t *__restrict__ rec, uint32_t lo,
                                              uint32_t n, uint32_t nb_log, double *__restrict__ xy_out,
                                              int32_t *__restrict__ event_point, uint32_t *n_pos_out,
-                                             uint32_t *n_neg_out) {
-    constexpr uint32_t NONE = (sizeof(Idx) == 2) ? 0xFFFFu : 0xFFFFFFFFu;
+                                             uint32_t *n_neg_out, const OrderScratch *ord, uint32_t *evk) {
+    constexpr uint32_t ERASED = (sizeof(Idx) == 2) ? 0x8000u : 0x80000000u;   // flag on rep[]: the pixel fired with both polarities
     const uint32_t tid = threadIdx.x;
     double2 *const pts = wk.pts;
     uint8_t *const pol = wk.pol;
@@ -231,14 +234,13 @@ __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint
         sorted[at] = (Idx) k;
     }
     __syncthreads();
-    // d. first occurrence per (pixel, polarity); erase pixels that fired with both polarities
-    uint32_t cntP = 0, cntN = 0;  // this thread's representatives (blocked ownership below)
+    // d. first occurrence per (pixel, polarity) = the key the set keeps; pixels that fired with both polarities are erased
     for (uint32_t k = tid; k < n; k += T) {
         const double2 p = pts[k];
         const uint32_t b = pixel_hash(p.x, p.y) & mask;
         uint32_t m = b ? ld_word<GLOBAL>(&bend[b - 1]) : 0u;
         const uint32_t e = ld_word<GLOBAL>(&bend[b]);
-        uint32_t minP = NONE, minN = NONE;
+        uint32_t minP = 0xFFFFFFFFu, minN = 0xFFFFFFFFu;
         for (; m < e; m++) {
             const uint32_t j = sorted[m];
             const double2 q = pts[j];
@@ -246,26 +248,69 @@ __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint
                 if (pol[j]) minP = min(minP, j); else minN = min(minN, j);
             }
         }
-        const bool erased = (minP != NONE) && (minN != NONE);  // EventFrame.cpp:24-32
-        rep[k] = (Idx) (erased ? NONE : (pol[k] ? minP : minN));
+        const bool erased = (minP != 0xFFFFFFFFu) && (minN != 0xFFFFFFFFu);  // EventFrame.cpp:24-32
+        rep[k] = (Idx) ((pol[k] ? minP : minN) | (erased ? ERASED : 0u));
     }
     __syncthreads();
-    // e. ranks of the representatives in event order (blocked ownership: contiguous k per thread)
+    // e. rank of every key among the keys of its polarity, in event order (blocked ownership: contiguous k per thread):
+    // canonical order — the keys that survive the cancellation; reference order — all keys (the order in which the set
+    // saw them, EventFrame.cpp:14-21).
+    const bool reforder = ord != nullptr;
     const uint32_t per = (n + T - 1) / T, k0 = tid * per;
+    uint32_t cntP = 0, cntN = 0;
     for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if (rep[k] == k) { if (pol[k]) cntP++; else cntN++; }
+        const uint32_t r = rep[k];
+        if ((r & ~ERASED) == k && (reforder || !(r & ERASED))) { if (pol[k]) cntP++; else cntN++; }
     }
     uint32_t exP, exN, nP, nN;
     block_exscan2<T>(cntP, cntN, wk.red, &exP, &exN, &nP, &nN);
     for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if (rep[k] == k) pos[k] = pol[k] ? exP++ : exN++;
+        const uint32_t r = rep[k];
+        if ((r & ~ERASED) == k && (reforder || !(r & ERASED))) pos[k] = pol[k] ? exP++ : exN++;
     }
     __syncthreads();
-    // f. outputs: positives first, then negatives (canonical order = first occurrence)
+    if (reforder) {
+        // e'. per polarity: the set's iteration order of its keys (slice_order.hpp), then the erased keys drop out
+        const OrderScratch w = *ord;
+        const uint32_t mk[2] = {nN, nP};
+        uint32_t kept_tot[2] = {0u, 0u};
+        for (int pl = 1; pl >= 0; pl--) {
+            const uint32_t m = mk[pl];
+            if (m) {
+                for (uint32_t k = tid; k < n; k += T) {
+                    if ((uint32_t) pol[k] == (uint32_t) pl && (rep[k] & ~ERASED) == k) {
+                        const uint32_t u = pos[k];
+                        w.h[u] = ref_pixel_hash(pts[k].x, pts[k].y);
+                        evk[u] = k;
+                    }
+                }
+                __syncthreads();
+                reference_list_order<T>(w, m, wk.red);
+                for (uint32_t u = tid; u < m; u += T) w.cnt[w.cur[u]] = (rep[evk[u]] & ERASED) ? 0u : 1u;   // by list position
+                __syncthreads();
+                const uint32_t perq = (m + T - 1) / T, q0 = tid * perq;
+                uint32_t sum = 0;
+                for (uint32_t q = q0; q < q0 + perq && q < m; q++) sum += ld_word<GLOBAL>(&w.cnt[q]);
+                uint32_t tot;
+                uint32_t ex = block_exscan_u32<T>(sum, wk.red, &tot);
+                for (uint32_t q = q0; q < q0 + perq && q < m; q++) {
+                    w.bas[q] = ex;
+                    ex += ld_word<GLOBAL>(&w.cnt[q]);
+                }
+                kept_tot[pl] = tot;
+                __syncthreads();
+                for (uint32_t u = tid; u < m; u += T) pos[evk[u]] = ld_word<GLOBAL>(&w.bas[w.cur[u]]);
+                __syncthreads();
+            }
+        }
+        nP = kept_tot[1];
+        nN = kept_tot[0];
+    }
+    // f. outputs: positives first, then negatives
     double2 *out2 = reinterpret_cast<double2 *>(xy_out);
     for (uint32_t k = tid; k < n; k += T) {
         const uint32_t r = rep[k];
-        if (r == NONE) {
+        if (r & ERASED) {
             event_point[k] = -1;
         } else {
             const uint32_t at = pos[r];
@@ -275,6 +320,23 @@ __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint
     }
     *n_pos_out = nP;
     *n_neg_out = nN;
+}
+
+// scratch of the reference-order pass for windows of up to cap events: h u64[cap]; cur, slot, cnt, bas, region, evk
+// u32[cap]; fa u32[9 cap / 4 + 16]
+__host__ __device__ constexpr size_t order_scratch_bytes(size_t cap) {
+    return ((8 + 6 * 4) * cap + 4 * (9 * cap / 4 + 16) + 255) & ~(size_t) 255;
+}
+__device__ __forceinline__ void order_scratch_carve(unsigned char *o, size_t cap, OrderScratch *ord, uint32_t **evk) {
+    ord->h = reinterpret_cast<uint64_t *>(o);
+    uint32_t *w = reinterpret_cast<uint32_t *>(o + 8 * cap);
+    ord->cur = w;
+    ord->slot = w + cap;
+    ord->cnt = w + 2 * cap;
+    ord->bas = w + 3 * cap;
+    ord->region = w + 4 * cap;
+    *evk = w + 5 * cap;
+    ord->fa = w + 6 * cap;
 }
 
 template <int CAP>
@@ -307,7 +369,8 @@ __device__ __forceinline__ void slice_tier_window(unsigned char *smem, uint32_t 
                                                   const uint32_t *__restrict__ win_base, uint32_t lo_excl,
                                                   uint32_t cap_points, double *__restrict__ xy_out,
                                                   uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt,
-                                                  int32_t *__restrict__ event_point, int *overflow) {
+                                                  int32_t *__restrict__ event_point, int *overflow,
+                                                  unsigned char *order_scratch) {
     const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
     if (n == 0) {
         if (lo_excl == 0 && threadIdx.x == 0) {
@@ -337,8 +400,14 @@ __device__ __forceinline__ void slice_tier_window(unsigned char *smem, uint32_t 
     w.pol = reinterpret_cast<uint8_t *>(smem + L::pol_off);
     w.red = reinterpret_cast<uint32_t *>(smem + L::red_off);
     uint32_t nP, nN;
+    OrderScratch ord;
+    uint32_t *evk = nullptr;
+    if (order_scratch) {   // this workgroup's slice of the order scratch (order_scratch_bytes(CAP) each)
+        unsigned char *o = order_scratch + (size_t) blockIdx.x * order_scratch_bytes(CAP);
+        order_scratch_carve(o, CAP, &ord, &evk);
+    }
     slice_window<T, false, uint16_t>(w, rec, lo, n, Log2c<NB>::value, xy_out + 2 * (size_t) base, event_point + base,
-                                     &nP, &nN);
+                                     &nP, &nN, order_scratch ? &ord : nullptr, evk);
     if (threadIdx.x == 0) {
         seg_off[2 * s] = base;
         seg_cnt[2 * s] = nP;
@@ -358,12 +427,13 @@ __global__ __launch_bounds__(T) void slice_lds_kernel(const uint8_t *__restrict_
                                                       uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt,
                                                       int32_t *__restrict__ event_point, int *overflow, uint32_t S,
                                                       const uint32_t *__restrict__ todo,
-                                                      const uint32_t *__restrict__ todo_count) {
+                                                      const uint32_t *__restrict__ todo_count,
+                                                      unsigned char *order_scratch /* null: canonical order */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t count = todo ? *todo_count : S;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         slice_tier_window<CAP, NB, T>(smem, todo ? todo[k] : k, rec, win_lo, win_hi, win_base, lo_excl, cap_points, xy_out,
-                                      seg_off, seg_cnt, event_point, overflow);
+                                      seg_off, seg_cnt, event_point, overflow, order_scratch);
         __syncthreads();
     }
 }
@@ -567,9 +637,152 @@ struct PixHash {
     static constexpr size_t red_off = tab_off + 8 * SLOTS;                 // 16 x u64 + 4 x u32 flags
     static constexpr size_t bytes = red_off + 16 * 8 + 16;
     static __device__ __forceinline__ uint32_t slot(uint32_t pix) { return (pix * 0x9E3779B1u) >> (32u - LOGC); }
+    // reference element order (slice_order.hpp): what takes the tables' place once they are dead
+    //   W u32[SLOTS]       per sequence position: members of the bucket first seen there, then  base << 16 | count
+    //   region u16[SLOTS]  the sorted sequence's slots; at the very end pos u16[SLOTS] by event index
+    //   cur u16[SLOTS]     list position of key uid (positive keys first)
+    //   fa u32[FA_CAP]     first sequence position per bucket, the + table then the - table; before the epochs the batch
+    //                      counts of the rank scan, during the early epochs also the early keys' hashes (u64[2][128])
+    //   keep u32[2][SLOTS / 32 + 1]   kept keys by list position, and the running counts of its words
+    static constexpr uint32_t FA_CAP = LOGC == 11 ? 2400u : 7456u;   // B(+) + B(-): 1109 + 1109 / 5087 + 2357 (+ slack)
+    static constexpr size_t w_off = 0;
+    static constexpr size_t region_off = w_off + 4 * SLOTS;
+    static constexpr size_t cur_off = region_off + 2 * SLOTS;
+    static constexpr size_t fa_off = cur_off + 2 * SLOTS;
+    static constexpr size_t keep_off = fa_off + 4 * FA_CAP;
+    static constexpr size_t ored_off = keep_off + 8 * (SLOTS / 32 + 1);
+    static constexpr size_t obytes = ored_off + 16 * 8 + 16;
+    static constexpr uint32_t HTAB_WORD = 1024;   // early hashes at fa[1024 ..) (the early epochs' own tables end at fa[256))
 };
 
-template <int LOGC>
+// std::hash<double> of the integers 0 .. 2047 (the pixel kernels' coordinates), built at compile time
+struct HashIntTable {
+    uint64_t v[2048];
+    constexpr HashIntTable() : v{} {
+        for (int i = 0; i < 2048; i++) v[i] = ref_hash_f64_bits(__builtin_bit_cast(uint64_t, (double) i));
+    }
+};
+__device__ const HashIntTable HASH_INT = HashIntTable();
+
+// h % B for B < 2^13 in two exact fp64 steps (64-bit integer division is a long software sequence on the GPU): with
+// inv = (1 / B)(1 - 2^-50) the estimate trunc(v inv) is the quotient or one less for every v < 2^53 B / 2^13, so one
+// conditional subtraction finishes a step; h = d1 2^40 + d0, d1 < 2^24:  (d1 % B) 2^40 + d0 < 2^53.
+struct ModB {
+    double b, inv;
+};
+__host__ __device__ constexpr double ref_step_inv(int e) { return (1.0 / (double) ref_bucket_step(e)) * (1.0 - 0x1p-50); }
+struct StepInvTable {
+    double inv[12];
+    constexpr StepInvTable() : inv{} {
+        for (int e = 0; e < 12; e++) inv[e] = ref_step_inv(e);
+    }
+};
+__device__ __forceinline__ ModB mod_for_epoch(int e) {
+    constexpr StepInvTable tabl = StepInvTable();
+    ModB m;
+    m.b = (double) ref_bucket_step(e);
+    m.inv = tabl.inv[e];
+    return m;
+}
+__device__ __forceinline__ double mod_step(double v, const ModB m) {
+    const double q = __builtin_trunc(v * m.inv);
+    double r = __builtin_fma(-q, m.b, v);
+    if (r >= m.b) r -= m.b;
+    return r;
+}
+__device__ __forceinline__ uint32_t mod_hash(uint64_t h, const ModB m) {
+    const double d1 = (double) (uint32_t) (h >> 40);
+    const double d0 = __builtin_fma((double) (uint32_t) ((h >> 32) & 0xFFu), 0x1p32, (double) (uint32_t) h);
+    const double r1 = mod_step(d1, m);
+    return (uint32_t) mod_step(__builtin_fma(r1, 0x1p40, d0), m);
+}
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The early epochs of one polarity's set, run by ONE wave (no workgroup barrier): keys u < min(m, 127) = the epochs with
+// 13, 29, 59 and 127 buckets, at most two keys per lane.  hk = the keys' hashes, fa / W / region = 128-entry scratch of
+// this polarity; writes cur_out[u] = list position after the last early epoch.
+__device__ __forceinline__ void early_epochs(const uint64_t *hk, uint32_t m, uint32_t *fa, uint32_t *W, uint16_t *region,
+                                             uint16_t *cur_out) {
+    constexpr int EARLY = 4;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t m_e = m < 127u ? m : 127u;
+    uint64_t h[2];
+    uint32_t cur[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 2; i++) h[i] = (lane + 64u * i < m_e) ? hk[lane + 64u * i] : 0ull;
+    uint32_t n_prev = 0;
+    for (int e = 0; e < EARLY && n_prev < m_e; e++) {
+        const uint32_t B = (uint32_t) ref_bucket_step(e);
+        const uint32_t n_e = m_e < B ? m_e : B;
+        const ModB md = mod_for_epoch(e);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            fa[lane + 64u * i] = 0xFFFFFFFFu;
+            W[lane + 64u * i] = 0u;
+        }
+        wave_sync_lds();
+        uint32_t b[2], q[2], f[2], sl[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            q[i] = u < n_prev ? cur[i] : u;
+            b[i] = mod_hash(h[i], md);
+            if (u < n_e) atomicMin(&fa[b[i]], q[i]);
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            f[i] = 0;
+            sl[i] = 0;
+            if (u < n_e) {
+                f[i] = fa[b[i]];
+                sl[i] = atomicAdd(&W[f[i]], 1u);
+            }
+        }
+        wave_sync_lds();
+        {   // exclusive scan of the counts over the positions 2 lane, 2 lane + 1
+            const uint32_t c0 = W[2u * lane], c1 = W[2u * lane + 1u];
+            uint32_t inc = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= (uint32_t) d) inc += o;
+            }
+            const uint32_t ex = inc - c0 - c1;
+            W[2u * lane] = (ex << 16) | c0;
+            W[2u * lane + 1u] = ((ex + c0) << 16) | c1;
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            if (u < n_e) region[(W[f[i]] >> 16) + sl[i]] = (uint16_t) q[i];
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            if (u < n_e) {
+                const uint32_t w = W[f[i]], b0 = w >> 16, c = w & 0xFFFFu;
+                uint32_t within = 0;
+                for (uint32_t t = 0; t < c; t++) within += ((uint32_t) region[b0 + t] < q[i]) ? 1u : 0u;
+                cur[i] = n_e - 1u - (b0 + within);
+            }
+        }
+        wave_sync_lds();
+        n_prev = n_e;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+        if (lane + 64u * i < m_e) cur_out[lane + 64u * i] = (uint16_t) cur[i];
+}
+
+template <int LOGC, bool REFORDER>
 __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uint32_t s, const uint8_t *__restrict__ rec,
                                                   const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
                                                   const uint32_t *__restrict__ win_base, uint32_t cap_points,
@@ -688,6 +901,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
     if (ECAL_SL_STOP == 2) return;
     // c. representative = first occurrence of the pixel with this polarity, unless the pixel also fired with the other one
     uint32_t repk[PXH_PER];  // representative of event tid + j T (NONE: erased)
+    uint32_t firstk[PXH_PER];  // (reference order) its set's key = first occurrence of the pixel with the polarity | erased << 15
     {
         uint32_t fw[PXH_PER], ow[PXH_PER];
 #pragma unroll
@@ -713,13 +927,250 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     w = o[h];
                 }
                 repk[j] = both ? NONE : first;
+                firstk[j] = first | (both ? 0x8000u : 0u);
             } else {
                 repk[j] = NONE;
+                firstk[j] = 0xFFFFu;
             }
         }
     }
     __syncthreads();  // the tables are dead from here: pos takes their place
     if (ECAL_SL_STOP == 3) return;
+    if constexpr (REFORDER) {
+        // ---- the reference's element order (slice_order.hpp; EventFrame.cpp:12-13,34-35) ----
+        constexpr int EARLY = 4;                       // epochs run by one wave per polarity (keys u < 127)
+        constexpr uint32_t N_EARLY = 127u;
+        uint32_t *const W = reinterpret_cast<uint32_t *>(smem + L::w_off);
+        uint16_t *const region = reinterpret_cast<uint16_t *>(smem + L::region_off);
+        uint16_t *const cur = reinterpret_cast<uint16_t *>(smem + L::cur_off);
+        uint32_t *const fa = reinterpret_cast<uint32_t *>(smem + L::fa_off);
+        uint32_t *const keepW = reinterpret_cast<uint32_t *>(smem + L::keep_off);
+        uint32_t *const keepPre = keepW + (PXH_SLOTS / 32u + 1u);
+        uint64_t *const htab = reinterpret_cast<uint64_t *>(fa + L::HTAB_WORD);
+        uint32_t *const ored = reinterpret_cast<uint32_t *>(smem + L::ored_off);
+        uint16_t *const posE = region;
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        // d'. rank of every key among its polarity's keys, in event order = the order in which the set saw them
+        constexpr uint32_t NBATCH = (uint32_t) PXH_PER * (T / 64);
+        uint32_t *const bcnt = fa;
+        uint32_t urank[PXH_PER];
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            const bool isu = k < n && (firstk[j] & 0x7FFFu) == k;
+            const unsigned long long mP = __ballot(isu && vp[j] != 0), mN = __ballot(isu && vp[j] == 0);
+            const unsigned long long lower = (1ull << lane) - 1ull;
+            urank[j] = (uint32_t) __popcll((vp[j] ? mP : mN) & lower);
+            if (lane == 0) bcnt[j * (T / 64) + wave] = (uint32_t) __popcll(mP) | ((uint32_t) __popcll(mN) << 16);
+        }
+        __syncthreads();
+        if (tid < 64u) {
+            const uint32_t v = tid < NBATCH ? bcnt[tid] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(inc, d, 64);
+                if (lane >= (uint32_t) d) inc += o;
+            }
+            if (tid < NBATCH) bcnt[tid] = inc - v;
+            if (tid == 63u) bcnt[NBATCH] = inc;
+        }
+        __syncthreads();
+        const uint32_t totals = bcnt[NBATCH], mP = totals & 0xFFFFu, mN = totals >> 16;
+        const int EP = mP ? ref_epochs(mP) : 0, EN = mN ? ref_epochs(mN) : 0;
+        {
+            const uint32_t need = (EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u) + (EN ? (uint32_t) ref_bucket_step(EN - 1) : 0u);
+            if (need > L::FA_CAP || EP > 12 || EN > 12) {   // more keys than the bucket tables hold: next tier
+                if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+                return;
+            }
+        }
+        uint64_t hk[PXH_PER];
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            urank[j] += (vp[j] ? (bcnt[j * (T / 64) + wave] & 0xFFFFu) : (bcnt[j * (T / 64) + wave] >> 16));
+            hk[j] = 0;
+            if (k < n && (firstk[j] & 0x7FFFu) == k) {
+                hk[j] = ref_hash_combine2(HASH_INT.v[pix[j] >> 10], HASH_INT.v[pix[j] & 0x3FFu]);   // utility.hpp:38-51
+            }
+        }
+        __syncthreads();   // bcnt (= fa) is dead
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            if (k < n && (firstk[j] & 0x7FFFu) == k && urank[j] < N_EARLY) htab[(vp[j] ? 0u : 128u) + urank[j]] = hk[j];
+        }
+        {
+            uint4 *k4 = reinterpret_cast<uint4 *>(keepW);
+            for (uint32_t q = tid; q < (PXH_SLOTS / 32u + 1u + 3u) / 4u; q += T) k4[q] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __syncthreads();
+        // early epochs: wave 0 the positive set, wave 1 the negative one; key uid = rank (+) / mP + rank (-)
+        if (wave == 0 && mP) early_epochs(htab, mP, fa, W, region, cur);
+        if (wave == 1 && mN) early_epochs(htab + 128, mN, fa + 128, W + 128, region + 128, cur + mP);
+        __syncthreads();
+        // block epochs
+        const int EMAX = EP > EN ? EP : EN;
+        for (int e = EARLY; e < EMAX; e++) {
+            const uint32_t B = (uint32_t) ref_bucket_step(e), Bprev = (uint32_t) ref_bucket_step(e - 1);
+            const ModB md = mod_for_epoch(e);
+            const bool onP = e < EP, onN = e < EN;
+            const uint32_t nP_e = onP ? (mP < B ? mP : B) : 0u, nN_e = onN ? (mN < B ? mN : B) : 0u;
+            const uint32_t faN = onP ? B : 0u;   // offset of the - table
+            {
+                const uint32_t words = faN + (onN ? B : 0u);
+                for (uint32_t q = tid; q < words; q += T) fa[q] = 0xFFFFFFFFu;
+                uint4 *w4 = reinterpret_cast<uint4 *>(W);
+                for (uint32_t q = tid; q < PXH_SLOTS / 4u; q += T) w4[q] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+            uint32_t bq[PXH_PER], fs[PXH_PER];   // bucket << 12 | sequence position ; first position << 12 | slot
+            unsigned act = 0;
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) {
+                const uint32_t k = tid + j * T;
+                const bool isu = k < n && (firstk[j] & 0x7FFFu) == k;
+                const bool on = isu && (vp[j] ? (onP && urank[j] < nP_e) : (onN && urank[j] < nN_e));
+                bq[j] = 0;
+                if (on) {
+                    act |= 1u << j;
+                    const uint32_t uid = (vp[j] ? 0u : mP) + urank[j];
+                    const uint32_t q = urank[j] < Bprev ? (uint32_t) cur[uid] : urank[j];
+                    const uint32_t b = (vp[j] ? 0u : faN) + mod_hash(hk[j], md);
+                    bq[j] = (b << 12) | q;
+                    atomicMin(&fa[b], q);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) {
+                fs[j] = 0;
+                if (act & (1u << j)) {
+                    const uint32_t f = fa[bq[j] >> 12];
+                    const uint32_t sl = atomicAdd(&W[(vp[j] ? 0u : mP) + f], 1u);
+                    fs[j] = (f << 12) | sl;
+                }
+            }
+            __syncthreads();
+            {   // exclusive scan of the counts over the sequence positions (the - positions restart at mP)
+                constexpr uint32_t SP = PXH_SLOTS / T;
+                uint32_t c[SP], sum = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < SP; i++) {
+                    c[i] = W[tid * SP + i];
+                    sum += c[i];
+                }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d, 64);
+                    if (lane >= (uint32_t) d) inc += o;
+                }
+                if (lane == 63u) ored[wave] = inc;
+                __syncthreads();
+                uint32_t pre = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < (uint32_t) (T / 64); w++) pre += (w < wave) ? ored[w] : 0u;
+                uint32_t ex = pre + inc - sum;
+#pragma unroll
+                for (uint32_t i = 0; i < SP; i++) {
+                    const uint32_t qpos = tid * SP + i;
+                    const uint32_t rel = qpos >= mP ? ex - nP_e : ex;
+                    W[qpos] = (rel << 16) | c[i];
+                    ex += c[i];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) {
+                if (act & (1u << j)) {
+                    const uint32_t off = vp[j] ? 0u : mP;
+                    const uint32_t w = W[off + (fs[j] >> 12)];
+                    region[off + (w >> 16) + (fs[j] & 0xFFFu)] = (uint16_t) (bq[j] & 0xFFFu);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) {
+                if (act & (1u << j)) {
+                    const uint32_t off = vp[j] ? 0u : mP;
+                    const uint32_t w = W[off + (fs[j] >> 12)], b0 = w >> 16, cnt = w & 0xFFFFu, q = bq[j] & 0xFFFu;
+                    uint32_t within = 0;
+                    for (uint32_t t = 0; t < cnt; t++) within += ((uint32_t) region[off + b0 + t] < q) ? 1u : 0u;
+                    const uint32_t n_e = vp[j] ? nP_e : nN_e;
+                    cur[off + urank[j]] = (uint16_t) (n_e - 1u - (b0 + within));
+                }
+            }
+            __syncthreads();
+        }
+        // the erased keys drop out (EventFrame.cpp:24-32): index of a kept key = kept keys in front of it in the list
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            if (k < n && firstk[j] == k) {   // a key, and not erased
+                const uint32_t at = (vp[j] ? 0u : mP) + (uint32_t) cur[(vp[j] ? 0u : mP) + urank[j]];
+                atomicOr(&keepW[at >> 5], 1u << (at & 31u));
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            constexpr uint32_t KW = PXH_SLOTS / 32u;   // 64 or 128 words
+            uint32_t carry = 0;
+#pragma unroll
+            for (uint32_t w0 = 0; w0 < KW; w0 += 64u) {
+                const uint32_t c = (uint32_t) __popc(keepW[w0 + lane]);
+                uint32_t inc = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d, 64);
+                    if (lane >= (uint32_t) d) inc += o;
+                }
+                keepPre[w0 + lane] = carry + inc - c;
+                carry += __shfl(inc, 63, 64);
+            }
+        }
+        __syncthreads();
+        auto kept_below = [&](uint32_t at) { return keepPre[at >> 5] + (uint32_t) __popc(keepW[at >> 5] & ((1u << (at & 31u)) - 1u)); };
+        const uint32_t nP = kept_below(mP), nN = kept_below(mP + mN) - nP;
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            if (k < n && firstk[j] == k) {
+                const uint32_t at = (vp[j] ? 0u : mP) + (uint32_t) cur[(vp[j] ? 0u : mP) + urank[j]];
+                posE[k] = (uint16_t) (kept_below(at) - (vp[j] ? 0u : nP));
+            }
+        }
+        __syncthreads();
+        double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
+        int32_t *ep = event_point + base;
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) {
+            const uint32_t k = tid + j * T;
+            if (k < n) {
+                const uint32_t r = firstk[j];
+                if (r & 0x8000u) {
+                    ep[k] = -1;
+                } else {
+                    const uint32_t at = posE[r];
+                    ep[k] = (int32_t) at;
+                    if (r == k) {
+                        double2 v;
+                        v.x = (double) (pix[j] >> 10);
+                        v.y = (double) (pix[j] & 0x3FFu);
+                        out2[vp[j] ? at : nP + at] = v;
+                    }
+                }
+            }
+        }
+        if (tid == 0) {
+            seg_off[2 * s] = base;
+            seg_cnt[2 * s] = nP;
+            seg_off[2 * s + 1] = base + nP;
+            seg_cnt[2 * s + 1] = nN;
+        }
+        return;
+    }
     // d. ranks of the representatives in event order.  Batch (j, wave) holds 64 consecutive events and the batches ascend in
     // event index: rank = representatives of the same polarity in the batches before + on the lanes below (ballots; the
     // per-batch counts, both polarities packed in one word, are scanned by wave 0).
@@ -791,6 +1242,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
 }
 
 // first pass: workgroup b handles window b; what it cannot take goes to todo / todo_count
+template <bool REFORDER>
 __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__restrict__ rec,
                                                            const uint32_t *__restrict__ win_lo,
                                                            const uint32_t *__restrict__ win_hi,
@@ -801,11 +1253,12 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
                                                            uint32_t *__restrict__ todo,
                                                            uint32_t *__restrict__ todo_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    slice_hash_window<11>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
+    slice_hash_window<11, REFORDER>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
                           todo, todo_count);
 }
 
 // second pass: the workgroups share the list the first pass left (in_list[0 .. *in_count)); windows of up to 4095 events
+template <bool REFORDER>
 __global__ __launch_bounds__(PXH_T) void slice_hash_list_kernel(const uint8_t *__restrict__ rec,
                                                                 const uint32_t *__restrict__ win_lo,
                                                                 const uint32_t *__restrict__ win_hi,
@@ -819,7 +1272,7 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_list_kernel(const uint8_t *_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        slice_hash_window<12>(smem, in_list[k], rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point,
+        slice_hash_window<12, REFORDER>(smem, in_list[k], rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point,
                               overflow, todo, todo_count);
         __syncthreads();
     }
@@ -831,12 +1284,13 @@ __global__ __launch_bounds__(SLICE_BIG_T) void slice_big_kernel(
     const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
     const uint32_t *__restrict__ win_base, uint32_t lo_excl, uint32_t cap_points, double *__restrict__ xy_out,
     uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
-    double2 *g_pts, uint8_t *g_pol, uint32_t *g_bend, uint32_t *g_sorted, uint32_t *g_rep, uint32_t *g_pos) {
-    __shared__ unsigned long long red64[16];
+    double2 *g_pts, uint8_t *g_pol, uint32_t *g_bend, uint32_t *g_sorted, uint32_t *g_rep, uint32_t *g_pos,
+    unsigned char *order_scratch /* null: canonical order; else order_scratch_bytes(cap_points) + 64 S bytes */) {
+    __shared__ unsigned long long red64[17];
     const uint32_t s = blockIdx.x;
     const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
     if (n <= lo_excl) return;
-    if ((uint64_t) base + n > cap_points) {
+    if ((uint64_t) base + n > cap_points || n >= 0x80000000u) {
         if (threadIdx.x == 0) {
             *overflow = 1;
             seg_off[2 * s] = seg_off[2 * s + 1] = 0;
@@ -855,8 +1309,22 @@ __global__ __launch_bounds__(SLICE_BIG_T) void slice_big_kernel(
     uint32_t nb_log = 31u - (uint32_t) __clz((int) n);  // largest power of two <= n
     if (nb_log > 20u) nb_log = 20u;
     uint32_t nP, nN;
+    OrderScratch ord;
+    uint32_t *evk = nullptr;
+    if (order_scratch) {   // per-window slices: the n-entry arrays at `base`, fa at 9 base / 4 + 16 s (it holds B(n) < 9 n / 4 + 16 words)
+        const size_t cap = cap_points;
+        order_scratch_carve(order_scratch, cap, &ord, &evk);
+        ord.h += base;
+        ord.cur += base;
+        ord.slot += base;
+        ord.cnt += base;
+        ord.bas += base;
+        ord.region += base;
+        evk += base;
+        ord.fa += (size_t) base * 9 / 4 + 16 * (size_t) s;
+    }
     slice_window<SLICE_BIG_T, true, uint32_t>(w, rec, lo, n, nb_log, xy_out + 2 * (size_t) base, event_point + base, &nP,
-                                              &nN);
+                                              &nN, order_scratch ? &ord : nullptr, evk);
     if (threadIdx.x == 0) {
         seg_off[2 * s] = base;
         seg_cnt[2 * s] = nP;
@@ -921,6 +1389,9 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
+    const bool reforder = ctx->point_order == ECAL_ORDER_REFERENCE;
+    constexpr size_t H11 = PixHash<11>::bytes > PixHash<11>::obytes ? PixHash<11>::bytes : PixHash<11>::obytes;
+    constexpr size_t H12 = PixHash<12>::bytes > PixHash<12>::obytes ? PixHash<12>::bytes : PixHash<12>::obytes;
     if (!ctx->slice_attrs_set) {
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_lds_kernel<SCAP0, 2048, 256>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -928,8 +1399,10 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_lds_kernel<SCAP1, 4096, 512>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int) SliceLayout<SCAP1>::bytes));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_list_kernel),
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_list_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixHash<12>::bytes));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_list_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) H12));
         ctx->slice_attrs_set = true;
     }
     ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
@@ -944,14 +1417,24 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
         todo = list;
         todo_count = cnt;
-        if (!getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)
-            hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
-                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
-            if (mx > PixHash<11>::CAP && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
+        if (reforder || !getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)
+            if (reforder)
+                hipLaunchKernelGGL(slice_hash_kernel<true>, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
+                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+            else
+                hipLaunchKernelGGL(slice_hash_kernel<false>, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
+                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+            // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
+            if ((reforder || mx > PixHash<11>::CAP) && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
                 const uint32_t grid2 = S < 768u ? S : 768u;
-                hipLaunchKernelGGL(slice_hash_list_kernel, dim3(grid2), dim3(PXH_T), PixHash<12>::bytes, st, d_events, d_win_lo,
-                                   d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
-                                   cnt2, (const uint32_t *) list, (const uint32_t *) cnt);
+                if (reforder)
+                    hipLaunchKernelGGL(slice_hash_list_kernel<true>, dim3(grid2), dim3(PXH_T), H12, st, d_events, d_win_lo,
+                                       d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
+                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt);
+                else
+                    hipLaunchKernelGGL(slice_hash_list_kernel<false>, dim3(grid2), dim3(PXH_T), PixHash<12>::bytes, st, d_events, d_win_lo,
+                                       d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
+                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt);
                 todo = list2;
                 todo_count = cnt2;
             }
@@ -961,13 +1444,21 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         }
         grid = S < 512u ? S : 512u;
     }
+    // general tiers; in reference order they take their order scratch from global memory, one slice per workgroup
+    unsigned char *ord_lds = nullptr, *ord_big = nullptr;
+    if (reforder) {
+        int rc;
+        const size_t cap = mx > (uint32_t) SCAP0 ? SCAP1 : SCAP0;
+        if ((rc = ecal_ensure(ctx, ctx->sl_order, (size_t) grid * order_scratch_bytes(cap)))) return rc;
+        ord_lds = (unsigned char *) ctx->sl_order.ptr;
+    }
     hipLaunchKernelGGL((slice_lds_kernel<SCAP0, 2048, 256>), dim3(grid), dim3(256), SliceLayout<SCAP0>::bytes, st, d_events,
                        d_win_lo, d_win_hi, d_win_base, 0u, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point,
-                       d_overflow, S, todo, todo_count);
+                       d_overflow, S, todo, todo_count, ord_lds);
     if (mx > (uint32_t) SCAP0)
         hipLaunchKernelGGL((slice_lds_kernel<SCAP1, 4096, 512>), dim3(grid), dim3(512), SliceLayout<SCAP1>::bytes, st,
                            d_events, d_win_lo, d_win_hi, d_win_base, (uint32_t) SCAP0, cap_points, d_xy, d_seg_off,
-                           d_seg_cnt, d_event_point, d_overflow, S, todo, todo_count);
+                           d_seg_cnt, d_event_point, d_overflow, S, todo, todo_count, ord_lds);
     if (mx > (uint32_t) SCAP1) {
         const size_t w = cap_points;
         int rc;
@@ -977,11 +1468,29 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_ensure(ctx, ctx->sl_sorted, w * sizeof(uint32_t)))) return rc;
         if ((rc = ecal_ensure(ctx, ctx->sl_rep, w * sizeof(uint32_t)))) return rc;
         if ((rc = ecal_ensure(ctx, ctx->sl_pos, w * sizeof(uint32_t)))) return rc;
+        if (reforder) {
+            if ((rc = ecal_ensure(ctx, ctx->sl_order_big, order_scratch_bytes(w) + 64 * ((size_t) S + 1)))) return rc;
+            ord_big = (unsigned char *) ctx->sl_order_big.ptr;
+        }
         hipLaunchKernelGGL(slice_big_kernel, dim3(S), dim3(SLICE_BIG_T), 0, st, d_events, d_win_lo, d_win_hi, d_win_base,
                            (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
                            (double2 *) ctx->sl_pts.ptr, (uint8_t *) ctx->sl_pol.ptr, (uint32_t *) ctx->sl_bend.ptr,
-                           (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr);
+                           (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr, ord_big);
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
+}
+
+extern "C" int ecal_set_point_order(ecal_ctx *ctx, int order) {
+    if (!ctx || (order != ECAL_ORDER_REFERENCE && order != ECAL_ORDER_FIRST_OCCURRENCE)) return ECAL_ERR_INVALID;
+    ctx->point_order = order;
+    return ECAL_OK;
+}
+
+extern "C" int ecal_get_point_order(const ecal_ctx *ctx) { return ctx ? ctx->point_order : ECAL_ERR_INVALID; }
+
+/* the tables of slice_order.hpp, for the CPU suite (tests/test_oracle_events.py checks them against libstdc++ itself) */
+extern "C" uint64_t ecal_ref_bucket_step(int epoch) { return (epoch >= 0 && epoch < REF_N_STEPS) ? ref_bucket_step(epoch) : 0; }
+extern "C" uint64_t ecal_ref_pixel_hash(double x, double y) {
+    return ref_hash_combine2(ref_hash_f64_bits(__builtin_bit_cast(uint64_t, x)), ref_hash_f64_bits(__builtin_bit_cast(uint64_t, y)));
 }

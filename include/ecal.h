@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ECAL_ABI_VERSION 1
+#define ECAL_ABI_VERSION 2
 
 typedef enum ecal_status {
     ECAL_OK = 0,
@@ -93,13 +93,28 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
  *   of d_xy / d_event_point (capacity cap_points slots):
  *     segment 2s   = positiveEvents_ : d_xy[d_seg_off[2s]   ..+d_seg_cnt[2s]]
  *     segment 2s+1 = negativeEvents_ : d_xy[d_seg_off[2s+1] ..+d_seg_cnt[2s+1]]
- *   in the build's canonical order (ascending first occurrence inside the window; the reference's
- *   order is libstdc++ unordered_set iteration order, an implementation artefact — DESIGN.md §2).
+ *   in the element order ecal_set_point_order selected: by default THE REFERENCE'S — the iteration
+ *   order of its std::unordered_set<Vector2d, EigenMatrixHash> (EventFrame.cpp:12-13,34-35;
+ *   core/utility/include/opengv2/utility/utility.hpp:38-51; libstdc++), which DBSCAN's cluster
+ *   assignments depend on (insertion-order kd-tree, kdtree.cpp:128-131,169) — or first occurrence.
  *   d_event_point[win_base[s]+k] = index of event k's pixel inside its polarity's segment, or -1
  *   if the pixel was erased.  The segment arrays feed ecal_dbscan_batch_dev directly (S' = 2S).
  *   *d_overflow = 1 if some window did not fit cap_points (its segments are then empty).
  *   max_win_events: upper bound on any window size, 0 = unknown.
  */
+/* Element order of the pixel sets every slicing entry point of this context emits (ecal_slice_events_dev and everything
+ * built on it: ecal_detect_*, ecal_slice_events).  ECAL_ORDER_REFERENCE (default): positiveEvents_ / negativeEvents_ exactly
+ * as the reference's EventFrame constructor leaves them on libstdc++ — same `.bin` => same point order => same DBSCAN
+ * labels as the reference.  ECAL_ORDER_FIRST_OCCURRENCE: ascending first occurrence of the pixel inside the window (the
+ * same sets, a cheaper order; labels then equal the reference's only up to the order-dependent effects). */
+enum { ECAL_ORDER_REFERENCE = 0, ECAL_ORDER_FIRST_OCCURRENCE = 1 };
+int ecal_set_point_order(ecal_ctx *ctx, int order);
+int ecal_get_point_order(const ecal_ctx *ctx);
+/* the restated libstdc++ tables behind ECAL_ORDER_REFERENCE, exported for verification (no GPU needed): bucket count of
+ * epoch e (13, 29, 59, ...; 0 past the table) and EigenMatrixHash of a pixel */
+uint64_t ecal_ref_bucket_step(int epoch);
+uint64_t ecal_ref_pixel_hash(double x, double y);
+
 int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_t0,
                            const double *d_t1, uint32_t S, uint32_t *d_win_lo, uint32_t *d_win_hi,
                            uint32_t *d_win_base /*[S+1]*/, void *stream);

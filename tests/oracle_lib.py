@@ -122,6 +122,19 @@ def _declare_events(L):
     L.oracle_check_sorted.restype = ctypes.c_int
     L.oracle_event_frame.argtypes = [_u8p, ctypes.c_uint64, ctypes.c_uint64, _dp, _u32p, _u32p, _i32p]
     L.oracle_event_frame.restype = ctypes.c_int
+    L.oracle_event_frame_ref.argtypes = L.oracle_event_frame.argtypes
+    L.oracle_event_frame_ref.restype = ctypes.c_int
+    L.oracle_event_frame_model.argtypes = [_u8p, ctypes.c_uint64, ctypes.c_uint64, _u64p, ctypes.c_uint32, _dp, _u32p, _u32p,
+                                           _i32p]
+    L.oracle_event_frame_model.restype = ctypes.c_int
+    L.oracle_pixel_hash.argtypes = [ctypes.c_double, ctypes.c_double]
+    L.oracle_pixel_hash.restype = ctypes.c_uint64
+    L.oracle_pixel_hash_restated.argtypes = [ctypes.c_double, ctypes.c_double]
+    L.oracle_pixel_hash_restated.restype = ctypes.c_uint64
+    L.oracle_bucket_counts.argtypes = [ctypes.c_uint32, _u64p]
+    L.oracle_bucket_counts.restype = None
+    L.oracle_next_bkt.argtypes = [ctypes.c_uint64]
+    L.oracle_next_bkt.restype = ctypes.c_uint64
 
 
 def window_bounds(rec, t0, t1):
@@ -140,8 +153,20 @@ def check_sorted(rec):
     return L.oracle_check_sorted(_p(rec, _u8p), rec.size // 25)
 
 
-def event_frame(rec, lo, hi):
-    """EventFrame ctor on events [lo,hi): (xy_pos [nP,2], xy_neg [nN,2], event_point int32 [hi-lo])."""
+def bucket_steps(n_steps=28):
+    """libstdc++'s unordered_set bucket counts, epoch by epoch (13, 29, 59, ...), from the library's own policy object."""
+    L = lib()
+    _declare_events(L)
+    out = [int(L.oracle_next_bkt(12))]
+    while len(out) < n_steps:
+        out.append(int(L.oracle_next_bkt(2 * out[-1])))
+    return np.array(out, dtype=np.uint64)
+
+
+def event_frame(rec, lo, hi, order="canonical"):
+    """EventFrame ctor on events [lo,hi): (xy_pos [nP,2], xy_neg [nN,2], event_point int32 [hi-lo]).
+    order: "canonical" (first occurrence), "reference" (real std::unordered_set, EventFrame.cpp:34-35) or "model"
+    (the restated list rules the HIP slicer follows)."""
     L = lib()
     _declare_events(L)
     rec = np.ascontiguousarray(rec, dtype=np.uint8)
@@ -149,7 +174,14 @@ def event_frame(rec, lo, hi):
     xy = np.zeros((max(n, 1), 2), dtype=np.float64)
     ep = np.full(max(n, 1), -1, dtype=np.int32)
     npos, nneg = ctypes.c_uint32(0), ctypes.c_uint32(0)
-    L.oracle_event_frame(_p(rec, _u8p), lo, hi, _p(xy, _dp), ctypes.byref(npos), ctypes.byref(nneg), _p(ep, _i32p))
+    if order == "model":
+        st = bucket_steps()
+        rc = L.oracle_event_frame_model(_p(rec, _u8p), lo, hi, _p(st, _u64p), len(st), _p(xy, _dp), ctypes.byref(npos),
+                                        ctypes.byref(nneg), _p(ep, _i32p))
+        assert rc == 0
+    else:
+        fn = {"canonical": L.oracle_event_frame, "reference": L.oracle_event_frame_ref}[order]
+        fn(_p(rec, _u8p), lo, hi, _p(xy, _dp), ctypes.byref(npos), ctypes.byref(nneg), _p(ep, _i32p))
     return xy[:npos.value].copy(), xy[npos.value:npos.value + nneg.value].copy(), ep[:n]
 
 

@@ -8,18 +8,23 @@ import synth_stream as SS
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def env():
+@pytest.fixture(scope="module", params=["reference", "first"])
+def env(request):
+    """Every test runs in both element orders: the reference's (EventFrame.cpp:34-35 on libstdc++, checked against the
+    oracle's real std::unordered_set) and first occurrence (checked against the oracle's canonical mode)."""
     import torch
     import eventcalib_amd
     from eventcalib_amd.pipeline import DetectPipeline
     ctx = eventcalib_amd.Context(0)
+    assert ctx.point_order() == "reference"          # the default is the reference's order
+    ctx.set_point_order(request.param)
     yield ctx, DetectPipeline(ctx), torch
     ctx.close()
 
 
 def _compare(pipe, torch, rec_np, t0, t1, eps=4.0, minpts=2, check_labels=True):
     S = len(t0)
+    order = {"reference": "reference", "first": "canonical"}[pipe.ctx.point_order()]
     lo = pipe.win_lo[:S].cpu().numpy().astype(np.int64)
     hi = pipe.win_hi[:S].cpu().numpy().astype(np.int64)
     base = pipe.win_base[:S + 1].cpu().numpy().astype(np.int64)
@@ -36,7 +41,7 @@ def _compare(pipe, torch, rec_np, t0, t1, eps=4.0, minpts=2, check_labels=True):
         assert (lo[s], hi[s]) == (olo, ohi), "window %d bounds" % s
         assert base[s] == run
         run += ohi - olo
-        pos, neg, oep = O.event_frame(rec_np, olo, ohi)
+        pos, neg, oep = O.event_frame(rec_np, olo, ohi, order)
         assert seg_cnt[2 * s] == pos.shape[0] and seg_cnt[2 * s + 1] == neg.shape[0], "window %d counts" % s
         if ohi > olo:
             assert seg_off[2 * s] == base[s] and seg_off[2 * s + 1] == base[s] + pos.shape[0]

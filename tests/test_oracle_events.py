@@ -44,3 +44,88 @@ def test_nonzero_polarity_byte_is_positive():
     rec = O.pack_events([0.0, 1e-4], [3.0, 4.0], [3.0, 4.0], [2, 255])   # read into a bool, Event.hpp:45
     pos, neg, ep = O.event_frame(rec, 0, 2)
     assert pos.shape[0] == 2 and neg.shape[0] == 0
+
+
+# ---- the reference's element order (EventFrame.cpp:12-13,34-35 + utility.hpp:38-51 on libstdc++) --------------------
+def _random_window(rng, trial):
+    n = int(rng.integers(1, 3000))
+    W = int(rng.choice([8, 40, 346]))
+    H = int(rng.choice([8, 30, 260]))
+    x = rng.integers(0, W, n).astype(float)
+    y = rng.integers(0, H, n).astype(float)
+    if trial % 5 == 0:
+        x = x * 0.5 - 3          # non-integer and negative coordinates
+    if trial % 7 == 0:
+        x[rng.random(n) < 0.05] = -0.0
+    p = rng.integers(0, 2, n)
+    return O.pack_events(np.arange(n) * 1e-6, x, y, p), n
+
+
+def test_reference_order_is_a_permutation_of_the_canonical_sets():
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        rec, n = _random_window(rng, trial)
+        rp, rn, rep = O.event_frame(rec, 0, n, "reference")
+        cp, cn, cep = O.event_frame(rec, 0, n, "canonical")
+        assert sorted(map(tuple, rp)) == sorted(map(tuple, cp)) and sorted(map(tuple, rn)) == sorted(map(tuple, cn))
+        assert np.array_equal(rep < 0, cep < 0)
+        # event_point points at the event's own pixel
+        t, xy, pol = rec.reshape(-1, 25)[:, :8], rec.reshape(-1, 25)[:, 8:24].copy().view(np.float64), rec.reshape(-1, 25)[:, 24]
+        for k in range(0, n, 37):
+            if rep[k] >= 0:
+                assert np.array_equal((rp if pol[k] else rn)[rep[k]], xy[k])
+
+
+def test_restated_list_rules_equal_the_real_unordered_set():
+    """oracle_event_frame_model (the rules of eventcalib_amd/csrc/slice_order.hpp, which the HIP slicer follows: bucket
+    counts 13, 29, 59, ...; insert at the front of the bucket's run or of the list; rehash walk) against the real
+    std::unordered_set with the restated EigenMatrixHash."""
+    rng = np.random.default_rng(1)
+    for trial in range(120):
+        rec, n = _random_window(rng, trial)
+        a = O.event_frame(rec, 0, n, "reference")
+        b = O.event_frame(rec, 0, n, "model")
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v), (trial, n)
+
+
+def test_known_answer_small_set():
+    """Hand-checkable case: three positive pixels land in buckets h % 13; each new bucket goes to the FRONT of the list."""
+    rec = O.pack_events(np.arange(3) * 1e-6, [1.0, 2.0, 3.0], [0.0, 0.0, 0.0], [1, 1, 1])
+    pos, neg, ep = O.event_frame(rec, 0, 3, "reference")
+    L = O.lib()
+    b = [L.oracle_pixel_hash(float(v), 0.0) % 13 for v in (1, 2, 3)]
+    assert len(set(b)) == 3                      # three different buckets -> pure reverse insertion order
+    assert pos.tolist() == [[3.0, 0.0], [2.0, 0.0], [1.0, 0.0]] and ep.tolist() == [2, 1, 0]
+
+
+def test_hash_restatement_and_bucket_steps_match_libstdcxx():
+    import ctypes
+    import os
+    L = O.lib()
+    O._declare_events(L)
+    rng = np.random.default_rng(2)
+    vals = [0.0, -0.0, 1.0, 345.0, 259.0, 0.5, -3.25, 1e300, 5e-324, np.inf] + list(rng.normal(size=50)) + list(rng.integers(0, 2048, 200).astype(float))
+    for x in vals:
+        for y in vals[:12]:
+            assert L.oracle_pixel_hash(x, y) == L.oracle_pixel_hash_restated(x, y), (x, y)
+    # growth of a real unordered_set == the policy object's steps
+    bc = np.zeros(12000, np.uint64)
+    L.oracle_bucket_counts(12000, O._p(bc, O._u64p))
+    steps = O.bucket_steps(28)
+    seen = sorted(set(int(v) for v in bc))
+    assert seen == [int(v) for v in steps[:len(seen)]]
+    for k in range(12000):                       # key number k+1 lives in the first step >= k+1
+        assert bc[k] == steps[np.searchsorted(steps, k + 1)]
+    # the product's tables (libecal.so exports them; loading needs no GPU)
+    so = os.path.join(O.ROOT, "eventcalib_amd", "libecal.so")
+    E = ctypes.CDLL(so)
+    E.ecal_ref_bucket_step.argtypes = [ctypes.c_int]
+    E.ecal_ref_bucket_step.restype = ctypes.c_uint64
+    E.ecal_ref_pixel_hash.argtypes = [ctypes.c_double, ctypes.c_double]
+    E.ecal_ref_pixel_hash.restype = ctypes.c_uint64
+    assert [E.ecal_ref_bucket_step(e) for e in range(28)] == [int(v) for v in steps]
+    assert E.ecal_ref_bucket_step(28) == 0
+    for x in vals:
+        for y in vals[:12]:
+            assert E.ecal_ref_pixel_hash(x, y) == L.oracle_pixel_hash(x, y), (x, y)
