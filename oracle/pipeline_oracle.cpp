@@ -12,8 +12,8 @@
 
 extern "C" {
 int oracle_window_bounds(const uint8_t *rec, uint64_t n, double t0, double t1, uint64_t *lo, uint64_t *hi);
-int oracle_event_frame(const uint8_t *rec, uint64_t lo, uint64_t hi, double *xy_out, uint32_t *n_pos, uint32_t *n_neg,
-                       int32_t *event_point);
+int oracle_event_frame_ref(const uint8_t *rec, uint64_t lo, uint64_t hi, double *xy_out, uint32_t *n_pos, uint32_t *n_neg,
+                           int32_t *event_point);
 int oracle_extract_candidates(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg, double eps,
                               uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters, double radius_thr,
                               uint32_t *info, uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos,
@@ -42,7 +42,7 @@ uint64_t oracle_detect_windows(const uint8_t *rec, uint64_t n, const double *t0,
         pair.resize(2 * m);
         cxyr.resize(3 * m);
         uint32_t np = 0, nn = 0, info[4];
-        oracle_event_frame(rec, lo, hi, xy.data(), &np, &nn, ep.data());
+        oracle_event_frame_ref(rec, lo, hi, xy.data(), &np, &nn, ep.data());   // the reference's containers and order
         oracle_extract_candidates(xy.data(), np, xy.data() + 2 * (std::size_t) np, nn, eps, minpts, cluster_min,
                                   need_clusters, radius_thr, info, pair.data(), cxyr.data(), kp.data(), kn.data(),
                                   rp.data(), rn.data());

@@ -293,3 +293,43 @@ def test_hash_slicer_second_pass_equals_general_slicer(env):
         for pol in range(2):
             o, c = int(a[2][2 * s + pol]), int(a[3][2 * s + pol])
             assert np.array_equal(a[5][o:o + c], b[5][o:o + c]), (s, pol)
+
+
+def test_golden_eventframe_order_fixtures(env):
+    """`.bin` records -> the reference's point order -> DBSCAN labels, against the committed fixtures
+    (tests/golden/eventframe_order_*.npz: real std::unordered_set + the reference's kd-tree, made in the build container)."""
+    import glob
+    import os
+    ctx, pipe, torch = env
+    if ctx.point_order() != "reference":
+        pytest.skip("the fixtures hold the reference's order")
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eventframe_order_*.npz")))
+    assert len(files) >= 4
+    for f in files:
+        g = np.load(f)
+        rec = g["records"]
+        t = rec.reshape(-1, 25)[:, :8].copy().view(np.float64).reshape(-1)
+        b = g["bounds"]
+        t0 = [float(t[lo]) for lo, hi in b]
+        t1 = [float(t[hi - 1]) for lo, hi in b]
+        S = len(b)
+        pipe.set_windows(t0, t1)
+        pipe.run(torch.from_numpy(rec).cuda(), slots=int((b[:, 1] - b[:, 0]).sum()) + 64, eps=float(g["eps"]), minpts=int(g["minpts"]),
+                 detect=False)
+        torch.cuda.synchronize()
+        assert np.array_equal(pipe.win_lo[:S].cpu().numpy(), b[:, 0]) and np.array_equal(pipe.win_hi[:S].cpu().numpy(), b[:, 1]), f
+        assert np.array_equal(pipe.seg_cnt[:2 * S].cpu().numpy(), g["seg_cnt"]), f
+        assert np.array_equal(pipe.n_clusters[:2 * S].cpu().numpy(), g["n_clusters"]), f
+        off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
+        base = pipe.win_base[:S + 1].cpu().numpy().astype(np.int64)
+        xy, lab, ep = pipe.xy.cpu().numpy(), pipe.labels.cpu().numpy(), pipe.event_point.cpu().numpy()
+        po, eo = 0, 0
+        for s in range(S):
+            for k in range(2):
+                o, c = off[2 * s + k], int(g["seg_cnt"][2 * s + k])
+                assert np.array_equal(xy[o:o + c].view(np.uint64), g["xy"][po:po + c].view(np.uint64)), (f, s, k)
+                assert np.array_equal(lab[o:o + c], g["labels"][po:po + c]), (f, s, k)
+                po += c
+            n = int(b[s, 1] - b[s, 0])
+            assert np.array_equal(ep[base[s]:base[s] + n], g["event_point"][eo:eo + n]), (f, s)
+            eo += n

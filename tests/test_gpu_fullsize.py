@@ -94,7 +94,11 @@ def test_partition_property(run):
 
 
 def test_oracle_spot_checks(run):
+    """`.bin`-level parity on a sample of windows: the records of a window -> the reference's point order (real
+    std::unordered_set + EigenMatrixHash, EventFrame.cpp:10-36) -> DBSCAN::Run on the reference's own kd-tree
+    (oracle/_ref, dbscan.h:115-265) == the pipeline's points and labels, bit for bit."""
     ctx, pipe, ev, t0, t1, torch = run
+    assert ctx.point_order() == "reference"
     S = len(t0)
     rng = np.random.default_rng(0)
     pick = np.sort(rng.choice(S, 40, replace=False))
@@ -104,12 +108,13 @@ def test_oracle_spot_checks(run):
     cnt = pipe.seg_cnt[:2 * S].cpu().numpy().astype(np.int64)
     for s in pick:
         rec = ev[25 * lo[s]: 25 * hi[s]].cpu().numpy()
-        pos, neg, ep = O.event_frame(rec, 0, hi[s] - lo[s])
+        pos, neg, ep = O.event_frame(rec, 0, hi[s] - lo[s], "reference")
+        assert np.array_equal(pipe.event_point[pipe.win_base[s]:pipe.win_base[s] + (hi[s] - lo[s])].cpu().numpy(), ep)
         for k, pts in ((0, pos), (1, neg)):
             o, n = off[2 * s + k], cnt[2 * s + k]
             assert n == pts.shape[0]
             assert np.array_equal(pipe.xy[o:o + n].cpu().numpy(), pts)
-            rc, lab, nc = O.dbscan(pts, 4.0, 2)
+            rc, lab, nc = O.dbscan(pts, 4.0, 2, kdapi=O.have_ref_kdtree())
             assert np.array_equal(pipe.labels[o:o + n].cpu().numpy(), lab)
 
 

@@ -58,6 +58,6 @@ def test_synthetic_window_gives_candidates():
     t, _, _ = SS.unpack_records(buf)
     rec = buf.numpy()
     lo, hi = O.window_bounds(rec, float(t[0]), float(t[0]) + 1.5e-3)
-    pos, neg, _ = O.event_frame(rec, lo, hi)
+    pos, neg, _ = O.event_frame(rec, lo, hi, "reference")
     out = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
     assert out["status"] == 0 and out["n"] >= 30

@@ -129,3 +129,29 @@ def test_hash_restatement_and_bucket_steps_match_libstdcxx():
     for x in vals:
         for y in vals[:12]:
             assert E.ecal_ref_pixel_hash(x, y) == L.oracle_pixel_hash(x, y), (x, y)
+
+
+def test_golden_eventframe_order_fixtures():
+    """tests/golden/eventframe_order_*.npz (made by make_eventframe_golden.py on g++ 11.4's libstdc++ with the reference's
+    kd-tree): the oracle on this box — real container and restated rules — reproduces points, event map and labels."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eventframe_order_*.npz")))
+    assert len(files) >= 4
+    for f in files:
+        g = np.load(f)
+        rec, eps, minpts = g["records"], float(g["eps"]), int(g["minpts"])
+        po, eo, seg = 0, 0, 0
+        for lo, hi in g["bounds"]:
+            for order in ("reference", "model"):
+                pos, neg, ep = O.event_frame(rec, int(lo), int(hi), order)
+                assert (pos.shape[0], neg.shape[0]) == tuple(g["seg_cnt"][seg:seg + 2]), f
+                assert np.array_equal(np.concatenate([pos, neg]).view(np.uint64), g["xy"][po:po + len(pos) + len(neg)].view(np.uint64)), f
+                assert np.array_equal(ep, g["event_point"][eo:eo + hi - lo]), f
+            for pts in (pos, neg):
+                if pts.shape[0]:
+                    rc, lab, nc = O.dbscan(pts, eps, minpts)
+                    assert np.array_equal(lab, g["labels"][po:po + pts.shape[0]]) and nc == g["n_clusters"][seg], f
+                po += pts.shape[0]
+                seg += 1
+            eo += hi - lo

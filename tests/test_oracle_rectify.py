@@ -15,7 +15,7 @@ def _window(seed=3, n=6000, rate=4.0e6):
     t, _, _ = SS.unpack_records(buf)
     t0, t1 = float(t[0]), float(t[-1])
     lo, hi = O.window_bounds(rec, t0, t1)
-    pos, neg, _ = O.event_frame(rec, lo, hi)
+    pos, neg, _ = O.event_frame(rec, lo, hi, "reference")
     ex = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
     return 0.5 * (t0 + t1), pos, neg, ex
 
