@@ -443,6 +443,9 @@ __global__ __launch_bounds__(T) void slice_lds_kernel(const uint8_t *__restrict_
 // pixels; -0.0 == +0.0 as operator== has it): an event is one 31-bit key (x 15 | y 15 | polarity), the workspace is
 // 24 KB of LDS instead of 58 KB, so a CU holds six windows instead of two — the kernel is a chain of dependent LDS
 // operations (latency bound), throughput follows the workgroups in flight.  Anything else goes to the to-do list.
+#ifndef ECAL_RO_STOP
+#define ECAL_RO_STOP 0   // debug builds: leave the reference-order block of slice_hash_window after phase k
+#endif
 #ifndef ECAL_SL_STOP
 #define ECAL_SL_STOP 0   // debug builds: leave slice_pixel_kernel after phase k (tools/px_stop_probe.sh)
 #endif
@@ -643,14 +646,15 @@ struct PixHash {
     //   cur u16[SLOTS]     list position of key uid (positive keys first)
     //   fa u32[FA_CAP]     first sequence position per bucket, the + table then the - table; before the epochs the batch
     //                      counts of the rank scan, during the early epochs also the early keys' hashes (u64[2][128])
-    //   keep u32[2][SLOTS / 32 + 1]   kept keys by list position, and the running counts of its words
+    //   keep u32[2][SLOTS / 32 + 1] (+ 16)   kept keys by list position, and the running counts of its words
     static constexpr uint32_t FA_CAP = LOGC == 11 ? 2400u : 7456u;   // B(+) + B(-): 1109 + 1109 / 5087 + 2357 (+ slack)
     static constexpr size_t w_off = 0;
     static constexpr size_t region_off = w_off + 4 * SLOTS;
     static constexpr size_t cur_off = region_off + 2 * SLOTS;
     static constexpr size_t fa_off = cur_off + 2 * SLOTS;
     static constexpr size_t keep_off = fa_off + 4 * FA_CAP;
-    static constexpr size_t ored_off = keep_off + 8 * (SLOTS / 32 + 1);
+    static constexpr size_t bcnt_off = keep_off + 8 * (SLOTS / 32 + 1) + 64;   // u32[PER * 4 + 1]: batch counts of the rank scan
+    static constexpr size_t ored_off = bcnt_off + 4 * (SLOTS / 64 + 4);
     static constexpr size_t obytes = ored_off + 16 * 8 + 16;
     static constexpr uint32_t HTAB_WORD = 1024;   // early hashes at fa[1024 ..) (the early epochs' own tables end at fa[256))
 };
@@ -756,6 +760,93 @@ __device__ __forceinline__ void early_epochs(const uint64_t *hk, uint32_t m, uin
             const uint32_t ex = inc - c0 - c1;
             W[2u * lane] = (ex << 16) | c0;
             W[2u * lane + 1u] = ((ex + c0) << 16) | c1;
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            if (u < n_e) region[(W[f[i]] >> 16) + sl[i]] = (uint16_t) q[i];
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            if (u < n_e) {
+                const uint32_t w = W[f[i]], b0 = w >> 16, c = w & 0xFFFFu;
+                uint32_t within = 0;
+                for (uint32_t t = 0; t < c; t++) within += ((uint32_t) region[b0 + t] < q[i]) ? 1u : 0u;
+                cur[i] = n_e - 1u - (b0 + within);
+            }
+        }
+        wave_sync_lds();
+        n_prev = n_e;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+        if (lane + 64u * i < m_e) cur_out[lane + 64u * i] = (uint16_t) cur[i];
+}
+
+// Inclusive add-scan over the 64 lanes in registers (DPP row shifts + row broadcasts, the gfx9 sequence): seven VALU
+// instructions and no LDS round trip; __shfl_up costs a ds_bpermute per step.
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
+    uint32_t t = x;
+    t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x113, 0xF, 0xF, false);   // row_shr:3
+    t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x114, 0xF, 0xE, false);   // row_shr:4, banks 1-3
+    t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x118, 0xF, 0xC, false);   // row_shr:8, banks 2-3
+    t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    t += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return t;
+}
+
+// The early epochs (13, 29, 59, 127 buckets) of one polarity's set, run by ONE wave (no workgroup barrier): keys
+// u < min(m, 127), at most two per lane.  In: fa[u] = the key's four bucket numbers packed 4 + 5 + 6 + 7 bits (the table
+// itself takes that place afterwards).  W / region: 128-entry scratch of this polarity.  Out: cur_out[u] = list position
+// after the last early epoch.
+__device__ __forceinline__ void early_epochs_packed(uint32_t m, uint32_t *fa, uint32_t *W, uint16_t *region, uint16_t *cur_out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t m_e = m < 127u ? m : 127u;
+    uint32_t bw[2], cur[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 2; i++) bw[i] = (lane + 64u * i < m_e) ? fa[lane + 64u * i] : 0u;
+    wave_sync_lds();
+    uint32_t n_prev = 0;
+    for (int e = 0; e < 4 && n_prev < m_e; e++) {
+        const uint32_t B = (uint32_t) ref_bucket_step(e);
+        const uint32_t n_e = m_e < B ? m_e : B;
+        const uint32_t sh = e == 0 ? 0u : (e == 1 ? 4u : (e == 2 ? 9u : 15u)), mask = (16u << e) - 1u;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (lane + 64u * i < B) fa[lane + 64u * i] = 0xFFFFFFFFu;   // (the other polarity's tables may start right behind)
+            if (lane + 64u * i < m_e) W[lane + 64u * i] = 0u;
+        }
+        wave_sync_lds();
+        uint32_t b[2], q[2], f[2], sl[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            q[i] = u < n_prev ? cur[i] : u;
+            b[i] = (bw[i] >> sh) & mask;
+            if (u < n_e) atomicMin(&fa[b[i]], q[i]);
+        }
+        wave_sync_lds();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const uint32_t u = lane + 64u * i;
+            f[i] = 0;
+            sl[i] = 0;
+            if (u < n_e) {
+                f[i] = fa[b[i]];
+                sl[i] = atomicAdd(&W[f[i]], 1u);
+            }
+        }
+        wave_sync_lds();
+        {   // exclusive scan of the counts over the positions 2 lane, 2 lane + 1
+            const uint32_t c0 = 2u * lane < n_e ? W[2u * lane] : 0u, c1 = 2u * lane + 1u < n_e ? W[2u * lane + 1u] : 0u;
+            const uint32_t ex = wave_incl_scan_dpp(c0 + c1) - c0 - c1;
+            if (2u * lane < n_e) W[2u * lane] = (ex << 16) | c0;
+            if (2u * lane + 1u < n_e) W[2u * lane + 1u] = ((ex + c0) << 16) | c1;
         }
         wave_sync_lds();
 #pragma unroll
@@ -938,8 +1029,14 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
     if (ECAL_SL_STOP == 3) return;
     if constexpr (REFORDER) {
         // ---- the reference's element order (slice_order.hpp; EventFrame.cpp:12-13,34-35) ----
-        constexpr int EARLY = 4;                       // epochs run by one wave per polarity (keys u < 127)
+        // Keys = first occurrences (before the cancellation).  Per key one word  meta = first | erased << 12 | polarity << 13
+        // | key << 14 | rank << 16  and its hash reduced modulo the product of the block epochs' bucket counts (one word per
+        // three epochs: bucket = residue % B is then ONE exact fp64 step per epoch).
+        constexpr int EARLY = 4;                       // epochs 13, 29, 59, 127: one wave per polarity, no workgroup barrier
         constexpr uint32_t N_EARLY = 127u;
+        constexpr int NRES = LOGC == 11 ? 1 : 2;       // residues: mod 257 * 541 * 1109 (epochs 4 - 6), mod 2357 * 5087 (7, 8)
+        constexpr double M0 = 257.0 * 541.0 * 1109.0, M1 = 2357.0 * 5087.0;
+        constexpr uint32_t SP = PXH_SLOTS / T;         // sequence positions per thread in the scan
         uint32_t *const W = reinterpret_cast<uint32_t *>(smem + L::w_off);
         uint16_t *const region = reinterpret_cast<uint16_t *>(smem + L::region_off);
         uint16_t *const cur = reinterpret_cast<uint16_t *>(smem + L::cur_off);
@@ -952,16 +1049,19 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         const uint32_t lane = tid & 63u, wave = tid >> 6;
         // d'. rank of every key among its polarity's keys, in event order = the order in which the set saw them
         constexpr uint32_t NBATCH = (uint32_t) PXH_PER * (T / 64);
-        uint32_t *const bcnt = fa;
-        uint32_t urank[PXH_PER];
+        uint32_t *const bcnt = reinterpret_cast<uint32_t *>(smem + L::bcnt_off);
+        uint32_t meta[PXH_PER];
 #pragma unroll
         for (int j = 0; j < PXH_PER; j++) {
             const uint32_t k = tid + j * T;
             const bool isu = k < n && (firstk[j] & 0x7FFFu) == k;
             const unsigned long long mP = __ballot(isu && vp[j] != 0), mN = __ballot(isu && vp[j] == 0);
             const unsigned long long lower = (1ull << lane) - 1ull;
-            urank[j] = (uint32_t) __popcll((vp[j] ? mP : mN) & lower);
+            const uint32_t below = (uint32_t) __popcll((vp[j] ? mP : mN) & lower);
             if (lane == 0) bcnt[j * (T / 64) + wave] = (uint32_t) __popcll(mP) | ((uint32_t) __popcll(mN) << 16);
+            meta[j] = k < n ? ((firstk[j] & 0xFFFu) | ((firstk[j] & 0x8000u) ? 0x1000u : 0u) | (vp[j] ? 0x2000u : 0u) |
+                               (isu ? 0x4000u : 0u) | (below << 16))
+                            : 0x1000u;   // (no event: "erased", not a key)
         }
         __syncthreads();
         if (tid < 64u) {
@@ -980,81 +1080,316 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         const int EP = mP ? ref_epochs(mP) : 0, EN = mN ? ref_epochs(mN) : 0;
         {
             const uint32_t need = (EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u) + (EN ? (uint32_t) ref_bucket_step(EN - 1) : 0u);
-            if (need > L::FA_CAP || EP > 12 || EN > 12) {   // more keys than the bucket tables hold: next tier
+            if (need > L::FA_CAP || EP > (NRES == 1 ? 7 : 9) || EN > (NRES == 1 ? 7 : 9)) {   // more keys than the bucket tables hold: next tier
                 if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
                 return;
             }
         }
-        uint64_t hk[PXH_PER];
+        if constexpr (LOGC == 11) {
+            // ---- first pass: one wave PAIR per polarity; early epochs by one wave each, block epochs by the pair ----
+            constexpr int NI = 9;    // 128 NI >= 1109 keys per polarity
+            static_assert(16 * NI <= (int) (2 * (PXH_SLOTS / 32 + 1) + 16), "bitmap room");
+            const uint32_t faN = EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u;   // the - set's bucket table starts here
+            {
+                constexpr double ME = 13.0 * 29.0 * 59.0 * 127.0;
+                ModB m0, mE;
+                m0.b = M0;
+                m0.inv = (1.0 / M0) * (1.0 - 0x1p-50);
+                mE.b = ME;
+                mE.inv = (1.0 / ME) * (1.0 - 0x1p-50);
+                const ModB e0 = mod_for_epoch(0), e1 = mod_for_epoch(1), e2 = mod_for_epoch(2), e3 = mod_for_epoch(3),
+                           e4 = mod_for_epoch(4), e5 = mod_for_epoch(5), e6 = mod_for_epoch(6);
 #pragma unroll
-        for (int j = 0; j < PXH_PER; j++) {
-            const uint32_t k = tid + j * T;
-            urank[j] += (vp[j] ? (bcnt[j * (T / 64) + wave] & 0xFFFFu) : (bcnt[j * (T / 64) + wave] >> 16));
-            hk[j] = 0;
-            if (k < n && (firstk[j] & 0x7FFFu) == k) {
-                hk[j] = ref_hash_combine2(HASH_INT.v[pix[j] >> 10], HASH_INT.v[pix[j] & 0x3FFu]);   // utility.hpp:38-51
+                for (int j = 0; j < PXH_PER; j++) {
+                    const uint32_t ex = bcnt[j * (T / 64) + wave];
+                    meta[j] += ((meta[j] & 0x2000u) ? (ex & 0xFFFFu) : (ex >> 16)) << 16;
+                    if (meta[j] & 0x4000u) {
+                        const uint64_t h = ref_hash_combine2(HASH_INT.v[pix[j] >> 10], HASH_INT.v[pix[j] & 0x3FFu]);   // utility.hpp:38-51
+                        const uint32_t rank = meta[j] >> 16;
+                        const bool pos_ = (meta[j] & 0x2000u) != 0;
+                        // h % M in two exact fp64 steps: h = d2 2^48 + d1 2^24 + d0, d2 < 2^16 < M; then residue % B, one step each
+                        const double d2 = (double) (uint32_t) (h >> 48), d1 = (double) (uint32_t) ((h >> 24) & 0xFFFFFFu),
+                                     d0 = (double) (uint32_t) (h & 0xFFFFFFu);
+                        const double r0 = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), m0), 0x1p24, d0), m0);
+                        W[(pos_ ? 0u : mP) + rank] = (uint32_t) mod_step(r0, e4) | ((uint32_t) mod_step(r0, e5) << 9) |
+                                                     ((uint32_t) mod_step(r0, e6) << 19) | ((meta[j] & 0x1000u) ? 0x80000000u : 0u);
+                        if (rank < N_EARLY) {
+                            const double rE = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), mE), 0x1p24, d0), mE);
+                            fa[(pos_ ? 0u : faN) + rank] = (uint32_t) mod_step(rE, e0) | ((uint32_t) mod_step(rE, e1) << 4) |
+                                                           ((uint32_t) mod_step(rE, e2) << 9) | ((uint32_t) mod_step(rE, e3) << 15);
+                        }
+                    }
+                }
             }
-        }
-        __syncthreads();   // bcnt (= fa) is dead
+            if (ECAL_RO_STOP == 2) return;
+            // Wave pair 0 (waves 0, 1) takes the + set, pair 1 the - set; thread l128 = 0 .. 127 of a pair owns the keys
+            // u = l128 + 128 i: packed bucket numbers and list position stay in its registers from here on.
+            const uint32_t pol = __builtin_amdgcn_readfirstlane(wave >> 1), sub = __builtin_amdgcn_readfirstlane(wave & 1u);
+            const uint32_t l128 = lane + 64u * sub;
+            const uint32_t m = pol == 0u ? mP : mN;
+            const int E = pol == 0u ? EP : EN;
+            const uint32_t uoff = pol == 0u ? 0u : mP;
+            uint32_t *const Wp = W + uoff, *const fap = fa + (pol == 0u ? 0u : faN);
+            uint16_t *const regp = region + uoff, *const curp = cur + uoff;
+            constexpr uint32_t KW = 4u * NI;   // bitmap words per polarity (128 NI list positions)
+            uint32_t *const kW = keepW + pol * KW, *const kPre = keepW + 2u * KW + pol * KW;   // bitmaps, their running counts
+            if (tid == 0) ored[10] = 0u;
+            __syncthreads();
+            uint32_t bk[NI], cu[NI];
 #pragma unroll
-        for (int j = 0; j < PXH_PER; j++) {
-            const uint32_t k = tid + j * T;
-            if (k < n && (firstk[j] & 0x7FFFu) == k && urank[j] < N_EARLY) htab[(vp[j] ? 0u : 128u) + urank[j]] = hk[j];
+            for (int i = 0; i < NI; i++) {
+                const uint32_t u = l128 + 128u * i;
+                bk[i] = u < m ? Wp[u] : 0u;
+                cu[i] = 0u;
+            }
+            if (l128 < KW) kW[l128] = 0u;
+            __syncthreads();
+            if (sub == 0u && m) early_epochs_packed(m, fap, Wp, regp, curp);
+            __syncthreads();
+            if (ECAL_RO_STOP == 3) return;
+            if (l128 < (m < 127u ? m : 127u)) cu[0] = curp[l128];
+            const int EMAX = EP > EN ? EP : EN;
+            if (E > 4) {
+                for (uint32_t b = l128; b < 257u; b += 128u) fap[b] = 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            for (int e = 4; e < EMAX; e++) {
+                const bool on = e < E;
+                const uint32_t B = (uint32_t) ref_bucket_step(e), Bprev = (uint32_t) ref_bucket_step(e - 1);
+                const uint32_t n_e = on ? (m < B ? m : B) : 0u;
+                const uint32_t sh = e == 4 ? 0u : (e == 5 ? 9u : 19u), bmask = e == 4 ? 0x1FFu : (e == 5 ? 0x3FFu : 0x7FFu);
+                const uint32_t per = (n_e + 127u) >> 7;   // sequence positions per thread in the scan
+                uint32_t fq[NI];                          // first position of the key's bucket
+                // first sequence position per bucket  (and W, last read before the barrier that ended the previous epoch, is cleared)
+                for (uint32_t q = l128; q < n_e; q += 128u) Wp[q] = 0u;
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const uint32_t u = l128 + 128u * i;
+                    if (128u * i >= n_e) break;
+                    if (u < n_e) atomicMin(&fap[(bk[i] >> sh) & bmask], u < Bprev ? cu[i] : u);
+                }
+                __syncthreads();
+                // members per bucket, counted at the bucket's first position
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const uint32_t u = l128 + 128u * i;
+                    fq[i] = 0u;
+                    if (128u * i >= n_e) break;
+                    if (u < n_e) {
+                        fq[i] = fap[(bk[i] >> sh) & bmask];
+                        atomicAdd(&Wp[fq[i]], 1u);
+                    }
+                }
+                __syncthreads();
+                {   // exclusive scan of the counts: thread l128 holds the positions [l128 per, l128 per + per); the second
+                    // wave's part still lacks the first wave's total (ored[]), added by the readers
+                    uint32_t c[NI], sum = 0, big = 0;
+#pragma unroll
+                    for (int t = 0; t < NI; t++) {
+                        c[t] = 0u;
+                        if ((uint32_t) t < per && l128 * per + t < n_e) c[t] = Wp[l128 * per + t];
+                        sum += c[t];
+                        big |= c[t];
+                    }
+                    if (__any(big > 1023u)) ored[10] = 1u;   // a bucket of > 1023 keys does not fit the packed word: next tier
+                    const uint32_t inc = wave_incl_scan_dpp(sum);
+                    if (lane == 63u) ored[wave] = inc;
+                    uint32_t ex = inc - sum;
+#pragma unroll
+                    for (int t = 0; t < NI; t++) {
+                        if ((uint32_t) t < per && l128 * per + t < n_e) Wp[l128 * per + t] = (ex << 20) | ((c[t] & 0x3FFu) << 10);
+                        ex += c[t];
+                    }
+                    if (e + 1 < E) {   // the bucket table is dead (fq[] holds what was read from it): set it up for the next epoch
+                        const uint32_t Bn = (uint32_t) ref_bucket_step(e + 1);
+                        for (uint32_t b = l128; b < Bn; b += 128u) fap[b] = 0xFFFFFFFFu;
+                    }
+                }
+                __syncthreads();
+                const uint32_t carry_from = 64u * per, carry = __builtin_amdgcn_readfirstlane(ored[pol * 2u]);
+                // the members of a shared bucket take the slots of its run in arrival order ...
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const uint32_t u = l128 + 128u * i;
+                    if (128u * i >= n_e) break;
+                    if (u < n_e && ((Wp[fq[i]] >> 10) & 0x3FFu) > 1u) {   // (a key alone in its bucket needs no slot)
+                        const uint32_t w = atomicAdd(&Wp[fq[i]], 1u);
+                        regp[(w >> 20) + (fq[i] >= carry_from ? carry : 0u) + (w & 0x3FFu)] = (uint16_t) (u < Bprev ? cu[i] : u);
+                    }
+                }
+                __syncthreads();
+                // ... and rank themselves by sequence position: new list position = n - 1 - (run start + members before it)
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const uint32_t u = l128 + 128u * i;
+                    if (128u * i >= n_e) break;
+                    if (u < n_e) {
+                        const uint32_t w = Wp[fq[i]], b0 = (w >> 20) + (fq[i] >= carry_from ? carry : 0u), cnt = (w >> 10) & 0x3FFu;
+                        uint32_t within = 0;
+                        if (cnt > 1u) {
+                            const uint32_t q = u < Bprev ? cu[i] : u;
+                            for (uint32_t t = 0; t < cnt; t++) within += ((uint32_t) regp[b0 + t] < q) ? 1u : 0u;
+                        }
+                        cu[i] = n_e - 1u - (b0 + within);
+                    }
+                }
+                __syncthreads();
+            }
+            if (ECAL_RO_STOP == 4) return;
+            if (ored[10]) {
+                if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+                return;
+            }
+            // the erased keys drop out (EventFrame.cpp:24-32): index of a kept key = kept keys in front of it in the list
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const uint32_t u = l128 + 128u * i;
+                if (u < m && !(bk[i] >> 31)) atomicOr(&kW[cu[i] >> 5], 1u << (cu[i] & 31u));
+            }
+            __syncthreads();
+            if (sub == 0u) {
+                const uint32_t c = lane < KW ? (uint32_t) __popc(kW[lane]) : 0u;
+                const uint32_t inc = wave_incl_scan_dpp(c);
+                if (lane < KW) kPre[lane] = inc - c;
+                if (lane == 63u) ored[8u + pol] = inc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const uint32_t u = l128 + 128u * i;
+                if (u < m && !(bk[i] >> 31))
+                    curp[u] = (uint16_t) (kPre[cu[i] >> 5] + (uint32_t) __popc(kW[cu[i] >> 5] & ((1u << (cu[i] & 31u)) - 1u)));
+            }
+            __syncthreads();
+            const uint32_t nP = mP ? __builtin_amdgcn_readfirstlane(ored[8]) : 0u, nN = mN ? __builtin_amdgcn_readfirstlane(ored[9]) : 0u;
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) {
+                if ((meta[j] & 0x5000u) == 0x4000u)   // a key, and not erased
+                    posE[meta[j] & 0xFFFu] = cur[((meta[j] & 0x2000u) ? 0u : mP) + (meta[j] >> 16)];
+            }
+            __syncthreads();
+            double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
+            int32_t *ep = event_point + base;
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) {
+                const uint32_t k = tid + j * T;
+                if (k < n) {
+                    if (meta[j] & 0x1000u) {
+                        ep[k] = -1;
+                    } else {
+                        const uint32_t at = posE[meta[j] & 0xFFFu];
+                        ep[k] = (int32_t) at;
+                        if (meta[j] & 0x4000u) {
+                            double2 v;
+                            v.x = (double) (pix[j] >> 10);
+                            v.y = (double) (pix[j] & 0x3FFu);
+                            out2[(meta[j] & 0x2000u) ? at : nP + at] = v;
+                        }
+                    }
+                }
+            }
+            if (tid == 0) {
+                seg_off[2 * s] = base;
+                seg_cnt[2 * s] = nP;
+                seg_off[2 * s + 1] = base + nP;
+                seg_cnt[2 * s + 1] = nN;
+            }
+            return;
+        }
+        // ---- second pass (up to 4095 events): the epochs as workgroup-wide phases ----
+        // buckets of the block epochs, packed: epochs 4, 5, 6 (257, 541, 1109 buckets: 9 + 10 + 11 bits) in bk[0], epochs
+        // 7, 8 (2357, 5087: 12 + 13 bits) in bk[1] — the divisions happen once, here, not in the epoch loop
+        uint32_t bk[NRES][PXH_PER];
+        {
+            ModB m0, m1;
+            m0.b = M0;
+            m0.inv = (1.0 / M0) * (1.0 - 0x1p-50);
+            m1.b = M1;
+            m1.inv = (1.0 / M1) * (1.0 - 0x1p-50);
+            const ModB e4 = mod_for_epoch(4), e5 = mod_for_epoch(5), e6 = mod_for_epoch(6), e7 = mod_for_epoch(7), e8 = mod_for_epoch(8);
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) {
+                const uint32_t ex = bcnt[j * (T / 64) + wave];
+                meta[j] += ((meta[j] & 0x2000u) ? (ex & 0xFFFFu) : (ex >> 16)) << 16;
+                bk[0][j] = 0;
+                if (NRES > 1) bk[NRES - 1][j] = 0;
+                if (meta[j] & 0x4000u) {
+                    const uint64_t h = ref_hash_combine2(HASH_INT.v[pix[j] >> 10], HASH_INT.v[pix[j] & 0x3FFu]);   // utility.hpp:38-51
+                    const uint32_t rank = meta[j] >> 16;
+                    if (rank < N_EARLY) htab[((meta[j] & 0x2000u) ? 0u : 128u) + rank] = h;
+                    // h % M in two exact fp64 steps: h = d2 2^48 + d1 2^24 + d0, d2 < 2^16 < M; then residue % B, one step each
+                    const double d2 = (double) (uint32_t) (h >> 48), d1 = (double) (uint32_t) ((h >> 24) & 0xFFFFFFu),
+                                 d0 = (double) (uint32_t) (h & 0xFFFFFFu);
+                    const double r0 = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), m0), 0x1p24, d0), m0);
+                    bk[0][j] = (uint32_t) mod_step(r0, e4) | ((uint32_t) mod_step(r0, e5) << 9) | ((uint32_t) mod_step(r0, e6) << 19);
+                    if (NRES > 1) {
+                        const double r1 = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), m1), 0x1p24, d0), m1);
+                        bk[NRES - 1][j] = (uint32_t) mod_step(r1, e7) | ((uint32_t) mod_step(r1, e8) << 12);
+                    }
+                }
+            }
         }
         {
             uint4 *k4 = reinterpret_cast<uint4 *>(keepW);
             for (uint32_t q = tid; q < (PXH_SLOTS / 32u + 1u + 3u) / 4u; q += T) k4[q] = make_uint4(0u, 0u, 0u, 0u);
         }
+        if (ECAL_RO_STOP == 2) return;
         __syncthreads();
         // early epochs: wave 0 the positive set, wave 1 the negative one; key uid = rank (+) / mP + rank (-)
         if (wave == 0 && mP) early_epochs(htab, mP, fa, W, region, cur);
         if (wave == 1 && mN) early_epochs(htab + 128, mN, fa + 128, W + 128, region + 128, cur + mP);
         __syncthreads();
+        if (ECAL_RO_STOP == 3) return;
         // block epochs
         const int EMAX = EP > EN ? EP : EN;
+        if (EMAX > EARLY) {
+            const uint32_t B = (uint32_t) ref_bucket_step(EARLY);
+            const uint32_t words = (EP > EARLY ? B : 0u) + (EN > EARLY ? B : 0u);
+            for (uint32_t q = tid; q < words; q += T) fa[q] = 0xFFFFFFFFu;
+        }
         for (int e = EARLY; e < EMAX; e++) {
             const uint32_t B = (uint32_t) ref_bucket_step(e), Bprev = (uint32_t) ref_bucket_step(e - 1);
-            const ModB md = mod_for_epoch(e);
+            const uint32_t bsh = e == 4 ? 0u : (e == 5 ? 9u : (e == 6 ? 19u : (e == 7 ? 0u : 12u)));
+            const uint32_t bmask = e == 4 ? 0x1FFu : (e == 5 ? 0x3FFu : (e == 6 ? 0x7FFu : (e == 7 ? 0xFFFu : 0x1FFFu)));
             const bool onP = e < EP, onN = e < EN;
             const uint32_t nP_e = onP ? (mP < B ? mP : B) : 0u, nN_e = onN ? (mN < B ? mN : B) : 0u;
             const uint32_t faN = onP ? B : 0u;   // offset of the - table
-            {
-                const uint32_t words = faN + (onN ? B : 0u);
-                for (uint32_t q = tid; q < words; q += T) fa[q] = 0xFFFFFFFFu;
+            uint32_t st[PXH_PER];                // bucket, then  first position << 12 | slot
+            unsigned act = 0;
+            // (keeps the compiler from hoisting every slot's rank / offset / LDS address out of the epoch loop: that
+            // costs ~40 VGPRs = two waves per SIMD, to save a handful of shifts per epoch)
+#pragma unroll
+            for (int j = 0; j < PXH_PER; j++) asm volatile("" : "+v"(meta[j]));
+            {   // (W was last read before the barrier that ended the previous epoch)
                 uint4 *w4 = reinterpret_cast<uint4 *>(W);
                 for (uint32_t q = tid; q < PXH_SLOTS / 4u; q += T) w4[q] = make_uint4(0u, 0u, 0u, 0u);
             }
-            __syncthreads();
-            uint32_t bq[PXH_PER], fs[PXH_PER];   // bucket << 12 | sequence position ; first position << 12 | slot
-            unsigned act = 0;
 #pragma unroll
             for (int j = 0; j < PXH_PER; j++) {
-                const uint32_t k = tid + j * T;
-                const bool isu = k < n && (firstk[j] & 0x7FFFu) == k;
-                const bool on = isu && (vp[j] ? (onP && urank[j] < nP_e) : (onN && urank[j] < nN_e));
-                bq[j] = 0;
+                const uint32_t rank = meta[j] >> 16;
+                const bool pos_ = (meta[j] & 0x2000u) != 0;
+                const bool on = (meta[j] & 0x4000u) && (pos_ ? rank < nP_e : rank < nN_e);
+                st[j] = 0;
                 if (on) {
                     act |= 1u << j;
-                    const uint32_t uid = (vp[j] ? 0u : mP) + urank[j];
-                    const uint32_t q = urank[j] < Bprev ? (uint32_t) cur[uid] : urank[j];
-                    const uint32_t b = (vp[j] ? 0u : faN) + mod_hash(hk[j], md);
-                    bq[j] = (b << 12) | q;
+                    const uint32_t q = rank < Bprev ? (uint32_t) cur[(pos_ ? 0u : mP) + rank] : rank;
+                    const uint32_t r = (NRES > 1 && e >= 7) ? bk[NRES - 1][j] : bk[0][j];
+                    const uint32_t b = (pos_ ? 0u : faN) + ((r >> bsh) & bmask);
+                    st[j] = b;
                     atomicMin(&fa[b], q);
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < PXH_PER; j++) {
-                fs[j] = 0;
                 if (act & (1u << j)) {
-                    const uint32_t f = fa[bq[j] >> 12];
-                    const uint32_t sl = atomicAdd(&W[(vp[j] ? 0u : mP) + f], 1u);
-                    fs[j] = (f << 12) | sl;
+                    const uint32_t f = fa[st[j]];
+                    const uint32_t sl = atomicAdd(&W[((meta[j] & 0x2000u) ? 0u : mP) + f], 1u);
+                    st[j] = (f << 12) | sl;
                 }
             }
             __syncthreads();
-            {   // exclusive scan of the counts over the sequence positions (the - positions restart at mP)
-                constexpr uint32_t SP = PXH_SLOTS / T;
+            {   // per-wave exclusive scan of the counts over the sequence positions; the wave totals go to ored[]
                 uint32_t c[SP], sum = 0;
 #pragma unroll
                 for (uint32_t i = 0; i < SP; i++) {
@@ -1068,48 +1403,67 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     if (lane >= (uint32_t) d) inc += o;
                 }
                 if (lane == 63u) ored[wave] = inc;
-                __syncthreads();
-                uint32_t pre = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < (uint32_t) (T / 64); w++) pre += (w < wave) ? ored[w] : 0u;
-                uint32_t ex = pre + inc - sum;
+                uint32_t ex = inc - sum;
 #pragma unroll
                 for (uint32_t i = 0; i < SP; i++) {
-                    const uint32_t qpos = tid * SP + i;
-                    const uint32_t rel = qpos >= mP ? ex - nP_e : ex;
-                    W[qpos] = (rel << 16) | c[i];
+                    W[tid * SP + i] = (ex << 16) | c[i];
                     ex += c[i];
                 }
+                if (e + 1 < EMAX) {   // fa is dead: set it up for the next epoch
+                    const uint32_t Bn = (uint32_t) ref_bucket_step(e + 1);
+                    const uint32_t words = (e + 1 < EP ? Bn : 0u) + (e + 1 < EN ? Bn : 0u);
+                    for (uint32_t q = tid; q < words; q += T) fa[q] = 0xFFFFFFFFu;
+                }
             }
             __syncthreads();
+            static_assert(T == 256, "four wave chunks");
+            // positions before wave w's chunk of the scan (uniform values: scalar registers)
+            const uint32_t wp1 = __builtin_amdgcn_readfirstlane(ored[0]), wp2 = wp1 + __builtin_amdgcn_readfirstlane(ored[1]),
+                           wp3 = wp2 + __builtin_amdgcn_readfirstlane(ored[2]);
+            auto chunk_pre = [&](uint32_t at) {
+                const uint32_t w = at / (64u * SP);
+                return w == 0u ? 0u : (w == 1u ? wp1 : (w == 2u ? wp2 : wp3));
+            };
 #pragma unroll
             for (int j = 0; j < PXH_PER; j++) {
                 if (act & (1u << j)) {
-                    const uint32_t off = vp[j] ? 0u : mP;
-                    const uint32_t w = W[off + (fs[j] >> 12)];
-                    region[off + (w >> 16) + (fs[j] & 0xFFFu)] = (uint16_t) (bq[j] & 0xFFFu);
+                    const bool pos_ = (meta[j] & 0x2000u) != 0;
+                    const uint32_t off = pos_ ? 0u : mP, at = off + (st[j] >> 12);
+                    const uint32_t w = W[at];
+                    if ((w & 0xFFFFu) > 1u) {   // (a key alone in its bucket needs no slot)
+                        const uint32_t rank = meta[j] >> 16;
+                        const uint32_t q = rank < Bprev ? (uint32_t) cur[off + rank] : rank;
+                        const uint32_t b0 = (w >> 16) + chunk_pre(at) - (pos_ ? 0u : nP_e);
+                        region[off + b0 + (st[j] & 0xFFFu)] = (uint16_t) q;
+                    }
                 }
             }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < PXH_PER; j++) {
                 if (act & (1u << j)) {
-                    const uint32_t off = vp[j] ? 0u : mP;
-                    const uint32_t w = W[off + (fs[j] >> 12)], b0 = w >> 16, cnt = w & 0xFFFFu, q = bq[j] & 0xFFFu;
+                    const bool pos_ = (meta[j] & 0x2000u) != 0;
+                    const uint32_t off = pos_ ? 0u : mP, at = off + (st[j] >> 12);
+                    const uint32_t w = W[at], cnt = w & 0xFFFFu;
+                    const uint32_t b0 = (w >> 16) + chunk_pre(at) - (pos_ ? 0u : nP_e);
+                    const uint32_t rank = meta[j] >> 16;
                     uint32_t within = 0;
-                    for (uint32_t t = 0; t < cnt; t++) within += ((uint32_t) region[off + b0 + t] < q) ? 1u : 0u;
-                    const uint32_t n_e = vp[j] ? nP_e : nN_e;
-                    cur[off + urank[j]] = (uint16_t) (n_e - 1u - (b0 + within));
+                    if (cnt > 1u) {
+                        const uint32_t q = rank < Bprev ? (uint32_t) cur[off + rank] : rank;
+                        for (uint32_t t = 0; t < cnt; t++) within += ((uint32_t) region[off + b0 + t] < q) ? 1u : 0u;
+                    }
+                    cur[off + rank] = (uint16_t) ((pos_ ? nP_e : nN_e) - 1u - (b0 + within));
                 }
             }
             __syncthreads();
         }
+        if (ECAL_RO_STOP == 4) return;
         // the erased keys drop out (EventFrame.cpp:24-32): index of a kept key = kept keys in front of it in the list
 #pragma unroll
         for (int j = 0; j < PXH_PER; j++) {
-            const uint32_t k = tid + j * T;
-            if (k < n && firstk[j] == k) {   // a key, and not erased
-                const uint32_t at = (vp[j] ? 0u : mP) + (uint32_t) cur[(vp[j] ? 0u : mP) + urank[j]];
+            if ((meta[j] & 0x5000u) == 0x4000u) {   // a key, and not erased
+                const uint32_t off = (meta[j] & 0x2000u) ? 0u : mP;
+                const uint32_t at = off + (uint32_t) cur[off + (meta[j] >> 16)];
                 atomicOr(&keepW[at >> 5], 1u << (at & 31u));
             }
         }
@@ -1132,33 +1486,37 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         }
         __syncthreads();
         auto kept_below = [&](uint32_t at) { return keepPre[at >> 5] + (uint32_t) __popc(keepW[at >> 5] & ((1u << (at & 31u)) - 1u)); };
-        const uint32_t nP = kept_below(mP), nN = kept_below(mP + mN) - nP;
+        const uint32_t nP = __builtin_amdgcn_readfirstlane(kept_below(mP)), nN = __builtin_amdgcn_readfirstlane(kept_below(mP + mN)) - nP;
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) asm volatile("" : "+v"(meta[j]));   // (nothing carried over from the loop above)
 #pragma unroll
         for (int j = 0; j < PXH_PER; j++) {
-            const uint32_t k = tid + j * T;
-            if (k < n && firstk[j] == k) {
-                const uint32_t at = (vp[j] ? 0u : mP) + (uint32_t) cur[(vp[j] ? 0u : mP) + urank[j]];
-                posE[k] = (uint16_t) (kept_below(at) - (vp[j] ? 0u : nP));
+            if ((meta[j] & 0x5000u) == 0x4000u) {
+                const bool pos_ = (meta[j] & 0x2000u) != 0;
+                const uint32_t off = pos_ ? 0u : mP;
+                const uint32_t at = off + (uint32_t) cur[off + (meta[j] >> 16)];
+                posE[meta[j] & 0xFFFu] = (uint16_t) (kept_below(at) - (pos_ ? 0u : nP));
             }
         }
         __syncthreads();
         double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
         int32_t *ep = event_point + base;
 #pragma unroll
+        for (int j = 0; j < PXH_PER; j++) asm volatile("" : "+v"(meta[j]));
+#pragma unroll
         for (int j = 0; j < PXH_PER; j++) {
             const uint32_t k = tid + j * T;
             if (k < n) {
-                const uint32_t r = firstk[j];
-                if (r & 0x8000u) {
+                if (meta[j] & 0x1000u) {
                     ep[k] = -1;
                 } else {
-                    const uint32_t at = posE[r];
+                    const uint32_t at = posE[meta[j] & 0xFFFu];
                     ep[k] = (int32_t) at;
-                    if (r == k) {
+                    if (meta[j] & 0x4000u) {
                         double2 v;
                         v.x = (double) (pix[j] >> 10);
                         v.y = (double) (pix[j] & 0x3FFu);
-                        out2[vp[j] ? at : nP + at] = v;
+                        out2[(meta[j] & 0x2000u) ? at : nP + at] = v;
                     }
                 }
             }
@@ -1242,7 +1600,28 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
 }
 
 // first pass: workgroup b handles window b; what it cannot take goes to todo / todo_count
-template <bool REFORDER>
+#ifndef ECAL_RO_WAVES
+#define ECAL_RO_WAVES 6   // waves per SIMD the reference-order kernel is compiled for (0: the compiler's choice; 6 measured = 5 > 0)
+#endif
+#if ECAL_RO_WAVES
+#define ECAL_RO_ATTR __attribute__((amdgpu_waves_per_eu(ECAL_RO_WAVES, ECAL_RO_WAVES)))
+#else
+#define ECAL_RO_ATTR
+#endif
+__global__ __launch_bounds__(PXH_T) ECAL_RO_ATTR void slice_hash_ref_kernel(const uint8_t *__restrict__ rec,
+                                                           const uint32_t *__restrict__ win_lo,
+                                                           const uint32_t *__restrict__ win_hi,
+                                                           const uint32_t *__restrict__ win_base, uint32_t cap_points,
+                                                           double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
+                                                           uint32_t *__restrict__ seg_cnt,
+                                                           int32_t *__restrict__ event_point, int *overflow,
+                                                           uint32_t *__restrict__ todo,
+                                                           uint32_t *__restrict__ todo_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    slice_hash_window<11, true>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
+                                todo, todo_count);
+}
+
 __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__restrict__ rec,
                                                            const uint32_t *__restrict__ win_lo,
                                                            const uint32_t *__restrict__ win_hi,
@@ -1253,8 +1632,8 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
                                                            uint32_t *__restrict__ todo,
                                                            uint32_t *__restrict__ todo_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    slice_hash_window<11, REFORDER>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
-                          todo, todo_count);
+    slice_hash_window<11, false>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
+                                 todo, todo_count);
 }
 
 // second pass: the workgroups share the list the first pass left (in_list[0 .. *in_count)); windows of up to 4095 events
@@ -1419,10 +1798,10 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         todo_count = cnt;
         if (reforder || !getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)
             if (reforder)
-                hipLaunchKernelGGL(slice_hash_kernel<true>, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
+                hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
                                    d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
             else
-                hipLaunchKernelGGL(slice_hash_kernel<false>, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
+                hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
                                    d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
             // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
             if ((reforder || mx > PixHash<11>::CAP) && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
