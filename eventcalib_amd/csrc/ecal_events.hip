@@ -443,6 +443,20 @@ __global__ __launch_bounds__(T) void slice_lds_kernel(const uint8_t *__restrict_
 // pixels; -0.0 == +0.0 as operator== has it): an event is one 31-bit key (x 15 | y 15 | polarity), the workspace is
 // 24 KB of LDS instead of 58 KB, so a CU holds six windows instead of two — the kernel is a chain of dependent LDS
 // operations (latency bound), throughput follows the workgroups in flight.  Anything else goes to the to-do list.
+#ifdef ECAL_PHASE_PROF
+// debug builds (tools/ro_phase_prof.py): shader-clock cycles between the barriers of the reference-order slicer, thread 0
+__device__ unsigned long long g_ro_cycles[16];
+#define RO_MARK(i)                                                                                  \
+    do {                                                                                            \
+        if (REFORDER && LOGC == 11 && threadIdx.x == 0) {                                           \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime();                          \
+            atomicAdd(&g_ro_cycles[i], now__ - ro_t__);                                             \
+            ro_t__ = now__;                                                                         \
+        }                                                                                           \
+    } while (0)
+#else
+#define RO_MARK(i)
+#endif
 #ifndef ECAL_RO_STOP
 #define ECAL_RO_STOP 0   // debug builds: leave the reference-order block of slice_hash_window after phase k
 #endif
@@ -648,10 +662,13 @@ struct PixHash {
     //                      counts of the rank scan, during the early epochs also the early keys' hashes (u64[2][128])
     //   keep u32[2][SLOTS / 32 + 1] (+ 16)   kept keys by list position, and the running counts of its words
     static constexpr uint32_t FA_CAP = LOGC == 11 ? 2400u : 7456u;   // B(+) + B(-): 1109 + 1109 / 5087 + 2357 (+ slack)
+    // (first pass: the - set's part of W / region / cur starts at the fixed offset NOFF = 1152 = 128 x 9 keys per thread of a
+    // wave pair, so every run of 128 positions a scan touches lies inside the set's own part: no bounds tests)
+    static constexpr uint32_t NOFF = 1152u, PSL = LOGC == 11 ? 2u * NOFF : SLOTS;
     static constexpr size_t w_off = 0;
-    static constexpr size_t region_off = w_off + 4 * SLOTS;
-    static constexpr size_t cur_off = region_off + 2 * SLOTS;
-    static constexpr size_t fa_off = cur_off + 2 * SLOTS;
+    static constexpr size_t region_off = w_off + 4 * PSL;
+    static constexpr size_t cur_off = region_off + 2 * PSL;
+    static constexpr size_t fa_off = cur_off + 2 * PSL;
     static constexpr size_t keep_off = fa_off + 4 * FA_CAP;
     static constexpr size_t bcnt_off = keep_off + 8 * (SLOTS / 32 + 1) + 64;   // u32[PER * 4 + 1]: batch counts of the rank scan
     static constexpr size_t ored_off = bcnt_off + 4 * (SLOTS / 64 + 4);
@@ -699,6 +716,11 @@ __device__ __forceinline__ uint32_t mod_hash(uint64_t h, const ModB m) {
     const double d0 = __builtin_fma((double) (uint32_t) ((h >> 32) & 0xFFu), 0x1p32, (double) (uint32_t) h);
     const double r1 = mod_step(d1, m);
     return (uint32_t) mod_step(__builtin_fma(r1, 0x1p40, d0), m);
+}
+
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight (__syncthreads() drains them)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ void wave_sync_lds() {
@@ -873,6 +895,20 @@ __device__ __forceinline__ void early_epochs_packed(uint32_t m, uint32_t *fa, ui
         if (lane + 64u * i < m_e) cur_out[lane + 64u * i] = (uint16_t) cur[i];
 }
 
+// Bucket numbers of every sensor pixel the first pass can see (x <= 2047, y <= 1023), for the seven bucket counts a set of
+// up to 1109 keys goes through: [pix = x << 10 | y] -> { epochs 4, 5, 6 packed 9 + 10 + 11 bits, epochs 0 .. 3 packed
+// 4 + 5 + 6 + 7 bits }.  Built once per context (16 MB); the slicer then needs ONE 8-byte gather per key instead of the
+// 64-bit hash (two table loads + hash_combine) and seven exact divisions.
+__global__ void bucket_table_kernel(uint2 *__restrict__ tab) {
+    const uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (1u << 21)) return;
+    const uint64_t h = ref_hash_combine2(HASH_INT.v[pix >> 10], HASH_INT.v[pix & 0x3FFu]);   // utility.hpp:38-51
+    uint2 w;
+    w.x = (uint32_t) (h % 257ull) | ((uint32_t) (h % 541ull) << 9) | ((uint32_t) (h % 1109ull) << 19);
+    w.y = (uint32_t) (h % 13ull) | ((uint32_t) (h % 29ull) << 4) | ((uint32_t) (h % 59ull) << 9) | ((uint32_t) (h % 127ull) << 15);
+    tab[pix] = w;
+}
+
 template <int LOGC, bool REFORDER>
 __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uint32_t s, const uint8_t *__restrict__ rec,
                                                   const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
@@ -880,9 +916,12 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                                                   double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
                                                   uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point,
                                                   int *overflow, uint32_t *__restrict__ todo,
-                                                  uint32_t *__restrict__ todo_count) {
+                                                  uint32_t *__restrict__ todo_count, const uint2 *__restrict__ bucket_tab = nullptr) {
     using L = PixHash<LOGC>;
     constexpr int T = PXH_T;
+#ifdef ECAL_PHASE_PROF
+    unsigned long long ro_t__ = __builtin_amdgcn_s_memtime();
+#endif
     constexpr uint32_t PXH_CAP = L::CAP, PXH_SLOTS = L::SLOTS, IDXM = L::CAP, PIXB = L::PIXB;
     constexpr int PXH_PER = L::PER;
     constexpr uint32_t NONE = L::CAP, EMPTY = 0xFFFFFFFFu;
@@ -955,6 +994,14 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         return;
     }
     if (ECAL_SL_STOP == 1) return;
+    // (reference order, first pass) the bucket numbers of every event's pixel are asked for NOW: the gather's latency hides
+    // behind the table phases, whose barriers therefore order LDS traffic only
+    constexpr bool EARLY_GATHER = REFORDER && LOGC == 11;
+    uint2 bw[EARLY_GATHER ? PXH_PER : 1];
+    if constexpr (EARLY_GATHER) {
+#pragma unroll
+        for (int j = 0; j < PXH_PER; j++) bw[j] = (tid + j * T < n) ? bucket_tab[pix[j]] : make_uint2(0u, 0u);
+    }
     // b. every event into its polarity's table: the slot of its pixel ends up holding the smallest event index
     // (The first probe of all of a thread's events is read before any is looked at: the probes of different events are
     // independent, a loop per event would pay one LDS latency after the other; only the ~15 % of events whose first slot
@@ -988,7 +1035,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             }
         }
     }
-    __syncthreads();
+    if constexpr (EARLY_GATHER) lds_barrier(); else __syncthreads();
     if (ECAL_SL_STOP == 2) return;
     // c. representative = first occurrence of the pixel with this polarity, unless the pixel also fired with the other one
     uint32_t repk[PXH_PER];  // representative of event tid + j T (NONE: erased)
@@ -1025,7 +1072,8 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             }
         }
     }
-    __syncthreads();  // the tables are dead from here: pos takes their place
+    if constexpr (EARLY_GATHER) lds_barrier(); else __syncthreads();  // the tables are dead from here: pos takes their place
+    RO_MARK(1);
     if (ECAL_SL_STOP == 3) return;
     if constexpr (REFORDER) {
         // ---- the reference's element order (slice_order.hpp; EventFrame.cpp:12-13,34-35) ----
@@ -1063,7 +1111,8 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                                (isu ? 0x4000u : 0u) | (below << 16))
                             : 0x1000u;   // (no event: "erased", not a key)
         }
-        __syncthreads();
+        if constexpr (EARLY_GATHER) lds_barrier(); else __syncthreads();
+    RO_MARK(2);
         if (tid < 64u) {
             const uint32_t v = tid < NBATCH ? bcnt[tid] : 0u;
             uint32_t inc = v;
@@ -1075,7 +1124,8 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             if (tid < NBATCH) bcnt[tid] = inc - v;
             if (tid == 63u) bcnt[NBATCH] = inc;
         }
-        __syncthreads();
+        if constexpr (EARLY_GATHER) lds_barrier(); else __syncthreads();
+    RO_MARK(3);
         const uint32_t totals = bcnt[NBATCH], mP = totals & 0xFFFFu, mN = totals >> 16;
         const int EP = mP ? ref_epochs(mP) : 0, EN = mN ? ref_epochs(mN) : 0;
         {
@@ -1091,33 +1141,15 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             static_assert(16 * NI <= (int) (2 * (PXH_SLOTS / 32 + 1) + 16), "bitmap room");
             const uint32_t faN = EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u;   // the - set's bucket table starts here
             {
-                constexpr double ME = 13.0 * 29.0 * 59.0 * 127.0;
-                ModB m0, mE;
-                m0.b = M0;
-                m0.inv = (1.0 / M0) * (1.0 - 0x1p-50);
-                mE.b = ME;
-                mE.inv = (1.0 / ME) * (1.0 - 0x1p-50);
-                const ModB e0 = mod_for_epoch(0), e1 = mod_for_epoch(1), e2 = mod_for_epoch(2), e3 = mod_for_epoch(3),
-                           e4 = mod_for_epoch(4), e5 = mod_for_epoch(5), e6 = mod_for_epoch(6);
 #pragma unroll
                 for (int j = 0; j < PXH_PER; j++) {
                     const uint32_t ex = bcnt[j * (T / 64) + wave];
                     meta[j] += ((meta[j] & 0x2000u) ? (ex & 0xFFFFu) : (ex >> 16)) << 16;
                     if (meta[j] & 0x4000u) {
-                        const uint64_t h = ref_hash_combine2(HASH_INT.v[pix[j] >> 10], HASH_INT.v[pix[j] & 0x3FFu]);   // utility.hpp:38-51
                         const uint32_t rank = meta[j] >> 16;
                         const bool pos_ = (meta[j] & 0x2000u) != 0;
-                        // h % M in two exact fp64 steps: h = d2 2^48 + d1 2^24 + d0, d2 < 2^16 < M; then residue % B, one step each
-                        const double d2 = (double) (uint32_t) (h >> 48), d1 = (double) (uint32_t) ((h >> 24) & 0xFFFFFFu),
-                                     d0 = (double) (uint32_t) (h & 0xFFFFFFu);
-                        const double r0 = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), m0), 0x1p24, d0), m0);
-                        W[(pos_ ? 0u : mP) + rank] = (uint32_t) mod_step(r0, e4) | ((uint32_t) mod_step(r0, e5) << 9) |
-                                                     ((uint32_t) mod_step(r0, e6) << 19) | ((meta[j] & 0x1000u) ? 0x80000000u : 0u);
-                        if (rank < N_EARLY) {
-                            const double rE = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), mE), 0x1p24, d0), mE);
-                            fa[(pos_ ? 0u : faN) + rank] = (uint32_t) mod_step(rE, e0) | ((uint32_t) mod_step(rE, e1) << 4) |
-                                                           ((uint32_t) mod_step(rE, e2) << 9) | ((uint32_t) mod_step(rE, e3) << 15);
-                        }
+                        W[(pos_ ? 0u : L::NOFF) + rank] = bw[j].x | ((meta[j] & 0x1000u) ? 0x80000000u : 0u);
+                        if (rank < N_EARLY) fa[(pos_ ? 0u : faN) + rank] = bw[j].y;
                     }
                 }
             }
@@ -1128,13 +1160,14 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             const uint32_t l128 = lane + 64u * sub;
             const uint32_t m = pol == 0u ? mP : mN;
             const int E = pol == 0u ? EP : EN;
-            const uint32_t uoff = pol == 0u ? 0u : mP;
+            const uint32_t uoff = pol == 0u ? 0u : L::NOFF;
             uint32_t *const Wp = W + uoff, *const fap = fa + (pol == 0u ? 0u : faN);
             uint16_t *const regp = region + uoff, *const curp = cur + uoff;
             constexpr uint32_t KW = 4u * NI;   // bitmap words per polarity (128 NI list positions)
             uint32_t *const kW = keepW + pol * KW, *const kPre = keepW + 2u * KW + pol * KW;   // bitmaps, their running counts
             if (tid == 0) ored[10] = 0u;
             __syncthreads();
+    RO_MARK(4);
             uint32_t bk[NI], cu[NI];
 #pragma unroll
             for (int i = 0; i < NI; i++) {
@@ -1144,8 +1177,10 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             }
             if (l128 < KW) kW[l128] = 0u;
             __syncthreads();
+    RO_MARK(5);
             if (sub == 0u && m) early_epochs_packed(m, fap, Wp, regp, curp);
             __syncthreads();
+    RO_MARK(6);
             if (ECAL_RO_STOP == 3) return;
             if (l128 < (m < 127u ? m : 127u)) cu[0] = curp[l128];
             const int EMAX = EP > EN ? EP : EN;
@@ -1153,6 +1188,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 for (uint32_t b = l128; b < 257u; b += 128u) fap[b] = 0xFFFFFFFFu;
             }
             __syncthreads();
+    RO_MARK(7);
             for (int e = 4; e < EMAX; e++) {
                 const bool on = e < E;
                 const uint32_t B = (uint32_t) ref_bucket_step(e), Bprev = (uint32_t) ref_bucket_step(e - 1);
@@ -1161,7 +1197,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 const uint32_t per = (n_e + 127u) >> 7;   // sequence positions per thread in the scan
                 uint32_t fq[NI];                          // first position of the key's bucket
                 // first sequence position per bucket  (and W, last read before the barrier that ended the previous epoch, is cleared)
-                for (uint32_t q = l128; q < n_e; q += 128u) Wp[q] = 0u;
+                for (uint32_t t = 0; t < per; t++) Wp[l128 + 128u * t] = 0u;   // (128 per positions: the scan reads them all)
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     const uint32_t u = l128 + 128u * i;
@@ -1169,15 +1205,15 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     if (u < n_e) atomicMin(&fap[(bk[i] >> sh) & bmask], u < Bprev ? cu[i] : u);
                 }
                 __syncthreads();
-                // members per bucket, counted at the bucket's first position
+                // members per bucket, counted at the bucket's first position; the arrival number is the member's slot
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     const uint32_t u = l128 + 128u * i;
                     fq[i] = 0u;
                     if (128u * i >= n_e) break;
                     if (u < n_e) {
-                        fq[i] = fap[(bk[i] >> sh) & bmask];
-                        atomicAdd(&Wp[fq[i]], 1u);
+                        const uint32_t f = fap[(bk[i] >> sh) & bmask];
+                        fq[i] = f | (atomicAdd(&Wp[f], 1u) << 12);
                     }
                 }
                 __syncthreads();
@@ -1187,17 +1223,17 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
 #pragma unroll
                     for (int t = 0; t < NI; t++) {
                         c[t] = 0u;
-                        if ((uint32_t) t < per && l128 * per + t < n_e) c[t] = Wp[l128 * per + t];
+                        if ((uint32_t) t < per) c[t] = Wp[l128 * per + t];
                         sum += c[t];
                         big |= c[t];
                     }
-                    if (__any(big > 1023u)) ored[10] = 1u;   // a bucket of > 1023 keys does not fit the packed word: next tier
+                    if (__any(big > 1023u)) ored[10] = 1u;   // a bucket of > 1023 keys does not fit the packed words: next tier
                     const uint32_t inc = wave_incl_scan_dpp(sum);
                     if (lane == 63u) ored[wave] = inc;
                     uint32_t ex = inc - sum;
 #pragma unroll
                     for (int t = 0; t < NI; t++) {
-                        if ((uint32_t) t < per && l128 * per + t < n_e) Wp[l128 * per + t] = (ex << 20) | ((c[t] & 0x3FFu) << 10);
+                        if ((uint32_t) t < per) Wp[l128 * per + t] = (ex << 10) | (c[t] & 0x3FFu);
                         ex += c[t];
                     }
                     if (e + 1 < E) {   // the bucket table is dead (fq[] holds what was read from it): set it up for the next epoch
@@ -1207,33 +1243,38 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 }
                 __syncthreads();
                 const uint32_t carry_from = 64u * per, carry = __builtin_amdgcn_readfirstlane(ored[pol * 2u]);
-                // the members of a shared bucket take the slots of its run in arrival order ...
-#pragma unroll
-                for (int i = 0; i < NI; i++) {
-                    const uint32_t u = l128 + 128u * i;
-                    if (128u * i >= n_e) break;
-                    if (u < n_e && ((Wp[fq[i]] >> 10) & 0x3FFu) > 1u) {   // (a key alone in its bucket needs no slot)
-                        const uint32_t w = atomicAdd(&Wp[fq[i]], 1u);
-                        regp[(w >> 20) + (fq[i] >= carry_from ? carry : 0u) + (w & 0x3FFu)] = (uint16_t) (u < Bprev ? cu[i] : u);
-                    }
-                }
-                __syncthreads();
-                // ... and rank themselves by sequence position: new list position = n - 1 - (run start + members before it)
+                // buckets of three and more: the members take the slots of the bucket's run in arrival order ...
 #pragma unroll
                 for (int i = 0; i < NI; i++) {
                     const uint32_t u = l128 + 128u * i;
                     if (128u * i >= n_e) break;
                     if (u < n_e) {
-                        const uint32_t w = Wp[fq[i]], b0 = (w >> 20) + (fq[i] >= carry_from ? carry : 0u), cnt = (w >> 10) & 0x3FFu;
-                        uint32_t within = 0;
-                        if (cnt > 1u) {
-                            const uint32_t q = u < Bprev ? cu[i] : u;
-                            for (uint32_t t = 0; t < cnt; t++) within += ((uint32_t) regp[b0 + t] < q) ? 1u : 0u;
+                        const uint32_t f = fq[i] & 0xFFFu, w = Wp[f];
+                        if ((w & 0x3FFu) > 2u)
+                            regp[(w >> 10) + (f >= carry_from ? carry : 0u) + (fq[i] >> 12)] = (uint16_t) (u < Bprev ? cu[i] : u);
+                    }
+                }
+                __syncthreads();
+                // ... and rank themselves by sequence position: new list position = n - 1 - (run start + members before it).
+                // (Alone: none before it.  A bucket of two: the one whose position IS the bucket's first position is first.)
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const uint32_t u = l128 + 128u * i;
+                    if (128u * i >= n_e) break;
+                    if (u < n_e) {
+                        const uint32_t f = fq[i] & 0xFFFu, w = Wp[f], b0 = (w >> 10) + (f >= carry_from ? carry : 0u), cnt = w & 0x3FFu;
+                        const uint32_t q = u < Bprev ? cu[i] : u;
+                        uint32_t within = (q != f) ? 1u : 0u;
+                        if (cnt > 2u) {   // (buckets of five and more are rare: four slots read at once, a loop for the rest)
+                            const uint32_t r0 = regp[b0], r1 = regp[b0 + 1u], r2 = regp[b0 + 2u], r3 = regp[b0 + 3u];
+                            within = (r0 < q ? 1u : 0u) + (r1 < q ? 1u : 0u) + (r2 < q ? 1u : 0u) + ((cnt > 3u && r3 < q) ? 1u : 0u);
+                            for (uint32_t t = 4; t < cnt; t++) within += ((uint32_t) regp[b0 + t] < q) ? 1u : 0u;
                         }
                         cu[i] = n_e - 1u - (b0 + within);
                     }
                 }
                 __syncthreads();
+                RO_MARK(8 + (e - 4));
             }
             if (ECAL_RO_STOP == 4) return;
             if (ored[10]) {
@@ -1247,6 +1288,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 if (u < m && !(bk[i] >> 31)) atomicOr(&kW[cu[i] >> 5], 1u << (cu[i] & 31u));
             }
             __syncthreads();
+    RO_MARK(11);
             if (sub == 0u) {
                 const uint32_t c = lane < KW ? (uint32_t) __popc(kW[lane]) : 0u;
                 const uint32_t inc = wave_incl_scan_dpp(c);
@@ -1254,6 +1296,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 if (lane == 63u) ored[8u + pol] = inc;
             }
             __syncthreads();
+    RO_MARK(12);
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 const uint32_t u = l128 + 128u * i;
@@ -1261,13 +1304,15 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     curp[u] = (uint16_t) (kPre[cu[i] >> 5] + (uint32_t) __popc(kW[cu[i] >> 5] & ((1u << (cu[i] & 31u)) - 1u)));
             }
             __syncthreads();
+    RO_MARK(13);
             const uint32_t nP = mP ? __builtin_amdgcn_readfirstlane(ored[8]) : 0u, nN = mN ? __builtin_amdgcn_readfirstlane(ored[9]) : 0u;
 #pragma unroll
             for (int j = 0; j < PXH_PER; j++) {
                 if ((meta[j] & 0x5000u) == 0x4000u)   // a key, and not erased
-                    posE[meta[j] & 0xFFFu] = cur[((meta[j] & 0x2000u) ? 0u : mP) + (meta[j] >> 16)];
+                    posE[meta[j] & 0xFFFu] = cur[((meta[j] & 0x2000u) ? 0u : L::NOFF) + (meta[j] >> 16)];
             }
             __syncthreads();
+    RO_MARK(14);
             double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
             int32_t *ep = event_point + base;
 #pragma unroll
@@ -1294,6 +1339,8 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 seg_off[2 * s + 1] = base + nP;
                 seg_cnt[2 * s + 1] = nN;
             }
+            RO_MARK(15);
+            RO_MARK(0);   // (adds ~0: counts the workgroups through the number of marks... see tools/ro_phase_prof.py)
             return;
         }
         // ---- second pass (up to 4095 events): the epochs as workgroup-wide phases ----
@@ -1601,7 +1648,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
 
 // first pass: workgroup b handles window b; what it cannot take goes to todo / todo_count
 #ifndef ECAL_RO_WAVES
-#define ECAL_RO_WAVES 6   // waves per SIMD the reference-order kernel is compiled for (0: the compiler's choice; 6 measured = 5 > 0)
+#define ECAL_RO_WAVES 5   // waves per SIMD the reference-order kernel is compiled for (0: the compiler's choice = 4; measured 50 M events: 4 -> 1.15 ms, 5 -> 1.03 ms, 6 (104 B of scratch per lane) -> 1.13 ms)
 #endif
 #if ECAL_RO_WAVES
 #define ECAL_RO_ATTR __attribute__((amdgpu_waves_per_eu(ECAL_RO_WAVES, ECAL_RO_WAVES)))
@@ -1616,10 +1663,11 @@ __global__ __launch_bounds__(PXH_T) ECAL_RO_ATTR void slice_hash_ref_kernel(cons
                                                            uint32_t *__restrict__ seg_cnt,
                                                            int32_t *__restrict__ event_point, int *overflow,
                                                            uint32_t *__restrict__ todo,
-                                                           uint32_t *__restrict__ todo_count) {
+                                                           uint32_t *__restrict__ todo_count,
+                                                           const uint2 *__restrict__ bucket_tab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     slice_hash_window<11, true>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
-                                todo, todo_count);
+                                todo, todo_count, bucket_tab);
 }
 
 __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__restrict__ rec,
@@ -1797,9 +1845,17 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         todo = list;
         todo_count = cnt;
         if (reforder || !getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)
-            if (reforder)
+            if (reforder) {
+                if (!ctx->bucket_tab_built) {   // once per context (16 MB, ~0.1 ms)
+                    if ((rc = ecal_ensure(ctx, ctx->bucket_tab, sizeof(uint2) << 21))) return rc;
+                    hipLaunchKernelGGL(bucket_table_kernel, dim3((1u << 21) / 256), dim3(256), 0, st, (uint2 *) ctx->bucket_tab.ptr);
+                    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));   // (later calls may come on other streams)
+                    ctx->bucket_tab_built = true;
+                }
                 hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
-                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt,
+                                   (const uint2 *) ctx->bucket_tab.ptr);
+            }
             else
                 hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
                                    d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
@@ -1873,3 +1929,14 @@ extern "C" uint64_t ecal_ref_bucket_step(int epoch) { return (epoch >= 0 && epoc
 extern "C" uint64_t ecal_ref_pixel_hash(double x, double y) {
     return ref_hash_combine2(ref_hash_f64_bits(__builtin_bit_cast(uint64_t, x)), ref_hash_f64_bits(__builtin_bit_cast(uint64_t, y)));
 }
+
+#ifdef ECAL_PHASE_PROF
+extern "C" int ecal_debug_ro_cycles(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_ro_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_ro_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
