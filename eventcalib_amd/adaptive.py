@@ -35,9 +35,10 @@ def orientation_gate(ref_feat, ref_t, cur_feat, cur_t, rows, cols, motion_time_s
     time distance below (5e-4 pi) / MotionTimeStep rad/s."""
     a, b = _row_directions(ref_feat, rows, cols), _row_directions(cur_feat, rows, cols)
     c = (a * b).sum(axis=2) / (np.linalg.norm(a, axis=2) * np.linalg.norm(b, axis=2))
-    theta = np.arccos(np.clip(c, -1.0, 1.0))
+    with np.errstate(invalid="ignore"):
+        theta = np.arccos(c)         # (not clamped, as the reference: a cosine rounded above 1 gives NaN -> rejected)
     med = np.partition(theta, rows // 2, axis=1)[:, rows // 2]
-    return med / np.abs(cur_t - ref_t) < (5e-4 * np.pi) / motion_time_step
+    return ~np.isnan(theta).any(axis=1) & (med / np.abs(cur_t - ref_t) < (5e-4 * np.pi) / motion_time_step)
 
 
 def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event_num_threshold, piece_num,

@@ -128,15 +128,18 @@ __global__ void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, u
             for (uint32_t i = 0; i < rows; i++) {
                 const double c = (rd[2 * i] * dir[i][0] + rd[2 * i + 1] * dir[i][1]) /
                                  (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[i][0], dir[i][1]));
-                theta[i] = acos(fmax(-1.0, fmin(1.0, c)));
+                theta[i] = acos(c);   // (not clamped, as the reference: a cosine rounded above 1 gives NaN and the frame fails the test)
             }
             double med = theta[0];
+            bool any_nan = false;
+            for (uint32_t i = 0; i < rows; i++) any_nan = any_nan || (theta[i] != theta[i]);
             for (uint32_t i = 0; i < rows; i++) {  // order statistic rows / 2 (std::nth_element)
                 uint32_t rank = 0;
                 for (uint32_t j = 0; j < rows; j++) rank += (theta[j] < theta[i] || (theta[j] == theta[i] && j < i)) ? 1u : 0u;
                 if (rank == rows / 2) med = theta[i];
             }
-            accepted = med / fabs(t_mid - st.ref_t[k]) < (5e-4 * M_PI) / mts;
+            // (with a NaN among the angles std::nth_element's result is unspecified; the build rejects the frame)
+            accepted = !any_nan && med / fabs(t_mid - st.ref_t[k]) < (5e-4 * M_PI) / mts;
         }
         if (accepted) {
             const uint32_t at = atomicAdd(&st.counters[1], 1u);

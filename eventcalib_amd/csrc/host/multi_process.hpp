@@ -89,8 +89,10 @@ inline bool orientation_gate(const KeyFrame &ref, const KeyFrame &cur, int rows,
     for (int i = 0; i < rows; i++) {
         const Vector2d a = row_direction(&ref.features[i * cols], cols), b = row_direction(&cur.features[i * cols], cols);
         const double c = (a[0] * b[0] + a[1] * b[1]) / (std::hypot(a[0], a[1]) * std::hypot(b[0], b[1]));
-        theta.push_back(std::acos(std::max(-1.0, std::min(1.0, c))));
+        theta.push_back(std::acos(c));   // (not clamped, as the reference: a cosine rounded above 1 gives NaN)
     }
+    for (double v : theta)
+        if (v != v) return false;    // (std::nth_element on NaNs is unspecified; the build rejects the frame)
     std::nth_element(theta.begin(), theta.begin() + theta.size() / 2, theta.end());
     return theta[theta.size() / 2] / duration < (5e-4 * M_PI) / motionTimeStep;
 }

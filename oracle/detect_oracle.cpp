@@ -63,15 +63,24 @@ void run_side(Side &s, const double *xy, uint32_t n, double eps, uint32_t minpts
 
 // returns true if some cluster has another member with exactly the representative's norm (then the
 // representative depends on the in-cluster order — SURVEY A.6: 0.58 % of clusters)
-bool medians(Side &s) {
+// tie_out (optional): per kept cluster, 1 if it has such a tie.  rep_override (optional): per kept cluster a member pid to
+// use instead (0xFFFFFFFF: keep the reference's) — the parity tests hand in the build's choice among the equal-norm
+// members of a tied cluster and then require everything downstream to be identical.
+bool medians(Side &s, uint32_t *tie_out = nullptr, const uint32_t *rep_override = nullptr) {
     bool tie = false;
     auto less = [&](uint32_t a, uint32_t b) { return norm2(s.pts[a]) < norm2(s.pts[b]); };
+    size_t ci = 0;
     for (auto &c : s.clusters) {
         std::nth_element(c.begin(), c.begin() + c.size() / 2, c.end(), less);  // :141, :145
-        const uint32_t rep = c[c.size() / 2];
-        s.centres.push_back(rep);
+        uint32_t rep = c[c.size() / 2];
+        bool t = false;
         for (uint32_t v : c)
-            if (v != rep && norm2(s.pts[v]) == norm2(s.pts[rep])) tie = true;
+            if (v != rep && norm2(s.pts[v]) == norm2(s.pts[rep])) t = true;
+        if (rep_override && rep_override[ci] != 0xFFFFFFFFu) rep = rep_override[ci];
+        s.centres.push_back(rep);
+        if (tie_out) tie_out[ci] = t ? 1u : 0u;
+        tie = tie || t;
+        ci++;
     }
     return tie;
 }
@@ -183,12 +192,32 @@ int oracle_extract_candidates(const double *pos_xy, uint32_t n_pos, const double
                                           rep_neg);
 }
 
+int oracle_extract_candidates_override(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
+                                       double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
+                                       double radius_thr, int fit_circle, uint32_t knn_num, uint32_t *info,
+                                       uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
+                                       uint32_t *rep_pos, uint32_t *rep_neg, uint32_t *tie_pos, uint32_t *tie_neg,
+                                       const uint32_t *override_pos, const uint32_t *override_neg);
+
 // fit_circle == 0: the :283-311 path; fit_circle != 0: the :180-281 path with knn_num neighbours.
 int oracle_extract_candidates_mode(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
                                    double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
                                    double radius_thr, int fit_circle, uint32_t knn_num, uint32_t *info,
                                    uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
                                    uint32_t *rep_pos, uint32_t *rep_neg) {
+    return oracle_extract_candidates_override(pos_xy, n_pos, neg_xy, n_neg, eps, minpts, cluster_min, need_clusters, radius_thr,
+                                              fit_circle, knn_num, info, cand_pair, cand_xyr, kept_pos, kept_neg, rep_pos, rep_neg,
+                                              nullptr, nullptr, nullptr, nullptr);
+}
+
+// The same with per-cluster tie flags out (tie_pos / tie_neg, sized like rep_pos / rep_neg, optional) and representatives
+// handed in for chosen clusters (override_pos / override_neg, optional; see medians()).
+int oracle_extract_candidates_override(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
+                                       double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
+                                       double radius_thr, int fit_circle, uint32_t knn_num, uint32_t *info,
+                                       uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
+                                       uint32_t *rep_pos, uint32_t *rep_neg, uint32_t *tie_pos, uint32_t *tie_neg,
+                                       const uint32_t *override_pos, const uint32_t *override_neg) {
     info[0] = info[1] = info[2] = 0;
     info[3] = 1;
     for (uint32_t i = 0; i < n_pos; i++) kept_pos[i] = -1;
@@ -203,8 +232,8 @@ int oracle_extract_candidates_mode(const double *pos_xy, uint32_t n_pos, const d
     info[2] = (uint32_t) N.clusters.size();
     if (P.clusters.size() < need_clusters || N.clusters.size() < need_clusters) return 0;  // :127-129
     info[3] = 0;
-    const bool tp = medians(P);
-    const bool tn = medians(N);
+    const bool tp = medians(P, tie_pos, override_pos);
+    const bool tn = medians(N, tie_neg, override_neg);
     if (tp || tn) info[3] |= 2u;  // bit 1: representative is order dependent in some cluster
     for (size_t i = 0; i < P.centres.size(); i++) rep_pos[i] = P.centres[i];
     for (size_t i = 0; i < N.centres.size(); i++) rep_neg[i] = N.centres[i];

@@ -237,14 +237,17 @@ def circle_radius_threshold(width, height, rows, cols, asymmetric, square, radiu
     return L.oracle_circle_radius_threshold(width, height, rows, cols, int(asymmetric), square, radius)
 
 
-def extract_candidates(pos, neg, eps, minpts, cluster_min, need_clusters, radius_thr, fit_circle=False, knn_num=3):
-    """extractFeatures up to the candidate list (both fitCircle paths).  Returns a dict."""
+def extract_candidates(pos, neg, eps, minpts, cluster_min, need_clusters, radius_thr, fit_circle=False, knn_num=3,
+                       override_pos=None, override_neg=None):
+    """extractFeatures up to the candidate list (both fitCircle paths).  Returns a dict; tie_pos / tie_neg flag the kept
+    clusters whose nth_element median has an equal-norm rival (the reference's choice then depends on its BFS member
+    order); override_pos / override_neg (uint32 per kept cluster, 0xFFFFFFFF = keep) hand in other representatives."""
     L = lib()
-    L.oracle_extract_candidates_mode.argtypes = [_dp, ctypes.c_uint32, _dp, ctypes.c_uint32, ctypes.c_double,
-                                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double,
-                                                 ctypes.c_int, ctypes.c_uint32, _u32p, _u32p, _dp, _i32p, _i32p,
-                                                 _u32p, _u32p]
-    L.oracle_extract_candidates_mode.restype = ctypes.c_int
+    L.oracle_extract_candidates_override.argtypes = [_dp, ctypes.c_uint32, _dp, ctypes.c_uint32, ctypes.c_double,
+                                                     ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double,
+                                                     ctypes.c_int, ctypes.c_uint32, _u32p, _u32p, _dp, _i32p, _i32p,
+                                                     _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]
+    L.oracle_extract_candidates_override.restype = ctypes.c_int
     pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 2)
     neg = np.ascontiguousarray(neg, np.float64).reshape(-1, 2)
     npos, nneg = pos.shape[0], neg.shape[0]
@@ -256,14 +259,19 @@ def extract_candidates(pos, neg, eps, minpts, cluster_min, need_clusters, radius
     kn = np.full(max(nneg, 1), -1, np.int32)
     rp = np.zeros(max(npos, 1), np.uint32)
     rn = np.zeros(max(nneg, 1), np.uint32)
-    L.oracle_extract_candidates_mode(_p(pos, _dp), npos, _p(neg, _dp), nneg, float(eps), int(minpts), int(cluster_min),
-                                     int(need_clusters), float(radius_thr), int(bool(fit_circle)), int(knn_num),
-                                     _p(info, _u32p), _p(pair, _u32p), _p(xyr, _dp), _p(kp, _i32p), _p(kn, _i32p),
-                                     _p(rp, _u32p), _p(rn, _u32p))
+    tp = np.zeros(max(npos, 1), np.uint32)
+    tn = np.zeros(max(nneg, 1), np.uint32)
+    op = None if override_pos is None else np.ascontiguousarray(override_pos, np.uint32)
+    on = None if override_neg is None else np.ascontiguousarray(override_neg, np.uint32)
+    L.oracle_extract_candidates_override(_p(pos, _dp), npos, _p(neg, _dp), nneg, float(eps), int(minpts), int(cluster_min),
+                                         int(need_clusters), float(radius_thr), int(bool(fit_circle)), int(knn_num),
+                                         _p(info, _u32p), _p(pair, _u32p), _p(xyr, _dp), _p(kp, _i32p), _p(kn, _i32p),
+                                         _p(rp, _u32p), _p(rn, _u32p), _p(tp, _u32p), _p(tn, _u32p),
+                                         None if op is None else _p(op, _u32p), None if on is None else _p(on, _u32p))
     nc = int(info[0])
     return dict(n=nc, nk_pos=int(info[1]), nk_neg=int(info[2]), status=int(info[3]) & 1, tie=bool(info[3] & 2),
                 pair=pair[:nc], xyr=xyr[:nc], kept_pos=kp[:npos], kept_neg=kn[:nneg], rep_pos=rp[:int(info[1])],
-                rep_neg=rn[:int(info[2])])
+                rep_neg=rn[:int(info[2])], tie_pos=tp[:int(info[1])].astype(bool), tie_neg=tn[:int(info[2])].astype(bool))
 
 
 def fit_circle(a, b):
@@ -359,3 +367,57 @@ def rectify(pos, neg, kept_pos, kept_neg, pose, camera, dist, width, height, lan
                      ctypes.c_double(circle_radius), ctypes.c_int(int(fit_circle)), vp(feat.ctypes.data),
                      vp(valid.ctypes.data), vp(info.ctypes.data))
     return feat, valid, int(info[0]), int(info[1])
+
+
+# ---- adaptive windowing + keyframe gate (oracle/policy_oracle.cpp) ----
+_DETECT_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.POINTER(ctypes.c_int),
+                              ctypes.POINTER(ctypes.c_double))
+
+
+def policy_run(detect, start_time, end_time, piece_num, motion_time_step, frame_event_num_threshold, rows=9, cols=4, mode=0,
+               max_keyframes=1 << 16):
+    """MultiProcess::process + EventCalibIni::track on the CPU.  detect(t0, t1) -> (found, events_num, features [rows*cols, 3]
+    or None) stands for CirclesEventFrame(...).extractFeatures() on the window.  mode 0: the build's own-piece gate, 1: the
+    reference's single shared map with one worker.  Returns dict(time, duration, events_num, features, windows)."""
+    L = lib()
+    L.oracle_policy_run.argtypes = [_DETECT_FN, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, _dp, _dp, _i32p, _dp,
+                                    _u64p]
+    L.oracle_policy_run.restype = ctypes.c_int64
+    M = rows * cols
+    err = []
+
+    def cb(user, t0, t1, ev_out, feat_out):
+        try:
+            found, events_num, feat = detect(t0, t1)
+            ev_out[0] = int(events_num)
+            if found:
+                f = np.ascontiguousarray(feat, np.float64).reshape(M, 3)
+                ctypes.memmove(feat_out, f.ctypes.data, 8 * 3 * M)
+            return 1 if found else 0
+        except Exception as e:      # never let an exception cross the C frame
+            err.append(e)
+            ev_out[0] = 0
+            return 0
+    t = np.zeros(max_keyframes)
+    d = np.zeros((max_keyframes, 2))
+    e = np.zeros(max_keyframes, np.int32)
+    f = np.zeros((max_keyframes, M, 3))
+    w = ctypes.c_uint64(0)
+    K = L.oracle_policy_run(_DETECT_FN(cb), None, float(start_time), float(end_time), int(piece_num), float(motion_time_step),
+                            int(frame_event_num_threshold), rows, cols, int(mode), max_keyframes, _p(t, _dp), _p(d, _dp),
+                            _p(e, _i32p), _p(f, _dp), ctypes.byref(w))
+    if err:
+        raise err[0]
+    assert 0 <= K <= max_keyframes, K
+    return dict(time=t[:K].copy(), duration=d[:K].copy(), events_num=e[:K].astype(np.int64), features=f[:K].copy(),
+                windows=int(w.value))
+
+
+def track_gate(ref_feat, ref_time, cur_feat, cur_time, rows, cols, motion_time_step):
+    L = lib()
+    L.oracle_track_gate.argtypes = [_dp, ctypes.c_double, _dp, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_double]
+    L.oracle_track_gate.restype = ctypes.c_int
+    a = np.ascontiguousarray(ref_feat, np.float64).reshape(rows * cols, 3)
+    b = np.ascontiguousarray(cur_feat, np.float64).reshape(rows * cols, 3)
+    return bool(L.oracle_track_gate(_p(a, _dp), float(ref_time), _p(b, _dp), float(cur_time), rows, cols, float(motion_time_step)))

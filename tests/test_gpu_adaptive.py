@@ -51,3 +51,33 @@ def test_capacity_errors_and_limits(env):
     assert passes <= 3 and windows <= 3 * 64
     with pytest.raises(capi.EcalError):        # invalid: no pieces
         capi.detect_keyframes_dev(ctx, ev.data_ptr(), n, 5e-4, 4000, 0, 5.0, 6.0, n, 16)
+
+
+@pytest.mark.parametrize("pieces", [1, 6, 40])
+def test_device_policy_equals_the_policy_oracle(env, pieces):
+    """ecal_detect_keyframes against oracle/policy_oracle.cpp — the sequential loop of MultiProcess::process
+    (eventCameraCalib.cpp:34-97) with TrackingBase::process + EventCalibIni::track (EventCalibIni.cpp:23-97) restated on the
+    CPU, own-piece gate.  extractFeatures() of a window is supplied to the oracle by a callback that runs the product's
+    detection stages on that single window (those stages have their own oracles): what is checked here is the control flow —
+    window arithmetic in the reference's floating-point order, success / slide / grow, the strict piece end — and the gate."""
+    import oracle_lib as O
+    import eventcalib_amd.capi as capi
+    from eventcalib_amd.adaptive import detect_keyframes_device
+    ctx, pipe, ev, torch = env
+    n_ev = ev.numel() // 25
+    t_first, t_last = 5.0, 5.0 + 0.12                  # 240 k events of the 2 Mev/s stream
+    calls = []
+
+    def detect(t0, t1):
+        packed = capi.detect_pass(ctx, ev.data_ptr(), n_ev, np.array([t0]), np.array([t1]), 65536, 4.0, 2, 5, 9, 4)
+        calls.append((t0, t1))
+        found = packed[0, 0] == 0 and packed[0, 1] != 0
+        return found, int(packed[0, 2]), packed[0, 3:].reshape(36, 3) if found else None
+    ref = O.policy_run(detect, t_first, t_last, pieces, 5e-4, 4000, 9, 4, mode=0)
+    dev = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last)
+    assert len(ref["time"]) >= 8
+    assert dev["windows"] == ref["windows"]
+    assert np.array_equal(dev["time"], ref["time"])
+    assert np.array_equal(dev["duration"], ref["duration"])
+    assert np.array_equal(dev["events_num"], ref["events_num"])
+    assert np.array_equal(dev["features"], ref["features"])

@@ -53,14 +53,23 @@ def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=
             assert info[s, 0] == 0
             continue
         if ref["tie"]:
-            # some cluster's median is order dependent in the reference: representatives may differ
-            # by a pixel of equal norm; the GPU's choice must still have the oracle's norm
+            # Some cluster's median has an equal-norm rival: which of the two the reference's nth_element returns depends
+            # on its BFS member order, the build takes the smaller pid.  That choice is the ONLY freedom:
+            # every untied cluster's representative must be the oracle's, a tied cluster's must be a member of the same
+            # cluster with the oracle's norm, and with those representatives handed to the oracle everything downstream
+            # (pairs, circles, count) must again be identical.
             tied += 1
-            gp = pos[rep[op:op + ref["nk_pos"]]]
-            rp = pos[ref["rep_pos"]]
-            assert np.array_equal(np.sqrt((gp ** 2).sum(1)), np.sqrt((rp ** 2).sum(1)))
-            continue
-        exact += 1
+            over = []
+            for k, (o, pts, keptl) in enumerate(((op, pos, ref["kept_pos"]), (on, neg, ref["kept_neg"]))):
+                nk = ref["nk_pos"] if k == 0 else ref["nk_neg"]
+                g, r, tie_c = rep[o:o + nk].astype(np.int64), ref["rep_pos" if k == 0 else "rep_neg"].astype(np.int64), ref["tie_pos" if k == 0 else "tie_neg"]
+                assert np.array_equal(g[~tie_c], r[~tie_c]), "window %d untied representatives (%s)" % (s, "+-"[k])
+                assert np.array_equal(keptl[g], np.arange(nk)), "window %d tied representative outside its cluster" % s
+                assert np.array_equal((pts[g] ** 2).sum(1), (pts[r] ** 2).sum(1)), "window %d tied representative norm" % s
+                over.append(np.where(tie_c, g, 0xFFFFFFFF).astype(np.uint32))
+            ref = O.extract_candidates(pos, neg, 4.0, 2, cluster_min, need, thr, fit_circle, knn_num, over[0], over[1])
+        else:
+            exact += 1
         assert np.array_equal(rep[op:op + ref["nk_pos"]], ref["rep_pos"]), "window %d rep +" % s
         assert np.array_equal(rep[on:on + ref["nk_neg"]], ref["rep_neg"]), "window %d rep -" % s
         n = ref["n"]
@@ -88,7 +97,7 @@ def test_synthetic_stream(env, rate):
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)
     assert exact + tied > 0 or rate < 2.0e6      # sparse 1 Mev/s windows may all fail the 36-cluster test
     if rate >= 2.0e6:
-        assert exact >= 3
+        assert exact + tied >= 0.7 * len(t0), (exact, tied, len(t0))   # most windows reach the pairing stage at these rates
 
 
 def test_small_need_and_cluster_min(env):
@@ -105,7 +114,7 @@ def test_small_need_and_cluster_min(env):
     pipe.run(buf.cuda())
     torch.cuda.synchronize()
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 3, 10, 40.0)
-    assert exact >= 5
+    assert exact + tied >= len(t0) - 2, (exact, tied, len(t0))     # every non-empty window pairs with these parameters
 
 
 def test_large_windows_use_the_global_scratch_path(env):
@@ -121,7 +130,7 @@ def test_large_windows_use_the_global_scratch_path(env):
     S = len(t0)
     assert int((pipe.seg_cnt[:2 * S:2] + pipe.seg_cnt[1:2 * S:2]).max()) > 1408
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)
-    assert exact + tied >= 3 or rate < 2.0e6
+    assert exact + tied >= 0.7 * S, (exact, tied, S)
 
 
 @pytest.mark.parametrize("knn_num", [1, 3])
@@ -136,7 +145,7 @@ def test_fit_circle_path(env, knn_num):
     pipe.run(buf.cuda())
     torch.cuda.synchronize()
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, True, knn_num)
-    assert exact >= 5
+    assert exact + tied >= 0.7 * len(t0), (exact, tied, len(t0))
     pipe.set_detect_params(5, 36, THR)
 
 
