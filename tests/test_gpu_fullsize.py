@@ -144,3 +144,98 @@ def test_pixel_kernel_equals_general_tiers_repeatedly(run):
         torch.cuda.synchronize()
         assert torch.equal(p2.n_clusters[:2 * S], ref_n), rep
         assert torch.equal(p2.labels[used], ref_l[used]), rep
+
+
+def test_config0_one_window_of_100k_events():
+    """BASELINE configs[0]: a 100 k-event stream taken as ONE time slice (StartTime/EndTime cover everything) — the window
+    goes through the global-scratch tiers (slice_big_kernel, dbscan_big_kernel, the global extraction path) instead of the
+    per-window LDS kernels.  Points in the reference's order, labels on the reference's kd-tree, candidates: == oracle."""
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    try:
+        pipe = DetectPipeline(ctx)
+        n = 100_000
+        buf = SS.make_stream(n, device="cpu", seed=3)
+        rec = buf.numpy()
+        t, _, _ = SS.unpack_records(buf)
+        pipe.set_windows([float(t[0])], [float(t[-1])])
+        pipe.set_detect_params(5, 36, 15.511363636363637)
+        pipe.run(buf.cuda())
+        torch.cuda.synchronize()
+        assert not pipe.overflowed()
+        assert int(pipe.win_lo[0]) == 0 and int(pipe.win_hi[0]) == n
+        pos, neg, ep = O.event_frame(rec, 0, n, "reference")
+        cnt = pipe.seg_cnt[:2].cpu().numpy()
+        off = pipe.seg_off[:2].cpu().numpy()
+        assert (int(cnt[0]), int(cnt[1])) == (len(pos), len(neg)) and len(pos) > 4096 and len(neg) > 4096   # beyond every LDS tier
+        assert np.array_equal(pipe.xy[off[0]:off[0] + cnt[0]].cpu().numpy(), pos)
+        assert np.array_equal(pipe.xy[off[1]:off[1] + cnt[1]].cpu().numpy(), neg)
+        assert np.array_equal(pipe.event_point[:n].cpu().numpy(), ep)
+        for k, pts in ((0, pos), (1, neg)):
+            rc, lab, nc = O.dbscan(pts, 4.0, 2, kdapi=O.have_ref_kdtree())
+            assert np.array_equal(pipe.labels[off[k]:off[k] + cnt[k]].cpu().numpy(), lab), k
+            assert int(pipe.n_clusters[k]) == nc
+        ref = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
+        info = pipe.win_info[0].cpu().numpy()
+        assert info[3] == ref["status"] and info[1] == ref["nk_pos"] and info[2] == ref["nk_neg"]
+        assert np.array_equal(pipe.kept_labels[off[0]:off[0] + cnt[0]].cpu().numpy(), ref["kept_pos"])
+        assert np.array_equal(pipe.kept_labels[off[1]:off[1] + cnt[1]].cpu().numpy(), ref["kept_neg"])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n_events", [50_000_000])
+def test_oracle_spot_checks_at_the_benchmark_size(n_events):
+    """BASELINE configs[2] (the 50 M-event stream bench.py times): 24 windows sampled over the whole stream, records ->
+    reference point order -> labels on the reference's kd-tree -> candidates, == the oracle; plus the structure invariants
+    that do not need the oracle.  ~9 GB of HBM, seconds of CPU."""
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.pipeline import DetectPipeline
+    if torch.cuda.get_device_properties(0).total_memory < 40e9:
+        pytest.skip("needs ~10 GB of device memory")
+    ctx = eventcalib_amd.Context(0)
+    try:
+        pipe = DetectPipeline(ctx)
+        ev = SS.make_stream(n_events, device="cuda")
+        t0, t1 = SS.tiled_windows(5.0, 5.0 + (n_events - 1) / 1e6)
+        S = len(t0)
+        pipe.set_windows(t0, t1)
+        pipe.set_detect_params(5, 36, 15.511363636363637)
+        pipe.run(ev)
+        torch.cuda.synchronize()
+        assert not pipe.overflowed()
+        lo, hi = pipe.win_lo[:S].long(), pipe.win_hi[:S].long()
+        assert int(lo[0]) == 0 and int(hi[-1]) == n_events and bool((lo[1:] == hi[:-1]).all())
+        cnt = pipe.seg_cnt[:2 * S].long()
+        assert bool((cnt[0::2] + cnt[1::2] <= hi - lo).all())
+        rng = np.random.default_rng(7)
+        pick = np.sort(rng.choice(S, 24, replace=False))
+        lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
+        off, cntn = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64), cnt.cpu().numpy()
+        info = pipe.win_info[:S].cpu().numpy()
+        paired = 0
+        for s in pick:
+            rec = ev[25 * int(lo[s]): 25 * int(hi[s])].cpu().numpy()
+            pos, neg, ep = O.event_frame(rec, 0, int(hi[s] - lo[s]), "reference")
+            base = int(pipe.win_base[s])
+            assert np.array_equal(pipe.event_point[base:base + int(hi[s] - lo[s])].cpu().numpy(), ep), s
+            for k, pts in ((0, pos), (1, neg)):
+                o, c = off[2 * s + k], cntn[2 * s + k]
+                assert c == len(pts) and np.array_equal(pipe.xy[o:o + c].cpu().numpy(), pts), (s, k)
+                rc, lab, nc = O.dbscan(pts, 4.0, 2, kdapi=O.have_ref_kdtree())
+                assert np.array_equal(pipe.labels[o:o + c].cpu().numpy(), lab), (s, k)
+            ref = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
+            assert info[s, 3] == ref["status"], s
+            assert np.array_equal(pipe.kept_labels[off[2 * s]:off[2 * s] + len(pos)].cpu().numpy(), ref["kept_pos"]), s
+            if not ref["status"] and not ref["tie"]:
+                paired += 1
+                n = ref["n"]
+                assert info[s, 0] == n
+                assert np.array_equal(pipe.cand_pair[off[2 * s]:off[2 * s] + n].cpu().numpy(), ref["pair"]), s
+                assert np.array_equal(pipe.cand_xyr[off[2 * s]:off[2 * s] + n].cpu().numpy(), ref["xyr"]), s
+        assert paired >= 5
+    finally:
+        ctx.close()
