@@ -45,6 +45,20 @@ def main():
     ap.add_argument("--calib-cpu-views", type=int, default=8, help="views timed on the numpy oracle (0 = skip)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as CHILD processes of this one (which has
+        # not touched the GPU and never will — a process that has initialised HIP must not exec), relay rank 0's JSON line
+        # and exit with the launcher's return code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -74,6 +88,13 @@ def main():
     import synth_stream as SS
 
     ctx = eventcalib_amd.Context(local_rank)
+    if world > 1 and backend == "nccl":
+        # the library's own RCCL communicator (ecal_comm_init): rank 0's id goes to the others through the process group
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt = torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8).to(dev)
+        dist.broadcast(idt, 0)
+        ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
     pipe = DetectPipeline(ctx, dev)
 
     # ---- synthetic input, resident in HBM before the timed region ----
@@ -333,10 +354,11 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
     solver = Solver(ctx, prob)
     del prob
     opt = solver.default_options()
-    hook = make_allreduce_hook(ctx, world)
+    hook = make_allreduce_hook(ctx, world) if (world > 1 and ctx.comm_size() == 1) else None   # gloo test hook only
     if world > 1:
-        opt.allreduce = hook
-        opt.distributed, opt.rank, opt.world_size = 1, rank, world
+        if hook is not None:
+            opt.allreduce = hook
+        opt.distributed, opt.rank, opt.world_size = 1, rank, world       # (with a communicator the library all-reduces itself)
     # warm-up: two iterations
     opt.max_num_iterations = 2
     solver.solve(x0, opt)
@@ -452,7 +474,7 @@ def calib_leg(args, ctx, dev, world, rank, dist, torch, np):
     obj, img, rv, tv = SC.make_views(V, 0, seed=2024, noise_px=0.1)      # every rank builds the same 64 views ...
     lo, hi = (V * rank) // world, (V * (rank + 1)) // world              # ... and keeps its shard
     mine = img[lo:hi]
-    hook = capi.make_allreduce_hook(ctx, world) if world > 1 else None
+    hook = capi.make_allreduce_hook(ctx, world) if (world > 1 and ctx.comm_size() == 1) else None   # gloo test hook only
     capi.calibrate_views(ctx, obj, mine, SC.WIDTH, SC.HEIGHT, 0, SC.FLAGS_EXAMPLE, 1.0, allreduce=hook)   # warm-up
     reps = 5
     if world > 1:

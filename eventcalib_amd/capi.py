@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = [
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
+    "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
@@ -77,6 +78,18 @@ def load_library():
     L.ecal_dbscan_batch_dev.argtypes = [vp, vp, vp, vp, u32, u32, u32, f64, u32, vp, vp, vp]
     L.ecal_dbscan_batch_dev.restype = i32
     u64 = ctypes.c_uint64
+    L.ecal_comm_unique_id.argtypes = [vp]
+    L.ecal_comm_unique_id.restype = i32
+    L.ecal_comm_init.argtypes = [vp, vp, i32, i32]
+    L.ecal_comm_init.restype = i32
+    L.ecal_comm_destroy.argtypes = [vp]
+    L.ecal_comm_destroy.restype = i32
+    L.ecal_comm_size.argtypes = [vp]
+    L.ecal_comm_size.restype = i32
+    L.ecal_comm_rank.argtypes = [vp]
+    L.ecal_comm_rank.restype = i32
+    L.ecal_comm_allreduce_sum_dev.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.ecal_comm_allreduce_sum_dev.restype = i32
     L.ecal_set_point_order.argtypes = [vp, i32]
     L.ecal_set_point_order.restype = i32
     L.ecal_get_point_order.argtypes = [vp]
@@ -170,6 +183,32 @@ class Context:
         self._check(self._L.ecal_dbscan_batch_dev(self._h, d_xy, d_seg_off, d_seg_cnt, int(S), int(n_points),
                                                   int(max_seg_points), float(eps), int(minpts), d_labels,
                                                   d_n_clusters, stream))
+
+    # ---- in-library RCCL communicator (one rank per GPU) ----
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the 128 bytes every rank passes to comm_init (hand them over with any transport)."""
+        buf = ctypes.create_string_buffer(128)
+        rc = load_library().ecal_comm_unique_id(buf)
+        if rc:
+            raise EcalError(rc, "ecal_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world_size):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._L.ecal_comm_init(self._h, buf, int(rank), int(world_size)))
+
+    def comm_destroy(self):
+        self._check(self._L.ecal_comm_destroy(self._h))
+
+    def comm_size(self):
+        return self._L.ecal_comm_size(self._h)
+
+    def comm_rank(self):
+        return self._L.ecal_comm_rank(self._h)
+
+    def comm_allreduce_sum_dev(self, d_buf, n_doubles, stream=0):
+        self._check(self._L.ecal_comm_allreduce_sum_dev(self._h, d_buf, int(n_doubles), stream))
 
     # ---- ingest + slicing (device buffers, raw pointers) ----
     ORDER_REFERENCE, ORDER_FIRST_OCCURRENCE = 0, 1

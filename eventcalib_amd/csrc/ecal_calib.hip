@@ -891,9 +891,17 @@ extern "C" void ecal_calib_default_options(ecal_calib_options *o) {
 }
 
 extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const double *img, uint32_t n_views, double width,
-                                    double height, const ecal_calib_options *opt, ecal_calib_result *res, double *rvecs, double *tvecs,
+                                    double height, const ecal_calib_options *opt_in, ecal_calib_result *res, double *rvecs, double *tvecs,
                                     double *per_view_err) {
     if (!ctx) return ECAL_ERR_INVALID;
+    ecal_calib_options opt_local;
+    const ecal_calib_options *opt = opt_in;
+    if (opt_in && !opt_in->allreduce && ctx->comm && ctx->comm_size > 1) {   // the context's own RCCL communicator (ecal_comm_init)
+        opt_local = *opt_in;
+        opt_local.allreduce = ecal_comm_allreduce_hook;
+        opt_local.allreduce_user = ctx;
+        opt = &opt_local;
+    }
     if (!obj || (!img && n_views) || !opt || !res || n_pts < 4 || n_pts > CB_MAXPTS || (opt->model != 0 && opt->model != 1) ||
         !(width > 0) || !(height > 0)) {
         ctx->last_error = "ecal_calibrate_views: bad argument";

@@ -41,6 +41,7 @@ extern "C" const char *ecal_strerror(int status) {
         case ECAL_ERR_NOMEM: return "out of memory";
         case ECAL_ERR_UNSORTED: return "event timestamps not sorted";
         case ECAL_ERR_RANGE: return "size out of range";
+        case ECAL_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -78,6 +79,7 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
         (void) hipStreamSynchronize(ctx->stream);
         (void) hipStreamDestroy(ctx->stream);
     }
+    (void) ecal_comm_destroy(ctx);
     if (ctx->calib_pinned) (void) hipHostFree(ctx->calib_pinned);
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
     if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);

@@ -46,6 +46,8 @@ struct ecal_ctx {
     ecal_devbuf calib_scratch;  // ecal_calibrate_views: views, blocks, reduced records
     ecal_devbuf adaptive_state, adaptive_keys;  // ecal_detect_keyframes: per-piece window state, keyframe records
     double *calib_pinned = nullptr;  // pinned host landing zone of the reduced record
+    void *comm = nullptr;   // ncclComm_t (ecal_comm.hip); null = single rank
+    int comm_rank = 0, comm_size = 1;
     uint32_t n_cu = 256;  // compute units of the device (grid size of the persistent kernels)
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
@@ -70,5 +72,7 @@ struct ecal_ctx {
         }                                                                                             \
     } while (0)
 
+// all-reduce through the context's communicator (user = the ecal_ctx): ecal_allreduce_fn for the solver / calibration
+int ecal_comm_allreduce_hook(void *user, double *d_buf, size_t n_doubles, void *stream);
 // ensure a scratch buffer of at least `bytes` (contents are NOT preserved)
 int ecal_ensure(ecal_ctx *ctx, ecal_devbuf &b, size_t bytes);

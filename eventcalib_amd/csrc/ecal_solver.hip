@@ -634,6 +634,12 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     ecal_lm_options opt;
     if (opt_in) opt = *opt_in; else ecal_lm_default_options(&opt);
     ecal_ctx *ctx = s->ctx;
+    if (!opt.allreduce && ctx->comm && ctx->comm_size > 1) {   // the context's own RCCL communicator (ecal_comm_init)
+        opt.allreduce = ecal_comm_allreduce_hook;
+        opt.allreduce_user = ctx;
+        opt.rank = ctx->comm_rank;
+        opt.world_size = ctx->comm_size;
+    }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const size_t np = s->n_params(), na = s->n_accum(), nc = 6 * (size_t) s->n_cp, nt = nc + 9;

@@ -35,7 +35,8 @@ typedef enum ecal_status {
     ECAL_ERR_HIP = -3,        /* a HIP call failed; ecal_last_error() has the text */
     ECAL_ERR_NOMEM = -4,      /* device or host allocation failed */
     ECAL_ERR_UNSORTED = -5,   /* event timestamps are not non-decreasing */
-    ECAL_ERR_RANGE = -6       /* a size exceeds what the ABI can index (2^32-1 points) */
+    ECAL_ERR_RANGE = -6,      /* a size exceeds what the ABI can index (2^32-1 points) */
+    ECAL_ERR_COMM = -7        /* RCCL error (ecal_last_error has the text) */
 } ecal_status;
 
 typedef struct ecal_ctx ecal_ctx;
@@ -373,6 +374,24 @@ typedef struct ecal_spline_problem {
                                    Parameterization; 1 = cumulative SO3 spline (CalibReprojectionError_SO3,
                                    EventCalibSpline.hpp:65-135) + LocalParameterizationSO3 (q <- q * exp(delta)) */
 } ecal_spline_problem;
+/* ---- multi-GPU: one process per GPU, one RCCL communicator per context ---------------------------------------
+ * The reference has no distributed backend; north_star shards calibration views and spline residuals one batch per GPU
+ * and sums the per-view / per-rank normal-equation blocks with an RCCL all-reduce over xGMI.  Rank 0 calls
+ * ecal_comm_unique_id and hands the ECAL_COMM_ID_BYTES bytes to the other ranks by any means (a file, a socket, MPI,
+ * torch.distributed); then EVERY rank calls ecal_comm_init on its own context (collective: returns when all world_size
+ * ranks have joined; one rank per GPU — RCCL refuses two ranks on one device).  From then on ecal_solver_solve and
+ * ecal_calibrate_views all-reduce through the communicator themselves whenever their options carry no callback
+ * (rank / world_size of ecal_lm_options are then taken from the communicator).  ecal_comm_allreduce_sum_dev: d_buf[0 ..
+ * n) summed over the ranks in place, enqueued on `stream` (no host synchronisation); a no-op without a communicator. */
+#define ECAL_COMM_ID_BYTES 128
+int ecal_comm_unique_id(void *id_out /*[ECAL_COMM_ID_BYTES]*/);
+int ecal_comm_init(ecal_ctx *ctx, const void *unique_id, int rank, int world_size);
+int ecal_comm_destroy(ecal_ctx *ctx);
+int ecal_comm_size(const ecal_ctx *ctx);   /* 1 without a communicator */
+int ecal_comm_rank(const ecal_ctx *ctx);
+int ecal_comm_allreduce_sum_dev(ecal_ctx *ctx, double *d_buf, size_t n_doubles, void *stream);
+
+/* all-reduce supplied by the caller instead (any transport; takes precedence over the context's communicator) */
 typedef int (*ecal_allreduce_fn)(void *user, double *d_buf, size_t n_doubles, void *stream);
 typedef struct ecal_lm_options {
     int max_num_iterations;
@@ -380,7 +399,7 @@ typedef struct ecal_lm_options {
     double initial_trust_region_radius, max_trust_region_radius, min_relative_decrease;
     double min_lm_diagonal, max_lm_diagonal;
     int jacobi_scaling;
-    ecal_allreduce_fn allreduce; /* NULL on one GPU; sums d_buf over ranks in place (RCCL) otherwise */
+    ecal_allreduce_fn allreduce; /* NULL: the context's RCCL communicator if it has one (ecal_comm_init), else one GPU */
     void *allreduce_user;
     /* distributed != 0 (needs allreduce): every rank owns its OWN spline segments in its own ecal_solver (its residuals,
      * its control points) and only the 9 intrinsics are shared.  Exchanged per evaluation: the 91-double head (cost,
@@ -460,7 +479,7 @@ typedef struct ecal_calib_options {
     double aspect_ratio;  /* Calibrate_FixAspectRatio (used with ECAL_CALIB_FIX_ASPECT_RATIO) */
     int max_iter;         /* 0 = OpenCV's default TermCriteria: 30 (calibrateCamera) / 100 (fisheye) */
     double eps;           /* 0 = DBL_EPSILON */
-    ecal_allreduce_fn allreduce; /* NULL on one GPU; sums a small device buffer over ranks in place (RCCL) */
+    ecal_allreduce_fn allreduce; /* NULL: the context's RCCL communicator if it has one (ecal_comm_init), else one GPU */
     void *allreduce_user;
 } ecal_calib_options;
 typedef struct ecal_calib_result {

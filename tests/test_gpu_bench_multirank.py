@@ -13,12 +13,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(nproc, extra):
+def _bench(nproc, extra, launcher=True):
     env = dict(os.environ, ECAL_BENCH_SINGLE_DEVICE="1", ECAL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
                ECAL_BENCH_SOLVER_CHECK="1")
     args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--events", "2000000", "--cpu-sample", "0",
             "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0", "--ingest-events", "0"] + extra
-    if nproc == 1:
+    if nproc == 1 or not launcher:
+        # exactly what the driver may type: `python bench.py --gpus N ...` — for N > 1 bench.py starts its own ranks under
+        # torch.distributed.run as child processes (before it touches the GPU) and relays rank 0's JSON line
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
@@ -27,6 +29,11 @@ def _bench(nproc, extra):
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
+
+
+def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
+    two = _bench(2, ["--solver-iters", "0", "--calib-views", "0"], launcher=False)
+    assert two["n_gpus"] == 2 and two["config"]["events_per_gpu"] == 2000000 and two["value"] > 0
 
 
 def test_two_ranks_match_one_rank():

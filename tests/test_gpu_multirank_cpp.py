@@ -1,0 +1,48 @@
+"""GPU: libecal.so's multi-rank paths from plain C++ (tests/cpp/test_multirank.cpp), one process per rank:
+the in-library RCCL communicator (ecal_comm_init + ncclAllReduce inside ecal_calibrate_views) and the ecal_allreduce_fn
+callback seam with two ranks on one GPU (shared-memory transport)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import synth_calib as SC
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    d = tmp_path_factory.mktemp("multirank")
+    out = str(d / "test_multirank")
+    lib_dir = os.path.join(ROOT, "eventcalib_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", out,
+                           os.path.join(ROOT, "tests", "cpp", "test_multirank.cpp"), "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir,
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"])
+    obj, img, rv, tv = SC.make_views(24, 0, seed=5, noise_px=0.05)
+    vf = str(d / "views.bin")
+    np.concatenate([[24, obj.shape[0], 0], img.ravel()]).astype(np.float64).tofile(vf)
+    return out, vf, str(d)
+
+
+def _run(exe, mode, world):
+    out, vf, d = exe
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([out, mode, str(world), vf, d], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "multirank ok" in r.stdout and "-> same" in r.stdout
+    return r.stdout
+
+
+def test_callback_allreduce_two_ranks_on_one_gpu(exe):
+    out = _run(exe, "shm", 2)
+    assert "rank 0/2" in out and "rank 1/2" in out
+
+
+def test_rccl_communicator_in_the_library(exe):
+    import torch
+    world = min(2, torch.cuda.device_count())      # RCCL refuses two ranks on one device
+    out = _run(exe, "rccl", world)
+    assert "rank 0/%d" % world in out
