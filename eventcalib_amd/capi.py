@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
     "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
-    "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_lm_default_options",
+    "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
     "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval",
 ]
@@ -368,6 +368,7 @@ class Solver:
         self.n_normal = int(L.ecal_solver_normal_size(h))
         self.n_cp = (self.n_params - 9) // 7
         self.n_chunks = int(L.ecal_solver_num_chunks(h))
+        self.n_res = int(P.n_res)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -386,6 +387,20 @@ class Solver:
         acc = np.zeros(self.n_normal if with_jacobian else 1)
         self.ctx._check(self.ctx._L.ecal_solver_evaluate(self._h, _ptr(p), int(with_jacobian), _ptr(acc)))
         return acc
+
+    def residuals(self, params, with_jacobian=True):
+        """ecal_residuals: (r [n_res], J [n_res, 33] or None, cp0 [n_res]) — the per-residual CostFunction::Evaluate seam."""
+        p = np.ascontiguousarray(params, np.float64)
+        assert p.shape[0] == self.n_params
+        L = self.ctx._L
+        L.ecal_residuals.argtypes = [ctypes.c_void_p] * 5
+        L.ecal_residuals.restype = ctypes.c_int
+        n = int(self.n_res)
+        r = np.zeros(max(n, 1))
+        J = np.zeros((max(n, 1), 33)) if with_jacobian else None
+        c = np.zeros(max(n, 1), np.uint32)
+        self.ctx._check(L.ecal_residuals(self._h, _ptr(p), _ptr(r), _ptr(J) if with_jacobian else None, _ptr(c)))
+        return r[:n], (J[:n] if with_jacobian else None), c[:n]
 
     def evaluate_dev(self, d_params, with_jacobian, d_accum, stream=0):
         self.ctx._check(self.ctx._L.ecal_solver_evaluate_dev(self._h, d_params, int(with_jacobian), d_accum, stream))

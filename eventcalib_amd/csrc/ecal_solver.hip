@@ -216,6 +216,52 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
     }
 }
 
+// The Ceres CostFunction::Evaluate seam (EventCalibSpline.hpp:137-146,231-240 behind AutoDiffCostFunction<..., 1, 9, 4, 4, 4, 4,
+// 3, 3, 3, 3> and the local parameterisations): per residual its raw value (no loss function) and the raw 1 x 33 row of the
+// tangent-space Jacobian, columns [ intrinsics 9 | rotation tangent of control points cp0 .. cp0+3 (3 each) | translation of
+// cp0 .. cp0+3 (3 each) ].  One thread per residual, chunks as in normal_eq_kernel.
+template <bool SO3>
+__global__ __launch_bounds__(NE_T) void residual_rows_kernel(const ResRecord *__restrict__ rec, const Chunk *__restrict__ chunks,
+                                                            const double *__restrict__ knots, const uint32_t *__restrict__ knot_off,
+                                                            const uint32_t *__restrict__ cp_off, const double *__restrict__ params,
+                                                            uint32_t n_cp_total, const double *__restrict__ landmarks, double radius,
+                                                            double *__restrict__ r_out, double *__restrict__ J_out,
+                                                            uint32_t *__restrict__ cp0_out) {
+    const Chunk ch = chunks[blockIdx.x];
+    const double *kn = knots + knot_off[ch.seg];
+    const uint32_t c0 = cp_off[ch.seg] + ch.span - 3;
+    const double *qall = params + 9;
+    const double *tall = params + 9 + 4 * (size_t) n_cp_total;
+    double q[4][4], t[4][3], pin[9], binv[6];
+    for (int i = 0; i < 9; i++) pin[i] = params[i];
+    spline_span_inverses(kn, ch.span, binv);
+    const double ifx = 1.0 / pin[0], ify = 1.0 / pin[1];
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 4; k++) q[j][k] = qall[4 * (size_t) (c0 + j) + k];
+        for (int k = 0; k < 3; k++) t[j][k] = tall[3 * (size_t) (c0 + j) + k];
+    }
+    for (uint32_t k = threadIdx.x; k < ch.count; k += NE_T) {
+        const size_t at = (size_t) ch.start + k;
+        const ResRecord e = rec[at];
+        ResidualInput in;
+        in.u = e.u;
+        in.v = e.v;
+        in.lmx = landmarks[3 * (size_t) e.lm];
+        in.lmy = landmarks[3 * (size_t) e.lm + 1];
+        in.lmz = landmarks[3 * (size_t) e.lm + 2];
+        in.radius = radius;
+        in.ifx = ifx;
+        in.ify = ify;
+        spline_basis_inv(kn, ch.span, binv, e.t, in.b);
+        double J[RES_NJ];
+        const double r = SO3 ? spline_residual_so3(in, pin, q, t, J_out ? J : nullptr) : spline_residual(in, pin, q, t, J_out ? J : nullptr);
+        r_out[at] = r;
+        if (J_out)
+            for (int i = 0; i < RES_NJ; i++) J_out[at * RES_NJ + i] = J[i];
+        if (cp0_out) cp0_out[at] = c0;
+    }
+}
+
 // accum[0..91) = sum over the replicas
 __global__ void reduce_heads_kernel(const double *__restrict__ heads, double *__restrict__ accum, uint32_t n_out) {
     const uint32_t i = threadIdx.x;
@@ -386,6 +432,59 @@ extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, 
                            with_jacobian ? (uint32_t) ACC_HEAD : 1u);
         ECAL_HIP_TRY(ctx, hipGetLastError());
     }
+    return ECAL_OK;
+}
+
+extern "C" int ecal_residuals_dev(ecal_solver *s, const double *d_params, double *d_r, double *d_J, uint32_t *d_cp0, void *stream) {
+    if (!s || !d_params || (s->n_res && !d_r)) return ECAL_ERR_INVALID;
+    ecal_ctx *ctx = s->ctx;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t) stream;
+    if (s->n_chunks) {
+        if (s->use_so3)
+            hipLaunchKernelGGL(residual_rows_kernel<true>, dim3(s->n_chunks), dim3(NE_T), 0, st, s->d_rec, s->d_chunks, s->d_knots,
+                               s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, d_r, d_J, d_cp0);
+        else
+            hipLaunchKernelGGL(residual_rows_kernel<false>, dim3(s->n_chunks), dim3(NE_T), 0, st, s->d_rec, s->d_chunks, s->d_knots,
+                               s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, d_r, d_J, d_cp0);
+        ECAL_HIP_TRY(ctx, hipGetLastError());
+    }
+    return ECAL_OK;
+}
+
+extern "C" int ecal_residuals(ecal_solver *s, const double *params, double *r, double *J, uint32_t *cp0) {
+    if (!s || !params || (s->n_res && !r)) return ECAL_ERR_INVALID;
+    ecal_ctx *ctx = s->ctx;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t n = s->n_res;
+    double *d_r = nullptr, *d_J = nullptr;
+    uint32_t *d_c = nullptr;
+    struct Guard {
+        void *a = nullptr, *b = nullptr, *c = nullptr;
+        ~Guard() {
+            if (a) (void) hipFree(a);
+            if (b) (void) hipFree(b);
+            if (c) (void) hipFree(c);
+        }
+    } g;
+    ECAL_HIP_TRY(ctx, hipMalloc((void **) &d_r, (n ? n : 1) * sizeof(double)));
+    g.a = d_r;
+    if (J) {
+        ECAL_HIP_TRY(ctx, hipMalloc((void **) &d_J, (n ? n : 1) * RES_NJ * sizeof(double)));
+        g.b = d_J;
+    }
+    if (cp0) {
+        ECAL_HIP_TRY(ctx, hipMalloc((void **) &d_c, (n ? n : 1) * sizeof(uint32_t)));
+        g.c = d_c;
+    }
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(s->d_params, params, s->n_params() * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = ecal_residuals_dev(s, s->d_params, d_r, d_J, d_c, st);
+    if (rc) return rc;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(r, d_r, n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (J) ECAL_HIP_TRY(ctx, hipMemcpyAsync(J, d_J, n * RES_NJ * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (cp0) ECAL_HIP_TRY(ctx, hipMemcpyAsync(cp0, d_c, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
     return ECAL_OK;
 }
 

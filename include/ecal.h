@@ -424,6 +424,14 @@ size_t ecal_solver_normal_size(const ecal_solver *s);
 uint32_t ecal_solver_num_chunks(const ecal_solver *s);
 int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum, void *stream);
 int ecal_solver_evaluate(ecal_solver *s, const double *params, int with_jacobian, double *accum);
+/* The Ceres CostFunction::Evaluate seam (CalibReprojectionError{,_SO3}::Create, EventCalibSpline.hpp:137-146,231-240:
+ * AutoDiffCostFunction<..., 1, 9, 4, 4, 4, 4, 3, 3, 3, 3> + EigenQuaternionParameterization / LocalParameterizationSO3) for
+ * every residual of the problem at `params`: r[k] = the raw residual (no loss function); J[k][33] (optional) = the raw row
+ * of the tangent-space Jacobian, columns [ intrinsics 9 | rotation tangent of control points cp0[k] .. cp0[k]+3, 3 each |
+ * translation of the same four, 3 each ]; cp0[k] (optional) = the first of the four control points residual k touches. */
+int ecal_residuals_dev(ecal_solver *s, const double *d_params, double *d_r /*[n_res]*/, double *d_J /*[n_res][33] or NULL*/,
+                       uint32_t *d_cp0 /*[n_res] or NULL*/, void *stream);
+int ecal_residuals(ecal_solver *s, const double *params, double *r, double *J, uint32_t *cp0);
 void ecal_lm_default_options(ecal_lm_options *opt);
 int ecal_solver_solve(ecal_solver *s, double *params /*in: start, out: solution*/, const ecal_lm_options *opt,
                       ecal_lm_summary *summary);

@@ -149,3 +149,53 @@ def test_inverse_radial(ctx):
     from eventcalib_amd.capi import inverse_radial_distortion
     b = inverse_radial_distortion([-0.34991902, -0.014698517, 0.59684463, 0.0])
     assert np.array_equal(b, O.inverse_radial([-0.34991902, -0.014698517, 0.59684463, 0.0]))
+
+
+@pytest.mark.parametrize("use_so3", [False, True])
+def test_per_residual_rows_match_dual_numbers(ctx, use_so3):
+    """ecal_residuals (the Ceres CostFunction::Evaluate seam, EventCalibSpline.hpp:137-146,231-240): raw residual and raw
+    1 x 33 tangent row of EVERY residual against forward-mode dual numbers through the oracle's restated functor +
+    local parameterisation (oracle_residual / oracle_residual_so3); spans and basis values against oracle_find_span /
+    oracle_basis (BsplineReal.hpp:107-145,208-231)."""
+    import ctypes
+    from eventcalib_amd.capi import Solver
+    L = O.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.oracle_find_span.argtypes = [dp, ctypes.c_uint32, ctypes.c_double]
+    L.oracle_find_span.restype = ctypes.c_uint32
+    L.oracle_basis.argtypes = [dp, ctypes.c_uint32, ctypes.c_double, dp]
+    fn = L.oracle_residual_so3 if use_so3 else L.oracle_residual
+    fn.argtypes = [dp, dp, dp, dp, dp, dp, ctypes.c_double, dp, dp]
+    fn.restype = ctypes.c_double
+    n_res, n_cp = 2500, 7
+    rng = np.random.default_rng(91)
+    prob, x = SV.make_problem(n_res, n_cp=n_cp, seed=91, pixel_noise=0.5, use_so3=use_so3)
+    y = SV.perturb(x, n_cp, rng, intr_rel=0.01, rot=0.005, trans=0.2)
+    s = Solver(ctx, prob)
+    r, J, cp0 = s.residuals(y)
+    r_only, none, _ = s.residuals(y, with_jacobian=False)
+    assert none is None and np.array_equal(r_only, r)
+    intr = np.ascontiguousarray(y[:9])
+    q = np.ascontiguousarray(y[9:9 + 4 * n_cp]).reshape(n_cp, 4)
+    t = np.ascontiguousarray(y[9 + 4 * n_cp:]).reshape(n_cp, 3)
+    kn = np.ascontiguousarray(prob["knots"], np.float64)
+    lms = np.ascontiguousarray(prob["landmarks"], np.float64).reshape(-1, 3)
+    p = lambda a: a.ctypes.data_as(dp)
+    worst_r = worst_j = 0.0
+    for k in range(0, n_res, 3):
+        u = float(prob["time"][k])
+        span = L.oracle_find_span(p(kn), n_cp, u)
+        assert cp0[k] == span - 3
+        b4 = np.zeros(4)
+        L.oracle_basis(p(kn), span, u, p(b4))
+        q4 = np.ascontiguousarray(q[span - 3:span + 1]).copy()
+        t4 = np.ascontiguousarray(t[span - 3:span + 1]).copy()
+        obs = np.ascontiguousarray(prob["obs"][k], np.float64).copy()
+        lm = lms[int(prob["lm_id"][k])].copy()
+        J33 = np.zeros(33)
+        rr = fn(p(intr), p(q4), p(t4), p(b4), p(obs), p(lm), float(prob["circle_radius"]), None, p(J33))
+        worst_r = max(worst_r, abs(r[k] - rr))
+        worst_j = max(worst_j, np.abs(J[k] - J33).max() / max(1.0, np.abs(J33).max()))
+    # f64, analytic derivative vs dual numbers: stated tolerance 1e-11 (absolute on r in cm, relative to the row's largest entry on J)
+    assert worst_r < 1e-11 and worst_j < 1e-11, (worst_r, worst_j)
+    s.close()
