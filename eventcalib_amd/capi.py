@@ -12,7 +12,7 @@ _LIB = None
 EXPORTED_SYMBOLS = [
     "ecal_abi_version", "ecal_init", "ecal_destroy", "ecal_strerror", "ecal_last_error", "ecal_sync",
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
-    "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_slice_events_dev",
+    "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_sort_events_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
     "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev",
@@ -224,6 +224,11 @@ class Context:
     def window_bounds_dev(self, d_events, n_events, d_t0, d_t1, S, d_win_lo, d_win_hi, d_win_base, stream=0):
         self._check(self._L.ecal_window_bounds_dev(self._h, d_events, int(n_events), d_t0, d_t1, int(S), d_win_lo,
                                                    d_win_hi, d_win_base, stream))
+
+    def sort_events_dev(self, d_events, n_events, d_sorted, stream=0):
+        self._L.ecal_sort_events_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+        self._L.ecal_sort_events_dev.restype = ctypes.c_int
+        self._check(self._L.ecal_sort_events_dev(self._h, d_events, int(n_events), d_sorted, stream))
 
     def check_sorted_dev(self, d_events, n_events, d_flag, stream=0):
         self._check(self._L.ecal_check_sorted_dev(self._h, d_events, int(n_events), d_flag, stream))

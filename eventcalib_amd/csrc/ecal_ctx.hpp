@@ -27,6 +27,7 @@ struct ecal_ctx {
     ecal_devbuf pxs_todo;  // same for the pixel slicer
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
+    ecal_devbuf sort_scratch;  // ecal_sort_events_dev: keys, indices, radix-sort workspace
     ecal_devbuf bucket_tab;  // reference element order: bucket numbers per sensor pixel (ecal_events.hip)
     bool bucket_tab_built = false;
     ecal_devbuf sl_order, sl_order_big;  // reference element order: scratch of the general slicing tiers (slice_order.hpp)
@@ -52,7 +53,7 @@ struct ecal_ctx {
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
-                &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos, &sl_order, &sl_order_big, &bucket_tab,
+                &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos, &sl_order, &sl_order_big, &bucket_tab, &sort_scratch,
                 &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
                 &host_rect[7], &host_rect[8], &host_rect[9], &host_rect[10],

@@ -49,8 +49,22 @@ extern "C" int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t
     }
     (void) hipFree(d_flag);
     if (rc == ECAL_OK && h_flag) {
-        ctx->last_error = "event timestamps are not non-decreasing";
-        rc = ECAL_ERR_UNSORTED;
+        // not in time order: bring it into the order the reference's multimap iterates in (stable by time stamp,
+        // eventCameraCalib.cpp:154-163) with one device sort
+        uint8_t *d_sorted = nullptr;
+        e = hipMalloc((void **) &d_sorted, bytes);
+        if (e != hipSuccess) {
+            rc = e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
+        } else {
+            rc = ecal_sort_events_dev(ctx, s->d_events, n_events, d_sorted, ctx->stream);
+            if (rc == ECAL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = ECAL_ERR_HIP;
+            if (rc == ECAL_OK) {
+                (void) hipFree(s->d_events);
+                s->d_events = d_sorted;
+            } else {
+                (void) hipFree(d_sorted);
+            }
+        }
     }
     if (rc != ECAL_OK) {
         (void) hipFree(s->d_events);

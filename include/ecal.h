@@ -120,6 +120,11 @@ int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_ev
                            const double *d_t1, uint32_t S, uint32_t *d_win_lo, uint32_t *d_win_hi,
                            uint32_t *d_win_base /*[S+1]*/, void *stream);
 int ecal_check_sorted_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, int *d_flag, void *stream);
+/* d_sorted (n_events * 25 bytes, not overlapping d_events) = the records in the order the reference's
+ * std::multimap<double, Event_loc_pol> iterates in (eventCameraCalib.cpp:154-163): ascending time stamp, records with
+ * equal time stamps in their input order (stable).  For streams that do not arrive in time order; the _dev entry points
+ * above take time-ordered records, ecal_stream_create sorts by itself when it has to. */
+int ecal_sort_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, uint8_t *d_sorted, void *stream);
 int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const uint32_t *d_win_lo,
                           const uint32_t *d_win_hi, const uint32_t *d_win_base, uint32_t S, uint32_t max_win_events,
                           uint32_t cap_points, double *d_xy, uint32_t *d_seg_off /*[2S]*/,
@@ -162,7 +167,8 @@ int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_
  * ecal_stream: the event stream uploaded once and kept in HBM — the counterpart of the reference's
  *   EventContainer (event/include/opengv2/event/EventContainer.hpp:25-30), filled once by the driver
  *   (event_camera_calib/test/eventCameraCalib.cpp:154-163) and shared read-only by all workers.
- *   `events` = packed 25-byte records in time order (ECAL_ERR_UNSORTED otherwise).
+ *   `events` = packed 25-byte records, any order: like the reference's multimap (eventCameraCalib.cpp:154-163) the
+ *   stream is brought into time order (stable for equal time stamps; one device sort, only when it is not sorted already).
  * ecal_detect_batch: for every window [t0[s], t1[s]] the EventFrame constructor followed by
  *   extractFeatures up to the candidate circles (the four device entry points above, in order) and
  *   copies the requested results to host memory.  Every pointer of ecal_detect_result may be NULL

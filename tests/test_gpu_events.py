@@ -333,3 +333,36 @@ def test_golden_eventframe_order_fixtures(env):
             n = int(b[s, 1] - b[s, 0])
             assert np.array_equal(ep[base[s]:base[s] + n], g["event_point"][eo:eo + n]), (f, s)
             eo += n
+
+
+def test_unsorted_stream_is_sorted_like_the_multimap(env):
+    """ecal_sort_events_dev / ecal_stream_create on records in arbitrary order: ascending time stamp, equal time stamps in
+    input order (std::multimap::emplace, eventCameraCalib.cpp:154-163) == numpy's stable argsort; negative, zero (+-0.0) and
+    repeated time stamps included."""
+    ctx, pipe, torch = env
+    rng = np.random.default_rng(8)
+    n = 200_000
+    t = rng.choice(np.concatenate([rng.uniform(-1, 3, 5000), [0.0, -0.0, 1.5, 1.5, 2.0]]), n)   # many equal keys
+    x = np.arange(n, dtype=np.float64)             # the payload identifies the record
+    rec = O.pack_events(t, x, x % 7, (np.arange(n) & 1).astype(np.uint8))
+    d = torch.from_numpy(rec).cuda()
+    out = torch.empty_like(d)
+    ctx.sort_events_dev(d.data_ptr(), n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = rec.reshape(n, 25)[np.argsort(t, kind="stable")]
+    assert np.array_equal(out.cpu().numpy().reshape(n, 25), want)
+    # through the host-pointer entry point: the stream object holds the sorted records
+    import ctypes
+    L = ctx._L
+    L.ecal_stream_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    L.ecal_stream_create.restype = ctypes.c_int
+    L.ecal_stream_data.argtypes = [ctypes.c_void_p]
+    L.ecal_stream_data.restype = ctypes.c_void_p
+    L.ecal_stream_destroy.argtypes = [ctypes.c_void_p]
+    L.ecal_copy_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int]
+    h = ctypes.c_void_p()
+    assert L.ecal_stream_create(ctx._h, rec.ctypes.data, n, ctypes.byref(h)) == 0
+    back = torch.empty(n * 25, dtype=torch.uint8, device="cuda")
+    assert L.ecal_copy_dev(ctx._h, back.data_ptr(), L.ecal_stream_data(h), n * 25, None, 1) == 0
+    assert np.array_equal(back.cpu().numpy().reshape(n, 25), want)
+    L.ecal_stream_destroy(h)
