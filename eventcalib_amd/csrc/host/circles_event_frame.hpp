@@ -12,11 +12,20 @@
 #include <unordered_set>
 
 #include "event.hpp"
+#include "file_settings.hpp"
 
 namespace opengv2 {
 
 struct CirclePatternParameters {
     typedef std::shared_ptr<CirclePatternParameters> Ptr;
+    CirclePatternParameters() = default;
+    explicit CirclePatternParameters(const FileSettings &node) {   // parameters.hpp:15-21
+        node["BoardSize_Cols"] >> cols;
+        node["BoardSize_Rows"] >> rows;
+        node["Square_Size"] >> squareSize;
+        node["Is_Pattern_Asymmetric"] >> isAsymmetric;
+        node["Circles_Radius"] >> circleRadius;
+    }
     bool isAsymmetric = true;
     int rows = 9, cols = 4;
     double squareSize = 5.5, circleRadius = 1.75;
@@ -26,6 +35,13 @@ class CirclesEventFrame : public EventFrame {
 public:
     struct Params {
         Params() : dbscan_eps(4), dbscan_startMinSample(2), clusterMinSample(5), knn_num(3), fitCircle(false) {}
+        explicit Params(const FileSettings &node) : Params() {   // CirclesEventFrame.cpp:42-48
+            node["dbscan_eps"] >> dbscan_eps;
+            node["dbscan_startMinSample"] >> dbscan_startMinSample;
+            node["clusterMinSample"] >> clusterMinSample;
+            node["knn_num"] >> knn_num;
+            node["fitCircle"] >> fitCircle;
+        }
         double dbscan_eps;          // pixel unit
         int dbscan_startMinSample;
         int clusterMinSample;

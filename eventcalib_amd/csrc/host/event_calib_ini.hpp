@@ -27,6 +27,22 @@ struct CalibrationSetting {
     bool fixK1 = false, fixK2 = false, fixK3 = false, fixK4 = true, fixK5 = true;
     uint32_t flag = 0;                    // ECAL_CALIB_* (the reference keeps cv::CALIB_* bits here)
 
+    CalibrationSetting() = default;
+    explicit CalibrationSetting(const FileSettings &node) {   // parameters.hpp:32-46
+        circlePatternParameters = std::make_shared<CirclePatternParameters>(node);
+        node["Calibrate_FixAspectRatio"] >> aspectRatio;
+        node["Calibrate_AssumeZeroTangentialDistortion"] >> calibZeroTangentDist;
+        node["Calibrate_FixPrincipalPointAtTheCenter"] >> calibFixPrincipalPoint;
+        node["Calibrate_UseFisheyeModel"] >> useFisheye;
+        node["Fix_K1"] >> fixK1;
+        node["Fix_K2"] >> fixK2;
+        node["Fix_K3"] >> fixK3;
+        node["Fix_K4"] >> fixK4;
+        node["Fix_K5"] >> fixK5;
+        node["Calibrate_NrOfFrameToUse"] >> NumOfFrameToUse;
+        validate();
+    }
+
     void validate() {  // parameters.hpp:47-69
         flag = 0;
         if (calibFixPrincipalPoint) flag |= ECAL_CALIB_FIX_PRINCIPAL_POINT;

@@ -10,6 +10,44 @@ import synth_stream as SS
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# a settings file with the keys the reference driver reads (eventCameraCalib.cpp:114-207, parameters.hpp:15-43,
+# CirclesEventFrame.cpp:42-48) and the values of the shipped configuration (SURVEY Appendix C.2); PieceNum is the build's
+# own key (the reference derives the piece count from the host's core count)
+SETTINGS_YAML = """%%YAML:1.0
+# event stream
+StartTime: %(start)s
+EndTime: %(end)s      # optional
+MotionTimeStep: 5e-4
+FrameEventNumThreshold: 4000
+Camera.width: 346
+Camera.height: 260
+Is_Pattern_Asymmetric: 1
+BoardSize_Rows: 9
+BoardSize_Cols: 4
+Square_Size: 5.5
+Circles_Radius: 1.75
+Calibrate_NrOfFrameToUse: 200
+Calibrate_UseFisheyeModel: 0
+Calibrate_FixAspectRatio: 1
+Calibrate_AssumeZeroTangentialDistortion: 1
+Calibrate_FixPrincipalPointAtTheCenter: 1
+Fix_K1: 0
+Fix_K2: 0
+Fix_K3: 0
+Fix_K4: 1
+Fix_K5: 1
+dbscan_eps: 4
+dbscan_startMinSample: 2
+clusterMinSample: 5
+knn_num: 3
+fitCircle: 0
+useSO3: 0
+reduceMap: 0
+Viewer.Facing: [ 1,0,0,0,1,0,0,0,1 ]
+Qbs: [ 0, 0, 0, 1 ]
+PieceNum: 30
+"""
+
 
 def test_cpp_shims(tmp_path):
     exe = str(tmp_path / "test_shims")
@@ -97,7 +135,9 @@ def test_cpp_driver_chain(tmp_path):
         SS.TRAJECTORY = "hover"
     binf = str(tmp_path / "events.bin")
     buf.numpy().tofile(binf)
-    out = subprocess.run([exe, binf, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    yamlf = str(tmp_path / "settings.yaml")
+    open(yamlf, "w").write(SETTINGS_YAML % dict(start=5, end=8))
+    out = subprocess.run([exe, yamlf, binf, str(tmp_path)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = out.stdout.splitlines()
     init = lines[1].split()
