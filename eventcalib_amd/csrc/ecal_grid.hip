@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned long long pack_key(double d2, uint32_t idx) 
 __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__restrict__ win_info,
                                                           const uint32_t *__restrict__ seg_off,
                                                           const double *__restrict__ cand_xyr, uint32_t rows,
-                                                          uint32_t cols, double tol_frac, int32_t *__restrict__ order,
+                                                          uint32_t cols, double tol_frac, double tol_px, int32_t *__restrict__ order,
                                                           uint32_t *__restrict__ found) {
     __shared__ double px[GR_MAXC], py[GR_MAXC];
     __shared__ double e1x[GR_MAXC], e1y[GR_MAXC], e2x[GR_MAXC], e2y[GR_MAXC];  // local lattice basis per node
@@ -149,7 +149,10 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             if (r == ~0ull) continue;
             const uint32_t j = (uint32_t) (r & 0xFFu);
             const double ddx = px[j] - tx, ddy = py[j] - ty;
-            const double lim = tol_frac * tol_frac * (sxp * sxp + syp * syp);
+            // the vendored finder takes the nearest keypoint within minDistanceToAddKeypoint = 20 px of (neighbour + basis
+            // vector) as the hole, else the line stays incomplete (circlesgrid.cpp:528,812-840,928-930: a synthetic
+            // keypoint earns no existingVertexGain); capped at tol_frac of the step for small apparent patterns
+            const double lim = fmin(tol_px * tol_px, tol_frac * tol_frac * (sxp * sxp + syp * syp));
             if (ddx * ddx + ddy * ddy > lim) continue;
             if (lane == 0) {
                 assigned[j] = 1;
@@ -228,8 +231,10 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
         return ECAL_ERR_INVALID;
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const char *tol_env = getenv("ECAL_GRID_TOL_PX");   // debug switch (tests of the tolerance's effect); default = the reference's 20 px
+    const double tol_px = tol_env ? atof(tol_env) : 20.0;
     hipLaunchKernelGGL(grid_order_kernel, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
-                       d_cand_xyr, rows, cols, 0.4, d_order, d_found);
+                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
