@@ -179,16 +179,40 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
         for (int w = 0; w < NE_T / 64; w++) c += red[w];
         atomicAdd(&head[0], c);
     }
-    if (!with_jac || grp >= NE_GROUPS) return;
-    // flush this thread's tile into the global block storage
+    if (!with_jac) return;
+    // the row groups' partial tiles are summed in LDS (the row buffer is free now) so that ONE group flushes: the
+    // FP64 atomics of a chunk drop from NE_GROUPS x ~600 to ~600 (they were 0.67 GB of write traffic per launch)
+    {
+        constexpr int TSZ = NE_TW * NE_TW, NPART = NE_TILES * TSZ;
+        double *part = rows;                         // [NE_GROUPS][NE_TILES * TSZ]
+        double *total = rows;                        // (in place of group 0's slice: entry e is read and written by ONE thread)
+        static_assert(NE_GROUPS * NPART <= NE_T * NE_LD, "the row buffer holds the partial tiles");
+        __syncthreads();
+        if (grp < NE_GROUPS) {
 #pragma unroll
-    for (int x = 0; x < NE_TW; x++) {
+            for (int i = 0; i < TSZ; i++) part[(size_t) grp * NPART + (tid % NE_TILES) * TSZ + i] = acc[i];
+        }
+        __syncthreads();
+        for (int e = tid; e < NPART; e += NE_T) {    // every thread sums a few entries over the groups
+            double v = 0.0;
 #pragma unroll
-        for (int y = 0; y < NE_TW; y++) {
-            const int li = NE_TW * ti + x, lj = NE_TW * tj + y;
-            if (li > lj || lj >= 34 || li >= 33) continue;
-            const double v = acc[NE_TW * x + y];
+            for (int g = 0; g < NE_GROUPS; g++) v += part[(size_t) g * NPART + e];
+            total[e] = v;
+        }
+        __syncthreads();
+        // flush: one entry of the summed tiles per thread and turn (not a tile per thread: nothing of acc[] stays live)
+        for (int e = tid; e < NPART; e += NE_T) {
+            const double v = total[e];
             if (v == 0.0) continue;
+            const int tile = e / TSZ, x = (e % TSZ) / NE_TW, y = e % NE_TW;
+            int fi = 0, rem = tile;   // tile -> (fi, fj), fi <= fj, rows of the upper triangle
+            for (fi = 0; fi < NE_TG; fi++) {
+                if (rem < NE_TG - fi) break;
+                rem -= NE_TG - fi;
+            }
+            const int fj = fi + rem;
+            const int li = NE_TW * fi + x, lj = NE_TW * fj + y;
+            if (li > lj || lj >= 34 || li >= 33) continue;
             bool ia, ib;
             uint32_t ca, ka, cb, kb;
             local_to_unknown(li, c0, ia, ca, ka);
