@@ -199,3 +199,48 @@ def test_per_residual_rows_match_dual_numbers(ctx, use_so3):
     # f64, analytic derivative vs dual numbers: stated tolerance 1e-11 (absolute on r in cm, relative to the row's largest entry on J)
     assert worst_r < 1e-11 and worst_j < 1e-11, (worst_r, worst_j)
     s.close()
+
+
+@pytest.mark.parametrize("n_cp,n_res", [(4, 2000), (9, 3000), (27, 6000), (50, 12000), (131, 30000), (700, 150000)])
+def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
+    """The partitioned banded-arrow Cholesky on the device (arrow_device.hpp: interiors in parallel, separators' reduced
+    system, intrinsics, back substitution) against the sequential host factorisation of the same scaled, damped system:
+    f64, different elimination order -> relative 1e-8 on the step."""
+    import ctypes
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(n_cp)
+    prob, x = SV.make_problem(n_res, n_cp=n_cp, seed=n_cp, pixel_noise=0.5)
+    y = SV.perturb(x, n_cp, rng, intr_rel=0.01, rot=0.005, trans=0.2)
+    s = Solver(ctx, prob)
+    acc = np.ascontiguousarray(s.evaluate(y, True))
+    nt = 6 * n_cp + 9
+    L = ctx._L
+    L.ecal_debug_arrow_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    L.ecal_debug_arrow_solve.restype = ctypes.c_int
+    from eventcalib_amd.capi import unpack_normal
+    cost, g, H = unpack_normal(acc, n_cp)
+    # unknown order of the dense form: [intr 9 | cp ...]; of the solver: [cp ... | intr 9]
+    diag = np.concatenate([np.diag(H)[9:], np.diag(H)[:9]])
+    scale = np.ascontiguousarray(1.0 / (1.0 + np.sqrt(diag)))
+    for radius in (1e4, 3.0):
+        out = []
+        for dev in (0, 1):
+            d = np.zeros(nt)
+            fail = ctypes.c_int(-1)
+            rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d.ctypes.data, ctypes.byref(fail), dev)
+            assert rc == 0 and fail.value == 0, (rc, fail.value, dev)
+            out.append(d)
+        host, devd = out
+        assert np.abs(host).max() > 0
+        assert np.abs(devd - host).max() <= 1e-8 * np.abs(host).max(), (n_cp, radius, np.abs(devd - host).max(), np.abs(host).max())
+        # and it solves the system: (S A S + D) y = -S g, checked densely for the small cases
+        if n_cp <= 50:
+            perm = np.concatenate([np.arange(9, nt), np.arange(9)])
+            A = H[np.ix_(perm, perm)]
+            gg = g[perm]
+            As = A * scale[:, None] * scale[None, :]
+            D = np.clip(np.diag(As), 1e-6, 1e32) / radius
+            yy = np.linalg.solve(As + np.diag(D), -gg * scale)
+            assert np.abs(devd - yy * scale).max() <= 1e-7 * np.abs(yy * scale).max()
+    s.close()
