@@ -82,103 +82,254 @@ __device__ __forceinline__ double ar_wave_sum_to_last(double v) {
     return v;
 }
 
-// One wavefront: Cholesky of a banded matrix of n rows (band BWT incl. the diagonal, zero outside blocks of BLK: a column of
-// block column J reaches down to the last row of block J + BWT / BLK - 1) with NB border columns carried along:
-//   L L^T = band,  Z = L^-1 border.   load(i, row) fills the LDS row [BWT + NB] of matrix row i (band offsets 0 .. BWT-1:
-// A(i, i-k); then the border).  Finished rows go to L_out [n][BWT] / Z_out [n][NB]; G (NB x NB, upper, row-major full
-// storage) receives Z^T Z.  win: (BWT + BLK) x (BWT + NB) doubles of LDS: the BWT rows a column reaches plus one block of
-// rows loaded ahead — a freed block of slots is refilled with ONE batch of global loads per block column (a row per column
-// step would expose a memory round trip per step).  Returns false when a pivot is not positive.
-template <int BWT, int NB, int BLK, class Loader>
-__device__ bool band_border_factor(uint32_t n, Loader load, double *__restrict__ L_out, double *__restrict__ Z_out,
-                                   double *__restrict__ G_out, double *win, double *colv) {
-    constexpr int W = BWT + NB;
-    constexpr int NG = NB * (NB + 1) / 2, GPL = (NG + 63) / 64;
+#ifdef ECAL_PHASE_PROF
+__device__ unsigned long long g_ar_cycles[8];
+#define AR_MARK(i)                                                                       \
+    do {                                                                                 \
+        if (lane == 0 && blockIdx.x == 0) {                                              \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime();               \
+            atomicAdd(&g_ar_cycles[i], now__ - ar_t__);                                  \
+            ar_t__ = now__;                                                              \
+        }                                                                                \
+    } while (0)
+#else
+#define AR_MARK(i)
+#endif
+
+// One wavefront: Cholesky of a banded matrix of n rows (n a multiple of BLK; band BWT incl. the diagonal, BWT a multiple of
+// BLK, zero outside blocks of BLK: a column of block column J reaches down to the last row of block J + BWT / BLK - 1) with
+// NB border columns carried along:   L L^T = band,  Z = L^-1 border.
+// fetch(i, c) returns entry c of the stored row [BWT + NB] of matrix row i (band offsets 0 .. BWT-1: A(i, i-k); then the
+// border) — a pure function, so that a block of rows is requested with ALL its global loads in flight at once.  Finished
+// rows go to L_out [n][BWT] / Z_out [n][NB]; with WITH_G, G_out (NB x NB, full storage) receives Z^T Z.
+// BLOCK steps: a chain of scalar column steps costs a few hundred instructions of overhead per column; here a block column
+// (BLK scalar columns) is one step —
+//   1. the diagonal block and its BLK pivot rows are finished by scalar steps confined to those rows;
+//   2. every row below (RB = BWT - BLK of them, one lane each) gets its BLK entries of the block column by forward
+//      substitution against the diagonal block: the panel pn[RB][BLK];
+//   3. the trailing update  row_i -= pn[i] . (pn[c] | Z_pivot[.][c])  with ONE LANE PER COLUMN of the window row (RB band
+//      columns + NB border columns: 64 lanes for the interiors): the lane's BLK factors stay in registers, pn[i] is a
+//      broadcast read, one LDS read-modify-write per row and lane.
+// win: (BWT + BLK) x (BWT + NB) doubles of LDS (a freed block of slots is refilled with one batch of loads), pn: RB x BLK.
+// Returns false when a pivot is not positive.
+template <int BWT, int NB, int BLK, bool WITH_G, class Loader>
+__device__ bool band_border_factor(uint32_t n, Loader fetch, double *__restrict__ L_out, double *__restrict__ Z_out,
+                                   double *__restrict__ G_out, double *win, double *colv, double *pn) {
+    constexpr int W = BWT + NB, RB = BWT - BLK;
+    constexpr uint32_t WR = (uint32_t) (BWT + BLK);
+    static_assert(RB + NB <= 64 && BWT % BLK == 0, "one lane per column of the trailing update");
+    constexpr int NG = NB * (NB + 1) / 2;
+    static_assert(!WITH_G || NG <= 64, "G: one entry per lane");
     const uint32_t lane = threadIdx.x & 63u;
-    // this lane's entries of the upper triangle of G
-    double g[GPL];
-    uint32_t ga[GPL], gb[GPL];
-#pragma unroll
-    for (int m = 0; m < GPL; m++) {
-        g[m] = 0.0;
-        uint32_t e = lane + 64u * m, a = 0;
-        if (e >= (uint32_t) NG) e = 0;   // (idle slot: recomputes entry 0, never written)
-        while (e >= (uint32_t) NB - a) {
-            e -= (uint32_t) NB - a;
-            a++;
+    double g = 0.0;
+    uint32_t ga = 0, gb = 0;
+    if (WITH_G) {
+        uint32_t e = lane < (uint32_t) NG ? lane : 0u;
+        while (e >= (uint32_t) NB - ga) {
+            e -= (uint32_t) NB - ga;
+            ga++;
         }
-        ga[m] = a;
-        gb[m] = a + e;
+        gb = ga + e;
     }
-    constexpr uint32_t WR = (uint32_t) (BWT + BLK);   // window rows
-    for (uint32_t i = 0; i < WR && i < n; i++) load(i, win + (size_t) (i % WR) * W);
-    ar_wave_sync();
-    bool ok = true;
-    for (uint32_t j = 0; j < n; j++) {
-        double *rowj = win + (size_t) (j % WR) * W;
-        const double piv = rowj[0];
-        if (!(piv > 0.0)) {
-            ok = false;
-            break;
-        }
-        const double d = sqrt(piv), inv = 1.0 / d;
-        const uint32_t reach = (uint32_t) BWT - 1u - (j % (uint32_t) BLK);
-        const uint32_t rmax = reach < n - 1u - j ? reach : n - 1u - j;
-        ar_wave_sync();   // (everyone has read the pivot)
-        if (lane == 0) rowj[0] = d;
-        for (uint32_t c = lane; c < (uint32_t) NB; c += 64u) rowj[BWT + c] *= inv;
-        for (uint32_t r = 1u + lane; r <= rmax; r += 64u) {
-            double *rr = win + (size_t) ((j + r) % WR) * W;
-            const double v = rr[r] * inv;
-            rr[r] = v;
-            colv[r] = v;
-        }
-        ar_wave_sync();
-        // rank-1 update of the rows below.  A lane owns one column of the window row (two for the first W - 64 lanes): band
-        // column c = t + 1 (t < BWT: entry (r, c) sits at offset r - c, rows r >= c only) or border column t; its factor from
-        // the pivot row stays in a register, the rows' multipliers are broadcast reads.
-        {
-            const uint32_t t0 = lane, t1 = lane + 64u;
-            const double p0 = t0 < (uint32_t) BWT ? (t0 + 1u <= rmax ? colv[t0 + 1u] : 0.0) : rowj[t0 < (uint32_t) W ? t0 : 0];
-            const double p1 = t1 < (uint32_t) W ? (t1 < (uint32_t) BWT ? (t1 + 1u <= rmax ? colv[t1 + 1u] : 0.0) : rowj[t1]) : 0.0;
-            for (uint32_t r = 1; r <= rmax; r++) {
-                double *rr = win + (size_t) ((j + r) % WR) * W;
-                const double lr = colv[r];
-                if (t0 < (uint32_t) W) {
-                    if (t0 >= (uint32_t) BWT) rr[t0] -= lr * p0;
-                    else if (t0 + 1u <= r) rr[r - t0 - 1u] -= lr * p0;
-                }
-                if (t1 < (uint32_t) W) {
-                    if (t1 >= (uint32_t) BWT) rr[t1] -= lr * p1;
-                    else if (t1 + 1u <= r) rr[r - t1 - 1u] -= lr * p1;
-                }
+    constexpr int CPL = (W + 63) / 64;   // stored columns per lane
+    double tmp[BLK][CPL];                // a block of rows on its way from global memory to the window
+    auto fetch_block = [&](uint32_t i0) {   // rows i0 .. i0 + BLK - 1: all loads issued together
+#pragma unroll
+        for (int q = 0; q < BLK; q++)
+#pragma unroll
+            for (int m = 0; m < CPL; m++) {
+                const uint32_t c = lane + 64u * m;
+                tmp[q][m] = (i0 + q < n && c < (uint32_t) W) ? fetch(i0 + (uint32_t) q, c) : 0.0;
+            }
+    };
+    auto store_block = [&](uint32_t i0, uint32_t slot) {
+#pragma unroll
+        for (int q = 0; q < BLK; q++) {
+            uint32_t sl = slot + (uint32_t) q;
+            if (sl >= WR) sl -= WR;
+#pragma unroll
+            for (int m = 0; m < CPL; m++) {
+                const uint32_t c = lane + 64u * m;
+                if (i0 + q < n && c < (uint32_t) W) win[(size_t) sl * W + c] = tmp[q][m];
             }
         }
-        // row j is final: out it goes, its border adds to G
-        for (uint32_t c = lane; c < (uint32_t) W; c += 64u) {
-            if (c < (uint32_t) BWT) L_out[(size_t) j * BWT + c] = rowj[c];
-            else Z_out[(size_t) j * NB + (c - BWT)] = rowj[c];
-        }
-#pragma unroll
-        for (int m = 0; m < GPL; m++) g[m] += rowj[BWT + ga[m]] * rowj[BWT + gb[m]];
-        ar_wave_sync();
-        if ((j + 1u) % (uint32_t) BLK == 0u) {   // a block column is done: its BLK slots take the next BLK rows, loaded together
-            for (uint32_t q = 0; q < (uint32_t) BLK; q++) {
-                const uint32_t i = j + 1u - (uint32_t) BLK + q + WR;
-                if (i < n) load(i, win + (size_t) (i % WR) * W);
+    };
+    for (uint32_t i = 0; i < WR && i < n; i += (uint32_t) BLK) {
+        fetch_block(i);
+        store_block(i, i % WR);
+    }
+    ar_wave_sync();
+    bool ok = true;
+#ifdef ECAL_PHASE_PROF
+    unsigned long long ar_t__ = __builtin_amdgcn_s_memtime();
+#endif
+    uint32_t slot0 = 0;   // window slot of row j0
+    for (uint32_t j0 = 0; j0 < n && ok; j0 += (uint32_t) BLK) {
+        auto rowp = [&](uint32_t r) -> double * {   // window row of matrix row j0 + r (r < WR)
+            uint32_t sl = slot0 + r;
+            if (sl >= WR) sl -= WR;
+            return win + (size_t) sl * W;
+        };
+        const bool more = j0 + WR < n;
+        AR_MARK(0);
+        if (more) fetch_block(j0 + WR);   // the rows that will take this block's slots: requested now, stored at the end
+        AR_MARK(1);
+        // 1. the pivot rows
+        for (uint32_t q = 0; q < (uint32_t) BLK; q++) {
+            double *rowj = rowp(q);
+            const double piv = rowj[0];
+            if (!(piv > 0.0)) {
+                ok = false;
+                break;
+            }
+            const double d = sqrt(piv), inv = 1.0 / d;
+            const uint32_t rin = (uint32_t) BLK - 1u - q;   // rows of the block below the pivot
+            ar_wave_sync();
+            if (lane == 0) {
+                rowj[0] = d;
+                colv[BWT + q] = inv;   // (kept for the panel solve: multiplications instead of divisions)
+            }
+            if (lane < (uint32_t) NB) rowj[BWT + lane] *= inv;
+            if (lane >= 1u && lane <= rin) {
+                double *rr = rowp(q + lane);
+                const double v = rr[lane] * inv;
+                rr[lane] = v;
+                colv[lane] = v;
+            }
+            ar_wave_sync();
+            // lane t < BLK - 1: band column c = t + 1 of the block; lanes BLK .. BLK + NB - 1: the border columns
+            if (lane < rin) {
+                const double pc = colv[lane + 1u];
+                for (uint32_t r = lane + 1u; r <= rin; r++) rowp(q + r)[r - lane - 1u] -= colv[r] * pc;
+            } else if (lane >= (uint32_t) BLK && lane < (uint32_t) (BLK + NB)) {
+                const uint32_t bc = (uint32_t) BWT + lane - (uint32_t) BLK;
+                const double pz = rowj[bc];
+                for (uint32_t r = 1; r <= rin; r++) rowp(q + r)[bc] -= colv[r] * pz;
             }
             ar_wave_sync();
         }
-    }
+        if (!ok) break;
+        AR_MARK(2);
+        const uint32_t left = n - j0 - (uint32_t) BLK, nr = left < (uint32_t) RB ? left : (uint32_t) RB;   // rows below
+        // 2. the panel: row j0 + BLK + ri solves  pn[ri] Ld^T = A(row, block)
+        if (lane < nr) {
+            double *rr = rowp((uint32_t) BLK + lane);
+            double x[BLK];
 #pragma unroll
-    for (int m = 0; m < GPL; m++) {
-        const uint32_t e = lane + 64u * m;
-        if (e < (uint32_t) NG) {
-            G_out[ga[m] * NB + gb[m]] = g[m];
-            G_out[gb[m] * NB + ga[m]] = g[m];
+            for (int q = 0; q < BLK; q++) {
+                const double *pq = rowp((uint32_t) q);
+                double v = rr[(uint32_t) BLK + lane - (uint32_t) q];
+#pragma unroll
+                for (int q2 = 0; q2 < q; q2++) v -= x[q2] * pq[q - q2];
+                x[q] = v * colv[BWT + q];
+                rr[(uint32_t) BLK + lane - (uint32_t) q] = x[q];
+                pn[lane * BLK + q] = x[q];
+            }
         }
+        ar_wave_sync();
+        AR_MARK(3);
+        // 3. trailing update, one lane per column
+        if (nr) {
+            double mine[BLK];
+            const bool is_band = lane < (uint32_t) RB, is_border = lane >= (uint32_t) RB && lane < (uint32_t) (RB + NB);
+#pragma unroll
+            for (int q = 0; q < BLK; q++) {
+                mine[q] = 0.0;
+                if (is_band && lane < nr) mine[q] = pn[lane * BLK + q];
+                else if (is_border) mine[q] = rowp((uint32_t) q)[(uint32_t) BWT + lane - (uint32_t) RB];
+            }
+            // (all the window reads first, then the writes: nothing here aliases, but the compiler cannot know that)
+            double upd[RB];
+#pragma unroll
+            for (int ri = 0; ri < RB; ri++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < BLK; q++) acc += pn[ri * BLK + q] * mine[q];
+                const double *rr = rowp((uint32_t) BLK + (uint32_t) ri);
+                double old = 0.0;
+                if ((uint32_t) ri < nr) {
+                    if (is_band) {
+                        if (lane <= (uint32_t) ri) old = rr[(uint32_t) ri - lane];
+                    } else if (is_border) {
+                        old = rr[(uint32_t) BWT + lane - (uint32_t) RB];
+                    }
+                }
+                upd[ri] = old - acc;
+            }
+#pragma unroll
+            for (int ri = 0; ri < RB; ri++) {
+                double *rr = rowp((uint32_t) BLK + (uint32_t) ri);
+                if ((uint32_t) ri < nr) {
+                    if (is_band) {
+                        if (lane <= (uint32_t) ri) rr[(uint32_t) ri - lane] = upd[ri];
+                    } else if (is_border) {
+                        rr[(uint32_t) BWT + lane - (uint32_t) RB] = upd[ri];
+                    }
+                }
+            }
+        }
+        AR_MARK(4);
+        // the BLK pivot rows are final: out they go
+        for (uint32_t q = 0; q < (uint32_t) BLK; q++) {
+            const double *rowj = rowp(q);
+            for (uint32_t c = lane; c < (uint32_t) W; c += 64u) {
+                if (c < (uint32_t) BWT) L_out[(size_t) (j0 + q) * BWT + c] = rowj[c];
+                else Z_out[(size_t) (j0 + q) * NB + (c - BWT)] = rowj[c];
+            }
+            if (WITH_G) g += rowj[BWT + ga] * rowj[BWT + gb];
+        }
+        ar_wave_sync();
+        AR_MARK(5);
+        if (more) store_block(j0 + WR, slot0);
+        ar_wave_sync();
+        AR_MARK(6);
+        slot0 += (uint32_t) BLK;
+        if (slot0 >= WR) slot0 -= WR;
+    }
+    if (WITH_G && lane < (uint32_t) NG) {
+        G_out[ga * NB + gb] = g;
+        G_out[gb * NB + ga] = g;
     }
     return ok;
+}
+
+// G_p = Z^T Z of every interior (46 x 46, full storage): rows staged through LDS, a few entries per thread
+__global__ __launch_bounds__(256) void arrow_gram_kernel(ArrowPlan plan, const double *__restrict__ Zfac, double *__restrict__ Gp) {
+    constexpr int TR = 32, NG = AR_NB * (AR_NB + 1) / 2, EPT = (NG + 255) / 256;
+    __shared__ double zt[TR * AR_NB];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lo = 6u * plan.int_lo(p), n = 6u * plan.int_hi(p) - lo;
+    uint32_t ea[EPT], eb[EPT];
+    double acc[EPT];
+#pragma unroll
+    for (int m = 0; m < EPT; m++) {
+        acc[m] = 0.0;
+        uint32_t e = tid + 256u * m, a = 0;
+        if (e >= (uint32_t) NG) e = 0;
+        while (e >= (uint32_t) AR_NB - a) {
+            e -= (uint32_t) AR_NB - a;
+            a++;
+        }
+        ea[m] = a;
+        eb[m] = a + e;
+    }
+    for (uint32_t r0 = 0; r0 < n; r0 += TR) {
+        const uint32_t nr = n - r0 < (uint32_t) TR ? n - r0 : (uint32_t) TR;
+        for (uint32_t k = tid; k < nr * AR_NB; k += 256u) zt[k] = Zfac[(size_t) (lo + r0) * AR_NB + k];
+        __syncthreads();
+        for (uint32_t r = 0; r < nr; r++) {
+#pragma unroll
+            for (int m = 0; m < EPT; m++) acc[m] += zt[r * AR_NB + ea[m]] * zt[r * AR_NB + eb[m]];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < EPT; m++) {
+        if (tid + 256u * m < (uint32_t) NG) {
+            Gp[(size_t) p * AR_NB * AR_NB + ea[m] * AR_NB + eb[m]] = acc[m];
+            Gp[(size_t) p * AR_NB * AR_NB + eb[m] * AR_NB + ea[m]] = acc[m];
+        }
+    }
 }
 
 // Jacobi column scaling from the initial normal matrix, as Ceres computes it once: 1 / (1 + sqrt(diagonal))
@@ -192,39 +343,38 @@ __global__ void arrow_scale_kernel(const double *__restrict__ acc, uint32_t n_cp
 // 1. the interiors
 __global__ __launch_bounds__(64) void arrow_interior_kernel(const double *__restrict__ acc, const double *__restrict__ scale,
                                                             ArrowPlan plan, ArrowLm lm, double *__restrict__ Lfac,
-                                                            double *__restrict__ Zfac, double *__restrict__ Gp, int *fail) {
+                                                            double *__restrict__ Zfac, int *fail) {
     __shared__ double win[(AR_BW + 6) * (AR_BW + AR_NB)];
-    __shared__ double colv[AR_BW];
+    __shared__ double colv[AR_BW + 6];
+    __shared__ double pn[(AR_BW - 6) * 6];
     const uint32_t p = blockIdx.x, lane = threadIdx.x;
     const uint32_t lo = 6u * plan.int_lo(p), hi = 6u * plan.int_hi(p), n = hi - lo, nc = 6u * plan.n_cp;
     const bool has_left = p > 0, has_right = p + 1 < plan.P;
-    auto load = [&](uint32_t i, double *row) {
+    auto load = [&](uint32_t i, uint32_t c) -> double {
         const uint32_t gi = lo + i;
         const double si = scale[gi];
-        for (uint32_t c = lane; c < (uint32_t) (AR_BW + AR_NB); c += 64u) {
-            double v = 0.0;
-            if (c < (uint32_t) AR_BW) {                      // band: columns inside the interior
-                if (c <= i) {
-                    v = ar_band(acc, gi, gi - c) * si * scale[gi - c];
-                    if (c == 0) v += ar_lm_diag(v, lm);
-                }
-            } else if (c < (uint32_t) (AR_BW + AR_SEP)) {    // left separator: the 18 columns in front of the interior
-                const uint32_t a = c - AR_BW, col = lo - AR_SEP + a;
-                if (has_left && gi - col < (uint32_t) AR_BW) v = ar_band(acc, gi, col) * si * scale[col];
-            } else if (c < (uint32_t) (AR_BW + 2 * AR_SEP)) {   // right separator: its rows reach back into the interior
-                const uint32_t a = c - AR_BW - AR_SEP, rw = hi + a;
-                if (has_right && rw - gi < (uint32_t) AR_BW) v = ar_band(acc, rw, gi) * si * scale[rw];
-            } else if (c < (uint32_t) (AR_BW + 2 * AR_SEP + 9)) {
-                const int jx = (int) (c - AR_BW - 2 * AR_SEP);
-                v = ar_border(acc, gi, jx) * si * scale[nc + jx];
-            } else {
-                v = -ar_gc(acc, gi) * si;
+        double v = 0.0;
+        if (c < (uint32_t) AR_BW) {                      // band: columns inside the interior
+            if (c <= i) {
+                v = ar_band(acc, gi, gi - c) * si * scale[gi - c];
+                if (c == 0) v += ar_lm_diag(v, lm);
             }
-            row[c] = v;
+        } else if (c < (uint32_t) (AR_BW + AR_SEP)) {    // left separator: the 18 columns in front of the interior
+            const uint32_t a = c - AR_BW, col = lo - AR_SEP + a;
+            if (has_left && gi - col < (uint32_t) AR_BW) v = ar_band(acc, gi, col) * si * scale[col];
+        } else if (c < (uint32_t) (AR_BW + 2 * AR_SEP)) {   // right separator: its rows reach back into the interior
+            const uint32_t a = c - AR_BW - AR_SEP, rw = hi + a;
+            if (has_right && rw - gi < (uint32_t) AR_BW) v = ar_band(acc, rw, gi) * si * scale[rw];
+        } else if (c < (uint32_t) (AR_BW + 2 * AR_SEP + 9)) {
+            const int jx = (int) (c - AR_BW - 2 * AR_SEP);
+            v = ar_border(acc, gi, jx) * si * scale[nc + jx];
+        } else {
+            v = -ar_gc(acc, gi) * si;
         }
+        return v;
     };
-    const bool ok = band_border_factor<AR_BW, AR_NB, 6>(n, load, Lfac + (size_t) lo * AR_BW, Zfac + (size_t) lo * AR_NB,
-                                                         Gp + (size_t) p * AR_NB * AR_NB, win, colv);
+    const bool ok = band_border_factor<AR_BW, AR_NB, 6, false>(n, load, Lfac + (size_t) lo * AR_BW, Zfac + (size_t) lo * AR_NB, nullptr, win,
+                                                                colv, pn);
     if (!ok && lane == 0) atomicExch(fail, 1);
 }
 
@@ -234,41 +384,40 @@ __global__ __launch_bounds__(64) void arrow_reduced_kernel(const double *__restr
                                                            double *__restrict__ Lred, double *__restrict__ Zred,
                                                            double *__restrict__ Gtot /*[100]*/, int *fail) {
     __shared__ double win[(AR_RBW + AR_SEP) * (AR_RBW + AR_RNB)];
-    __shared__ double colv[AR_RBW];
+    __shared__ double colv[AR_RBW + AR_SEP];
+    __shared__ double pn[(AR_RBW - AR_SEP) * AR_SEP];
     __shared__ double Gred[AR_RNB * AR_RNB];
     const uint32_t lane = threadIdx.x, nc = 6u * plan.n_cp, n = plan.n_red();
     auto G = [&](uint32_t p, uint32_t a, uint32_t b) { return Gp[(size_t) p * AR_NB * AR_NB + a * AR_NB + b]; };
-    auto load = [&](uint32_t r, double *row) {
+    auto load = [&](uint32_t r, uint32_t c) -> double {
         const uint32_t s = r / AR_SEP, a = r % AR_SEP;           // separator s sits between the partitions s and s + 1
         const uint32_t gi = 6u * plan.int_hi(s) + a;
         const double si = scale[gi];
-        for (uint32_t c = lane; c < (uint32_t) (AR_RBW + AR_RNB); c += 64u) {
-            double v = 0.0;
-            if (c < (uint32_t) AR_RBW) {
-                if (c <= r) {
-                    const uint32_t rc = r - c, s2 = rc / AR_SEP, a2 = rc % AR_SEP;
-                    if (s2 == s) {   // inside the separator: its own coupling minus both neighbours' Schur contributions
-                        const uint32_t gcol = gi - c;
-                        v = ar_band(acc, gi, gcol) * si * scale[gcol];
-                        if (c == 0) v += ar_lm_diag(v, lm);
-                        v -= G(s, AR_SEP + a, AR_SEP + a2) + G(s + 1, a, a2);
-                    } else if (s2 + 1u == s) {   // the previous separator: coupled through the interior between them only
-                        v = -G(s, AR_SEP + a, a2);
-                    }                            // (band offsets that reach a separator further back: zero)
-                }
-            } else if (c < (uint32_t) (AR_RBW + 9)) {
-                const uint32_t jx = c - AR_RBW;
-                v = ar_border(acc, gi, (int) jx) * si * scale[nc + jx] - G(s, AR_SEP + a, 2 * AR_SEP + jx) - G(s + 1, a, 2 * AR_SEP + jx);
-            } else {
-                v = -ar_gc(acc, gi) * si - G(s, AR_SEP + a, 2 * AR_SEP + 9) - G(s + 1, a, 2 * AR_SEP + 9);
+        double v = 0.0;
+        if (c < (uint32_t) AR_RBW) {
+            if (c <= r) {
+                const uint32_t rc = r - c, s2 = rc / AR_SEP, a2 = rc % AR_SEP;
+                if (s2 == s) {   // inside the separator: its own coupling minus both neighbours' Schur contributions
+                    const uint32_t gcol = gi - c;
+                    v = ar_band(acc, gi, gcol) * si * scale[gcol];
+                    if (c == 0) v += ar_lm_diag(v, lm);
+                    v -= G(s, AR_SEP + a, AR_SEP + a2) + G(s + 1, a, a2);
+                } else if (s2 + 1u == s) {   // the previous separator: coupled through the interior between them only
+                    v = -G(s, AR_SEP + a, a2);
+                }                            // (band offsets that reach a separator further back: zero)
             }
-            row[c] = v;
+        } else if (c < (uint32_t) (AR_RBW + 9)) {
+            const uint32_t jx = c - AR_RBW;
+            v = ar_border(acc, gi, (int) jx) * si * scale[nc + jx] - G(s, AR_SEP + a, 2 * AR_SEP + jx) - G(s + 1, a, 2 * AR_SEP + jx);
+        } else {
+            v = -ar_gc(acc, gi) * si - G(s, AR_SEP + a, 2 * AR_SEP + 9) - G(s + 1, a, 2 * AR_SEP + 9);
         }
+        return v;
     };
     for (uint32_t e = lane; e < (uint32_t) (AR_RNB * AR_RNB); e += 64u) Gred[e] = 0.0;
     ar_wave_sync();
     bool ok = true;
-    if (n) ok = band_border_factor<AR_RBW, AR_RNB, AR_SEP>(n, load, Lred, Zred, Gred, win, colv);
+    if (n) ok = band_border_factor<AR_RBW, AR_RNB, AR_SEP, true>(n, load, Lred, Zred, Gred, win, colv, pn);
     ar_wave_sync();
     if (!ok && lane == 0) atomicExch(fail, 1);
     // [Zb z]^T [Zb z] over everything eliminated so far: the interiors' intrinsics / rhs block and the separators'

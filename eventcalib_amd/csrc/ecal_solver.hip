@@ -794,7 +794,8 @@ extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const
 static int arrow_solve_dev(ecal_solver *s, DeviceLm &D, const double *d_acc, const ArrowLm lm, hipStream_t st) {
     const ArrowPlan &pl = D.plan;
     int *fail = reinterpret_cast<int *>(D.sc + 4);
-    hipLaunchKernelGGL(arrow_interior_kernel, dim3(pl.P), dim3(64), 0, st, d_acc, (const double *) D.scale, pl, lm, D.Lfac, D.Zfac, D.Gp, fail);
+    hipLaunchKernelGGL(arrow_interior_kernel, dim3(pl.P), dim3(64), 0, st, d_acc, (const double *) D.scale, pl, lm, D.Lfac, D.Zfac, fail);
+    hipLaunchKernelGGL(arrow_gram_kernel, dim3(pl.P), dim3(256), 0, st, pl, (const double *) D.Zfac, D.Gp);
     hipLaunchKernelGGL(arrow_reduced_kernel, dim3(1), dim3(64), 0, st, d_acc, (const double *) D.scale, pl, lm, (const double *) D.Gp, D.Lred,
                        D.Zred, D.Gtot, fail);
     hipLaunchKernelGGL(arrow_corner_kernel, dim3(1), dim3(64), (pl.n_red() + 1) * sizeof(double), st, d_acc, (const double *) D.scale, pl, lm,
@@ -968,7 +969,10 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    if (!opt.allreduce && !getenv("ECAL_SOLVER_HOST_LINEAR_SOLVE")) {   // one rank: linear algebra on the device
+    // ECAL_SOLVER_DEVICE_LINEAR_SOLVE=1 (one rank): the whole iteration on the device (arrow_device.hpp) — correct and tested,
+    // but measured SLOWER than the host factorisation on the benchmark problem (12 009 unknowns: 2.9 ms of device kernels per
+    // linear solve against 1.3 ms on one host core + 0.5 ms of copies), so the host loop stays the default.
+    if (!opt.allreduce && getenv("ECAL_SOLVER_DEVICE_LINEAR_SOLVE")) {
         const int rc_dev = device_lm_solve(s, params, opt, sum);
         if (rc_dev != ECAL_ERR_RANGE) return rc_dev;                     // (too large for the LDS-resident parts: host loop)
     }
@@ -1237,3 +1241,14 @@ extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const
     memcpy(fail_out, &D.h_sc[4], sizeof(int));
     return ECAL_OK;
 }
+
+#ifdef ECAL_PHASE_PROF
+extern "C" int ecal_debug_ar_cycles(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(ecal::g_ar_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_ar_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

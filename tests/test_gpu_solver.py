@@ -106,11 +106,15 @@ def test_two_segments(ctx):
     s.close()
 
 
-def test_lm_recovers_ground_truth_and_matches_reference_loop(ctx):
+@pytest.mark.parametrize("device_solve,n_cp,n_res", [(False, 8, 4000), (True, 8, 4000), (True, 60, 30000)])
+def test_lm_recovers_ground_truth_and_matches_reference_loop(ctx, device_solve, n_cp, n_res, monkeypatch):
+    """device_solve: the whole LM iteration on the device (ECAL_SOLVER_DEVICE_LINEAR_SOLVE: partitioned arrow Cholesky, step,
+    acceptance sums; one 64-byte read-back per iteration) — same minimiser, same iterates as the host loop."""
     from eventcalib_amd.capi import Solver
+    if device_solve:
+        monkeypatch.setenv("ECAL_SOLVER_DEVICE_LINEAR_SOLVE", "1")
     rng = np.random.default_rng(4)
-    n_cp = 8
-    prob, x_gt = SV.make_problem(4000, n_cp=n_cp, seed=4)
+    prob, x_gt = SV.make_problem(n_res, n_cp=n_cp, seed=4)
     x0 = SV.perturb(x_gt, n_cp, rng)
     s = Solver(ctx, prob)
     x, summ = s.solve(x0)
