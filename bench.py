@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--calib-views", type=int, default=64,
                     help="views of the init calibration leg (configs[3]: 64 views sharded over the GPUs; 0 = skip)")
     ap.add_argument("--calib-cpu-views", type=int, default=8, help="views timed on the numpy oracle (0 = skip)")
+    ap.add_argument("--e2e-events", type=int, default=10_000_000,
+                    help="events of the end-to-end leg: one stream with tilted views through keyframe search -> init calibration -> "
+                         "rectify -> splines -> ecal_associate_dev -> the spline solve fed by THAT association (0 = skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -315,11 +318,39 @@ def main():
         out_calib = calib_leg(args, ctx, dev, world, rank, dist, torch, np)
         if rank == 0:
             out["init_calibration"] = out_calib
+    if args.e2e_events > 0 and rank == 0 and world == 1:
+        out["end_to_end"] = e2e_leg(args, ctx, dev, torch, np)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+
+
+def e2e_leg(args, ctx, dev, torch, np):
+    """The reference driver's chain on one stream (eventCameraCalib.cpp:99-233): the solver's residuals here are what
+    ecal_associate_dev finds in the event stream (EventCalibSpline.cpp:140-192), not generated records."""
+    import synth_stream as SS
+    from eventcalib_amd.calibrate import calibrate_stream
+    n, rate, t_start = args.e2e_events, 1.0e6, 5.0
+    SS.TRAJECTORY = "orbit"        # tilted views: a near fronto-parallel sequence leaves the focal length unobservable
+    try:
+        ev = SS.make_stream(n, rate=rate, t_start=t_start, device=dev, seed=21)
+    finally:
+        SS.TRAJECTORY = "hover"
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    r = calibrate_stream(ctx, ev, t_start, t_start + (n - 1) / rate)
+    wall = time.perf_counter() - t0
+    sp = r["spline"]
+    return {"events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
+            "residuals_from_association": sp["residuals"], "unknowns": sp["unknowns"], "splines": sp["splines"],
+            "lm_iterations": sp["iterations"], "lm_seconds": round(sp["seconds"], 4),
+            "lm_iterations_per_s": round(sp["iterations"] / max(sp["seconds"], 1e-9), 2),
+            "refined_fx_rel_err": float(abs(r["intrinsics"][0] / SS.FX - 1)),
+            "refined_cx_err_px": float(abs(r["intrinsics"][2] - (SS.CX - 0.5))), "wall_seconds_whole_chain": round(wall, 2),
+            "note": "keyframe search (policy P2) -> init calibration -> PnP / checkPose / rectify -> spline fit -> association of "
+                    "every event -> LM; host-side Python glue between the stages is inside wall_seconds_whole_chain"}
 
 
 def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np):
@@ -397,7 +428,9 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
         el = float(tt.item())
     iters = int(summ.iterations)
     res_total = n_res * world
-    FLOP_JAC = 2100.0            # per residual and Jacobian evaluation: ~700 residual+gradient, 45 tiles x 16 FMA x 2
+    # SURVEY 8(d)'s ALGORITHMIC count per residual and Jacobian evaluation: ~0.7 kflop residual + analytic gradient, 561 FMA
+    # for the upper J^T J, 33 FMA for J^T r = 1.9 kflop (the kernel executes ~2.1 kflop: 6 x 6 tiles pad 34 -> 36 columns)
+    FLOP_JAC = 1900.0
     out = {
         "metric": "LM solver iterations/s", "value": round(iters / el, 3), "unit": "iterations/s",
         "iterations": iters, "seconds": round(el, 4), "seconds_evaluate": round(float(summ.seconds_evaluate), 4),

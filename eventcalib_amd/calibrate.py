@@ -209,7 +209,8 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     solver.close()
     out["spline"] = {"splines": len(segs), "control_points": int(seg_cp_off[-1]), "residuals": int(len(tm)),
                      "iterations": int(summ.iterations), "initial_cost": float(summ.initial_cost),
-                     "final_cost": float(summ.final_cost)}
+                     "final_cost": float(summ.final_cost), "seconds": float(summ.seconds),
+                     "jacobian_evaluations": int(summ.jacobian_evaluations), "unknowns": int(9 + 6 * seg_cp_off[-1])}
     out["intrinsics"] = x[:9].copy()
     # updateMap (:253-317): keyframe poses re-read from the optimised splines
     n_cp = seg_cp_off[-1]

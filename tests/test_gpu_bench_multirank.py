@@ -17,7 +17,7 @@ def _bench(nproc, extra, launcher=True):
     env = dict(os.environ, ECAL_BENCH_SINGLE_DEVICE="1", ECAL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
                ECAL_BENCH_SOLVER_CHECK="1")
     args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--events", "2000000", "--cpu-sample", "0",
-            "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0", "--ingest-events", "0"] + extra
+            "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0", "--ingest-events", "0", "--e2e-events", "0"] + extra
     if nproc == 1 or not launcher:
         # exactly what the driver may type: `python bench.py --gpus N ...` — for N > 1 bench.py starts its own ranks under
         # torch.distributed.run as child processes (before it touches the GPU) and relays rank 0's JSON line
