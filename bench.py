@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--calib-views", type=int, default=64,
                     help="views of the init calibration leg (configs[3]: 64 views sharded over the GPUs; 0 = skip)")
     ap.add_argument("--calib-cpu-views", type=int, default=8, help="views timed on the numpy oracle (0 = skip)")
-    ap.add_argument("--e2e-events", type=int, default=10_000_000,
+    ap.add_argument("--e2e-events", type=int, default=50_000_000,
                     help="events of the end-to-end leg: one stream with tilted views through keyframe search -> init calibration -> "
                          "rectify -> splines -> ecal_associate_dev -> the spline solve fed by THAT association (0 = skip)")
     args = ap.parse_args()

@@ -18,7 +18,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ECAL_HD __host__ __device__ __forceinline__
 #else
 #define ECAL_HD inline
