@@ -654,26 +654,29 @@ struct PixHash {
     static constexpr size_t red_off = tab_off + 8 * SLOTS;                 // 16 x u64 + 4 x u32 flags
     static constexpr size_t bytes = red_off + 16 * 8 + 16;
     static __device__ __forceinline__ uint32_t slot(uint32_t pix) { return (pix * 0x9E3779B1u) >> (32u - LOGC); }
-    // reference element order (slice_order.hpp): what takes the tables' place once they are dead
-    //   W u32[SLOTS]       per sequence position: members of the bucket first seen there, then  base << 16 | count
-    //   region u16[SLOTS]  the sorted sequence's slots; at the very end pos u16[SLOTS] by event index
-    //   cur u16[SLOTS]     list position of key uid (positive keys first)
-    //   fa u32[FA_CAP]     first sequence position per bucket, the + table then the - table; before the epochs the batch
-    //                      counts of the rank scan, during the early epochs also the early keys' hashes (u64[2][128])
-    //   keep u32[2][SLOTS / 32 + 1] (+ 16)   kept keys by list position, and the running counts of its words
-    static constexpr uint32_t FA_CAP = LOGC == 11 ? 2400u : 7456u;   // B(+) + B(-): 1109 + 1109 / 5087 + 2357 (+ slack)
-    // (first pass: the - set's part of W / region / cur starts at the fixed offset NOFF = 1152 = 128 x 9 keys per thread of a
-    // wave pair, so every run of 128 positions a scan touches lies inside the set's own part: no bounds tests)
-    static constexpr uint32_t NOFF = 1152u, PSL = LOGC == 11 ? 2u * NOFF : SLOTS;
+    // reference element order (slice_order.hpp): what takes the tables' place once they are dead.  A wave PAIR per polarity
+    // runs the epochs; thread l128 of a pair owns the keys l128 + 128 i, i < NI.
+    //   W u32[2 NOFF]       per sequence position: members of the bucket first seen there, then  run start << 10 | members
+    //   region u16[2 NOFF]  the runs of the buckets of three and more; before the epochs the keys' epoch-7 buckets (second
+    //                       pass); at the very end pos u16[SLOTS] by event index
+    //   cur u16[2 NOFF]     list position of key uid after the early epochs, final index at the end
+    //   fa u32[FA_CAP]      first sequence position per bucket, the + table then the - table; before the epochs the keys'
+    //                       early bucket words
+    //   keep u32[16 NI]     kept keys by list position (bitmaps of both sets) and the running counts of their words
+    // The - set's part of W / region / cur starts at the fixed offset NOFF = 128 NI: every run of 128 positions a scan
+    // touches lies inside the set's own part (no bounds tests).
+    static constexpr int NI = LOGC == 11 ? 9 : 19;                    // keys per thread of a pair: 1152 >= 1109 / 2432 >= 2357
+    static constexpr int MAX_EPOCHS = LOGC == 11 ? 7 : 8;             // bucket counts up to 1109 / 2357
+    static constexpr uint32_t NOFF = 128u * NI, PSL = 2u * NOFF;
+    static constexpr uint32_t FA_CAP = LOGC == 11 ? 2400u : 4800u;    // B(+) + B(-): 1109 + 1109 / 2357 + 2357 (+ slack)
     static constexpr size_t w_off = 0;
     static constexpr size_t region_off = w_off + 4 * PSL;
-    static constexpr size_t cur_off = region_off + 2 * PSL;
+    static constexpr size_t cur_off = region_off + 2 * (PSL > SLOTS ? PSL : SLOTS);
     static constexpr size_t fa_off = cur_off + 2 * PSL;
     static constexpr size_t keep_off = fa_off + 4 * FA_CAP;
-    static constexpr size_t bcnt_off = keep_off + 8 * (SLOTS / 32 + 1) + 64;   // u32[PER * 4 + 1]: batch counts of the rank scan
+    static constexpr size_t bcnt_off = keep_off + 4 * 16 * NI;        // u32[PER * 4 + 1]: batch counts of the rank scan
     static constexpr size_t ored_off = bcnt_off + 4 * (SLOTS / 64 + 4);
     static constexpr size_t obytes = ored_off + 16 * 8 + 16;
-    static constexpr uint32_t HTAB_WORD = 1024;   // early hashes at fa[1024 ..) (the early epochs' own tables end at fa[256))
 };
 
 // std::hash<double> of the integers 0 .. 2047 (the pixel kernels' coordinates), built at compile time
@@ -726,86 +729,6 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-}
-
-// The early epochs of one polarity's set, run by ONE wave (no workgroup barrier): keys u < min(m, 127) = the epochs with
-// 13, 29, 59 and 127 buckets, at most two keys per lane.  hk = the keys' hashes, fa / W / region = 128-entry scratch of
-// this polarity; writes cur_out[u] = list position after the last early epoch.
-__device__ __forceinline__ void early_epochs(const uint64_t *hk, uint32_t m, uint32_t *fa, uint32_t *W, uint16_t *region,
-                                             uint16_t *cur_out) {
-    constexpr int EARLY = 4;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t m_e = m < 127u ? m : 127u;
-    uint64_t h[2];
-    uint32_t cur[2] = {0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 2; i++) h[i] = (lane + 64u * i < m_e) ? hk[lane + 64u * i] : 0ull;
-    uint32_t n_prev = 0;
-    for (int e = 0; e < EARLY && n_prev < m_e; e++) {
-        const uint32_t B = (uint32_t) ref_bucket_step(e);
-        const uint32_t n_e = m_e < B ? m_e : B;
-        const ModB md = mod_for_epoch(e);
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            fa[lane + 64u * i] = 0xFFFFFFFFu;
-            W[lane + 64u * i] = 0u;
-        }
-        wave_sync_lds();
-        uint32_t b[2], q[2], f[2], sl[2];
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t u = lane + 64u * i;
-            q[i] = u < n_prev ? cur[i] : u;
-            b[i] = mod_hash(h[i], md);
-            if (u < n_e) atomicMin(&fa[b[i]], q[i]);
-        }
-        wave_sync_lds();
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t u = lane + 64u * i;
-            f[i] = 0;
-            sl[i] = 0;
-            if (u < n_e) {
-                f[i] = fa[b[i]];
-                sl[i] = atomicAdd(&W[f[i]], 1u);
-            }
-        }
-        wave_sync_lds();
-        {   // exclusive scan of the counts over the positions 2 lane, 2 lane + 1
-            const uint32_t c0 = W[2u * lane], c1 = W[2u * lane + 1u];
-            uint32_t inc = c0 + c1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(inc, d, 64);
-                if (lane >= (uint32_t) d) inc += o;
-            }
-            const uint32_t ex = inc - c0 - c1;
-            W[2u * lane] = (ex << 16) | c0;
-            W[2u * lane + 1u] = ((ex + c0) << 16) | c1;
-        }
-        wave_sync_lds();
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t u = lane + 64u * i;
-            if (u < n_e) region[(W[f[i]] >> 16) + sl[i]] = (uint16_t) q[i];
-        }
-        wave_sync_lds();
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const uint32_t u = lane + 64u * i;
-            if (u < n_e) {
-                const uint32_t w = W[f[i]], b0 = w >> 16, c = w & 0xFFFFu;
-                uint32_t within = 0;
-                for (uint32_t t = 0; t < c; t++) within += ((uint32_t) region[b0 + t] < q[i]) ? 1u : 0u;
-                cur[i] = n_e - 1u - (b0 + within);
-            }
-        }
-        wave_sync_lds();
-        n_prev = n_e;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-        if (lane + 64u * i < m_e) cur_out[lane + 64u * i] = (uint16_t) cur[i];
 }
 
 // Inclusive add-scan over the 64 lanes in registers (DPP row shifts + row broadcasts, the gfx9 sequence): seven VALU
@@ -996,7 +919,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
     if (ECAL_SL_STOP == 1) return;
     // (reference order, first pass) the bucket numbers of every event's pixel are asked for NOW: the gather's latency hides
     // behind the table phases, whose barriers therefore order LDS traffic only
-    constexpr bool EARLY_GATHER = REFORDER && LOGC == 11;
+    constexpr bool EARLY_GATHER = REFORDER;
     uint2 bw[EARLY_GATHER ? PXH_PER : 1];
     if constexpr (EARLY_GATHER) {
 #pragma unroll
@@ -1077,21 +1000,15 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
     if (ECAL_SL_STOP == 3) return;
     if constexpr (REFORDER) {
         // ---- the reference's element order (slice_order.hpp; EventFrame.cpp:12-13,34-35) ----
-        // Keys = first occurrences (before the cancellation).  Per key one word  meta = first | erased << 12 | polarity << 13
-        // | key << 14 | rank << 16  and its hash reduced modulo the product of the block epochs' bucket counts (one word per
-        // three epochs: bucket = residue % B is then ONE exact fp64 step per epoch).
-        constexpr int EARLY = 4;                       // epochs 13, 29, 59, 127: one wave per polarity, no workgroup barrier
-        constexpr uint32_t N_EARLY = 127u;
-        constexpr int NRES = LOGC == 11 ? 1 : 2;       // residues: mod 257 * 541 * 1109 (epochs 4 - 6), mod 2357 * 5087 (7, 8)
-        constexpr double M0 = 257.0 * 541.0 * 1109.0, M1 = 2357.0 * 5087.0;
-        constexpr uint32_t SP = PXH_SLOTS / T;         // sequence positions per thread in the scan
+        // Keys = first occurrences (before the cancellation).  Per event one word  meta = first | erased << 12 | polarity << 13
+        // | key << 14 | rank << 16; per key its bucket numbers for every epoch it can go through, packed (the divisions were
+        // done once per sensor pixel, bucket_table_kernel; the second pass's epoch with 2357 buckets is divided here).
+        constexpr uint32_t N_EARLY = 127u;             // keys of the epochs 13, 29, 59, 127: one wave per polarity
         uint32_t *const W = reinterpret_cast<uint32_t *>(smem + L::w_off);
         uint16_t *const region = reinterpret_cast<uint16_t *>(smem + L::region_off);
         uint16_t *const cur = reinterpret_cast<uint16_t *>(smem + L::cur_off);
         uint32_t *const fa = reinterpret_cast<uint32_t *>(smem + L::fa_off);
         uint32_t *const keepW = reinterpret_cast<uint32_t *>(smem + L::keep_off);
-        uint32_t *const keepPre = keepW + (PXH_SLOTS / 32u + 1u);
-        uint64_t *const htab = reinterpret_cast<uint64_t *>(fa + L::HTAB_WORD);
         uint32_t *const ored = reinterpret_cast<uint32_t *>(smem + L::ored_off);
         uint16_t *const posE = region;
         const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -1130,15 +1047,14 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
         const int EP = mP ? ref_epochs(mP) : 0, EN = mN ? ref_epochs(mN) : 0;
         {
             const uint32_t need = (EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u) + (EN ? (uint32_t) ref_bucket_step(EN - 1) : 0u);
-            if (need > L::FA_CAP || EP > (NRES == 1 ? 7 : 9) || EN > (NRES == 1 ? 7 : 9)) {   // more keys than the bucket tables hold: next tier
+            if (need > L::FA_CAP || EP > L::MAX_EPOCHS || EN > L::MAX_EPOCHS) {   // more keys than the bucket tables hold: next tier
                 if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
                 return;
             }
         }
-        if constexpr (LOGC == 11) {
-            // ---- first pass: one wave PAIR per polarity; early epochs by one wave each, block epochs by the pair ----
-            constexpr int NI = 9;    // 128 NI >= 1109 keys per polarity
-            static_assert(16 * NI <= (int) (2 * (PXH_SLOTS / 32 + 1) + 16), "bitmap room");
+        {
+            // ---- one wave PAIR per polarity: early epochs (13 .. 127 buckets) by one wave each, the rest by the pair ----
+            constexpr int NI = L::NI;
             const uint32_t faN = EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u;   // the - set's bucket table starts here
             {
 #pragma unroll
@@ -1150,6 +1066,9 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                         const bool pos_ = (meta[j] & 0x2000u) != 0;
                         W[(pos_ ? 0u : L::NOFF) + rank] = bw[j].x | ((meta[j] & 0x1000u) ? 0x80000000u : 0u);
                         if (rank < N_EARLY) fa[(pos_ ? 0u : faN) + rank] = bw[j].y;
+                        if (L::MAX_EPOCHS > 7 && (pos_ ? EP : EN) > 7)   // (second pass, a set of more than 1109 keys)
+                            region[(pos_ ? 0u : L::NOFF) + rank] =
+                                (uint16_t) mod_hash(ref_hash_combine2(HASH_INT.v[pix[j] >> 10], HASH_INT.v[pix[j] & 0x3FFu]), mod_for_epoch(7));
                     }
                 }
             }
@@ -1168,12 +1087,12 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             if (tid == 0) ored[10] = 0u;
             __syncthreads();
     RO_MARK(4);
-            uint32_t bk[NI], cu[NI];
+            uint32_t bk[NI], cu[NI];   // (second pass: the epoch-7 bucket rides in the upper half of cu[] until that epoch)
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 const uint32_t u = l128 + 128u * i;
                 bk[i] = u < m ? Wp[u] : 0u;
-                cu[i] = 0u;
+                cu[i] = (L::MAX_EPOCHS > 7 && E > 7 && u < m) ? ((uint32_t) regp[u] << 16) : 0u;
             }
             if (l128 < KW) kW[l128] = 0u;
             __syncthreads();
@@ -1182,7 +1101,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             __syncthreads();
     RO_MARK(6);
             if (ECAL_RO_STOP == 3) return;
-            if (l128 < (m < 127u ? m : 127u)) cu[0] = curp[l128];
+            if (l128 < (m < 127u ? m : 127u)) cu[0] = (cu[0] & 0xFFFF0000u) | (uint32_t) curp[l128];
             const int EMAX = EP > EN ? EP : EN;
             if (E > 4) {
                 for (uint32_t b = l128; b < 257u; b += 128u) fap[b] = 0xFFFFFFFFu;
@@ -1193,7 +1112,9 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 const bool on = e < E;
                 const uint32_t B = (uint32_t) ref_bucket_step(e), Bprev = (uint32_t) ref_bucket_step(e - 1);
                 const uint32_t n_e = on ? (m < B ? m : B) : 0u;
-                const uint32_t sh = e == 4 ? 0u : (e == 5 ? 9u : 19u), bmask = e == 4 ? 0x1FFu : (e == 5 ? 0x3FFu : 0x7FFu);
+                const uint32_t sh = e == 4 ? 0u : (e == 5 ? 9u : (e == 6 ? 19u : 16u)),
+                               bmask = e == 4 ? 0x1FFu : (e == 5 ? 0x3FFu : (e == 6 ? 0x7FFu : 0xFFFu));
+                const bool e7 = e == 7;   // (its buckets sit in cu[]'s upper half)
                 const uint32_t per = (n_e + 127u) >> 7;   // sequence positions per thread in the scan
                 uint32_t fq[NI];                          // first position of the key's bucket
                 // first sequence position per bucket  (and W, last read before the barrier that ended the previous epoch, is cleared)
@@ -1202,7 +1123,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                 for (int i = 0; i < NI; i++) {
                     const uint32_t u = l128 + 128u * i;
                     if (128u * i >= n_e) break;
-                    if (u < n_e) atomicMin(&fap[(bk[i] >> sh) & bmask], u < Bprev ? cu[i] : u);
+                    if (u < n_e) atomicMin(&fap[((e7 ? cu[i] : bk[i]) >> sh) & bmask], u < Bprev ? (cu[i] & 0xFFFFu) : u);
                 }
                 __syncthreads();
                 // members per bucket, counted at the bucket's first position; the arrival number is the member's slot
@@ -1212,7 +1133,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     fq[i] = 0u;
                     if (128u * i >= n_e) break;
                     if (u < n_e) {
-                        const uint32_t f = fap[(bk[i] >> sh) & bmask];
+                        const uint32_t f = fap[((e7 ? cu[i] : bk[i]) >> sh) & bmask];
                         fq[i] = f | (atomicAdd(&Wp[f], 1u) << 12);
                     }
                 }
@@ -1251,7 +1172,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     if (u < n_e) {
                         const uint32_t f = fq[i] & 0xFFFu, w = Wp[f];
                         if ((w & 0x3FFu) > 2u)
-                            regp[(w >> 10) + (f >= carry_from ? carry : 0u) + (fq[i] >> 12)] = (uint16_t) (u < Bprev ? cu[i] : u);
+                            regp[(w >> 10) + (f >= carry_from ? carry : 0u) + (fq[i] >> 12)] = (uint16_t) (u < Bprev ? (cu[i] & 0xFFFFu) : u);
                     }
                 }
                 __syncthreads();
@@ -1263,14 +1184,14 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
                     if (128u * i >= n_e) break;
                     if (u < n_e) {
                         const uint32_t f = fq[i] & 0xFFFu, w = Wp[f], b0 = (w >> 10) + (f >= carry_from ? carry : 0u), cnt = w & 0x3FFu;
-                        const uint32_t q = u < Bprev ? cu[i] : u;
+                        const uint32_t q = u < Bprev ? (cu[i] & 0xFFFFu) : u;
                         uint32_t within = (q != f) ? 1u : 0u;
                         if (cnt > 2u) {   // (buckets of five and more are rare: four slots read at once, a loop for the rest)
                             const uint32_t r0 = regp[b0], r1 = regp[b0 + 1u], r2 = regp[b0 + 2u], r3 = regp[b0 + 3u];
                             within = (r0 < q ? 1u : 0u) + (r1 < q ? 1u : 0u) + (r2 < q ? 1u : 0u) + ((cnt > 3u && r3 < q) ? 1u : 0u);
                             for (uint32_t t = 4; t < cnt; t++) within += ((uint32_t) regp[b0 + t] < q) ? 1u : 0u;
                         }
-                        cu[i] = n_e - 1u - (b0 + within);
+                        cu[i] = (cu[i] & 0xFFFF0000u) | (n_e - 1u - (b0 + within));
                     }
                 }
                 __syncthreads();
@@ -1285,14 +1206,17 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 const uint32_t u = l128 + 128u * i;
-                if (u < m && !(bk[i] >> 31)) atomicOr(&kW[cu[i] >> 5], 1u << (cu[i] & 31u));
+                if (u < m && !(bk[i] >> 31)) atomicOr(&kW[(cu[i] & 0xFFFFu) >> 5], 1u << (cu[i] & 31u));
             }
             __syncthreads();
     RO_MARK(11);
             if (sub == 0u) {
-                const uint32_t c = lane < KW ? (uint32_t) __popc(kW[lane]) : 0u;
-                const uint32_t inc = wave_incl_scan_dpp(c);
-                if (lane < KW) kPre[lane] = inc - c;
+                static_assert(KW <= 128u, "two bitmap words per lane");
+                const uint32_t c0 = 2u * lane < KW ? (uint32_t) __popc(kW[2u * lane]) : 0u;
+                const uint32_t c1 = 2u * lane + 1u < KW ? (uint32_t) __popc(kW[2u * lane + 1u]) : 0u;
+                const uint32_t inc = wave_incl_scan_dpp(c0 + c1);
+                if (2u * lane < KW) kPre[2u * lane] = inc - c0 - c1;
+                if (2u * lane + 1u < KW) kPre[2u * lane + 1u] = inc - c1;
                 if (lane == 63u) ored[8u + pol] = inc;
             }
             __syncthreads();
@@ -1301,7 +1225,7 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             for (int i = 0; i < NI; i++) {
                 const uint32_t u = l128 + 128u * i;
                 if (u < m && !(bk[i] >> 31))
-                    curp[u] = (uint16_t) (kPre[cu[i] >> 5] + (uint32_t) __popc(kW[cu[i] >> 5] & ((1u << (cu[i] & 31u)) - 1u)));
+                    curp[u] = (uint16_t) (kPre[(cu[i] & 0xFFFFu) >> 5] + (uint32_t) __popc(kW[(cu[i] & 0xFFFFu) >> 5] & ((1u << (cu[i] & 31u)) - 1u)));
             }
             __syncthreads();
     RO_MARK(13);
@@ -1343,238 +1267,6 @@ __device__ __forceinline__ void slice_hash_window(unsigned char *smem, const uin
             RO_MARK(0);   // (adds ~0: counts the workgroups through the number of marks... see tools/ro_phase_prof.py)
             return;
         }
-        // ---- second pass (up to 4095 events): the epochs as workgroup-wide phases ----
-        // buckets of the block epochs, packed: epochs 4, 5, 6 (257, 541, 1109 buckets: 9 + 10 + 11 bits) in bk[0], epochs
-        // 7, 8 (2357, 5087: 12 + 13 bits) in bk[1] — the divisions happen once, here, not in the epoch loop
-        uint32_t bk[NRES][PXH_PER];
-        {
-            ModB m0, m1;
-            m0.b = M0;
-            m0.inv = (1.0 / M0) * (1.0 - 0x1p-50);
-            m1.b = M1;
-            m1.inv = (1.0 / M1) * (1.0 - 0x1p-50);
-            const ModB e4 = mod_for_epoch(4), e5 = mod_for_epoch(5), e6 = mod_for_epoch(6), e7 = mod_for_epoch(7), e8 = mod_for_epoch(8);
-#pragma unroll
-            for (int j = 0; j < PXH_PER; j++) {
-                const uint32_t ex = bcnt[j * (T / 64) + wave];
-                meta[j] += ((meta[j] & 0x2000u) ? (ex & 0xFFFFu) : (ex >> 16)) << 16;
-                bk[0][j] = 0;
-                if (NRES > 1) bk[NRES - 1][j] = 0;
-                if (meta[j] & 0x4000u) {
-                    const uint64_t h = ref_hash_combine2(HASH_INT.v[pix[j] >> 10], HASH_INT.v[pix[j] & 0x3FFu]);   // utility.hpp:38-51
-                    const uint32_t rank = meta[j] >> 16;
-                    if (rank < N_EARLY) htab[((meta[j] & 0x2000u) ? 0u : 128u) + rank] = h;
-                    // h % M in two exact fp64 steps: h = d2 2^48 + d1 2^24 + d0, d2 < 2^16 < M; then residue % B, one step each
-                    const double d2 = (double) (uint32_t) (h >> 48), d1 = (double) (uint32_t) ((h >> 24) & 0xFFFFFFu),
-                                 d0 = (double) (uint32_t) (h & 0xFFFFFFu);
-                    const double r0 = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), m0), 0x1p24, d0), m0);
-                    bk[0][j] = (uint32_t) mod_step(r0, e4) | ((uint32_t) mod_step(r0, e5) << 9) | ((uint32_t) mod_step(r0, e6) << 19);
-                    if (NRES > 1) {
-                        const double r1 = mod_step(__builtin_fma(mod_step(__builtin_fma(d2, 0x1p24, d1), m1), 0x1p24, d0), m1);
-                        bk[NRES - 1][j] = (uint32_t) mod_step(r1, e7) | ((uint32_t) mod_step(r1, e8) << 12);
-                    }
-                }
-            }
-        }
-        {
-            uint4 *k4 = reinterpret_cast<uint4 *>(keepW);
-            for (uint32_t q = tid; q < (PXH_SLOTS / 32u + 1u + 3u) / 4u; q += T) k4[q] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        if (ECAL_RO_STOP == 2) return;
-        __syncthreads();
-        // early epochs: wave 0 the positive set, wave 1 the negative one; key uid = rank (+) / mP + rank (-)
-        if (wave == 0 && mP) early_epochs(htab, mP, fa, W, region, cur);
-        if (wave == 1 && mN) early_epochs(htab + 128, mN, fa + 128, W + 128, region + 128, cur + mP);
-        __syncthreads();
-        if (ECAL_RO_STOP == 3) return;
-        // block epochs
-        const int EMAX = EP > EN ? EP : EN;
-        if (EMAX > EARLY) {
-            const uint32_t B = (uint32_t) ref_bucket_step(EARLY);
-            const uint32_t words = (EP > EARLY ? B : 0u) + (EN > EARLY ? B : 0u);
-            for (uint32_t q = tid; q < words; q += T) fa[q] = 0xFFFFFFFFu;
-        }
-        for (int e = EARLY; e < EMAX; e++) {
-            const uint32_t B = (uint32_t) ref_bucket_step(e), Bprev = (uint32_t) ref_bucket_step(e - 1);
-            const uint32_t bsh = e == 4 ? 0u : (e == 5 ? 9u : (e == 6 ? 19u : (e == 7 ? 0u : 12u)));
-            const uint32_t bmask = e == 4 ? 0x1FFu : (e == 5 ? 0x3FFu : (e == 6 ? 0x7FFu : (e == 7 ? 0xFFFu : 0x1FFFu)));
-            const bool onP = e < EP, onN = e < EN;
-            const uint32_t nP_e = onP ? (mP < B ? mP : B) : 0u, nN_e = onN ? (mN < B ? mN : B) : 0u;
-            const uint32_t faN = onP ? B : 0u;   // offset of the - table
-            uint32_t st[PXH_PER];                // bucket, then  first position << 12 | slot
-            unsigned act = 0;
-            // (keeps the compiler from hoisting every slot's rank / offset / LDS address out of the epoch loop: that
-            // costs ~40 VGPRs = two waves per SIMD, to save a handful of shifts per epoch)
-#pragma unroll
-            for (int j = 0; j < PXH_PER; j++) asm volatile("" : "+v"(meta[j]));
-            {   // (W was last read before the barrier that ended the previous epoch)
-                uint4 *w4 = reinterpret_cast<uint4 *>(W);
-                for (uint32_t q = tid; q < PXH_SLOTS / 4u; q += T) w4[q] = make_uint4(0u, 0u, 0u, 0u);
-            }
-#pragma unroll
-            for (int j = 0; j < PXH_PER; j++) {
-                const uint32_t rank = meta[j] >> 16;
-                const bool pos_ = (meta[j] & 0x2000u) != 0;
-                const bool on = (meta[j] & 0x4000u) && (pos_ ? rank < nP_e : rank < nN_e);
-                st[j] = 0;
-                if (on) {
-                    act |= 1u << j;
-                    const uint32_t q = rank < Bprev ? (uint32_t) cur[(pos_ ? 0u : mP) + rank] : rank;
-                    const uint32_t r = (NRES > 1 && e >= 7) ? bk[NRES - 1][j] : bk[0][j];
-                    const uint32_t b = (pos_ ? 0u : faN) + ((r >> bsh) & bmask);
-                    st[j] = b;
-                    atomicMin(&fa[b], q);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < PXH_PER; j++) {
-                if (act & (1u << j)) {
-                    const uint32_t f = fa[st[j]];
-                    const uint32_t sl = atomicAdd(&W[((meta[j] & 0x2000u) ? 0u : mP) + f], 1u);
-                    st[j] = (f << 12) | sl;
-                }
-            }
-            __syncthreads();
-            {   // per-wave exclusive scan of the counts over the sequence positions; the wave totals go to ored[]
-                uint32_t c[SP], sum = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < SP; i++) {
-                    c[i] = W[tid * SP + i];
-                    sum += c[i];
-                }
-                uint32_t inc = sum;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = __shfl_up(inc, d, 64);
-                    if (lane >= (uint32_t) d) inc += o;
-                }
-                if (lane == 63u) ored[wave] = inc;
-                uint32_t ex = inc - sum;
-#pragma unroll
-                for (uint32_t i = 0; i < SP; i++) {
-                    W[tid * SP + i] = (ex << 16) | c[i];
-                    ex += c[i];
-                }
-                if (e + 1 < EMAX) {   // fa is dead: set it up for the next epoch
-                    const uint32_t Bn = (uint32_t) ref_bucket_step(e + 1);
-                    const uint32_t words = (e + 1 < EP ? Bn : 0u) + (e + 1 < EN ? Bn : 0u);
-                    for (uint32_t q = tid; q < words; q += T) fa[q] = 0xFFFFFFFFu;
-                }
-            }
-            __syncthreads();
-            static_assert(T == 256, "four wave chunks");
-            // positions before wave w's chunk of the scan (uniform values: scalar registers)
-            const uint32_t wp1 = __builtin_amdgcn_readfirstlane(ored[0]), wp2 = wp1 + __builtin_amdgcn_readfirstlane(ored[1]),
-                           wp3 = wp2 + __builtin_amdgcn_readfirstlane(ored[2]);
-            auto chunk_pre = [&](uint32_t at) {
-                const uint32_t w = at / (64u * SP);
-                return w == 0u ? 0u : (w == 1u ? wp1 : (w == 2u ? wp2 : wp3));
-            };
-#pragma unroll
-            for (int j = 0; j < PXH_PER; j++) {
-                if (act & (1u << j)) {
-                    const bool pos_ = (meta[j] & 0x2000u) != 0;
-                    const uint32_t off = pos_ ? 0u : mP, at = off + (st[j] >> 12);
-                    const uint32_t w = W[at];
-                    if ((w & 0xFFFFu) > 1u) {   // (a key alone in its bucket needs no slot)
-                        const uint32_t rank = meta[j] >> 16;
-                        const uint32_t q = rank < Bprev ? (uint32_t) cur[off + rank] : rank;
-                        const uint32_t b0 = (w >> 16) + chunk_pre(at) - (pos_ ? 0u : nP_e);
-                        region[off + b0 + (st[j] & 0xFFFu)] = (uint16_t) q;
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < PXH_PER; j++) {
-                if (act & (1u << j)) {
-                    const bool pos_ = (meta[j] & 0x2000u) != 0;
-                    const uint32_t off = pos_ ? 0u : mP, at = off + (st[j] >> 12);
-                    const uint32_t w = W[at], cnt = w & 0xFFFFu;
-                    const uint32_t b0 = (w >> 16) + chunk_pre(at) - (pos_ ? 0u : nP_e);
-                    const uint32_t rank = meta[j] >> 16;
-                    uint32_t within = 0;
-                    if (cnt > 1u) {
-                        const uint32_t q = rank < Bprev ? (uint32_t) cur[off + rank] : rank;
-                        for (uint32_t t = 0; t < cnt; t++) within += ((uint32_t) region[off + b0 + t] < q) ? 1u : 0u;
-                    }
-                    cur[off + rank] = (uint16_t) ((pos_ ? nP_e : nN_e) - 1u - (b0 + within));
-                }
-            }
-            __syncthreads();
-        }
-        if (ECAL_RO_STOP == 4) return;
-        // the erased keys drop out (EventFrame.cpp:24-32): index of a kept key = kept keys in front of it in the list
-#pragma unroll
-        for (int j = 0; j < PXH_PER; j++) {
-            if ((meta[j] & 0x5000u) == 0x4000u) {   // a key, and not erased
-                const uint32_t off = (meta[j] & 0x2000u) ? 0u : mP;
-                const uint32_t at = off + (uint32_t) cur[off + (meta[j] >> 16)];
-                atomicOr(&keepW[at >> 5], 1u << (at & 31u));
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            constexpr uint32_t KW = PXH_SLOTS / 32u;   // 64 or 128 words
-            uint32_t carry = 0;
-#pragma unroll
-            for (uint32_t w0 = 0; w0 < KW; w0 += 64u) {
-                const uint32_t c = (uint32_t) __popc(keepW[w0 + lane]);
-                uint32_t inc = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t o = __shfl_up(inc, d, 64);
-                    if (lane >= (uint32_t) d) inc += o;
-                }
-                keepPre[w0 + lane] = carry + inc - c;
-                carry += __shfl(inc, 63, 64);
-            }
-        }
-        __syncthreads();
-        auto kept_below = [&](uint32_t at) { return keepPre[at >> 5] + (uint32_t) __popc(keepW[at >> 5] & ((1u << (at & 31u)) - 1u)); };
-        const uint32_t nP = __builtin_amdgcn_readfirstlane(kept_below(mP)), nN = __builtin_amdgcn_readfirstlane(kept_below(mP + mN)) - nP;
-#pragma unroll
-        for (int j = 0; j < PXH_PER; j++) asm volatile("" : "+v"(meta[j]));   // (nothing carried over from the loop above)
-#pragma unroll
-        for (int j = 0; j < PXH_PER; j++) {
-            if ((meta[j] & 0x5000u) == 0x4000u) {
-                const bool pos_ = (meta[j] & 0x2000u) != 0;
-                const uint32_t off = pos_ ? 0u : mP;
-                const uint32_t at = off + (uint32_t) cur[off + (meta[j] >> 16)];
-                posE[meta[j] & 0xFFFu] = (uint16_t) (kept_below(at) - (pos_ ? 0u : nP));
-            }
-        }
-        __syncthreads();
-        double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
-        int32_t *ep = event_point + base;
-#pragma unroll
-        for (int j = 0; j < PXH_PER; j++) asm volatile("" : "+v"(meta[j]));
-#pragma unroll
-        for (int j = 0; j < PXH_PER; j++) {
-            const uint32_t k = tid + j * T;
-            if (k < n) {
-                if (meta[j] & 0x1000u) {
-                    ep[k] = -1;
-                } else {
-                    const uint32_t at = posE[meta[j] & 0xFFFu];
-                    ep[k] = (int32_t) at;
-                    if (meta[j] & 0x4000u) {
-                        double2 v;
-                        v.x = (double) (pix[j] >> 10);
-                        v.y = (double) (pix[j] & 0x3FFu);
-                        out2[(meta[j] & 0x2000u) ? at : nP + at] = v;
-                    }
-                }
-            }
-        }
-        if (tid == 0) {
-            seg_off[2 * s] = base;
-            seg_cnt[2 * s] = nP;
-            seg_off[2 * s + 1] = base + nP;
-            seg_cnt[2 * s + 1] = nN;
-        }
-        return;
     }
     // d. ranks of the representatives in event order.  Batch (j, wave) holds 64 consecutive events and the batches ascend in
     // event index: rank = representatives of the same polarity in the batches before + on the lanes below (ballots; the
@@ -1695,12 +1387,13 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_list_kernel(const uint8_t *_
                                                                 int32_t *__restrict__ event_point, int *overflow,
                                                                 uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
                                                                 const uint32_t *__restrict__ in_list,
-                                                                const uint32_t *__restrict__ in_count) {
+                                                                const uint32_t *__restrict__ in_count,
+                                                                const uint2 *__restrict__ bucket_tab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         slice_hash_window<12, REFORDER>(smem, in_list[k], rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point,
-                              overflow, todo, todo_count);
+                              overflow, todo, todo_count, bucket_tab);
         __syncthreads();
     }
 }
@@ -1865,11 +1558,11 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
                 if (reforder)
                     hipLaunchKernelGGL(slice_hash_list_kernel<true>, dim3(grid2), dim3(PXH_T), H12, st, d_events, d_win_lo,
                                        d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
-                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt);
+                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) ctx->bucket_tab.ptr);
                 else
                     hipLaunchKernelGGL(slice_hash_list_kernel<false>, dim3(grid2), dim3(PXH_T), PixHash<12>::bytes, st, d_events, d_win_lo,
                                        d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
-                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt);
+                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) nullptr);
                 todo = list2;
                 todo_count = cnt2;
             }
