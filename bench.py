@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_EVENT = 29.0     # 25 B record read once + 4 B int32 label written once
-TRAFFIC_PROFILE = "r01w_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
+TRAFFIC_PROFILE = "r02a_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -200,7 +200,7 @@ def main():
     }
     if rank == 0:
         dom = int(np.argmax(stage_ms))
-        names = ["window_bounds_kernel", "slice_hash_kernel", "dbscan_pixel_kernel", "extract_kernel"]
+        names = ["window_bounds_kernel", "slice_hash_ref_kernel", "dbscan_pixel_kernel", "extract_kernel"]   # reference point order (the default)
         achieved = ALGO_BYTES_PER_EVENT * n_events / (stage_ms[dom] * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
         # committed profile (tools/pmc_traffic.py over two rocprofv3 --pmc passes of this same command) is
@@ -208,7 +208,7 @@ def main():
         traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
-            key = {2: "ecal::dbscan_pixel_kernel", 1: "ecal::slice_hash_kernel", 3: "ecal::extract_kernel"}.get(dom)
+            key = {2: "ecal::dbscan_pixel_kernel", 1: "ecal::slice_hash_ref_kernel", 3: "ecal::extract_kernel"}.get(dom)
             hits = [v for k, v in tr["kernels"].items() if k.split("<")[0] == key]   # template arguments vary
             if tr.get("events") == n_events and hits:
                 traffic = max(h["hbm_bytes_per_launch"] for h in hits)
