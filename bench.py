@@ -171,6 +171,27 @@ def main():
             stage_ms[j] += ev[k][j].elapsed_time(ev[k][j + 1])
     stage_ms /= max(args.steps, 1)
 
+    # the same pass as ONE call / one kernel per window (ecal_detect_fused_dev): measured beside the stage-by-stage form above,
+    # outside the timed region; identical results (tests/test_gpu_fused.py).  The faster form is not assumed: both are reported.
+    fused_ms = None
+    if rank == 0 and args.steps > 0:
+        def fused_step():
+            c.detect_fused_dev(events.data_ptr(), n_events, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(),
+                               S, max_win, max_seg, n_events, eps, minpts, pipe.det[0], pipe.det[1], pipe.det[2], pipe.xy.data_ptr(),
+                               pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(), pipe.flags.data_ptr(),
+                               pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(),
+                               pipe.cand_xyr.data_ptr(), pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream,
+                               fit_circle=pipe.det[3], knn_num=pipe.det[4])
+        for _ in range(2):
+            fused_step()
+        fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        fe[0].record(st)
+        for _ in range(args.steps):
+            fused_step()
+        fe[1].record(st)
+        torch.cuda.synchronize(dev)
+        fused_ms = fe[0].elapsed_time(fe[1]) / args.steps
+
     total_events = n_events * world * args.steps
     value = total_events / elapsed / 1e6
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -222,6 +243,11 @@ def main():
             "stage_ms": {"window_bounds": round(float(stage_ms[0]), 4), "slice": round(float(stage_ms[1]), 4),
                          "dbscan": round(float(stage_ms[2]), 4), "extract": round(float(stage_ms[3]), 4)},
         }
+        if fused_ms is not None:
+            out["fused_pass"] = {"ms_slice_dbscan_extract": round(float(fused_ms), 4),
+                                 "staged_ms_slice_dbscan_extract": round(float(stage_ms[1] + stage_ms[2] + stage_ms[3]), 4),
+                                 "note": "ecal_detect_fused_dev: one kernel carries a window through slicing, both DBSCAN runs and "
+                                         "extraction; same results; not the timed path (the stage-by-stage form is faster, profiles/r02_notes.md)"}
         if args.cpu_sample > 0 and world == 1:
             import oracle_lib as O
             m = min(args.cpu_sample, n_events)

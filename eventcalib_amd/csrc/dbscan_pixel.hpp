@@ -168,12 +168,15 @@ __device__ __forceinline__ bool px_level_step(unsigned char *slotb, uint32_t i, 
     return true;
 }
 
-template <int E2I, int CAP>
-__device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_t s, const double *__restrict__ xy,
+// returns the number of clusters, or -1 when the segment was left to the to-do list.  KNOWN: the segment's count and offset are handed in (the fused
+// pass, ecal_fused.hip: they were written by this very workgroup a moment ago, and a scalar load could find a stale line of
+// the constant cache, which a neighbouring workgroup may have filled with the array's previous contents)
+template <int E2I, int CAP, bool KNOWN = false>
+__device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t s, const double *__restrict__ xy,
                                            const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
                                            const PxGeom &geom, uint32_t minpts, int32_t *__restrict__ labels,
                                            uint32_t *__restrict__ n_clusters, uint32_t *__restrict__ todo,
-                                           uint32_t *__restrict__ todo_count) {
+                                           uint32_t *__restrict__ todo_count, uint32_t known_cnt = 0, uint32_t known_off = 0) {
     using L = PixelLayout<CAP>;
     using F = PxFmt<CAP>;
     using G = GeoI16;
@@ -183,16 +186,16 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     unsigned long long phase_t__ = __builtin_readcyclecounter(), d7__ = 0;
     uint32_t levels__ = 0;
 #endif
-    const uint32_t n = seg_cnt[s];
-    const uint32_t base32 = seg_off[s];  // asked for together with the count: one trip to memory instead of two in a row
+    const uint32_t n = KNOWN ? known_cnt : seg_cnt[s];
+    const uint32_t base32 = KNOWN ? known_off : seg_off[s];  // asked for together with the count: one trip to memory instead of two in a row
     asm volatile("" ::"s"(base32));     // (a use right here, or the compiler sinks the load below the branches on n)
     if (n == 0) {
         if (tid == 0) n_clusters[s] = 0;
-        return;
+        return 0;
     }
     if (n > (uint32_t) CAP) {
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
-        return;
+        return -1;
     }
     // E2I > 0: the disc is a compile-time constant (masks become literals, the row loops unroll)
     const int Rd = E2I > 0 ? px_isqrt(E2I) : geom.Rd;
@@ -229,7 +232,7 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
 #define PX_BAIL()                                                  \
     do {                                                           \
         if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;         \
-        return;                                                    \
+        return -1;                                                \
     } while (0)
     // debug builds (-DECAL_PX_STOP=k, tools/px_stop_probe.sh): leave after phase k with the phase's results written
     // out, so that instruction counters can be attributed to phases
@@ -241,7 +244,7 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
             if (i < n) labels[base + i] = (int32_t) (expr);                               \
         }                                                                                 \
         if (tid == 0) n_clusters[s] = 0;                                                  \
-        return;                                                                           \
+        return 0;                                                                         \
     }
 #else
 #define PX_STOP(k, expr)
@@ -726,6 +729,7 @@ __device__ __forceinline__ void px_segment(unsigned char *px_smem, const uint32_
     ECAL_PHASE_MARK(4);
 #undef PX_BAIL
 #undef PX_STOP
+    return (int) total;
 }
 
 // first pass: workgroup b handles segment b; what it cannot take goes to todo / todo_count

@@ -231,7 +231,8 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
     if (rc) return rc;
     hipStream_t st = (hipStream_t) stream;
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
-    const bool second_pass = mx > (uint32_t) PX_CAP && !getenv("ECAL_DBSCAN_NO_SECOND_PASS");  // debug switch
+    // (fused pass: its to-do list also holds the segments of windows the fused kernel did not slice, of any size)
+    const bool second_pass = (mx > (uint32_t) PX_CAP || ctx->fused_pass) && !getenv("ECAL_DBSCAN_NO_SECOND_PASS");  // debug switch
 
     // event pixels (integer coordinates, eps < 16): the lean pixel kernel takes every segment it can and lists
     // the others; the general tiers then work that list off with a small grid (it is normally empty)
@@ -243,11 +244,13 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
         // two to-do lists: what the first pass (<= 1024 points) leaves, and what the second (<= 2048 points) leaves of that
         if ((rc = ecal_ensure(ctx, ctx->px_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
         uint32_t *cnt = (uint32_t *) ctx->px_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
-        ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+        // (fused pass, ecal_fused.hip: the first pass has run inside the fused kernel and has filled the first to-do list)
+        const bool fused = ctx->fused_pass;
+        if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
         const uint32_t grid2 = S < 1024u ? S : 1024u;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC")) {
-            hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
+            if (!fused) hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
             if (second_pass)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<16, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,

@@ -57,7 +57,8 @@ class DetectPipeline:
         """clusterMinSample, rows*cols, circleRadiusThreshold_, fitCircle, knn_num (defaults: example.yaml, 346x260)."""
         self.det = (int(cluster_min), int(need_clusters), float(radius_threshold), bool(fit_circle), int(knn_num))
 
-    def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True, slice_only=False):
+    def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True, slice_only=False,
+            fused=False):
         """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN -> candidate
         extraction on the current torch stream; results stay in HBM (self.xy / seg_off / seg_cnt /
         labels / n_clusters / win_info / cand_pair / cand_xyr / kept_labels / rep)."""
@@ -70,6 +71,16 @@ class DetectPipeline:
         c = self.ctx
         c.window_bounds_dev(events.data_ptr(), n, self.t0.data_ptr(), self.t1.data_ptr(), S, self.win_lo.data_ptr(),
                             self.win_hi.data_ptr(), self.win_base.data_ptr(), st)
+        if fused:               # the three stages below as one call (ecal_detect_fused_dev): same arrays, same results
+            if not hasattr(self, "det"):
+                self.set_detect_params()
+            c.detect_fused_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(), self.win_base.data_ptr(), S,
+                               max_win_events, max_seg_points, slots, eps, minpts, self.det[0], self.det[1], self.det[2],
+                               self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),
+                               self.flags.data_ptr(), self.labels.data_ptr(), self.n_clusters.data_ptr(), self.win_info.data_ptr(),
+                               self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(), self.kept_labels.data_ptr(), self.rep.data_ptr(),
+                               st, fit_circle=self.det[3], knn_num=self.det[4])
+            return self
         c.slice_events_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(),
                            self.win_base.data_ptr(), S, max_win_events, slots, self.xy.data_ptr(),
                            self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),

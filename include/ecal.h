@@ -163,6 +163,21 @@ int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_
                            double *d_cand_xyr /*[n_points][3]*/, int32_t *d_kept_labels /*[n_points]*/,
                            uint32_t *d_rep /*[n_points]*/, void *stream);
 
+/* ---- the whole per-window body in one call ---------------------------------------------------
+ * ecal_detect_fused_dev = ecal_slice_events_dev + ecal_dbscan_batch_dev (over the 2S segments) + ecal_extract_batch_dev
+ * with the same arguments, the same output arrays and the same results bit for bit — the body of the reference's worker
+ * loop per window (event_camera_calib/test/eventCameraCalib.cpp:49-56: EventFrame constructor, extractFeatures with its two
+ * DBSCAN::Run calls).  In the shipped configuration (reference point order, eps < 16, fitCircle == 0) ONE kernel carries a
+ * window through all three stages on one compute unit; what that kernel cannot take goes through the stages' later passes
+ * as before.  Any other configuration runs the three stage functions one after the other. */
+int ecal_detect_fused_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const uint32_t *d_win_lo,
+                          const uint32_t *d_win_hi, const uint32_t *d_win_base, uint32_t S, uint32_t max_win_events,
+                          uint32_t max_seg_points, uint32_t cap_points, double eps, uint32_t minpts, uint32_t cluster_min,
+                          uint32_t need_clusters, double radius_threshold, int fit_circle, uint32_t knn_num,
+                          double *d_xy, uint32_t *d_seg_off /*[2S]*/, uint32_t *d_seg_cnt /*[2S]*/, int32_t *d_event_point,
+                          int *d_overflow, int32_t *d_labels, uint32_t *d_n_clusters /*[2S]*/, uint32_t *d_win_info /*[S][4]*/,
+                          uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream);
+
 /* ---- host-buffer conveniences (what the C++ shims in eventcalib_amd/csrc/host/ call) ----------
  * ecal_stream: the event stream uploaded once and kept in HBM — the counterpart of the reference's
  *   EventContainer (event/include/opengv2/event/EventContainer.hpp:25-30), filled once by the driver
