@@ -8,9 +8,10 @@
 //   CalibReprojectionError::operator() (EventCalibSpline.hpp:158-229) — see spline_residual.hpp.
 // Residuals are sorted by (segment, time); a "chunk" is a run of residuals inside one knot span, so all
 // its rows share the same 33 columns and J^T J of the chunk is one dense 34x34 (33 + residual) Gram
-// matrix.  It is accumulated with register-tiled FP64 FMAs (4x4 tiles): on gfx950 the FP64 MFMA peak
-// equals the FP64 vector peak and the 16x16x4 shape would pad 34 to 48 (2x the flops), so matrix
-// cores buy nothing here.
+// matrix.  It is accumulated with register-tiled FP64 FMAs (6x6 tiles).  The matrix cores were tried and measured
+// (profiles/experiments/r02_normal_eq_mfma_f64.patch): v_mfma_f64_16x16x4_f64 pads 34 columns to 48 (six 16x16 tiles,
+// 2x the multiply-adds) and runs at 46 - 50 TFLOP/s on this part against 65 - 72 for plain v_fma_f64
+// (profiles/experiments/r02_fp64_*_rate.hip): 4.63 ms per evaluation against 3.59.
 #include <functional>
 #include <limits>
 #include "ecal_ctx.hpp"
@@ -66,7 +67,31 @@ __device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_i
     }
 }
 
-template <bool SO3>
+// The Gram accumulation reads two tile slices of a row (six 16-byte LDS reads) per 36 FMAs.  Left to the compiler every row's
+// reads sit at the top of their own iteration and their latency opens it (the kernel is at the register limit: the scheduler
+// will not keep a second row in flight).  These helpers issue a row's reads and wait for the reads issued BEFORE the last
+// six: the loop keeps one row in flight behind the row it is multiplying.  (LDS operations of a wave complete in order.)
+typedef double ne_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ne_lds_read6(uint32_t a_addr, uint32_t b_addr, ne_v2d (&A)[3], ne_v2d (&B)[3]) {
+    asm volatile(
+        "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+        "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\tds_read_b128 %5, %7 offset:32"
+        : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(B[0]), "=&v"(B[1]), "=&v"(B[2])
+        : "v"(a_addr), "v"(b_addr));
+}
+__device__ __forceinline__ void ne_lds_wait_but6(ne_v2d (&A)[3], ne_v2d (&B)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]));
+}
+__device__ __forceinline__ void ne_fma36(double (&acc)[36], const ne_v2d (&A)[3], const ne_v2d (&B)[3]) {
+    const double a[6] = {A[0].x, A[0].y, A[1].x, A[1].y, A[2].x, A[2].y}, b[6] = {B[0].x, B[0].y, B[1].x, B[1].y, B[2].x, B[2].y};
+#pragma unroll
+    for (int x = 0; x < 6; x++)
+#pragma unroll
+        for (int y = 0; y < 6; y++) acc[6 * x + y] += a[x] * b[y];
+}
+
+// WITH_JAC = false: cost only (no rows, no LDS, no tiles) — its own, small instantiation (69 VGPRs against 233)
+template <bool SO3, bool WITH_JAC>
 __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResRecord *__restrict__ rec,
                                                          const Chunk *__restrict__ chunks,
                                                          const double *__restrict__ knots,
@@ -74,8 +99,9 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
                                                          const uint32_t *__restrict__ cp_off,
                                                          const double *__restrict__ params, uint32_t n_cp_total,
                                                          const double *__restrict__ landmarks, double radius,
-                                                         double huber_a, int with_jac, double *__restrict__ accum,
+                                                         double huber_a, double *__restrict__ accum,
                                                          double *__restrict__ heads) {
+    constexpr bool with_jac = WITH_JAC;
     constexpr int NE_TW = SO3 ? 4 : 6;
     constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES, NE_GROUPS = NeTiles<NE_TW>::GROUPS;
     extern __shared__ __attribute__((aligned(16))) double rows[];  // [NE_T][NE_LD] when with_jac
@@ -150,22 +176,46 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             __syncthreads();
             if (grp < NE_GROUPS) {
                 const uint32_t nrow = min((uint32_t) NE_T, ch.count - b0);
-                for (uint32_t rk = grp; rk < nrow; rk += NE_GROUPS) {
-                    const double *rw = rows + (size_t) rk * NE_LD;
-                    double a[NE_TW], bb[NE_TW];
-#pragma unroll
-                    for (int x = 0; x < NE_TW; x += 2) {  // 16-byte LDS reads (tile starts are 48-byte aligned)
-                        const double2 av = *reinterpret_cast<const double2 *>(rw + NE_TW * ti + x);
-                        const double2 bv = *reinterpret_cast<const double2 *>(rw + NE_TW * tj + x);
-                        a[x] = av.x;
-                        a[x + 1] = av.y;
-                        bb[x] = bv.x;
-                        bb[x + 1] = bv.y;
+                if constexpr (NE_TW == 6) {
+                    // one row in flight behind the row being multiplied (see ne_lds_read6); rows past the end are clamped reads
+                    // whose values are dropped
+                    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) double *) rows;
+                    const uint32_t a0 = lds0 + 8u * NE_TW * (uint32_t) ti, b0a = lds0 + 8u * NE_TW * (uint32_t) tj;
+                    constexpr uint32_t ROWB = NE_LD * 8u;
+                    ne_v2d A0[3], B0[3], A1[3], B1[3];
+                    {
+                        const uint32_t o = min((uint32_t) grp, nrow - 1u) * ROWB;
+                        ne_lds_read6(a0 + o, b0a + o, A0, B0);
                     }
+                    for (uint32_t rk = grp; rk < nrow; rk += 2 * NE_GROUPS) {
+                        const uint32_t r1 = rk + NE_GROUPS, r2 = rk + 2 * NE_GROUPS;
+                        const uint32_t o1 = min(r1, nrow - 1u) * ROWB, o2 = min(r2, nrow - 1u) * ROWB;
+                        ne_lds_read6(a0 + o1, b0a + o1, A1, B1);
+                        ne_lds_wait_but6(A0, B0);
+                        ne_fma36(acc, A0, B0);
+                        ne_lds_read6(a0 + o2, b0a + o2, A0, B0);
+                        ne_lds_wait_but6(A1, B1);
+                        if (r1 < nrow) ne_fma36(acc, A1, B1);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last (unused) prefetch, before the rows are rewritten
+                } else {
+                    for (uint32_t rk = grp; rk < nrow; rk += NE_GROUPS) {
+                        const double *rw = rows + (size_t) rk * NE_LD;
+                        double a[NE_TW], bb[NE_TW];
 #pragma unroll
-                    for (int x = 0; x < NE_TW; x++)
+                        for (int x = 0; x < NE_TW; x += 2) {  // 16-byte LDS reads (tile starts are 48-byte aligned)
+                            const double2 av = *reinterpret_cast<const double2 *>(rw + NE_TW * ti + x);
+                            const double2 bv = *reinterpret_cast<const double2 *>(rw + NE_TW * tj + x);
+                            a[x] = av.x;
+                            a[x + 1] = av.y;
+                            bb[x] = bv.x;
+                            bb[x + 1] = bv.y;
+                        }
 #pragma unroll
-                        for (int y = 0; y < NE_TW; y++) acc[NE_TW * x + y] += a[x] * bb[y];
+                        for (int x = 0; x < NE_TW; x++)
+#pragma unroll
+                            for (int y = 0; y < NE_TW; y++) acc[NE_TW * x + y] += a[x] * bb[y];
+                    }
                 }
             }
             __syncthreads();
@@ -421,10 +471,10 @@ extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, e
     if (e == hipSuccess) e = hipMalloc((void **) &s->d_accum, s->n_accum() * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **) &s->d_heads, NE_REPL * ACC_HEAD * sizeof(double));
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
     if (e != hipSuccess) {
         ctx->last_error = std::string("ecal_solver_create: ") + hipGetErrorString(e);
@@ -445,14 +495,15 @@ extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, 
     ECAL_HIP_TRY(ctx, hipMemsetAsync(s->d_heads, 0, NE_REPL * ACC_HEAD * sizeof(double), st));
     if (s->n_chunks) {
         const size_t lds = with_jacobian ? NE_T * NE_LD * sizeof(double) : 0;
-        if (s->use_so3)
-            hipLaunchKernelGGL(normal_eq_kernel<true>, dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks,
-                               s->d_knots, s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius,
-                               s->huber_a, with_jacobian, d_accum, s->d_heads);
-        else
-            hipLaunchKernelGGL(normal_eq_kernel<false>, dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks,
-                               s->d_knots, s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius,
-                               s->huber_a, with_jacobian, d_accum, s->d_heads);
+#define ECAL_NE_LAUNCH(SO3_, JAC_)                                                                                          \
+    hipLaunchKernelGGL((normal_eq_kernel<SO3_, JAC_>), dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks, s->d_knots, \
+                       s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads)
+        if (s->use_so3) {
+            if (with_jacobian) ECAL_NE_LAUNCH(true, true); else ECAL_NE_LAUNCH(true, false);
+        } else {
+            if (with_jacobian) ECAL_NE_LAUNCH(false, true); else ECAL_NE_LAUNCH(false, false);
+        }
+#undef ECAL_NE_LAUNCH
         hipLaunchKernelGGL(reduce_heads_kernel, dim3(1), dim3(128), 0, st, s->d_heads, d_accum,
                            with_jacobian ? (uint32_t) ACC_HEAD : 1u);
         ECAL_HIP_TRY(ctx, hipGetLastError());
