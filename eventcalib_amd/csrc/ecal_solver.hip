@@ -12,7 +12,12 @@
 // (profiles/experiments/r02_normal_eq_mfma_f64.patch): v_mfma_f64_16x16x4_f64 pads 34 columns to 48 (six 16x16 tiles,
 // 2x the multiply-adds) and runs at 46 - 50 TFLOP/s on this part against 65 - 72 for plain v_fma_f64
 // (profiles/experiments/r02_fp64_*_rate.hip): 4.63 ms per evaluation against 3.59.
+#include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <limits>
 #include "ecal_ctx.hpp"
 #include "spline_residual.hpp"
@@ -595,31 +600,45 @@ struct ArrowSystem {
 };
 
 // unpack the accumulation buffer (upper blocks) into the symmetric arrow system
-void unpack(const double *acc, uint32_t n_cp, ArrowSystem &A) {
-    A.nc = 6 * (size_t) n_cp;
-    A.band.assign(A.nc * BW, 0.0);
-    A.border.assign(A.nc * 9, 0.0);
-    A.gc.assign(A.nc, 0.0);
+void unpack_head(const double *acc, ArrowSystem &A) {
     for (int i = 0; i < 9; i++) {
         A.gi[i] = acc[1 + i];
         for (int j = i; j < 9; j++) A.corner[9 * i + j] = A.corner[9 * j + i] = acc[10 + 9 * i + j];
     }
-    for (uint32_t c = 0; c < n_cp; c++) {
-        const double *b = acc + ACC_HEAD + ACC_PER_CP * (size_t) c;
+}
+// rows of control points [r_lo, r_hi): the band row of control point r = blocks (c, r) for c = r - 3 .. r, read from the column
+// owners' records — a range writes its own rows only, so ranges may run on different threads
+void unpack_rows(const double *acc, ArrowSystem &A, uint32_t r_lo, uint32_t r_hi) {
+    for (uint32_t r = r_lo; r < r_hi; r++) {
+        const double *b = acc + ACC_HEAD + ACC_PER_CP * (size_t) r;
         for (int k = 0; k < 6; k++) {
-            A.gc[6 * c + k] = b[k];
-            for (int j = 0; j < 9; j++) A.border[(6 * c + k) * 9 + j] = b[6 + 9 * k + j];
+            A.gc[6 * r + k] = b[k];
+            for (int j = 0; j < 9; j++) A.border[(6 * (size_t) r + k) * 9 + j] = b[6 + 9 * k + j];
+            double *row = &A.band[(6 * (size_t) r + k) * BW];
+            for (int q = 0; q < BW; q++) row[q] = 0.0;
         }
-        for (uint32_t d = 0; d < 4 && c + d < n_cp; d++) {
-            const double *blk = b + 60 + 36 * d;
+        for (uint32_t d = 0; d < 4 && d <= r; d++) {
+            const uint32_t c = r - d;   // column owner: block (c, c + d) of its record
+            const double *blk = acc + ACC_HEAD + ACC_PER_CP * (size_t) c + 60 + 36 * d;
             for (int ka = 0; ka < 6; ka++)
                 for (int kb = 0; kb < 6; kb++) {
                     if (d == 0 && kb < ka) continue;  // diagonal block: upper stored
-                    const size_t row = 6 * (size_t) (c + d) + kb, col = 6 * (size_t) c + ka;  // row >= col
+                    const size_t row = 6 * (size_t) r + kb, col = 6 * (size_t) c + ka;  // row >= col
                     A.band[row * BW + (row - col)] = blk[6 * ka + kb];
                 }
         }
     }
+}
+void unpack_alloc(uint32_t n_cp, ArrowSystem &A) {
+    A.nc = 6 * (size_t) n_cp;
+    A.band.resize(A.nc * BW);
+    A.border.resize(A.nc * 9);
+    A.gc.resize(A.nc);
+}
+void unpack(const double *acc, uint32_t n_cp, ArrowSystem &A) {
+    unpack_alloc(n_cp, A);
+    unpack_head(acc, A);
+    unpack_rows(acc, A, 0, n_cp);
 }
 
 // Solve (S A S + diag(dd)) y = -S g for the arrow system; returns false if not positive definite.
@@ -747,18 +766,38 @@ __attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const
     return true;
 }
 
+#include "arrow_host_parts.hpp"
+
 // y^T A y and g^T y on the unscaled system (for the model cost change)
 // skip_shared: distributed mode, ranks other than 0 — the intrinsics-only terms are counted once
-void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd, double *dHd, bool skip_shared = false) {
+void quad_forms_rows(const ArrowSystem &A, const std::vector<double> &d, size_t lo, size_t hi, double *gTd, double *dHd) {
     const size_t nc = A.nc;
     double g = 0, h = 0;
-    for (size_t i = 0; i < nc; i++) {
+    for (size_t i = lo; i < hi; i++) {
         g += A.gc[i] * d[i];
         double row = A.band[i * BW] * d[i];
         const int kmax = std::min<size_t>(BW - 1, i);
         for (int k = 1; k <= kmax; k++) row += 2.0 * A.band[i * BW + k] * d[i - k];
         h += d[i] * row;
         for (int j = 0; j < 9; j++) h += 2.0 * d[i] * A.border[i * 9 + j] * d[nc + j];
+    }
+    *gTd = g;
+    *dHd = h;
+}
+void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd, double *dHd, bool skip_shared = false, HostPool *pool = nullptr,
+                int tasks = 1) {
+    const size_t nc = A.nc;
+    double g = 0, h = 0;
+    if (pool && tasks > 1) {   // fixed ranges, partial sums added in range order: the result does not depend on the thread count
+        std::vector<double> part(2 * (size_t) tasks, 0.0);
+        const size_t per = (nc + tasks - 1) / tasks;
+        pool->run(tasks, [&](int t) { quad_forms_rows(A, d, std::min(nc, t * per), std::min(nc, (t + 1) * per), &part[2 * t], &part[2 * t + 1]); });
+        for (int t = 0; t < tasks; t++) {
+            g += part[2 * t];
+            h += part[2 * t + 1];
+        }
+    } else {
+        quad_forms_rows(A, d, 0, nc, &g, &h);
     }
     for (int i = 0; i < 9 && !skip_shared; i++) {
         g += A.gi[i] * d[nc + i];
@@ -1107,6 +1146,33 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         return ECAL_OK;
     };
 
+    // one rank, a long spline: the factorisation, the unpacking and the quadratic forms run on several host cores
+    // (arrow_host_parts.hpp); the sharded modes keep the sequential routines (their segments are short, and the sequential
+    // routine's 10 x 10 Schur sums are what the ranks exchange)
+    ArrowParts parts;
+    int n_parts = dist_mode ? 1 : arrow_parts_for(s->n_cp);
+    if ((uint32_t) (7 * n_parts) > s->n_cp) n_parts = 1;
+    std::unique_ptr<HostPool> pool;
+    double t_unpack = 0, t_pool = 0;
+    if (n_parts > 1) {   // (the workers start while the GPU runs the first evaluation)
+        const auto tp = now();
+        const int hw = (int) std::max(1u, std::thread::hardware_concurrency());
+        pool.reset(new HostPool(std::max(0, std::min(n_parts, hw) - 1)));
+        t_pool = secs(tp, now());
+    }
+    auto unpack_acc = [&]() {
+        const auto tu = now();
+        if (pool) {   // band rows by ranges of control points, one range per task
+            unpack_alloc(s->n_cp, A);
+            unpack_head(acc, A);
+            const uint32_t T = 4u * (uint32_t) n_parts, per = (s->n_cp + T - 1) / T;
+            pool->run((int) T, [&](int t) { unpack_rows(acc, A, std::min(s->n_cp, (uint32_t) t * per), std::min(s->n_cp, ((uint32_t) t + 1) * per)); });
+        } else {
+            unpack(acc, s->n_cp, A);
+        }
+        t_unpack += secs(tu, now());
+    };
+
     ecal_lm_summary S;
     memset(&S, 0, sizeof(S));
     double cost = 0, radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
@@ -1114,7 +1180,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     if (rc) return rc;
     S.jacobian_evaluations = 1;
     S.initial_cost = cost;
-    unpack(acc, s->n_cp, A);
+    unpack_acc();
     if (opt.jacobi_scaling) {  // computed once from the initial Jacobian, as Ceres does
         for (size_t i = 0; i < nc; i++) scale[i] = 1.0 / (1.0 + std::sqrt(A.band[i * BW]));
         for (int i = 0; i < 9; i++) scale[nc + i] = 1.0 / (1.0 + std::sqrt(A.corner[10 * i]));
@@ -1157,12 +1223,12 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             dd[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
         }
         const auto tl = now();
-        bool ok = solve_arrow(A, scale, dd, delta, ws);
+        bool ok = n_parts > 1 ? solve_arrow_parts(A, scale, dd, delta, ws, parts, *pool, n_parts) : solve_arrow(A, scale, dd, delta, ws);
         double model_change = 0;
         if (ok) {
             for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
             double gTd, dHd;
-            quad_forms(A, delta, &gTd, &dHd, dist_mode && my_rank != 0);
+            quad_forms(A, delta, &gTd, &dHd, dist_mode && my_rank != 0, pool.get(), n_parts);
             if (dist_mode) {
                 double two[2] = {gTd, dHd};
                 if (!reduce_small(two, 2)) return ECAL_ERR_HIP;
@@ -1215,7 +1281,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
                 if (rc) return rc;
                 S.jacobian_evaluations++;
             }
-            unpack(acc, s->n_cp, A);
+            unpack_acc();
             S.successful_steps++;
             last_step_ok = true;
             const double t = 2.0 * rel - 1.0;
@@ -1236,6 +1302,9 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     S.seconds_evaluate = t_eval;
     S.seconds_linear_solve = t_lin;
+    if (getenv("ECAL_SOLVER_TRACE"))
+        fprintf(stderr, "ecal_solver_solve: total %.4f s | evaluate %.4f | linear solve %.4f (%d parts) | unpack %.4f | pool %.4f\n", S.seconds,
+                t_eval, t_lin, n_parts, t_unpack, t_pool);
     memcpy(params, x.data(), np * sizeof(double));
     if (sum) *sum = S;
     return ECAL_OK;
@@ -1260,7 +1329,7 @@ extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const
     if (!s || !accum || !scale || !delta_out || !fail_out) return ECAL_ERR_INVALID;
     ecal_ctx *ctx = s->ctx;
     const size_t nc = 6 * (size_t) s->n_cp, nt = nc + 9, na = s->n_accum();
-    if (!use_device) {
+    if (use_device != 1) {
         ArrowSystem A;
         ArrowWorkspace ws;
         unpack(accum, s->n_cp, A);
@@ -1269,7 +1338,17 @@ extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const
             const double h = (i < nc ? A.band[i * BW] : A.corner[10 * (i - nc)]) * sc[i] * sc[i];
             dd[i] = std::min(std::max(h, min_diag), max_diag) / radius;
         }
-        const bool ok = solve_arrow(A, sc, dd, y, ws);
+        bool ok;
+        if (use_device == 2) {   // the host routine's partitioned form (arrow_host_parts.hpp)
+            ArrowParts parts;
+            int P = arrow_parts_for(s->n_cp);
+            if (P < 2) P = 4;
+            if ((uint32_t) (7 * P) > s->n_cp) return ECAL_ERR_RANGE;
+            HostPool pool(3);
+            ok = solve_arrow_parts(A, sc, dd, y, ws, parts, pool, P);
+        } else {
+            ok = solve_arrow(A, sc, dd, y, ws);
+        }
         *fail_out = ok ? 0 : 1;
         if (ok)
             for (size_t i = 0; i < nt; i++) delta_out[i] = y[i] * sc[i];

@@ -205,7 +205,7 @@ def test_per_residual_rows_match_dual_numbers(ctx, use_so3):
     s.close()
 
 
-@pytest.mark.parametrize("n_cp,n_res", [(4, 2000), (9, 3000), (27, 6000), (50, 12000), (131, 30000), (700, 150000)])
+@pytest.mark.parametrize("n_cp,n_res", [(4, 2000), (9, 3000), (27, 6000), (28, 6000), (50, 12000), (131, 30000), (700, 150000)])
 def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
     """The partitioned banded-arrow Cholesky on the device (arrow_device.hpp: interiors in parallel, separators' reduced
     system, intrinsics, back substitution) against the sequential host factorisation of the same scaled, damped system:
@@ -238,6 +238,14 @@ def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
         host, devd = out
         assert np.abs(host).max() > 0
         assert np.abs(devd - host).max() <= 1e-8 * np.abs(host).max(), (n_cp, radius, np.abs(devd - host).max(), np.abs(host).max())
+        # the host routine's own partitioned form (arrow_host_parts.hpp: interiors on several cores, separators' reduced system):
+        # mode 2 of the hook, 4 interiors here, what ecal_solver_solve uses on long splines
+        if n_cp >= 28:
+            d = np.zeros(nt)
+            fail = ctypes.c_int(-1)
+            rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d.ctypes.data, ctypes.byref(fail), 2)
+            assert rc == 0 and fail.value == 0, (rc, fail.value)
+            assert np.abs(d - host).max() <= 1e-9 * np.abs(host).max(), (n_cp, radius, np.abs(d - host).max(), np.abs(host).max())
         # and it solves the system: (S A S + D) y = -S g, checked densely for the small cases
         if n_cp <= 50:
             perm = np.concatenate([np.arange(9, nt), np.arange(9)])
