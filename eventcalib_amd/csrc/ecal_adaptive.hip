@@ -98,16 +98,18 @@ __global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_t
     t1[k] = act ? second : -INFINITY;
 }
 
-// one thread per piece: verdict of the pass -> gate -> keyframe record -> next window
-__global__ void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t pass, const uint32_t *__restrict__ win_info,
+// one 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window.  The rows' line fits (a
+// 3 x 3 Jacobi eigen-decomposition each, the bulk of the work) run on one lane per row; lane 0 does the rest.
+__global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t pass, const uint32_t *__restrict__ win_info,
                                      const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
                                      const double *__restrict__ cand_xyr, const int32_t *__restrict__ order,
                                      const uint32_t *__restrict__ found, AdaptiveArrays st, double mts, uint32_t thr_events,
                                      uint32_t max_keys, double *__restrict__ kf_time, double *__restrict__ kf_dur,
                                      int32_t *__restrict__ kf_events, double *__restrict__ kf_feat, double *__restrict__ t0,
                                      double *__restrict__ t1, const int *__restrict__ overflow) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0 && *overflow) st.counters[3] = 1;  // the slicer clears its flag at every call: keep it until the host looks
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
+    __shared__ double dir[AD_MAX_ROWS][2];
+    if (k == 0 && lane == 0 && *overflow) st.counters[3] = 1;  // the slicer clears its flag at every call: keep it until the host looks
     if (k >= P || !st.active[k]) return;
     const uint32_t M = rows * cols;
     const double ln = 3 * mts, gap = 5 * mts;
@@ -115,12 +117,17 @@ __global__ void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, u
     const uint32_t cnt = seg_cnt[2 * k] + seg_cnt[2 * k + 1];  // EventFrame::eventsNum()
     const bool ok = win_info[4 * k + 3] == 0 && found[k];     // extractFeatures() == true
     bool accepted = false;
+    if (ok) {   // (uniform over the workgroup)
+        const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * k];
+        const int32_t *ord = order + (size_t) k * M;
+        if (lane < rows) row_direction(xyr, ord + lane * cols, cols, dir[lane][0], dir[lane][1]);
+        __syncthreads();
+    }
+    if (lane != 0) return;
     if (ok) {
         const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * k];
         const int32_t *ord = order + (size_t) k * M;
         const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
-        double dir[AD_MAX_ROWS][2];
-        for (uint32_t i = 0; i < rows; i++) row_direction(xyr, ord + i * cols, cols, dir[i][0], dir[i][1]);
         accepted = true;
         if (st.have_ref[k]) {  // EventCalibIni::track: median row angle / time distance
             double theta[AD_MAX_ROWS];
@@ -268,7 +275,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
                                       (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
             return rc;
-        hipLaunchKernelGGL(adaptive_step_kernel, dim3((P + 127) / 128), dim3(128), 0, st, P, prm->rows, prm->cols, pass,
+        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, pass,
                            (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
                            (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                            (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
