@@ -1167,7 +1167,12 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     if (n_parts > 1) {   // (the workers start while the GPU runs the first evaluation)
         const auto tp = now();
         const int hw = (int) std::max(1u, std::thread::hardware_concurrency());
-        pool.reset(new HostPool(std::max(0, std::min(n_parts, hw) - 1)));
+        try {
+            pool.reset(new HostPool(std::max(0, std::min(n_parts, hw) - 1)));
+        } catch (...) {   // no threads to be had: the sequential routines
+            pool.reset();
+            n_parts = 1;
+        }
         t_pool = secs(tp, now());
     }
     auto unpack_acc = [&]() {
