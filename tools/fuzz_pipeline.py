@@ -17,7 +17,7 @@ for seed, rate, noise in itertools.product(range(int(sys.argv[1]) if len(sys.arg
     t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
     pipe.set_windows(t0, t1)
     pipe.set_detect_params(5, 36, TD.THR)
-    pipe.run(buf.cuda())
+    pipe.run(buf.cuda(), fused=bool(os.environ.get("FUSED")))   # FUSED=1: through ecal_detect_fused_dev
     torch.cuda.synchronize()
     TE._compare(pipe, torch, buf.numpy(), t0, t1, check_labels=True)          # slicing + DBSCAN labels
     exact, tied = TD._check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, TD.THR)   # extraction
