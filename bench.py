@@ -38,7 +38,7 @@ def main():
                     help="pieces of the adaptive-window policy P2 (SURVEY 8d) measured after M1 (0 = skip; -1 = the reference's "
                          "own choice on this host, 5 * (hardware threads - 2), and 4096)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe upload timing")
-    ap.add_argument("--ingest-events", type=int, default=50_000_000,
+    ap.add_argument("--ingest-events", type=int, default=200_000_000,
                     help="events of the double-buffered ingest leg (configs[4]; host-resident stream; 0 = skip)")
     ap.add_argument("--calib-views", type=int, default=64,
                     help="views of the init calibration leg (configs[3]: 64 views sharded over the GPUs; 0 = skip)")
