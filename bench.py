@@ -338,8 +338,10 @@ def main():
         out_solver = solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np)
         if rank == 0:
             out["solver"] = out_solver
-    if args.ingest_events > 0 and rank == 0 and world == 1:
-        out["ingest"] = ingest_leg(args, ctx, dev, torch, np, rate)
+    if args.ingest_events > 0:
+        out_ingest = ingest_leg(args, ctx, dev, world, rank, dist, torch, np, rate)
+        if rank == 0:
+            out["ingest"] = out_ingest
     if args.calib_views > 0:
         out_calib = calib_leg(args, ctx, dev, world, rank, dist, torch, np)
         if rank == 0:
@@ -498,27 +500,38 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
     solver.close()
     return out
 
-def ingest_leg(args, ctx, dev, torch, np, rate):
+def ingest_leg(args, ctx, dev, world, rank, dist, torch, np, rate):
     """configs[4]: the stream starts in (pinned) HOST memory; chunks are uploaded with hipMemcpyAsync on a copy stream
-    while the previous chunk is detected (ecal_detect_stream_tiled) — PCIe-inclusive events/s, reported beside M1."""
+    while the previous chunk is detected (ecal_detect_stream_tiled) — PCIe-inclusive events/s, reported beside M1.
+    N GPUs: the events are split into N time ranges, one per rank (own pinned buffer, own PCIe link, no collective);
+    the rate is all events over the slowest rank's time."""
     import synth_stream as SS
     from eventcalib_amd import capi
-    n = args.ingest_events
+    n = args.ingest_events // world                 # this rank's time range
+    t_begin = 5.0 + rank * (n / rate)
     host = torch.empty(n * 25, dtype=torch.uint8, pin_memory=True)
-    host.copy_(SS.make_stream(n, rate=rate, t_start=5.0, seed=4242, device=dev))
+    host.copy_(SS.make_stream(n, rate=rate, t_start=t_begin, seed=4242 + rank, device=dev))
     torch.cuda.synchronize(dev)
     S = int(np.floor((n - 1) / rate / 1.5e-3)) + 1
     res = {}
     for wpc in (2048, S + 1):                       # double-buffered chunks vs one chunk (upload, then detect)
-        capi.detect_stream_tiled(ctx, host.data_ptr(), n, 5.0, 1.5e-3, wpc, S + 8, want_features=False)   # warm-up (allocations)
+        capi.detect_stream_tiled(ctx, host.data_ptr(), n, t_begin, 1.5e-3, wpc, S + 8, want_features=False)   # warm-up (allocations)
+        if world > 1:
+            dist.barrier()
         tb = time.perf_counter()
-        info, found, _, st = capi.detect_stream_tiled(ctx, host.data_ptr(), n, 5.0, 1.5e-3, wpc, S + 8, want_features=False)
+        info, found, _, st = capi.detect_stream_tiled(ctx, host.data_ptr(), n, t_begin, 1.5e-3, wpc, S + 8, want_features=False)
         el = time.perf_counter() - tb
-        res[wpc] = (el, st["chunks"], int((found != 0).sum()))
+        nf = int((found != 0).sum())
+        if world > 1:
+            tt = torch.tensor([el, -float(nf)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt[0].item())
+        res[wpc] = (el, st["chunks"], nf)
     (e2, c2, f2), (e1, c1, f1) = res[2048], res[S + 1]
-    return {"metric": "Mevents/s including the PCIe upload", "value": round(n / e2 / 1e6, 1), "unit": "Mevents/s", "events": n,
-            "windows": S, "chunks": c2, "seconds": round(e2, 4), "grids_found": f2,
-            "single_chunk_seconds": round(e1, 4), "single_chunk_Mevents_per_s": round(n / e1 / 1e6, 1),
+    total = n * world
+    return {"metric": "Mevents/s including the PCIe upload", "value": round(total / e2 / 1e6, 1), "unit": "Mevents/s", "events": total,
+            "events_per_gpu": n, "windows_per_gpu": S, "chunks_per_gpu": c2, "seconds": round(e2, 4), "grids_found_rank0": f2,
+            "single_chunk_seconds": round(e1, 4), "single_chunk_Mevents_per_s": round(total / e1 / 1e6, 1),
             "pcie_floor_seconds_at_57GBs": round(n * 25 / 57e9, 4),
             "note": "stages: window bounds + slicing + DBSCAN + candidates + grid ordering per chunk of 2048 windows; the copy of "
                     "chunk k+1 overlaps the kernels of chunk k; never part of `value`"}

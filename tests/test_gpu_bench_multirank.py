@@ -17,7 +17,7 @@ def _bench(nproc, extra, launcher=True):
     env = dict(os.environ, ECAL_BENCH_SINGLE_DEVICE="1", ECAL_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
                ECAL_BENCH_SOLVER_CHECK="1")
     args = ["--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--events", "2000000", "--cpu-sample", "0",
-            "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0", "--ingest-events", "0", "--e2e-events", "0"] + extra
+            "--solver-iters", "3", "--solver-cpu-sample", "0", "--p2-pieces", "0", "--no-h2d", "--calib-cpu-views", "0", "--ingest-events", "1000000", "--e2e-events", "0"] + extra
     if nproc == 1 or not launcher:
         # exactly what the driver may type: `python bench.py --gpus N ...` — for N > 1 bench.py starts its own ranks under
         # torch.distributed.run as child processes (before it touches the GPU) and relays rank 0's JSON line
@@ -54,6 +54,9 @@ def test_two_ranks_match_one_rank():
     assert two["solver"]["residuals"] == 2 * one["solver"]["residuals"]
     # distributed segments (each rank factorises its own band, 91 / 101 + N / 4 doubles exchanged) == one solver over both
     # segments: same iterates up to the summation order
+    # the ingest leg (configs[4]): the host-resident events split into one time range per rank
+    assert one["ingest"]["events"] == two["ingest"]["events"] == 1000000 and two["ingest"]["events_per_gpu"] == 500000
+    assert one["ingest"]["value"] > 0 and two["ingest"]["value"] > 0
     chk = two["solver"]["check_vs_single_solver"]
     assert chk["iterations"][0] == chk["iterations"][1]
     assert chk["intrinsics_rel_diff"] < 1e-8 and chk["final_cost_rel_diff"] < 1e-9 and chk["own_control_points_abs_diff"] < 1e-7
