@@ -77,7 +77,14 @@ __device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_i
 // will not keep a second row in flight).  These helpers issue a row's reads and wait for the reads issued BEFORE the last
 // six: the loop keeps one row in flight behind the row it is multiplying.  (LDS operations of a wave complete in order.)
 typedef double ne_v2d __attribute__((ext_vector_type(2)));
+// (profiling builds: -DECAL_NE_SKIP_P1 / -DECAL_NE_SKIP_P2 drop the residual code / the Gram accumulation, -DECAL_NE_P2_NOLDS /
+// -DECAL_NE_P2_NOFMA keep the accumulation's FMAs without its LDS reads / its reads without the FMAs: the phase split of
+// profiles/r02_notes.md.  Results are meaningless in those builds.)
 __device__ __forceinline__ void ne_lds_read6(uint32_t a_addr, uint32_t b_addr, ne_v2d (&A)[3], ne_v2d (&B)[3]) {
+#ifdef ECAL_NE_P2_NOLDS
+    asm volatile("" : "=v"(A[0]), "=v"(A[1]), "=v"(A[2]), "=v"(B[0]), "=v"(B[1]), "=v"(B[2]) : "v"(a_addr), "v"(b_addr));
+    return;
+#endif
     asm volatile(
         "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
         "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\tds_read_b128 %5, %7 offset:32"
@@ -88,6 +95,10 @@ __device__ __forceinline__ void ne_lds_wait_but6(ne_v2d (&A)[3], ne_v2d (&B)[3])
     asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]));
 }
 __device__ __forceinline__ void ne_fma36(double (&acc)[36], const ne_v2d (&A)[3], const ne_v2d (&B)[3]) {
+#ifdef ECAL_NE_P2_NOFMA
+    acc[0] += A[0].x + A[1].x + A[2].x + B[0].x + B[1].x + B[2].x;
+    return;
+#endif
     const double a[6] = {A[0].x, A[0].y, A[1].x, A[1].y, A[2].x, A[2].y}, b[6] = {B[0].x, B[0].y, B[1].x, B[1].y, B[2].x, B[2].y};
 #pragma unroll
     for (int x = 0; x < 6; x++)
@@ -153,7 +164,17 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
         double r = 0.0, sc = 0.0;
         const ResRecord e = e_next;
         e_next = rec[ch.start + min(k + (uint32_t) NE_T, ch.count - 1u)];
+#ifdef ECAL_NE_SKIP_P1
         if (k < ch.count) {
+            r = e.u;
+            sc = e.v;
+            for (int i = 0; i < RES_NJ; i++) J[i] = e.t + i;
+            cost += r;
+        }
+        if (false) {
+#else
+        if (k < ch.count) {
+#endif
             ResidualInput in;
             in.u = e.u;
             in.v = e.v;
@@ -183,7 +204,11 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             row[34] = 0.0;
             row[35] = 0.0;
             __syncthreads();
+#ifdef ECAL_NE_SKIP_P2
+            if (false) {
+#else
             if (grp < NE_GROUPS) {
+#endif
                 const uint32_t nrow = min((uint32_t) NE_T, ch.count - b0);
                 if constexpr (NE_TW == 6) {
                     // one row in flight behind the row being multiplied (see ne_lds_read6); rows past the end are clamped reads
