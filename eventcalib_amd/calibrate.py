@@ -169,8 +169,9 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
         cp_num = max(cp_num, 4)
         kn, c_t = capi.spline_fit(u, twb[acc][s], cp_num)
         _, c_q = capi.spline_fit(u, Qwb[s], cp_num)
-        if use_so3:
+        if use_so3:   # BsplineSO3's constructor: unit quaternions, then optimizeCP (BsplineSO3.cpp:55, :285-341)
             c_q /= np.linalg.norm(c_q, axis=1, keepdims=True)
+            c_q, _ = capi.spline_so3_refine(kn, c_q, Qwb[s], u)
         knots.append(kn)
         cq.append(c_q)
         ct.append(c_t)

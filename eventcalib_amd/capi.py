@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
-    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval",
+    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval", "ecal_spline_so3_refine",
 ]
 
 
@@ -587,6 +587,23 @@ def spline_eval(knots, cp, u):
     if st != 0:
         raise EcalError(st, L.ecal_strerror(st).decode())
     return out
+
+
+def spline_so3_refine(knots, cp_quat, sample_quat, u, max_iterations=0):
+    """ecal_spline_so3_refine (BsplineSO3::optimizeCP): returns (refined control points [n_cp][4], summary dict)."""
+    L = load_library()
+    knots, u = np.ascontiguousarray(knots, np.float64), np.ascontiguousarray(u, np.float64)
+    cp = np.ascontiguousarray(cp_quat, np.float64).copy()
+    sq = np.ascontiguousarray(sample_quat, np.float64)
+    c0, c1, it = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int(0)
+    L.ecal_spline_so3_refine.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_double),
+                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
+    st = L.ecal_spline_so3_refine(_ptr(knots), cp.shape[0], _ptr(cp), _ptr(sq), _ptr(u), len(u), int(max_iterations),
+                                  ctypes.byref(c0), ctypes.byref(c1), ctypes.byref(it))
+    if st != 0:
+        raise EcalError(st, L.ecal_strerror(st).decode())
+    return cp, {"initial_cost": c0.value, "final_cost": c1.value, "iterations": it.value}
 
 
 # ---- double-buffered ingest ----

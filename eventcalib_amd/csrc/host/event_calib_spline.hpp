@@ -100,12 +100,17 @@ public:
             int rc = ecal_spline_fit(u.data(), tw.data(), (uint32_t) u.size(), 3, (uint32_t) cpNum, kn.data(), ct.data());
             if (rc == ECAL_OK) rc = ecal_spline_fit(u.data(), qw.data(), (uint32_t) u.size(), 4, (uint32_t) cpNum, kn2.data(), cq.data());
             if (rc != ECAL_OK) throw std::logic_error(std::string("spline initialisation failed: ") + ecal_strerror(rc));
-            if (useSO3_)  // BsplineSO3::initialGuess stores unit quaternions (Sophus::SO3d::setQuaternion)
+            if (useSO3_) {  // BsplineSO3::initialGuess stores unit quaternions (Sophus::SO3d::setQuaternion) ...
                 for (int c = 0; c < cpNum; c++) {
                     double *q = &cq[4 * (size_t) c];
                     const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
                     for (int k = 0; k < 4; k++) q[k] /= n;
                 }
+                // ... and the constructor ends with optimizeCP (BsplineSO3.cpp:55, :285-341): the fit on the group
+                rc = ecal_spline_so3_refine(kn2.data(), (uint32_t) cpNum, cq.data(), qw.data(), u.data(), (uint32_t) u.size(), 0, nullptr,
+                                            nullptr, nullptr);
+                if (rc != ECAL_OK) throw std::logic_error(std::string("SO3 spline refinement failed: ") + ecal_strerror(rc));
+            }
             knots_.insert(knots_.end(), kn.begin(), kn.end());
             cpQ_.insert(cpQ_.end(), cq.begin(), cq.end());
             cpT_.insert(cpT_.end(), ct.begin(), ct.end());

@@ -537,14 +537,22 @@ int ecal_calibrate_views(ecal_ctx *ctx, const double *obj /*[n_pts][3]*/, uint32
  * ecal_spline_fit: BsplineReal<dim>(3, Q, controlPointsNum, u) (core/spline/include/opengv2/spline/
  *   BsplineReal.hpp:17-100,329-449) as EventCalibSpline builds twbSplines_ / QwbSplines_ from the keyframe poses
  *   (event_camera_calib/src/EventCalibSpline.cpp:61-91), and BsplineSO3's knotSpacing + initialGuess
- *   (core/spline/src/BsplineSO3.cpp:60-72,198-279; its Ceres refinement optimizeCP is not restated — the
- *   calibration solve refines the same control points).  u [m] ascending sample parameters (timestamps, first and
+ *   (core/spline/src/BsplineSO3.cpp:60-72,198-279; its Ceres refinement optimizeCP: ecal_spline_so3_refine below).  u [m] ascending sample parameters (timestamps, first and
  *   last already widened by 3 steps as :63-66), data [m][dim]; outputs the clamped knot vector [n_cp + 4]
  *   (NURBS book 9.68) — the layout ecal_spline_problem.knots takes — and the control points [n_cp][dim]: first and
  *   last interpolate, the interior ones minimise the squared distance at the interior samples.
  *   ECAL_ERR_INVALID if n_cp < 4, m < 2 or a control point has no supporting sample.
  * ecal_spline_eval: BsplineReal::evaluate(u, 0, ..) (:454-470) at m parameters (updateMap, EventCalibSpline.cpp:
  *   253-317); ECAL_ERR_RANGE outside the knot range. */
+/* ecal_spline_so3_refine: BsplineSO3::optimizeCP (core/spline/src/BsplineSO3.cpp:285-341) — the control points of the
+ *   cumulative cubic SO3 spline (unit quaternions x y z w, [n_cp][4], in: the initial guess of ecal_spline_fit on the
+ *   quaternion coefficients, out: refined) fitted on the group to the sample rotations [m][4] at parameters u [m]:
+ *   minimises sum_i |log(S_i^-1 X(u_i))|^2 / 2 (P3ApproximationError, BsplineSO3.hpp:121-153) over steps cp <- cp exp(delta)
+ *   (LocalParameterizationSO3, :190-222), first and last control point constant, Ceres' trust-region loop restated,
+ *   function / gradient tolerance 1e-10, max_iterations <= 0 = Ceres' default 50.  Host only. */
+int ecal_spline_so3_refine(const double *knots /*[n_cp+4]*/, uint32_t n_cp, double *cp_quat /*[n_cp][4]*/,
+                           const double *sample_quat /*[m][4]*/, const double *u /*[m]*/, uint32_t m, int max_iterations,
+                           double *initial_cost /*or NULL*/, double *final_cost /*or NULL*/, int *iterations /*or NULL*/);
 int ecal_spline_fit(const double *u, const double *data, uint32_t m, uint32_t dim, uint32_t n_cp, double *knots /*[n_cp+4]*/,
                     double *cp /*[n_cp][dim]*/);
 int ecal_spline_eval(const double *knots, const double *cp, uint32_t n_cp, uint32_t dim, const double *u, uint32_t m,
