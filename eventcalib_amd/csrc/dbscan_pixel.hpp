@@ -1,15 +1,16 @@
-// DBSCAN of one segment of event PIXELS (integer coordinates) by one workgroup, in 25 KB of LDS.
+// DBSCAN of one segment of event PIXELS (integer coordinates) by one workgroup, in 22 KB of LDS (seven per CU).
 //
 // Same contract as dbscan_device.hpp (labels identical to dbscan/include/dbscan.h:115-265 on top of
 // dbscan/src/kdtree.cpp:106-179, including the range query's pruning quirk); this is the form the hot path
-// takes: segments of <= 1024 points whose coordinates are integers (|v| <= 16383), whose bounding box padded
+// takes: segments of <= 768 points whose coordinates are integers (|v| <= 16383), whose bounding box padded
 // by the disc radius fits a 3232-word bitmap (a 346x260 sensor does) and eps < 16.  Anything else is appended
 // to a to-do list that the general kernels work off.
 //
 // What makes it small and why that matters: the kernel is latency bound — a workgroup is a ~45 us chain of
 // dependent LDS operations and barriers, and kernel time is ~ 1 / (workgroups per CU) from 1 to 6
 // (tools/occupancy_probe.sh, profiles/r01_notes.md) — so throughput is proportional to the workgroups a CU can
-// hold, i.e. to 160 KB / LDS per workgroup.  For integer pixels the
+// hold, i.e. to 160 KB / LDS per workgroup (capacity 768 points instead of 1024: 22.1 KB, 7 instead of 6 workgroups,
+// 1.157 -> 1.033 ms on the benchmark stream whose segments hold <= 666 points).  For integer pixels the
 // closed form of the pruning quirk collapses to two bits per point,
 //     f_d(j) = "an ancestor of j in the insertion-order kd-tree splits on d at j's own d-coordinate",
 // and  i -> j is pruned  <=>  j = i + eps * e_d exactly  and  f_d(j)   (integral eps only),
@@ -31,11 +32,11 @@ namespace ecal {
 #define ECAL_PX_T 256
 #endif
 constexpr int PX_T = ECAL_PX_T;
-constexpr int PX_CAP = 1024;   // points per segment of the first pass (four per thread)
+constexpr int PX_CAP = 768;    // points per segment of the first pass (three per thread)
 constexpr int PX_CAP2 = 2048;  // second pass over the segments the first one left: eight per thread, 10-bit bitmap coordinates
 constexpr uint32_t PX_WORDS = 3232;    // bitmap words: 346x260 padded by 2*4 = 354x268 bits = 268 rows x 12 words = 3216
 constexpr uint32_t PX_ROWS = 472;      // rowstart[PX_ROWS + 1]: 512 u16
-constexpr uint32_t PX_EDGE_CAP = 128;  // one-way edges kept (more: left to the general kernel)
+constexpr uint32_t PX_EDGE_CAP = 64;   // one-way edges kept (more: left to the general kernel)
 constexpr int PX_RMAX = 15;
 
 // Everything the kernel needs to know about eps, worked out once on the host (the f64 square roots used to run in
