@@ -71,7 +71,10 @@ struct PixHash {
     //   keep u32[16 NI]     kept keys by list position (bitmaps of both sets) and the running counts of their words
     // The - set's part of W / region / cur starts at the fixed offset NOFF = 128 NI: every run of 128 positions a scan
     // touches lies inside the set's own part (no bounds tests).
-    static constexpr int NI = LOGC == 11 ? 9 : 19;                    // keys per thread of a pair: 1152 >= 1109 / 2432 >= 2357
+#ifndef ECAL_RO_NI
+#define ECAL_RO_NI 9
+#endif
+    static constexpr int NI = LOGC == 11 ? ECAL_RO_NI : 19;           // keys per thread of a pair: 1152 >= 1109 / 2432 >= 2357
     static constexpr int MAX_EPOCHS = LOGC == 11 ? 7 : 8;             // bucket counts up to 1109 / 2357
     static constexpr uint32_t NOFF = 128u * NI, PSL = 2u * NOFF;
     static constexpr uint32_t FA_CAP = LOGC == 11 ? 2400u : 4800u;    // B(+) + B(-): 1109 + 1109 / 2357 + 2357 (+ slack)
@@ -439,7 +442,8 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
         const int EP = mP ? ref_epochs(mP) : 0, EN = mN ? ref_epochs(mN) : 0;
         {
             const uint32_t need = (EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u) + (EN ? (uint32_t) ref_bucket_step(EN - 1) : 0u);
-            if (need > L::FA_CAP || EP > L::MAX_EPOCHS || EN > L::MAX_EPOCHS) {   // more keys than the bucket tables hold: next tier
+            if (need > L::FA_CAP || EP > L::MAX_EPOCHS || EN > L::MAX_EPOCHS || mP > 128u * (uint32_t) L::NI ||
+                mN > 128u * (uint32_t) L::NI) {   // more keys than the bucket tables / the pair's registers hold: next tier
                 if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
                 return false;
             }
