@@ -240,12 +240,20 @@ def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
         assert np.abs(devd - host).max() <= 1e-8 * np.abs(host).max(), (n_cp, radius, np.abs(devd - host).max(), np.abs(host).max())
         # the host routine's own partitioned form (arrow_host_parts.hpp: interiors on several cores, separators' reduced system):
         # mode 2 of the hook, 4 interiors here, what ecal_solver_solve uses on long splines
-        if n_cp >= 28:
-            d = np.zeros(nt)
-            fail = ctypes.c_int(-1)
-            rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d.ctypes.data, ctypes.byref(fail), 2)
-            assert rc == 0 and fail.value == 0, (rc, fail.value)
-            assert np.abs(d - host).max() <= 1e-9 * np.abs(host).max(), (n_cp, radius, np.abs(d - host).max(), np.abs(host).max())
+        import os
+        for parts in ([None] if n_cp >= 28 else []) + ([2, 3, 5, 8, 16] if n_cp >= 131 else []):
+            if parts is None:
+                os.environ.pop("ECAL_HOST_ARROW_PARTS", None)
+            else:
+                os.environ["ECAL_HOST_ARROW_PARTS"] = str(parts)
+            try:
+                d = np.zeros(nt)
+                fail = ctypes.c_int(-1)
+                rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d.ctypes.data, ctypes.byref(fail), 2)
+            finally:
+                os.environ.pop("ECAL_HOST_ARROW_PARTS", None)
+            assert rc == 0 and fail.value == 0, (rc, fail.value, parts)
+            assert np.abs(d - host).max() <= 1e-9 * np.abs(host).max(), (n_cp, parts, radius, np.abs(d - host).max(), np.abs(host).max())
         # and it solves the system: (S A S + D) y = -S g, checked densely for the small cases
         if n_cp <= 50:
             perm = np.concatenate([np.arange(9, nt), np.arange(9)])
