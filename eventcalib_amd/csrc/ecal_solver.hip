@@ -1185,8 +1185,10 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     // (arrow_host_parts.hpp); the sharded modes keep the sequential routines (their segments are short, and the sequential
     // routine's 10 x 10 Schur sums are what the ranks exchange)
     ArrowParts parts;
-    int n_parts = dist_mode ? 1 : arrow_parts_for(s->n_cp);
+    int n_parts = arrow_parts_for(s->n_cp);
     if ((uint32_t) (7 * n_parts) > s->n_cp) n_parts = 1;
+    // (sharded segments: unpacking and the quadratic forms still use the pool, the factorisation stays the sequential routine)
+    const bool parts_solve = !dist_mode;
     std::unique_ptr<HostPool> pool;
     double t_unpack = 0, t_pool = 0;
     if (n_parts > 1) {   // (the workers start while the GPU runs the first evaluation)
@@ -1263,7 +1265,8 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             dd[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
         }
         const auto tl = now();
-        bool ok = n_parts > 1 ? solve_arrow_parts(A, scale, dd, delta, ws, parts, *pool, n_parts) : solve_arrow(A, scale, dd, delta, ws);
+        bool ok = (n_parts > 1 && parts_solve) ? solve_arrow_parts(A, scale, dd, delta, ws, parts, *pool, n_parts)
+                                               : solve_arrow(A, scale, dd, delta, ws);
         double model_change = 0;
         if (ok) {
             for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
