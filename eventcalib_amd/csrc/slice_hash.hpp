@@ -77,7 +77,10 @@ struct PixHash {
     static constexpr int NI = LOGC == 11 ? ECAL_RO_NI : 19;           // keys per thread of a pair: 1152 >= 1109 / 2432 >= 2357
     static constexpr int MAX_EPOCHS = LOGC == 11 ? 7 : 8;             // bucket counts up to 1109 / 2357
     static constexpr uint32_t NOFF = 128u * NI, PSL = 2u * NOFF;
-    static constexpr uint32_t FA_CAP = LOGC == 11 ? 2400u : 4800u;    // B(+) + B(-): 1109 + 1109 / 2357 + 2357 (+ slack)
+#ifndef ECAL_RO_FA
+#define ECAL_RO_FA 2400
+#endif
+    static constexpr uint32_t FA_CAP = LOGC == 11 ? (uint32_t) ECAL_RO_FA : 4800u;    // B(+) + B(-): 1109 + 1109 / 2357 + 2357 (+ slack)
     static constexpr size_t w_off = 0;
     static constexpr size_t region_off = w_off + 4 * PSL;
     static constexpr size_t cur_off = region_off + 2 * (PSL > SLOTS ? PSL : SLOTS);
