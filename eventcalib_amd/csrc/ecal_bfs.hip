@@ -1,0 +1,282 @@
+// The member ORDER of the reference's clusters.
+//
+// DBSCAN<T,Float>::Clusters[c] (dbscan/include/dbscan.h:92) lists a cluster's core points in the order expandCluster's queue
+// pops them (:229-265): the seed (the cluster's smallest pid, Run's outer loop :140-158), then breadth first, every popped
+// core point pushing its not yet queued neighbours in the order regionQuery returns them (:198-227) — the kd-tree's result
+// list, which kd_nearest_range fills by inserting each hit at the HEAD (rlist_insert with dist_sq = -1, kdtree.cpp:469-486),
+// i.e. the REVERSE of find_nearest's visiting order (:148-179: the node, then the near child, then the far child if
+// fabs(dx) < range).  ecal_dbscan_batch_dev's labels say which cluster a point belongs to; this pass adds where in
+// Clusters[c] it stands.  extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147) depend
+// on that order when two members tie in norm.
+//
+// One workgroup per segment (<= 2048 points; coordinates as the doubles they are, no pixel assumption):
+//   1. the insertion-order kd-tree rebuilt level-synchronously: every point stands at a node, goes to the child on its side
+//      or, where that child is missing, bids its pid for it with ds_min — the smallest pid wins, as sequential insertion
+//      (kdtree.cpp:106-146) would place it; one level per round for everybody;
+//   2. one range query per core point, all in parallel (a thread per query): find_nearest's traversal with an explicit
+//      stack, hits written in visiting order to a list in global scratch;
+//   3. one queue simulation per cluster, all clusters in parallel (a thread per cluster): pops in Clusters[c]'s order.
+#include "ecal_ctx.hpp"
+
+#pragma clang fp contract(off)
+
+namespace ecal {
+
+constexpr int BO_T = 256;
+constexpr uint32_t BO_CAP = 2048;        // points per segment
+constexpr int BO_PPT = (int) (BO_CAP / BO_T);
+constexpr uint32_t BO_MAXN = 64;         // hits per range query kept (a disc of radius 4 holds 48 other pixels)
+constexpr uint32_t BO_STACK = 96;        // pending far subtrees of one traversal
+constexpr uint32_t BO_NONE = 0xFFFFFFFFu;
+
+struct BoLayout {
+    static constexpr size_t px_off = 0;                                   // f64[CAP]
+    static constexpr size_t py_off = px_off + 8 * BO_CAP;                 // f64[CAP]
+    static constexpr size_t child_off = py_off + 8 * BO_CAP;              // u32[2 CAP]: children (left, right) of node i
+    static constexpr size_t lab_off = child_off + 8 * BO_CAP;             // i32[CAP]
+    static constexpr size_t queue_off = lab_off + 4 * BO_CAP;             // u16[CAP]: the clusters' queues, back to back
+    static constexpr size_t qbase_off = queue_off + 2 * BO_CAP;           // u32[CAP + 1]: members per cluster, then offsets
+    static constexpr size_t inq_off = qbase_off + 4 * (BO_CAP + 1) + 12;  // u32[CAP / 32]: point is (or was) in its cluster's queue
+    static constexpr size_t seed_off = inq_off + 4 * (BO_CAP / 32);       // u32[CAP]: smallest pid per cluster
+    static constexpr size_t red_off = seed_off + 4 * BO_CAP;              // u32[16]
+    static constexpr size_t bytes = red_off + 64;
+};
+
+__device__ __forceinline__ bool bo_block_any(bool v, uint32_t *flag, uint32_t &round) {
+    // three rotating flag words: the word cleared now is read next in the round after the next barrier
+    uint32_t *cur = flag + round % 3u, *nxt = flag + (round + 1u) % 3u;
+    if (threadIdx.x == 0) *nxt = 0;
+    if (v) *cur = 1;
+    __syncthreads();
+    const bool any = *cur != 0;
+    round++;
+    return any;
+}
+
+__global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
+                                                            const uint32_t *__restrict__ seg_cnt, uint32_t S, double eps,
+                                                            const int32_t *__restrict__ labels,
+                                                            const uint32_t *__restrict__ n_clusters, int32_t *__restrict__ order,
+                                                            uint32_t *__restrict__ status, uint16_t *__restrict__ lists,
+                                                            uint8_t *__restrict__ list_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *const px = reinterpret_cast<double *>(smem + BoLayout::px_off);
+    double *const py = reinterpret_cast<double *>(smem + BoLayout::py_off);
+    uint32_t *const child = reinterpret_cast<uint32_t *>(smem + BoLayout::child_off);
+    int32_t *const lab = reinterpret_cast<int32_t *>(smem + BoLayout::lab_off);
+    uint16_t *const queue = reinterpret_cast<uint16_t *>(smem + BoLayout::queue_off);
+    uint32_t *const qbase = reinterpret_cast<uint32_t *>(smem + BoLayout::qbase_off);
+    uint32_t *const inq = reinterpret_cast<uint32_t *>(smem + BoLayout::inq_off);
+    uint32_t *const seed = reinterpret_cast<uint32_t *>(smem + BoLayout::seed_off);
+    uint32_t *const red = reinterpret_cast<uint32_t *>(smem + BoLayout::red_off);
+    const uint32_t tid = threadIdx.x;
+    // this workgroup's slice of the neighbour lists
+    uint16_t *const my_lists = lists + (size_t) blockIdx.x * BO_CAP * BO_MAXN;
+    uint8_t *const my_cnt = list_cnt + (size_t) blockIdx.x * BO_CAP;
+    const double eps2 = eps * eps;   // SQ(range), kdtree.cpp:155-159
+
+    for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
+        const uint32_t n = seg_cnt[s], base = seg_off[s], nc = n_clusters[s];
+        __syncthreads();   // the previous segment's LDS is dead
+        if (n == 0) {
+            if (tid == 0) status[s] = 0;
+            continue;
+        }
+        if (n > BO_CAP || nc > BO_CAP) {
+            for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
+            if (tid == 0) status[s] = 1;
+            continue;
+        }
+        if (tid < 4) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure
+        for (uint32_t i = tid; i < n; i += BO_T) {
+            const double2 p = reinterpret_cast<const double2 *>(xy)[base + i];
+            px[i] = p.x;
+            py[i] = p.y;
+            lab[i] = labels[base + i];
+            child[2 * i] = BO_NONE;
+            child[2 * i + 1] = BO_NONE;
+        }
+        for (uint32_t c = tid; c <= nc; c += BO_T) qbase[c] = 0;
+        for (uint32_t c = tid; c < nc; c += BO_T) seed[c] = BO_NONE;
+        for (uint32_t w = tid; w < (n + 31u) / 32u; w += BO_T) inq[w] = 0;
+        __syncthreads();
+        // ---- 1. the insertion-order kd-tree (root = point 0 splits on x, children alternate: kdtree.cpp:127) ----
+        uint32_t cur[BO_PPT], pend[BO_PPT], dep[BO_PPT];
+        bool placed[BO_PPT];
+#pragma unroll
+        for (int u = 0; u < BO_PPT; u++) {
+            const uint32_t i = tid + u * BO_T;
+            cur[u] = 0;
+            dep[u] = 0;
+            pend[u] = BO_NONE;
+            placed[u] = i == 0 || i >= n;
+        }
+        uint32_t round = 0;
+        for (;;) {
+            // a round = one tree level for every unplaced point: look at the child slot on the point's side (everybody reads
+            // before anybody bids: a slot that is empty NOW is decided among the points that stand at it in this round) ...
+            bool active = false;
+#pragma unroll
+            for (int u = 0; u < BO_PPT; u++) {
+                if (placed[u]) continue;
+                const uint32_t i = tid + u * BO_T, c = cur[u];
+                const bool dy = dep[u] & 1u;
+                const double v = dy ? py[i] : px[i], cv = dy ? py[c] : px[c];
+                const uint32_t at = 2 * c + (v < cv ? 0u : 1u);   // left iff pos[dir] < node->pos[dir] (kdtree.cpp:128-131)
+                const uint32_t w = child[at];
+                if (w == BO_NONE) {
+                    pend[u] = at;
+                } else {
+                    cur[u] = w;
+                    dep[u]++;
+                    pend[u] = BO_NONE;
+                }
+                active = true;
+            }
+            if (!bo_block_any(active, red, round)) break;
+            // ... bid for it with the pid (the smallest wins, as sequential insertion would place it) ...
+#pragma unroll
+            for (int u = 0; u < BO_PPT; u++)
+                if (!placed[u] && pend[u] != BO_NONE) atomicMin(&child[pend[u]], tid + u * BO_T);
+            __syncthreads();
+            // ... and stay there as the new node, or go on below the winner
+#pragma unroll
+            for (int u = 0; u < BO_PPT; u++) {
+                if (placed[u] || pend[u] == BO_NONE) continue;
+                const uint32_t w = child[pend[u]];
+                if (w == tid + u * BO_T) {
+                    placed[u] = true;
+                } else {
+                    cur[u] = w;
+                    dep[u]++;
+                }
+            }
+            __syncthreads();   // (the next round's reads come after every resolve)
+        }
+        // members per cluster, the clusters' seeds (= smallest pid)
+#pragma unroll
+        for (int u = 0; u < BO_PPT; u++) {
+            const uint32_t i = tid + u * BO_T;
+            if (i < n && lab[i] >= 0) {
+                atomicAdd(&qbase[lab[i] + 1], 1u);
+                atomicMin(&seed[lab[i]], i);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {   // offsets of the clusters' queues (<= a few dozen clusters per segment in practice)
+            uint32_t run = 0;
+            for (uint32_t c = 0; c <= nc; c++) {
+                run += qbase[c];
+                qbase[c] = run;
+            }
+        }
+        // ---- 2. one range query per core point: find_nearest's visiting order (kdtree.cpp:148-179) ----
+        bool fail = false;
+#pragma unroll 1
+        for (int u = 0; u < BO_PPT; u++) {
+            const uint32_t i = tid + u * BO_T;
+            if (i >= n || lab[i] < 0) continue;
+            const double qx = px[i], qy = py[i];
+            uint16_t *out = my_lists + (size_t) i * BO_MAXN;
+            uint32_t cnt = 0, sp = 0;
+            uint32_t stk[BO_STACK];   // node | dir << 31
+            uint32_t node = 0, dir = 0;
+            for (;;) {
+                while (node != BO_NONE) {
+                    const double ddx = px[node] - qx, ddy = py[node] - qy;
+                    double d2 = 0;
+                    d2 += ddx * ddx;   // dist_sq += SQ(node->pos[i] - pos[i]), i ascending
+                    d2 += ddy * ddy;
+                    if (d2 <= eps2 && node != i) {   // regionQuery drops the query point itself (dbscan.h:218)
+                        if (cnt < BO_MAXN) out[cnt] = (uint16_t) node;
+                        cnt++;
+                    }
+                    const double dx = dir ? (qy - py[node]) : (qx - px[node]);
+                    const uint32_t l = child[2 * node], r = child[2 * node + 1];
+                    const uint32_t nearc = dx <= 0.0 ? l : r, farc = dx <= 0.0 ? r : l;
+                    if (fabs(dx) < eps && farc != BO_NONE) {
+                        if (sp < BO_STACK) stk[sp] = farc | ((dir ^ 1u) << 31);
+                        sp++;
+                    }
+                    node = nearc;
+                    dir ^= 1u;
+                }
+                if (sp == 0 || sp > BO_STACK) break;
+                sp--;
+                node = stk[sp] & 0x7FFFFFFFu;
+                dir = stk[sp] >> 31;
+            }
+            if (cnt > BO_MAXN || sp > BO_STACK) fail = true;
+            my_cnt[i] = (uint8_t) (cnt > BO_MAXN ? BO_MAXN : cnt);
+        }
+        if (fail) red[3] = 1;
+        __threadfence_block();
+        __syncthreads();
+        if (red[3]) {
+            for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
+            if (tid == 0) status[s] = 1;
+            continue;
+        }
+        // ---- 3. expandCluster's queue, one thread per cluster (dbscan.h:229-265) ----
+        for (uint32_t i = tid; i < n; i += BO_T)
+            if (lab[i] < 0) order[base + i] = -1;
+        for (uint32_t c = tid; c < nc; c += BO_T) {
+            const uint32_t qb = qbase[c], sd = seed[c];
+            if (sd == BO_NONE) continue;   // (a cluster without members cannot be)
+            uint32_t head = 0, tail = 1;
+            queue[qb] = (uint16_t) sd;
+            atomicOr(&inq[sd >> 5], 1u << (sd & 31u));
+            while (head < tail) {
+                const uint32_t q = queue[qb + head];
+                order[base + q] = (int32_t) head;
+                head++;
+                const uint32_t m = my_cnt[q];
+                const uint16_t *lst = my_lists + (size_t) q * BO_MAXN;
+                for (uint32_t k = m; k-- > 0;) {   // the result list = hits in REVERSE visiting order (rlist_insert at the head)
+                    const uint32_t j = lst[k];
+                    if ((uint32_t) lab[j] != c) continue;   // not a core point of this cluster: never expands, never listed
+                    const uint32_t bit = 1u << (j & 31u);
+                    if (atomicOr(&inq[j >> 5], bit) & bit) continue;   // already in the border set
+                    queue[qb + tail] = (uint16_t) j;
+                    tail++;
+                }
+            }
+        }
+        if (tid == 0) status[s] = 0;
+    }
+}
+
+}  // namespace ecal
+
+using namespace ecal;
+
+extern "C" int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                      uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters,
+                                      int32_t *d_order, uint32_t *d_status, void *stream) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (S == 0) return ECAL_OK;
+    if (!d_xy || !d_seg_off || !d_seg_cnt || !d_labels || !d_n_clusters || !d_order || !d_status) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    if (!(eps > 0.0) || !(eps < 1.0e300)) {
+        ctx->last_error = "eps must be a positive finite number";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t) stream;
+    const uint32_t grid = std::min<uint32_t>(S, 2u * ctx->n_cu);
+    int rc;
+    if ((rc = ecal_ensure(ctx, ctx->bfs_lists, (size_t) grid * BO_CAP * (BO_MAXN * sizeof(uint16_t) + 1)))) return rc;
+    uint16_t *lists = (uint16_t *) ctx->bfs_lists.ptr;
+    uint8_t *cnt = (uint8_t *) (lists + (size_t) grid * BO_CAP * BO_MAXN);
+    if (!ctx->bfs_attr_set) {
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout::bytes));
+        ctx->bfs_attr_set = true;
+    }
+    hipLaunchKernelGGL(cluster_order_kernel, dim3(grid), dim3(BO_T), BoLayout::bytes, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels,
+                       d_n_clusters, d_order, d_status, lists, cnt);
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}

@@ -77,6 +77,19 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
                           uint32_t S, uint32_t n_points, uint32_t max_seg_points, double eps, uint32_t minpts,
                           int32_t *d_labels, uint32_t *d_n_clusters, void *stream);
 
+/* ecal_cluster_order_dev: the member ORDER of DBSCAN<T,Float>::Clusters (dbscan.h:92): d_order[slot] = position of the
+ * point inside Clusters[label] — the order expandCluster's queue pops the cluster's core points in (dbscan.h:229-265; the
+ * seed = the cluster's smallest pid first), which follows the result order of the kd-tree's range query (hits in reverse
+ * visiting order, kdtree.cpp:148-179,469-486) —, -1 for Noise.  d_xy / d_seg_off / d_seg_cnt as ecal_dbscan_batch_dev
+ * takes them, d_labels / d_n_clusters as it returned them, same eps.  d_status[s] = 0, or 1 for a segment this pass does
+ * not take (more than 2048 points or clusters, more than 64 points in one eps-ball, a tree deeper than 96 levels): its
+ * d_order entries are -1.  What it is for: Clusters[c] in the reference's order for callers that index into it, and
+ * extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147), which depend on that order
+ * when two members tie in norm. */
+int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
+                           double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order /*[n_points]*/,
+                           uint32_t *d_status /*[S]*/, void *stream);
+
 /* ---- ingest + time-slicing ----------------------------------------------------------------
  * The event stream is the reference's .bin image: packed 25-byte little-endian records
  * {f64 t_sec, f64 x, f64 y, u8 polarity} (event/include/opengv2/event/Event.hpp:41-47,

@@ -1,0 +1,114 @@
+"""GPU: ecal_cluster_order_dev — the member ORDER of the reference's Clusters[c] (expandCluster's pop order over the kd-tree's
+result lists, dbscan.h:229-265, kdtree.cpp:148-179,469-486) — against the oracle driver running on the REFERENCE's own
+kd-tree (oracle/_ref, where built) or on the oracle's restatement of it."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import synth_stream as SS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import eventcalib_amd
+    ctx = eventcalib_amd.Context(0)
+    yield ctx, torch
+    ctx.close()
+
+
+def _order_of(ctx, torch, segs, eps, minpts):
+    """segs: list of [n][2] float64 arrays -> (labels, order, status) per segment through the C ABI."""
+    S = len(segs)
+    cnt = np.array([len(s) for s in segs], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+    N = int(cnt.sum())
+    xy = torch.as_tensor(np.concatenate(segs).reshape(-1, 2) if N else np.zeros((0, 2)), device="cuda").contiguous()
+    d_off, d_cnt = torch.as_tensor(off, device="cuda"), torch.as_tensor(cnt, device="cuda")
+    labels = torch.empty(max(N, 1), dtype=torch.int32, device="cuda")
+    ncl = torch.empty(S, dtype=torch.int32, device="cuda")
+    order = torch.full((max(N, 1),), -7, dtype=torch.int32, device="cuda")
+    status = torch.full((S,), -7, dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.dbscan_batch_dev(xy.data_ptr(), d_off.data_ptr(), d_cnt.data_ptr(), S, N, int(cnt.max()) if S else 0, eps, minpts,
+                         labels.data_ptr(), ncl.data_ptr(), st)
+    ctx.cluster_order_dev(xy.data_ptr(), d_off.data_ptr(), d_cnt.data_ptr(), S, eps, labels.data_ptr(), ncl.data_ptr(),
+                          order.data_ptr(), status.data_ptr(), st)
+    torch.cuda.synchronize()
+    lab, od, stt = labels.cpu().numpy(), order.cpu().numpy(), status.cpu().numpy()
+    return [(lab[off[s]:off[s] + cnt[s]], od[off[s]:off[s] + cnt[s]], int(stt[s])) for s in range(S)]
+
+
+def _check(seg, lab, od, eps, minpts):
+    kd = O.have_ref_kdtree()
+    _rc, labels_o, _nc, clusters = O.dbscan(seg, eps, minpts, kdapi=kd, with_members=True)
+    assert np.array_equal(lab, labels_o)
+    assert np.array_equal(od < 0, lab < 0)
+    for c, members in enumerate(clusters):
+        idx = np.flatnonzero(lab == c)
+        mine = idx[np.argsort(od[idx], kind="stable")]
+        assert np.array_equal(np.sort(od[idx]), np.arange(len(idx))), c          # positions 0 .. size - 1, each once
+        assert np.array_equal(mine, members), (c, mine[:12], members[:12])
+
+
+def test_stream_windows_match_the_reference_member_order(env):
+    ctx, torch = env
+    from eventcalib_amd.pipeline import DetectPipeline
+    n = 300_000
+    ev = SS.make_stream(n, device="cuda", seed=17)
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 1e6)
+    pipe = DetectPipeline(ctx)
+    pipe.set_windows(t0, t1)
+    pipe.run(ev, slice_only=True)
+    torch.cuda.synchronize()
+    S = len(t0)
+    off, cnt = pipe.seg_off[:2 * S].cpu().numpy(), pipe.seg_cnt[:2 * S].cpu().numpy()
+    xy = pipe.xy.cpu().numpy()
+    segs = [xy[off[s]:off[s] + cnt[s]].copy() for s in range(0, 2 * S, 7)]
+    res = _order_of(ctx, torch, segs, 4.0, 2)
+    placed = 0
+    for seg, (lab, od, st) in zip(segs, res):
+        assert st == 0
+        _check(seg, lab, od, 4.0, 2)
+        placed += int((od > 0).sum())
+    assert placed > 5000          # the order is not trivial: thousands of non-seed members were placed
+
+
+@pytest.mark.parametrize("eps,minpts", [(4.0, 2), (3.0, 3), (4.5, 2), (2.5, 1), (1.7, 5)])
+def test_random_segments(env, eps, minpts):
+    """Integer lattices (the pruning quirk bites at integral eps), half-pixel lattices and continuous coordinates, 1 .. 2048 points."""
+    ctx, torch = env
+    rng = np.random.default_rng(int(eps * 10) + minpts)
+    segs = []
+    for n in (1, 2, 3, 17, 64, 200, 650, 1024, 2048):
+        side = max(4, int(np.sqrt(n) * 2.2))
+        pts = rng.permutation(side * side)[:n]
+        segs.append(np.stack([pts % side, pts // side], 1).astype(np.float64))                 # unique integer pixels
+        segs.append(np.stack([pts % side, pts // side], 1).astype(np.float64) * 0.5 + 3.25)    # half-pixel lattice
+        segs.append(rng.uniform(0, side, size=(n, 2)))                                        # continuous
+    res = _order_of(ctx, torch, segs, eps, minpts)
+    taken = 0
+    for seg, (lab, od, st) in zip(segs, res):
+        if st == 1:       # only because some eps-ball holds more than 64 other points (dense lattices at the larger radii)
+            d2 = ((seg[:, None, :] - seg[None, :, :]) ** 2).sum(-1)
+            assert int((d2 <= eps * eps).sum(1).max()) - 1 > 64 and (od == -1).all()
+            continue
+        assert st == 0
+        _check(seg, lab, od, eps, minpts)
+        taken += 1
+    assert taken >= 18
+
+
+def test_oversized_segment_is_reported_and_a_degenerate_tree_is_taken(env):
+    ctx, torch = env
+    rng = np.random.default_rng(5)
+    big = np.stack([np.arange(3000) % 60, np.arange(3000) // 60], 1).astype(np.float64)[rng.permutation(3000)]   # > 2048 points
+    chain = np.stack([np.arange(400, dtype=np.float64), np.zeros(400)], 1)      # sorted insertion: a tree 400 levels deep (no far
+    ok = rng.uniform(0, 30, size=(300, 2))                                      # subtrees pending: the traversal's stack stays empty)
+    res = _order_of(ctx, torch, [big, chain, ok], 4.0, 2)
+    assert res[0][2] == 1 and (res[0][1] == -1).all()
+    for seg, r in ((chain, res[1]), (ok, res[2])):
+        assert r[2] == 0
+        _check(seg, r[0], r[1], 4.0, 2)
