@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_sort_events_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
     "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev",
-    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_detect_fused_dev", "ecal_cluster_order_dev",
+    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
     "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_rectify_batch_dev", "ecal_rectify_batch",
@@ -282,6 +282,23 @@ class Context:
         L.ecal_cluster_order_dev.restype = ctypes.c_int
         self._check(L.ecal_cluster_order_dev(self._h, d_xy, d_seg_off, d_seg_cnt, int(S), float(eps), d_labels, d_n_clusters, d_order,
                                              d_status, stream))
+
+    def cluster_order(self, xy, slice_off, eps, labels, n_clusters):
+        """Host-buffer form of cluster_order_dev: returns (order [N] int32, status [S] uint32)."""
+        L = self._L
+        vp = ctypes.c_void_p
+        xy = np.ascontiguousarray(xy, np.float64)
+        slice_off = np.ascontiguousarray(slice_off, np.uint32)
+        labels = np.ascontiguousarray(labels, np.int32)
+        n_clusters = np.ascontiguousarray(n_clusters, np.uint32)
+        S = len(slice_off) - 1
+        order = np.full(max(len(labels), 1), -9, np.int32)
+        status = np.full(max(S, 1), 9, np.uint32)
+        L.ecal_cluster_order.argtypes = [vp, vp, vp, ctypes.c_uint32, ctypes.c_double, vp, vp, vp, vp]
+        L.ecal_cluster_order.restype = ctypes.c_int
+        self._check(L.ecal_cluster_order(self._h, _ptr(xy), _ptr(slice_off), S, float(eps), _ptr(labels), _ptr(n_clusters), _ptr(order),
+                                         _ptr(status)))
+        return order[:len(labels)], status[:S]
 
     def detect_fused_dev(self, d_events, n_events, d_win_lo, d_win_hi, d_win_base, S, max_win_events, max_seg_points, cap_points,
                          eps, minpts, cluster_min, need_clusters, radius_threshold, d_xy, d_seg_off, d_seg_cnt, d_event_point,

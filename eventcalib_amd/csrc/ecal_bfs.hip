@@ -16,6 +16,7 @@
 //   2. one range query per core point, all in parallel (a thread per query): find_nearest's traversal with an explicit
 //      stack, hits written in visiting order to a list in global scratch;
 //   3. one queue simulation per cluster, all clusters in parallel (a thread per cluster): pops in Clusters[c]'s order.
+#include <algorithm>
 #include "ecal_ctx.hpp"
 
 #pragma clang fp contract(off)
@@ -278,5 +279,58 @@ extern "C" int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const u
     hipLaunchKernelGGL(cluster_order_kernel, dim3(grid), dim3(BO_T), BoLayout::bytes, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels,
                        d_n_clusters, d_order, d_status, lists, cnt);
     ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}
+
+/* host-buffer form: slices [slice_off[s], slice_off[s + 1]) of xy as ecal_dbscan_batch takes them */
+extern "C" int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_t *slice_off, uint32_t S, double eps,
+                                  const int32_t *labels, const uint32_t *n_clusters, int32_t *order, uint32_t *status) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (S == 0) return ECAL_OK;
+    if (!slice_off || !n_clusters || !status) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    for (uint32_t s = 0; s < S; s++)
+        if (slice_off[s + 1] < slice_off[s]) {
+            ctx->last_error = "slice_off must be non-decreasing";
+            return ECAL_ERR_INVALID;
+        }
+    const uint32_t base0 = slice_off[0];
+    const size_t N = (size_t) slice_off[S] - base0;
+    if (N && (!xy || !labels || !order)) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    // staging: xy | labels | order | off | cnt | n_clusters | status
+    const size_t bytes = (N + 1) * 16 + (N + 1) * 4 * 2 + (size_t) S * 4 * 4 + 64;
+    if ((rc = ecal_ensure(ctx, ctx->bfs_host, bytes))) return rc;
+    unsigned char *p = (unsigned char *) ctx->bfs_host.ptr;
+    double *d_xy = (double *) p;
+    int32_t *d_lab = (int32_t *) (p + (N + 1) * 16), *d_ord = d_lab + (N + 1);
+    uint32_t *d_off = (uint32_t *) (d_ord + (N + 1)), *d_cnt = d_off + S, *d_ncl = d_cnt + S, *d_st = d_ncl + S;
+    std::vector<uint32_t> h(2 * (size_t) S);
+    for (uint32_t s = 0; s < S; s++) {
+        h[s] = slice_off[s] - base0;
+        h[S + s] = slice_off[s + 1] - slice_off[s];
+    }
+    if (N) {
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_xy, xy + 2 * (size_t) base0, N * 16, hipMemcpyHostToDevice, st));
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_lab, labels + base0, N * 4, hipMemcpyHostToDevice, st));
+    }
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_off, h.data(), 2 * (size_t) S * 4, hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_ncl, n_clusters, (size_t) S * 4, hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));   // h is pageable: consumed
+    if ((rc = ecal_cluster_order_dev(ctx, d_xy, d_off, d_cnt, S, eps, d_lab, d_ncl, d_ord, d_st, st))) return rc;
+    std::vector<int32_t> to(N);
+    std::vector<uint32_t> ts(S);
+    if (N) ECAL_HIP_TRY(ctx, hipMemcpyAsync(to.data(), d_ord, N * 4, hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(ts.data(), d_st, (size_t) S * 4, hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (N) memcpy(order + base0, to.data(), N * 4);   // caller buffers are written only on success
+    memcpy(status, ts.data(), (size_t) S * 4);
     return ECAL_OK;
 }

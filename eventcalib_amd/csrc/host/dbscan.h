@@ -4,8 +4,9 @@
 // DBSCAN<T,Float> in the reference (dbscan.h:42-113): a caller such as CirclesEventFrame.cpp:66-72
 // compiles unchanged against this header.  What differs, and is documented in INTEGRATION.md:
 //   * only dim == 2 runs on the GPU path (the one the reference uses); other dims return FAILED;
-//   * Clusters[c] lists its members in ascending pid, the reference in BFS/LIFO visit order
-//     (cluster membership and numbering are identical, bit for bit);
+//   * Clusters[c] lists its members in the reference's order (expandCluster's pop order, ecal_cluster_order) for inputs of up
+//     to 2048 points with at most 64 points per eps-ball; beyond that in ascending pid (membership and numbering are
+//     identical, bit for bit, either way);
 //   * the distance-function argument is accepted and ignored (as in the reference's kd-tree build,
 //     where it is only used under BRUTEFORCE, dbscan.h:64,203-206).
 #ifndef ECAL_HOST_DBSCAN_H_
@@ -74,6 +75,14 @@ public:
         for (size_t pid = 0; pid < n; ++pid) {
             if (labels[pid] >= 0) Clusters[labels[pid]].push_back((uint) pid);
             else Noise.push_back((uint) pid);
+        }
+        // member order = the reference's (dbscan.h:229-265): position of every core point in its cluster's pop order
+        std::vector<int32_t> order(n);
+        uint32_t status = 1;
+        if (ecal_cluster_order(ecal_host::thread_ctx(), xy.data(), off, 1, (double) eps, labels.data(), &n_clusters, order.data(),
+                               &status) == ECAL_OK && status == 0) {
+            for (size_t pid = 0; pid < n; ++pid)
+                if (labels[pid] >= 0) Clusters[labels[pid]][(size_t) order[pid]] = (uint) pid;
         }
         return SUCCESS;
     }

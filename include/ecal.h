@@ -89,6 +89,9 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
 int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                            double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order /*[n_points]*/,
                            uint32_t *d_status /*[S]*/, void *stream);
+/* host-buffer form (what host/dbscan.h calls): slices as ecal_dbscan_batch takes them, labels / n_clusters as it returned them */
+int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_t *slice_off /*[S+1]*/, uint32_t S, double eps,
+                       const int32_t *labels, const uint32_t *n_clusters /*[S]*/, int32_t *order /*[N]*/, uint32_t *status /*[S]*/);
 
 /* ---- ingest + time-slicing ----------------------------------------------------------------
  * The event stream is the reference's .bin image: packed 25-byte little-endian records

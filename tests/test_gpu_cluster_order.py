@@ -112,3 +112,19 @@ def test_oversized_segment_is_reported_and_a_degenerate_tree_is_taken(env):
     for seg, r in ((chain, res[1]), (ok, res[2])):
         assert r[2] == 0
         _check(seg, r[0], r[1], 4.0, 2)
+
+
+def test_host_buffer_form_equals_the_device_form(env):
+    """ecal_cluster_order (what the DBSCAN<T,Float> shim calls to put Clusters[c] into the reference's order)."""
+    ctx, torch = env
+    rng = np.random.default_rng(8)
+    segs = [rng.integers(0, 40, size=(n, 2)).astype(np.float64) for n in (300, 1, 0, 700)]
+    segs = [np.unique(s, axis=0)[rng.permutation(len(np.unique(s, axis=0)))] if len(s) else s for s in segs]
+    res = _order_of(ctx, torch, segs, 4.0, 2)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint32)
+    xy = np.concatenate([s.reshape(-1, 2) for s in segs])
+    labels = np.concatenate([r[0] for r in res])
+    ncl = np.array([int(r[0].max()) + 1 if len(r[0]) and r[0].max() >= 0 else 0 for r in res], np.uint32)
+    order, status = ctx.cluster_order(xy, off, 4.0, labels, ncl)
+    assert np.array_equal(status, [r[2] for r in res])
+    assert np.array_equal(order, np.concatenate([r[1] for r in res]))
