@@ -20,24 +20,24 @@ namespace ecal {
 
 // FIT = Params::fitCircle: the algebraic-fit pairing keeps two 3x4 systems in registers; compiled apart so that the default
 // path (fitCircle == 0) stays below 72 VGPRs.  First pass: workgroup b takes window b.
-template <bool FIT>
+template <bool FIT, bool ORD = false>
 __global__ __launch_bounds__(DET_T) void extract_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
     uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
     uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
-    double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count) {
+    double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count, const int32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
     __shared__ uint32_t nk_sh[4];  // kept clusters per polarity, their members per polarity
-    extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true>(smem, red, nk_sh, blockIdx.x, xy, seg_off, seg_cnt, labels, n_clusters, prm,
-                                                      win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff, ksize, sorted,
-                                                      norms, todo, todo_count);
+    extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, ORD>(smem, red, nk_sh, blockIdx.x, xy, seg_off, seg_cnt, labels, n_clusters,
+                                                                  prm, win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff,
+                                                                  ksize, sorted, norms, todo, todo_count, nullptr, order);
 }
 
 // the first pass over a list: the windows the fused detection pass (ecal_fused.hip) did not carry through to extraction
-template <bool FIT>
+template <bool FIT, bool ORD = false>
 __global__ __launch_bounds__(DET_T) void extract_first_list_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
@@ -45,36 +45,37 @@ __global__ __launch_bounds__(DET_T) void extract_first_list_kernel(
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
     uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
     double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
-    const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count) {
+    const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count, const int32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
     __shared__ uint32_t nk_sh[4];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true>(smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters, prm,
-                                                          win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff, ksize, sorted,
-                                                          norms, todo, todo_count);
+        extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, ORD>(smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters,
+                                                                      prm, win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff,
+                                                                      ksize, sorted, norms, todo, todo_count, nullptr, order);
         __syncthreads();
     }
 }
 
 // second pass: the workgroups share the list of windows of DET_LDS_PTS + 1 ... DET_LDS_PTS2 points the first pass left
-template <bool FIT>
+template <bool FIT, bool ORD = false>
 __global__ __launch_bounds__(DET_T) void extract_list_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
     uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
     uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
-    double *__restrict__ norms, const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count) {
+    double *__restrict__ norms, const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count,
+    const int32_t *__restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
     __shared__ uint32_t nk_sh[4];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        extract_one<FIT, DET_LDS_PTS2, DET_LDS_MAXC2, false>(smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters,
-                                                             prm, win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff,
-                                                             ksize, sorted, norms, nullptr, nullptr);
+        extract_one<FIT, DET_LDS_PTS2, DET_LDS_MAXC2, false, false, ORD>(smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels,
+                                                                         n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
+                                                                         members, koff, ksize, sorted, norms, nullptr, nullptr, nullptr, order);
         __syncthreads();
     }
 }
@@ -110,12 +111,11 @@ extern "C" double ecal_circle_radius_threshold(double width, double height, int 
     return (m1 < m2 ? m1 : m2) / square_size * circle_radius * 1.5;
 }
 
-extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off,
-                                      const uint32_t *d_seg_cnt, const int32_t *d_labels,
-                                      const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points,
-                                      uint32_t cluster_min, uint32_t need_clusters, double radius_threshold,
-                                      int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
-                                      int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
+// d_order: the points' positions inside the reference's Clusters[label] (ecal_cluster_order_dev), or NULL
+static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
+                         const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters,
+                         double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair,
+                         double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, const int32_t *d_order, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (!d_seg_off || !d_seg_cnt || !d_n_clusters || !d_win_info ||
@@ -147,16 +147,18 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
         return ECAL_ERR_INVALID;
     }
     if (!ctx->det_attr_set) {
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_first_list_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_list_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES2));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&extract_list_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) DET_LDS_BYTES2));
+#define ECAL_DET_ATTR(K, BYTES)                                                                                        \
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int) (BYTES)))
+        ECAL_DET_ATTR((extract_kernel<false, false>), DET_LDS_BYTES);
+        ECAL_DET_ATTR((extract_kernel<true, false>), DET_LDS_BYTES);
+        ECAL_DET_ATTR((extract_kernel<false, true>), DET_LDS_BYTES);
+        ECAL_DET_ATTR((extract_kernel<true, true>), DET_LDS_BYTES);
+        ECAL_DET_ATTR((extract_first_list_kernel<false, false>), DET_LDS_BYTES);
+        ECAL_DET_ATTR((extract_list_kernel<false, false>), DET_LDS_BYTES2);
+        ECAL_DET_ATTR((extract_list_kernel<true, false>), DET_LDS_BYTES2);
+        ECAL_DET_ATTR((extract_list_kernel<false, true>), DET_LDS_BYTES2);
+        ECAL_DET_ATTR((extract_list_kernel<true, true>), DET_LDS_BYTES2);
+#undef ECAL_DET_ATTR
         ctx->det_attr_set = true;
     }
     // windows too large for the first pass's LDS staging but not for the second's are listed by the first pass
@@ -171,29 +173,57 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
              *so = (uint32_t *) ctx->det_sorted.ptr;
     double *no = (double *) ctx->det_norms.ptr;
     const uint32_t grid2 = S < 768u ? S : 768u;
-    if (prm.fit_circle) {
-        hipLaunchKernelGGL(extract_kernel<true>, dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,
-                           d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,
-                           second ? list : nullptr, cnt);
-        if (second)
-            hipLaunchKernelGGL(extract_list_kernel<true>, dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,
-                               d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks,
-                               so, no, (const uint32_t *) list, (const uint32_t *) cnt);
+#define ECAL_DET_FIRST(FIT_, ORD_)                                                                                                   \
+    hipLaunchKernelGGL((extract_kernel<FIT_, ORD_>), dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,     \
+                       d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,              \
+                       second ? list : nullptr, cnt, d_order)
+#define ECAL_DET_SECOND(FIT_, ORD_)                                                                                                  \
+    hipLaunchKernelGGL((extract_list_kernel<FIT_, ORD_>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,     \
+                       d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,    \
+                       (const uint32_t *) list, (const uint32_t *) cnt, d_order)
+    if (fused && !prm.fit_circle && !d_order) {
+        const uint32_t *dcnt = (const uint32_t *) ctx->fused_def.ptr, *dlist = dcnt + 4;
+        hipLaunchKernelGGL((extract_first_list_kernel<false, false>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off,
+                           d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks,
+                           so, no, second ? list : nullptr, cnt, dlist, dcnt, (const int32_t *) nullptr);
+    } else if (prm.fit_circle) {
+        if (d_order) ECAL_DET_FIRST(true, true); else ECAL_DET_FIRST(true, false);
     } else {
-        if (fused) {
-            const uint32_t *dcnt = (const uint32_t *) ctx->fused_def.ptr, *dlist = dcnt + 4;
-            hipLaunchKernelGGL(extract_first_list_kernel<false>, dim3(grid2), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt,
-                               d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so,
-                               no, second ? list : nullptr, cnt, dlist, dcnt);
-        } else
-        hipLaunchKernelGGL(extract_kernel<false>, dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,
-                           d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,
-                           second ? list : nullptr, cnt);
-        if (second)
-            hipLaunchKernelGGL(extract_list_kernel<false>, dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,
-                               d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks,
-                               so, no, (const uint32_t *) list, (const uint32_t *) cnt);
+        if (d_order) ECAL_DET_FIRST(false, true); else ECAL_DET_FIRST(false, false);
     }
+    if (second) {
+        if (prm.fit_circle) {
+            if (d_order) ECAL_DET_SECOND(true, true); else ECAL_DET_SECOND(true, false);
+        } else {
+            if (d_order) ECAL_DET_SECOND(false, true); else ECAL_DET_SECOND(false, false);
+        }
+    }
+#undef ECAL_DET_FIRST
+#undef ECAL_DET_SECOND
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
+}
+
+extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off,
+                                      const uint32_t *d_seg_cnt, const int32_t *d_labels,
+                                      const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points,
+                                      uint32_t cluster_min, uint32_t need_clusters, double radius_threshold,
+                                      int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
+                                      int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
+    return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
+                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, nullptr, stream);
+}
+
+extern "C" int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                              const int32_t *d_labels, const uint32_t *d_n_clusters, const int32_t *d_cluster_order,
+                                              uint32_t S, uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters,
+                                              double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,
+                                              uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep,
+                                              void *stream) {
+    if (ctx && n_points && !d_cluster_order) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
+                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, d_cluster_order, stream);
 }

@@ -61,7 +61,8 @@ struct DetGlobal {
     __device__ __forceinline__ double key(uint32_t li) const { return norms[li]; }  // ordering key of the median
     __device__ __forceinline__ void set_norm(uint32_t li, double v) const { norms[li] = v; }
     static constexpr bool INT_PIXELS = false;
-    static constexpr uint32_t IDX_MASK = 0xFFFFFFFFu;
+    static constexpr uint32_t REP_TIE = 0x80000000u;   // (ORD) flag on a representative whose rank has an equal-norm rival
+    static constexpr uint32_t IDX_MASK = 0xFFFFFFFFu, IDXB = 0u;
     static constexpr int J = 1;
     static constexpr uint32_t MAXC = 0;
     using CIdx = uint32_t;  // renumbered cluster id / first member slot of a DBSCAN cluster
@@ -75,6 +76,7 @@ template <uint32_t PTS_, uint32_t MAXC_>
 struct DetLdsT {
     static constexpr uint32_t IDXB = PTS_ > 2048u ? 12u : 11u;   // bits of the window-local point index in a member word
     static constexpr uint32_t IDX_MASK = (1u << IDXB) - 1u;
+    static constexpr uint32_t REP_TIE = 0x8000u;                  // (ORD) flag on a representative (u16, point indices < 2^12)
     static constexpr int J = (int) ((PTS_ + 255u) / 256u);        // points per thread at most
     static constexpr uint32_t MAXC = MAXC_;
     uint32_t *pts;  // x | y << 16, two's complement int16 each (exact: the staged path is taken for integer pixels only)
@@ -226,9 +228,78 @@ __device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, u
 }
 
 // base[pol]: window-local offset of the polarity's points (and of its kept-cluster arrays).
-template <bool FIT, typename ST>
+// std::nth_element(a, a + nth, a + m, comp) of libstdc++ (bits/stl_algo.h: __introselect with __unguarded_partition_pivot /
+// __move_median_to_first, finished by __insertion_sort on <= 3 elements), restated: CirclesEventFrame.cpp:136-147 runs it over
+// Clusters[c] with comp = "norm of the pixel is smaller", and WHICH of two members of equal norm ends up at a + nth depends on
+// the input order and on these very data movements.  a[] = window-local point indices in the reference's member order
+// (ecal_cluster_order_dev); key = the norm's ordering key.  Returns a[nth], or ~0 if the depth limit 2 lg(m) ran out (the
+// library then switches to __heap_select; not restated — with median-of-three pivots on a few dozen elements it does not
+// happen, and the caller keeps its own choice).
+template <typename ST>
+__device__ __forceinline__ uint32_t ref_nth_element(const ST &st, uint32_t o, uint32_t *a, uint32_t m, uint32_t nth) {
+    auto less = [&](uint32_t x, uint32_t y) { return st.key(o + x) < st.key(o + y); };
+    auto swp = [&](uint32_t i, uint32_t j) {
+        const uint32_t t = a[i];
+        a[i] = a[j];
+        a[j] = t;
+    };
+    uint32_t first = 0, last = m;
+    uint32_t depth = 2u * (31u - (uint32_t) __clz((int) m));   // std::__lg(m) * 2
+    while (last - first > 3u) {
+        if (depth == 0u) return ~0u;
+        depth--;
+        // __unguarded_partition_pivot
+        const uint32_t mid = first + (last - first) / 2u;
+        {   // __move_median_to_first(first, first + 1, mid, last - 1)
+            const uint32_t pa = first + 1u, pb = mid, pc = last - 1u;
+            if (less(a[pa], a[pb])) {
+                if (less(a[pb], a[pc])) swp(first, pb);
+                else if (less(a[pa], a[pc])) swp(first, pc);
+                else swp(first, pa);
+            } else if (less(a[pa], a[pc])) {
+                swp(first, pa);
+            } else if (less(a[pb], a[pc])) {
+                swp(first, pc);
+            } else {
+                swp(first, pb);
+            }
+        }
+        uint32_t lo = first + 1u, hi = last;   // __unguarded_partition(first + 1, last, pivot = first)
+        for (;;) {
+            while (less(a[lo], a[first])) lo++;
+            hi--;
+            while (less(a[first], a[hi])) hi--;
+            if (!(lo < hi)) break;
+            swp(lo, hi);
+            lo++;
+        }
+        if (lo <= nth) first = lo;
+        else last = lo;
+    }
+    // __insertion_sort(first, last)
+    for (uint32_t i = first + 1u; i < last; i++) {
+        const uint32_t val = a[i];
+        if (less(val, a[first])) {
+            for (uint32_t j = i; j > first; j--) a[j] = a[j - 1u];   // move_backward(first, i, i + 1)
+            a[first] = val;
+        } else {   // __unguarded_linear_insert
+            uint32_t j = i;
+            while (less(val, a[j - 1u])) {
+                a[j] = a[j - 1u];
+                j--;
+            }
+            a[j] = val;
+        }
+    }
+    return a[nth];
+}
+
+// ORD: ord0 / ord1 = the points' positions inside the reference's Clusters[label] (ecal_cluster_order_dev), per polarity:
+// the representative of a cluster whose median rank has an equal-norm rival is then the reference's own pick.
+template <bool FIT, bool ORD, typename ST>
 __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&base)[2], const uint32_t (&kb)[2],
                                                const uint32_t (&n_pol)[2], const int32_t *lab0, const int32_t *lab1,
+                                               const int32_t *ord0, const int32_t *ord1,
                                                const uint32_t (&nc_pol)[2], const DetectParams &prm, uint32_t *csize,
                                                typename ST::CIdx *newid, typename ST::CIdx *coff,
                                                unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
@@ -315,13 +386,14 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         const uint32_t i = st.composite() ? (wq & ST::IDX_MASK) : wq;
         const int32_t kl = st.kept[o + i];
         const uint32_t m = st.ksize[kb[pol] + kl], first = o + st.koff[kb[pol] + kl];
-        uint32_t rank = 0, at = 0;
+        uint32_t rank = 0, at = 0, eq = 0;   // eq (ORD): members of the same norm, itself included
         if (st.composite()) {
             const uint32_t wi = wq;
             for (uint32_t t = 0; t < m; t++) {
                 const uint32_t wj = st.members[first + t];
                 rank += (wj < wi) ? 1u : 0u;
                 at += ((wj & ST::IDX_MASK) < i) ? 1u : 0u;
+                if constexpr (ORD) eq += ((wj >> ST::IDXB) == (wi >> ST::IDXB)) ? 1u : 0u;
             }
         } else {
             const auto ni = st.key(o + i);
@@ -330,12 +402,40 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 const auto nj = st.key(o + j);
                 rank += (nj < ni || (nj == ni && j < i)) ? 1u : 0u;
                 at += (j < i) ? 1u : 0u;
+                if constexpr (ORD) eq += (nj == ni) ? 1u : 0u;
             }
         }
-        if (rank == m / 2) st.rep[kb[pol] + kl] = i;
+        if (rank == m / 2) st.rep[kb[pol] + kl] = (ORD && eq > 1u) ? (i | ST::REP_TIE) : i;
         st.sorted[first + at] = i;
     }
     __syncthreads();
+    if constexpr (ORD) {
+        // the flagged clusters, a thread each: members into the reference's order (members[] is free from here on), the
+        // library's nth_element on them.  Without a usable order (segment not taken by ecal_cluster_order_dev) the smaller
+        // pid stays.
+        for (int pol = 0; pol < 2; pol++) {
+            const int32_t *ord = pol ? ord1 : ord0;
+            for (uint32_t k = tid; k < nk[pol]; k += DET_T) {
+                const uint32_t rv = st.rep[kb[pol] + k];
+                if (!(rv & ST::REP_TIE)) continue;
+                uint32_t pick = rv & ~ST::REP_TIE;
+                const uint32_t m = st.ksize[kb[pol] + k], first = base[pol] + st.koff[kb[pol] + k];
+                bool usable = ord != nullptr;
+                for (uint32_t t = 0; usable && t < m; t++) {
+                    const uint32_t i = st.sorted[first + t];
+                    const int32_t p = ord[i];
+                    if (p < 0 || (uint32_t) p >= m) usable = false;
+                    else st.members[first + (uint32_t) p] = i;
+                }
+                if (usable) {
+                    const uint32_t r = ref_nth_element(st, base[pol], &st.members[first], m, m / 2u);
+                    if (r != ~0u) pick = r;
+                }
+                st.rep[kb[pol] + k] = pick;
+            }
+        }
+        __syncthreads();
+    }
     DET_MARK(2);
     if (ECAL_DET_STOP == 3) return;
     // mutual nearest +/- representatives and the circle test (:283-311); candidates in + cluster order
@@ -628,7 +728,7 @@ struct DetLdsLayoutT {
 // fit the second pass's (DET_LDS_PTS2 points, DET_LDS_MAXC2 clusters) to the to-do list instead of taking the global path.
 // KNOWN: offsets, counts and cluster counts of the window's two segments are handed in (the fused pass, ecal_fused.hip: the
 // workgroup wrote them itself a moment ago; a scalar load might find a stale line in the constant cache).
-template <bool FIT, uint32_t PTS, uint32_t MAXC, bool FIRST, bool KNOWN = false>
+template <bool FIT, uint32_t PTS, uint32_t MAXC, bool FIRST, bool KNOWN = false, bool ORD = false>
 __device__ __forceinline__ void extract_one(
     unsigned char *smem, unsigned long long *red, uint32_t *nk_sh, const uint32_t s, const double *__restrict__ xy,
     const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt, const int32_t *__restrict__ labels,
@@ -636,7 +736,7 @@ __device__ __forceinline__ void extract_one(
     uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr, int32_t *__restrict__ kept_labels,
     uint32_t *__restrict__ rep, uint32_t *__restrict__ members, uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize,
     uint32_t *__restrict__ sorted, double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
-    const uint32_t *known = nullptr) {
+    const uint32_t *known = nullptr, const int32_t *__restrict__ order = nullptr) {
     using LL = DetLdsLayoutT<PTS, MAXC>;
     // csize: members per DBSCAN cluster, later a scatter cursor; newid: renumbered id of a kept cluster;
     // coff: first member slot of a kept cluster.  Sized for the global path; the LDS path uses the first
@@ -727,7 +827,8 @@ __device__ __forceinline__ void extract_one(
         st.small = small_px;
         const uint32_t base[2] = {0u, n_pol[0]};
         const uint32_t kb[2] = {0u, MAXC};  // per-cluster arrays: one block of MAXC per polarity
-        extract_window<FIT>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize,
+        extract_window<FIT, ORD>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
+                                 order ? order + o_pol[1] : nullptr, nc_pol, prm, csize,
                        reinterpret_cast<uint16_t *>(smem + LL::newid_off), reinterpret_cast<uint16_t *>(smem + LL::coff_off), red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
         __syncthreads();
@@ -757,7 +858,8 @@ __device__ __forceinline__ void extract_one(
         st.kept = kept_labels + w0;
         st.norms = norms + w0;
         const uint32_t base[2] = {o_pol[0] - w0, o_pol[1] - w0};
-        extract_window<FIT>(st, base, base, n_pol, labels + o_pol[0], labels + o_pol[1], nc_pol, prm, csize, csize + DET_MAXC,
+        extract_window<FIT, ORD>(st, base, base, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
+                                 order ? order + o_pol[1] : nullptr, nc_pol, prm, csize, csize + DET_MAXC,
                        csize + 2 * DET_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
     }

@@ -58,7 +58,7 @@ class DetectPipeline:
         self.det = (int(cluster_min), int(need_clusters), float(radius_threshold), bool(fit_circle), int(knn_num))
 
     def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True, slice_only=False,
-            fused=False):
+            fused=False, exact_ties=False):
         """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN -> candidate
         extraction on the current torch stream; results stay in HBM (self.xy / seg_off / seg_cnt /
         labels / n_clusters / win_info / cand_pair / cand_xyr / kept_labels / rep)."""
@@ -89,7 +89,23 @@ class DetectPipeline:
             return self
         c.dbscan_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots,
                            max_seg_points, eps, minpts, self.labels.data_ptr(), self.n_clusters.data_ptr(), st)
-        if detect:
+        if detect and exact_ties:
+            # the reference's own representative where a cluster's median rank is tied in norm: the members' order inside
+            # Clusters[c] (ecal_cluster_order_dev) + libstdc++'s nth_element on it (ecal_extract_batch_ordered_dev)
+            if not hasattr(self, "det"):
+                self.set_detect_params()
+            if getattr(self, "_order_cap", 0) < slots or getattr(self, "_ostat_cap", 0) < 2 * S:
+                self.cluster_order = torch.empty(slots, dtype=torch.int32, device=self.dev)
+                self.order_status = torch.empty(2 * S, dtype=torch.int32, device=self.dev)
+                self._order_cap, self._ostat_cap = slots, 2 * S
+            c.cluster_order_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, eps, self.labels.data_ptr(),
+                                self.n_clusters.data_ptr(), self.cluster_order.data_ptr(), self.order_status.data_ptr(), st)
+            c.extract_batch_ordered_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.labels.data_ptr(),
+                                        self.n_clusters.data_ptr(), self.cluster_order.data_ptr(), S, slots, self.det[0], self.det[1],
+                                        self.det[2], self.win_info.data_ptr(), self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(),
+                                        self.kept_labels.data_ptr(), self.rep.data_ptr(), st, fit_circle=self.det[3],
+                                        knn_num=self.det[4])
+        elif detect:
             if not hasattr(self, "det"):
                 self.set_detect_params()
             c.extract_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(),

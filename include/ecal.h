@@ -194,6 +194,18 @@ int ecal_detect_fused_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
                           int *d_overflow, int32_t *d_labels, uint32_t *d_n_clusters /*[2S]*/, uint32_t *d_win_info /*[S][4]*/,
                           uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream);
 
+/* ecal_extract_batch_ordered_dev = ecal_extract_batch_dev with the reference's own choice where a cluster's median rank has an
+ * equal-norm rival: d_cluster_order = ecal_cluster_order_dev's output for the same segments (the members' positions inside
+ * Clusters[c]); the representative of such a cluster is what libstdc++'s std::nth_element leaves at Clusters[c][size / 2]
+ * (CirclesEventFrame.cpp:136-147; introselect restated), everything downstream follows.  Clusters of segments
+ * ecal_cluster_order_dev did not take (status 1) keep ecal_extract_batch_dev's rule (the smaller pid). */
+int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                   const int32_t *d_labels, const uint32_t *d_n_clusters, const int32_t *d_cluster_order,
+                                   uint32_t S /*windows*/, uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters,
+                                   double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,
+                                   uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep,
+                                   void *stream);
+
 /* ---- host-buffer conveniences (what the C++ shims in eventcalib_amd/csrc/host/ call) ----------
  * ecal_stream: the event stream uploaded once and kept in HBM — the counterpart of the reference's
  *   EventContainer (event/include/opengv2/event/EventContainer.hpp:25-30), filled once by the driver

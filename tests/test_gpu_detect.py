@@ -28,7 +28,7 @@ def test_radius_threshold_kat(env):
                                                                                                      False, 3.0, 1.0)
 
 
-def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=False, knn_num=3):
+def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=False, knn_num=3, exact_ties=False):
     S = len(t0)
     info = pipe.win_info[:S].cpu().numpy().astype(np.int64)
     seg_off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
@@ -52,7 +52,9 @@ def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=
         if ref["status"]:
             assert info[s, 0] == 0
             continue
-        if ref["tie"]:
+        if ref["tie"] and exact_ties:
+            tied += 1        # run(exact_ties=True): the reference's own pick — nothing is handed to the oracle, see below
+        elif ref["tie"]:
             # Some cluster's median has an equal-norm rival: which of the two the reference's nth_element returns depends
             # on its BFS member order, the build takes the smaller pid.  That choice is the ONLY freedom:
             # every untied cluster's representative must be the oracle's, a tied cluster's must be a member of the same
@@ -168,3 +170,44 @@ def test_translated_pixels_take_the_plain_key_path(env, rate):
     torch.cuda.synchronize()
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)
     assert exact + tied >= 3 or rate < 2.0e6
+
+
+@pytest.mark.parametrize("rate,params", [(1.0e6, (3, 10, 40.0)), (2.0e6, (5, 36, THR)), (4.0e6, (5, 36, THR))])
+def test_exact_ties_reference_representatives(env, rate, params):
+    """run(exact_ties=True): where a cluster's median rank has an equal-norm rival the representative is the reference's OWN pick
+    (std::nth_element over Clusters[c] in expandCluster's order) — so representatives, pairs, circles and counts equal the oracle's
+    in EVERY window, with nothing handed to the oracle."""
+    ctx, pipe, torch = env
+    buf = SS.make_stream(int(0.12 * rate), rate=rate, device="cpu", seed=41)      # 80 windows at every density
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(*params)
+    pipe.run(buf.cuda(), exact_ties=True)
+    torch.cuda.synchronize()
+    assert int((pipe.order_status[:2 * len(t0)] != 0).sum()) == 0
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, *params, exact_ties=True)
+    assert tied >= 2 and exact + tied >= 0.7 * len(t0), (exact, tied, len(t0))
+
+
+def test_exact_ties_in_the_global_scratch_path_and_with_fit_circle(env):
+    ctx, pipe, torch = env
+    buf = SS.make_stream(400000, rate=2.0e6, device="cpu", seed=12)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]), 3.0e-3)          # > 1408 unique pixels per window
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR)
+    pipe.run(buf.cuda(), exact_ties=True)
+    torch.cuda.synchronize()
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, exact_ties=True)
+    assert tied >= 1 and exact + tied >= 0.7 * len(t0)
+    buf = SS.make_stream(90000, rate=2.0e6, device="cpu", seed=77)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR, fit_circle=True, knn_num=3)
+    pipe.run(buf.cuda(), exact_ties=True)
+    torch.cuda.synchronize()
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, fit_circle=True, knn_num=3, exact_ties=True)
+    assert tied >= 1
+    pipe.set_detect_params(5, 36, THR)
