@@ -59,7 +59,7 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
                                                             const int32_t *__restrict__ labels,
                                                             const uint32_t *__restrict__ n_clusters, int32_t *__restrict__ order,
                                                             uint32_t *__restrict__ status, uint16_t *__restrict__ lists,
-                                                            uint8_t *__restrict__ list_cnt) {
+                                                            uint8_t *__restrict__ list_cnt, int only_tied) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *const px = reinterpret_cast<double *>(smem + BoLayout::px_off);
     double *const py = reinterpret_cast<double *>(smem + BoLayout::py_off);
@@ -101,6 +101,72 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
         for (uint32_t c = tid; c < nc; c += BO_T) seed[c] = BO_NONE;
         for (uint32_t w = tid; w < (n + 31u) / 32u; w += BO_T) inq[w] = 0;
         __syncthreads();
+        // members per cluster, the clusters' seeds (= smallest pid), the clusters' member lists (in queue[], for the tie test)
+        for (uint32_t i = tid; i < n; i += BO_T) {
+            if (lab[i] >= 0) {
+                atomicAdd(&qbase[lab[i] + 1], 1u);
+                atomicMin(&seed[lab[i]], i);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {   // offsets of the clusters' queues (a few dozen clusters per segment in practice)
+            uint32_t run = 0;
+            for (uint32_t c = 0; c <= nc; c++) {
+                run += qbase[c];
+                qbase[c] = run;
+            }
+        }
+        __syncthreads();
+        // only_tied: the order is wanted for the clusters whose median has an equal-norm rival (what std::nth_element's
+        // result depends on it for, CirclesEventFrame.cpp:136-147) — the test ecal_extract_batch_ordered_dev applies: the
+        // member of rank size / 2 in the order (norm, pid) shares its norm with another member.  tie[c] lives in the upper
+        // half of seed[]'s word... kept apart: cursor[] = child[] (not yet in use), tie flags = bit 31 of qbase's copy.
+        bool seg_has_tie = !only_tied;
+        if (only_tied) {
+            uint32_t *const cursor = child;               // [nc] scatter cursors (the tree is built later)
+            uint32_t *const tie = child + BO_CAP;         // [nc]
+            for (uint32_t c = tid; c < nc; c += BO_T) {
+                cursor[c] = 0;
+                tie[c] = 0;
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += BO_T)
+                if (lab[i] >= 0) queue[qbase[lab[i]] + atomicAdd(&cursor[lab[i]], 1u)] = (uint16_t) i;
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += BO_T) {
+                if (lab[i] < 0) continue;
+                const uint32_t c = (uint32_t) lab[i], qb = qbase[c], m = qbase[c + 1] - qb;
+                const double ki = __dsqrt_rn(px[i] * px[i] + py[i] * py[i]);   // Vector2d::norm()
+                uint32_t rank = 0, eq = 0;
+                for (uint32_t t = 0; t < m; t++) {
+                    const uint32_t j = queue[qb + t];
+                    const double kj = __dsqrt_rn(px[j] * px[j] + py[j] * py[j]);
+                    rank += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
+                    eq += (kj == ki) ? 1u : 0u;
+                }
+                if (rank == m / 2u && eq > 1u) tie[c] = 1;
+            }
+            __syncthreads();
+            bool any_tie = false;
+            for (uint32_t c = tid; c < nc; c += BO_T) {
+                if (tie[c]) any_tie = true;
+                else seed[c] = BO_NONE - 1u;              // not wanted: no queue simulation, members get -2
+            }
+            uint32_t rr = 0;
+            seg_has_tie = bo_block_any(any_tie, red, rr);
+            __syncthreads();
+            if (!seg_has_tie) {
+                for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = lab[i] < 0 ? -1 : -2;
+                if (tid == 0) status[s] = 0;
+                continue;
+            }
+            for (uint32_t i = tid; i < n; i += BO_T) {    // child[] goes back to the tree
+                child[2 * i] = BO_NONE;
+                child[2 * i + 1] = BO_NONE;
+            }
+            if (tid < 4) red[tid] = 0;
+            __syncthreads();
+        }
         // ---- 1. the insertion-order kd-tree (root = point 0 splits on x, children alternate: kdtree.cpp:127) ----
         uint32_t cur[BO_PPT], pend[BO_PPT], dep[BO_PPT];
         bool placed[BO_PPT];
@@ -154,29 +220,12 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             }
             __syncthreads();   // (the next round's reads come after every resolve)
         }
-        // members per cluster, the clusters' seeds (= smallest pid)
-#pragma unroll
-        for (int u = 0; u < BO_PPT; u++) {
-            const uint32_t i = tid + u * BO_T;
-            if (i < n && lab[i] >= 0) {
-                atomicAdd(&qbase[lab[i] + 1], 1u);
-                atomicMin(&seed[lab[i]], i);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {   // offsets of the clusters' queues (<= a few dozen clusters per segment in practice)
-            uint32_t run = 0;
-            for (uint32_t c = 0; c <= nc; c++) {
-                run += qbase[c];
-                qbase[c] = run;
-            }
-        }
         // ---- 2. one range query per core point: find_nearest's visiting order (kdtree.cpp:148-179) ----
         bool fail = false;
 #pragma unroll 1
         for (int u = 0; u < BO_PPT; u++) {
             const uint32_t i = tid + u * BO_T;
-            if (i >= n || lab[i] < 0) continue;
+            if (i >= n || lab[i] < 0 || seed[lab[i]] == BO_NONE - 1u) continue;
             const double qx = px[i], qy = py[i];
             uint16_t *out = my_lists + (size_t) i * BO_MAXN;
             uint32_t cnt = 0, sp = 0;
@@ -221,9 +270,10 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
         // ---- 3. expandCluster's queue, one thread per cluster (dbscan.h:229-265) ----
         for (uint32_t i = tid; i < n; i += BO_T)
             if (lab[i] < 0) order[base + i] = -1;
+            else if (seed[lab[i]] == BO_NONE - 1u) order[base + i] = -2;
         for (uint32_t c = tid; c < nc; c += BO_T) {
             const uint32_t qb = qbase[c], sd = seed[c];
-            if (sd == BO_NONE) continue;   // (a cluster without members cannot be)
+            if (sd >= BO_NONE - 1u) continue;   // not wanted (or, impossible, without members)
             uint32_t head = 0, tail = 1;
             queue[qb] = (uint16_t) sd;
             atomicOr(&inq[sd >> 5], 1u << (sd & 31u));
@@ -253,7 +303,7 @@ using namespace ecal;
 
 extern "C" int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
                                       uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters,
-                                      int32_t *d_order, uint32_t *d_status, void *stream) {
+                                      int32_t *d_order, uint32_t *d_status, int only_tied_medians, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (!d_xy || !d_seg_off || !d_seg_cnt || !d_labels || !d_n_clusters || !d_order || !d_status) {
@@ -277,7 +327,7 @@ extern "C" int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const u
         ctx->bfs_attr_set = true;
     }
     hipLaunchKernelGGL(cluster_order_kernel, dim3(grid), dim3(BO_T), BoLayout::bytes, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels,
-                       d_n_clusters, d_order, d_status, lists, cnt);
+                       d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
@@ -324,7 +374,7 @@ extern "C" int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_off, h.data(), 2 * (size_t) S * 4, hipMemcpyHostToDevice, st));
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_ncl, n_clusters, (size_t) S * 4, hipMemcpyHostToDevice, st));
     ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));   // h is pageable: consumed
-    if ((rc = ecal_cluster_order_dev(ctx, d_xy, d_off, d_cnt, S, eps, d_lab, d_ncl, d_ord, d_st, st))) return rc;
+    if ((rc = ecal_cluster_order_dev(ctx, d_xy, d_off, d_cnt, S, eps, d_lab, d_ncl, d_ord, d_st, 0, st))) return rc;
     std::vector<int32_t> to(N);
     std::vector<uint32_t> ts(S);
     if (N) ECAL_HIP_TRY(ctx, hipMemcpyAsync(to.data(), d_ord, N * 4, hipMemcpyDeviceToHost, st));

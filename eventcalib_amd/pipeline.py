@@ -99,7 +99,8 @@ class DetectPipeline:
                 self.order_status = torch.empty(2 * S, dtype=torch.int32, device=self.dev)
                 self._order_cap, self._ostat_cap = slots, 2 * S
             c.cluster_order_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, eps, self.labels.data_ptr(),
-                                self.n_clusters.data_ptr(), self.cluster_order.data_ptr(), self.order_status.data_ptr(), st)
+                                self.n_clusters.data_ptr(), self.cluster_order.data_ptr(), self.order_status.data_ptr(), st,
+                                only_tied_medians=True)
             c.extract_batch_ordered_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.labels.data_ptr(),
                                         self.n_clusters.data_ptr(), self.cluster_order.data_ptr(), S, slots, self.det[0], self.det[1],
                                         self.det[2], self.win_info.data_ptr(), self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(),

@@ -85,10 +85,13 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
  * not take (more than 2048 points or clusters, more than 64 points in one eps-ball, a tree deeper than 96 levels): its
  * d_order entries are -1.  What it is for: Clusters[c] in the reference's order for callers that index into it, and
  * extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147), which depend on that order
- * when two members tie in norm. */
+ * when two members tie in norm.  only_tied_medians != 0: the order is worked out only for the clusters that need it for that
+ * purpose — those whose member of rank size / 2 in the order (norm, pid) shares its norm with another member (the test
+ * ecal_extract_batch_ordered_dev applies) —, the members of all other clusters get -2; segments without such a cluster (four
+ * in five on the benchmark stream) do not even have their tree rebuilt. */
 int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                            double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order /*[n_points]*/,
-                           uint32_t *d_status /*[S]*/, void *stream);
+                           uint32_t *d_status /*[S]*/, int only_tied_medians, void *stream);
 /* host-buffer form (what host/dbscan.h calls): slices as ecal_dbscan_batch takes them, labels / n_clusters as it returned them */
 int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_t *slice_off /*[S+1]*/, uint32_t S, double eps,
                        const int32_t *labels, const uint32_t *n_clusters /*[S]*/, int32_t *order /*[N]*/, uint32_t *status /*[S]*/);

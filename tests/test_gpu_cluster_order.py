@@ -128,3 +128,47 @@ def test_host_buffer_form_equals_the_device_form(env):
     order, status = ctx.cluster_order(xy, off, 4.0, labels, ncl)
     assert np.array_equal(status, [r[2] for r in res])
     assert np.array_equal(order, np.concatenate([r[1] for r in res]))
+
+
+def test_only_tied_medians_mode(env):
+    """only_tied_medians: the same positions for the clusters whose median has an equal-norm rival, -2 for all other members."""
+    ctx, torch = env
+    from eventcalib_amd.pipeline import DetectPipeline
+    n = 400_000
+    ev = SS.make_stream(n, device="cuda", seed=23)
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 1e6)
+    pipe = DetectPipeline(ctx)
+    pipe.set_windows(t0, t1)
+    pipe.run(ev, detect=False)
+    S = len(t0)
+    st = torch.cuda.current_stream().cuda_stream
+    full = torch.empty(n, dtype=torch.int32, device="cuda")
+    part = torch.full((n,), -9, dtype=torch.int32, device="cuda")
+    s1 = torch.empty(2 * S, dtype=torch.int32, device="cuda")
+    s2 = torch.empty(2 * S, dtype=torch.int32, device="cuda")
+    args = (pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * S, 4.0, pipe.labels.data_ptr(), pipe.n_clusters.data_ptr())
+    ctx.cluster_order_dev(*args, full.data_ptr(), s1.data_ptr(), st)
+    ctx.cluster_order_dev(*args, part.data_ptr(), s2.data_ptr(), st, only_tied_medians=True)
+    torch.cuda.synchronize()
+    assert int(s1.sum()) == 0 and int(s2.sum()) == 0
+    off, cnt = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64), pipe.seg_cnt[:2 * S].cpu().numpy().astype(np.int64)
+    full, part = full.cpu().numpy(), part.cpu().numpy()
+    lab, xy = pipe.labels.cpu().numpy(), pipe.xy.cpu().numpy()
+    tied_clusters = plain_clusters = 0
+    for sg in range(2 * S):
+        o, m = off[sg], cnt[sg]
+        f, p, l, pts = full[o:o + m], part[o:o + m], lab[o:o + m], xy[o:o + m]
+        assert np.array_equal(p == -1, l < 0)
+        key = (pts ** 2).sum(1)
+        for c in range(int(l.max()) + 1 if m else 0):
+            idx = np.flatnonzero(l == c)
+            srt = idx[np.lexsort((idx, key[idx]))]                    # (norm, pid)
+            mid = srt[len(idx) // 2]
+            tied = int((key[idx] == key[mid]).sum()) > 1
+            if tied:
+                tied_clusters += 1
+                assert np.array_equal(p[idx], f[idx]), (sg, c)
+            else:
+                plain_clusters += 1
+                assert (p[idx] == -2).all(), (sg, c)
+    assert tied_clusters > 10 and plain_clusters > 20 * tied_clusters
