@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_sort_events_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
     "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev",
-    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
+    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
     "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_rectify_batch_dev", "ecal_rectify_batch",
@@ -287,6 +287,20 @@ class Context:
                                                      int(n_points), int(cluster_min), int(need_clusters), float(radius_threshold),
                                                      int(bool(fit_circle)), int(knn_num), d_win_info, d_cand_pair, d_cand_xyr,
                                                      d_kept_labels, d_rep, stream))
+
+    def extract_batch_exact_dev(self, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min, need_clusters,
+                                radius_threshold, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, stream=0, fit_circle=False,
+                                knn_num=3):
+        """The exact extraction in one call: plain pass + member order of the tied clusters + re-extraction of their windows."""
+        L = self._L
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        L.ecal_extract_batch_exact_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, ctypes.c_double, u32, u32, ctypes.c_double,
+                                                   ctypes.c_int, u32, vp, vp, vp, vp, vp, vp]
+        L.ecal_extract_batch_exact_dev.restype = ctypes.c_int
+        self._check(L.ecal_extract_batch_exact_dev(self._h, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, int(S), int(n_points),
+                                                   float(eps), int(cluster_min), int(need_clusters), float(radius_threshold),
+                                                   int(bool(fit_circle)), int(knn_num), d_win_info, d_cand_pair, d_cand_xyr,
+                                                   d_kept_labels, d_rep, stream))
 
     def cluster_order_dev(self, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, stream=0,
                           only_tied_medians=False):

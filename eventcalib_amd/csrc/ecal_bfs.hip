@@ -59,7 +59,9 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
                                                             const int32_t *__restrict__ labels,
                                                             const uint32_t *__restrict__ n_clusters, int32_t *__restrict__ order,
                                                             uint32_t *__restrict__ status, uint16_t *__restrict__ lists,
-                                                            uint8_t *__restrict__ list_cnt, int only_tied) {
+                                                            uint8_t *__restrict__ list_cnt, int only_tied,
+                                                            const uint32_t *__restrict__ win_list,
+                                                            const uint32_t *__restrict__ win_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *const px = reinterpret_cast<double *>(smem + BoLayout::px_off);
     double *const py = reinterpret_cast<double *>(smem + BoLayout::py_off);
@@ -76,7 +78,10 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
     uint8_t *const my_cnt = list_cnt + (size_t) blockIdx.x * BO_CAP;
     const double eps2 = eps * eps;   // SQ(range), kdtree.cpp:155-159
 
-    for (uint32_t s = blockIdx.x; s < S; s += gridDim.x) {
+    // win_list: only the two segments (2 w, 2 w + 1) of the listed windows w
+    const uint32_t n_work = win_list ? 2u * *win_count : S;
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const uint32_t s = win_list ? 2u * win_list[wk >> 1] + (wk & 1u) : wk;
         const uint32_t n = seg_cnt[s], base = seg_off[s], nc = n_clusters[s];
         __syncthreads();   // the previous segment's LDS is dead
         if (n == 0) {
@@ -301,9 +306,22 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
 
 using namespace ecal;
 
+extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                           uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
+                                           uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list,
+                                           const uint32_t *d_win_count, void *stream);
 extern "C" int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
                                       uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters,
                                       int32_t *d_order, uint32_t *d_status, int only_tied_medians, void *stream) {
+    return ecal_cluster_order_list_dev(ctx, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status,
+                                       only_tied_medians, nullptr, nullptr, stream);
+}
+
+// d_win_list != NULL: only the segments 2 w and 2 w + 1 of the windows w = d_win_list[0 .. *d_win_count) (S = 2 x windows in all)
+extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                           uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
+                                           uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list,
+                                           const uint32_t *d_win_count, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (!d_xy || !d_seg_off || !d_seg_cnt || !d_labels || !d_n_clusters || !d_order || !d_status) {
@@ -327,7 +345,7 @@ extern "C" int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const u
         ctx->bfs_attr_set = true;
     }
     hipLaunchKernelGGL(cluster_order_kernel, dim3(grid), dim3(BO_T), BoLayout::bytes, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels,
-                       d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians);
+                       d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

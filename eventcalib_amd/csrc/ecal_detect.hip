@@ -20,24 +20,26 @@ namespace ecal {
 
 // FIT = Params::fitCircle: the algebraic-fit pairing keeps two 3x4 systems in registers; compiled apart so that the default
 // path (fitCircle == 0) stays below 72 VGPRs.  First pass: workgroup b takes window b.
-template <bool FIT, bool ORD = false>
+// MODE 0: the smaller pid at tied medians; 1: the reference's pick (order given); 2: as 0 + the windows with a tied median listed
+template <bool FIT, int MODE = 0>
 __global__ __launch_bounds__(DET_T) void extract_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
     uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
     uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
-    double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count, const int32_t *__restrict__ order) {
+    double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count, const int32_t *__restrict__ order,
+    uint32_t *__restrict__ tie_list, uint32_t *__restrict__ tie_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
     __shared__ uint32_t nk_sh[4];  // kept clusters per polarity, their members per polarity
-    extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, ORD>(smem, red, nk_sh, blockIdx.x, xy, seg_off, seg_cnt, labels, n_clusters,
-                                                                  prm, win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff,
-                                                                  ksize, sorted, norms, todo, todo_count, nullptr, order);
+    extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, MODE == 1, MODE == 2>(
+        smem, red, nk_sh, blockIdx.x, xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
+        members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order, tie_list, tie_count);
 }
 
 // the first pass over a list: the windows the fused detection pass (ecal_fused.hip) did not carry through to extraction
-template <bool FIT, bool ORD = false>
+template <bool FIT, int MODE = 0>
 __global__ __launch_bounds__(DET_T) void extract_first_list_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
@@ -51,15 +53,15 @@ __global__ __launch_bounds__(DET_T) void extract_first_list_kernel(
     __shared__ uint32_t nk_sh[4];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, ORD>(smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters,
-                                                                      prm, win_info, cand_pair, cand_xyr, kept_labels, rep, members, koff,
-                                                                      ksize, sorted, norms, todo, todo_count, nullptr, order);
+        extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, MODE == 1, false>(
+            smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
+            members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order);
         __syncthreads();
     }
 }
 
 // second pass: the workgroups share the list of windows of DET_LDS_PTS + 1 ... DET_LDS_PTS2 points the first pass left
-template <bool FIT, bool ORD = false>
+template <bool FIT, int MODE = 0>
 __global__ __launch_bounds__(DET_T) void extract_list_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
@@ -67,15 +69,15 @@ __global__ __launch_bounds__(DET_T) void extract_list_kernel(
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
     uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
     double *__restrict__ norms, const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count,
-    const int32_t *__restrict__ order) {
+    const int32_t *__restrict__ order, uint32_t *__restrict__ tie_list, uint32_t *__restrict__ tie_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
     __shared__ uint32_t nk_sh[4];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        extract_one<FIT, DET_LDS_PTS2, DET_LDS_MAXC2, false, false, ORD>(smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels,
-                                                                         n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
-                                                                         members, koff, ksize, sorted, norms, nullptr, nullptr, nullptr, order);
+        extract_one<FIT, DET_LDS_PTS2, DET_LDS_MAXC2, false, false, MODE == 1, MODE == 2>(
+            smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
+            members, koff, ksize, sorted, norms, nullptr, nullptr, nullptr, order, tie_list, tie_count);
         __syncthreads();
     }
 }
@@ -111,11 +113,13 @@ extern "C" double ecal_circle_radius_threshold(double width, double height, int 
     return (m1 < m2 ? m1 : m2) / square_size * circle_radius * 1.5;
 }
 
-// d_order: the points' positions inside the reference's Clusters[label] (ecal_cluster_order_dev), or NULL
+// mode 0: plain; 1: d_order = the points' positions inside the reference's Clusters[label] (ecal_cluster_order_dev), the windows
+// = in_list[0 .. *in_count) (or all S when in_list is null); 2: plain + the windows with a tied median appended to tie_list
 static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
                          const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters,
                          double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair,
-                         double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, const int32_t *d_order, void *stream) {
+                         double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, int mode, const int32_t *d_order,
+                         const uint32_t *d_in_list, const uint32_t *d_in_count, uint32_t *d_tie_list, uint32_t *d_tie_count, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (!d_seg_off || !d_seg_cnt || !d_n_clusters || !d_win_info ||
@@ -149,15 +153,19 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     if (!ctx->det_attr_set) {
 #define ECAL_DET_ATTR(K, BYTES)                                                                                        \
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int) (BYTES)))
-        ECAL_DET_ATTR((extract_kernel<false, false>), DET_LDS_BYTES);
-        ECAL_DET_ATTR((extract_kernel<true, false>), DET_LDS_BYTES);
-        ECAL_DET_ATTR((extract_kernel<false, true>), DET_LDS_BYTES);
-        ECAL_DET_ATTR((extract_kernel<true, true>), DET_LDS_BYTES);
-        ECAL_DET_ATTR((extract_first_list_kernel<false, false>), DET_LDS_BYTES);
-        ECAL_DET_ATTR((extract_list_kernel<false, false>), DET_LDS_BYTES2);
-        ECAL_DET_ATTR((extract_list_kernel<true, false>), DET_LDS_BYTES2);
-        ECAL_DET_ATTR((extract_list_kernel<false, true>), DET_LDS_BYTES2);
-        ECAL_DET_ATTR((extract_list_kernel<true, true>), DET_LDS_BYTES2);
+#define ECAL_DET_ATTR3(K, BYTES)           \
+    ECAL_DET_ATTR((K<false, 0>), BYTES);   \
+    ECAL_DET_ATTR((K<false, 1>), BYTES);   \
+    ECAL_DET_ATTR((K<false, 2>), BYTES);   \
+    ECAL_DET_ATTR((K<true, 0>), BYTES);    \
+    ECAL_DET_ATTR((K<true, 1>), BYTES);    \
+    ECAL_DET_ATTR((K<true, 2>), BYTES)
+        ECAL_DET_ATTR3(extract_kernel, DET_LDS_BYTES);
+        ECAL_DET_ATTR3(extract_list_kernel, DET_LDS_BYTES2);
+        ECAL_DET_ATTR((extract_first_list_kernel<false, 0>), DET_LDS_BYTES);
+        ECAL_DET_ATTR((extract_first_list_kernel<false, 1>), DET_LDS_BYTES);
+        ECAL_DET_ATTR((extract_first_list_kernel<true, 1>), DET_LDS_BYTES);
+#undef ECAL_DET_ATTR3
 #undef ECAL_DET_ATTR
         ctx->det_attr_set = true;
     }
@@ -167,38 +175,48 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     const bool second = !getenv("ECAL_EXTRACT_NO_SECOND_PASS");
     hipStream_t st = (hipStream_t) stream;
     // (fused pass, ecal_fused.hip: the fused kernel has extracted every window it carried through and listed the others)
-    const bool fused = ctx->fused_pass;
+    const bool fused = ctx->fused_pass && mode == 0;
     if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
     uint32_t *mem = (uint32_t *) ctx->det_members.ptr, *ko = (uint32_t *) ctx->det_koff.ptr, *ks = (uint32_t *) ctx->det_ksize.ptr,
              *so = (uint32_t *) ctx->det_sorted.ptr;
     double *no = (double *) ctx->det_norms.ptr;
     const uint32_t grid2 = S < 768u ? S : 768u;
-#define ECAL_DET_FIRST(FIT_, ORD_)                                                                                                   \
-    hipLaunchKernelGGL((extract_kernel<FIT_, ORD_>), dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,     \
+#define ECAL_DET_FIRST(FIT_, MODE_)                                                                                                  \
+    hipLaunchKernelGGL((extract_kernel<FIT_, MODE_>), dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,    \
                        d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,              \
-                       second ? list : nullptr, cnt, d_order)
-#define ECAL_DET_SECOND(FIT_, ORD_)                                                                                                  \
-    hipLaunchKernelGGL((extract_list_kernel<FIT_, ORD_>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,     \
+                       second ? list : nullptr, cnt, d_order, d_tie_list, d_tie_count)
+#define ECAL_DET_FIRST_LIST(FIT_, MODE_, LIST_, COUNT_)                                                                              \
+    hipLaunchKernelGGL((extract_first_list_kernel<FIT_, MODE_>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off,         \
+                       d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, \
+                       so, no, second ? list : nullptr, cnt, LIST_, COUNT_, d_order)
+#define ECAL_DET_SECOND(FIT_, MODE_)                                                                                                 \
+    hipLaunchKernelGGL((extract_list_kernel<FIT_, MODE_>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,    \
                        d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,    \
-                       (const uint32_t *) list, (const uint32_t *) cnt, d_order)
-    if (fused && !prm.fit_circle && !d_order) {
+                       (const uint32_t *) list, (const uint32_t *) cnt, d_order, d_tie_list, d_tie_count)
+    const bool fit = prm.fit_circle != 0;
+    if (fused && !fit) {
         const uint32_t *dcnt = (const uint32_t *) ctx->fused_def.ptr, *dlist = dcnt + 4;
-        hipLaunchKernelGGL((extract_first_list_kernel<false, false>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off,
-                           d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks,
-                           so, no, second ? list : nullptr, cnt, dlist, dcnt, (const int32_t *) nullptr);
-    } else if (prm.fit_circle) {
-        if (d_order) ECAL_DET_FIRST(true, true); else ECAL_DET_FIRST(true, false);
+        ECAL_DET_FIRST_LIST(false, 0, dlist, dcnt);
+    } else if (mode == 1 && d_in_list) {
+        if (fit) ECAL_DET_FIRST_LIST(true, 1, d_in_list, d_in_count); else ECAL_DET_FIRST_LIST(false, 1, d_in_list, d_in_count);
+    } else if (mode == 1) {
+        if (fit) ECAL_DET_FIRST(true, 1); else ECAL_DET_FIRST(false, 1);
+    } else if (mode == 2) {
+        if (fit) ECAL_DET_FIRST(true, 2); else ECAL_DET_FIRST(false, 2);
     } else {
-        if (d_order) ECAL_DET_FIRST(false, true); else ECAL_DET_FIRST(false, false);
+        if (fit) ECAL_DET_FIRST(true, 0); else ECAL_DET_FIRST(false, 0);
     }
     if (second) {
-        if (prm.fit_circle) {
-            if (d_order) ECAL_DET_SECOND(true, true); else ECAL_DET_SECOND(true, false);
+        if (mode == 1) {
+            if (fit) ECAL_DET_SECOND(true, 1); else ECAL_DET_SECOND(false, 1);
+        } else if (mode == 2) {
+            if (fit) ECAL_DET_SECOND(true, 2); else ECAL_DET_SECOND(false, 2);
         } else {
-            if (d_order) ECAL_DET_SECOND(false, true); else ECAL_DET_SECOND(false, false);
+            if (fit) ECAL_DET_SECOND(true, 0); else ECAL_DET_SECOND(false, 0);
         }
     }
 #undef ECAL_DET_FIRST
+#undef ECAL_DET_FIRST_LIST
 #undef ECAL_DET_SECOND
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
@@ -211,7 +229,8 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
                                       int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
                                       int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
-                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, nullptr, stream);
+                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 0, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, stream);
 }
 
 extern "C" int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
@@ -225,5 +244,40 @@ extern "C" int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy,
         return ECAL_ERR_INVALID;
     }
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
-                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, d_cluster_order, stream);
+                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, d_cluster_order, nullptr, nullptr,
+                         nullptr, nullptr, stream);
+}
+
+// The exact extraction in one call: the plain pass lists the windows in which some kept cluster's median is tied in norm (a third of
+// them on the benchmark stream), ecal_cluster_order_dev works out the reference's member order for the tied clusters of those
+// windows only, and the listed windows are extracted again with it.
+extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                           uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
+                                           uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list,
+                                           const uint32_t *d_win_count, void *stream);
+extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                            const int32_t *d_labels, const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps,
+                                            uint32_t cluster_min, uint32_t need_clusters, double radius_threshold, int fit_circle,
+                                            uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
+                                            int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (S == 0) return ECAL_OK;
+    int rc;
+    if ((rc = ecal_ensure(ctx, ctx->tie_list, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->tie_order, ((size_t) n_points + 16) * sizeof(int32_t) + 2 * (size_t) S * sizeof(uint32_t)))) return rc;
+    uint32_t *tcnt = (uint32_t *) ctx->tie_list.ptr, *tlist = tcnt + 4;
+    int32_t *order = (int32_t *) ctx->tie_order.ptr;
+    uint32_t *ostatus = (uint32_t *) (order + (size_t) n_points + 16);
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(tcnt, 0, sizeof(uint32_t), (hipStream_t) stream));
+    if ((rc = extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
+                            fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 2, nullptr, nullptr, nullptr, tlist,
+                            tcnt, stream)))
+        return rc;
+    if ((rc = ecal_cluster_order_list_dev(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, eps, d_labels, d_n_clusters, order, ostatus, 1, tlist, tcnt,
+                                          stream)))
+        return rc;
+    return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
+                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, order, tlist, tcnt, nullptr, nullptr,
+                         stream);
 }

@@ -296,10 +296,13 @@ __device__ __forceinline__ uint32_t ref_nth_element(const ST &st, uint32_t o, ui
 
 // ORD: ord0 / ord1 = the points' positions inside the reference's Clusters[label] (ecal_cluster_order_dev), per polarity:
 // the representative of a cluster whose median rank has an equal-norm rival is then the reference's own pick.
-template <bool FIT, bool ORD, typename ST>
+// TDET (without ORD): the window is appended to tie_list when some kept cluster's median is tied — the representatives stay
+// the smaller-pid ones; a later pass over that list (ORD) replaces them (ecal_extract_batch_exact_dev).
+template <bool FIT, bool ORD, bool TDET, typename ST>
 __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&base)[2], const uint32_t (&kb)[2],
                                                const uint32_t (&n_pol)[2], const int32_t *lab0, const int32_t *lab1,
-                                               const int32_t *ord0, const int32_t *ord1,
+                                               const int32_t *ord0, const int32_t *ord1, uint32_t *tie_list, uint32_t *tie_count,
+                                               uint32_t tie_token,
                                                const uint32_t (&nc_pol)[2], const DetectParams &prm, uint32_t *csize,
                                                typename ST::CIdx *newid, typename ST::CIdx *coff,
                                                unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
@@ -393,7 +396,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 const uint32_t wj = st.members[first + t];
                 rank += (wj < wi) ? 1u : 0u;
                 at += ((wj & ST::IDX_MASK) < i) ? 1u : 0u;
-                if constexpr (ORD) eq += ((wj >> ST::IDXB) == (wi >> ST::IDXB)) ? 1u : 0u;
+                if constexpr (ORD || TDET) eq += ((wj >> ST::IDXB) == (wi >> ST::IDXB)) ? 1u : 0u;
             }
         } else {
             const auto ni = st.key(o + i);
@@ -402,13 +405,31 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 const auto nj = st.key(o + j);
                 rank += (nj < ni || (nj == ni && j < i)) ? 1u : 0u;
                 at += (j < i) ? 1u : 0u;
-                if constexpr (ORD) eq += (nj == ni) ? 1u : 0u;
+                if constexpr (ORD || TDET) eq += (nj == ni) ? 1u : 0u;
             }
         }
-        if (rank == m / 2) st.rep[kb[pol] + kl] = (ORD && eq > 1u) ? (i | ST::REP_TIE) : i;
+        if (rank == m / 2) st.rep[kb[pol] + kl] = ((ORD || TDET) && eq > 1u) ? (i | ST::REP_TIE) : i;
         st.sorted[first + at] = i;
     }
     __syncthreads();
+    if constexpr (TDET && !ORD) {
+        bool mine = false;
+        for (int pol = 0; pol < 2; pol++)
+            for (uint32_t k = tid; k < nk[pol]; k += DET_T) {
+                const uint32_t rv = st.rep[kb[pol] + k];
+                if (rv & ST::REP_TIE) {
+                    st.rep[kb[pol] + k] = rv & ~ST::REP_TIE;
+                    mine = true;
+                }
+            }
+        if (mine) nk_sh[0] |= 0x80000000u;   // (nk[] was read into registers above; every writer stores the same bit)
+        __syncthreads();
+        if (tid == 0 && (nk_sh[0] & 0x80000000u)) {
+            nk_sh[0] &= 0x7FFFFFFFu;
+            if (tie_list) tie_list[atomicAdd(tie_count, 1u)] = tie_token;
+        }
+        __syncthreads();
+    }
     if constexpr (ORD) {
         // the flagged clusters, a thread each: members into the reference's order (members[] is free from here on), the
         // library's nth_element on them.  Without a usable order (segment not taken by ecal_cluster_order_dev) the smaller
@@ -728,7 +749,7 @@ struct DetLdsLayoutT {
 // fit the second pass's (DET_LDS_PTS2 points, DET_LDS_MAXC2 clusters) to the to-do list instead of taking the global path.
 // KNOWN: offsets, counts and cluster counts of the window's two segments are handed in (the fused pass, ecal_fused.hip: the
 // workgroup wrote them itself a moment ago; a scalar load might find a stale line in the constant cache).
-template <bool FIT, uint32_t PTS, uint32_t MAXC, bool FIRST, bool KNOWN = false, bool ORD = false>
+template <bool FIT, uint32_t PTS, uint32_t MAXC, bool FIRST, bool KNOWN = false, bool ORD = false, bool TDET = false>
 __device__ __forceinline__ void extract_one(
     unsigned char *smem, unsigned long long *red, uint32_t *nk_sh, const uint32_t s, const double *__restrict__ xy,
     const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt, const int32_t *__restrict__ labels,
@@ -736,7 +757,8 @@ __device__ __forceinline__ void extract_one(
     uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr, int32_t *__restrict__ kept_labels,
     uint32_t *__restrict__ rep, uint32_t *__restrict__ members, uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize,
     uint32_t *__restrict__ sorted, double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
-    const uint32_t *known = nullptr, const int32_t *__restrict__ order = nullptr) {
+    const uint32_t *known = nullptr, const int32_t *__restrict__ order = nullptr, uint32_t *tie_list = nullptr,
+    uint32_t *tie_count = nullptr) {
     using LL = DetLdsLayoutT<PTS, MAXC>;
     // csize: members per DBSCAN cluster, later a scatter cursor; newid: renumbered id of a kept cluster;
     // coff: first member slot of a kept cluster.  Sized for the global path; the LDS path uses the first
@@ -827,8 +849,8 @@ __device__ __forceinline__ void extract_one(
         st.small = small_px;
         const uint32_t base[2] = {0u, n_pol[0]};
         const uint32_t kb[2] = {0u, MAXC};  // per-cluster arrays: one block of MAXC per polarity
-        extract_window<FIT, ORD>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
-                                 order ? order + o_pol[1] : nullptr, nc_pol, prm, csize,
+        extract_window<FIT, ORD, TDET>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
+                                       order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, nc_pol, prm, csize,
                        reinterpret_cast<uint16_t *>(smem + LL::newid_off), reinterpret_cast<uint16_t *>(smem + LL::coff_off), red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
         __syncthreads();
@@ -858,8 +880,8 @@ __device__ __forceinline__ void extract_one(
         st.kept = kept_labels + w0;
         st.norms = norms + w0;
         const uint32_t base[2] = {o_pol[0] - w0, o_pol[1] - w0};
-        extract_window<FIT, ORD>(st, base, base, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
-                                 order ? order + o_pol[1] : nullptr, nc_pol, prm, csize, csize + DET_MAXC,
+        extract_window<FIT, ORD, TDET>(st, base, base, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
+                                       order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, nc_pol, prm, csize, csize + DET_MAXC,
                        csize + 2 * DET_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
     }

@@ -91,21 +91,13 @@ class DetectPipeline:
                            max_seg_points, eps, minpts, self.labels.data_ptr(), self.n_clusters.data_ptr(), st)
         if detect and exact_ties:
             # the reference's own representative where a cluster's median rank is tied in norm: the members' order inside
-            # Clusters[c] (ecal_cluster_order_dev) + libstdc++'s nth_element on it (ecal_extract_batch_ordered_dev)
+            # Clusters[c] + libstdc++'s nth_element on it, for the windows that have such a cluster (ecal_extract_batch_exact_dev)
             if not hasattr(self, "det"):
                 self.set_detect_params()
-            if getattr(self, "_order_cap", 0) < slots or getattr(self, "_ostat_cap", 0) < 2 * S:
-                self.cluster_order = torch.empty(slots, dtype=torch.int32, device=self.dev)
-                self.order_status = torch.empty(2 * S, dtype=torch.int32, device=self.dev)
-                self._order_cap, self._ostat_cap = slots, 2 * S
-            c.cluster_order_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, eps, self.labels.data_ptr(),
-                                self.n_clusters.data_ptr(), self.cluster_order.data_ptr(), self.order_status.data_ptr(), st,
-                                only_tied_medians=True)
-            c.extract_batch_ordered_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.labels.data_ptr(),
-                                        self.n_clusters.data_ptr(), self.cluster_order.data_ptr(), S, slots, self.det[0], self.det[1],
-                                        self.det[2], self.win_info.data_ptr(), self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(),
-                                        self.kept_labels.data_ptr(), self.rep.data_ptr(), st, fit_circle=self.det[3],
-                                        knn_num=self.det[4])
+            c.extract_batch_exact_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.labels.data_ptr(),
+                                      self.n_clusters.data_ptr(), S, slots, eps, self.det[0], self.det[1], self.det[2],
+                                      self.win_info.data_ptr(), self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(),
+                                      self.kept_labels.data_ptr(), self.rep.data_ptr(), st, fit_circle=self.det[3], knn_num=self.det[4])
         elif detect:
             if not hasattr(self, "det"):
                 self.set_detect_params()

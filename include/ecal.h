@@ -209,6 +209,21 @@ int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint
                                    uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep,
                                    void *stream);
 
+/* ecal_extract_batch_exact_dev: the exact extraction in one call (eps = the DBSCAN radius the labels were made with): the plain
+ * pass lists the windows in which some kept cluster's median is tied in norm (about a third on the benchmark stream),
+ * ecal_cluster_order_list_dev works out the reference's member order for the tied clusters of those windows only, and the
+ * listed windows are extracted again with it.  Results = ecal_extract_batch_ordered_dev's = the reference's own. */
+int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                 const int32_t *d_labels, const uint32_t *d_n_clusters, uint32_t S /*windows*/, uint32_t n_points,
+                                 double eps, uint32_t cluster_min, uint32_t need_clusters, double radius_threshold, int fit_circle,
+                                 uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
+                                 int32_t *d_kept_labels, uint32_t *d_rep, void *stream);
+/* ecal_cluster_order_dev restricted to the segments 2 w, 2 w + 1 of the windows w = d_win_list[0 .. *d_win_count) (device memory) */
+int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
+                                double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
+                                uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
+                                void *stream);
+
 /* ---- host-buffer conveniences (what the C++ shims in eventcalib_amd/csrc/host/ call) ----------
  * ecal_stream: the event stream uploaded once and kept in HBM — the counterpart of the reference's
  *   EventContainer (event/include/opengv2/event/EventContainer.hpp:25-30), filled once by the driver

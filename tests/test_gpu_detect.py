@@ -185,7 +185,6 @@ def test_exact_ties_reference_representatives(env, rate, params):
     pipe.set_detect_params(*params)
     pipe.run(buf.cuda(), exact_ties=True)
     torch.cuda.synchronize()
-    assert int((pipe.order_status[:2 * len(t0)] != 0).sum()) == 0
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, *params, exact_ties=True)
     assert tied >= 2 and exact + tied >= 0.7 * len(t0), (exact, tied, len(t0))
 
