@@ -15,7 +15,8 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_sort_events_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
     "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev",
-    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
+    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_set_median_ties",
+    "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
     "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_rectify_batch_dev", "ecal_rectify_batch",
@@ -215,6 +216,14 @@ class Context:
 
     # ---- ingest + slicing (device buffers, raw pointers) ----
     ORDER_REFERENCE, ORDER_FIRST_OCCURRENCE = 0, 1
+
+    TIES_REFERENCE, TIES_SMALLER_PID = 0, 1
+
+    def set_median_ties(self, mode):
+        """What the composite entry points do at tied medians: "reference" (default) or "smaller_pid"."""
+        code = {"reference": 0, "smaller_pid": 1, 0: 0, 1: 1}[mode]
+        self._L.ecal_set_median_ties.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._check(self._L.ecal_set_median_ties(self._h, code))
 
     def set_point_order(self, order):
         """Element order of the pixel sets: "reference" (EventFrame.cpp:34-35 on libstdc++; default) or "first"."""

@@ -62,6 +62,7 @@ extern "C" int ecal_init(int device, ecal_ctx **out) {
         delete ctx;
         return ECAL_ERR_HIP;
     }
+    if (const char *e = getenv("ECAL_MEDIAN_TIES")) ctx->median_ties = atoi(e) ? ECAL_TIES_SMALLER_PID : ECAL_TIES_REFERENCE;   // debug switch
     *out = ctx;
     return ECAL_OK;
 }

@@ -32,6 +32,7 @@ struct ecal_ctx {
     bool bucket_tab_built = false;
     ecal_devbuf sl_order, sl_order_big;  // reference element order: scratch of the general slicing tiers (slice_order.hpp)
     int point_order = ECAL_ORDER_REFERENCE;  // ecal_set_point_order
+    int median_ties = ECAL_TIES_REFERENCE;   // ecal_set_median_ties: what the composite entry points do at tied medians
     ecal_devbuf det_members, det_koff, det_ksize, det_sorted, det_norms;  // detection stage scratch
     ecal_devbuf det_todo;  // [4 + S] u32: count, then the windows the first extraction pass left to the second
     ecal_devbuf tie_list, tie_order;  // ecal_extract_batch_exact_dev: windows with a tied median, their members' order
@@ -80,6 +81,11 @@ struct ecal_ctx {
 
 // all-reduce through the context's communicator (user = the ecal_ctx): ecal_allreduce_fn for the solver / calibration
 int ecal_comm_allreduce_hook(void *user, double *d_buf, size_t n_doubles, void *stream);
+// extraction as the context's ecal_set_median_ties setting wants it (ecal_detect.hip): the exact form needs the DBSCAN radius
+int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
+                         const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min,
+                         uint32_t need_clusters, double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,
+                         uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream);
 // reference element order: the per-pixel bucket table of the hot-path slicer, built on first use (ecal_events.hip)
 int ecal_ensure_bucket_table(ecal_ctx *ctx, hipStream_t st);
 // ensure a scratch buffer of at least `bytes` (contents are NOT preserved)

@@ -281,3 +281,23 @@ extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, c
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, order, tlist, tcnt, nullptr, nullptr,
                          stream);
 }
+
+int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
+                         const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min,
+                         uint32_t need_clusters, double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,
+                         uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
+    if (ctx && ctx->median_ties == ECAL_TIES_REFERENCE)
+        return ecal_extract_batch_exact_dev(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min,
+                                            need_clusters, radius_threshold, fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr,
+                                            d_kept_labels, d_rep, stream);
+    return ecal_extract_batch_dev(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters,
+                                  radius_threshold, fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, stream);
+}
+
+extern "C" int ecal_set_median_ties(ecal_ctx *ctx, int mode) {
+    if (!ctx || (mode != ECAL_TIES_REFERENCE && mode != ECAL_TIES_SMALLER_PID)) return ECAL_ERR_INVALID;
+    ctx->median_ties = mode;
+    return ECAL_OK;
+}
+
+extern "C" int ecal_get_median_ties(const ecal_ctx *ctx) { return ctx ? ctx->median_ties : ECAL_ERR_INVALID; }

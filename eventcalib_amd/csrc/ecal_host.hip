@@ -127,8 +127,8 @@ extern "C" int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const dou
                                     cap_points, 0, prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr,
                                     (uint32_t *) B[10].ptr, st)))
         return rc;
-    if ((rc = ecal_extract_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
-                                     (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, S, cap_points, prm->cluster_min_sample,
+    if ((rc = ecal_extract_for_ctx(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
+                                     (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, S, cap_points, prm->dbscan_eps, prm->cluster_min_sample,
                                      prm->need_clusters, prm->circle_radius_threshold, prm->fit_circle, prm->knn_num,
                                      (uint32_t *) B[13].ptr,
                                      (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr,
@@ -284,8 +284,8 @@ extern "C" int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t
     if ((rc = ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * S, cap_points, 0,
                                     prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, st)))
         return rc;
-    if ((rc = ecal_extract_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
-                                     (uint32_t *) B[10].ptr, S, cap_points, prm->cluster_min_sample, prm->need_clusters,
+    if ((rc = ecal_extract_for_ctx(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
+                                     (uint32_t *) B[10].ptr, S, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
                                      prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
                                      (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st)))
         return rc;
@@ -416,8 +416,8 @@ extern "C" int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events, ui
                                         (uint32_t) max_ev, 0, prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr,
                                         (uint32_t *) B[10].ptr, st)))
             return rc;
-        if ((rc = ecal_extract_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
-                                         (uint32_t *) B[10].ptr, nw, (uint32_t) max_ev, prm->cluster_min_sample, prm->need_clusters,
+        if ((rc = ecal_extract_for_ctx(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
+                                         (uint32_t *) B[10].ptr, nw, (uint32_t) max_ev, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
                                          prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
                                          (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr,
                                          st)))

@@ -58,7 +58,7 @@ class DetectPipeline:
         self.det = (int(cluster_min), int(need_clusters), float(radius_threshold), bool(fit_circle), int(knn_num))
 
     def run(self, events, eps=4.0, minpts=2, slots=None, max_win_events=0, max_seg_points=0, detect=True, slice_only=False,
-            fused=False, exact_ties=False):
+            fused=False, exact_ties=True):
         """events: uint8 CUDA tensor holding n*25 bytes.  Enqueues bounds -> slice -> DBSCAN -> candidate
         extraction on the current torch stream; results stay in HBM (self.xy / seg_off / seg_cnt /
         labels / n_clusters / win_info / cand_pair / cand_xyr / kept_labels / rep)."""

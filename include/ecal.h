@@ -209,6 +209,14 @@ int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint
                                    uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep,
                                    void *stream);
 
+/* What the composite entry points (ecal_detect_batch, ecal_detect_pass, ecal_detect_keyframes, ecal_detect_stream_tiled) do where
+ * a kept cluster's median rank has an equal-norm rival: ECAL_TIES_REFERENCE (default) = the reference's own pick
+ * (ecal_extract_batch_exact_dev), ECAL_TIES_SMALLER_PID = the cheaper rule of ecal_extract_batch_dev. */
+#define ECAL_TIES_REFERENCE 0
+#define ECAL_TIES_SMALLER_PID 1
+int ecal_set_median_ties(ecal_ctx *ctx, int mode);
+int ecal_get_median_ties(const ecal_ctx *ctx);
+
 /* ecal_extract_batch_exact_dev: the exact extraction in one call (eps = the DBSCAN radius the labels were made with): the plain
  * pass lists the windows in which some kept cluster's median is tied in norm (about a third on the benchmark stream),
  * ecal_cluster_order_list_dev works out the reference's member order for the tied clusters of those windows only, and the

@@ -28,7 +28,7 @@ def test_radius_threshold_kat(env):
                                                                                                      False, 3.0, 1.0)
 
 
-def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=False, knn_num=3, exact_ties=False):
+def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=False, knn_num=3, exact_ties=True):
     S = len(t0)
     info = pipe.win_info[:S].cpu().numpy().astype(np.int64)
     seg_off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
@@ -53,7 +53,7 @@ def _check_windows(pipe, torch, rec, t0, t1, cluster_min, need, thr, fit_circle=
             assert info[s, 0] == 0
             continue
         if ref["tie"] and exact_ties:
-            tied += 1        # run(exact_ties=True): the reference's own pick — nothing is handed to the oracle, see below
+            tied += 1        # the default (exact ties): the reference's own pick — nothing is handed to the oracle, see below
         elif ref["tie"]:
             # Some cluster's median has an equal-norm rival: which of the two the reference's nth_element returns depends
             # on its BFS member order, the build takes the smaller pid.  That choice is the ONLY freedom:
@@ -210,3 +210,18 @@ def test_exact_ties_in_the_global_scratch_path_and_with_fit_circle(env):
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, fit_circle=True, knn_num=3, exact_ties=True)
     assert tied >= 1
     pipe.set_detect_params(5, 36, THR)
+
+
+def test_smaller_pid_rule_of_the_plain_primitive(env):
+    """run(exact_ties=False) = ecal_extract_batch_dev alone: at a tied median the smaller pid — any other representative, and with
+    that ONE choice handed to the oracle everything downstream, must still be identical."""
+    ctx, pipe, torch = env
+    buf = SS.make_stream(240000, rate=2.0e6, device="cpu", seed=43)
+    t, _, _ = SS.unpack_records(buf)
+    t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR)
+    pipe.run(buf.cuda(), exact_ties=False)
+    torch.cuda.synchronize()
+    exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, exact_ties=False)
+    assert tied >= 2 and exact + tied >= 0.7 * len(t0)

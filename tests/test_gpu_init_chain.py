@@ -34,12 +34,14 @@ def result():
 def test_init_calibration_from_detected_keyframes(result):
     ini = result[False]["init"]
     assert result[False]["keyframes"] > 300 and ini["views"] == 200
-    # the init stage works on midpoint circles (rms ~3 px): its focal length lands within 0.2 .. 0.8 % of the truth depending
-    # on which windows become keyframes (measured over both point orders and two hole tolerances); the spline refinement
-    # below is what is held to 0.2 %
-    assert abs(ini["intr"][0] / SS.FX - 1) < 1e-2 and ini["intr"][0] == ini["intr"][1]        # fixed aspect ratio
+    # the init stage works on midpoint circles (rms ~3 px): its focal length lands within 0.2 .. 1.7 % of the truth and k1 within
+    # 0.02 .. 0.14 depending on which windows become keyframes and on the representatives of the clusters whose median is tied
+    # in norm — the two members of equal norm can lie pixels apart, and the reference's pick (the default since round 2) moves a
+    # circle centre by up to 4 px where the smaller-pid rule had another one (measured over both point orders, two hole
+    # tolerances and both tie rules); the spline refinement below is what is held to 0.2 %
+    assert abs(ini["intr"][0] / SS.FX - 1) < 2e-2 and ini["intr"][0] == ini["intr"][1]        # fixed aspect ratio
     assert (ini["intr"][2], ini["intr"][3]) == ((346 - 1) / 2, (260 - 1) / 2)                  # fixed principal point
-    assert abs(ini["intr"][4] - SS.K1) < 0.05 and ini["rms"] < 5.0                             # midpoint circles: ~3 px
+    assert abs(ini["intr"][4] - SS.K1) < 0.2 and ini["rms"] < 5.0                              # midpoint circles: ~3 px
     assert ini["accepted"] > 200 and ini["discarded_by_rectify"] < 20
 
 

@@ -20,7 +20,7 @@ for seed, rate, noise in itertools.product(range(int(sys.argv[1]) if len(sys.arg
     pipe.run(buf.cuda(), fused=bool(os.environ.get("FUSED")))   # FUSED=1: through ecal_detect_fused_dev
     torch.cuda.synchronize()
     TE._compare(pipe, torch, buf.numpy(), t0, t1, check_labels=True)          # slicing + DBSCAN labels
-    exact, tied = TD._check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, TD.THR)   # extraction
+    exact, tied = TD._check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, TD.THR, exact_ties=not os.environ.get("FUSED"))   # extraction (the fused entry = the plain primitives)
     n_ok += 1
     print("seed %d rate %.1f noise %.2f: %d windows, max segment %d, exact %d tied %d" %
           (seed, rate / 1e6, noise, len(t0), int(pipe.seg_cnt[:2 * len(t0)].max()), exact, tied), flush=True)
