@@ -152,11 +152,13 @@ def main():
         c.dbscan_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * S, n, max_seg,
                            eps, minpts, pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), st.cuda_stream)
         ev[k][3].record(st)
-        c.extract_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
-                            pipe.n_clusters.data_ptr(), S, n, pipe.det[0], pipe.det[1], pipe.det[2],
-                            pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
-                            pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream, fit_circle=pipe.det[3],
-                            knn_num=pipe.det[4])
+        # the exact extraction (the library's default): plain pass + the reference's member order for the clusters whose median
+        # is tied in norm + re-extraction of their windows
+        c.extract_batch_exact_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
+                                  pipe.n_clusters.data_ptr(), S, n, eps, pipe.det[0], pipe.det[1], pipe.det[2],
+                                  pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
+                                  pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream, fit_circle=pipe.det[3],
+                                  knn_num=pipe.det[4])
         ev[k][4].record(st)
     barrier()
     elapsed = time.perf_counter() - t_begin
@@ -173,7 +175,7 @@ def main():
 
     # the same pass as ONE call / one kernel per window (ecal_detect_fused_dev): measured beside the stage-by-stage form above,
     # outside the timed region; identical results (tests/test_gpu_fused.py).  The faster form is not assumed: both are reported.
-    fused_ms = None
+    fused_ms = plain_extract_ms = None
     if rank == 0 and args.steps > 0:
         def fused_step():
             c.detect_fused_dev(events.data_ptr(), n_events, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(),
@@ -191,6 +193,19 @@ def main():
         fe[1].record(st)
         torch.cuda.synchronize(dev)
         fused_ms = fe[0].elapsed_time(fe[1]) / args.steps
+        # the plain extraction (smaller pid at tied medians: ecal_extract_batch_dev alone), for comparison
+        def plain_extract():
+            c.extract_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
+                                pipe.n_clusters.data_ptr(), S, n_events, pipe.det[0], pipe.det[1], pipe.det[2], pipe.win_info.data_ptr(),
+                                pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(), pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(),
+                                st.cuda_stream, fit_circle=pipe.det[3], knn_num=pipe.det[4])
+        plain_extract()
+        fe[0].record(st)
+        for _ in range(args.steps):
+            plain_extract()
+        fe[1].record(st)
+        torch.cuda.synchronize(dev)
+        plain_extract_ms = fe[0].elapsed_time(fe[1]) / args.steps
 
     total_events = n_events * world * args.steps
     value = total_events / elapsed / 1e6
@@ -221,7 +236,7 @@ def main():
     }
     if rank == 0:
         dom = int(np.argmax(stage_ms))
-        names = ["window_bounds_kernel", "slice_hash_ref_kernel", "dbscan_pixel_kernel", "extract_kernel"]   # reference point order (the default)
+        names = ["window_bounds_kernel", "slice_hash_ref_kernel", "dbscan_pixel_kernel", "extract_kernel (+ cluster_order_kernel)"]   # reference point order (the default)
         achieved = ALGO_BYTES_PER_EVENT * n_events / (stage_ms[dom] * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
         # committed profile (tools/pmc_traffic.py over two rocprofv3 --pmc passes of this same command) is
@@ -243,11 +258,15 @@ def main():
             "stage_ms": {"window_bounds": round(float(stage_ms[0]), 4), "slice": round(float(stage_ms[1]), 4),
                          "dbscan": round(float(stage_ms[2]), 4), "extract": round(float(stage_ms[3]), 4)},
         }
+        if plain_extract_ms is not None:
+            out["median_ties"] = {"timed": "reference (std::nth_element over the reference's cluster member order where a median is tied)",
+                                  "extract_ms_exact": round(float(stage_ms[3]), 4), "extract_ms_smaller_pid_rule": round(float(plain_extract_ms), 4),
+                                  "pass_ms_smaller_pid_rule": round(float(stage_ms[0] + stage_ms[1] + stage_ms[2] + plain_extract_ms), 4)}
         if fused_ms is not None:
             out["fused_pass"] = {"ms_slice_dbscan_extract": round(float(fused_ms), 4),
-                                 "staged_ms_slice_dbscan_extract": round(float(stage_ms[1] + stage_ms[2] + stage_ms[3]), 4),
+                                 "staged_ms_slice_dbscan_extract": round(float(stage_ms[1] + stage_ms[2] + plain_extract_ms), 4),
                                  "note": "ecal_detect_fused_dev: one kernel carries a window through slicing, both DBSCAN runs and "
-                                         "extraction; same results; not the timed path (the stage-by-stage form is faster, profiles/r02_notes.md)"}
+                                         "extraction (plain tie rule); same results as the three plain stage calls; not the timed path (the stage-by-stage form is faster, profiles/r02_notes.md)"}
         if args.cpu_sample > 0 and world == 1:
             import oracle_lib as O
             m = min(args.cpu_sample, n_events)

@@ -24,24 +24,43 @@
 namespace ecal {
 
 constexpr int BO_T = 256;
-constexpr uint32_t BO_CAP = 2048;        // points per segment
-constexpr int BO_PPT = (int) (BO_CAP / BO_T);
+constexpr uint32_t BO_CAP = 2048;        // points per segment (second launch; the first takes <= 1024 with half the LDS: 4 instead of
+constexpr uint32_t BO_CAP1 = 1024;       // 2 workgroups per CU)
 constexpr uint32_t BO_MAXN = 64;         // hits per range query kept (a disc of radius 4 holds 48 other pixels)
+constexpr uint32_t BO_POOL = 48;         // range-query lists kept in LDS (the members of the tied clusters: a few dozen); the rest
+                                         // go to global scratch
 constexpr uint32_t BO_STACK = 96;        // pending far subtrees of one traversal
 constexpr uint32_t BO_NONE = 0xFFFFFFFFu;
 
+template <uint32_t CAP>
 struct BoLayout {
     static constexpr size_t px_off = 0;                                   // f64[CAP]
-    static constexpr size_t py_off = px_off + 8 * BO_CAP;                 // f64[CAP]
-    static constexpr size_t child_off = py_off + 8 * BO_CAP;              // u32[2 CAP]: children (left, right) of node i
-    static constexpr size_t lab_off = child_off + 8 * BO_CAP;             // i32[CAP]
-    static constexpr size_t queue_off = lab_off + 4 * BO_CAP;             // u16[CAP]: the clusters' queues, back to back
-    static constexpr size_t qbase_off = queue_off + 2 * BO_CAP;           // u32[CAP + 1]: members per cluster, then offsets
-    static constexpr size_t inq_off = qbase_off + 4 * (BO_CAP + 1) + 12;  // u32[CAP / 32]: point is (or was) in its cluster's queue
-    static constexpr size_t seed_off = inq_off + 4 * (BO_CAP / 32);       // u32[CAP]: smallest pid per cluster
-    static constexpr size_t red_off = seed_off + 4 * BO_CAP;              // u32[16]
+    static constexpr size_t py_off = px_off + 8 * CAP;                    // f64[CAP]
+    static constexpr size_t child_off = py_off + 8 * CAP;                 // u32[2 CAP]: children (left, right) of node i
+    static constexpr size_t lab_off = child_off + 8 * CAP;                // i32[CAP]
+    static constexpr size_t queue_off = lab_off + 4 * CAP;                // u16[CAP]: the clusters' queues, back to back
+    static constexpr size_t qbase_off = queue_off + 2 * CAP;              // u32[CAP + 1]: members per cluster, then offsets
+    static constexpr size_t inq_off = qbase_off + 4 * (CAP + 1) + 12;     // u32[CAP / 32]: point is (or was) in its cluster's queue
+    static constexpr size_t seed_off = inq_off + 4 * (CAP / 32);          // u32[CAP]: smallest pid per cluster
+    static constexpr size_t slot_off = seed_off + 4 * CAP;                // u16[CAP]: LDS list slot of a point's range query, 0xFFFF: global
+    static constexpr size_t pool_off = slot_off + 2 * CAP;                // u16[BO_POOL][BO_MAXN] + u16[BO_POOL] counts
+    static constexpr size_t red_off = pool_off + 2 * BO_POOL * (BO_MAXN + 1);   // u32[16]
     static constexpr size_t bytes = red_off + 64;
 };
+
+#ifdef ECAL_PHASE_PROF
+static __device__ unsigned long long g_bo_cycles[16];
+#define BO_MARK(i)                                                   \
+    do {                                                             \
+        if (threadIdx.x == 0) {                                      \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+            atomicAdd(&g_bo_cycles[i], now__ - bo_t__);              \
+            bo_t__ = now__;                                          \
+        }                                                            \
+    } while (0)
+#else
+#define BO_MARK(i)
+#endif
 
 __device__ __forceinline__ bool bo_block_any(bool v, uint32_t *flag, uint32_t &round) {
     // three rotating flag words: the word cleared now is read next in the round after the next barrier
@@ -54,6 +73,8 @@ __device__ __forceinline__ bool bo_block_any(bool v, uint32_t *flag, uint32_t &r
     return any;
 }
 
+// status: 0 taken; 1 not taken at all (see ecal.h); 2 left by the CAP1 launch to the CAP launch (FIRST / !FIRST)
+template <uint32_t CAP, bool FIRST>
 __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
                                                             const uint32_t *__restrict__ seg_cnt, uint32_t S, double eps,
                                                             const int32_t *__restrict__ labels,
@@ -63,15 +84,19 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
                                                             const uint32_t *__restrict__ win_list,
                                                             const uint32_t *__restrict__ win_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *const px = reinterpret_cast<double *>(smem + BoLayout::px_off);
-    double *const py = reinterpret_cast<double *>(smem + BoLayout::py_off);
-    uint32_t *const child = reinterpret_cast<uint32_t *>(smem + BoLayout::child_off);
-    int32_t *const lab = reinterpret_cast<int32_t *>(smem + BoLayout::lab_off);
-    uint16_t *const queue = reinterpret_cast<uint16_t *>(smem + BoLayout::queue_off);
-    uint32_t *const qbase = reinterpret_cast<uint32_t *>(smem + BoLayout::qbase_off);
-    uint32_t *const inq = reinterpret_cast<uint32_t *>(smem + BoLayout::inq_off);
-    uint32_t *const seed = reinterpret_cast<uint32_t *>(smem + BoLayout::seed_off);
-    uint32_t *const red = reinterpret_cast<uint32_t *>(smem + BoLayout::red_off);
+    double *const px = reinterpret_cast<double *>(smem + BoLayout<CAP>::px_off);
+    double *const py = reinterpret_cast<double *>(smem + BoLayout<CAP>::py_off);
+    uint32_t *const child = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::child_off);
+    int32_t *const lab = reinterpret_cast<int32_t *>(smem + BoLayout<CAP>::lab_off);
+    uint16_t *const queue = reinterpret_cast<uint16_t *>(smem + BoLayout<CAP>::queue_off);
+    uint32_t *const qbase = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::qbase_off);
+    uint32_t *const inq = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::inq_off);
+    uint32_t *const seed = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::seed_off);
+    uint32_t *const red = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::red_off);
+    uint16_t *const slotmap = reinterpret_cast<uint16_t *>(smem + BoLayout<CAP>::slot_off);
+    uint16_t *const pool = reinterpret_cast<uint16_t *>(smem + BoLayout<CAP>::pool_off);
+    uint16_t *const pool_cnt = pool + BO_POOL * BO_MAXN;
+    constexpr int BO_PPT = (int) (CAP / BO_T);
     const uint32_t tid = threadIdx.x;
     // this workgroup's slice of the neighbour lists
     uint16_t *const my_lists = lists + (size_t) blockIdx.x * BO_CAP * BO_MAXN;
@@ -83,17 +108,27 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
     for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
         const uint32_t s = win_list ? 2u * win_list[wk >> 1] + (wk & 1u) : wk;
         const uint32_t n = seg_cnt[s], base = seg_off[s], nc = n_clusters[s];
+#ifdef ECAL_PHASE_PROF
+        unsigned long long bo_t__ = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();   // the previous segment's LDS is dead
         if (n == 0) {
             if (tid == 0) status[s] = 0;
             continue;
         }
-        if (n > BO_CAP || nc > BO_CAP) {
-            for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
-            if (tid == 0) status[s] = 1;
+        if constexpr (!FIRST) {
+            if (status[s] != 2u) continue;   // taken (or refused) by the first launch
+        }
+        if (n > CAP || nc > CAP) {
+            if (FIRST && n <= BO_CAP && nc <= BO_CAP) {
+                if (tid == 0) status[s] = 2;   // the second launch
+            } else {
+                for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
+                if (tid == 0) status[s] = 1;
+            }
             continue;
         }
-        if (tid < 4) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure
+        if (tid < 8) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure; [4]: LDS list slots handed out
         for (uint32_t i = tid; i < n; i += BO_T) {
             const double2 p = reinterpret_cast<const double2 *>(xy)[base + i];
             px[i] = p.x;
@@ -106,6 +141,7 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
         for (uint32_t c = tid; c < nc; c += BO_T) seed[c] = BO_NONE;
         for (uint32_t w = tid; w < (n + 31u) / 32u; w += BO_T) inq[w] = 0;
         __syncthreads();
+        BO_MARK(0);
         // members per cluster, the clusters' seeds (= smallest pid), the clusters' member lists (in queue[], for the tie test)
         for (uint32_t i = tid; i < n; i += BO_T) {
             if (lab[i] >= 0) {
@@ -114,7 +150,18 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             }
         }
         __syncthreads();
-        if (tid == 0) {   // offsets of the clusters' queues (a few dozen clusters per segment in practice)
+        if (nc < 64u) {   // offsets of the clusters' queues: one wave scans the (usually few dozen) counts
+            if (tid < 64u) {
+                const uint32_t v = tid <= nc ? qbase[tid] : 0u;
+                uint32_t inc = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d, 64);
+                    if ((int) tid >= d) inc += o;
+                }
+                if (tid <= nc) qbase[tid] = inc;
+            }
+        } else if (tid == 0) {
             uint32_t run = 0;
             for (uint32_t c = 0; c <= nc; c++) {
                 run += qbase[c];
@@ -127,9 +174,36 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
         // member of rank size / 2 in the order (norm, pid) shares its norm with another member.  tie[c] lives in the upper
         // half of seed[]'s word... kept apart: cursor[] = child[] (not yet in use), tie flags = bit 31 of qbase's copy.
         bool seg_has_tie = !only_tied;
-        if (only_tied) {
+        if (only_tied == 2) {
+            // the caller named the clusters: a -3 in `order` on the slot of one of their points (ecal_extract_batch_exact_dev's plain
+            // pass marks the representative of every cluster whose median it found tied)
+            uint32_t *const tie = child + CAP;            // [nc] (the tree is built later)
+            for (uint32_t c = tid; c < nc; c += BO_T) tie[c] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += BO_T)
+                if (lab[i] >= 0 && order[base + i] == -3) tie[lab[i]] = 1;
+            __syncthreads();
+            bool any_tie = false;
+            for (uint32_t c = tid; c < nc; c += BO_T) {
+                if (tie[c]) any_tie = true;
+                else seed[c] = BO_NONE - 1u;
+            }
+            uint32_t rr = 0;
+            seg_has_tie = bo_block_any(any_tie, red, rr);
+            __syncthreads();
+            BO_MARK(1);
+            if (!seg_has_tie) {
+                for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = lab[i] < 0 ? -1 : -2;
+                if (tid == 0) status[s] = 0;
+                BO_MARK(2);
+                continue;
+            }
+            for (uint32_t c = tid; c < nc; c += BO_T) tie[c] = BO_NONE;   // child[] goes back to the tree
+            if (tid < 4) red[tid] = 0;
+            __syncthreads();
+        } else if (only_tied) {
             uint32_t *const cursor = child;               // [nc] scatter cursors (the tree is built later)
-            uint32_t *const tie = child + BO_CAP;         // [nc]
+            uint32_t *const tie = child + CAP;            // [nc]
             for (uint32_t c = tid; c < nc; c += BO_T) {
                 cursor[c] = 0;
                 tie[c] = 0;
@@ -141,13 +215,27 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             for (uint32_t i = tid; i < n; i += BO_T) {
                 if (lab[i] < 0) continue;
                 const uint32_t c = (uint32_t) lab[i], qb = qbase[c], m = qbase[c + 1] - qb;
-                const double ki = __dsqrt_rn(px[i] * px[i] + py[i] * py[i]);   // Vector2d::norm()
+                // the norms' order (Vector2d::norm() = sqrt(x^2 + y^2)): where both squared norms are whole numbers (integer
+                // pixels) they order exactly like their roots — the square root is injective on integers below 2^53 —, and the
+                // two square roots per pair are only taken otherwise
+                const double di = px[i] * px[i] + py[i] * py[i];
+                const bool whole_i = di == floor(di);
+                const double ki = __dsqrt_rn(di);
                 uint32_t rank = 0, eq = 0;
                 for (uint32_t t = 0; t < m; t++) {
                     const uint32_t j = queue[qb + t];
-                    const double kj = __dsqrt_rn(px[j] * px[j] + py[j] * py[j]);
-                    rank += (kj < ki || (kj == ki && j < i)) ? 1u : 0u;
-                    eq += (kj == ki) ? 1u : 0u;
+                    const double dj = px[j] * px[j] + py[j] * py[j];
+                    bool lt, same;
+                    if (whole_i && dj == floor(dj)) {
+                        lt = dj < di;
+                        same = dj == di;
+                    } else {
+                        const double kj = __dsqrt_rn(dj);
+                        lt = kj < ki;
+                        same = kj == ki;
+                    }
+                    rank += (lt || (same && j < i)) ? 1u : 0u;
+                    eq += same ? 1u : 0u;
                 }
                 if (rank == m / 2u && eq > 1u) tie[c] = 1;
             }
@@ -160,9 +248,11 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             uint32_t rr = 0;
             seg_has_tie = bo_block_any(any_tie, red, rr);
             __syncthreads();
+            BO_MARK(1);
             if (!seg_has_tie) {
                 for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = lab[i] < 0 ? -1 : -2;
                 if (tid == 0) status[s] = 0;
+                BO_MARK(2);
                 continue;
             }
             for (uint32_t i = tid; i < n; i += BO_T) {    // child[] goes back to the tree
@@ -173,49 +263,41 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             __syncthreads();
         }
         // ---- 1. the insertion-order kd-tree (root = point 0 splits on x, children alternate: kdtree.cpp:127) ----
-        uint32_t cur[BO_PPT], pend[BO_PPT], dep[BO_PPT];
+        // Sequential insertion puts at every empty child slot the FIRST (smallest pid) of the points whose descent reaches it.
+        // Level by level: in round r every unplaced point stands at a node of depth r and bids (atomicMin of its pid) for the
+        // child slot on its side — a slot of depth r + 1, which nobody can have filled before —; the winner is that node, the
+        // others go on below it.  One barrier a round: the slots read after it (depth r + 1) are not the ones bid for next
+        // (depth r + 2), and the "anybody still unplaced" vote rides on the same barrier (three rotating flag words).
+        uint32_t cur[BO_PPT], dep[BO_PPT];
         bool placed[BO_PPT];
 #pragma unroll
         for (int u = 0; u < BO_PPT; u++) {
             const uint32_t i = tid + u * BO_T;
             cur[u] = 0;
             dep[u] = 0;
-            pend[u] = BO_NONE;
             placed[u] = i == 0 || i >= n;
         }
-        uint32_t round = 0;
-        for (;;) {
-            // a round = one tree level for every unplaced point: look at the child slot on the point's side (everybody reads
-            // before anybody bids: a slot that is empty NOW is decided among the points that stand at it in this round) ...
+        for (uint32_t round = 0;; round++) {
+            uint32_t at[BO_PPT];
             bool active = false;
+            if (tid == 0) red[(round + 1u) % 3u] = 0;
 #pragma unroll
             for (int u = 0; u < BO_PPT; u++) {
                 if (placed[u]) continue;
                 const uint32_t i = tid + u * BO_T, c = cur[u];
                 const bool dy = dep[u] & 1u;
                 const double v = dy ? py[i] : px[i], cv = dy ? py[c] : px[c];
-                const uint32_t at = 2 * c + (v < cv ? 0u : 1u);   // left iff pos[dir] < node->pos[dir] (kdtree.cpp:128-131)
-                const uint32_t w = child[at];
-                if (w == BO_NONE) {
-                    pend[u] = at;
-                } else {
-                    cur[u] = w;
-                    dep[u]++;
-                    pend[u] = BO_NONE;
-                }
+                at[u] = 2 * c + (v < cv ? 0u : 1u);   // left iff pos[dir] < node->pos[dir] (kdtree.cpp:128-131)
+                atomicMin(&child[at[u]], i);
                 active = true;
             }
-            if (!bo_block_any(active, red, round)) break;
-            // ... bid for it with the pid (the smallest wins, as sequential insertion would place it) ...
-#pragma unroll
-            for (int u = 0; u < BO_PPT; u++)
-                if (!placed[u] && pend[u] != BO_NONE) atomicMin(&child[pend[u]], tid + u * BO_T);
+            if (active) red[round % 3u] = 1;
             __syncthreads();
-            // ... and stay there as the new node, or go on below the winner
+            if (red[round % 3u] == 0) break;
 #pragma unroll
             for (int u = 0; u < BO_PPT; u++) {
-                if (placed[u] || pend[u] == BO_NONE) continue;
-                const uint32_t w = child[pend[u]];
+                if (placed[u]) continue;
+                const uint32_t w = child[at[u]];
                 if (w == tid + u * BO_T) {
                     placed[u] = true;
                 } else {
@@ -223,8 +305,9 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
                     dep[u]++;
                 }
             }
-            __syncthreads();   // (the next round's reads come after every resolve)
         }
+        __syncthreads();
+        BO_MARK(3);
         // ---- 2. one range query per core point: find_nearest's visiting order (kdtree.cpp:148-179) ----
         bool fail = false;
 #pragma unroll 1
@@ -232,7 +315,10 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             const uint32_t i = tid + u * BO_T;
             if (i >= n || lab[i] < 0 || seed[lab[i]] == BO_NONE - 1u) continue;
             const double qx = px[i], qy = py[i];
-            uint16_t *out = my_lists + (size_t) i * BO_MAXN;
+            const uint32_t slot = atomicAdd(&red[4], 1u);
+            const bool in_lds = slot < BO_POOL;
+            slotmap[i] = in_lds ? (uint16_t) slot : (uint16_t) 0xFFFFu;
+            uint16_t *out = in_lds ? pool + slot * BO_MAXN : my_lists + (size_t) i * BO_MAXN;
             uint32_t cnt = 0, sp = 0;
             uint32_t stk[BO_STACK];   // node | dir << 31
             uint32_t node = 0, dir = 0;
@@ -262,7 +348,8 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
                 dir = stk[sp] >> 31;
             }
             if (cnt > BO_MAXN || sp > BO_STACK) fail = true;
-            my_cnt[i] = (uint8_t) (cnt > BO_MAXN ? BO_MAXN : cnt);
+            if (in_lds) pool_cnt[slot] = (uint16_t) (cnt > BO_MAXN ? BO_MAXN : cnt);
+            else my_cnt[i] = (uint8_t) (cnt > BO_MAXN ? BO_MAXN : cnt);
         }
         if (fail) red[3] = 1;
         __threadfence_block();
@@ -272,6 +359,7 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             if (tid == 0) status[s] = 1;
             continue;
         }
+        BO_MARK(4);
         // ---- 3. expandCluster's queue, one thread per cluster (dbscan.h:229-265) ----
         for (uint32_t i = tid; i < n; i += BO_T)
             if (lab[i] < 0) order[base + i] = -1;
@@ -286,8 +374,9 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
                 const uint32_t q = queue[qb + head];
                 order[base + q] = (int32_t) head;
                 head++;
-                const uint32_t m = my_cnt[q];
-                const uint16_t *lst = my_lists + (size_t) q * BO_MAXN;
+                const uint32_t sl = slotmap[q];
+                const uint32_t m = sl != 0xFFFFu ? (uint32_t) pool_cnt[sl] : (uint32_t) my_cnt[q];
+                const uint16_t *lst = sl != 0xFFFFu ? pool + sl * BO_MAXN : my_lists + (size_t) q * BO_MAXN;
                 for (uint32_t k = m; k-- > 0;) {   // the result list = hits in REVERSE visiting order (rlist_insert at the head)
                     const uint32_t j = lst[k];
                     if ((uint32_t) lab[j] != c) continue;   // not a core point of this cluster: never expands, never listed
@@ -299,6 +388,8 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             }
         }
         if (tid == 0) status[s] = 0;
+        __syncthreads();
+        BO_MARK(5);
     }
 }
 
@@ -334,18 +425,23 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
-    const uint32_t grid = std::min<uint32_t>(S, 2u * ctx->n_cu);
+    const uint32_t grid1 = std::min<uint32_t>(S, 4u * ctx->n_cu), grid2 = std::min<uint32_t>(S, 2u * ctx->n_cu);
     int rc;
-    if ((rc = ecal_ensure(ctx, ctx->bfs_lists, (size_t) grid * BO_CAP * (BO_MAXN * sizeof(uint16_t) + 1)))) return rc;
+    // global lists: one slice per workgroup of the larger grid (the first launch's workgroups use BO_CAP1 rows of theirs)
+    if ((rc = ecal_ensure(ctx, ctx->bfs_lists, (size_t) grid1 * BO_CAP * (BO_MAXN * sizeof(uint16_t) + 1)))) return rc;
     uint16_t *lists = (uint16_t *) ctx->bfs_lists.ptr;
-    uint8_t *cnt = (uint8_t *) (lists + (size_t) grid * BO_CAP * BO_MAXN);
+    uint8_t *cnt = (uint8_t *) (lists + (size_t) grid1 * BO_CAP * BO_MAXN);
     if (!ctx->bfs_attr_set) {
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout::bytes));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP1, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP1>::bytes));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP>::bytes));
         ctx->bfs_attr_set = true;
     }
-    hipLaunchKernelGGL(cluster_order_kernel, dim3(grid), dim3(BO_T), BoLayout::bytes, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels,
-                       d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
+    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP1, true>), dim3(grid1), dim3(BO_T), BoLayout<BO_CAP1>::bytes, st, d_xy, d_seg_off,
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
+    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP, false>), dim3(grid2), dim3(BO_T), BoLayout<BO_CAP>::bytes, st, d_xy, d_seg_off,
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
@@ -402,3 +498,14 @@ extern "C" int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_
     memcpy(status, ts.data(), (size_t) S * 4);
     return ECAL_OK;
 }
+
+#ifdef ECAL_PHASE_PROF
+extern "C" int ecal_debug_bo_cycles(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_bo_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_bo_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -29,13 +29,13 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
     uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
     double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count, const int32_t *__restrict__ order,
-    uint32_t *__restrict__ tie_list, uint32_t *__restrict__ tie_count) {
+    uint32_t *__restrict__ tie_list, uint32_t *__restrict__ tie_count, int32_t *__restrict__ tie_mark) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
     __shared__ uint32_t nk_sh[4];  // kept clusters per polarity, their members per polarity
     extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, MODE == 1, MODE == 2>(
         smem, red, nk_sh, blockIdx.x, xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
-        members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order, tie_list, tie_count);
+        members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order, tie_list, tie_count, tie_mark);
 }
 
 // the first pass over a list: the windows the fused detection pass (ecal_fused.hip) did not carry through to extraction
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(DET_T) void extract_list_kernel(
     int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
     uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
     double *__restrict__ norms, const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count,
-    const int32_t *__restrict__ order, uint32_t *__restrict__ tie_list, uint32_t *__restrict__ tie_count) {
+    const int32_t *__restrict__ order, uint32_t *__restrict__ tie_list, uint32_t *__restrict__ tie_count, int32_t *__restrict__ tie_mark) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long red[DET_T / 64];
     __shared__ uint32_t nk_sh[4];
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(DET_T) void extract_list_kernel(
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         extract_one<FIT, DET_LDS_PTS2, DET_LDS_MAXC2, false, false, MODE == 1, MODE == 2>(
             smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
-            members, koff, ksize, sorted, norms, nullptr, nullptr, nullptr, order, tie_list, tie_count);
+            members, koff, ksize, sorted, norms, nullptr, nullptr, nullptr, order, tie_list, tie_count, tie_mark);
         __syncthreads();
     }
 }
@@ -119,7 +119,8 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                          const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters,
                          double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair,
                          double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, int mode, const int32_t *d_order,
-                         const uint32_t *d_in_list, const uint32_t *d_in_count, uint32_t *d_tie_list, uint32_t *d_tie_count, void *stream) {
+                         const uint32_t *d_in_list, const uint32_t *d_in_count, uint32_t *d_tie_list, uint32_t *d_tie_count, int32_t *d_tie_mark,
+                         void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (!d_seg_off || !d_seg_cnt || !d_n_clusters || !d_win_info ||
@@ -184,7 +185,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
 #define ECAL_DET_FIRST(FIT_, MODE_)                                                                                                  \
     hipLaunchKernelGGL((extract_kernel<FIT_, MODE_>), dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,    \
                        d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,              \
-                       second ? list : nullptr, cnt, d_order, d_tie_list, d_tie_count)
+                       second ? list : nullptr, cnt, d_order, d_tie_list, d_tie_count, d_tie_mark)
 #define ECAL_DET_FIRST_LIST(FIT_, MODE_, LIST_, COUNT_)                                                                              \
     hipLaunchKernelGGL((extract_first_list_kernel<FIT_, MODE_>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off,         \
                        d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, \
@@ -192,7 +193,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
 #define ECAL_DET_SECOND(FIT_, MODE_)                                                                                                 \
     hipLaunchKernelGGL((extract_list_kernel<FIT_, MODE_>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES2, st, d_xy, d_seg_off, d_seg_cnt,    \
                        d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,    \
-                       (const uint32_t *) list, (const uint32_t *) cnt, d_order, d_tie_list, d_tie_count)
+                       (const uint32_t *) list, (const uint32_t *) cnt, d_order, d_tie_list, d_tie_count, d_tie_mark)
     const bool fit = prm.fit_circle != 0;
     if (fused && !fit) {
         const uint32_t *dcnt = (const uint32_t *) ctx->fused_def.ptr, *dlist = dcnt + 4;
@@ -230,7 +231,7 @@ extern "C" int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
                                       int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 0, nullptr, nullptr, nullptr, nullptr,
-                         nullptr, stream);
+                         nullptr, nullptr, stream);
 }
 
 extern "C" int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
@@ -245,7 +246,7 @@ extern "C" int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy,
     }
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, d_cluster_order, nullptr, nullptr,
-                         nullptr, nullptr, stream);
+                         nullptr, nullptr, nullptr, stream);
 }
 
 // The exact extraction in one call: the plain pass lists the windows in which some kept cluster's median is tied in norm (a third of
@@ -264,7 +265,13 @@ extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, c
     if (S == 0) return ECAL_OK;
     int rc;
     if ((rc = ecal_ensure(ctx, ctx->tie_list, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
+    const void *const order_was = ctx->tie_order.ptr;
     if ((rc = ecal_ensure(ctx, ctx->tie_order, ((size_t) n_points + 16) * sizeof(int32_t) + 2 * (size_t) S * sizeof(uint32_t)))) return rc;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // the marks below are read back from this buffer: fresh memory must not hold one by accident (every later pass leaves
+    // the listed windows' slots holding ranks or -1 / -2, never the mark)
+    if (ctx->tie_order.ptr != order_was)
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(ctx->tie_order.ptr, 0, ((size_t) n_points + 16) * sizeof(int32_t), (hipStream_t) stream));
     uint32_t *tcnt = (uint32_t *) ctx->tie_list.ptr, *tlist = tcnt + 4;
     int32_t *order = (int32_t *) ctx->tie_order.ptr;
     uint32_t *ostatus = (uint32_t *) (order + (size_t) n_points + 16);
@@ -272,14 +279,15 @@ extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, c
     ECAL_HIP_TRY(ctx, hipMemsetAsync(tcnt, 0, sizeof(uint32_t), (hipStream_t) stream));
     if ((rc = extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                             fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 2, nullptr, nullptr, nullptr, tlist,
-                            tcnt, stream)))
+                            tcnt, order, stream)))
         return rc;
-    if ((rc = ecal_cluster_order_list_dev(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, eps, d_labels, d_n_clusters, order, ostatus, 1, tlist, tcnt,
+    // (only_tied_medians = 2: the tied clusters are the ones whose representative's slot the plain pass marked in `order`)
+    if ((rc = ecal_cluster_order_list_dev(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, eps, d_labels, d_n_clusters, order, ostatus, 2, tlist, tcnt,
                                           stream)))
         return rc;
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, order, tlist, tcnt, nullptr, nullptr,
-                         stream);
+                         nullptr, stream);
 }
 
 int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,

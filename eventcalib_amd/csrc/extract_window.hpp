@@ -302,7 +302,7 @@ template <bool FIT, bool ORD, bool TDET, typename ST>
 __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&base)[2], const uint32_t (&kb)[2],
                                                const uint32_t (&n_pol)[2], const int32_t *lab0, const int32_t *lab1,
                                                const int32_t *ord0, const int32_t *ord1, uint32_t *tie_list, uint32_t *tie_count,
-                                               uint32_t tie_token,
+                                               uint32_t tie_token, int32_t *mark0, int32_t *mark1,
                                                const uint32_t (&nc_pol)[2], const DetectParams &prm, uint32_t *csize,
                                                typename ST::CIdx *newid, typename ST::CIdx *coff,
                                                unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
@@ -420,6 +420,9 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 if (rv & ST::REP_TIE) {
                     st.rep[kb[pol] + k] = rv & ~ST::REP_TIE;
                     mine = true;
+                    // the cluster is named to ecal_cluster_order_list_dev by a mark on its representative's slot
+                    int32_t *mk = pol ? mark1 : mark0;
+                    if (mk) mk[rv & ~ST::REP_TIE] = -3;
                 }
             }
         if (mine) nk_sh[0] |= 0x80000000u;   // (nk[] was read into registers above; every writer stores the same bit)
@@ -758,7 +761,7 @@ __device__ __forceinline__ void extract_one(
     uint32_t *__restrict__ rep, uint32_t *__restrict__ members, uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize,
     uint32_t *__restrict__ sorted, double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
     const uint32_t *known = nullptr, const int32_t *__restrict__ order = nullptr, uint32_t *tie_list = nullptr,
-    uint32_t *tie_count = nullptr) {
+    uint32_t *tie_count = nullptr, int32_t *tie_mark = nullptr) {
     using LL = DetLdsLayoutT<PTS, MAXC>;
     // csize: members per DBSCAN cluster, later a scatter cursor; newid: renumbered id of a kept cluster;
     // coff: first member slot of a kept cluster.  Sized for the global path; the LDS path uses the first
@@ -850,7 +853,8 @@ __device__ __forceinline__ void extract_one(
         const uint32_t base[2] = {0u, n_pol[0]};
         const uint32_t kb[2] = {0u, MAXC};  // per-cluster arrays: one block of MAXC per polarity
         extract_window<FIT, ORD, TDET>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
-                                       order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, nc_pol, prm, csize,
+                                       order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, tie_mark ? tie_mark + o_pol[0] : nullptr,
+                                       tie_mark ? tie_mark + o_pol[1] : nullptr, nc_pol, prm, csize,
                        reinterpret_cast<uint16_t *>(smem + LL::newid_off), reinterpret_cast<uint16_t *>(smem + LL::coff_off), red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
         __syncthreads();
@@ -881,7 +885,8 @@ __device__ __forceinline__ void extract_one(
         st.norms = norms + w0;
         const uint32_t base[2] = {o_pol[0] - w0, o_pol[1] - w0};
         extract_window<FIT, ORD, TDET>(st, base, base, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
-                                       order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, nc_pol, prm, csize, csize + DET_MAXC,
+                                       order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, tie_mark ? tie_mark + o_pol[0] : nullptr,
+                                       tie_mark ? tie_mark + o_pol[1] : nullptr, nc_pol, prm, csize, csize + DET_MAXC,
                        csize + 2 * DET_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
                        cand_xyr + 3 * (size_t) o_pol[0]);
     }
