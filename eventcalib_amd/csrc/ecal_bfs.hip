@@ -24,25 +24,27 @@
 namespace ecal {
 
 constexpr int BO_T = 256;
-constexpr uint32_t BO_CAP = 2048;        // points per segment (second launch; the first takes <= 1024 with half the LDS: 4 instead of
-constexpr uint32_t BO_CAP1 = 1024;       // 2 workgroups per CU)
+constexpr uint32_t BO_CAP = 2048;        // points per segment (second launch; the first takes <= 768 — the pixel DBSCAN's first tier too —
+constexpr uint32_t BO_CAP1 = 768;        // and <= 256 clusters in 26 KB of LDS: 6 workgroups per CU instead of 1; the pass is latency bound,
+constexpr uint32_t BO_WG1 = 6;           // waves in flight pay).  BO_WG1: workgroups per CU of the first launch
 constexpr uint32_t BO_MAXN = 64;         // hits per range query kept (a disc of radius 4 holds 48 other pixels)
-constexpr uint32_t BO_POOL = 48;         // range-query lists kept in LDS (the members of the tied clusters: a few dozen); the rest
+constexpr uint32_t BO_POOL = 8;          // range-query lists kept in LDS (the members of the tied clusters: a few dozen); the rest
                                          // go to global scratch
 constexpr uint32_t BO_STACK = 96;        // pending far subtrees of one traversal
 constexpr uint32_t BO_NONE = 0xFFFFFFFFu;
 
 template <uint32_t CAP>
 struct BoLayout {
+    static constexpr uint32_t NCAP = CAP == BO_CAP ? CAP : CAP / 3;       // clusters per segment
     static constexpr size_t px_off = 0;                                   // f64[CAP]
     static constexpr size_t py_off = px_off + 8 * CAP;                    // f64[CAP]
     static constexpr size_t child_off = py_off + 8 * CAP;                 // u32[2 CAP]: children (left, right) of node i
-    static constexpr size_t lab_off = child_off + 8 * CAP;                // i32[CAP]
-    static constexpr size_t queue_off = lab_off + 4 * CAP;                // u16[CAP]: the clusters' queues, back to back
-    static constexpr size_t qbase_off = queue_off + 2 * CAP;              // u32[CAP + 1]: members per cluster, then offsets
-    static constexpr size_t inq_off = qbase_off + 4 * (CAP + 1) + 12;     // u32[CAP / 32]: point is (or was) in its cluster's queue
-    static constexpr size_t seed_off = inq_off + 4 * (CAP / 32);          // u32[CAP]: smallest pid per cluster
-    static constexpr size_t slot_off = seed_off + 4 * CAP;                // u16[CAP]: LDS list slot of a point's range query, 0xFFFF: global
+    static constexpr size_t lab_off = child_off + 8 * CAP;                // i16[CAP]
+    static constexpr size_t queue_off = lab_off + 2 * CAP;                // u16[CAP]: the clusters' queues, back to back
+    static constexpr size_t qbase_off = queue_off + 2 * CAP;              // u32[NCAP + 1]: members per cluster, then offsets
+    static constexpr size_t inq_off = qbase_off + 4 * (NCAP + 1) + 12;    // u32[CAP / 32]: point is (or was) in its cluster's queue
+    static constexpr size_t seed_off = inq_off + 4 * (CAP / 32);          // u32[NCAP]: smallest pid per cluster
+    static constexpr size_t slot_off = seed_off + 4 * NCAP;               // u16[CAP]: LDS list slot of a point's range query, 0xFFFF: global
     static constexpr size_t pool_off = slot_off + 2 * CAP;                // u16[BO_POOL][BO_MAXN] + u16[BO_POOL] counts
     static constexpr size_t red_off = pool_off + 2 * BO_POOL * (BO_MAXN + 1);   // u32[16]
     static constexpr size_t bytes = red_off + 64;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
     double *const px = reinterpret_cast<double *>(smem + BoLayout<CAP>::px_off);
     double *const py = reinterpret_cast<double *>(smem + BoLayout<CAP>::py_off);
     uint32_t *const child = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::child_off);
-    int32_t *const lab = reinterpret_cast<int32_t *>(smem + BoLayout<CAP>::lab_off);
+    int16_t *const lab = reinterpret_cast<int16_t *>(smem + BoLayout<CAP>::lab_off);
     uint16_t *const queue = reinterpret_cast<uint16_t *>(smem + BoLayout<CAP>::queue_off);
     uint32_t *const qbase = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::qbase_off);
     uint32_t *const inq = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::inq_off);
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
         if constexpr (!FIRST) {
             if (status[s] != 2u) continue;   // taken (or refused) by the first launch
         }
-        if (n > CAP || nc > CAP) {
+        if (n > CAP || nc > BoLayout<CAP>::NCAP) {
             if (FIRST && n <= BO_CAP && nc <= BO_CAP) {
                 if (tid == 0) status[s] = 2;   // the second launch
             } else {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             const double2 p = reinterpret_cast<const double2 *>(xy)[base + i];
             px[i] = p.x;
             py[i] = p.y;
-            lab[i] = labels[base + i];
+            lab[i] = (int16_t) labels[base + i];   // (-1 or < n_clusters <= CAP)
             child[2 * i] = BO_NONE;
             child[2 * i + 1] = BO_NONE;
         }
@@ -425,7 +427,7 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
-    const uint32_t grid1 = std::min<uint32_t>(S, 4u * ctx->n_cu), grid2 = std::min<uint32_t>(S, 2u * ctx->n_cu);
+    const uint32_t grid1 = std::min<uint32_t>(S, BO_WG1 * ctx->n_cu), grid2 = std::min<uint32_t>(S, 2u * ctx->n_cu);
     int rc;
     // global lists: one slice per workgroup of the larger grid (the first launch's workgroups use BO_CAP1 rows of theirs)
     if ((rc = ecal_ensure(ctx, ctx->bfs_lists, (size_t) grid1 * BO_CAP * (BO_MAXN * sizeof(uint16_t) + 1)))) return rc;

@@ -114,6 +114,27 @@ def test_oversized_segment_is_reported_and_a_degenerate_tree_is_taken(env):
         _check(seg, r[0], r[1], 4.0, 2)
 
 
+def test_tier_boundaries_of_the_two_launches(env):
+    """The first launch takes <= 768 points and <= 256 clusters per segment, the second the rest up to 2048: same answers."""
+    ctx, torch = env
+    rng = np.random.default_rng(21)
+    segs = []
+    for pairs in (250, 256, 257, 380):                       # clusters of two pixels, 10 apart: n = 2 * pairs <= 768, n_clusters = pairs
+        cells = rng.permutation(40 * 40)[:pairs]
+        a = np.stack([cells % 40, cells // 40], 1).astype(np.float64) * 10.0
+        pts = np.concatenate([a, a + [1.0, 0.0]])
+        segs.append(pts[rng.permutation(len(pts))])
+    for n in (767, 768, 769, 900):
+        side = int(np.sqrt(n) * 2.2)
+        pts = rng.permutation(side * side)[:n]
+        segs.append(np.stack([pts % side, pts // side], 1).astype(np.float64))
+    res = _order_of(ctx, torch, segs, 4.0, 1)                # (minPts 1: one neighbour makes a core point)
+    for seg, (lab, od, st) in zip(segs, res):
+        assert st == 0
+        _check(seg, lab, od, 4.0, 1)
+    assert [int(r[0].max()) + 1 for r in res[:4]] == [250, 256, 257, 380]
+
+
 def test_host_buffer_form_equals_the_device_form(env):
     """ecal_cluster_order (what the DBSCAN<T,Float> shim calls to put Clusters[c] into the reference's order)."""
     ctx, torch = env
