@@ -427,11 +427,16 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
             }
         if (mine) nk_sh[0] |= 0x80000000u;   // (nk[] was read into registers above; every writer stores the same bit)
         __syncthreads();
-        if (tid == 0 && (nk_sh[0] & 0x80000000u)) {
+        const bool window_tied = (nk_sh[0] & 0x80000000u) != 0;
+        __syncthreads();
+        if (tid == 0 && window_tied) {
             nk_sh[0] &= 0x7FFFFFFFu;
             if (tie_list) tie_list[atomicAdd(tie_count, 1u)] = tie_token;
         }
         __syncthreads();
+        // a listed window is extracted again from the start with the reference's picks (ORD): its pairing here would be
+        // thrown away
+        if (window_tied && tie_list) return;
     }
     if constexpr (ORD) {
         // the flagged clusters, a thread each: members into the reference's order (members[] is free from here on), the

@@ -87,8 +87,10 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
  * extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147), which depend on that order
  * when two members tie in norm.  only_tied_medians != 0: the order is worked out only for the clusters that need it for that
  * purpose — those whose member of rank size / 2 in the order (norm, pid) shares its norm with another member (the test
- * ecal_extract_batch_ordered_dev applies) —, the members of all other clusters get -2; segments without such a cluster (four
- * in five on the benchmark stream) do not even have their tree rebuilt. */
+ * ecal_extract_batch_ordered_dev applies) —, the members of all other clusters get -2; segments without such a cluster do
+ * not even have their tree rebuilt.  (only_tied_medians == 2, used by ecal_extract_batch_exact_dev: the caller has named
+ * those clusters itself by storing -3 in d_order on the slot of one member of each.)
+ * Two launches: segments of up to 768 points and 256 clusters, then the rest up to 2048. */
 int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                            double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order /*[n_points]*/,
                            uint32_t *d_status /*[S]*/, int only_tied_medians, void *stream);
@@ -218,7 +220,8 @@ int ecal_set_median_ties(ecal_ctx *ctx, int mode);
 int ecal_get_median_ties(const ecal_ctx *ctx);
 
 /* ecal_extract_batch_exact_dev: the exact extraction in one call (eps = the DBSCAN radius the labels were made with): the plain
- * pass lists the windows in which some kept cluster's median is tied in norm (about a third on the benchmark stream),
+ * pass lists the windows in which some kept cluster's median is tied in norm (a third of them on recorded-like data, all of
+ * them on the dense benchmark stream),
  * ecal_cluster_order_list_dev works out the reference's member order for the tied clusters of those windows only, and the
  * listed windows are extracted again with it.  Results = ecal_extract_batch_ordered_dev's = the reference's own. */
 int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
