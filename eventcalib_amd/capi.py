@@ -313,13 +313,14 @@ class Context:
 
     def cluster_order_dev(self, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, stream=0,
                           only_tied_medians=False):
-        """Position of every core point inside the reference's Clusters[label] (expandCluster's pop order); -1 for noise."""
+        """Position of every core point inside the reference's Clusters[label] (expandCluster's pop order); -1 for noise.
+        only_tied_medians: False / True, or 2 = only the clusters the caller marked with -3 in d_order (ecal.h)."""
         L = self._L
         vp = ctypes.c_void_p
         L.ecal_cluster_order_dev.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_double, vp, vp, vp, vp, ctypes.c_int, vp]
         L.ecal_cluster_order_dev.restype = ctypes.c_int
         self._check(L.ecal_cluster_order_dev(self._h, d_xy, d_seg_off, d_seg_cnt, int(S), float(eps), d_labels, d_n_clusters, d_order,
-                                             d_status, int(bool(only_tied_medians)), stream))
+                                             d_status, int(only_tied_medians), stream))
 
     def cluster_order(self, xy, slice_off, eps, labels, n_clusters):
         """Host-buffer form of cluster_order_dev: returns (order [N] int32, status [S] uint32)."""

@@ -193,3 +193,40 @@ def test_only_tied_medians_mode(env):
                 plain_clusters += 1
                 assert (p[idx] == -2).all(), (sg, c)
     assert tied_clusters > 10 and plain_clusters > 20 * tied_clusters
+
+
+def test_marked_clusters_mode(env):
+    """only_tied_medians = 2 (what ecal_extract_batch_exact_dev uses): the caller names the clusters by a -3 on the slot of one
+    member each; those get their positions, every other cluster -2, segments without a mark are left without a tree."""
+    ctx, torch = env
+    rng = np.random.default_rng(31)
+    segs = [rng.integers(0, 45, size=(n, 2)).astype(np.float64) for n in (500, 300, 760, 1500)]
+    segs = [np.unique(s, axis=0)[rng.permutation(len(np.unique(s, axis=0)))] for s in segs]
+    res = _order_of(ctx, torch, segs, 4.0, 2)
+    cnt = np.array([len(s) for s in segs], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32)
+    labels = np.concatenate([r[0] for r in res]).astype(np.int32)
+    full = np.concatenate([r[1] for r in res])
+    ncl = np.array([int(r[0].max()) + 1 for r in res], dtype=np.int32)
+    marks = np.full(len(labels), 7, dtype=np.int32)          # stale content of the buffer: anything but the mark
+    wanted = []
+    for s in (0, 2, 3):                                      # segment 1 stays unmarked
+        ids = rng.permutation(ncl[s])[: max(1, ncl[s] // 3)]
+        for c in ids:
+            members = np.flatnonzero(labels[off[s]:off[s] + cnt[s]] == c)
+            marks[off[s] + members[rng.integers(len(members))]] = -3
+            wanted.append((s, int(c)))
+    xy = torch.as_tensor(np.concatenate(segs), device="cuda").contiguous()
+    d = lambda a: torch.as_tensor(a, device="cuda")
+    d_off, d_cnt, d_lab, d_ncl, d_ord = d(off), d(cnt), d(labels), d(ncl), d(marks)
+    status = torch.full((4,), -7, dtype=torch.int32, device="cuda")
+    ctx.cluster_order_dev(xy.data_ptr(), d_off.data_ptr(), d_cnt.data_ptr(), 4, 4.0, d_lab.data_ptr(), d_ncl.data_ptr(), d_ord.data_ptr(),
+                          status.data_ptr(), torch.cuda.current_stream().cuda_stream, only_tied_medians=2)
+    torch.cuda.synchronize()
+    got = d_ord.cpu().numpy()
+    assert status.cpu().tolist() == [0, 0, 0, 0]
+    want = np.where(labels < 0, -1, -2).astype(np.int32)
+    for s, c in wanted:
+        sel = off[s] + np.flatnonzero(labels[off[s]:off[s] + cnt[s]] == c)
+        want[sel] = full[sel]
+    assert np.array_equal(got, want)
