@@ -23,19 +23,26 @@
 
 namespace ecal {
 
-constexpr int BO_T = 256;
-constexpr uint32_t BO_CAP = 2048;        // points per segment (second launch; the first takes <= 768 — the pixel DBSCAN's first tier too —
-constexpr uint32_t BO_CAP1 = 768;        // and <= 256 clusters in 26 KB of LDS: 6 workgroups per CU instead of 1; the pass is latency bound,
-constexpr uint32_t BO_WG1 = 6;           // waves in flight pay).  BO_WG1: workgroups per CU of the first launch
+// Three launches.  The first takes segments of <= 768 points (the pixel DBSCAN's first tier too) and <= 256 clusters in 26 KB
+// of LDS with 256 threads: 6 workgroups per CU — the pass is latency bound, workgroups in flight pay.  The second (<= 2048
+// points) and third (<= 4096 points, <= 2048 clusters: 141 KB, one workgroup per CU) run 1024 threads: the few segments that
+// reach them (windows grown by the adaptive policy) are on the critical path of a lock-step pass, where the latency of ONE
+// segment counts.
+constexpr int BO_T1 = 256, BO_T2 = 1024;
+constexpr uint32_t BO_CAP1 = 768, BO_CAP2 = 2048, BO_CAP3 = 4096;
+constexpr uint32_t BO_WG1 = 6, BO_WG2 = 1, BO_WG3 = 1;   // workgroups per CU
+constexpr uint32_t BO_WAVE_MIN = 32;     // clusters of at least this many members: a wave runs the queue (a lane per neighbour)
 constexpr uint32_t BO_MAXN = 64;         // hits per range query kept (a disc of radius 4 holds 48 other pixels)
-constexpr uint32_t BO_POOL = 8;          // range-query lists kept in LDS (the members of the tied clusters: a few dozen); the rest
-                                         // go to global scratch
+// Range-query lists kept in LDS (handed out first come first served; the rest go to global scratch).  The first tier keeps a
+// token 8: there more workgroups per CU beat lists in LDS (profiles/r02_notes.md).  The later tiers run one workgroup per CU
+// and fill the LDS with lists: their queue is a dependent chain of pops, and a list in global memory is a round trip per pop.
 constexpr uint32_t BO_STACK = 96;        // pending far subtrees of one traversal
 constexpr uint32_t BO_NONE = 0xFFFFFFFFu;
 
 template <uint32_t CAP>
 struct BoLayout {
-    static constexpr uint32_t NCAP = CAP == BO_CAP ? CAP : CAP / 3;       // clusters per segment
+    static constexpr uint32_t NCAP = CAP == BO_CAP1 ? 256u : 2048u;       // clusters per segment
+    static constexpr uint32_t POOL = CAP == BO_CAP1 ? 8u : (CAP == BO_CAP2 ? 640u : 168u);
     static constexpr size_t px_off = 0;                                   // f64[CAP]
     static constexpr size_t py_off = px_off + 8 * CAP;                    // f64[CAP]
     static constexpr size_t child_off = py_off + 8 * CAP;                 // u32[2 CAP]: children (left, right) of node i
@@ -45,16 +52,20 @@ struct BoLayout {
     static constexpr size_t inq_off = qbase_off + 4 * (NCAP + 1) + 12;    // u32[CAP / 32]: point is (or was) in its cluster's queue
     static constexpr size_t seed_off = inq_off + 4 * (CAP / 32);          // u32[NCAP]: smallest pid per cluster
     static constexpr size_t slot_off = seed_off + 4 * NCAP;               // u16[CAP]: LDS list slot of a point's range query, 0xFFFF: global
-    static constexpr size_t pool_off = slot_off + 2 * CAP;                // u16[BO_POOL][BO_MAXN] + u16[BO_POOL] counts
-    static constexpr size_t red_off = pool_off + 2 * BO_POOL * (BO_MAXN + 1);   // u32[16]
+    static constexpr size_t pool_off = slot_off + 2 * CAP;                // u16[POOL][BO_MAXN] + u16[POOL] counts
+    static constexpr size_t red_off = pool_off + 2 * POOL * (BO_MAXN + 1) + (2 * POOL * (BO_MAXN + 1)) % 16;   // u32[16]
     static constexpr size_t bytes = red_off + 64;
+    static_assert(bytes <= 160 * 1024, "LDS of a CU");
 };
 
 #ifdef ECAL_PHASE_PROF
+#ifndef ECAL_BO_PROF_CAP
+#define ECAL_BO_PROF_CAP 0   // marks of one tier only (its CAP)
+#endif
 static __device__ unsigned long long g_bo_cycles[16];
 #define BO_MARK(i)                                                   \
     do {                                                             \
-        if (threadIdx.x == 0) {                                      \
+        if (threadIdx.x == 0 && (ECAL_BO_PROF_CAP == 0 || CAP == ECAL_BO_PROF_CAP)) { \
             const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
             atomicAdd(&g_bo_cycles[i], now__ - bo_t__);              \
             bo_t__ = now__;                                          \
@@ -75,9 +86,9 @@ __device__ __forceinline__ bool bo_block_any(bool v, uint32_t *flag, uint32_t &r
     return any;
 }
 
-// status: 0 taken; 1 not taken at all (see ecal.h); 2 left by the CAP1 launch to the CAP launch (FIRST / !FIRST)
-template <uint32_t CAP, bool FIRST>
-__global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
+// status: 0 taken; 1 not taken at all (see ecal.h).  TIER 0, 1, 2: the three launches
+template <uint32_t CAP, int T, int TIER>
+__global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
                                                             const uint32_t *__restrict__ seg_cnt, uint32_t S, double eps,
                                                             const int32_t *__restrict__ labels,
                                                             const uint32_t *__restrict__ n_clusters, int32_t *__restrict__ order,
@@ -97,12 +108,14 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
     uint32_t *const red = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::red_off);
     uint16_t *const slotmap = reinterpret_cast<uint16_t *>(smem + BoLayout<CAP>::slot_off);
     uint16_t *const pool = reinterpret_cast<uint16_t *>(smem + BoLayout<CAP>::pool_off);
+    constexpr uint32_t BO_POOL = BoLayout<CAP>::POOL;
     uint16_t *const pool_cnt = pool + BO_POOL * BO_MAXN;
-    constexpr int BO_PPT = (int) (CAP / BO_T);
+    constexpr int BO_PPT = (int) ((CAP + T - 1) / T);
+    constexpr uint32_t BO_T = T;
     const uint32_t tid = threadIdx.x;
     // this workgroup's slice of the neighbour lists
-    uint16_t *const my_lists = lists + (size_t) blockIdx.x * BO_CAP * BO_MAXN;
-    uint8_t *const my_cnt = list_cnt + (size_t) blockIdx.x * BO_CAP;
+    uint16_t *const my_lists = lists + (size_t) blockIdx.x * CAP * BO_MAXN;
+    uint8_t *const my_cnt = list_cnt + (size_t) blockIdx.x * CAP;
     const double eps2 = eps * eps;   // SQ(range), kdtree.cpp:155-159
 
     // win_list: only the two segments (2 w, 2 w + 1) of the listed windows w
@@ -118,13 +131,12 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
             if (tid == 0) status[s] = 0;
             continue;
         }
-        if constexpr (!FIRST) {
-            if (status[s] != 2u) continue;   // taken (or refused) by the first launch
-        }
-        if (n > CAP || nc > BoLayout<CAP>::NCAP) {
-            if (FIRST && n <= BO_CAP && nc <= BO_CAP) {
-                if (tid == 0) status[s] = 2;   // the second launch
-            } else {
+        // which launch takes a segment follows from its size alone (the launches run side by side)
+        const int tier = (n <= BO_CAP1 && nc <= BoLayout<BO_CAP1>::NCAP) ? 0
+                         : (n <= BO_CAP2 && nc <= BoLayout<BO_CAP2>::NCAP) ? 1
+                         : (n <= BO_CAP3 && nc <= BoLayout<BO_CAP3>::NCAP) ? 2 : 3;
+        if (tier != TIER) {
+            if (TIER == 2 && tier == 3) {
                 for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
                 if (tid == 0) status[s] = 1;
             }
@@ -366,9 +378,11 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
         for (uint32_t i = tid; i < n; i += BO_T)
             if (lab[i] < 0) order[base + i] = -1;
             else if (seed[lab[i]] == BO_NONE - 1u) order[base + i] = -2;
+        // (a thread per small cluster; a wave per large one, its lanes taking one neighbour of the popped point each: the pops
+        // of one cluster are a dependent chain, and in a lock-step pass of the adaptive policy that chain is the kernel's latency)
         for (uint32_t c = tid; c < nc; c += BO_T) {
             const uint32_t qb = qbase[c], sd = seed[c];
-            if (sd >= BO_NONE - 1u) continue;   // not wanted (or, impossible, without members)
+            if (sd >= BO_NONE - 1u || qbase[c + 1] - qb >= BO_WAVE_MIN) continue;   // not wanted (or, impossible, without members)
             uint32_t head = 0, tail = 1;
             queue[qb] = (uint16_t) sd;
             atomicOr(&inq[sd >> 5], 1u << (sd & 31u));
@@ -386,6 +400,44 @@ __global__ __launch_bounds__(BO_T) void cluster_order_kernel(const double *__res
                     if (atomicOr(&inq[j >> 5], bit) & bit) continue;   // already in the border set
                     queue[qb + tail] = (uint16_t) j;
                     tail++;
+                }
+            }
+        }
+        {
+            const uint32_t lane = tid & 63u;
+            for (uint32_t c = tid >> 6; c < nc; c += BO_T / 64u) {   // (uniform in the wave)
+                const uint32_t qb = qbase[c], sd = seed[c];
+                if (sd >= BO_NONE - 1u || qbase[c + 1] - qb < BO_WAVE_MIN) continue;
+                uint32_t head = 0, tail = 1;
+                if (lane == 0) {
+                    queue[qb] = (uint16_t) sd;
+                    atomicOr(&inq[sd >> 5], 1u << (sd & 31u));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                while (head < tail) {
+                    const uint32_t q = reinterpret_cast<volatile uint16_t *>(queue)[qb + head];
+                    if (lane == 0) order[base + q] = (int32_t) head;
+                    head++;
+                    const uint32_t sl = slotmap[q];
+                    const uint32_t m = sl != 0xFFFFu ? (uint32_t) pool_cnt[sl] : (uint32_t) my_cnt[q];
+                    const uint16_t *lst = sl != 0xFFFFu ? pool + sl * BO_MAXN : my_lists + (size_t) q * BO_MAXN;
+                    // lane l takes the l-th entry from the END of the list (BO_MAXN = the wave's width); the hits of one query
+                    // are distinct points, so the lanes' bits in inq[] never coincide
+                    bool take = false;
+                    uint32_t j = 0;
+                    if (lane < m) {
+                        j = lst[m - 1u - lane];
+                        if ((uint32_t) lab[j] == c) {
+                            const uint32_t bit = 1u << (j & 31u);
+                            take = !(atomicOr(&inq[j >> 5], bit) & bit);
+                        }
+                    }
+                    const unsigned long long mask = __ballot(take);
+                    if (take) queue[qb + tail + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t) j;
+                    tail += (uint32_t) __popcll(mask);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
@@ -427,22 +479,30 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
-    const uint32_t grid1 = std::min<uint32_t>(S, BO_WG1 * ctx->n_cu), grid2 = std::min<uint32_t>(S, 2u * ctx->n_cu);
+    const uint32_t grid1 = std::min<uint32_t>(S, BO_WG1 * ctx->n_cu), grid2 = std::min<uint32_t>(S, BO_WG2 * ctx->n_cu),
+                   grid3 = std::min<uint32_t>(S, BO_WG3 * ctx->n_cu);
     int rc;
-    // global lists: one slice per workgroup of the larger grid (the first launch's workgroups use BO_CAP1 rows of theirs)
-    if ((rc = ecal_ensure(ctx, ctx->bfs_lists, (size_t) grid1 * BO_CAP * (BO_MAXN * sizeof(uint16_t) + 1)))) return rc;
+    // global lists: a slice of CAP rows per workgroup; the launches follow each other on the stream and share the buffer
+    const size_t rows = std::max({(size_t) grid1 * BO_CAP1, (size_t) grid2 * BO_CAP2, (size_t) grid3 * BO_CAP3});
+    if ((rc = ecal_ensure(ctx, ctx->bfs_lists, rows * (BO_MAXN * sizeof(uint16_t) + 1)))) return rc;
     uint16_t *lists = (uint16_t *) ctx->bfs_lists.ptr;
-    uint8_t *cnt = (uint8_t *) (lists + (size_t) grid1 * BO_CAP * BO_MAXN);
+    uint8_t *cnt = (uint8_t *) (lists + rows * BO_MAXN);
     if (!ctx->bfs_attr_set) {
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP1, true>),
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP1, BO_T1, 0>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP1>::bytes));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP>::bytes));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP2, BO_T2, 1>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP2>::bytes));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP3, BO_T2, 2>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP3>::bytes));
         ctx->bfs_attr_set = true;
     }
-    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP1, true>), dim3(grid1), dim3(BO_T), BoLayout<BO_CAP1>::bytes, st, d_xy, d_seg_off,
+    // (The three launches are independent — a segment's size names its launch —, but starting the later ones on streams of
+    // their own beside the first cost more in cross-stream waits than it saved: 0.74 against 0.65 ms per lock-step pass.)
+    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP1, BO_T1, 0>), dim3(grid1), dim3(BO_T1), BoLayout<BO_CAP1>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
-    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP, false>), dim3(grid2), dim3(BO_T), BoLayout<BO_CAP>::bytes, st, d_xy, d_seg_off,
+    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP2, BO_T2, 1>), dim3(grid2), dim3(BO_T2), BoLayout<BO_CAP2>::bytes, st, d_xy, d_seg_off,
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
+    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP3, BO_T2, 2>), dim3(grid3), dim3(BO_T2), BoLayout<BO_CAP3>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;

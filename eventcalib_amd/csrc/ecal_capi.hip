@@ -1,6 +1,38 @@
 // Context lifecycle and shared helpers of libecal.so.
 #include "ecal_ctx.hpp"
 
+constexpr uint32_t ZERO_RING_WORDS = 16384, ZERO_RING_GRAIN = 16;
+
+uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n) {
+    if (n > ZERO_RING_GRAIN || getenv("ECAL_NO_ZERO_RING")) return nullptr;
+    ecal_ctx::zero_ring *r = nullptr;
+    for (auto &c : ctx->zero_rings)
+        if (c.used && c.stream == st) r = &c;
+    if (!r) {
+        for (auto &c : ctx->zero_rings)
+            if (!c.used && !r) r = &c;
+        if (!r) return nullptr;
+        if (hipMalloc((void **) &r->ptr, ZERO_RING_WORDS * sizeof(uint32_t)) != hipSuccess) {
+            r->ptr = nullptr;
+            return nullptr;
+        }
+        r->used = true;
+        r->stream = st;
+        r->pos = ZERO_RING_WORDS;   // wiped below
+    }
+    // The ring is wiped half by half, on entry: the words handed out last (the other half: 512 calls) stay as their owners
+    // left them — an entry point may still be enqueueing kernels that read a counter it took a few calls ago —, and every
+    // earlier user of the half entered is ahead of this memset on the same stream.
+    constexpr uint32_t HALF = ZERO_RING_WORDS / 2;
+    if (r->pos >= ZERO_RING_WORDS) r->pos = 0;
+    if (r->pos % HALF == 0) {
+        if (hipMemsetAsync(r->ptr + r->pos, 0, HALF * sizeof(uint32_t), st) != hipSuccess) return nullptr;
+    }
+    uint32_t *p = r->ptr + r->pos;
+    r->pos += ZERO_RING_GRAIN;
+    return p;
+}
+
 int ecal_ensure(ecal_ctx *ctx, ecal_devbuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return ECAL_OK;
@@ -83,6 +115,8 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     (void) ecal_comm_destroy(ctx);
     if (ctx->calib_pinned) (void) hipHostFree(ctx->calib_pinned);
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
+    for (auto &c : ctx->zero_rings)
+        if (c.ptr) (void) hipFree(c.ptr);
     if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_uploaded[k]) (void) hipEventDestroy(ctx->ev_uploaded[k]);

@@ -55,6 +55,14 @@ struct ecal_ctx {
     double *calib_pinned = nullptr;  // pinned host landing zone of the reduced record
     void *comm = nullptr;   // ncclComm_t (ecal_comm.hip); null = single rank
     int comm_rank = 0, comm_size = 1;
+    // Words of device memory that are zero when handed out (ecal_zero_words): the to-do counters of the stage calls.  A ring
+    // per stream that has asked (up to four), wiped half by half as it is used up.
+    struct zero_ring {
+        hipStream_t stream = nullptr;
+        uint32_t *ptr = nullptr;
+        uint32_t pos = 0;
+        bool used = false;
+    } zero_rings[4];
     uint32_t n_cu = 256;  // compute units of the device (grid size of the persistent kernels)
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false, fused_attr_set = false, bfs_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
@@ -88,5 +96,8 @@ int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                          uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream);
 // reference element order: the per-pixel bucket table of the hot-path slicer, built on first use (ecal_events.hip)
 int ecal_ensure_bucket_table(ecal_ctx *ctx, hipStream_t st);
+// n <= 16 words that are zero once everything enqueued on `st` so far has run, or nullptr (more streams than rings, no memory):
+// the caller then zeroes words of its own.  They stay the caller's for the next 512 calls on that stream at least.
+uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n);
 // ensure a scratch buffer of at least `bytes` (contents are NOT preserved)
 int ecal_ensure(ecal_ctx *ctx, ecal_devbuf &b, size_t bytes);

@@ -246,7 +246,14 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
         uint32_t *cnt = (uint32_t *) ctx->px_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
         // (fused pass, ecal_fused.hip: the first pass has run inside the fused kernel and has filled the first to-do list)
         const bool fused = ctx->fused_pass;
-        if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+        if (!fused) {   // the lists' counters: words that are zero already, else two wiped now
+            if (uint32_t *z = ecal_zero_words(ctx, st, 2)) {
+                cnt = z;
+                cnt2 = z + 1;
+            } else {
+                ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+            }
+        }
         const uint32_t grid2 = S < 1024u ? S : 1024u;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC")) {

@@ -177,7 +177,10 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     hipStream_t st = (hipStream_t) stream;
     // (fused pass, ecal_fused.hip: the fused kernel has extracted every window it carried through and listed the others)
     const bool fused = ctx->fused_pass && mode == 0;
-    if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+    if (!fused) {   // the list's counter: a word that is zero already, else one wiped now
+        if (uint32_t *z = ecal_zero_words(ctx, st, 1)) cnt = z;
+        else ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+    }
     uint32_t *mem = (uint32_t *) ctx->det_members.ptr, *ko = (uint32_t *) ctx->det_koff.ptr, *ks = (uint32_t *) ctx->det_ksize.ptr,
              *so = (uint32_t *) ctx->det_sorted.ptr;
     double *no = (double *) ctx->det_norms.ptr;
@@ -273,10 +276,12 @@ extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, c
     if (ctx->tie_order.ptr != order_was)
         ECAL_HIP_TRY(ctx, hipMemsetAsync(ctx->tie_order.ptr, 0, ((size_t) n_points + 16) * sizeof(int32_t), (hipStream_t) stream));
     uint32_t *tcnt = (uint32_t *) ctx->tie_list.ptr, *tlist = tcnt + 4;
+    uint32_t *const tcnt_zero = ecal_zero_words(ctx, (hipStream_t) stream, 1);
+    if (tcnt_zero) tcnt = tcnt_zero;
     int32_t *order = (int32_t *) ctx->tie_order.ptr;
     uint32_t *ostatus = (uint32_t *) (order + (size_t) n_points + 16);
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ECAL_HIP_TRY(ctx, hipMemsetAsync(tcnt, 0, sizeof(uint32_t), (hipStream_t) stream));
+    if (!tcnt_zero) ECAL_HIP_TRY(ctx, hipMemsetAsync(tcnt, 0, sizeof(uint32_t), (hipStream_t) stream));
     if ((rc = extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                             fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 2, nullptr, nullptr, nullptr, tlist,
                             tcnt, order, stream)))

@@ -829,7 +829,14 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         int rc;
         if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
         uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
-        if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+        if (!fused) {   // the lists' counters: words that are zero already, else two wiped now
+            if (uint32_t *z = ecal_zero_words(ctx, st, 2)) {
+                cnt = z;
+                cnt2 = z + 1;
+            } else {
+                ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+            }
+        }
         todo = list;
         todo_count = cnt;
         if (reforder || !getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)

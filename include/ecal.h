@@ -82,7 +82,8 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
  * seed = the cluster's smallest pid first), which follows the result order of the kd-tree's range query (hits in reverse
  * visiting order, kdtree.cpp:148-179,469-486) —, -1 for Noise.  d_xy / d_seg_off / d_seg_cnt as ecal_dbscan_batch_dev
  * takes them, d_labels / d_n_clusters as it returned them, same eps.  d_status[s] = 0, or 1 for a segment this pass does
- * not take (more than 2048 points or clusters, more than 64 points in one eps-ball, a tree deeper than 96 levels): its
+ * not take (more than 4096 points or 2048 clusters, more than 64 points in one eps-ball, more than 96 pending subtrees in a
+ * traversal): its
  * d_order entries are -1.  What it is for: Clusters[c] in the reference's order for callers that index into it, and
  * extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147), which depend on that order
  * when two members tie in norm.  only_tied_medians != 0: the order is worked out only for the clusters that need it for that
@@ -90,7 +91,7 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
  * ecal_extract_batch_ordered_dev applies) —, the members of all other clusters get -2; segments without such a cluster do
  * not even have their tree rebuilt.  (only_tied_medians == 2, used by ecal_extract_batch_exact_dev: the caller has named
  * those clusters itself by storing -3 in d_order on the slot of one member of each.)
- * Two launches: segments of up to 768 points and 256 clusters, then the rest up to 2048. */
+ * Three launches: segments of up to 768 points and 256 clusters, then up to 2048 points, then up to 4096. */
 int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                            double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order /*[n_points]*/,
                            uint32_t *d_status /*[S]*/, int only_tied_medians, void *stream);

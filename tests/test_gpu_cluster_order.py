@@ -104,7 +104,7 @@ def test_random_segments(env, eps, minpts):
 def test_oversized_segment_is_reported_and_a_degenerate_tree_is_taken(env):
     ctx, torch = env
     rng = np.random.default_rng(5)
-    big = np.stack([np.arange(3000) % 60, np.arange(3000) // 60], 1).astype(np.float64)[rng.permutation(3000)]   # > 2048 points
+    big = np.stack([np.arange(5000) % 80, np.arange(5000) // 80], 1).astype(np.float64)[rng.permutation(5000)]   # > 4096 points
     chain = np.stack([np.arange(400, dtype=np.float64), np.zeros(400)], 1)      # sorted insertion: a tree 400 levels deep (no far
     ok = rng.uniform(0, 30, size=(300, 2))                                      # subtrees pending: the traversal's stack stays empty)
     res = _order_of(ctx, torch, [big, chain, ok], 4.0, 2)
@@ -115,7 +115,7 @@ def test_oversized_segment_is_reported_and_a_degenerate_tree_is_taken(env):
 
 
 def test_tier_boundaries_of_the_two_launches(env):
-    """The first launch takes <= 768 points and <= 256 clusters per segment, the second the rest up to 2048: same answers."""
+    """The first launch takes <= 768 points and <= 256 clusters per segment, the second up to 2048, the third up to 4096 points: same answers."""
     ctx, torch = env
     rng = np.random.default_rng(21)
     segs = []
@@ -124,7 +124,7 @@ def test_tier_boundaries_of_the_two_launches(env):
         a = np.stack([cells % 40, cells // 40], 1).astype(np.float64) * 10.0
         pts = np.concatenate([a, a + [1.0, 0.0]])
         segs.append(pts[rng.permutation(len(pts))])
-    for n in (767, 768, 769, 900):
+    for n in (767, 768, 769, 900, 2048, 2049, 3000, 4096):
         side = int(np.sqrt(n) * 2.2)
         pts = rng.permutation(side * side)[:n]
         segs.append(np.stack([pts % side, pts // side], 1).astype(np.float64))
