@@ -9,13 +9,15 @@
 // Clusters[c] it stands.  extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147) depend
 // on that order when two members tie in norm.
 //
-// One workgroup per segment (<= 2048 points; coordinates as the doubles they are, no pixel assumption):
-//   1. the insertion-order kd-tree rebuilt level-synchronously: every point stands at a node, goes to the child on its side
-//      or, where that child is missing, bids its pid for it with ds_min — the smallest pid wins, as sequential insertion
-//      (kdtree.cpp:106-146) would place it; one level per round for everybody;
-//   2. one range query per core point, all in parallel (a thread per query): find_nearest's traversal with an explicit
-//      stack, hits written in visiting order to a list in global scratch;
-//   3. one queue simulation per cluster, all clusters in parallel (a thread per cluster): pops in Clusters[c]'s order.
+// One workgroup per segment (<= 4096 points in three size tiers; coordinates as the doubles they are, no pixel assumption):
+//   1. the insertion-order kd-tree rebuilt level-synchronously: every unplaced point stands at a node of the current depth
+//      and bids its pid with ds_min for the child slot on its side — the smallest pid wins, as sequential insertion
+//      (kdtree.cpp:106-146) would place it —, the others go on below the winner; one level and one barrier per round;
+//   2. one range query per core point of the wanted clusters, all in parallel (a thread per query): find_nearest's
+//      traversal with an explicit stack, hits written in visiting order to a list in LDS or global scratch;
+//   3. one queue simulation per wanted cluster, all clusters in parallel (a thread per small cluster, a wave per large one):
+//      pops in Clusters[c]'s order.
+// Which clusters are wanted: all, those with a tied median (own test), or those the caller marked (only_tied = 0 / 1 / 2).
 #include <algorithm>
 #include "ecal_ctx.hpp"
 
