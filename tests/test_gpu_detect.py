@@ -225,3 +225,39 @@ def test_smaller_pid_rule_of_the_plain_primitive(env):
     torch.cuda.synchronize()
     exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR, exact_ties=False)
     assert tied >= 2 and exact + tied >= 0.7 * len(t0)
+
+
+def test_counter_words_from_the_ring_or_wiped_per_call(env, monkeypatch):
+    """The to-do counters of the stage calls come from a per-stream ring of zeroed words (ecal_zero_words) or, without one —
+    ECAL_NO_ZERO_RING, or a fifth stream on one context —, from words wiped per call: same results, also across the ring's
+    half-by-half wipes (600 passes = 3 600 counter words on one stream)."""
+    ctx, pipe, torch = env
+    n = 200_000
+    ev = SS.make_stream(n, device="cuda", seed=41, rate=1.6e6)
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 1.6e6)
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR)
+    S = len(t0)
+
+    def snapshot():
+        torch.cuda.synchronize()
+        m = int(pipe.seg_off[2 * S - 1] + pipe.seg_cnt[2 * S - 1])
+        c = int(pipe.win_info[:S, 0].sum())
+        return [pipe.win_info[:S].clone(), pipe.labels[:m].clone(), pipe.kept_labels[:m].clone(), pipe.cand_pair[:c].clone(),
+                pipe.cand_xyr[:c].clone()]
+
+    pipe.run(ev)
+    want = snapshot()
+    for _ in range(600):                       # through several wipes of the ring
+        pipe.run(ev)
+    for a, b in zip(snapshot(), want):
+        assert torch.equal(a, b)
+    for k in range(6):                         # more streams than the context has rings
+        with torch.cuda.stream(torch.cuda.Stream()):
+            pipe.run(ev)
+            for a, b in zip(snapshot(), want):
+                assert torch.equal(a, b)
+    monkeypatch.setenv("ECAL_NO_ZERO_RING", "1")
+    pipe.run(ev)
+    for a, b in zip(snapshot(), want):
+        assert torch.equal(a, b)
