@@ -88,7 +88,7 @@ __device__ __forceinline__ bool bo_block_any(bool v, uint32_t *flag, uint32_t &r
     return any;
 }
 
-// status: 0 taken; 1 not taken at all (see ecal.h).  TIER 0, 1, 2: the three launches
+// status: 0 taken; 1 not taken at all (see ecal.h).  TIER 0, 1, 2: the three launches (a segment's size names its launch)
 template <uint32_t CAP, int T, int TIER>
 __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
                                                             const uint32_t *__restrict__ seg_cnt, uint32_t S, double eps,
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
                                                             uint32_t *__restrict__ status, uint16_t *__restrict__ lists,
                                                             uint8_t *__restrict__ list_cnt, int only_tied,
                                                             const uint32_t *__restrict__ win_list,
-                                                            const uint32_t *__restrict__ win_count) {
+                                                            const uint32_t *__restrict__ win_count,
+                                                            uint32_t *__restrict__ defer_list, uint32_t *__restrict__ defer_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *const px = reinterpret_cast<double *>(smem + BoLayout<CAP>::px_off);
     double *const py = reinterpret_cast<double *>(smem + BoLayout<CAP>::py_off);
@@ -120,10 +121,11 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
     uint8_t *const my_cnt = list_cnt + (size_t) blockIdx.x * CAP;
     const double eps2 = eps * eps;   // SQ(range), kdtree.cpp:155-159
 
-    // win_list: only the two segments (2 w, 2 w + 1) of the listed windows w
-    const uint32_t n_work = win_list ? 2u * *win_count : S;
+    // win_list: only the two segments (2 w, 2 w + 1) of the listed windows w.  The first launch looks at all of them and lists
+    // the ones it leaves to the second (defer_list[0 .. S)) and third (defer_list[S .. 2 S)), which look at nothing else.
+    const uint32_t n_work = TIER > 0 ? defer_cnt[TIER - 1] : (win_list ? 2u * *win_count : S);
     for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
-        const uint32_t s = win_list ? 2u * win_list[wk >> 1] + (wk & 1u) : wk;
+        const uint32_t s = TIER > 0 ? defer_list[(size_t) (TIER - 1) * S + wk] : (win_list ? 2u * win_list[wk >> 1] + (wk & 1u) : wk);
         const uint32_t n = seg_cnt[s], base = seg_off[s], nc = n_clusters[s];
 #ifdef ECAL_PHASE_PROF
         unsigned long long bo_t__ = __builtin_amdgcn_s_memtime();
@@ -138,11 +140,15 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
                          : (n <= BO_CAP2 && nc <= BoLayout<BO_CAP2>::NCAP) ? 1
                          : (n <= BO_CAP3 && nc <= BoLayout<BO_CAP3>::NCAP) ? 2 : 3;
         if (tier != TIER) {
-            if (TIER == 2 && tier == 3) {
-                for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
-                if (tid == 0) status[s] = 1;
+            if constexpr (TIER == 0) {
+                if (tier == 3) {
+                    for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
+                    if (tid == 0) status[s] = 1;
+                } else if (tid == 0) {
+                    defer_list[(size_t) (tier - 1) * S + atomicAdd(&defer_cnt[tier - 1], 1u)] = s;
+                }
             }
-            continue;
+            continue;   // (the later launches only see what was listed for them)
         }
         if (tid < 8) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure; [4]: LDS list slots handed out
         for (uint32_t i = tid; i < n; i += BO_T) {
@@ -489,6 +495,11 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
     if ((rc = ecal_ensure(ctx, ctx->bfs_lists, rows * (BO_MAXN * sizeof(uint16_t) + 1)))) return rc;
     uint16_t *lists = (uint16_t *) ctx->bfs_lists.ptr;
     uint8_t *cnt = (uint8_t *) (lists + rows * BO_MAXN);
+    // the segments the first launch leaves to the later ones: two counters, two lists of up to S entries
+    if ((rc = ecal_ensure(ctx, ctx->bfs_defer, (2 * (size_t) S + 4) * sizeof(uint32_t)))) return rc;
+    uint32_t *dcnt = (uint32_t *) ctx->bfs_defer.ptr, *dlist = dcnt + 4;
+    if (uint32_t *z = ecal_zero_words(ctx, st, 2)) dcnt = z;
+    else ECAL_HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 2 * sizeof(uint32_t), st));
     if (!ctx->bfs_attr_set) {
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP1, BO_T1, 0>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP1>::bytes));
@@ -501,11 +512,11 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
     // (The three launches are independent — a segment's size names its launch —, but starting the later ones on streams of
     // their own beside the first cost more in cross-stream waits than it saved: 0.74 against 0.65 ms per lock-step pass.)
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP1, BO_T1, 0>), dim3(grid1), dim3(BO_T1), BoLayout<BO_CAP1>::bytes, st, d_xy, d_seg_off,
-                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP2, BO_T2, 1>), dim3(grid2), dim3(BO_T2), BoLayout<BO_CAP2>::bytes, st, d_xy, d_seg_off,
-                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP3, BO_T2, 2>), dim3(grid3), dim3(BO_T2), BoLayout<BO_CAP3>::bytes, st, d_xy, d_seg_off,
-                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count);
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

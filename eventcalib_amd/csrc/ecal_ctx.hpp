@@ -38,6 +38,7 @@ struct ecal_ctx {
     ecal_devbuf tie_list, tie_order;  // ecal_extract_batch_exact_dev: windows with a tied median, their members' order
     ecal_devbuf bfs_host;   // staging of ecal_cluster_order
     ecal_devbuf bfs_lists;  // ecal_cluster_order_dev: neighbour lists of the range queries, one slice per workgroup
+    ecal_devbuf bfs_defer;  // ecal_cluster_order_dev: the segments the first launch leaves to the later ones
     ecal_devbuf fused_def;  // [4 + S] u32: count, then the windows the fused pass (ecal_fused.hip) did not carry to the end
     bool fused_pass = false;  // set by ecal_detect_fused_dev around its calls of the three stage functions: their first passes have run
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
@@ -68,7 +69,7 @@ struct ecal_ctx {
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos, &sl_order, &sl_order_big, &bucket_tab, &sort_scratch,
-                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &fused_def, &bfs_lists, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
+                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &fused_def, &bfs_lists, &bfs_defer, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
                 &host_rect[7], &host_rect[8], &host_rect[9], &host_rect[10],
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
