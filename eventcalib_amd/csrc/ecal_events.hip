@@ -81,17 +81,24 @@ __global__ void window_bounds_kernel(const uint8_t *__restrict__ rec, uint64_t n
     hi_out[s] = (uint32_t) (up < lo ? lo : up);
 }
 
-// exclusive scan of (hi - lo) over the windows; base[S] = total.  One block, S is small (<= ~1e6).
+// exclusive scan of (hi - lo) over the windows; base[S] = total.  One block (S is small, <= ~1e6), eight windows per thread
+// and round: the rounds are a dependent chain of global loads and barriers, so there should be few of them.
 __global__ __launch_bounds__(1024) void window_base_kernel(const uint32_t *__restrict__ lo,
                                                            const uint32_t *__restrict__ hi, uint32_t S,
                                                            uint32_t *__restrict__ base) {
+    constexpr uint32_t PER = 8;
     __shared__ uint32_t red[17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (uint32_t s0 = 0; s0 < S; s0 += 1024) {
-        const uint32_t s = s0 + threadIdx.x;
-        const uint32_t v = (s < S) ? hi[s] - lo[s] : 0u;
-        uint32_t inc = v;
+    for (uint32_t s0 = 0; s0 < S; s0 += 1024 * PER) {
+        const uint32_t s = s0 + threadIdx.x * PER;
+        uint32_t v[PER], mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            v[k] = (s + k < S) ? hi[s + k] - lo[s + k] : 0u;
+            mine += v[k];
+        }
+        uint32_t inc = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = __shfl_up(inc, d, 64);
@@ -106,7 +113,12 @@ __global__ __launch_bounds__(1024) void window_base_kernel(const uint32_t *__res
             if (w < wave) pre += x;
             tot += x;
         }
-        if (s < S) base[s] = carry + pre + inc - v;
+        uint32_t run = carry + pre + inc - mine;
+#pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            if (s + k < S) base[s + k] = run;
+            run += v[k];
+        }
         carry += tot;
         __syncthreads();
     }
