@@ -19,20 +19,21 @@
 //      pops in Clusters[c]'s order.
 // Which clusters are wanted: all, those with a tied median (own test), or those the caller marked (only_tied = 0 / 1 / 2).
 #include <algorithm>
+#include <type_traits>
 #include "ecal_ctx.hpp"
 
 #pragma clang fp contract(off)
 
 namespace ecal {
 
-// Three launches.  The first takes segments of <= 768 points (the pixel DBSCAN's first tier too) and <= 256 clusters in 26 KB
-// of LDS with 256 threads: 6 workgroups per CU — the pass is latency bound, workgroups in flight pay.  The second (<= 2048
+// Three launches.  The first takes segments of <= 768 points (the pixel DBSCAN's first tier too) and <= 256 clusters in 20 KB
+// of LDS with 256 threads: 8 workgroups per CU — the pass is latency bound, workgroups in flight pay.  The second (<= 2048
 // points) and third (<= 4096 points, <= 2048 clusters: 141 KB, one workgroup per CU) run 1024 threads: the few segments that
 // reach them (windows grown by the adaptive policy) are on the critical path of a lock-step pass, where the latency of ONE
 // segment counts.
 constexpr int BO_T1 = 256, BO_T2 = 1024;
 constexpr uint32_t BO_CAP1 = 768, BO_CAP2 = 2048, BO_CAP3 = 4096;
-constexpr uint32_t BO_WG1 = 6, BO_WG2 = 1, BO_WG3 = 1;   // workgroups per CU
+constexpr uint32_t BO_WG1 = 8, BO_WG2 = 1, BO_WG3 = 1;   // workgroups per CU
 constexpr uint32_t BO_WAVE_MIN = 32;     // clusters of at least this many members: a wave runs the queue (a lane per neighbour)
 constexpr uint32_t BO_MAXN = 64;         // hits per range query kept (a disc of radius 4 holds 48 other pixels)
 // Range-query lists kept in LDS (handed out first come first served; the rest go to global scratch).  The first tier keeps a
@@ -45,9 +46,12 @@ template <uint32_t CAP>
 struct BoLayout {
     static constexpr uint32_t NCAP = CAP == BO_CAP1 ? 256u : 2048u;       // clusters per segment
     static constexpr uint32_t POOL = CAP == BO_CAP1 ? 8u : (CAP == BO_CAP2 ? 640u : 168u);
-    static constexpr size_t px_off = 0;                                   // f64[CAP]
-    static constexpr size_t py_off = px_off + 8 * CAP;                    // f64[CAP]
-    static constexpr size_t child_off = py_off + 8 * CAP;                 // u32[2 CAP]: children (left, right) of node i
+    // coordinates: the first tier holds them as floats and takes only segments whose doubles ARE floats (pixels are) — read
+    // back and widened they are the same numbers, and 6 KB less LDS is two more workgroups per CU; the rest keep doubles
+    static constexpr size_t CB = CAP == BO_CAP1 ? 4 : 8;
+    static constexpr size_t px_off = 0;                                   // f32 | f64 [CAP]
+    static constexpr size_t py_off = px_off + CB * CAP;                   // f32 | f64 [CAP]
+    static constexpr size_t child_off = py_off + CB * CAP;                // u32[2 CAP]: children (left, right) of node i
     static constexpr size_t lab_off = child_off + 8 * CAP;                // i16[CAP]
     static constexpr size_t queue_off = lab_off + 2 * CAP;                // u16[CAP]: the clusters' queues, back to back
     static constexpr size_t qbase_off = queue_off + 2 * CAP;              // u32[NCAP + 1]: members per cluster, then offsets
@@ -90,7 +94,7 @@ __device__ __forceinline__ bool bo_block_any(bool v, uint32_t *flag, uint32_t &r
 
 // status: 0 taken; 1 not taken at all (see ecal.h).  TIER 0, 1, 2: the three launches (a segment's size names its launch)
 template <uint32_t CAP, int T, int TIER>
-__global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
+__global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
                                                             const uint32_t *__restrict__ seg_cnt, uint32_t S, double eps,
                                                             const int32_t *__restrict__ labels,
                                                             const uint32_t *__restrict__ n_clusters, int32_t *__restrict__ order,
@@ -100,8 +104,11 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
                                                             const uint32_t *__restrict__ win_count,
                                                             uint32_t *__restrict__ defer_list, uint32_t *__restrict__ defer_cnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double *const px = reinterpret_cast<double *>(smem + BoLayout<CAP>::px_off);
-    double *const py = reinterpret_cast<double *>(smem + BoLayout<CAP>::py_off);
+    using Coord = typename std::conditional<BoLayout<CAP>::CB == 4, float, double>::type;
+    Coord *const px = reinterpret_cast<Coord *>(smem + BoLayout<CAP>::px_off);
+    Coord *const py = reinterpret_cast<Coord *>(smem + BoLayout<CAP>::py_off);
+    auto X = [&](uint32_t i) { return (double) px[i]; };
+    auto Y = [&](uint32_t i) { return (double) py[i]; };
     uint32_t *const child = reinterpret_cast<uint32_t *>(smem + BoLayout<CAP>::child_off);
     int16_t *const lab = reinterpret_cast<int16_t *>(smem + BoLayout<CAP>::lab_off);
     uint16_t *const queue = reinterpret_cast<uint16_t *>(smem + BoLayout<CAP>::queue_off);
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
         const int tier = (n <= BO_CAP1 && nc <= BoLayout<BO_CAP1>::NCAP) ? 0
                          : (n <= BO_CAP2 && nc <= BoLayout<BO_CAP2>::NCAP) ? 1
                          : (n <= BO_CAP3 && nc <= BoLayout<BO_CAP3>::NCAP) ? 2 : 3;
-        if (tier != TIER) {
+        if (TIER > 0 ? (n > CAP || nc > BoLayout<CAP>::NCAP) : tier != 0) {   // (the later launches take what was listed for them)
             if constexpr (TIER == 0) {
                 if (tier == 3) {
                     for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
@@ -148,13 +155,15 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
                     defer_list[(size_t) (tier - 1) * S + atomicAdd(&defer_cnt[tier - 1], 1u)] = s;
                 }
             }
-            continue;   // (the later launches only see what was listed for them)
+            continue;
         }
-        if (tid < 8) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure; [4]: LDS list slots handed out
+        if (tid < 8) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure; [4]: LDS list slots handed out; [5]: not floats
+        bool inexact = false;
         for (uint32_t i = tid; i < n; i += BO_T) {
             const double2 p = reinterpret_cast<const double2 *>(xy)[base + i];
-            px[i] = p.x;
-            py[i] = p.y;
+            px[i] = (Coord) p.x;
+            py[i] = (Coord) p.y;
+            if (BoLayout<CAP>::CB == 4 && ((double) px[i] != p.x || (double) py[i] != p.y)) inexact = true;
             lab[i] = (int16_t) labels[base + i];   // (-1 or < n_clusters <= CAP)
             child[2 * i] = BO_NONE;
             child[2 * i + 1] = BO_NONE;
@@ -163,6 +172,14 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
         for (uint32_t c = tid; c < nc; c += BO_T) seed[c] = BO_NONE;
         for (uint32_t w = tid; w < (n + 31u) / 32u; w += BO_T) inq[w] = 0;
         __syncthreads();
+        if constexpr (BoLayout<CAP>::CB == 4) {   // coordinates that are not floats: the second launch keeps doubles
+            if (inexact) red[5] = 1;
+            __syncthreads();
+            if (red[5]) {
+                if (tid == 0) defer_list[atomicAdd(&defer_cnt[0], 1u)] = s;
+                continue;
+            }
+        }
         BO_MARK(0);
         // members per cluster, the clusters' seeds (= smallest pid), the clusters' member lists (in queue[], for the tie test)
         for (uint32_t i = tid; i < n; i += BO_T) {
@@ -240,13 +257,13 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
                 // the norms' order (Vector2d::norm() = sqrt(x^2 + y^2)): where both squared norms are whole numbers (integer
                 // pixels) they order exactly like their roots — the square root is injective on integers below 2^53 —, and the
                 // two square roots per pair are only taken otherwise
-                const double di = px[i] * px[i] + py[i] * py[i];
+                const double di = X(i) * X(i) + Y(i) * Y(i);
                 const bool whole_i = di == floor(di);
                 const double ki = __dsqrt_rn(di);
                 uint32_t rank = 0, eq = 0;
                 for (uint32_t t = 0; t < m; t++) {
                     const uint32_t j = queue[qb + t];
-                    const double dj = px[j] * px[j] + py[j] * py[j];
+                    const double dj = X(j) * X(j) + Y(j) * Y(j);
                     bool lt, same;
                     if (whole_i && dj == floor(dj)) {
                         lt = dj < di;
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
                 if (placed[u]) continue;
                 const uint32_t i = tid + u * BO_T, c = cur[u];
                 const bool dy = dep[u] & 1u;
-                const double v = dy ? py[i] : px[i], cv = dy ? py[c] : px[c];
+                const double v = dy ? Y(i) : X(i), cv = dy ? Y(c) : X(c);
                 at[u] = 2 * c + (v < cv ? 0u : 1u);   // left iff pos[dir] < node->pos[dir] (kdtree.cpp:128-131)
                 atomicMin(&child[at[u]], i);
                 active = true;
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
         for (int u = 0; u < BO_PPT; u++) {
             const uint32_t i = tid + u * BO_T;
             if (i >= n || lab[i] < 0 || seed[lab[i]] == BO_NONE - 1u) continue;
-            const double qx = px[i], qy = py[i];
+            const double qx = X(i), qy = Y(i);
             const uint32_t slot = atomicAdd(&red[4], 1u);
             const bool in_lds = slot < BO_POOL;
             slotmap[i] = in_lds ? (uint16_t) slot : (uint16_t) 0xFFFFu;
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
             uint32_t node = 0, dir = 0;
             for (;;) {
                 while (node != BO_NONE) {
-                    const double ddx = px[node] - qx, ddy = py[node] - qy;
+                    const double ddx = X(node) - qx, ddy = Y(node) - qy;
                     double d2 = 0;
                     d2 += ddx * ddx;   // dist_sq += SQ(node->pos[i] - pos[i]), i ascending
                     d2 += ddy * ddy;
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(T) void cluster_order_kernel(const double *__restri
                         if (cnt < BO_MAXN) out[cnt] = (uint16_t) node;
                         cnt++;
                     }
-                    const double dx = dir ? (qy - py[node]) : (qx - px[node]);
+                    const double dx = dir ? (qy - Y(node)) : (qx - X(node));
                     const uint32_t l = child[2 * node], r = child[2 * node + 1];
                     const uint32_t nearc = dx <= 0.0 ? l : r, farc = dx <= 0.0 ? r : l;
                     if (fabs(dx) < eps && farc != BO_NONE) {
