@@ -62,6 +62,7 @@ struct DetGlobal {
     __device__ __forceinline__ void set_norm(uint32_t li, double v) const { norms[li] = v; }
     static constexpr bool INT_PIXELS = false;
     static constexpr uint32_t REP_TIE = 0x80000000u;   // (ORD) flag on a representative whose rank has an equal-norm rival
+    static constexpr uint32_t REP_BAD = 0x40000000u;   // (ORD) ... and whose cluster has no usable member order
     static constexpr uint32_t IDX_MASK = 0xFFFFFFFFu, IDXB = 0u;
     static constexpr int J = 1;
     static constexpr uint32_t MAXC = 0;
@@ -77,6 +78,7 @@ struct DetLdsT {
     static constexpr uint32_t IDXB = PTS_ > 2048u ? 12u : 11u;   // bits of the window-local point index in a member word
     static constexpr uint32_t IDX_MASK = (1u << IDXB) - 1u;
     static constexpr uint32_t REP_TIE = 0x8000u;                  // (ORD) flag on a representative (u16, point indices < 2^12)
+    static constexpr uint32_t REP_BAD = 0x4000u;
     static constexpr int J = (int) ((PTS_ + 255u) / 256u);        // points per thread at most
     static constexpr uint32_t MAXC = MAXC_;
     uint32_t *pts;  // x | y << 16, two's complement int16 each (exact: the staged path is taken for integer pixels only)
@@ -439,24 +441,29 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         if (window_tied && tie_list) return;
     }
     if constexpr (ORD) {
-        // the flagged clusters, a thread each: members into the reference's order (members[] is free from here on), the
-        // library's nth_element on them.  Without a usable order (segment not taken by ecal_cluster_order_dev) the smaller
-        // pid stays.
+        // the flagged clusters: members into the reference's order (members[] is free from here on; a thread per POINT
+        // scatters itself to its position), then the library's nth_element on them, a thread per cluster.  Without a usable
+        // order (segment not taken by ecal_cluster_order_dev) the smaller pid stays.
         for (int pol = 0; pol < 2; pol++) {
             const int32_t *ord = pol ? ord1 : ord0;
+            for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) {
+                const int32_t kl = st.kept[base[pol] + i];
+                if (kl < 0) continue;
+                const uint32_t rv = st.rep[kb[pol] + kl];
+                if (!(rv & ST::REP_TIE)) continue;
+                const int32_t p = ord ? ord[i] : -1;
+                if (p < 0 || (uint32_t) p >= st.ksize[kb[pol] + kl]) st.rep[kb[pol] + kl] = rv | ST::REP_BAD;   // (every writer: the same value)
+                else st.members[base[pol] + st.koff[kb[pol] + kl] + (uint32_t) p] = i;
+            }
+        }
+        __syncthreads();
+        for (int pol = 0; pol < 2; pol++) {
             for (uint32_t k = tid; k < nk[pol]; k += DET_T) {
                 const uint32_t rv = st.rep[kb[pol] + k];
                 if (!(rv & ST::REP_TIE)) continue;
-                uint32_t pick = rv & ~ST::REP_TIE;
+                uint32_t pick = rv & ~(ST::REP_TIE | ST::REP_BAD);
                 const uint32_t m = st.ksize[kb[pol] + k], first = base[pol] + st.koff[kb[pol] + k];
-                bool usable = ord != nullptr;
-                for (uint32_t t = 0; usable && t < m; t++) {
-                    const uint32_t i = st.sorted[first + t];
-                    const int32_t p = ord[i];
-                    if (p < 0 || (uint32_t) p >= m) usable = false;
-                    else st.members[first + (uint32_t) p] = i;
-                }
-                if (usable) {
+                if (!(rv & ST::REP_BAD)) {
                     const uint32_t r = ref_nth_element(st, base[pol], &st.members[first], m, m / 2u);
                     if (r != ~0u) pick = r;
                 }
