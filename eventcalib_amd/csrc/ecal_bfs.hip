@@ -131,9 +131,28 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
     // win_list: only the two segments (2 w, 2 w + 1) of the listed windows w.  The first launch looks at all of them and lists
     // the ones it leaves to the second (defer_list[0 .. S)) and third (defer_list[S .. 2 S)), which look at nothing else.
     const uint32_t n_work = TIER > 0 ? defer_cnt[TIER - 1] : (win_list ? 2u * *win_count : S);
-    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
-        const uint32_t s = TIER > 0 ? defer_list[(size_t) (TIER - 1) * S + wk] : (win_list ? 2u * win_list[wk >> 1] + (wk & 1u) : wk);
-        const uint32_t n = seg_cnt[s], base = seg_off[s], nc = n_clusters[s];
+    // A segment starts with a chain of dependent global reads — which segment, its extent, then its points — that is a third of
+    // the time a workgroup spends on it: the first two links are fetched one and two segments ahead.
+    auto seg_of = [&](uint32_t w) -> uint32_t {
+        return TIER > 0 ? defer_list[(size_t) (TIER - 1) * S + w] : (win_list ? 2u * win_list[w >> 1] + (w & 1u) : w);
+    };
+    const uint32_t G = gridDim.x;
+    uint32_t s_cur = blockIdx.x < n_work ? seg_of(blockIdx.x) : 0u, n_cur = 0, base_cur = 0, nc_cur = 0;
+    if (blockIdx.x < n_work) {
+        n_cur = seg_cnt[s_cur];
+        base_cur = seg_off[s_cur];
+        nc_cur = n_clusters[s_cur];
+    }
+    uint32_t s_nxt = blockIdx.x + G < n_work ? seg_of(blockIdx.x + G) : 0u;
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += G) {
+        const uint32_t s = s_cur, n = n_cur, base = base_cur, nc = nc_cur;
+        s_cur = s_nxt;
+        if (wk + G < n_work) {
+            n_cur = seg_cnt[s_cur];
+            base_cur = seg_off[s_cur];
+            nc_cur = n_clusters[s_cur];
+        }
+        s_nxt = wk + 2u * G < n_work ? seg_of(wk + 2u * G) : 0u;
 #ifdef ECAL_PHASE_PROF
         unsigned long long bo_t__ = __builtin_amdgcn_s_memtime();
 #endif
@@ -159,7 +178,9 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
         }
         if (tid < 8) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure; [4]: LDS list slots handed out; [5]: not floats
         bool inexact = false;
-        for (uint32_t i = tid; i < n; i += BO_T) {
+        uint32_t marked = 0;   // only_tied == 2: bit u = the caller's mark on point tid + u BO_T (read here, with the point)
+        for (uint32_t i = tid, u = 0; i < n; i += BO_T, u++) {
+            if (only_tied == 2 && order[base + i] == -3) marked |= 1u << u;
             const double2 p = reinterpret_cast<const double2 *>(xy)[base + i];
             px[i] = (Coord) p.x;
             py[i] = (Coord) p.y;
@@ -219,8 +240,8 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
             uint32_t *const tie = child + CAP;            // [nc] (the tree is built later)
             for (uint32_t c = tid; c < nc; c += BO_T) tie[c] = 0;
             __syncthreads();
-            for (uint32_t i = tid; i < n; i += BO_T)
-                if (lab[i] >= 0 && order[base + i] == -3) tie[lab[i]] = 1;
+            for (uint32_t i = tid, u = 0; i < n; i += BO_T, u++)
+                if (lab[i] >= 0 && ((marked >> u) & 1u)) tie[lab[i]] = 1;
             __syncthreads();
             bool any_tie = false;
             for (uint32_t c = tid; c < nc; c += BO_T) {
