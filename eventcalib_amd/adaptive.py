@@ -87,8 +87,10 @@ def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_thres
     torch.cuda.synchronize(events.device)   # the passes run on the context's own stream: `events` must be complete
     n_ev = events.numel() // 25
     span = max(end_time - start_time, 1e-9)
-    # a pass covers one window of <= 10 steps per piece: twice the mean event count of such spans, to start with
-    cap = int(min(n_ev, piece_num * (2 * 10 * motion_time_step * n_ev / span + 1024)))
+    # a pass covers, per piece, one window of <= 10 steps and the windows that can follow it (accept / slide / grow: together
+    # <= 16 steps): twice the mean event count of such spans, to start with
+    cap_max = min(4 * n_ev + 4096, 2 ** 32 - 64)     # (the four windows of a piece overlap: a pass can cover events more than once)
+    cap = int(min(cap_max, piece_num * (2 * 16 * motion_time_step * n_ev / span + 4096)))
     max_keys = int(span / (8 * motion_time_step)) + piece_num + 64   # one keyframe per window + gap at the very most
     while True:
         try:
@@ -97,9 +99,9 @@ def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_thres
                                                                     max_keys, eps, minpts, 5, rows, cols, max_passes=max_passes)
             break
         except capi.EcalError as err:
-            if err.status != -6 or (cap >= n_ev and max_keys > 4 * n_ev):
+            if err.status != -6 or (cap >= cap_max and max_keys > 4 * n_ev):
                 raise
-            cap, max_keys = min(n_ev, 2 * cap), 2 * max_keys
+            cap, max_keys = min(cap_max, 2 * cap), 2 * max_keys
     return dict(time=t, duration=d, events_num=e, features=f, steps=passes, windows=windows)
 
 

@@ -78,13 +78,48 @@ struct AdaptiveArrays {
     unsigned long long *windows;                          // windows evaluated
 };
 
-__global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_time, double ln, AdaptiveArrays st, double *t0, double *t1) {
+// The window that follows (f, s2) under outcome o of eventCameraCalib.cpp:61-62 (0: keyframe accepted), :67-69,75-77 (1: slide),
+// :70-71,78-79 (2: grow) — the ONE place these sums are written, so that a window evaluated ahead of time is bit for bit the
+// window the policy arrives at.
+constexpr int AD_SPEC = 4;   // window slots per piece and pass: the current window and its three possible successors
+__device__ __forceinline__ void next_window(int o, double f, double s2, double mts, double &nf, double &ns) {
+    const double ln = 3 * mts, gap = 5 * mts;
+    if (o == 0) {
+        nf = s2 + gap;
+        ns = nf + ln;
+    } else if (o == 1) {
+        nf = f + mts;
+        ns = nf + ln;
+    } else {
+        nf = f;
+        ns = s2 + mts;
+    }
+}
+
+// slots 4 k .. 4 k + 3 of piece k: its current window (f, s2) — empty (+inf, -inf: every stage skips it) when the piece is
+// finished — and the three windows that can follow it, each empty when it would end the piece (:50) or cannot occur (a window
+// longer than three lengths never grows)
+__device__ __forceinline__ void write_slots(uint32_t k, bool act, double f, double s2, double hi, double mts, double *t0, double *t1) {
+    t0[AD_SPEC * k] = act ? f : INFINITY;
+    t1[AD_SPEC * k] = act ? s2 : -INFINITY;
+    const double ln = 3 * mts;
+    for (int o = 0; o < 3; o++) {
+        double nf, ns;
+        next_window(o, f, s2, mts, nf, ns);
+        const bool can = act && ns < hi && !(o == 2 && (s2 - f) > 3 * ln);
+        t0[AD_SPEC * k + 1 + o] = can ? nf : INFINITY;
+        t1[AD_SPEC * k + 1 + o] = can ? ns : -INFINITY;
+    }
+}
+
+__global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_time, double mts, AdaptiveArrays st, double *t0, double *t1) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) {
         st.counters[0] = st.counters[1] = st.counters[2] = st.counters[3] = 0;
         *st.windows = 0;
     }
     if (k >= P) return;
+    const double ln = 3 * mts;
     const double step = (end_time - start_time) / (double) P;  // eventCameraCalib.cpp:168-179
     const double hi = end_time - step * (double) k, first = end_time - step * (double) (k + 1), second = first + ln;
     st.bound_hi[k] = hi;
@@ -94,13 +129,16 @@ __global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_t
     st.active[k] = act ? 1u : 0u;
     st.have_ref[k] = 0;
     st.ref_t[k] = 0;
-    t0[k] = act ? first : INFINITY;
-    t1[k] = act ? second : -INFINITY;
+    write_slots(k, act, first, second, hi, mts, t0, t1);
 }
 
-// one 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window.  The rows' line fits (a
-// 3 x 3 Jacobi eigen-decomposition each, the bulk of the work) run on one lane per row; lane 0 does the rest.
-__global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t pass, const uint32_t *__restrict__ win_info,
+// One 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window, n_levels (1 or 2) times:
+// the second time on the successor window that the first verdict selects among the three evaluated beside the current one.
+// (A lock-step pass costs the latency of one workgroup through ~25 kernels whatever the number of windows — 0.63 ms for 1270,
+// 0.80 ms for 4096 —, and a piece's windows are a dependent chain: two links per pass for four times the windows.)
+// The rows' line fits (a 3 x 3 Jacobi eigen-decomposition each, the bulk of the work) run on one lane per row; lane 0 does the rest.
+__global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t level0, uint32_t n_levels,
+                                     const uint32_t *__restrict__ win_info,
                                      const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
                                      const double *__restrict__ cand_xyr, const int32_t *__restrict__ order,
                                      const uint32_t *__restrict__ found, AdaptiveArrays st, double mts, uint32_t thr_events,
@@ -109,88 +147,98 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                                      double *__restrict__ t1, const int *__restrict__ overflow) {
     const uint32_t k = blockIdx.x, lane = threadIdx.x;
     __shared__ double dir[AD_MAX_ROWS][2];
+    __shared__ double sh_f, sh_s2;
+    __shared__ int sh_act, sh_o;
     if (k == 0 && lane == 0 && *overflow) st.counters[3] = 1;  // the slicer clears its flag at every call: keep it until the host looks
     if (k >= P || !st.active[k]) return;
     const uint32_t M = rows * cols;
-    const double ln = 3 * mts, gap = 5 * mts;
-    const double f = st.first[k], s2 = st.second[k];
-    const uint32_t cnt = seg_cnt[2 * k] + seg_cnt[2 * k + 1];  // EventFrame::eventsNum()
-    const bool ok = win_info[4 * k + 3] == 0 && found[k];     // extractFeatures() == true
-    bool accepted = false;
-    if (ok) {   // (uniform over the workgroup)
-        const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * k];
-        const int32_t *ord = order + (size_t) k * M;
-        if (lane < rows) row_direction(xyr, ord + lane * cols, cols, dir[lane][0], dir[lane][1]);
-        __syncthreads();
+    const double ln = 3 * mts;
+    if (lane == 0) {
+        sh_f = st.first[k];
+        sh_s2 = st.second[k];
     }
-    if (lane != 0) return;
-    if (ok) {
-        const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * k];
-        const int32_t *ord = order + (size_t) k * M;
-        const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
-        accepted = true;
-        if (st.have_ref[k]) {  // EventCalibIni::track: median row angle / time distance
-            double theta[AD_MAX_ROWS];
-            const double *rd = st.ref_dir + (size_t) k * rows * 2;
-            for (uint32_t i = 0; i < rows; i++) {
-                const double c = (rd[2 * i] * dir[i][0] + rd[2 * i + 1] * dir[i][1]) /
-                                 (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[i][0], dir[i][1]));
-                theta[i] = acos(c);   // (not clamped, as the reference: a cosine rounded above 1 gives NaN and the frame fails the test)
-            }
-            double med = theta[0];
-            bool any_nan = false;
-            for (uint32_t i = 0; i < rows; i++) any_nan = any_nan || (theta[i] != theta[i]);
-            for (uint32_t i = 0; i < rows; i++) {  // order statistic rows / 2 (std::nth_element)
-                uint32_t rank = 0;
-                for (uint32_t j = 0; j < rows; j++) rank += (theta[j] < theta[i] || (theta[j] == theta[i] && j < i)) ? 1u : 0u;
-                if (rank == rows / 2) med = theta[i];
-            }
-            // (with a NaN among the angles std::nth_element's result is unspecified; the build rejects the frame)
-            accepted = !any_nan && med / fabs(t_mid - st.ref_t[k]) < (5e-4 * M_PI) / mts;
+    uint32_t w = AD_SPEC * k;   // slot of the window under evaluation
+    bool act = true;
+    for (uint32_t level = 0; level < n_levels; level++) {
+        __syncthreads();
+        const double f = sh_f, s2 = sh_s2;
+        const uint32_t cnt = seg_cnt[2 * w] + seg_cnt[2 * w + 1];  // EventFrame::eventsNum()
+        const bool ok = win_info[4 * w + 3] == 0 && found[w];     // extractFeatures() == true
+        if (ok) {   // (uniform over the workgroup)
+            const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
+            const int32_t *ord = order + (size_t) w * M;
+            if (lane < rows) row_direction(xyr, ord + lane * cols, cols, dir[lane][0], dir[lane][1]);
         }
-        if (accepted) {
-            const uint32_t at = atomicAdd(&st.counters[1], 1u);
-            if (at < max_keys) {
-                kf_time[at] = t_mid;
-                kf_dur[2 * at] = f;
-                kf_dur[2 * at + 1] = s2;
-                kf_events[at] = (int32_t) cnt;
-                for (uint32_t c = 0; c < M; c++) {
-                    kf_feat[3 * ((size_t) at * M + c)] = xyr[3 * (size_t) ord[c]];
-                    kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[3 * (size_t) ord[c] + 1];
-                    kf_feat[3 * ((size_t) at * M + c) + 2] = xyr[3 * (size_t) ord[c] + 2];
+        __syncthreads();
+        if (lane == 0) {
+            bool accepted = false;
+            if (ok) {
+                const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
+                const int32_t *ord = order + (size_t) w * M;
+                const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
+                accepted = true;
+                if (st.have_ref[k]) {  // EventCalibIni::track: median row angle / time distance
+                    double theta[AD_MAX_ROWS];
+                    const double *rd = st.ref_dir + (size_t) k * rows * 2;
+                    for (uint32_t i = 0; i < rows; i++) {
+                        const double c = (rd[2 * i] * dir[i][0] + rd[2 * i + 1] * dir[i][1]) /
+                                         (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[i][0], dir[i][1]));
+                        theta[i] = acos(c);   // (not clamped, as the reference: a cosine rounded above 1 gives NaN and the frame fails the test)
+                    }
+                    double med = theta[0];
+                    bool any_nan = false;
+                    for (uint32_t i = 0; i < rows; i++) any_nan = any_nan || (theta[i] != theta[i]);
+                    for (uint32_t i = 0; i < rows; i++) {  // order statistic rows / 2 (std::nth_element)
+                        uint32_t rank = 0;
+                        for (uint32_t j = 0; j < rows; j++) rank += (theta[j] < theta[i] || (theta[j] == theta[i] && j < i)) ? 1u : 0u;
+                        if (rank == rows / 2) med = theta[i];
+                    }
+                    // (with a NaN among the angles std::nth_element's result is unspecified; the build rejects the frame)
+                    accepted = !any_nan && med / fabs(t_mid - st.ref_t[k]) < (5e-4 * M_PI) / mts;
+                }
+                if (accepted) {
+                    const uint32_t at = atomicAdd(&st.counters[1], 1u);
+                    if (at < max_keys) {
+                        kf_time[at] = t_mid;
+                        kf_dur[2 * at] = f;
+                        kf_dur[2 * at + 1] = s2;
+                        kf_events[at] = (int32_t) cnt;
+                        for (uint32_t c = 0; c < M; c++) {
+                            kf_feat[3 * ((size_t) at * M + c)] = xyr[3 * (size_t) ord[c]];
+                            kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[3 * (size_t) ord[c] + 1];
+                            kf_feat[3 * ((size_t) at * M + c) + 2] = xyr[3 * (size_t) ord[c] + 2];
+                        }
+                    }
+                    st.have_ref[k] = 1;
+                    st.ref_t[k] = t_mid;
+                    double *rd = st.ref_dir + (size_t) k * rows * 2;
+                    for (uint32_t i = 0; i < rows; i++) {
+                        rd[2 * i] = dir[i][0];
+                        rd[2 * i + 1] = dir[i][1];
+                    }
                 }
             }
-            st.have_ref[k] = 1;
-            st.ref_t[k] = t_mid;
-            double *rd = st.ref_dir + (size_t) k * rows * 2;
-            for (uint32_t i = 0; i < rows; i++) {
-                rd[2 * i] = dir[i][0];
-                rd[2 * i + 1] = dir[i][1];
-            }
+            const int o = accepted ? 0 : ((cnt > thr_events || (s2 - f) > 3 * ln) ? 1 : 2);
+            double nf, ns;
+            next_window(o, f, s2, mts, nf, ns);
+            sh_f = nf;
+            sh_s2 = ns;
+            sh_o = o;
+            sh_act = ns < st.bound_hi[k] ? 1 : 0;  // :50
+            atomicMax(&st.counters[2], level0 + level + 1u);
+            atomicAdd(st.windows, 1ull);
         }
+        __syncthreads();
+        act = sh_act != 0;
+        if (!act) break;
+        w = AD_SPEC * k + 1u + (uint32_t) sh_o;   // the window just chosen: evaluated in this pass, in its successor slot
     }
-    // eventCameraCalib.cpp:61-62 (success), :67-69,75-77 (slide), :70-71,78-79 (grow)
-    double nf, ns;
-    if (accepted) {
-        nf = s2 + gap;
-        ns = nf + ln;
-    } else if (cnt > thr_events || (s2 - f) > 3 * ln) {
-        nf = f + mts;
-        ns = nf + ln;
-    } else {
-        nf = f;
-        ns = s2 + mts;
-    }
-    st.first[k] = nf;
-    st.second[k] = ns;
-    const bool act = ns < st.bound_hi[k];  // :50
+    if (lane != 0) return;
+    st.first[k] = sh_f;
+    st.second[k] = sh_s2;
     st.active[k] = act ? 1u : 0u;
-    t0[k] = act ? nf : INFINITY;
-    t1[k] = act ? ns : -INFINITY;
+    write_slots(k, act, sh_f, sh_s2, st.bound_hi[k], mts, t0, t1);
     if (act) atomicAdd(&st.counters[0], 1u);
-    atomicMax(&st.counters[2], pass + 1u);
-    atomicAdd(st.windows, 1ull);
 }
 
 }  // namespace
@@ -212,7 +260,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc;
-    const uint32_t S = P;
+    const uint32_t S = AD_SPEC * P;   // window slots per pass: every piece's current window and its three possible successors
     const size_t cap = (size_t) cap_points + 16;
     ecal_devbuf *B = ctx->host_pipe;  // roles as in ecal_detect_pass; 0 holds t0 and t1 back to back
     const size_t sizes[17] = {2ul * S * sizeof(double), 16, S * 4ul, S * 4ul, (S + 1) * 4ul, cap * 16, 2ul * S * 4, 2ul * S * 4, cap * 4,
@@ -249,13 +297,14 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     double *d_kt = (double *) ctx->adaptive_keys.ptr, *d_kd = d_kt + max_keyframes, *d_kf = d_kd + 2 * (size_t) max_keyframes;
     int32_t *d_ke = (int32_t *) (d_kf + 3 * (size_t) max_keyframes * M);
     double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
-    const double ln = 3 * ap->motion_time_step;
-    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, ap->start_time, ap->end_time, ln, a, d_t0, d_t1);
+    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, ap->start_time, ap->end_time, ap->motion_time_step, a, d_t0, d_t1);
     ECAL_HIP_TRY(ctx, hipMemsetAsync(B[16].ptr, 0, sizeof(int), st));
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..3] counters, [4] overflow flag
     const uint32_t check_every = ap->check_every ? ap->check_every : 8u;
-    const uint32_t max_passes = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
-    for (uint32_t pass = 0; pass < max_passes; pass++) {
+    // max_passes counts windows per piece (the lock-step passes of the one-window-per-pass form); a pass here evaluates two
+    const uint32_t max_levels = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
+    for (uint32_t pass = 0, level0 = 0; level0 < max_levels; pass++) {
+        const uint32_t n_levels = max_levels - level0 < 2u ? max_levels - level0 : 2u;
         ECAL_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st));  // pieces active after this pass
         if ((rc = ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                          (uint32_t *) B[4].ptr, st)))
@@ -275,12 +324,13 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
                                       (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
             return rc;
-        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, pass,
+        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, level0, n_levels,
                            (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
                            (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                            (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                            max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1, (const int *) B[16].ptr);
-        if (pass % check_every == check_every - 1 || pass + 1 == max_passes) {
+        level0 += n_levels;
+        if (pass % check_every == check_every - 1 || level0 >= max_levels) {
             ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
             if (h[3]) {

@@ -206,8 +206,10 @@ inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, 
     const uint64_t n = ecal_stream_size(es);
     const size_t M = (size_t) prm.rows * prm.cols;
     const double span = std::max(endTime - startTime, 1e-9);
-    // a pass covers one window of <= 10 steps per piece; doubled on ECAL_ERR_RANGE
-    uint64_t cap = std::min<uint64_t>(n, (uint64_t) (pieceNum * (20.0 * motionTimeStep * (double) n / span + 1024.0)));
+    // a pass covers, per piece, one window of <= 10 steps and its possible successors (together <= 16 steps); doubled on
+    // ECAL_ERR_RANGE
+    const uint64_t cap_max = std::min<uint64_t>(4 * n + 4096, 0xFFFFFFC0ull);   // (a piece's four windows overlap)
+    uint64_t cap = std::min<uint64_t>(cap_max, (uint64_t) (pieceNum * (32.0 * motionTimeStep * (double) n / span + 4096.0)));
     uint32_t max_keys = (uint32_t) (span / (8 * motionTimeStep)) + (uint32_t) pieceNum + 64;
     std::vector<double> t, d, f;
     std::vector<int32_t> e;
@@ -220,10 +222,10 @@ inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, 
         const int rc = ecal_detect_keyframes(ecal_host::thread_ctx(), ecal_stream_data(es), n, &ap, &prm, (uint32_t) cap, max_keys,
                                              t.data(), d.data(), e.data(), f.data(), &K, nullptr, nullptr);
         if (rc == ECAL_OK) break;
-        if (rc != ECAL_ERR_RANGE || (cap >= n && max_keys > (1u << 30)))
+        if (rc != ECAL_ERR_RANGE || (cap >= cap_max && max_keys > (1u << 30)))
             throw std::runtime_error(std::string("ecal_detect_keyframes: ") + ecal_strerror(rc) + " — " +
                                      ecal_last_error(ecal_host::thread_ctx()));
-        cap = std::min<uint64_t>(n, 2 * cap);
+        cap = std::min<uint64_t>(cap_max, 2 * cap);
         max_keys *= 2;
     }
     std::vector<KeyFrame> all(K);

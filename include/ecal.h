@@ -316,13 +316,16 @@ int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, 
  * (MultiProcess::process, event_camera_calib/test/eventCameraCalib.cpp:34-97: success / slide / grow rule :49-95) over
  * piece_num pieces of [start_time, end_time] (:168-179) with the keyframe gate of EventCalibIni::track (event_camera_calib/
  * src/EventCalibIni.cpp:23-97) against the previous keyframe of the window's own piece (the deterministic policy of
- * host/multi_process.hpp).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over the current
- * window of every piece + one policy kernel, enqueued back to back; the host reads a 4-byte counter every check_every
- * passes.  d_events: DEVICE-resident stream.  cap_points >= the events covered by the windows of any one pass
- * (ECAL_ERR_RANGE otherwise: call again with more).  Outputs (host), sorted by time stamp: kf_time [K], kf_duration
+ * host/multi_process.hpp).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over FOUR windows of
+ * every piece — its current one and the three that can follow it (accepted / slide / grow) — + one policy kernel that applies
+ * the rule twice, the second time to the successor the first verdict selects: two windows of a piece's chain per pass, same
+ * keyframes as one by one.  All enqueued back to back; the host reads a 4-byte counter every check_every passes.
+ * d_events: DEVICE-resident stream.  cap_points >= the events covered by the windows of any one pass — up to ~16 motion
+ * time steps per piece — (ECAL_ERR_RANGE otherwise: call again with more).  Outputs (host), sorted by time stamp: kf_time [K], kf_duration
  * [K][2], kf_events_num [K] (EventFrame::eventsNum()), kf_features [K][rows*cols][3] (x, y, radius in grid order);
- * *n_keyframes = K (ECAL_ERR_RANGE with the needed count if K > max_keyframes); *passes = lock-step passes that
- * evaluated a window, *windows = windows evaluated.  Synchronous; runs on the context's own stream: d_events must be
+ * *n_keyframes = K (ECAL_ERR_RANGE with the needed count if K > max_keyframes); *passes = the longest chain of windows
+ * a piece went through (the lock-step passes of the one-window-per-pass form; max_passes bounds it), *windows = windows the
+ * rule was applied to (the ones evaluated ahead and not taken do not count).  Synchronous; runs on the context's own stream: d_events must be
  * complete when the call is made (no pending writes on other streams). */
 typedef struct ecal_adaptive_params {
     double motion_time_step;             /* MotionTimeStep: window = 3 steps, gap after a keyframe = 5 steps */
