@@ -157,6 +157,7 @@ struct SliceWork {
     Idx *rep;        // [n] representative event of this event's (pixel, polarity), NONE if erased
     uint32_t *pos;   // [n] packed exclusive counts: low 16/.. see below (LDS) or two words (global)
     uint32_t *red;   // block-scan scratch (LDS)
+    uint32_t bend_words = 0;   // words of bend[] when it lives in LDS (else 0)
 };
 
 __device__ __forceinline__ uint32_t pixel_hash(double x, double y) {
@@ -306,7 +307,9 @@ __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint
                     }
                 }
                 __syncthreads();
-                reference_list_order<T>(w, m, wk.red);
+                // (bend[] — the counting sort's bucket ends, CAP + 4 words — is dead since step d: the small epochs' arrays)
+                if constexpr (GLOBAL) reference_list_order<T>(w, m, wk.red);
+                else reference_list_order<T, (sizeof(Idx) == 2 ? 10 : 0)>(w, m, wk.red, bend, wk.bend_words / 8u);   // (LDS tiers: <= 10 keys a thread)
                 for (uint32_t u = tid; u < m; u += T) w.cnt[w.cur[u]] = (rep[evk[u]] & ERASED) ? 0u : 1u;   // by list position
                 __syncthreads();
                 const uint32_t perq = (m + T - 1) / T, q0 = tid * perq;
@@ -415,6 +418,7 @@ __device__ __forceinline__ void slice_tier_window(unsigned char *smem, uint32_t 
     SliceWork<uint16_t> w;
     w.pts = reinterpret_cast<double2 *>(smem + L::pts_off);
     w.bend = reinterpret_cast<uint32_t *>(smem + L::bend_off);
+    w.bend_words = CAP + 4;
     w.pos = reinterpret_cast<uint32_t *>(smem + L::pos_off);
     w.sorted = reinterpret_cast<uint16_t *>(smem + L::sorted_off);
     w.rep = reinterpret_cast<uint16_t *>(smem + L::rep_off);

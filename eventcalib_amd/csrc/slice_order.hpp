@@ -107,58 +107,121 @@ __device__ __forceinline__ uint32_t block_exscan_u32(uint32_t v, uint32_t *red /
     return pre + inc - v;
 }
 
-template <int T>
-__device__ void reference_list_order(const OrderScratch w, uint32_t m, uint32_t *red) {
+// lds (optional): 8 lds_keys words of LDS (8-byte aligned) that are free during the call.  The epochs of up to lds_keys buckets
+// — with 541, six of the nine a set of ~2500 keys goes through — then keep all their arrays (and the hashes of their keys)
+// there: an epoch is six barrier-separated phases, each a round trip to its arrays, and from global memory those round trips
+// are what the general slicing tiers' order pass consists of.
+// h % B without the 64-bit division (a library call of ~200 instructions, asked four times per key and epoch before): for
+// B < 2^16, h = hi 2^32 + lo gives (hi % B) (2^32 % B) + lo % B < B^2 <= 2^32 - 2^17 + 1 + 2^16: three 32-bit remainders.
+__device__ __forceinline__ uint32_t ref_bucket_of(uint64_t h, uint64_t B, uint32_t two32_mod_b) {
+    if (B < 65536ull) {
+        const uint32_t b = (uint32_t) B;
+        return ((uint32_t) (h >> 32) % b * two32_mod_b + (uint32_t) h % b) % b;
+    }
+    return (uint32_t) (h % B);
+}
+
+// KPT > 0: no thread holds more than KPT keys (m <= KPT T) — a key's bucket is then worked out once per epoch and kept in a
+// register; KPT = 0: any m, the bucket is worked out where it is needed.
+template <int T, int KPT = 0>
+__device__ void reference_list_order(const OrderScratch w, uint32_t m, uint32_t *red, uint32_t *lds = nullptr, uint32_t lds_keys = 0) {
     const uint32_t tid = threadIdx.x;
+    OrderScratch l = w;   // the small epochs' arrays: h (2 words a key), cur, slot, cnt, bas, region, fa
+    if (lds_keys < 13u) lds = nullptr;
+    if (lds) {
+        l.h = reinterpret_cast<uint64_t *>(lds);
+        l.cur = lds + 2 * lds_keys;
+        l.slot = l.cur + lds_keys;
+        l.cnt = l.slot + lds_keys;
+        l.bas = l.cnt + lds_keys;
+        l.region = l.bas + lds_keys;
+        l.fa = l.region + lds_keys;
+        for (uint32_t u = tid; u < m && u < lds_keys; u += T) l.h[u] = w.h[u];
+        __syncthreads();
+    }
     uint32_t n_prev = 0;
+    bool prev_small = false;
     for (int e = 0; n_prev < m; e++) {
         const uint64_t B = ref_bucket_step(e);
         const uint32_t n_e = (uint64_t) m < B ? m : (uint32_t) B;
-        for (uint64_t b = tid; b < B; b += T) w.fa[b] = 0xFFFFFFFFu;
-        for (uint32_t q = tid; q < n_e; q += T) w.cnt[q] = 0;
+        const bool small = lds != nullptr && B <= lds_keys;
+        if (prev_small && !small) {   // the positions so far move to where the large epochs keep them
+            for (uint32_t u = tid; u < n_prev; u += T) w.cur[u] = l.cur[u];
+            __syncthreads();
+        }
+        const OrderScratch v = small ? l : w;
+        const uint32_t t32 = B < 65536ull ? (uint32_t) (0x100000000ull % B) : 0u;
+        constexpr int NK = KPT > 0 ? KPT : 1;
+        uint32_t hb[NK];   // (KPT > 0) the buckets of this thread's keys tid, tid + T, ...
+        if constexpr (KPT > 0) {
+#pragma unroll
+            for (int j = 0; j < KPT; j++) {
+                const uint32_t u = tid + (uint32_t) j * T;
+                hb[j] = u < n_e ? ref_bucket_of(v.h[u], B, t32) : 0u;
+            }
+        }
+        // the epoch's four passes over the keys: fn(u, bucket of u)
+        auto for_keys = [&](auto fn) {
+            if constexpr (KPT > 0) {
+#pragma unroll
+                for (int j = 0; j < KPT; j++) {
+                    const uint32_t u = tid + (uint32_t) j * T;
+                    if (u < n_e) fn(u, hb[j]);
+                }
+            } else {
+                for (uint32_t u = tid; u < n_e; u += T) fn(u, ref_bucket_of(v.h[u], B, t32));
+            }
+        };
+        for (uint64_t b = tid; b < B; b += T) v.fa[b] = 0xFFFFFFFFu;
+        for (uint32_t q = tid; q < n_e; q += T) v.cnt[q] = 0;
         __syncthreads();
         // first sequence position of every bucket
-        for (uint32_t u = tid; u < n_e; u += T) {
-            const uint32_t q = u < n_prev ? w.cur[u] : u;
-            atomicMin(&w.fa[w.h[u] % B], q);
-        }
+        for_keys([&](uint32_t u, uint32_t bk) {
+            const uint32_t q = u < n_prev ? v.cur[u] : u;
+            atomicMin(&v.fa[bk], q);
+        });
         __syncthreads();
         // members per bucket, counted at the bucket's first position; the arrival number is the member's slot
-        for (uint32_t u = tid; u < n_e; u += T) {
-            const uint32_t f = __hip_atomic_load(&w.fa[w.h[u] % B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w.slot[u] = atomicAdd(&w.cnt[f], 1u);
-        }
+        for_keys([&](uint32_t u, uint32_t bk) {
+            const uint32_t f = __hip_atomic_load(&v.fa[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.slot[u] = atomicAdd(&v.cnt[f], 1u);
+        });
         __syncthreads();
         // exclusive scan of the counts over the sequence positions: where a bucket's run starts in the sorted sequence
         {
             const uint32_t per = (n_e + T - 1) / T, q0 = tid * per;
             uint32_t sum = 0;
-            for (uint32_t q = q0; q < q0 + per && q < n_e; q++) sum += __hip_atomic_load(&w.cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t q = q0; q < q0 + per && q < n_e; q++) sum += __hip_atomic_load(&v.cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t tot;
             uint32_t ex = block_exscan_u32<T>(sum, red, &tot);
             for (uint32_t q = q0; q < q0 + per && q < n_e; q++) {
-                w.bas[q] = ex;
-                ex += __hip_atomic_load(&w.cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v.bas[q] = ex;
+                ex += __hip_atomic_load(&v.cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         __syncthreads();
-        for (uint32_t u = tid; u < n_e; u += T) {
-            const uint32_t q = u < n_prev ? w.cur[u] : u;
-            const uint32_t f = __hip_atomic_load(&w.fa[w.h[u] % B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w.region[w.bas[f] + w.slot[u]] = q;
-        }
+        for_keys([&](uint32_t u, uint32_t bk) {
+            const uint32_t q = u < n_prev ? v.cur[u] : u;
+            const uint32_t f = __hip_atomic_load(&v.fa[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v.region[v.bas[f] + v.slot[u]] = q;
+        });
         __syncthreads();
-        for (uint32_t u = tid; u < n_e; u += T) {
-            const uint32_t q = u < n_prev ? w.cur[u] : u;
-            const uint32_t f = __hip_atomic_load(&w.fa[w.h[u] % B], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t b0 = w.bas[f], c = __hip_atomic_load(&w.cnt[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for_keys([&](uint32_t u, uint32_t bk) {
+            const uint32_t q = u < n_prev ? v.cur[u] : u;
+            const uint32_t f = __hip_atomic_load(&v.fa[bk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t b0 = v.bas[f], c = __hip_atomic_load(&v.cnt[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t within = 0;
-            for (uint32_t i = 0; i < c; i++) within += (w.region[b0 + i] < q) ? 1u : 0u;
-            w.cur[u] = n_e - 1u - (b0 + within);   // (key u is always handled by the same thread: no hazard on cur)
-        }
+            for (uint32_t i = 0; i < c; i++) within += (v.region[b0 + i] < q) ? 1u : 0u;
+            v.cur[u] = n_e - 1u - (b0 + within);   // (key u is always handled by the same thread: no hazard on cur)
+        });
         __syncthreads();
         n_prev = n_e;
+        prev_small = small;
         if ((uint64_t) m <= B) break;
+    }
+    if (prev_small) {   // a set that never left the small epochs
+        for (uint32_t u = tid; u < m; u += T) w.cur[u] = l.cur[u];
+        __syncthreads();
     }
 }
 
