@@ -346,12 +346,12 @@ def main():
             p2d_s = time.perf_counter() - tp
             out["policy_p2"].append({"value": round(n_events / p2d_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2d_s, 4),
                                      "pieces": pieces, "host_threads": 1, "longest_window_chain": kd["steps"],
-                                     "lockstep_passes": (kd["steps"] + 1) // 2, "windows_evaluated": kd["windows"],
+                                     "windows_evaluated": kd["windows"],
                                      "keyframes": int(len(kd["time"])), "driver": "device",
                                      "same_keyframes_as_host_driver": bool(np.array_equal(kd["time"], kf["time"])),
                                      "note": "the same policy in one call: five stages + grid ordering over every piece's current window and "
-                                             "its three possible successors + one policy kernel that applies the rule twice (two windows of "
-                                             "every piece's chain per pass), enqueued back to back; the host reads a 4-byte counter every 8 passes"})
+                                             "the five that follow it if every verdict is the likely one + one policy kernel that applies the rule "
+                                             "along that chain while the verdicts agree, enqueued back to back; the host reads a 4-byte counter every 8 passes"})
         pipe.set_windows(t0, t1)
     # ------------------------------------------------------------------------------------------
     # M2: Levenberg-Marquardt iterations/s of the continuous-time solve on the same stream

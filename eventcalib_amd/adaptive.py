@@ -87,10 +87,9 @@ def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_thres
     torch.cuda.synchronize(events.device)   # the passes run on the context's own stream: `events` must be complete
     n_ev = events.numel() // 25
     span = max(end_time - start_time, 1e-9)
-    # a pass covers, per piece, one window of <= 10 steps and the windows that can follow it (accept / slide / grow: together
-    # <= 16 steps): twice the mean event count of such spans, to start with
-    cap_max = min(4 * n_ev + 4096, 2 ** 32 - 64)     # (the four windows of a piece overlap: a pass can cover events more than once)
-    cap = int(min(cap_max, piece_num * (2 * 16 * motion_time_step * n_ev / span + 4096)))
+    # a pass covers a chain of windows per piece: the library's own estimate, doubled whenever it reports it too small
+    cap_max = 2 ** 32 - 64
+    cap = capi.detect_keyframes_cap_hint(ctx, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time)
     max_keys = int(span / (8 * motion_time_step)) + piece_num + 64   # one keyframe per window + gap at the very most
     while True:
         try:

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
-    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_rectify_batch_dev", "ecal_rectify_batch",
+    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_detect_keyframes_cap_hint", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion",
@@ -711,6 +711,15 @@ class AdaptiveParams(ctypes.Structure):
     _fields_ = [("motion_time_step", ctypes.c_double), ("frame_event_num_threshold", ctypes.c_uint32), ("piece_num", ctypes.c_uint32),
                 ("start_time", ctypes.c_double), ("end_time", ctypes.c_double), ("max_passes", ctypes.c_uint32),
                 ("check_every", ctypes.c_uint32)]
+
+
+def detect_keyframes_cap_hint(ctx: Context, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time):
+    """ecal_detect_keyframes_cap_hint: a cap_points that detect_keyframes_dev will usually find sufficient."""
+    L = ctx._L
+    L.ecal_detect_keyframes_cap_hint.argtypes = [ctypes.POINTER(AdaptiveParams), ctypes.c_uint64]
+    L.ecal_detect_keyframes_cap_hint.restype = ctypes.c_uint64
+    ap = AdaptiveParams(float(motion_time_step), int(frame_event_num_threshold), int(piece_num), float(start_time), float(end_time), 0, 0)
+    return int(L.ecal_detect_keyframes_cap_hint(ctypes.byref(ap), int(n_events)))
 
 
 def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time,

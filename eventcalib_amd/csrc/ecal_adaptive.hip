@@ -73,7 +73,7 @@ __device__ void row_direction(const double *xyr, const int32_t *order, uint32_t 
 
 struct AdaptiveArrays {
     double *first, *second, *bound_hi, *ref_t, *ref_dir;  // [P], [P], [P], [P], [P][rows][2]
-    uint32_t *active, *have_ref;                          // [P]
+    uint32_t *active, *have_ref, *levels;                 // [P]; levels: windows the piece has gone through
     uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: slots overflowed
     unsigned long long *windows;                          // windows evaluated
 };
@@ -81,7 +81,17 @@ struct AdaptiveArrays {
 // The window that follows (f, s2) under outcome o of eventCameraCalib.cpp:61-62 (0: keyframe accepted), :67-69,75-77 (1: slide),
 // :70-71,78-79 (2: grow) — the ONE place these sums are written, so that a window evaluated ahead of time is bit for bit the
 // window the policy arrives at.
-constexpr int AD_SPEC = 4;   // window slots per piece and pass: the current window and its three possible successors
+// Window slots per piece and pass: the current window and the likeliest windows after it.  Measured on the benchmark stream
+// (Mev/s at 1270 / 4096 pieces): 1 slot 145 / 490, 2: 246 / 690, 3: 307 / 781, 4: 358 / 800, 5: 406 / 837, 6: 434 / 849,
+// 8 and more: less again (the work of a pass grows with the chain, the likely verdicts get rarer along it).
+constexpr uint32_t AD_DEPTH_MAX = 8;
+static uint32_t adaptive_depth(uint32_t pieces) {
+    if (const char *e = getenv("ECAL_ADAPTIVE_DEPTH")) {   // debug / measurement switch; the result does not depend on it
+        const int d = atoi(e);
+        if (d >= 1 && d <= (int) AD_DEPTH_MAX) return (uint32_t) d;
+    }
+    return pieces <= 8192u ? 6u : (pieces <= 32768u ? 3u : 1u);   // (many pieces fill the GPU by themselves)
+}
 __device__ __forceinline__ void next_window(int o, double f, double s2, double mts, double &nf, double &ns) {
     const double ln = 3 * mts, gap = 5 * mts;
     if (o == 0) {
@@ -96,23 +106,29 @@ __device__ __forceinline__ void next_window(int o, double f, double s2, double m
     }
 }
 
-// slots 4 k .. 4 k + 3 of piece k: its current window (f, s2) — empty (+inf, -inf: every stage skips it) when the piece is
-// finished — and the three windows that can follow it, each empty when it would end the piece (:50) or cannot occur (a window
-// longer than three lengths never grows)
-__device__ __forceinline__ void write_slots(uint32_t k, bool act, double f, double s2, double hi, double mts, double *t0, double *t1) {
-    t0[AD_SPEC * k] = act ? f : INFINITY;
-    t1[AD_SPEC * k] = act ? s2 : -INFINITY;
-    const double ln = 3 * mts;
-    for (int o = 0; o < 3; o++) {
-        double nf, ns;
-        next_window(o, f, s2, mts, nf, ns);
-        const bool can = act && ns < hi && !(o == 2 && (s2 - f) > 3 * ln);
-        t0[AD_SPEC * k + 1 + o] = can ? nf : INFINITY;
-        t1[AD_SPEC * k + 1 + o] = can ? ns : -INFINITY;
+// The verdict that is to be expected of a window: not a keyframe (one window in thirteen is), and then the rule's choice
+// between slide and grow as far as the window's length decides it (a window longer than three lengths slides; a shorter one
+// grows unless it holds more than the event threshold, which is rare).
+__device__ __forceinline__ int likely_outcome(double f, double s2, double mts) { return (s2 - f) > 3 * (3 * mts) ? 1 : 2; }
+
+// slots D k .. D k + D - 1 of piece k: its current window (f, s2) — empty (+inf, -inf: every stage skips
+// it) when the piece is finished — and the chain of windows that follows it if every verdict is the likely one, cut where it
+// would end the piece (:50)
+__device__ __forceinline__ void write_slots(uint32_t D, uint32_t k, bool act, double f, double s2, double hi, double mts, double *t0, double *t1) {
+    for (uint32_t j = 0; j < D; j++) {
+        t0[D * k + j] = act ? f : INFINITY;
+        t1[D * k + j] = act ? s2 : -INFINITY;
+        if (act) {
+            double nf, ns;
+            next_window(likely_outcome(f, s2, mts), f, s2, mts, nf, ns);
+            f = nf;
+            s2 = ns;
+            act = ns < hi;
+        }
     }
 }
 
-__global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_time, double mts, AdaptiveArrays st, double *t0, double *t1) {
+__global__ void adaptive_init_kernel(uint32_t P, uint32_t D, double start_time, double end_time, double mts, AdaptiveArrays st, double *t0, double *t1) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) {
         st.counters[0] = st.counters[1] = st.counters[2] = st.counters[3] = 0;
@@ -128,16 +144,18 @@ __global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_t
     const bool act = second < hi;
     st.active[k] = act ? 1u : 0u;
     st.have_ref[k] = 0;
+    st.levels[k] = 0;
     st.ref_t[k] = 0;
-    write_slots(k, act, first, second, hi, mts, t0, t1);
+    write_slots(D, k, act, first, second, hi, mts, t0, t1);
 }
 
-// One 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window, n_levels (1 or 2) times:
-// the second time on the successor window that the first verdict selects among the three evaluated beside the current one.
-// (A lock-step pass costs the latency of one workgroup through ~25 kernels whatever the number of windows — 0.63 ms for 1270,
-// 0.80 ms for 4096 —, and a piece's windows are a dependent chain: two links per pass for four times the windows.)
+// One 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window, up to n_levels times: as long
+// as the verdict is the likely one, the next window is the next slot of the chain that this pass evaluated ahead of time.
+// (A lock-step pass costs the latency of one workgroup through ~25 kernels plus the work of its windows — 0.63 ms for 1270
+// windows of ~6 steps, 0.84 ms for three times the events —, and a piece's windows are a dependent chain: 2.7 links per pass
+// at nine verdicts in ten as expected.)
 // The rows' line fits (a 3 x 3 Jacobi eigen-decomposition each, the bulk of the work) run on one lane per row; lane 0 does the rest.
-__global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t level0, uint32_t n_levels,
+__global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t D, uint32_t rows, uint32_t cols, uint32_t max_levels,
                                      const uint32_t *__restrict__ win_info,
                                      const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
                                      const double *__restrict__ cand_xyr, const int32_t *__restrict__ order,
@@ -157,8 +175,11 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         sh_f = st.first[k];
         sh_s2 = st.second[k];
     }
-    uint32_t w = AD_SPEC * k;   // slot of the window under evaluation
+    uint32_t w = D * k;   // slot of the window under evaluation
     bool act = true;
+    const uint32_t lev0 = st.levels[k];   // (max_levels: the caller's bound on the windows of a piece)
+    const uint32_t n_levels = max_levels - lev0 < D ? max_levels - lev0 : D;
+    if (n_levels == 0) return;
     for (uint32_t level = 0; level < n_levels; level++) {
         __syncthreads();
         const double f = sh_f, s2 = sh_s2;
@@ -225,23 +246,36 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
             sh_s2 = ns;
             sh_o = o;
             sh_act = ns < st.bound_hi[k] ? 1 : 0;  // :50
-            atomicMax(&st.counters[2], level0 + level + 1u);
+            atomicMax(&st.counters[2], lev0 + level + 1u);
+            st.levels[k] = lev0 + level + 1u;
             atomicAdd(st.windows, 1ull);
         }
         __syncthreads();
         act = sh_act != 0;
-        if (!act) break;
-        w = AD_SPEC * k + 1u + (uint32_t) sh_o;   // the window just chosen: evaluated in this pass, in its successor slot
+        if (!act || sh_o != likely_outcome(f, s2, mts)) break;   // the chain evaluated ahead holds the likely successor only
+        w++;
     }
     if (lane != 0) return;
     st.first[k] = sh_f;
     st.second[k] = sh_s2;
     st.active[k] = act ? 1u : 0u;
-    write_slots(k, act, sh_f, sh_s2, st.bound_hi[k], mts, t0, t1);
-    if (act) atomicAdd(&st.counters[0], 1u);
+    write_slots(D, k, act, sh_f, sh_s2, st.bound_hi[k], mts, t0, t1);
+    if (act && st.levels[k] < max_levels) atomicAdd(&st.counters[0], 1u);   // pieces with windows still to go
 }
 
 }  // namespace
+
+extern "C" uint64_t ecal_detect_keyframes_cap_hint(const ecal_adaptive_params *ap, uint64_t n_events) {
+    if (!ap || ap->piece_num == 0 || !(ap->motion_time_step > 0) || !(ap->end_time > ap->start_time)) return 0;
+    const uint32_t D = adaptive_depth(ap->piece_num);
+    // a pass holds D windows per piece, of three to ten time steps, grown along the chain: eight steps each at the stream's
+    // mean rate and some room (too little costs one aborted attempt of a few passes: ECAL_ERR_RANGE, doubled, again)
+    const double per_step = (double) n_events * ap->motion_time_step / (ap->end_time - ap->start_time);
+    const double want = (double) ap->piece_num * D * (8.0 * per_step + 256.0);
+    const double most = (double) D * (double) n_events + 4096.0;   // (the windows of one slot index are disjoint)
+    const double cap = want < most ? want : most;
+    return cap > 4294967232.0 ? 4294967232ull : (uint64_t) cap;
+}
 
 extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                                      const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
@@ -260,7 +294,8 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc;
-    const uint32_t S = AD_SPEC * P;   // window slots per pass: every piece's current window and its three possible successors
+    const uint32_t D = adaptive_depth(P);
+    const uint32_t S = D * P;   // window slots per pass: every piece's current window and the likely chain after it
     const size_t cap = (size_t) cap_points + 16;
     ecal_devbuf *B = ctx->host_pipe;  // roles as in ecal_detect_pass; 0 holds t0 and t1 back to back
     const size_t sizes[17] = {2ul * S * sizeof(double), 16, S * 4ul, S * 4ul, (S + 1) * 4ul, cap * 16, 2ul * S * 4, 2ul * S * 4, cap * 4,
@@ -269,7 +304,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_ensure(ctx, B[i], sizes[i]))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
-    const size_t state_bytes = (size_t) P * (4 * 8 + 2 * 8 * prm->rows + 2 * 4) + 64;
+    const size_t state_bytes = (size_t) P * (4 * 8 + 2 * 8 * prm->rows + 3 * 4) + 64;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
     const size_t key_stride = 8 + 16 + 8 + 24 * (size_t) M;  // time, duration, events (padded), features
     if ((rc = ecal_ensure(ctx, ctx->adaptive_keys, (size_t) max_keyframes * key_stride + 64))) return rc;
@@ -293,18 +328,19 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         a.ref_dir = a.ref_t + P;
         a.active = (uint32_t *) (a.ref_dir + (size_t) P * prm->rows * 2);
         a.have_ref = a.active + P;
+        a.levels = a.have_ref + P;
     }
     double *d_kt = (double *) ctx->adaptive_keys.ptr, *d_kd = d_kt + max_keyframes, *d_kf = d_kd + 2 * (size_t) max_keyframes;
     int32_t *d_ke = (int32_t *) (d_kf + 3 * (size_t) max_keyframes * M);
     double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
-    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, ap->start_time, ap->end_time, ap->motion_time_step, a, d_t0, d_t1);
+    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, D, ap->start_time, ap->end_time, ap->motion_time_step, a, d_t0, d_t1);
     ECAL_HIP_TRY(ctx, hipMemsetAsync(B[16].ptr, 0, sizeof(int), st));
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..3] counters, [4] overflow flag
     const uint32_t check_every = ap->check_every ? ap->check_every : 8u;
-    // max_passes counts windows per piece (the lock-step passes of the one-window-per-pass form); a pass here evaluates two
+    // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
+    // takes a piece through up to D of them
     const uint32_t max_levels = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
-    for (uint32_t pass = 0, level0 = 0; level0 < max_levels; pass++) {
-        const uint32_t n_levels = max_levels - level0 < 2u ? max_levels - level0 : 2u;
+    for (uint32_t pass = 0; pass < max_levels; pass++) {
         ECAL_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st));  // pieces active after this pass
         if ((rc = ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                          (uint32_t *) B[4].ptr, st)))
@@ -324,13 +360,12 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
                                       (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
             return rc;
-        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, level0, n_levels,
+        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, D, prm->rows, prm->cols, max_levels,
                            (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
                            (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                            (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                            max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1, (const int *) B[16].ptr);
-        level0 += n_levels;
-        if (pass % check_every == check_every - 1 || level0 >= max_levels) {
+        if (pass % check_every == check_every - 1 || pass + 1 == max_levels) {
             ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
             if (h[3]) {

@@ -206,10 +206,9 @@ inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, 
     const uint64_t n = ecal_stream_size(es);
     const size_t M = (size_t) prm.rows * prm.cols;
     const double span = std::max(endTime - startTime, 1e-9);
-    // a pass covers, per piece, one window of <= 10 steps and its possible successors (together <= 16 steps); doubled on
-    // ECAL_ERR_RANGE
-    const uint64_t cap_max = std::min<uint64_t>(4 * n + 4096, 0xFFFFFFC0ull);   // (a piece's four windows overlap)
-    uint64_t cap = std::min<uint64_t>(cap_max, (uint64_t) (pieceNum * (32.0 * motionTimeStep * (double) n / span + 4096.0)));
+    // a pass covers a chain of windows per piece: the library's own estimate, doubled on ECAL_ERR_RANGE
+    const uint64_t cap_max = 0xFFFFFFC0ull;
+    uint64_t cap = ecal_detect_keyframes_cap_hint(&ap, n);
     uint32_t max_keys = (uint32_t) (span / (8 * motionTimeStep)) + (uint32_t) pieceNum + 64;
     std::vector<double> t, d, f;
     std::vector<int32_t> e;

@@ -316,12 +316,13 @@ int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, 
  * (MultiProcess::process, event_camera_calib/test/eventCameraCalib.cpp:34-97: success / slide / grow rule :49-95) over
  * piece_num pieces of [start_time, end_time] (:168-179) with the keyframe gate of EventCalibIni::track (event_camera_calib/
  * src/EventCalibIni.cpp:23-97) against the previous keyframe of the window's own piece (the deterministic policy of
- * host/multi_process.hpp).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over FOUR windows of
- * every piece — its current one and the three that can follow it (accepted / slide / grow) — + one policy kernel that applies
- * the rule twice, the second time to the successor the first verdict selects: two windows of a piece's chain per pass, same
- * keyframes as one by one.  All enqueued back to back; the host reads a 4-byte counter every check_every passes.
- * d_events: DEVICE-resident stream.  cap_points >= the events covered by the windows of any one pass — up to ~16 motion
- * time steps per piece — (ECAL_ERR_RANGE otherwise: call again with more).  Outputs (host), sorted by time stamp: kf_time [K], kf_duration
+ * host/multi_process.hpp).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over a CHAIN of
+ * windows per piece — its current one and the (up to five) windows that follow it if every verdict is the likely one: no
+ * keyframe, grow (or slide once the window is longer than three lengths) — + one policy kernel that applies the rule along
+ * that chain for as long as the verdicts are the likely ones (nine in ten are): several windows of a piece's chain per pass,
+ * same keyframes as one by one.  All enqueued back to back; the host reads a 4-byte counter every check_every passes.
+ * d_events: DEVICE-resident stream.  cap_points >= the events covered by the windows of any one pass
+ * (ecal_detect_keyframes_cap_hint; ECAL_ERR_RANGE otherwise: call again with more).  Outputs (host), sorted by time stamp: kf_time [K], kf_duration
  * [K][2], kf_events_num [K] (EventFrame::eventsNum()), kf_features [K][rows*cols][3] (x, y, radius in grid order);
  * *n_keyframes = K (ECAL_ERR_RANGE with the needed count if K > max_keyframes); *passes = the longest chain of windows
  * a piece went through (the lock-step passes of the one-window-per-pass form; max_passes bounds it), *windows = windows the
@@ -339,6 +340,9 @@ int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
                           const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                           double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
                           uint32_t *passes, uint64_t *windows);
+/* a cap_points that ecal_detect_keyframes will usually find sufficient for a stream of n_events events (0: invalid
+ * parameters); ECAL_ERR_RANGE still says when it was not — double it and call again */
+uint64_t ecal_detect_keyframes_cap_hint(const ecal_adaptive_params *ap, uint64_t n_events);
 int ecal_pin_host(ecal_ctx *ctx, void *ptr, size_t bytes);   /* hipHostRegister */
 int ecal_unpin_host(ecal_ctx *ctx, void *ptr);
 int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events /*host*/, uint64_t n_events, double t_start, double window_len,
