@@ -350,8 +350,9 @@ def main():
                                      "keyframes": int(len(kd["time"])), "driver": "device",
                                      "same_keyframes_as_host_driver": bool(np.array_equal(kd["time"], kf["time"])),
                                      "note": "the same policy in one call: five stages + grid ordering over every piece's current window and "
-                                             "the five that follow it if every verdict is the likely one + one policy kernel that applies the rule "
-                                             "along that chain while the verdicts agree, enqueued back to back; the host reads a 4-byte counter every 8 passes"})
+                                             "the windows that follow it if every verdict is the likely one (the slots of a pass go to the pieces "
+                                             "still at work) + one policy kernel that applies the rule along that chain while the verdicts agree, "
+                                             "enqueued back to back; the host follows a 4-byte counter two passes behind"})
         pipe.set_windows(t0, t1)
     # ------------------------------------------------------------------------------------------
     # M2: Levenberg-Marquardt iterations/s of the continuous-time solve on the same stream

@@ -74,6 +74,7 @@ __device__ void row_direction(const double *xyr, const int32_t *order, uint32_t 
 struct AdaptiveArrays {
     double *first, *second, *bound_hi, *ref_t, *ref_dir;  // [P], [P], [P], [P], [P][rows][2]
     uint32_t *active, *have_ref, *levels;                 // [P]; levels: windows the piece has gone through
+    uint32_t *slot0, *depth;                              // [P]: the piece's window slots of this pass (adaptive_alloc_kernel)
     uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: slots overflowed
     unsigned long long *windows;                          // windows evaluated
 };
@@ -81,17 +82,6 @@ struct AdaptiveArrays {
 // The window that follows (f, s2) under outcome o of eventCameraCalib.cpp:61-62 (0: keyframe accepted), :67-69,75-77 (1: slide),
 // :70-71,78-79 (2: grow) — the ONE place these sums are written, so that a window evaluated ahead of time is bit for bit the
 // window the policy arrives at.
-// Window slots per piece and pass: the current window and the likeliest windows after it.  Measured on the benchmark stream
-// (Mev/s at 1270 / 4096 pieces): 1 slot 145 / 490, 2: 246 / 690, 3: 307 / 781, 4: 358 / 800, 5: 406 / 837, 6: 434 / 849,
-// 8 and more: less again (the work of a pass grows with the chain, the likely verdicts get rarer along it).
-constexpr uint32_t AD_DEPTH_MAX = 8;
-static uint32_t adaptive_depth(uint32_t pieces) {
-    if (const char *e = getenv("ECAL_ADAPTIVE_DEPTH")) {   // debug / measurement switch; the result does not depend on it
-        const int d = atoi(e);
-        if (d >= 1 && d <= (int) AD_DEPTH_MAX) return (uint32_t) d;
-    }
-    return pieces <= 8192u ? 6u : (pieces <= 32768u ? 3u : 1u);   // (many pieces fill the GPU by themselves)
-}
 __device__ __forceinline__ void next_window(int o, double f, double s2, double mts, double &nf, double &ns) {
     const double ln = 3 * mts, gap = 5 * mts;
     if (o == 0) {
@@ -106,18 +96,40 @@ __device__ __forceinline__ void next_window(int o, double f, double s2, double m
     }
 }
 
+// Window slots of a pass: a few per piece in all, dealt out among the pieces still at work (adaptive_alloc_kernel)
+// up to AD_DEPTH_MAX windows of chain each.  Measured on the benchmark stream (Mev/s at 1270 / 4096 pieces) with the same
+// chain length for every piece: 1 window 145 / 490, 2: 246 / 690, 3: 307 / 781, 4: 358 / 800, 5: 406 / 837, 6: 432 / 840,
+// 8 and more: less again (the work of a pass grows with the chain, the likely verdicts get rarer along it); with the slots
+// of the finished pieces going to the others: 6 slots per piece and chains of <= 12: 533 / 922, <= 24: 592 / 943,
+// <= 48: 633 / 962, <= 64: 626 / 973; 4, 5, 8 slots per piece (<= 64, <= 48, <= 64): 559 / 1001, 582 / 1017, 541 / 823.
+constexpr uint32_t AD_DEPTH_MAX = 48;
+static uint32_t adaptive_slots_per_piece(uint32_t pieces) {
+    if (const char *e = getenv("ECAL_ADAPTIVE_DEPTH")) {   // debug / measurement switch; the result does not depend on it
+        const int d = atoi(e);
+        if (d >= 1 && d <= 64) return (uint32_t) d;
+    }
+    return pieces <= 2048u ? 6u : (pieces <= 8192u ? 5u : (pieces <= 32768u ? 3u : 1u));   // (many pieces fill the GPU by themselves)
+}
+static uint32_t adaptive_depth_max() {
+    if (const char *e = getenv("ECAL_ADAPTIVE_DEPTH_MAX")) {   // debug / measurement switch
+        const int d = atoi(e);
+        if (d >= 1 && d <= 64) return (uint32_t) d;
+    }
+    return AD_DEPTH_MAX;
+}
+
 // The verdict that is to be expected of a window: not a keyframe (one window in thirteen is), and then the rule's choice
 // between slide and grow as far as the window's length decides it (a window longer than three lengths slides; a shorter one
 // grows unless it holds more than the event threshold, which is rare).
 __device__ __forceinline__ int likely_outcome(double f, double s2, double mts) { return (s2 - f) > 3 * (3 * mts) ? 1 : 2; }
 
-// slots D k .. D k + D - 1 of piece k: its current window (f, s2) — empty (+inf, -inf: every stage skips
-// it) when the piece is finished — and the chain of windows that follows it if every verdict is the likely one, cut where it
-// would end the piece (:50)
-__device__ __forceinline__ void write_slots(uint32_t D, uint32_t k, bool act, double f, double s2, double hi, double mts, double *t0, double *t1) {
+// The chain of D windows that starts at the piece's current window (f, s2) and goes on as if every verdict were the likely
+// one, cut where it would end the piece (:50; the slots behind the cut stay empty: +inf, -inf, which every stage skips)
+__device__ __forceinline__ void write_chain(uint32_t D, double f, double s2, double hi, double mts, double *t0, double *t1) {
+    bool act = true;
     for (uint32_t j = 0; j < D; j++) {
-        t0[D * k + j] = act ? f : INFINITY;
-        t1[D * k + j] = act ? s2 : -INFINITY;
+        t0[j] = act ? f : INFINITY;
+        t1[j] = act ? s2 : -INFINITY;
         if (act) {
             double nf, ns;
             next_window(likely_outcome(f, s2, mts), f, s2, mts, nf, ns);
@@ -128,7 +140,50 @@ __device__ __forceinline__ void write_slots(uint32_t D, uint32_t k, bool act, do
     }
 }
 
-__global__ void adaptive_init_kernel(uint32_t P, uint32_t D, double start_time, double end_time, double mts, AdaptiveArrays st, double *t0, double *t1) {
+// The window slots of the next pass.  The pieces' chains differ a lot in length (the benchmark's longest has 559 windows, the
+// average 83), so most passes see few pieces still at work: the B slots of a pass are dealt out evenly among THOSE, up to
+// d_max windows of chain each — the fewer pieces remain, the further each one looks ahead.  One workgroup.
+constexpr int AD_ALLOC_T = 1024;
+__global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t d_max, AdaptiveArrays st, double mts,
+                                                                    double *t0, double *t1) {
+    __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
+    uint32_t mine = 0;
+    for (uint32_t k = k0; k < k0 + per && k < P; k++) mine += st.active[k] ? 1u : 0u;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if ((int) lane >= d) inc += o;
+    }
+    if (lane == 63) red[wave] = inc;
+    __syncthreads();
+    uint32_t pre = 0, n_act = 0;
+    for (uint32_t w = 0; w < AD_ALLOC_T / 64; w++) {
+        if (w < wave) pre += red[w];
+        n_act += red[w];
+    }
+    uint32_t D = n_act ? B / n_act : 0u;   // (B >= P: at least one)
+    if (D > d_max) D = d_max;
+    uint32_t at = pre + inc - mine;        // active pieces before this thread's
+    for (uint32_t k = k0; k < k0 + per && k < P; k++) {
+        if (st.active[k]) {
+            st.slot0[k] = at * D;
+            st.depth[k] = D;
+            write_chain(D, st.first[k], st.second[k], st.bound_hi[k], mts, t0 + (size_t) at * D, t1 + (size_t) at * D);
+            at++;
+        } else {
+            st.depth[k] = 0;
+        }
+    }
+    for (uint32_t i = n_act * D + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
+        t0[i] = INFINITY;
+        t1[i] = -INFINITY;
+    }
+}
+
+__global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_time, double mts, AdaptiveArrays st) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) {
         st.counters[0] = st.counters[1] = st.counters[2] = st.counters[3] = 0;
@@ -146,7 +201,6 @@ __global__ void adaptive_init_kernel(uint32_t P, uint32_t D, double start_time, 
     st.have_ref[k] = 0;
     st.levels[k] = 0;
     st.ref_t[k] = 0;
-    write_slots(D, k, act, first, second, hi, mts, t0, t1);
 }
 
 // One 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window, up to n_levels times: as long
@@ -155,7 +209,7 @@ __global__ void adaptive_init_kernel(uint32_t P, uint32_t D, double start_time, 
 // windows of ~6 steps, 0.84 ms for three times the events —, and a piece's windows are a dependent chain: 2.7 links per pass
 // at nine verdicts in ten as expected.)
 // The rows' line fits (a 3 x 3 Jacobi eigen-decomposition each, the bulk of the work) run on one lane per row; lane 0 does the rest.
-__global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t D, uint32_t rows, uint32_t cols, uint32_t max_levels,
+__global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t max_levels,
                                      const uint32_t *__restrict__ win_info,
                                      const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
                                      const double *__restrict__ cand_xyr, const int32_t *__restrict__ order,
@@ -175,7 +229,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         sh_f = st.first[k];
         sh_s2 = st.second[k];
     }
-    uint32_t w = D * k;   // slot of the window under evaluation
+    uint32_t w = st.slot0[k];   // slot of the window under evaluation
+    const uint32_t D = st.depth[k];
     bool act = true;
     const uint32_t lev0 = st.levels[k];   // (max_levels: the caller's bound on the windows of a piece)
     const uint32_t n_levels = max_levels - lev0 < D ? max_levels - lev0 : D;
@@ -259,7 +314,6 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
     st.first[k] = sh_f;
     st.second[k] = sh_s2;
     st.active[k] = act ? 1u : 0u;
-    write_slots(D, k, act, sh_f, sh_s2, st.bound_hi[k], mts, t0, t1);
     if (act && st.levels[k] < max_levels) atomicAdd(&st.counters[0], 1u);   // pieces with windows still to go
 }
 
@@ -267,7 +321,7 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
 
 extern "C" uint64_t ecal_detect_keyframes_cap_hint(const ecal_adaptive_params *ap, uint64_t n_events) {
     if (!ap || ap->piece_num == 0 || !(ap->motion_time_step > 0) || !(ap->end_time > ap->start_time)) return 0;
-    const uint32_t D = adaptive_depth(ap->piece_num);
+    const uint32_t D = adaptive_slots_per_piece(ap->piece_num);
     // a pass holds D windows per piece, of three to ten time steps, grown along the chain: eight steps each at the stream's
     // mean rate and some room (too little costs one aborted attempt of a few passes: ECAL_ERR_RANGE, doubled, again)
     const double per_step = (double) n_events * ap->motion_time_step / (ap->end_time - ap->start_time);
@@ -294,8 +348,8 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc;
-    const uint32_t D = adaptive_depth(P);
-    const uint32_t S = D * P;   // window slots per pass: every piece's current window and the likely chain after it
+    const uint32_t D = adaptive_slots_per_piece(P), d_max = adaptive_depth_max();
+    const uint32_t S = D * P;   // window slots per pass, dealt out among the pieces still at work: the current window and the likely chain after it
     const size_t cap = (size_t) cap_points + 16;
     ecal_devbuf *B = ctx->host_pipe;  // roles as in ecal_detect_pass; 0 holds t0 and t1 back to back
     const size_t sizes[17] = {2ul * S * sizeof(double), 16, S * 4ul, S * 4ul, (S + 1) * 4ul, cap * 16, 2ul * S * 4, 2ul * S * 4, cap * 4,
@@ -304,7 +358,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_ensure(ctx, B[i], sizes[i]))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
-    const size_t state_bytes = (size_t) P * (4 * 8 + 2 * 8 * prm->rows + 3 * 4) + 64;
+    const size_t state_bytes = (size_t) P * (4 * 8 + 2 * 8 * prm->rows + 5 * 4) + 64;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
     const size_t key_stride = 8 + 16 + 8 + 24 * (size_t) M;  // time, duration, events (padded), features
     if ((rc = ecal_ensure(ctx, ctx->adaptive_keys, (size_t) max_keyframes * key_stride + 64))) return rc;
@@ -329,18 +383,40 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         a.active = (uint32_t *) (a.ref_dir + (size_t) P * prm->rows * 2);
         a.have_ref = a.active + P;
         a.levels = a.have_ref + P;
+        a.slot0 = a.levels + P;
+        a.depth = a.slot0 + P;
     }
     double *d_kt = (double *) ctx->adaptive_keys.ptr, *d_kd = d_kt + max_keyframes, *d_kf = d_kd + 2 * (size_t) max_keyframes;
     int32_t *d_ke = (int32_t *) (d_kf + 3 * (size_t) max_keyframes * M);
     double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
-    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, D, ap->start_time, ap->end_time, ap->motion_time_step, a, d_t0, d_t1);
+    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, ap->start_time, ap->end_time, ap->motion_time_step, a);
+    hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, d_max, a, ap->motion_time_step, d_t0, d_t1);
     ECAL_HIP_TRY(ctx, hipMemsetAsync(B[16].ptr, 0, sizeof(int), st));
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..3] counters, [4] overflow flag
-    const uint32_t check_every = ap->check_every ? ap->check_every : 8u;
+    // The host runs `ahead` passes ahead of the device's counters: before it enqueues pass p it waits for the counters that pass
+    // p - ahead left (a copy to pinned memory + an event behind every pass) — the device always has work queued, and at most
+    // `ahead` passes run with nothing left to do.
+    const uint32_t ahead = ap->check_every ? (ap->check_every < 8u ? ap->check_every : 8u) : 2u;
+    for (int i = 0; i < 8; i++)
+        if (!ctx->adaptive_ev[i]) ECAL_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->adaptive_ev[i], hipEventDisableTiming));
+    uint32_t *ring = h + 16;   // [8][4] counters as the passes left them
+    bool done = false;
     // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
     // takes a piece through up to D of them
     const uint32_t max_levels = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
-    for (uint32_t pass = 0; pass < max_levels; pass++) {
+    uint32_t n_passes = 0;
+    for (uint32_t pass = 0; pass < max_levels && !done; pass++) {
+        if (pass >= ahead) {
+            const uint32_t q = (pass - ahead) % 8u;
+            ECAL_HIP_TRY(ctx, hipEventSynchronize(ctx->adaptive_ev[q]));
+            if (ring[4 * q + 3]) {
+                (void) hipStreamSynchronize(st);
+                ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
+                return ECAL_ERR_RANGE;
+            }
+            if (ring[4 * q] == 0) break;   // (the passes enqueued since find nothing to do)
+        }
+        n_passes = pass + 1;
         ECAL_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st));  // pieces active after this pass
         if ((rc = ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                          (uint32_t *) B[4].ptr, st)))
@@ -360,21 +436,22 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
                                       (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
             return rc;
-        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, D, prm->rows, prm->cols, max_levels,
+        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, max_levels,
                            (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
                            (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                            (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                            max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1, (const int *) B[16].ptr);
-        if (pass % check_every == check_every - 1 || pass + 1 == max_levels) {
-            ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
-            if (h[3]) {
-                ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
-                return ECAL_ERR_RANGE;
-            }
-            if (h[0] == 0) break;
-        }
+        hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, d_max, a, ap->motion_time_step, d_t0, d_t1);
+        ECAL_HIP_TRY(ctx, hipMemcpyAsync(ring + 4 * (pass % 8u), a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        ECAL_HIP_TRY(ctx, hipEventRecord(ctx->adaptive_ev[pass % 8u], st));
     }
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    for (uint32_t q = 0; q < 8u && q < n_passes; q++)   // (the last passes' counters: an overflow may sit in any of them)
+        if (ring[4 * q + 3]) {
+            ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
+            return ECAL_ERR_RANGE;
+        }
+    if (getenv("ECAL_ADAPTIVE_TRACE")) fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes\n", P, S, d_max, n_passes);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     unsigned long long nwin = 0;
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));

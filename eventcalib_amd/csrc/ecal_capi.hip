@@ -117,6 +117,8 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
     for (auto &c : ctx->zero_rings)
         if (c.ptr) (void) hipFree(c.ptr);
+    for (auto &e : ctx->adaptive_ev)
+        if (e) (void) hipEventDestroy(e);
     if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_uploaded[k]) (void) hipEventDestroy(ctx->ev_uploaded[k]);

@@ -53,6 +53,7 @@ struct ecal_ctx {
     ecal_devbuf host_rect[11];  // staging of ecal_rectify_batch
     ecal_devbuf calib_scratch;  // ecal_calibrate_views: views, blocks, reduced records
     ecal_devbuf adaptive_state, adaptive_keys;  // ecal_detect_keyframes: per-piece window state, keyframe records
+    hipEvent_t adaptive_ev[8] = {};             // ecal_detect_keyframes: one behind every pass in flight
     double *calib_pinned = nullptr;  // pinned host landing zone of the reduced record
     void *comm = nullptr;   // ncclComm_t (ecal_comm.hip); null = single rank
     int comm_rank = 0, comm_size = 1;

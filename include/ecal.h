@@ -317,10 +317,10 @@ int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, 
  * piece_num pieces of [start_time, end_time] (:168-179) with the keyframe gate of EventCalibIni::track (event_camera_calib/
  * src/EventCalibIni.cpp:23-97) against the previous keyframe of the window's own piece (the deterministic policy of
  * host/multi_process.hpp).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over a CHAIN of
- * windows per piece — its current one and the (up to five) windows that follow it if every verdict is the likely one: no
- * keyframe, grow (or slide once the window is longer than three lengths) — + one policy kernel that applies the rule along
- * that chain for as long as the verdicts are the likely ones (nine in ten are): several windows of a piece's chain per pass,
- * same keyframes as one by one.  All enqueued back to back; the host reads a 4-byte counter every check_every passes.
+ * windows per piece — its current one and the windows that follow it if every verdict is the likely one: no keyframe, grow
+ * (or slide once the window is longer than three lengths); the window slots of a pass, a few per piece in all, go to the
+ * pieces still at work — + one policy kernel that applies the rule along that chain for as long as the verdicts are the
+ * likely ones (nine in ten are): many windows of a piece's chain per pass, same keyframes as one by one.  All enqueued back to back; the host follows a 4-byte counter check_every passes behind.
  * d_events: DEVICE-resident stream.  cap_points >= the events covered by the windows of any one pass
  * (ecal_detect_keyframes_cap_hint; ECAL_ERR_RANGE otherwise: call again with more).  Outputs (host), sorted by time stamp: kf_time [K], kf_duration
  * [K][2], kf_events_num [K] (EventFrame::eventsNum()), kf_features [K][rows*cols][3] (x, y, radius in grid order);
@@ -334,7 +334,7 @@ typedef struct ecal_adaptive_params {
     uint32_t piece_num;                  /* the reference: 5 * (hardware threads - 2) */
     double start_time, end_time;         /* StartTime / EndTime */
     uint32_t max_passes;                 /* 0 = unlimited */
-    uint32_t check_every;                /* passes between two looks at the active-piece counter (0 = 8) */
+    uint32_t check_every;                /* passes the host may run ahead of the device's active-piece counter (0 = 2, at most 8) */
 } ecal_adaptive_params;
 int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                           const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
