@@ -81,3 +81,21 @@ def test_device_policy_equals_the_policy_oracle(env, pieces):
     assert np.array_equal(dev["duration"], ref["duration"])
     assert np.array_equal(dev["events_num"], ref["events_num"])
     assert np.array_equal(dev["features"], ref["features"])
+
+
+@pytest.mark.parametrize("slots,chain", [(1, 1), (2, 2), (3, 64), (6, 5)])
+def test_look_ahead_does_not_change_the_keyframes(env, slots, chain, monkeypatch):
+    """How far a pass looks ahead along a piece's likely chain of windows (window slots per piece, longest chain: debug
+    switches of ecal_detect_keyframes; (1, 1) = one window per piece and pass, the reference's loop as it stands) decides
+    the number of passes, never the result."""
+    from eventcalib_amd.adaptive import detect_keyframes_device
+    ctx, pipe, ev, torch = env
+    t_first, t_last = 5.0, 5.0 + 0.4
+    want = detect_keyframes_device(ctx, ev, 5e-4, 4000, 23, t_first, t_last)
+    monkeypatch.setenv("ECAL_ADAPTIVE_DEPTH", str(slots))
+    monkeypatch.setenv("ECAL_ADAPTIVE_DEPTH_MAX", str(chain))
+    got = detect_keyframes_device(ctx, ev, 5e-4, 4000, 23, t_first, t_last)
+    assert len(want["time"]) >= 20
+    for k in ("time", "duration", "events_num", "features"):
+        assert np.array_equal(got[k], want[k]), k
+    assert got["steps"] == want["steps"] and got["windows"] == want["windows"]
