@@ -203,12 +203,29 @@ __global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_t
     st.ref_t[k] = 0;
 }
 
+// The rows' line fits of every window of the pass that produced a grid (a 3 x 3 Jacobi eigen-decomposition per row: the bulk of
+// the policy's arithmetic), a workgroup per window slot, a lane per row: all chains' windows side by side, so that the walk
+// along a chain below is left with the gate's few operations per window.
+__global__ __launch_bounds__(64) void adaptive_dir_kernel(uint32_t rows, uint32_t cols, const uint32_t *__restrict__ win_info,
+                                                          const uint32_t *__restrict__ seg_off, const double *__restrict__ cand_xyr,
+                                                          const int32_t *__restrict__ order, const uint32_t *__restrict__ found,
+                                                          double *__restrict__ dirs /*[S][rows][2]*/) {
+    const uint32_t w = blockIdx.x, lane = threadIdx.x;
+    if (!(win_info[4 * w + 3] == 0 && found[w]) || lane >= rows) return;
+    const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
+    const int32_t *ord = order + (size_t) w * rows * cols;
+    double dx, dy;
+    row_direction(xyr, ord + lane * cols, cols, dx, dy);
+    dirs[2 * ((size_t) w * rows + lane)] = dx;
+    dirs[2 * ((size_t) w * rows + lane) + 1] = dy;
+}
+
 // One 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window, up to n_levels times: as long
 // as the verdict is the likely one, the next window is the next slot of the chain that this pass evaluated ahead of time.
 // (A lock-step pass costs the latency of one workgroup through ~25 kernels plus the work of its windows — 0.63 ms for 1270
 // windows of ~6 steps, 0.84 ms for three times the events —, and a piece's windows are a dependent chain: 2.7 links per pass
 // at nine verdicts in ten as expected.)
-// The rows' line fits (a 3 x 3 Jacobi eigen-decomposition each, the bulk of the work) run on one lane per row; lane 0 does the rest.
+// (The rows' line fits come from adaptive_dir_kernel; lane 0 does the rest.)
 __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t max_levels,
                                      const uint32_t *__restrict__ win_info,
                                      const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
@@ -216,9 +233,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                                      const uint32_t *__restrict__ found, AdaptiveArrays st, double mts, uint32_t thr_events,
                                      uint32_t max_keys, double *__restrict__ kf_time, double *__restrict__ kf_dur,
                                      int32_t *__restrict__ kf_events, double *__restrict__ kf_feat, double *__restrict__ t0,
-                                     double *__restrict__ t1, const int *__restrict__ overflow) {
+                                     double *__restrict__ t1, const int *__restrict__ overflow, const double *__restrict__ dirs) {
     const uint32_t k = blockIdx.x, lane = threadIdx.x;
-    __shared__ double dir[AD_MAX_ROWS][2];
     __shared__ double sh_f, sh_s2;
     __shared__ int sh_act, sh_o;
     if (k == 0 && lane == 0 && *overflow) st.counters[3] = 1;  // the slicer clears its flag at every call: keep it until the host looks
@@ -240,13 +256,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         const double f = sh_f, s2 = sh_s2;
         const uint32_t cnt = seg_cnt[2 * w] + seg_cnt[2 * w + 1];  // EventFrame::eventsNum()
         const bool ok = win_info[4 * w + 3] == 0 && found[w];     // extractFeatures() == true
-        if (ok) {   // (uniform over the workgroup)
-            const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
-            const int32_t *ord = order + (size_t) w * M;
-            if (lane < rows) row_direction(xyr, ord + lane * cols, cols, dir[lane][0], dir[lane][1]);
-        }
-        __syncthreads();
         if (lane == 0) {
+            const double *dir = dirs + 2 * (size_t) w * rows;   // [rows][2]
             bool accepted = false;
             if (ok) {
                 const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
@@ -257,8 +268,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                     double theta[AD_MAX_ROWS];
                     const double *rd = st.ref_dir + (size_t) k * rows * 2;
                     for (uint32_t i = 0; i < rows; i++) {
-                        const double c = (rd[2 * i] * dir[i][0] + rd[2 * i + 1] * dir[i][1]) /
-                                         (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[i][0], dir[i][1]));
+                        const double c = (rd[2 * i] * dir[2 * i] + rd[2 * i + 1] * dir[2 * i + 1]) /
+                                         (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[2 * i], dir[2 * i + 1]));
                         theta[i] = acos(c);   // (not clamped, as the reference: a cosine rounded above 1 gives NaN and the frame fails the test)
                     }
                     double med = theta[0];
@@ -289,8 +300,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                     st.ref_t[k] = t_mid;
                     double *rd = st.ref_dir + (size_t) k * rows * 2;
                     for (uint32_t i = 0; i < rows; i++) {
-                        rd[2 * i] = dir[i][0];
-                        rd[2 * i + 1] = dir[i][1];
+                        rd[2 * i] = dir[2 * i];
+                        rd[2 * i + 1] = dir[2 * i + 1];
                     }
                 }
             }
@@ -360,6 +371,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
     const size_t state_bytes = (size_t) P * (4 * 8 + 2 * 8 * prm->rows + 5 * 4) + 64;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->adaptive_dirs, (size_t) S * prm->rows * 2 * sizeof(double)))) return rc;
     const size_t key_stride = 8 + 16 + 8 + 24 * (size_t) M;  // time, duration, events (padded), features
     if ((rc = ecal_ensure(ctx, ctx->adaptive_keys, (size_t) max_keyframes * key_stride + 64))) return rc;
     if (ctx->pass_pinned_cap < 64) {
@@ -436,11 +448,14 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
                                       (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
             return rc;
+        hipLaunchKernelGGL(adaptive_dir_kernel, dim3(S), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
+                           (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
+                           (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);
         hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, max_levels,
                            (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
                            (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                            (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
-                           max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1, (const int *) B[16].ptr);
+                           max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1, (const int *) B[16].ptr, (const double *) ctx->adaptive_dirs.ptr);
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, d_max, a, ap->motion_time_step, d_t0, d_t1);
         ECAL_HIP_TRY(ctx, hipMemcpyAsync(ring + 4 * (pass % 8u), a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ECAL_HIP_TRY(ctx, hipEventRecord(ctx->adaptive_ev[pass % 8u], st));

@@ -52,7 +52,7 @@ struct ecal_ctx {
     ecal_devbuf host_grid_order, host_grid_found;
     ecal_devbuf host_rect[11];  // staging of ecal_rectify_batch
     ecal_devbuf calib_scratch;  // ecal_calibrate_views: views, blocks, reduced records
-    ecal_devbuf adaptive_state, adaptive_keys;  // ecal_detect_keyframes: per-piece window state, keyframe records
+    ecal_devbuf adaptive_state, adaptive_keys, adaptive_dirs;  // ecal_detect_keyframes: per-piece window state, keyframe records, row directions per window
     hipEvent_t adaptive_ev[8] = {};             // ecal_detect_keyframes: one behind every pass in flight
     double *calib_pinned = nullptr;  // pinned host landing zone of the reduced record
     void *comm = nullptr;   // ncclComm_t (ecal_comm.hip); null = single rank
@@ -76,7 +76,7 @@ struct ecal_ctx {
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
                 &host_pipe[6], &host_pipe[7], &host_pipe[8], &host_pipe[9], &host_pipe[10], &host_pipe[11],
                 &host_pipe[12], &host_pipe[13], &host_pipe[14], &host_pipe[15], &host_pipe[16],
-                &host_grid_order, &host_grid_found, &calib_scratch, &adaptive_state, &adaptive_keys, &as_host, &ingest_ev[0], &ingest_ev[1], &ingest_feat};
+                &host_grid_order, &host_grid_found, &calib_scratch, &adaptive_state, &adaptive_keys, &adaptive_dirs, &as_host, &ingest_ev[0], &ingest_ev[1], &ingest_feat};
     }
 };
 
