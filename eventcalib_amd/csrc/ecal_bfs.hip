@@ -133,12 +133,16 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
     const uint32_t n_work = TIER > 0 ? defer_cnt[TIER - 1] : (win_list ? 2u * *win_count : S);
     // A segment starts with a chain of dependent global reads — which segment, its extent, then its points — that is a third of
     // the time a workgroup spends on it: the first two links are fetched one and two segments ahead.
+    // (a list entry with bit 30 / 31 set: the caller has no use for the window's first / second segment — BO_NONE, skipped)
     auto seg_of = [&](uint32_t w) -> uint32_t {
-        return TIER > 0 ? defer_list[(size_t) (TIER - 1) * S + w] : (win_list ? 2u * win_list[w >> 1] + (w & 1u) : w);
+        if (TIER > 0) return defer_list[(size_t) (TIER - 1) * S + w];
+        if (!win_list) return w;
+        const uint32_t t = win_list[w >> 1];
+        return ((t >> (30u + (w & 1u))) & 1u) ? BO_NONE : 2u * (t & 0x3FFFFFFFu) + (w & 1u);
     };
     const uint32_t G = gridDim.x;
     uint32_t s_cur = blockIdx.x < n_work ? seg_of(blockIdx.x) : 0u, n_cur = 0, base_cur = 0, nc_cur = 0;
-    if (blockIdx.x < n_work) {
+    if (blockIdx.x < n_work && s_cur != BO_NONE) {
         n_cur = seg_cnt[s_cur];
         base_cur = seg_off[s_cur];
         nc_cur = n_clusters[s_cur];
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
     for (uint32_t wk = blockIdx.x; wk < n_work; wk += G) {
         const uint32_t s = s_cur, n = n_cur, base = base_cur, nc = nc_cur;
         s_cur = s_nxt;
-        if (wk + G < n_work) {
+        if (wk + G < n_work && s_cur != BO_NONE) {
             n_cur = seg_cnt[s_cur];
             base_cur = seg_off[s_cur];
             nc_cur = n_clusters[s_cur];
@@ -157,6 +161,7 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
         unsigned long long bo_t__ = __builtin_amdgcn_s_memtime();
 #endif
         __syncthreads();   // the previous segment's LDS is dead
+        if (s == BO_NONE) continue;
         if (n == 0) {
             if (tid == 0) status[s] = 0;
             continue;

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(DET_T) void extract_first_list_kernel(
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, MODE == 1, false>(
-            smem, red, nk_sh, in_list[k], xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
+            smem, red, nk_sh, in_list[k] & 0x3FFFFFFFu /* (bits 30, 31: segments for ecal_cluster_order_list_dev to skip) */, xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
             members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order);
         __syncthreads();
     }

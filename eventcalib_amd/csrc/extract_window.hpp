@@ -415,25 +415,26 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     }
     __syncthreads();
     if constexpr (TDET && !ORD) {
-        bool mine = false;
         for (int pol = 0; pol < 2; pol++)
             for (uint32_t k = tid; k < nk[pol]; k += DET_T) {
                 const uint32_t rv = st.rep[kb[pol] + k];
                 if (rv & ST::REP_TIE) {
                     st.rep[kb[pol] + k] = rv & ~ST::REP_TIE;
-                    mine = true;
+                    nk_sh[pol] |= 0x80000000u;   // (nk[] was read into registers above; every writer stores the same bit)
                     // the cluster is named to ecal_cluster_order_list_dev by a mark on its representative's slot
                     int32_t *mk = pol ? mark1 : mark0;
                     if (mk) mk[rv & ~ST::REP_TIE] = -3;
                 }
             }
-        if (mine) nk_sh[0] |= 0x80000000u;   // (nk[] was read into registers above; every writer stores the same bit)
         __syncthreads();
-        const bool window_tied = (nk_sh[0] & 0x80000000u) != 0;
+        const uint32_t tied0 = nk_sh[0] >> 31, tied1 = nk_sh[1] >> 31;
+        const bool window_tied = (tied0 | tied1) != 0;
         __syncthreads();
         if (tid == 0 && window_tied) {
             nk_sh[0] &= 0x7FFFFFFFu;
-            if (tie_list) tie_list[atomicAdd(tie_count, 1u)] = tie_token;
+            nk_sh[1] &= 0x7FFFFFFFu;
+            // the list entry: the window, bits 30 / 31 set = its + / - segment holds no tied cluster (ecal_cluster_order_list_dev skips it)
+            if (tie_list) tie_list[atomicAdd(tie_count, 1u)] = tie_token | ((tied0 ^ 1u) << 30) | ((tied1 ^ 1u) << 31);
         }
         __syncthreads();
         // a listed window is extracted again from the start with the reference's picks (ORD): its pairing here would be

@@ -230,7 +230,8 @@ int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, const uint32
                                  double eps, uint32_t cluster_min, uint32_t need_clusters, double radius_threshold, int fit_circle,
                                  uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
                                  int32_t *d_kept_labels, uint32_t *d_rep, void *stream);
-/* ecal_cluster_order_dev restricted to the segments 2 w, 2 w + 1 of the windows w = d_win_list[0 .. *d_win_count) (device memory) */
+/* ecal_cluster_order_dev restricted to the segments 2 w, 2 w + 1 of the windows w = d_win_list[0 .. *d_win_count) (device memory;
+ * an entry with bit 30 / bit 31 set: without segment 2 w / 2 w + 1, whose d_order and d_status entries are then left as they are) */
 int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                                 double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
                                 uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
