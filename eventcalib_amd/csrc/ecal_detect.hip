@@ -185,12 +185,15 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
              *so = (uint32_t *) ctx->det_sorted.ptr;
     double *no = (double *) ctx->det_norms.ptr;
     const uint32_t grid2 = S < 768u ? S : 768u;
+    // the first pass over a LIST of windows (the tied ones: possibly all of them) shares the list among as many workgroups as
+    // the device holds at once — six per CU
+    const uint32_t gridf = S < 6u * ctx->n_cu ? S : 6u * ctx->n_cu;
 #define ECAL_DET_FIRST(FIT_, MODE_)                                                                                                  \
     hipLaunchKernelGGL((extract_kernel<FIT_, MODE_>), dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,    \
                        d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,              \
                        second ? list : nullptr, cnt, d_order, d_tie_list, d_tie_count, d_tie_mark)
 #define ECAL_DET_FIRST_LIST(FIT_, MODE_, LIST_, COUNT_)                                                                              \
-    hipLaunchKernelGGL((extract_first_list_kernel<FIT_, MODE_>), dim3(grid2), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off,         \
+    hipLaunchKernelGGL((extract_first_list_kernel<FIT_, MODE_>), dim3(gridf), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off,         \
                        d_seg_cnt, d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, \
                        so, no, second ? list : nullptr, cnt, LIST_, COUNT_, d_order)
 #define ECAL_DET_SECOND(FIT_, MODE_)                                                                                                 \
