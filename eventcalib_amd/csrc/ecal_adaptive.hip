@@ -186,7 +186,7 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
 __global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_time, double mts, AdaptiveArrays st) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) {
-        st.counters[0] = st.counters[1] = st.counters[2] = st.counters[3] = 0;
+        for (int i = 0; i < 8; i++) st.counters[i] = 0;
         *st.windows = 0;
     }
     if (k >= P) return;
@@ -312,6 +312,12 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
             sh_s2 = ns;
             sh_o = o;
             sh_act = ns < st.bound_hi[k] ? 1 : 0;  // :50
+#ifdef ECAL_ADAPTIVE_STATS
+            if (o == 0) atomicAdd(&st.counters[4], 1u);
+            else if (o != likely_outcome(f, s2, mts)) atomicAdd(&st.counters[5], 1u);
+            else if (level + 1 == n_levels) atomicAdd(&st.counters[6], 1u);
+            if (!sh_act) atomicAdd(&st.counters[7], 1u);
+#endif
             atomicMax(&st.counters[2], lev0 + level + 1u);
             st.levels[k] = lev0 + level + 1u;
             atomicAdd(st.windows, 1ull);
@@ -466,6 +472,13 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
             ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
             return ECAL_ERR_RANGE;
         }
+#ifdef ECAL_ADAPTIVE_STATS
+    {
+        uint32_t hs[8];
+        (void) hipMemcpy(hs, a.counters, sizeof(hs), hipMemcpyDeviceToHost);
+        fprintf(stderr, "chain ends: keyframe %u, other verdict %u, chain used up %u, piece finished %u\n", hs[4], hs[5], hs[6], hs[7]);
+    }
+#endif
     if (getenv("ECAL_ADAPTIVE_TRACE")) fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes\n", P, S, d_max, n_passes);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     unsigned long long nwin = 0;
