@@ -444,7 +444,9 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
     if world > 1:
         if hook is not None:
             opt.allreduce = hook
-        opt.distributed, opt.rank, opt.world_size = 1, rank, world       # (with a communicator the library all-reduces itself)
+        else:   # the library's RCCL communicator, asked for explicitly (a NULL all-reduce is a rank-local solve)
+            opt.allreduce, opt.allreduce_user = ctx.comm_allreduce_fn()
+        opt.distributed, opt.rank, opt.world_size = 1, rank, world
     # warm-up: two iterations
     opt.max_num_iterations = 2
     solver.solve(x0, opt)
@@ -573,7 +575,9 @@ def calib_leg(args, ctx, dev, world, rank, dist, torch, np):
     obj, img, rv, tv = SC.make_views(V, 0, seed=2024, noise_px=0.1)      # every rank builds the same 64 views ...
     lo, hi = (V * rank) // world, (V * (rank + 1)) // world              # ... and keeps its shard
     mine = img[lo:hi]
-    hook = capi.make_allreduce_hook(ctx, world) if (world > 1 and ctx.comm_size() == 1) else None   # gloo test hook only
+    hook = None
+    if world > 1:   # gloo test hook, or the library's RCCL communicator asked for explicitly
+        hook = capi.make_allreduce_hook(ctx, world) if ctx.comm_size() == 1 else ctx.comm_allreduce_fn()
     capi.calibrate_views(ctx, obj, mine, SC.WIDTH, SC.HEIGHT, 0, SC.FLAGS_EXAMPLE, 1.0, allreduce=hook)   # warm-up
     reps = 5
     if world > 1:

@@ -137,7 +137,7 @@ def _detect_pieces(ctx, events, motion_time_step, frame_event_num_threshold, pie
                 if e.status != -6 or S * per_window >= n_ev:
                     raise
                 per_window *= 2
-        status, found, cnt = packed[:, 0].astype(np.int64), packed[:, 1] != 0, packed[:, 2].astype(np.int64)   # cnt = EventFrame::eventsNum()
+        status, found, cnt = packed[:, 0].astype(np.int64) & 0xFF, packed[:, 1] != 0, packed[:, 2].astype(np.int64)   # cnt = EventFrame::eventsNum()
         ok = (status == 0) & found
         accepted = np.zeros(S, bool)
         if ok.any():

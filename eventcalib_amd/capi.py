@@ -14,7 +14,7 @@ EXPORTED_SYMBOLS = [
     "ecal_dbscan_batch", "ecal_dbscan_batch_dev",
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_sort_events_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
-    "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev",
+    "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev", "ecal_comm_allreduce",
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_set_median_ties",
     "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
@@ -210,6 +210,12 @@ class Context:
 
     def comm_rank(self):
         return self._L.ecal_comm_rank(self._h)
+
+    def comm_allreduce_fn(self):
+        """(ALLREDUCE_FN, user pointer) that make a solve / calibration all-reduce through this context's communicator
+        (options.allreduce = ecal_comm_allreduce, options.allreduce_user = the context) — collectives are explicit."""
+        fn = ctypes.cast(self._L.ecal_comm_allreduce, ALLREDUCE_FN)
+        return fn, ctypes.cast(self._h, ctypes.c_void_p)
 
     def comm_allreduce_sum_dev(self, d_buf, n_doubles, stream=0):
         self._check(self._L.ecal_comm_allreduce_sum_dev(self._h, d_buf, int(n_doubles), stream))
@@ -603,7 +609,10 @@ def calibrate_views(ctx: Context, obj, img, width, height, model=0, flags=0, asp
     L.ecal_calib_default_options(ctypes.byref(opt))
     opt.model, opt.flags, opt.aspect_ratio, opt.max_iter, opt.eps = int(model), int(flags), float(aspect_ratio), int(max_iter), float(eps)
     if allreduce is not None:
-        opt.allreduce = allreduce
+        if isinstance(allreduce, tuple):   # Context.comm_allreduce_fn(): (function, user pointer)
+            opt.allreduce, opt.allreduce_user = allreduce
+        else:
+            opt.allreduce = allreduce
     res = CalibResult()
     rv, tv, pe = np.zeros((V, 3)), np.zeros((V, 3)), np.zeros(V)
     ctx._check(L.ecal_calibrate_views(ctx._h, _ptr(obj), obj.shape[0], _ptr(img) if V else None, V, float(width), float(height),

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64) void adaptive_dir_kernel(uint32_t rows, uint32_
                                                           const int32_t *__restrict__ order, const uint32_t *__restrict__ found,
                                                           double *__restrict__ dirs /*[S][rows][2]*/) {
     const uint32_t w = blockIdx.x, lane = threadIdx.x;
-    if (!(win_info[4 * w + 3] == 0 && found[w]) || lane >= rows) return;
+    if (!(ECAL_WIN_STATUS(win_info[4 * w + 3]) == 0 && found[w]) || lane >= rows) return;
     const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
     const int32_t *ord = order + (size_t) w * rows * cols;
     double dx, dy;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         __syncthreads();
         const double f = sh_f, s2 = sh_s2;
         const uint32_t cnt = seg_cnt[2 * w] + seg_cnt[2 * w + 1];  // EventFrame::eventsNum()
-        const bool ok = win_info[4 * w + 3] == 0 && found[w];     // extractFeatures() == true
+        const bool ok = ECAL_WIN_STATUS(win_info[4 * w + 3]) == 0 && found[w];     // extractFeatures() == true
         if (lane == 0) {
             const double *dir = dirs + 2 * (size_t) w * rows;   // [rows][2]
             bool accepted = false;

@@ -9,7 +9,8 @@
 // Clusters[c] it stands.  extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147) depend
 // on that order when two members tie in norm.
 //
-// One workgroup per segment (<= 4096 points in three size tiers; coordinates as the doubles they are, no pixel assumption):
+// One workgroup per segment (three LDS tiers up to 4096 points, then a global-scratch tier for anything larger or anything a
+// tier's fixed list / stack sizes cannot hold; coordinates as the doubles they are, no pixel assumption):
 //   1. the insertion-order kd-tree rebuilt level-synchronously: every unplaced point stands at a node of the current depth
 //      and bids its pid with ds_min for the child slot on its side — the smallest pid wins, as sequential insertion
 //      (kdtree.cpp:106-146) would place it —, the others go on below the winner; one level and one barrier per round;
@@ -21,6 +22,7 @@
 #include <algorithm>
 #include <type_traits>
 #include "ecal_ctx.hpp"
+#include "block_utils.hpp"
 
 #pragma clang fp contract(off)
 
@@ -171,13 +173,8 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
                          : (n <= BO_CAP2 && nc <= BoLayout<BO_CAP2>::NCAP) ? 1
                          : (n <= BO_CAP3 && nc <= BoLayout<BO_CAP3>::NCAP) ? 2 : 3;
         if (TIER > 0 ? (n > CAP || nc > BoLayout<CAP>::NCAP) : tier != 0) {   // (the later launches take what was listed for them)
-            if constexpr (TIER == 0) {
-                if (tier == 3) {
-                    for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
-                    if (tid == 0) status[s] = 1;
-                } else if (tid == 0) {
-                    defer_list[(size_t) (tier - 1) * S + atomicAdd(&defer_cnt[tier - 1], 1u)] = s;
-                }
+            if constexpr (TIER == 0) {   // (tier 3: the global-scratch launch, cluster_order_big_kernel)
+                if (tid == 0) defer_list[(size_t) (tier - 1) * S + atomicAdd(&defer_cnt[tier - 1], 1u)] = s;
             }
             continue;
         }
@@ -419,10 +416,9 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
         if (fail) red[3] = 1;
         __threadfence_block();
         __syncthreads();
-        if (red[3]) {
-            for (uint32_t i = tid; i < n; i += BO_T) order[base + i] = -1;
-            if (tid == 0) status[s] = 1;
-            continue;
+        if (red[3]) {   // more hits in one eps-ball or more pending subtrees than this tier's fixed sizes: the global-scratch launch
+            if (tid == 0) defer_list[(size_t) 2 * S + atomicAdd(&defer_cnt[2], 1u)] = s;
+            continue;   // (the caller's marks in `order` are still in place: nothing has been written yet)
         }
         BO_MARK(4);
         // ---- 3. expandCluster's queue, one thread per cluster (dbscan.h:229-265) ----
@@ -498,19 +494,333 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
     }
 }
 
+// ---- the global-scratch launch: segments of any size -------------------------------------------------------------------------
+// What the LDS tiers leave over — more than 4096 points or 2048 clusters (BASELINE configs[0]: 100 k events in ONE window), more
+// than BO_MAXN hits in one eps-ball, more than BO_STACK pending subtrees — is taken here with the same three steps on a workspace
+// in global memory, without fixed list or stack sizes:
+//   * the tree is rebuilt level by level as above (all unplaced points of round r stand at depth r) and keeps PARENT links;
+//   * a range query walks the tree without a stack, and directly in the order of the reference's RESULT list: that list is
+//     the reverse of find_nearest's visiting order (node, near subtree, far subtree; kdtree.cpp:148-179,469-486), i.e.
+//     [far subtree reversed, if fabs(dx) < range] [near subtree reversed] [node] — a post-order walk that needs only "where did
+//     I come from" (parent, far child or near child) to go on;
+//   * every wanted core point's query runs twice, in parallel: once to count its hits, once (after a scan of the counts) to
+//     write them into the workgroup's arena; then a wave per wanted cluster simulates expandCluster's queue.
+// Latency does not matter here (the segments are rare and large); what matters is that no size is refused: status 1 is left
+// for segments beyond the workspace (BO_BIG_W points) or whose hit lists overflow the arena.
+constexpr int BO_TB = 1024;
+constexpr uint32_t BO_BIG_GRID = 2;
+constexpr uint32_t BO_BIG_W = 1u << 20;        // points per segment the workspace is sized for (at most; the caller's n_points if smaller)
+constexpr uint32_t BO_BIG_ARENA = 1u << 24;    // hit-list entries per workgroup (at most; 64 per point of the workspace if smaller)
+// workspace words per point of capacity: child 2 | parent | cur | off (+1) | queue | qbase (+1) | seed | tie | inq (1/32)
+__host__ __device__ constexpr size_t bo_big_words(size_t W) { return 10 * W + W / 32 + 16; }
+
+__device__ __forceinline__ uint32_t bo_ld(const uint32_t *p) {   // a word other waves wrote with atomics: read at L2
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One range query in result-list order.  emit(j) is called for every hit (d2 <= eps^2, the query point itself excluded,
+// dbscan.h:218) in the order the reference's list holds them.
+template <typename F>
+__device__ __forceinline__ void bo_query_reversed(const double2 *__restrict__ pts, const uint32_t *child, const uint32_t *parent,
+                                                  uint32_t q, double eps, double eps2, F emit) {
+    const double2 pq = pts[q];
+    uint32_t node = 0, from = BO_NONE, dir = 0;   // from: BO_NONE = arrived from the parent, else the child just finished
+    for (;;) {
+        const double2 pn = pts[node];
+        const double dx = dir ? (pq.y - pn.y) : (pq.x - pn.x);
+        const uint32_t l = bo_ld(&child[2 * node]), r = bo_ld(&child[2 * node + 1]);   // (written by atomics: read at L2)
+        const uint32_t nearc = dx <= 0.0 ? l : r, farc = dx <= 0.0 ? r : l;
+        uint32_t next = BO_NONE;
+        if (from == BO_NONE) {                       // first arrival: the far subtree comes first in the list, then the near one
+            if (fabs(dx) < eps && farc != BO_NONE) next = farc;
+            else if (nearc != BO_NONE) next = nearc;
+        } else if (from == farc && nearc != BO_NONE) {
+            next = nearc;                            // (from == nearc: both subtrees are done)
+        }
+        if (next != BO_NONE) {
+            node = next;
+            from = BO_NONE;
+            dir ^= 1u;
+            continue;
+        }
+        {   // the node itself closes its subtree's part of the list
+            const double ddx = pn.x - pq.x, ddy = pn.y - pq.y;
+            double d2 = 0;
+            d2 += ddx * ddx;   // dist_sq += SQ(node->pos[i] - pos[i]), i ascending (kdtree.cpp:155-159)
+            d2 += ddy * ddy;
+            if (d2 <= eps2 && node != q) emit(node);
+        }
+        const uint32_t up = parent[node];
+        if (up == BO_NONE) return;
+        from = node;
+        node = up;
+        dir ^= 1u;
+    }
+}
+
+__global__ __launch_bounds__(BO_TB) void cluster_order_big_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
+                                                                  const uint32_t *__restrict__ seg_cnt, uint32_t S, double eps,
+                                                                  const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters,
+                                                                  int32_t *__restrict__ order, uint32_t *__restrict__ status, int only_tied,
+                                                                  const uint32_t *__restrict__ defer_list, const uint32_t *__restrict__ defer_cnt,
+                                                                  uint32_t *__restrict__ ws, uint32_t W, uint32_t *__restrict__ arena_all,
+                                                                  uint32_t arena_cap) {
+    __shared__ unsigned long long red[BO_TB / 64 + 2];
+    __shared__ uint32_t flag[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t *const w0 = ws + (size_t) blockIdx.x * bo_big_words(W);
+    uint32_t *const child = w0, *const parent = child + 2 * (size_t) W, *const cur = parent + W, *const off = cur + W,
+                    *const queue = off + W + 1, *const qbase = queue + W, *const seed = qbase + W + 1, *const tie = seed + W,
+                    *const inq = tie + W;
+    uint32_t *const arena = arena_all + (size_t) blockIdx.x * arena_cap;
+    const double eps2 = eps * eps;
+    const uint32_t n_work = defer_cnt[2];
+    for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
+        const uint32_t s = defer_list[(size_t) 2 * S + wk];
+        const uint32_t n = seg_cnt[s], base = seg_off[s], nc = n_clusters[s];
+        const double2 *const pts = reinterpret_cast<const double2 *>(xy) + base;
+        const int32_t *const lab = labels + base;
+        __syncthreads();
+        auto refuse = [&]() {
+            for (uint32_t i = tid; i < n; i += BO_TB) order[base + i] = -1;
+            if (tid == 0) status[s] = 1;
+        };
+        if (n > W || nc > W) {
+            refuse();
+            continue;
+        }
+        if (tid < 4) flag[tid] = 0;
+        for (uint32_t i = tid; i < n; i += BO_TB) {
+            // (only_tied == 2) the caller's marks, read before anything is written to `order`
+            tie[i] = (only_tied == 2 && order[base + i] == -3) ? 1u : 0u;
+            child[2 * i] = BO_NONE;
+            child[2 * i + 1] = BO_NONE;
+            parent[i] = BO_NONE;
+            cur[i] = i == 0 ? BO_NONE : 0u;   // the node the point stands at; BO_NONE once it is placed (the root is)
+        }
+        for (uint32_t c = tid; c <= nc; c += BO_TB) qbase[c] = 0;
+        for (uint32_t c = tid; c < nc; c += BO_TB) seed[c] = BO_NONE;
+        for (uint32_t w = tid; w < n / 32u + 1u; w += BO_TB) inq[w] = 0;
+        __threadfence();
+        __syncthreads();
+        // members per cluster, seeds; the marks move from the points to their clusters (queue[] = scratch for them)
+        for (uint32_t i = tid; i < n; i += BO_TB)
+            if (lab[i] >= 0) {
+                atomicAdd(&qbase[lab[i] + 1], 1u);
+                atomicMin(&seed[lab[i]], i);
+            }
+        for (uint32_t c = tid; c < nc; c += BO_TB) queue[c] = 0;
+        __threadfence();
+        __syncthreads();
+        if (only_tied == 2)
+            for (uint32_t i = tid; i < n; i += BO_TB)
+                if (lab[i] >= 0 && tie[i]) queue[lab[i]] = 1;   // (every writer: the same value)
+        {   // offsets of the clusters' queues: inclusive scan of the counts, a contiguous chunk per thread
+            const uint32_t per = (nc + 1u + BO_TB - 1u) / BO_TB, c0 = tid * per;
+            uint32_t sum = 0;
+            for (uint32_t c = c0; c < c0 + per && c <= nc; c++) sum += bo_ld(&qbase[c]);
+            uint32_t ex, d0, tot, d1;
+            block_exscan_pair<BO_TB>(sum, 0u, red, &ex, &d0, &tot, &d1);
+            for (uint32_t c = c0; c < c0 + per && c <= nc; c++) {
+                ex += bo_ld(&qbase[c]);
+                qbase[c] = ex;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        // which clusters are wanted (seed[c] = BO_NONE - 1: not wanted, its members get -2)
+        if (only_tied == 2) {
+            bool any = false;
+            for (uint32_t c = tid; c < nc; c += BO_TB) {
+                if (queue[c]) any = true;
+                else seed[c] = BO_NONE - 1u;
+            }
+            if (any) flag[0] = 1;
+        } else if (only_tied) {
+            // own test (as the LDS tiers): the member of rank size / 2 in the order (norm, pid) shares its norm with another
+            for (uint32_t c = tid; c < nc; c += BO_TB) tie[c] = 0;   // (the marks are not in use in this mode)
+            for (uint32_t c = tid; c < nc; c += BO_TB) cur[c] = 0;   // scatter cursors (cur[] is set up again below)
+            __threadfence();
+            __syncthreads();
+            uint32_t *const members = arena;   // [n] (the arena is free until the hit lists are written)
+            if (n <= arena_cap) {
+                for (uint32_t i = tid; i < n; i += BO_TB)
+                    if (lab[i] >= 0) members[qbase[lab[i]] + atomicAdd(&cur[lab[i]], 1u)] = i;
+                __threadfence();
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += BO_TB) {
+                    if (lab[i] < 0) continue;
+                    const uint32_t c = (uint32_t) lab[i], qb = qbase[c], m = qbase[c + 1] - qb;
+                    const double di = pts[i].x * pts[i].x + pts[i].y * pts[i].y;
+                    const bool whole_i = di == floor(di);
+                    const double ki = __dsqrt_rn(di);
+                    uint32_t rank = 0, eq = 0;
+                    for (uint32_t t = 0; t < m; t++) {
+                        const uint32_t j = members[qb + t];
+                        const double dj = pts[j].x * pts[j].x + pts[j].y * pts[j].y;
+                        bool lt, same;
+                        if (whole_i && dj == floor(dj)) {
+                            lt = dj < di;
+                            same = dj == di;
+                        } else {
+                            const double kj = __dsqrt_rn(dj);
+                            lt = kj < ki;
+                            same = kj == ki;
+                        }
+                        rank += (lt || (same && j < i)) ? 1u : 0u;
+                        eq += same ? 1u : 0u;
+                    }
+                    if (rank == m / 2u && eq > 1u) tie[c] = 1;
+                }
+            } else if (tid == 0) {
+                flag[3] = 1;
+            }
+            __threadfence();
+            __syncthreads();
+            bool any = false;
+            for (uint32_t c = tid; c < nc; c += BO_TB) {
+                if (tie[c]) any = true;
+                else seed[c] = BO_NONE - 1u;
+            }
+            if (any) flag[0] = 1;
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += BO_TB) cur[i] = i == 0 ? BO_NONE : 0u;
+        } else if (tid == 0) {
+            flag[0] = 1;
+        }
+        __threadfence();
+        __syncthreads();
+        if (flag[3]) {
+            refuse();
+            continue;
+        }
+        if (!flag[0]) {   // no wanted cluster in this segment
+            for (uint32_t i = tid; i < n; i += BO_TB) order[base + i] = lab[i] < 0 ? -1 : -2;
+            if (tid == 0) status[s] = 0;
+            continue;
+        }
+        // ---- 1. the insertion-order kd-tree, level by level (kdtree.cpp:106-146; see cluster_order_kernel) ----
+        for (uint32_t round = 0;; round++) {
+            const bool dy = round & 1u;
+            bool active = false;
+            if (tid == 0) flag[1 + ((round + 1u) & 1u)] = 0;
+            for (uint32_t i = tid; i < n; i += BO_TB) {
+                const uint32_t c = cur[i];
+                if (c == BO_NONE) continue;
+                const double v = dy ? pts[i].y : pts[i].x, cv = dy ? pts[c].y : pts[c].x;
+                atomicMin(&child[2 * c + (v < cv ? 0u : 1u)], i);   // left iff pos[dir] < node->pos[dir] (kdtree.cpp:128-131)
+                active = true;
+            }
+            if (active) flag[1 + (round & 1u)] = 1;
+            __threadfence();
+            __syncthreads();
+            if (flag[1 + (round & 1u)] == 0) break;
+            for (uint32_t i = tid; i < n; i += BO_TB) {
+                const uint32_t c = cur[i];
+                if (c == BO_NONE) continue;
+                const double v = dy ? pts[i].y : pts[i].x, cv = dy ? pts[c].y : pts[c].x;
+                const uint32_t w = bo_ld(&child[2 * c + (v < cv ? 0u : 1u)]);
+                if (w == i) {
+                    parent[i] = c;
+                    cur[i] = BO_NONE;
+                } else {
+                    cur[i] = w;
+                }
+            }
+            __syncthreads();   // (flag[] of this round is cleared by thread 0 at the top of the round after the next)
+        }
+        __threadfence();
+        __syncthreads();
+        // ---- 2. the range queries of the wanted clusters' core points: count, scan, fill ----
+        // (child[] was written by atomics: the walks read it at L2; parent[] by plain stores of this workgroup)
+        auto wanted = [&](uint32_t i) { return lab[i] >= 0 && bo_ld(&seed[lab[i]]) != BO_NONE - 1u; };
+        for (uint32_t i = tid; i < n; i += BO_TB) {
+            uint32_t cnt = 0;
+            if (wanted(i)) bo_query_reversed(pts, child, parent, i, eps, eps2, [&](uint32_t) { cnt++; });
+            cur[i] = cnt;
+        }
+        __syncthreads();
+        {
+            const uint32_t per = (n + BO_TB - 1u) / BO_TB, i0 = tid * per;
+            unsigned long long sum = 0;
+            for (uint32_t i = i0; i < i0 + per && i < n; i++) sum += cur[i];
+            // (two 32-bit lanes of the pair scan carry the low and high half: totals beyond 2^32 must be seen as overflow)
+            uint32_t ex, exh, tot, toth;
+            block_exscan_pair<BO_TB>((uint32_t) (sum & 0xFFFFFu), (uint32_t) (sum >> 20), red, &ex, &exh, &tot, &toth);
+            const unsigned long long total = ((unsigned long long) toth << 20) + tot;
+            if (total > arena_cap) {
+                if (tid == 0) flag[3] = 1;
+            } else {
+                uint32_t run = (uint32_t) (((unsigned long long) exh << 20) + ex);
+                for (uint32_t i = i0; i < i0 + per && i < n; i++) {
+                    off[i] = run;
+                    run += cur[i];
+                }
+                if (tid == 0) off[n] = (uint32_t) total;
+            }
+        }
+        __syncthreads();
+        if (flag[3]) {
+            refuse();
+            continue;
+        }
+        for (uint32_t i = tid; i < n; i += BO_TB) {
+            if (!wanted(i)) continue;
+            uint32_t *out = arena + off[i];
+            bo_query_reversed(pts, child, parent, i, eps, eps2, [&](uint32_t j) { *out++ = j; });
+        }
+        for (uint32_t i = tid; i < n; i += BO_TB)
+            if (lab[i] < 0) order[base + i] = -1;
+            else if (bo_ld(&seed[lab[i]]) == BO_NONE - 1u) order[base + i] = -2;
+        __threadfence();
+        __syncthreads();
+        // ---- 3. expandCluster's queue (dbscan.h:229-265), a wave per wanted cluster, a lane per neighbour of the popped point ----
+        for (uint32_t c = wave; c < nc; c += BO_TB / 64u) {   // (uniform in the wave)
+            const uint32_t qb = qbase[c], sd = bo_ld(&seed[c]);
+            if (sd >= BO_NONE - 1u) continue;
+            uint32_t head = 0, tail = 1;
+            if (lane == 0) {
+                queue[qb] = sd;
+                atomicOr(&inq[sd >> 5], 1u << (sd & 31u));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            while (head < tail) {
+                const uint32_t q = reinterpret_cast<volatile uint32_t *>(queue)[qb + head];
+                if (lane == 0) order[base + q] = (int32_t) head;
+                head++;
+                const uint32_t lo = off[q], m = off[q + 1] - lo;   // (a wanted cluster's members all have their lists)
+                for (uint32_t k0 = 0; k0 < m; k0 += 64u) {
+                    bool take = false;
+                    uint32_t j = 0;
+                    if (k0 + lane < m) {
+                        j = arena[lo + k0 + lane];
+                        if ((uint32_t) lab[j] == c) {   // a core point of this cluster (others never expand, never get listed)
+                            const uint32_t bit = 1u << (j & 31u);
+                            take = !(atomicOr(&inq[j >> 5], bit) & bit);   // not yet in the border set
+                        }
+                    }
+                    const unsigned long long mask = __ballot(take);
+                    if (take) queue[qb + tail + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                    tail += (uint32_t) __popcll(mask);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (tid == 0) status[s] = 0;
+    }
+}
+
 }  // namespace ecal
 
 using namespace ecal;
 
-extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
-                                           uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
-                                           uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list,
-                                           const uint32_t *d_win_count, void *stream);
 extern "C" int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
                                       uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters,
                                       int32_t *d_order, uint32_t *d_status, int only_tied_medians, void *stream) {
-    return ecal_cluster_order_list_dev(ctx, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status,
-                                       only_tied_medians, nullptr, nullptr, stream);
+    return ecal_cluster_order_sized(ctx, d_xy, d_seg_off, d_seg_cnt, S, 0xFFFFFFFFu, eps, d_labels, d_n_clusters, d_order, d_status,
+                                    only_tied_medians, nullptr, nullptr, stream);
 }
 
 // d_win_list != NULL: only the segments 2 w and 2 w + 1 of the windows w = d_win_list[0 .. *d_win_count) (S = 2 x windows in all)
@@ -518,6 +828,16 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
                                            uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
                                            uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list,
                                            const uint32_t *d_win_count, void *stream) {
+    return ecal_cluster_order_sized(ctx, d_xy, d_seg_off, d_seg_cnt, S, 0xFFFFFFFFu, eps, d_labels, d_n_clusters, d_order, d_status,
+                                    only_tied_medians, d_win_list, d_win_count, stream);
+}
+
+// n_points: an upper bound on any segment's size (the callers inside the library know their point capacity) — it sizes the
+// global-scratch launch's workspace
+int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
+                             uint32_t n_points, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
+                             uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
+                             void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (!d_xy || !d_seg_off || !d_seg_cnt || !d_labels || !d_n_clusters || !d_order || !d_status) {
@@ -539,10 +859,16 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
     uint16_t *lists = (uint16_t *) ctx->bfs_lists.ptr;
     uint8_t *cnt = (uint8_t *) (lists + rows * BO_MAXN);
     // the segments the first launch leaves to the later ones: two counters, two lists of up to S entries
-    if ((rc = ecal_ensure(ctx, ctx->bfs_defer, (2 * (size_t) S + 4) * sizeof(uint32_t)))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->bfs_defer, (3 * (size_t) S + 4) * sizeof(uint32_t)))) return rc;
     uint32_t *dcnt = (uint32_t *) ctx->bfs_defer.ptr, *dlist = dcnt + 4;
-    if (uint32_t *z = ecal_zero_words(ctx, st, 2)) dcnt = z;
-    else ECAL_HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 2 * sizeof(uint32_t), st));
+    if (uint32_t *z = ecal_zero_words(ctx, st, 3)) dcnt = z;
+    else ECAL_HIP_TRY(ctx, hipMemsetAsync(dcnt, 0, 3 * sizeof(uint32_t), st));
+    // the global-scratch launch's workspace and hit-list arena, a slice per workgroup
+    const uint32_t bigW = std::max<uint32_t>(std::min<uint32_t>(n_points, BO_BIG_W), 64u);
+    const uint32_t big_arena = (uint32_t) std::min<uint64_t>(BO_BIG_ARENA, std::max<uint64_t>(64ull * bigW, std::min<uint64_t>((uint64_t) bigW * bigW, 1ull << 22)));
+    const uint32_t grid_big = std::min<uint32_t>(S, BO_BIG_GRID);
+    if ((rc = ecal_ensure(ctx, ctx->bfs_big, (size_t) grid_big * (bo_big_words(bigW) + big_arena) * sizeof(uint32_t)))) return rc;
+    uint32_t *big_ws = (uint32_t *) ctx->bfs_big.ptr, *big_hits = big_ws + (size_t) grid_big * bo_big_words(bigW);
     if (!ctx->bfs_attr_set) {
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP1, BO_T1, 0>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP1>::bytes));
@@ -560,6 +886,8 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP3, BO_T2, 2>), dim3(grid3), dim3(BO_T2), BoLayout<BO_CAP3>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
+    hipLaunchKernelGGL(cluster_order_big_kernel, dim3(grid_big), dim3(BO_TB), 0, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels, d_n_clusters,
+                       d_order, d_status, only_tied_medians, (const uint32_t *) dlist, (const uint32_t *) dcnt, big_ws, bigW, big_hits, big_arena);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
@@ -606,7 +934,9 @@ extern "C" int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_off, h.data(), 2 * (size_t) S * 4, hipMemcpyHostToDevice, st));
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_ncl, n_clusters, (size_t) S * 4, hipMemcpyHostToDevice, st));
     ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));   // h is pageable: consumed
-    if ((rc = ecal_cluster_order_dev(ctx, d_xy, d_off, d_cnt, S, eps, d_lab, d_ncl, d_ord, d_st, 0, st))) return rc;
+    if ((rc = ecal_cluster_order_sized(ctx, d_xy, d_off, d_cnt, S, (uint32_t) std::min<size_t>(N, 0xFFFFFFFFu), eps, d_lab, d_ncl, d_ord, d_st, 0,
+                                       nullptr, nullptr, st)))
+        return rc;
     std::vector<int32_t> to(N);
     std::vector<uint32_t> ts(S);
     if (N) ECAL_HIP_TRY(ctx, hipMemcpyAsync(to.data(), d_ord, N * 4, hipMemcpyDeviceToHost, st));

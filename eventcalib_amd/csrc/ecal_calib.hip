@@ -894,14 +894,7 @@ extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n
                                     double height, const ecal_calib_options *opt_in, ecal_calib_result *res, double *rvecs, double *tvecs,
                                     double *per_view_err) {
     if (!ctx) return ECAL_ERR_INVALID;
-    ecal_calib_options opt_local;
-    const ecal_calib_options *opt = opt_in;
-    if (opt_in && !opt_in->allreduce && ctx->comm && ctx->comm_size > 1) {   // the context's own RCCL communicator (ecal_comm_init)
-        opt_local = *opt_in;
-        opt_local.allreduce = ecal_comm_allreduce_hook;
-        opt_local.allreduce_user = ctx;
-        opt = &opt_local;
-    }
+    const ecal_calib_options *opt = opt_in;   // opt->allreduce == NULL: rank-local, always (ecal_comm_allreduce is explicit)
     if (!obj || (!img && n_views) || !opt || !res || n_pts < 4 || n_pts > CB_MAXPTS || (opt->model != 0 && opt->model != 1) ||
         !(width > 0) || !(height > 0)) {
         ctx->last_error = "ecal_calibrate_views: bad argument";

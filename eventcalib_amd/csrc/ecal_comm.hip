@@ -4,8 +4,9 @@
 // the spline residuals sharded one batch per GPU with the per-view J^T J / J^T r blocks summed by an RCCL all-reduce over
 // xGMI.  The messages are tiny (91 .. 170 doubles per evaluation): latency bound, one ncclAllReduce on the
 // solver's own stream each, nothing proportional to the number of control points or views crosses the links.
-// ecal_solver_solve and ecal_calibrate_views use this communicator by themselves when the caller's options carry no
-// all-reduce callback (the callback form stays for transports other than RCCL, e.g. the gloo tests).
+// ecal_solver_solve and ecal_calibrate_views use this communicator only when the caller says so: options.allreduce =
+// ecal_comm_allreduce, options.allreduce_user = the context (NULL always means a rank-local call; the callback seam takes
+// any other transport, e.g. the gloo tests).
 #include "ecal_ctx.hpp"
 
 #include <rccl/rccl.h>
@@ -69,7 +70,12 @@ extern "C" int ecal_comm_allreduce_sum_dev(ecal_ctx *ctx, double *d_buf, size_t 
     return ECAL_OK;
 }
 
-// the ecal_allreduce_fn the solver and the calibration fall back to when the options carry none
-int ecal_comm_allreduce_hook(void *user, double *d_buf, size_t n_doubles, void *stream) {
-    return ecal_comm_allreduce_sum_dev((ecal_ctx *) user, d_buf, n_doubles, stream);
+// the ecal_allreduce_fn a caller puts into its options to all-reduce through the context's communicator (user = the context)
+extern "C" int ecal_comm_allreduce(void *user, double *d_buf, size_t n_doubles, void *stream) {
+    ecal_ctx *ctx = (ecal_ctx *) user;
+    if (ctx && !ctx->comm) {   // asked for a collective on a context that never joined one: say so instead of summing nothing
+        ctx->last_error = "ecal_comm_allreduce: the context has no communicator (ecal_comm_init)";
+        return ECAL_ERR_COMM;
+    }
+    return ecal_comm_allreduce_sum_dev(ctx, d_buf, n_doubles, stream);
 }

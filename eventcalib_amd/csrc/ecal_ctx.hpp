@@ -39,6 +39,7 @@ struct ecal_ctx {
     ecal_devbuf bfs_host;   // staging of ecal_cluster_order
     ecal_devbuf bfs_lists;  // ecal_cluster_order_dev: neighbour lists of the range queries, one slice per workgroup
     ecal_devbuf bfs_defer;  // ecal_cluster_order_dev: the segments the first launch leaves to the later ones
+    ecal_devbuf bfs_big;    // ecal_cluster_order_dev: workspace + hit-list arena of the global-scratch launch
     ecal_devbuf fused_def;  // [4 + S] u32: count, then the windows the fused pass (ecal_fused.hip) did not carry to the end
     bool fused_pass = false;  // set by ecal_detect_fused_dev around its calls of the three stage functions: their first passes have run
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
@@ -70,7 +71,7 @@ struct ecal_ctx {
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos, &sl_order, &sl_order_big, &bucket_tab, &sort_scratch,
-                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &fused_def, &bfs_lists, &bfs_defer, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
+                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &fused_def, &bfs_lists, &bfs_defer, &bfs_big, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
                 &host_rect[7], &host_rect[8], &host_rect[9], &host_rect[10],
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],
@@ -89,8 +90,11 @@ struct ecal_ctx {
         }                                                                                             \
     } while (0)
 
-// all-reduce through the context's communicator (user = the ecal_ctx): ecal_allreduce_fn for the solver / calibration
-int ecal_comm_allreduce_hook(void *user, double *d_buf, size_t n_doubles, void *stream);
+// ecal_cluster_order_list_dev with the callers' bound on a segment's size (ecal_bfs.hip)
+int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
+                             uint32_t n_points, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
+                             uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
+                             void *stream);
 // extraction as the context's ecal_set_median_ties setting wants it (ecal_detect.hip): the exact form needs the DBSCAN radius
 int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
                          const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min,

@@ -290,8 +290,8 @@ extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, c
                             tcnt, order, stream)))
         return rc;
     // (only_tied_medians = 2: the tied clusters are the ones whose representative's slot the plain pass marked in `order`)
-    if ((rc = ecal_cluster_order_list_dev(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, eps, d_labels, d_n_clusters, order, ostatus, 2, tlist, tcnt,
-                                          stream)))
+    if ((rc = ecal_cluster_order_sized(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, n_points, eps, d_labels, d_n_clusters, order, ostatus, 2, tlist,
+                                       tcnt, stream)))
         return rc;
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, order, tlist, tcnt, nullptr, nullptr,

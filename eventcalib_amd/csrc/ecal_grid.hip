@@ -53,7 +53,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     int32_t *out = order + (size_t) s * M;
     for (uint32_t m = lane; m < M; m += GR_T) out[m] = -1;
     if (lane == 0) found[s] = 0;
-    if (win_info[4 * (size_t) s + 3] != 0 || n < M || n > GR_MAXC || M > GR_MAXM) return;
+    if (ECAL_WIN_STATUS(win_info[4 * (size_t) s + 3]) != 0 || n < M || n > GR_MAXC || M > GR_MAXM) return;
     const double *c = cand_xyr + 3 * (size_t) seg_off[2 * s];
     for (uint32_t i = lane; i < n; i += GR_T) {
         px[i] = c[3 * i];

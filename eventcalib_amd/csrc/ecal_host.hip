@@ -182,7 +182,7 @@ __global__ void gather_features_kernel(const uint32_t *win_info, const uint32_t 
     if (i >= S * M) return;
     const uint32_t s = i / M;
     double x = NAN, y = NAN, r = NAN;
-    if (win_info[4 * s + 3] == 0 && found[s]) {
+    if (ECAL_WIN_STATUS(win_info[4 * s + 3]) == 0 && found[s]) {
         const size_t c = (size_t) seg_off[2 * s] + (uint32_t) order[i];
         x = cand_xyr[3 * c];
         y = cand_xyr[3 * c + 1];
@@ -222,7 +222,7 @@ __global__ void pack_pass_kernel(const uint32_t *win_info, const uint32_t *seg_o
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= S * (M + 1)) return;
     const uint32_t s = i / (M + 1), k = i % (M + 1);
-    const bool ok = win_info[4 * s + 3] == 0 && found[s];
+    const bool ok = ECAL_WIN_STATUS(win_info[4 * s + 3]) == 0 && found[s];
     double *o = out + (size_t) s * W;
     if (k == M) {  // header: status, grid flag, EventFrame::eventsNum()
         o[0] = (double) win_info[4 * s + 3];

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(RC_T) void rectify_kernel(const double2 *__restrict
     const uint32_t s = frame_window[f], n = prm.rows * prm.cols;
     const uint32_t base[2] = {seg_off[2 * s], seg_off[2 * s + 1]}, cnt[2] = {seg_cnt[2 * s], seg_cnt[2 * s + 1]};
     const uint32_t nk[2] = {win_info[4 * (size_t) s + 1], win_info[4 * (size_t) s + 2]};
-    const bool unsupported = win_info[4 * (size_t) s + 3] == 4 || nk[0] > RC_MAXK || nk[1] > RC_MAXK;
+    const bool unsupported = ECAL_WIN_STATUS(win_info[4 * (size_t) s + 3]) == 4 || nk[0] > RC_MAXK || nk[1] > RC_MAXK;
     double R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 9; i++) R[i] = pose[12 * (size_t) f + i];

@@ -1086,11 +1086,11 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     ecal_lm_options opt;
     if (opt_in) opt = *opt_in; else ecal_lm_default_options(&opt);
     ecal_ctx *ctx = s->ctx;
-    if (!opt.allreduce && ctx->comm && ctx->comm_size > 1) {   // the context's own RCCL communicator (ecal_comm_init)
-        opt.allreduce = ecal_comm_allreduce_hook;
-        opt.allreduce_user = ctx;
-        opt.rank = ctx->comm_rank;
-        opt.world_size = ctx->comm_size;
+    // a NULL all-reduce is a rank-local solve, whether or not the context has joined a communicator: collectives are the
+    // caller's explicit choice (opt.allreduce = ecal_comm_allreduce, opt.allreduce_user = ctx, rank / world_size set)
+    if (opt.allreduce == ecal_comm_allreduce && (opt.allreduce_user != ctx || opt.rank != ctx->comm_rank || opt.world_size != ctx->comm_size)) {
+        ctx->last_error = "ecal_solver_solve: ecal_comm_allreduce needs allreduce_user = the solver's context and its rank / world_size";
+        return ECAL_ERR_INVALID;
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

@@ -444,7 +444,9 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     if constexpr (ORD) {
         // the flagged clusters: members into the reference's order (members[] is free from here on; a thread per POINT
         // scatters itself to its position), then the library's nth_element on them, a thread per cluster.  Without a usable
-        // order (segment not taken by ecal_cluster_order_dev) the smaller pid stays.
+        // order (segment not taken by ecal_cluster_order_dev) the smaller pid stays — and the window says so in its status word
+        // (ECAL_WIN_TIE_FALLBACK): that pick is not guaranteed to be the reference's.
+        if (tid == 0) nk_sh[2] = 0;   // (the member totals were read above; the word now collects the fallbacks)
         for (int pol = 0; pol < 2; pol++) {
             const int32_t *ord = pol ? ord1 : ord0;
             for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) {
@@ -464,10 +466,15 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 if (!(rv & ST::REP_TIE)) continue;
                 uint32_t pick = rv & ~(ST::REP_TIE | ST::REP_BAD);
                 const uint32_t m = st.ksize[kb[pol] + k], first = base[pol] + st.koff[kb[pol] + k];
+                bool fell_back = true;
                 if (!(rv & ST::REP_BAD)) {
                     const uint32_t r = ref_nth_element(st, base[pol], &st.members[first], m, m / 2u);
-                    if (r != ~0u) pick = r;
+                    if (r != ~0u) {
+                        pick = r;
+                        fell_back = false;
+                    }
                 }
+                if (fell_back) nk_sh[2] = 1;   // (every writer: the same value)
                 st.rep[kb[pol] + k] = pick;
             }
         }
@@ -740,7 +747,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         info[0] = carry;
         info[1] = nk[0];
         info[2] = nk[1];
-        info[3] = 0;
+        info[3] = (ORD && nk_sh[2]) ? ECAL_WIN_TIE_FALLBACK : 0u;
     }
 }
 

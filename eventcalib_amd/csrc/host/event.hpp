@@ -157,6 +157,7 @@ struct FrameDetection {
     std::vector<int32_t> labelsPos, labelsNeg;  // DBSCAN labels (index into Clusters, -1 = Noise)
     std::vector<int32_t> keptPos, keptNeg;      // after the clusterMinSample filter
     uint32_t nClustersPos = 0, nClustersNeg = 0, keptClustersPos = 0, keptClustersNeg = 0, status = 1;
+    bool tieFallback = false;   // ECAL_WIN_TIE_FALLBACK: a tied median of this window is not guaranteed to be the reference's pick
     std::vector<std::pair<size_t, size_t>> candidates;  // (+ cluster, - cluster), kept numbering
     std::vector<Vector2d> candidateCenters;
     std::vector<double> candidatesRadius;
@@ -231,7 +232,8 @@ inline void detect_windows(EventContainer &c, const std::vector<std::pair<double
         f.nClustersNeg = ncl[2 * s + 1];
         f.keptClustersPos = info[4 * s + 1];
         f.keptClustersNeg = info[4 * s + 2];
-        f.status = info[4 * s + 3];
+        f.status = ECAL_WIN_STATUS(info[4 * s + 3]);
+        f.tieFallback = (info[4 * s + 3] & ECAL_WIN_TIE_FALLBACK) != 0;
         for (uint32_t j = 0; j < info[4 * s]; j++) {
             f.candidates.emplace_back(pair[2 * (op + j)], pair[2 * (op + j) + 1]);
             f.candidateCenters.push_back(Vector2d{{xyr[3 * (op + j)], xyr[3 * (op + j) + 1]}});

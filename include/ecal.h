@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define ECAL_ABI_VERSION 2
+#define ECAL_ABI_VERSION 3
 
 typedef enum ecal_status {
     ECAL_OK = 0,
@@ -82,16 +82,15 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
  * seed = the cluster's smallest pid first), which follows the result order of the kd-tree's range query (hits in reverse
  * visiting order, kdtree.cpp:148-179,469-486) —, -1 for Noise.  d_xy / d_seg_off / d_seg_cnt as ecal_dbscan_batch_dev
  * takes them, d_labels / d_n_clusters as it returned them, same eps.  d_status[s] = 0, or 1 for a segment this pass does
- * not take (more than 4096 points or 2048 clusters, more than 64 points in one eps-ball, more than 96 pending subtrees in a
- * traversal): its
- * d_order entries are -1.  What it is for: Clusters[c] in the reference's order for callers that index into it, and
+ * not take (more than 2^20 points, or range-query result lists of more than 2^24 entries in all — segments of up to 4096
+ * points run in LDS, anything beyond or denser in a global workspace): its d_order entries are -1.  What it is for: Clusters[c] in the reference's order for callers that index into it, and
  * extractFeatures' medians (std::nth_element over Clusters[c], CirclesEventFrame.cpp:136-147), which depend on that order
  * when two members tie in norm.  only_tied_medians != 0: the order is worked out only for the clusters that need it for that
  * purpose — those whose member of rank size / 2 in the order (norm, pid) shares its norm with another member (the test
  * ecal_extract_batch_ordered_dev applies) —, the members of all other clusters get -2; segments without such a cluster do
  * not even have their tree rebuilt.  (only_tied_medians == 2, used by ecal_extract_batch_exact_dev: the caller has named
  * those clusters itself by storing -3 in d_order on the slot of one member of each.)
- * Three launches: segments of up to 768 points and 256 clusters, then up to 2048 points, then up to 4096. */
+ * Four launches: segments of up to 768 points and 256 clusters, then up to 2048 points, then up to 4096, then the rest. */
 int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                            double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order /*[n_points]*/,
                            uint32_t *d_status /*[S]*/, int only_tied_medians, void *stream);
@@ -172,10 +171,16 @@ int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
  *     d_win_info[4s..] = { n candidates, kept + clusters, kept - clusters, status } with status
  *        0 = ok, 1 = extractFeatures would return false before pairing (an empty polarity :62-64
  *        or fewer than need_clusters = rows*cols kept clusters :127-129), 4 = more than 2048 DBSCAN
- *        clusters in one polarity (not handled; no candidates)
+ *        clusters in one polarity (not handled; no candidates).  The exact extraction (ecal_extract_batch_exact_dev / _ordered_dev
+ *        and every composite entry point under ECAL_TIES_REFERENCE) ORs ECAL_WIN_TIE_FALLBACK into the word when some tied
+ *        median of the window was decided by the smaller-pid rule because the reference's pick could not be worked out (see
+ *        ecal_cluster_order_dev's status 1; libstdc++'s heap-select branch of nth_element): everything else about the window
+ *        is as for status 0, the representative of that cluster may differ from the reference's.  ECAL_WIN_STATUS(w) strips it.
  *   The ordering of the candidates into the pattern grid (cv::findCirclesGrid, :332-353) is not
  *   part of this entry point.
  */
+#define ECAL_WIN_TIE_FALLBACK 0x100u
+#define ECAL_WIN_STATUS(word) ((word) & 0xFFu)
 double ecal_circle_radius_threshold(double width, double height, int rows, int cols, int asymmetric,
                                     double square_size, double circle_radius);
 int ecal_extract_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
@@ -204,7 +209,8 @@ int ecal_detect_fused_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
  * equal-norm rival: d_cluster_order = ecal_cluster_order_dev's output for the same segments (the members' positions inside
  * Clusters[c]); the representative of such a cluster is what libstdc++'s std::nth_element leaves at Clusters[c][size / 2]
  * (CirclesEventFrame.cpp:136-147; introselect restated), everything downstream follows.  Clusters of segments
- * ecal_cluster_order_dev did not take (status 1) keep ecal_extract_batch_dev's rule (the smaller pid). */
+ * ecal_cluster_order_dev did not take (status 1) keep ecal_extract_batch_dev's rule (the smaller pid) and their window's status
+ * word carries ECAL_WIN_TIE_FALLBACK. */
 int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
                                    const int32_t *d_labels, const uint32_t *d_n_clusters, const int32_t *d_cluster_order,
                                    uint32_t S /*windows*/, uint32_t n_points, uint32_t cluster_min, uint32_t need_clusters,
@@ -466,9 +472,10 @@ typedef struct ecal_spline_problem {
  * and sums the per-view / per-rank normal-equation blocks with an RCCL all-reduce over xGMI.  Rank 0 calls
  * ecal_comm_unique_id and hands the ECAL_COMM_ID_BYTES bytes to the other ranks by any means (a file, a socket, MPI,
  * torch.distributed); then EVERY rank calls ecal_comm_init on its own context (collective: returns when all world_size
- * ranks have joined; one rank per GPU — RCCL refuses two ranks on one device).  From then on ecal_solver_solve and
- * ecal_calibrate_views all-reduce through the communicator themselves whenever their options carry no callback
- * (rank / world_size of ecal_lm_options are then taken from the communicator).  ecal_comm_allreduce_sum_dev: d_buf[0 ..
+ * ranks have joined; one rank per GPU — RCCL refuses two ranks on one device).  Joining changes nothing by itself: a call
+ * whose options carry allreduce == NULL stays rank-local.  A collective solve / calibration is asked for explicitly with
+ * options.allreduce = ecal_comm_allreduce and options.allreduce_user = the context (ecal_lm_options.rank / world_size =
+ * ecal_comm_rank / ecal_comm_size of that context; anything else is ECAL_ERR_INVALID).  ecal_comm_allreduce_sum_dev: d_buf[0 ..
  * n) summed over the ranks in place, enqueued on `stream` (no host synchronisation); a no-op without a communicator. */
 #define ECAL_COMM_ID_BYTES 128
 int ecal_comm_unique_id(void *id_out /*[ECAL_COMM_ID_BYTES]*/);
@@ -478,15 +485,17 @@ int ecal_comm_size(const ecal_ctx *ctx);   /* 1 without a communicator */
 int ecal_comm_rank(const ecal_ctx *ctx);
 int ecal_comm_allreduce_sum_dev(ecal_ctx *ctx, double *d_buf, size_t n_doubles, void *stream);
 
-/* all-reduce supplied by the caller instead (any transport; takes precedence over the context's communicator) */
+/* all-reduce of the solver / calibration: any transport with this signature, or ecal_comm_allreduce (user = the ecal_ctx that
+ * joined the communicator; ECAL_ERR_COMM if it never did) */
 typedef int (*ecal_allreduce_fn)(void *user, double *d_buf, size_t n_doubles, void *stream);
+int ecal_comm_allreduce(void *user /*ecal_ctx* */, double *d_buf, size_t n_doubles, void *stream);
 typedef struct ecal_lm_options {
     int max_num_iterations;
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     double initial_trust_region_radius, max_trust_region_radius, min_relative_decrease;
     double min_lm_diagonal, max_lm_diagonal;
     int jacobi_scaling;
-    ecal_allreduce_fn allreduce; /* NULL: the context's RCCL communicator if it has one (ecal_comm_init), else one GPU */
+    ecal_allreduce_fn allreduce; /* NULL: this rank alone.  ecal_comm_allreduce (+ allreduce_user = ctx): the context's RCCL communicator */
     void *allreduce_user;
     /* distributed != 0 (needs allreduce): every rank owns its OWN spline segments in its own ecal_solver (its residuals,
      * its control points) and only the 9 intrinsics are shared.  Exchanged per evaluation: the 91-double head (cost,
@@ -574,7 +583,7 @@ typedef struct ecal_calib_options {
     double aspect_ratio;  /* Calibrate_FixAspectRatio (used with ECAL_CALIB_FIX_ASPECT_RATIO) */
     int max_iter;         /* 0 = OpenCV's default TermCriteria: 30 (calibrateCamera) / 100 (fisheye) */
     double eps;           /* 0 = DBL_EPSILON */
-    ecal_allreduce_fn allreduce; /* NULL: the context's RCCL communicator if it has one (ecal_comm_init), else one GPU */
+    ecal_allreduce_fn allreduce; /* NULL: this rank alone.  ecal_comm_allreduce (+ allreduce_user = ctx): the context's RCCL communicator */
     void *allreduce_user;
 } ecal_calib_options;
 typedef struct ecal_calib_result {

@@ -1,7 +1,7 @@
 // Multi-rank plumbing of libecal.so from plain C++ (no Python, no torch): one process per rank.
 //   usage: test_multirank <mode> <world> views.bin [scratch_dir]
 //     mode rccl : every rank joins the library's RCCL communicator (ecal_comm_unique_id / ecal_comm_init) on device
-//                 (rank % device count) and ecal_calibrate_views all-reduces through it by itself (options.allreduce = NULL).
+//                 (rank % device count) and ecal_calibrate_views all-reduces through it (options.allreduce = ecal_comm_allreduce, user = ctx).
 //                 RCCL refuses two ranks on one GPU, so on a one-GPU box this runs with world = 1 (the call path is the
 //                 same: communicator, ncclAllReduce on the calibration stream); with >= 2 GPUs it is a real 2-rank run.
 //     mode shm  : world ranks on device 0, the all-reduce supplied as a CALLBACK that sums through POSIX shared memory
@@ -127,6 +127,8 @@ int run_rank(const std::string &mode, int world, const char *views, const std::s
         (void) hipFree(d);
         for (int i = 0; i < 4; i++)
             if (h[i] != (i + 1) * world * (world + 1) / 2.0) return 11;
+        opt.allreduce = ecal_comm_allreduce;   // collectives are explicit: NULL would be a rank-local calibration
+        opt.allreduce_user = ctx;
     } else {
         const std::string name = dir + "/shm";
         const int fd = open(name.c_str(), O_RDWR);
@@ -164,6 +166,14 @@ int run_rank(const std::string &mode, int world, const char *views, const std::s
         if (std::fabs(res.rms - r1.rms) > 1e-9) bad++;   // (the iteration count may differ: the stop test compares changes with DBL_EPSILON and the sharded sums round differently)
         std::printf("single rms %.12g fx %.12g iterations %d -> %s\n", r1.rms, r1.intr[0], r1.iterations, bad ? "MISMATCH" : "same");
         ecal_destroy(one);
+        if (mode == "rccl") {
+            // a rank-local call (allreduce == NULL) on the context that HAS joined the communicator: it must not become a
+            // collective (rank 0 alone is here: an implicit ncclAllReduce would hang or sum unrelated blocks)
+            ecal_calib_result r2;
+            if (ecal_calibrate_views(ctx, obj.data(), n, img.data(), V, 346, 260, &o1, &r2, rv1.data(), tv1.data(), nullptr) != ECAL_OK) return 15;
+            if (r2.rms != r1.rms || r2.intr[0] != r1.intr[0] || r2.iterations != r1.iterations) bad++;
+            std::printf("rank-local call on the communicator's context: rms %.12g -> %s\n", r2.rms, bad ? "MISMATCH" : "same");
+        }
     }
     ecal_destroy(ctx);   // (destroys the communicator too)
     return bad ? 20 : 0;

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libecal.so does not export %s" % name
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
-    assert eventcalib_amd.load_library().ecal_abi_version() == 2
+    assert eventcalib_amd.load_library().ecal_abi_version() == 3
 
 
 def test_strerror_and_no_device_is_loud():

@@ -261,3 +261,45 @@ def test_counter_words_from_the_ring_or_wiped_per_call(env, monkeypatch):
     pipe.run(ev)
     for a, b in zip(snapshot(), want):
         assert torch.equal(a, b)
+
+
+def test_records_to_candidates_with_no_gpu_array_in_between(env):
+    """The whole chain on the oracle's side — packed records -> window bounds -> EventFrame (the reference's unordered_set
+    order) -> extractFeatures up to the candidate circles — against ecal_detect_pass / the pipeline's arrays, with NO GPU
+    array handed to the oracle (the other tests of this file feed it the sliced points the GPU produced).  Tie windows
+    included: the representatives are the reference's own picks."""
+    ctx, pipe, torch = env
+    from eventcalib_amd import capi
+    n = 240_000
+    buf = SS.make_stream(n, device="cpu", seed=29)
+    rec = buf.numpy()
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 1e6)
+    S = len(t0)
+    ev = buf.cuda()
+    pipe.set_windows(t0, t1)
+    pipe.set_detect_params(5, 36, THR)
+    pipe.run(ev)
+    torch.cuda.synchronize()
+    packed = capi.detect_pass(ctx, ev.data_ptr(), n, t0, t1, n + 4096)
+    info = pipe.win_info[:S].cpu().numpy().astype(np.int64)
+    seg_off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
+    rep, pair, xyr = pipe.rep.cpu().numpy(), pipe.cand_pair.cpu().numpy(), pipe.cand_xyr.cpu().numpy()
+    paired = tied = 0
+    for s in range(S):
+        lo, hi = O.window_bounds(rec, t0[s], t1[s])
+        pos, neg, _ep = O.event_frame(rec, int(lo), int(hi), "reference")
+        ref = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, THR)
+        assert info[s, 3] == ref["status"], s                      # (no ECAL_WIN_TIE_FALLBACK bit either)
+        assert packed[s, 0] == ref["status"] and packed[s, 2] == len(pos) + len(neg), s
+        if ref["status"]:
+            assert info[s, 0] == 0 and packed[s, 1] == 0
+            continue
+        paired += 1
+        tied += int(bool(ref["tie"]))
+        op, on, m = seg_off[2 * s], seg_off[2 * s + 1], ref["n"]
+        assert np.array_equal(rep[op:op + ref["nk_pos"]], ref["rep_pos"]) and np.array_equal(rep[on:on + ref["nk_neg"]], ref["rep_neg"]), s
+        assert info[s, 0] == m and np.array_equal(pair[op:op + m], ref["pair"]) and np.array_equal(xyr[op:op + m], ref["xyr"]), s
+        if packed[s, 1]:       # the ordered circles ecal_detect_pass hands the policy are candidates of the oracle's list
+            feat = packed[s, 3:].reshape(-1, 3)
+            assert all((ref["xyr"] == f).all(1).any() for f in feat), s
+    assert paired >= S // 2 and tied >= 3

@@ -182,6 +182,16 @@ def test_config0_one_window_of_100k_events():
         assert info[3] == ref["status"] and info[1] == ref["nk_pos"] and info[2] == ref["nk_neg"]
         assert np.array_equal(pipe.kept_labels[off[0]:off[0] + cnt[0]].cpu().numpy(), ref["kept_pos"])
         assert np.array_equal(pipe.kept_labels[off[1]:off[1] + cnt[1]].cpu().numpy(), ref["kept_neg"])
+        # representatives (the reference's nth_element picks: the member order of these > 4096-point segments comes from the
+        # global-scratch launch of ecal_cluster_order_dev), pairs, circles — and no fallback flag on the window
+        assert int(info[3]) & 0x100 == 0
+        if not ref["status"]:
+            assert np.array_equal(pipe.rep[off[0]:off[0] + ref["nk_pos"]].cpu().numpy(), ref["rep_pos"])
+            assert np.array_equal(pipe.rep[off[1]:off[1] + ref["nk_neg"]].cpu().numpy(), ref["rep_neg"])
+            nc = ref["n"]
+            assert int(info[0]) == nc
+            assert np.array_equal(pipe.cand_pair[off[0]:off[0] + nc].cpu().numpy(), ref["pair"])
+            assert np.array_equal(pipe.cand_xyr[off[0]:off[0] + nc].cpu().numpy(), ref["xyr"])
     finally:
         ctx.close()
 
@@ -216,7 +226,7 @@ def test_oracle_spot_checks_at_the_benchmark_size(n_events):
         lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
         off, cntn = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64), cnt.cpu().numpy()
         info = pipe.win_info[:S].cpu().numpy()
-        paired = 0
+        paired = tied = 0
         for s in pick:
             rec = ev[25 * int(lo[s]): 25 * int(hi[s])].cpu().numpy()
             pos, neg, ep = O.event_frame(rec, 0, int(hi[s] - lo[s]), "reference")
@@ -230,12 +240,16 @@ def test_oracle_spot_checks_at_the_benchmark_size(n_events):
             ref = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
             assert info[s, 3] == ref["status"], s
             assert np.array_equal(pipe.kept_labels[off[2 * s]:off[2 * s] + len(pos)].cpu().numpy(), ref["kept_pos"]), s
-            if not ref["status"] and not ref["tie"]:
+            assert int(info[s, 3]) & 0x100 == 0, s
+            if not ref["status"]:      # tie windows included: the reference's own picks, nothing handed to the oracle
                 paired += 1
+                tied += int(bool(ref["tie"]))
                 n = ref["n"]
+                assert np.array_equal(pipe.rep[off[2 * s]:off[2 * s] + ref["nk_pos"]].cpu().numpy(), ref["rep_pos"]), s
+                assert np.array_equal(pipe.rep[off[2 * s + 1]:off[2 * s + 1] + ref["nk_neg"]].cpu().numpy(), ref["rep_neg"]), s
                 assert info[s, 0] == n
                 assert np.array_equal(pipe.cand_pair[off[2 * s]:off[2 * s] + n].cpu().numpy(), ref["pair"]), s
                 assert np.array_equal(pipe.cand_xyr[off[2 * s]:off[2 * s] + n].cpu().numpy(), ref["xyr"]), s
-        assert paired >= 5
+        assert paired >= 12 and tied >= 3, (paired, tied)
     finally:
         ctx.close()

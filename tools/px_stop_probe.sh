@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: per-phase instruction counts of the pixel DBSCAN kernel from -DECAL_PX_STOP=k builds
-# (build_ab/libecal_stop<k>.so, made by tools/build_px_stop.sh here).  Output: gpurun_out/<tag>/px_stop.txt
+# (ab_libs/libecal_stop<k>.so, made by tools/build_px_stop.sh here).  Output: gpurun_out/<tag>/px_stop.txt
 set -u
 TAG=${1:-r01x}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 KERNEL=${PX_KERNEL:-dbscan_pixel_kernel}   # PX_KERNEL=extract_kernel PX_PREFIX=det ECAL_PROBE_DETECT=1 for the extraction kernel
 PREFIX=${PX_PREFIX:-stop}
 for k in ${PX_STOPS:-1 2 3 4 5 6 full}; do
-  lib=$ROOT/build_ab/libecal_$PREFIX$k.so
+  lib=$ROOT/ab_libs/libecal_$PREFIX$k.so
   [ "$k" = full ] && lib=$ROOT/eventcalib_amd/libecal.so
   export ECAL_LIB=$lib
   rm -rf $OUT/p

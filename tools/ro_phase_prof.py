@@ -16,7 +16,7 @@ for f in sorted(os.listdir(src)):
         else:
             o = os.path.join(src, "build", f[:-4] + ".o")
         objs.append(o)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + objs + ["-L/opt/rocm/lib", "-lrccl"])
 import torch
 import eventcalib_amd.capi as capi
 capi.lib_path = lambda: out
