@@ -352,7 +352,18 @@ def main():
                                      "note": "the same policy in one call: five stages + grid ordering over every piece's current window and "
                                              "the windows that follow it if every verdict is the likely one (the slots of a pass go to the pieces "
                                              "still at work) + one policy kernel that applies the rule along that chain while the verdicts agree, "
-                                             "enqueued back to back; the host follows a 4-byte counter two passes behind"})
+                                             "enqueued back to back; the host follows a 4-byte counter two passes behind",
+                                     "gate": "own piece"})
+            # ... and with the reference's own gate semantics: ONE keyframe map, single-worker order (ECAL_GATE_SHARED_MAP ==
+            # oracle/policy_oracle.cpp mode 1): speculation as above + verification rounds across the piece boundaries
+            from eventcalib_amd import capi as _capi
+            tp = time.perf_counter()
+            ks = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, gate_mode=_capi.GATE_SHARED_MAP)
+            p2s_s = time.perf_counter() - tp
+            out["policy_p2"].append({"value": round(n_events / p2s_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2s_s, 4),
+                                     "pieces": pieces, "host_threads": 1, "longest_window_chain": ks["steps"],
+                                     "windows_evaluated": ks["windows"], "keyframes": int(len(ks["time"])), "driver": "device",
+                                     "gate": "shared map, single worker (the reference's TrackingBase / EventCalibIni::track semantics)"})
         pipe.set_windows(t0, t1)
     # ------------------------------------------------------------------------------------------
     # M2: Levenberg-Marquardt iterations/s of the continuous-time solve on the same stream

@@ -30,15 +30,31 @@ def _row_directions(feat, rows, cols):
     return d * sign[:, :, None]
 
 
+def _nth_element_median(theta):
+    """theta [n, rows]: what libstdc++'s std::nth_element leaves at position rows // 2 of every row — with NaNs among the
+    angles (every comparison false) that is not the order statistic but whatever the library's loops leave there
+    (EventCalibIni.cpp:78); the library's restatement is exported by libecal for exactly this (ecal_ref_nth_element_f64)."""
+    import ctypes
+    L = capi.load_library()
+    L.ecal_ref_nth_element_f64.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    L.ecal_ref_nth_element_f64.restype = None
+    out = np.empty(theta.shape[0])
+    for i in range(theta.shape[0]):
+        row = np.ascontiguousarray(theta[i], np.float64).copy()
+        L.ecal_ref_nth_element_f64(row.ctypes.data, row.shape[0], row.shape[0] // 2)
+        out[i] = row[row.shape[0] // 2]
+    return out
+
+
 def orientation_gate(ref_feat, ref_t, cur_feat, cur_t, rows, cols, motion_time_step):
     """EventCalibIni::track's test for n frame pairs: median angle between corresponding pattern rows divided by the
     time distance below (5e-4 pi) / MotionTimeStep rad/s."""
     a, b = _row_directions(ref_feat, rows, cols), _row_directions(cur_feat, rows, cols)
     c = (a * b).sum(axis=2) / (np.linalg.norm(a, axis=2) * np.linalg.norm(b, axis=2))
     with np.errstate(invalid="ignore"):
-        theta = np.arccos(c)         # (not clamped, as the reference: a cosine rounded above 1 gives NaN -> rejected)
-    med = np.partition(theta, rows // 2, axis=1)[:, rows // 2]
-    return ~np.isnan(theta).any(axis=1) & (med / np.abs(cur_t - ref_t) < (5e-4 * np.pi) / motion_time_step)
+        theta = np.arccos(c)         # (not clamped, as the reference: a cosine rounded above 1 gives NaN)
+        med = _nth_element_median(theta)
+        return med / np.abs(cur_t - ref_t) < (5e-4 * np.pi) / motion_time_step
 
 
 def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event_num_threshold, piece_num,
@@ -81,26 +97,36 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
 
 
 def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps=4.0,
-                            minpts=2, rows=9, cols=4, max_passes=0):
+                            minpts=2, rows=9, cols=4, max_passes=0, gate_mode=0):
     """Same result as detect_keyframes, with the policy on the device (ecal_detect_keyframes): no per-pass host round trip.
-    Slots and the keyframe capacity are estimated and doubled when the library reports them too small."""
+    gate_mode = capi.GATE_SHARED_MAP: the reference's single-worker run (one keyframe map for all pieces) instead of the
+    own-piece gate.  Slots and the keyframe capacity are estimated and doubled when the library reports them too small."""
     torch.cuda.synchronize(events.device)   # the passes run on the context's own stream: `events` must be complete
     n_ev = events.numel() // 25
     span = max(end_time - start_time, 1e-9)
     # a pass covers a chain of windows per piece: the library's own estimate, doubled whenever it reports it too small
-    cap_max = 2 ** 32 - 64
+    cap_max = min(2 ** 32 - 64, 6 * n_ev + 4096)     # (the hint's own maximum: the windows of one slot index are disjoint)
     cap = capi.detect_keyframes_cap_hint(ctx, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time)
     max_keys = int(span / (8 * motion_time_step)) + piece_num + 64   # one keyframe per window + gap at the very most
     while True:
         try:
             t, d, e, f, passes, windows = capi.detect_keyframes_dev(ctx, events.data_ptr(), n_ev, motion_time_step,
                                                                     frame_event_num_threshold, piece_num, start_time, end_time, cap,
-                                                                    max_keys, eps, minpts, 5, rows, cols, max_passes=max_passes)
+                                                                    max_keys, eps, minpts, 5, rows, cols, max_passes=max_passes,
+                                                                    gate_mode=gate_mode)
             break
         except capi.EcalError as err:
-            if err.status != -6 or (cap >= cap_max and max_keys > 4 * n_ev):
+            if err.status != -6:
                 raise
-            cap, max_keys = min(cap_max, 2 * cap), 2 * max_keys
+            # double only what was short: the message names it (the keyframe count comes back with the error)
+            if "max_keyframes" in str(err):
+                if max_keys > 4 * n_ev:
+                    raise
+                max_keys *= 2
+            else:
+                if cap >= cap_max:
+                    raise
+                cap = min(cap_max, 2 * cap)
     return dict(time=t, duration=d, events_num=e, features=f, steps=passes, windows=windows)
 
 

@@ -8,7 +8,24 @@
 // ordering + ONE policy kernel (a thread per piece: gate, keyframe record, next window), all enqueued back to back on
 // one stream; the host only reads a 4-byte "pieces still active" counter every few passes.  Every pass covers ALL
 // pieces: a finished piece has the empty window (+inf, -inf), which every stage skips.
+//
+// Two gate modes (ecal_adaptive_params.gate_mode):
+//   ECAL_GATE_OWN_PIECE   a window is checked against the previous keyframe of ITS OWN piece, every piece's first successful
+//                         window is accepted like the reference's very first frame — deterministic whatever the schedule;
+//   ECAL_GATE_SHARED_MAP  the reference with ONE worker thread: one keyframe map for all pieces, pieces taken in pop_back
+//                         order = ascending time (eventCameraCalib.cpp:40-41,177-179), so keyframes().lower_bound(t) is always
+//                         end() and the reference frame is the map's LAST keyframe (EventCalibIni.cpp:26-36) — the previous
+//                         keyframe of the own piece, or, before the piece's first acceptance, the last keyframe of the nearest
+//                         earlier piece that has one; only the first success of the whole run is ungated (TrackingBase.cpp:18-27).
+//                         A piece therefore depends on its predecessors only through ONE frame R (time + row directions), and
+//                         only until its first acceptance: F(R) = "reject successes until one passes the gate against R, then
+//                         go on as usual".  All pieces run speculatively with R = none (= the own-piece run); then rounds of
+//                         { verify every piece against its predecessor's current last keyframe — from the recorded successes
+//                         up to the first acceptance —, re-run the pieces whose verdict sequence changes, with that frame as
+//                         the initial reference } until nothing changes.  The earliest unsettled piece is settled by every
+//                         round, so the result is the sequential single-worker run's; on the benchmark stream a few rounds.
 #include "ecal_ctx.hpp"
+#include "ref_nth_element.hpp"
 
 #include <math.h>
 
@@ -71,13 +88,35 @@ __device__ void row_direction(const double *xyr, const int32_t *order, uint32_t 
     dy_out = dy;
 }
 
+constexpr uint32_t AD_NREJ = 4;   // successes rejected before a piece's first acceptance that are kept for the verification
 struct AdaptiveArrays {
     double *first, *second, *bound_hi, *ref_t, *ref_dir;  // [P], [P], [P], [P], [P][rows][2]
     uint32_t *active, *have_ref, *levels;                 // [P]; levels: windows the piece has gone through
     uint32_t *slot0, *depth;                              // [P]: the piece's window slots of this pass (adaptive_alloc_kernel)
-    uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: slots overflowed
+    uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: slots overflowed,
+                         // 8: pieces to run again (shared-map verification)
     unsigned long long *windows;                          // windows evaluated
+    // shared-map mode: the run a piece's current results come from, and what a change of its initial reference frame can alter
+    uint32_t *gen, *nacc, *nrej, *init_has, *rerun;       // [P]: run number, accepted / rejected-before-the-first-acceptance successes
+    double *init_t, *init_dir;                            // [P], [P][rows][2]: the reference frame the run started with (init_has)
+    double *facc_t, *facc_dir;                            // [P], [P][rows][2]: the first accepted success
+    double *rej_t, *rej_dir;                              // [P][AD_NREJ], [P][AD_NREJ][rows][2]: the rejected ones before it
+    double start_time, end_time;
 };
+
+// EventCalibIni::track's test (EventCalibIni.cpp:73-82): the median — what libstdc++'s std::nth_element leaves at position
+// rows / 2, NaNs included: an angle is NaN when the cosine rounds above 1 (no clamp in the reference) — of the angles between
+// corresponding pattern rows, over the time distance, below (5e-4 pi) / MotionTimeStep
+__device__ bool gate_accepts(const double *rd, double ref_t, const double *dir, double t_mid, uint32_t rows, double mts) {
+    double theta[AD_MAX_ROWS];
+    for (uint32_t i = 0; i < rows; i++) {
+        const double c = (rd[2 * i] * dir[2 * i] + rd[2 * i + 1] * dir[2 * i + 1]) /
+                         (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[2 * i], dir[2 * i + 1]));
+        theta[i] = acos(c);
+    }
+    ecal::ref_nth_element(theta, rows, rows / 2u, [](double x, double y) { return x < y; });
+    return theta[rows / 2u] / fabs(t_mid - ref_t) < (5e-4 * M_PI) / mts;
+}
 
 // The window that follows (f, s2) under outcome o of eventCameraCalib.cpp:61-62 (0: keyframe accepted), :67-69,75-77 (1: slide),
 // :70-71,78-79 (2: grow) — the ONE place these sums are written, so that a window evaluated ahead of time is bit for bit the
@@ -183,24 +222,80 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     }
 }
 
-__global__ void adaptive_init_kernel(uint32_t P, double start_time, double end_time, double mts, AdaptiveArrays st) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) {
-        for (int i = 0; i < 8; i++) st.counters[i] = 0;
-        *st.windows = 0;
-    }
-    if (k >= P) return;
+// piece k at the start of a run: its first window, and the reference frame it starts with (none, or init_*)
+__device__ void piece_start(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st) {
     const double ln = 3 * mts;
-    const double step = (end_time - start_time) / (double) P;  // eventCameraCalib.cpp:168-179
-    const double hi = end_time - step * (double) k, first = end_time - step * (double) (k + 1), second = first + ln;
+    const double step = (st.end_time - st.start_time) / (double) P;  // eventCameraCalib.cpp:168-179
+    const double hi = st.end_time - step * (double) k, first = st.end_time - step * (double) (k + 1), second = first + ln;
     st.bound_hi[k] = hi;
     st.first[k] = first;
     st.second[k] = second;
-    const bool act = second < hi;
-    st.active[k] = act ? 1u : 0u;
-    st.have_ref[k] = 0;
+    st.active[k] = second < hi ? 1u : 0u;
     st.levels[k] = 0;
-    st.ref_t[k] = 0;
+    st.nacc[k] = 0;
+    st.nrej[k] = 0;
+    st.have_ref[k] = st.init_has[k];
+    st.ref_t[k] = st.init_t[k];
+    for (uint32_t i = 0; i < 2 * rows; i++) st.ref_dir[(size_t) k * rows * 2 + i] = st.init_dir[(size_t) k * rows * 2 + i];
+}
+
+__global__ void adaptive_init_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) {
+        for (int i = 0; i < 16; i++) st.counters[i] = 0;
+        *st.windows = 0;
+    }
+    if (k >= P) return;
+    st.gen[k] = 0;
+    st.rerun[k] = 0;
+    st.init_has[k] = 0;
+    st.init_t[k] = 0;
+    for (uint32_t i = 0; i < 2 * rows; i++) st.init_dir[(size_t) k * rows * 2 + i] = 0;
+    piece_start(k, P, rows, mts, st);
+}
+
+// Shared-map mode, after a set of runs has finished: does piece k's result stand with the reference frame its predecessors
+// NOW hand it — R = the last keyframe of the nearest earlier piece (larger index: piece 0 is the last in time) that has one?
+// It does iff the verdicts on its successes up to the first acceptance come out the same: every recorded rejected one is
+// rejected against R too, the first accepted one accepted (no R: the run's very first success, ungated).  Otherwise the piece
+// is marked, R becomes its initial reference and adaptive_restart_kernel starts it again.  (Reads other pieces' ref_*,
+// writes only its own init_* and mark: the restart is a kernel of its own.)
+__global__ void adaptive_verify_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    uint32_t j = k + 1;
+    while (j < P && st.nacc[j] == 0) j++;
+    const bool has = j < P;
+    const double r_t = has ? st.ref_t[j] : 0.0;
+    const double *r_dir = st.ref_dir + (size_t) (has ? j : 0) * rows * 2;
+    double *i_dir = st.init_dir + (size_t) k * rows * 2;
+    bool same = (st.init_has[k] != 0) == has;
+    if (same && has) {
+        same = st.init_t[k] == r_t;
+        for (uint32_t i = 0; i < 2 * rows && same; i++) same = i_dir[i] == r_dir[i];
+    }
+    if (same) return;
+    bool again = st.nrej[k] > AD_NREJ;   // more rejected successes than were kept: not decidable here
+    const uint32_t nr = st.nrej[k] < AD_NREJ ? st.nrej[k] : AD_NREJ;
+    for (uint32_t i = 0; i < nr && !again; i++)
+        again = !has || gate_accepts(r_dir, r_t, st.rej_dir + ((size_t) k * AD_NREJ + i) * rows * 2, st.rej_t[(size_t) k * AD_NREJ + i], rows, mts);
+    if (!again && st.nacc[k] > 0)
+        again = has && !gate_accepts(r_dir, r_t, st.facc_dir + (size_t) k * rows * 2, st.facc_t[k], rows, mts);
+    st.init_has[k] = has ? 1u : 0u;   // (the frame the piece's results are now known to be right for)
+    st.init_t[k] = r_t;
+    for (uint32_t i = 0; i < 2 * rows; i++) i_dir[i] = has ? r_dir[i] : 0.0;
+    if (again) {
+        st.rerun[k] = 1;
+        atomicAdd(&st.counters[8], 1u);
+    }
+}
+
+__global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P || !st.rerun[k]) return;
+    st.rerun[k] = 0;
+    st.gen[k]++;   // the keyframe records of the earlier runs of this piece are dead
+    piece_start(k, P, rows, mts, st);
 }
 
 // The rows' line fits of every window of the pass that produced a grid (a 3 x 3 Jacobi eigen-decomposition per row: the bulk of
@@ -232,7 +327,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                                      const double *__restrict__ cand_xyr, const int32_t *__restrict__ order,
                                      const uint32_t *__restrict__ found, AdaptiveArrays st, double mts, uint32_t thr_events,
                                      uint32_t max_keys, double *__restrict__ kf_time, double *__restrict__ kf_dur,
-                                     int32_t *__restrict__ kf_events, double *__restrict__ kf_feat, double *__restrict__ t0,
+                                     int32_t *__restrict__ kf_events, double *__restrict__ kf_feat, uint32_t *__restrict__ kf_piece,
+                                     uint32_t *__restrict__ kf_gen, double *__restrict__ t0,
                                      double *__restrict__ t1, const int *__restrict__ overflow, const double *__restrict__ dirs) {
     const uint32_t k = blockIdx.x, lane = threadIdx.x;
     __shared__ double sh_f, sh_s2;
@@ -264,25 +360,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                 const int32_t *ord = order + (size_t) w * M;
                 const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
                 accepted = true;
-                if (st.have_ref[k]) {  // EventCalibIni::track: median row angle / time distance
-                    double theta[AD_MAX_ROWS];
-                    const double *rd = st.ref_dir + (size_t) k * rows * 2;
-                    for (uint32_t i = 0; i < rows; i++) {
-                        const double c = (rd[2 * i] * dir[2 * i] + rd[2 * i + 1] * dir[2 * i + 1]) /
-                                         (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[2 * i], dir[2 * i + 1]));
-                        theta[i] = acos(c);   // (not clamped, as the reference: a cosine rounded above 1 gives NaN and the frame fails the test)
-                    }
-                    double med = theta[0];
-                    bool any_nan = false;
-                    for (uint32_t i = 0; i < rows; i++) any_nan = any_nan || (theta[i] != theta[i]);
-                    for (uint32_t i = 0; i < rows; i++) {  // order statistic rows / 2 (std::nth_element)
-                        uint32_t rank = 0;
-                        for (uint32_t j = 0; j < rows; j++) rank += (theta[j] < theta[i] || (theta[j] == theta[i] && j < i)) ? 1u : 0u;
-                        if (rank == rows / 2) med = theta[i];
-                    }
-                    // (with a NaN among the angles std::nth_element's result is unspecified; the build rejects the frame)
-                    accepted = !any_nan && med / fabs(t_mid - st.ref_t[k]) < (5e-4 * M_PI) / mts;
-                }
+                if (st.have_ref[k])   // EventCalibIni::track: median row angle / time distance
+                    accepted = gate_accepts(st.ref_dir + (size_t) k * rows * 2, st.ref_t[k], dir, t_mid, rows, mts);
                 if (accepted) {
                     const uint32_t at = atomicAdd(&st.counters[1], 1u);
                     if (at < max_keys) {
@@ -290,6 +369,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                         kf_dur[2 * at] = f;
                         kf_dur[2 * at + 1] = s2;
                         kf_events[at] = (int32_t) cnt;
+                        kf_piece[at] = k;
+                        kf_gen[at] = st.gen[k];
                         for (uint32_t c = 0; c < M; c++) {
                             kf_feat[3 * ((size_t) at * M + c)] = xyr[3 * (size_t) ord[c]];
                             kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[3 * (size_t) ord[c] + 1];
@@ -299,10 +380,19 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                     st.have_ref[k] = 1;
                     st.ref_t[k] = t_mid;
                     double *rd = st.ref_dir + (size_t) k * rows * 2;
-                    for (uint32_t i = 0; i < rows; i++) {
-                        rd[2 * i] = dir[2 * i];
-                        rd[2 * i + 1] = dir[2 * i + 1];
+                    for (uint32_t i = 0; i < 2 * rows; i++) rd[i] = dir[i];
+                    if (st.nacc[k] == 0) {   // the piece's first acceptance: what the shared-map verification looks at
+                        st.facc_t[k] = t_mid;
+                        for (uint32_t i = 0; i < 2 * rows; i++) st.facc_dir[(size_t) k * rows * 2 + i] = dir[i];
                     }
+                    st.nacc[k]++;
+                } else if (st.nacc[k] == 0) {   // a success rejected before the first acceptance
+                    const uint32_t r = st.nrej[k];
+                    if (r < AD_NREJ) {
+                        st.rej_t[(size_t) k * AD_NREJ + r] = t_mid;
+                        for (uint32_t i = 0; i < 2 * rows; i++) st.rej_dir[((size_t) k * AD_NREJ + r) * rows * 2 + i] = dir[i];
+                    }
+                    st.nrej[k] = r + 1;
                 }
             }
             const int o = accepted ? 0 : ((cnt > thr_events || (s2 - f) > 3 * ln) ? 1 : 2);
@@ -318,7 +408,6 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
             else if (level + 1 == n_levels) atomicAdd(&st.counters[6], 1u);
             if (!sh_act) atomicAdd(&st.counters[7], 1u);
 #endif
-            atomicMax(&st.counters[2], lev0 + level + 1u);
             st.levels[k] = lev0 + level + 1u;
             atomicAdd(st.windows, 1ull);
         }
@@ -356,12 +445,14 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     *n_keyframes = 0;
     if (passes) *passes = 0;
     if (windows) *windows = 0;
-    const uint32_t P = ap->piece_num, M = prm->rows * prm->cols;
+    const uint32_t P = ap->piece_num, M = prm->rows * prm->cols, rows = prm->rows;
     if (P == 0 || M == 0 || M > 128 || prm->rows > (uint32_t) AD_MAX_ROWS || !(ap->motion_time_step > 0) ||
-        !(ap->end_time > ap->start_time) || (max_keyframes && (!kf_time || !kf_duration || !kf_events_num || !kf_features))) {
+        !(ap->end_time > ap->start_time) || (max_keyframes && (!kf_time || !kf_duration || !kf_events_num || !kf_features)) ||
+        (ap->gate_mode != ECAL_GATE_OWN_PIECE && ap->gate_mode != ECAL_GATE_SHARED_MAP)) {
         ctx->last_error = "ecal_detect_keyframes: invalid parameters";
         return ECAL_ERR_INVALID;
     }
+    const bool shared = ap->gate_mode == ECAL_GATE_SHARED_MAP;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc;
@@ -375,11 +466,15 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         if ((rc = ecal_ensure(ctx, B[i], sizes[i]))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
-    const size_t state_bytes = (size_t) P * (4 * 8 + 2 * 8 * prm->rows + 5 * 4) + 64;
+    // per piece: 7 doubles + (3 + AD_NREJ) x rows x 2 doubles of row directions + AD_NREJ doubles + 10 words
+    const size_t state_bytes = (size_t) P * (8 * (7 + AD_NREJ + 2 * (size_t) rows * (3 + AD_NREJ)) + 4 * 10) + 128;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
-    if ((rc = ecal_ensure(ctx, ctx->adaptive_dirs, (size_t) S * prm->rows * 2 * sizeof(double)))) return rc;
-    const size_t key_stride = 8 + 16 + 8 + 24 * (size_t) M;  // time, duration, events (padded), features
-    if ((rc = ecal_ensure(ctx, ctx->adaptive_keys, (size_t) max_keyframes * key_stride + 64))) return rc;
+    if ((rc = ecal_ensure(ctx, ctx->adaptive_dirs, (size_t) S * rows * 2 * sizeof(double)))) return rc;
+    // keyframe records: in shared-map mode the pieces that run again leave dead records behind
+    const size_t rec_cap = shared ? 2 * (size_t) max_keyframes + P + 64 : (size_t) max_keyframes;
+    if (rec_cap > 0xFFFFFFF0ull) return ECAL_ERR_RANGE;
+    const size_t key_stride = 8 + 16 + 8 + 24 * (size_t) M + 8;  // time, duration, events (padded), features, piece + run
+    if ((rc = ecal_ensure(ctx, ctx->adaptive_keys, rec_cap * key_stride + 64))) return rc;
     if (ctx->pass_pinned_cap < 64) {
         if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
         ctx->pass_pinned = nullptr;
@@ -391,26 +486,42 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     {
         unsigned char *p = (unsigned char *) ctx->adaptive_state.ptr;
         a.windows = (unsigned long long *) p;
-        a.counters = (uint32_t *) (p + 16);
-        p += 64;
-        a.first = (double *) p;
-        a.second = a.first + P;
-        a.bound_hi = a.second + P;
-        a.ref_t = a.bound_hi + P;
-        a.ref_dir = a.ref_t + P;
-        a.active = (uint32_t *) (a.ref_dir + (size_t) P * prm->rows * 2);
-        a.have_ref = a.active + P;
-        a.levels = a.have_ref + P;
-        a.slot0 = a.levels + P;
-        a.depth = a.slot0 + P;
+        a.counters = (uint32_t *) (p + 16);   // [16]
+        p += 128;
+        double *d = (double *) p;
+        a.first = d, d += P;
+        a.second = d, d += P;
+        a.bound_hi = d, d += P;
+        a.ref_t = d, d += P;
+        a.init_t = d, d += P;
+        a.facc_t = d, d += P;
+        a.rej_t = d, d += (size_t) P * AD_NREJ;
+        a.ref_dir = d, d += (size_t) P * rows * 2;
+        a.init_dir = d, d += (size_t) P * rows * 2;
+        a.facc_dir = d, d += (size_t) P * rows * 2;
+        a.rej_dir = d, d += (size_t) P * AD_NREJ * rows * 2;
+        uint32_t *u = (uint32_t *) d;
+        a.active = u, u += P;
+        a.have_ref = u, u += P;
+        a.levels = u, u += P;
+        a.slot0 = u, u += P;
+        a.depth = u, u += P;
+        a.gen = u, u += P;
+        a.nacc = u, u += P;
+        a.nrej = u, u += P;
+        a.init_has = u, u += P;
+        a.rerun = u, u += P;
+        a.start_time = ap->start_time;
+        a.end_time = ap->end_time;
     }
-    double *d_kt = (double *) ctx->adaptive_keys.ptr, *d_kd = d_kt + max_keyframes, *d_kf = d_kd + 2 * (size_t) max_keyframes;
-    int32_t *d_ke = (int32_t *) (d_kf + 3 * (size_t) max_keyframes * M);
+    const uint32_t max_keys = (uint32_t) rec_cap;
+    double *d_kt = (double *) ctx->adaptive_keys.ptr, *d_kd = d_kt + max_keys, *d_kf = d_kd + 2 * (size_t) max_keys;
+    int32_t *d_ke = (int32_t *) (d_kf + 3 * (size_t) max_keys * M);
+    uint32_t *d_kp = (uint32_t *) (d_ke + max_keys + (max_keys & 1u)), *d_kg = d_kp + max_keys;
     double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
-    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, ap->start_time, ap->end_time, ap->motion_time_step, a);
-    hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, d_max, a, ap->motion_time_step, d_t0, d_t1);
+    hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
     ECAL_HIP_TRY(ctx, hipMemsetAsync(B[16].ptr, 0, sizeof(int), st));
-    uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..3] counters, [4] overflow flag
+    uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..15] counters
     // The host runs `ahead` passes ahead of the device's counters: before it enqueues pass p it waits for the counters that pass
     // p - ahead left (a copy to pinned memory + an event behind every pass) — the device always has work queued, and at most
     // `ahead` passes run with nothing left to do.
@@ -418,92 +529,137 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     for (int i = 0; i < 8; i++)
         if (!ctx->adaptive_ev[i]) ECAL_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->adaptive_ev[i], hipEventDisableTiming));
     uint32_t *ring = h + 16;   // [8][4] counters as the passes left them
-    bool done = false;
     // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
     // takes a piece through up to D of them
     const uint32_t max_levels = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
     uint32_t n_passes = 0;
-    for (uint32_t pass = 0; pass < max_levels && !done; pass++) {
-        if (pass >= ahead) {
-            const uint32_t q = (pass - ahead) % 8u;
-            ECAL_HIP_TRY(ctx, hipEventSynchronize(ctx->adaptive_ev[q]));
-            if (ring[4 * q + 3]) {
-                (void) hipStreamSynchronize(st);
-                ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
-                return ECAL_ERR_RANGE;
-            }
-            if (ring[4 * q] == 0) break;   // (the passes enqueued since find nothing to do)
-        }
-        n_passes = pass + 1;
-        ECAL_HIP_TRY(ctx, hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st));  // pieces active after this pass
-        if ((rc = ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
-                                         (uint32_t *) B[4].ptr, st)))
-            return rc;
-        if ((rc = ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, S, 0,
-                                        cap_points, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
-                                        (int32_t *) B[8].ptr, (int *) B[16].ptr, st)))
-            return rc;
-        if ((rc = ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * S, cap_points, 0,
-                                        prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, st)))
-            return rc;
-        if ((rc = ecal_extract_for_ctx(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
-                                         (uint32_t *) B[10].ptr, S, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
-                                         prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
-                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st)))
-            return rc;
-        if ((rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
-                                      (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
-            return rc;
-        hipLaunchKernelGGL(adaptive_dir_kernel, dim3(S), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
-                           (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
-                           (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);
-        hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, max_levels,
-                           (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
-                           (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
-                           (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
-                           max_keyframes, d_kt, d_kd, d_ke, d_kf, d_t0, d_t1, (const int *) B[16].ptr, (const double *) ctx->adaptive_dirs.ptr);
+    const char *const range_msg = "cap_points is smaller than the number of events covered by the windows of one pass";
+    // every error return below leaves nothing in flight on the stream (passes write the pinned ring and the context's scratch)
+#define AD_TRY(call)                                  \
+    do {                                              \
+        if ((rc = (call))) {                          \
+            (void) hipStreamSynchronize(st);          \
+            return rc;                                \
+        }                                             \
+    } while (0)
+    auto hip_rc = [&](hipError_t e, const char *what) -> int {
+        if (e == hipSuccess) return ECAL_OK;
+        ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
+    };
+    // the lock-step passes of one set of runs: until no piece has a window left
+    auto run_passes = [&]() -> int {
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, d_max, a, ap->motion_time_step, d_t0, d_t1);
-        ECAL_HIP_TRY(ctx, hipMemcpyAsync(ring + 4 * (pass % 8u), a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        ECAL_HIP_TRY(ctx, hipEventRecord(ctx->adaptive_ev[pass % 8u], st));
-    }
-    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
-    for (uint32_t q = 0; q < 8u && q < n_passes; q++)   // (the last passes' counters: an overflow may sit in any of them)
-        if (ring[4 * q + 3]) {
-            ctx->last_error = "cap_points is smaller than the number of events covered by the windows of one pass";
+        for (uint32_t pass = 0; pass < max_levels; pass++) {
+            if (pass >= ahead) {
+                const uint32_t q = (pass - ahead) % 8u;
+                AD_TRY(hip_rc(hipEventSynchronize(ctx->adaptive_ev[q]), "hipEventSynchronize"));
+                if (ring[4 * q + 3]) {
+                    (void) hipStreamSynchronize(st);
+                    ctx->last_error = range_msg;
+                    return ECAL_ERR_RANGE;
+                }
+                if (ring[4 * q] == 0) break;   // (the passes enqueued since find nothing to do)
+            }
+            n_passes++;
+            AD_TRY(hip_rc(hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st), "hipMemsetAsync"));  // pieces active after this pass
+            AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
+                                          (uint32_t *) B[4].ptr, st));
+            AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, S, 0,
+                                         cap_points, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
+                                         (int32_t *) B[8].ptr, (int *) B[16].ptr, st));
+            AD_TRY(ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * S, cap_points, 0,
+                                         prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, st));
+            AD_TRY(ecal_extract_for_ctx(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
+                                        (uint32_t *) B[10].ptr, S, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
+                                        prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
+                                        (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st));
+            AD_TRY(ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
+                                       (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st));
+            hipLaunchKernelGGL(adaptive_dir_kernel, dim3(S), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
+                               (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
+                               (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);
+            hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, max_levels,
+                               (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
+                               (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
+                               (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
+                               max_keys, d_kt, d_kd, d_ke, d_kf, d_kp, d_kg, d_t0, d_t1, (const int *) B[16].ptr,
+                               (const double *) ctx->adaptive_dirs.ptr);
+            hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, d_max, a, ap->motion_time_step, d_t0, d_t1);
+            AD_TRY(hip_rc(hipMemcpyAsync(ring + 4 * (pass % 8u), a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync"));
+            AD_TRY(hip_rc(hipEventRecord(ctx->adaptive_ev[pass % 8u], st), "hipEventRecord"));
+        }
+        AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
+        AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));
+        if (h[3]) {   // (an overflow may sit in any of the last passes)
+            ctx->last_error = range_msg;
             return ECAL_ERR_RANGE;
         }
-#ifdef ECAL_ADAPTIVE_STATS
-    {
-        uint32_t hs[8];
-        (void) hipMemcpy(hs, a.counters, sizeof(hs), hipMemcpyDeviceToHost);
-        fprintf(stderr, "chain ends: keyframe %u, other verdict %u, chain used up %u, piece finished %u\n", hs[4], hs[5], hs[6], hs[7]);
+        return ECAL_OK;
+    };
+    if ((rc = run_passes())) return rc;
+    uint32_t rounds = 0;
+    if (shared) {
+        // verify every piece against the frame its predecessors now hand it; run the ones again whose verdicts change
+        for (;; rounds++) {
+            AD_TRY(hip_rc(hipMemsetAsync(a.counters + 8, 0, sizeof(uint32_t), st), "hipMemsetAsync"));
+            hipLaunchKernelGGL(adaptive_verify_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
+            hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
+            AD_TRY(hip_rc(hipMemcpyAsync(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync"));
+            AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
+            if (h[8] == 0) break;
+            if (h[1] > max_keys) break;   // the records have run over: reported below
+            if ((rc = run_passes())) return rc;
+        }
     }
+#undef AD_TRY
+#ifdef ECAL_ADAPTIVE_STATS
+    fprintf(stderr, "chain ends: keyframe %u, other verdict %u, chain used up %u, piece finished %u\n", h[4], h[5], h[6], h[7]);
 #endif
-    if (getenv("ECAL_ADAPTIVE_TRACE")) fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes\n", P, S, d_max, n_passes);
+    if (getenv("ECAL_ADAPTIVE_TRACE"))
+        fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes, %u verification rounds\n", P, S,
+                d_max, n_passes, rounds);
     ECAL_HIP_TRY(ctx, hipGetLastError());
+    // windows the rule was applied to / the longest chain of a piece: from the pieces' final runs
+    std::vector<uint32_t> lev(P), gen(P);
+    ECAL_HIP_TRY(ctx, hipMemcpy(lev.data(), a.levels, (size_t) P * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(gen.data(), a.gen, (size_t) P * sizeof(uint32_t), hipMemcpyDeviceToHost));
     unsigned long long nwin = 0;
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(h, a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(&nwin, a.windows, sizeof(nwin), hipMemcpyDeviceToHost, st));
-    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
-    const uint32_t K = h[1];
-    if (passes) *passes = h[2];
+    uint32_t longest = 0;
+    for (uint32_t k = 0; k < P; k++) {
+        nwin += lev[k];
+        longest = std::max(longest, lev[k]);
+    }
+    if (passes) *passes = longest;
     if (windows) *windows = nwin;
-    if (K > max_keyframes) {
-        *n_keyframes = K;
+    const uint32_t K_all = h[1];   // records written, dead ones included
+    if (K_all > max_keys) {
+        *n_keyframes = K_all;
         ctx->last_error = "ecal_detect_keyframes: more keyframes than max_keyframes (n_keyframes holds the count)";
         return ECAL_ERR_RANGE;
     }
+    if (K_all == 0) return ECAL_OK;
+    // the records arrive in completion order: keep the live ones (their piece's final run), sort by time stamp (the
+    // reference's keyframe map is ordered by time)
+    std::vector<double> t(K_all), d(2 * (size_t) K_all), ft(3 * (size_t) K_all * M);
+    std::vector<int32_t> e(K_all);
+    std::vector<uint32_t> kp(K_all), kg(K_all);
+    ECAL_HIP_TRY(ctx, hipMemcpy(t.data(), d_kt, K_all * sizeof(double), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(d.data(), d_kd, 2ul * K_all * sizeof(double), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(ft.data(), d_kf, 3ul * K_all * M * sizeof(double), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(e.data(), d_ke, K_all * sizeof(int32_t), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(kp.data(), d_kp, K_all * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    ECAL_HIP_TRY(ctx, hipMemcpy(kg.data(), d_kg, K_all * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> perm;
+    perm.reserve(K_all);
+    for (uint32_t i = 0; i < K_all; i++)
+        if (kg[i] == gen[kp[i]]) perm.push_back(i);
+    const uint32_t K = (uint32_t) perm.size();
     *n_keyframes = K;
-    if (K == 0) return ECAL_OK;
-    // the records arrive in completion order: sort by time stamp (the reference's keyframe map is ordered by time)
-    std::vector<double> t(K), d(2 * (size_t) K), ft(3 * (size_t) K * M);
-    std::vector<int32_t> e(K);
-    ECAL_HIP_TRY(ctx, hipMemcpy(t.data(), d_kt, K * sizeof(double), hipMemcpyDeviceToHost));
-    ECAL_HIP_TRY(ctx, hipMemcpy(d.data(), d_kd, 2ul * K * sizeof(double), hipMemcpyDeviceToHost));
-    ECAL_HIP_TRY(ctx, hipMemcpy(ft.data(), d_kf, 3ul * K * M * sizeof(double), hipMemcpyDeviceToHost));
-    ECAL_HIP_TRY(ctx, hipMemcpy(e.data(), d_ke, K * sizeof(int32_t), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> perm(K);
-    std::iota(perm.begin(), perm.end(), 0u);
+    if (K > max_keyframes) {
+        ctx->last_error = "ecal_detect_keyframes: more keyframes than max_keyframes (n_keyframes holds the count)";
+        return ECAL_ERR_RANGE;
+    }
     std::sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return t[x] < t[y] || (t[x] == t[y] && d[2 * x] < d[2 * y]); });
     for (uint32_t i = 0; i < K; i++) {
         const uint32_t j = perm[i];
@@ -514,4 +670,9 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         memcpy(kf_features + 3 * (size_t) i * M, ft.data() + 3 * (size_t) j * M, 3 * M * sizeof(double));
     }
     return ECAL_OK;
+}
+
+// The gate and the restated std::nth_element alone, for verification against the oracle (host; no GPU involved)
+extern "C" void ecal_ref_nth_element_f64(double *a, uint32_t n, uint32_t nth) {
+    if (a) ecal::ref_nth_element(a, n, nth, [](double x, double y) { return x < y; });
 }

@@ -4,6 +4,7 @@
 #pragma once
 #include "ecal_ctx.hpp"
 #include "block_utils.hpp"
+#include "ref_nth_element.hpp"
 
 #pragma clang fp contract(off)
 
@@ -230,69 +231,13 @@ __device__ __forceinline__ uint32_t knn_gated(const ST &st, uint32_t base_pol, u
 }
 
 // base[pol]: window-local offset of the polarity's points (and of its kept-cluster arrays).
-// std::nth_element(a, a + nth, a + m, comp) of libstdc++ (bits/stl_algo.h: __introselect with __unguarded_partition_pivot /
-// __move_median_to_first, finished by __insertion_sort on <= 3 elements), restated: CirclesEventFrame.cpp:136-147 runs it over
-// Clusters[c] with comp = "norm of the pixel is smaller", and WHICH of two members of equal norm ends up at a + nth depends on
-// the input order and on these very data movements.  a[] = window-local point indices in the reference's member order
-// (ecal_cluster_order_dev); key = the norm's ordering key.  Returns a[nth], or ~0 if the depth limit 2 lg(m) ran out (the
-// library then switches to __heap_select; not restated — with median-of-three pivots on a few dozen elements it does not
-// happen, and the caller keeps its own choice).
+// std::nth_element(a, a + nth, a + m, comp) of libstdc++ — ref_nth_element.hpp: __introselect with its heap-select branch, restated —
+// as CirclesEventFrame.cpp:136-147 runs it over Clusters[c] with comp = "norm of the pixel is smaller": WHICH of two members of
+// equal norm ends up at a + nth depends on the input order and on the library's data movements.  a[] = window-local point
+// indices in the reference's member order (ecal_cluster_order_dev); key = the norm's ordering key.  Returns a[nth].
 template <typename ST>
-__device__ __forceinline__ uint32_t ref_nth_element(const ST &st, uint32_t o, uint32_t *a, uint32_t m, uint32_t nth) {
-    auto less = [&](uint32_t x, uint32_t y) { return st.key(o + x) < st.key(o + y); };
-    auto swp = [&](uint32_t i, uint32_t j) {
-        const uint32_t t = a[i];
-        a[i] = a[j];
-        a[j] = t;
-    };
-    uint32_t first = 0, last = m;
-    uint32_t depth = 2u * (31u - (uint32_t) __clz((int) m));   // std::__lg(m) * 2
-    while (last - first > 3u) {
-        if (depth == 0u) return ~0u;
-        depth--;
-        // __unguarded_partition_pivot
-        const uint32_t mid = first + (last - first) / 2u;
-        {   // __move_median_to_first(first, first + 1, mid, last - 1)
-            const uint32_t pa = first + 1u, pb = mid, pc = last - 1u;
-            if (less(a[pa], a[pb])) {
-                if (less(a[pb], a[pc])) swp(first, pb);
-                else if (less(a[pa], a[pc])) swp(first, pc);
-                else swp(first, pa);
-            } else if (less(a[pa], a[pc])) {
-                swp(first, pa);
-            } else if (less(a[pb], a[pc])) {
-                swp(first, pc);
-            } else {
-                swp(first, pb);
-            }
-        }
-        uint32_t lo = first + 1u, hi = last;   // __unguarded_partition(first + 1, last, pivot = first)
-        for (;;) {
-            while (less(a[lo], a[first])) lo++;
-            hi--;
-            while (less(a[first], a[hi])) hi--;
-            if (!(lo < hi)) break;
-            swp(lo, hi);
-            lo++;
-        }
-        if (lo <= nth) first = lo;
-        else last = lo;
-    }
-    // __insertion_sort(first, last)
-    for (uint32_t i = first + 1u; i < last; i++) {
-        const uint32_t val = a[i];
-        if (less(val, a[first])) {
-            for (uint32_t j = i; j > first; j--) a[j] = a[j - 1u];   // move_backward(first, i, i + 1)
-            a[first] = val;
-        } else {   // __unguarded_linear_insert
-            uint32_t j = i;
-            while (less(val, a[j - 1u])) {
-                a[j] = a[j - 1u];
-                j--;
-            }
-            a[j] = val;
-        }
-    }
+__device__ __forceinline__ uint32_t ref_nth_member(const ST &st, uint32_t o, uint32_t *a, uint32_t m, uint32_t nth) {
+    ecal::ref_nth_element(a, m, nth, [&](uint32_t x, uint32_t y) { return st.key(o + x) < st.key(o + y); });
     return a[nth];
 }
 
@@ -466,15 +411,8 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 if (!(rv & ST::REP_TIE)) continue;
                 uint32_t pick = rv & ~(ST::REP_TIE | ST::REP_BAD);
                 const uint32_t m = st.ksize[kb[pol] + k], first = base[pol] + st.koff[kb[pol] + k];
-                bool fell_back = true;
-                if (!(rv & ST::REP_BAD)) {
-                    const uint32_t r = ref_nth_element(st, base[pol], &st.members[first], m, m / 2u);
-                    if (r != ~0u) {
-                        pick = r;
-                        fell_back = false;
-                    }
-                }
-                if (fell_back) nk_sh[2] = 1;   // (every writer: the same value)
+                if (!(rv & ST::REP_BAD)) pick = ref_nth_member(st, base[pol], &st.members[first], m, m / 2u);
+                else nk_sh[2] = 1;   // no member order for this cluster (every writer: the same value)
                 st.rep[kb[pol] + k] = pick;
             }
         }

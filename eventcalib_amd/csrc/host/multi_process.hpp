@@ -91,8 +91,8 @@ inline bool orientation_gate(const KeyFrame &ref, const KeyFrame &cur, int rows,
         const double c = (a[0] * b[0] + a[1] * b[1]) / (std::hypot(a[0], a[1]) * std::hypot(b[0], b[1]));
         theta.push_back(std::acos(c));   // (not clamped, as the reference: a cosine rounded above 1 gives NaN)
     }
-    for (double v : theta)
-        if (v != v) return false;    // (std::nth_element on NaNs is unspecified; the build rejects the frame)
+    // (with a NaN among the angles the result is whatever the library's loops leave at the position — on libstdc++ the very
+    // function the reference calls; the device policy restates those loops, ref_nth_element.hpp)
     std::nth_element(theta.begin(), theta.begin() + theta.size() / 2, theta.end());
     return theta[theta.size() / 2] / duration < (5e-4 * M_PI) / motionTimeStep;
 }
@@ -179,9 +179,12 @@ inline std::vector<KeyFrame> detect_keyframes(EventContainer &container, CircleP
 
 // The same search with the policy ON THE DEVICE (ecal_detect_keyframes): the passes are enqueued back to back, nothing
 // but a 4-byte counter crosses PCIe until the keyframes come back.  Same keyframes as detect_keyframes above.
+// gateMode: ECAL_GATE_OWN_PIECE (the deterministic own-piece gate of detect_keyframes above) or ECAL_GATE_SHARED_MAP (the
+// reference run with one worker thread: one keyframe map for all pieces, TrackingBase.cpp:16-46 + EventCalibIni.cpp:26-36).
 inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, CirclePatternParameters::Ptr pattern,
                                                      const CirclesEventFrame::Params &params, double motionTimeStep,
-                                                     int frameEventNumThreshold, int pieceNum, double startTime, double endTime) {
+                                                     int frameEventNumThreshold, int pieceNum, double startTime, double endTime,
+                                                     int gateMode = ECAL_GATE_OWN_PIECE) {
     ecal_detect_params prm;
     prm.dbscan_eps = params.dbscan_eps;
     prm.dbscan_min_samples = (uint32_t) params.dbscan_startMinSample;
@@ -202,12 +205,13 @@ inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, 
     ap.end_time = endTime;
     ap.max_passes = 0;
     ap.check_every = 0;
+    ap.gate_mode = gateMode;
     const ecal_stream *es = container.device();
     const uint64_t n = ecal_stream_size(es);
     const size_t M = (size_t) prm.rows * prm.cols;
     const double span = std::max(endTime - startTime, 1e-9);
     // a pass covers a chain of windows per piece: the library's own estimate, doubled on ECAL_ERR_RANGE
-    const uint64_t cap_max = 0xFFFFFFC0ull;
+    const uint64_t cap_max = std::min<uint64_t>(0xFFFFFFC0ull, 6 * n + 4096);   // (the hint's own maximum: the windows of one slot index are disjoint)
     uint64_t cap = ecal_detect_keyframes_cap_hint(&ap, n);
     uint32_t max_keys = (uint32_t) (span / (8 * motionTimeStep)) + (uint32_t) pieceNum + 64;
     std::vector<double> t, d, f;
@@ -221,11 +225,13 @@ inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, 
         const int rc = ecal_detect_keyframes(ecal_host::thread_ctx(), ecal_stream_data(es), n, &ap, &prm, (uint32_t) cap, max_keys,
                                              t.data(), d.data(), e.data(), f.data(), &K, nullptr, nullptr);
         if (rc == ECAL_OK) break;
-        if (rc != ECAL_ERR_RANGE || (cap >= cap_max && max_keys > (1u << 30)))
+        // double only the quantity that was short: K comes back with the needed keyframe count when that was it
+        const bool keys_short = rc == ECAL_ERR_RANGE && K > max_keys;
+        if (rc != ECAL_ERR_RANGE || (keys_short ? max_keys > (1u << 30) : cap >= cap_max))
             throw std::runtime_error(std::string("ecal_detect_keyframes: ") + ecal_strerror(rc) + " — " +
                                      ecal_last_error(ecal_host::thread_ctx()));
-        cap = std::min<uint64_t>(cap_max, 2 * cap);
-        max_keys *= 2;
+        if (keys_short) max_keys = std::max(2 * max_keys, K + 64);
+        else cap = std::min<uint64_t>(cap_max, 2 * cap);
     }
     std::vector<KeyFrame> all(K);
     for (uint32_t k = 0; k < K; k++) {

@@ -174,7 +174,7 @@ int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
  *        clusters in one polarity (not handled; no candidates).  The exact extraction (ecal_extract_batch_exact_dev / _ordered_dev
  *        and every composite entry point under ECAL_TIES_REFERENCE) ORs ECAL_WIN_TIE_FALLBACK into the word when some tied
  *        median of the window was decided by the smaller-pid rule because the reference's pick could not be worked out (see
- *        ecal_cluster_order_dev's status 1; libstdc++'s heap-select branch of nth_element): everything else about the window
+ *        ecal_cluster_order_dev's status 1: a segment beyond its workspace): everything else about the window
  *        is as for status 0, the representative of that cluster may differ from the reference's.  ECAL_WIN_STATUS(w) strips it.
  *   The ordering of the candidates into the pattern grid (cv::findCirclesGrid, :332-353) is not
  *   part of this entry point.
@@ -322,8 +322,8 @@ int ecal_detect_pass(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, 
 /* ecal_detect_keyframes: the whole adaptive-window driver with the policy on the device — the reference's worker loop
  * (MultiProcess::process, event_camera_calib/test/eventCameraCalib.cpp:34-97: success / slide / grow rule :49-95) over
  * piece_num pieces of [start_time, end_time] (:168-179) with the keyframe gate of EventCalibIni::track (event_camera_calib/
- * src/EventCalibIni.cpp:23-97) against the previous keyframe of the window's own piece (the deterministic policy of
- * host/multi_process.hpp).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over a CHAIN of
+ * src/EventCalibIni.cpp:23-97) against the previous keyframe of the window's own piece or, in the reference's single-worker
+ * semantics, of the one shared map (ecal_adaptive_params.gate_mode).  Every lock-step pass = bounds, slicing, DBSCAN, candidates, grid ordering over a CHAIN of
  * windows per piece — its current one and the windows that follow it if every verdict is the likely one: no keyframe, grow
  * (or slide once the window is longer than three lengths); the window slots of a pass, a few per piece in all, go to the
  * pieces still at work — + one policy kernel that applies the rule along that chain for as long as the verdicts are the
@@ -342,7 +342,21 @@ typedef struct ecal_adaptive_params {
     double start_time, end_time;         /* StartTime / EndTime */
     uint32_t max_passes;                 /* 0 = unlimited */
     uint32_t check_every;                /* passes the host may run ahead of the device's active-piece counter (0 = 2, at most 8) */
+    int gate_mode;                       /* ECAL_GATE_OWN_PIECE / ECAL_GATE_SHARED_MAP (below) */
 } ecal_adaptive_params;
+/* Which keyframe a successful window is gated against (EventCalibIni::track, EventCalibIni.cpp:26-36: the map's
+ * lower_bound(time stamp), else its last keyframe; TrackingBase.cpp:18-27: only the very first frame is ungated):
+ *   ECAL_GATE_OWN_PIECE   the previous keyframe of the window's own piece; every piece's first success is accepted ungated.
+ *                         Deterministic and schedule-free, but not what any run of the reference computes.
+ *   ECAL_GATE_SHARED_MAP  the reference run with ONE worker thread (threadNum = 1): one map, pieces in pop_back order =
+ *                         ascending time, so the reference frame is the map's last keyframe — across piece boundaries too; only
+ *                         the first success of the whole run is ungated.  == oracle/policy_oracle.cpp mode 1.  (With several
+ *                         workers the reference's result depends on the thread schedule: no deterministic counterpart.) */
+#define ECAL_GATE_OWN_PIECE 0
+#define ECAL_GATE_SHARED_MAP 1
+/* libstdc++'s std::nth_element on doubles with operator< (NaNs compare false), restated — what the gate's median is
+ * (EventCalibIni.cpp:78); exported for verification against the real library (host only, no GPU) */
+void ecal_ref_nth_element_f64(double *a, uint32_t n, uint32_t nth);
 int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                           const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                           double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,

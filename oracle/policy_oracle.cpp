@@ -108,8 +108,8 @@ bool track_gate(const Key &ref, const Key &cur, int rows, int cols, double motio
         const double c = (a[0] * b[0] + a[1] * b[1]) / (std::sqrt(a[0] * a[0] + a[1] * a[1]) * std::sqrt(b[0] * b[0] + b[1] * b[1]));
         theta.push_back(std::acos(c));   // (EventCalibIni.cpp:75: no clamp — a cosine rounded above 1 gives NaN)
     }
-    for (double v : theta)
-        if (v != v) return false;   // std::nth_element on NaNs is unspecified: documented as "rejected" (the build does the same)
+    // (a NaN among the angles: the standard leaves the result unspecified; this IS libstdc++'s std::nth_element, the function the
+    // reference calls, so whatever it leaves at the position is the reference's behaviour on this toolchain)
     std::nth_element(theta.begin(), theta.begin() + theta.size() / 2, theta.end());
     return theta[theta.size() / 2] / duration < (5e-4 * M_PI) / motion_time_step;
 }
@@ -194,6 +194,35 @@ int64_t oracle_policy_run(oracle_detect_fn detect, void *user, double start_time
     }
     if (windows_evaluated) *windows_evaluated = evaluated;
     return (int64_t) K;
+}
+
+// libstdc++'s own std::nth_element on doubles (operator<), for pinning the product's restatement of it
+void oracle_nth_element_f64(double *a, uint32_t n, uint32_t nth) {
+    if (a && nth < n) std::nth_element(a, a + nth, a + n);
+}
+
+// An input on which std::nth_element(a, a + nth, a + n) runs out of its depth limit 2 lg n and takes its heap-select branch:
+// McIlroy's adversary ("A killer adversary for quicksort", 1999) played against the library itself — the values are decided
+// while the library compares them, so that every pivot turns out to be nearly the smallest element left.  out[n] = the values.
+void oracle_nth_killer(uint32_t n, uint32_t nth, double *out) {
+    std::vector<int> val(n), idx(n);
+    const int gas = (int) n;
+    int nsolid = 0, candidate = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        val[i] = gas;
+        idx[i] = (int) i;
+    }
+    auto cmp = [&](int x, int y) {
+        if (val[x] == gas && val[y] == gas) {
+            if (x == candidate) val[x] = nsolid++;
+            else val[y] = nsolid++;
+        }
+        if (val[x] == gas) candidate = x;
+        else if (val[y] == gas) candidate = y;
+        return val[x] < val[y];
+    };
+    if (nth < n) std::nth_element(idx.begin(), idx.begin() + nth, idx.end(), cmp);
+    for (uint32_t i = 0; i < n; i++) out[i] = (double) (val[i] == gas ? nsolid++ : val[i]);
 }
 
 // the gate alone, for known-answer tests: 1 = accepted

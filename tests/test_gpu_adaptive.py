@@ -99,3 +99,73 @@ def test_look_ahead_does_not_change_the_keyframes(env, slots, chain, monkeypatch
     for k in ("time", "duration", "events_num", "features"):
         assert np.array_equal(got[k], want[k]), k
     assert got["steps"] == want["steps"] and got["windows"] == want["windows"]
+
+
+def _oracle_detect(ctx, ev, n_ev, cache):
+    import eventcalib_amd.capi as capi
+
+    def detect(t0, t1):
+        if (t0, t1) not in cache:
+            packed = capi.detect_pass(ctx, ev.data_ptr(), n_ev, np.array([t0]), np.array([t1]), 65536, 4.0, 2, 5, 9, 4)
+            found = (int(packed[0, 0]) & 0xFF) == 0 and packed[0, 1] != 0
+            cache[(t0, t1)] = (found, int(packed[0, 2]), packed[0, 3:].reshape(36, 3).copy() if found else None)
+        return cache[(t0, t1)]
+    return detect
+
+
+def _same_keyframes(dev, ref):
+    assert dev["windows"] == ref["windows"]
+    for k in ("time", "duration", "events_num", "features"):
+        assert np.array_equal(dev[k], ref[k]), k
+
+
+@pytest.mark.parametrize("pieces", [1, 6, 40])
+def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
+    """gate_mode = ECAL_GATE_SHARED_MAP against oracle/policy_oracle.cpp mode 1: ONE keyframe map for all pieces, pieces in the
+    reference's pop_back order, only the very first frame ungated (TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36) — what the
+    reference computes with a single worker thread.  The product gets there by speculation + verification rounds
+    (ecal_adaptive.hip); keyframes, windows and counts must be the sequential run's."""
+    import oracle_lib as O
+    import eventcalib_amd.capi as capi
+    from eventcalib_amd.adaptive import detect_keyframes_device
+    ctx, pipe, ev, torch = env
+    n_ev = ev.numel() // 25
+    t_first, t_last = 5.0, 5.0 + 0.4
+    cache = {}
+    detect = _oracle_detect(ctx, ev, n_ev, cache)
+    ref = O.policy_run(detect, t_first, t_last, pieces, 5e-4, 4000, 9, 4, mode=1)
+    own = O.policy_run(detect, t_first, t_last, pieces, 5e-4, 4000, 9, 4, mode=0)
+    dev = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
+    assert len(ref["time"]) >= 20
+    _same_keyframes(dev, ref)
+    if pieces == 1:
+        _same_keyframes(dev, own)              # one piece: the two modes are the same run
+    _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last), own)
+
+
+def test_shared_map_gate_at_the_reference_s_piece_count():
+    """1270 pieces (5 x (256 - 2) hardware threads, eventCameraCalib.cpp:172-173) over a 12.7 s stream: pieces of 10 ms, most of
+    them starting within a few milliseconds of their predecessor's last keyframe — the gate across the piece boundary
+    rejects many first successes, the verification runs several rounds.  == the sequential single-worker oracle."""
+    import torch
+    import eventcalib_amd
+    import eventcalib_amd.capi as capi
+    import oracle_lib as O
+    from eventcalib_amd.adaptive import detect_keyframes_device
+    ctx = eventcalib_amd.Context(0)
+    try:
+        n_ev = 12_700_000
+        ev = SS.make_stream(n_ev, device="cuda", seed=5)
+        torch.cuda.synchronize()
+        t_first, t_last = 5.0, 5.0 + (n_ev - 1) / 1e6
+        cache = {}
+        detect = _oracle_detect(ctx, ev, n_ev, cache)
+        ref = O.policy_run(detect, t_first, t_last, 1270, 5e-4, 4000, 9, 4, mode=1)
+        own = O.policy_run(detect, t_first, t_last, 1270, 5e-4, 4000, 9, 4, mode=0)
+        dev = detect_keyframes_device(ctx, ev, 5e-4, 4000, 1270, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
+        print("keyframes: shared map %d, own piece %d" % (len(ref["time"]), len(own["time"])))
+        assert len(ref["time"]) >= 1000 and not np.array_equal(ref["time"], own["time"])   # the modes differ: the test bites
+        _same_keyframes(dev, ref)
+        _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, 1270, t_first, t_last), own)
+    finally:
+        ctx.close()

@@ -108,3 +108,62 @@ def test_own_piece_gate_and_single_worker_map_differ_as_documented():
     slow = lambda t0, t1: (True, 1500, grid(0.2 * ((t0 + t1) / 2 - 2.0)))
     a, b = O.policy_run(slow, 2.0, 2.0 + 128 * STEP, 4, STEP, 4000, mode=0), O.policy_run(slow, 2.0, 2.0 + 128 * STEP, 4, STEP, 4000, mode=1)
     assert np.array_equal(a["time"], b["time"]) and len(a["time"]) == 16
+
+
+def _both_nth(a, nth):
+    """(libstdc++'s std::nth_element, the product's restatement of it) on copies of a."""
+    import ctypes
+    import eventcalib_amd
+    L, P = O.lib(), eventcalib_amd.load_library()
+    for f in (L.oracle_nth_element_f64, P.ecal_ref_nth_element_f64):
+        f.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+        f.restype = None
+    x, y = np.array(a, np.float64), np.array(a, np.float64)
+    L.oracle_nth_element_f64(x.ctypes.data, len(x), nth)
+    P.ecal_ref_nth_element_f64(y.ctypes.data, len(y), nth)
+    return x, y
+
+
+def test_restated_nth_element_is_the_library_s_move_for_move():
+    """ref_nth_element.hpp (the gate's median on the device, the clusters' median representative) against the real
+    std::nth_element: the WHOLE array afterwards, bit for bit — ties, NaNs (every comparison false: EventCalibIni.cpp:75-78
+    takes acos of a cosine that may round above 1), and inputs that exhaust introselect's depth limit (heap-select branch)."""
+    rng = np.random.default_rng(3)
+    for trial in range(3000):
+        n = int(rng.integers(1, 70))
+        a = rng.integers(0, max(2, n // 3), n).astype(np.float64) if trial % 2 else rng.normal(size=n)
+        if trial % 3 == 0:
+            a[rng.random(n) < 0.25] = np.nan
+        nth = int(rng.integers(0, n))
+        x, y = _both_nth(a, nth)
+        assert np.array_equal(x, y, equal_nan=True), (trial, a, nth)
+    # inputs built by McIlroy's adversary against the library itself: the depth limit 2 lg n runs out, the heap-select branch
+    # decides (oracle_nth_killer; the compare count of a plain introselect round is ~n, these take several times that)
+    import ctypes
+    L = O.lib()
+    L.oracle_nth_killer.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+    L.oracle_nth_killer.restype = None
+    for n in (9, 32, 64, 200, 1000, 4096):
+        for nth in (n // 2, n - 2, 1):
+            a = np.empty(n)
+            L.oracle_nth_killer(n, nth, a.ctypes.data)
+            assert np.array_equal(np.sort(a), np.arange(n))          # a permutation
+            x, y = _both_nth(a, nth)
+            assert np.array_equal(x, y), (n, nth)
+            assert x[nth] == nth
+            b = a.copy()
+            b[::5] = np.nan
+            x, y = _both_nth(b, nth)
+            assert np.array_equal(x, y, equal_nan=True), (n, nth)
+
+
+def test_gate_with_a_nan_angle_is_the_library_s_nth_element():
+    """Two frames whose rows are parallel to rounding: some cosines round above 1, acos gives NaN (no clamp in the reference,
+    EventCalibIni.cpp:75).  The verdict is whatever std::nth_element leaves at rows / 2 — the oracle runs the real one."""
+    a = grid(0.3)
+    seen_nan = accepted = 0
+    for k in range(400):
+        b = grid(0.3 + 1e-9 * k, shift=(100.0 + 0.37 * k, 80.0), pitch=20.0 + 0.01 * k)
+        ok = O.track_gate(a, 1.0, b, 1.004, ROWS, COLS, STEP)
+        accepted += ok
+    assert accepted >= 300     # nearly identical orientation: accepted unless NaNs land on the median position
