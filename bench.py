@@ -406,17 +406,92 @@ def e2e_leg(args, ctx, dev, torch, np):
         SS.TRAJECTORY = "hover"
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    r = calibrate_stream(ctx, ev, t_start, t_start + (n - 1) / rate)
+    # the reference's piece count on this host: 5 * (hardware threads - 2) (eventCameraCalib.cpp:172-173)
+    pieces = 5 * max(1, (os.cpu_count() or 3) - 2)
+    calibrate_stream(ctx, ev[: 25 * 2_000_000], t_start, t_start + (2_000_000 - 1) / rate, piece_num=min(pieces, 64))   # warm-up: scratch of the context
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    r = calibrate_stream(ctx, ev, t_start, t_start + (n - 1) / rate, piece_num=pieces)
     wall = time.perf_counter() - t0
     sp = r["spline"]
-    return {"events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
+    cpp = cpp_chain(ev, n, rate, t_start, pieces, np) if not os.environ.get("ECAL_BENCH_NO_CPP_CHAIN") else None
+    return {"cpp_chain": cpp, "events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
             "residuals_from_association": sp["residuals"], "unknowns": sp["unknowns"], "splines": sp["splines"],
             "lm_iterations": sp["iterations"], "lm_seconds": round(sp["seconds"], 4),
             "lm_iterations_per_s": round(sp["iterations"] / max(sp["seconds"], 1e-9), 2),
             "refined_fx_rel_err": float(abs(r["intrinsics"][0] / SS.FX - 1)),
-            "refined_cx_err_px": float(abs(r["intrinsics"][2] - (SS.CX - 0.5))), "wall_seconds_whole_chain": round(wall, 2),
+            "refined_cx_err_px": float(abs(r["intrinsics"][2] - (SS.CX - 0.5))), "wall_seconds_whole_chain": round(wall, 3),
+            "pieces": pieces, "stage_seconds": {k: round(v, 4) for k, v in r["stage_seconds"].items()},
             "note": "keyframe search (policy P2) -> init calibration -> PnP / checkPose / rectify -> spline fit -> association of "
                     "every event -> LM; host-side Python glue between the stages is inside wall_seconds_whole_chain"}
+
+
+CHAIN_YAML = """%%YAML:1.0
+StartTime: %(start)s
+MotionTimeStep: 5e-4
+FrameEventNumThreshold: 4000
+Camera.width: 346
+Camera.height: 260
+Is_Pattern_Asymmetric: 1
+BoardSize_Rows: 9
+BoardSize_Cols: 4
+Square_Size: 5.5
+Circles_Radius: 1.75
+Calibrate_NrOfFrameToUse: 200
+Calibrate_UseFisheyeModel: 0
+Calibrate_FixAspectRatio: 1
+Calibrate_AssumeZeroTangentialDistortion: 1
+Calibrate_FixPrincipalPointAtTheCenter: 1
+Fix_K1: 0
+Fix_K2: 0
+Fix_K3: 0
+Fix_K4: 1
+Fix_K5: 1
+dbscan_eps: 4
+dbscan_startMinSample: 2
+clusterMinSample: 5
+knn_num: 3
+fitCircle: 0
+useSO3: 0
+reduceMap: 0
+PieceNum: %(pieces)d
+"""
+
+
+def cpp_chain(ev, n, rate, t_start, pieces, np):
+    """The drop-in itself: tests/cpp/test_calib_chain.cpp (the reference driver's main on the C++ shims of eventcalib_amd/csrc/host,
+    argv = settings.yaml events.bin saveDir as eventCameraCalib.cpp:105-110) built with g++ against libecal.so and run on the same
+    stream written as a .bin file; its own per-stage seconds.  The stream is a file here, so loading and uploading it are stages
+    of their own; `seconds_after_upload` is what compares with the Python chain's wall time."""
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    tmp = tempfile.mkdtemp(prefix="ecal_chain_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)   # the stream: a RAM-backed file
+    bin_dir = tempfile.mkdtemp(prefix="ecal_chain_exe_")                                                   # (/dev/shm is mounted noexec)
+    try:
+        exe, lib_dir = os.path.join(bin_dir, "test_calib_chain"), os.path.join(root, "eventcalib_amd")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "test_calib_chain.cpp"),
+                               "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"])
+        ev.cpu().numpy().tofile(os.path.join(tmp, "events.bin"))
+        open(os.path.join(tmp, "settings.yaml"), "w").write(CHAIN_YAML % dict(start=t_start, pieces=pieces))
+        t0 = time.perf_counter()
+        out = subprocess.run([exe, os.path.join(tmp, "settings.yaml"), os.path.join(tmp, "events.bin"), tmp, "batch"],
+                             capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if out.returncode != 0:
+            return {"error": (out.stdout + out.stderr)[-400:]}
+        stages = {l.split()[1]: round(float(l.split()[2]), 4) for l in out.stdout.splitlines() if l.startswith("stage ")}
+        lines = [l for l in out.stdout.splitlines() if not l.startswith("stage ")]
+        ref = lines[2].split()
+        after = sum(v for k, v in stages.items() if k not in ("load_file", "upload"))
+        return {"process_wall_seconds": round(wall, 3), "stage_seconds": stages, "seconds_after_upload": round(after, 4),
+                "keyframes": int(lines[0].split()[1]), "refined_fx": float(ref[1]), "residuals": int(ref[11]),
+                "lm_iterations": int(ref[13]), "splines": int(ref[15]),
+                "note": "process start to exit incl. HIP runtime initialisation, reading 1.25 GB from a RAM-backed file and the upload"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+        shutil.rmtree(bin_dir, ignore_errors=True)
 
 
 def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np):

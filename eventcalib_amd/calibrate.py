@@ -78,18 +78,29 @@ def check_pose(R_ref, twb_ref, t_ref, R_cur, twb_cur, t_cur, step):
 
 def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, frame_event_num_threshold=4000, piece_num=30,
                      frames_to_use=200, width=346.0, height=260.0, rows=9, cols=4, square=5.5, circle_radius=1.75,
-                     flags=EXAMPLE_FLAGS, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2):
+                     flags=EXAMPLE_FLAGS, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2, gate_mode=0):
     """events: uint8 CUDA tensor of packed 25-byte records.  Returns a dict with the initial calibration, the refined
     intrinsics [fx fy cx cy k1..k5 (inverse radial polynomial)] and the keyframe trajectory."""
+    import time as _time
     dev = events.device
     st = torch.cuda.current_stream(dev).cuda_stream
     step = motion_time_step
     n_circ = rows * cols
+    stages = {}
+    t_mark = [_time.perf_counter()]
+
+    def mark(name):   # wall seconds per stage (the GPU is drained at every mark: stages do not overlap)
+        torch.cuda.synchronize(dev)
+        now = _time.perf_counter()
+        stages[name] = stages.get(name, 0.0) + now - t_mark[0]
+        t_mark[0] = now
     pipe = DetectPipeline(ctx, dev)
     # -- 1. keyframes
-    kf = detect_keyframes_device(pipe.ctx, events, step, frame_event_num_threshold, piece_num, t_first, t_last, eps, minpts, rows, cols)
+    kf = detect_keyframes_device(pipe.ctx, events, step, frame_event_num_threshold, piece_num, t_first, t_last, eps, minpts, rows, cols,
+                                 gate_mode=gate_mode)
     K = len(kf["time"])
-    out = {"keyframes": K}
+    out = {"keyframes": K, "stage_seconds": stages}
+    mark("keyframe_search")
     if K == 0:
         raise RuntimeError("no keyframe found")
     # -- 2. init calibration on a subset (EventCalibIni.cpp:163-181), image points narrowed to float like cv::Point2f
@@ -103,6 +114,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     ini = capi.calibrate_views(ctx, obj, feat32[sel], width, height, 0, flags, aspect_ratio)
     intr0 = ini["intr"]
     out["init"] = {"intr": intr0, "rms": ini["rms"], "iterations": ini["iterations"], "views": use}
+    mark("init_calibration")
     # solvePnPRansac on every keyframe, one batched launch
     d_obj = torch.as_tensor(obj, device=dev)
     d_img = torch.as_tensor(np.ascontiguousarray(feat32), device=dev)
@@ -117,6 +129,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     Rsw = rodrigues(pose[:, :3])
     tsw = pose[:, 3:]
     twb = -np.einsum("nji,nj->ni", Rsw, tsw)
+    mark("pnp")
     # rectifyFeatures for all keyframes at once: their windows go through the detection pipeline again
     pipe.set_windows(kf["duration"][:, 0], kf["duration"][:, 1])
     pipe.run(events, eps, minpts)
@@ -135,20 +148,33 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
                           pipe.win_info.data_ptr(), d_frames.data_ptr(), d_rpose.data_ptr(), K, d_obj.data_ptr(), prm,
                           d_feat.data_ptr(), d_valid.data_ptr(), d_info.data_ptr(), st)
     rect_ok = d_info[:, 0].cpu().numpy().astype(bool)
-    circles = d_feat.cpu().numpy()
-    # the sequential gates of EventCalibIni.cpp:281-302 (checkPose against the last accepted keyframe, then rectify)
+    mark("rectify")
+    # the sequential gates of EventCalibIni.cpp:281-302 (checkPose against the last accepted keyframe, then rectify).  The
+    # test against the PREVIOUS keyframe is worked out for all keyframes at once; the loop falls back to the scalar test only
+    # where the last accepted keyframe is not the previous one (a rejection in between)
+    kt = kf["time"]
+    pair_ok = np.zeros(K, bool)
+    if K > 1:
+        dt = kt[1:] - kt[:-1]
+        v_t = np.linalg.norm(twb[1:] - twb[:-1], axis=1) / dt
+        c = (np.einsum("nij,nij->n", Rsw[1:], Rsw[:-1]) - 1) * 0.5          # trace(R_cur R_ref^T)
+        v_r = np.abs(np.arccos(np.minimum(1.0, np.maximum(-1.0, c))) / dt)
+        pair_ok[1:] = (v_t < (2.5e-1 / step) * 2) & (v_r < (5e-4 * np.pi) * 2 / step)
     acc, last, n_check, n_rect = [], -1, 0, 0
+    ok_l, rect_l, pair_l = ok.tolist(), rect_ok.tolist(), pair_ok.tolist()
     for f in range(K):
-        if not ok[f] or (last >= 0 and not check_pose(Rsw[last], twb[last], kf["time"][last], Rsw[f], twb[f], kf["time"][f], step)):
+        if not ok_l[f] or (last >= 0 and not (pair_l[f] if last == f - 1 else
+                                              check_pose(Rsw[last], twb[last], kt[last], Rsw[f], twb[f], kt[f], step))):
             n_check += 1
             continue
-        if not rect_ok[f]:
+        if not rect_l[f]:
             n_rect += 1
             continue
         acc.append(f)
         last = f
     out["init"].update(accepted=len(acc), discarded_by_check_pose=n_check, discarded_by_rectify=n_rect)
     acc = np.array(acc, np.int64)
+    mark("check_pose_gates")
     if len(acc) <= 10:
         raise RuntimeError("too few frames in the map.")     # EventCalibSpline.cpp:26-28
     # -- 3. splines: a gap of more than 50 steps starts a new one; fewer than 4 frames -> dropped (:318-345)
@@ -179,36 +205,41 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
         ranges.append((u[0], u[-1]))
     keep = np.concatenate(segs)
     kf_idx = acc[keep]
-    # association (EventCalibSpline.cpp:140-192): every event against the nearest keyframe's rectified circles
+    mark("spline_fit")
+    # association (EventCalibSpline.cpp:140-192): every event against the nearest keyframe's rectified circles — all spline
+    # segments in ONE pass over the stream, the residual arrays and their count stay in HBM and the solver is built on them
+    # in place (ecal_associate_ranges_dev -> ecal_solver_create_dev): nothing proportional to the events crosses PCIe
     n_events = events.numel() // 25
+    d_kidx = torch.as_tensor(kf_idx, device=dev)
     d_kt = torch.as_tensor(kf["time"][kf_idx], device=dev)
-    d_kc = torch.as_tensor(np.ascontiguousarray(circles[kf_idx]), device=dev)
+    d_kc = d_feat[d_kidx].contiguous()                       # the rectified circles of the kept keyframes, never downloaded
+    d_rng = torch.as_tensor(np.ascontiguousarray(np.array(ranges, np.float64)), device=dev)
     d_o = torch.empty(n_events, 2, dtype=torch.float64, device=dev)
     d_t = torch.empty(n_events, dtype=torch.float64, device=dev)
     d_l = torch.empty(n_events, dtype=torch.int32, device=dev)
+    d_s = torch.empty(n_events, dtype=torch.int32, device=dev)
     d_c = torch.zeros(1, dtype=torch.int32, device=dev)
-    obs, tm, lm, sid = [], [], [], []
-    for i, (a, b) in enumerate(ranges):
-        ctx.associate_dev(events.data_ptr(), n_events, d_kt.data_ptr(), d_kc.data_ptr(), len(kf_idx), n_circ, a, b, 5 * step, 5.0,
-                          d_o.data_ptr(), d_t.data_ptr(), d_l.data_ptr(), d_c.data_ptr(), st)
-        m = int(d_c.item())
-        obs.append(d_o[:m].cpu().numpy())
-        tm.append(d_t[:m].cpu().numpy())
-        lm.append(d_l[:m].cpu().numpy())
-        sid.append(np.full(m, i, np.uint32))
-    obs, tm, lm, sid = np.concatenate(obs), np.concatenate(tm), np.concatenate(lm), np.concatenate(sid)
+    ctx.associate_ranges_dev(events.data_ptr(), n_events, d_kt.data_ptr(), d_kc.data_ptr(), len(kf_idx), n_circ, d_rng.data_ptr(),
+                             len(ranges), 5 * step, 5.0, d_o.data_ptr(), d_t.data_ptr(), d_l.data_ptr(), d_s.data_ptr(),
+                             d_c.data_ptr(), st)
+    mark("association")
     # intrinsics: K + the inverse radial polynomial of (k1, k2, k3) (:93-105)
     b5 = capi.inverse_radial_distortion([intr0[4], intr0[5], intr0[8], 0.0])
     x0 = np.concatenate([intr0[:4], b5, np.concatenate(cq).ravel(), np.concatenate(ct).ravel()])
-    prob = dict(seg_cp_off=np.array(seg_cp_off, np.uint32), knots=np.concatenate(knots), obs=obs, time=tm, lm_id=lm.astype(np.uint32),
-                seg_id=sid, landmarks=board_points(rows, cols, square).astype(np.float64), circle_radius=circle_radius,
+    prob = dict(seg_cp_off=np.array(seg_cp_off, np.uint32), knots=np.concatenate(knots),
+                landmarks=board_points(rows, cols, square).astype(np.float64), circle_radius=circle_radius,
                 huber_a=0.2 * circle_radius, use_so3=bool(use_so3))
-    solver = capi.Solver(ctx, prob)
+    solver = capi.Solver(ctx, prob, device_arrays=(d_o.data_ptr(), d_t.data_ptr(), d_l.data_ptr(), d_s.data_ptr(), n_events,
+                                                   d_c.data_ptr()), stream=st)
+    n_res = solver.n_res
+    del d_o, d_t, d_l, d_s
+    mark("solver_setup")
     opt = solver.default_options()
     opt.max_num_iterations = max_num_iterations
     x, summ = solver.solve(x0, opt)
     solver.close()
-    out["spline"] = {"splines": len(segs), "control_points": int(seg_cp_off[-1]), "residuals": int(len(tm)),
+    mark("lm_solve")
+    out["spline"] = {"splines": len(segs), "control_points": int(seg_cp_off[-1]), "residuals": int(n_res),
                      "iterations": int(summ.iterations), "initial_cost": float(summ.initial_cost),
                      "final_cost": float(summ.final_cost), "seconds": float(summ.seconds),
                      "jacobian_evaluations": int(summ.jacobian_evaluations), "unknowns": int(9 + 6 * seg_cp_off[-1])}
@@ -225,6 +256,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
         traj.append(np.concatenate([tt[:, None], capi.spline_eval(knots[i], t_all[a:b], tt), q], axis=1))
     out["trajectory"] = np.concatenate(traj)                 # timestamp tx ty tz qx qy qz qw (TUM)
     out["init_trajectory"] = np.concatenate([times[keep][:, None], twb[kf_idx], Qwb[keep]], axis=1)
+    mark("update_map")
     return out
 
 

@@ -22,7 +22,8 @@ EXPORTED_SYMBOLS = [
     "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_detect_keyframes_cap_hint", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
-    "ecal_solver_solve", "ecal_inverse_radial_distortion",
+    "ecal_solver_solve", "ecal_inverse_radial_distortion", "ecal_solver_create_dev", "ecal_solver_num_residuals",
+    "ecal_associate_ranges_dev", "ecal_ref_nth_element_f64", "ecal_solver_create_from_stream", "ecal_rectify_keyframes",
     "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval", "ecal_spline_so3_refine",
 ]
 
@@ -119,6 +120,8 @@ def load_library():
     L.ecal_rectify_batch_dev.restype = i32
     L.ecal_associate_dev.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, u32, u32, f64, f64, f64, f64, vp, vp, vp, vp, vp]
     L.ecal_associate_dev.restype = i32
+    L.ecal_associate_ranges_dev.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, u32, u32, vp, u32, f64, f64, vp, vp, vp, vp, vp, vp]
+    L.ecal_associate_ranges_dev.restype = i32
     L.ecal_copy_dev.argtypes = [vp, vp, vp, ctypes.c_size_t, vp, i32]
     L.ecal_copy_dev.restype = i32
     _LIB = L
@@ -276,6 +279,13 @@ class Context:
                                                int(n_keyframes), int(n_circles), float(t_min), float(t_max),
                                                float(max_dt), float(edge_tol), d_obs, d_time, d_lm_id, d_count, stream))
 
+    def associate_ranges_dev(self, d_events, n_events, d_kf_time, d_kf_circles, n_keyframes, n_circles, d_ranges, n_ranges,
+                             max_dt, edge_tol, d_obs, d_time, d_lm_id, d_seg_id, d_count, stream=0):
+        """ecal_associate_ranges_dev: all spline segments in one pass; the count stays on the device."""
+        self._check(self._L.ecal_associate_ranges_dev(self._h, d_events, int(n_events), d_kf_time, d_kf_circles, int(n_keyframes),
+                                                      int(n_circles), d_ranges, int(n_ranges), float(max_dt), float(edge_tol),
+                                                      d_obs, d_time, d_lm_id, d_seg_id, d_count, stream))
+
     # ---- circle-candidate extraction ----
     def circle_radius_threshold(self, width, height, rows, cols, asymmetric, square_size, circle_radius):
         return self._L.ecal_circle_radius_threshold(float(width), float(height), int(rows), int(cols),
@@ -392,6 +402,10 @@ def _declare_solver(L):
     vp, i32, f64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     L.ecal_solver_create.argtypes = [vp, ctypes.POINTER(_SplineProblem), ctypes.POINTER(vp)]
     L.ecal_solver_create.restype = i32
+    L.ecal_solver_create_dev.argtypes = [vp, ctypes.POINTER(_SplineProblem), vp, vp, ctypes.POINTER(vp)]
+    L.ecal_solver_create_dev.restype = i32
+    L.ecal_solver_num_residuals.argtypes = [vp]
+    L.ecal_solver_num_residuals.restype = ctypes.c_uint64
     L.ecal_solver_destroy.argtypes = [vp]
     L.ecal_solver_destroy.restype = None
     for f in (L.ecal_solver_param_size, L.ecal_solver_normal_size):
@@ -427,7 +441,10 @@ class Solver:
     seg_id [M] u32 or None, landmarks [L,3], circle_radius, huber_a, use_so3 (optional, default False).
     Parameter vector layout: [intr 9 | q n_cp x 4 (xyzw) | t n_cp x 3]."""
 
-    def __init__(self, ctx: Context, problem):
+    def __init__(self, ctx: Context, problem, device_arrays=None, stream=0):
+        """device_arrays = (d_obs, d_time, d_lm_id, d_seg_id or None, capacity, d_count or None): raw DEVICE pointers of the
+        residual arrays (ecal_associate_ranges_dev's outputs) — ecal_solver_create_dev builds the problem in place; the
+        dict then carries only seg_cp_off, knots, landmarks and the scalars."""
         self.ctx = ctx
         L = ctx._L
         _declare_solver(L)
@@ -442,24 +459,31 @@ class Solver:
         P.seg_cp_off = arr("seg_cp_off", np.uint32)
         P.n_segments = keep["seg_cp_off"].shape[0] - 1
         P.knots = arr("knots", np.float64)
-        P.obs = arr("obs", np.float64)
-        P.time = arr("time", np.float64)
-        P.lm_id = arr("lm_id", np.uint32)
-        P.n_res = keep["time"].shape[0]
-        P.seg_id = arr("seg_id", np.uint32) if problem.get("seg_id") is not None else None
+        if device_arrays is None:
+            P.obs = arr("obs", np.float64)
+            P.time = arr("time", np.float64)
+            P.lm_id = arr("lm_id", np.uint32)
+            P.n_res = keep["time"].shape[0]
+            P.seg_id = arr("seg_id", np.uint32) if problem.get("seg_id") is not None else None
+        else:
+            d_obs, d_time, d_lm, d_seg, cap, d_count = device_arrays
+            P.obs, P.time, P.lm_id, P.seg_id, P.n_res = d_obs, d_time, d_lm, d_seg, int(cap)
         P.landmarks = arr("landmarks", np.float64)
         P.n_landmarks = keep["landmarks"].reshape(-1, 3).shape[0]
         P.circle_radius = float(problem["circle_radius"])
         P.huber_a = float(problem["huber_a"])
         P.use_so3 = int(bool(problem.get("use_so3", False)))
         h = ctypes.c_void_p()
-        ctx._check(L.ecal_solver_create(ctx._h, ctypes.byref(P), ctypes.byref(h)))
+        if device_arrays is None:
+            ctx._check(L.ecal_solver_create(ctx._h, ctypes.byref(P), ctypes.byref(h)))
+        else:
+            ctx._check(L.ecal_solver_create_dev(ctx._h, ctypes.byref(P), device_arrays[5], stream, ctypes.byref(h)))
         self._h = h
         self.n_params = int(L.ecal_solver_param_size(h))
         self.n_normal = int(L.ecal_solver_normal_size(h))
         self.n_cp = (self.n_params - 9) // 7
         self.n_chunks = int(L.ecal_solver_num_chunks(h))
-        self.n_res = int(P.n_res)
+        self.n_res = int(L.ecal_solver_num_residuals(h))
 
     def close(self):
         if getattr(self, "_h", None):

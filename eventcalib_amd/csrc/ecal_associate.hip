@@ -22,6 +22,16 @@ __device__ __forceinline__ double load_f64_u(const uint8_t *p) {
     return v;
 }
 
+// the range r with ranges[2 r] <= t <= ranges[2 r + 1] (ascending, disjoint), or -1
+__device__ __forceinline__ int range_of(double t, const double *ranges, uint32_t R) {
+    uint32_t a = 0, b = R;   // first range whose end is not below t
+    while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (ranges[2 * m + 1] < t) a = m + 1; else b = m;
+    }
+    return (a < R && t >= ranges[2 * a]) ? (int) a : -1;
+}
+
 // returns the circle index or -1
 __device__ __forceinline__ int associate_one(double t, double x, double y, const double *kf_time, const double *circles,
                                              uint32_t K, uint32_t n_circ, double t_min, double t_max, double max_dt2,
@@ -65,22 +75,30 @@ __global__ __launch_bounds__(AS_T) void associate_kernel(const uint8_t *__restri
                                                          double edge_tol, uint32_t *__restrict__ block_cnt,
                                                          const uint32_t *__restrict__ block_off,
                                                          double *__restrict__ obs, double *__restrict__ time,
-                                                         uint32_t *__restrict__ lm) {
+                                                         uint32_t *__restrict__ lm, const double *__restrict__ ranges,
+                                                         uint32_t n_ranges, uint32_t *__restrict__ seg) {
     __shared__ uint32_t wsum[AS_T / 64];
     const uint64_t base = (uint64_t) blockIdx.x * (AS_T * AS_PER) + (uint64_t) threadIdx.x * AS_PER;
-    int hit[AS_PER];
+    int hit[AS_PER], rng[AS_PER];
     double tt[AS_PER], xx[AS_PER], yy[AS_PER];
     uint32_t mine = 0;
 #pragma unroll
     for (int e = 0; e < AS_PER; e++) {
         hit[e] = -1;
+        rng[e] = 0;
         const uint64_t i = base + e;
         if (i < n) {
             const uint8_t *r = rec + i * 25;
             tt[e] = load_f64_u(r);
             xx[e] = load_f64_u(r + 8);
             yy[e] = load_f64_u(r + 16);
-            hit[e] = associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, t_min, t_max, max_dt2, edge_tol);
+            if (ranges) {   // all spline segments in one pass: the event's range, if any, names its segment
+                rng[e] = range_of(tt[e], ranges, n_ranges);
+                if (rng[e] >= 0)
+                    hit[e] = associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, tt[e], tt[e], max_dt2, edge_tol);
+            } else {
+                hit[e] = associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, t_min, t_max, max_dt2, edge_tol);
+            }
             mine += hit[e] >= 0 ? 1u : 0u;
         }
     }
@@ -111,6 +129,7 @@ __global__ __launch_bounds__(AS_T) void associate_kernel(const uint8_t *__restri
             obs[2 * at + 1] = yy[e];
             time[at] = tt[e];
             lm[at] = (uint32_t) hit[e];
+            if (seg) seg[at] = (uint32_t) rng[e];
             at++;
         }
     }
@@ -149,10 +168,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(const uint32_t *__res
 
 using namespace ecal;
 
-extern "C" int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
-                                  const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, double t_min,
-                                  double t_max, double max_dt, double edge_tol, double *d_obs, double *d_time,
-                                  uint32_t *d_lm_id, uint32_t *d_count, void *stream) {
+static int associate_common(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
+                            const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, double t_min, double t_max,
+                            const double *d_ranges, uint32_t n_ranges, double max_dt, double edge_tol, double *d_obs, double *d_time,
+                            uint32_t *d_lm_id, uint32_t *d_seg_id, uint32_t *d_count, void *stream) {
     if (!ctx || !d_count) return ECAL_ERR_INVALID;
     if (n_events > 0xFFFFFFFFull) return ECAL_ERR_RANGE;
     if (n_events && (!d_events || !d_obs || !d_time || !d_lm_id)) return ECAL_ERR_INVALID;
@@ -171,14 +190,40 @@ extern "C" int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64
     const double md2 = max_dt * max_dt;
     hipLaunchKernelGGL((associate_kernel<false>), dim3(nb), dim3(AS_T), 0, st, d_events, n_events, d_kf_time,
                        d_kf_circles, n_keyframes, n_circles, t_min, t_max, md2, edge_tol, cnt, off, d_obs, d_time,
-                       d_lm_id);
+                       d_lm_id, d_ranges, n_ranges, d_seg_id);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, cnt, nb, off);
     hipLaunchKernelGGL((associate_kernel<true>), dim3(nb), dim3(AS_T), 0, st, d_events, n_events, d_kf_time,
                        d_kf_circles, n_keyframes, n_circles, t_min, t_max, md2, edge_tol, cnt, off, d_obs, d_time,
-                       d_lm_id);
+                       d_lm_id, d_ranges, n_ranges, d_seg_id);
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_count, off + nb, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
+}
+
+extern "C" int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
+                                  const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, double t_min,
+                                  double t_max, double max_dt, double edge_tol, double *d_obs, double *d_time,
+                                  uint32_t *d_lm_id, uint32_t *d_count, void *stream) {
+    return associate_common(ctx, d_events, n_events, d_kf_time, d_kf_circles, n_keyframes, n_circles, t_min, t_max, nullptr, 0, max_dt,
+                            edge_tol, d_obs, d_time, d_lm_id, nullptr, d_count, stream);
+}
+
+extern "C" int ecal_associate_ranges_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
+                                         const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, const double *d_ranges,
+                                         uint32_t n_ranges, double max_dt, double edge_tol, double *d_obs, double *d_time,
+                                         uint32_t *d_lm_id, uint32_t *d_seg_id, uint32_t *d_count, void *stream) {
+    if (ctx && n_events && (!d_ranges || !d_seg_id) && n_ranges) {
+        ctx->last_error = "null pointer";
+        return ECAL_ERR_INVALID;
+    }
+    if (n_ranges == 0) {   // no spline segment: no residual
+        if (!ctx || !d_count) return ECAL_ERR_INVALID;
+        ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(uint32_t), (hipStream_t) stream));
+        return ECAL_OK;
+    }
+    return associate_common(ctx, d_events, n_events, d_kf_time, d_kf_circles, n_keyframes, n_circles, 0.0, 0.0, d_ranges, n_ranges, max_dt,
+                            edge_tol, d_obs, d_time, d_lm_id, d_seg_id, d_count, stream);
 }
 
 // host-buffer form (what host/event_calib_spline.hpp calls): the event stream stays in HBM (ecal_stream), the
@@ -220,4 +265,47 @@ extern "C" int ecal_associate(ecal_ctx *ctx, const ecal_stream *es, const double
         ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
     }
     return ECAL_OK;
+}
+
+
+// Association of every spline segment + the solver built on the result, in one host call (what host/event_calib_spline.hpp
+// calls): the event stream is resident (ecal_stream), the keyframe tables and the segments' time ranges go up, the residual
+// arrays never leave HBM (ecal_associate_ranges_dev -> ecal_solver_create_dev).  layout = the problem without its residual
+// arrays (obs / time / lm_id / seg_id / n_res are ignored).
+extern "C" int ecal_solver_create_from_stream(ecal_ctx *ctx, const ecal_stream *es, const double *kf_time, const double *kf_circles,
+                                              uint32_t n_keyframes, uint32_t n_circles, const double *ranges, uint32_t n_ranges,
+                                              double max_dt, double edge_tol, const ecal_spline_problem *layout, ecal_solver **out) {
+    if (!ctx || !es || !layout || !out || (n_keyframes && (!kf_time || !kf_circles)) || (n_ranges && !ranges)) return ECAL_ERR_INVALID;
+    *out = nullptr;
+    if (n_ranges != layout->n_segments) {
+        ctx->last_error = "ecal_solver_create_from_stream: one time range per spline segment";
+        return ECAL_ERR_INVALID;
+    }
+    const uint64_t n = ecal_stream_size(es);
+    if (n > 0xFFFFFFFFull) return ECAL_ERR_RANGE;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t kb = (size_t) n_keyframes * 8, cb = (size_t) n_keyframes * n_circles * 24, rb = (size_t) n_ranges * 16;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_kt = 0, o_kc = up(kb), o_rg = o_kc + up(cb), o_obs = o_rg + up(rb), o_tm = o_obs + up(n * 16), o_lm = o_tm + up(n * 8),
+                 o_sg = o_lm + up(n * 4), o_cnt = o_sg + up(n * 4), total = o_cnt + 256;
+    int rc = ecal_ensure(ctx, ctx->as_host, total);
+    if (rc) return rc;
+    char *base = (char *) ctx->as_host.ptr;
+    hipStream_t st = ctx->stream;
+    if (kb) ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_kt, kf_time, kb, hipMemcpyHostToDevice, st));
+    if (cb) ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_kc, kf_circles, cb, hipMemcpyHostToDevice, st));
+    if (rb) ECAL_HIP_TRY(ctx, hipMemcpyAsync(base + o_rg, ranges, rb, hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));   // (pageable sources: consumed)
+    rc = ecal_associate_ranges_dev(ctx, ecal_stream_data(es), n, (const double *) (base + o_kt), (const double *) (base + o_kc), n_keyframes,
+                                   n_circles, (const double *) (base + o_rg), n_ranges, max_dt, edge_tol, (double *) (base + o_obs),
+                                   (double *) (base + o_tm), (uint32_t *) (base + o_lm), (uint32_t *) (base + o_sg),
+                                   (uint32_t *) (base + o_cnt), st);
+    if (rc) return rc;
+    ecal_spline_problem p = *layout;
+    p.obs = (const double *) (base + o_obs);
+    p.time = (const double *) (base + o_tm);
+    p.lm_id = (const uint32_t *) (base + o_lm);
+    p.seg_id = (const uint32_t *) (base + o_sg);
+    p.n_res = n;
+    return ecal_solver_create_dev(ctx, &p, (const uint32_t *) (base + o_cnt), st, out);
 }

@@ -170,6 +170,68 @@ extern "C" int ecal_detect_batch(ecal_ctx *ctx, const ecal_stream *es, const dou
     return ECAL_OK;
 }
 
+// rectifyFeatures for F keyframes given by their time windows, everything on the device (what host/event_calib_ini.hpp's
+// batched path calls): EventFrame + extractFeatures up to the kept clusters for every window (the stages of ecal_detect_batch,
+// nothing copied back), then ecal_rectify_batch_dev with keyframe f = window f.
+extern "C" int ecal_rectify_keyframes(ecal_ctx *ctx, const ecal_stream *es, const double *durations, uint32_t F,
+                                      const ecal_detect_params *dprm, const double *poses, const double *landmarks,
+                                      const ecal_rectify_params *rprm, double *feat_xyr, uint32_t *feat_valid, uint32_t *frame_info) {
+    if (!ctx || !es || !dprm || !rprm || (F && (!durations || !poses || !landmarks || !feat_xyr || !feat_valid || !frame_info)))
+        return ECAL_ERR_INVALID;
+    if (es->ctx != ctx) {
+        ctx->last_error = "stream belongs to another context";
+        return ECAL_ERR_INVALID;
+    }
+    if (F == 0) return ECAL_OK;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    std::vector<double> t0(F), t1(F);
+    for (uint32_t f = 0; f < F; f++) {
+        t0[f] = durations[2 * f];
+        t1[f] = durations[2 * f + 1];
+    }
+    // slots = the events the windows cover: one bounds pass tells
+    ecal_devbuf *B = ctx->host_pipe;
+    const size_t pre[5] = {F * sizeof(double), F * sizeof(double), F * 4ul, F * 4ul, (F + 1) * 4ul};
+    for (int i = 0; i < 5; i++)
+        if ((rc = ecal_ensure(ctx, B[i], pre[i]))) return rc;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(B[0].ptr, t0.data(), F * sizeof(double), hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(B[1].ptr, t1.data(), F * sizeof(double), hipMemcpyHostToDevice, st));
+    if ((rc = ecal_window_bounds_dev(ctx, es->d_events, es->n_events, (double *) B[0].ptr, (double *) B[1].ptr, F, (uint32_t *) B[2].ptr,
+                                     (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, st)))
+        return rc;
+    uint32_t total = 0;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(&total, (uint32_t *) B[4].ptr + F, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    ecal_detect_params dp = *dprm;
+    dp.rows = dp.cols = 0;   // (no grid ordering: rectifyFeatures works on the clusters)
+    ecal_detect_result none;
+    memset(&none, 0, sizeof(none));
+    if ((rc = ecal_detect_batch(ctx, es, t0.data(), t1.data(), F, &dp, total + 64u, &none))) return rc;
+    const uint32_t n = rprm->rows * rprm->cols;
+    ecal_devbuf *R = ctx->host_rect;
+    const size_t rs[6] = {(size_t) F * 12 * 8, (size_t) n * 3 * 8, (size_t) F * 4, (size_t) F * n * 24, (size_t) F * n * 4, (size_t) F * 8};
+    for (int i = 0; i < 6; i++)
+        if ((rc = ecal_ensure(ctx, R[i], rs[i]))) return rc;
+    std::vector<uint32_t> ident(F);
+    for (uint32_t f = 0; f < F; f++) ident[f] = f;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(R[0].ptr, poses, rs[0], hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(R[1].ptr, landmarks, rs[1], hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(R[2].ptr, ident.data(), rs[2], hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));   // (pageable sources: consumed)
+    if ((rc = ecal_rectify_batch_dev(ctx, (const double *) B[5].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
+                                     (const int32_t *) B[11].ptr, (const uint32_t *) B[13].ptr, (const uint32_t *) R[2].ptr,
+                                     (const double *) R[0].ptr, F, (const double *) R[1].ptr, rprm, (double *) R[3].ptr, (uint32_t *) R[4].ptr,
+                                     (uint32_t *) R[5].ptr, st)))
+        return rc;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(feat_xyr, R[3].ptr, rs[3], hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(feat_valid, R[4].ptr, rs[4], hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(frame_info, R[5].ptr, rs[5], hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ECAL_OK;
+}
+
 // ---- double-buffered ingest ------------------------------------------------------------------------------
 // The event file does not have to be resident before detection starts: chunks of whole windows are uploaded on a
 // copy stream (hipMemcpyAsync from pinned host memory) into one of two device buffers while the detection kernels

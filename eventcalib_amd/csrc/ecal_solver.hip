@@ -525,6 +525,227 @@ extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, e
     return ECAL_OK;
 }
 
+// ---- the problem built in place from DEVICE arrays (the association's outputs) ---------------------------------------------
+// EventCalibSpline::optimize adds a residual block per associated event where it finds it (EventCalibSpline.cpp:181-235);
+// here the association (ecal_associate_ranges_dev) leaves obs / time / lm_id / seg_id in HBM and the solver's records and
+// chunk table are made from them by three small kernels — the 28 bytes per residual never cross PCIe.
+namespace {
+
+// flags: 1 residual out of time order / outside its segment's knot range, 2 landmark id out of range, 4 segment ids not
+// non-decreasing or >= n_segments
+__global__ void solver_pack_kernel(const double *__restrict__ obs, const double *__restrict__ time, const uint32_t *__restrict__ lm,
+                                   const uint32_t *__restrict__ seg, const uint32_t *__restrict__ d_n, uint64_t n_cap, uint32_t n_seg,
+                                   uint32_t n_lm, const double *__restrict__ knots, const uint32_t *__restrict__ knot_off,
+                                   const uint32_t *__restrict__ cp_off, ResRecord *__restrict__ rec, uint32_t *__restrict__ flags) {
+    const uint64_t n = d_n ? (uint64_t) *d_n : n_cap;
+    const uint64_t k = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && n > n_cap) atomicOr(flags, 8u);
+    if (k >= n || k >= n_cap) return;
+    ResRecord r;
+    r.u = obs[2 * k];
+    r.v = obs[2 * k + 1];
+    r.t = time[k];
+    r.lm = lm[k];
+    r.seg = seg ? seg[k] : 0u;
+    uint32_t f = 0;
+    if (r.seg >= n_seg) {
+        f |= 4u;
+    } else {
+        const double *kn = knots + knot_off[r.seg];
+        const uint32_t ncp = cp_off[r.seg + 1] - cp_off[r.seg];
+        if (r.t < kn[3] || r.t > kn[ncp]) f |= 1u;
+        if (k > 0) {
+            const uint32_t sp = seg ? seg[k - 1] : 0u;
+            if (sp > r.seg) f |= 4u;
+            if (sp == r.seg && r.t < time[k - 1]) f |= 1u;
+        }
+    }
+    if (r.lm >= n_lm) f |= 2u;
+    if (f) atomicOr(flags, f);
+    rec[k] = r;
+}
+
+// one thread per (segment, span): the span's residual range [a, b) — [u_span, u_span+1) by lower bounds on the time, the first
+// span from the segment's first residual, the last to its last — and how many equal chunks it is cut into (ecal_solver_create)
+__global__ void solver_span_kernel(const ResRecord *__restrict__ rec, const uint32_t *__restrict__ d_n, uint64_t n_cap, uint32_t n_seg,
+                                   const double *__restrict__ knots, const uint32_t *__restrict__ knot_off,
+                                   const uint32_t *__restrict__ cp_off, const uint32_t *__restrict__ span_off /*[n_seg + 1]*/,
+                                   uint32_t *__restrict__ span_a, uint32_t *__restrict__ span_m, uint32_t *__restrict__ span_chunks) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= span_off[n_seg]) return;
+    const uint32_t n = (uint32_t) (d_n ? (uint64_t) *d_n : n_cap);
+    uint32_t g = 0;
+    while (j >= span_off[g + 1]) g++;
+    const uint32_t ncp = cp_off[g + 1] - cp_off[g], span = 3u + (j - span_off[g]);
+    const double *kn = knots + knot_off[g];
+    // first index whose (segment, time) is not below (sg, tv)
+    auto lower = [&](uint32_t sg, double tv, bool any_time) {
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const ResRecord &r = rec[mid];
+            const bool below = r.seg < sg || (r.seg == sg && !any_time && r.t < tv);
+            if (below) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t a = span == 3u ? lower(g, 0.0, true) : lower(g, kn[span], false);
+    const uint32_t b = span == ncp - 1u ? lower(g + 1u, 0.0, true) : lower(g, kn[span + 1u], false);
+    const uint32_t m = b > a ? b - a : 0u;
+    span_a[j] = a;
+    span_m[j] = m;
+    uint32_t nch = 0;
+    if (m) {
+        const uint32_t parts = (m + NE_CHUNK - 1u) / NE_CHUNK;
+        const uint32_t per = ((m + parts - 1u) / parts + NE_T - 1u) / NE_T * NE_T;
+        nch = (m + per - 1u) / per;
+    }
+    span_chunks[j] = nch;
+}
+
+// exclusive scan of the spans' chunk counts (one workgroup), then every span writes its chunks
+__global__ __launch_bounds__(1024) void solver_chunks_kernel(uint32_t n_spans, uint32_t n_seg, const uint32_t *__restrict__ span_off,
+                                                             const uint32_t *__restrict__ span_a, const uint32_t *__restrict__ span_m,
+                                                             const uint32_t *__restrict__ span_chunks, Chunk *__restrict__ chunks,
+                                                             uint32_t chunk_cap, uint32_t *__restrict__ n_chunks_out) {
+    __shared__ uint32_t red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t j0 = 0; j0 < n_spans; j0 += 1024) {
+        const uint32_t j = j0 + threadIdx.x;
+        const uint32_t v = j < n_spans ? span_chunks[j] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) red[wave] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) pre += red[w];
+            tot += red[w];
+        }
+        if (j < n_spans && v) {
+            uint32_t at = carry + pre + inc - v, g = 0;
+            while (j >= span_off[g + 1]) g++;
+            const uint32_t m = span_m[j], a = span_a[j], parts = (m + NE_CHUNK - 1u) / NE_CHUNK;
+            const uint32_t per = ((m + parts - 1u) / parts + NE_T - 1u) / NE_T * NE_T;
+            for (uint32_t c = 0; c < m; c += per, at++)
+                if (at < chunk_cap) chunks[at] = Chunk{a + c, per < m - c ? per : m - c, g, 3u + (j - span_off[g])};
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_chunks_out = carry;
+}
+
+}  // namespace
+
+extern "C" int ecal_solver_create_dev(ecal_ctx *ctx, const ecal_spline_problem *p, const uint32_t *d_n_res, void *stream,
+                                      ecal_solver **out) {
+    if (!ctx || !p || !out) return ECAL_ERR_INVALID;
+    *out = nullptr;
+    if (p->n_segments < 1 || !p->seg_cp_off || !p->knots || !p->landmarks || (p->n_res && (!p->obs || !p->time || !p->lm_id))) {
+        ctx->last_error = "null pointer / no segment";
+        return ECAL_ERR_INVALID;
+    }
+    if (p->n_res > 0xFFFFFFFFull) return ECAL_ERR_RANGE;
+    ecal_solver *s = new (std::nothrow) ecal_solver;
+    if (!s) return ECAL_ERR_NOMEM;
+    s->ctx = ctx;
+    s->n_seg = p->n_segments;
+    s->radius = p->circle_radius;
+    s->huber_a = p->huber_a;
+    s->use_so3 = p->use_so3 != 0;
+    s->cp_off.assign(p->seg_cp_off, p->seg_cp_off + p->n_segments + 1);
+    s->n_cp = s->cp_off[p->n_segments];
+    s->knot_off.resize(p->n_segments + 1);
+    for (uint32_t g = 0; g <= p->n_segments; g++) s->knot_off[g] = s->cp_off[g] + 4 * g;
+    s->knots.assign(p->knots, p->knots + s->knot_off[p->n_segments]);
+    std::vector<uint32_t> span_off(p->n_segments + 1, 0u);
+    for (uint32_t g = 0; g < p->n_segments; g++) {
+        if (s->cp_off[g + 1] - s->cp_off[g] < 4) {
+            ctx->last_error = "a spline segment needs at least degree + 1 = 4 control points";
+            delete s;
+            return ECAL_ERR_INVALID;
+        }
+        span_off[g + 1] = span_off[g] + (s->cp_off[g + 1] - s->cp_off[g] - 3u);
+    }
+    const uint32_t n_spans = span_off[p->n_segments];
+    const size_t n_cap = p->n_res;
+    const size_t chunk_cap = n_cap / NE_CHUNK + n_spans + 1;   // a span of m residuals is cut into <= m / NE_CHUNK + 1 chunks
+    hipStream_t st = (hipStream_t) stream;
+    hipError_t e = hipSetDevice(ctx->device);
+    uint32_t *d_tmp = nullptr;   // span_off [n_seg + 1] | span_a, span_m, span_chunks [n_spans] each | flags, n_chunks
+    const size_t tmp_words = (p->n_segments + 1) + 3 * (size_t) n_spans + 4;
+    auto up = [&](void **dst, const void *src, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(dst, bytes ? bytes : 16);
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_rec, (n_cap ? n_cap : 1) * sizeof(ResRecord));
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_chunks, chunk_cap * sizeof(Chunk));
+    if (e == hipSuccess) e = hipMalloc((void **) &d_tmp, tmp_words * sizeof(uint32_t));
+    up((void **) &s->d_knots, s->knots.data(), s->knots.size() * sizeof(double));
+    up((void **) &s->d_landmarks, p->landmarks, 3 * (size_t) p->n_landmarks * sizeof(double));
+    up((void **) &s->d_knot_off, s->knot_off.data(), s->knot_off.size() * sizeof(uint32_t));
+    up((void **) &s->d_cp_off, s->cp_off.data(), s->cp_off.size() * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_params, s->n_params() * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_accum, s->n_accum() * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **) &s->d_heads, NE_REPL * ACC_HEAD * sizeof(double));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    uint32_t h[2] = {0, 0}, h_n = (uint32_t) n_cap;
+    if (e == hipSuccess) {
+        uint32_t *d_span_off = d_tmp, *d_a = d_span_off + p->n_segments + 1, *d_m = d_a + n_spans, *d_c = d_m + n_spans,
+                 *d_flags = d_c + n_spans;
+        e = hipMemcpyAsync(d_span_off, span_off.data(), span_off.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, 4 * sizeof(uint32_t), st);
+        if (e == hipSuccess && n_cap) {
+            hipLaunchKernelGGL(solver_pack_kernel, dim3((unsigned) ((n_cap + 255) / 256)), dim3(256), 0, st, p->obs, p->time, p->lm_id, p->seg_id,
+                               d_n_res, (uint64_t) n_cap, p->n_segments, p->n_landmarks, (const double *) s->d_knots,
+                               (const uint32_t *) s->d_knot_off, (const uint32_t *) s->d_cp_off, s->d_rec, d_flags);
+            hipLaunchKernelGGL(solver_span_kernel, dim3((n_spans + 255) / 256), dim3(256), 0, st, (const ResRecord *) s->d_rec, d_n_res,
+                               (uint64_t) n_cap, p->n_segments, (const double *) s->d_knots, (const uint32_t *) s->d_knot_off,
+                               (const uint32_t *) s->d_cp_off, (const uint32_t *) d_span_off, d_a, d_m, d_c);
+            hipLaunchKernelGGL(solver_chunks_kernel, dim3(1), dim3(1024), 0, st, n_spans, p->n_segments, (const uint32_t *) d_span_off,
+                               (const uint32_t *) d_a, (const uint32_t *) d_m, (const uint32_t *) d_c, s->d_chunks, (uint32_t) chunk_cap,
+                               d_flags + 1);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d_flags, sizeof(h), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && d_n_res) e = hipMemcpyAsync(&h_n, d_n_res, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);   // (the one round trip of the call: 12 bytes)
+    }
+    if (d_tmp) (void) hipFree(d_tmp);
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("ecal_solver_create_dev: ") + hipGetErrorString(e);
+        ecal_solver_destroy(s);
+        return e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
+    }
+    if (h[0] || h[1] > chunk_cap) {
+        ctx->last_error = (h[0] & 8u)   ? "more residuals than the arrays hold (*d_n_res > problem.n_res)"
+                          : (h[0] & 4u) ? "seg_id must be non-decreasing and < n_segments"
+                          : (h[0] & 2u) ? "landmark id out of range"
+                                        : "residual times must be sorted inside a segment and lie inside its knot range";
+        ecal_solver_destroy(s);
+        return (h[0] & 8u) ? ECAL_ERR_RANGE : ECAL_ERR_INVALID;
+    }
+    s->n_res = h_n;
+    s->n_chunks = h[1];
+    *out = s;
+    return ECAL_OK;
+}
+
+extern "C" uint64_t ecal_solver_num_residuals(const ecal_solver *s) { return s ? s->n_res : 0; }
+
 extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum,
                                         void *stream) {
     if (!s || !d_params || !d_accum) return ECAL_ERR_INVALID;

@@ -86,6 +86,9 @@ public:
     };
     // optional hook = cf->rectifyFeatures(outlierIdxs, Rsw, tsw) of the frame behind keyframe i (EventCalibIni.cpp:294)
     typedef std::function<bool(size_t, const FramePose &)> RectifyFn;
+    // the same for ALL keyframes at once, called once after the PnP (rectifyFeatures of a frame depends on its own pose only,
+    // not on which frames were accepted before it): ok[f] = its return value for keyframe f (ecal_rectify_keyframes)
+    typedef std::function<void(const std::vector<FramePose> &, const std::vector<char> &pnp_ok, std::vector<char> &ok)> BatchRectifyFn;
 
     EventCalibIni(CalibrationSetting::Ptr setting, double motionTimeStep)
         : calibrationSetting_(std::move(setting)), motionTimeStep_(motionTimeStep) {}
@@ -114,7 +117,7 @@ public:
     }
 
     bool cvCalibration(const std::vector<KeyFrame> &keyframes, double width, double height, Result &res,
-                       const RectifyFn &rectify = RectifyFn()) {
+                       const RectifyFn &rectify = RectifyFn(), const BatchRectifyFn &batchRectify = BatchRectifyFn()) {
         res = Result();
         auto &cs = *calibrationSetting_;
         const int frameNum = (int) keyframes.size();
@@ -168,7 +171,6 @@ public:
                             inl.data(), nullptr, okf.data());
         if (rc != ECAL_OK) throw std::runtime_error(std::string("ecal_pnp_batch: ") + ecal_last_error(ctx));
         res.poses.resize(frameNum);
-        long last = -1;
         for (int f = 0; f < frameNum; f++) {
             FramePose &fp = res.poses[f];
             rodrigues(&pose[6 * (size_t) f], fp.Rsw);
@@ -176,6 +178,17 @@ public:
             for (int k = 0; k < 3; k++) fp.twb[k] = -(fp.Rsw[k] * fp.tsw[0] + fp.Rsw[3 + k] * fp.tsw[1] + fp.Rsw[6 + k] * fp.tsw[2]);
             for (uint32_t i = 0; i < n; i++)
                 if (!inl[(size_t) f * n + i]) fp.outlierIdxs.push_back((int) i);
+        }
+        std::vector<char> batch_ok;
+        if (batchRectify) {
+            std::vector<char> pnp_ok(frameNum);
+            for (int f = 0; f < frameNum; f++) pnp_ok[f] = okf[f] ? 1 : 0;
+            batch_ok.assign(frameNum, 0);
+            batchRectify(res.poses, pnp_ok, batch_ok);
+        }
+        long last = -1;
+        for (int f = 0; f < frameNum; f++) {
+            FramePose &fp = res.poses[f];
             if (!okf[f]) {
                 res.discardedByCheckPose++;
                 continue;
@@ -184,7 +197,7 @@ public:
                 res.discardedByCheckPose++;
                 continue;
             }
-            if (rectify && !rectify((size_t) f, fp)) {
+            if (batchRectify ? !batch_ok[f] : (rectify && !rectify((size_t) f, fp))) {
                 res.discardedByRectify++;
                 continue;
             }

@@ -179,22 +179,6 @@ private:
             kf_time[f] = frames_[f].timeStamp;
             std::copy(frames_[f].circles.begin(), frames_[f].circles.end(), kf_circ.begin() + (size_t) f * n_circ * 3);
         }
-        std::vector<double> obs, tm, o1(2 * (size_t) n_events), t1(n_events);
-        std::vector<uint32_t> lm, seg, l1(n_events);
-        for (size_t i = 0; i < segments_.size(); i++) {  // :158-192, one association pass per spline
-            uint64_t cnt = 0;
-            const int rc = ecal_associate(ctx, es, kf_time.data(), kf_circ.data(), F, n_circ, time2splineIdx_[i].first,
-                                          time2splineIdx_[i].second, 5 * motionTimeStep_, 5.0, n_events, o1.data(), t1.data(),
-                                          l1.data(), &cnt);
-            if (rc != ECAL_OK) throw std::runtime_error(std::string("ecal_associate: ") + ecal_last_error(ctx));
-            obs.insert(obs.end(), o1.begin(), o1.begin() + 2 * cnt);
-            tm.insert(tm.end(), t1.begin(), t1.begin() + cnt);
-            lm.insert(lm.end(), l1.begin(), l1.begin() + cnt);
-            seg.insert(seg.end(), cnt, (uint32_t) i);
-        }
-        eventContainer_->release();  // eventContainer_->container.clear() (:194)
-        summary_.residuals = tm.size();
-        if (tm.empty()) return false;
         std::vector<std::array<double, 3>> corners;
         std::vector<double> landmarks;
         for (int i = 0; i < pattern_->rows; i++)
@@ -207,19 +191,34 @@ private:
         prob.n_segments = (uint32_t) segments_.size();
         prob.seg_cp_off = segCpOff_.data();
         prob.knots = knots_.data();
-        prob.n_res = tm.size();
-        prob.obs = obs.data();
-        prob.time = tm.data();
-        prob.lm_id = lm.data();
-        prob.seg_id = seg.data();
+        prob.n_res = 0;          // the residual arrays are made on the device (below)
+        prob.obs = nullptr;
+        prob.time = nullptr;
+        prob.lm_id = nullptr;
+        prob.seg_id = nullptr;
         prob.n_landmarks = n_circ;
         prob.landmarks = landmarks.data();
         prob.circle_radius = circleRadius_;
         prob.huber_a = 0.2 * circleRadius_;  // :205
         prob.use_so3 = useSO3_ ? 1 : 0;
+        // :158-192 — every event of every spline's range against its nearest keyframe's circles, and the Ceres problem's
+        // residual blocks added where they are found (:181-235): one pass over the resident stream, the records stay in HBM
+        std::vector<double> ranges;
+        for (size_t i = 0; i < segments_.size(); i++) {
+            ranges.push_back(time2splineIdx_[i].first);
+            ranges.push_back(time2splineIdx_[i].second);
+        }
         ecal_solver *solver = nullptr;
-        int rc = ecal_solver_create(ctx, &prob, &solver);
-        if (rc != ECAL_OK) throw std::runtime_error(std::string("ecal_solver_create: ") + ecal_last_error(ctx));
+        int rc = ecal_solver_create_from_stream(ctx, es, kf_time.data(), kf_circ.data(), F, n_circ, ranges.data(), (uint32_t) segments_.size(),
+                                                5 * motionTimeStep_, 5.0, &prob, &solver);
+        if (rc != ECAL_OK) throw std::runtime_error(std::string("ecal_solver_create_from_stream: ") + ecal_last_error(ctx));
+        (void) n_events;
+        eventContainer_->release();  // eventContainer_->container.clear() (:194)
+        summary_.residuals = ecal_solver_num_residuals(solver);
+        if (summary_.residuals == 0) {
+            ecal_solver_destroy(solver);
+            return false;
+        }
         std::vector<double> x(ecal_solver_param_size(solver));
         std::copy(intrinsics_, intrinsics_ + 9, x.begin());
         std::copy(cpQ_.begin(), cpQ_.end(), x.begin() + 9);

@@ -421,6 +421,14 @@ int ecal_rectify_batch(ecal_ctx *ctx, const double *xy /*[n_points][2]*/, const 
                        const double *pose /*[F][12]*/, uint32_t F, const double *landmarks, const ecal_rectify_params *prm,
                        double *feat_xyr, uint32_t *feat_valid, uint32_t *frame_info);
 
+/* rectifyFeatures for F keyframes named by their time windows over a resident ecal_stream (durations [F][2]; what the batched
+ * path of host/event_calib_ini.hpp calls after solvePnPRansac, EventCalibIni.cpp:281-302): the EventFrame constructor and
+ * extractFeatures up to the kept clusters run for every window on the device, then ecal_rectify_batch_dev — only the poses go
+ * up and the rectified circles (feat_xyr [F][rows*cols][3], feat_valid, frame_info [F][2], layouts as above) come back. */
+int ecal_rectify_keyframes(ecal_ctx *ctx, const ecal_stream *es, const double *durations /*[F][2]*/, uint32_t F,
+                           const ecal_detect_params *detect_prm, const double *poses /*[F][12]*/, const double *landmarks,
+                           const ecal_rectify_params *prm, double *feat_xyr, uint32_t *feat_valid, uint32_t *frame_info);
+
 /* ---- event -> residual association ----------------------------------------------------------------
  * Replaces the association loop of EventCalibSpline::optimize (event_camera_calib/src/EventCalibSpline.cpp:
  * 140-192) and CirclesEventFrame::findCenter (include/opengv2/event_camera_calib/CirclesEventFrame.hpp:50-65):
@@ -434,6 +442,15 @@ int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events
                        const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, double t_min, double t_max,
                        double max_dt, double edge_tol, double *d_obs, double *d_time, uint32_t *d_lm_id,
                        uint32_t *d_count, void *stream);
+
+/* The same for ALL spline segments of a calibration in one pass over the stream: d_ranges [R][2] = (t_min, t_max) of segment r
+ * (ascending, disjoint: EventCalibSpline.cpp:318-345 cuts the keyframes at gaps); an event inside range r that passes the two
+ * gates becomes a residual of segment r: d_seg_id[j] = r.  Outputs in event order = sorted by (segment, time), which is what
+ * ecal_solver_create[_dev] takes; *d_count stays on the device (ecal_solver_create_dev reads it there). */
+int ecal_associate_ranges_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
+                              const double *d_kf_circles, uint32_t n_keyframes, uint32_t n_circles, const double *d_ranges,
+                              uint32_t n_ranges, double max_dt, double edge_tol, double *d_obs, double *d_time, uint32_t *d_lm_id,
+                              uint32_t *d_seg_id, uint32_t *d_count, void *stream);
 
 /* host-buffer form: events from an ecal_stream (resident in HBM), keyframe tables and results in host memory;
  * obs/time/lm_id need room for `capacity` records, *count = records found (ECAL_ERR_RANGE if more than capacity) */
@@ -528,6 +545,21 @@ typedef struct ecal_lm_summary {
     double seconds_linear_solve; /* banded-arrow Cholesky + model change on the host, summed */
 } ecal_lm_summary;
 int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *problem, ecal_solver **out);
+/* The problem built in place (EventCalibSpline.cpp:181-235 adds the residual blocks where the association finds them):
+ * problem->obs / time / lm_id / seg_id are DEVICE pointers — the outputs of ecal_associate_ranges_dev, consumed when the call
+ * returns —, problem->n_res their capacity and *d_n_res (device; NULL: n_res itself) the number of residuals; the other members
+ * (seg_cp_off, knots, landmarks) stay host pointers.  Records and chunk table are made by kernels on `stream`; one 12-byte
+ * read-back.  Same solver object, same checks (ECAL_ERR_INVALID) as ecal_solver_create. */
+int ecal_solver_create_dev(ecal_ctx *ctx, const ecal_spline_problem *problem, const uint32_t *d_n_res, void *stream,
+                           ecal_solver **out);
+uint64_t ecal_solver_num_residuals(const ecal_solver *s);
+/* Host-pointer convenience of the two (what host/event_calib_spline.hpp calls): the association of every spline segment over a
+ * resident ecal_stream + the solver built on the result, the residual arrays never leaving HBM.  kf_time / kf_circles / ranges
+ * [n_ranges][2] are host tables (ecal_associate_ranges_dev's arguments); layout = the problem without its residual arrays (obs,
+ * time, lm_id, seg_id, n_res ignored); n_ranges must equal layout->n_segments.  ecal_solver_num_residuals says how many were found. */
+int ecal_solver_create_from_stream(ecal_ctx *ctx, const ecal_stream *es, const double *kf_time, const double *kf_circles,
+                                   uint32_t n_keyframes, uint32_t n_circles, const double *ranges, uint32_t n_ranges, double max_dt,
+                                   double edge_tol, const ecal_spline_problem *layout, ecal_solver **out);
 void ecal_solver_destroy(ecal_solver *s);
 size_t ecal_solver_param_size(const ecal_solver *s);
 size_t ecal_solver_normal_size(const ecal_solver *s);

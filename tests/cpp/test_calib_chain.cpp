@@ -1,14 +1,26 @@
 // The reference driver's main (event_camera_calib/test/eventCameraCalib.cpp:99-233) on the C++ shims:
 // stream -> container -> keyframe search -> EventCalibIni::cvCalibration (+ rectifyFeatures per keyframe) ->
 // EventCalibSpline -> TrajectoryByEvent.txt.  Built and run by tests/test_gpu_shims.py.
-//   usage: test_calib_chain settings.yaml events.bin saveDir      (the reference's argv, eventCameraCalib.cpp:105-110)
+//   usage: test_calib_chain settings.yaml events.bin saveDir [batch]     (the reference's argv, eventCameraCalib.cpp:105-110)
+// "batch": rectifyFeatures of all keyframes in one device pass (ecal_rectify_keyframes) instead of one CirclesEventFrame per
+// keyframe, the file read in one piece, and a "stage <name> <seconds>" line per stage of the chain (bench.py's end_to_end leg).
+#include <chrono>
 #include <cstdio>
 
 #include "../../eventcalib_amd/csrc/host/event_calib_spline.hpp"
 
 int main(int argc, char **argv) {
     using namespace opengv2;
-    if (argc != 4) {
+    const bool batch = argc == 5 && std::string(argv[4]) == "batch";
+    double t_mark = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto stage = [&](const char *name) {
+        const double t = now();
+        if (batch) std::printf("stage %s %.6f\n", name, t - t_mark);
+        t_mark = t;
+    };
+    t_mark = now();
+    if (argc != 4 && !batch) {
         std::fprintf(stderr, "Usage: test_calib_chain settingFilePath binFilePath SavePath\n");
         return 1;
     }
@@ -27,12 +39,31 @@ int main(int argc, char **argv) {
     int width = fsSettings["Camera.width"], height = fsSettings["Camera.height"];   // :141-142
     container->cameraSize[0] = width;
     container->cameraSize[1] = height;
+    if (batch) {   // the same records, read in one piece (the loop below costs ~20 ns per event)
+        es.close();
+        std::ifstream is(argv[2], std::ios::binary | std::ios::ate);
+        const size_t bytes = (size_t) is.tellg() / 25 * 25;
+        is.seekg(0);
+        container->records.resize(bytes);
+        is.read((char *) container->records.data(), (std::streamsize) bytes);
+        size_t lo = 0, hi = bytes / 25;
+        auto tt = [&](size_t i) { double t; std::memcpy(&t, &container->records[25 * i], 8); return t; };
+        while (lo < hi && tt(lo) < startTime) lo++;
+        if (customEnd) while (hi > lo && tt(hi - 1) >= endTimeSetting) hi--;
+        if (lo || hi != bytes / 25) {
+            container->records.erase(container->records.begin() + 25 * hi, container->records.end());
+            container->records.erase(container->records.begin(), container->records.begin() + 25 * lo);
+        }
+    }
     while (!es.isEnd()) {                                    // :154-163
         if (customEnd && es.current().timeStamp() >= endTimeSetting) break;
         if (es.current().timeStamp() >= startTime) container->emplace(es.current());
         es.next();
     }
     es.close();
+    stage("load_file");
+    (void) container->device();                              // the one upload (the reference fills its multimap here)
+    stage("upload");
     const double endTime = container->lastTime();            // :165
     const int frameEventNumThreshold = fsSettings["FrameEventNumThreshold"];   // :168
     auto pattern = cs->circlePatternParameters;
@@ -41,6 +72,7 @@ int main(int argc, char **argv) {
     fsSettings["PieceNum"] >> pieceNum;                      //  of the build's own-piece gate depends on it, so the test pins it)
     std::vector<KeyFrame> kfs = detect_keyframes_device(*container, pattern, fp, step, frameEventNumThreshold, pieceNum, startTime, endTime);
     std::printf("keyframes %zu\n", kfs.size());
+    stage("keyframe_search");
     EventCalibIni ini(cs, step);
     EventCalibIni::Result res;
     std::vector<EventCalibSpline::Frame> frames;
@@ -58,7 +90,68 @@ int main(int argc, char **argv) {
         frames.push_back(EventCalibSpline::makeFrame(kfs[f].timeStamp, p, cf.features(), cf.featureLandmark(), n_circ));
         return true;
     };
-    if (!ini.cvCalibration(kfs, container->cameraSize[0], container->cameraSize[1], res, rectify)) return 1;
+    // ... or for all keyframes at once, on the device
+    std::vector<double> rect_feat;
+    std::vector<uint32_t> rect_valid;
+    auto rectify_all = [&](const std::vector<EventCalibIni::FramePose> &poses, const std::vector<char> &pnp_ok, std::vector<char> &ok) {
+        const uint32_t F = (uint32_t) kfs.size();
+        std::vector<double> dur(2 * (size_t) F), pose(12 * (size_t) F), lm(3 * n_circ);
+        for (uint32_t f = 0; f < F; f++) {
+            dur[2 * f] = kfs[f].duration.first;
+            dur[2 * f + 1] = kfs[f].duration.second;
+            for (int i = 0; i < 9; i++) pose[12 * (size_t) f + i] = poses[f].Rsw[i];
+            for (int i = 0; i < 3; i++) pose[12 * (size_t) f + 9 + i] = poses[f].tsw[i];
+        }
+        for (int i = 0; i < pattern->rows; i++)
+            for (int j = 0; j < pattern->cols; j++) {
+                double *o = &lm[3 * (size_t) (i * pattern->cols + j)];
+                o[0] = (float) ((pattern->isAsymmetric ? (2 * j + i % 2) : j) * pattern->squareSize);
+                o[1] = (float) (i * pattern->squareSize);
+                o[2] = 0;
+            }
+        CirclesEventFrame probe(container, kfs[0].duration, pattern, fp);
+        ecal_detect_params dp;
+        dp.dbscan_eps = fp.dbscan_eps;
+        dp.dbscan_min_samples = (uint32_t) fp.dbscan_startMinSample;
+        dp.cluster_min_sample = (uint32_t) fp.clusterMinSample;
+        dp.need_clusters = (uint32_t) n_circ;
+        dp.circle_radius_threshold = probe.circleRadiusThreshold();
+        dp.fit_circle = fp.fitCircle ? 1 : 0;
+        dp.knn_num = (uint32_t) fp.knn_num;
+        dp.rows = (uint32_t) pattern->rows;
+        dp.cols = (uint32_t) pattern->cols;
+        ecal_rectify_params rp;
+        rp.fx = res.K[0], rp.fy = res.K[1], rp.cx = res.K[2], rp.cy = res.K[3];
+        for (int i = 0; i < 5; i++) rp.dist[i] = res.distCoeffs[i];
+        rp.width = container->cameraSize[0], rp.height = container->cameraSize[1];
+        rp.rows = (uint32_t) pattern->rows, rp.cols = (uint32_t) pattern->cols;
+        rp.asymmetric = pattern->isAsymmetric ? 1 : 0;
+        rp.circle_radius = pattern->circleRadius;
+        rp.fit_circle = fp.fitCircle ? 1 : 0;
+        rect_feat.resize(3 * n_circ * (size_t) F);
+        rect_valid.resize(n_circ * (size_t) F);
+        std::vector<uint32_t> info(2 * (size_t) F);
+        const int rc = ecal_rectify_keyframes(ecal_host::thread_ctx(), container->device(), dur.data(), F, &dp, pose.data(), lm.data(), &rp,
+                                              rect_feat.data(), rect_valid.data(), info.data());
+        if (rc != ECAL_OK) throw std::runtime_error(std::string("ecal_rectify_keyframes: ") + ecal_last_error(ecal_host::thread_ctx()));
+        for (uint32_t f = 0; f < F; f++) ok[f] = pnp_ok[f] && info[2 * f] != 0;
+    };
+    if (!ini.cvCalibration(kfs, container->cameraSize[0], container->cameraSize[1], res, batch ? EventCalibIni::RectifyFn() : rectify,
+                           batch ? EventCalibIni::BatchRectifyFn(rectify_all) : EventCalibIni::BatchRectifyFn()))
+        return 1;
+    if (batch)   // the accepted keyframes' frames from the batch's arrays
+        for (size_t f : res.acceptedFrames) {
+            std::vector<CirclesEventFrame::CalibCircle> feats;
+            std::vector<int> lmk;
+            for (size_t k = 0; k < n_circ; k++)
+                if (rect_valid[f * n_circ + k]) {
+                    const double *p = &rect_feat[3 * (f * n_circ + k)];
+                    feats.push_back(CirclesEventFrame::CalibCircle{Vector2d{{p[0], p[1]}}, p[2]});
+                    lmk.push_back((int) k);
+                }
+            frames.push_back(EventCalibSpline::makeFrame(kfs[f].timeStamp, res.poses[f], feats, lmk, n_circ));
+        }
+    stage("init_calibration_pnp_rectify");
     std::printf("init K %.9g %.9g %.9g %.9g rms %.6g accepted %zu checkPose %d rectify %d\n", res.K[0], res.K[1], res.K[2], res.K[3],
                 res.rms, res.acceptedFrames.size(), res.discardedByCheckPose, res.discardedByRectify);
     const double dist5[5] = {res.distCoeffs[0], res.distCoeffs[1], res.distCoeffs[2], res.distCoeffs[3], res.distCoeffs[4]};
@@ -68,6 +161,8 @@ int main(int argc, char **argv) {
     const double *x = spline.intrinsics();
     std::printf("refined %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g residuals %zu iterations %d splines %zu\n", x[0], x[1], x[2], x[3],
                 x[4], x[5], x[6], x[7], x[8], spline.summary().residuals, spline.summary().iterations, spline.splineNum());
+    stage("spline_fit_association_lm");
     spline.saveKeyFrameTrajectoryTUM(std::string(argv[3]) + "/TrajectoryByEvent.txt");   // :212
+    stage("save_trajectory");
     return 0;
 }

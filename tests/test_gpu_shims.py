@@ -153,3 +153,14 @@ def test_cpp_driver_chain(tmp_path):
     traj = np.loadtxt(str(tmp_path / "TrajectoryByEvent.txt"))
     assert traj.shape[1] == 8 and len(traj) == len(py["trajectory"])
     assert np.abs(traj - py["trajectory"]).max() < 1e-3
+    # "batch": rectifyFeatures of all keyframes in one device pass (ecal_rectify_keyframes), the file read in one piece —
+    # the same chain, the same numbers, plus a time per stage (what bench.py's end_to_end leg runs at 50 M events)
+    out2 = subprocess.run([exe, yamlf, binf, str(tmp_path), "batch"], capture_output=True, text=True, timeout=600)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    l2 = [l for l in out2.stdout.splitlines() if not l.startswith("stage ")]
+    assert l2[0] == lines[0] and l2[1] == lines[1]                 # keyframes, init calibration + accepted / discarded counts
+    ref2 = [float(v) for v in l2[2].split()[1:10]]
+    assert np.abs(np.array(ref2) - np.array(ref)).max() < 1e-9 * 400 and l2[2].split()[10:] == lines[2].split()[10:]
+    stages = dict(l.split()[1:3] for l in out2.stdout.splitlines() if l.startswith("stage "))
+    assert set(stages) == {"load_file", "upload", "keyframe_search", "init_calibration_pnp_rectify", "spline_fit_association_lm",
+                           "save_trajectory"}
