@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 src = os.path.join(ROOT, "eventcalib_amd", "csrc")
 out = "/tmp/libecal_prof.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                       "-DECAL_PHASE_PROF", "-shared", "-o", out] + sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith(".hip")))
+                       "-DECAL_PHASE_PROF", "-shared", "-o", out] + os.environ.get("ECAL_PROF_FLAGS", "").split() + ["-L/opt/rocm/lib", "-lrccl"] + sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith(".hip")))
 import numpy as np, torch
 import eventcalib_amd.capi as capi
 capi.lib_path = lambda: out
