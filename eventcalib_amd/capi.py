@@ -374,7 +374,8 @@ class _SplineProblem(ctypes.Structure):
                 ("n_res", ctypes.c_uint64), ("obs", ctypes.c_void_p), ("time", ctypes.c_void_p),
                 ("lm_id", ctypes.c_void_p), ("seg_id", ctypes.c_void_p), ("n_landmarks", ctypes.c_uint32),
                 ("landmarks", ctypes.c_void_p), ("circle_radius", ctypes.c_double), ("huber_a", ctypes.c_double),
-                ("use_so3", ctypes.c_int)]
+                ("use_so3", ctypes.c_int), ("camera_model", ctypes.c_int)]
+CAMERA_RADIAL, CAMERA_FISHEYE = 0, 1
 
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
@@ -438,7 +439,7 @@ class Solver:
     """ecal_solver: residual records + spline layout resident on the GPU.
 
     problem: dict with seg_cp_off [G+1] u32, knots f64, obs [M,2], time [M], lm_id [M] u32,
-    seg_id [M] u32 or None, landmarks [L,3], circle_radius, huber_a, use_so3 (optional, default False).
+    seg_id [M] u32 or None, landmarks [L,3], circle_radius, huber_a, use_so3 / fisheye (optional, default False).
     Parameter vector layout: [intr 9 | q n_cp x 4 (xyzw) | t n_cp x 3]."""
 
     def __init__(self, ctx: Context, problem, device_arrays=None, stream=0):
@@ -473,6 +474,7 @@ class Solver:
         P.circle_radius = float(problem["circle_radius"])
         P.huber_a = float(problem["huber_a"])
         P.use_so3 = int(bool(problem.get("use_so3", False)))
+        P.camera_model = CAMERA_FISHEYE if problem.get("fisheye", False) else CAMERA_RADIAL
         h = ctypes.c_void_p()
         if device_arrays is None:
             ctx._check(L.ecal_solver_create(ctx._h, ctypes.byref(P), ctypes.byref(h)))

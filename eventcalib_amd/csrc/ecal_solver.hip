@@ -107,7 +107,7 @@ __device__ __forceinline__ void ne_fma36(double (&acc)[36], const ne_v2d (&A)[3]
 }
 
 // WITH_JAC = false: cost only (no rows, no LDS, no tiles) — its own, small instantiation (69 VGPRs against 233)
-template <bool SO3, bool WITH_JAC>
+template <bool SO3, bool WITH_JAC, bool FISHEYE = false>
 __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResRecord *__restrict__ rec,
                                                          const Chunk *__restrict__ chunks,
                                                          const double *__restrict__ knots,
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             in.ifx = ifx;
             in.ify = ify;
             spline_basis_inv(kn, ch.span, binv, e.t, in.b);
-            r = SO3 ? spline_residual_so3(in, pin, q, t, with_jac ? J : nullptr)
-                    : spline_residual(in, pin, q, t, with_jac ? J : nullptr);
+            r = SO3 ? spline_residual_so3<FISHEYE>(in, pin, q, t, with_jac ? J : nullptr)
+                    : spline_residual<FISHEYE>(in, pin, q, t, with_jac ? J : nullptr);
             double hr;
             sc = huber_scale(r, huber_a, &hr);
             cost += hr;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
 // 3, 3, 3, 3> and the local parameterisations): per residual its raw value (no loss function) and the raw 1 x 33 row of the
 // tangent-space Jacobian, columns [ intrinsics 9 | rotation tangent of control points cp0 .. cp0+3 (3 each) | translation of
 // cp0 .. cp0+3 (3 each) ].  One thread per residual, chunks as in normal_eq_kernel.
-template <bool SO3>
+template <bool SO3, bool FISHEYE = false>
 __global__ __launch_bounds__(NE_T) void residual_rows_kernel(const ResRecord *__restrict__ rec, const Chunk *__restrict__ chunks,
                                                             const double *__restrict__ knots, const uint32_t *__restrict__ knot_off,
                                                             const uint32_t *__restrict__ cp_off, const double *__restrict__ params,
@@ -363,7 +363,8 @@ __global__ __launch_bounds__(NE_T) void residual_rows_kernel(const ResRecord *__
         in.ify = ify;
         spline_basis_inv(kn, ch.span, binv, e.t, in.b);
         double J[RES_NJ];
-        const double r = SO3 ? spline_residual_so3(in, pin, q, t, J_out ? J : nullptr) : spline_residual(in, pin, q, t, J_out ? J : nullptr);
+        const double r = SO3 ? spline_residual_so3<FISHEYE>(in, pin, q, t, J_out ? J : nullptr)
+                             : spline_residual<FISHEYE>(in, pin, q, t, J_out ? J : nullptr);
         r_out[at] = r;
         if (J_out)
             for (int i = 0; i < RES_NJ; i++) J_out[at * RES_NJ + i] = J[i];
@@ -390,6 +391,7 @@ struct ecal_solver {
     uint32_t n_cp = 0, n_seg = 0, n_chunks = 0;
     double radius = 0, huber_a = 0;
     bool use_so3 = false;  // cumulative SO3 spline + LocalParameterizationSO3 instead of the quaternion spline
+    bool fisheye = false;  // camera_model == ECAL_CAMERA_FISHEYE
     std::vector<uint32_t> cp_off, knot_off;
     std::vector<double> knots;
     ResRecord *d_rec = nullptr;
@@ -429,6 +431,7 @@ extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, e
     s->radius = p->circle_radius;
     s->huber_a = p->huber_a;
     s->use_so3 = p->use_so3 != 0;
+    s->fisheye = p->camera_model == ECAL_CAMERA_FISHEYE;
     s->cp_off.assign(p->seg_cp_off, p->seg_cp_off + p->n_segments + 1);
     s->n_cp = s->cp_off[p->n_segments];
     s->knot_off.resize(p->n_segments + 1);
@@ -515,6 +518,12 @@ extern "C" int ecal_solver_create(ecal_ctx *ctx, const ecal_spline_problem *p, e
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<false, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
     if (e != hipSuccess) {
         ctx->last_error = std::string("ecal_solver_create: ") + hipGetErrorString(e);
@@ -660,6 +669,7 @@ extern "C" int ecal_solver_create_dev(ecal_ctx *ctx, const ecal_spline_problem *
     s->radius = p->circle_radius;
     s->huber_a = p->huber_a;
     s->use_so3 = p->use_so3 != 0;
+    s->fisheye = p->camera_model == ECAL_CAMERA_FISHEYE;
     s->cp_off.assign(p->seg_cp_off, p->seg_cp_off + p->n_segments + 1);
     s->n_cp = s->cp_off[p->n_segments];
     s->knot_off.resize(p->n_segments + 1);
@@ -701,6 +711,12 @@ extern "C" int ecal_solver_create_dev(ecal_ctx *ctx, const ecal_spline_problem *
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<false, true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_kernel<true, true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int) (NE_T * NE_LD * sizeof(double)));
     uint32_t h[2] = {0, 0}, h_n = (uint32_t) n_cap;
     if (e == hipSuccess) {
@@ -756,14 +772,20 @@ extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, 
     ECAL_HIP_TRY(ctx, hipMemsetAsync(s->d_heads, 0, NE_REPL * ACC_HEAD * sizeof(double), st));
     if (s->n_chunks) {
         const size_t lds = with_jacobian ? NE_T * NE_LD * sizeof(double) : 0;
-#define ECAL_NE_LAUNCH(SO3_, JAC_)                                                                                          \
-    hipLaunchKernelGGL((normal_eq_kernel<SO3_, JAC_>), dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks, s->d_knots, \
+#define ECAL_NE_LAUNCH(SO3_, JAC_, FISH_)                                                                                          \
+    hipLaunchKernelGGL((normal_eq_kernel<SO3_, JAC_, FISH_>), dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks, s->d_knots, \
                        s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads)
+#define ECAL_NE_LAUNCH2(SO3_, JAC_)                                       \
+    do {                                                                  \
+        if (s->fisheye) ECAL_NE_LAUNCH(SO3_, JAC_, true);                 \
+        else ECAL_NE_LAUNCH(SO3_, JAC_, false);                           \
+    } while (0)
         if (s->use_so3) {
-            if (with_jacobian) ECAL_NE_LAUNCH(true, true); else ECAL_NE_LAUNCH(true, false);
+            if (with_jacobian) ECAL_NE_LAUNCH2(true, true); else ECAL_NE_LAUNCH2(true, false);
         } else {
-            if (with_jacobian) ECAL_NE_LAUNCH(false, true); else ECAL_NE_LAUNCH(false, false);
+            if (with_jacobian) ECAL_NE_LAUNCH2(false, true); else ECAL_NE_LAUNCH2(false, false);
         }
+#undef ECAL_NE_LAUNCH2
 #undef ECAL_NE_LAUNCH
         hipLaunchKernelGGL(reduce_heads_kernel, dim3(1), dim3(128), 0, st, s->d_heads, d_accum,
                            with_jacobian ? (uint32_t) ACC_HEAD : 1u);
@@ -778,12 +800,15 @@ extern "C" int ecal_residuals_dev(ecal_solver *s, const double *d_params, double
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
     if (s->n_chunks) {
-        if (s->use_so3)
-            hipLaunchKernelGGL(residual_rows_kernel<true>, dim3(s->n_chunks), dim3(NE_T), 0, st, s->d_rec, s->d_chunks, s->d_knots,
-                               s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, d_r, d_J, d_cp0);
-        else
-            hipLaunchKernelGGL(residual_rows_kernel<false>, dim3(s->n_chunks), dim3(NE_T), 0, st, s->d_rec, s->d_chunks, s->d_knots,
-                               s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, d_r, d_J, d_cp0);
+#define ECAL_RR_LAUNCH(SO3_, FISH_)                                                                                                  \
+    hipLaunchKernelGGL((residual_rows_kernel<SO3_, FISH_>), dim3(s->n_chunks), dim3(NE_T), 0, st, s->d_rec, s->d_chunks, s->d_knots, \
+                       s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, d_r, d_J, d_cp0)
+        if (s->use_so3) {
+            if (s->fisheye) ECAL_RR_LAUNCH(true, true); else ECAL_RR_LAUNCH(true, false);
+        } else {
+            if (s->fisheye) ECAL_RR_LAUNCH(false, true); else ECAL_RR_LAUNCH(false, false);
+        }
+#undef ECAL_RR_LAUNCH
         ECAL_HIP_TRY(ctx, hipGetLastError());
     }
     return ECAL_OK;

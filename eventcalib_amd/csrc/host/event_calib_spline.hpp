@@ -75,9 +75,10 @@ public:
     }
 
     EventCalibSpline(std::vector<Frame> frames, EventContainer::Ptr eventContainer, CirclePatternParameters::Ptr pattern, bool useSO3,
-                     double motionTimeStep, const double K[4], const double distCoeffs[5], int maxIterations = 50)
+                     double motionTimeStep, const double K[4], const double distCoeffs[5], int maxIterations = 50,
+                     bool fisheye = false)
         : frames_(std::move(frames)), eventContainer_(std::move(eventContainer)), pattern_(std::move(pattern)), useSO3_(useSO3),
-          motionTimeStep_(motionTimeStep), circleRadius_(pattern_->circleRadius), maxIterations_(maxIterations) {
+          fisheye_(fisheye), motionTimeStep_(motionTimeStep), circleRadius_(pattern_->circleRadius), maxIterations_(maxIterations) {
         if (frames_.size() <= 10) throw std::logic_error("too few frames in the map.");  // :26-28
         std::sort(frames_.begin(), frames_.end(), [](const Frame &a, const Frame &b) { return a.timeStamp < b.timeStamp; });
         reduceMap();
@@ -116,8 +117,9 @@ public:
             cpT_.insert(cpT_.end(), ct.begin(), ct.end());
             segCpOff_.push_back(segCpOff_.back() + (uint32_t) cpNum);
         }
-        // intrinsics (:93-105): only radial distortion
-        const double radial[4] = {distCoeffs[0], distCoeffs[1], distCoeffs[4], 0.0};
+        // intrinsics (:93-105): only radial distortion (the reference throws for anything else, :97-99).  fisheye (new, BASELINE
+        // configs[4]): distCoeffs = cv::fisheye's k1..k4, reverted by the same series into the solver's inverse polynomial
+        const double radial[4] = {distCoeffs[0], distCoeffs[1], fisheye_ ? distCoeffs[2] : distCoeffs[4], fisheye_ ? distCoeffs[3] : 0.0};
         double inv[5];
         ecal_inverse_radial_distortion(radial, inv);
         for (int k = 0; k < 4; k++) intrinsics_[k] = K[k];
@@ -201,6 +203,7 @@ private:
         prob.circle_radius = circleRadius_;
         prob.huber_a = 0.2 * circleRadius_;  // :205
         prob.use_so3 = useSO3_ ? 1 : 0;
+        prob.camera_model = fisheye_ ? ECAL_CAMERA_FISHEYE : ECAL_CAMERA_RADIAL;
         // :158-192 — every event of every spline's range against its nearest keyframe's circles, and the Ceres problem's
         // residual blocks added where they are found (:181-235): one pass over the resident stream, the records stay in HBM
         std::vector<double> ranges;
@@ -259,7 +262,7 @@ private:
     std::vector<Frame> frames_;
     EventContainer::Ptr eventContainer_;
     CirclePatternParameters::Ptr pattern_;
-    bool useSO3_;
+    bool useSO3_, fisheye_;
     double motionTimeStep_, circleRadius_;
     int maxIterations_;
     std::vector<std::vector<size_t>> segments_;             // sampleIdSets_

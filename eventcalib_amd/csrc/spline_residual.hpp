@@ -10,6 +10,12 @@
 //   x = (u-cx)/fx, y = (v-cy)/fy, r2 = x^2+y^2, c = 1 + k1 r2 + .. + k5 r2^5, p = (x c, y c, 1);
 //   Y = R(q) p, Xw = T - T_z * Y / Y_z   (ray / plane z = 0 intersection: depth = -T_z / (R3 . p));
 //   res = |Xw - lm| - Rc.
+// FISHEYE (BASELINE configs[4]; new functionality — the reference's solver takes the radial model only,
+// EventCalibSpline.cpp:97-99): the Kannala-Brandt camera in the SAME inverse form, so that the nine intrinsics keep their
+// slots and PinholeCamera::inverseRadialDistortion (a plain series reversion) initialises them from the forward
+// coefficients of cv::fisheye::calibrate: with r = sqrt(x^2 + y^2) the DISTORTED angle theta_d of the pixel,
+//   theta = r (1 + k1 r^2 + .. + k5 r^10)   (the inverse polynomial),   p = (x, y, 0) tan(theta) / r + (0, 0, 1),
+// i.e. c = tan(theta) / r takes the place of the radial factor; everything behind p is shared.
 // The Jacobian row has 33 entries in tangent space:
 //   [0..8]   intrinsics fx fy cx cy k1..k5
 //   [9+3j..] rotation control point j (j = 0..3): delta of  q_j <- exp(delta) (x) q_j
@@ -96,6 +102,7 @@ struct ResidualInput {
 
 // Shared tail of both rotation parameterisations: residual for the unit quaternion (ux,uy,uz,w) and translation T;
 // when J != nullptr fills J[0..8] (intrinsics), gq = d res / d (unit quaternion, ambient xyzw) and gT = d res / d T.
+template <bool FISHEYE = false>
 ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double ux, double uy, double uz, double w,
                              const double T[3], double *J, double gq[4], double gT[3]) {
     const double cx = intr[2], cy = intr[3];
@@ -104,7 +111,15 @@ ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double
     // undistorted ray
     const double x = (in.u - cx) * ifx, y = (in.v - cy) * ify;
     const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
-    const double c = 1.0 + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    const double poly = 1.0 + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    double c = poly, sec2 = 1.0;   // sec2 = d c / d poly
+    if (FISHEYE) {
+        if (r2 > 1e-16) {
+            const double r = sqrt(r2), tn = tan(r * poly);
+            sec2 = 1.0 + tn * tn;
+            c = tn / r;
+        }   // (r -> 0: tan(r poly) / r -> poly, sec^2 -> 1)
+    }
     const double px = x * c, py = y * c, pz = 1.0;
     // Y = p + 2 w (u x p) + 2 (u (u.p) - p (u.u))
     const double cxp0 = uy * pz - uz * py, cxp1 = uz * px - ux * pz, cxp2 = ux * py - uy * px;  // u x p
@@ -135,14 +150,18 @@ ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double
     const double gp0 = gY0 - 2 * w * cxg0 + 2 * (ux * udg - gY0 * udu);
     const double gp1 = gY1 - 2 * w * cxg1 + 2 * (uy * udg - gY1 * udu);
     // intrinsics
-    const double cp = intr[4] + 2 * intr[5] * r2 + 3 * intr[6] * r4 + 4 * intr[7] * r6 + 5 * intr[8] * r8;  // dc/dr2
+    double cp = intr[4] + 2 * intr[5] * r2 + 3 * intr[6] * r4 + 4 * intr[7] * r6 + 5 * intr[8] * r8;  // d poly / d r2
+    if (FISHEYE) {
+        // c = tan(r poly) / r:  dc/dr2 = (sec^2 (poly / 2 + r2 poly') - c / 2) / r2  ->  poly' + poly^3 / 3 at r = 0
+        cp = r2 > 1e-8 ? (sec2 * (0.5 * poly + r2 * cp) - 0.5 * c) / r2 : cp + poly * poly * poly * (1.0 / 3.0);
+    }
     const double gx = gp0 * (c + 2 * x * x * cp) + gp1 * (2 * x * y * cp);
     const double gy = gp0 * (2 * x * y * cp) + gp1 * (c + 2 * y * y * cp);
     J[0] = -gx * x * ifx;
     J[1] = -gy * y * ify;
     J[2] = -gx * ifx;
     J[3] = -gy * ify;
-    const double gk = gp0 * x + gp1 * y;
+    const double gk = (gp0 * x + gp1 * y) * sec2;   // d c / d k_i = sec^2 r2^i (pinhole: sec2 = 1)
     J[4] = gk * r2;
     J[5] = gk * r4;
     J[6] = gk * r6;
@@ -160,6 +179,7 @@ ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double
 
 // intr[9]; q[4][4] rotation control points (x y z w); t[4][3] translation control points.
 // Returns the residual; if J != nullptr fills the 33 tangent-space partials.
+template <bool FISHEYE = false>
 ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, const double (*q)[4], const double (*t)[3],
                                double *J) {
     // pose at the event time
@@ -172,7 +192,7 @@ ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, cons
     const double ivn = 1.0 / vn;
     const double ux = vq[0] * ivn, uy = vq[1] * ivn, uz = vq[2] * ivn, w = vq[3] * ivn;
     double gq[4], gT[3];
-    const double res = residual_core(in, intr, ux, uy, uz, w, T, J, gq, gT);
+    const double res = residual_core<FISHEYE>(in, intr, ux, uy, uz, w, T, J, gq, gT);
     if (!J) return res;
     // through the normalisation q = v / |v|
     const double qdg = ux * gq[0] + uy * gq[1] + uz * gq[2] + w * gq[3];
@@ -305,6 +325,7 @@ ECAL_HD void so3_exp(const double phi[3], double q[4]) {
 
 // q[4][4]: SO3 control points as unit quaternions (x y z w); in.b = the four N values (the cumulative basis is
 // formed here).  J layout as spline_residual, rotation columns = delta of r_cp_j <- r_cp_j * exp(delta).
+template <bool FISHEYE = false>
 ECAL_HD double spline_residual_so3(const ResidualInput &in, const double *intr, const double (*q)[4],
                                    const double (*t)[3], double *J) {
     double beta[3];
@@ -325,7 +346,7 @@ ECAL_HD double spline_residual_so3(const ResidualInput &in, const double *intr, 
     for (int j = 0; j < 4; j++)
         for (int k = 0; k < 3; k++) T[k] += in.b[j] * t[j][k];
     double gq[4], gT[3];
-    const double res = residual_core(in, intr, Q[0], Q[1], Q[2], Q[3], T, J, gq, gT);
+    const double res = residual_core<FISHEYE>(in, intr, Q[0], Q[1], Q[2], Q[3], T, J, gq, gT);
     if (!J) return res;
     // g_w: R <- R Exp(omega) is Q <- Q (x) (omega/2, 1)
     double v[3], m[3], a[3], n[3];

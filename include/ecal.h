@@ -497,7 +497,15 @@ typedef struct ecal_spline_problem {
     int use_so3;                /* useSO3 (eventCameraCalib.cpp:204-208): 0 = quaternion spline + EigenQuaternion-
                                    Parameterization; 1 = cumulative SO3 spline (CalibReprojectionError_SO3,
                                    EventCalibSpline.hpp:65-135) + LocalParameterizationSO3 (q <- q * exp(delta)) */
+    int camera_model;           /* ECAL_CAMERA_RADIAL (the reference's unDistort, EventCalibSpline.hpp:36-63: k1..k5 = the
+                                   inverse radial polynomial) or ECAL_CAMERA_FISHEYE (BASELINE configs[4], new: the reference's
+                                   solver refuses anything else, EventCalibSpline.cpp:97-99): Kannala-Brandt in the same inverse
+                                   form — theta = theta_d (1 + k1 theta_d^2 + .. + k5 theta_d^10) with theta_d = |((u-cx)/fx,
+                                   (v-cy)/fy)|, ray = (x, y) tan(theta) / theta_d; k1..k5 are initialised from cv::fisheye's
+                                   forward k1..k4 by the same series reversion (ecal_inverse_radial_distortion) */
 } ecal_spline_problem;
+#define ECAL_CAMERA_RADIAL 0
+#define ECAL_CAMERA_FISHEYE 1
 /* ---- multi-GPU: one process per GPU, one RCCL communicator per context ---------------------------------------
  * The reference has no distributed backend; north_star shards calibration views and spline residuals one batch per GPU
  * and sums the per-view / per-rank normal-equation blocks with an RCCL all-reduce over xGMI.  Rank 0 calls

@@ -54,14 +54,27 @@ inline double atan_(double x) { return std::atan(x); }
 inline Jet sin_(const Jet &x) { Jet r; r.a = std::sin(x.a); const double c = std::cos(x.a); for (int i = 0; i < NP; i++) r.v[i] = c * x.v[i]; return r; }
 inline Jet cos_(const Jet &x) { Jet r; r.a = std::cos(x.a); const double s = -std::sin(x.a); for (int i = 0; i < NP; i++) r.v[i] = s * x.v[i]; return r; }
 inline Jet atan_(const Jet &x) { Jet r; r.a = std::atan(x.a); const double d = 1.0 / (1.0 + x.a * x.a); for (int i = 0; i < NP; i++) r.v[i] = d * x.v[i]; return r; }
+inline double tan_(double x) { return std::tan(x); }
+inline Jet tan_(const Jet &x) { Jet r; r.a = std::tan(x.a); const double d = 1.0 + r.a * r.a; for (int i = 0; i < NP; i++) r.v[i] = d * x.v[i]; return r; }
 inline double val(double x) { return x; }
 inline double val(const Jet &x) { return x.a; }
 
 // EventCalibSpline.hpp:158-229 with T = double or Jet.  Quaternion rotation of a vector follows
 // Eigen's QuaternionBase::_transformVector (v + w*2(u x v) + u x 2(u x v)).
+// The fisheye camera of BASELINE configs[4] — NEW functionality, no reference counterpart (the reference's solver throws for
+// anything but the radial model, EventCalibSpline.cpp:97-99): Kannala-Brandt in the inverse form of unDistort — the pixel's
+// distorted angle theta_d = r goes to the ray angle theta = r * poly(r^2) (the same five coefficients), and the ray's x, y
+// are scaled by tan(theta) / r instead of by poly.  Written as unDistort is, over T; sqrt has no derivative at r = 0 (the
+// product's code takes the limit there; the tests stay away from the exact centre).
+template <typename T>
+T fisheye_scale(const T &r2, const T &poly) {
+    const T r = sqrt_(r2);
+    return tan_(r * poly) / r;
+}
+
 template <typename T>
 T residual_functor(const T *intr, const T (*rq)[4], const T (*tp)[3], const double *rb, const double *tb,
-                   const double obs[2], const double lm[3], double radius) {
+                   const double obs[2], const double lm[3], double radius, bool fisheye = false) {
     T q[4], t[3];
     for (int k = 0; k < 4; k++) q[k] = T(rb[0]) * rq[0][k] + T(rb[1]) * rq[1][k] + T(rb[2]) * rq[2][k] + T(rb[3]) * rq[3][k];
     const T nrm = sqrt_(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);  // Qwb_v.normalize()
@@ -74,7 +87,8 @@ T residual_functor(const T *intr, const T (*rq)[4], const T (*tp)[3], const doub
     Xc[2] = T(1.0);
     const T xx = Xc[0] * Xc[0], yy = Xc[1] * Xc[1];
     const T r2 = xx + yy, r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
-    const T coeff = T(1.0) + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    T coeff = T(1.0) + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    if (fisheye) coeff = fisheye_scale(r2, coeff);
     Xc[0] *= coeff;
     Xc[1] *= coeff;
     // :213-224
@@ -147,7 +161,7 @@ void so3_log(const T q[4], T w[3]) {
 
 template <typename T>
 T residual_functor_so3(const T *intr, const T (*rq)[4], const T (*tp)[3], const double *rb, const double *tb,
-                       const double obs[2], const double lm[3], double radius) {
+                       const double obs[2], const double lm[3], double radius, bool fisheye = false) {
     // :103-108  Qwb = r_cp0 * prod_j exp(beta_j log(r_cp{j-1}^-1 r_cp{j}));  rb = cumulative basis (3 values)
     T Q[4] = {rq[0][0], rq[0][1], rq[0][2], rq[0][3]};
     for (int j = 1; j <= 3; j++) {
@@ -169,7 +183,8 @@ T residual_functor_so3(const T *intr, const T (*rq)[4], const T (*tp)[3], const 
     Xc[2] = T(1.0);
     const T r2 = Xc[0] * Xc[0] + Xc[1] * Xc[1];
     const T r4 = r2 * r2, r6 = r4 * r2, r8 = r6 * r2, r10 = r8 * r2;
-    const T coeff = T(1.0) + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    T coeff = T(1.0) + intr[4] * r2 + intr[5] * r4 + intr[6] * r6 + intr[7] * r8 + intr[8] * r10;
+    if (fisheye) coeff = fisheye_scale(r2, coeff);
     Xc[0] *= coeff;
     Xc[1] *= coeff;
     const T tx = T(2.0) * Q[0], ty = T(2.0) * Q[1], tz = T(2.0) * Q[2];
@@ -226,15 +241,21 @@ void oracle_basis(const double *knots, uint32_t span, double u, double *b4) {
 // residual and its Jacobian: J37 = ambient partials [intr 9 | q0..q3 (4 each) | t0..t3 (3 each)] as
 // Ceres' autodiff would return them; J33 = after EigenQuaternionParameterization (tangent space)
 // [intr 9 | delta_0..delta_3 (3 each) | t0..t3].  Either may be NULL.
+double oracle_residual_cam(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                           const double *obs2, const double *lm3, double radius, double *J37, double *J33, int fisheye);
 double oracle_residual(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
                        const double *obs2, const double *lm3, double radius, double *J37, double *J33) {
+    return oracle_residual_cam(intr, q4x4, t4x3, basis4, obs2, lm3, radius, J37, J33, 0);
+}
+double oracle_residual_cam(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                           const double *obs2, const double *lm3, double radius, double *J37, double *J33, int fisheye) {
     Jet ji[9], jq[4][4], jt[4][3];
     for (int i = 0; i < 9; i++) ji[i] = Jet::var(intr[i], i);
     for (int j = 0; j < 4; j++) {
         for (int k = 0; k < 4; k++) jq[j][k] = Jet::var(q4x4[4 * j + k], 9 + 4 * j + k);
         for (int k = 0; k < 3; k++) jt[j][k] = Jet::var(t4x3[3 * j + k], 25 + 3 * j + k);
     }
-    const Jet r = residual_functor<Jet>(ji, jq, jt, basis4, basis4, obs2, lm3, radius);
+    const Jet r = residual_functor<Jet>(ji, jq, jt, basis4, basis4, obs2, lm3, radius, fisheye != 0);
     if (J37) for (int i = 0; i < NP; i++) J37[i] = r.v[i];
     if (J33) {
         for (int i = 0; i < 9; i++) J33[i] = r.v[i];
@@ -256,8 +277,14 @@ double oracle_residual(const double *intr, const double *q4x4, const double *t4x
 // (core/spline/src/BsplineSO3.cpp:88-94) is formed here.  J33 = ambient partials times
 // Sophus::SO3::Dx_this_mul_exp_x_at_0 (LocalParameterizationSO3::ComputeJacobian, BsplineSO3.hpp:209-216):
 // the tangent of  r_cp <- r_cp * exp(delta).
+double oracle_residual_so3_cam(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                               const double *obs2, const double *lm3, double radius, double *J37, double *J33, int fisheye);
 double oracle_residual_so3(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
                            const double *obs2, const double *lm3, double radius, double *J37, double *J33) {
+    return oracle_residual_so3_cam(intr, q4x4, t4x3, basis4, obs2, lm3, radius, J37, J33, 0);
+}
+double oracle_residual_so3_cam(const double *intr, const double *q4x4, const double *t4x3, const double *basis4,
+                               const double *obs2, const double *lm3, double radius, double *J37, double *J33, int fisheye) {
     double beta[3];
     beta[2] = basis4[3];
     beta[1] = beta[2] + basis4[2];
@@ -268,7 +295,7 @@ double oracle_residual_so3(const double *intr, const double *q4x4, const double 
         for (int k = 0; k < 4; k++) jq[j][k] = Jet::var(q4x4[4 * j + k], 9 + 4 * j + k);
         for (int k = 0; k < 3; k++) jt[j][k] = Jet::var(t4x3[3 * j + k], 25 + 3 * j + k);
     }
-    const Jet r = residual_functor_so3<Jet>(ji, jq, jt, beta, basis4, obs2, lm3, radius);
+    const Jet r = residual_functor_so3<Jet>(ji, jq, jt, beta, basis4, obs2, lm3, radius, fisheye != 0);
     if (J37) for (int i = 0; i < NP; i++) J37[i] = r.v[i];
     if (J33) {
         for (int i = 0; i < 9; i++) J33[i] = r.v[i];
@@ -335,9 +362,10 @@ double oracle_evaluate_mode(const double *intr, uint32_t n_cp, const double *q, 
         double b[4], J[33];
         oracle_basis(knots, span, u, b);
         const uint32_t c0 = span - 3;
-        double r = (use_so3 ? oracle_residual_so3 : oracle_residual)(intr, q + 4 * (size_t) c0, t + 3 * (size_t) c0, b,
-                                                                     obs + 2 * m, landmarks + 3 * (size_t) lm_id[m],
-                                                                     radius, nullptr, (g || H) ? J : nullptr);
+        // (use_so3: bit 0 = the SO3 spline, bit 1 = the fisheye camera)
+        double r = ((use_so3 & 1) ? oracle_residual_so3_cam : oracle_residual_cam)(intr, q + 4 * (size_t) c0, t + 3 * (size_t) c0, b,
+                                                                                   obs + 2 * m, landmarks + 3 * (size_t) lm_id[m], radius,
+                                                                                   nullptr, (g || H) ? J : nullptr, (use_so3 >> 1) & 1);
         // HuberLoss + Corrector
         const double s = r * r, a2 = huber_a * huber_a;
         double rho, scale;

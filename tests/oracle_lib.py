@@ -308,7 +308,8 @@ def solver_evaluate(problem, x, want_H=True):
     H = np.zeros((n, n)) if want_H else None
     cost = L.oracle_evaluate_mode(_p(intr, _dp), n_cp, _p(q, _dp), _p(t, _dp), _p(kn, _dp), tm.shape[0], _p(obs, _dp),
                                   _p(tm, _dp), _p(lm, _u32p), _p(lms, _dp), float(problem["circle_radius"]),
-                                  float(problem["huber_a"]), int(bool(problem.get("use_so3", False))), _p(g, _dp),
+                                  float(problem["huber_a"]),
+                                  int(bool(problem.get("use_so3", False))) | (2 if problem.get("fisheye", False) else 0), _p(g, _dp),
                                   _p(H, _dp) if want_H else None)
     return cost, g, H
 

@@ -264,3 +264,82 @@ def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
             yy = np.linalg.solve(As + np.diag(D), -gg * scale)
             assert np.abs(devd - yy * scale).max() <= 1e-7 * np.abs(yy * scale).max()
     s.close()
+
+
+# ---- the fisheye camera of BASELINE configs[4] (new functionality: the reference's solver refuses anything but the radial
+# model, EventCalibSpline.cpp:97-99; parity = the oracle's dual numbers through the restated Kannala-Brandt functor) ----
+@pytest.mark.parametrize("use_so3,n_res,n_cp", [(False, 3000, 9), (True, 2000, 6), (False, 40000, 4)])
+def test_fisheye_normal_equations_match_oracle(ctx, use_so3, n_res, n_cp):
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(n_res + 7)
+    prob, x = SV.make_problem(n_res, n_cp=n_cp, seed=n_res + 7, pixel_noise=0.5, use_so3=use_so3, fisheye=True)
+    y = SV.perturb(x, n_cp, rng, intr_rel=0.01, rot=0.005, trans=0.2)
+    s = Solver(ctx, prob)
+    cost, g, H = _dense(s.evaluate(y, True), n_cp)
+    oc, og, oH = O.solver_evaluate(prob, y)
+    assert abs(cost - oc) <= 1e-11 * abs(oc)
+    assert np.abs(g - og).max() <= 1e-9 * np.abs(og).max()
+    assert np.abs(H - oH).max() <= 1e-9 * np.abs(oH).max()
+    assert abs(s.evaluate(y, False)[0] - oc) <= 1e-11 * abs(oc)
+    # a different function from the radial model on the same numbers
+    rc = O.solver_evaluate(dict(prob, fisheye=False), y, want_H=False)[0]
+    assert abs(rc - oc) > 1e-6 * abs(oc)
+    s.close()
+
+
+@pytest.mark.parametrize("use_so3", [False, True])
+def test_fisheye_lm_recovers_ground_truth(ctx, use_so3):
+    from eventcalib_amd.capi import Solver
+    rng = np.random.default_rng(15)
+    n_cp = 8
+    prob, x_gt = SV.make_problem(4000, n_cp=n_cp, seed=15, use_so3=use_so3, fisheye=True)
+    x0 = SV.perturb(x_gt, n_cp, rng)
+    s = Solver(ctx, prob)
+    x, summ = s.solve(x0)
+    assert summ.termination == 0 and summ.final_cost < 1e-12 * summ.initial_cost + 1e-16
+    assert np.abs(x[:4] / x_gt[:4] - 1).max() < 1e-6                 # fx fy cx cy
+    assert np.abs(x[4:9] - x_gt[4:9]).max() < 1e-4                   # the inverse polynomial (the high orders are weakly observed)
+    xr, hist, it = ref_lm.solve(prob, x0)                            # the same minimum as the Python restatement of the LM loop
+    assert np.abs(x[:9] - xr[:9]).max() <= 1e-6 * np.abs(xr[:9]).max()
+    s.close()
+
+
+def test_fisheye_rows_match_dual_numbers(ctx):
+    import ctypes
+    from eventcalib_amd.capi import Solver
+    L = O.lib()
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.oracle_find_span.argtypes = [dp, ctypes.c_uint32, ctypes.c_double]
+    L.oracle_find_span.restype = ctypes.c_uint32
+    L.oracle_basis.argtypes = [dp, ctypes.c_uint32, ctypes.c_double, dp]
+    fn = L.oracle_residual_cam
+    fn.argtypes = [dp, dp, dp, dp, dp, dp, ctypes.c_double, dp, dp, ctypes.c_int]
+    fn.restype = ctypes.c_double
+    n_res, n_cp = 1500, 7
+    rng = np.random.default_rng(92)
+    prob, x = SV.make_problem(n_res, n_cp=n_cp, seed=92, pixel_noise=0.5, fisheye=True)
+    y = SV.perturb(x, n_cp, rng, intr_rel=0.01, rot=0.005, trans=0.2)
+    s = Solver(ctx, prob)
+    r, J, cp0 = s.residuals(y)
+    intr = np.ascontiguousarray(y[:9])
+    q = np.ascontiguousarray(y[9:9 + 4 * n_cp]).reshape(n_cp, 4)
+    t = np.ascontiguousarray(y[9 + 4 * n_cp:]).reshape(n_cp, 3)
+    kn = np.ascontiguousarray(prob["knots"], np.float64)
+    lms = np.ascontiguousarray(prob["landmarks"], np.float64).reshape(-1, 3)
+    p = lambda a: a.ctypes.data_as(dp)
+    worst_r = worst_j = 0.0
+    for k in range(0, n_res, 2):
+        u = float(prob["time"][k])
+        span = L.oracle_find_span(p(kn), n_cp, u)
+        b4 = np.zeros(4)
+        L.oracle_basis(p(kn), span, u, p(b4))
+        q4 = np.ascontiguousarray(q[span - 3:span + 1]).copy()
+        t4 = np.ascontiguousarray(t[span - 3:span + 1]).copy()
+        obs = np.ascontiguousarray(prob["obs"][k], np.float64).copy()
+        lm = lms[int(prob["lm_id"][k])].copy()
+        J33 = np.zeros(33)
+        rr = fn(p(intr), p(q4), p(t4), p(b4), p(obs), p(lm), float(prob["circle_radius"]), None, p(J33), 1)
+        worst_r = max(worst_r, abs(r[k] - rr))
+        worst_j = max(worst_j, np.abs(J[k] - J33).max() / max(1.0, np.abs(J33).max()))
+    assert worst_r < 1e-11 and worst_j < 1e-10, (worst_r, worst_j)
+    s.close()
