@@ -415,7 +415,31 @@ def e2e_leg(args, ctx, dev, torch, np):
     wall = time.perf_counter() - t0
     sp = r["spline"]
     cpp = cpp_chain(ev, n, rate, t_start, pieces, np) if not os.environ.get("ECAL_BENCH_NO_CPP_CHAIN") else None
-    return {"cpp_chain": cpp, "events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
+    # configs[4]'s camera through the same chain: Kannala-Brandt stream, fisheye init calibration / PnP / rectify / spline residual
+    del ev
+    SS.TRAJECTORY, SS.CAMERA = "orbit", "fisheye"
+    try:
+        evf = SS.make_stream(n, rate=rate, t_start=t_start, device=dev, seed=21)
+    finally:
+        SS.TRAJECTORY, SS.CAMERA = "hover", "pinhole"
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    rf = calibrate_stream(ctx, evf, t_start, t_start + (n - 1) / rate, piece_num=pieces, fisheye=True)
+    wall_f = time.perf_counter() - t0
+    del evf
+    bf = rf["intrinsics"][4:9]
+    th = np.linspace(0.02, 0.30, 40)
+    thd = th * (1 + SS.KB[0] * th ** 2 + SS.KB[1] * th ** 4 + SS.KB[2] * th ** 6 + SS.KB[3] * th ** 8)
+    back = thd * (1 + bf[0] * thd ** 2 + bf[1] * thd ** 4 + bf[2] * thd ** 6 + bf[3] * thd ** 8 + bf[4] * thd ** 10)
+    fish = {"events": n, "keyframes": rf["keyframes"], "residuals_from_association": rf["spline"]["residuals"],
+            "lm_iterations": rf["spline"]["iterations"], "init_fx_rel_err": float(abs(rf["init"]["intr"][0] / SS.FX - 1)),
+            "refined_fx_rel_err": float(abs(rf["intrinsics"][0] / SS.FX - 1)),
+            "refined_cx_err_px": float(abs(rf["intrinsics"][2] - (SS.CX - 0.5))),
+            "angle_map_max_err_rad_within_0.3rad": float(np.abs(back - th).max()), "wall_seconds_whole_chain": round(wall_f, 3),
+            "stage_seconds": {k: round(v, 4) for k, v in rf["stage_seconds"].items()},
+            "note": "Kannala-Brandt stream (k = 0.05, -0.01, 0.002, 0); fisheye model in the init calibration (started from the radial "
+                    "model's focal length), PnP, rectifyFeatures' projections and the spline residual (new functionality)"}
+    return {"cpp_chain": cpp, "fisheye": fish, "events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
             "residuals_from_association": sp["residuals"], "unknowns": sp["unknowns"], "splines": sp["splines"],
             "lm_iterations": sp["iterations"], "lm_seconds": round(sp["seconds"], 4),
             "lm_iterations_per_s": round(sp["iterations"] / max(sp["seconds"], 1e-9), 2),
@@ -625,7 +649,11 @@ def ingest_leg(args, ctx, dev, world, rank, dist, torch, np, rate):
     n = args.ingest_events // world                 # this rank's time range
     t_begin = 5.0 + rank * (n / rate)
     host = torch.empty(n * 25, dtype=torch.uint8, pin_memory=True)
-    host.copy_(SS.make_stream(n, rate=rate, t_start=t_begin, seed=4242 + rank, device=dev))
+    SS.CAMERA = "fisheye"       # configs[4]: the fisheye lens (Kannala-Brandt k = 0.05, -0.01, 0.002, 0: SURVEY 8d)
+    try:
+        host.copy_(SS.make_stream(n, rate=rate, t_start=t_begin, seed=4242 + rank, device=dev))
+    finally:
+        SS.CAMERA = "pinhole"
     torch.cuda.synchronize(dev)
     S = int(np.floor((n - 1) / rate / 1.5e-3)) + 1
     res = {}
@@ -647,7 +675,7 @@ def ingest_leg(args, ctx, dev, world, rank, dist, torch, np, rate):
     return {"metric": "Mevents/s including the PCIe upload", "value": round(total / e2 / 1e6, 1), "unit": "Mevents/s", "events": total,
             "events_per_gpu": n, "windows_per_gpu": S, "chunks_per_gpu": c2, "seconds": round(e2, 4), "grids_found_rank0": f2,
             "single_chunk_seconds": round(e1, 4), "single_chunk_Mevents_per_s": round(total / e1 / 1e6, 1),
-            "pcie_floor_seconds_at_57GBs": round(n * 25 / 57e9, 4),
+            "pcie_floor_seconds_at_57GBs": round(n * 25 / 57e9, 4), "camera": "fisheye (Kannala-Brandt k = 0.05, -0.01, 0.002, 0)",
             "note": "stages: window bounds + slicing + DBSCAN + candidates + grid ordering per chunk of 2048 windows; the copy of "
                     "chunk k+1 overlaps the kernels of chunk k; never part of `value`"}
 

@@ -22,6 +22,8 @@ from .pipeline import DetectPipeline
 
 EXAMPLE_FLAGS = (capi.CALIB_FIX_ASPECT_RATIO | capi.CALIB_FIX_PRINCIPAL_POINT | capi.CALIB_ZERO_TANGENT_DIST |
                  capi.CALIB_FIX_K4 | capi.CALIB_FIX_K5 | capi.CALIB_FIX_K6)       # parameters.hpp:47-58 on example.yaml
+# Calibrate_UseFisheyeModel: 1 on the same file — the fisheye enum overwrites the flags (parameters.hpp:59-68)
+EXAMPLE_FLAGS_FISHEYE = (capi.CALIB_FIX_SKEW | capi.CALIB_RECOMPUTE_EXTRINSIC | capi.CALIB_FIX_K4 | capi.CALIB_FIX_PRINCIPAL_POINT)
 
 
 def board_points(rows=9, cols=4, square=5.5, asymmetric=True):
@@ -78,9 +80,16 @@ def check_pose(R_ref, twb_ref, t_ref, R_cur, twb_cur, t_cur, step):
 
 def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, frame_event_num_threshold=4000, piece_num=30,
                      frames_to_use=200, width=346.0, height=260.0, rows=9, cols=4, square=5.5, circle_radius=1.75,
-                     flags=EXAMPLE_FLAGS, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2, gate_mode=0):
+                     flags=None, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2, gate_mode=0,
+                     fisheye=False):
     """events: uint8 CUDA tensor of packed 25-byte records.  Returns a dict with the initial calibration, the refined
-    intrinsics [fx fy cx cy k1..k5 (inverse radial polynomial)] and the keyframe trajectory."""
+    intrinsics [fx fy cx cy k1..k5 (inverse radial polynomial)] and the keyframe trajectory.
+    fisheye (Calibrate_UseFisheyeModel: 1; BASELINE configs[4]): cv::fisheye::calibrate's model in the init stage
+    (EventCalibIni.cpp:186-190), and — new: the reference stops at EventCalibSpline.cpp:97-99 — the Kannala-Brandt camera in
+    the PnP, in rectifyFeatures' projections and in the spline solve (k1..k5 = the inverse angle polynomial)."""
+    if flags is None:
+        flags = EXAMPLE_FLAGS_FISHEYE if fisheye else EXAMPLE_FLAGS
+    model = 1 if fisheye else 0
     import time as _time
     dev = events.device
     st = torch.cuda.current_stream(dev).cuda_stream
@@ -111,7 +120,17 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     sel = np.arange(use) * sel_step
     obj = board_points(rows, cols, square)
     feat32 = kf["features"][:, :, :2].astype(np.float32).astype(np.float64)
-    ini = capi.calibrate_views(ctx, obj, feat32[sel], width, height, 0, flags, aspect_ratio)
+    guess = None
+    if fisheye:
+        # cv::fisheye::calibrate starts from f = max(w, h) / pi, the focal length of a lens that fills the sensor with ~180
+        # degrees; a lens far from that (this one: 55 degrees) puts the first extrinsics' undistortion outside its domain and
+        # the iteration fails.  The radial model's calibration of the same views gives the start instead
+        # (CALIB_USE_INTRINSIC_GUESS, as a user of cv::fisheye::calibrate would)
+        pin = capi.calibrate_views(ctx, obj, feat32[sel], width, height, 0, EXAMPLE_FLAGS, aspect_ratio)["intr"]
+        guess = np.zeros(12)
+        guess[:4] = pin[:4]
+        flags |= capi.CALIB_USE_INTRINSIC_GUESS
+    ini = capi.calibrate_views(ctx, obj, feat32[sel], width, height, model, flags, aspect_ratio, intr_guess=guess)
     intr0 = ini["intr"]
     out["init"] = {"intr": intr0, "rms": ini["rms"], "iterations": ini["iterations"], "views": use}
     mark("init_calibration")
@@ -122,7 +141,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     d_pose = torch.empty(K, 6, dtype=torch.float64, device=dev)
     d_inl = torch.empty(K, n_circ, dtype=torch.int32, device=dev)
     d_ok = torch.empty(K, dtype=torch.int32, device=dev)
-    capi.pnp_batch_dev(ctx, d_obj.data_ptr(), n_circ, d_img.data_ptr(), None, K, 0, d_intr.data_ptr(), 4.0, 3, 0, d_pose.data_ptr(),
+    capi.pnp_batch_dev(ctx, d_obj.data_ptr(), n_circ, d_img.data_ptr(), None, K, model, d_intr.data_ptr(), 4.0, 3, 0, d_pose.data_ptr(),
                        d_inl.data_ptr(), None, d_ok.data_ptr(), st)
     pose = d_pose.cpu().numpy()
     ok = d_ok.cpu().numpy().astype(bool)
@@ -136,7 +155,8 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     prm = capi.RectifyParams()
     prm.fx, prm.fy, prm.cx, prm.cy = intr0[:4]
     for i in range(5):
-        prm.dist[i] = intr0[4 + i]                         # k1 k2 p1 p2 k3
+        prm.dist[i] = (intr0[5 + i] if i < 4 else 0.0) if fisheye else intr0[4 + i]   # k1 k2 p1 p2 k3 | fisheye: k1..k4 (slot 4 = alpha)
+    prm.model = model
     prm.width, prm.height, prm.rows, prm.cols, prm.asymmetric = width, height, rows, cols, 1
     prm.circle_radius, prm.fit_circle = circle_radius, int(pipe.det[3])
     d_frames = torch.arange(K, dtype=torch.int32, device=dev)
@@ -224,11 +244,11 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
                              d_c.data_ptr(), st)
     mark("association")
     # intrinsics: K + the inverse radial polynomial of (k1, k2, k3) (:93-105)
-    b5 = capi.inverse_radial_distortion([intr0[4], intr0[5], intr0[8], 0.0])
+    b5 = capi.inverse_radial_distortion([intr0[5], intr0[6], intr0[7], intr0[8]] if fisheye else [intr0[4], intr0[5], intr0[8], 0.0])
     x0 = np.concatenate([intr0[:4], b5, np.concatenate(cq).ravel(), np.concatenate(ct).ravel()])
     prob = dict(seg_cp_off=np.array(seg_cp_off, np.uint32), knots=np.concatenate(knots),
                 landmarks=board_points(rows, cols, square).astype(np.float64), circle_radius=circle_radius,
-                huber_a=0.2 * circle_radius, use_so3=bool(use_so3))
+                huber_a=0.2 * circle_radius, use_so3=bool(use_so3), fisheye=bool(fisheye))
     solver = capi.Solver(ctx, prob, device_arrays=(d_o.data_ptr(), d_t.data_ptr(), d_l.data_ptr(), d_s.data_ptr(), n_events,
                                                    d_c.data_ptr()), stream=st)
     n_res = solver.n_res

@@ -33,7 +33,7 @@ class RectifyParams(ctypes.Structure):
     _fields_ = [("fx", ctypes.c_double), ("fy", ctypes.c_double), ("cx", ctypes.c_double), ("cy", ctypes.c_double),
                 ("dist", ctypes.c_double * 5), ("width", ctypes.c_double), ("height", ctypes.c_double),
                 ("rows", ctypes.c_uint32), ("cols", ctypes.c_uint32), ("asymmetric", ctypes.c_int),
-                ("circle_radius", ctypes.c_double), ("fit_circle", ctypes.c_int)]
+                ("circle_radius", ctypes.c_double), ("fit_circle", ctypes.c_int), ("model", ctypes.c_int)]
 
 
 class EcalError(RuntimeError):
@@ -595,6 +595,7 @@ CALIB_FIX_ASPECT_RATIO, CALIB_FIX_PRINCIPAL_POINT, CALIB_ZERO_TANGENT_DIST = 1 <
 CALIB_FIX_K1, CALIB_FIX_K2, CALIB_FIX_K3, CALIB_FIX_K4, CALIB_FIX_K5, CALIB_FIX_K6 = (1 << 3, 1 << 4, 1 << 5, 1 << 6,
                                                                                       1 << 7, 1 << 8)
 CALIB_FIX_SKEW, CALIB_RECOMPUTE_EXTRINSIC = 1 << 9, 1 << 10
+CALIB_USE_INTRINSIC_GUESS = 1 << 11
 CALIB_BLOCK_DOUBLES = 272
 
 
@@ -624,8 +625,9 @@ def _declare_calib(L):
 
 
 def calibrate_views(ctx: Context, obj, img, width, height, model=0, flags=0, aspect_ratio=1.0, max_iter=0, eps=0.0,
-                    allreduce=None):
-    """ecal_calibrate_views: obj [n][3], img [V][n][2] (this rank's views).  Returns a dict."""
+                    allreduce=None, intr_guess=None):
+    """ecal_calibrate_views: obj [n][3], img [V][n][2] (this rank's views).  Returns a dict.  intr_guess [12] goes with
+    CALIB_USE_INTRINSIC_GUESS in flags."""
     L = ctx._L
     _declare_calib(L)
     obj = np.ascontiguousarray(obj, np.float64)
@@ -640,6 +642,9 @@ def calibrate_views(ctx: Context, obj, img, width, height, model=0, flags=0, asp
         else:
             opt.allreduce = allreduce
     res = CalibResult()
+    if intr_guess is not None:
+        for j, v in enumerate(np.asarray(intr_guess, np.float64)[:12]):
+            res.intr[j] = float(v)
     rv, tv, pe = np.zeros((V, 3)), np.zeros((V, 3)), np.zeros(V)
     ctx._check(L.ecal_calibrate_views(ctx._h, _ptr(obj), obj.shape[0], _ptr(img) if V else None, V, float(width), float(height),
                                       ctypes.byref(opt), ctypes.byref(res), _ptr(rv) if V else None, _ptr(tv) if V else None,

@@ -953,7 +953,15 @@ extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n
     double intr[CB_NI];
     for (int j = 0; j < CB_NI; j++) intr[j] = 0;
     std::vector<uint32_t> okv(Va);
-    if (opt->model == 0) {
+    if (opt->flags & ECAL_CALIB_USE_INTRINSIC_GUESS) {
+        // cv::CALIB_USE_INTRINSIC_GUESS / cv::fisheye::CALIB_USE_INTRINSIC_GUESS: the caller's res->intr is the start
+        for (int j = 0; j < CB_NI; j++) intr[j] = res->intr[j];
+        if (!(intr[0] > 0) || !(intr[1] > 0) || !std::isfinite(intr[2]) || !std::isfinite(intr[3])) {
+            ctx->last_error = "ecal_calibrate_views: ECAL_CALIB_USE_INTRINSIC_GUESS needs fx, fy > 0 and a principal point in res->intr";
+            return ECAL_ERR_INVALID;
+        }
+        if (w.cc.fix_aspect && opt->model == 0 && opt->aspect_ratio != 0) intr[0] = opt->aspect_ratio * intr[1];
+    } else if (opt->model == 0) {
         // cvInitIntrinsicParams2D: principal point at the image centre, focal lengths from the vanishing-point
         // constraints of every view's homography; 2 x 2 normal equations summed over ranks
         const double cx = (width - 1) * 0.5, cy = (height - 1) * 0.5;

@@ -31,7 +31,7 @@ struct RectifyConst {
     double width, height;
     double circle_radius;
     uint32_t rows, cols;
-    int asymmetric, fit_circle;
+    int asymmetric, fit_circle, model;
 };
 
 __device__ __forceinline__ void project_point(const double *R, const double *t, const RectifyConst &p, float X, float Y,
@@ -43,6 +43,14 @@ __device__ __forceinline__ void project_point(const double *R, const double *t, 
     z = z != 0.0 ? 1. / z : 1;
     x *= z;
     y *= z;
+    if (p.model == 1) {   // cv::fisheye::projectPoints (Kannala-Brandt k1..k4 = k[0..3], no skew): BASELINE configs[4]
+        const double r = sqrt(x * x + y * y), th = atan(r), th2 = th * th;
+        const double thd = th * (1 + th2 * (p.k[0] + th2 * (p.k[1] + th2 * (p.k[2] + th2 * p.k[3]))));
+        const double sc = r > 1e-8 ? thd / r : 1.0;
+        *u = (double) (float) (x * sc * p.fx + p.cx);
+        *v = (double) (float) (y * sc * p.fy + p.cy);
+        return;
+    }
     const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
     const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
     const double cdist = 1 + p.k[0] * r2 + p.k[1] * r4 + p.k[4] * r6;
@@ -257,6 +265,7 @@ extern "C" int ecal_rectify_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
     for (int i = 0; i < 5; i++) c.k[i] = prm->dist[i];
     c.width = prm->width, c.height = prm->height, c.circle_radius = prm->circle_radius;
     c.rows = prm->rows, c.cols = prm->cols, c.asymmetric = prm->asymmetric, c.fit_circle = prm->fit_circle;
+    c.model = prm->model == 1 ? 1 : 0;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(rectify_kernel, dim3(F), dim3(RC_T), 0, (hipStream_t) stream, (const double2 *) d_xy, d_seg_off,
                        d_seg_cnt, d_kept_labels, d_win_info, d_frame_window, d_pose, d_landmarks, c, d_feat_xyr,

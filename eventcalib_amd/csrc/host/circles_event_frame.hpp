@@ -80,6 +80,7 @@ public:
     struct Camera {
         double fx, fy, cx, cy;
         double distCoeffs[5];
+        bool fisheye = false;   // distCoeffs[0..3] = cv::fisheye's k1..k4 (new: BASELINE configs[4])
     };
 
     // CirclesEventFrame::rectifyFeatures (:417-638) after extractFeatures() succeeded: every feature is re-found
@@ -117,6 +118,7 @@ public:
         prm.asymmetric = pattern_->isAsymmetric ? 1 : 0;
         prm.circle_radius = pattern_->circleRadius;
         prm.fit_circle = params_.fitCircle ? 1 : 0;
+        prm.model = camera.fisheye ? 1 : 0;
         std::vector<uint32_t> valid(n);
         uint32_t info[2] = {0, 0};
         const int rc = ecal_rectify_batch(ecal_host::thread_ctx(), xy.data(), off, cnt, kept.data(),

@@ -409,6 +409,9 @@ typedef struct ecal_rectify_params {
     int asymmetric;            /* pattern_->isAsymmetric */
     double circle_radius;      /* Circles_Radius (world units) */
     int fit_circle;            /* params_.fitCircle: != 0 skips the border-score test */
+    int model;                 /* 0: cv::projectPoints with dist = k1 k2 p1 p2 k3 (the reference); 1: cv::fisheye::projectPoints
+                                  with dist[0..3] = k1..k4 (BASELINE configs[4]; the reference hands its fisheye coefficients to
+                                  the pinhole projection, EventCalibIni.cpp:258 / CirclesEventFrame.cpp:449 — not reproduced) */
 } ecal_rectify_params;
 int ecal_rectify_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
                            const int32_t *d_kept_labels, const uint32_t *d_win_info, const uint32_t *d_frame_window /*[F]*/,
@@ -630,6 +633,9 @@ void ecal_inverse_radial_distortion(const double *k4, double *b5);
 #define ECAL_CALIB_FIX_K6              (1u << 8)
 #define ECAL_CALIB_FIX_SKEW            (1u << 9)  /* cv::fisheye::CALIB_FIX_SKEW */
 #define ECAL_CALIB_RECOMPUTE_EXTRINSIC (1u << 10) /* cv::fisheye::CALIB_RECOMPUTE_EXTRINSIC */
+#define ECAL_CALIB_USE_INTRINSIC_GUESS  (1u << 11) /* cv::CALIB_USE_INTRINSIC_GUESS / cv::fisheye::CALIB_USE_INTRINSIC_GUESS: res->intr
+                                                     (all 12 slots) is the START of the iteration instead of the models' own
+                                                     initialisation (homographies / max(w, h) / pi) */
 #define ECAL_CALIB_BLOCK_DOUBLES 272
 typedef struct ecal_calib_options {
     int model;            /* 0 = pinhole (Calibrate_UseFisheyeModel: 0), 1 = fisheye */

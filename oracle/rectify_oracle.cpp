@@ -26,6 +26,7 @@ extern "C" int oracle_fit_circle(const double *a_xy, uint32_t na, const double *
 namespace {
 
 // cv::projectPoints, one point (no rational / thin-prism / tilt terms: the reference has 5 coefficients)
+int g_fisheye = 0;   // set by oracle_rectify_cam around its call (the oracle is single-threaded test infrastructure)
 void project_point(const double *R, const double *t, const double *K4, const double *k, float X, float Y, float Z,
                    float *u, float *v) {
     const double Xd = X, Yd = Y, Zd = Z;
@@ -35,6 +36,14 @@ void project_point(const double *R, const double *t, const double *K4, const dou
     z = z ? 1. / z : 1;
     x *= z;
     y *= z;
+    if (g_fisheye) {   // cv::fisheye::projectPoints (k = k1..k4, alpha = 0): the build's fisheye chain (BASELINE configs[4], new)
+        const double r = std::sqrt(x * x + y * y), th = std::atan(r), th2 = th * th;
+        const double thd = th * (1 + th2 * (k[0] + th2 * (k[1] + th2 * (k[2] + th2 * k[3]))));
+        const double sc = r > 1e-8 ? thd / r : 1.0;
+        *u = (float) (x * sc * K4[0] + K4[2]);
+        *v = (float) (y * sc * K4[1] + K4[3]);
+        return;
+    }
     const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
     const double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
     const double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
@@ -52,6 +61,21 @@ extern "C" {
 // pClusters_/nClusters_ (:120-121) or -1.  pose = Rcw row-major (9) + tcw (3); camera = fx fy cx cy; dist = k1 k2
 // p1 p2 k3; landmarks [n][3] in grid order (n = rows*cols).  Outputs: feat_xyr [n][3], feat_valid [n] (0 = erased),
 // info[2] = {return value, erased count}.
+int oracle_rectify(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg, const int32_t *kept_pos,
+                   const int32_t *kept_neg, const double *pose, const double *camera, const double *dist, double width,
+                   double height, const double *landmarks, uint32_t rows, uint32_t cols, int asymmetric,
+                   double circle_radius, int fit_circle, double *feat_xyr, uint32_t *feat_valid, uint32_t *info);
+// model 1: the projections of rectifyFeatures go through cv::fisheye::projectPoints (dist[0..3] = k1..k4)
+int oracle_rectify_cam(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg, const int32_t *kept_pos,
+                       const int32_t *kept_neg, const double *pose, const double *camera, const double *dist, double width,
+                       double height, const double *landmarks, uint32_t rows, uint32_t cols, int asymmetric,
+                       double circle_radius, int fit_circle, double *feat_xyr, uint32_t *feat_valid, uint32_t *info, int model) {
+    g_fisheye = model == 1;
+    const int rc = oracle_rectify(pos_xy, n_pos, neg_xy, n_neg, kept_pos, kept_neg, pose, camera, dist, width, height, landmarks, rows, cols,
+                                  asymmetric, circle_radius, fit_circle, feat_xyr, feat_valid, info);
+    g_fisheye = 0;
+    return rc;
+}
 int oracle_rectify(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg, const int32_t *kept_pos,
                    const int32_t *kept_neg, const double *pose, const double *camera, const double *dist, double width,
                    double height, const double *landmarks, uint32_t rows, uint32_t cols, int asymmetric,

@@ -81,8 +81,9 @@ int main(int argc, char **argv) {
     auto rectify = [&](size_t f, const EventCalibIni::FramePose &p) {
         CirclesEventFrame cf(container, kfs[f].duration, pattern, fp);
         if (!cf.extractFeatures()) return false;
-        const CirclesEventFrame::Camera cam{res.K[0], res.K[1], res.K[2], res.K[3],
-                                            {res.distCoeffs[0], res.distCoeffs[1], res.distCoeffs[2], res.distCoeffs[3], res.distCoeffs[4]}};
+        CirclesEventFrame::Camera cam{res.K[0], res.K[1], res.K[2], res.K[3], {0, 0, 0, 0, 0}};
+        for (size_t i = 0; i < 5 && i < res.distCoeffs.size(); i++) cam.distCoeffs[i] = res.distCoeffs[i];
+        cam.fisheye = cs->useFisheye;   // (4 coefficients k1..k4 then)
         double R[9], t[3];
         for (int i = 0; i < 9; i++) R[i] = p.Rsw[i];
         for (int i = 0; i < 3; i++) t[i] = p.tsw[i];
@@ -122,12 +123,13 @@ int main(int argc, char **argv) {
         dp.cols = (uint32_t) pattern->cols;
         ecal_rectify_params rp;
         rp.fx = res.K[0], rp.fy = res.K[1], rp.cx = res.K[2], rp.cy = res.K[3];
-        for (int i = 0; i < 5; i++) rp.dist[i] = res.distCoeffs[i];
+        for (size_t i = 0; i < 5; i++) rp.dist[i] = i < res.distCoeffs.size() ? res.distCoeffs[i] : 0.0;
         rp.width = container->cameraSize[0], rp.height = container->cameraSize[1];
         rp.rows = (uint32_t) pattern->rows, rp.cols = (uint32_t) pattern->cols;
         rp.asymmetric = pattern->isAsymmetric ? 1 : 0;
         rp.circle_radius = pattern->circleRadius;
         rp.fit_circle = fp.fitCircle ? 1 : 0;
+        rp.model = cs->useFisheye ? 1 : 0;
         rect_feat.resize(3 * n_circ * (size_t) F);
         rect_valid.resize(n_circ * (size_t) F);
         std::vector<uint32_t> info(2 * (size_t) F);
@@ -154,10 +156,11 @@ int main(int argc, char **argv) {
     stage("init_calibration_pnp_rectify");
     std::printf("init K %.9g %.9g %.9g %.9g rms %.6g accepted %zu checkPose %d rectify %d\n", res.K[0], res.K[1], res.K[2], res.K[3],
                 res.rms, res.acceptedFrames.size(), res.discardedByCheckPose, res.discardedByRectify);
-    const double dist5[5] = {res.distCoeffs[0], res.distCoeffs[1], res.distCoeffs[2], res.distCoeffs[3], res.distCoeffs[4]};
+    double dist5[5] = {0, 0, 0, 0, 0};
+    for (size_t i = 0; i < 5 && i < res.distCoeffs.size(); i++) dist5[i] = res.distCoeffs[i];
     bool useSO3 = false;
     fsSettings["useSO3"] >> useSO3;                          // :204-206 (reduceMap: experimental in the reference, not restated)
-    EventCalibSpline spline(frames, container, pattern, useSO3, step, res.K, dist5);
+    EventCalibSpline spline(frames, container, pattern, useSO3, step, res.K, dist5, 50, cs->useFisheye);
     const double *x = spline.intrinsics();
     std::printf("refined %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g residuals %zu iterations %d splines %zu\n", x[0], x[1], x[2], x[3],
                 x[4], x[5], x[6], x[7], x[8], spline.summary().residuals, spline.summary().iterations, spline.splineNum());

@@ -344,10 +344,11 @@ def associate(rec, kf_time, circles, t_min, t_max, max_dt, edge_tol):
 
 
 def rectify(pos, neg, kept_pos, kept_neg, pose, camera, dist, width, height, landmarks, rows, cols, asymmetric,
-            circle_radius, fit_circle=False):
-    """CirclesEventFrame::rectifyFeatures for one keyframe -> (feat_xyr [n,3], valid [n], ok, erased)."""
+            circle_radius, fit_circle=False, model=0):
+    """CirclesEventFrame::rectifyFeatures for one keyframe -> (feat_xyr [n,3], valid [n], ok, erased).  model 1: fisheye
+    projections (dist[0..3] = k1..k4)."""
     L = lib()
-    L.oracle_rectify.restype = ctypes.c_int
+    L.oracle_rectify_cam.restype = ctypes.c_int
     pos = np.ascontiguousarray(pos, np.float64).reshape(-1, 2)
     neg = np.ascontiguousarray(neg, np.float64).reshape(-1, 2)
     kp = np.ascontiguousarray(kept_pos, np.int32)
@@ -361,12 +362,12 @@ def rectify(pos, neg, kept_pos, kept_neg, pose, camera, dist, width, height, lan
     valid = np.zeros(n, np.uint32)
     info = np.zeros(2, np.uint32)
     vp = ctypes.c_void_p
-    L.oracle_rectify(vp(pos.ctypes.data), ctypes.c_uint32(len(pos)), vp(neg.ctypes.data), ctypes.c_uint32(len(neg)),
+    L.oracle_rectify_cam(vp(pos.ctypes.data), ctypes.c_uint32(len(pos)), vp(neg.ctypes.data), ctypes.c_uint32(len(neg)),
                      vp(kp.ctypes.data), vp(kn.ctypes.data), vp(pose.ctypes.data), vp(camera.ctypes.data),
                      vp(dist.ctypes.data), ctypes.c_double(width), ctypes.c_double(height), vp(lm.ctypes.data),
                      ctypes.c_uint32(rows), ctypes.c_uint32(cols), ctypes.c_int(int(asymmetric)),
                      ctypes.c_double(circle_radius), ctypes.c_int(int(fit_circle)), vp(feat.ctypes.data),
-                     vp(valid.ctypes.data), vp(info.ctypes.data))
+                     vp(valid.ctypes.data), vp(info.ctypes.data), ctypes.c_int(int(model)))
     return feat, valid, int(info[0]), int(info[1])
 
 

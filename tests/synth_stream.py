@@ -27,6 +27,9 @@ CX, CY = 172.5, 129.5
 K1, K2, K3 = -0.34991902, -0.014698517, 0.59684463
 RECORD = 25
 CHUNK = 1 << 22
+# BASELINE configs[4] / SURVEY 8(d): the same sensor with a fisheye lens — Kannala-Brandt, forward coefficients k1..k4
+CAMERA = "pinhole"     # "pinhole": radial model above; "fisheye": theta_d = theta (1 + k1 theta^2 + .. + k4 theta^8)
+KB = (0.05, -0.01, 0.002, 0.0)
 
 
 def landmarks(device="cpu"):
@@ -88,11 +91,17 @@ def pose(t):
 
 
 def project(Xw, R_wc, C):
-    """World points [n,3] -> distorted pixel coordinates [n,2] (forward radial model)."""
+    """World points [n,3] -> distorted pixel coordinates [n,2] (forward radial model, or Kannala-Brandt: CAMERA)."""
     Xc = torch.einsum("nji,nj->ni", R_wc, Xw - C)          # R_wc^T (Xw - C)
     xn = Xc[:, 0] / Xc[:, 2]
     yn = Xc[:, 1] / Xc[:, 2]
     r2 = xn * xn + yn * yn
+    if CAMERA == "fisheye":                                  # cv::fisheye::projectPoints, alpha = 0
+        r = torch.sqrt(r2).clamp_min(1e-12)
+        th = torch.atan(r)
+        th2 = th * th
+        d = th * (1 + th2 * (KB[0] + th2 * (KB[1] + th2 * (KB[2] + th2 * KB[3])))) / r
+        return torch.stack([FX * xn * d + CX, FY * yn * d + CY], dim=1)
     d = 1 + K1 * r2 + K2 * r2 * r2 + K3 * r2 * r2 * r2
     return torch.stack([FX * xn * d + CX, FY * yn * d + CY], dim=1)
 

@@ -69,3 +69,41 @@ def test_tum_writer_roundtrip(result, tmp_path):
     back = np.loadtxt(p)
     assert back.shape == result[False]["trajectory"].shape and np.abs(back - result[False]["trajectory"]).max() < 1e-9
     assert len(open(p).readline().split()) == 8 and len(open(p).readline().split()[0].split(".")[1]) == 10
+
+
+def test_fisheye_stream_end_to_end():
+    """BASELINE configs[4]'s camera through the whole chain: a Kannala-Brandt stream (k = 0.05, -0.01, 0.002, 0) ->
+    keyframes -> cv::fisheye::calibrate's model in the init stage (EventCalibIni.cpp:186-190) -> fisheye PnP, rectifyFeatures
+    with the fisheye projection -> the spline solve with the fisheye residual (new: the reference stops at
+    EventCalibSpline.cpp:97-99).  Stated tolerance: fx, fy within 0.3 %, the principal point within 0.5 px, and the
+    refined angle polynomial maps pixel radii to ray angles within 5e-4 rad of the ground truth over the part of the sensor the
+    board was seen in (0.3 rad around the axis)."""
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.calibrate import calibrate_stream
+    SS.TRAJECTORY, SS.CAMERA = "orbit", "fisheye"
+    try:
+        n = 3_000_000
+        buf = SS.make_stream(n, rate=1.0e6, t_start=5.0, device="cuda", seed=21)
+    finally:
+        SS.TRAJECTORY, SS.CAMERA = "hover", "pinhole"
+    ctx = eventcalib_amd.Context(0)
+    try:
+        r = calibrate_stream(ctx, buf, 5.0, 5.0 + (n - 1) / 1e6, fisheye=True)
+    finally:
+        ctx.close()
+    ini = r["init"]
+    assert r["keyframes"] > 300 and ini["accepted"] > 150
+    assert abs(ini["intr"][0] / SS.FX - 1) < 3e-2 and ini["rms"] < 5.0              # midpoint circles: a rough start
+    fx, fy, cx, cy = r["intrinsics"][:4]
+    assert abs(fx / SS.FX - 1) < 3e-3 and abs(fy / SS.FY - 1) < 3e-3, (fx, fy)
+    assert abs(cx - (SS.CX - 0.5)) < 0.5 and abs(cy - (SS.CY - 0.5)) < 0.5, (cx, cy)
+    assert r["spline"]["final_cost"] < r["spline"]["initial_cost"] and r["spline"]["residuals"] > 1_000_000
+    # the angle map: theta(theta_d) from the refined inverse polynomial against the forward model's inverse (Newton)
+    b = r["intrinsics"][4:9]
+    th = np.linspace(0.02, 0.55, 60)                                                  # ray angles of the 346 x 260 sensor
+    thd = th * (1 + SS.KB[0] * th ** 2 + SS.KB[1] * th ** 4 + SS.KB[2] * th ** 6 + SS.KB[3] * th ** 8)
+    back = thd * (1 + b[0] * thd ** 2 + b[1] * thd ** 4 + b[2] * thd ** 6 + b[3] * thd ** 8 + b[4] * thd ** 10)
+    err = np.abs(back - th)
+    # where the board's circles were seen (within ~0.3 rad of the axis); beyond, five free coefficients extrapolate freely
+    assert err[th <= 0.30].max() < 5e-4, (err[th <= 0.30].max(), err[th <= 0.40].max(), err.max())

@@ -12,14 +12,19 @@ import synth_stream as SS
 pytestmark = pytest.mark.gpu
 
 
-def _run(fit_circle):
+def _run(fit_circle, fisheye=False):
     import torch
     import eventcalib_amd
     from eventcalib_amd.capi import RectifyParams
     from eventcalib_amd.pipeline import DetectPipeline
     ctx = eventcalib_amd.Context(0)
     pipe = DetectPipeline(ctx)
-    buf = SS.make_stream(400_000, rate=4.0e6, device="cpu", seed=4)
+    SS.CAMERA = "fisheye" if fisheye else "pinhole"
+    try:
+        buf = SS.make_stream(400_000, rate=4.0e6, device="cpu", seed=4)
+    finally:
+        SS.CAMERA = "pinhole"
+    dist = (SS.KB[0], SS.KB[1], SS.KB[2], SS.KB[3], 0.0) if fisheye else SR.DIST
     t, _, _ = SS.unpack_records(buf)
     t0, t1 = SS.tiled_windows(float(t[0]), float(t[-1]))
     pipe.set_windows(t0, t1)
@@ -36,8 +41,9 @@ def _run(fit_circle):
     lm = SR.landmarks_f32()
     prm = RectifyParams()
     prm.fx, prm.fy, prm.cx, prm.cy = SR.CAMERA
-    for i, v in enumerate(SR.DIST):
+    for i, v in enumerate(dist):
         prm.dist[i] = v
+    prm.model = 1 if fisheye else 0
     prm.width, prm.height = SS.SENSOR_W, SS.SENSOR_H
     prm.rows, prm.cols, prm.asymmetric = 9, 4, 1
     prm.circle_radius, prm.fit_circle = SS.RADIUS, int(fit_circle)
@@ -62,8 +68,8 @@ def _run(fit_circle):
         s = frames[f]
         pos, neg = xy[off[2 * s]: off[2 * s] + cnt[2 * s]], xy[off[2 * s + 1]: off[2 * s + 1] + cnt[2 * s + 1]]
         kp, kn = kept[off[2 * s]: off[2 * s] + cnt[2 * s]], kept[off[2 * s + 1]: off[2 * s + 1] + cnt[2 * s + 1]]
-        o_feat, o_valid, o_ok, o_erased = O.rectify(pos, neg, kp, kn, pose[f], SR.CAMERA, SR.DIST, SS.SENSOR_W,
-                                                    SS.SENSOR_H, lm, 9, 4, True, SS.RADIUS, fit_circle=fit_circle)
+        o_feat, o_valid, o_ok, o_erased = O.rectify(pos, neg, kp, kn, pose[f], SR.CAMERA, dist, SS.SENSOR_W,
+                                                    SS.SENSOR_H, lm, 9, 4, True, SS.RADIUS, fit_circle=fit_circle, model=int(fisheye))
         assert np.array_equal(valid[f], o_valid.astype(np.int32)), "frame %d validity" % f
         assert (info[f, 0], info[f, 1]) == (o_ok, o_erased), "frame %d verdict" % f
         assert np.array_equal(feat[f], o_feat, equal_nan=True), "frame %d circles" % f
@@ -79,3 +85,8 @@ def test_rectify_matches_oracle():
 
 def test_rectify_fit_circle_mode_matches_oracle():
     _run(True)
+
+
+def test_rectify_with_the_fisheye_projection_matches_oracle():
+    """BASELINE configs[4]: the projections of rectifyFeatures through cv::fisheye::projectPoints (Kannala-Brandt stream)."""
+    _run(False, fisheye=True)
