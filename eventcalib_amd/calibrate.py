@@ -22,8 +22,12 @@ from .pipeline import DetectPipeline
 
 EXAMPLE_FLAGS = (capi.CALIB_FIX_ASPECT_RATIO | capi.CALIB_FIX_PRINCIPAL_POINT | capi.CALIB_ZERO_TANGENT_DIST |
                  capi.CALIB_FIX_K4 | capi.CALIB_FIX_K5 | capi.CALIB_FIX_K6)       # parameters.hpp:47-58 on example.yaml
-# Calibrate_UseFisheyeModel: 1 on the same file — the fisheye enum overwrites the flags (parameters.hpp:59-68)
-EXAMPLE_FLAGS_FISHEYE = (capi.CALIB_FIX_SKEW | capi.CALIB_RECOMPUTE_EXTRINSIC | capi.CALIB_FIX_K4 | capi.CALIB_FIX_PRINCIPAL_POINT)
+# Calibrate_UseFisheyeModel: 1 — the fisheye enum overwrites the flags (parameters.hpp:59-68) — with Fix_K2 .. Fix_K4: 1: from
+# circle centres good to ~3 px a 55-degree lens shows k1 only; free, k2 and k3 come out in the tens (the fit follows the noise at
+# the image border) and their series reversion starts the spline solve in the basin of a wrong minimum (measured: principal point
+# 4 px off, fx 1 % off).  The spline solve itself frees all five inverse coefficients, as the reference does for the radial model.
+EXAMPLE_FLAGS_FISHEYE = (capi.CALIB_FIX_SKEW | capi.CALIB_RECOMPUTE_EXTRINSIC | capi.CALIB_FIX_PRINCIPAL_POINT |
+                         capi.CALIB_FIX_K2 | capi.CALIB_FIX_K3 | capi.CALIB_FIX_K4)
 
 
 def board_points(rows=9, cols=4, square=5.5, asymmetric=True):

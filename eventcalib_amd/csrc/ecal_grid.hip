@@ -48,6 +48,9 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     __shared__ int8_t cu[GR_MAXC], cv[GR_MAXC];
     __shared__ uint8_t assigned[GR_MAXC], queue[GR_MAXC];
     __shared__ uint8_t occ[GR_L * GR_L];  // lattice cell -> candidate index + 1
+    __shared__ double hn[8][9];           // normal equations of the partial grid's homography (second attempt)
+    __shared__ double hh[8];
+    __shared__ uint32_t sh_qt;
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
     const uint32_t n = win_info[4 * (size_t) s], M = rows * cols;
     int32_t *out = order + (size_t) s * M;
@@ -86,35 +89,40 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         sy += __shfl_xor(sy, o, 64);
     }
     const uint32_t seed = (uint32_t) (nearest(sx / n, sy / n, false, 0xFFFFFFFFu) & 0xFFu);
-    // its four nearest neighbours give the two diagonal steps
-    uint32_t nb[4];
+    // its nearest neighbours give the walk's two steps: the nearest one, and the nearest one that is not (anti)parallel to
+    // it.  In a frontal view these are two of the four diagonal neighbours; under steep perspective some other pair of short
+    // independent lattice vectors — the foreshortened axis brings second neighbours along it in front of the diagonal ones
+    // (at 58 degrees of tilt about a diagonal the first three neighbours are a, -a, 2 a) — which the matching below allows for.
+    constexpr int GR_NB = 8;
+    uint32_t nb[GR_NB];
     {
         if (lane == 0) assigned[seed] = 1;
         __syncthreads();
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < GR_NB; k++) {
             const unsigned long long r = nearest(px[seed], py[seed], true, seed);
-            nb[k] = (uint32_t) (r & 0xFFu);
-            if (lane == 0) assigned[nb[k]] = 1;
+            nb[k] = r == ~0ull ? seed : (uint32_t) (r & 0xFFu);
+            if (lane == 0 && r != ~0ull) assigned[nb[k]] = 1;
             __syncthreads();
         }
         if (lane == 0)
-            for (int k = 0; k < 4; k++) assigned[nb[k]] = 0;
+            for (int k = 0; k < GR_NB; k++) assigned[nb[k]] = 0;
         __syncthreads();
     }
     double ax = px[nb[0]] - px[seed], ay = py[nb[0]] - py[seed];
     double bx = 0, by = 0, bestperp = -1.0;
-    for (int k = 1; k < 4; k++) {
+    for (int k = 1; k < GR_NB && bestperp < 0; k++) {
+        if (nb[k] == seed) break;
         const double dx = px[nb[k]] - px[seed], dy = py[nb[k]] - py[seed];
         const double cr = fabs(ax * dy - ay * dx), nn = sqrt((ax * ax + ay * ay) * (dx * dx + dy * dy));
         const double perp = nn > 0 ? cr / nn : 0.0;
-        if (perp > bestperp) {
+        if (perp > 0.5) {
             bestperp = perp;
             bx = dx;
             by = dy;
         }
     }
     const double la = sqrt(ax * ax + ay * ay), lb = sqrt(bx * bx + by * by);
-    if (!(bestperp > 0.5) || !(lb > 0.5 * la && lb < 2.0 * la)) return;  // no usable lattice around the seed
+    if (!(bestperp > 0.5) || !(lb < 4.0 * la)) return;  // no usable lattice around the seed
     if (ax * by - ay * bx < 0) {  // right-handed (u, v) in image coordinates
         bx = -bx;
         by = -by;
@@ -172,48 +180,168 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         }
     }
     __syncthreads();
-    if (qt < M) return;
-    // match the pattern: model point (x, y) = ((2j + i%2), i) has lattice coordinates U = (x+y)/2,
-    // V = (y-x)/2 in the right-handed basis E1 = (1,1), E2 = (-1,1); try the four rotations of the
-    // image lattice and every visited node as the image of model point 0
-    const uint32_t combos = 4 * qt;
-    uint32_t win = 0xFFFFFFFFu;
-    for (uint32_t cb = lane; cb < combos; cb += GR_T) {
-        const uint32_t rot = cb / qt, a = queue[cb % qt];
-        bool ok = true;
-        for (uint32_t m = 0; m < M && ok; m++) {
+    auto match_pattern = [&]() -> bool {
+        if (qt < M) return false;
+        // match the pattern: model point (x, y) = ((2j + i%2), i) has lattice coordinates U = (x+y)/2, V = (y-x)/2 in the
+        // right-handed basis E1 = (1,1), E2 = (-1,1).  The walk's basis (two short independent steps around the seed) is SOME
+        // right-handed basis of the same lattice: the diagonal steps in a frontal view — then the walk's coordinates are a
+        // rotation of the model's —, but beyond ~55 degrees of tilt the foreshortened axis brings the second neighbour along it
+        // closer than the diagonal ones and the basis comes out sheared.  So the model's coordinates go through every
+        // T in SL2(Z) with entries in [-2, 2] (the four rotations first) and every visited node is tried as the image of model
+        // point 0.  (This is what the vendored finder's second attempt on the homography-rectified points and its clustering
+        // variant are for, cv_calib.cpp:34-84, circlesgrid.cpp:72-180: a complete pattern seen at a steep angle is still found.)
+        auto transform_of = [](uint32_t t, int &a, int &b, int &c, int &d) -> bool {
+            if (t < 4u) {   // rotations by 0, 90, 180, 270 degrees
+                a = t == 0 ? 1 : (t == 2 ? -1 : 0);
+                b = t == 1 ? -1 : (t == 3 ? 1 : 0);
+                c = -b;
+                d = a;
+                return true;
+            }
+            const uint32_t q = t - 4u;   // the other matrices of [-2, 2]^4 with determinant + 1
+            a = (int) (q % 5u) - 2;
+            b = (int) (q / 5u % 5u) - 2;
+            c = (int) (q / 25u % 5u) - 2;
+            d = (int) (q / 125u) - 2;
+            if (a * d - b * c != 1) return false;
+            return !(b == -c && a == d && a * a + b * b == 1);   // (the rotations came first)
+        };
+        auto cell_of = [&](uint32_t anchor, int a, int b, int c, int d, uint32_t m, int &u, int &v) {
             const int i = (int) (m / cols), jj = (int) (m % cols);
             const int x = 2 * jj + (i & 1), y = i;
             const int U = (x + y) / 2, V = (y - x) / 2;  // relative to model point 0 = (0, 0)
-            int ru, rv;
-            switch (rot) {
-                case 0: ru = U; rv = V; break;
-                case 1: ru = -V; rv = U; break;
-                case 2: ru = -U; rv = -V; break;
-                default: ru = V; rv = -U; break;
+            u = cu[anchor] + a * U + b * V;
+            v = cv[anchor] + c * U + d * V;
+        };
+        const uint32_t n_tf = 4u + 625u, combos = n_tf * qt;
+        uint32_t win = 0xFFFFFFFFu;
+        for (uint32_t cb0 = 0; cb0 < combos && win == 0xFFFFFFFFu; cb0 += GR_T) {   // (in order: the first match wins, rotations first)
+            const uint32_t cb = cb0 + lane;
+            bool ok = cb < combos;
+            int a = 0, b = 0, c = 0, d = 0;
+            if (ok) ok = transform_of(cb / qt, a, b, c, d);
+            for (uint32_t m = 0; m < M && ok; m++) {
+                int u, v;
+                cell_of(queue[cb % qt], a, b, c, d, m, u, v);
+                ok = u >= -GR_L / 2 && u < GR_L / 2 && v >= -GR_L / 2 && v < GR_L / 2 &&
+                     occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] != 0;
             }
-            const int u = cu[a] + ru, v = cv[a] + rv;
-            ok = u >= -GR_L / 2 && u < GR_L / 2 && v >= -GR_L / 2 && v < GR_L / 2 &&
-                 occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] != 0;
+            uint32_t mine = ok ? cb : 0xFFFFFFFFu;
+            for (int o = 32; o > 0; o >>= 1) mine = min(mine, (uint32_t) __shfl_xor((int) mine, o, 64));
+            win = mine;
         }
-        if (ok) win = min(win, cb);
-    }
-    for (int o = 32; o > 0; o >>= 1) win = min(win, (uint32_t) __shfl_xor((int) win, o, 64));
-    if (win == 0xFFFFFFFFu) return;
-    const uint32_t rot = win / qt, a = queue[win % qt];
-    for (uint32_t m = lane; m < M; m += GR_T) {
-        const int i = (int) (m / cols), jj = (int) (m % cols);
-        const int x = 2 * jj + (i & 1), y = i;
-        const int U = (x + y) / 2, V = (y - x) / 2;
-        int ru, rv;
-        switch (rot) {
-            case 0: ru = U; rv = V; break;
-            case 1: ru = -V; rv = U; break;
-            case 2: ru = -U; rv = -V; break;
-            default: ru = V; rv = -U; break;
+        if (win == 0xFFFFFFFFu) return false;
+        int ta, tb, tc, td;
+        (void) transform_of(win / qt, ta, tb, tc, td);
+        const uint32_t anchor = queue[win % qt];
+        for (uint32_t m = lane; m < M; m += GR_T) {
+            int u, v;
+            cell_of(anchor, ta, tb, tc, td, m, u, v);
+            out[m] = (int32_t) occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1;
         }
-        out[m] = (int32_t) occ[(cv[a] + rv + GR_L / 2) * GR_L + (cu[a] + ru + GR_L / 2)] - 1;
+        return true;
+
+    };
+    bool got = match_pattern();
+    if (!got && qt >= 4u) {
+        // Second attempt, as cv::findCirclesGrid's (cv_calib.cpp:34-84: the holes found so far give a homography,
+        // CirclesGridFinder::rectifyGrid, and the search runs again on the rectified points).  Under steep perspective the
+        // first walk's local steps drift and a step can land on the wrong neighbour (the foreshortened lattice has
+        // neighbours closer than a step's prediction error): only the seed's 3 x 3 neighbourhood of that walk is kept; the
+        // homography lattice (u, v) -> image is fitted to it (inhomogeneous DLT, 8 x 8 normal equations) and the walk is
+        // redone ring by ring with ITS predictions — exact under perspective —, refitted after every ring.
+        if (lane == 0) {
+            uint32_t keep = 0;
+            for (uint32_t k = 0; k < qt; k++) {
+                const uint32_t j = queue[k];
+                if (cu[j] >= -1 && cu[j] <= 1 && cv[j] >= -1 && cv[j] <= 1) {
+                    queue[keep++] = (uint8_t) j;
+                } else {
+                    assigned[j] = 0;
+                    occ[(cv[j] + GR_L / 2) * GR_L + (cu[j] + GR_L / 2)] = 0;
+                }
+            }
+            sh_qt = keep;
+        }
+        __syncthreads();
+        qt = sh_qt;
+        for (int sweep = 0; sweep < 20 && !got && qt >= 4u; sweep++) {
+            for (uint32_t e = lane; e < 72u; e += GR_T) {
+                const uint32_t r = e / 9u, c = e % 9u;
+                double acc = 0;
+                for (uint32_t k = 0; k < qt; k++) {
+                    const uint32_t j = queue[k];
+                    const double u = cu[j], v = cv[j], x = px[j], y = py[j];
+                    const double r1[9] = {u, v, 1, 0, 0, 0, -u * x, -v * x, x}, r2[9] = {0, 0, 0, u, v, 1, -u * y, -v * y, y};
+                    acc += r1[r] * r1[c] + r2[r] * r2[c];
+                }
+                hn[r][c] = acc;
+            }
+            __syncthreads();
+            if (lane == 0) {   // Gaussian elimination with partial pivoting
+                bool okh = true;
+                for (int c = 0; c < 8 && okh; c++) {
+                    int piv = c;
+                    for (int r = c + 1; r < 8; r++)
+                        if (fabs(hn[r][c]) > fabs(hn[piv][c])) piv = r;
+                    if (!(fabs(hn[piv][c]) > 1e-12)) {
+                        okh = false;
+                        break;
+                    }
+                    for (int k = 0; k < 9; k++) {
+                        const double t = hn[c][k];
+                        hn[c][k] = hn[piv][k];
+                        hn[piv][k] = t;
+                    }
+                    for (int r = c + 1; r < 8; r++) {
+                        const double f = hn[r][c] / hn[c][c];
+                        for (int k = c; k < 9; k++) hn[r][k] -= f * hn[c][k];
+                    }
+                }
+                for (int r = 7; r >= 0 && okh; r--) {
+                    double t = hn[r][8];
+                    for (int k = r + 1; k < 8; k++) t -= hn[r][k] * hh[k];
+                    hh[r] = t / hn[r][r];
+                }
+                if (!okh) hh[0] = NAN;
+            }
+            __syncthreads();
+            if (!(hh[0] == hh[0])) break;
+            const uint32_t qt_before = qt;
+            for (uint32_t qi = 0; qi < qt_before; qi++) {
+                const uint32_t cur = queue[qi];
+                const int u0 = cu[cur], v0 = cv[cur];
+                for (int dir = 0; dir < 4; dir++) {
+                    const int du = dir == 0 ? 1 : (dir == 1 ? -1 : 0), dv = dir == 2 ? 1 : (dir == 3 ? -1 : 0);
+                    const int u = u0 + du, v = v0 + dv;
+                    if (u < -GR_L / 2 || u >= GR_L / 2 || v < -GR_L / 2 || v >= GR_L / 2) continue;
+                    if (occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)]) continue;
+                    const double wq = hh[6] * u + hh[7] * v + 1.0;
+                    if (!(wq > 1e-6)) continue;
+                    const double tx = (hh[0] * u + hh[1] * v + hh[2]) / wq, ty = (hh[3] * u + hh[4] * v + hh[5]) / wq;
+                    const unsigned long long r = nearest(tx, ty, true, 0xFFFFFFFFu);
+                    if (r == ~0ull) continue;
+                    const uint32_t j = (uint32_t) (r & 0xFFu);
+                    const double ddx = px[j] - tx, ddy = py[j] - ty;
+                    const double sxp = tx - px[cur], syp = ty - py[cur];
+                    const double lim = fmin(tol_px * tol_px, tol_frac * tol_frac * (sxp * sxp + syp * syp));
+                    if (ddx * ddx + ddy * ddy > lim) continue;
+                    if (lane == 0) {
+                        assigned[j] = 1;
+                        cu[j] = (int8_t) u;
+                        cv[j] = (int8_t) v;
+                        occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] = (uint8_t) (j + 1);
+                        queue[qt] = (uint8_t) j;
+                    }
+                    qt++;
+                    __syncthreads();
+                }
+            }
+            if (qt == qt_before) break;
+            if (qt >= M) got = match_pattern();
+        }
     }
+    if (!got) return;
     if (lane == 0) found[s] = 1;
 }
 
