@@ -38,6 +38,9 @@ def main():
                     help="pieces of the adaptive-window policy P2 (SURVEY 8d) measured after M1 (0 = skip; -1 = the reference's "
                          "own choice on this host, 5 * (hardware threads - 2), and 4096)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe upload timing")
+    ap.add_argument("--scaling", choices=["weak", "both"], default="both",
+                    help="`value` is always the weak-scaling figure (one --events stream per GPU, the contract's definition); "
+                         "\"both\" adds, under --gpus N > 1, a strong-scaling leg: ONE --events stream cut into N time ranges")
     ap.add_argument("--ingest-events", type=int, default=200_000_000,
                     help="events of the double-buffered ingest leg (configs[4]; host-resident stream; 0 = skip)")
     ap.add_argument("--calib-views", type=int, default=64,
@@ -211,6 +214,41 @@ def main():
     value = total_events / elapsed / 1e6
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
 
+    # ---- strong scaling (BASELINE.json's metric reads "on 50M-event stream @1/2/4/8 GPU"): ONE stream of --events events —
+    # rank 0's — cut into N contiguous ranges of whole windows, one per rank, no data-path collective (tiled windows do not
+    # overlap; the adaptive policy's ranges would overlap by the longest window, 9 steps).  Every rank generates ITS range of
+    # that same stream (chunks seeded by index: the same records).  Rate = the whole stream over the slowest rank.
+    strong = None
+    if world > 1 and args.scaling == "both" and args.steps > 0:
+        g0, g1 = SS.tiled_windows(5.0, 5.0 + (n_events - 1) / rate, 1.5e-3)
+        Sg = len(g0)
+        w_lo, w_hi = (Sg * rank) // world, (Sg * (rank + 1)) // world
+        k_lo = max(0, int((g0[w_lo] - 5.0) * rate) - 2)
+        k_hi = min(n_events, int((g1[w_hi - 1] - 5.0) * rate) + 3)
+        del events
+        torch.cuda.empty_cache()
+        ev_s = SS.make_stream(k_hi - k_lo, rate=rate, t_start=5.0, seed=12345, device=dev, k_offset=k_lo, total=n_events)
+        pipe.set_windows(g0[w_lo:w_hi], g1[w_lo:w_hi])
+        for _ in range(max(1, args.warmup)):
+            pipe.run(ev_s, eps, minpts)
+        barrier()
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.run(ev_s, eps, minpts)
+        barrier()
+        el_s = time.perf_counter() - tb
+        cnt = torch.tensor([float(int(pipe.win_hi[w_hi - w_lo - 1]) - int(pipe.win_lo[0])), el_s], dtype=torch.float64, device=dev)
+        tot = cnt.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        el_s = float(cnt[1].item())
+        strong = {"value": round(n_events * args.steps / el_s / 1e6, 3), "unit": "Mevents/s", "scaling": "strong",
+                  "events_total": n_events, "events_covered_by_the_ranks_windows": int(tot[0].item()),
+                  "windows_total": Sg, "ms_per_step": round(el_s / args.steps * 1e3, 4),
+                  "note": "one %dM-event stream cut into %d time ranges of whole windows; no collective on the data path" % (n_events // 1_000_000, world)}
+        events = ev_s
+        t0, t1 = g0[w_lo:w_hi], g1[w_lo:w_hi]
+
     out = {
         "metric": "Mevents/s DBSCAN+detect",
         "value": round(value, 3),
@@ -234,6 +272,8 @@ def main():
             "sharding": "time ranges, one stream per GPU, no data-path collective",
         },
     }
+    if strong is not None:
+        out["strong_scaling"] = strong
     if rank == 0:
         # the dominant KERNEL: the extraction stage is three launches (plain pass, member order, listed windows again), of
         # which the plain pass — timed alone below the stage — is the longest

@@ -143,13 +143,18 @@ def pack_records(t, xy, pol):
     return rec.reshape(-1)
 
 
-def make_stream(n_events, rate=1.0e6, t_start=5.0, seed=12345, device="cpu", noise_frac=0.1):
-    """Packed .bin image of the stream: uint8 tensor of n_events*25 bytes on `device`."""
+def make_stream(n_events, rate=1.0e6, t_start=5.0, seed=12345, device="cpu", noise_frac=0.1, k_offset=0, total=None):
+    """Packed .bin image of the stream: uint8 tensor of n_events*25 bytes on `device`.  k_offset / total: the events
+    k_offset .. k_offset + n_events - 1 of the `total`-event stream that starts at t_start — a time range of it, for sharding
+    ONE stream over ranks: the chunks are generated as the whole stream generates them (seeded by their index, sized by
+    `total`) and cut, so the slice holds the same records whoever generates it."""
+    total = k_offset + n_events if total is None else total
     parts = []
-    for k0 in range(0, n_events, CHUNK):
-        n = min(CHUNK, n_events - k0)
-        t, xy, pol = _chunk(k0, n, rate, t_start, seed, device, noise_frac)
-        parts.append(pack_records(t, xy, pol))
+    k_end = k_offset + n_events
+    for k0 in range((k_offset // CHUNK) * CHUNK, k_end, CHUNK):
+        t, xy, pol = _chunk(k0, min(CHUNK, total - k0), rate, t_start, seed, device, noise_frac)
+        lo, hi = max(k0, k_offset) - k0, min(k0 + CHUNK, k_end) - k0
+        parts.append(pack_records(t[lo:hi], xy[lo:hi], pol[lo:hi]))
     return torch.cat(parts) if len(parts) > 1 else parts[0]
 
 

@@ -41,6 +41,12 @@ def test_two_ranks_match_one_rank():
     two = _bench(2, [])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["events_per_gpu"] == one["config"]["events_per_gpu"] == 2000000     # weak scaling
+    # ... and the strong-scaling leg beside it: ONE 2 M-event stream cut into two time ranges of whole windows — together
+    # the ranks' windows cover every event of it exactly once
+    assert "strong_scaling" not in one
+    ss = two["strong_scaling"]
+    assert ss["scaling"] == "strong" and ss["events_total"] == 2000000 and ss["events_covered_by_the_ranks_windows"] == 2000000
+    assert ss["value"] > 0 and ss["windows_total"] == one["config"]["windows_per_gpu"]
     # the sharded init calibration lands on the single-rank answer (same 64 views, Schur records summed over ranks)
     c1, c2 = one["init_calibration"], two["init_calibration"]
     assert c1["views_per_gpu"] == 64 and c2["views_per_gpu"] == 32
