@@ -655,6 +655,8 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
         "sharding": "one spline segment (time range) per GPU in its own solver, shared intrinsics: 91 doubles all-reduced per "
                     "evaluation, 101 + N per linear solve, 4 per step" if world > 1 else "single GPU",
     }
+    if world > 1:
+        out["time_sharded_spline"] = time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook)
     if combined is not None:
         ref = Solver(ctx, combined[0])
         o2 = ref.default_options()
@@ -678,6 +680,76 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
                                "implied_iterations_per_s_on_this_problem": round(m / cel / (2 * n_res), 6)}
     solver.close()
     return out
+
+def time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook):
+    """ONE spline (world x n_cp control points over world x duration) whose residuals are cut by time into
+    one range per rank (ecal_lm_options.distributed = 2): per Jacobian evaluation the 91-double head + 612 doubles per cut are
+    all-reduced, per linear solve 1082 doubles per rank, nothing proportional to the control points until the solution is put
+    together at the end.  Every rank generates ITS time range of the same problem."""
+    import synth_solver_torch as ST
+    from eventcalib_amd import capi
+    from eventcalib_amd.capi import Solver
+    N, C = n_res * world, n_cp * world
+    ta, tb = 5.0, 5.0 + duration * world
+    knots = ST.uniform_knots(C, ta, tb)
+    cuts = np.concatenate([[-np.inf], capi.time_shard_cuts(knots, C, world), [np.inf]])
+    lo_t, hi_t = cuts[rank], cuts[rank + 1]
+    k_lo = 0 if rank == 0 else int((lo_t - ta) / (tb - ta) * N) - 2
+    k_hi = N if rank == world - 1 else int((hi_t - ta) / (tb - ta) * N) + 3
+    prob, x_gt = ST.make_problem(N, C, ta, tb, seed=4242, device=dev, round_pixels=True, k_range=(k_lo, k_hi))
+    keep = (prob["time"] >= lo_t) & (prob["time"] < hi_t)
+    prob = dict(prob, obs=prob["obs"][keep], time=prob["time"][keep], lm_id=prob["lm_id"][keep])
+    mine = int(keep.sum())
+    rngp = np.random.default_rng(99)
+    x0 = x_gt.copy()
+    x0[:4] *= 1 + 0.01 * rngp.uniform(-1, 1, 4)
+    x0[4:9] += 0.01 * rngp.uniform(-1, 1, 5)
+    solver = Solver(ctx, prob)
+    del prob
+    opt = solver.default_options()
+    if hook is not None:
+        opt.allreduce = hook
+    else:
+        opt.allreduce, opt.allreduce_user = ctx.comm_allreduce_fn()
+    opt.distributed, opt.rank, opt.world_size = 2, rank, world
+    opt.max_num_iterations = 2
+    solver.solve(x0, opt)                      # warm-up
+    opt.max_num_iterations = args.solver_iters
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    x, summ = solver.solve(x0, opt)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el, float(mine)], dtype=torch.float64, device=dev)
+    tsum = tt.clone()
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    el = float(tt[0].item())
+    out = {"value": round(int(summ.iterations) / el, 3), "unit": "iterations/s", "iterations": int(summ.iterations),
+           "residuals": int(tsum[1].item()), "control_points": C, "unknowns": 9 + 6 * C, "seconds": round(el, 4),
+           "initial_cost": float(summ.initial_cost), "final_cost": float(summ.final_cost),
+           "intrinsics_rel_err_after": float(np.abs(x[:4] / x_gt[:4] - 1).max()),
+           "allreduce_doubles": {"per_jacobian_evaluation": 91 + 612 * (world - 1), "per_linear_solve": 1082 * world, "per_step": 4,
+                                 "once_at_the_end": int(9 + 7 * C)},
+           "sharding": "one spline, residuals cut by time at %d knots (3-control-point separators)" % (world - 1)}
+    if os.environ.get("ECAL_BENCH_SOLVER_CHECK") and rank == 0:
+        # test hook: the same problem in ONE solver, solved by rank 0 alone
+        full, _ = ST.make_problem(N, C, ta, tb, seed=4242, device=dev, round_pixels=True)
+        ref = Solver(ctx, full)
+        o2 = ref.default_options()
+        o2.max_num_iterations = args.solver_iters
+        xr, sr = ref.solve(x0, o2)
+        ref.close()
+        assert full["time"].shape[0] == out["residuals"], (full["time"].shape[0], out["residuals"])
+        out["check_vs_single_solver"] = {"intrinsics_rel_diff": float(np.abs(x[:9] / xr[:9] - 1).max()),
+                                         "control_points_abs_diff": float(np.abs(x[9:] - xr[9:]).max()),
+                                         "final_cost_rel_diff": float(abs(summ.final_cost / sr.final_cost - 1)),
+                                         "iterations": [int(summ.iterations), int(sr.iterations)]}
+    solver.close()
+    return out
+
 
 def ingest_leg(args, ctx, dev, world, rank, dist, torch, np, rate):
     """configs[4]: the stream starts in (pinned) HOST memory; chunks are uploaded with hipMemcpyAsync on a copy stream

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion", "ecal_solver_create_dev", "ecal_solver_num_residuals",
-    "ecal_associate_ranges_dev", "ecal_ref_nth_element_f64", "ecal_solver_create_from_stream", "ecal_rectify_keyframes",
+    "ecal_associate_ranges_dev", "ecal_ref_nth_element_f64", "ecal_solver_create_from_stream", "ecal_rectify_keyframes", "ecal_solver_time_shard_cuts",
     "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval", "ecal_spline_so3_refine",
 ]
 
@@ -424,6 +424,19 @@ def _declare_solver(L):
     L.ecal_solver_solve.restype = i32
     L.ecal_inverse_radial_distortion.argtypes = [vp, vp]
     L.ecal_inverse_radial_distortion.restype = None
+
+
+def time_shard_cuts(knots, n_cp, world_size):
+    """ecal_solver_time_shard_cuts: the world_size - 1 cut times of a spline's time shards (LmOptions.distributed = 2)."""
+    L = load_library()
+    L.ecal_solver_time_shard_cuts.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    L.ecal_solver_time_shard_cuts.restype = ctypes.c_int
+    kn = np.ascontiguousarray(knots, np.float64)
+    out = np.zeros(max(world_size - 1, 1))
+    rc = L.ecal_solver_time_shard_cuts(kn.ctypes.data, int(n_cp), int(world_size), out.ctypes.data)
+    if rc:
+        raise EcalError(rc, "ecal_solver_time_shard_cuts")
+    return out[:world_size - 1]
 
 
 def inverse_radial_distortion(k4):

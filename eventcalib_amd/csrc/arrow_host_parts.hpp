@@ -215,31 +215,56 @@ __attribute__((target("avx2,fma"))) inline void arrow_part_backsub(const ArrowWo
     }
 }
 
-// (S A S + diag(dd)) y = -S g with P interiors on the pool's threads; false if not positive definite
+// interiors of (nearly) equal size, separators of 3 control points between them: first control point and number of control
+// points of interior p.  The ONE place the cut is defined: the time-sharded multi-GPU mode cuts the residuals at the same
+// control points (ecal_solver_time_shard_cuts).
+inline void arrow_partition(uint32_t n_cp, int P, std::vector<uint32_t> &first_cp, std::vector<uint32_t> &num_cp) {
+    first_cp.resize(P);
+    num_cp.resize(P);
+    const uint32_t inner = n_cp - 3u * (uint32_t) (P - 1);
+    uint32_t at = 0;
+    for (int p = 0; p < P; p++) {
+        const uint32_t m = inner / P + ((uint32_t) p < inner % P ? 1u : 0u);
+        first_cp[p] = at;
+        num_cp[p] = m;
+        at += m + 3u;
+    }
+}
+
+// (S A S + diag(dd)) y = -S g with P interiors on the pool's threads; false if not positive definite.
+// only_part >= 0 (time-sharded ranks: one interior per rank): this process factorises and back-substitutes that interior only;
+// `exchange` sums pt.G (all P blocks; the other ranks' are zero here) and pt.ok over the ranks in between.  A holds this rank's
+// rows, the separators' and the intrinsics' rows summed over the ranks; y comes back with this interior, every separator and
+// the intrinsics filled in.
 inline bool solve_arrow_parts(const ArrowSystem &A, const std::vector<double> &scale, const std::vector<double> &dd, std::vector<double> &y,
-                              ArrowWorkspace &ws, ArrowParts &pt, HostPool &pool, int P) {
+                              ArrowWorkspace &ws, ArrowParts &pt, HostPool *pool, int P, int only_part = -1,
+                              const std::function<bool(ArrowParts &)> *exchange = nullptr) {
     const size_t nc = A.nc;
     const uint32_t n_cp = (uint32_t) (nc / 6);
     const double *sc = scale.data();
-    // interiors of (nearly) equal size, separators of 3 control points between them
     pt.P = P;
     pt.a.resize(P);
     pt.n.resize(P);
     {
-        const uint32_t inner = n_cp - 3u * (uint32_t) (P - 1);
-        uint32_t at = 0;
+        std::vector<uint32_t> f, m;
+        arrow_partition(n_cp, P, f, m);
         for (int p = 0; p < P; p++) {
-            const uint32_t m = inner / P + ((uint32_t) p < inner % P ? 1u : 0u);
-            pt.a[p] = 6 * (size_t) at;
-            pt.n[p] = 6 * (size_t) m;
-            at += m + 3u;
+            pt.a[p] = 6 * (size_t) f[p];
+            pt.n[p] = 6 * (size_t) m[p];
         }
     }
     ws.L.resize(nc * BW);
     pt.Z.resize(nc * APZ);
-    pt.G.resize((size_t) P * APZ * APZ);
+    pt.G.assign((size_t) P * APZ * APZ, 0.0);
     pt.ok.assign(P, 0);
-    pool.run(P, [&](int p) { arrow_part_factor(A, sc, dd.data(), ws, pt, p); });
+    if (only_part >= 0) {
+        arrow_part_factor(A, sc, dd.data(), ws, pt, only_part);
+        if (!exchange || !(*exchange)(pt)) return false;
+    } else if (pool) {
+        pool->run(P, [&](int p) { arrow_part_factor(A, sc, dd.data(), ws, pt, p); });
+    } else {
+        for (int p = 0; p < P; p++) arrow_part_factor(A, sc, dd.data(), ws, pt, p);
+    }
     for (int p = 0; p < P; p++)
         if (!pt.ok[p]) return false;
     // reduced system over [separator 0 .. separator P-2 | intrinsics]: block tridiagonal + dense border, skyline Cholesky
@@ -312,6 +337,9 @@ inline bool solve_arrow_parts(const ArrowSystem &A, const std::vector<double> &s
     for (int j = 0; j < 9; j++) y[nc + j] = yr[NS + j];
     for (int s = 0; s + 1 < P; s++)
         for (int i = 0; i < APW; i++) y[pt.a[s] + pt.n[s] + i] = yr[APW * s + i];
-    pool.run(P, [&](int p) { arrow_part_backsub(ws, pt, p, yr.data(), y.data()); });
+    if (only_part >= 0) arrow_part_backsub(ws, pt, only_part, yr.data(), y.data());
+    else if (pool) pool->run(P, [&](int p) { arrow_part_backsub(ws, pt, p, yr.data(), y.data()); });
+    else
+        for (int p = 0; p < P; p++) arrow_part_backsub(ws, pt, p, yr.data(), y.data());
     return true;
 }

@@ -1370,11 +1370,28 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     // Distributed segments (ecal_lm_options.distributed): every rank owns its own spline segments in its own
     // ecal_solver; only the 9 intrinsics are shared.  Per evaluation the 91-double head is all-reduced; per linear solve
     // the 10 x 10 Schur sums (+ a failure flag and one slot per rank for the gradient max-norm); per step four scalars.
-    const bool dist_mode = opt.distributed != 0 && opt.allreduce != nullptr;
+    // distributed == 2, time shards of ONE spline: every rank holds the whole spline layout and the residuals
+    // of its time range — the spline's control points cut into `world` interiors with 3-control-point separators
+    // (arrow_partition; ecal_solver_time_shard_cuts gives the caller the cut times).  Per evaluation the head and the
+    // separators' records are all-reduced (91 + 612 (N - 1) doubles), per linear solve the interiors' 46 x 46 Gram blocks
+    // (1082 N doubles); every rank factorises its own interior, solves the small reduced system redundantly and
+    // back-substitutes its own control points.  Nothing proportional to the number of control points crosses the links
+    // until the solution is put together at the end (one all-reduce of the parameter vector).
+    const bool ts_mode = opt.distributed == 2 && opt.allreduce != nullptr;
+    const bool dist_mode = (opt.distributed == 1 && opt.allreduce != nullptr) || ts_mode;
     const int world = dist_mode ? std::max(1, opt.world_size) : 1, my_rank = dist_mode ? opt.rank : 0;
     if (dist_mode && (my_rank < 0 || my_rank >= world || world > 1024)) return ECAL_ERR_INVALID;
+    std::vector<uint32_t> ts_first, ts_num;   // interiors (control points) of the time shards
+    if (ts_mode) {
+        if (s->n_seg != 1 || (uint32_t) (7 * world) > s->n_cp) {
+            ctx->last_error = "time-sharded solve: one spline segment with at least 7 control points per rank";
+            return ECAL_ERR_INVALID;
+        }
+        arrow_partition(s->n_cp, world, ts_first, ts_num);
+    }
+    constexpr size_t TS_G = (size_t) APZ * (APZ + 1) / 2 + 1;   // upper triangle of an interior's Gram block + its flag
     double *d_small = nullptr, *h_small = nullptr;
-    const size_t n_small = 128 + (size_t) world;
+    const size_t n_small = std::max<size_t>(128 + (size_t) world, ts_mode ? std::max<size_t>(TS_G * (size_t) world, ACC_HEAD + 3 * ACC_PER_CP * (size_t) (world - 1)) : 0);
     if (dist_mode) {
         ECAL_HIP_TRY(ctx, hipMalloc((void **) &d_small, n_small * sizeof(double)));
         if (hipHostMalloc((void **) &h_small, n_small * sizeof(double), hipHostMallocDefault) != hipSuccess) {
@@ -1411,7 +1428,22 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         int rc = ecal_solver_evaluate_dev(s, s->d_params, with_jac, s->d_accum, st);
         if (rc) return rc;
         const size_t n = with_jac ? na : 1;
-        if (opt.allreduce) {  // per-GPU partials summed over ranks (RCCL all-reduce supplied by the caller)
+        if (opt.allreduce && ts_mode && with_jac) {
+            // time shards: the head and the separators' records (3 control points per cut) are what two ranks both add to
+            size_t at = ACC_HEAD;
+            hipError_t e2 = hipMemcpyAsync(d_small, s->d_accum, ACC_HEAD * sizeof(double), hipMemcpyDeviceToDevice, st);
+            for (int c = 0; c + 1 < world && e2 == hipSuccess; c++, at += 3 * ACC_PER_CP)
+                e2 = hipMemcpyAsync(d_small + at, s->d_accum + ACC_HEAD + ACC_PER_CP * (size_t) (ts_first[c] + ts_num[c]),
+                                    3 * ACC_PER_CP * sizeof(double), hipMemcpyDeviceToDevice, st);
+            if (e2 != hipSuccess) return ECAL_ERR_HIP;
+            if (opt.allreduce(opt.allreduce_user, d_small, at, st) != 0) return ECAL_ERR_HIP;
+            e2 = hipMemcpyAsync(s->d_accum, d_small, ACC_HEAD * sizeof(double), hipMemcpyDeviceToDevice, st);
+            at = ACC_HEAD;
+            for (int c = 0; c + 1 < world && e2 == hipSuccess; c++, at += 3 * ACC_PER_CP)
+                e2 = hipMemcpyAsync(s->d_accum + ACC_HEAD + ACC_PER_CP * (size_t) (ts_first[c] + ts_num[c]), d_small + at,
+                                    3 * ACC_PER_CP * sizeof(double), hipMemcpyDeviceToDevice, st);
+            if (e2 != hipSuccess) return ECAL_ERR_HIP;
+        } else if (opt.allreduce) {  // per-GPU partials summed over ranks (RCCL all-reduce supplied by the caller)
             // distributed segments: only the head (cost, intrinsics gradient and block) is shared between ranks
             rc = opt.allreduce(opt.allreduce_user, s->d_accum, dist_mode ? std::min(n, (size_t) ACC_HEAD) : n, st);
             if (rc) return ECAL_ERR_HIP;
@@ -1435,6 +1467,33 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     if ((uint32_t) (7 * n_parts) > s->n_cp) n_parts = 1;
     // (sharded segments: unpacking and the quadratic forms still use the pool, the factorisation stays the sequential routine)
     const bool parts_solve = !dist_mode;
+    // time shards: the interiors' Gram blocks (upper triangles) + a "positive definite" flag, one slot per rank, summed
+    ArrowParts ts_parts;
+    const std::function<bool(ArrowParts &)> ts_exchange = [&](ArrowParts &pt) -> bool {
+        std::vector<double> buf(TS_G * (size_t) world, 0.0);
+        double *mine = buf.data() + TS_G * (size_t) my_rank;
+        const double *G = pt.G.data() + (size_t) my_rank * APZ * APZ;
+        size_t k = 0;
+        bool finite = true;
+        for (int i = 0; i < APZ; i++)
+            for (int j = i; j < APZ; j++) {
+                finite = finite && std::isfinite(G[(size_t) i * APZ + j]);
+                mine[k++] = G[(size_t) i * APZ + j];
+            }
+        if (!finite)
+            for (size_t q = 0; q + 1 < TS_G; q++) mine[q] = 0.0;
+        mine[TS_G - 1] = (pt.ok[my_rank] && finite) ? 1.0 : 0.0;
+        if (!reduce_small(buf.data(), buf.size())) return false;
+        for (int p = 0; p < world; p++) {
+            const double *src = buf.data() + TS_G * (size_t) p;
+            double *Gp = pt.G.data() + (size_t) p * APZ * APZ;
+            size_t q = 0;
+            for (int i = 0; i < APZ; i++)
+                for (int j = i; j < APZ; j++) Gp[(size_t) i * APZ + j] = src[q++];
+            pt.ok[p] = src[TS_G - 1] == 1.0 ? 1 : 0;
+        }
+        return true;
+    };
     std::unique_ptr<HostPool> pool;
     double t_unpack = 0, t_pool = 0;
     if (n_parts > 1) {   // (the workers start while the GPU runs the first evaluation)
@@ -1511,10 +1570,31 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             dd[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
         }
         const auto tl = now();
-        bool ok = (n_parts > 1 && parts_solve) ? solve_arrow_parts(A, scale, dd, delta, ws, parts, *pool, n_parts)
-                                               : solve_arrow(A, scale, dd, delta, ws);
+        bool ok = ts_mode ? solve_arrow_parts(A, scale, dd, delta, ws, ts_parts, nullptr, world, my_rank, &ts_exchange)
+                  : (n_parts > 1 && parts_solve) ? solve_arrow_parts(A, scale, dd, delta, ws, parts, pool.get(), n_parts)
+                                                 : solve_arrow(A, scale, dd, delta, ws);
         double model_change = 0;
-        if (ok) {
+        if (ok && ts_mode) {
+            // the step solves (H + D) y = -g exactly, so y^T H y = -g^T y - y^T D y and the model change -g^T y - y^T H y / 2 is
+            // (y^T D y - g^T y) / 2: sums over unknowns — this rank's interior, rank 0 also the separators and the intrinsics
+            // (every rank holds the same values for those)
+            double two[2] = {0, 0};
+            auto add = [&](size_t i) {
+                const double g = i < nc ? A.gc[i] : A.gi[i - nc];
+                two[0] += g * scale[i] * delta[i];
+                two[1] += dd[i] * delta[i] * delta[i];
+            };
+            for (size_t i = 6 * (size_t) ts_first[my_rank]; i < 6 * (size_t) (ts_first[my_rank] + ts_num[my_rank]); i++) add(i);
+            if (my_rank == 0) {
+                for (int c = 0; c + 1 < world; c++)
+                    for (size_t i = 6 * (size_t) (ts_first[c] + ts_num[c]); i < 6 * (size_t) (ts_first[c] + ts_num[c] + 3); i++) add(i);
+                for (size_t i = nc; i < nt; i++) add(i);
+            }
+            if (!reduce_small(two, 2)) return ECAL_ERR_HIP;
+            for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
+            model_change = 0.5 * (two[1] - two[0]);
+            ok = model_change > 0.0;
+        } else if (ok) {
             for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
             double gTd, dHd;
             quad_forms(A, delta, &gTd, &dHd, dist_mode && my_rank != 0, pool.get(), n_parts);
@@ -1546,7 +1626,24 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         else S.cost_evaluations++;
         const double rel = (cost - new_cost) / model_change;
         double step2 = 0, x2 = 0;
-        if (dist_mode) {  // own control points from every rank, the shared intrinsics once
+        if (ts_mode) {   // own interior from every rank; separators and intrinsics once (rank 0)
+            auto own = [&](uint32_t c) {
+                for (int k = 0; k < 6; k++) step2 += delta[6 * (size_t) c + k] * delta[6 * (size_t) c + k];
+                for (int k = 0; k < 4; k++) x2 += x[9 + 4 * (size_t) c + k] * x[9 + 4 * (size_t) c + k];
+                for (int k = 0; k < 3; k++) x2 += x[9 + 4 * (size_t) s->n_cp + 3 * (size_t) c + k] * x[9 + 4 * (size_t) s->n_cp + 3 * (size_t) c + k];
+            };
+            for (uint32_t c = ts_first[my_rank]; c < ts_first[my_rank] + ts_num[my_rank]; c++) own(c);
+            if (my_rank == 0) {
+                for (int q = 0; q + 1 < world; q++)
+                    for (uint32_t c = ts_first[q] + ts_num[q]; c < ts_first[q] + ts_num[q] + 3; c++) own(c);
+                for (size_t i = nc; i < nt; i++) step2 += delta[i] * delta[i];
+                for (size_t i = 0; i < 9; i++) x2 += x[i] * x[i];
+            }
+            double two[2] = {step2, x2};
+            if (!reduce_small(two, 2)) return ECAL_ERR_HIP;
+            step2 = two[0];
+            x2 = two[1];
+        } else if (dist_mode) {  // own control points from every rank, the shared intrinsics once
             for (size_t i = 0; i < nc; i++) step2 += delta[i] * delta[i];
             for (size_t i = 9; i < np; i++) x2 += x[i] * x[i];
             double two[2] = {step2, x2};
@@ -1587,6 +1684,27 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         if (S.termination == 1 && std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(x2) + opt.parameter_tolerance))
             S.termination = 0;
     }
+    if (ts_mode) {
+        // the solution put together: every rank contributes its interior, rank 0 the separators and the intrinsics (the one
+        // exchange proportional to the spline's length, once per solve)
+        std::vector<double> mine(np, 0.0);
+        auto take = [&](uint32_t c) {
+            for (int k = 0; k < 4; k++) mine[9 + 4 * (size_t) c + k] = x[9 + 4 * (size_t) c + k];
+            for (int k = 0; k < 3; k++) mine[9 + 4 * (size_t) s->n_cp + 3 * (size_t) c + k] = x[9 + 4 * (size_t) s->n_cp + 3 * (size_t) c + k];
+        };
+        for (uint32_t c = ts_first[my_rank]; c < ts_first[my_rank] + ts_num[my_rank]; c++) take(c);
+        if (my_rank == 0) {
+            for (int q = 0; q + 1 < world; q++)
+                for (uint32_t c = ts_first[q] + ts_num[q]; c < ts_first[q] + ts_num[q] + 3; c++) take(c);
+            for (int i = 0; i < 9; i++) mine[i] = x[i];
+        }
+        memcpy(xpin, mine.data(), np * sizeof(double));
+        if (hipMemcpyAsync(s->d_params, xpin, np * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return ECAL_ERR_HIP;
+        if (opt.allreduce(opt.allreduce_user, s->d_params, np, st) != 0) return ECAL_ERR_HIP;
+        if (hipMemcpyAsync(xpin, s->d_params, np * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return ECAL_ERR_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return ECAL_ERR_HIP;
+        memcpy(x.data(), xpin, np * sizeof(double));
+    }
     S.final_cost = cost;
     S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     S.seconds_evaluate = t_eval;
@@ -1596,6 +1714,18 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
                 t_eval, t_lin, n_parts, t_unpack, t_pool);
     memcpy(params, x.data(), np * sizeof(double));
     if (sum) *sum = S;
+    return ECAL_OK;
+}
+
+// The time shards of one spline (ecal_lm_options.distributed == 2): cut_time[c] for c < world - 1 — rank r owns the residuals
+// with cut_time[r - 1] <= t < cut_time[r] (rank 0 from the first knot, the last rank to the last).  The cuts sit on knots: the
+// control points are cut into `world` interiors with 3-control-point separators, the partition of the host's own multi-core
+// solve (arrow_partition); a residual left of the knot behind a separator touches no control point right of it and vice versa.
+extern "C" int ecal_solver_time_shard_cuts(const double *knots, uint32_t n_cp, int world, double *cut_time) {
+    if (!knots || !cut_time || world < 1 || (uint32_t) (7 * world) > n_cp) return ECAL_ERR_INVALID;
+    std::vector<uint32_t> f, m;
+    arrow_partition(n_cp, world, f, m);
+    for (int c = 0; c + 1 < world; c++) cut_time[c] = knots[f[c] + m[c] + 3];   // spans up to (first separator CP + 2) stay left
     return ECAL_OK;
 }
 
@@ -1634,7 +1764,7 @@ extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const
             if (P < 2) P = 4;
             if ((uint32_t) (7 * P) > s->n_cp) return ECAL_ERR_RANGE;
             HostPool pool(3);
-            ok = solve_arrow_parts(A, sc, dd, y, ws, parts, pool, P);
+            ok = solve_arrow_parts(A, sc, dd, y, ws, parts, &pool, P);
         } else {
             ok = solve_arrow(A, sc, dd, y, ws);
         }

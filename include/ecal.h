@@ -539,15 +539,23 @@ typedef struct ecal_lm_options {
     int jacobi_scaling;
     ecal_allreduce_fn allreduce; /* NULL: this rank alone.  ecal_comm_allreduce (+ allreduce_user = ctx): the context's RCCL communicator */
     void *allreduce_user;
-    /* distributed != 0 (needs allreduce): every rank owns its OWN spline segments in its own ecal_solver (its residuals,
+    /* distributed == 1 (needs allreduce): every rank owns its OWN spline segments in its own ecal_solver (its residuals,
      * its control points) and only the 9 intrinsics are shared.  Exchanged per evaluation: the 91-double head (cost,
      * intrinsics gradient and block); per linear solve: the 10 x 10 Schur sums of the rank's banded factorisation + a
      * failure flag + one slot per rank (gradient max-norm); per step: four scalars.  Every rank factorises only its own
      * band and returns its own control points; all ranks return the same intrinsics, cost and summary.
      * distributed == 0 with allreduce set: every rank holds the whole parameter vector and the whole normal-equation
-     * buffer is summed (residuals of one segment may then be spread over ranks). */
+     * buffer is summed (residuals of one segment may then be spread over ranks).
+     * distributed == 2 (needs allreduce): TIME SHARDS OF ONE SPLINE — every rank builds its ecal_solver with
+     * the whole spline layout (one segment) and the residuals of ITS time range, cut at ecal_solver_time_shard_cuts' times, and
+     * passes the same start vector.  The control points fall into world_size interiors separated by 3-control-point
+     * separators; exchanged per Jacobian evaluation: the 91-double head + the separators' records (612 doubles per cut); per
+     * linear solve: the interiors' 46 x 46 Gram blocks (1082 doubles per rank); per step: four scalars; once at the end: the
+     * parameter vector.  Every rank factorises its own interior and all return the same, complete solution. */
     int distributed, rank, world_size;
 } ecal_lm_options;
+/* cut_time [world_size - 1]: rank r owns the residuals with cut_time[r - 1] <= t < cut_time[r] (distributed == 2) */
+int ecal_solver_time_shard_cuts(const double *knots /*[n_cp + 4]*/, uint32_t n_cp, int world_size, double *cut_time);
 typedef struct ecal_lm_summary {
     int iterations, successful_steps, unsuccessful_steps, jacobian_evaluations, cost_evaluations;
     int termination; /* 0 = converged (a tolerance fired), 1 = max_num_iterations reached */

@@ -41,8 +41,10 @@ def quat_rotate(q, v):
     return v + w * uv + torch.cross(u, uv, dim=1)
 
 
-def make_problem(n_res, n_cp, t0, t1, seed=0, device="cpu", round_pixels=True, intr=SV.GT_INTR, chunk=1 << 22):
-    """Returns (problem dict of numpy arrays, ground-truth parameter vector)."""
+def make_problem(n_res, n_cp, t0, t1, seed=0, device="cpu", round_pixels=True, intr=SV.GT_INTR, chunk=1 << 22, k_range=None):
+    """Returns (problem dict of numpy arrays, ground-truth parameter vector).  k_range = (lo, hi): only the residuals
+    lo .. hi - 1 of the n_res (they are in time order) — a time range of the SAME problem, for sharding one spline over
+    ranks: the chunks are generated whole (seeded by index) and cut."""
     dev = torch.device(device)
     knots = uniform_knots(n_cp, t0, t1)
     q_cp, t_cp = SV.gt_control_points(n_cp, t0, t1)
@@ -54,7 +56,8 @@ def make_problem(n_res, n_cp, t0, t1, seed=0, device="cpu", round_pixels=True, i
     obs_l, time_l, lm_l = [], [], []
     g = torch.Generator(device=dev)
     dt = (t1 - t0) / (n_cp - 3)
-    for k0 in range(0, n_res, chunk):
+    k_lo, k_hi = (0, n_res) if k_range is None else (max(0, int(k_range[0])), min(n_res, int(k_range[1])))
+    for k0 in range((k_lo // chunk) * chunk, k_hi, chunk):
         n = min(chunk, n_res - k0)
         g.manual_seed(seed * 7919 + k0 // chunk)
         # times: the k-th of n_res equally spaced instants, jittered inside its cell (sorted by construction)
@@ -87,9 +90,10 @@ def make_problem(n_res, n_cp, t0, t1, seed=0, device="cpu", round_pixels=True, i
         px = torch.stack([it[0] * pd[:, 0] + it[2], it[1] * pd[:, 1] + it[3]], 1)
         if round_pixels:
             px = torch.floor(px)          # the sensor reports integer pixels
-        obs_l.append(px.cpu())
-        time_l.append(u.cpu())
-        lm_l.append(lm.to(torch.int32).cpu())
+        a, b_ = max(k_lo, k0) - k0, min(k_hi, k0 + n) - k0
+        obs_l.append(px[a:b_].cpu())
+        time_l.append(u[a:b_].cpu())
+        lm_l.append(lm[a:b_].to(torch.int32).cpu())
     problem = dict(seg_cp_off=np.array([0, n_cp], np.uint32), knots=knots, obs=torch.cat(obs_l).numpy(),
                    time=torch.cat(time_l).numpy(), lm_id=torch.cat(lm_l).numpy().astype(np.uint32), seg_id=None,
                    landmarks=SV.landmarks(), circle_radius=SV.RADIUS, huber_a=0.2 * SV.RADIUS)

@@ -66,3 +66,10 @@ def test_two_ranks_match_one_rank():
     chk = two["solver"]["check_vs_single_solver"]
     assert chk["iterations"][0] == chk["iterations"][1]
     assert chk["intrinsics_rel_diff"] < 1e-8 and chk["final_cost_rel_diff"] < 1e-9 and chk["own_control_points_abs_diff"] < 1e-7
+    # time shards of ONE spline (distributed = 2): the two ranks' solve == one solver over all residuals
+    ts = two["solver"]["time_sharded_spline"]
+    tc = ts["check_vs_single_solver"]
+    assert ts["residuals"] == two["solver"]["residuals"] and ts["control_points"] == two["solver"]["control_points"]
+    assert tc["iterations"][0] == tc["iterations"][1]
+    assert tc["intrinsics_rel_diff"] < 1e-8 and tc["final_cost_rel_diff"] < 1e-9 and tc["control_points_abs_diff"] < 1e-6
+    assert ts["allreduce_doubles"]["per_jacobian_evaluation"] == 91 + 612 and ts["final_cost"] < ts["initial_cost"]
