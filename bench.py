@@ -115,7 +115,8 @@ def main():
     S = len(t0)
 
     eps, minpts = 4.0, 2                                   # example.yaml:68-71
-    # size hints from an untimed pass (lets the launcher skip empty size tiers)
+    # an untimed pass for the workload's description (config.*); the TIMED passes get no size hints from it: max_win_events
+    # = max_seg_points = 0 ("unknown"), every size tier is launched — what a first pass over new data costs
     pipe.run(events, eps, minpts)
     torch.cuda.synchronize(dev)
     assert not pipe.overflowed()
@@ -126,7 +127,7 @@ def main():
     n_cand = int(pipe.win_info[:S, 0].sum().item())
 
     def step():
-        pipe.run(events, eps, minpts, max_win_events=max_win, max_seg_points=max_seg)
+        pipe.run(events, eps, minpts)
 
     def barrier():
         if world > 1:
@@ -140,6 +141,7 @@ def main():
     c = ctx
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     pipe.set_detect_params(5, 36, ctx.circle_radius_threshold(346, 260, 9, 4, True, 5.5, 1.75))
+    pk = pipe._pk()
     barrier()
     t_begin = time.perf_counter()
     for k in range(args.steps):
@@ -148,20 +150,22 @@ def main():
         c.window_bounds_dev(events.data_ptr(), n, pipe.t0.data_ptr(), pipe.t1.data_ptr(), S, pipe.win_lo.data_ptr(),
                             pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(), st.cuda_stream)
         ev[k][1].record(st)
-        c.slice_events_dev(events.data_ptr(), n, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(),
-                           pipe.win_base.data_ptr(), S, max_win, n, pipe.xy.data_ptr(), pipe.seg_off.data_ptr(),
-                           pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(), pipe.flags.data_ptr(), st.cuda_stream)
+        # the three stages on packed points (ecal_packed_points): integer-pixel windows travel as 4-byte words between the
+        # stages; the doubles of positiveEvents_ / negativeEvents_ are written on request only (pipe.xy), outside this loop
+        c.slice_events_packed_dev(events.data_ptr(), n, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(), S, 0, n,
+                                  pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(),
+                                  pipe.flags.data_ptr(), pk, st.cuda_stream)
         ev[k][2].record(st)
-        c.dbscan_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * S, n, max_seg,
-                           eps, minpts, pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), st.cuda_stream)
+        c.dbscan_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * S, n, 0,
+                                  eps, minpts, pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), pk, st.cuda_stream)
         ev[k][3].record(st)
         # the exact extraction (the library's default): plain pass + the reference's member order for the clusters whose median
         # is tied in norm + re-extraction of their windows
-        c.extract_batch_exact_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
-                                  pipe.n_clusters.data_ptr(), S, n, eps, pipe.det[0], pipe.det[1], pipe.det[2],
-                                  pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
-                                  pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream, fit_circle=pipe.det[3],
-                                  knn_num=pipe.det[4])
+        c.extract_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
+                                   pipe.n_clusters.data_ptr(), S, n, eps, pipe.det[0], pipe.det[1], pipe.det[2],
+                                   pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
+                                   pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), pk, st.cuda_stream, fit_circle=pipe.det[3],
+                                   knn_num=pipe.det[4])
         ev[k][4].record(st)
     barrier()
     elapsed = time.perf_counter() - t_begin
@@ -182,7 +186,7 @@ def main():
     if rank == 0 and args.steps > 0:
         def fused_step():
             c.detect_fused_dev(events.data_ptr(), n_events, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(),
-                               S, max_win, max_seg, n_events, eps, minpts, pipe.det[0], pipe.det[1], pipe.det[2], pipe.xy.data_ptr(),
+                               S, 0, 0, n_events, eps, minpts, pipe.det[0], pipe.det[1], pipe.det[2], pipe._xy.data_ptr(),
                                pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(), pipe.flags.data_ptr(),
                                pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(),
                                pipe.cand_xyr.data_ptr(), pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream,
@@ -198,10 +202,15 @@ def main():
         fused_ms = fe[0].elapsed_time(fe[1]) / args.steps
         # the plain extraction (smaller pid at tied medians: ecal_extract_batch_dev alone), for comparison
         def plain_extract():
-            c.extract_batch_dev(pipe.xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
-                                pipe.n_clusters.data_ptr(), S, n_events, pipe.det[0], pipe.det[1], pipe.det[2], pipe.win_info.data_ptr(),
-                                pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(), pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(),
-                                st.cuda_stream, fit_circle=pipe.det[3], knn_num=pipe.det[4])
+            c.set_median_ties(1)       # ECAL_TIES_SMALLER_PID: the plain extraction, same packed points
+            try:
+                c.extract_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
+                                           pipe.n_clusters.data_ptr(), S, n_events, eps, pipe.det[0], pipe.det[1], pipe.det[2],
+                                           pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
+                                           pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), pk, st.cuda_stream, fit_circle=pipe.det[3],
+                                           knn_num=pipe.det[4])
+            finally:
+                c.set_median_ties(0)
         plain_extract()
         fe[0].record(st)
         for _ in range(args.steps):

@@ -24,8 +24,14 @@ EXPORTED_SYMBOLS = [
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion", "ecal_solver_create_dev", "ecal_solver_num_residuals",
     "ecal_associate_ranges_dev", "ecal_ref_nth_element_f64", "ecal_solver_create_from_stream", "ecal_rectify_keyframes", "ecal_solver_time_shard_cuts",
+    "ecal_slice_events_packed_dev", "ecal_dbscan_batch_packed_dev", "ecal_extract_batch_packed_dev", "ecal_unpack_points_dev",
     "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval", "ecal_spline_so3_refine",
 ]
+
+
+class PackedPoints(ctypes.Structure):
+    """ecal_packed_points: d_xy16 [cap_points] u32 (x | y << 16), d_seg_fmt [2S] u32 (0 doubles, 1 packed, 3 both)."""
+    _fields_ = [("d_xy16", ctypes.c_void_p), ("d_seg_fmt", ctypes.c_void_p)]
 
 
 class RectifyParams(ctypes.Structure):
@@ -259,6 +265,58 @@ class Context:
         self._check(self._L.ecal_slice_events_dev(self._h, d_events, int(n_events), d_win_lo, d_win_hi, d_win_base,
                                                   int(S), int(max_win_events), int(cap_points), d_xy, d_seg_off,
                                                   d_seg_cnt, d_event_point, d_overflow, stream))
+
+    # ---- the three stages on packed points (ecal_packed_points) ----
+    def slice_events_packed_dev(self, d_events, n_events, d_win_lo, d_win_hi, d_win_base, S, max_win_events, cap_points,
+                                d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, pk, stream=0):
+        L = self._L
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        L.ecal_slice_events_packed_dev.argtypes = [vp, vp, ctypes.c_uint64, vp, vp, vp, u32, u32, u32, vp, vp, vp, vp, vp,
+                                                   ctypes.POINTER(PackedPoints), vp]
+        L.ecal_slice_events_packed_dev.restype = ctypes.c_int
+        self._check(L.ecal_slice_events_packed_dev(self._h, d_events, int(n_events), d_win_lo, d_win_hi, d_win_base, int(S),
+                                                   int(max_win_events), int(cap_points), d_xy, d_seg_off, d_seg_cnt, d_event_point,
+                                                   d_overflow, ctypes.byref(pk) if pk is not None else None, stream))
+
+    def dbscan_batch_packed_dev(self, d_xy, d_seg_off, d_seg_cnt, S, n_points, max_seg_points, eps, minpts, d_labels, d_n_clusters,
+                                pk, stream=0):
+        L = self._L
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        L.ecal_dbscan_batch_packed_dev.argtypes = [vp, vp, vp, vp, u32, u32, u32, ctypes.c_double, u32, vp, vp,
+                                                   ctypes.POINTER(PackedPoints), vp]
+        L.ecal_dbscan_batch_packed_dev.restype = ctypes.c_int
+        self._check(L.ecal_dbscan_batch_packed_dev(self._h, d_xy, d_seg_off, d_seg_cnt, int(S), int(n_points), int(max_seg_points),
+                                                   float(eps), int(minpts), d_labels, d_n_clusters,
+                                                   ctypes.byref(pk) if pk is not None else None, stream))
+
+    def extract_batch_packed_dev(self, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min, need_clusters,
+                                 radius_threshold, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, pk, stream=0,
+                                 fit_circle=False, knn_num=3):
+        """The extraction the context's median-ties setting asks for (exact by default), on packed points."""
+        L = self._L
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        L.ecal_extract_batch_packed_dev.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, ctypes.c_double, u32, u32, ctypes.c_double,
+                                                    ctypes.c_int, u32, vp, vp, vp, vp, vp, ctypes.POINTER(PackedPoints), vp]
+        L.ecal_extract_batch_packed_dev.restype = ctypes.c_int
+        self._check(L.ecal_extract_batch_packed_dev(self._h, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, int(S), int(n_points),
+                                                    float(eps), int(cluster_min), int(need_clusters), float(radius_threshold),
+                                                    int(bool(fit_circle)), int(knn_num), d_win_info, d_cand_pair, d_cand_xyr,
+                                                    d_kept_labels, d_rep, ctypes.byref(pk) if pk is not None else None, stream))
+
+    def unpack_points_dev(self, pk, d_seg_off, d_seg_cnt, n_segments, d_xy, stream=0):
+        L = self._L
+        vp = ctypes.c_void_p
+        L.ecal_unpack_points_dev.argtypes = [vp, ctypes.POINTER(PackedPoints), vp, vp, ctypes.c_uint32, vp, vp]
+        L.ecal_unpack_points_dev.restype = ctypes.c_int
+        self._check(L.ecal_unpack_points_dev(self._h, ctypes.byref(pk), d_seg_off, d_seg_cnt, int(n_segments), d_xy, stream))
+
+    def set_median_ties(self, mode):
+        self._L.ecal_set_median_ties.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._check(self._L.ecal_set_median_ties(self._h, int(mode)))
+
+    def get_median_ties(self):
+        self._L.ecal_get_median_ties.argtypes = [ctypes.c_void_p]
+        return int(self._L.ecal_get_median_ties(self._h))
 
     # ---- grid ordering ----
     def grid_order_dev(self, d_win_info, d_seg_off, d_cand_xyr, S, rows, cols, d_order, d_found, stream=0):

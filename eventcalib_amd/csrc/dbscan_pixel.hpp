@@ -177,7 +177,8 @@ __device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t
                                            const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
                                            const PxGeom &geom, uint32_t minpts, int32_t *__restrict__ labels,
                                            uint32_t *__restrict__ n_clusters, uint32_t *__restrict__ todo,
-                                           uint32_t *__restrict__ todo_count, uint32_t known_cnt = 0, uint32_t known_off = 0) {
+                                           uint32_t *__restrict__ todo_count, uint32_t known_cnt = 0, uint32_t known_off = 0,
+                                           const uint32_t *__restrict__ xy16 = nullptr, const uint32_t *__restrict__ seg_fmt = nullptr) {
     using L = PixelLayout<CAP>;
     using F = PxFmt<CAP>;
     using G = GeoI16;
@@ -266,17 +267,30 @@ __device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t
         // all of the thread's loads are issued before the first is used (index clamped instead of a branch around the
         // load): with the load inside `if (i < n)` the compiler waited for each one in turn — up to four serial HBM
         // round trips at the head of every workgroup
+        // (packed points, ecal_packed_points: a segment the slicer wrote as x | y << 16 is read as that — 4 bytes a point
+        // instead of 16, nothing to test: it holds sensor pixels)
+        const bool packed = xy16 && (seg_fmt[s] & 1u);
         double2 vin[PPT];
+        uint32_t win[PPT];
+        if (packed) {
 #pragma unroll
-        for (int u = 0; u < PPT; u++) vin[u] = src[min(tid + u * T, n - 1u)];
+            for (int u = 0; u < PPT; u++) win[u] = xy16[base + min(tid + u * T, n - 1u)];
+        } else {
+#pragma unroll
+            for (int u = 0; u < PPT; u++) vin[u] = src[min(tid + u * T, n - 1u)];
+        }
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
             const uint32_t i = tid + u * T;
             pp[u] = 0;
             if (i < n) {
-                const double2 v = vin[u];
-                fits = fits && G::fits(v);
-                pp[u] = G::pack(v);
+                if (packed) {
+                    pp[u] = win[u];
+                } else {
+                    const double2 v = vin[u];
+                    fits = fits && G::fits(v);
+                    pp[u] = G::pack(v);
+                }
                 slot[2 * i] = NONE32;
                 slot[2 * i + 1] = NONE32;
                 const short2v c = {(short) G::sx(pp[u]), (short) G::sy(pp[u])};
@@ -741,9 +755,10 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                                                             uint32_t minpts, int32_t *__restrict__ labels,
                                                             uint32_t *__restrict__ n_clusters,
                                                             uint32_t *__restrict__ todo,
-                                                            uint32_t *__restrict__ todo_count) {
+                                                            uint32_t *__restrict__ todo_count,
+                                                            const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
-    px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count);
+    px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt);
 }
 
 // second pass (CAP = PX_CAP2): the workgroups share the list of segments the first pass left over
@@ -757,11 +772,12 @@ __global__ __launch_bounds__(PX_T, 4) void dbscan_pixel_list_kernel(const double
                                                                  uint32_t *__restrict__ todo,
                                                                  uint32_t *__restrict__ todo_count,
                                                                  const uint32_t *__restrict__ in_list,
-                                                                 const uint32_t *__restrict__ in_count) {
+                                                                 const uint32_t *__restrict__ in_count,
+                                                                 const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        px_segment<E2I, CAP>(px_smem, in_list[k], xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count);
+        px_segment<E2I, CAP>(px_smem, in_list[k], xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt);
         __syncthreads();
     }
 }

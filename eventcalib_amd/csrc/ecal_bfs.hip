@@ -104,7 +104,8 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
                                                             uint8_t *__restrict__ list_cnt, int only_tied,
                                                             const uint32_t *__restrict__ win_list,
                                                             const uint32_t *__restrict__ win_count,
-                                                            uint32_t *__restrict__ defer_list, uint32_t *__restrict__ defer_cnt) {
+                                                            uint32_t *__restrict__ defer_list, uint32_t *__restrict__ defer_cnt,
+                                                            const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Coord = typename std::conditional<BoLayout<CAP>::CB == 4, float, double>::type;
     Coord *const px = reinterpret_cast<Coord *>(smem + BoLayout<CAP>::px_off);
@@ -181,9 +182,18 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
         if (tid < 8) red[tid] = 0;   // [0 .. 2]: block_any flags; [3]: failure; [4]: LDS list slots handed out; [5]: not floats
         bool inexact = false;
         uint32_t marked = 0;   // only_tied == 2: bit u = the caller's mark on point tid + u BO_T (read here, with the point)
+        // (packed points, first launch: a segment sliced into 4-byte pixel words is read as those; the later launches' segments
+        // have had their doubles written, ecal_cluster_order_sized)
+        const bool packed = TIER == 0 && xy16 && (seg_fmt[s] & 1u);
         for (uint32_t i = tid, u = 0; i < n; i += BO_T, u++) {
             if (only_tied == 2 && order[base + i] == -3) marked |= 1u << u;
-            const double2 p = reinterpret_cast<const double2 *>(xy)[base + i];
+            double2 p;
+            if (packed) {
+                const uint32_t w = xy16[base + i];
+                p = make_double2((double) (int) (short) (w & 0xFFFFu), (double) (((int) w) >> 16));
+            } else {
+                p = reinterpret_cast<const double2 *>(xy)[base + i];
+            }
             px[i] = (Coord) p.x;
             py[i] = (Coord) p.y;
             if (BoLayout<CAP>::CB == 4 && ((double) px[i] != p.x || (double) py[i] != p.y)) inexact = true;
@@ -837,9 +847,11 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
 int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                              uint32_t n_points, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
                              uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
-                             void *stream) {
+                             void *stream, const ecal_packed_points *pk) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
+    if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
+    const uint32_t *const xy16 = pk ? pk->d_xy16 : nullptr, *const sfmt = pk ? pk->d_seg_fmt : nullptr;
     if (!d_xy || !d_seg_off || !d_seg_cnt || !d_labels || !d_n_clusters || !d_order || !d_status) {
         ctx->last_error = "null pointer";
         return ECAL_ERR_INVALID;
@@ -881,11 +893,20 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
     // (The three launches are independent — a segment's size names its launch —, but starting the later ones on streams of
     // their own beside the first cost more in cross-stream waits than it saved: 0.74 against 0.65 ms per lock-step pass.)
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP1, BO_T1, 0>), dim3(grid1), dim3(BO_T1), BoLayout<BO_CAP1>::bytes, st, d_xy, d_seg_off,
-                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
+                       xy16, sfmt);
+    if (pk) {   // the later launches read doubles: the segments the first one listed for them are unpacked
+        int rcu;
+        for (int k = 0; k < 3; k++)
+            if ((rcu = ecal_unpack_listed(ctx, pk, dlist + (size_t) k * S, dcnt + k, S, d_seg_off, d_seg_cnt, const_cast<double *>(d_xy), 0, st)))
+                return rcu;
+    }
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP2, BO_T2, 1>), dim3(grid2), dim3(BO_T2), BoLayout<BO_CAP2>::bytes, st, d_xy, d_seg_off,
-                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
+                       nullptr, nullptr);
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP3, BO_T2, 2>), dim3(grid3), dim3(BO_T2), BoLayout<BO_CAP3>::bytes, st, d_xy, d_seg_off,
-                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt);
+                       d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
+                       nullptr, nullptr);
     hipLaunchKernelGGL(cluster_order_big_kernel, dim3(grid_big), dim3(BO_TB), 0, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels, d_n_clusters,
                        d_order, d_status, only_tied_medians, (const uint32_t *) dlist, (const uint32_t *) dcnt, big_ws, bigW, big_hits, big_arena);
     ECAL_HIP_TRY(ctx, hipGetLastError());

@@ -90,16 +90,20 @@ struct ecal_ctx {
         }                                                                                             \
     } while (0)
 
+// packed points: the doubles of the listed segments / windows (ecal_events.hip)
+int ecal_unpack_listed(ecal_ctx *ctx, const ecal_packed_points *pk, const uint32_t *d_list, const uint32_t *d_count, uint32_t S,
+                       const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, double *d_xy, int windows, hipStream_t st);
 // ecal_cluster_order_list_dev with the callers' bound on a segment's size (ecal_bfs.hip)
 int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                              uint32_t n_points, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
                              uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
-                             void *stream);
+                             void *stream, const ecal_packed_points *pk = nullptr);
 // extraction as the context's ecal_set_median_ties setting wants it (ecal_detect.hip): the exact form needs the DBSCAN radius
 int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
                          const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min,
                          uint32_t need_clusters, double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,
-                         uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream);
+                         uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream,
+                         const ecal_packed_points *pk = nullptr);
 // reference element order: the per-pixel bucket table of the hot-path slicer, built on first use (ecal_events.hip)
 int ecal_ensure_bucket_table(ecal_ctx *ctx, hipStream_t st);
 // n <= 16 words that are zero once everything enqueued on `st` so far has run, or nullptr (more streams than rings, no memory):

@@ -212,7 +212,19 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
                                      const uint32_t *d_seg_cnt, uint32_t S, uint32_t n_points, uint32_t max_seg_points,
                                      double eps, uint32_t minpts, int32_t *d_labels, uint32_t *d_n_clusters,
                                      void *stream) {
+    return ecal_dbscan_batch_packed_dev(ctx, const_cast<double *>(d_xy), d_seg_off, d_seg_cnt, S, n_points, max_seg_points, eps, minpts,
+                                        d_labels, d_n_clusters, nullptr, stream);
+}
+
+// pk != NULL: segments marked packed are read from pk->d_xy16; the ones the pixel kernels leave to the general tiers get their
+// doubles written into d_xy first (hence not const)
+extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const uint32_t *d_seg_off,
+                                            const uint32_t *d_seg_cnt, uint32_t S, uint32_t n_points, uint32_t max_seg_points,
+                                            double eps, uint32_t minpts, int32_t *d_labels, uint32_t *d_n_clusters,
+                                            const ecal_packed_points *pk, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
+    if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
+    const uint32_t *const xy16 = pk ? pk->d_xy16 : nullptr, *const sfmt = pk ? pk->d_seg_fmt : nullptr;
     if (minpts < 1) {
         ctx->last_error = "minpts < 1 (DBSCAN::Run returns FAILED)";
         return ECAL_ERR_INVALID;
@@ -258,18 +270,18 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC")) {
             if (!fused) hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
-                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
+                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt);
             if (second_pass)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<16, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
-                                   (const uint32_t *) list, (const uint32_t *) cnt);
+                                   (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt);
         } else {
             hipLaunchKernelGGL((dbscan_pixel_kernel<0, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
-                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt);
+                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt);
             if (second_pass)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<0, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
-                                   (const uint32_t *) list, (const uint32_t *) cnt);
+                                   (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt);
         }
         if (second_pass) {
             todo = list2;
@@ -280,6 +292,8 @@ extern "C" int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const ui
         }
         grid = S < 1024u ? S : 1024u;
     }
+    // the general tiers read doubles: what is left for them (everything, without the pixel kernels) is unpacked first
+    if (pk && (rc = ecal_unpack_listed(ctx, pk, todo, todo_count, S, d_seg_off, d_seg_cnt, d_xy, 0, st))) return rc;
     hipLaunchKernelGGL((dbscan_lds_kernel<CAP0, CAP0 / 4>), dim3(grid), dim3(CAP0 / 4), TierLayout<CAP0>::bytes, st, d_xy,
                        d_seg_off, d_seg_cnt, 0u, eps, minpts, d_labels, d_n_clusters, S, todo, todo_count);
     if (mx > (uint32_t) CAP0)

@@ -83,6 +83,33 @@ __global__ __launch_bounds__(DET_T) void extract_list_kernel(
 }
 
 
+// packed points: a packed window that the staged passes will not take (more points or clusters than the second pass stages)
+// reads doubles in the global path — they are written here, before the first pass.  A thread per window looks, a workgroup unpacks.
+__global__ __launch_bounds__(256) void unpack_unstaged_windows_kernel(uint32_t S, uint32_t pts_lim, uint32_t maxc_lim, const uint32_t *__restrict__ seg_off,
+                                                                       const uint32_t *__restrict__ seg_cnt,
+                                                                       const uint32_t *__restrict__ n_clusters,
+                                                                       const uint32_t *__restrict__ xy16, uint32_t *__restrict__ fmt,
+                                                                       double *__restrict__ xy) {
+    for (uint32_t w = blockIdx.x; w < S; w += gridDim.x) {
+        if (!(fmt[2 * w] & 1u) || fmt[2 * w] == 3u) continue;
+        const uint32_t n0 = seg_cnt[2 * w], n1 = seg_cnt[2 * w + 1];
+        const bool staged = seg_off[2 * w + 1] == seg_off[2 * w] + n0 && n0 + n1 <= pts_lim && n_clusters[2 * w] <= maxc_lim &&
+                            n_clusters[2 * w + 1] <= maxc_lim;
+        if (staged) continue;
+        for (int h = 0; h < 2; h++) {
+            const uint32_t o = seg_off[2 * w + h], n = h ? n1 : n0;
+            double2 *out = reinterpret_cast<double2 *>(xy) + o;
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t v = xy16[o + i];
+                out[i] = make_double2((double) (int) (short) (v & 0xFFFFu), (double) (((int) v) >> 16));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) fmt[2 * w] = fmt[2 * w + 1] = 3u;
+        __syncthreads();
+    }
+}
+
 }  // namespace ecal
 
 using namespace ecal;
@@ -120,9 +147,10 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                          double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair,
                          double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, int mode, const int32_t *d_order,
                          const uint32_t *d_in_list, const uint32_t *d_in_count, uint32_t *d_tie_list, uint32_t *d_tie_count, int32_t *d_tie_mark,
-                         void *stream) {
+                         void *stream, const ecal_packed_points *pk = nullptr) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
+    if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
     if (!d_seg_off || !d_seg_cnt || !d_n_clusters || !d_win_info ||
         (n_points && (!d_xy || !d_labels || !d_cand_pair || !d_cand_xyr || !d_kept_labels || !d_rep))) {
         ctx->last_error = "null pointer";
@@ -147,6 +175,8 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     prm.thr = radius_threshold;
     prm.fit_circle = fit_circle ? 1u : 0u;
     prm.knn = knn_num;
+    prm.xy16 = pk ? pk->d_xy16 : nullptr;
+    prm.seg_fmt = pk ? pk->d_seg_fmt : nullptr;
     if (fit_circle && (knn_num < 1 || knn_num > DET_KNN_MAX)) {
         ctx->last_error = "knn_num must be in 1..8 when fitCircle is set";
         return ECAL_ERR_INVALID;
@@ -201,6 +231,10 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                        d_labels, d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,    \
                        (const uint32_t *) list, (const uint32_t *) cnt, d_order, d_tie_list, d_tie_count, d_tie_mark)
     const bool fit = prm.fit_circle != 0;
+    if (pk && mode != 1)   // (mode 1 follows a mode-2 pass over the same windows: done there)
+        hipLaunchKernelGGL(unpack_unstaged_windows_kernel, dim3(S < 1024u ? S : 1024u), dim3(256), 0, st, S, second ? DET_LDS_PTS2 : DET_LDS_PTS,
+                           second ? DET_LDS_MAXC2 : DET_LDS_MAXC, d_seg_off, d_seg_cnt, d_n_clusters, (const uint32_t *) pk->d_xy16,
+                           pk->d_seg_fmt, const_cast<double *>(d_xy));
     if (fused && !fit) {
         const uint32_t *dcnt = (const uint32_t *) ctx->fused_def.ptr, *dlist = dcnt + 4;
         ECAL_DET_FIRST_LIST(false, 0, dlist, dcnt);
@@ -262,11 +296,22 @@ extern "C" int ecal_cluster_order_list_dev(ecal_ctx *ctx, const double *d_xy, co
                                            uint32_t S, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
                                            uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list,
                                            const uint32_t *d_win_count, void *stream);
+static int extract_exact(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
+                         const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min, uint32_t need_clusters,
+                         double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair,
+                         double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, const ecal_packed_points *pk, void *stream);
 extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
                                             const int32_t *d_labels, const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps,
                                             uint32_t cluster_min, uint32_t need_clusters, double radius_threshold, int fit_circle,
                                             uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
                                             int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
+    return extract_exact(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min, need_clusters, radius_threshold,
+                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, nullptr, stream);
+}
+static int extract_exact(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
+                         const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min, uint32_t need_clusters,
+                         double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair,
+                         double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, const ecal_packed_points *pk, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     int rc;
@@ -287,27 +332,38 @@ extern "C" int ecal_extract_batch_exact_dev(ecal_ctx *ctx, const double *d_xy, c
     if (!tcnt_zero) ECAL_HIP_TRY(ctx, hipMemsetAsync(tcnt, 0, sizeof(uint32_t), (hipStream_t) stream));
     if ((rc = extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                             fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 2, nullptr, nullptr, nullptr, tlist,
-                            tcnt, order, stream)))
+                            tcnt, order, stream, pk)))
         return rc;
     // (only_tied_medians = 2: the tied clusters are the ones whose representative's slot the plain pass marked in `order`)
     if ((rc = ecal_cluster_order_sized(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, n_points, eps, d_labels, d_n_clusters, order, ostatus, 2, tlist,
-                                       tcnt, stream)))
+                                       tcnt, stream, pk)))
         return rc;
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, order, tlist, tcnt, nullptr, nullptr,
-                         nullptr, stream);
+                         nullptr, stream, pk);
 }
 
 int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
                          const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min,
                          uint32_t need_clusters, double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,
-                         uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream) {
+                         uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream,
+                         const ecal_packed_points *pk) {
     if (ctx && ctx->median_ties == ECAL_TIES_REFERENCE)
-        return ecal_extract_batch_exact_dev(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min,
-                                            need_clusters, radius_threshold, fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr,
-                                            d_kept_labels, d_rep, stream);
-    return ecal_extract_batch_dev(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters,
-                                  radius_threshold, fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, stream);
+        return extract_exact(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min, need_clusters,
+                             radius_threshold, fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, pk, stream);
+    return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
+                         fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 0, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, stream, pk);
+}
+
+// the extraction the context's ecal_set_median_ties setting asks for, on packed points
+extern "C" int ecal_extract_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                             const int32_t *d_labels, const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps,
+                                             uint32_t cluster_min, uint32_t need_clusters, double radius_threshold, int fit_circle,
+                                             uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
+                                             int32_t *d_kept_labels, uint32_t *d_rep, const ecal_packed_points *pk, void *stream) {
+    return ecal_extract_for_ctx(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min, need_clusters,
+                                radius_threshold, fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, stream, pk);
 }
 
 extern "C" int ecal_set_median_ties(ecal_ctx *ctx, int mode) {

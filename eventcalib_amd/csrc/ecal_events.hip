@@ -670,10 +670,11 @@ __global__ __launch_bounds__(PXH_T) ECAL_RO_ATTR void slice_hash_ref_kernel(cons
                                                            int32_t *__restrict__ event_point, int *overflow,
                                                            uint32_t *__restrict__ todo,
                                                            uint32_t *__restrict__ todo_count,
-                                                           const uint2 *__restrict__ bucket_tab) {
+                                                           const uint2 *__restrict__ bucket_tab, uint32_t *__restrict__ xy16,
+                                                           uint32_t *__restrict__ seg_fmt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     slice_hash_window<11, true>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
-                                todo, todo_count, bucket_tab);
+                                todo, todo_count, bucket_tab, xy16, seg_fmt);
 }
 
 __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__restrict__ rec,
@@ -684,10 +685,11 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
                                                            uint32_t *__restrict__ seg_cnt,
                                                            int32_t *__restrict__ event_point, int *overflow,
                                                            uint32_t *__restrict__ todo,
-                                                           uint32_t *__restrict__ todo_count) {
+                                                           uint32_t *__restrict__ todo_count, uint32_t *__restrict__ xy16,
+                                                           uint32_t *__restrict__ seg_fmt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     slice_hash_window<11, false>(smem, blockIdx.x, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
-                                 todo, todo_count);
+                                 todo, todo_count, nullptr, xy16, seg_fmt);
 }
 
 // second pass: the workgroups share the list the first pass left (in_list[0 .. *in_count)); windows of up to 4095 events
@@ -702,12 +704,13 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_list_kernel(const uint8_t *_
                                                                 uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
                                                                 const uint32_t *__restrict__ in_list,
                                                                 const uint32_t *__restrict__ in_count,
-                                                                const uint2 *__restrict__ bucket_tab) {
+                                                                const uint2 *__restrict__ bucket_tab, uint32_t *__restrict__ xy16,
+                                                                uint32_t *__restrict__ seg_fmt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
         slice_hash_window<12, REFORDER>(smem, in_list[k], rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point,
-                              overflow, todo, todo_count, bucket_tab);
+                              overflow, todo, todo_count, bucket_tab, xy16, seg_fmt);
         __syncthreads();
     }
 }
@@ -819,13 +822,69 @@ int ecal_ensure_bucket_table(ecal_ctx *ctx, hipStream_t st) {
     return ECAL_OK;
 }
 
+// ---- packed points (ecal_packed_points): segments of integer pixels as x | y << 16, doubles on request -------------------------
+namespace {
+// the segments list[0 .. *count) (or all S when list == nullptr) that exist packed only get their doubles written (fmt 1 -> 3)
+__global__ __launch_bounds__(256) void unpack_segments_kernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, uint32_t S,
+                                                             const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+                                                             const uint32_t *__restrict__ xy16, uint32_t *__restrict__ fmt,
+                                                             double *__restrict__ xy, int windows) {
+    const uint32_t n_work = list ? *count : S;
+    for (uint32_t k = blockIdx.x; k < n_work; k += gridDim.x) {
+        const uint32_t e = list ? list[k] : k;
+        for (int h = 0; h < (windows ? 2 : 1); h++) {   // (a list of windows names both of their segments)
+            const uint32_t s = windows ? 2u * (e & 0x3FFFFFFFu) + (uint32_t) h : e;
+            if (fmt[s] != 1u) continue;
+            const uint32_t o = seg_off[s], n = seg_cnt[s];
+            double2 *out = reinterpret_cast<double2 *>(xy) + o;
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t w = xy16[o + i];
+                out[i] = make_double2((double) (int) (short) (w & 0xFFFFu), (double) (((int) w) >> 16));
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) fmt[s] = 3u;
+            __syncthreads();
+        }
+    }
+}
+}  // namespace
+
+// the doubles of the listed segments (list == nullptr: of all S segments; windows != 0: the list names windows, S counts segments)
+int ecal_unpack_listed(ecal_ctx *ctx, const ecal_packed_points *pk, const uint32_t *d_list, const uint32_t *d_count, uint32_t S,
+                       const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, double *d_xy, int windows, hipStream_t st) {
+    if (!pk || !pk->d_xy16 || !pk->d_seg_fmt || S == 0) return ECAL_OK;
+    const uint32_t grid = S < 1024u ? S : 1024u;
+    hipLaunchKernelGGL(unpack_segments_kernel, dim3(grid), dim3(256), 0, st, d_list, d_count, S, d_seg_off, d_seg_cnt,
+                       (const uint32_t *) pk->d_xy16, pk->d_seg_fmt, d_xy, windows);
+    ECAL_HIP_TRY(ctx, hipGetLastError());
+    return ECAL_OK;
+}
+
+extern "C" int ecal_unpack_points_dev(ecal_ctx *ctx, const ecal_packed_points *pk, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                      uint32_t n_segments, double *d_xy, void *stream) {
+    if (!ctx || !pk || !d_seg_off || !d_seg_cnt || !d_xy) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ecal_unpack_listed(ctx, pk, nullptr, nullptr, n_segments, d_seg_off, d_seg_cnt, d_xy, 0, (hipStream_t) stream);
+}
+
 extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events,
                                      const uint32_t *d_win_lo, const uint32_t *d_win_hi, const uint32_t *d_win_base,
                                      uint32_t S, uint32_t max_win_events, uint32_t cap_points, double *d_xy,
                                      uint32_t *d_seg_off, uint32_t *d_seg_cnt, int32_t *d_event_point, int *d_overflow,
                                      void *stream) {
+    return ecal_slice_events_packed_dev(ctx, d_events, n_events, d_win_lo, d_win_hi, d_win_base, S, max_win_events, cap_points, d_xy,
+                                        d_seg_off, d_seg_cnt, d_event_point, d_overflow, nullptr, stream);
+}
+
+extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events,
+                                            const uint32_t *d_win_lo, const uint32_t *d_win_hi, const uint32_t *d_win_base,
+                                            uint32_t S, uint32_t max_win_events, uint32_t cap_points, double *d_xy,
+                                            uint32_t *d_seg_off, uint32_t *d_seg_cnt, int32_t *d_event_point, int *d_overflow,
+                                            const ecal_packed_points *pk, void *stream) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
+    if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
+    uint32_t *const xy16 = pk ? pk->d_xy16 : nullptr, *const sfmt = pk ? pk->d_seg_fmt : nullptr;
     if ((n_events && !d_events) || !d_win_lo || !d_win_hi || !d_win_base || !d_seg_off || !d_seg_cnt || !d_overflow ||
         (cap_points && (!d_xy || !d_event_point))) {
         ctx->last_error = "null pointer";
@@ -852,6 +911,8 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
     // (fused pass, ecal_fused.hip: the first pass has run inside the fused kernel and has filled the first to-do list)
     const bool fused = ctx->fused_pass;
     if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
+    // (packed points: every segment starts as "doubles"; the pixel kernels mark the windows they pack)
+    if (sfmt) ECAL_HIP_TRY(ctx, hipMemsetAsync(sfmt, 0, 2 * (size_t) S * sizeof(uint32_t), st));
     const uint32_t mx = max_win_events ? max_win_events : 0xFFFFFFFFu;
     // pixel windows first; what they leave over (longer windows, non-integer coordinates) is listed for the general tiers
     const uint32_t *todo = nullptr, *todo_count = nullptr;
@@ -875,22 +936,22 @@ extern "C" int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
                 if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
                 if (!fused) hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
                                    d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt,
-                                   (const uint2 *) ctx->bucket_tab.ptr);
+                                   (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
             }
             else
                 hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
-                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, xy16, sfmt);
             // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
             if ((reforder || mx > PixHash<11>::CAP) && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
                 const uint32_t grid2 = S < 768u ? S : 768u;
                 if (reforder)
                     hipLaunchKernelGGL(slice_hash_list_kernel<true>, dim3(grid2), dim3(PXH_T), H12, st, d_events, d_win_lo,
                                        d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
-                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) ctx->bucket_tab.ptr);
+                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
                 else
                     hipLaunchKernelGGL(slice_hash_list_kernel<false>, dim3(grid2), dim3(PXH_T), PixHash<12>::bytes, st, d_events, d_win_lo,
                                        d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
-                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) nullptr);
+                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) nullptr, xy16, sfmt);
                 todo = list2;
                 todo_count = cnt2;
             }

@@ -45,6 +45,8 @@ struct DetectParams {
     double thr;              // circleRadiusThreshold_
     uint32_t fit_circle;     // Params::fitCircle
     uint32_t knn;            // Params::knn_num (<= DET_KNN_MAX)
+    const uint32_t *xy16;    // packed points (ecal_packed_points) or null: windows marked seg_fmt & 1 are staged from these
+    const uint32_t *seg_fmt; //   (a packed window that cannot be staged has had its doubles written before the launch)
 };
 constexpr uint32_t DET_KNN_MAX = 8;
 
@@ -764,19 +766,25 @@ __device__ __forceinline__ void extract_one(
         // inside `if (i < n_all)` the compiler waits for each one in turn — five trips to HBM in a row at the head of every
         // workgroup instead of one
         constexpr int JS = (int) ((PTS + DET_T - 1) / DET_T);
+        // (packed points: the window's pixels are read as the 4-byte words they were sliced into — a quarter of the bytes)
+        const bool packed = !KNOWN && prm.xy16 && (prm.seg_fmt[2 * s] & 1u);
         double2 vin[JS];
+        uint32_t win[JS];
         int32_t lin[JS];
 #pragma unroll
         for (int j = 0; j < JS; j++) {
             const uint32_t i = min(tid + j * DET_T, n_all - 1u);
-            vin[j] = pts[o_pol[0] + i];
+            if (packed) win[j] = prm.xy16[o_pol[0] + i];
+            else vin[j] = pts[o_pol[0] + i];
             lin[j] = labels[o_pol[0] + i];
         }
 #pragma unroll
         for (int j = 0; j < JS; j++) {
             const uint32_t i = tid + j * DET_T;
             if (i < n_all) {
-                const double2 v = vin[j];
+                double2 v;
+                if (packed) v = make_double2((double) (int) (short) (win[j] & 0xFFFFu), (double) (((int) win[j]) >> 16));
+                else v = vin[j];
                 fits = fits && v.x == floor(v.x) && v.y == floor(v.y) && fabs(v.x) <= 32767.0 && fabs(v.y) <= 32767.0;
                 large = large || !(fabs(v.x) <= KEY_LIM && fabs(v.y) <= KEY_LIM);
                 lds_pts[i] = ((uint32_t) (int) v.x & 0xFFFFu) | ((uint32_t) (int) v.y << 16);

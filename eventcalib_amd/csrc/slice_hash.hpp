@@ -237,7 +237,10 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
                                                   double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
                                                   uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point,
                                                   int *overflow, uint32_t *__restrict__ todo,
-                                                  uint32_t *__restrict__ todo_count, const uint2 *__restrict__ bucket_tab = nullptr) {
+                                                  uint32_t *__restrict__ todo_count, const uint2 *__restrict__ bucket_tab = nullptr,
+                                                  uint32_t *__restrict__ xy16 = nullptr, uint32_t *__restrict__ seg_fmt = nullptr) {
+    // xy16 / seg_fmt (ecal_packed_points): the window's points go out as x | y << 16 (4 bytes a point instead of 16: these ARE
+    // sensor pixels) and its two segments are marked 1 = "packed only"; the doubles are made on request (ecal_unpack_points_dev)
     using L = PixHash<LOGC>;
     constexpr int T = PXH_T;
 #ifdef ECAL_PHASE_PROF
@@ -648,10 +651,15 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
                         const uint32_t at = posE[meta[j] & 0xFFFu];
                         ep[k] = (int32_t) at;
                         if (meta[j] & 0x4000u) {
-                            double2 v;
-                            v.x = (double) (pix[j] >> 10);
-                            v.y = (double) (pix[j] & 0x3FFu);
-                            out2[(meta[j] & 0x2000u) ? at : nP + at] = v;
+                            const uint32_t slot = (meta[j] & 0x2000u) ? at : nP + at;
+                            if (xy16) {
+                                xy16[base + slot] = (pix[j] >> 10) | ((pix[j] & 0x3FFu) << 16);
+                            } else {
+                                double2 v;
+                                v.x = (double) (pix[j] >> 10);
+                                v.y = (double) (pix[j] & 0x3FFu);
+                                out2[slot] = v;
+                            }
                         }
                     }
                 }
@@ -661,6 +669,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
                 seg_cnt[2 * s] = nP;
                 seg_off[2 * s + 1] = base + nP;
                 seg_cnt[2 * s + 1] = nN;
+                if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = xy16 ? 1u : 0u;
             }
             RO_MARK(15);
             RO_MARK(0);   // (adds ~0: counts the workgroups through the number of marks... see tools/ro_phase_prof.py)
@@ -721,10 +730,15 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
                 const uint32_t at = pos[r];
                 ep[k] = (int32_t) at;
                 if (r == k) {
-                    double2 v;
-                    v.x = (double) (pix[j] >> 10);
-                    v.y = (double) (pix[j] & 0x3FFu);
-                    out2[vp[j] ? at : nP + at] = v;
+                    const uint32_t slot = vp[j] ? at : nP + at;
+                    if (xy16) {
+                        xy16[base + slot] = (pix[j] >> 10) | ((pix[j] & 0x3FFu) << 16);
+                    } else {
+                        double2 v;
+                        v.x = (double) (pix[j] >> 10);
+                        v.y = (double) (pix[j] & 0x3FFu);
+                        out2[slot] = v;
+                    }
                 }
             }
         }
@@ -734,6 +748,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
         seg_cnt[2 * s] = nP;
         seg_off[2 * s + 1] = base + nP;
         seg_cnt[2 * s + 1] = nN;
+        if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = xy16 ? 1u : 0u;
     }
     return true;
 }

@@ -8,7 +8,7 @@ libecal.so (eventcalib_amd.capi).  Mirrors the per-piece loop of the reference d
 import numpy as np
 import torch
 
-from .capi import Context
+from .capi import Context, PackedPoints
 
 RECORD = 25
 
@@ -16,11 +16,28 @@ RECORD = 25
 class DetectPipeline:
     """Buffers are sized once (grow-only) so a timed loop performs no allocation."""
 
-    def __init__(self, ctx: Context, device=None):
+    def __init__(self, ctx: Context, device=None, packed=True):
+        """packed: between the stages the points of integer-pixel windows travel as 4-byte words (ecal_packed_points) instead
+        of 16-byte doubles; `xy` (positiveEvents_ / negativeEvents_ as doubles) is then written on first access.  Results are
+        bit for bit the same either way."""
         self.ctx = ctx
         self.dev = torch.device("cuda", ctx.device) if device is None else device
         self._cap_windows = 0
         self._cap_slots = 0
+        self.packed = bool(packed)
+        self._xy_stale = False
+
+    @property
+    def xy(self):
+        """[slots, 2] f64: the windows' points as doubles (unpacked on demand after a packed run)."""
+        if self._xy_stale:
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            self.ctx.unpack_points_dev(self._pk(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * self.S, self._xy.data_ptr(), st)
+            self._xy_stale = False
+        return self._xy
+
+    def _pk(self):
+        return PackedPoints(self.xy16.data_ptr(), self.seg_fmt.data_ptr())
 
     def _ensure(self, S, slots):
         dev = self.dev
@@ -35,9 +52,11 @@ class DetectPipeline:
             self.win_info = torch.empty(S, 4, dtype=torch.int32, device=dev)
             self.grid_order = torch.empty(S, 128, dtype=torch.int32, device=dev)
             self.grid_found = torch.empty(S, dtype=torch.int32, device=dev)
+            self.seg_fmt = torch.zeros(2 * S, dtype=torch.int32, device=dev)
             self._cap_windows = S
         if slots > self._cap_slots:
-            self.xy = torch.empty(slots, 2, dtype=torch.float64, device=dev)
+            self._xy = torch.empty(slots, 2, dtype=torch.float64, device=dev)
+            self.xy16 = torch.empty(slots, dtype=torch.int32, device=dev)
             self.event_point = torch.empty(slots, dtype=torch.int32, device=dev)
             self.labels = torch.empty(slots, dtype=torch.int32, device=dev)
             self.kept_labels = torch.empty(slots, dtype=torch.int32, device=dev)
@@ -71,37 +90,65 @@ class DetectPipeline:
         c = self.ctx
         c.window_bounds_dev(events.data_ptr(), n, self.t0.data_ptr(), self.t1.data_ptr(), S, self.win_lo.data_ptr(),
                             self.win_hi.data_ptr(), self.win_base.data_ptr(), st)
+        self._xy_stale = False
         if fused:               # the three stages below as one call (ecal_detect_fused_dev): same arrays, same results
             if not hasattr(self, "det"):
                 self.set_detect_params()
             c.detect_fused_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(), self.win_base.data_ptr(), S,
                                max_win_events, max_seg_points, slots, eps, minpts, self.det[0], self.det[1], self.det[2],
-                               self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),
+                               self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),
                                self.flags.data_ptr(), self.labels.data_ptr(), self.n_clusters.data_ptr(), self.win_info.data_ptr(),
                                self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(), self.kept_labels.data_ptr(), self.rep.data_ptr(),
                                st, fit_circle=self.det[3], knn_num=self.det[4])
             return self
+        if self.packed:
+            pk = self._pk()
+            self._xy_stale = True
+            c.slice_events_packed_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(), self.win_base.data_ptr(), S,
+                                      max_win_events, slots, self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(),
+                                      self.event_point.data_ptr(), self.flags.data_ptr(), pk, st)
+            if slice_only:
+                return self
+            c.dbscan_batch_packed_dev(self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots, max_seg_points,
+                                      eps, minpts, self.labels.data_ptr(), self.n_clusters.data_ptr(), pk, st)
+            if detect:
+                if not hasattr(self, "det"):
+                    self.set_detect_params()
+                want = 0 if exact_ties else 1          # ECAL_TIES_REFERENCE / ECAL_TIES_SMALLER_PID
+                was = c.get_median_ties()
+                if was != want:
+                    c.set_median_ties(want)
+                try:
+                    c.extract_batch_packed_dev(self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.labels.data_ptr(),
+                                               self.n_clusters.data_ptr(), S, slots, eps, self.det[0], self.det[1], self.det[2],
+                                               self.win_info.data_ptr(), self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(),
+                                               self.kept_labels.data_ptr(), self.rep.data_ptr(), pk, st, fit_circle=self.det[3],
+                                               knn_num=self.det[4])
+                finally:
+                    if was != want:
+                        c.set_median_ties(was)
+            return self
         c.slice_events_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(),
-                           self.win_base.data_ptr(), S, max_win_events, slots, self.xy.data_ptr(),
+                           self.win_base.data_ptr(), S, max_win_events, slots, self._xy.data_ptr(),
                            self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),
                            self.flags.data_ptr(), st)
         if slice_only:          # profiling aid: bounds + slicing only
             return self
-        c.dbscan_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots,
+        c.dbscan_batch_dev(self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots,
                            max_seg_points, eps, minpts, self.labels.data_ptr(), self.n_clusters.data_ptr(), st)
         if detect and exact_ties:
             # the reference's own representative where a cluster's median rank is tied in norm: the members' order inside
             # Clusters[c] + libstdc++'s nth_element on it, for the windows that have such a cluster (ecal_extract_batch_exact_dev)
             if not hasattr(self, "det"):
                 self.set_detect_params()
-            c.extract_batch_exact_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.labels.data_ptr(),
+            c.extract_batch_exact_dev(self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.labels.data_ptr(),
                                       self.n_clusters.data_ptr(), S, slots, eps, self.det[0], self.det[1], self.det[2],
                                       self.win_info.data_ptr(), self.cand_pair.data_ptr(), self.cand_xyr.data_ptr(),
                                       self.kept_labels.data_ptr(), self.rep.data_ptr(), st, fit_circle=self.det[3], knn_num=self.det[4])
         elif detect:
             if not hasattr(self, "det"):
                 self.set_detect_params()
-            c.extract_batch_dev(self.xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(),
+            c.extract_batch_dev(self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(),
                                 self.labels.data_ptr(), self.n_clusters.data_ptr(), S, slots, self.det[0], self.det[1],
                                 self.det[2], self.win_info.data_ptr(), self.cand_pair.data_ptr(),
                                 self.cand_xyr.data_ptr(), self.kept_labels.data_ptr(), self.rep.data_ptr(), st,

@@ -151,6 +151,35 @@ int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
                           uint32_t cap_points, double *d_xy, uint32_t *d_seg_off /*[2S]*/,
                           uint32_t *d_seg_cnt /*[2S]*/, int32_t *d_event_point, int *d_overflow, void *stream);
 
+/* ---- packed points -----------------------------------------------------------------------------------------------------
+ * Event pixels are small integers: between the stages a point needs 4 bytes (x | y << 16, two's complement int16 each), not
+ * the 16 of the reference's Vector2d.  The *_packed_dev forms of the three stage entry points take an ecal_packed_points
+ * (caller-owned device buffers: d_xy16 [cap_points], d_seg_fmt [2S]; NULL = the plain forms): the slicer writes the windows
+ * its pixel kernels take (sensor pixels 0 <= x <= 2047, 0 <= y <= 1023, up to 4095 events) to d_xy16 only and marks their two
+ * segments d_seg_fmt = 1; every other window goes to d_xy as doubles (d_seg_fmt = 0).  DBSCAN and the extraction read
+ * whichever form a segment has (and write its doubles themselves, d_seg_fmt 1 -> 3, before a segment goes to one of their
+ * general tiers); results are bit for bit those of the plain forms.  ecal_unpack_points_dev writes the doubles of every
+ * segment that has none yet — for callers that want d_xy itself (positiveEvents_ / negativeEvents_ as doubles). */
+typedef struct ecal_packed_points {
+    uint32_t *d_xy16;     /* [cap_points] */
+    uint32_t *d_seg_fmt;  /* [2S]: 0 doubles only, 1 packed only, 3 both */
+} ecal_packed_points;
+int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const uint32_t *d_win_lo,
+                                 const uint32_t *d_win_hi, const uint32_t *d_win_base, uint32_t S, uint32_t max_win_events,
+                                 uint32_t cap_points, double *d_xy, uint32_t *d_seg_off, uint32_t *d_seg_cnt, int32_t *d_event_point,
+                                 int *d_overflow, const ecal_packed_points *pk, void *stream);
+int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
+                                 uint32_t n_points, uint32_t max_seg_points, double eps, uint32_t minpts, int32_t *d_labels,
+                                 uint32_t *d_n_clusters, const ecal_packed_points *pk, void *stream);
+/* (the extraction the context's ecal_set_median_ties setting asks for: ecal_extract_batch_exact_dev or ecal_extract_batch_dev) */
+int ecal_extract_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                                  const int32_t *d_labels, const uint32_t *d_n_clusters, uint32_t S /*windows*/, uint32_t n_points,
+                                  double eps, uint32_t cluster_min, uint32_t need_clusters, double radius_threshold, int fit_circle,
+                                  uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair, double *d_cand_xyr,
+                                  int32_t *d_kept_labels, uint32_t *d_rep, const ecal_packed_points *pk, void *stream);
+int ecal_unpack_points_dev(ecal_ctx *ctx, const ecal_packed_points *pk, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt,
+                           uint32_t n_segments, double *d_xy, void *stream);
+
 /* ---- circle-candidate extraction -----------------------------------------------------------
  * Replaces CirclesEventFrame::extractFeatures between its DBSCAN::Run calls and cv::findCirclesGrid
  * (event_camera_calib/src/CirclesEventFrame.cpp:89-312) for all windows at once: fit_circle == 0 is the

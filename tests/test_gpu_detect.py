@@ -303,3 +303,57 @@ def test_records_to_candidates_with_no_gpu_array_in_between(env):
             feat = packed[s, 3:].reshape(-1, 3)
             assert all((ref["xyr"] == f).all(1).any() for f in feat), s
     assert paired >= S // 2 and tied >= 3
+
+
+def test_packed_points_give_the_same_results_bit_for_bit(env):
+    """ecal_packed_points (the *_packed_dev stage entry points, DetectPipeline's default): integer-pixel windows travel between
+    the stages as 4-byte words, the doubles are written on request — every output array equals the plain (doubles) form, on a
+    stream that mixes the cases: ordinary windows, windows of 2 000 - 9 000 events (second passes, general tiers: their
+    doubles are written before those tiers read them), and windows whose coordinates are not pixels (never packed)."""
+    ctx, _pipe, torch = env
+    from eventcalib_amd.pipeline import DetectPipeline
+    n = 400_000
+    buf = SS.make_stream(n, rate=1.0e6, device="cpu", seed=31)
+    t, xy, pol = SS.unpack_records(buf)
+    xy = xy.clone()
+    xy[150_000:170_000] += 0.25                     # 20 ms of half-way coordinates: the general slicing tiers, doubles only
+    buf = SS.pack_records(t, xy, pol)
+    t_first = float(t[0])
+    edges = [t_first]
+    for length in [1.5e-3] * 60 + [4e-3, 9e-3, 2.5e-3] + [1.5e-3] * 40 + [6e-3] + [1.5e-3] * 120:
+        edges.append(edges[-1] + length)
+    t0 = np.array(edges[:-1])
+    t1 = np.nextafter(np.array(edges[1:]), -np.inf)
+    ev = buf.cuda()
+    outs = []
+    for packed in (True, False):
+        pipe = DetectPipeline(ctx, packed=packed)
+        pipe.set_windows(t0, t1)
+        pipe.set_detect_params(5, 36, THR)
+        pipe.run(ev)
+        torch.cuda.synchronize()
+        S = len(t0)
+        fmt = pipe.seg_fmt[:2 * S].cpu().numpy().copy() if packed else None
+        off, cnt = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64), pipe.seg_cnt[:2 * S].cpu().numpy().astype(np.int64)
+        xyo = pipe.xy.cpu().numpy()          # (packed: unpacks what has no doubles yet)
+        pts = np.concatenate([xyo[off[s]:off[s] + cnt[s]] for s in range(2 * S)])
+        outs.append(dict(off=off, cnt=cnt, pts=pts, ep=pipe.event_point[:n].cpu().numpy().copy(), lab=pipe.labels[:n].cpu().numpy().copy(),
+                         ncl=pipe.n_clusters[:2 * S].cpu().numpy().copy(), info=pipe.win_info[:S].cpu().numpy().copy(),
+                         kept=pipe.kept_labels[:n].cpu().numpy().copy(), rep=pipe.rep[:n].cpu().numpy().copy(),
+                         pair=pipe.cand_pair[:n].cpu().numpy().copy(), xyr=pipe.cand_xyr[:n].cpu().numpy().copy(), fmt=fmt))
+    a, b = outs
+    assert (a["fmt"] == 0).sum() >= 20 and ((a["fmt"] & 1) == 1).sum() >= 300          # both forms occur ...
+    big = a["cnt"][0::2] + a["cnt"][1::2]
+    assert (big > 2816).any() and (big > 1408).sum() >= 3                               # ... and the later tiers are exercised
+    slots = np.concatenate([np.arange(a["off"][s], a["off"][s] + a["cnt"][s]) for s in range(len(a["off"]))])
+    for k in ("off", "cnt", "pts", "ep", "ncl", "info"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("lab", "kept"):
+        assert np.array_equal(a[k][slots], b[k][slots]), k
+    for s in range(len(t0)):
+        o, m = a["off"][2 * s], a["info"][s, 0]
+        assert np.array_equal(a["pair"][o:o + m], b["pair"][o:o + m]) and np.array_equal(a["xyr"][o:o + m], b["xyr"][o:o + m]), s
+        if a["info"][s, 3] == 0:
+            for h in (0, 1):
+                oo = a["off"][2 * s + h]
+                assert np.array_equal(a["rep"][oo:oo + a["info"][s, 1 + h]], b["rep"][oo:oo + b["info"][s, 1 + h]]), s
