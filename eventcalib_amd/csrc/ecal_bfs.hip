@@ -41,7 +41,10 @@ constexpr uint32_t BO_MAXN = 64;         // hits per range query kept (a disc of
 // Range-query lists kept in LDS (handed out first come first served; the rest go to global scratch).  The first tier keeps a
 // token 8: there more workgroups per CU beat lists in LDS (profiles/r02_notes.md).  The later tiers run one workgroup per CU
 // and fill the LDS with lists: their queue is a dependent chain of pops, and a list in global memory is a round trip per pop.
-constexpr uint32_t BO_STACK = 96;        // pending far subtrees of one traversal
+#ifndef ECAL_BO_STACK
+#define ECAL_BO_STACK 96
+#endif
+constexpr uint32_t BO_STACK = ECAL_BO_STACK;   // pending far subtrees of one traversal
 constexpr uint32_t BO_NONE = 0xFFFFFFFFu;
 
 template <uint32_t CAP>
@@ -392,7 +395,13 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
             slotmap[i] = in_lds ? (uint16_t) slot : (uint16_t) 0xFFFFu;
             uint16_t *out = in_lds ? pool + slot * BO_MAXN : my_lists + (size_t) i * BO_MAXN;
             uint32_t cnt = 0, sp = 0;
-            uint32_t stk[BO_STACK];   // node | dir << 31
+            // the pending far subtrees: a stack of (node | dir << 15) entries.  First tier: kept in REGISTERS as a 192-bit shift
+            // register of twelve 16-bit entries (an indexed array would live in scratch memory: 400 bytes per lane); a traversal
+            // with more pending subtrees sends the segment to the global-scratch launch.  Later tiers: an array.
+            constexpr bool REG_STACK = TIER == 0;
+            constexpr uint32_t STACK_CAP = REG_STACK ? 12u : BO_STACK;
+            unsigned long long s0 = 0, s1 = 0, s2 = 0;
+            uint32_t stk[REG_STACK ? 1 : BO_STACK];
             uint32_t node = 0, dir = 0;
             for (;;) {
                 while (node != BO_NONE) {
@@ -408,18 +417,36 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
                     const uint32_t l = child[2 * node], r = child[2 * node + 1];
                     const uint32_t nearc = dx <= 0.0 ? l : r, farc = dx <= 0.0 ? r : l;
                     if (fabs(dx) < eps && farc != BO_NONE) {
-                        if (sp < BO_STACK) stk[sp] = farc | ((dir ^ 1u) << 31);
+                        if (sp < STACK_CAP) {
+                            const uint32_t e = farc | ((dir ^ 1u) << 15);
+                            if constexpr (REG_STACK) {
+                                s2 = (s2 << 16) | (s1 >> 48);
+                                s1 = (s1 << 16) | (s0 >> 48);
+                                s0 = (s0 << 16) | e;
+                            } else {
+                                stk[sp] = e;
+                            }
+                        }
                         sp++;
                     }
                     node = nearc;
                     dir ^= 1u;
                 }
-                if (sp == 0 || sp > BO_STACK) break;
+                if (sp == 0 || sp > STACK_CAP) break;
                 sp--;
-                node = stk[sp] & 0x7FFFFFFFu;
-                dir = stk[sp] >> 31;
+                uint32_t e;
+                if constexpr (REG_STACK) {
+                    e = (uint32_t) (s0 & 0xFFFFu);
+                    s0 = (s0 >> 16) | (s1 << 48);
+                    s1 = (s1 >> 16) | (s2 << 48);
+                    s2 >>= 16;
+                } else {
+                    e = stk[sp];
+                }
+                node = e & 0x7FFFu;
+                dir = e >> 15;
             }
-            if (cnt > BO_MAXN || sp > BO_STACK) fail = true;
+            if (cnt > BO_MAXN || sp > STACK_CAP) fail = true;
             if (in_lds) pool_cnt[slot] = (uint16_t) (cnt > BO_MAXN ? BO_MAXN : cnt);
             else my_cnt[i] = (uint8_t) (cnt > BO_MAXN ? BO_MAXN : cnt);
         }

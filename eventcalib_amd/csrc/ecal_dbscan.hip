@@ -137,18 +137,24 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
 constexpr int BIG_T = 1024;
 
 // Segments with n > lo_excl: workspace in global scratch, indexed by the segment's point offset.
+// (the segments beyond the LDS tiers, from the to-do list the pixel passes left — all S segments without one —, walked by a
+// small grid: S workgroups of 1024 threads that find nothing to do cost tens of microseconds per call)
 __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restrict__ xy,
                                                            const uint32_t *__restrict__ seg_off,
                                                            const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
                                                            double eps, uint32_t minpts, int32_t *__restrict__ labels,
                                                            uint32_t *__restrict__ n_clusters, uint32_t *gslot,
                                                            uint32_t *ganc, uint32_t *gcur, uint32_t *ginv,
-                                                           double2 *gcs, uint8_t *gflags) {
+                                                           double2 *gcs, uint8_t *gflags, uint32_t S,
+                                                           const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count) {
     __shared__ uint32_t red[48];
     __shared__ uint32_t edges[2 * EDGE_CAP];
-    const uint32_t s = blockIdx.x;
+    const uint32_t n_work = todo ? *todo_count : S;
+  for (uint32_t kk = blockIdx.x; kk < n_work; kk += gridDim.x) {
+    __syncthreads();
+    const uint32_t s = todo ? todo[kk] : kk;
     const uint32_t n = seg_cnt[s];
-    if (n <= lo_excl) return;
+    if (n <= lo_excl) continue;
     const size_t base = seg_off[s];
     DbWork<uint32_t, GeoF64> w;
     const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
@@ -167,6 +173,7 @@ __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restr
     if (nb_log > 20u) nb_log = 20u;
     const uint32_t total = dbscan_segment<BIG_T, true, uint32_t, 0, GeoF64>(w, src, n, eps, minpts, nb_log, labels + base);
     if (threadIdx.x == 0) n_clusters[s] = total;
+  }
 }
 
 }  // namespace ecal
@@ -312,10 +319,10 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         if ((rc = ecal_ensure(ctx, ctx->big_flags, 2 * np + 16))) return rc;
         if ((rc = ecal_ensure(ctx, ctx->big_anc, 4 * np * sizeof(uint32_t)))) return rc;
         if ((rc = ecal_ensure(ctx, ctx->big_cur, np * sizeof(uint32_t)))) return rc;
-        hipLaunchKernelGGL(dbscan_big_kernel, dim3(S), dim3(BIG_T), 0, st, d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP2,
+        hipLaunchKernelGGL(dbscan_big_kernel, dim3(S < 256u ? S : 256u), dim3(BIG_T), 0, st, d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP2,
                            eps, minpts, d_labels, d_n_clusters, (uint32_t *) ctx->big_slot.ptr, (uint32_t *) ctx->big_anc.ptr,
                            (uint32_t *) ctx->big_cur.ptr, (uint32_t *) ctx->big_inv.ptr, (double2 *) ctx->big_cs.ptr,
-                           (uint8_t *) ctx->big_flags.ptr);
+                           (uint8_t *) ctx->big_flags.ptr, S, todo, todo_count);
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;

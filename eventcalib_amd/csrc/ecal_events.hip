@@ -717,14 +717,12 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_list_kernel(const uint8_t *_
 
 constexpr int SLICE_BIG_T = 1024;
 
-__global__ __launch_bounds__(SLICE_BIG_T) void slice_big_kernel(
+__device__ __forceinline__ void slice_big_window(const uint32_t s, unsigned long long *red64,
     const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
     const uint32_t *__restrict__ win_base, uint32_t lo_excl, uint32_t cap_points, double *__restrict__ xy_out,
     uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
     double2 *g_pts, uint8_t *g_pol, uint32_t *g_bend, uint32_t *g_sorted, uint32_t *g_rep, uint32_t *g_pos,
     unsigned char *order_scratch /* null: canonical order; else order_scratch_bytes(cap_points) + 64 S bytes */) {
-    __shared__ unsigned long long red64[17];
-    const uint32_t s = blockIdx.x;
     const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
     if (n <= lo_excl) return;
     if ((uint64_t) base + n > cap_points || n >= 0x80000000u) {
@@ -767,6 +765,24 @@ __global__ __launch_bounds__(SLICE_BIG_T) void slice_big_kernel(
         seg_cnt[2 * s] = nP;
         seg_off[2 * s + 1] = base + nP;
         seg_cnt[2 * s + 1] = nN;
+    }
+}
+
+
+// the windows beyond the LDS tiers, from the to-do list the earlier passes left (all S windows without one): a small grid walks
+// the list — a launch of S workgroups of 1024 threads that find nothing to do cost 30 - 60 us per call when the sizes are unknown
+__global__ __launch_bounds__(SLICE_BIG_T) void slice_big_kernel(
+    const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
+    const uint32_t *__restrict__ win_base, uint32_t lo_excl, uint32_t cap_points, double *__restrict__ xy_out,
+    uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
+    double2 *g_pts, uint8_t *g_pol, uint32_t *g_bend, uint32_t *g_sorted, uint32_t *g_rep, uint32_t *g_pos,
+    unsigned char *order_scratch, uint32_t S, const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count) {
+    __shared__ unsigned long long red64[17];
+    const uint32_t n_work = todo ? *todo_count : S;
+    for (uint32_t k = blockIdx.x; k < n_work; k += gridDim.x) {
+        slice_big_window(todo ? todo[k] : k, red64, rec, win_lo, win_hi, win_base, lo_excl, cap_points, xy_out, seg_off, seg_cnt, event_point,
+                         overflow, g_pts, g_pol, g_bend, g_sorted, g_rep, g_pos, order_scratch);
+        __syncthreads();
     }
 }
 
@@ -989,10 +1005,11 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
             if ((rc = ecal_ensure(ctx, ctx->sl_order_big, order_scratch_bytes(w) + 64 * ((size_t) S + 1)))) return rc;
             ord_big = (unsigned char *) ctx->sl_order_big.ptr;
         }
-        hipLaunchKernelGGL(slice_big_kernel, dim3(S), dim3(SLICE_BIG_T), 0, st, d_events, d_win_lo, d_win_hi, d_win_base,
+        hipLaunchKernelGGL(slice_big_kernel, dim3(S < 256u ? S : 256u), dim3(SLICE_BIG_T), 0, st, d_events, d_win_lo, d_win_hi, d_win_base,
                            (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
                            (double2 *) ctx->sl_pts.ptr, (uint8_t *) ctx->sl_pol.ptr, (uint32_t *) ctx->sl_bend.ptr,
-                           (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr, ord_big);
+                           (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr, ord_big, S, todo,
+                           todo_count);
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
