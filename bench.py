@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_EVENT = 29.0     # 25 B record read once + 4 B int32 label written once
-TRAFFIC_PROFILE = "r02j_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
+TRAFFIC_PROFILE = "r03a_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -295,9 +295,18 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
         # committed profile (tools/pmc_traffic.py over two rocprofv3 --pmc passes of this same command) is
         # quoted when it was taken on the same workload size, else null
-        traffic = None
+        traffic = pass_traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)))
+            if tr.get("events") == n_events:
+                # the detection kernels of one timed pass: every kernel of the profile's passes (a pass = one launch of
+                # window_bounds_kernel) except the other legs' — the fused pass, the plain extraction (MODE 0), solver, calibration
+                passes = max(1, max(v.get("launches", 0) for k, v in tr["kernels"].items() if "window_bounds_kernel" in k))
+                skip = ("normal_eq", "reduce_heads", "calib_", "view_", "residual_rows", "arrow_", "lm_plus", "solver_", "bucket_table",
+                        "associate", "scan_blocks", "detect_fused", "extract_kernel<false, 0>", "extract_list_kernel<false, 0>",
+                        "extract_first_list_kernel<false, 0>", "grid_order", "adaptive_", "gather_features", "rectify", "pnp_", "sort_")
+                pass_traffic = sum(v["hbm_bytes_per_launch"] * min(1.0, v.get("launches", passes) / passes) for k, v in tr["kernels"].items()
+                                   if not any(x in k for x in skip))
             key = {2: "ecal::dbscan_pixel_kernel", 1: "ecal::slice_hash_ref_kernel", 3: "ecal::extract_kernel"}.get(dom)
             hits = [v for k, v in tr["kernels"].items() if k.split("<")[0] == key]   # template arguments vary
             if tr.get("events") == n_events and hits:
@@ -309,6 +318,11 @@ def main():
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_events,
             "kernel_ms": round(kernel_ms[dom], 4),
+            # the whole pass (every kernel of the timed region) on the same algorithmic bytes, and its measured traffic
+            "whole_pass": {"achieved": round(ALGO_BYTES_PER_EVENT * n_events / (ms_per_step * 1e-3) / 1e9, 2),
+                           "frac": round(ALGO_BYTES_PER_EVENT * n_events / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                           "traffic": pass_traffic,
+                           "traffic_over_algorithmic": round(pass_traffic / (ALGO_BYTES_PER_EVENT * n_events), 3) if pass_traffic else None},
             "stage_ms": {"window_bounds": round(float(stage_ms[0]), 4), "slice": round(float(stage_ms[1]), 4),
                          "dbscan": round(float(stage_ms[2]), 4), "extract": round(float(stage_ms[3]), 4)},
         }
@@ -644,6 +658,21 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
         el = float(tt.item())
     iters = int(summ.iterations)
     res_total = n_res * world
+    # the same solve with the linear algebra on the device (arrow_device.hpp: whole iteration in HBM, one 64-byte read-back)
+    dev_solve = None
+    if world == 1:
+        os.environ["ECAL_SOLVER_DEVICE_LINEAR_SOLVE"] = "1"
+        try:
+            solver.solve(x0, opt)
+            torch.cuda.synchronize(dev)
+            tb = time.perf_counter()
+            xd, sd = solver.solve(x0, opt)
+            torch.cuda.synchronize(dev)
+            eld = time.perf_counter() - tb
+            dev_solve = {"value": round(int(sd.iterations) / eld, 3), "unit": "iterations/s", "iterations": int(sd.iterations),
+                         "seconds": round(eld, 4), "final_cost_rel_diff_vs_host_solve": float(abs(sd.final_cost / summ.final_cost - 1))}
+        finally:
+            del os.environ["ECAL_SOLVER_DEVICE_LINEAR_SOLVE"]
     # SURVEY 8(d)'s ALGORITHMIC count per residual and Jacobian evaluation: ~0.7 kflop residual + analytic gradient, 561 FMA
     # for the upper J^T J, 33 FMA for J^T r = 1.9 kflop (the kernel executes ~2.1 kflop: 6 x 6 tiles pad 34 -> 36 columns)
     FLOP_JAC = 1900.0
@@ -661,6 +690,7 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
         "roofline_fp64": {"kernel": "normal_eq_kernel", "flop_per_residual": FLOP_JAC,
                           "achieved_TFLOPs": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 1e12, 3), "peak_TFLOPs": 78.6,
                           "frac": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 78.6e12, 4)},
+        "device_linear_solve": dev_solve,
         "sharding": "one spline segment (time range) per GPU in its own solver, shared intrinsics: 91 doubles all-reduced per "
                     "evaluation, 101 + N per linear solve, 4 per step" if world > 1 else "single GPU",
     }

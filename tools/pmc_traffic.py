@@ -11,13 +11,15 @@ def per_dispatch(path, counter):
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k] += float(r["Counter_Value"]); cnt[k] += 1
+    LAUNCHES.update({k: max(LAUNCHES.get(k, 0), cnt[k]) for k in cnt})
     return {k: agg[k] / cnt[k] for k in agg}
 
 
+LAUNCHES = {}
 f = per_dispatch(sys.argv[1], "FETCH_SIZE")
 w = per_dispatch(sys.argv[2], "WRITE_SIZE")
 out = {"events": int(sys.argv[4]), "note": "bytes = 2*FETCH_SIZE_KB*1024 + WRITE_SIZE_KB*1024 (gfx950 FETCH_SIZE correction)",
-       "kernels": {k: {"fetch_size_kb": f.get(k, 0.0), "write_size_kb": w.get(k, 0.0),
+       "kernels": {k: {"fetch_size_kb": f.get(k, 0.0), "write_size_kb": w.get(k, 0.0), "launches": LAUNCHES.get(k, 0),
                        "hbm_bytes_per_launch": 2 * f.get(k, 0.0) * 1024 + w.get(k, 0.0) * 1024} for k in sorted(set(f) | set(w))}}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out["kernels"].items():
