@@ -310,10 +310,6 @@ class Context:
         L.ecal_unpack_points_dev.restype = ctypes.c_int
         self._check(L.ecal_unpack_points_dev(self._h, ctypes.byref(pk), d_seg_off, d_seg_cnt, int(n_segments), d_xy, stream))
 
-    def set_median_ties(self, mode):
-        self._L.ecal_set_median_ties.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        self._check(self._L.ecal_set_median_ties(self._h, int(mode)))
-
     def get_median_ties(self):
         self._L.ecal_get_median_ties.argtypes = [ctypes.c_void_p]
         return int(self._L.ecal_get_median_ties(self._h))
