@@ -599,6 +599,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     };
     if ((rc = run_passes())) return rc;
     uint32_t rounds = 0;
+    const bool trace = getenv("ECAL_ADAPTIVE_TRACE") != nullptr;
     if (shared) {
         // verify every piece against the frame its predecessors now hand it; run the ones again whose verdicts change
         for (;; rounds++) {
@@ -609,14 +610,16 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
             AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
             if (h[8] == 0) break;
             if (h[1] > max_keys) break;   // the records have run over: reported below
+            const uint32_t before = n_passes, again = h[8];
             if ((rc = run_passes())) return rc;
+            if (trace) fprintf(stderr, "  round %u: %u pieces run again, %u passes\n", rounds, again, n_passes - before);
         }
     }
 #undef AD_TRY
 #ifdef ECAL_ADAPTIVE_STATS
     fprintf(stderr, "chain ends: keyframe %u, other verdict %u, chain used up %u, piece finished %u\n", h[4], h[5], h[6], h[7]);
 #endif
-    if (getenv("ECAL_ADAPTIVE_TRACE"))
+    if (trace)
         fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes, %u verification rounds\n", P, S,
                 d_max, n_passes, rounds);
     ECAL_HIP_TRY(ctx, hipGetLastError());

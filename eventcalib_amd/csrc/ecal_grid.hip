@@ -25,12 +25,32 @@ constexpr uint32_t GR_MAXC = 128;  // candidates per window handled
 constexpr int GR_L = 32;           // lattice coordinate window (u, v in [-16, 15])
 constexpr uint32_t GR_MAXM = 128;  // pattern points handled (rows * cols)
 
+// the changes of lattice basis the pattern is matched through: the four rotations, then the other integer matrices
+// (a b; c d) of determinant + 1 with entries in [-2, 2], in ascending order of (a + 2) + 5 (b + 2) + 25 (c + 2) + 125 (d + 2)
+constexpr uint32_t GR_NTF = 52;
+__constant__ int8_t GR_TF[GR_NTF][4] = {{1, 0, 0, 1}, {0, -1, 1, 0}, {-1, 0, 0, -1}, {0, 1, -1, 0}, {-1, -1, -1, -2}, {0, 1, -1, -2}, {0, -1, 1, -2}, {-1, 1, 1, -2}, {-1, 0, -2, -1}, {1, 1, -2, -1}, {-2, -1, -1, -1}, {-1, 0, -1, -1}, {0, 1, -1, -1}, {1, 2, -1, -1}, {-1, -2, 0, -1}, {-1, -1, 0, -1}, {-1, 1, 0, -1}, {-1, 2, 0, -1}, {1, -2, 1, -1}, {0, -1, 1, -1}, {-1, 0, 1, -1}, {-2, 1, 1, -1}, {1, -1, 2, -1}, {-1, 0, 2, -1}, {-2, 1, -1, 0}, {-1, 1, -1, 0}, {1, 1, -1, 0}, {2, 1, -1, 0}, {-2, -1, 1, 0}, {-1, -1, 1, 0}, {1, -1, 1, 0}, {2, -1, 1, 0}, {1, 0, -2, 1}, {-1, 1, -2, 1}, {2, -1, -1, 1}, {1, 0, -1, 1}, {0, 1, -1, 1}, {-1, 2, -1, 1}, {1, -2, 0, 1}, {1, -1, 0, 1}, {1, 1, 0, 1}, {1, 2, 0, 1}, {-1, -2, 1, 1}, {0, -1, 1, 1}, {1, 0, 1, 1}, {2, 1, 1, 1}, {-1, -1, 2, 1}, {1, 0, 2, 1}, {1, -1, -1, 2}, {0, 1, -1, 2}, {0, -1, 1, 2}, {1, 1, 1, 2}};
+
+// minimum over the wave, in every lane: a DPP reduction towards lane 63 (row shifts, then the row broadcasts) + a read of that
+// lane — vector-ALU moves instead of twelve dependent trips through the LDS crossbar (__shfl_xor), which were most of the
+// walk's latency: the walk asks for a nearest candidate ~150 times per window, one after the other
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
+#define ECAL_GR_MIN_STEP(ctrl, row_mask)                                                                              \
+    {                                                                                                                 \
+        const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(-1, (int) (uint32_t) v, ctrl, row_mask, 0xF, false);   \
+        const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(-1, (int) (uint32_t) (v >> 32), ctrl, row_mask, 0xF, false); \
+        const unsigned long long w = ((unsigned long long) hi << 32) | lo;                                             \
+        v = w < v ? w : v;                                                                                            \
     }
-    return v;
+    ECAL_GR_MIN_STEP(0x111, 0xF)   // row_shr:1
+    ECAL_GR_MIN_STEP(0x112, 0xF)   // row_shr:2
+    ECAL_GR_MIN_STEP(0x114, 0xF)   // row_shr:4
+    ECAL_GR_MIN_STEP(0x118, 0xF)   // row_shr:8: lane 15 of every row holds the row's minimum
+    ECAL_GR_MIN_STEP(0x142, 0xA)   // row_bcast:15 -> rows 1, 3
+    ECAL_GR_MIN_STEP(0x143, 0xC)   // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's
+#undef ECAL_GR_MIN_STEP
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, 63);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), 63);
+    return ((unsigned long long) hi << 32) | lo;
 }
 
 __device__ __forceinline__ unsigned long long pack_key(double d2, uint32_t idx) {
@@ -190,21 +210,11 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         // T in SL2(Z) with entries in [-2, 2] (the four rotations first) and every visited node is tried as the image of model
         // point 0.  (This is what the vendored finder's second attempt on the homography-rectified points and its clustering
         // variant are for, cv_calib.cpp:34-84, circlesgrid.cpp:72-180: a complete pattern seen at a steep angle is still found.)
-        auto transform_of = [](uint32_t t, int &a, int &b, int &c, int &d) -> bool {
-            if (t < 4u) {   // rotations by 0, 90, 180, 270 degrees
-                a = t == 0 ? 1 : (t == 2 ? -1 : 0);
-                b = t == 1 ? -1 : (t == 3 ? 1 : 0);
-                c = -b;
-                d = a;
-                return true;
-            }
-            const uint32_t q = t - 4u;   // the other matrices of [-2, 2]^4 with determinant + 1
-            a = (int) (q % 5u) - 2;
-            b = (int) (q / 5u % 5u) - 2;
-            c = (int) (q / 25u % 5u) - 2;
-            d = (int) (q / 125u) - 2;
-            if (a * d - b * c != 1) return false;
-            return !(b == -c && a == d && a * a + b * b == 1);   // (the rotations came first)
+        auto transform_of = [](uint32_t t, int &a, int &b, int &c, int &d) {
+            a = GR_TF[t][0];
+            b = GR_TF[t][1];
+            c = GR_TF[t][2];
+            d = GR_TF[t][3];
         };
         auto cell_of = [&](uint32_t anchor, int a, int b, int c, int d, uint32_t m, int &u, int &v) {
             const int i = (int) (m / cols), jj = (int) (m % cols);
@@ -213,26 +223,31 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             u = cu[anchor] + a * U + b * V;
             v = cv[anchor] + c * U + d * V;
         };
-        const uint32_t n_tf = 4u + 625u, combos = n_tf * qt;
+        const uint32_t combos = GR_NTF * qt;
         uint32_t win = 0xFFFFFFFFu;
         for (uint32_t cb0 = 0; cb0 < combos && win == 0xFFFFFFFFu; cb0 += GR_T) {   // (in order: the first match wins, rotations first)
             const uint32_t cb = cb0 + lane;
             bool ok = cb < combos;
             int a = 0, b = 0, c = 0, d = 0;
-            if (ok) ok = transform_of(cb / qt, a, b, c, d);
-            for (uint32_t m = 0; m < M && ok; m++) {
+            if (ok) transform_of(cb / qt, a, b, c, d);
+            const uint32_t anchor_c = ok ? queue[cb % qt] : 0u;
+            auto occupied = [&](uint32_t m) -> bool {
                 int u, v;
-                cell_of(queue[cb % qt], a, b, c, d, m, u, v);
-                ok = u >= -GR_L / 2 && u < GR_L / 2 && v >= -GR_L / 2 && v < GR_L / 2 &&
-                     occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] != 0;
-            }
+                cell_of(anchor_c, a, b, c, d, m, u, v);
+                return u >= -GR_L / 2 && u < GR_L / 2 && v >= -GR_L / 2 && v < GR_L / 2 &&
+                       occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] != 0;
+            };
+            // (a conjunction over the cells: the order of the tests is free — the pattern's far corners fail first for nearly
+            // every wrong combination, so the wave's slowest lane is done after three tests instead of a dozen)
+            ok = ok && occupied(M - 1u) && occupied(cols - 1u) && occupied(M - cols);
+            for (uint32_t m = 0; m < M && ok; m++) ok = occupied(m);
             uint32_t mine = ok ? cb : 0xFFFFFFFFu;
             for (int o = 32; o > 0; o >>= 1) mine = min(mine, (uint32_t) __shfl_xor((int) mine, o, 64));
             win = mine;
         }
         if (win == 0xFFFFFFFFu) return false;
         int ta, tb, tc, td;
-        (void) transform_of(win / qt, ta, tb, tc, td);
+        transform_of(win / qt, ta, tb, tc, td);
         const uint32_t anchor = queue[win % qt];
         for (uint32_t m = lane; m < M; m += GR_T) {
             int u, v;

@@ -394,6 +394,8 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         // order (segment not taken by ecal_cluster_order_dev) the smaller pid stays — and the window says so in its status word
         // (ECAL_WIN_TIE_FALLBACK): that pick is not guaranteed to be the reference's.
         if (tid == 0) nk_sh[2] = 0;   // (the member totals were read above; the word now collects the fallbacks)
+        // (two steps: a cluster without a usable order keeps its member list as it is — ascending pid, which the circle test's
+        // sums run over —, so nobody scatters before every member's position has been looked at)
         for (int pol = 0; pol < 2; pol++) {
             const int32_t *ord = pol ? ord1 : ord0;
             for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) {
@@ -403,7 +405,17 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                 if (!(rv & ST::REP_TIE)) continue;
                 const int32_t p = ord ? ord[i] : -1;
                 if (p < 0 || (uint32_t) p >= st.ksize[kb[pol] + kl]) st.rep[kb[pol] + kl] = rv | ST::REP_BAD;   // (every writer: the same value)
-                else st.members[base[pol] + st.koff[kb[pol] + kl] + (uint32_t) p] = i;
+            }
+        }
+        __syncthreads();
+        for (int pol = 0; pol < 2; pol++) {
+            const int32_t *ord = pol ? ord1 : ord0;
+            for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) {
+                const int32_t kl = st.kept[base[pol] + i];
+                if (kl < 0) continue;
+                const uint32_t rv = st.rep[kb[pol] + kl];
+                if ((rv & (ST::REP_TIE | ST::REP_BAD)) != ST::REP_TIE) continue;
+                st.members[base[pol] + st.koff[kb[pol] + kl] + (uint32_t) ord[i]] = i;
             }
         }
         __syncthreads();

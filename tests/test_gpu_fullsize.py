@@ -199,44 +199,49 @@ def test_config0_one_window_of_100k_events():
 def test_a_tie_pick_that_cannot_be_reproduced_is_flagged_not_silent(monkeypatch):
     """The one case left in which the exact extraction falls back to the plain rule (smaller pid among the tied medians): a
     segment beyond the member-order kernel's global workspace — forced here by shrinking its range-query arena
-    (ECAL_BO_BIG_ARENA, a test switch).  The window must say so (ECAL_WIN_TIE_FALLBACK in win_info[..][3]), and everything
-    about it must then be the plain primitive's result."""
+    (ECAL_BO_BIG_ARENA, a test switch) below what the tied clusters' range queries need.  The window must say so
+    (ECAL_WIN_TIE_FALLBACK in win_info[..][3]); every representative is then either the reference's pick (the polarity whose
+    queries still fitted) or the plain primitive's, and the rest of the window follows from them as usual."""
     import torch
     import eventcalib_amd
-    from eventcalib_amd import capi
     from eventcalib_amd.pipeline import DetectPipeline
     n = 100_000
     buf = SS.make_stream(n, device="cpu", seed=3)
     t, _, _ = SS.unpack_records(buf)
     outs = {}
-    for mode in ("exact_small_arena", "plain"):
+    for mode in ("exact", "exact_small_arena", "plain"):
         if mode == "exact_small_arena":
-            monkeypatch.setenv("ECAL_BO_BIG_ARENA", "4096")
+            monkeypatch.setenv("ECAL_BO_BIG_ARENA", "64")
         else:
             monkeypatch.delenv("ECAL_BO_BIG_ARENA", raising=False)
         ctx = eventcalib_amd.Context(0)
         try:
-            if mode == "plain":
-                ctx.set_median_ties("smaller_pid")
             pipe = DetectPipeline(ctx)
             pipe.set_windows([float(t[0])], [float(t[-1])])
             pipe.set_detect_params(5, 36, 15.511363636363637)
-            pipe.run(buf.cuda())
+            pipe.run(buf.cuda(), exact_ties=mode != "plain")
             torch.cuda.synchronize()
             off = pipe.seg_off[:2].cpu().numpy()
             info = pipe.win_info[0].cpu().numpy().astype(np.int64)
-            outs[mode] = dict(info=info, rep0=pipe.rep[off[0]:off[0] + info[1]].cpu().numpy(),
-                              rep1=pipe.rep[off[1]:off[1] + info[2]].cpu().numpy(),
+            outs[mode] = dict(info=info, rep=np.concatenate([pipe.rep[off[0]:off[0] + info[1]].cpu().numpy(),
+                                                              pipe.rep[off[1]:off[1] + info[2]].cpu().numpy()]),
                               pair=pipe.cand_pair[off[0]:off[0] + info[0]].cpu().numpy(),
                               xyr=pipe.cand_xyr[off[0]:off[0] + info[0]].cpu().numpy())
         finally:
             ctx.close()
-    a, b = outs["exact_small_arena"], outs["plain"]
+    e, a, b = outs["exact"], outs["exact_small_arena"], outs["plain"]
     assert int(a["info"][3]) & 0x100, "the fallback must be reported"
-    assert int(b["info"][3]) & 0x100 == 0
-    assert (int(a["info"][3]) & 0xFF) == int(b["info"][3]) and np.array_equal(a["info"][:3], b["info"][:3])
-    for k in ("rep0", "rep1", "pair", "xyr"):
-        assert np.array_equal(a[k], b[k]), k
+    assert int(b["info"][3]) & 0x100 == 0 and int(e["info"][3]) & 0x100 == 0
+    assert (int(a["info"][3]) & 0xFF) == int(b["info"][3]) == int(e["info"][3])
+    assert np.array_equal(a["info"][1:3], b["info"][1:3]) and np.array_equal(a["info"][1:3], e["info"][1:3])
+    differ = e["rep"] != b["rep"]
+    assert differ.any()                                                     # (the window does hold medians the two rules pick differently)
+    assert np.all((a["rep"] == e["rep"]) | (a["rep"] == b["rep"]))
+    assert np.any(differ & (a["rep"] == b["rep"]))                           # some pick really is the plain rule's
+    for other in (e, b):   # with the same representatives everything downstream is the same, bit for bit
+        if np.array_equal(a["rep"], other["rep"]):
+            assert a["info"][0] == other["info"][0]
+            assert np.array_equal(a["pair"], other["pair"]) and np.array_equal(a["xyr"], other["xyr"])
 
 
 @pytest.mark.parametrize("n_events", [50_000_000])

@@ -11,9 +11,10 @@ nth = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = eventcalib_amd.Context(0)
 ev = SS.make_stream(n, device="cuda")
 pipe = DetectPipeline(ctx)
-dev = len(sys.argv) > 4 and sys.argv[4] == "dev"     # policy on the device (ecal_detect_keyframes)
+dev = len(sys.argv) > 4 and sys.argv[4] in ("dev", "shared")     # policy on the device (ecal_detect_keyframes); shared = the shared-map gate
 if dev:
-    run = lambda a, b: detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, a, b)
+    gm = 1 if sys.argv[4] == "shared" else 0
+    run = lambda a, b: detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, a, b, gate_mode=gm)
 else:
     run = lambda a, b: detect_keyframes(pipe, ev, 5e-4, 4000, pieces, a, b, n_threads=nth)
 run(5.0, 5.5)
