@@ -97,23 +97,69 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
 
 
 def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps=4.0,
-                            minpts=2, rows=9, cols=4, max_passes=0, gate_mode=0):
+                            minpts=2, rows=9, cols=4, max_passes=0, gate_mode=0, n_threads=1, contexts=None):
     """Same result as detect_keyframes, with the policy on the device (ecal_detect_keyframes): no per-pass host round trip.
     gate_mode = capi.GATE_SHARED_MAP: the reference's single-worker run (one keyframe map for all pieces) instead of the
-    own-piece gate.  Slots and the keyframe capacity are estimated and doubled when the library reports them too small."""
-    torch.cuda.synchronize(events.device)   # the passes run on the context's own stream: `events` must be complete
+    own-piece gate.  Slots and the keyframe capacity are estimated and doubled when the library reports them too small.
+
+    n_threads > 1 (own-piece gate only): the pieces are cut into that many contiguous groups, each searched by its own call
+    on its own context and host thread (ecal_adaptive_params.piece_first / piece_count) — a lock-step pass is a chain of
+    latency-bound launches, several chains side by side fill the GPU; the keyframes are the same ones.  `contexts`: the
+    contexts to use (kept by the caller between calls: their scratch buffers stay allocated), else created and closed here."""
+    torch.cuda.synchronize(events.device)   # the passes run on the contexts' own streams: `events` must be complete
     n_ev = events.numel() // 25
+    n_threads = max(1, min(int(n_threads), int(piece_num)))
+    if n_threads == 1 or gate_mode != 0:
+        return _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps, minpts,
+                             rows, cols, max_passes, gate_mode, 0, 0)
+    import threading
+    from .capi import Context
+    own = contexts is None
+    ctxs = [Context(ctx.device) for _ in range(n_threads)] if own else list(contexts)[:n_threads]
+    cuts = [piece_num * g // n_threads for g in range(n_threads + 1)]
+    outs, errs = [None] * n_threads, [None] * n_threads
+
+    def work(g):
+        try:
+            outs[g] = _detect_group(ctxs[g], events, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time,
+                                    eps, minpts, rows, cols, max_passes, gate_mode, cuts[g], cuts[g + 1] - cuts[g])
+        except BaseException as e:   # noqa: BLE001 — re-raised in the caller's thread
+            errs[g] = e
+    th = [threading.Thread(target=work, args=(g,)) for g in range(n_threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if own:
+        for c in ctxs:
+            c.close()
+    for e in errs:
+        if e is not None:
+            raise e
+    t = np.concatenate([o["time"] for o in outs])
+    d = np.concatenate([o["duration"] for o in outs])
+    o_ = np.lexsort((d[:, 0], t))          # the library's order: time stamp, then window start
+    return dict(time=t[o_], duration=d[o_], events_num=np.concatenate([o["events_num"] for o in outs])[o_],
+                features=np.concatenate([o["features"] for o in outs])[o_], steps=max(o["steps"] for o in outs),
+                windows=sum(o["windows"] for o in outs))
+
+
+def _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps, minpts, rows,
+                  cols, max_passes, gate_mode, piece_first, piece_count):
     span = max(end_time - start_time, 1e-9)
+    n_mine = piece_count if piece_count else piece_num
     # a pass covers a chain of windows per piece: the library's own estimate, doubled whenever it reports it too small
     cap_max = min(2 ** 32 - 64, 6 * n_ev + 4096)     # (the hint's own maximum: the windows of one slot index are disjoint)
-    cap = capi.detect_keyframes_cap_hint(ctx, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time)
-    max_keys = int(span / (8 * motion_time_step)) + piece_num + 64   # one keyframe per window + gap at the very most
+    cap = capi.detect_keyframes_cap_hint(ctx, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time,
+                                         piece_first, piece_count)
+    max_keys = int(span * n_mine / piece_num / (8 * motion_time_step)) + n_mine + 64   # one keyframe per window + gap at the very most
     while True:
         try:
             t, d, e, f, passes, windows = capi.detect_keyframes_dev(ctx, events.data_ptr(), n_ev, motion_time_step,
                                                                     frame_event_num_threshold, piece_num, start_time, end_time, cap,
                                                                     max_keys, eps, minpts, 5, rows, cols, max_passes=max_passes,
-                                                                    gate_mode=gate_mode)
+                                                                    gate_mode=gate_mode, piece_first=piece_first,
+                                                                    piece_count=piece_count)
             break
         except capi.EcalError as err:
             if err.status != -6:

@@ -817,23 +817,27 @@ def detect_stream_tiled(ctx: Context, host_ptr, n_events, t_start, window_len, w
 class AdaptiveParams(ctypes.Structure):
     _fields_ = [("motion_time_step", ctypes.c_double), ("frame_event_num_threshold", ctypes.c_uint32), ("piece_num", ctypes.c_uint32),
                 ("start_time", ctypes.c_double), ("end_time", ctypes.c_double), ("max_passes", ctypes.c_uint32),
-                ("check_every", ctypes.c_uint32), ("gate_mode", ctypes.c_int)]
+                ("check_every", ctypes.c_uint32), ("gate_mode", ctypes.c_int), ("piece_first", ctypes.c_uint32),
+                ("piece_count", ctypes.c_uint32)]
 GATE_OWN_PIECE, GATE_SHARED_MAP = 0, 1
 
 
-def detect_keyframes_cap_hint(ctx: Context, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time):
+def detect_keyframes_cap_hint(ctx: Context, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time,
+                              piece_first=0, piece_count=0):
     """ecal_detect_keyframes_cap_hint: a cap_points that detect_keyframes_dev will usually find sufficient."""
     L = ctx._L
     L.ecal_detect_keyframes_cap_hint.argtypes = [ctypes.POINTER(AdaptiveParams), ctypes.c_uint64]
     L.ecal_detect_keyframes_cap_hint.restype = ctypes.c_uint64
-    ap = AdaptiveParams(float(motion_time_step), int(frame_event_num_threshold), int(piece_num), float(start_time), float(end_time), 0, 0, 0)
+    ap = AdaptiveParams(float(motion_time_step), int(frame_event_num_threshold), int(piece_num), float(start_time), float(end_time), 0, 0, 0,
+                        int(piece_first), int(piece_count))
     return int(L.ecal_detect_keyframes_cap_hint(ctypes.byref(ap), int(n_events)))
 
 
 def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time,
                          end_time, cap_points, max_keyframes, eps=4.0, minpts=2, cluster_min=5, rows=9, cols=4,
-                         radius_threshold=15.511363636363637, max_passes=0, check_every=0, gate_mode=0):
-    """ecal_detect_keyframes (policy on the device; gate_mode: GATE_OWN_PIECE / GATE_SHARED_MAP).  Returns (time [K], duration [K,2], events_num [K], features [K, rows cols, 3],
+                         radius_threshold=15.511363636363637, max_passes=0, check_every=0, gate_mode=0, piece_first=0, piece_count=0):
+    """ecal_detect_keyframes (policy on the device; gate_mode: GATE_OWN_PIECE / GATE_SHARED_MAP; piece_count != 0: only the pieces
+    piece_first .. piece_first + piece_count - 1 of the piece_num).  Returns (time [K], duration [K,2], events_num [K], features [K, rows cols, 3],
     passes, windows); raises EcalError(-6) when cap_points or max_keyframes is too small."""
     L = ctx._L
     vp, u32 = ctypes.c_void_p, ctypes.c_uint32
@@ -841,7 +845,7 @@ def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, fra
                                         vp, vp, vp, vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_uint64)]
     L.ecal_detect_keyframes.restype = ctypes.c_int
     ap = AdaptiveParams(float(motion_time_step), int(frame_event_num_threshold), int(piece_num), float(start_time), float(end_time),
-                        int(max_passes), int(check_every), int(gate_mode))
+                        int(max_passes), int(check_every), int(gate_mode), int(piece_first), int(piece_count))
     prm = DetectParams(float(eps), int(minpts), int(cluster_min), int(rows * cols), float(radius_threshold), 0, 3, int(rows), int(cols))
     M = rows * cols
     t = np.empty(max_keyframes)

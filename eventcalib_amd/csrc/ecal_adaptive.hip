@@ -102,6 +102,7 @@ struct AdaptiveArrays {
     double *facc_t, *facc_dir;                            // [P], [P][rows][2]: the first accepted success
     double *rej_t, *rej_dir;                              // [P][AD_NREJ], [P][AD_NREJ][rows][2]: the rejected ones before it
     double start_time, end_time;
+    uint32_t p_total, p_first;   // the pieces at work are p_first .. p_first + P - 1 of the p_total pieces of [start_time, end_time]
 };
 
 // EventCalibIni::track's test (EventCalibIni.cpp:73-82): the median — what libstdc++'s std::nth_element leaves at position
@@ -225,8 +226,9 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
 // piece k at the start of a run: its first window, and the reference frame it starts with (none, or init_*)
 __device__ void piece_start(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st) {
     const double ln = 3 * mts;
-    const double step = (st.end_time - st.start_time) / (double) P;  // eventCameraCalib.cpp:168-179
-    const double hi = st.end_time - step * (double) k, first = st.end_time - step * (double) (k + 1), second = first + ln;
+    const double step = (st.end_time - st.start_time) / (double) st.p_total;  // eventCameraCalib.cpp:168-179
+    const uint32_t kg = st.p_first + k;
+    const double hi = st.end_time - step * (double) kg, first = st.end_time - step * (double) (kg + 1), second = first + ln;
     st.bound_hi[k] = hi;
     st.first[k] = first;
     st.second[k] = second;
@@ -427,11 +429,13 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
 
 extern "C" uint64_t ecal_detect_keyframes_cap_hint(const ecal_adaptive_params *ap, uint64_t n_events) {
     if (!ap || ap->piece_num == 0 || !(ap->motion_time_step > 0) || !(ap->end_time > ap->start_time)) return 0;
-    const uint32_t D = adaptive_slots_per_piece(ap->piece_num);
+    if ((uint64_t) ap->piece_first + ap->piece_count > ap->piece_num) return 0;
+    const uint32_t P = ap->piece_count ? ap->piece_count : ap->piece_num;
+    const uint32_t D = adaptive_slots_per_piece(P);
     // a pass holds D windows per piece, of three to ten time steps, grown along the chain: eight steps each at the stream's
     // mean rate and some room (too little costs one aborted attempt of a few passes: ECAL_ERR_RANGE, doubled, again)
     const double per_step = (double) n_events * ap->motion_time_step / (ap->end_time - ap->start_time);
-    const double want = (double) ap->piece_num * D * (8.0 * per_step + 256.0);
+    const double want = (double) P * D * (8.0 * per_step + 256.0);
     const double most = (double) D * (double) n_events + 4096.0;   // (the windows of one slot index are disjoint)
     const double cap = want < most ? want : most;
     return cap > 4294967232.0 ? 4294967232ull : (uint64_t) cap;
@@ -445,7 +449,14 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     *n_keyframes = 0;
     if (passes) *passes = 0;
     if (windows) *windows = 0;
-    const uint32_t P = ap->piece_num, M = prm->rows * prm->cols, rows = prm->rows;
+    const uint32_t P = ap->piece_count ? ap->piece_count : ap->piece_num, M = prm->rows * prm->cols, rows = prm->rows;
+    const bool subset = ap->piece_count != 0 && ap->piece_count != ap->piece_num;
+    if ((uint64_t) ap->piece_first + ap->piece_count > ap->piece_num || (!ap->piece_count && ap->piece_first) ||
+        (subset && ap->gate_mode == ECAL_GATE_SHARED_MAP)) {
+        ctx->last_error = "ecal_detect_keyframes: piece_first + piece_count beyond piece_num, or a subset of the pieces under the shared-map gate "
+                          "(a piece's gate frame comes from the pieces before it)";
+        return ECAL_ERR_INVALID;
+    }
     if (P == 0 || M == 0 || M > 128 || prm->rows > (uint32_t) AD_MAX_ROWS || !(ap->motion_time_step > 0) ||
         !(ap->end_time > ap->start_time) || (max_keyframes && (!kf_time || !kf_duration || !kf_events_num || !kf_features)) ||
         (ap->gate_mode != ECAL_GATE_OWN_PIECE && ap->gate_mode != ECAL_GATE_SHARED_MAP)) {
@@ -513,6 +524,8 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         a.rerun = u, u += P;
         a.start_time = ap->start_time;
         a.end_time = ap->end_time;
+        a.p_total = ap->piece_num;
+        a.p_first = ap->piece_count ? ap->piece_first : 0u;
     }
     const uint32_t max_keys = (uint32_t) rec_cap;
     double *d_kt = (double *) ctx->adaptive_keys.ptr, *d_kd = d_kt + max_keys, *d_kf = d_kd + 2 * (size_t) max_keys;

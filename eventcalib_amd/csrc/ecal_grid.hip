@@ -68,7 +68,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     __shared__ int8_t cu[GR_MAXC], cv[GR_MAXC];
     __shared__ uint8_t assigned[GR_MAXC], queue[GR_MAXC];
     __shared__ uint8_t occ[GR_L * GR_L];  // lattice cell -> candidate index + 1
-    __shared__ double hn[8][9];           // normal equations of the partial grid's homography (second attempt)
+    __shared__ double hm[24];             // moment sums of the partial grid's homography fit (second attempt)
     __shared__ double hh[8];
     __shared__ uint32_t sh_qt;
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
@@ -262,65 +262,138 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         // Second attempt, as cv::findCirclesGrid's (cv_calib.cpp:34-84: the holes found so far give a homography,
         // CirclesGridFinder::rectifyGrid, and the search runs again on the rectified points).  Under steep perspective the
         // first walk's local steps drift and a step can land on the wrong neighbour (the foreshortened lattice has
-        // neighbours closer than a step's prediction error): only the seed's 3 x 3 neighbourhood of that walk is kept; the
-        // homography lattice (u, v) -> image is fitted to it (inhomogeneous DLT, 8 x 8 normal equations) and the walk is
-        // redone ring by ring with ITS predictions — exact under perspective —, refitted after every ring.
-        if (lane == 0) {
-            uint32_t keep = 0;
-            for (uint32_t k = 0; k < qt; k++) {
-                const uint32_t j = queue[k];
-                if (cu[j] >= -1 && cu[j] <= 1 && cv[j] >= -1 && cv[j] <= 1) {
-                    queue[keep++] = (uint8_t) j;
-                } else {
-                    assigned[j] = 0;
-                    occ[(cv[j] + GR_L / 2) * GR_L + (cu[j] + GR_L / 2)] = 0;
-                }
-            }
-            sh_qt = keep;
-        }
-        __syncthreads();
-        qt = sh_qt;
-        for (int sweep = 0; sweep < 20 && !got && qt >= 4u; sweep++) {
-            for (uint32_t e = lane; e < 72u; e += GR_T) {
-                const uint32_t r = e / 9u, c = e % 9u;
+        // neighbours closer than a step's prediction error); a homography's predictions are exact under perspective.
+        // fit_h: the homography lattice (u, v) -> image through the placed nodes (inhomogeneous DLT, 8 x 8 normal equations)
+        auto fit_h = [&]() {
+            // The normal equations of the node rows [u v 1 0 0 0 -ux -vx | x], [0 0 0 u v 1 -uy -vy | y] are made of 24 sums
+            // S(a, b, g) = sum over the nodes of u^a v^b g with a + b <= 2 and g in {1, x, y, x^2 + y^2}: a lane per sum
+            // (index 4 * m + g, m = 0..5 for u^a v^b = 1, u, v, u^2, u v, v^2), nodes in queue order.
+            if (lane < 24u) {
+                const uint32_t m = lane >> 2, g = lane & 3u;
                 double acc = 0;
                 for (uint32_t k = 0; k < qt; k++) {
                     const uint32_t j = queue[k];
                     const double u = cu[j], v = cv[j], x = px[j], y = py[j];
-                    const double r1[9] = {u, v, 1, 0, 0, 0, -u * x, -v * x, x}, r2[9] = {0, 0, 0, u, v, 1, -u * y, -v * y, y};
-                    acc += r1[r] * r1[c] + r2[r] * r2[c];
+                    const double mono = m == 0u ? 1.0 : (m == 1u ? u : (m == 2u ? v : (m == 3u ? u * u : (m == 4u ? u * v : v * v))));
+                    const double gg = g == 0u ? 1.0 : (g == 1u ? x : (g == 2u ? y : x * x + y * y));
+                    acc += mono * gg;
                 }
-                hn[r][c] = acc;
+                hm[lane] = acc;
             }
             __syncthreads();
-            if (lane == 0) {   // Gaussian elimination with partial pivoting
-                bool okh = true;
-                for (int c = 0; c < 8 && okh; c++) {
-                    int piv = c;
-                    for (int r = c + 1; r < 8; r++)
-                        if (fabs(hn[r][c]) > fabs(hn[piv][c])) piv = r;
-                    if (!(fabs(hn[piv][c]) > 1e-12)) {
-                        okh = false;
-                        break;
+            // row r of the 8 x 9 system in lane r's registers.  S1(p, q) = sum of t_p t_q g for t = (u, v, 1)
+            auto S = [&](uint32_t p, uint32_t q, uint32_t g) -> double {   // p, q in {0: u, 1: v, 2: 1}
+                const uint32_t lo = p < q ? p : q, hi = p < q ? q : p;
+                // (u,u) 3  (u,v) 4  (u,1) 1  (v,v) 5  (v,1) 2  (1,1) 0
+                const uint32_t m = lo == 0u ? (hi == 0u ? 3u : (hi == 1u ? 4u : 1u)) : (lo == 1u ? (hi == 1u ? 5u : 2u) : 0u);
+                return hm[4u * m + g];
+            };
+            double row[9];
+            {
+                const uint32_t r = lane & 7u;
+#pragma unroll
+                for (uint32_t c = 0; c < 9; c++) {
+                    double val;
+                    if (r < 3u) {          // d/dh of the x rows: t_r * [t | 0 | -t_{0,1} x | x]
+                        val = c < 3u ? S(r, c, 0) : (c < 6u ? 0.0 : (c < 8u ? -S(r, c - 6u, 1) : S(r, 2, 1)));
+                    } else if (r < 6u) {   // the y rows
+                        val = c < 3u ? 0.0 : (c < 6u ? S(r - 3u, c - 3u, 0) : (c < 8u ? -S(r - 3u, c - 6u, 2) : S(r - 3u, 2, 2)));
+                    } else {               // -t_{r-6} x * x row + -t_{r-6} y * y row
+                        val = c < 3u ? -S(r - 6u, c, 1) : (c < 6u ? -S(r - 6u, c - 3u, 2) : (c < 8u ? S(r - 6u, c - 6u, 3) : -S(r - 6u, 2, 3)));
                     }
-                    for (int k = 0; k < 9; k++) {
-                        const double t = hn[c][k];
-                        hn[c][k] = hn[piv][k];
-                        hn[piv][k] = t;
-                    }
-                    for (int r = c + 1; r < 8; r++) {
-                        const double f = hn[r][c] / hn[c][c];
-                        for (int k = c; k < 9; k++) hn[r][k] -= f * hn[c][k];
-                    }
+                    row[c] = val;
                 }
-                for (int r = 7; r >= 0 && okh; r--) {
-                    double t = hn[r][8];
-                    for (int k = r + 1; k < 8; k++) t -= hn[r][k] * hh[k];
-                    hh[r] = t / hn[r][r];
+            }
+            // Gaussian elimination with partial pivoting on the eight lanes' registers: the pivot row of a column is the unused
+            // row with the largest entry (the first such in row order), broadcast with v_readlane; no row is moved
+            auto bcast = [](double v, uint32_t src) -> double {
+                const long long b = __double_as_longlong(v);
+                const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b, (int) src);
+                const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (b >> 32), (int) src);
+                return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+            };
+            uint32_t used = 0, perm[8];
+            bool okh = true;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                uint32_t piv = 0xFFFFFFFFu;
+                double best = -1.0;
+#pragma unroll
+                for (uint32_t r = 0; r < 8; r++) {
+                    const double v = fabs(bcast(row[c], r));
+                    const bool take = !((used >> r) & 1u) && v > best;
+                    best = take ? v : best;
+                    piv = take ? r : piv;
                 }
-                if (!okh) hh[0] = NAN;
+                if (!(best > 1e-12)) okh = false;
+                piv = okh ? piv : 0u;
+                perm[c] = piv;
+                used |= 1u << piv;
+                const double pc = bcast(row[c], piv);
+                const bool mine = lane < 8u && !((used >> lane) & 1u);
+                const double f = row[c] / pc;
+#pragma unroll
+                for (int k = c; k < 9; k++) {
+                    const double pk = bcast(row[k], piv);
+                    row[k] = mine ? row[k] - f * pk : row[k];
+                }
+            }
+            double x[8];
+#pragma unroll
+            for (int c = 7; c >= 0; c--) {
+                double t = row[8];
+#pragma unroll
+                for (int k = c + 1; k < 8; k++) t -= row[k] * x[k];
+                x[c] = bcast(t / row[c], perm[c]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) hh[c] = okh ? x[c] : NAN;
             }
             __syncthreads();
+        };
+        // Are the first walk's labels one consistent perspective view of a lattice?  Then the walk did not go astray — it
+        // stopped because circles are missing (the usual reason a window of the adaptive search has no grid yet) —, its nodes
+        // stay and only the open cells around them are tried again with the homography's predictions: one sweep that adds
+        // nothing ends the attempt.  Otherwise (a step landed on the wrong neighbour) only the seed's 3 x 3 neighbourhood is
+        // kept and the walk is redone ring by ring.
+        bool consistent = false;
+        fit_h();
+        if (hh[0] == hh[0]) {
+            double worst = 0.0;
+            for (uint32_t k = lane; k < qt; k += GR_T) {
+                const uint32_t j = queue[k];
+                const double u = cu[j], v = cv[j], wq = hh[6] * u + hh[7] * v + 1.0;
+                const double ex = (hh[0] * u + hh[1] * v + hh[2]) / wq - px[j], ey = (hh[3] * u + hh[4] * v + hh[5]) / wq - py[j];
+                const double d2 = wq > 1e-6 ? ex * ex + ey * ey : 1e300;
+                worst = d2 > worst ? d2 : worst;
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+                const double w = __shfl_xor(worst, o, 64);
+                worst = w > worst ? w : worst;
+            }
+            consistent = worst <= 2.0 * 2.0;   // px^2
+        }
+        __syncthreads();
+        if (!consistent) {
+            if (lane == 0) {
+                uint32_t keep = 0;
+                for (uint32_t k = 0; k < qt; k++) {
+                    const uint32_t j = queue[k];
+                    if (cu[j] >= -1 && cu[j] <= 1 && cv[j] >= -1 && cv[j] <= 1) {
+                        queue[keep++] = (uint8_t) j;
+                    } else {
+                        assigned[j] = 0;
+                        occ[(cv[j] + GR_L / 2) * GR_L + (cu[j] + GR_L / 2)] = 0;
+                    }
+                }
+                sh_qt = keep;
+            }
+            __syncthreads();
+            qt = sh_qt;
+        }
+        for (int sweep = 0; sweep < 20 && !got && qt >= 4u; sweep++) {
+            if (sweep > 0 || !consistent) fit_h();
             if (!(hh[0] == hh[0])) break;
             const uint32_t qt_before = qt;
             for (uint32_t qi = 0; qi < qt_before; qi++) {

@@ -184,7 +184,9 @@ inline std::vector<KeyFrame> detect_keyframes(EventContainer &container, CircleP
 inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, CirclePatternParameters::Ptr pattern,
                                                      const CirclesEventFrame::Params &params, double motionTimeStep,
                                                      int frameEventNumThreshold, int pieceNum, double startTime, double endTime,
-                                                     int gateMode = ECAL_GATE_OWN_PIECE) {
+                                                     int gateMode = ECAL_GATE_OWN_PIECE, int pieceFirst = 0, int pieceCount = 0) {
+    // (pieceCount != 0: only the pieces pieceFirst .. pieceFirst + pieceCount - 1, with the bounds they have in the whole run —
+    // the cut of one search over processes / GPUs; own-piece gate only)
     ecal_detect_params prm;
     prm.dbscan_eps = params.dbscan_eps;
     prm.dbscan_min_samples = (uint32_t) params.dbscan_startMinSample;
@@ -206,6 +208,8 @@ inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, 
     ap.max_passes = 0;
     ap.check_every = 0;
     ap.gate_mode = gateMode;
+    ap.piece_first = (uint32_t) pieceFirst;
+    ap.piece_count = (uint32_t) pieceCount;
     const ecal_stream *es = container.device();
     const uint64_t n = ecal_stream_size(es);
     const size_t M = (size_t) prm.rows * prm.cols;

@@ -372,6 +372,11 @@ typedef struct ecal_adaptive_params {
     uint32_t max_passes;                 /* 0 = unlimited */
     uint32_t check_every;                /* passes the host may run ahead of the device's active-piece counter (0 = 2, at most 8) */
     int gate_mode;                       /* ECAL_GATE_OWN_PIECE / ECAL_GATE_SHARED_MAP (below) */
+    /* piece_count != 0: only the pieces piece_first .. piece_first + piece_count - 1 of the piece_num pieces (piece 0 is the last
+     * in time, eventCameraCalib.cpp:172-179), with exactly the bounds they have in the whole run.  Pieces are independent under
+     * ECAL_GATE_OWN_PIECE, so several calls — one context and host thread each — share one search: their kernels overlap on the
+     * GPU (a lock-step pass is latency bound) and the union of their keyframes is the whole run's.  Not with ECAL_GATE_SHARED_MAP. */
+    uint32_t piece_first, piece_count;
 } ecal_adaptive_params;
 /* Which keyframe a successful window is gated against (EventCalibIni::track, EventCalibIni.cpp:26-36: the map's
  * lower_bound(time stamp), else its last keyframe; TrackingBase.cpp:18-27: only the very first frame is ungated):

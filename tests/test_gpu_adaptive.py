@@ -37,6 +37,32 @@ def test_device_policy_equals_host_policy(env, pieces):
     assert np.array_equal(dev["features"], host["features"])      # the same candidate circles, bit for bit
 
 
+@pytest.mark.parametrize("pieces,groups", [(7, 2), (64, 3), (500, 4)])
+def test_piece_subsets_add_up_to_the_whole_search(env, pieces, groups):
+    """ecal_adaptive_params.piece_first / piece_count: a call searches only some of the pieces, with the bounds they have in the
+    whole run (how the search is cut over contexts / host threads and over GPUs).  The union of the groups' keyframes is the
+    whole run's, bit for bit; the shared-map gate refuses a subset (a piece's gate frame comes from the pieces before it)."""
+    from eventcalib_amd import capi
+    from eventcalib_amd.adaptive import detect_keyframes_device
+    ctx, pipe, ev, torch = env
+    t_first, t_last = 5.0, 5.0 + (3_000_000 - 1) / 2.0e6
+    whole = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last)
+    parts = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, n_threads=groups)
+    assert len(whole["time"]) >= 5
+    for k in ("time", "duration", "events_num", "features"):
+        assert np.array_equal(parts[k], whole[k]), k
+    assert parts["windows"] == whole["windows"] and parts["steps"] == whole["steps"]
+    n_ev = ev.numel() // 25
+    with pytest.raises(capi.EcalError) as e:
+        capi.detect_keyframes_dev(ctx, ev.data_ptr(), n_ev, 5e-4, 4000, pieces, t_first, t_last, 1 << 22, 4096,
+                                  gate_mode=capi.GATE_SHARED_MAP, piece_first=1, piece_count=pieces - 1)
+    assert e.value.status == -1
+    with pytest.raises(capi.EcalError) as e:
+        capi.detect_keyframes_dev(ctx, ev.data_ptr(), n_ev, 5e-4, 4000, pieces, t_first, t_last, 1 << 22, 4096, piece_first=2,
+                                  piece_count=pieces - 1)
+    assert e.value.status == -1
+
+
 def test_capacity_errors_and_limits(env):
     import eventcalib_amd.capi as capi
     ctx, pipe, ev, torch = env

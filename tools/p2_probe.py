@@ -14,11 +14,15 @@ pipe = DetectPipeline(ctx)
 dev = len(sys.argv) > 4 and sys.argv[4] in ("dev", "shared")     # policy on the device (ecal_detect_keyframes); shared = the shared-map gate
 if dev:
     gm = 1 if sys.argv[4] == "shared" else 0
-    run = lambda a, b: detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, a, b, gate_mode=gm)
+    ctxs = [eventcalib_amd.Context(0) for _ in range(nth)] if nth > 1 else None
+    run = lambda a, b: detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, a, b, gate_mode=gm, n_threads=nth, contexts=ctxs)
 else:
     run = lambda a, b: detect_keyframes(pipe, ev, 5e-4, 4000, pieces, a, b, n_threads=nth)
 run(5.0, 5.5)
+run(5.0, 5.0 + (n - 1) / 1e6)          # (sizes the scratch buffers: the timed run does not allocate)
 torch.cuda.synchronize(); t = time.perf_counter()
 kf = run(5.0, 5.0 + (n - 1) / 1e6)
 torch.cuda.synchronize(); el = time.perf_counter() - t
+import hashlib
+print("keyframes sha", hashlib.sha1(kf["time"].tobytes() + kf["features"].tobytes()).hexdigest()[:12])
 print("threads %d " % nth + "P2: %d events, %d pieces, %.3f s, %d passes (%.3f ms each), %d windows, %d keyframes" % (n, pieces, el, kf["steps"], el / kf["steps"] * 1e3, kf["windows"], len(kf["time"])))
