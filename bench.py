@@ -257,6 +257,36 @@ def main():
                   "note": "one %dM-event stream cut into %d time ranges of whole windows; no collective on the data path" % (n_events // 1_000_000, world)}
         events = ev_s
         t0, t1 = g0[w_lo:w_hi], g1[w_lo:w_hi]
+        if args.p2_pieces != 0:
+            # the reference driver's adaptive-window search (policy P2) over the same stream: its pieces are independent time
+            # ranges (own-piece gate), so rank r searches the pieces [P r / N, P (r + 1) / N) — with the bounds they have in
+            # the whole run (ecal_adaptive_params.piece_first / piece_count) — on its own range of the stream; no collective
+            from eventcalib_amd.adaptive import detect_keyframes_device
+            P = 5 * max(1, (os.cpu_count() or 3) - 2) if args.p2_pieces < 0 else args.p2_pieces
+            P = max(P, world)
+            tf, tl = 5.0, 5.0 + (n_events - 1) / rate
+            p_lo, p_hi = (P * rank) // world, (P * (rank + 1)) // world
+            step = (tl - tf) / P
+            k_lo = max(0, int((tl - step * p_hi - 5.0) * rate) - 4)        # (piece 0 is the LAST in time)
+            k_hi = min(n_events, int((tl - step * p_lo - 5.0) * rate) + 5)
+            del events, ev_s
+            torch.cuda.empty_cache()
+            ev_p = SS.make_stream(k_hi - k_lo, rate=rate, t_start=5.0, seed=12345, device=dev, k_offset=k_lo, total=n_events)
+            detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, piece_first=p_lo, piece_count=p_hi - p_lo)   # warm-up
+            barrier()
+            tb = time.perf_counter()
+            kp = detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, piece_first=p_lo, piece_count=p_hi - p_lo)
+            barrier()
+            el_p = time.perf_counter() - tb
+            agg = torch.tensor([float(len(kp["time"])), float(kp["windows"])], dtype=torch.float64, device=dev)
+            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+            mx = torch.tensor([el_p], dtype=torch.float64, device=dev)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            strong["policy_p2"] = {"value": round(n_events / float(mx[0].item()) / 1e6, 1), "unit": "Mevents/s", "pieces": P,
+                                   "pieces_per_gpu": p_hi - p_lo, "seconds": round(float(mx[0].item()), 4),
+                                   "keyframes": int(agg[0].item()), "windows_evaluated": int(agg[1].item()), "gate": "own piece",
+                                   "note": "the pieces of one search cut over the ranks, every rank on its own time range of the stream"}
+            events = ev_p
 
     out = {
         "metric": "Mevents/s DBSCAN+detect",

@@ -97,21 +97,26 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
 
 
 def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps=4.0,
-                            minpts=2, rows=9, cols=4, max_passes=0, gate_mode=0, n_threads=1, contexts=None):
+                            minpts=2, rows=9, cols=4, max_passes=0, gate_mode=0, n_threads=1, contexts=None, piece_first=0,
+                            piece_count=0):
     """Same result as detect_keyframes, with the policy on the device (ecal_detect_keyframes): no per-pass host round trip.
     gate_mode = capi.GATE_SHARED_MAP: the reference's single-worker run (one keyframe map for all pieces) instead of the
     own-piece gate.  Slots and the keyframe capacity are estimated and doubled when the library reports them too small.
 
     n_threads > 1 (own-piece gate only): the pieces are cut into that many contiguous groups, each searched by its own call
     on its own context and host thread (ecal_adaptive_params.piece_first / piece_count) — a lock-step pass is a chain of
-    latency-bound launches, several chains side by side fill the GPU; the keyframes are the same ones.  `contexts`: the
-    contexts to use (kept by the caller between calls: their scratch buffers stay allocated), else created and closed here."""
+    latency-bound launches; the keyframes are the same ones (measured on one MI355X: no gain, the passes of 1270 pieces
+    keep the GPU busy — the cut is there for several GPUs).  `contexts`: the contexts to use (kept by the caller between
+    calls: their scratch buffers stay allocated), else created and closed here.
+
+    piece_count != 0: only the pieces piece_first .. piece_first + piece_count - 1 (one rank's share of a search cut over
+    GPUs; `events` then only has to hold those pieces' time range)."""
     torch.cuda.synchronize(events.device)   # the passes run on the contexts' own streams: `events` must be complete
     n_ev = events.numel() // 25
     n_threads = max(1, min(int(n_threads), int(piece_num)))
-    if n_threads == 1 or gate_mode != 0:
+    if n_threads == 1 or gate_mode != 0 or piece_count:
         return _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps, minpts,
-                             rows, cols, max_passes, gate_mode, 0, 0)
+                             rows, cols, max_passes, gate_mode, piece_first, piece_count)
     import threading
     from .capi import Context
     own = contexts is None

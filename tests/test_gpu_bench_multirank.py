@@ -37,8 +37,8 @@ def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
 
 
 def test_two_ranks_match_one_rank():
-    one = _bench(1, [])
-    two = _bench(2, [])
+    one = _bench(1, ["--p2-pieces", "40"])
+    two = _bench(2, ["--p2-pieces", "40"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["events_per_gpu"] == one["config"]["events_per_gpu"] == 2000000     # weak scaling
     # ... and the strong-scaling leg beside it: ONE 2 M-event stream cut into two time ranges of whole windows — together
@@ -47,6 +47,12 @@ def test_two_ranks_match_one_rank():
     ss = two["strong_scaling"]
     assert ss["scaling"] == "strong" and ss["events_total"] == 2000000 and ss["events_covered_by_the_ranks_windows"] == 2000000
     assert ss["value"] > 0 and ss["windows_total"] == one["config"]["windows_per_gpu"]
+    # ... and the adaptive-window search of that stream with its pieces cut over the ranks: the keyframes and windows of the
+    # single-rank search (own-piece gate, same piece count)
+    p1 = [p for p in one["policy_p2"] if p.get("driver") == "device" and p.get("gate") == "own piece"][0]
+    p2 = ss["policy_p2"]
+    assert p2["pieces"] == p1["pieces"] and p2["pieces_per_gpu"] <= (p1["pieces"] + 1) // 2
+    assert p2["keyframes"] == p1["keyframes"] > 0 and p2["windows_evaluated"] == p1["windows_evaluated"]
     # the sharded init calibration lands on the single-rank answer (same 64 views, Schur records summed over ranks)
     c1, c2 = one["init_calibration"], two["init_calibration"]
     assert c1["views_per_gpu"] == 64 and c2["views_per_gpu"] == 32
