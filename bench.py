@@ -507,6 +507,16 @@ def e2e_leg(args, ctx, dev, torch, np):
     r = calibrate_stream(ctx, ev, t_start, t_start + (n - 1) / rate, piece_num=pieces)
     wall = time.perf_counter() - t0
     sp = r["spline"]
+    # the same chain with the reference's single-worker keyframe gate (one keyframe map for all pieces)
+    from eventcalib_amd import capi as _capi
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    rs = calibrate_stream(ctx, ev, t_start, t_start + (n - 1) / rate, piece_num=pieces, gate_mode=_capi.GATE_SHARED_MAP)
+    wall_s = time.perf_counter() - t0
+    shared = {"keyframes": rs["keyframes"], "wall_seconds_whole_chain": round(wall_s, 3),
+              "keyframe_search_seconds": round(rs["stage_seconds"]["keyframe_search"], 4),
+              "refined_fx_rel_err": float(abs(rs["intrinsics"][0] / SS.FX - 1)), "lm_iterations": rs["spline"]["iterations"],
+              "gate": "shared map, single worker (TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36)"}
     cpp = cpp_chain(ev, n, rate, t_start, pieces, np) if not os.environ.get("ECAL_BENCH_NO_CPP_CHAIN") else None
     # configs[4]'s camera through the same chain: Kannala-Brandt stream, fisheye init calibration / PnP / rectify / spline residual
     del ev
@@ -532,7 +542,7 @@ def e2e_leg(args, ctx, dev, torch, np):
             "stage_seconds": {k: round(v, 4) for k, v in rf["stage_seconds"].items()},
             "note": "Kannala-Brandt stream (k = 0.05, -0.01, 0.002, 0); fisheye model in the init calibration (started from the radial "
                     "model's focal length), PnP, rectifyFeatures' projections and the spline residual (new functionality)"}
-    return {"cpp_chain": cpp, "fisheye": fish, "events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
+    return {"cpp_chain": cpp, "fisheye": fish, "shared_map_gate": shared, "gate": "own piece", "events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
             "residuals_from_association": sp["residuals"], "unknowns": sp["unknowns"], "splines": sp["splines"],
             "lm_iterations": sp["iterations"], "lm_seconds": round(sp["seconds"], 4),
             "lm_iterations_per_s": round(sp["iterations"] / max(sp["seconds"], 1e-9), 2),

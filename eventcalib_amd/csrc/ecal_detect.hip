@@ -336,8 +336,11 @@ static int extract_exact(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
         return rc;
     // (only_tied_medians = 2: the tied clusters are the ones whose representative's slot the plain pass marked in `order`)
     if ((rc = ecal_cluster_order_sized(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, n_points, eps, d_labels, d_n_clusters, order, ostatus, 2, tlist,
-                                       tcnt, stream, pk)))
+                                       tcnt, stream, pk))) {
+        // the marks of this call must not outlive it (a later call over other windows would take them for its own)
+        (void) hipMemsetAsync(order, 0, ((size_t) n_points + 16) * sizeof(int32_t), (hipStream_t) stream);
         return rc;
+    }
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, order, tlist, tcnt, nullptr, nullptr,
                          nullptr, stream, pk);

@@ -38,3 +38,10 @@ L.ecal_debug_det_cycles(d, 0)
 d = list(d); dw = max(d[8], 1) / 2      # two timed runs accumulated? (reset only DBSCAN's) -> per call counts included
 print("extract kernel (cycles/WG over %d staged WGs): stage-in %.0f  label/scatter %.0f  rank scan %.0f  pairing+circle test %.0f  write-out %.0f"
       % (d[8], d[0] / max(d[8], 1), d[1] / max(d[8], 1), d[2] / max(d[8], 1), d[3] / max(d[8], 1), d[4] / max(d[8], 1)))
+b = (ctypes.c_ulonglong * 16)()
+L.ecal_debug_bo_cycles(b, 1)
+pipe.run(ev); torch.cuda.synchronize()
+L.ecal_debug_bo_cycles(b, 0)
+b = list(b); S2 = 2 * len(t0)
+print("member-order kernel (cycles per segment, all tiers summed, %d segments): stage-in + marks %.0f  tie vote %.0f  untied exit %.0f  tree %.0f  range queries %.0f  queue simulation + order out %.0f"
+      % (S2, b[0] / S2, b[1] / S2, b[2] / S2, b[3] / S2, b[4] / S2, b[5] / S2))
