@@ -155,8 +155,10 @@ def _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold
     n_mine = piece_count if piece_count else piece_num
     # a pass covers a chain of windows per piece: the library's own estimate, doubled whenever it reports it too small
     cap_max = min(2 ** 32 - 64, 6 * n_ev + 4096)     # (the hint's own maximum: the windows of one slot index are disjoint)
-    cap = capi.detect_keyframes_cap_hint(ctx, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time,
-                                         piece_first, piece_count)
+    cap = capi.detect_keyframes_cap_hint_dev(ctx, events.data_ptr(), n_ev, motion_time_step, frame_event_num_threshold, piece_num,
+                                             start_time, end_time, piece_first, piece_count)
+    if cap == 0:
+        raise capi.EcalError(-1, "ecal_detect_keyframes_cap_hint_dev: invalid parameters")
     max_keys = int(span * n_mine / piece_num / (8 * motion_time_step)) + n_mine + 64   # one keyframe per window + gap at the very most
     while True:
         try:

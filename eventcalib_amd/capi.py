@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
-    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_detect_keyframes_cap_hint", "ecal_rectify_batch_dev", "ecal_rectify_batch",
+    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_detect_keyframes_cap_hint", "ecal_detect_keyframes_cap_hint_dev", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion", "ecal_solver_create_dev", "ecal_solver_num_residuals",
@@ -831,6 +831,17 @@ def detect_keyframes_cap_hint(ctx: Context, n_events, motion_time_step, frame_ev
     ap = AdaptiveParams(float(motion_time_step), int(frame_event_num_threshold), int(piece_num), float(start_time), float(end_time), 0, 0, 0,
                         int(piece_first), int(piece_count))
     return int(L.ecal_detect_keyframes_cap_hint(ctypes.byref(ap), int(n_events)))
+
+
+def detect_keyframes_cap_hint_dev(ctx: Context, d_events, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time,
+                                  end_time, piece_first=0, piece_count=0):
+    """ecal_detect_keyframes_cap_hint_dev: the hint from the events of the resident stream inside [start_time, end_time]."""
+    L = ctx._L
+    L.ecal_detect_keyframes_cap_hint_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(AdaptiveParams)]
+    L.ecal_detect_keyframes_cap_hint_dev.restype = ctypes.c_uint64
+    ap = AdaptiveParams(float(motion_time_step), int(frame_event_num_threshold), int(piece_num), float(start_time), float(end_time), 0, 0, 0,
+                        int(piece_first), int(piece_count))
+    return int(L.ecal_detect_keyframes_cap_hint_dev(ctx._h, d_events, int(n_events), ctypes.byref(ap)))
 
 
 def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time,

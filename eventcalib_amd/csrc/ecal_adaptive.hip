@@ -443,6 +443,29 @@ extern "C" uint64_t ecal_detect_keyframes_cap_hint(const ecal_adaptive_params *a
     return cap > 4294967232.0 ? 4294967232ull : (uint64_t) cap;
 }
 
+// the same estimate from the events that lie in [start_time, end_time] (two binary searches on the resident stream): a search
+// over part of a stream is sized for that part
+extern "C" uint64_t ecal_detect_keyframes_cap_hint_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events,
+                                                       const ecal_adaptive_params *ap) {
+    if (!ctx || !ap || (n_events && !d_events)) return 0;
+    if (n_events == 0) return ecal_detect_keyframes_cap_hint(ap, 0);
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
+    ecal_devbuf *B = ctx->host_pipe;
+    if (ecal_ensure(ctx, B[0], 2 * sizeof(double)) || ecal_ensure(ctx, B[2], 4) || ecal_ensure(ctx, B[3], 4) || ecal_ensure(ctx, B[4], 8)) return 0;
+    const double t[2] = {ap->start_time, ap->end_time};
+    uint32_t lo = 0, hi = 0;
+    hipStream_t st = ctx->stream;
+    if (hipMemcpyAsync(B[0].ptr, t, sizeof(t), hipMemcpyHostToDevice, st) != hipSuccess) return 0;
+    if (ecal_window_bounds_dev(ctx, d_events, n_events, (const double *) B[0].ptr, (const double *) B[0].ptr + 1, 1, (uint32_t *) B[2].ptr,
+                               (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, st))
+        return 0;
+    if (hipMemcpyAsync(&lo, B[2].ptr, 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(&hi, B[3].ptr, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+        return 0;
+    const uint64_t hint = ecal_detect_keyframes_cap_hint(ap, hi > lo ? hi - lo : 0);
+    return hint < 4096 ? 4096 : hint;
+}
+
 extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                                      const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                                      double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,

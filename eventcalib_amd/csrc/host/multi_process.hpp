@@ -216,7 +216,8 @@ inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, 
     const double span = std::max(endTime - startTime, 1e-9);
     // a pass covers a chain of windows per piece: the library's own estimate, doubled on ECAL_ERR_RANGE
     const uint64_t cap_max = std::min<uint64_t>(0xFFFFFFC0ull, 6 * n + 4096);   // (the hint's own maximum: the windows of one slot index are disjoint)
-    uint64_t cap = ecal_detect_keyframes_cap_hint(&ap, n);
+    uint64_t cap = ecal_detect_keyframes_cap_hint_dev(ecal_host::thread_ctx(), ecal_stream_data(es), n, &ap);
+    if (cap == 0) throw std::runtime_error("ecal_detect_keyframes_cap_hint_dev: invalid parameters");
     uint32_t max_keys = (uint32_t) (span / (8 * motionTimeStep)) + (uint32_t) pieceNum + 64;
     std::vector<double> t, d, f;
     std::vector<int32_t> e;

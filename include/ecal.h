@@ -398,6 +398,9 @@ int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
 /* a cap_points that ecal_detect_keyframes will usually find sufficient for a stream of n_events events (0: invalid
  * parameters); ECAL_ERR_RANGE still says when it was not — double it and call again */
 uint64_t ecal_detect_keyframes_cap_hint(const ecal_adaptive_params *ap, uint64_t n_events);
+/* ... from the events of the resident stream that lie in [start_time, end_time] (n_events above = events IN that range: a
+ * search over part of a stream is sized for that part).  Synchronous on the context's stream; 0 on an error */
+uint64_t ecal_detect_keyframes_cap_hint_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap);
 int ecal_pin_host(ecal_ctx *ctx, void *ptr, size_t bytes);   /* hipHostRegister */
 int ecal_unpin_host(ecal_ctx *ctx, void *ptr);
 int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events /*host*/, uint64_t n_events, double t_start, double window_len,
