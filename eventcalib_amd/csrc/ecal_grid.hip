@@ -58,6 +58,21 @@ __device__ __forceinline__ unsigned long long pack_key(double d2, uint32_t idx) 
     return (((unsigned long long) __double_as_longlong(d2)) & ~0xFFull) | (idx & 0xFFu);
 }
 
+#ifdef ECAL_PHASE_PROF
+static __device__ unsigned long long g_gr_cycles[16];
+static __device__ unsigned long long g_gr_hist[32];   // [0..23]: windows by log2 of their cycles; [24]: max (cycles << 24 | n << 16 | nodes << 8 | sweeps)
+#define GR_MARK(i)                                                       \
+    do {                                                                 \
+        if (lane == 0) {                                                 \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime(); \
+            atomicAdd(&g_gr_cycles[i], now__ - gr_t__);                  \
+            gr_t__ = now__;                                              \
+        }                                                                \
+    } while (0)
+#else
+#define GR_MARK(i)
+#endif
+
 __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__restrict__ win_info,
                                                           const uint32_t *__restrict__ seg_off,
                                                           const double *__restrict__ cand_xyr, uint32_t rows,
@@ -71,6 +86,9 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     __shared__ double hm[24];             // moment sums of the partial grid's homography fit (second attempt)
     __shared__ double hh[8];
     __shared__ uint32_t sh_qt;
+    __shared__ int sh_box[4];                       // box of the visited lattice cells (match_pattern)
+    __shared__ int8_t mU[GR_MAXM], mV[GR_MAXM];     // lattice coordinates of the model points relative to model point 0
+    __shared__ int8_t tf_sh[4 * GR_NTF];            // the table of basis changes
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
     const uint32_t n = win_info[4 * (size_t) s], M = rows * cols;
     int32_t *out = order + (size_t) s * M;
@@ -84,6 +102,13 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         assigned[i] = 0;
     }
     for (uint32_t k = lane; k < GR_L * GR_L; k += GR_T) occ[k] = 0;
+    for (uint32_t m = lane; m < M; m += GR_T) {   // model point (x, y) = (2 j + i % 2, i): U = (x + y) / 2, V = (y - x) / 2
+        const int i = (int) (m / cols), jj = (int) (m % cols);
+        const int x = 2 * jj + (i & 1), y = i;
+        mU[m] = (int8_t) ((x + y) / 2);
+        mV[m] = (int8_t) ((y - x) / 2);
+    }
+    for (uint32_t k = lane; k < 4u * GR_NTF; k += GR_T) tf_sh[k] = GR_TF[k / 4u][k % 4u];
     __syncthreads();
 
     // nearest candidate to (qx, qy) among those passing `want`; returns packed (dist^2, index)
@@ -108,6 +133,19 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         sx += __shfl_xor(sx, o, 64);
         sy += __shfl_xor(sy, o, 64);
     }
+#ifdef ECAL_PHASE_PROF
+    unsigned long long gr_t__ = __builtin_amdgcn_s_memtime();
+    const unsigned long long gr_t0__ = gr_t__;
+    uint32_t gr_sweeps__ = 0;
+    if (lane == 0) atomicAdd(&g_gr_cycles[15], 1ull);
+    auto gr_done__ = [&](uint32_t nodes) {
+        if (lane == 0) {
+            const unsigned long long cyc = __builtin_amdgcn_s_memtime() - gr_t0__;
+            atomicAdd(&g_gr_hist[63 - __clzll((long long) (cyc | 1ull)) < 23 ? 63 - __clzll((long long) (cyc | 1ull)) : 23], 1ull);
+            atomicMax(&g_gr_hist[24], (cyc << 24) | ((unsigned long long) (n & 0xFFu) << 16) | ((unsigned long long) (nodes & 0xFFu) << 8) | (gr_sweeps__ & 0xFFu));
+        }
+    };
+#endif
     const uint32_t seed = (uint32_t) (nearest(sx / n, sy / n, false, 0xFFFFFFFFu) & 0xFFu);
     // its nearest neighbours give the walk's two steps: the nearest one, and the nearest one that is not (anti)parallel to
     // it.  In a frontal view these are two of the four diagonal neighbours; under steep perspective some other pair of short
@@ -147,6 +185,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         bx = -bx;
         by = -by;
     }
+    GR_MARK(0);   // seed + basis
     // breadth-first walk
     uint32_t qh = 0, qt = 0;
     if (lane == 0) {
@@ -200,6 +239,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         }
     }
     __syncthreads();
+    GR_MARK(1);   // first walk
     auto match_pattern = [&]() -> bool {
         if (qt < M) return false;
         // match the pattern: model point (x, y) = ((2j + i%2), i) has lattice coordinates U = (x+y)/2, V = (y-x)/2 in the
@@ -210,54 +250,72 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         // T in SL2(Z) with entries in [-2, 2] (the four rotations first) and every visited node is tried as the image of model
         // point 0.  (This is what the vendored finder's second attempt on the homography-rectified points and its clustering
         // variant are for, cv_calib.cpp:34-84, circlesgrid.cpp:72-180: a complete pattern seen at a steep angle is still found.)
-        auto transform_of = [](uint32_t t, int &a, int &b, int &c, int &d) {
-            a = GR_TF[t][0];
-            b = GR_TF[t][1];
-            c = GR_TF[t][2];
-            d = GR_TF[t][3];
-        };
-        auto cell_of = [&](uint32_t anchor, int a, int b, int c, int d, uint32_t m, int &u, int &v) {
-            const int i = (int) (m / cols), jj = (int) (m % cols);
-            const int x = 2 * jj + (i & 1), y = i;
-            const int U = (x + y) / 2, V = (y - x) / 2;  // relative to model point 0 = (0, 0)
-            u = cu[anchor] + a * U + b * V;
-            v = cv[anchor] + c * U + d * V;
-        };
-        const uint32_t combos = GR_NTF * qt;
-        uint32_t win = 0xFFFFFFFFu;
-        for (uint32_t cb0 = 0; cb0 < combos && win == 0xFFFFFFFFu; cb0 += GR_T) {   // (in order: the first match wins, rotations first)
-            const uint32_t cb = cb0 + lane;
-            bool ok = cb < combos;
-            int a = 0, b = 0, c = 0, d = 0;
-            if (ok) transform_of(cb / qt, a, b, c, d);
-            const uint32_t anchor_c = ok ? queue[cb % qt] : 0u;
-            auto occupied = [&](uint32_t m) -> bool {
-                int u, v;
-                cell_of(anchor_c, a, b, c, d, m, u, v);
-                return u >= -GR_L / 2 && u < GR_L / 2 && v >= -GR_L / 2 && v < GR_L / 2 &&
-                       occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] != 0;
-            };
-            // (a conjunction over the cells: the order of the tests is free — the pattern's far corners fail first for nearly
-            // every wrong combination, so the wave's slowest lane is done after three tests instead of a dozen)
-            ok = ok && occupied(M - 1u) && occupied(cols - 1u) && occupied(M - cols);
-            for (uint32_t m = 0; m < M && ok; m++) ok = occupied(m);
-            uint32_t mine = ok ? cb : 0xFFFFFFFFu;
-            for (int o = 32; o > 0; o >>= 1) mine = min(mine, (uint32_t) __shfl_xor((int) mine, o, 64));
-            win = mine;
+        // The model points' lattice coordinates are worked out once (mU, mV); the transforms go one after the other (the same
+        // for the whole wave), a lane per anchor.  A transform whose image of the pattern is wider or taller than the box of
+        // the visited cells cannot match whatever the anchor: most of the sheared ones end there, after a handful of
+        // lane-uniform operations (the pattern's extent is that of its four corner points).
+        if (lane == 0) {
+            sh_box[0] = sh_box[2] = 127;
+            sh_box[1] = sh_box[3] = -128;
         }
-        if (win == 0xFFFFFFFFu) return false;
-        int ta, tb, tc, td;
-        transform_of(win / qt, ta, tb, tc, td);
-        const uint32_t anchor = queue[win % qt];
-        for (uint32_t m = lane; m < M; m += GR_T) {
-            int u, v;
-            cell_of(anchor, ta, tb, tc, td, m, u, v);
-            out[m] = (int32_t) occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1;
+        __syncthreads();
+        for (uint32_t k = lane; k < qt; k += GR_T) {
+            const uint32_t j = queue[k];
+            atomicMin(&sh_box[0], (int) cu[j]);
+            atomicMax(&sh_box[1], (int) cu[j]);
+            atomicMin(&sh_box[2], (int) cv[j]);
+            atomicMax(&sh_box[3], (int) cv[j]);
+        }
+        __syncthreads();
+        const int box_u = sh_box[1] - sh_box[0], box_v = sh_box[3] - sh_box[2];
+        const uint32_t corner[3] = {cols - 1u, M - cols, M - 1u};
+        uint32_t win_t = 0xFFFFFFFFu, win_anchor = 0;
+        for (uint32_t t = 0; t < GR_NTF && win_t == 0xFFFFFFFFu; t++) {   // (in order: the first match wins, rotations first)
+            const int a = tf_sh[4 * t], b = tf_sh[4 * t + 1], c = tf_sh[4 * t + 2], d = tf_sh[4 * t + 3];
+            int ulo = 0, uhi = 0, vlo = 0, vhi = 0;   // (model point 0 sits at the anchor)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int du = a * mU[corner[q]] + b * mV[corner[q]], dv = c * mU[corner[q]] + d * mV[corner[q]];
+                ulo = min(ulo, du);
+                uhi = max(uhi, du);
+                vlo = min(vlo, dv);
+                vhi = max(vhi, dv);
+            }
+            if (uhi - ulo > box_u || vhi - vlo > box_v) continue;
+            for (uint32_t k0 = 0; k0 < qt && win_t == 0xFFFFFFFFu; k0 += GR_T) {
+                const uint32_t k = k0 + lane;
+                const uint32_t anchor_c = k < qt ? queue[k] : 0u;
+                const int u0 = cu[anchor_c], v0 = cv[anchor_c];
+                auto occupied = [&](uint32_t m) -> bool {
+                    const int u = u0 + a * mU[m] + b * mV[m], v = v0 + c * mU[m] + d * mV[m];
+                    return u >= -GR_L / 2 && u < GR_L / 2 && v >= -GR_L / 2 && v < GR_L / 2 &&
+                           occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] != 0;
+                };
+                // (a conjunction over the cells: the order of the tests is free — the far corners fail first for nearly every
+                // wrong anchor, so the wave's slowest lane is done after three tests instead of a dozen)
+                bool ok = k < qt && occupied(corner[2]) && occupied(corner[0]) && occupied(corner[1]);
+                if (__ballot(ok) == 0ull) continue;
+                for (uint32_t m = 0; m < M && ok; m++) ok = occupied(m);
+                const unsigned long long hits = __ballot(ok);
+                if (hits) {
+                    win_t = t;
+                    win_anchor = queue[k0 + (uint32_t) __ffsll((long long) hits) - 1u];
+                }
+            }
+        }
+        if (win_t == 0xFFFFFFFFu) return false;
+        {
+            const int a = tf_sh[4 * win_t], b = tf_sh[4 * win_t + 1], c = tf_sh[4 * win_t + 2], d = tf_sh[4 * win_t + 3];
+            for (uint32_t m = lane; m < M; m += GR_T) {
+                const int u = cu[win_anchor] + a * mU[m] + b * mV[m], v = cv[win_anchor] + c * mU[m] + d * mV[m];
+                out[m] = (int32_t) occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1;
+            }
         }
         return true;
 
     };
     bool got = match_pattern();
+    GR_MARK(2);   // first match
     if (!got && qt >= 4u) {
         // Second attempt, as cv::findCirclesGrid's (cv_calib.cpp:34-84: the holes found so far give a homography,
         // CirclesGridFinder::rectifyGrid, and the search runs again on the rectified points).  Under steep perspective the
@@ -352,48 +410,32 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             }
             __syncthreads();
         };
-        // Are the first walk's labels one consistent perspective view of a lattice?  Then the walk did not go astray — it
-        // stopped because circles are missing (the usual reason a window of the adaptive search has no grid yet) —, its nodes
-        // stay and only the open cells around them are tried again with the homography's predictions: one sweep that adds
-        // nothing ends the attempt.  Otherwise (a step landed on the wrong neighbour) only the seed's 3 x 3 neighbourhood is
-        // kept and the walk is redone ring by ring.
-        bool consistent = false;
-        fit_h();
-        if (hh[0] == hh[0]) {
-            double worst = 0.0;
-            for (uint32_t k = lane; k < qt; k += GR_T) {
+        // Only the seed's 3 x 3 neighbourhood of the first walk is kept (a step of that walk may have landed on the wrong
+        // neighbour) and the walk is redone ring by ring with the homography's predictions, refitted after every ring.
+        // (Keeping a first walk whose nodes all lie near one homography instead was measured: at 2 px it is 4 walks in 18 000 —
+        // lens distortion —, at a third of a lattice step it changes nothing in the kernel's time.)
+        if (lane == 0) {
+            uint32_t keep = 0;
+            for (uint32_t k = 0; k < qt; k++) {
                 const uint32_t j = queue[k];
-                const double u = cu[j], v = cv[j], wq = hh[6] * u + hh[7] * v + 1.0;
-                const double ex = (hh[0] * u + hh[1] * v + hh[2]) / wq - px[j], ey = (hh[3] * u + hh[4] * v + hh[5]) / wq - py[j];
-                const double d2 = wq > 1e-6 ? ex * ex + ey * ey : 1e300;
-                worst = d2 > worst ? d2 : worst;
+                if (cu[j] >= -1 && cu[j] <= 1 && cv[j] >= -1 && cv[j] <= 1) {
+                    queue[keep++] = (uint8_t) j;
+                } else {
+                    assigned[j] = 0;
+                    occ[(cv[j] + GR_L / 2) * GR_L + (cu[j] + GR_L / 2)] = 0;
+                }
             }
-            for (int o = 32; o > 0; o >>= 1) {
-                const double w = __shfl_xor(worst, o, 64);
-                worst = w > worst ? w : worst;
-            }
-            consistent = worst <= 2.0 * 2.0;   // px^2
+            sh_qt = keep;
         }
         __syncthreads();
-        if (!consistent) {
-            if (lane == 0) {
-                uint32_t keep = 0;
-                for (uint32_t k = 0; k < qt; k++) {
-                    const uint32_t j = queue[k];
-                    if (cu[j] >= -1 && cu[j] <= 1 && cv[j] >= -1 && cv[j] <= 1) {
-                        queue[keep++] = (uint8_t) j;
-                    } else {
-                        assigned[j] = 0;
-                        occ[(cv[j] + GR_L / 2) * GR_L + (cu[j] + GR_L / 2)] = 0;
-                    }
-                }
-                sh_qt = keep;
-            }
-            __syncthreads();
-            qt = sh_qt;
-        }
+        qt = sh_qt;
         for (int sweep = 0; sweep < 20 && !got && qt >= 4u; sweep++) {
-            if (sweep > 0 || !consistent) fit_h();
+            GR_MARK(3);   // (restart, loop overhead)
+#ifdef ECAL_PHASE_PROF
+            gr_sweeps__++;
+#endif
+            fit_h();
+            GR_MARK(4);   // homography fits
             if (!(hh[0] == hh[0])) break;
             const uint32_t qt_before = qt;
             for (uint32_t qi = 0; qi < qt_before; qi++) {
@@ -425,10 +467,15 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                     __syncthreads();
                 }
             }
+            GR_MARK(5);   // sweeps' searches
             if (qt == qt_before) break;
             if (qt >= M) got = match_pattern();
+            GR_MARK(6);   // matches after sweeps
         }
     }
+#ifdef ECAL_PHASE_PROF
+    gr_done__(qt);
+#endif
     if (!got) return;
     if (lane == 0) found[s] = 1;
 }
@@ -454,3 +501,23 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
+
+#ifdef ECAL_PHASE_PROF
+extern "C" int ecal_debug_grid_cycles(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_gr_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset >= 2) {   // the histogram instead
+        unsigned long long hst[32];
+        if (hipMemcpyFromSymbol(hst, HIP_SYMBOL(ecal::g_gr_hist), sizeof(hst)) != hipSuccess) return -1;
+        for (int i = 0; i < 16; i++) out16[i] = hst[i + 10];   // 2^10 .. 2^23+ and the max in [14] -> out16[14]
+        out16[14] = hst[24];
+        unsigned long long z[32] = {0};
+        if (reset == 3 && hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_gr_hist), z, sizeof(z)) != hipSuccess) return -1;
+        return 0;
+    }
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_gr_cycles), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
