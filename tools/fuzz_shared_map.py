@@ -1,0 +1,37 @@
+"""Debug: ecal_detect_keyframes under the shared-map gate (speculation + verification rounds) against the sequential
+single-worker oracle (oracle/policy_oracle.cpp mode 1) over random streams, rates, trajectories, piece counts — and the
+own-piece gate against mode 0 on the same windows.  extractFeatures() of a window comes to the oracle from the product's
+detection stages (ecal_detect_pass, cached): what is compared is the policy."""
+import os, sys, itertools
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import eventcalib_amd
+import eventcalib_amd.capi as capi
+from eventcalib_amd.adaptive import detect_keyframes_device
+import synth_stream as SS
+import oracle_lib as O
+import test_gpu_adaptive as TA
+ctx = eventcalib_amd.Context(0)
+n_ok = 0
+for seed, (rate, traj), pieces in itertools.product(range(int(sys.argv[1]) if len(sys.argv) > 1 else 2),
+                                                    ((0.7e6, "hover"), (1.0e6, "orbit"), (2.0e6, "hover"), (1.4e6, "orbit")), (2, 9, 61, 333)):
+    n = 1_500_000
+    SS.TRAJECTORY = traj
+    try:
+        ev = SS.make_stream(n, rate=rate, device="cuda", seed=900 + seed, noise_frac=0.05 + 0.04 * seed)
+    finally:
+        SS.TRAJECTORY = "hover"
+    torch.cuda.synchronize()
+    t_first, t_last = 5.0, 5.0 + (n - 1) / rate
+    cache = {}
+    detect = TA._oracle_detect(ctx, ev, n, cache)
+    ref = O.policy_run(detect, t_first, t_last, pieces, 5e-4, 4000, 9, 4, mode=1)
+    own = O.policy_run(detect, t_first, t_last, pieces, 5e-4, 4000, 9, 4, mode=0)
+    dev = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
+    TA._same_keyframes(dev, ref)
+    TA._same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last), own)
+    n_ok += 1
+    print("seed %d rate %.1f %s pieces %d: shared map %d keyframes, own piece %d, %d windows" %
+          (seed, rate / 1e6, traj, pieces, len(ref["time"]), len(own["time"]), ref["windows"]), flush=True)
+print("all", n_ok, "runs: both gates == the policy oracle")
