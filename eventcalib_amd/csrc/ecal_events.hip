@@ -158,6 +158,7 @@ struct SliceWork {
     uint32_t *pos;   // [n] packed exclusive counts: low 16/.. see below (LDS) or two words (global)
     uint32_t *red;   // block-scan scratch (LDS)
     uint32_t bend_words = 0;   // words of bend[] when it lives in LDS (else 0)
+    uint32_t pts_words = 0;    // words of pts[] when it lives in LDS (else 0)
 };
 
 __device__ __forceinline__ uint32_t pixel_hash(double x, double y) {
@@ -293,23 +294,25 @@ __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint
     __syncthreads();
     if (reforder) {
         // e'. per polarity: the set's iteration order of its keys (slice_order.hpp), then the erased keys drop out
-        const OrderScratch w = *ord;
         const uint32_t mk[2] = {nN, nP};
         uint32_t kept_tot[2] = {0u, 0u};
+        // the keys' hashes, both sets at once (the + set's at h[0 .. nP), the - set's behind them): in the LDS tiers the decoded
+        // points then make room for the order pass — its epochs' arrays, 32 bytes a key, where the points' 16 bytes an event
+        // were: epochs of up to CAP / 2 buckets (2357 for a window of 5000 events) stay out of global memory; the points
+        // are decoded once more for the outputs
+        for (uint32_t k = tid; k < n; k += T)
+            if ((rep[k] & ~ERASED) == k) ord->h[(pol[k] ? 0u : nP) + pos[k]] = ref_pixel_hash(pts[k].x, pts[k].y);
+        __syncthreads();
         for (int pl = 1; pl >= 0; pl--) {
             const uint32_t m = mk[pl];
             if (m) {
-                for (uint32_t k = tid; k < n; k += T) {
-                    if ((uint32_t) pol[k] == (uint32_t) pl && (rep[k] & ~ERASED) == k) {
-                        const uint32_t u = pos[k];
-                        w.h[u] = ref_pixel_hash(pts[k].x, pts[k].y);
-                        evk[u] = k;
-                    }
-                }
+                OrderScratch w = *ord;
+                if (pl == 0) w.h += nP;
+                for (uint32_t k = tid; k < n; k += T)
+                    if ((uint32_t) pol[k] == (uint32_t) pl && (rep[k] & ~ERASED) == k) evk[pos[k]] = k;
                 __syncthreads();
-                // (bend[] — the counting sort's bucket ends, CAP + 4 words — is dead since step d: the small epochs' arrays)
                 if constexpr (GLOBAL) reference_list_order<T>(w, m, wk.red);
-                else reference_list_order<T, (sizeof(Idx) == 2 ? 10 : 0)>(w, m, wk.red, bend, wk.bend_words / 8u);   // (LDS tiers: <= 10 keys a thread)
+                else reference_list_order<T, (sizeof(Idx) == 2 ? 10 : 0)>(w, m, wk.red, reinterpret_cast<uint32_t *>(pts), wk.pts_words / 8u);   // (LDS tiers: <= 10 keys a thread)
                 for (uint32_t u = tid; u < m; u += T) w.cnt[w.cur[u]] = (rep[evk[u]] & ERASED) ? 0u : 1u;   // by list position
                 __syncthreads();
                 const uint32_t perq = (m + T - 1) / T, q0 = tid * perq;
@@ -339,7 +342,17 @@ __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint
         } else {
             const uint32_t at = pos[r];
             event_point[k] = (int32_t) at;
-            if (r == k) out2[pol[k] ? at : nP + at] = pts[k];
+            if (r == k) {
+                double2 p;
+                if (!GLOBAL && reforder) {   // (the LDS tiers' point buffer served the order pass)
+                    const uint8_t *rr = rec + (uint64_t) (lo + k) * RECORD_BYTES;
+                    p.x = load_f64_unaligned(rr + 8);
+                    p.y = load_f64_unaligned(rr + 16);
+                } else {
+                    p = pts[k];
+                }
+                out2[pol[k] ? at : nP + at] = p;
+            }
         }
     }
     *n_pos_out = nP;
@@ -419,6 +432,7 @@ __device__ __forceinline__ void slice_tier_window(unsigned char *smem, uint32_t 
     w.pts = reinterpret_cast<double2 *>(smem + L::pts_off);
     w.bend = reinterpret_cast<uint32_t *>(smem + L::bend_off);
     w.bend_words = CAP + 4;
+    w.pts_words = 4 * CAP;
     w.pos = reinterpret_cast<uint32_t *>(smem + L::pos_off);
     w.sorted = reinterpret_cast<uint16_t *>(smem + L::sorted_off);
     w.rep = reinterpret_cast<uint16_t *>(smem + L::rep_off);
