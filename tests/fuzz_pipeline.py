@@ -1,7 +1,7 @@
 """Debug: the whole detection pass (slicing, DBSCAN labels, extraction) against the CPU oracle on many small random streams:
 event rates from 0.5 to 3.5 Mev/s (first passes, second passes and general tiers all get their share), noise 5-30 %."""
 import os, sys, itertools
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (tests/ holds the oracle-checked fuzzers: only tests may call the oracle)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import eventcalib_amd

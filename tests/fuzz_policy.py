@@ -2,7 +2,7 @@
 same call with one window per piece and pass (ECAL_ADAPTIVE_DEPTH=1: the reference's loop as it stands, which the tests pin
 on the policy oracle) over random streams, rates and piece counts: same keyframes, same windows."""
 import os, sys, itertools
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (tests/ holds the oracle-checked fuzzers: only tests may call the oracle)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import eventcalib_amd

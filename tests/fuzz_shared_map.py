@@ -3,7 +3,7 @@ single-worker oracle (oracle/policy_oracle.cpp mode 1) over random streams, rate
 own-piece gate against mode 0 on the same windows.  extractFeatures() of a window comes to the oracle from the product's
 detection stages (ecal_detect_pass, cached): what is compared is the policy."""
 import os, sys, itertools
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (tests/ holds the oracle-checked fuzzers: only tests may call the oracle)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import eventcalib_amd
