@@ -34,9 +34,15 @@ namespace ecal {
 // points) and third (<= 4096 points, <= 2048 clusters: 141 KB, one workgroup per CU) run 1024 threads: the few segments that
 // reach them (windows grown by the adaptive policy) are on the critical path of a lock-step pass, where the latency of ONE
 // segment counts.
-constexpr int BO_T1 = 256, BO_T2 = 1024;
+#ifndef ECAL_BO_T1B
+#define ECAL_BO_T1B 512
+#endif
+#ifndef ECAL_BO_WG2
+#define ECAL_BO_WG2 2
+#endif
+constexpr int BO_T1 = 256, BO_T1B = ECAL_BO_T1B, BO_T2 = 1024;
 constexpr uint32_t BO_CAP1 = 768, BO_CAP2 = 2048, BO_CAP3 = 4096;
-constexpr uint32_t BO_WG1 = 8, BO_WG2 = 1, BO_WG3 = 1;   // workgroups per CU
+constexpr uint32_t BO_WG1 = 8, BO_WG2 = ECAL_BO_WG2, BO_WG3 = 1;   // workgroups per CU
 constexpr uint32_t BO_WAVE_MIN = 32;     // clusters of at least this many members: a wave runs the queue (a lane per neighbour)
 constexpr uint32_t BO_MAXN = 64;         // hits per range query kept (a disc of radius 4 holds 48 other pixels)
 // Range-query lists kept in LDS (handed out first come first served; the rest go to global scratch).  The first tier keeps a
@@ -50,11 +56,11 @@ constexpr uint32_t BO_NONE = 0xFFFFFFFFu;
 
 template <uint32_t CAP>
 struct BoLayout {
-    static constexpr uint32_t NCAP = CAP == BO_CAP1 ? 256u : 2048u;       // clusters per segment
-    static constexpr uint32_t POOL = CAP == BO_CAP1 ? 8u : (CAP == BO_CAP2 ? 640u : 168u);
+    static constexpr uint32_t NCAP = CAP == BO_CAP1 ? 256u : (CAP == BO_CAP2 && ECAL_BO_WG2 > 1 ? (ECAL_BO_WG2 > 2 ? 512u : 1024u) : 2048u);   // clusters per segment
+    static constexpr uint32_t POOL = CAP == BO_CAP1 ? 8u : (CAP == BO_CAP2 ? (ECAL_BO_WG2 > 1 ? (ECAL_BO_WG2 > 2 ? 12u : 200u) : 640u) : 168u);
     // coordinates: the first tier holds them as floats and takes only segments whose doubles ARE floats (pixels are) — read
     // back and widened they are the same numbers, and 6 KB less LDS is two more workgroups per CU; the rest keep doubles
-    static constexpr size_t CB = CAP == BO_CAP1 ? 4 : 8;
+    static constexpr size_t CB = (CAP == BO_CAP1 || (CAP == BO_CAP2 && ECAL_BO_WG2 > 1)) ? 4 : 8;
     static constexpr size_t px_off = 0;                                   // f32 | f64 [CAP]
     static constexpr size_t py_off = px_off + CB * CAP;                   // f32 | f64 [CAP]
     static constexpr size_t child_off = py_off + CB * CAP;                // u32[2 CAP]: children (left, right) of node i
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
             if (inexact) red[5] = 1;
             __syncthreads();
             if (red[5]) {
-                if (tid == 0) defer_list[atomicAdd(&defer_cnt[0], 1u)] = s;
+                if (tid == 0) defer_list[(size_t) TIER * S + atomicAdd(&defer_cnt[TIER], 1u)] = s;   // (to the next launch)
                 continue;
             }
         }
@@ -914,7 +920,7 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
     if (!ctx->bfs_attr_set) {
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP1, BO_T1, 0>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP1>::bytes));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP2, BO_T2, 1>),
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP2, BO_T1B, 1>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP2>::bytes));
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&cluster_order_kernel<BO_CAP3, BO_T2, 2>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) BoLayout<BO_CAP3>::bytes));
@@ -931,7 +937,7 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
             if ((rcu = ecal_unpack_listed(ctx, pk, dlist + (size_t) k * S, dcnt + k, S, d_seg_off, d_seg_cnt, const_cast<double *>(d_xy), 0, st)))
                 return rcu;
     }
-    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP2, BO_T2, 1>), dim3(grid2), dim3(BO_T2), BoLayout<BO_CAP2>::bytes, st, d_xy, d_seg_off,
+    hipLaunchKernelGGL((cluster_order_kernel<BO_CAP2, BO_T1B, 1>), dim3(grid2), dim3(BO_T1B), BoLayout<BO_CAP2>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
                        nullptr, nullptr);
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP3, BO_T2, 2>), dim3(grid3), dim3(BO_T2), BoLayout<BO_CAP3>::bytes, st, d_xy, d_seg_off,

@@ -2,7 +2,11 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import torch, eventcalib_amd, synth_stream as SS
+import torch
+if os.environ.get("ECAL_AB_LIB"):        # A/B: another build of the library (ab_libs/)
+    import eventcalib_amd.capi as _capi
+    _capi.lib_path = lambda: os.path.abspath(os.environ["ECAL_AB_LIB"])
+import eventcalib_amd, synth_stream as SS
 from eventcalib_amd.adaptive import detect_keyframes, detect_keyframes_device
 from eventcalib_amd.pipeline import DetectPipeline
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
