@@ -596,6 +596,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
                 if (ring[4 * q + 3]) {
                     (void) hipStreamSynchronize(st);
                     ctx->last_error = range_msg;
+                    if (getenv("ECAL_ADAPTIVE_TRACE")) fprintf(stderr, "ecal_detect_keyframes: cap_points %u too small after %u passes\n", cap_points, n_passes);
                     return ECAL_ERR_RANGE;
                 }
                 if (ring[4 * q] == 0) break;   // (the passes enqueued since find nothing to do)
@@ -632,6 +633,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));
         if (h[3]) {   // (an overflow may sit in any of the last passes)
             ctx->last_error = range_msg;
+            if (getenv("ECAL_ADAPTIVE_TRACE")) fprintf(stderr, "ecal_detect_keyframes: cap_points %u too small (seen at the end, %u passes)\n", cap_points, n_passes);
             return ECAL_ERR_RANGE;
         }
         return ECAL_OK;
