@@ -438,34 +438,89 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             GR_MARK(4);   // homography fits
             if (!(hh[0] == hh[0])) break;
             const uint32_t qt_before = qt;
-            for (uint32_t qi = 0; qi < qt_before; qi++) {
-                const uint32_t cur = queue[qi];
-                const int u0 = cu[cur], v0 = cv[cur];
+            // One ring: every open lattice cell next to a visited one is tried at the homography's prediction — all of them at
+            // once, a lane per cell (the first walk's step vectors are dead: their arrays hold the cell list and the claims).
+            // A cell takes the free candidate nearest to its prediction if that lies within the tolerance of a step from one of
+            // the cell's visited neighbours (as in the first walk); a candidate wanted by two cells goes to the nearer one,
+            // the other cell tries again in the next ring.  New nodes join the queue in row-major order of their cells.
+            unsigned long long *const claim = reinterpret_cast<unsigned long long *>(e1x);   // [GR_MAXC]
+            int8_t *const fl_u = reinterpret_cast<int8_t *>(e1y), *const fl_v = fl_u + 512;      // [<= 512] open cells of the ring
+            if (lane == 0) {
+                sh_box[0] = sh_box[2] = 127;
+                sh_box[1] = sh_box[3] = -128;
+            }
+            for (uint32_t i = lane; i < n; i += GR_T) claim[i] = ~0ull;
+            __syncthreads();
+            for (uint32_t k = lane; k < qt; k += GR_T) {
+                const uint32_t j = queue[k];
+                atomicMin(&sh_box[0], (int) cu[j]);
+                atomicMax(&sh_box[1], (int) cu[j]);
+                atomicMin(&sh_box[2], (int) cv[j]);
+                atomicMax(&sh_box[3], (int) cv[j]);
+            }
+            __syncthreads();
+            const int vlo = max(sh_box[2] - 1, -GR_L / 2), vhi = min(sh_box[3] + 1, GR_L / 2 - 1);
+            auto visited = [&](int u, int v) -> uint32_t {   // candidate index + 1 of the cell, 0: open or outside
+                return (u < -GR_L / 2 || u >= GR_L / 2 || v < -GR_L / 2 || v >= GR_L / 2) ? 0u : occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)];
+            };
+            uint32_t nf = 0;   // the ring's open cells (two lattice rows of 32 per step)
+            for (int v0 = vlo; v0 <= vhi; v0 += 2) {
+                const int v = v0 + (int) (lane >> 5), u = (int) (lane & 31u) - GR_L / 2;
+                const bool open = v <= vhi && visited(u, v) == 0u &&
+                                  (visited(u + 1, v) | visited(u - 1, v) | visited(u, v + 1) | visited(u, v - 1)) != 0u;
+                const unsigned long long m = __ballot(open);
+                const uint32_t at = nf + (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+                if (open && at < 512u) {
+                    fl_u[at] = (int8_t) u;
+                    fl_v[at] = (int8_t) v;
+                }
+                nf += (uint32_t) __popcll(m);
+            }
+            nf = nf < 512u ? nf : 512u;
+            __syncthreads();
+            for (uint32_t k0 = 0; k0 < nf; k0 += GR_T) {
+                const uint32_t k = k0 + lane;
+                const bool mine = k < nf;
+                const int u = mine ? fl_u[k] : 0, v = mine ? fl_v[k] : 0;
+                const double wq = hh[6] * u + hh[7] * v + 1.0;
+                const double tx = (hh[0] * u + hh[1] * v + hh[2]) / wq, ty = (hh[3] * u + hh[4] * v + hh[5]) / wq;
+                double far2 = 0.0;   // the longest step to the cell from a visited neighbour
+#pragma unroll
                 for (int dir = 0; dir < 4; dir++) {
                     const int du = dir == 0 ? 1 : (dir == 1 ? -1 : 0), dv = dir == 2 ? 1 : (dir == 3 ? -1 : 0);
-                    const int u = u0 + du, v = v0 + dv;
-                    if (u < -GR_L / 2 || u >= GR_L / 2 || v < -GR_L / 2 || v >= GR_L / 2) continue;
-                    if (occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)]) continue;
-                    const double wq = hh[6] * u + hh[7] * v + 1.0;
-                    if (!(wq > 1e-6)) continue;
-                    const double tx = (hh[0] * u + hh[1] * v + hh[2]) / wq, ty = (hh[3] * u + hh[4] * v + hh[5]) / wq;
-                    const unsigned long long r = nearest(tx, ty, true, 0xFFFFFFFFu);
-                    if (r == ~0ull) continue;
-                    const uint32_t j = (uint32_t) (r & 0xFFu);
-                    const double ddx = px[j] - tx, ddy = py[j] - ty;
-                    const double sxp = tx - px[cur], syp = ty - py[cur];
-                    const double lim = fmin(tol_px * tol_px, tol_frac * tol_frac * (sxp * sxp + syp * syp));
-                    if (ddx * ddx + ddy * ddy > lim) continue;
-                    if (lane == 0) {
-                        assigned[j] = 1;
-                        cu[j] = (int8_t) u;
-                        cv[j] = (int8_t) v;
-                        occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] = (uint8_t) (j + 1);
-                        queue[qt] = (uint8_t) j;
+                    const uint32_t nb = mine ? visited(u + du, v + dv) : 0u;
+                    if (nb) {
+                        const double sx_ = tx - px[nb - 1u], sy_ = ty - py[nb - 1u];
+                        far2 = fmax(far2, sx_ * sx_ + sy_ * sy_);
                     }
-                    qt++;
-                    __syncthreads();
                 }
+                double best = INFINITY;
+                uint32_t bj = 0;
+                for (uint32_t i = 0; i < n; i++) {   // (the same i in every lane: broadcast reads)
+                    if (assigned[i]) continue;
+                    const double dx = px[i] - tx, dy = py[i] - ty, d2 = dx * dx + dy * dy;
+                    if (d2 < best) {
+                        best = d2;
+                        bj = i;
+                    }
+                }
+                const bool want = mine && wq > 1e-6 && best <= fmin(tol_px * tol_px, tol_frac * tol_frac * far2);
+                // (distances order like their bit patterns; the low bits carry the cell: ties go to the earlier one)
+                const unsigned long long key = (((unsigned long long) __double_as_longlong(best)) & ~0x3FFull) | (unsigned long long) k;
+                if (want) atomicMin(&claim[bj], key);
+                __syncthreads();
+                const bool won = want && claim[bj] == key;
+                const unsigned long long wm = __ballot(won);
+                if (won) {
+                    const uint32_t at = qt + (uint32_t) __popcll(wm & ((1ull << lane) - 1ull));
+                    assigned[bj] = 1;
+                    cu[bj] = (int8_t) u;
+                    cv[bj] = (int8_t) v;
+                    occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] = (uint8_t) (bj + 1);
+                    queue[at] = (uint8_t) bj;
+                }
+                qt += (uint32_t) __popcll(wm);
+                __syncthreads();
             }
             GR_MARK(5);   // sweeps' searches
             if (qt == qt_before) break;
