@@ -49,37 +49,46 @@ def rodrigues(rv):
 
 def quat_from_matrix(R):
     """[n,3,3] -> [n,4] x y z w (Eigen::Quaterniond(Matrix3d)'s branches)."""
+    R = np.asarray(R, np.float64)
     out = np.zeros((len(R), 4))
-    for n, m in enumerate(R):
-        t = np.trace(m)
-        if t > 0:
-            t = np.sqrt(t + 1.0)
-            out[n, 3] = 0.5 * t
-            t = 0.5 / t
-            out[n, :3] = (m[2, 1] - m[1, 2]) * t, (m[0, 2] - m[2, 0]) * t, (m[1, 0] - m[0, 1]) * t
-        else:
-            i = 0
-            if m[1, 1] > m[0, 0]:
-                i = 1
-            if m[2, 2] > m[i, i]:
-                i = 2
-            j, k = (i + 1) % 3, (i + 2) % 3
-            t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0)
-            out[n, i] = 0.5 * t
-            t = 0.5 / t
-            out[n, 3] = (m[k, j] - m[j, k]) * t
-            out[n, j] = (m[j, i] + m[i, j]) * t
-            out[n, k] = (m[k, i] + m[i, k]) * t
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    pos = tr > 0
+    if pos.any():   # the usual branch, all such matrices at once
+        m = R[pos]
+        t = np.sqrt(tr[pos] + 1.0)
+        w = 0.5 * t
+        t = 0.5 / t
+        out[pos] = np.stack([(m[:, 2, 1] - m[:, 1, 2]) * t, (m[:, 0, 2] - m[:, 2, 0]) * t, (m[:, 1, 0] - m[:, 0, 1]) * t, w], axis=1)
+    for n in np.flatnonzero(~pos):
+        m = R[n]
+        i = 0
+        if m[1, 1] > m[0, 0]:
+            i = 1
+        if m[2, 2] > m[i, i]:
+            i = 2
+        j, k = (i + 1) % 3, (i + 2) % 3
+        t = np.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0)
+        out[n, i] = 0.5 * t
+        t = 0.5 / t
+        out[n, 3] = (m[k, j] - m[j, k]) * t
+        out[n, j] = (m[j, i] + m[i, j]) * t
+        out[n, k] = (m[k, i] + m[i, k]) * t
     return out
 
 
 def check_pose(R_ref, twb_ref, t_ref, R_cur, twb_cur, t_cur, step):
     """EventCalibIni::checkPose (EventCalibIni.cpp:327-347)."""
-    dt = t_cur - t_ref
-    v_t = np.linalg.norm(twb_cur - twb_ref) / dt
-    c = (np.trace(R_cur @ R_ref.T) - 1) * 0.5
-    v_r = abs(np.arccos(min(1.0, max(-1.0, c))) / dt)
-    return v_t < (2.5e-1 / step) * 2 and v_r < (5e-4 * np.pi) * 2 / step
+    import math
+    dt = float(t_cur - t_ref)
+    d = [float(twb_cur[i]) - float(twb_ref[i]) for i in range(3)]
+    v_t = math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) / dt
+    a, b = np.asarray(R_cur, np.float64).ravel().tolist(), np.asarray(R_ref, np.float64).ravel().tolist()
+    tr = 0.0                                     # trace(R_cur R_ref^T) = sum of the elementwise products
+    for i in range(9):
+        tr += a[i] * b[i]
+    c = (tr - 1) * 0.5
+    v_r = abs(math.acos(min(1.0, max(-1.0, c))) / dt)
+    return v_t < (2.5e-1 / step) * 2 and v_r < (5e-4 * math.pi) * 2 / step
 
 
 def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, frame_event_num_threshold=4000, piece_num=30,
@@ -185,17 +194,28 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
         v_r = np.abs(np.arccos(np.minimum(1.0, np.maximum(-1.0, c))) / dt)
         pair_ok[1:] = (v_t < (2.5e-1 / step) * 2) & (v_r < (5e-4 * np.pi) * 2 / step)
     acc, last, n_check, n_rect = [], -1, 0, 0
+    # a keyframe that passes all three precomputed tests right after an accepted one is accepted: such runs are taken in one
+    # piece, the loop below only walks the frames around a rejection
+    regular = ok & pair_ok & rect_ok
+    irregular = np.flatnonzero(~regular)
     ok_l, rect_l, pair_l = ok.tolist(), rect_ok.tolist(), pair_ok.tolist()
-    for f in range(K):
+    f = 0
+    while f < K:
+        if last == f - 1 and last >= 0 and regular[f]:
+            g = int(irregular[np.searchsorted(irregular, f)]) if len(irregular) and irregular[-1] > f else K   # next frame that is not
+            acc.extend(range(f, g))
+            last = g - 1
+            f = g
+            continue
         if not ok_l[f] or (last >= 0 and not (pair_l[f] if last == f - 1 else
                                               check_pose(Rsw[last], twb[last], kt[last], Rsw[f], twb[f], kt[f], step))):
             n_check += 1
-            continue
-        if not rect_l[f]:
+        elif not rect_l[f]:
             n_rect += 1
-            continue
-        acc.append(f)
-        last = f
+        else:
+            acc.append(f)
+            last = f
+        f += 1
     out["init"].update(accepted=len(acc), discarded_by_check_pose=n_check, discarded_by_rectify=n_rect)
     acc = np.array(acc, np.int64)
     mark("check_pose_gates")
@@ -208,7 +228,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     if not segs:
         raise RuntimeError("sampleSets not filtered")
     Qwb = quat_from_matrix(np.transpose(Rsw[acc], (0, 2, 1)))
-    seg_cp_off, knots, cq, ct, ranges = [0], [], [], [], []
+    seg_cp_off, knots, cq, ct, ranges, jobs = [0], [], [], [], [], []
     for s in segs:
         u = times[s].copy()
         u[0] -= 3 * step
@@ -217,16 +237,29 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
         if cp_num > len(u):
             cp_num = len(u) - 1
         cp_num = max(cp_num, 4)
-        kn, c_t = capi.spline_fit(u, twb[acc][s], cp_num)
+        jobs.append((u, s, cp_num))
+        seg_cp_off.append(seg_cp_off[-1] + cp_num)
+        ranges.append((u[0], u[-1]))
+    twb_acc = twb[acc]
+
+    def fit(job):   # (host code of libecal.so: ctypes releases the interpreter lock, the segments' fits run side by side)
+        u, s, cp_num = job
+        kn, c_t = capi.spline_fit(u, twb_acc[s], cp_num)
         _, c_q = capi.spline_fit(u, Qwb[s], cp_num)
         if use_so3:   # BsplineSO3's constructor: unit quaternions, then optimizeCP (BsplineSO3.cpp:55, :285-341)
             c_q /= np.linalg.norm(c_q, axis=1, keepdims=True)
             c_q, _ = capi.spline_so3_refine(kn, c_q, Qwb[s], u)
+        return kn, c_q, c_t
+    if len(jobs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 8)) as pool:
+            fits = list(pool.map(fit, jobs))
+    else:
+        fits = [fit(j) for j in jobs]
+    for kn, c_q, c_t in fits:
         knots.append(kn)
         cq.append(c_q)
         ct.append(c_t)
-        seg_cp_off.append(seg_cp_off[-1] + cp_num)
-        ranges.append((u[0], u[-1]))
     keep = np.concatenate(segs)
     kf_idx = acc[keep]
     mark("spline_fit")
