@@ -764,7 +764,10 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
 // second pass (CAP = PX_CAP2): the workgroups share the list of segments the first pass left over
 // (in_list[0 .. *in_count)); what this pass cannot take either goes to todo / todo_count for the general tiers
 template <int E2I, int CAP>
-__global__ __launch_bounds__(PX_T, 4) void dbscan_pixel_list_kernel(const double *__restrict__ xy,
+#ifndef ECAL_PX2_WG
+#define ECAL_PX2_WG 5
+#endif
+__global__ __launch_bounds__(PX_T, ECAL_PX2_WG) void dbscan_pixel_list_kernel(const double *__restrict__ xy,
                                                                  const uint32_t *__restrict__ seg_off,
                                                                  const uint32_t *__restrict__ seg_cnt, const PxGeom geom,
                                                                  uint32_t minpts, int32_t *__restrict__ labels,

@@ -273,7 +273,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
                 ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
             }
         }
-        const uint32_t grid2 = S < 1024u ? S : 1024u;
+        const uint32_t grid2 = std::min<uint32_t>(S, (uint32_t) ECAL_PX2_WG * ctx->n_cu);
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC")) {
             if (!fused) hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,

@@ -708,7 +708,10 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
 
 // second pass: the workgroups share the list the first pass left (in_list[0 .. *in_count)); windows of up to 4095 events
 template <bool REFORDER>
-__global__ __launch_bounds__(PXH_T) void slice_hash_list_kernel(const uint8_t *__restrict__ rec,
+#ifndef ECAL_SL2_WAVES
+#define ECAL_SL2_WAVES 3
+#endif
+__global__ __launch_bounds__(PXH_T) __attribute__((amdgpu_waves_per_eu(ECAL_SL2_WAVES, ECAL_SL2_WAVES))) void slice_hash_list_kernel(const uint8_t *__restrict__ rec,
                                                                 const uint32_t *__restrict__ win_lo,
                                                                 const uint32_t *__restrict__ win_hi,
                                                                 const uint32_t *__restrict__ win_base, uint32_t cap_points,

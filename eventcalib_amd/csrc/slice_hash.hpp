@@ -74,7 +74,13 @@ struct PixHash {
 #ifndef ECAL_RO_NI
 #define ECAL_RO_NI 9
 #endif
-    static constexpr int NI = LOGC == 11 ? ECAL_RO_NI : 19;           // keys per thread of a pair: 1152 >= 1109 / 2432 >= 2357
+#ifndef ECAL_RO_NI2
+#define ECAL_RO_NI2 16
+#endif
+    // keys per thread of a pair: 1152 >= 1109 in the first pass; the second pass takes sets of up to 2048 keys (19 would hold
+    // the 2357 of its last epoch, but with 16 the layout is 52 KB instead of 60: three windows per CU instead of two — a
+    // window of 4095 events has ~1600 keys per polarity; the rare larger set goes to the general tier)
+    static constexpr int NI = LOGC == 11 ? ECAL_RO_NI : ECAL_RO_NI2;
     static constexpr int MAX_EPOCHS = LOGC == 11 ? 7 : 8;             // bucket counts up to 1109 / 2357
     static constexpr uint32_t NOFF = 128u * NI, PSL = 2u * NOFF;
 #ifndef ECAL_RO_FA
