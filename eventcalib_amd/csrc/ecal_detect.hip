@@ -40,7 +40,10 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
 
 // the first pass over a list: the windows the fused detection pass (ecal_fused.hip) did not carry through to extraction
 template <bool FIT, int MODE = 0>
-__global__ __launch_bounds__(DET_T) void extract_first_list_kernel(
+#ifndef ECAL_EFL_WAVES
+#define ECAL_EFL_WAVES 6
+#endif
+__global__ __launch_bounds__(DET_T) __attribute__((amdgpu_waves_per_eu(ECAL_EFL_WAVES, ECAL_EFL_WAVES))) void extract_first_list_kernel(
     const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
     const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
     uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
