@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_EVENT = 29.0     # 25 B record read once + 4 B int32 label written once
-TRAFFIC_PROFILE = "r03b_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
+TRAFFIC_PROFILE = "r03c_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
