@@ -616,7 +616,7 @@ def cpp_chain(ev, n, rate, t_start, pieces, np):
         return {"process_wall_seconds": round(wall, 3), "stage_seconds": stages, "seconds_after_upload": round(after, 4),
                 "keyframes": int(lines[0].split()[1]), "refined_fx": float(ref[1]), "residuals": int(ref[11]),
                 "lm_iterations": int(ref[13]), "splines": int(ref[15]),
-                "note": "process start to exit incl. HIP runtime initialisation, reading 1.25 GB from a RAM-backed file and the upload"}
+                "note": "process start to exit incl. HIP runtime initialisation and EventContainer::loadFile (ecal_stream_create_from_file: 1.25 GB from a RAM-backed file, chunked reads overlapped with the upload)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
         shutil.rmtree(bin_dir, ignore_errors=True)

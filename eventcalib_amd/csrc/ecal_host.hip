@@ -4,6 +4,11 @@
 #include <chrono>
 #include <algorithm>
 #include <math.h>
+#include <fcntl.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <thread>
 #include "ecal_ctx.hpp"
 
 struct ecal_stream {
@@ -11,6 +16,7 @@ struct ecal_stream {
     uint8_t *d_events;
     uint64_t n_events;
 };
+static int finish_stream(ecal_ctx *ctx, ecal_stream *s);
 
 extern "C" const uint8_t *ecal_stream_data(const ecal_stream *s) { return s ? s->d_events : nullptr; }
 
@@ -31,12 +37,28 @@ extern "C" int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t
     hipError_t e = hipMalloc((void **) &s->d_events, bytes);
     if (e == hipSuccess && n_events)
         e = hipMemcpyAsync(s->d_events, events, (size_t) n_events * 25, hipMemcpyHostToDevice, ctx->stream);
-    int *d_flag = nullptr;
-    int h_flag = 0;
-    if (e == hipSuccess) e = hipMalloc((void **) &d_flag, sizeof(int));
     if (e != hipSuccess) {
         ctx->last_error = std::string("ecal_stream_create: ") + hipGetErrorString(e);
         if (s->d_events) (void) hipFree(s->d_events);
+        delete s;
+        return e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
+    }
+    const int rc = finish_stream(ctx, s);
+    if (rc != ECAL_OK) return rc;
+    *out = s;
+    return ECAL_OK;
+}
+
+// The records are on the device: bring them into the multimap's order if they are not in it (frees the stream on an error)
+static int finish_stream(ecal_ctx *ctx, ecal_stream *s) {
+    const uint64_t n_events = s->n_events;
+    const size_t bytes = (size_t) n_events * 25 + 16;
+    int *d_flag = nullptr;
+    int h_flag = 0;
+    hipError_t e = hipMalloc((void **) &d_flag, sizeof(int));
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("ecal_stream_create: ") + hipGetErrorString(e);
+        (void) hipFree(s->d_events);
         delete s;
         return e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
     }
@@ -71,7 +93,153 @@ extern "C" int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t
         delete s;
         return rc;
     }
+    return ECAL_OK;
+}
+
+// A .bin file of 25-byte records (EventStream's format, Event.hpp:41-47) into a resident stream — the loop of
+// eventCameraCalib.cpp:154-163 (`if (timeStamp >= StartTime) emplace`, stop at the first record with timeStamp >= EndTime when
+// an end is set) without the host container: the file is read in chunks by a few threads into two pinned buffers, the
+// upload of a chunk runs while the next one is read.  has_end == 0: to the end of the file.
+extern "C" int ecal_stream_create_from_file(ecal_ctx *ctx, const char *path, double start_time, int has_end, double end_time,
+                                            ecal_stream **out) {
+    if (!ctx || !path || !out) return ECAL_ERR_INVALID;
+    *out = nullptr;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        ctx->last_error = std::string("ecal_stream_create_from_file: cannot open ") + path;
+        return ECAL_ERR_INVALID;
+    }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        return ECAL_ERR_INVALID;
+    }
+    const uint64_t n_file = (uint64_t) sb.st_size / 25u;
+    if (n_file > 0xFFFFFFFFull) {
+        close(fd);
+        ctx->last_error = "more than 2^32-1 events in one stream";
+        return ECAL_ERR_RANGE;
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        close(fd);
+        return ECAL_ERR_HIP;
+    }
+    ecal_stream *s = new (std::nothrow) ecal_stream;
+    if (!s) {
+        close(fd);
+        return ECAL_ERR_NOMEM;
+    }
+    s->ctx = ctx;
+    s->n_events = 0;
+    s->d_events = nullptr;
+    constexpr uint64_t CH = 1u << 20;                    // records per chunk (25 MiB)
+    constexpr int NT = 4;                                // reader threads
+    uint8_t *pin[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipError_t e = hipMalloc((void **) &s->d_events, (size_t) n_file * 25 + 16);
+    for (int b = 0; b < 2 && e == hipSuccess; b++) {
+        e = hipHostMalloc((void **) &pin[b], (size_t) CH * 25, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+    }
+    auto cleanup = [&]() {
+        for (int b = 0; b < 2; b++) {
+            if (done[b]) (void) hipEventDestroy(done[b]);
+            if (pin[b]) (void) hipHostFree(pin[b]);
+        }
+        close(fd);
+    };
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("ecal_stream_create_from_file: ") + hipGetErrorString(e);
+        cleanup();
+        if (s->d_events) (void) hipFree(s->d_events);
+        delete s;
+        return e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
+    }
+    uint64_t kept = 0;
+    bool stop = false, io_error = false;
+    for (uint64_t r0 = 0, k = 0; r0 < n_file && !stop && !io_error; r0 += CH, k++) {
+        const int b = (int) (k & 1u);
+        const uint64_t nr = std::min<uint64_t>(CH, n_file - r0);
+        if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) io_error = true;   // the buffer's previous upload
+        // read + look at the time stamps, a quarter of the chunk per thread: is every record kept (the usual chunk)?
+        struct Part {
+            bool ok = true, plain = true;
+        } part[NT];
+        std::thread th[NT];
+        for (int t = 0; t < NT; t++)
+            th[t] = std::thread([&, t]() {
+                const uint64_t a = nr * (uint64_t) t / NT, z = nr * (uint64_t) (t + 1) / NT;
+                uint8_t *dst = pin[b] + a * 25;
+                size_t want = (size_t) (z - a) * 25, got = 0;
+                while (got < want) {
+                    const ssize_t rd = pread(fd, dst + got, want - got, (off_t) ((r0 + a) * 25 + got));
+                    if (rd <= 0) {
+                        part[t].ok = false;
+                        return;
+                    }
+                    got += (size_t) rd;
+                }
+                for (uint64_t i = a; i < z; i++) {
+                    double ts;
+                    memcpy(&ts, pin[b] + i * 25, 8);
+                    if (!(ts >= start_time) || (has_end && ts >= end_time)) {
+                        part[t].plain = false;
+                        break;
+                    }
+                }
+            });
+        bool plain = true;
+        for (int t = 0; t < NT; t++) {
+            th[t].join();
+            io_error = io_error || !part[t].ok;
+            plain = plain && part[t].plain;
+        }
+        if (io_error) break;
+        uint64_t n_out = nr;
+        if (!plain) {   // the reference's loop, record by record (kept ones move to the front of the buffer)
+            n_out = 0;
+            for (uint64_t i = 0; i < nr; i++) {
+                double ts;
+                memcpy(&ts, pin[b] + i * 25, 8);
+                if (has_end && ts >= end_time) {
+                    stop = true;
+                    break;
+                }
+                if (ts >= start_time) {
+                    if (n_out != i) memmove(pin[b] + n_out * 25, pin[b] + i * 25, 25);
+                    n_out++;
+                }
+            }
+        }
+        if (n_out && hipMemcpyAsync(s->d_events + kept * 25, pin[b], (size_t) n_out * 25, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            io_error = true;
+        if (hipEventRecord(done[b], ctx->stream) != hipSuccess) io_error = true;
+        kept += n_out;
+    }
+    const bool synced = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    cleanup();
+    if (io_error || !synced) {
+        ctx->last_error = std::string("ecal_stream_create_from_file: read or copy failed for ") + path;
+        (void) hipFree(s->d_events);
+        delete s;
+        return ECAL_ERR_HIP;
+    }
+    s->n_events = kept;
+    const int rc = finish_stream(ctx, s);
+    if (rc != ECAL_OK) return rc;
     *out = s;
+    return ECAL_OK;
+}
+
+// time stamps of the first and the last record of the stream (0 events: both 0)
+extern "C" int ecal_stream_times(const ecal_stream *s, double *first, double *last) {
+    if (!s || !first || !last) return ECAL_ERR_INVALID;
+    *first = *last = 0.0;
+    if (s->n_events == 0) return ECAL_OK;
+    if (hipSetDevice(s->ctx->device) != hipSuccess) return ECAL_ERR_HIP;
+    if (hipMemcpy(first, s->d_events, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(last, s->d_events + (s->n_events - 1) * 25, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return ECAL_ERR_HIP;
     return ECAL_OK;
 }
 

@@ -121,12 +121,30 @@ struct EventContainer {
         std::memcpy(r + 8, &e.location()[0], 8);
         std::memcpy(r + 16, &e.location()[1], 8);
         r[24] = e.polarity() ? 1 : 0;
+        if (fromFile_) throw std::logic_error("EventContainer: emplace after loadFile (the records live in HBM only)");
         records.insert(records.end(), r, r + Event::kRecordBytes);
         if (stream_) release();
     }
-    size_t size() const { return records.size() / Event::kRecordBytes; }
-    double firstTime() const { return Event::unpack(records.data()).timeStamp(); }
-    double lastTime() const { return Event::unpack(records.data() + records.size() - Event::kRecordBytes).timeStamp(); }
+    // The whole reading loop of eventCameraCalib.cpp:154-163 in one call (ecal_stream_create_from_file): the records with
+    // timeStamp >= startTime — up to the first one with timeStamp >= endTime when customEnd — go from the file straight
+    // to HBM (chunked reads overlapped with the upload); `records` stays empty.
+    void loadFile(const std::string &binFilePath, double startTime, bool customEnd = false, double endTime = 0.0) {
+        release();
+        records.clear();
+        const int rc = ecal_stream_create_from_file(ecal_host::thread_ctx(), binFilePath.c_str(), startTime, customEnd ? 1 : 0, endTime,
+                                                    &stream_);
+        if (rc == ECAL_ERR_INVALID) throw std::invalid_argument("No such file: " + binFilePath);
+        if (rc != ECAL_OK)
+            throw std::runtime_error(std::string("ecal_stream_create_from_file: ") + ecal_strerror(rc) + " — " +
+                                     ecal_last_error(ecal_host::thread_ctx()));
+        if (ecal_stream_times(stream_, &devFirst_, &devLast_) != ECAL_OK) throw std::runtime_error("ecal_stream_times");
+        fromFile_ = true;
+    }
+    size_t size() const { return fromFile_ ? (size_t) ecal_stream_size(stream_) : records.size() / Event::kRecordBytes; }
+    double firstTime() const { return fromFile_ ? devFirst_ : Event::unpack(records.data()).timeStamp(); }
+    double lastTime() const {
+        return fromFile_ ? devLast_ : Event::unpack(records.data() + records.size() - Event::kRecordBytes).timeStamp();
+    }
 
     // device image, uploaded lazily; throws if the records are not in time order
     const ecal_stream *device() {
@@ -141,6 +159,7 @@ struct EventContainer {
     void release() {
         if (stream_) ecal_stream_destroy(stream_);
         stream_ = nullptr;
+        fromFile_ = false;
     }
     ~EventContainer() { release(); }
 
@@ -149,6 +168,8 @@ struct EventContainer {
 
 private:
     ecal_stream *stream_ = nullptr;
+    bool fromFile_ = false;
+    double devFirst_ = 0, devLast_ = 0;
 };
 
 // Result of the GPU pass over one window (shared by EventFrame and CirclesEventFrame)

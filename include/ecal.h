@@ -312,6 +312,12 @@ typedef struct ecal_detect_result {
     uint32_t *grid_found;      /* [S] */
 } ecal_detect_result;
 int ecal_stream_create(ecal_ctx *ctx, const uint8_t *events, uint64_t n_events, ecal_stream **out);
+/* The same from a .bin file of 25-byte records (EventStream's format): the loop of eventCameraCalib.cpp:154-163 — records with
+ * timeStamp >= start_time are kept, and with has_end != 0 the first record with timeStamp >= end_time ends the reading —
+ * without a host copy of the file: chunks are read by a few threads into pinned buffers while the previous chunk uploads. */
+int ecal_stream_create_from_file(ecal_ctx *ctx, const char *path, double start_time, int has_end, double end_time, ecal_stream **out);
+/* time stamps of the first and the last record (both 0 for an empty stream) */
+int ecal_stream_times(const ecal_stream *s, double *first, double *last);
 void ecal_stream_destroy(ecal_stream *s);
 uint64_t ecal_stream_size(const ecal_stream *s);
 /* DEVICE pointer of the packed records (what the _dev entry points take as d_events) */

@@ -39,21 +39,9 @@ int main(int argc, char **argv) {
     int width = fsSettings["Camera.width"], height = fsSettings["Camera.height"];   // :141-142
     container->cameraSize[0] = width;
     container->cameraSize[1] = height;
-    if (batch) {   // the same records, read in one piece (the loop below costs ~20 ns per event)
+    if (batch) {   // the same loop as one call: file -> HBM, reads and upload overlapped (EventContainer::loadFile)
         es.close();
-        std::ifstream is(argv[2], std::ios::binary | std::ios::ate);
-        const size_t bytes = (size_t) is.tellg() / 25 * 25;
-        is.seekg(0);
-        container->records.resize(bytes);
-        is.read((char *) container->records.data(), (std::streamsize) bytes);
-        size_t lo = 0, hi = bytes / 25;
-        auto tt = [&](size_t i) { double t; std::memcpy(&t, &container->records[25 * i], 8); return t; };
-        while (lo < hi && tt(lo) < startTime) lo++;
-        if (customEnd) while (hi > lo && tt(hi - 1) >= endTimeSetting) hi--;
-        if (lo || hi != bytes / 25) {
-            container->records.erase(container->records.begin() + 25 * hi, container->records.end());
-            container->records.erase(container->records.begin(), container->records.begin() + 25 * lo);
-        }
+        container->loadFile(argv[2], startTime, customEnd, endTimeSetting);
     }
     while (!es.isEnd()) {                                    // :154-163
         if (customEnd && es.current().timeStamp() >= endTimeSetting) break;
