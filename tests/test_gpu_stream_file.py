@@ -90,5 +90,10 @@ def test_stream_from_file():
                 assert rc == 0 and at_least < len(want) < 200_000 and np.array_equal(got, want), (has_end, len(want))
             rc, _, _ = _from_file(ctx, torch, os.path.join(tmp, "missing.bin"), 0.0, 0, 0.0)
             assert rc == -1
+            p3 = os.path.join(tmp, "short.bin")               # no whole record: an empty stream, as an EventStream at its end
+            with open(p3, "wb") as f:
+                f.write(b"\x00" * 24)
+            rc, got, times = _from_file(ctx, torch, p3, 0.0, 0, 0.0)
+            assert rc == 0 and got.shape == (0, 25) and times == (0.0, 0.0)
     finally:
         ctx.close()
