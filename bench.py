@@ -25,6 +25,25 @@ TRAFFIC_PROFILE = "r03c_traffic.json"   # tools/profile_round.sh: PMC passes of 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
+class leg:
+    """`with leg(out, key):` around a leg beside the headline that only rank 0 of a one-rank run executes: an exception there is
+    printed, recorded under `key` (unless the leg had already put its result there) and the JSON line still comes out."""
+
+    def __init__(self, out, key):
+        self.out, self.key = out, key
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None or not issubclass(et, Exception):
+            return False
+        import traceback
+        traceback.print_exception(et, ev, tb, file=sys.stderr)
+        self.out.setdefault(self.key, {"error": "%s: %s" % (et.__name__, str(ev)[:300])})
+        return True
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,119 +385,134 @@ def main():
                                  "note": "ecal_detect_fused_dev: one kernel carries a window through slicing, both DBSCAN runs and "
                                          "extraction (plain tie rule); same results as the three plain stage calls; not the timed path (the stage-by-stage form is faster, profiles/r02_notes.md)"}
         if args.cpu_sample > 0 and world == 1:
-            import oracle_lib as O
-            m = min(args.cpu_sample, n_events)
-            rec = events[: m * 25].cpu().numpy()
-            nw = int(np.searchsorted(t1, t_start + (m - 1) / rate))
-            tc = time.perf_counter()
-            cev, ccl = O.detect_windows(rec, t0[:nw], t1[:nw], eps, minpts)
-            cel = time.perf_counter() - tc
-            # the reference's own threading: T = hardware threads - 2 workers over 5 T pieces (eventCameraCalib.cpp:172-190);
-            # bounded sample: as many windows as T threads finish in about the single-thread sample's time
-            T = max(1, (os.cpu_count() or 3) - 2)
-            nw_mt = int(min(len(t0), nw * min(T, 16)))
-            rec_mt = events[: min(n_events, int((t1[nw_mt - 1] - t_start) * rate) + 2) * 25].cpu().numpy()
-            tc = time.perf_counter()
-            mev, _ = O.detect_windows_mt(rec_mt, t0[:nw_mt], t1[:nw_mt], eps, minpts, T)
-            mel = time.perf_counter() - tc
-            out["cpu_baseline"] = {
-                "value": round(mev / mel / 1e6, 4), "unit": "Mevents/s", "cores": T, "kind": "port",
-                "sample": "first %d windows (%d events) of the same stream, oracle EventFrame + extractFeatures (DBSCAN +/-, "
-                          "filter, medians, pairing) per window on %d threads over %d pieces (the reference driver's "
-                          "threading), %.2f s" % (nw_mt, mev, T, 5 * T, mel),
-                "single_thread": {"value": round(cev / cel / 1e6, 4), "unit": "Mevents/s", "cores": 1,
-                                  "sample": "first %d windows (%d events), %.1f s" % (nw, cev, cel)},
-                "host_cpus": os.cpu_count(),
-            }
+            with leg(out, "cpu_baseline"):
+                import oracle_lib as O
+                m = min(args.cpu_sample, n_events)
+                rec = events[: m * 25].cpu().numpy()
+                nw = int(np.searchsorted(t1, t_start + (m - 1) / rate))
+                tc = time.perf_counter()
+                cev, ccl = O.detect_windows(rec, t0[:nw], t1[:nw], eps, minpts)
+                cel = time.perf_counter() - tc
+                # the reference's own threading: T = hardware threads - 2 workers over 5 T pieces (eventCameraCalib.cpp:172-190);
+                # bounded sample: as many windows as T threads finish in about the single-thread sample's time
+                T = max(1, (os.cpu_count() or 3) - 2)
+                nw_mt = int(min(len(t0), nw * min(T, 16)))
+                rec_mt = events[: min(n_events, int((t1[nw_mt - 1] - t_start) * rate) + 2) * 25].cpu().numpy()
+                tc = time.perf_counter()
+                mev, _ = O.detect_windows_mt(rec_mt, t0[:nw_mt], t1[:nw_mt], eps, minpts, T)
+                mel = time.perf_counter() - tc
+                out["cpu_baseline"] = {
+                    "value": round(mev / mel / 1e6, 4), "unit": "Mevents/s", "cores": T, "kind": "port",
+                    "sample": "first %d windows (%d events) of the same stream, oracle EventFrame + extractFeatures (DBSCAN +/-, "
+                              "filter, medians, pairing) per window on %d threads over %d pieces (the reference driver's "
+                              "threading), %.2f s" % (nw_mt, mev, T, 5 * T, mel),
+                    "single_thread": {"value": round(cev / cel / 1e6, 4), "unit": "Mevents/s", "cores": 1,
+                                      "sample": "first %d windows (%d events), %.1f s" % (nw, cev, cel)},
+                    "host_cpus": os.cpu_count(),
+                }
     # ---- reported beside the contract number (rank 0, one GPU): PCIe upload and the reference's window policy ----
     if rank == 0 and world == 1 and not args.no_h2d:
-        host = torch.empty(events.numel(), dtype=torch.uint8, pin_memory=True)
-        host.copy_(events)
-        dst = torch.empty_like(events)
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        dst.copy_(host, non_blocking=True)
-        e1.record(st)
-        torch.cuda.synchronize(dev)
-        h2d_ms = e0.elapsed_time(e1)
-        del host, dst
-        out["h2d"] = {"bytes": int(events.numel()), "ms": round(h2d_ms, 3),
-                      "GBs": round(events.numel() / h2d_ms / 1e6, 2),
-                      "Mevents_per_s_including_upload": round(n_events / ((h2d_ms + ms_per_step) * 1e-3) / 1e6, 1),
-                      "note": "pinned host -> HBM copy of the packed stream, once per stream; never part of `value`"}
+        with leg(out, "h2d"):
+            host = torch.empty(events.numel(), dtype=torch.uint8, pin_memory=True)
+            host.copy_(events)
+            dst = torch.empty_like(events)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            dst.copy_(host, non_blocking=True)
+            e1.record(st)
+            torch.cuda.synchronize(dev)
+            h2d_ms = e0.elapsed_time(e1)
+            del host, dst
+            out["h2d"] = {"bytes": int(events.numel()), "ms": round(h2d_ms, 3),
+                          "GBs": round(events.numel() / h2d_ms / 1e6, 2),
+                          "Mevents_per_s_including_upload": round(n_events / ((h2d_ms + ms_per_step) * 1e-3) / 1e6, 1),
+                          "note": "pinned host -> HBM copy of the packed stream, once per stream; never part of `value`"}
     if rank == 0 and world == 1 and args.p2_pieces != 0:
-        # policy P2 of SURVEY 8d: the reference driver's adaptive success / slide / grow windows per piece
-        # (eventCameraCalib.cpp:49-95) + keyframe gate, lock-step over all pieces; counted as the reference
-        # would: all events of the stream / wall time, although the policy skips frameGap after every keyframe.
-        # The number of pieces is a property of the HOST in the reference (5 * (hardware threads - 2)); the chain of
-        # dependent windows inside a piece is what serialises, so the GPU wants many short pieces.
-        from eventcalib_amd.adaptive import detect_keyframes, detect_keyframes_device
-        ref_pieces = 5 * max(1, (os.cpu_count() or 3) - 2)
-        runs = [ref_pieces, 4096] if args.p2_pieces < 0 else [args.p2_pieces]
-        out["policy_p2"] = []
-        for pieces in runs:
-            nth = 2   # more host threads do not help: a pass is bound by the GPU-side chain of its largest window
-            detect_keyframes(pipe, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts, n_threads=nth)   # warm-up
-            torch.cuda.synchronize(dev)
-            tp = time.perf_counter()
-            kf = detect_keyframes(pipe, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, n_threads=nth)
-            torch.cuda.synchronize(dev)
-            p2_s = time.perf_counter() - tp
-            out["policy_p2"].append({"value": round(n_events / p2_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2_s, 4),
-                                     "pieces": pieces, "host_threads": nth, "lockstep_passes": kf["steps"], "windows_evaluated": kf["windows"],
-                                     "keyframes": int(len(kf["time"])),
-                                     "driver": "host",
-                                     "note": "adaptive windows + grid ordering + keyframe gate, host-driven (one H2D of the window "
-                                             "bounds and one D2H of verdicts + ordered circles per pass)"})
-            # the same policy with the rule on the device (ecal_detect_keyframes): no per-pass host round trip
-            detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts)   # warm-up
-            torch.cuda.synchronize(dev)
-            tp = time.perf_counter()
-            kd = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts)
-            p2d_s = time.perf_counter() - tp
-            out["policy_p2"].append({"value": round(n_events / p2d_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2d_s, 4),
-                                     "pieces": pieces, "host_threads": 1, "longest_window_chain": kd["steps"],
-                                     "windows_evaluated": kd["windows"],
-                                     "keyframes": int(len(kd["time"])), "driver": "device",
-                                     "same_keyframes_as_host_driver": bool(np.array_equal(kd["time"], kf["time"])),
-                                     "note": "the same policy in one call: five stages + grid ordering over every piece's current window and "
-                                             "the windows that follow it if every verdict is the likely one (the slots of a pass go to the pieces "
-                                             "still at work) + one policy kernel that applies the rule along that chain while the verdicts agree, "
-                                             "enqueued back to back; the host follows a 4-byte counter two passes behind",
-                                     "gate": "own piece"})
-            # ... and with the reference's own gate semantics: ONE keyframe map, single-worker order (ECAL_GATE_SHARED_MAP ==
-            # oracle/policy_oracle.cpp mode 1): speculation as above + verification rounds across the piece boundaries
-            from eventcalib_amd import capi as _capi
-            tp = time.perf_counter()
-            ks = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, gate_mode=_capi.GATE_SHARED_MAP)
-            p2s_s = time.perf_counter() - tp
-            out["policy_p2"].append({"value": round(n_events / p2s_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2s_s, 4),
-                                     "pieces": pieces, "host_threads": 1, "longest_window_chain": ks["steps"],
-                                     "windows_evaluated": ks["windows"], "keyframes": int(len(ks["time"])), "driver": "device",
-                                     "gate": "shared map, single worker (the reference's TrackingBase / EventCalibIni::track semantics)"})
-        pipe.set_windows(t0, t1)
+        with leg(out, "policy_p2_error"):
+            # policy P2 of SURVEY 8d: the reference driver's adaptive success / slide / grow windows per piece
+            # (eventCameraCalib.cpp:49-95) + keyframe gate, lock-step over all pieces; counted as the reference
+            # would: all events of the stream / wall time, although the policy skips frameGap after every keyframe.
+            # The number of pieces is a property of the HOST in the reference (5 * (hardware threads - 2)); the chain of
+            # dependent windows inside a piece is what serialises, so the GPU wants many short pieces.
+            from eventcalib_amd.adaptive import detect_keyframes, detect_keyframes_device
+            ref_pieces = 5 * max(1, (os.cpu_count() or 3) - 2)
+            runs = [ref_pieces, 4096] if args.p2_pieces < 0 else [args.p2_pieces]
+            out["policy_p2"] = []
+            for pieces in runs:
+                nth = 2   # more host threads do not help: a pass is bound by the GPU-side chain of its largest window
+                detect_keyframes(pipe, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts, n_threads=nth)   # warm-up
+                torch.cuda.synchronize(dev)
+                tp = time.perf_counter()
+                kf = detect_keyframes(pipe, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, n_threads=nth)
+                torch.cuda.synchronize(dev)
+                p2_s = time.perf_counter() - tp
+                out["policy_p2"].append({"value": round(n_events / p2_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2_s, 4),
+                                         "pieces": pieces, "host_threads": nth, "lockstep_passes": kf["steps"], "windows_evaluated": kf["windows"],
+                                         "keyframes": int(len(kf["time"])),
+                                         "driver": "host",
+                                         "note": "adaptive windows + grid ordering + keyframe gate, host-driven (one H2D of the window "
+                                                 "bounds and one D2H of verdicts + ordered circles per pass)"})
+                # the same policy with the rule on the device (ecal_detect_keyframes): no per-pass host round trip
+                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts)   # warm-up
+                torch.cuda.synchronize(dev)
+                tp = time.perf_counter()
+                kd = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts)
+                p2d_s = time.perf_counter() - tp
+                out["policy_p2"].append({"value": round(n_events / p2d_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2d_s, 4),
+                                         "pieces": pieces, "host_threads": 1, "longest_window_chain": kd["steps"],
+                                         "windows_evaluated": kd["windows"],
+                                         "keyframes": int(len(kd["time"])), "driver": "device",
+                                         "same_keyframes_as_host_driver": bool(np.array_equal(kd["time"], kf["time"])),
+                                         "note": "the same policy in one call: five stages + grid ordering over every piece's current window and "
+                                                 "the windows that follow it if every verdict is the likely one (the slots of a pass go to the pieces "
+                                                 "still at work) + one policy kernel that applies the rule along that chain while the verdicts agree, "
+                                                 "enqueued back to back; the host follows a 4-byte counter two passes behind",
+                                         "gate": "own piece"})
+                # ... and with the reference's own gate semantics: ONE keyframe map, single-worker order (ECAL_GATE_SHARED_MAP ==
+                # oracle/policy_oracle.cpp mode 1): speculation as above + verification rounds across the piece boundaries
+                from eventcalib_amd import capi as _capi
+                tp = time.perf_counter()
+                ks = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, gate_mode=_capi.GATE_SHARED_MAP)
+                p2s_s = time.perf_counter() - tp
+                out["policy_p2"].append({"value": round(n_events / p2s_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2s_s, 4),
+                                         "pieces": pieces, "host_threads": 1, "longest_window_chain": ks["steps"],
+                                         "windows_evaluated": ks["windows"], "keyframes": int(len(ks["time"])), "driver": "device",
+                                         "gate": "shared map, single worker (the reference's TrackingBase / EventCalibIni::track semantics)"})
+            pipe.set_windows(t0, t1)
     # ------------------------------------------------------------------------------------------
     # M2: Levenberg-Marquardt iterations/s of the continuous-time solve on the same stream
     # (configs[2]: 50 M events -> ~45 M associated residuals, control point every 50 steps = 25 ms)
     # ------------------------------------------------------------------------------------------
+    def guarded(fn, *a):
+        """The legs beside the headline: with one rank a failure there is reported in its place and the line still comes out
+        (with several ranks a leg's collectives have to be entered by all of them: an error stays an error)."""
+        if world > 1:
+            return fn(*a)
+        try:
+            return fn(*a)
+        except Exception as exc:   # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+
     if args.solver_iters > 0:
         del events
         pipe = None
         torch.cuda.empty_cache()
-        out_solver = solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np)
+        out_solver = guarded(solver_leg, args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np)
         if rank == 0:
             out["solver"] = out_solver
     if args.ingest_events > 0:
-        out_ingest = ingest_leg(args, ctx, dev, world, rank, dist, torch, np, rate)
+        out_ingest = guarded(ingest_leg, args, ctx, dev, world, rank, dist, torch, np, rate)
         if rank == 0:
             out["ingest"] = out_ingest
     if args.calib_views > 0:
-        out_calib = calib_leg(args, ctx, dev, world, rank, dist, torch, np)
+        out_calib = guarded(calib_leg, args, ctx, dev, world, rank, dist, torch, np)
         if rank == 0:
             out["init_calibration"] = out_calib
     if args.e2e_events > 0 and rank == 0 and world == 1:
-        out["end_to_end"] = e2e_leg(args, ctx, dev, torch, np)
+        out["end_to_end"] = guarded(e2e_leg, args, ctx, dev, torch, np)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -599,8 +633,10 @@ def cpp_chain(ev, n, rate, t_start, pieces, np):
     bin_dir = tempfile.mkdtemp(prefix="ecal_chain_exe_")                                                   # (/dev/shm is mounted noexec)
     try:
         exe, lib_dir = os.path.join(bin_dir, "test_calib_chain"), os.path.join(root, "eventcalib_amd")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "test_calib_chain.cpp"),
-                               "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"])
+        cc = subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "test_calib_chain.cpp"),
+                             "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"], capture_output=True, text=True)
+        if cc.returncode != 0:
+            return {"error": "g++: " + cc.stderr[-300:]}
         ev.cpu().numpy().tofile(os.path.join(tmp, "events.bin"))
         open(os.path.join(tmp, "settings.yaml"), "w").write(CHAIN_YAML % dict(start=t_start, pieces=pieces))
         t0 = time.perf_counter()
