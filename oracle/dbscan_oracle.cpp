@@ -34,6 +34,7 @@
 #include <queue>
 #include <set>
 #include <dlfcn.h>
+#include <string>
 
 namespace {
 
@@ -252,6 +253,11 @@ int run_driver(NeighbourSource &src, uint32_t n, uint32_t minpts, int32_t *label
     return 0;
 }
 
+KdApi g_backend_api;
+void *g_backend_handle = nullptr;
+bool g_backend_ref = false;
+std::string g_backend_path;
+
 }  // namespace
 
 extern "C" {
@@ -266,9 +272,38 @@ int oracle_dbscan(const double *xy, uint32_t n, double eps, uint32_t minpts, int
         if (n_clusters) *n_clusters = 0;
         return 1;
     }
+    if (g_backend_ref) {   // oracle_set_kd_backend: tree + range query are the reference's compiled kd_* functions
+        KdApiSource src(g_backend_api, xy, n, eps);
+        return run_driver(src, n, minpts, labels, n_clusters, members, member_off);
+    }
     OwnTreeSource src(xy, n, eps);
     return run_driver(src, n, minpts, labels, n_clusters, members, member_off);
 }
+
+// Process-wide choice of the k-d tree under oracle_dbscan() and everything built on it (extraction, the window loops):
+// so_path = oracle/_ref/libkdtree_ref.so -> the reference's own kdtree.cpp as compiled by oracle/Makefile (the library
+// stays mapped until the backend is changed, so a loaded-library listing shows it); NULL or "" -> this file's restated
+// tree.  Call it before any worker thread runs (kd_* on separate trees is thread-safe: plain malloc, no shared state).
+// Returns 0, or -1 when the library cannot be loaded (the backend is then the restated tree).
+int oracle_set_kd_backend(const char *so_path) {
+    if (so_path && *so_path && g_backend_ref && g_backend_path == so_path) return 0;   // already on it: keep it mapped
+    if (g_backend_handle) {
+        dlclose(g_backend_handle);
+        g_backend_handle = nullptr;
+    }
+    g_backend_ref = false;
+    if (!so_path || !*so_path) return 0;
+    if (!load_kdapi(so_path, g_backend_api, &g_backend_handle)) {
+        g_backend_handle = nullptr;
+        return -1;
+    }
+    g_backend_ref = true;
+    g_backend_path = so_path;
+    return 0;
+}
+
+// 1: oracle_dbscan runs on the reference's compiled kd-tree, 0: on the restated one
+int oracle_kd_backend(void) { return g_backend_ref ? 1 : 0; }
 
 // Same driver, but the tree and the range query are the reference's own kd_* functions taken
 // from `so_path` (oracle/_ref/libkdtree_ref.so).  Returns -1 if the library cannot be loaded.

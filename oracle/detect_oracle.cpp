@@ -43,6 +43,8 @@ struct Side {
     std::vector<std::vector<uint32_t>> clusters;  // kept clusters, reference element order
     std::vector<uint32_t> centres;                // representative pid per kept cluster
     std::vector<int32_t> kept_label;              // per point: renumbered cluster or -1
+    std::vector<int32_t> raw_label;               // per point: index into Run()'s Clusters or -1 (Noise)
+    uint32_t n_raw = 0;                           // Clusters.size() before the filter
 };
 
 void run_side(Side &s, const double *xy, uint32_t n, double eps, uint32_t minpts, uint32_t cluster_min) {
@@ -54,6 +56,8 @@ void run_side(Side &s, const double *xy, uint32_t n, double eps, uint32_t minpts
     std::vector<uint32_t> members(n), off(n + 2);
     uint32_t nc = 0;
     oracle_dbscan(xy, n, eps, minpts, labels.data(), &nc, members.data(), off.data());
+    s.raw_label = labels;
+    s.n_raw = nc;
     for (uint32_t c = 0; c < nc; c++) {
         if (off[c + 1] - off[c] < cluster_min) continue;  // :91, :106
         s.clusters.emplace_back(members.begin() + off[c], members.begin() + off[c + 1]);
@@ -199,6 +203,14 @@ int oracle_extract_candidates_override(const double *pos_xy, uint32_t n_pos, con
                                        uint32_t *rep_pos, uint32_t *rep_neg, uint32_t *tie_pos, uint32_t *tie_neg,
                                        const uint32_t *override_pos, const uint32_t *override_neg);
 
+int oracle_extract_candidates_full(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
+                                   double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
+                                   double radius_thr, int fit_circle, uint32_t knn_num, uint32_t *info,
+                                   uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
+                                   uint32_t *rep_pos, uint32_t *rep_neg, uint32_t *tie_pos, uint32_t *tie_neg,
+                                   const uint32_t *override_pos, const uint32_t *override_neg, int32_t *raw_pos,
+                                   int32_t *raw_neg, uint32_t *n_raw);
+
 // fit_circle == 0: the :283-311 path; fit_circle != 0: the :180-281 path with knn_num neighbours.
 int oracle_extract_candidates_mode(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
                                    double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
@@ -218,14 +230,51 @@ int oracle_extract_candidates_override(const double *pos_xy, uint32_t n_pos, con
                                        uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
                                        uint32_t *rep_pos, uint32_t *rep_neg, uint32_t *tie_pos, uint32_t *tie_neg,
                                        const uint32_t *override_pos, const uint32_t *override_neg) {
+    return oracle_extract_candidates_full(pos_xy, n_pos, neg_xy, n_neg, eps, minpts, cluster_min, need_clusters, radius_thr,
+                                          fit_circle, knn_num, info, cand_pair, cand_xyr, kept_pos, kept_neg, rep_pos, rep_neg,
+                                          tie_pos, tie_neg, override_pos, override_neg, nullptr, nullptr, nullptr);
+}
+
+// The same, and Run()'s own output per polarity as well (raw_pos / raw_neg: index into Clusters or -1 per point;
+// n_raw[2]: Clusters.size() of + and -), so that one pass over a window gives the labels AND the candidates.  With the raw
+// outputs asked for, a polarity is clustered even when the other one is empty (the reference returns before any
+// clustering then, :62-64: info says so as before; the labels are what Run() gives on that set alone).
+int oracle_extract_candidates_full(const double *pos_xy, uint32_t n_pos, const double *neg_xy, uint32_t n_neg,
+                                   double eps, uint32_t minpts, uint32_t cluster_min, uint32_t need_clusters,
+                                   double radius_thr, int fit_circle, uint32_t knn_num, uint32_t *info,
+                                   uint32_t *cand_pair, double *cand_xyr, int32_t *kept_pos, int32_t *kept_neg,
+                                   uint32_t *rep_pos, uint32_t *rep_neg, uint32_t *tie_pos, uint32_t *tie_neg,
+                                   const uint32_t *override_pos, const uint32_t *override_neg, int32_t *raw_pos,
+                                   int32_t *raw_neg, uint32_t *n_raw) {
     info[0] = info[1] = info[2] = 0;
     info[3] = 1;
     for (uint32_t i = 0; i < n_pos; i++) kept_pos[i] = -1;
     for (uint32_t i = 0; i < n_neg; i++) kept_neg[i] = -1;
-    if (n_pos == 0 || n_neg == 0) return 0;  // :62-64
+    if (n_raw) n_raw[0] = n_raw[1] = 0;
     Side P, N;
+    if (n_pos == 0 || n_neg == 0) {  // :62-64
+        if (raw_pos && n_pos) {
+            run_side(P, pos_xy, n_pos, eps, minpts, cluster_min);
+            for (uint32_t i = 0; i < n_pos; i++) raw_pos[i] = P.raw_label[i];
+            if (n_raw) n_raw[0] = P.n_raw;
+        }
+        if (raw_neg && n_neg) {
+            run_side(N, neg_xy, n_neg, eps, minpts, cluster_min);
+            for (uint32_t i = 0; i < n_neg; i++) raw_neg[i] = N.raw_label[i];
+            if (n_raw) n_raw[1] = N.n_raw;
+        }
+        return 0;
+    }
     run_side(P, pos_xy, n_pos, eps, minpts, cluster_min);
     run_side(N, neg_xy, n_neg, eps, minpts, cluster_min);
+    if (raw_pos)
+        for (uint32_t i = 0; i < n_pos; i++) raw_pos[i] = P.raw_label[i];
+    if (raw_neg)
+        for (uint32_t i = 0; i < n_neg; i++) raw_neg[i] = N.raw_label[i];
+    if (n_raw) {
+        n_raw[0] = P.n_raw;
+        n_raw[1] = N.n_raw;
+    }
     for (uint32_t i = 0; i < n_pos; i++) kept_pos[i] = P.kept_label[i];
     for (uint32_t i = 0; i < n_neg; i++) kept_neg[i] = N.kept_label[i];
     info[1] = (uint32_t) P.clusters.size();

@@ -228,6 +228,71 @@ def detect_windows_mt(rec, t0, t1, eps, minpts, n_threads, cluster_min=5, need_c
     return int(ev), int(ncl.value)
 
 
+def set_kd_backend(reference):
+    """Which k-d tree runs under oracle_dbscan and everything built on it (extract_candidates, the window loops):
+    True -> the reference's own kdtree.cpp as compiled into oracle/_ref/libkdtree_ref.so (kept mapped), False -> the
+    restated tree of oracle/dbscan_oracle.cpp.  Raises when the reference build is asked for and absent."""
+    L = lib()
+    L.oracle_set_kd_backend.argtypes = [ctypes.c_char_p]
+    L.oracle_set_kd_backend.restype = ctypes.c_int
+    if reference:
+        if not have_ref_kdtree() or L.oracle_set_kd_backend(REF_KDTREE_SO.encode()) != 0:
+            raise RuntimeError("oracle/_ref/libkdtree_ref.so (the reference's kdtree.cpp, built by `make -C oracle`) is not available")
+    else:
+        L.oracle_set_kd_backend(None)
+
+
+def kd_backend():
+    """'reference kdtree.cpp (oracle/_ref)' or 'restated kd-tree (oracle/dbscan_oracle.cpp)': what oracle_dbscan runs on."""
+    L = lib()
+    L.oracle_kd_backend.restype = ctypes.c_int
+    return "reference kdtree.cpp (oracle/_ref)" if L.oracle_kd_backend() else "restated kd-tree (oracle/dbscan_oracle.cpp)"
+
+
+def detect_windows_full(rec, t0, t1, win_base, slots, eps=4.0, minpts=2, cluster_min=5, need_clusters=36,
+                        radius_thr=15.511363636363637, fit_circle=False, knn_num=3, n_threads=None):
+    """Every result of every window in the device pipeline's slot layout (oracle_detect_windows_full_mt): a dict of numpy
+    arrays win_lo, win_hi, seg_cnt [2S], n_clusters [2S], win_info [S,4], tie [S], xy [slots,2], event_point, labels,
+    kept_labels, rep [slots], cand_pair [slots,2], cand_xyr [slots,3] and the byte masks def_pts / def_kept / def_rep /
+    def_cand [slots] of the slots the reference defines.  win_base: S + 1 slot offsets (exclusive scan of window sizes)."""
+    L = lib()
+    _u8 = _u8p
+    L.oracle_detect_windows_full_mt.argtypes = [_u8, ctypes.c_uint64, _dp, _dp, ctypes.c_uint32, ctypes.c_double, ctypes.c_uint32,
+                                                ctypes.c_uint32, ctypes.c_uint32, ctypes.c_double, ctypes.c_int, ctypes.c_uint32,
+                                                ctypes.c_uint32, _u64p, _u64p, _u64p, _u32p, _u32p, _u32p, _u8, _dp, _i32p, _i32p,
+                                                _i32p, _u32p, _u32p, _dp, _u8, _u8, _u8, _u8]
+    L.oracle_detect_windows_full_mt.restype = ctypes.c_uint64
+    rec = np.ascontiguousarray(rec, dtype=np.uint8)
+    t0 = np.ascontiguousarray(t0, dtype=np.float64)
+    t1 = np.ascontiguousarray(t1, dtype=np.float64)
+    S = t0.shape[0]
+    wb = np.ascontiguousarray(win_base, dtype=np.uint64)
+    assert wb.shape[0] == S + 1 and int(wb[-1]) <= slots
+    if n_threads is None:
+        n_threads = max(1, (os.cpu_count() or 1) - 2)
+    sl = max(int(slots), 1)
+    out = dict(win_lo=np.zeros(S, np.uint64), win_hi=np.zeros(S, np.uint64), seg_cnt=np.zeros(2 * S, np.uint32),
+               n_clusters=np.zeros(2 * S, np.uint32), win_info=np.zeros((S, 4), np.uint32), tie=np.zeros(S, np.uint8),
+               xy=np.zeros((sl, 2)), event_point=np.zeros(sl, np.int32), labels=np.zeros(sl, np.int32),
+               kept_labels=np.zeros(sl, np.int32), rep=np.zeros(sl, np.uint32), cand_pair=np.zeros((sl, 2), np.uint32),
+               cand_xyr=np.zeros((sl, 3)), def_pts=np.zeros(sl, np.uint8), def_kept=np.zeros(sl, np.uint8),
+               def_rep=np.zeros(sl, np.uint8), def_cand=np.zeros(sl, np.uint8))
+    o = out
+    ev = L.oracle_detect_windows_full_mt(_p(rec, _u8), rec.size // 25, _p(t0, _dp), _p(t1, _dp), S, float(eps), int(minpts),
+                                         int(cluster_min), int(need_clusters), float(radius_thr), int(bool(fit_circle)), int(knn_num),
+                                         int(n_threads), _p(wb, _u64p), _p(o["win_lo"], _u64p), _p(o["win_hi"], _u64p),
+                                         _p(o["seg_cnt"], _u32p), _p(o["n_clusters"], _u32p), _p(o["win_info"], _u32p),
+                                         _p(o["tie"], _u8), _p(o["xy"], _dp), _p(o["event_point"], _i32p), _p(o["labels"], _i32p),
+                                         _p(o["kept_labels"], _i32p), _p(o["rep"], _u32p), _p(o["cand_pair"], _u32p),
+                                         _p(o["cand_xyr"], _dp), _p(o["def_pts"], _u8), _p(o["def_kept"], _u8), _p(o["def_rep"], _u8),
+                                         _p(o["def_cand"], _u8))
+    if ev == (1 << 64) - 1:
+        raise RuntimeError("a window does not fit its slots (win_base is not the scan of the windows' sizes)")
+    out["events"] = int(ev)
+    out["n_threads"] = int(n_threads)
+    return out
+
+
 # ---- circle-candidate extraction (oracle/detect_oracle.cpp) ----
 def circle_radius_threshold(width, height, rows, cols, asymmetric, square, radius):
     L = lib()

@@ -42,8 +42,8 @@ def _order_of(ctx, torch, segs, eps, minpts):
 
 
 def _check(seg, lab, od, eps, minpts):
-    kd = O.have_ref_kdtree()
-    _rc, labels_o, _nc, clusters = O.dbscan(seg, eps, minpts, kdapi=kd, with_members=True)
+    # the oracle's k-d tree is the session's backend (tests/conftest.py: the reference's compiled kdtree.cpp when present)
+    _rc, labels_o, _nc, clusters = O.dbscan(seg, eps, minpts, with_members=True)
     assert np.array_equal(lab, labels_o)
     assert np.array_equal(od < 0, lab < 0)
     for c, members in enumerate(clusters):

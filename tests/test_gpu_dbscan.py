@@ -39,6 +39,31 @@ def test_golden_fixtures(ctx):
         assert (ncl == z["n_clusters"]).all(), f
 
 
+def test_which_kd_tree_checked_the_kernels(ctx):
+    """States (and asserts) what sits under the oracle when it judges the HIP kernels in this session: with oracle/_ref
+    present it is the reference's own kdtree.cpp — then the kernels are checked against BOTH trees here, which must agree with
+    each other; without it the session is checked by the restated tree only, and this test says so by being skipped."""
+    rng = np.random.default_rng(5)
+    xy, off = synth.arc_slices(rng, 96, 0.5)
+    cnt = np.diff(off).astype(np.uint32)
+    labels, ncl = ctx.dbscan_batch(xy, off, 4.0, 2)
+    print("\n[parity] oracle k-d tree of this session: %s" % O.kd_backend())
+    if not O.have_ref_kdtree():
+        ref_l, ref_n = O.dbscan_batch(xy, off[:-1], cnt, 4.0, 2)
+        assert np.array_equal(labels, ref_l) and np.array_equal(ncl, ref_n)
+        pytest.skip("oracle/_ref/libkdtree_ref.so absent: the kernels of this session are checked by the RESTATED k-d tree only")
+    assert "reference" in O.kd_backend()
+    try:
+        res = {}
+        for ref in (True, False):
+            O.set_kd_backend(ref)
+            res[ref] = O.dbscan_batch(xy, off[:-1], cnt, 4.0, 2)
+            assert np.array_equal(labels, res[ref][0]) and np.array_equal(ncl, res[ref][1]), O.kd_backend()
+        assert np.array_equal(res[True][0], res[False][0])
+    finally:
+        O.set_kd_backend(True)
+
+
 @pytest.mark.parametrize("noise", [0.0, 0.1, 0.5, 2.0])
 def test_arc_slices(ctx, noise):
     rng = np.random.default_rng(int(noise * 10) + 1)

@@ -114,8 +114,30 @@ def test_oracle_spot_checks(run):
             o, n = off[2 * s + k], cnt[2 * s + k]
             assert n == pts.shape[0]
             assert np.array_equal(pipe.xy[o:o + n].cpu().numpy(), pts)
-            rc, lab, nc = O.dbscan(pts, 4.0, 2, kdapi=O.have_ref_kdtree())
+            rc, lab, nc = O.dbscan(pts, 4.0, 2)
             assert np.array_equal(pipe.labels[o:o + n].cpu().numpy(), lab)
+
+
+def test_every_window_of_the_10M_stream_equals_the_oracle(run):
+    """BASELINE configs[1], no sampling: all 6 667 windows — bounds, points in the reference's order, event->point map,
+    DBSCAN labels, cluster counts, kept labels, verdicts, representatives (the reference's nth_element picks), pairs and
+    circles — against the oracle's whole-stream loop on all host threads.  Run twice when the reference's compiled
+    kdtree.cpp is present (oracle/_ref): on it and on the restated tree, which therefore agree with each other too."""
+    import full_compare as FC
+    ctx, pipe, ev, t0, t1, torch = run
+    rec = ev.cpu().numpy()
+    backends = [True, False] if O.have_ref_kdtree() else [False]
+    try:
+        for ref in backends:
+            O.set_kd_backend(ref)
+            st = FC.compare_all_windows(pipe, rec, t0, t1, torch)
+            print("\n[parity] 10 M events: %d windows, %d points, %d paired windows (%d with tied medians), %d candidates == oracle on %s "
+                  "(%d threads, %.1f s)" % (st["windows"], st["points"], st["paired"], st["tied"], st["candidates"], st["kd_backend"],
+                                           st["threads"], st["oracle_seconds"]))
+            assert st["events"] == N_EVENTS and st["windows"] == len(t0)
+            assert st["paired"] > len(t0) // 2 and st["tied"] > len(t0) // 10
+    finally:
+        FC.use_reference_kdtree_if_present()
 
 
 def test_pixel_kernel_equals_general_tiers_repeatedly(run):
@@ -174,7 +196,7 @@ def test_config0_one_window_of_100k_events():
         assert np.array_equal(pipe.xy[off[1]:off[1] + cnt[1]].cpu().numpy(), neg)
         assert np.array_equal(pipe.event_point[:n].cpu().numpy(), ep)
         for k, pts in ((0, pos), (1, neg)):
-            rc, lab, nc = O.dbscan(pts, 4.0, 2, kdapi=O.have_ref_kdtree())
+            rc, lab, nc = O.dbscan(pts, 4.0, 2)
             assert np.array_equal(pipe.labels[off[k]:off[k] + cnt[k]].cpu().numpy(), lab), k
             assert int(pipe.n_clusters[k]) == nc
         ref = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
@@ -245,12 +267,14 @@ def test_a_tie_pick_that_cannot_be_reproduced_is_flagged_not_silent(monkeypatch)
 
 
 @pytest.mark.parametrize("n_events", [50_000_000])
-def test_oracle_spot_checks_at_the_benchmark_size(n_events):
-    """BASELINE configs[2] (the 50 M-event stream bench.py times): 24 windows sampled over the whole stream, records ->
-    reference point order -> labels on the reference's kd-tree -> candidates, == the oracle; plus the structure invariants
-    that do not need the oracle.  ~9 GB of HBM, seconds of CPU."""
+def test_every_window_at_the_benchmark_size_equals_the_oracle(n_events):
+    """BASELINE configs[2] (the 50 M-event stream bench.py times): ALL 33 334 windows, records -> reference point order
+    (real std::unordered_set) -> labels on the reference's compiled kd-tree (oracle/_ref, when present) -> kept clusters ->
+    the reference's nth_element picks -> pairs and circles, == the oracle in every slot of every array; plus the structure
+    invariants that do not need the oracle.  ~9 GB of HBM, ~4 GB of host memory, seconds on the box's host threads."""
     import torch
     import eventcalib_amd
+    import full_compare as FC
     from eventcalib_amd.pipeline import DetectPipeline
     if torch.cuda.get_device_properties(0).total_memory < 40e9:
         pytest.skip("needs ~10 GB of device memory")
@@ -269,35 +293,12 @@ def test_oracle_spot_checks_at_the_benchmark_size(n_events):
         assert int(lo[0]) == 0 and int(hi[-1]) == n_events and bool((lo[1:] == hi[:-1]).all())
         cnt = pipe.seg_cnt[:2 * S].long()
         assert bool((cnt[0::2] + cnt[1::2] <= hi - lo).all())
-        rng = np.random.default_rng(7)
-        pick = np.sort(rng.choice(S, 24, replace=False))
-        lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
-        off, cntn = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64), cnt.cpu().numpy()
-        info = pipe.win_info[:S].cpu().numpy()
-        paired = tied = 0
-        for s in pick:
-            rec = ev[25 * int(lo[s]): 25 * int(hi[s])].cpu().numpy()
-            pos, neg, ep = O.event_frame(rec, 0, int(hi[s] - lo[s]), "reference")
-            base = int(pipe.win_base[s])
-            assert np.array_equal(pipe.event_point[base:base + int(hi[s] - lo[s])].cpu().numpy(), ep), s
-            for k, pts in ((0, pos), (1, neg)):
-                o, c = off[2 * s + k], cntn[2 * s + k]
-                assert c == len(pts) and np.array_equal(pipe.xy[o:o + c].cpu().numpy(), pts), (s, k)
-                rc, lab, nc = O.dbscan(pts, 4.0, 2, kdapi=O.have_ref_kdtree())
-                assert np.array_equal(pipe.labels[o:o + c].cpu().numpy(), lab), (s, k)
-            ref = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
-            assert info[s, 3] == ref["status"], s
-            assert np.array_equal(pipe.kept_labels[off[2 * s]:off[2 * s] + len(pos)].cpu().numpy(), ref["kept_pos"]), s
-            assert int(info[s, 3]) & 0x100 == 0, s
-            if not ref["status"]:      # tie windows included: the reference's own picks, nothing handed to the oracle
-                paired += 1
-                tied += int(bool(ref["tie"]))
-                n = ref["n"]
-                assert np.array_equal(pipe.rep[off[2 * s]:off[2 * s] + ref["nk_pos"]].cpu().numpy(), ref["rep_pos"]), s
-                assert np.array_equal(pipe.rep[off[2 * s + 1]:off[2 * s + 1] + ref["nk_neg"]].cpu().numpy(), ref["rep_neg"]), s
-                assert info[s, 0] == n
-                assert np.array_equal(pipe.cand_pair[off[2 * s]:off[2 * s] + n].cpu().numpy(), ref["pair"]), s
-                assert np.array_equal(pipe.cand_xyr[off[2 * s]:off[2 * s] + n].cpu().numpy(), ref["xyr"]), s
-        assert paired >= 12 and tied >= 3, (paired, tied)
+        backend = FC.use_reference_kdtree_if_present()
+        st = FC.compare_all_windows(pipe, ev.cpu().numpy(), t0, t1, torch)
+        print("\n[parity] 50 M events: %d windows, %d points, %d paired windows (%d with tied medians), %d candidates == oracle on %s "
+              "(%d threads, %.1f s)" % (st["windows"], st["points"], st["paired"], st["tied"], st["candidates"], backend, st["threads"],
+                                       st["oracle_seconds"]))
+        assert st["events"] == n_events and st["windows"] == S == 33334
+        assert st["paired"] > S // 2 and st["tied"] > S // 10, st
     finally:
         ctx.close()

@@ -42,3 +42,59 @@ def test_streamed_equals_resident():
     info, fnd, feat, st = capi.detect_stream_tiled(ctx, host.data_ptr(), 0, 5.0, 1.5e-3, 16, 8)
     assert len(info) == 0
     ctx.close()
+
+
+@pytest.mark.parametrize("n,rate", [(2_000_000, 1.0e6), (1_600_000, 4.0e6)])
+def test_configs4_fisheye_stream_through_the_ingest_equals_the_oracle(n, rate):
+    """BASELINE configs[4] as a whole: a Kannala-Brandt (fisheye) stream in HOST memory through the double-buffered
+    ingest (ecal_detect_stream_tiled: hipMemcpyAsync of chunk k + 1 under the kernels of chunk k), judged by the CPU
+    ORACLE — not by the resident pipeline: every window's verdict / kept-cluster / candidate counts == the oracle's
+    EventFrame + extractFeatures loop (EventFrame.cpp:10-36, CirclesEventFrame.cpp:61-312) on the same records, and every
+    circle the ingest returns for a window with a grid is, bit for bit, one of the oracle's candidate circles of that window
+    (36 distinct ones).  1 Mev/s is the configuration's rate; 4 Mev/s gives complete grids in 1.5 ms windows."""
+    import oracle_lib as O
+    import eventcalib_amd
+    from eventcalib_amd import capi
+    SS.CAMERA = "fisheye"
+    try:
+        buf = SS.make_stream(n, rate=rate, t_start=5.0, device="cpu", seed=21)
+    finally:
+        SS.CAMERA = "pinhole"
+    host = buf.pin_memory()
+    rec = buf.numpy()
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / rate, 1.5e-3)
+    S = len(t0)
+    t, _, _ = SS.unpack_records(buf)
+    t = t.numpy()
+    lo, hi = np.searchsorted(t, t0, "left"), np.searchsorted(t, t1, "right")
+    wb = np.concatenate([[0], np.cumsum(hi - lo)]).astype(np.uint64)
+    assert int(wb[-1]) == n
+    f = O.detect_windows_full(rec, t0, t1, wb, n)
+    assert f["events"] == n and np.array_equal(f["win_lo"], lo.astype(np.uint64)) and np.array_equal(f["win_hi"], hi.astype(np.uint64))
+    print("\n[parity] fisheye ingest, %d events at %.0f Mev/s: %d windows, %d paired; oracle on %s" % (
+        n, rate / 1e6, S, int((f["win_info"][:, 3] == 0).sum()), O.kd_backend()))
+    ctx = eventcalib_amd.Context(0)
+    try:
+        n_found = 0
+        for wpc in (48, S + 3, 5):
+            info, fnd, feat, st = capi.detect_stream_tiled(ctx, host.data_ptr(), n, 5.0, 1.5e-3, wpc, S + 8)
+            assert len(info) == S and st["chunks"] == -(-S // wpc) and st["bytes_uploaded"] == n * 25
+            bad = np.nonzero((info != f["win_info"]).any(axis=1))[0]
+            assert bad.size == 0, "verdicts differ from the oracle in %d windows, first %d: %s vs %s" % (
+                bad.size, bad[0], info[bad[0]], f["win_info"][bad[0]])
+            n_found = int((fnd != 0).sum())
+            for s in np.nonzero(fnd)[0]:
+                assert info[s, 3] == 0 and info[s, 0] >= 36
+                b = int(wb[s])
+                cand = f["cand_xyr"][b:b + int(info[s, 0])].view(np.uint64)
+                got = np.ascontiguousarray(feat[s]).view(np.uint64)
+                hit = (got[:, None, :] == cand[None, :, :]).all(axis=2)
+                assert (hit.sum(axis=1) >= 1).all(), s                       # each returned circle is an oracle candidate ...
+                assert len(set(hit.argmax(axis=1).tolist())) == 36, s        # ... and no candidate is used twice
+            assert np.isnan(feat[fnd == 0]).all()
+        if rate > 2e6:
+            assert n_found > S // 4, n_found
+        else:
+            assert int((f["win_info"][:, 3] == 0).sum()) > S // 2
+    finally:
+        ctx.close()

@@ -61,3 +61,60 @@ def test_synthetic_window_gives_candidates():
     pos, neg, _ = O.event_frame(rec, lo, hi, "reference")
     out = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
     assert out["status"] == 0 and out["n"] >= 30
+
+
+def test_full_window_loop_equals_the_single_window_functions_on_both_kd_trees():
+    """oracle_detect_windows_full_mt (the batch checker of the full-size GPU tests) lays out, per window, exactly what
+    event_frame + dbscan + extract_candidates give — with the restated kd-tree and with the reference's compiled one
+    (oracle/_ref), which must agree with each other in every array."""
+    n, rate = 120_000, 2.0e6
+    buf = SS.make_stream(n, rate=rate, seed=4)
+    rec = buf.numpy()
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / rate)
+    t0 = np.concatenate([t0, [t0[3], 1.0]])             # an overlapping window and an empty one
+    t1 = np.concatenate([t1, [t1[5], 1.1]])
+    S = len(t0)
+    bounds = [O.window_bounds(rec, a, b) for a, b in zip(t0, t1)]
+    size = np.array([hi - lo for lo, hi in bounds], np.uint64)
+    wb = np.concatenate([[0], np.cumsum(size)]).astype(np.uint64)
+    outs = {}
+    try:
+        for ref in ([False, True] if O.have_ref_kdtree() else [False]):
+            O.set_kd_backend(ref)
+            assert ("reference" in O.kd_backend()) == ref
+            outs[ref] = O.detect_windows_full(rec, t0, t1, wb, int(wb[-1]), n_threads=3)
+    finally:
+        O.set_kd_backend(False)
+    f = outs[False]
+    assert f["events"] == int(size.sum())
+    if True in outs:
+        for k, v in f.items():
+            assert np.array_equal(v, outs[True][k]), k
+    paired = 0
+    for s in range(S):
+        lo, hi = bounds[s]
+        assert (int(f["win_lo"][s]), int(f["win_hi"][s])) == (lo, hi)
+        pos, neg, ep = O.event_frame(rec, lo, hi, "reference")
+        b = int(wb[s])
+        assert (int(f["seg_cnt"][2 * s]), int(f["seg_cnt"][2 * s + 1])) == (len(pos), len(neg))
+        assert np.array_equal(f["event_point"][b:b + hi - lo], ep)
+        assert np.array_equal(f["xy"][b:b + len(pos)], pos) and np.array_equal(f["xy"][b + len(pos):b + len(pos) + len(neg)], neg)
+        assert f["def_pts"][b:b + len(pos) + len(neg)].all() and not f["def_pts"][b + len(pos) + len(neg):int(wb[s + 1])].any()
+        for o, pts, k in ((b, pos, 0), (b + len(pos), neg, 1)):
+            if len(pts):
+                rc, lab, nc = O.dbscan(pts, 4.0, 2)
+                assert np.array_equal(f["labels"][o:o + len(pts)], lab) and int(f["n_clusters"][2 * s + k]) == nc
+        r = O.extract_candidates(pos, neg, 4.0, 2, 5, 36, 15.511363636363637)
+        assert list(f["win_info"][s]) == [r["n"], r["nk_pos"], r["nk_neg"], r["status"]] and bool(f["tie"][s]) == r["tie"]
+        if len(pos) and len(neg):
+            assert np.array_equal(f["kept_labels"][b:b + len(pos)], r["kept_pos"]) and f["def_kept"][b:b + len(pos)].all()
+            assert np.array_equal(f["kept_labels"][b + len(pos):b + len(pos) + len(neg)], r["kept_neg"])
+        if not r["status"]:
+            paired += 1
+            assert np.array_equal(f["rep"][b:b + r["nk_pos"]], r["rep_pos"])
+            assert np.array_equal(f["rep"][b + len(pos):b + len(pos) + r["nk_neg"]], r["rep_neg"])
+            assert np.array_equal(f["cand_pair"][b:b + r["n"]], r["pair"]) and np.array_equal(f["cand_xyr"][b:b + r["n"]], r["xyr"])
+            assert int(f["def_rep"][b:int(wb[s + 1])].sum()) == r["nk_pos"] + r["nk_neg"] and int(f["def_cand"][b:int(wb[s + 1])].sum()) == r["n"]
+        else:
+            assert not f["def_rep"][b:int(wb[s + 1])].any() and not f["def_cand"][b:int(wb[s + 1])].any()
+    assert paired >= S // 2
