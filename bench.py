@@ -5,10 +5,14 @@ windows, policy P1 of SURVEY §8d), one process per GPU.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  The detection
-path shards by time range with no data-path collective: every rank owns its own
-50 M-event stream (weak scaling); the only collectives are the timing barrier and a MAX over ranks.
-A "step" = one full pass of the hot path over the rank's resident stream.  Prints ONE JSON line.
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).  The metric is
+quoted "on 50M-event stream @1/2/4/8 GPU": the headline is STRONG scaling — the ONE 50 M-event stream
+cut into N contiguous time ranges of whole windows, one per rank, no data-path collective (SURVEY
+§8e; the reference cuts the same stream into pieces, eventCameraCalib.cpp:172-179); the only
+collectives are the timing barrier and a MAX over ranks.  Weak scaling (one 50 M stream per GPU) is
+reported beside it.  A "step" = one full pass of the hot path over the stream, HBM-resident when the
+timed region starts (the upload is never part of `value`).  Prints ONE JSON line; a failure in a leg
+beside the headline is listed in `failed_legs` and makes the exit code 1.
 """
 import argparse
 import json
@@ -23,6 +27,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 ALGO_BYTES_PER_EVENT = 29.0     # 25 B record read once + 4 B int32 label written once
 TRAFFIC_PROFILE = "r03c_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def usable_cpus():
+    """Host cores this process can actually run on at once: min(hardware threads, affinity mask, cgroup CPU quota).  The GPU
+    box shows 256 hardware threads behind a quota of 16 CPUs: a CPU baseline on "254 threads" there is 16 cores' worth."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 class leg:
@@ -57,9 +78,13 @@ def main():
                     help="pieces of the adaptive-window policy P2 (SURVEY 8d) measured after M1 (0 = skip; -1 = the reference's "
                          "own choice on this host, 5 * (hardware threads - 2), and 4096)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe upload timing")
-    ap.add_argument("--scaling", choices=["weak", "both"], default="both",
-                    help="`value` is always the weak-scaling figure (one --events stream per GPU, the contract's definition); "
-                         "\"both\" adds, under --gpus N > 1, a strong-scaling leg: ONE --events stream cut into N time ranges")
+    ap.add_argument("--event-point", action="store_true",
+                    help="the timed passes also write the event -> point map (4 B per event; an output of this library's own that "
+                         "only the association stage reads — the reference's EventFrame has no such member)")
+    ap.add_argument("--scaling", choices=["strong", "both"], default="both",
+                    help="`value` is always the strong-scaling figure (ONE --events stream cut into N time ranges: BASELINE.json's "
+                         "metric is quoted on one 50 M-event stream at 1/2/4/8 GPUs); \"both\" adds, under --gpus N > 1, the "
+                         "weak-scaling leg beside it (one --events stream per GPU)")
     ap.add_argument("--ingest-events", type=int, default=200_000_000,
                     help="events of the double-buffered ingest leg (configs[4]; host-resident stream; 0 = skip)")
     ap.add_argument("--calib-views", type=int, default=64,
@@ -122,14 +147,26 @@ def main():
         ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
     pipe = DetectPipeline(ctx, dev)
 
-    # ---- synthetic input, resident in HBM before the timed region ----
+    # ---- synthetic input, resident in HBM before the timed region: ONE stream of --events events (seed 12345, from t = 5 s);
+    # N ranks: cut into N contiguous ranges of whole windows, one per rank (tiled windows do not overlap; the adaptive policy's
+    # ranges would overlap by the longest window, 9 steps).  Every rank generates ITS range of that same stream (chunks seeded
+    # by index: the same records whoever generates them).  Rate = the whole stream over the slowest rank.
     n_events = args.events
     rate = 1.0e6
-    t_start = 5.0 + rank * (n_events / rate + 1.0)      # every rank: its own time range of the motion
-    events = SS.make_stream(n_events, rate=rate, t_start=t_start, seed=12345 + rank, device=dev)
+    t_start = 5.0
+    g0, g1 = SS.tiled_windows(t_start, t_start + (n_events - 1) / rate, 1.5e-3)
+    Sg = len(g0)
+    w_lo, w_hi = (Sg * rank) // world, (Sg * (rank + 1)) // world
+    if world > 1:
+        k_lo = max(0, int((g0[w_lo] - t_start) * rate) - 2)
+        k_hi = min(n_events, int((g1[w_hi - 1] - t_start) * rate) + 3)
+    else:
+        k_lo, k_hi = 0, n_events
+    n_local = k_hi - k_lo                                   # records in this rank's buffer (its windows + a record or two each side)
+    events = SS.make_stream(n_local, rate=rate, t_start=t_start, seed=12345, device=dev, k_offset=k_lo, total=n_events)
+    t0, t1 = g0[w_lo:w_hi], g1[w_lo:w_hi]
     t_first = t_start
     t_last = t_start + (n_events - 1) / rate
-    t0, t1 = SS.tiled_windows(t_first, t_last, 1.5e-3)
     pipe.set_windows(t0, t1)
     S = len(t0)
 
@@ -144,6 +181,7 @@ def main():
     n_points = int(pipe.seg_cnt[:2 * S].sum().item())
     n_ok = int((pipe.win_info[:S, 3] == 0).sum().item())
     n_cand = int(pipe.win_info[:S, 0].sum().item())
+    n_covered = int(pipe.win_hi[S - 1].item()) - int(pipe.win_lo[0].item())     # events inside this rank's windows
 
     def step():
         pipe.run(events, eps, minpts)
@@ -158,40 +196,56 @@ def main():
     # per-stage HIP events on the stream the kernels are launched on (torch's current stream)
     st = torch.cuda.current_stream(dev)
     c = ctx
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     pipe.set_detect_params(5, 36, ctx.circle_radius_threshold(346, 260, 9, 4, True, 5.5, 1.75))
-    pk = pipe._pk()
-    barrier()
-    t_begin = time.perf_counter()
-    for k in range(args.steps):
-        n = n_events
-        ev[k][0].record(st)
-        c.window_bounds_dev(events.data_ptr(), n, pipe.t0.data_ptr(), pipe.t1.data_ptr(), S, pipe.win_lo.data_ptr(),
+
+    def staged_pass(n, Sw, marks=None):
+        """One pass of the hot path, stage by stage, on the launch stream; marks: five HIP events recorded around the stages."""
+        pk = pipe._pk()
+        if marks:
+            marks[0].record(st)
+        c.window_bounds_dev(events.data_ptr(), n, pipe.t0.data_ptr(), pipe.t1.data_ptr(), Sw, pipe.win_lo.data_ptr(),
                             pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(), st.cuda_stream)
-        ev[k][1].record(st)
+        if marks:
+            marks[1].record(st)
         # the three stages on packed points (ecal_packed_points): integer-pixel windows travel as 4-byte words between the
         # stages; the doubles of positiveEvents_ / negativeEvents_ are written on request only (pipe.xy), outside this loop
-        c.slice_events_packed_dev(events.data_ptr(), n, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(), S, 0, n,
-                                  pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(),
-                                  pipe.flags.data_ptr(), pk, st.cuda_stream)
-        ev[k][2].record(st)
-        c.dbscan_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * S, n, 0,
+        # (d_event_point = NULL unless --event-point: the event -> point map is this library's own extra for the association
+        # stage, the reference's EventFrame keeps none; the end-to-end leg, which associates, asks for it)
+        c.slice_events_packed_dev(events.data_ptr(), n, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(), Sw, 0, n,
+                                  pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(),
+                                  pipe.event_point.data_ptr() if args.event_point else 0, pipe.flags.data_ptr(), pk, st.cuda_stream)
+        if marks:
+            marks[2].record(st)
+        c.dbscan_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * Sw, n, 0,
                                   eps, minpts, pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), pk, st.cuda_stream)
-        ev[k][3].record(st)
+        if marks:
+            marks[3].record(st)
         # the exact extraction (the library's default): plain pass + the reference's member order for the clusters whose median
         # is tied in norm + re-extraction of their windows
         c.extract_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
-                                   pipe.n_clusters.data_ptr(), S, n, eps, pipe.det[0], pipe.det[1], pipe.det[2],
+                                   pipe.n_clusters.data_ptr(), Sw, n, eps, pipe.det[0], pipe.det[1], pipe.det[2],
                                    pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
                                    pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), pk, st.cuda_stream, fit_circle=pipe.det[3],
                                    knn_num=pipe.det[4])
-        ev[k][4].record(st)
+        if marks:
+            marks[4].record(st)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    barrier()
+    t_begin = time.perf_counter()
+    for k in range(args.steps):
+        staged_pass(n_local, S, ev[k])
     barrier()
     elapsed = time.perf_counter() - t_begin
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        cov = torch.tensor([float(n_covered)], dtype=torch.float64, device=dev)
+        dist.all_reduce(cov, op=dist.ReduceOp.SUM)
+        covered_total = int(cov.item())
+    else:
+        covered_total = n_covered
 
     stage_ms = np.zeros(4)
     for k in range(args.steps):
@@ -199,13 +253,37 @@ def main():
             stage_ms[j] += ev[k][j].elapsed_time(ev[k][j + 1])
     stage_ms /= max(args.steps, 1)
 
+    # the part of a pass that does not shrink with the stream (launches of tiers that find their to-do lists empty, window
+    # bounds, per-kernel ramp-up): passes over the first S, S/2 and S/4 windows, straight line through the three times,
+    # its value at zero windows.  At N = 8 a rank's pass is an eighth of the stream: this is what caps strong scaling.
+    pass_ms_fixed = None
+    if rank == 0 and args.steps > 0 and S >= 64:
+        sizes, times = [S, S // 2, S // 4], []
+        reps = max(10, args.steps)
+        for Sw in sizes:
+            for _ in range(3):
+                staged_pass(n_local, Sw)
+            fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            fe[0].record(st)
+            for _ in range(reps):
+                staged_pass(n_local, Sw)
+            fe[1].record(st)
+            torch.cuda.synchronize(dev)
+            times.append(fe[0].elapsed_time(fe[1]) / reps)
+        slope, icpt = np.polyfit(np.array(sizes, float), np.array(times), 1)
+        pass_ms_fixed = {"ms": round(float(icpt), 4), "ms_per_1000_windows": round(float(slope) * 1e3, 5),
+                         "passes_ms": {str(a): round(b, 4) for a, b in zip(sizes, times)},
+                         "note": "intercept of pass time against window count (S, S/2, S/4 windows of the same stream)"}
+        staged_pass(n_local, S)        # leave the arrays of the whole stream behind for the legs below
+        torch.cuda.synchronize(dev)
+
     # the same pass as ONE call / one kernel per window (ecal_detect_fused_dev): measured beside the stage-by-stage form above,
     # outside the timed region; identical results (tests/test_gpu_fused.py).  The faster form is not assumed: both are reported.
     fused_ms = plain_extract_ms = None
     if rank == 0 and args.steps > 0:
         def fused_step():
-            c.detect_fused_dev(events.data_ptr(), n_events, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(),
-                               S, 0, 0, n_events, eps, minpts, pipe.det[0], pipe.det[1], pipe.det[2], pipe._xy.data_ptr(),
+            c.detect_fused_dev(events.data_ptr(), n_local, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(),
+                               S, 0, 0, n_local, eps, minpts, pipe.det[0], pipe.det[1], pipe.det[2], pipe._xy.data_ptr(),
                                pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(), pipe.flags.data_ptr(),
                                pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(),
                                pipe.cand_xyr.data_ptr(), pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream,
@@ -224,9 +302,9 @@ def main():
             c.set_median_ties(1)       # ECAL_TIES_SMALLER_PID: the plain extraction, same packed points
             try:
                 c.extract_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.labels.data_ptr(),
-                                           pipe.n_clusters.data_ptr(), S, n_events, eps, pipe.det[0], pipe.det[1], pipe.det[2],
+                                           pipe.n_clusters.data_ptr(), S, n_local, eps, pipe.det[0], pipe.det[1], pipe.det[2],
                                            pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(), pipe.cand_xyr.data_ptr(),
-                                           pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), pk, st.cuda_stream, fit_circle=pipe.det[3],
+                                           pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), pipe._pk(), st.cuda_stream, fit_circle=pipe.det[3],
                                            knn_num=pipe.det[4])
             finally:
                 c.set_median_ties(0)
@@ -238,74 +316,68 @@ def main():
         torch.cuda.synchronize(dev)
         plain_extract_ms = fe[0].elapsed_time(fe[1]) / args.steps
 
-    total_events = n_events * world * args.steps
+    total_events = n_events * args.steps                   # every event of the ONE stream once per step, whatever N
     value = total_events / elapsed / 1e6
     ms_per_step = elapsed / max(args.steps, 1) * 1e3
 
-    # ---- strong scaling (BASELINE.json's metric reads "on 50M-event stream @1/2/4/8 GPU"): ONE stream of --events events —
-    # rank 0's — cut into N contiguous ranges of whole windows, one per rank, no data-path collective (tiled windows do not
-    # overlap; the adaptive policy's ranges would overlap by the longest window, 9 steps).  Every rank generates ITS range of
-    # that same stream (chunks seeded by index: the same records).  Rate = the whole stream over the slowest rank.
-    strong = None
-    if world > 1 and args.scaling == "both" and args.steps > 0:
-        g0, g1 = SS.tiled_windows(5.0, 5.0 + (n_events - 1) / rate, 1.5e-3)
-        Sg = len(g0)
-        w_lo, w_hi = (Sg * rank) // world, (Sg * (rank + 1)) // world
-        k_lo = max(0, int((g0[w_lo] - 5.0) * rate) - 2)
-        k_hi = min(n_events, int((g1[w_hi - 1] - 5.0) * rate) + 3)
-        del events
-        torch.cuda.empty_cache()
-        ev_s = SS.make_stream(k_hi - k_lo, rate=rate, t_start=5.0, seed=12345, device=dev, k_offset=k_lo, total=n_events)
-        pipe.set_windows(g0[w_lo:w_hi], g1[w_lo:w_hi])
-        for _ in range(max(1, args.warmup)):
-            pipe.run(ev_s, eps, minpts)
-        barrier()
-        tb = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.run(ev_s, eps, minpts)
-        barrier()
-        el_s = time.perf_counter() - tb
-        cnt = torch.tensor([float(int(pipe.win_hi[w_hi - w_lo - 1]) - int(pipe.win_lo[0])), el_s], dtype=torch.float64, device=dev)
-        tot = cnt.clone()
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-        el_s = float(cnt[1].item())
-        strong = {"value": round(n_events * args.steps / el_s / 1e6, 3), "unit": "Mevents/s", "scaling": "strong",
-                  "events_total": n_events, "events_covered_by_the_ranks_windows": int(tot[0].item()),
-                  "windows_total": Sg, "ms_per_step": round(el_s / args.steps * 1e3, 4),
-                  "note": "one %dM-event stream cut into %d time ranges of whole windows; no collective on the data path" % (n_events // 1_000_000, world)}
-        events = ev_s
-        t0, t1 = g0[w_lo:w_hi], g1[w_lo:w_hi]
+    # ---- beside the headline under N > 1: the adaptive-window search of the same stream cut over the ranks, and WEAK scaling
+    sharded_p2 = weak = None
+    if world > 1 and args.steps > 0:
         if args.p2_pieces != 0:
             # the reference driver's adaptive-window search (policy P2) over the same stream: its pieces are independent time
             # ranges (own-piece gate), so rank r searches the pieces [P r / N, P (r + 1) / N) — with the bounds they have in
             # the whole run (ecal_adaptive_params.piece_first / piece_count) — on its own range of the stream; no collective
             from eventcalib_amd.adaptive import detect_keyframes_device
+            from eventcalib_amd import capi as _capi
             P = 5 * max(1, (os.cpu_count() or 3) - 2) if args.p2_pieces < 0 else args.p2_pieces
             P = max(P, world)
-            tf, tl = 5.0, 5.0 + (n_events - 1) / rate
+            tf, tl = t_first, t_last
             p_lo, p_hi = (P * rank) // world, (P * (rank + 1)) // world
-            step = (tl - tf) / P
-            k_lo = max(0, int((tl - step * p_hi - 5.0) * rate) - 4)        # (piece 0 is the LAST in time)
-            k_hi = min(n_events, int((tl - step * p_lo - 5.0) * rate) + 5)
-            del events, ev_s
+            pstep = (tl - tf) / P
+            q_lo = max(0, int((tl - pstep * p_hi - t_start) * rate) - 4)        # (piece 0 is the LAST in time)
+            q_hi = min(n_events, int((tl - pstep * p_lo - t_start) * rate) + 5)
+            del events
             torch.cuda.empty_cache()
-            ev_p = SS.make_stream(k_hi - k_lo, rate=rate, t_start=5.0, seed=12345, device=dev, k_offset=k_lo, total=n_events)
-            detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, piece_first=p_lo, piece_count=p_hi - p_lo)   # warm-up
+            ev_p = SS.make_stream(q_hi - q_lo, rate=rate, t_start=t_start, seed=12345, device=dev, k_offset=q_lo, total=n_events)
+            kw = dict(piece_first=p_lo, piece_count=p_hi - p_lo, gate_mode=_capi.GATE_OWN_PIECE)
+            detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, **kw)   # warm-up
             barrier()
             tb = time.perf_counter()
-            kp = detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, piece_first=p_lo, piece_count=p_hi - p_lo)
+            kp = detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, **kw)
             barrier()
             el_p = time.perf_counter() - tb
             agg = torch.tensor([float(len(kp["time"])), float(kp["windows"])], dtype=torch.float64, device=dev)
             dist.all_reduce(agg, op=dist.ReduceOp.SUM)
             mx = torch.tensor([el_p], dtype=torch.float64, device=dev)
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            strong["policy_p2"] = {"value": round(n_events / float(mx[0].item()) / 1e6, 1), "unit": "Mevents/s", "pieces": P,
-                                   "pieces_per_gpu": p_hi - p_lo, "seconds": round(float(mx[0].item()), 4),
-                                   "keyframes": int(agg[0].item()), "windows_evaluated": int(agg[1].item()), "gate": "own piece",
-                                   "note": "the pieces of one search cut over the ranks, every rank on its own time range of the stream"}
+            sharded_p2 = {"value": round(n_events / float(mx[0].item()) / 1e6, 1), "unit": "Mevents/s", "scaling": "strong", "pieces": P,
+                          "pieces_per_gpu": p_hi - p_lo, "seconds": round(float(mx[0].item()), 4),
+                          "keyframes": int(agg[0].item()), "windows_evaluated": int(agg[1].item()), "gate": "own piece",
+                          "note": "the pieces of one search cut over the ranks, every rank on its own time range of the stream"}
             events = ev_p
+        if args.scaling == "both":
+            # weak scaling: every rank its OWN --events stream (its own time range of the motion), per-GPU work fixed
+            del events
+            torch.cuda.empty_cache()
+            tw = t_start + rank * (n_events / rate + 1.0)
+            events = SS.make_stream(n_events, rate=rate, t_start=tw, seed=12345 + rank, device=dev)
+            a0, a1 = SS.tiled_windows(tw, tw + (n_events - 1) / rate, 1.5e-3)
+            pipe.set_windows(a0, a1)
+            pipe.run(events, eps, minpts)          # (sizes the pipeline's arrays for a whole stream per rank)
+            for _ in range(max(1, args.warmup)):
+                staged_pass(n_events, len(a0))
+            barrier()
+            tb = time.perf_counter()
+            for _ in range(args.steps):
+                staged_pass(n_events, len(a0))
+            barrier()
+            el_w = time.perf_counter() - tb
+            mx = torch.tensor([el_w], dtype=torch.float64, device=dev)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            el_w = float(mx[0].item())
+            weak = {"value": round(n_events * world * args.steps / el_w / 1e6, 3), "unit": "Mevents/s", "scaling": "weak",
+                    "events_per_gpu": n_events, "windows_per_gpu": len(a0), "ms_per_step": round(el_w / args.steps * 1e3, 4),
+                    "note": "one %dM-event stream PER GPU (per-GPU work fixed); reported beside the headline, never `value`" % (n_events // 1_000_000)}
 
     out = {
         "metric": "Mevents/s DBSCAN+detect",
@@ -316,22 +388,30 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": "%dM-event synthetic circle-grid stream per GPU, 346x260, 1 Mev/s, tiled 1.5 ms windows "
-                        "(%d windows), eps 4 minpts 2; stages: window bounds + EventFrame slicing + DBSCAN(+/-) + circle candidates"
-                        % (n_events // 1_000_000, S),
-            "events_per_gpu": n_events, "windows_per_gpu": S, "unique_points_per_gpu": n_points,
+            "workload": "ONE %dM-event synthetic circle-grid stream (BASELINE configs[2]'s stream), 346x260, 1 Mev/s, tiled 1.5 ms "
+                        "windows (%d windows)%s, eps 4 minpts 2; stages: window bounds + EventFrame slicing (reference point order) + "
+                        "DBSCAN(+/-) + circle candidates (reference tie picks)%s; HBM-resident when the timed region starts, upload "
+                        "excluded (reported beside: h2d, ingest)"
+                        % (n_events // 1_000_000, Sg, "" if world == 1 else ", cut into %d time ranges of whole windows, one per GPU" % world,
+                           " + the event -> point map" if args.event_point else ""),
+            "events_total": n_events, "events_covered_by_the_ranks_windows": covered_total, "windows_total": Sg,
+            "events_per_gpu": n_covered, "windows_per_gpu": S, "unique_points_per_gpu": n_points,
             "max_window_events": max_win, "max_segment_points": max_seg,
             "windows_reaching_pairing": n_ok, "circle_candidates": n_cand,
-            "sharding": "time ranges, one stream per GPU, no data-path collective",
+            "sharding": "time ranges of ONE stream, no data-path collective" if world > 1 else "single GPU",
         },
     }
-    if strong is not None:
-        out["strong_scaling"] = strong
+    if weak is not None:
+        out["weak_scaling"] = weak
+    if sharded_p2 is not None:
+        out["policy_p2_sharded"] = sharded_p2
+    if pass_ms_fixed is not None:
+        out["pass_ms_fixed"] = pass_ms_fixed
     if rank == 0:
         # the dominant KERNEL: the extraction stage is three launches (plain pass, member order, listed windows again), of
         # which the plain pass — timed alone below the stage — is the longest
@@ -340,7 +420,7 @@ def main():
             kernel_ms[3] = float(plain_extract_ms)
         dom = int(np.argmax(kernel_ms))
         names = ["window_bounds_kernel", "slice_hash_ref_kernel", "dbscan_pixel_kernel", "extract_kernel"]   # reference point order (the default)
-        achieved = ALGO_BYTES_PER_EVENT * n_events / (kernel_ms[dom] * 1e-3) / 1e9
+        achieved = ALGO_BYTES_PER_EVENT * n_covered / (kernel_ms[dom] * 1e-3) / 1e9      # rank 0's launch: the events of ITS windows
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
         # committed profile (tools/pmc_traffic.py over two rocprofv3 --pmc passes of this same command) is
         # quoted when it was taken on the same workload size, else null
@@ -365,11 +445,12 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_events,
+            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_covered,
             "kernel_ms": round(kernel_ms[dom], 4),
             # the whole pass (every kernel of the timed region) on the same algorithmic bytes, and its measured traffic
             "whole_pass": {"achieved": round(ALGO_BYTES_PER_EVENT * n_events / (ms_per_step * 1e-3) / 1e9, 2),
-                           "frac": round(ALGO_BYTES_PER_EVENT * n_events / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                           "frac": round(ALGO_BYTES_PER_EVENT * n_events / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 5),
+                           "peak": HBM_PEAK_GBS * world,
                            "traffic": pass_traffic,
                            "traffic_over_algorithmic": round(pass_traffic / (ALGO_BYTES_PER_EVENT * n_events), 3) if pass_traffic else None},
             "stage_ms": {"window_bounds": round(float(stage_ms[0]), 4), "slice": round(float(stage_ms[1]), 4),
@@ -402,7 +483,8 @@ def main():
                 mev, _ = O.detect_windows_mt(rec_mt, t0[:nw_mt], t1[:nw_mt], eps, minpts, T)
                 mel = time.perf_counter() - tc
                 out["cpu_baseline"] = {
-                    "value": round(mev / mel / 1e6, 4), "unit": "Mevents/s", "cores": T, "kind": "port",
+                    "value": round(mev / mel / 1e6, 4), "unit": "Mevents/s", "cores": min(T, usable_cpus()), "threads": T,
+                    "host_cpu_quota": usable_cpus(), "kind": "port",
                     "sample": "first %d windows (%d events) of the same stream, oracle EventFrame + extractFeatures (DBSCAN +/-, "
                               "filter, medians, pairing) per window on %d threads over %d pieces (the reference driver's "
                               "threading), %.2f s" % (nw_mt, mev, T, 5 * T, mel),
@@ -454,10 +536,12 @@ def main():
                                          "note": "adaptive windows + grid ordering + keyframe gate, host-driven (one H2D of the window "
                                                  "bounds and one D2H of verdicts + ordered circles per pass)"})
                 # the same policy with the rule on the device (ecal_detect_keyframes): no per-pass host round trip
-                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts)   # warm-up
+                from eventcalib_amd import capi as _capi
+                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts,
+                                        gate_mode=_capi.GATE_OWN_PIECE)   # warm-up
                 torch.cuda.synchronize(dev)
                 tp = time.perf_counter()
-                kd = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts)
+                kd = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, gate_mode=_capi.GATE_OWN_PIECE)
                 p2d_s = time.perf_counter() - tp
                 out["policy_p2"].append({"value": round(n_events / p2d_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2d_s, 4),
                                          "pieces": pieces, "host_threads": 1, "longest_window_chain": kd["steps"],
@@ -472,6 +556,9 @@ def main():
                 # ... and with the reference's own gate semantics: ONE keyframe map, single-worker order (ECAL_GATE_SHARED_MAP ==
                 # oracle/policy_oracle.cpp mode 1): speculation as above + verification rounds across the piece boundaries
                 from eventcalib_amd import capi as _capi
+                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts,
+                                        gate_mode=_capi.GATE_SHARED_MAP)   # warm-up, as the two timings above (first-call allocations)
+                torch.cuda.synchronize(dev)
                 tp = time.perf_counter()
                 ks = detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, gate_mode=_capi.GATE_SHARED_MAP)
                 p2s_s = time.perf_counter() - tp
@@ -513,11 +600,27 @@ def main():
             out["init_calibration"] = out_calib
     if args.e2e_events > 0 and rank == 0 and world == 1:
         out["end_to_end"] = guarded(e2e_leg, args, ctx, dev, torch, np)
+    failed = []
     if rank == 0:
+        # a leg beside the headline that raised (a correctness assertion inside it, a library error) left {"error": ...} in its
+        # place: the line still comes out, the legs are named at the top level and the process exits 1
+        def walk(prefix, node):
+            if isinstance(node, dict):
+                if "error" in node and len(node) == 1:
+                    failed.append(prefix)
+                for k, v in node.items():
+                    walk(prefix + "." + k if prefix else k, v)
+            elif isinstance(node, list):
+                for i, v in enumerate(node):
+                    walk("%s[%d]" % (prefix, i), v)
+        walk("", out)
+        out["failed_legs"] = failed
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
     ctx.close()
+    if failed:
+        sys.exit(1)
 
 
 def e2e_leg(args, ctx, dev, torch, np):
@@ -666,8 +769,29 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
     duration = n_events / rate
     n_cp = max(4, int(duration / (50 * step)))                # EventCalibSpline.cpp:81
     n_res = int(0.9 * n_events)                               # the edge events; noise fails findCenter's gate
+    if world > 1:
+        # N ranks: the headline is the ONE spline of configs[2] (n_cp control points over the stream's duration, n_res
+        # residuals) with its TIME cut into N shards (ecal_lm_options.distributed = 2) — total work fixed, as the metric is
+        # quoted; one spline segment PER rank (per-GPU work fixed) is reported beside it
+        hook = make_allreduce_hook(ctx, world) if ctx.comm_size() == 1 else None   # gloo test hook only
+        out = time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook)
+        out = dict({"metric": "LM solver iterations/s", "scaling": "strong"}, **out)
+        if args.scaling == "both":
+            out["weak_segments_per_rank"] = segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook)
+        return out
+    return segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, None)
+
+
+def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook):
+    """One rank: THE solve of configs[2] (the headline of M2).  N ranks: every rank owns one spline segment (its own time range,
+    its own solver), the intrinsics are shared by all ranks (ecal_lm_options.distributed = 1) — weak scaling, beside the
+    time-sharded headline."""
+    import synth_solver_torch as ST
+    import synth_solver as SV
+    from eventcalib_amd.capi import Solver
     # every rank owns one spline segment (its time range); intrinsics are shared by all ranks
-    t0, t1 = t_start, t_start + duration
+    t0 = 5.0 + rank * (duration + 1.0)
+    t1 = t0 + duration
     prob, x_seg = ST.make_problem(n_res, n_cp, t0, t1, seed=777 + rank, device=dev, round_pixels=True)
     rngp = np.random.default_rng(99)                           # same perturbation of the shared intrinsics everywhere
     intr0 = x_seg[:9].copy()
@@ -690,7 +814,6 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
     solver = Solver(ctx, prob)
     del prob
     opt = solver.default_options()
-    hook = make_allreduce_hook(ctx, world) if (world > 1 and ctx.comm_size() == 1) else None   # gloo test hook only
     if world > 1:
         if hook is not None:
             opt.allreduce = hook
@@ -771,8 +894,6 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
         "sharding": "one spline segment (time range) per GPU in its own solver, shared intrinsics: 91 doubles all-reduced per "
                     "evaluation, 101 + N per linear solve, 4 per step" if world > 1 else "single GPU",
     }
-    if world > 1:
-        out["time_sharded_spline"] = time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook)
     if combined is not None:
         ref = Solver(ctx, combined[0])
         o2 = ref.default_options()
@@ -785,28 +906,40 @@ def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch
                                          "iterations": [iters, int(sr.iterations)]}
     if rank == 0 and args.solver_cpu_sample > 0 and world == 1:
         import oracle_lib as O
+        from concurrent.futures import ThreadPoolExecutor
         m = min(args.solver_cpu_sample, n_res)
         small, xs = ST.make_problem(m, 40, t0, t0 + 1.0, seed=5, device="cpu")
         tc = time.perf_counter()
         O.solver_evaluate(small, xs, want_H=False)
         cel = time.perf_counter() - tc
-        out["cpu_baseline"] = {"value": round(m / cel, 1), "unit": "residual Jacobian evaluations/s", "cores": 1,
-                               "kind": "port", "sample": "%d residuals, dual-number Jacobian + gradient accumulation, "
-                               "1 thread, %.1f s" % (m, cel),
-                               "implied_iterations_per_s_on_this_problem": round(m / cel / (2 * n_res), 6)}
+        # "cpu_ref LM with dual-number Jacobian, T threads" — T = hardware threads - 2 as the reference's workers
+        # (Ceres' own threading splits the residual blocks the same way); every thread evaluates one sample of m residuals
+        T = max(1, usable_cpus())      # (more threads than the cgroup lets run only queue behind each other)
+        with ThreadPoolExecutor(T) as ex:
+            tc = time.perf_counter()
+            list(ex.map(lambda _: O.solver_evaluate(small, xs, want_H=False), range(T)))
+            mel = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": round(T * m / mel, 1), "unit": "residual Jacobian evaluations/s", "cores": T,
+                               "kind": "port", "sample": "%d threads x %d residuals, dual-number Jacobian + gradient accumulation, "
+                               "%.1f s" % (T, m, mel),
+                               "implied_iterations_per_s_on_this_problem": round(T * m / mel / (2 * n_res), 6),
+                               "host_cpus": os.cpu_count(), "host_cpu_quota": usable_cpus(),
+                               "single_thread": {"value": round(m / cel, 1), "unit": "residual Jacobian evaluations/s", "cores": 1,
+                                                 "sample": "%d residuals, %.1f s (1 of %d hardware threads)" % (m, cel, os.cpu_count() or 1)}}
     solver.close()
     return out
 
 def time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook):
-    """ONE spline (world x n_cp control points over world x duration) whose residuals are cut by time into
-    one range per rank (ecal_lm_options.distributed = 2): per Jacobian evaluation the 91-double head + 612 doubles per cut are
-    all-reduced, per linear solve 1082 doubles per rank, nothing proportional to the control points until the solution is put
-    together at the end.  Every rank generates ITS time range of the same problem."""
+    """THE spline of configs[2] (n_cp control points over the stream's duration, n_res residuals — the same
+    problem whatever the number of ranks) whose residuals are cut by time into one range per rank
+    (ecal_lm_options.distributed = 2): per Jacobian evaluation the 91-double head + 612 doubles per cut are all-reduced, per
+    linear solve 1082 doubles per rank, nothing proportional to the control points until the solution is put together at
+    the end.  Every rank generates ITS time range of the same problem."""
     import synth_solver_torch as ST
     from eventcalib_amd import capi
     from eventcalib_amd.capi import Solver
-    N, C = n_res * world, n_cp * world
-    ta, tb = 5.0, 5.0 + duration * world
+    N, C = n_res, n_cp
+    ta, tb = 5.0, 5.0 + duration
     knots = ST.uniform_knots(C, ta, tb)
     cuts = np.concatenate([[-np.inf], capi.time_shard_cuts(knots, C, world), [np.inf]])
     lo_t, hi_t = cuts[rank], cuts[rank + 1]
@@ -849,7 +982,8 @@ def time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, du
            "intrinsics_rel_err_after": float(np.abs(x[:4] / x_gt[:4] - 1).max()),
            "allreduce_doubles": {"per_jacobian_evaluation": 91 + 612 * (world - 1), "per_linear_solve": 1082 * world, "per_step": 4,
                                  "once_at_the_end": int(9 + 7 * C)},
-           "sharding": "one spline, residuals cut by time at %d knots (3-control-point separators)" % (world - 1)}
+           "residuals_per_gpu_rank0": mine,
+           "sharding": "ONE spline (the single-GPU problem), residuals cut by time at %d knots (3-control-point separators)" % (world - 1)}
     if os.environ.get("ECAL_BENCH_SOLVER_CHECK") and rank == 0:
         # test hook: the same problem in ONE solver, solved by rank 0 alone
         full, _ = ST.make_problem(N, C, ta, tb, seed=4242, device=dev, round_pixels=True)
@@ -974,8 +1108,8 @@ def calib_leg(args, ctx, dev, world, rank, dist, torch, np):
         CO.calibrate(0, obj, img[:m], SC.WIDTH, SC.HEIGHT, SC.FLAGS_EXAMPLE, 1.0)
         cel = time.perf_counter() - tc
         out["cpu_baseline"] = {"value": round(1.0 / cel, 4), "unit": "calibrations/s", "cores": 1, "kind": "port",
-                               "sample": "%d of the %d views, numpy restatement with finite-difference Jacobians and the "
-                                         "dense (12 + 6V)^2 solve OpenCV uses, %.1f s" % (m, V, cel)}
+                               "host_cpus": os.cpu_count(), "sample": "1 thread of %d; %d of the %d views, numpy restatement with finite-difference Jacobians and the "
+                                         "dense (12 + 6V)^2 solve OpenCV uses, %.1f s" % (os.cpu_count() or 1, m, V, cel)}
     return out
 
 

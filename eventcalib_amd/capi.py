@@ -240,6 +240,15 @@ class Context:
         self._L.ecal_set_median_ties.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self._check(self._L.ecal_set_median_ties(self._h, code))
 
+    TAIL_AUTO, TAIL_TIERED, TAIL_LEAN = 0, 1, 2
+
+    def set_tail_mode(self, mode):
+        """How the stage calls schedule their later size tiers (ecal_set_tail_mode): "auto" (default: one general tail launch per
+        stage while the stage's to-do lists were empty at its previous call), "tiered" (every tier, every call), "lean"."""
+        code = {"auto": 0, "tiered": 1, "lean": 2, 0: 0, 1: 1, 2: 2}[mode]
+        self._L.ecal_set_tail_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self._check(self._L.ecal_set_tail_mode(self._h, code))
+
     def set_point_order(self, order):
         """Element order of the pixel sets: "reference" (EventFrame.cpp:34-35 on libstdc++; default) or "first"."""
         code = {"reference": 0, "first": 1, 0: 0, 1: 1}[order]

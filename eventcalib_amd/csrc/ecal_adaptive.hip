@@ -466,10 +466,28 @@ extern "C" uint64_t ecal_detect_keyframes_cap_hint_dev(ecal_ctx *ctx, const uint
     return hint < 4096 ? 4096 : hint;
 }
 
+static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                                 const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                                 double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                                 uint32_t *passes, uint64_t *windows);
 extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                                      const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                                      double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
                                      uint32_t *passes, uint64_t *windows) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    // the search's windows are three to ten steps long: second-tier work by design, so its passes launch every tier
+    // (ecal_set_tail_mode; a context left in ECAL_TAIL_AUTO would spend the first pass finding that out)
+    const int was = ctx->tail_mode;
+    if (was == ECAL_TAIL_AUTO) ctx->tail_mode = ECAL_TAIL_TIERED;
+    const int rc = detect_keyframes_impl(ctx, d_events, n_events, ap, prm, cap_points, max_keyframes, kf_time, kf_duration, kf_events_num,
+                                         kf_features, n_keyframes, passes, windows);
+    ctx->tail_mode = was;
+    return rc;
+}
+static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                                 const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                                 double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                                 uint32_t *passes, uint64_t *windows) {
     if (!ctx || !ap || !prm || !n_keyframes || (n_events && !d_events)) return ECAL_ERR_INVALID;
     *n_keyframes = 0;
     if (passes) *passes = 0;

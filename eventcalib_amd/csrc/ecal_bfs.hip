@@ -115,7 +115,8 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
                                                             const uint32_t *__restrict__ win_list,
                                                             const uint32_t *__restrict__ win_count,
                                                             uint32_t *__restrict__ defer_list, uint32_t *__restrict__ defer_cnt,
-                                                            const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt) {
+                                                            const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt,
+                                                            int lean /* TIER 2 only: this launch also takes the second launch's list (ecal_ctx::tail_seen) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Coord = typename std::conditional<BoLayout<CAP>::CB == 4, float, double>::type;
     Coord *const px = reinterpret_cast<Coord *>(smem + BoLayout<CAP>::px_off);
@@ -143,12 +144,13 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
 
     // win_list: only the two segments (2 w, 2 w + 1) of the listed windows w.  The first launch looks at all of them and lists
     // the ones it leaves to the second (defer_list[0 .. S)) and third (defer_list[S .. 2 S)), which look at nothing else.
-    const uint32_t n_work = TIER > 0 ? defer_cnt[TIER - 1] : (win_list ? 2u * *win_count : S);
+    const uint32_t n_first = (TIER == 2 && lean) ? defer_cnt[0] : 0u;   // (lean: list 0, then this launch's own list 1)
+    const uint32_t n_work = TIER > 0 ? defer_cnt[TIER - 1] + n_first : (win_list ? 2u * *win_count : S);
     // A segment starts with a chain of dependent global reads — which segment, its extent, then its points — that is a third of
     // the time a workgroup spends on it: the first two links are fetched one and two segments ahead.
     // (a list entry with bit 30 / 31 set: the caller has no use for the window's first / second segment — BO_NONE, skipped)
     auto seg_of = [&](uint32_t w) -> uint32_t {
-        if (TIER > 0) return defer_list[(size_t) (TIER - 1) * S + w];
+        if (TIER > 0) return w < n_first ? defer_list[w] : defer_list[(size_t) (TIER - 1) * S + (w - n_first)];
         if (!win_list) return w;
         const uint32_t t = win_list[w >> 1];
         return ((t >> (30u + (w & 1u))) & 1u) ? BO_NONE : 2u * (t & 0x3FFFFFFFu) + (w & 1u);
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
         uint32_t marked = 0;   // only_tied == 2: bit u = the caller's mark on point tid + u BO_T (read here, with the point)
         // (packed points, first launch: a segment sliced into 4-byte pixel words is read as those; the later launches' segments
         // have had their doubles written, ecal_cluster_order_sized)
-        const bool packed = TIER == 0 && xy16 && (seg_fmt[s] & 1u);
+        const bool packed = (TIER == 0 || (TIER == 2 && lean)) && xy16 && (seg_fmt[s] & 1u);
         for (uint32_t i = tid, u = 0; i < n; i += BO_T, u++) {
             if (only_tied == 2 && order[base + i] == -3) marked |= 1u << u;
             double2 p;
@@ -608,7 +610,8 @@ __global__ __launch_bounds__(BO_TB) void cluster_order_big_kernel(const double *
                                                                   int32_t *__restrict__ order, uint32_t *__restrict__ status, int only_tied,
                                                                   const uint32_t *__restrict__ defer_list, const uint32_t *__restrict__ defer_cnt,
                                                                   uint32_t *__restrict__ ws, uint32_t W, uint32_t *__restrict__ arena_all,
-                                                                  uint32_t arena_cap) {
+                                                                  uint32_t arena_cap, const uint32_t *__restrict__ xy16, uint32_t *__restrict__ seg_fmt,
+                                                                  uint32_t *seen) {
     __shared__ unsigned long long red[BO_TB / 64 + 2];
     __shared__ uint32_t flag[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -619,12 +622,23 @@ __global__ __launch_bounds__(BO_TB) void cluster_order_big_kernel(const double *
     uint32_t *const arena = arena_all + (size_t) blockIdx.x * arena_cap;
     const double eps2 = eps * eps;
     const uint32_t n_work = defer_cnt[2];
+    if (seen && blockIdx.x == 0 && tid < 3) seen[tid] = defer_cnt[tid];   // (the stage's last launch: what its lists held)
     for (uint32_t wk = blockIdx.x; wk < n_work; wk += gridDim.x) {
         const uint32_t s = defer_list[(size_t) 2 * S + wk];
         const uint32_t n = seg_cnt[s], base = seg_off[s], nc = n_clusters[s];
         const double2 *const pts = reinterpret_cast<const double2 *>(xy) + base;
         const int32_t *const lab = labels + base;
         __syncthreads();
+        if (xy16 && seg_fmt[s] == 1u) {   // (lean form: a segment that exists packed only gets its doubles here; fmt 1 -> 3)
+            double2 *out = const_cast<double2 *>(pts);
+            for (uint32_t i = tid; i < n; i += BO_TB) {
+                const uint32_t v = xy16[base + i];
+                out[i] = make_double2((double) (int) (short) (v & 0xFFFFu), (double) (((int) v) >> 16));
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) seg_fmt[s] = 3u;
+        }
         auto refuse = [&]() {
             for (uint32_t i = tid; i < n; i += BO_TB) order[base + i] = -1;
             if (tid == 0) status[s] = 1;
@@ -930,21 +944,27 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
     // their own beside the first cost more in cross-stream waits than it saved: 0.74 against 0.65 ms per lock-step pass.)
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP1, BO_T1, 0>), dim3(grid1), dim3(BO_T1), BoLayout<BO_CAP1>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
-                       xy16, sfmt);
-    if (pk) {   // the later launches read doubles: the segments the first one listed for them are unpacked
+                       xy16, sfmt, 0);
+    // lean (ecal_ctx::tail_seen: the first launch listed nothing when this stage last ran): the third launch takes the second's
+    // list with its own, reading packed segments as they are, and the global-scratch launch unpacks what it is given — two
+    // launches behind the first instead of six
+    const bool lean = ecal_tail_lean(ctx, ECAL_TAIL_ORDER, 3);
+    if (pk && !lean) {   // the later launches read doubles: the segments the first one listed for them are unpacked
         int rcu;
         for (int k = 0; k < 3; k++)
             if ((rcu = ecal_unpack_listed(ctx, pk, dlist + (size_t) k * S, dcnt + k, S, d_seg_off, d_seg_cnt, const_cast<double *>(d_xy), 0, st)))
                 return rcu;
     }
+    if (!lean)
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP2, BO_T1B, 1>), dim3(grid2), dim3(BO_T1B), BoLayout<BO_CAP2>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
-                       nullptr, nullptr);
+                       nullptr, nullptr, 0);
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP3, BO_T2, 2>), dim3(grid3), dim3(BO_T2), BoLayout<BO_CAP3>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
-                       nullptr, nullptr);
+                       lean ? xy16 : nullptr, lean ? sfmt : nullptr, lean ? 1 : 0);
     hipLaunchKernelGGL(cluster_order_big_kernel, dim3(grid_big), dim3(BO_TB), 0, st, d_xy, d_seg_off, d_seg_cnt, S, eps, d_labels, d_n_clusters,
-                       d_order, d_status, only_tied_medians, (const uint32_t *) dlist, (const uint32_t *) dcnt, big_ws, bigW, big_hits, big_arena);
+                       d_order, d_status, only_tied_medians, (const uint32_t *) dlist, (const uint32_t *) dcnt, big_ws, bigW, big_hits, big_arena,
+                       lean ? xy16 : nullptr, lean && pk ? pk->d_seg_fmt : nullptr, ctx->tail_seen_dev ? ctx->tail_seen_dev + ECAL_TAIL_ORDER : nullptr);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

@@ -95,6 +95,15 @@ extern "C" int ecal_init(int device, ecal_ctx **out) {
         return ECAL_ERR_HIP;
     }
     if (const char *e = getenv("ECAL_MEDIAN_TIES")) ctx->median_ties = atoi(e) ? ECAL_TIES_SMALLER_PID : ECAL_TIES_REFERENCE;   // debug switch
+    if (const char *e = getenv("ECAL_TAIL_MODE")) ctx->tail_mode = atoi(e);   // debug switch (0 auto, 1 every tier, 2 lean)
+    if (hipHostMalloc((void **) &ctx->tail_seen, ECAL_TAIL_SLOTS * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer((void **) &ctx->tail_seen_dev, ctx->tail_seen, 0) == hipSuccess) {
+        for (int k = 0; k < ECAL_TAIL_SLOTS; k++) ctx->tail_seen[k] = 0xFFFFFFFFu;
+    } else {   // no mapped host memory: every tier every time
+        if (ctx->tail_seen) (void) hipHostFree(ctx->tail_seen);
+        ctx->tail_seen = ctx->tail_seen_dev = nullptr;
+        (void) hipGetLastError();
+    }
     *out = ctx;
     return ECAL_OK;
 }
@@ -114,6 +123,7 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     }
     (void) ecal_comm_destroy(ctx);
     if (ctx->calib_pinned) (void) hipHostFree(ctx->calib_pinned);
+    if (ctx->tail_seen) (void) hipHostFree(ctx->tail_seen);
     if (ctx->copy_stream) (void) hipStreamDestroy(ctx->copy_stream);
     for (auto &c : ctx->zero_rings)
         if (c.ptr) (void) hipFree(c.ptr);
@@ -126,6 +136,14 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     }
     for (ecal_devbuf *b : ctx->all_bufs()) release(*b);
     delete ctx;
+}
+
+extern "C" int ecal_set_tail_mode(ecal_ctx *ctx, int mode) {
+    if (!ctx || mode < ECAL_TAIL_AUTO || mode > ECAL_TAIL_LEAN) return ECAL_ERR_INVALID;
+    ctx->tail_mode = mode;
+    if (ctx->tail_seen)   // what earlier calls saw says nothing about the calls to come in the new mode
+        for (int k = 0; k < ECAL_TAIL_SLOTS; k++) ctx->tail_seen[k] = 0xFFFFFFFFu;
+    return ECAL_OK;
 }
 
 extern "C" int ecal_sync(ecal_ctx *ctx) {

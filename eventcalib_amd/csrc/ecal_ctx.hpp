@@ -25,6 +25,8 @@ struct ecal_ctx {
     ecal_devbuf in_xy, in_off, in_cnt, out_labels, out_ncl;  // staging for the host-pointer API
     ecal_devbuf big_slot, big_anc, big_cur, big_inv, big_cs, big_flags;    // global-scratch tier of DBSCAN
     ecal_devbuf pxs_todo;  // same for the pixel slicer
+    ecal_devbuf wb_status;  // ecal_window_bounds_dev: one word per workgroup of the look-back scan
+    uint32_t wb_epoch = 0;  // ... and the number of the call that wrote it
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
     ecal_devbuf sort_scratch;  // ecal_sort_events_dev: keys, indices, radix-sort workspace
@@ -66,10 +68,17 @@ struct ecal_ctx {
         uint32_t pos = 0;
         bool used = false;
     } zero_rings[4];
+    // The later size tiers of a stage ("tails") normally find their to-do lists empty, and an empty launch still costs ~5 us:
+    // 20 of them were 0.1 ms of every pass.  tail_seen = pinned host words into which the last kernel of a stage writes the
+    // list counts it saw; when the stage's previous call saw empty lists (ECAL_TAIL_AUTO) the next call launches ONE tail
+    // kernel that takes whatever is listed through the most general tier ("lean") instead of every tier in turn.  Either way
+    // every listed window / segment is processed: the choice moves time, never results.
+    uint32_t *tail_seen = nullptr, *tail_seen_dev = nullptr;   // [ECAL_TAIL_SLOTS]; 0xFFFFFFFF = not known yet
+    int tail_mode = 0;                                         // ECAL_TAIL_AUTO / _TIERED / _LEAN (ecal_set_tail_mode)
     uint32_t n_cu = 256;  // compute units of the device (grid size of the persistent kernels)
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false, fused_attr_set = false, bfs_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
-        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
+        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &wb_status, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos, &sl_order, &sl_order_big, &bucket_tab, &sort_scratch,
                 &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &fused_def, &bfs_lists, &bfs_defer, &bfs_big, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
@@ -106,6 +115,15 @@ int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                          const ecal_packed_points *pk = nullptr);
 // reference element order: the per-pixel bucket table of the hot-path slicer, built on first use (ecal_events.hip)
 int ecal_ensure_bucket_table(ecal_ctx *ctx, hipStream_t st);
+// tail scheduling (see ecal_ctx::tail_seen): slots of the stages' lists, and "may this call run lean?"
+enum { ECAL_TAIL_SLICE = 0, ECAL_TAIL_DBSCAN = 2, ECAL_TAIL_EXTRACT = 4, ECAL_TAIL_ORDER = 6, ECAL_TAIL_SLOTS = 16 };
+inline bool ecal_tail_lean(const ecal_ctx *ctx, int first, int n) {
+    if (ctx->tail_mode == ECAL_TAIL_LEAN) return true;
+    if (ctx->tail_mode == ECAL_TAIL_TIERED || !ctx->tail_seen) return false;
+    for (int k = 0; k < n; k++)
+        if (__atomic_load_n(ctx->tail_seen + first + k, __ATOMIC_RELAXED) != 0u) return false;
+    return true;
+}
 // n <= 16 words that are zero once everything enqueued on `st` so far has run, or nullptr (more streams than rings, no memory):
 // the caller then zeroes words of its own.  They stay the caller's for the next 512 calls on that stream at least.
 uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n);

@@ -137,24 +137,11 @@ __global__ __launch_bounds__(T) void dbscan_lds_kernel(const double *__restrict_
 constexpr int BIG_T = 1024;
 
 // Segments with n > lo_excl: workspace in global scratch, indexed by the segment's point offset.
-// (the segments beyond the LDS tiers, from the to-do list the pixel passes left — all S segments without one —, walked by a
-// small grid: S workgroups of 1024 threads that find nothing to do cost tens of microseconds per call)
-__global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restrict__ xy,
-                                                           const uint32_t *__restrict__ seg_off,
-                                                           const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
-                                                           double eps, uint32_t minpts, int32_t *__restrict__ labels,
-                                                           uint32_t *__restrict__ n_clusters, uint32_t *gslot,
-                                                           uint32_t *ganc, uint32_t *gcur, uint32_t *ginv,
-                                                           double2 *gcs, uint8_t *gflags, uint32_t S,
-                                                           const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count) {
-    __shared__ uint32_t red[48];
-    __shared__ uint32_t edges[2 * EDGE_CAP];
-    const uint32_t n_work = todo ? *todo_count : S;
-  for (uint32_t kk = blockIdx.x; kk < n_work; kk += gridDim.x) {
-    __syncthreads();
-    const uint32_t s = todo ? todo[kk] : kk;
-    const uint32_t n = seg_cnt[s];
-    if (n <= lo_excl) continue;
+// one segment of any size with its workspace in global scratch, indexed by the segment's point offset
+__device__ __forceinline__ void big_segment(uint32_t s, uint32_t *red, uint32_t *edges, const double *__restrict__ xy,
+                                            const uint32_t *__restrict__ seg_off, uint32_t n, double eps, uint32_t minpts,
+                                            int32_t *__restrict__ labels, uint32_t *__restrict__ n_clusters, uint32_t *gslot, uint32_t *ganc,
+                                            uint32_t *gcur, uint32_t *ginv, double2 *gcs, uint8_t *gflags) {
     const size_t base = seg_off[s];
     DbWork<uint32_t, GeoF64> w;
     const double2 *src = reinterpret_cast<const double2 *>(xy) + base;
@@ -173,7 +160,77 @@ __global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restr
     if (nb_log > 20u) nb_log = 20u;
     const uint32_t total = dbscan_segment<BIG_T, true, uint32_t, 0, GeoF64>(w, src, n, eps, minpts, nb_log, labels + base);
     if (threadIdx.x == 0) n_clusters[s] = total;
-  }
+}
+
+// Segments with n > lo_excl: workspace in global scratch, indexed by the segment's point offset.
+// (the segments beyond the LDS tiers, from the to-do list the pixel passes left — all S segments without one —, walked by a
+// small grid: S workgroups of 1024 threads that find nothing to do cost tens of microseconds per call)
+// seen (ecal_ctx::tail_seen, optional): the last kernel of the stage records what the to-do lists held (cnt_a / cnt_b)
+__global__ __launch_bounds__(BIG_T) void dbscan_big_kernel(const double *__restrict__ xy,
+                                                           const uint32_t *__restrict__ seg_off,
+                                                           const uint32_t *__restrict__ seg_cnt, uint32_t lo_excl,
+                                                           double eps, uint32_t minpts, int32_t *__restrict__ labels,
+                                                           uint32_t *__restrict__ n_clusters, uint32_t *gslot,
+                                                           uint32_t *ganc, uint32_t *gcur, uint32_t *ginv,
+                                                           double2 *gcs, uint8_t *gflags, uint32_t S,
+                                                           const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count,
+                                                           uint32_t *seen, const uint32_t *cnt_a, const uint32_t *cnt_b) {
+    __shared__ uint32_t red[48];
+    __shared__ uint32_t edges[2 * EDGE_CAP];
+    const uint32_t n_work = todo ? *todo_count : S;
+    if (seen && blockIdx.x == 0 && threadIdx.x == 0) {
+        seen[0] = cnt_a ? *cnt_a : 0u;
+        seen[1] = cnt_b ? *cnt_b : 0u;
+    }
+    for (uint32_t kk = blockIdx.x; kk < n_work; kk += gridDim.x) {
+        __syncthreads();
+        const uint32_t s = todo ? todo[kk] : kk;
+        const uint32_t n = seg_cnt[s];
+        if (n <= lo_excl) continue;
+        big_segment(s, red, edges, xy, seg_off, n, eps, minpts, labels, n_clusters, gslot, ganc, gcur, ginv, gcs, gflags);
+    }
+}
+
+// The LEAN tail of the stage (ecal_ctx::tail_seen): ONE launch behind the pixel kernel that takes every listed segment — its
+// doubles written first where it exists packed only, then the 4096-point LDS tier's code (1024 threads) or, beyond that, the
+// global-scratch tier's.  What the tiered form does with six launches (second pixel pass, unpack, three LDS tiers, global
+// scratch); the list is normally empty and this is then one ~5 us launch instead of six.  Same results: every tier computes
+// the same labels (tests/test_gpu_dbscan.py compares them).
+__global__ __launch_bounds__(BIG_T) void dbscan_tail_kernel(double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
+                                                            const uint32_t *__restrict__ seg_cnt, double eps, uint32_t minpts,
+                                                            int32_t *__restrict__ labels, uint32_t *__restrict__ n_clusters,
+                                                            uint32_t *gslot, uint32_t *ganc, uint32_t *gcur, uint32_t *ginv, double2 *gcs,
+                                                            uint8_t *gflags, const uint32_t *__restrict__ todo,
+                                                            const uint32_t *__restrict__ todo_count, const uint32_t *__restrict__ xy16,
+                                                            uint32_t *__restrict__ fmt, uint32_t *seen) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using L = TierLayout<4096>;
+    const uint32_t n_work = *todo_count;
+    if (seen && blockIdx.x == 0 && threadIdx.x == 0) {
+        seen[0] = n_work;
+        seen[1] = 0u;
+    }
+    for (uint32_t kk = blockIdx.x; kk < n_work; kk += gridDim.x) {
+        __syncthreads();
+        const uint32_t s = todo[kk];
+        const uint32_t n = seg_cnt[s];
+        if (fmt && fmt[s] == 1u) {   // packed only: the general code reads doubles (ecal_packed_points; fmt 1 -> 3)
+            const uint32_t o = seg_off[s];
+            double2 *out = reinterpret_cast<double2 *>(xy) + o;
+            for (uint32_t i = threadIdx.x; i < n; i += BIG_T) {
+                const uint32_t v = xy16[o + i];
+                out[i] = make_double2((double) (int) (short) (v & 0xFFFFu), (double) (((int) v) >> 16));
+            }
+            __threadfence();
+            __syncthreads();
+            if (threadIdx.x == 0) fmt[s] = 3u;
+        }
+        if (n <= 4096u)
+            tier_segment<4096, 1024>(smem, s, xy, seg_off, seg_cnt, 0u, eps, minpts, labels, n_clusters);
+        else
+            big_segment(s, reinterpret_cast<uint32_t *>(smem + L::red_off), reinterpret_cast<uint32_t *>(smem + L::edges_off), xy, seg_off, n, eps,
+                        minpts, labels, n_clusters, gslot, ganc, gcur, ginv, gcs, gflags);
+    }
 }
 
 }  // namespace ecal
@@ -210,6 +267,8 @@ static int set_attrs(ecal_ctx *ctx) {
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP1, CAP1 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP1>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP2, CAP2 / 4>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP2>::bytes));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_tail_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP2>::bytes));
     ctx->attrs_set = true;
     return ECAL_OK;
@@ -251,7 +310,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
     hipStream_t st = (hipStream_t) stream;
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
     // (fused pass: its to-do list also holds the segments of windows the fused kernel did not slice, of any size)
-    const bool second_pass = (mx > (uint32_t) PX_CAP || ctx->fused_pass) && !getenv("ECAL_DBSCAN_NO_SECOND_PASS");  // debug switch
+    const bool second_pass_wanted = (mx > (uint32_t) PX_CAP || ctx->fused_pass) && !getenv("ECAL_DBSCAN_NO_SECOND_PASS");  // debug switch
 
     // event pixels (integer coordinates, eps < 16): the lean pixel kernel takes every segment it can and lists
     // the others; the general tiers then work that list off with a small grid (it is normally empty)
@@ -259,6 +318,10 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
     const bool pixel = px_geometry(eps, &geom) && !getenv("ECAL_DBSCAN_NO_PIXEL");
     const uint32_t *todo = nullptr, *todo_count = nullptr;
     uint32_t grid = S;
+    // lean: what the pixel kernel lists (nothing, when this stage last ran) goes to ONE tail launch (dbscan_tail_kernel) instead
+    // of the second pixel pass, the unpacking and the four general tiers (ecal_ctx::tail_seen); only without a size hint
+    const bool lean = pixel && !ctx->fused_pass && max_seg_points == 0 && ecal_tail_lean(ctx, ECAL_TAIL_DBSCAN, 2);
+    const uint32_t *cnt_a = nullptr, *cnt_b = nullptr;
     if (pixel) {
         // two to-do lists: what the first pass (<= 1024 points) leaves, and what the second (<= 2048 points) leaves of that
         if ((rc = ecal_ensure(ctx, ctx->px_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
@@ -274,6 +337,9 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
             }
         }
         const uint32_t grid2 = std::min<uint32_t>(S, (uint32_t) ECAL_PX2_WG * ctx->n_cu);
+        const bool second_pass = second_pass_wanted && !lean;
+        cnt_a = cnt;
+        cnt_b = second_pass ? cnt2 : nullptr;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC")) {
             if (!fused) hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
@@ -299,6 +365,22 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         }
         grid = S < 1024u ? S : 1024u;
     }
+    uint32_t *const seen = pixel && !ctx->fused_pass && ctx->tail_seen_dev ? ctx->tail_seen_dev + ECAL_TAIL_DBSCAN : nullptr;
+    if (lean) {
+        const size_t np = n_points;
+        if ((rc = ecal_ensure(ctx, ctx->big_slot, (2 * np + 4 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_inv, np * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_cs, np * 2 * sizeof(double)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_flags, 2 * np + 16))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_anc, 4 * np * sizeof(uint32_t)))) return rc;
+        if ((rc = ecal_ensure(ctx, ctx->big_cur, np * sizeof(uint32_t)))) return rc;
+        hipLaunchKernelGGL(dbscan_tail_kernel, dim3(S < 256u ? S : 256u), dim3(BIG_T), TierLayout<CAP2>::bytes, st, d_xy, d_seg_off, d_seg_cnt, eps,
+                           minpts, d_labels, d_n_clusters, (uint32_t *) ctx->big_slot.ptr, (uint32_t *) ctx->big_anc.ptr,
+                           (uint32_t *) ctx->big_cur.ptr, (uint32_t *) ctx->big_inv.ptr, (double2 *) ctx->big_cs.ptr,
+                           (uint8_t *) ctx->big_flags.ptr, todo, todo_count, pk ? pk->d_xy16 : nullptr, pk ? pk->d_seg_fmt : nullptr, seen);
+        ECAL_HIP_TRY(ctx, hipGetLastError());
+        return ECAL_OK;
+    }
     // the general tiers read doubles: what is left for them (everything, without the pixel kernels) is unpacked first
     if (pk && (rc = ecal_unpack_listed(ctx, pk, todo, todo_count, S, d_seg_off, d_seg_cnt, d_xy, 0, st))) return rc;
     hipLaunchKernelGGL((dbscan_lds_kernel<CAP0, CAP0 / 4>), dim3(grid), dim3(CAP0 / 4), TierLayout<CAP0>::bytes, st, d_xy,
@@ -322,7 +404,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         hipLaunchKernelGGL(dbscan_big_kernel, dim3(S < 256u ? S : 256u), dim3(BIG_T), 0, st, d_xy, d_seg_off, d_seg_cnt, (uint32_t) CAP2,
                            eps, minpts, d_labels, d_n_clusters, (uint32_t *) ctx->big_slot.ptr, (uint32_t *) ctx->big_anc.ptr,
                            (uint32_t *) ctx->big_cur.ptr, (uint32_t *) ctx->big_inv.ptr, (double2 *) ctx->big_cs.ptr,
-                           (uint8_t *) ctx->big_flags.ptr, S, todo, todo_count);
+                           (uint8_t *) ctx->big_flags.ptr, S, todo, todo_count, seen, cnt_a, cnt_b);
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;

@@ -87,28 +87,47 @@ __global__ __launch_bounds__(DET_T) void extract_list_kernel(
 
 
 // packed points: a packed window that the staged passes will not take (more points or clusters than the second pass stages)
-// reads doubles in the global path — they are written here, before the first pass.  A thread per window looks, a workgroup unpacks.
+// reads doubles in the global path — they are written here, before the first pass.  A THREAD per window looks (256 windows per
+// round of a workgroup: with a workgroup per window the look alone was a chain of 33 dependent loads per launch, 30 us of every
+// pass for windows that never turn up on the shipped configuration), the workgroup unpacks the ones found.
 __global__ __launch_bounds__(256) void unpack_unstaged_windows_kernel(uint32_t S, uint32_t pts_lim, uint32_t maxc_lim, const uint32_t *__restrict__ seg_off,
                                                                        const uint32_t *__restrict__ seg_cnt,
                                                                        const uint32_t *__restrict__ n_clusters,
                                                                        const uint32_t *__restrict__ xy16, uint32_t *__restrict__ fmt,
                                                                        double *__restrict__ xy) {
-    for (uint32_t w = blockIdx.x; w < S; w += gridDim.x) {
-        if (!(fmt[2 * w] & 1u) || fmt[2 * w] == 3u) continue;
-        const uint32_t n0 = seg_cnt[2 * w], n1 = seg_cnt[2 * w + 1];
-        const bool staged = seg_off[2 * w + 1] == seg_off[2 * w] + n0 && n0 + n1 <= pts_lim && n_clusters[2 * w] <= maxc_lim &&
-                            n_clusters[2 * w + 1] <= maxc_lim;
-        if (staged) continue;
-        for (int h = 0; h < 2; h++) {
-            const uint32_t o = seg_off[2 * w + h], n = h ? n1 : n0;
-            double2 *out = reinterpret_cast<double2 *>(xy) + o;
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-                const uint32_t v = xy16[o + i];
-                out[i] = make_double2((double) (int) (short) (v & 0xFFFFu), (double) (((int) v) >> 16));
+    __shared__ uint32_t found[256];
+    __shared__ uint32_t n_found;
+    for (uint32_t w0 = blockIdx.x * 256u; w0 < S; w0 += gridDim.x * 256u) {
+        if (threadIdx.x == 0) n_found = 0;
+        __syncthreads();
+        const uint32_t w = w0 + threadIdx.x;
+        if (w < S) {
+            const uint2 f = *reinterpret_cast<const uint2 *>(fmt + 2 * w);
+            if ((f.x & 1u) && f.x != 3u) {
+                const uint2 c = *reinterpret_cast<const uint2 *>(seg_cnt + 2 * w), o = *reinterpret_cast<const uint2 *>(seg_off + 2 * w),
+                            k = *reinterpret_cast<const uint2 *>(n_clusters + 2 * w);
+                const bool staged = o.y == o.x + c.x && c.x + c.y <= pts_lim && k.x <= maxc_lim && k.y <= maxc_lim;
+                if (!staged) found[atomicAdd(&n_found, 1u)] = w;
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) fmt[2 * w] = fmt[2 * w + 1] = 3u;
+        const uint32_t nf = n_found;
+        for (uint32_t q = 0; q < nf; q++) {
+            const uint32_t u = found[q];
+            for (int h = 0; h < 2; h++) {
+                const uint32_t o = seg_off[2 * u + h], n = seg_cnt[2 * u + h];
+                double2 *out = reinterpret_cast<double2 *>(xy) + o;
+                for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+                    const uint32_t v = xy16[o + i];
+                    out[i] = make_double2((double) (int) (short) (v & 0xFFFFu), (double) (((int) v) >> 16));
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < nf) {
+            const uint32_t u = found[threadIdx.x];
+            fmt[2 * u] = fmt[2 * u + 1] = 3u;
+        }
         __syncthreads();
     }
 }
@@ -235,7 +254,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                        (const uint32_t *) list, (const uint32_t *) cnt, d_order, d_tie_list, d_tie_count, d_tie_mark)
     const bool fit = prm.fit_circle != 0;
     if (pk && mode != 1)   // (mode 1 follows a mode-2 pass over the same windows: done there)
-        hipLaunchKernelGGL(unpack_unstaged_windows_kernel, dim3(S < 1024u ? S : 1024u), dim3(256), 0, st, S, second ? DET_LDS_PTS2 : DET_LDS_PTS,
+        hipLaunchKernelGGL(unpack_unstaged_windows_kernel, dim3((S + 255u) / 256u < 1024u ? (S + 255u) / 256u : 1024u), dim3(256), 0, st, S, second ? DET_LDS_PTS2 : DET_LDS_PTS,
                            second ? DET_LDS_MAXC2 : DET_LDS_MAXC, d_seg_off, d_seg_cnt, d_n_clusters, (const uint32_t *) pk->d_xy16,
                            pk->d_seg_fmt, const_cast<double *>(d_xy));
     if (fused && !fit) {

@@ -81,6 +81,92 @@ __global__ void window_bounds_kernel(const uint8_t *__restrict__ rec, uint64_t n
     hi_out[s] = (uint32_t) (up < lo ? lo : up);
 }
 
+// Bounds AND slot bases in ONE launch (round 4; it used to be the search kernel above + a one-workgroup scan: 14 + 13 us per
+// pass, a dependent pair at the head of every pass): a workgroup of 256 windows searches its bounds, scans its sizes and gets
+// the sum of all earlier workgroups by a decoupled look-back — workgroup ids are handed out by a ticket, so every
+// predecessor is running or done; a workgroup first publishes its own total, then wave 0 reads the 64 predecessors' words
+// at once (value | state << 32 | epoch << 34; epoch = the call's number, so the words of earlier calls read as "not there
+// yet" and the table never has to be wiped) until it meets one that carries its inclusive prefix.
+constexpr uint32_t WB_T = 256;
+__global__ __launch_bounds__(WB_T) void window_bounds_base_kernel(const uint8_t *__restrict__ rec, uint64_t n, const double *__restrict__ t0,
+                                                                  const double *__restrict__ t1, uint32_t S, uint32_t *__restrict__ lo_out,
+                                                                  uint32_t *__restrict__ hi_out, uint32_t *__restrict__ base_out,
+                                                                  unsigned long long *status, uint32_t epoch, uint32_t *ticket) {
+    __shared__ uint32_t sh_bid, sh_prefix, wsum[WB_T / 64];
+    if (threadIdx.x == 0) sh_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t bid = sh_bid;
+    const uint32_t s = bid * WB_T + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t size = 0;
+    if (s < S) {
+        const double a0 = t0[s], a1 = t1[s];
+        double t_first = 0, t_last = 0;
+        if (n) {
+            t_first = load_f64_unaligned(rec);
+            t_last = load_f64_unaligned(rec + (n - 1) * RECORD_BYTES);
+        }
+        const uint64_t lo = bound_search<false>(rec, n, a0, t_first, t_last);   // EventFrame.cpp:14
+        uint64_t up = bound_search<true>(rec, n, a1, t_first, t_last);          // EventFrame.cpp:15
+        if (up < lo) up = lo;
+        lo_out[s] = (uint32_t) lo;
+        hi_out[s] = (uint32_t) up;
+        size = (uint32_t) (up - lo);
+    }
+    uint32_t inc = size;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < (int) (WB_T / 64); w++) {
+        const uint32_t x = wsum[w];
+        if (w < wave) pre += x;
+        total += x;
+    }
+    const unsigned long long tag = (unsigned long long) epoch << 34;
+    if (wave == 0) {
+        uint32_t before = 0;
+        if (bid == 0) {
+            if (lane == 0) __hip_atomic_store(status, tag | (2ull << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(status + bid, tag | (1ull << 32) | total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t top = (int64_t) bid - 1;            // the nearest predecessor not yet accounted for
+            for (;;) {
+                const int64_t j = top - lane;
+                unsigned long long w = 0;
+                if (j >= 0) w = __hip_atomic_load(status + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const bool there = j < 0 || (w >> 34) == epoch;
+                const uint32_t state = there && j >= 0 ? (uint32_t) (w >> 32) & 3u : 0u;
+                const unsigned long long incl = __ballot(state == 2u), miss = __ballot(!there);
+                // lanes below the first inclusive word (or all 64) must be there
+                const int first_incl = incl ? __builtin_ctzll(incl) : 64;
+                const unsigned long long need = first_incl >= 63 ? ~0ull : ((2ull << first_incl) - 1ull);
+                if (miss & need) {
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                uint32_t v = (j >= 0 && lane <= first_incl) ? (uint32_t) w : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                before += v;
+                if (incl || top - 64 < 0) break;
+                top -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(status + bid, tag | (2ull << 32) | (before + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) sh_prefix = before;
+    }
+    __syncthreads();
+    const uint32_t b0 = sh_prefix + pre + inc - size;
+    if (s < S) base_out[s] = b0;
+    if (s == S - 1) base_out[S] = b0 + size;
+}
+
 // exclusive scan of (hi - lo) over the windows; base[S] = total.  One block (S is small, <= ~1e6), four windows per thread
 // and round in 16-byte accesses: the rounds are a dependent chain of global loads and barriers, so there should be few of
 // them (eight per thread in 4-byte accesses was slower than one: 46 against 33 us at 33 334 windows).
@@ -338,10 +424,10 @@ __device__ __forceinline__ void slice_window(const SliceWork<Idx> wk, const uint
     for (uint32_t k = tid; k < n; k += T) {
         const uint32_t r = rep[k];
         if (r & ERASED) {
-            event_point[k] = -1;
+            if (event_point) event_point[k] = -1;
         } else {
             const uint32_t at = pos[r];
-            event_point[k] = (int32_t) at;
+            if (event_point) event_point[k] = (int32_t) at;
             if (r == k) {
                 double2 p;
                 if (!GLOBAL && reforder) {   // (the LDS tiers' point buffer served the order pass)
@@ -445,7 +531,7 @@ __device__ __forceinline__ void slice_tier_window(unsigned char *smem, uint32_t 
         unsigned char *o = order_scratch + (size_t) blockIdx.x * order_scratch_bytes(CAP);
         order_scratch_carve(o, CAP, &ord, &evk);
     }
-    slice_window<T, false, uint16_t>(w, rec, lo, n, Log2c<NB>::value, xy_out + 2 * (size_t) base, event_point + base,
+    slice_window<T, false, uint16_t>(w, rec, lo, n, Log2c<NB>::value, xy_out + 2 * (size_t) base, event_point ? event_point + base : nullptr,
                                      &nP, &nN, order_scratch ? &ord : nullptr, evk);
     if (threadIdx.x == 0) {
         seg_off[2 * s] = base;
@@ -625,14 +711,14 @@ __global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__res
     if (ECAL_SL_STOP == 4) return;
     // f. outputs: positives first, then negatives (canonical order = first occurrence)
     double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
-    int32_t *ep = event_point + base;
+    int32_t *ep = event_point ? event_point + base : nullptr;
     for (uint32_t k = tid; k < n; k += T) {
         const uint32_t r = rep[k];
         if (r == NONE) {
-            ep[k] = -1;
+            if (ep) ep[k] = -1;
         } else {
             const uint32_t at = pos[r];
-            ep[k] = (int32_t) at;
+            if (ep) ep[k] = (int32_t) at;
             if (r == k) {
                 const uint32_t p = key[k];
                 double2 v;
@@ -775,7 +861,7 @@ __device__ __forceinline__ void slice_big_window(const uint32_t s, unsigned long
         evk += base;
         ord.fa += (size_t) base * 9 / 4 + 16 * (size_t) s;
     }
-    slice_window<SLICE_BIG_T, true, uint32_t>(w, rec, lo, n, nb_log, xy_out + 2 * (size_t) base, event_point + base, &nP,
+    slice_window<SLICE_BIG_T, true, uint32_t>(w, rec, lo, n, nb_log, xy_out + 2 * (size_t) base, event_point ? event_point + base : nullptr, &nP,
                                               &nN, order_scratch ? &ord : nullptr, evk);
     if (threadIdx.x == 0) {
         seg_off[2 * s] = base;
@@ -793,9 +879,15 @@ __global__ __launch_bounds__(SLICE_BIG_T) void slice_big_kernel(
     const uint32_t *__restrict__ win_base, uint32_t lo_excl, uint32_t cap_points, double *__restrict__ xy_out,
     uint32_t *__restrict__ seg_off, uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
     double2 *g_pts, uint8_t *g_pol, uint32_t *g_bend, uint32_t *g_sorted, uint32_t *g_rep, uint32_t *g_pos,
-    unsigned char *order_scratch, uint32_t S, const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count) {
+    unsigned char *order_scratch, uint32_t S, const uint32_t *__restrict__ todo, const uint32_t *__restrict__ todo_count,
+    uint32_t *seen /* ecal_ctx::tail_seen: what the stage's lists held (cnt_a, cnt_b: their counters, null = none) */,
+    const uint32_t *cnt_a, const uint32_t *cnt_b) {
     __shared__ unsigned long long red64[17];
     const uint32_t n_work = todo ? *todo_count : S;
+    if (seen && blockIdx.x == 0 && threadIdx.x == 0) {
+        seen[0] = cnt_a ? *cnt_a : 0u;
+        seen[1] = cnt_b ? *cnt_b : 0u;
+    }
     for (uint32_t k = blockIdx.x; k < n_work; k += gridDim.x) {
         slice_big_window(todo ? todo[k] : k, red64, rec, win_lo, win_hi, win_base, lo_excl, cap_points, xy_out, seg_off, seg_cnt, event_point,
                          overflow, g_pts, g_pol, g_bend, g_sorted, g_rep, g_pos, order_scratch);
@@ -824,9 +916,23 @@ extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, ui
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
-    hipLaunchKernelGGL(window_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d_events, n_events, d_t0, d_t1, S,
-                       d_win_lo, d_win_hi);
-    hipLaunchKernelGGL(window_base_kernel, dim3(1), dim3(1024), 0, st, d_win_lo, d_win_hi, S, d_win_base);
+    const uint32_t n_wg = (S + WB_T - 1) / WB_T;
+    uint32_t *ticket = getenv("ECAL_BOUNDS_TWO_KERNELS") ? nullptr : ecal_zero_words(ctx, st, 1);
+    if (ticket && ctx->wb_status.cap < (size_t) n_wg * sizeof(unsigned long long)) {
+        int rc;
+        if ((rc = ecal_ensure(ctx, ctx->wb_status, (size_t) n_wg * sizeof(unsigned long long)))) return rc;
+        // fresh memory must not carry a word that reads as this call's: wipe it once, the epochs do the rest
+        ECAL_HIP_TRY(ctx, hipMemsetAsync(ctx->wb_status.ptr, 0, ctx->wb_status.cap, st));
+    }
+    if (ticket) {
+        ctx->wb_epoch = (ctx->wb_epoch % 0x3FFFFFFFu) + 1u;       // 1 .. 2^30 - 1, never the wiped table's 0
+        hipLaunchKernelGGL(window_bounds_base_kernel, dim3(n_wg), dim3(WB_T), 0, st, d_events, n_events, d_t0, d_t1, S, d_win_lo, d_win_hi,
+                           d_win_base, (unsigned long long *) ctx->wb_status.ptr, ctx->wb_epoch, ticket);
+    } else {   // (no zeroed word to be had, or the debug switch: the search and the scan as two launches)
+        hipLaunchKernelGGL(window_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d_events, n_events, d_t0, d_t1, S,
+                           d_win_lo, d_win_hi);
+        hipLaunchKernelGGL(window_base_kernel, dim3(1), dim3(1024), 0, st, d_win_lo, d_win_hi, S, d_win_base);
+    }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }
@@ -919,7 +1025,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
     uint32_t *const xy16 = pk ? pk->d_xy16 : nullptr, *const sfmt = pk ? pk->d_seg_fmt : nullptr;
     if ((n_events && !d_events) || !d_win_lo || !d_win_hi || !d_win_base || !d_seg_off || !d_seg_cnt || !d_overflow ||
-        (cap_points && (!d_xy || !d_event_point))) {
+        (cap_points && !d_xy)) {   // (d_event_point may be null: the event -> point map is not wanted)
         ctx->last_error = "null pointer";
         return ECAL_ERR_INVALID;
     }
@@ -944,12 +1050,18 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     // (fused pass, ecal_fused.hip: the first pass has run inside the fused kernel and has filled the first to-do list)
     const bool fused = ctx->fused_pass;
     if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
-    // (packed points: every segment starts as "doubles"; the pixel kernels mark the windows they pack)
-    if (sfmt) ECAL_HIP_TRY(ctx, hipMemsetAsync(sfmt, 0, 2 * (size_t) S * sizeof(uint32_t), st));
+    // (packed points: every segment starts as "doubles"; the pixel kernels mark the windows they pack.  The hash slicers — the
+    // default — write the mark of EVERY window they look at, also of the ones they pass on: no wipe, one launch less per pass)
+    const bool hash_slicer = !getenv("ECAL_SLICE_NO_PIXEL") && (reforder || !getenv("ECAL_SLICE_SORT_KERNEL"));
+    if (sfmt && !(hash_slicer && !fused)) ECAL_HIP_TRY(ctx, hipMemsetAsync(sfmt, 0, 2 * (size_t) S * sizeof(uint32_t), st));
     const uint32_t mx = max_win_events ? max_win_events : 0xFFFFFFFFu;
     // pixel windows first; what they leave over (longer windows, non-integer coordinates) is listed for the general tiers
     const uint32_t *todo = nullptr, *todo_count = nullptr;
     uint32_t grid = S;
+    // lean: the listed windows (none, when this stage last ran) all go to the global-scratch tier, one launch behind the first
+    // pass instead of four (ecal_ctx::tail_seen); only without size hints — a caller who names its sizes gets what it asks for
+    const bool lean = hash_slicer && !fused && max_win_events == 0 && ecal_tail_lean(ctx, ECAL_TAIL_SLICE, 2);
+    const uint32_t *cnt_a = nullptr, *cnt_b = nullptr;
     if (!getenv("ECAL_SLICE_NO_PIXEL")) {
         int rc;
         if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
@@ -964,6 +1076,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         }
         todo = list;
         todo_count = cnt;
+        cnt_a = cnt;
         if (reforder || !getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)
             if (reforder) {
                 if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
@@ -975,7 +1088,8 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                 hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
                                    d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, xy16, sfmt);
             // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
-            if ((reforder || mx > PixHash<11>::CAP) && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
+            if (!lean && (reforder || mx > PixHash<11>::CAP) && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
+                cnt_b = cnt2;
                 const uint32_t grid2 = S < 768u ? S : 768u;
                 if (reforder)
                     hipLaunchKernelGGL(slice_hash_list_kernel<true>, dim3(grid2), dim3(PXH_T), H12, st, d_events, d_win_lo,
@@ -1002,10 +1116,11 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         if ((rc = ecal_ensure(ctx, ctx->sl_order, (size_t) grid * order_scratch_bytes(cap)))) return rc;
         ord_lds = (unsigned char *) ctx->sl_order.ptr;
     }
+    if (!lean)
     hipLaunchKernelGGL((slice_lds_kernel<SCAP0, 2048, 256>), dim3(grid), dim3(256), SliceLayout<SCAP0>::bytes, st, d_events,
                        d_win_lo, d_win_hi, d_win_base, 0u, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point,
                        d_overflow, S, todo, todo_count, ord_lds);
-    if (mx > (uint32_t) SCAP0)
+    if (!lean && mx > (uint32_t) SCAP0)
         hipLaunchKernelGGL((slice_lds_kernel<SCAP1, 4096, 512>), dim3(grid), dim3(512), SliceLayout<SCAP1>::bytes, st,
                            d_events, d_win_lo, d_win_hi, d_win_base, (uint32_t) SCAP0, cap_points, d_xy, d_seg_off,
                            d_seg_cnt, d_event_point, d_overflow, S, todo, todo_count, ord_lds);
@@ -1023,10 +1138,10 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
             ord_big = (unsigned char *) ctx->sl_order_big.ptr;
         }
         hipLaunchKernelGGL(slice_big_kernel, dim3(S < 256u ? S : 256u), dim3(SLICE_BIG_T), 0, st, d_events, d_win_lo, d_win_hi, d_win_base,
-                           (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
+                           lean ? 0u : (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
                            (double2 *) ctx->sl_pts.ptr, (uint8_t *) ctx->sl_pol.ptr, (uint32_t *) ctx->sl_bend.ptr,
                            (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr, ord_big, S, todo,
-                           todo_count);
+                           todo_count, hash_slicer && !fused ? ctx->tail_seen_dev + ECAL_TAIL_SLICE : nullptr, cnt_a, cnt_b);
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;

@@ -263,11 +263,15 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             seg_off[2 * s + 1] = seg_off[2 * s];
             seg_cnt[2 * s] = 0;
             seg_cnt[2 * s + 1] = 0;
+            if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;
         }
         return true;
     }
     if (n > PXH_CAP) {
-        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+        if (tid == 0) {
+            todo[atomicAdd(todo_count, 1u)] = s;
+            if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
+        }
         return false;
     }
     if ((uint64_t) base + n > cap_points) {  // caller's buffers too small: report, emit empty segments
@@ -275,6 +279,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             *overflow = 1;
             seg_off[2 * s] = seg_off[2 * s + 1] = 0;
             seg_cnt[2 * s] = seg_cnt[2 * s + 1] = 0;
+            if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;
         }
         return true;
     }
@@ -320,7 +325,10 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
     if ((tid & 63) == 0) badf[tid >> 6] = wave_bad ? 1u : 0u;   // one flag word per wave
     __syncthreads();
     if (badf[0] | badf[1] | badf[2] | badf[3]) {
-        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+        if (tid == 0) {
+            todo[atomicAdd(todo_count, 1u)] = s;
+            if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
+        }
         return false;
     }
     if (ECAL_SL_STOP == 1) return true;
@@ -456,7 +464,10 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             const uint32_t need = (EP ? (uint32_t) ref_bucket_step(EP - 1) : 0u) + (EN ? (uint32_t) ref_bucket_step(EN - 1) : 0u);
             if (need > L::FA_CAP || EP > L::MAX_EPOCHS || EN > L::MAX_EPOCHS || mP > 128u * (uint32_t) L::NI ||
                 mN > 128u * (uint32_t) L::NI) {   // more keys than the bucket tables / the pair's registers hold: next tier
-                if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+                if (tid == 0) {
+            todo[atomicAdd(todo_count, 1u)] = s;
+            if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
+        }
                 return false;
             }
         }
@@ -607,7 +618,10 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             }
             if (ECAL_RO_STOP == 4) return true;
             if (ored[10]) {
-                if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+                if (tid == 0) {
+            todo[atomicAdd(todo_count, 1u)] = s;
+            if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
+        }
                 return false;
             }
             // the erased keys drop out (EventFrame.cpp:24-32): index of a kept key = kept keys in front of it in the list
@@ -638,24 +652,31 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             __syncthreads();
     RO_MARK(13);
             const uint32_t nP = mP ? __builtin_amdgcn_readfirstlane(ored[8]) : 0u, nN = mN ? __builtin_amdgcn_readfirstlane(ored[9]) : 0u;
+            // the event -> point map is the one output that needs every event to learn its REPRESENTATIVE's index (a table
+            // by event index + a barrier); a caller that does not ask for it (event_point == nullptr) gets the points alone:
+            // a key's index is its own list position
+            const bool want_ep = event_point != nullptr;
+            if (want_ep) {
 #pragma unroll
-            for (int j = 0; j < PXH_PER; j++) {
-                if ((meta[j] & 0x5000u) == 0x4000u)   // a key, and not erased
-                    posE[meta[j] & 0xFFFu] = cur[((meta[j] & 0x2000u) ? 0u : L::NOFF) + (meta[j] >> 16)];
+                for (int j = 0; j < PXH_PER; j++) {
+                    if ((meta[j] & 0x5000u) == 0x4000u)   // a key, and not erased
+                        posE[meta[j] & 0xFFFu] = cur[((meta[j] & 0x2000u) ? 0u : L::NOFF) + (meta[j] >> 16)];
+                }
+                __syncthreads();
             }
-            __syncthreads();
     RO_MARK(14);
             double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
-            int32_t *ep = event_point + base;
+            int32_t *ep = want_ep ? event_point + base : nullptr;
 #pragma unroll
             for (int j = 0; j < PXH_PER; j++) {
                 const uint32_t k = tid + j * T;
                 if (k < n) {
                     if (meta[j] & 0x1000u) {
-                        ep[k] = -1;
-                    } else {
-                        const uint32_t at = posE[meta[j] & 0xFFFu];
-                        ep[k] = (int32_t) at;
+                        if (want_ep) ep[k] = -1;
+                    } else if (want_ep || (meta[j] & 0x4000u)) {
+                        const uint32_t at = want_ep ? posE[meta[j] & 0xFFFu]
+                                                    : (uint32_t) cur[((meta[j] & 0x2000u) ? 0u : L::NOFF) + (meta[j] >> 16)];
+                        if (want_ep) ep[k] = (int32_t) at;
                         if (meta[j] & 0x4000u) {
                             const uint32_t slot = (meta[j] & 0x2000u) ? at : nP + at;
                             if (xy16) {
@@ -724,17 +745,17 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
     if (ECAL_SL_STOP == 4) return true;
     // e. outputs: positives first, then negatives (canonical order = first occurrence)
     double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
-    int32_t *ep = event_point + base;
+    int32_t *ep = event_point ? event_point + base : nullptr;   // (null: the caller does not want the event -> point map)
 #pragma unroll
     for (int j = 0; j < PXH_PER; j++) {
         const uint32_t k = tid + j * T;
         if (k < n) {
             const uint32_t r = repk[j];
             if (r == NONE) {
-                ep[k] = -1;
+                if (ep) ep[k] = -1;
             } else {
                 const uint32_t at = pos[r];
-                ep[k] = (int32_t) at;
+                if (ep) ep[k] = (int32_t) at;
                 if (r == k) {
                     const uint32_t slot = vp[j] ? at : nP + at;
                     if (xy16) {

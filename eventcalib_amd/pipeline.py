@@ -16,7 +16,7 @@ RECORD = 25
 class DetectPipeline:
     """Buffers are sized once (grow-only) so a timed loop performs no allocation."""
 
-    def __init__(self, ctx: Context, device=None, packed=True):
+    def __init__(self, ctx: Context, device=None, packed=True, want_event_point=True):
         """packed: between the stages the points of integer-pixel windows travel as 4-byte words (ecal_packed_points) instead
         of 16-byte doubles; `xy` (positiveEvents_ / negativeEvents_ as doubles) is then written on first access.  Results are
         bit for bit the same either way."""
@@ -25,6 +25,7 @@ class DetectPipeline:
         self._cap_windows = 0
         self._cap_slots = 0
         self.packed = bool(packed)
+        self.want_event_point = bool(want_event_point)   # False: ecal_slice_events_*_dev gets d_event_point = NULL
         self._xy_stale = False
 
     @property
@@ -88,6 +89,7 @@ class DetectPipeline:
         self._ensure(S, slots)
         st = torch.cuda.current_stream(self.dev).cuda_stream
         c = self.ctx
+        ep_ptr = self.event_point.data_ptr() if self.want_event_point else 0
         c.window_bounds_dev(events.data_ptr(), n, self.t0.data_ptr(), self.t1.data_ptr(), S, self.win_lo.data_ptr(),
                             self.win_hi.data_ptr(), self.win_base.data_ptr(), st)
         self._xy_stale = False
@@ -106,7 +108,7 @@ class DetectPipeline:
             self._xy_stale = True
             c.slice_events_packed_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(), self.win_base.data_ptr(), S,
                                       max_win_events, slots, self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(),
-                                      self.event_point.data_ptr(), self.flags.data_ptr(), pk, st)
+                                      ep_ptr, self.flags.data_ptr(), pk, st)
             if slice_only:
                 return self
             c.dbscan_batch_packed_dev(self._xy.data_ptr(), self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), 2 * S, slots, max_seg_points,
@@ -130,7 +132,7 @@ class DetectPipeline:
             return self
         c.slice_events_dev(events.data_ptr(), n, self.win_lo.data_ptr(), self.win_hi.data_ptr(),
                            self.win_base.data_ptr(), S, max_win_events, slots, self._xy.data_ptr(),
-                           self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), self.event_point.data_ptr(),
+                           self.seg_off.data_ptr(), self.seg_cnt.data_ptr(), ep_ptr,
                            self.flags.data_ptr(), st)
         if slice_only:          # profiling aid: bounds + slicing only
             return self

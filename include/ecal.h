@@ -120,7 +120,9 @@ int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_t *slice_of
  *   core/utility/include/opengv2/utility/utility.hpp:38-51; libstdc++), which DBSCAN's cluster
  *   assignments depend on (insertion-order kd-tree, kdtree.cpp:128-131,169) — or first occurrence.
  *   d_event_point[win_base[s]+k] = index of event k's pixel inside its polarity's segment, or -1
- *   if the pixel was erased.  The segment arrays feed ecal_dbscan_batch_dev directly (S' = 2S).
+ *   if the pixel was erased — an output of this library's own (the reference's EventFrame keeps no such map; the
+ *   association stage uses it); d_event_point == NULL: not wanted, not written (4 bytes per event less to write,
+ *   one table phase less in the slicer).  The segment arrays feed ecal_dbscan_batch_dev directly (S' = 2S).
  *   *d_overflow = 1 if some window did not fit cap_points (its segments are then empty).
  *   max_win_events: upper bound on any window size, 0 = unknown.
  */
@@ -254,6 +256,19 @@ int ecal_extract_batch_ordered_dev(ecal_ctx *ctx, const double *d_xy, const uint
 #define ECAL_TIES_SMALLER_PID 1
 int ecal_set_median_ties(ecal_ctx *ctx, int mode);
 int ecal_get_median_ties(const ecal_ctx *ctx);
+
+/* How the stage calls (slicing, DBSCAN, extraction, member order) schedule their later size tiers.  Every stage runs a first-pass
+ * kernel that takes what the shipped configuration produces and lists the rest for tiers of growing capacity; on most data
+ * those lists stay empty, and a launch that finds its list empty still costs ~5 us (twenty of them: 0.1 ms of every pass).
+ * ECAL_TAIL_AUTO (default): a stage whose previous call on this context saw empty lists launches ONE kernel that takes
+ * whatever is listed through its most general tier; a stage that saw work launches every tier.  ECAL_TAIL_TIERED / ECAL_TAIL_LEAN
+ * force one form (tests; the adaptive search forces TIERED for its passes: its windows are second-tier work by design).
+ * The choice moves time only: every listed window is processed either way, results are bit-identical
+ * (tests/test_gpu_tail_modes.py). */
+#define ECAL_TAIL_AUTO 0
+#define ECAL_TAIL_TIERED 1
+#define ECAL_TAIL_LEAN 2
+int ecal_set_tail_mode(ecal_ctx *ctx, int mode);
 
 /* ecal_extract_batch_exact_dev: the exact extraction in one call (eps = the DBSCAN radius the labels were made with): the plain
  * pass lists the windows in which some kept cluster's median is tied in norm (a third of them on recorded-like data, all of

@@ -33,24 +33,33 @@ def _bench(nproc, extra, launcher=True):
 
 def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
     two = _bench(2, ["--solver-iters", "0", "--calib-views", "0"], launcher=False)
-    assert two["n_gpus"] == 2 and two["config"]["events_per_gpu"] == 2000000 and two["value"] > 0
+    assert two["n_gpus"] == 2 and two["config"]["events_total"] == 2000000 and two["value"] > 0 and two["failed_legs"] == []
 
 
 def test_two_ranks_match_one_rank():
     one = _bench(1, ["--p2-pieces", "40"])
     two = _bench(2, ["--p2-pieces", "40"])
-    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
-    assert two["config"]["events_per_gpu"] == one["config"]["events_per_gpu"] == 2000000     # weak scaling
-    # ... and the strong-scaling leg beside it: ONE 2 M-event stream cut into two time ranges of whole windows — together
-    # the ranks' windows cover every event of it exactly once
-    assert "strong_scaling" not in one
-    ss = two["strong_scaling"]
-    assert ss["scaling"] == "strong" and ss["events_total"] == 2000000 and ss["events_covered_by_the_ranks_windows"] == 2000000
-    assert ss["value"] > 0 and ss["windows_total"] == one["config"]["windows_per_gpu"]
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and one["failed_legs"] == [] and two["failed_legs"] == []
+    # the HEADLINE is strong scaling (BASELINE.json's metric: "on 50M-event stream @1/2/4/8 GPU"): ONE 2 M-event stream cut into
+    # two time ranges of whole windows — together the ranks' windows cover every event of it exactly once; value = the whole
+    # stream's events over the slowest rank's time (the same definition as with one rank)
+    for r in (one, two):
+        assert r["scaling"] == "strong" and r["config"]["events_total"] == 2000000
+        assert r["config"]["events_covered_by_the_ranks_windows"] == 2000000
+        assert abs(r["value"] - 2000000 * r["steps"] / (r["ms_per_step"] * 1e-3 * r["steps"]) / 1e6) < 1e-3 * r["value"]
+        assert "HBM-resident" in r["config"]["workload"] and "upload excluded" in r["config"]["workload"]
+    assert two["config"]["windows_total"] == one["config"]["windows_total"] == one["config"]["windows_per_gpu"]
+    assert two["config"]["windows_per_gpu"] == one["config"]["windows_per_gpu"] // 2 and two["config"]["events_per_gpu"] < 1_010_000
+    assert "strong_scaling" not in two and "weak_scaling" not in one
+    # ... weak scaling (one 2 M-event stream per rank) is reported beside it
+    ws = two["weak_scaling"]
+    assert ws["scaling"] == "weak" and ws["events_per_gpu"] == 2000000 and ws["value"] > 0
+    # the non-scaling part of a pass is measured (what caps strong scaling at N = 8)
+    assert one["pass_ms_fixed"]["ms"] < 0.5 * one["ms_per_step"] + 0.2
     # ... and the adaptive-window search of that stream with its pieces cut over the ranks: the keyframes and windows of the
     # single-rank search (own-piece gate, same piece count)
     p1 = [p for p in one["policy_p2"] if p.get("driver") == "device" and p.get("gate") == "own piece"][0]
-    p2 = ss["policy_p2"]
+    p2 = two["policy_p2_sharded"]
     assert p2["pieces"] == p1["pieces"] and p2["pieces_per_gpu"] <= (p1["pieces"] + 1) // 2
     assert p2["keyframes"] == p1["keyframes"] > 0 and p2["windows_evaluated"] == p1["windows_evaluated"]
     # the sharded init calibration lands on the single-rank answer (same 64 views, Schur records summed over ranks)
@@ -60,22 +69,23 @@ def test_two_ranks_match_one_rank():
     # adds the Schur records in a different order, so the count may differ by an iteration
     assert abs(c1["rms_px"] - c2["rms_px"]) < 1e-9 and abs(c1["lm_iterations"] - c2["lm_iterations"]) <= 1
     assert c1["fx_rel_err"] < 2e-3 and c2["fx_rel_err"] < 2e-3
-    # the solver's shared intrinsics move towards the truth in both layouts (start: 1 % off; 3 iterations only)
-    assert two["solver"]["intrinsics_rel_err_after"] < 8e-3 and one["solver"]["intrinsics_rel_err_after"] < 8e-3
-    assert two["solver"]["final_cost"] < two["solver"]["initial_cost"]
-    assert two["solver"]["residuals"] == 2 * one["solver"]["residuals"]
-    # distributed segments (each rank factorises its own band, 91 / 101 + N / 4 doubles exchanged) == one solver over both
-    # segments: same iterates up to the summation order
+    # M2 under two ranks: the headline is the SAME spline as with one rank, its time cut into two shards (distributed = 2)
+    s1, s2 = one["solver"], two["solver"]
+    assert s2["scaling"] == "strong" and s2["residuals"] == s1["residuals"] and s2["control_points"] == s1["control_points"]
+    assert s2["unknowns"] == s1["unknowns"] and s2["value"] > 0
+    assert s2["intrinsics_rel_err_after"] < 8e-3 and s1["intrinsics_rel_err_after"] < 8e-3
+    assert s2["final_cost"] < s2["initial_cost"]
+    tc = s2["check_vs_single_solver"]
+    assert tc["iterations"][0] == tc["iterations"][1]
+    assert tc["intrinsics_rel_diff"] < 1e-8 and tc["final_cost_rel_diff"] < 1e-9 and tc["control_points_abs_diff"] < 1e-6
+    assert s2["allreduce_doubles"]["per_jacobian_evaluation"] == 91 + 612
+    # ... beside it, one spline segment per rank (weak): distributed segments (each rank factorises its own band, 91 / 101 + N /
+    # 4 doubles exchanged) == one solver over both segments: same iterates up to the summation order
+    wk = s2["weak_segments_per_rank"]
+    assert wk["residuals"] == 2 * s1["residuals"] and wk["final_cost"] < wk["initial_cost"]
+    chk = wk["check_vs_single_solver"]
+    assert chk["iterations"][0] == chk["iterations"][1]
+    assert chk["intrinsics_rel_diff"] < 1e-8 and chk["final_cost_rel_diff"] < 1e-9 and chk["own_control_points_abs_diff"] < 1e-7
     # the ingest leg (configs[4]): the host-resident events split into one time range per rank
     assert one["ingest"]["events"] == two["ingest"]["events"] == 1000000 and two["ingest"]["events_per_gpu"] == 500000
     assert one["ingest"]["value"] > 0 and two["ingest"]["value"] > 0
-    chk = two["solver"]["check_vs_single_solver"]
-    assert chk["iterations"][0] == chk["iterations"][1]
-    assert chk["intrinsics_rel_diff"] < 1e-8 and chk["final_cost_rel_diff"] < 1e-9 and chk["own_control_points_abs_diff"] < 1e-7
-    # time shards of ONE spline (distributed = 2): the two ranks' solve == one solver over all residuals
-    ts = two["solver"]["time_sharded_spline"]
-    tc = ts["check_vs_single_solver"]
-    assert ts["residuals"] == two["solver"]["residuals"] and ts["control_points"] == two["solver"]["control_points"]
-    assert tc["iterations"][0] == tc["iterations"][1]
-    assert tc["intrinsics_rel_diff"] < 1e-8 and tc["final_cost_rel_diff"] < 1e-9 and tc["control_points_abs_diff"] < 1e-6
-    assert ts["allreduce_doubles"]["per_jacobian_evaluation"] == 91 + 612 and ts["final_cost"] < ts["initial_cost"]

@@ -366,3 +366,41 @@ def test_unsorted_stream_is_sorted_like_the_multimap(env):
     assert L.ecal_copy_dev(ctx._h, back.data_ptr(), L.ecal_stream_data(h), n * 25, None, 1) == 0
     assert np.array_equal(back.cpu().numpy().reshape(n, 25), want)
     L.ecal_stream_destroy(h)
+
+
+def test_event_point_map_is_optional():
+    """d_event_point = NULL (include/ecal.h): the event -> point map is not written, everything else comes out the same — on
+    the shipped configuration (reference order and first-occurrence order) and on windows of every tier."""
+    import torch
+    import eventcalib_amd
+    import test_gpu_fused as TF
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    try:
+        n = 800_000
+        ev = SS.make_stream(n, rate=2.0e6, device="cuda", seed=19, noise_frac=0.3)
+        rng = np.random.default_rng(5)
+        lens = rng.choice([0.0, 2e-5, 7e-4, 1.5e-3, 3e-3, 8e-3], size=200)
+        starts = 5.0 + rng.uniform(0, n / 2.0e6 - 1e-2, size=200)
+        for order in ("reference", "first"):
+            ctx.set_point_order(order)
+            snaps = []
+            for want in (True, False):
+                pipe = DetectPipeline(ctx, want_event_point=want)
+                pipe.set_windows(starts, starts + lens)
+                pipe._ensure(len(starts), 4_000_000)
+                pipe.event_point.fill_(-77)
+                pipe.run(ev, slots=4_000_000)
+                torch.cuda.synchronize()
+                assert not pipe.overflowed()
+                snaps.append((TF._snapshot(pipe, len(starts), torch), pipe.event_point.clone()))
+            (a, epa), (b, epb) = snaps
+            assert bool((epb == -77).all()) and not bool((epa == -77).all())
+            for k in a:
+                if k == "event_point":
+                    continue
+                x, y = a[k], b[k]
+                assert torch.equal(x.view(torch.int64) if x.dtype.is_floating_point else x, y.view(torch.int64) if y.dtype.is_floating_point else y), (order, k)
+    finally:
+        ctx.set_point_order("reference")
+        ctx.close()
