@@ -724,8 +724,8 @@ PieceNum: %(pieces)d
 
 
 def cpp_chain(ev, n, rate, t_start, pieces, np):
-    """The drop-in itself: tests/cpp/test_calib_chain.cpp (the reference driver's main on the C++ shims of eventcalib_amd/csrc/host,
-    argv = settings.yaml events.bin saveDir as eventCameraCalib.cpp:105-110) built with g++ against libecal.so and run on the same
+    """The drop-in itself: eventcalib_amd/unit_test_eventCameraCalib (host/event_camera_calib_main.cpp: the reference driver's main on the
+    C++ shims of eventcalib_amd/csrc/host, argv = settings.yaml events.bin saveDir as eventCameraCalib.cpp:105-110) run on the same
     stream written as a .bin file; its own per-stage seconds.  The stream is a file here, so loading and uploading it are stages
     of their own; `seconds_after_upload` is what compares with the Python chain's wall time."""
     import shutil
@@ -733,13 +733,13 @@ def cpp_chain(ev, n, rate, t_start, pieces, np):
     import tempfile
     root = os.path.dirname(os.path.abspath(__file__))
     tmp = tempfile.mkdtemp(prefix="ecal_chain_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)   # the stream: a RAM-backed file
-    bin_dir = tempfile.mkdtemp(prefix="ecal_chain_exe_")                                                   # (/dev/shm is mounted noexec)
     try:
-        exe, lib_dir = os.path.join(bin_dir, "test_calib_chain"), os.path.join(root, "eventcalib_amd")
-        cc = subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "test_calib_chain.cpp"),
-                             "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"], capture_output=True, text=True)
-        if cc.returncode != 0:
-            return {"error": "g++: " + cc.stderr[-300:]}
+        # the product's executable, built with the library (eventcalib_amd/csrc/Makefile, target `driver`)
+        exe = os.path.join(root, "eventcalib_amd", "unit_test_eventCameraCalib")
+        if not os.path.exists(exe):      # (it travels to the GPU box prebuilt, like libecal.so)
+            cc = subprocess.run(["make", "-s", "-C", os.path.join(root, "eventcalib_amd", "csrc"), "driver"], capture_output=True, text=True)
+            if cc.returncode != 0 or not os.path.exists(exe):
+                return {"error": "make driver: " + (cc.stdout + cc.stderr)[-300:]}
         ev.cpu().numpy().tofile(os.path.join(tmp, "events.bin"))
         open(os.path.join(tmp, "settings.yaml"), "w").write(CHAIN_YAML % dict(start=t_start, pieces=pieces))
         t0 = time.perf_counter()
@@ -758,7 +758,6 @@ def cpp_chain(ev, n, rate, t_start, pieces, np):
                 "note": "process start to exit incl. HIP runtime initialisation and EventContainer::loadFile (ecal_stream_create_from_file: 1.25 GB from a RAM-backed file, chunked reads overlapped with the upload)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-        shutil.rmtree(bin_dir, ignore_errors=True)
 
 
 def solver_leg(args, ctx, dev, world, rank, n_events, rate, t_start, dist, torch, np):

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                                                           const uint32_t *__restrict__ seg_off,
                                                           const double *__restrict__ cand_xyr, uint32_t rows,
                                                           uint32_t cols, double tol_frac, double tol_px, int32_t *__restrict__ order,
-                                                          uint32_t *__restrict__ found) {
+                                                          uint32_t *__restrict__ found, int debug) {
     __shared__ double px[GR_MAXC], py[GR_MAXC];
     __shared__ double e1x[GR_MAXC], e1y[GR_MAXC], e2x[GR_MAXC], e2y[GR_MAXC];  // local lattice basis per node
     __shared__ int8_t cu[GR_MAXC], cv[GR_MAXC];
@@ -89,6 +89,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     __shared__ int sh_box[4];                       // box of the visited lattice cells (match_pattern)
     __shared__ int8_t mU[GR_MAXM], mV[GR_MAXM];     // lattice coordinates of the model points relative to model point 0
     __shared__ int8_t tf_sh[4 * GR_NTF];            // the table of basis changes
+    __shared__ uint8_t sel[GR_MAXM];                // the matched candidate of every model point
     const uint32_t s = blockIdx.x, lane = threadIdx.x;
     const uint32_t n = win_info[4 * (size_t) s], M = rows * cols;
     int32_t *out = order + (size_t) s * M;
@@ -146,17 +147,38 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         }
     };
 #endif
-    const uint32_t seed = (uint32_t) (nearest(sx / n, sy / n, false, 0xFFFFFFFFu) & 0xFFu);
-    // its nearest neighbours give the walk's two steps: the nearest one, and the nearest one that is not (anti)parallel to
-    // it.  In a frontal view these are two of the four diagonal neighbours; under steep perspective some other pair of short
-    // independent lattice vectors — the foreshortened axis brings second neighbours along it in front of the diagonal ones
-    // (at 58 degrees of tilt about a diagonal the first three neighbours are a, -a, 2 a) — which the matching below allows for.
-    constexpr int GR_NB = 8;
-    uint32_t nb[GR_NB];
-    {
-        if (lane == 0) assigned[seed] = 1;
+    // Seed and basis, made robust against clutter INSIDE the pattern (round 4; spurious candidates between the circles are what
+    // the reference's primary finder absorbs by voting — findBasis clusters ALL the neighbourhood-graph edge vectors,
+    // circlesgrid.cpp:978-1044 — and what a seed or a step taken from one bad neighbour does not survive).  A lattice point
+    // inside the pattern has its neighbours in antipodal pairs: s + v and s - v are both candidates.  A spurious candidate has
+    // no such pairs, and a spurious neighbour of a true point has no antipode.  The FIRST start is the plain one, as it has
+    // always been — the candidate nearest the centroid, its nearest neighbour and the nearest one not parallel to it, both
+    // attempts —, so nothing that was found before is lost and a window that is found at once costs what it did.  When it finds
+    // no grid although there are more candidates than pattern points (clutter), a ROBUST start follows: the seed is the
+    // candidate nearest the centroid that has two independent PAIRED neighbour vectors (GR_SEEDS are looked at), its steps the
+    // plain rule's when both of those are paired, else the shortest two independent paired vectors; both attempts when the
+    // first walk places two thirds of the pattern.  Then up to two more starts from the next such seeds, first walk only.  (Measured on the 50 M-event search, 1270 pieces: five extra starts
+    // with second attempts cost 25 % of the search's time; tests/test_gpu_grid.py states the verdicts under clutter.)
+    constexpr int GR_NB = 8, GR_SEEDS = 5, GR_EXTRA = 3;
+    uint32_t seeds[GR_SEEDS];
+    int n_seeds = 0;
+    for (int st = 0; st < GR_SEEDS; st++) {   // the candidates nearest the centroid, nearest first
+        const unsigned long long rs = nearest(sx / n, sy / n, true, 0xFFFFFFFFu);
+        if (rs == ~0ull) break;
+        seeds[n_seeds++] = (uint32_t) (rs & 0xFFu);
+        if (lane == 0) assigned[seeds[st]] = 1;
         __syncthreads();
-        for (int k = 0; k < GR_NB; k++) {
+    }
+    if (lane == 0)
+        for (int q = 0; q < n_seeds; q++) assigned[seeds[q]] = 0;
+    __syncthreads();
+    if (n_seeds == 0) return;
+    // the two steps of a walk from `seed` (all candidates free on entry and on return); false: none
+    // mode 0: the first start's rule (false: the seed has no two independent paired vectors — try the next seed);
+    // mode 1: paired vectors only; mode 2: the plain rule whatever the pairs say
+    auto choose_basis = [&](uint32_t seed, int mode, double &ax, double &ay, double &bx, double &by) -> bool {
+        uint32_t nb[GR_NB];
+        for (int k = 0; k < GR_NB; k++) {   // the eight nearest neighbours, nearest first
             const unsigned long long r = nearest(px[seed], py[seed], true, seed);
             nb[k] = r == ~0ull ? seed : (uint32_t) (r & 0xFFu);
             if (lane == 0 && r != ~0ull) assigned[nb[k]] = 1;
@@ -165,29 +187,190 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         if (lane == 0)
             for (int k = 0; k < GR_NB; k++) assigned[nb[k]] = 0;
         __syncthreads();
-    }
-    double ax = px[nb[0]] - px[seed], ay = py[nb[0]] - py[seed];
-    double bx = 0, by = 0, bestperp = -1.0;
-    for (int k = 1; k < GR_NB && bestperp < 0; k++) {
-        if (nb[k] == seed) break;
-        const double dx = px[nb[k]] - px[seed], dy = py[nb[k]] - py[seed];
-        const double cr = fabs(ax * dy - ay * dx), nn = sqrt((ax * ax + ay * ay) * (dx * dx + dy * dy));
-        const double perp = nn > 0 ? cr / nn : 0.0;
-        if (perp > 0.5) {
-            bestperp = perp;
-            bx = dx;
-            by = dy;
+        // antipodal pairs: neighbour k counts when some other candidate sits at s - (p_k - s), within 0.3 of the step
+        uint32_t paired = 0;
+        if (mode != 2)
+            for (int k = 0; k < GR_NB; k++) {
+                if (nb[k] == seed) break;
+                const double vx = px[nb[k]] - px[seed], vy = py[nb[k]] - py[seed];
+                const unsigned long long r = nearest(px[seed] - vx, py[seed] - vy, false, seed);
+                if (r == ~0ull) continue;
+                const uint32_t j = (uint32_t) (r & 0xFFu);
+                const double ex = px[j] - (px[seed] - vx), ey = py[j] - (py[seed] - vy);
+                if (j != nb[k] && ex * ex + ey * ey <= 0.09 * (vx * vx + vy * vy)) paired |= 1u << k;
+            }
+        auto parallel = [&](uint32_t ka, uint32_t kb) -> bool {
+            const double ux = px[nb[ka]] - px[seed], uy = py[nb[ka]] - py[seed], dx = px[nb[kb]] - px[seed], dy = py[nb[kb]] - py[seed];
+            const double cr = fabs(ux * dy - uy * dx), nn = sqrt((ux * ux + uy * uy) * (dx * dx + dy * dy));
+            return !(nn > 0 && cr / nn > 0.5);
+        };
+        auto short_enough = [&](uint32_t ka, uint32_t kb) -> bool {   // not longer than four times the first
+            const double ux = px[nb[ka]] - px[seed], uy = py[nb[ka]] - py[seed], dx = px[nb[kb]] - px[seed], dy = py[nb[kb]] - py[seed];
+            return (dx * dx + dy * dy) < 16.0 * (ux * ux + uy * uy);
+        };
+        // the plain rule: the nearest neighbour and the FIRST one not parallel to it (too long: no lattice here)
+        int qa = -1, qb = -1;
+        if (nb[0] != seed) {
+            qa = 0;
+            for (int k = 1; k < GR_NB; k++) {
+                if (nb[k] == seed) break;
+                if (!parallel(0u, (uint32_t) k)) {
+                    if (short_enough(0u, (uint32_t) k)) qb = k;
+                    break;
+                }
+            }
+        }
+        // the paired rule: the shortest two independent paired vectors
+        int ka = -1, kb = -1;
+        for (int k = 0; k < GR_NB && kb < 0; k++) {
+            if (nb[k] == seed) break;
+            if (!((paired >> k) & 1u)) continue;
+            if (ka < 0) ka = k;
+            else if (!parallel((uint32_t) ka, (uint32_t) k) && short_enough((uint32_t) ka, (uint32_t) k)) kb = k;
+        }
+        if (mode == 2 || (mode == 0 && qb >= 0 && ((paired >> qa) & 1u) && ((paired >> qb) & 1u))) {
+            ka = qa;
+            kb = qb;
+        }
+        if (ka < 0 || kb < 0) return false;
+        ax = px[nb[ka]] - px[seed];
+        ay = py[nb[ka]] - py[seed];
+        bx = px[nb[kb]] - px[seed];
+        by = py[nb[kb]] - py[seed];
+        if (ax * by - ay * bx < 0) {  // right-handed (u, v) in image coordinates
+            bx = -bx;
+            by = -by;
+        }
+        return true;
+    };
+    bool got = false;
+    uint32_t qh = 0, qt = 0;
+    // fit_h: the homography lattice (u, v) -> image through the placed nodes (inhomogeneous DLT, 8 x 8 normal equations)
+    auto fit_h = [&]() {
+        // The normal equations of the node rows [u v 1 0 0 0 -ux -vx | x], [0 0 0 u v 1 -uy -vy | y] are made of 24 sums
+        // S(a, b, g) = sum over the nodes of u^a v^b g with a + b <= 2 and g in {1, x, y, x^2 + y^2}: a lane per sum
+        // (index 4 * m + g, m = 0..5 for u^a v^b = 1, u, v, u^2, u v, v^2), nodes in queue order.
+        if (lane < 24u) {
+            const uint32_t m = lane >> 2, g = lane & 3u;
+            double acc = 0;
+            for (uint32_t k = 0; k < qt; k++) {
+                const uint32_t j = queue[k];
+                const double u = cu[j], v = cv[j], x = px[j], y = py[j];
+                const double mono = m == 0u ? 1.0 : (m == 1u ? u : (m == 2u ? v : (m == 3u ? u * u : (m == 4u ? u * v : v * v))));
+                const double gg = g == 0u ? 1.0 : (g == 1u ? x : (g == 2u ? y : x * x + y * y));
+                acc += mono * gg;
+            }
+            hm[lane] = acc;
+        }
+        __syncthreads();
+        // row r of the 8 x 9 system in lane r's registers.  S1(p, q) = sum of t_p t_q g for t = (u, v, 1)
+        auto S = [&](uint32_t p, uint32_t q, uint32_t g) -> double {   // p, q in {0: u, 1: v, 2: 1}
+            const uint32_t lo = p < q ? p : q, hi = p < q ? q : p;
+            // (u,u) 3  (u,v) 4  (u,1) 1  (v,v) 5  (v,1) 2  (1,1) 0
+            const uint32_t m = lo == 0u ? (hi == 0u ? 3u : (hi == 1u ? 4u : 1u)) : (lo == 1u ? (hi == 1u ? 5u : 2u) : 0u);
+            return hm[4u * m + g];
+        };
+        double row[9];
+        {
+            const uint32_t r = lane & 7u;
+#pragma unroll
+            for (uint32_t c = 0; c < 9; c++) {
+                double val;
+                if (r < 3u) {          // d/dh of the x rows: t_r * [t | 0 | -t_{0,1} x | x]
+                    val = c < 3u ? S(r, c, 0) : (c < 6u ? 0.0 : (c < 8u ? -S(r, c - 6u, 1) : S(r, 2, 1)));
+                } else if (r < 6u) {   // the y rows
+                    val = c < 3u ? 0.0 : (c < 6u ? S(r - 3u, c - 3u, 0) : (c < 8u ? -S(r - 3u, c - 6u, 2) : S(r - 3u, 2, 2)));
+                } else {               // -t_{r-6} x * x row + -t_{r-6} y * y row
+                    val = c < 3u ? -S(r - 6u, c, 1) : (c < 6u ? -S(r - 6u, c - 3u, 2) : (c < 8u ? S(r - 6u, c - 6u, 3) : -S(r - 6u, 2, 3)));
+                }
+                row[c] = val;
+            }
+        }
+        // Gaussian elimination with partial pivoting on the eight lanes' registers: the pivot row of a column is the unused
+        // row with the largest entry (the first such in row order), broadcast with v_readlane; no row is moved
+        auto bcast = [](double v, uint32_t src) -> double {
+            const long long b = __double_as_longlong(v);
+            const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b, (int) src);
+            const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (b >> 32), (int) src);
+            return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+        };
+        uint32_t used = 0, perm[8];
+        bool okh = true;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            uint32_t piv = 0xFFFFFFFFu;
+            double best = -1.0;
+#pragma unroll
+            for (uint32_t r = 0; r < 8; r++) {
+                const double v = fabs(bcast(row[c], r));
+                const bool take = !((used >> r) & 1u) && v > best;
+                best = take ? v : best;
+                piv = take ? r : piv;
+            }
+            if (!(best > 1e-12)) okh = false;
+            piv = okh ? piv : 0u;
+            perm[c] = piv;
+            used |= 1u << piv;
+            const double pc = bcast(row[c], piv);
+            const bool mine = lane < 8u && !((used >> lane) & 1u);
+            const double f = row[c] / pc;
+#pragma unroll
+            for (int k = c; k < 9; k++) {
+                const double pk = bcast(row[k], piv);
+                row[k] = mine ? row[k] - f * pk : row[k];
+            }
+        }
+        double x[8];
+#pragma unroll
+        for (int c = 7; c >= 0; c--) {
+            double t = row[8];
+#pragma unroll
+            for (int k = c + 1; k < 8; k++) t -= row[k] * x[k];
+            x[c] = bcast(t / row[c], perm[c]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) hh[c] = okh ? x[c] : NAN;
+        }
+        __syncthreads();
+    };
+    auto fit_all = [&]() { fit_h(); };
+    auto nearest_any = [&](double qx, double qy) -> unsigned long long { return nearest(qx, qy, false, 0xFFFFFFFFu); };
+    int seed_at = 0;   // the next seed to look at
+#pragma nounroll
+    for (int start = 0; start <= GR_EXTRA && !got; start++) {
+    if (start > 0 && n <= M) break;   // (exactly the pattern's count of candidates: no clutter to have misled the first start)
+    uint32_t seed = seeds[0];
+    double ax = 0, ay = 0, bx = 0, by = 0;
+    bool have = false;
+    if (start == 0) {          // the plain start, as it has always been: nothing that was found before round 4 is lost
+        have = choose_basis(seed, 2, ax, ay, bx, by);
+    } else if (start == 1) {   // the robust start: the first seed with two independent paired vectors, plain steps if THEY are paired
+        for (int q = 0; q < n_seeds && !have; q++) {
+            seed = seeds[q];
+            have = choose_basis(seed, 0, ax, ay, bx, by);
+            seed_at = q + 1;
+        }
+    } else {                   // the next seeds, paired steps
+        while (seed_at < n_seeds && !have) {
+            seed = seeds[seed_at++];
+            have = choose_basis(seed, 1, ax, ay, bx, by);
         }
     }
-    const double la = sqrt(ax * ax + ay * ay), lb = sqrt(bx * bx + by * by);
-    if (!(bestperp > 0.5) || !(lb < 4.0 * la)) return;  // no usable lattice around the seed
-    if (ax * by - ay * bx < 0) {  // right-handed (u, v) in image coordinates
-        bx = -bx;
-        by = -by;
+    if (!have) {
+        if (debug && lane == 0) out[8 + start] = -1000;
+        if (start == 0) continue;
+        break;
+    }
+    if (start > 0) {   // the previous start's walk is wiped
+        for (uint32_t i = lane; i < n; i += GR_T) assigned[i] = 0;
+        for (uint32_t k = lane; k < GR_L * GR_L; k += GR_T) occ[k] = 0;
+        __syncthreads();
     }
     GR_MARK(0);   // seed + basis
     // breadth-first walk
-    uint32_t qh = 0, qt = 0;
+    qh = 0;
+    qt = 0;
     if (lane == 0) {
         assigned[seed] = 1;
         cu[seed] = 0;
@@ -309,107 +492,20 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             for (uint32_t m = lane; m < M; m += GR_T) {
                 const int u = cu[win_anchor] + a * mU[m] + b * mV[m], v = cv[win_anchor] + c * mU[m] + d * mV[m];
                 out[m] = (int32_t) occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1;
+                sel[m] = (uint8_t) (occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1);
             }
         }
         return true;
 
     };
-    bool got = match_pattern();
+    got = match_pattern();
     GR_MARK(2);   // first match
-    if (!got && qt >= 4u) {
+    // (the robust start gets its second attempt only when its first walk looks like the pattern's lattice: two thirds placed)
+    if (!got && qt >= 4u && (start == 0 || (start == 1 && 3u * qt >= 2u * M))) {
         // Second attempt, as cv::findCirclesGrid's (cv_calib.cpp:34-84: the holes found so far give a homography,
         // CirclesGridFinder::rectifyGrid, and the search runs again on the rectified points).  Under steep perspective the
         // first walk's local steps drift and a step can land on the wrong neighbour (the foreshortened lattice has
         // neighbours closer than a step's prediction error); a homography's predictions are exact under perspective.
-        // fit_h: the homography lattice (u, v) -> image through the placed nodes (inhomogeneous DLT, 8 x 8 normal equations)
-        auto fit_h = [&]() {
-            // The normal equations of the node rows [u v 1 0 0 0 -ux -vx | x], [0 0 0 u v 1 -uy -vy | y] are made of 24 sums
-            // S(a, b, g) = sum over the nodes of u^a v^b g with a + b <= 2 and g in {1, x, y, x^2 + y^2}: a lane per sum
-            // (index 4 * m + g, m = 0..5 for u^a v^b = 1, u, v, u^2, u v, v^2), nodes in queue order.
-            if (lane < 24u) {
-                const uint32_t m = lane >> 2, g = lane & 3u;
-                double acc = 0;
-                for (uint32_t k = 0; k < qt; k++) {
-                    const uint32_t j = queue[k];
-                    const double u = cu[j], v = cv[j], x = px[j], y = py[j];
-                    const double mono = m == 0u ? 1.0 : (m == 1u ? u : (m == 2u ? v : (m == 3u ? u * u : (m == 4u ? u * v : v * v))));
-                    const double gg = g == 0u ? 1.0 : (g == 1u ? x : (g == 2u ? y : x * x + y * y));
-                    acc += mono * gg;
-                }
-                hm[lane] = acc;
-            }
-            __syncthreads();
-            // row r of the 8 x 9 system in lane r's registers.  S1(p, q) = sum of t_p t_q g for t = (u, v, 1)
-            auto S = [&](uint32_t p, uint32_t q, uint32_t g) -> double {   // p, q in {0: u, 1: v, 2: 1}
-                const uint32_t lo = p < q ? p : q, hi = p < q ? q : p;
-                // (u,u) 3  (u,v) 4  (u,1) 1  (v,v) 5  (v,1) 2  (1,1) 0
-                const uint32_t m = lo == 0u ? (hi == 0u ? 3u : (hi == 1u ? 4u : 1u)) : (lo == 1u ? (hi == 1u ? 5u : 2u) : 0u);
-                return hm[4u * m + g];
-            };
-            double row[9];
-            {
-                const uint32_t r = lane & 7u;
-#pragma unroll
-                for (uint32_t c = 0; c < 9; c++) {
-                    double val;
-                    if (r < 3u) {          // d/dh of the x rows: t_r * [t | 0 | -t_{0,1} x | x]
-                        val = c < 3u ? S(r, c, 0) : (c < 6u ? 0.0 : (c < 8u ? -S(r, c - 6u, 1) : S(r, 2, 1)));
-                    } else if (r < 6u) {   // the y rows
-                        val = c < 3u ? 0.0 : (c < 6u ? S(r - 3u, c - 3u, 0) : (c < 8u ? -S(r - 3u, c - 6u, 2) : S(r - 3u, 2, 2)));
-                    } else {               // -t_{r-6} x * x row + -t_{r-6} y * y row
-                        val = c < 3u ? -S(r - 6u, c, 1) : (c < 6u ? -S(r - 6u, c - 3u, 2) : (c < 8u ? S(r - 6u, c - 6u, 3) : -S(r - 6u, 2, 3)));
-                    }
-                    row[c] = val;
-                }
-            }
-            // Gaussian elimination with partial pivoting on the eight lanes' registers: the pivot row of a column is the unused
-            // row with the largest entry (the first such in row order), broadcast with v_readlane; no row is moved
-            auto bcast = [](double v, uint32_t src) -> double {
-                const long long b = __double_as_longlong(v);
-                const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b, (int) src);
-                const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (b >> 32), (int) src);
-                return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
-            };
-            uint32_t used = 0, perm[8];
-            bool okh = true;
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                uint32_t piv = 0xFFFFFFFFu;
-                double best = -1.0;
-#pragma unroll
-                for (uint32_t r = 0; r < 8; r++) {
-                    const double v = fabs(bcast(row[c], r));
-                    const bool take = !((used >> r) & 1u) && v > best;
-                    best = take ? v : best;
-                    piv = take ? r : piv;
-                }
-                if (!(best > 1e-12)) okh = false;
-                piv = okh ? piv : 0u;
-                perm[c] = piv;
-                used |= 1u << piv;
-                const double pc = bcast(row[c], piv);
-                const bool mine = lane < 8u && !((used >> lane) & 1u);
-                const double f = row[c] / pc;
-#pragma unroll
-                for (int k = c; k < 9; k++) {
-                    const double pk = bcast(row[k], piv);
-                    row[k] = mine ? row[k] - f * pk : row[k];
-                }
-            }
-            double x[8];
-#pragma unroll
-            for (int c = 7; c >= 0; c--) {
-                double t = row[8];
-#pragma unroll
-                for (int k = c + 1; k < 8; k++) t -= row[k] * x[k];
-                x[c] = bcast(t / row[c], perm[c]);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; c++) hh[c] = okh ? x[c] : NAN;
-            }
-            __syncthreads();
-        };
         // Only the seed's 3 x 3 neighbourhood of the first walk is kept (a step of that walk may have landed on the wrong
         // neighbour) and the walk is redone ring by ring with the homography's predictions, refitted after every ring.
         // (Keeping a first walk whose nodes all lie near one homography instead was measured: at 2 px it is 4 walks in 18 000 —
@@ -528,10 +624,74 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             GR_MARK(6);   // matches after sweeps
         }
     }
+    if (debug && !got && lane == 0) out[8 + start] = -2000 - (int32_t) qt;   // (ECAL_GRID_DEBUG: nodes placed by a start that failed)
+    }   // (starts)
 #ifdef ECAL_PHASE_PROF
     gr_done__(qt);
 #endif
     if (!got) return;
+    // The holes, as the reference takes them: CirclesEventFrame.cpp:340-353 looks up the candidate nearest to every centre the
+    // finder returns, and the finder's centres under clutter are the keypoints nearest the positions its basis predicts.  Here:
+    // the homography model lattice -> image through the 36 matched candidates, refitted without the six worst (a hole a spurious
+    // candidate took during the walk — its step predictions drift, a spurious point can be the nearer one — is among them),
+    // and every model point takes the candidate nearest to its prediction; twice.  Without clutter nothing changes.
+    for (int it = 0; it < 2; it++) {
+        __syncthreads();
+        if (lane == 0) {
+            for (uint32_t m = 0; m < M; m++) {
+                const uint32_t j = sel[m];
+                queue[m] = (uint8_t) j;
+                cu[j] = mU[m];
+                cv[j] = mV[m];
+            }
+        }
+        qt = M;
+        __syncthreads();
+        fit_all();
+        if (!(hh[0] == hh[0])) break;
+        // residuals; the M - 6 best stay in the fit
+        double *const res = e2x;   // [M] (the walk's step vectors are dead)
+        for (uint32_t m = lane; m < M; m += GR_T) {
+            const uint32_t j = sel[m];
+            const double u = mU[m], v = mV[m], wq = hh[6] * u + hh[7] * v + 1.0;
+            const double dx = (hh[0] * u + hh[1] * v + hh[2]) / wq - px[j], dy = (hh[3] * u + hh[4] * v + hh[5]) / wq - py[j];
+            res[m] = dx * dx + dy * dy;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t keep = 0;
+            for (uint32_t m = 0; m < M; m++) {
+                uint32_t worse = 0;   // model points with a larger residual (ties: larger index)
+                for (uint32_t q = 0; q < M; q++) worse += (res[q] > res[m] || (res[q] == res[m] && q > m)) ? 1u : 0u;
+                if (worse >= 6u || M <= 12u) queue[keep++] = sel[m];
+            }
+            sh_qt = keep;
+        }
+        __syncthreads();
+        qt = sh_qt;
+        fit_all();
+        if (!(hh[0] == hh[0])) break;
+        // nearest candidates to the predictions; taken only when they are M distinct candidates
+        uint8_t *const pick = assigned;   // [M] (dead too)
+        bool distinct = true;
+        for (uint32_t m = 0; m < M; m++) {
+            const double u = mU[m], v = mV[m], wq = hh[6] * u + hh[7] * v + 1.0;
+            const unsigned long long r = nearest_any((hh[0] * u + hh[1] * v + hh[2]) / wq, (hh[3] * u + hh[4] * v + hh[5]) / wq);
+            if (lane == 0) pick[m] = (uint8_t) (r & 0xFFu);
+        }
+        __syncthreads();
+        for (uint32_t m = lane; m < M; m += GR_T)
+            for (uint32_t q = 0; q < m; q++)
+                if (pick[q] == pick[m]) distinct = false;
+        if (__ballot(!distinct) != 0ull) break;
+        bool changed = false;
+        for (uint32_t m = lane; m < M; m += GR_T) {
+            changed = changed || sel[m] != pick[m];
+            sel[m] = pick[m];
+            out[m] = (int32_t) pick[m];
+        }
+        if (__ballot(changed) == 0ull) break;
+    }
     if (lane == 0) found[s] = 1;
 }
 
@@ -552,7 +712,7 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
     const char *tol_env = getenv("ECAL_GRID_TOL_PX");   // debug switch (tests of the tolerance's effect); default = the reference's 20 px
     const double tol_px = tol_env ? atof(tol_env) : 20.0;
     hipLaunchKernelGGL(grid_order_kernel, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
-                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found);
+                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, getenv("ECAL_GRID_DEBUG") ? 1 : 0);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

@@ -5,7 +5,8 @@
 // compiles unchanged against this header.  What differs, and is documented in INTEGRATION.md:
 //   * only dim == 2 runs on the GPU path (the one the reference uses); other dims return FAILED;
 //   * Clusters[c] lists its members in the reference's order (expandCluster's pop order, ecal_cluster_order) for inputs of up
-//     to 4096 points with at most 64 points per eps-ball; beyond that in ascending pid (membership and numbering are
+//     to 2^20 points (the member-order kernel's global-scratch tier, whose range-query arena holds 2^24 entries); only
+//     beyond that — ecal_cluster_order reports status 1 for the input — in ascending pid (membership and numbering are
 //     identical, bit for bit, either way);
 //   * the distance-function argument is accepted and ignored (as in the reference's kd-tree build,
 //     where it is only used under BRUTEFORCE, dbscan.h:64,203-206).

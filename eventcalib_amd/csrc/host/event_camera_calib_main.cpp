@@ -1,13 +1,14 @@
-// The reference driver's main (event_camera_calib/test/eventCameraCalib.cpp:99-233) on the C++ shims:
+// unit_test_eventCameraCalib: the reference driver's main (event_camera_calib/test/eventCameraCalib.cpp:99-233) on the C++ shims:
 // stream -> container -> keyframe search -> EventCalibIni::cvCalibration (+ rectifyFeatures per keyframe) ->
-// EventCalibSpline -> TrajectoryByEvent.txt.  Built and run by tests/test_gpu_shims.py.
-//   usage: test_calib_chain settings.yaml events.bin saveDir [batch]     (the reference's argv, eventCameraCalib.cpp:105-110)
+// EventCalibSpline -> TrajectoryByEvent.txt.  Built by eventcalib_amd/csrc/Makefile (`make driver`, part of `all`) into
+// eventcalib_amd/unit_test_eventCameraCalib next to libecal.so; run by tests/test_gpu_shims.py and bench.py's end_to_end leg.
+//   usage: unit_test_eventCameraCalib settings.yaml events.bin saveDir [batch]     (the reference's argv, eventCameraCalib.cpp:105-110)
 // "batch": rectifyFeatures of all keyframes in one device pass (ecal_rectify_keyframes) instead of one CirclesEventFrame per
 // keyframe, the file read in one piece, and a "stage <name> <seconds>" line per stage of the chain (bench.py's end_to_end leg).
 #include <chrono>
 #include <cstdio>
 
-#include "../../eventcalib_amd/csrc/host/event_calib_spline.hpp"
+#include "event_calib_spline.hpp"
 
 int main(int argc, char **argv) {
     using namespace opengv2;
@@ -21,7 +22,7 @@ int main(int argc, char **argv) {
     };
     t_mark = now();
     if (argc != 4 && !batch) {
-        std::fprintf(stderr, "Usage: test_calib_chain settingFilePath binFilePath SavePath\n");
+        std::fprintf(stderr, "Usage: unit_test_eventCameraCalib settingFilePath binFilePath SavePath\n");
         return 1;
     }
     FileSettings fsSettings(argv[1]);                        // :114-118

@@ -123,10 +123,10 @@ def test_cpp_driver_chain(tmp_path):
     import torch
     import eventcalib_amd
     from eventcalib_amd.calibrate import calibrate_stream
-    exe = str(tmp_path / "test_calib_chain")
-    lib_dir = os.path.join(ROOT, "eventcalib_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_calib_chain.cpp"),
-                           "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"])
+    # the product's executable (eventcalib_amd/csrc/Makefile, target `driver`): built with the library, in-tree
+    exe = os.path.join(ROOT, "eventcalib_amd", "unit_test_eventCameraCalib")
+    if not os.path.exists(exe):      # (it travels to the GPU box prebuilt, like libecal.so)
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "eventcalib_amd", "csrc"), "driver"])
     SS.TRAJECTORY = "orbit"
     try:
         n = 2_000_000

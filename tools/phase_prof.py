@@ -25,14 +25,19 @@ L.ecal_debug_phase_cycles(buf, 1)
 pipe.run(ev, max_win_events=2000, max_seg_points=1000); torch.cuda.synchronize()
 L.ecal_debug_phase_cycles(buf, 1)
 v = list(buf); wg = max(v[10], 1)
-names = ["B kd-bounds", "C cell sort / bitmap build", "D count", "E labels (grid E.1 + E.2/3)", "F rank", "bitmap ranks", "bitmap E.1"]
-tot = sum(v[:7]) + v[12] + v[13] + v[14]
-for i, nm in enumerate(names):
-    print("%-28s %10.0f cycles/WG  %5.1f %%" % (nm, v[i] / wg, 100.0 * v[i] / tot))
-print("B split: init+B.0 %.0f  B.1 %.0f  B.2 %.0f  (rest = anc/flags)" % (v[12]/wg, v[13]/wg, v[14]/wg))
-print("D: candidate visits/WG %.0f (per point %.1f)   wave-steps/WG %.0f (x64 = %.0f lane slots)" % (v[12]/wg, v[12]/wg/578.0, v[13]/wg, 64*v[13]/wg))
-print("levels/WG %.1f  sweeps/WG %.2f  WGs %d  total cycles/WG %.0f" % (v[8] / wg, v[9] / wg, wg, tot / wg))
-print("pixel kernel: count/offset loads %.0f  points arrive %.0f  bbox + first barriers %.0f   (then init+B.0 %.0f)" % (v[7] / wg, v[9] / wg, v[15] / wg, v[12] / wg))
+# marks of dbscan_pixel.hpp (thread 0 of every workgroup, shader-clock cycles between the marks, summed over the launch's workgroups)
+rows = [(7, "A   scalar loads: segment count + offset"), (9, "A   own points arrive (global -> registers)"),
+        (12, "A+B.0  bbox, fits vote, wave 0 replays 64 inserts (incl. waiting for the slowest wave's points)"),
+        (13, "B.1 walks of the top tree + first bids (2 barriers)"), (14, "B.2 level-synchronous bidding (1 barrier per level)"),
+        (1, "bitmap clear + set (2 barriers)"), (5, "raster ranks: row prefix, block scan, rank table (4 barriers)"),
+        (2, "D   core test (1 barrier)"), (6, "E.1 union-find over the half disc (1 barrier)"),
+        (3, "E.2/3 flatten + one-way edges"), (4, "F   seed ranks + labels out (2 barriers)")]
+tot = sum(v[i] for i, _ in rows) + v[0]
+print("dbscan_pixel_kernel<16, 768>: cycles per workgroup (= per segment), %d workgroups" % wg)
+for i, nm in rows:
+    print("  %-100s %9.0f  %5.1f %%" % (nm, v[i] / wg, 100.0 * v[i] / tot))
+print("  total %.0f cycles/WG; tree levels below the top tree %.1f per WG; one-way edges %.3f per WG" % (tot / wg, v[8] / wg, v[11] / wg))
+print("  barriers per workgroup: 17 + levels = %.0f; longest dependent chain: B.2 (per level: LDS read -> compare -> ds_min -> barrier)" % (17 + v[8] / wg))
 d = (ctypes.c_ulonglong * 16)()
 L.ecal_debug_det_cycles(d, 0)
 d = list(d); dw = max(d[8], 1) / 2      # two timed runs accumulated? (reset only DBSCAN's) -> per call counts included
