@@ -50,7 +50,8 @@ def orientation_gate(ref_feat, ref_t, cur_feat, cur_t, rows, cols, motion_time_s
     """EventCalibIni::track's test for n frame pairs: median angle between corresponding pattern rows divided by the
     time distance below (5e-4 pi) / MotionTimeStep rad/s."""
     a, b = _row_directions(ref_feat, rows, cols), _row_directions(cur_feat, rows, cols)
-    c = (a * b).sum(axis=2) / (np.linalg.norm(a, axis=2) * np.linalg.norm(b, axis=2))
+    # Eigen's norm(): sqrt of the plain sum of squares (np.linalg.norm may scale; one ulp decides 0 against NaN below)
+    c = (a * b).sum(axis=2) / (np.sqrt(a[..., 0] * a[..., 0] + a[..., 1] * a[..., 1]) * np.sqrt(b[..., 0] * b[..., 0] + b[..., 1] * b[..., 1]))
     with np.errstate(invalid="ignore"):
         theta = np.arccos(c)         # (not clamped, as the reference: a cosine rounded above 1 gives NaN)
         med = _nth_element_median(theta)
@@ -171,11 +172,12 @@ def _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold
         except capi.EcalError as err:
             if err.status != -6:
                 raise
-            # double only what was short: the message names it (the keyframe count comes back with the error)
-            if "max_keyframes" in str(err):
+            # double only what was short: the call hands back the keyframe count with the error, and a count beyond the
+            # capacity is what "max_keyframes too small" means (no reading of the message text)
+            if getattr(err, "n_keyframes", 0) > max_keys:
                 if max_keys > 4 * n_ev:
                     raise
-                max_keys *= 2
+                max_keys = max(2 * max_keys, int(err.n_keyframes) + 64)
             else:
                 if cap >= cap_max:
                     raise

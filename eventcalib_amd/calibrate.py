@@ -133,17 +133,14 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     sel = np.arange(use) * sel_step
     obj = board_points(rows, cols, square)
     feat32 = kf["features"][:, :, :2].astype(np.float32).astype(np.float64)
-    guess = None
     if fisheye:
-        # cv::fisheye::calibrate starts from f = max(w, h) / pi, the focal length of a lens that fills the sensor with ~180
-        # degrees; a lens far from that (this one: 55 degrees) puts the first extrinsics' undistortion outside its domain and
-        # the iteration fails.  The radial model's calibration of the same views gives the start instead
-        # (CALIB_USE_INTRINSIC_GUESS, as a user of cv::fisheye::calibrate would)
-        pin = capi.calibrate_views(ctx, obj, feat32[sel], width, height, 0, EXAMPLE_FLAGS, aspect_ratio)["intr"]
-        guess = np.zeros(12)
-        guess[:4] = pin[:4]
-        flags |= capi.CALIB_USE_INTRINSIC_GUESS
-    ini = capi.calibrate_views(ctx, obj, feat32[sel], width, height, model, flags, aspect_ratio, intr_guess=guess)
+        # the library's one start procedure (ecal_calibrate_fisheye_views, the same the C++ shim calls): cv::fisheye::calibrate's
+        # own start first (f = max(w, h) / pi), the radial model's focal lengths as a guess only when that fails
+        ini = capi.calibrate_fisheye_views(ctx, obj, feat32[sel], width, height, flags, aspect_ratio)
+        out["fisheye_start"] = {0: "reference (f = max(w, h) / pi)", 1: "radial model's focal lengths (the reference's start failed)",
+                                2: "caller's guess"}[ini["start_used"]]
+    else:
+        ini = capi.calibrate_views(ctx, obj, feat32[sel], width, height, model, flags, aspect_ratio)
     intr0 = ini["intr"]
     out["init"] = {"intr": intr0, "rms": ini["rms"], "iterations": ini["iterations"], "views": use}
     mark("init_calibration")

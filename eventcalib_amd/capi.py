@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_sort_events_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
     "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev", "ecal_comm_allreduce",
-    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_set_median_ties",
+    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_set_median_ties", "ecal_set_tail_mode", "ecal_calibrate_fisheye_views",
     "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
@@ -40,6 +40,18 @@ class RectifyParams(ctypes.Structure):
                 ("dist", ctypes.c_double * 5), ("width", ctypes.c_double), ("height", ctypes.c_double),
                 ("rows", ctypes.c_uint32), ("cols", ctypes.c_uint32), ("asymmetric", ctypes.c_int),
                 ("circle_radius", ctypes.c_double), ("fit_circle", ctypes.c_int), ("model", ctypes.c_int)]
+
+
+import weakref
+
+_live_contexts = weakref.WeakSet()
+
+
+def sync_env():
+    """Tests: the library reads its debug switches (ECAL_* environment variables) once per context, at ecal_init; after changing
+    one under a live context, call this — every live Context re-reads them (ecal_debug_reload_env)."""
+    for c in list(_live_contexts):
+        c.reload_env()
 
 
 class EcalError(RuntimeError):
@@ -149,9 +161,17 @@ class Context:
             raise EcalError(st, self._L.ecal_strerror(st).decode())
         self._h = h
         self.device = int(device)
+        _live_contexts.add(self)
+
+    def reload_env(self):
+        """ecal_debug_reload_env: read the ECAL_* debug switches again (they are read once, at ecal_init)."""
+        if getattr(self, "_h", None):
+            self._L.ecal_debug_reload_env.argtypes = [ctypes.c_void_p]
+            self._check(self._L.ecal_debug_reload_env(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
+            _live_contexts.discard(self)
             self._L.ecal_destroy(self._h)
             self._h = None
 
@@ -730,6 +750,37 @@ def calibrate_views(ctx: Context, obj, img, width, height, model=0, flags=0, asp
             "error_evaluations": res.error_evaluations, "seconds": res.seconds}
 
 
+def calibrate_fisheye_views(ctx: Context, obj, img, width, height, flags=0, aspect_ratio=1.0, allreduce=None):
+    """ecal_calibrate_fisheye_views: the fisheye init calibration with the library's start procedure (the reference's own start
+    first, the radial model's focal lengths as a guess when that fails).  Returns calibrate_views' dict + "start_used"."""
+    L = ctx._L
+    _declare_calib(L)
+    obj = np.ascontiguousarray(obj, np.float64)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, obj.shape[0], 2)
+    V = img.shape[0]
+    opt = CalibOptions()
+    L.ecal_calib_default_options(ctypes.byref(opt))
+    opt.model, opt.flags, opt.aspect_ratio = 1, int(flags), float(aspect_ratio)
+    if allreduce is not None:
+        if isinstance(allreduce, tuple):
+            opt.allreduce, opt.allreduce_user = allreduce
+        else:
+            opt.allreduce = allreduce
+    res = CalibResult()
+    rv, tv, pe = np.zeros((V, 3)), np.zeros((V, 3)), np.zeros(V)
+    used = ctypes.c_int(-1)
+    L.ecal_calibrate_fisheye_views.restype = ctypes.c_int
+    L.ecal_calibrate_fisheye_views.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32,
+                                               ctypes.c_double, ctypes.c_double, ctypes.POINTER(CalibOptions), ctypes.POINTER(CalibResult),
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+    ctx._check(L.ecal_calibrate_fisheye_views(ctx._h, _ptr(obj), obj.shape[0], _ptr(img) if V else None, V, float(width), float(height),
+                                              ctypes.byref(opt), ctypes.byref(res), _ptr(rv) if V else None, _ptr(tv) if V else None,
+                                              _ptr(pe) if V else None, ctypes.byref(used)))
+    return {"intr": np.array(res.intr[:]), "rms": res.rms, "iterations": res.iterations, "rvecs": rv, "tvecs": tv,
+            "per_view_err": pe, "jacobian_evaluations": res.jacobian_evaluations, "error_evaluations": res.error_evaluations,
+            "seconds": res.seconds, "start_used": int(used.value)}
+
+
 def calib_view_blocks_dev(ctx: Context, d_obj, n_pts, d_img, n_views, model, flags, aspect_ratio, d_intr, d_view_params,
                           with_jacobian, d_blocks, stream=0):
     _declare_calib(ctx._L)
@@ -873,9 +924,13 @@ def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, fra
     e = np.empty(max_keyframes, np.int32)
     f = np.empty((max_keyframes, M, 3))
     nk, ps, nw = u32(0), u32(0), ctypes.c_uint64(0)
-    ctx._check(L.ecal_detect_keyframes(ctx._h, d_events, int(n_events), ctypes.byref(ap), ctypes.byref(prm), int(cap_points),
-                                       int(max_keyframes), _ptr(t), _ptr(d), _ptr(e), _ptr(f), ctypes.byref(nk), ctypes.byref(ps),
-                                       ctypes.byref(nw)))
+    try:
+        ctx._check(L.ecal_detect_keyframes(ctx._h, d_events, int(n_events), ctypes.byref(ap), ctypes.byref(prm), int(cap_points),
+                                           int(max_keyframes), _ptr(t), _ptr(d), _ptr(e), _ptr(f), ctypes.byref(nk), ctypes.byref(ps),
+                                           ctypes.byref(nw)))
+    except EcalError as err:
+        err.n_keyframes = int(nk.value)     # ECAL_ERR_RANGE with a count beyond max_keyframes: the keyframe capacity was short
+        raise
     K = nk.value
     return t[:K].copy(), d[:K].copy(), e[:K].astype(np.int64), f[:K].copy(), ps.value, nw.value
 

@@ -111,8 +111,10 @@ struct AdaptiveArrays {
 __device__ bool gate_accepts(const double *rd, double ref_t, const double *dir, double t_mid, uint32_t rows, double mts) {
     double theta[AD_MAX_ROWS];
     for (uint32_t i = 0; i < rows; i++) {
+        // (Eigen's norm() = sqrt of the sum of squares, EventCalibIni.cpp:73-77 — not hypot(): one ulp in the norm decides
+        // whether a cosine of near-parallel rows rounds above 1, i.e. whether the angle is 0 or NaN, and the NaN is kept)
         const double c = (rd[2 * i] * dir[2 * i] + rd[2 * i + 1] * dir[2 * i + 1]) /
-                         (hypot(rd[2 * i], rd[2 * i + 1]) * hypot(dir[2 * i], dir[2 * i + 1]));
+                         (sqrt(rd[2 * i] * rd[2 * i] + rd[2 * i + 1] * rd[2 * i + 1]) * sqrt(dir[2 * i] * dir[2 * i] + dir[2 * i + 1] * dir[2 * i + 1]));
         theta[i] = acos(c);
     }
     ecal::ref_nth_element(theta, rows, rows / 2u, [](double x, double y) { return x < y; });
@@ -143,18 +145,12 @@ __device__ __forceinline__ void next_window(int o, double f, double s2, double m
 // of the finished pieces going to the others: 6 slots per piece and chains of <= 12: 533 / 922, <= 24: 592 / 943,
 // <= 48: 633 / 962, <= 64: 626 / 973; 4, 5, 8 slots per piece (<= 64, <= 48, <= 64): 559 / 1001, 582 / 1017, 541 / 823.
 constexpr uint32_t AD_DEPTH_MAX = 48;
-static uint32_t adaptive_slots_per_piece(uint32_t pieces) {
-    if (const char *e = getenv("ECAL_ADAPTIVE_DEPTH")) {   // debug / measurement switch; the result does not depend on it
-        const int d = atoi(e);
-        if (d >= 1 && d <= 64) return (uint32_t) d;
-    }
+static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
+    if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_DEPTH: debug / measurement switch; the result does not depend on it)
     return pieces <= 2048u ? 6u : (pieces <= 8192u ? 5u : (pieces <= 32768u ? 3u : 1u));   // (many pieces fill the GPU by themselves)
 }
-static uint32_t adaptive_depth_max() {
-    if (const char *e = getenv("ECAL_ADAPTIVE_DEPTH_MAX")) {   // debug / measurement switch
-        const int d = atoi(e);
-        if (d >= 1 && d <= 64) return (uint32_t) d;
-    }
+static uint32_t adaptive_depth_max(int forced = 0) {
+    if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_DEPTH_MAX: debug / measurement switch)
     return AD_DEPTH_MAX;
 }
 
@@ -510,7 +506,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     int rc;
-    const uint32_t D = adaptive_slots_per_piece(P), d_max = adaptive_depth_max();
+    const uint32_t D = adaptive_slots_per_piece(P, ctx->sw.adaptive_depth), d_max = adaptive_depth_max(ctx->sw.adaptive_depth_max);
     const uint32_t S = D * P;   // window slots per pass, dealt out among the pieces still at work: the current window and the likely chain after it
     const size_t cap = (size_t) cap_points + 16;
     ecal_devbuf *B = ctx->host_pipe;  // roles as in ecal_detect_pass; 0 holds t0 and t1 back to back
@@ -614,7 +610,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 if (ring[4 * q + 3]) {
                     (void) hipStreamSynchronize(st);
                     ctx->last_error = range_msg;
-                    if (getenv("ECAL_ADAPTIVE_TRACE")) fprintf(stderr, "ecal_detect_keyframes: cap_points %u too small after %u passes\n", cap_points, n_passes);
+                    if (ctx->sw.adaptive_trace) fprintf(stderr, "ecal_detect_keyframes: cap_points %u too small after %u passes\n", cap_points, n_passes);
                     return ECAL_ERR_RANGE;
                 }
                 if (ring[4 * q] == 0) break;   // (the passes enqueued since find nothing to do)
@@ -651,14 +647,14 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));
         if (h[3]) {   // (an overflow may sit in any of the last passes)
             ctx->last_error = range_msg;
-            if (getenv("ECAL_ADAPTIVE_TRACE")) fprintf(stderr, "ecal_detect_keyframes: cap_points %u too small (seen at the end, %u passes)\n", cap_points, n_passes);
+            if (ctx->sw.adaptive_trace) fprintf(stderr, "ecal_detect_keyframes: cap_points %u too small (seen at the end, %u passes)\n", cap_points, n_passes);
             return ECAL_ERR_RANGE;
         }
         return ECAL_OK;
     };
     if ((rc = run_passes())) return rc;
     uint32_t rounds = 0;
-    const bool trace = getenv("ECAL_ADAPTIVE_TRACE") != nullptr;
+    const bool trace = ctx->sw.adaptive_trace;
     if (shared) {
         // verify every piece against the frame its predecessors now hand it; run the ones again whose verdicts change
         for (;; rounds++) {

@@ -281,6 +281,14 @@ extern "C" int ecal_solver_create_from_stream(ecal_ctx *ctx, const ecal_stream *
         ctx->last_error = "ecal_solver_create_from_stream: one time range per spline segment";
         return ECAL_ERR_INVALID;
     }
+    // the device side finds an event's range by bisection (range_of): ascending, disjoint, well-formed ranges or nothing
+    for (uint32_t r = 0; r < n_ranges; r++) {
+        const bool ok = ranges[2 * r] <= ranges[2 * r + 1] && (r == 0 || ranges[2 * r - 1] < ranges[2 * r]);
+        if (!ok) {   // (also catches NaN bounds)
+            ctx->last_error = "ecal_solver_create_from_stream: the time ranges must be ascending and disjoint (range " + std::to_string(r) + ")";
+            return ECAL_ERR_INVALID;
+        }
+    }
     const uint64_t n = ecal_stream_size(es);
     if (n > 0xFFFFFFFFull) return ECAL_ERR_RANGE;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -926,8 +926,8 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
     // the global-scratch launch's workspace and hit-list arena, a slice per workgroup
     const uint32_t bigW = std::max<uint32_t>(std::min<uint32_t>(n_points, BO_BIG_W), 64u);
     uint32_t big_arena = (uint32_t) std::min<uint64_t>(BO_BIG_ARENA, std::max<uint64_t>(64ull * bigW, std::min<uint64_t>((uint64_t) bigW * bigW, 1ull << 22)));
-    if (const char *e = getenv("ECAL_BO_BIG_ARENA"))   // tests: an arena too small for the segment = the flagged fallback (status 1)
-        big_arena = (uint32_t) std::min<uint64_t>(big_arena, std::max<uint64_t>(64, strtoull(e, nullptr, 10)));
+    if (ctx->sw.bo_big_arena)   // (ECAL_BO_BIG_ARENA; tests: an arena too small for the segment = the flagged fallback, status 1)
+        big_arena = (uint32_t) std::min<uint64_t>(big_arena, std::max<uint64_t>(64, ctx->sw.bo_big_arena));
     const uint32_t grid_big = std::min<uint32_t>(S, BO_BIG_GRID);
     if ((rc = ecal_ensure(ctx, ctx->bfs_big, (size_t) grid_big * (bo_big_words(bigW) + big_arena) * sizeof(uint32_t)))) return rc;
     uint32_t *big_ws = (uint32_t *) ctx->bfs_big.ptr, *big_hits = big_ws + (size_t) grid_big * bo_big_words(bigW);

@@ -1155,3 +1155,48 @@ extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n
     res->seconds = now_s() - t_begin;
     return ECAL_OK;
 }
+
+// cv::fisheye::calibrate's call at EventCalibIni.cpp:186-190, with one start procedure for every front end (the C++ shim
+// host/event_calib_ini.hpp and eventcalib_amd/calibrate.py used to differ): FIRST the reference's own start — principal point
+// at the image centre, f = max(w, h) / pi, no guess —; only when that fails (the smoothed Gauss-Newton ends on a singular
+// system or a non-finite result: a lens far from the 180-degree lens the start assumes, e.g. the example sensor's 55 degrees)
+// the radial model is calibrated on the same views with ECAL_CALIB_FISHEYE_PRECALIB_FLAGS and its focal lengths and principal
+// point start the fisheye model (CALIB_USE_INTRINSIC_GUESS, as a user of the OpenCV call would).  *start_used = 0 / 1 says
+// which.  opt->flags may already carry ECAL_CALIB_USE_INTRINSIC_GUESS (res->intr = the caller's guess): one run, *start_used = 2.
+extern "C" int ecal_calibrate_fisheye_views(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const double *img, uint32_t n_views,
+                                            double width, double height, const ecal_calib_options *opt, ecal_calib_result *res,
+                                            double *rvecs, double *tvecs, double *per_view_err, int *start_used) {
+    if (!ctx || !opt || !res) return ECAL_ERR_INVALID;
+    if (start_used) *start_used = 2;
+    ecal_calib_options fo = *opt;
+    fo.model = 1;
+    if (fo.flags & ECAL_CALIB_USE_INTRINSIC_GUESS) return ecal_calibrate_views(ctx, obj, n_pts, img, n_views, width, height, &fo, res, rvecs, tvecs, per_view_err);
+    auto sane = [](const ecal_calib_result &r) {
+        bool ok = std::isfinite(r.rms) && r.intr[0] > 0 && r.intr[1] > 0;
+        for (int j = 0; j < 12; j++) ok = ok && std::isfinite(r.intr[j]);
+        return ok;
+    };
+    ecal_calib_result first;
+    memset(&first, 0, sizeof(first));
+    int rc = ecal_calibrate_views(ctx, obj, n_pts, img, n_views, width, height, &fo, &first, rvecs, tvecs, per_view_err);
+    if (rc == ECAL_OK && sane(first)) {
+        *res = first;
+        if (start_used) *start_used = 0;
+        return ECAL_OK;
+    }
+    if (rc != ECAL_OK && rc != ECAL_ERR_INVALID) return rc;   // (a HIP / communication error is not a failed start)
+    ecal_calib_options po = *opt;    // (same all-reduce: every rank takes the same branch, the first run's verdict is global)
+    po.model = 0;
+    po.flags = ECAL_CALIB_FISHEYE_PRECALIB_FLAGS;
+    po.aspect_ratio = 1.0;
+    ecal_calib_result pr;
+    memset(&pr, 0, sizeof(pr));
+    rc = ecal_calibrate_views(ctx, obj, n_pts, img, n_views, width, height, &po, &pr, nullptr, nullptr, nullptr);
+    if (rc != ECAL_OK) return rc;
+    memset(res, 0, sizeof(*res));
+    for (int j = 0; j < 4; j++) res->intr[j] = pr.intr[j];
+    fo.flags |= ECAL_CALIB_USE_INTRINSIC_GUESS;
+    if (start_used) *start_used = 1;
+    return ecal_calibrate_views(ctx, obj, n_pts, img, n_views, width, height, &fo, res, rvecs, tvecs, per_view_err);
+}
+

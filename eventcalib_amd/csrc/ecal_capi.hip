@@ -3,8 +3,43 @@
 
 constexpr uint32_t ZERO_RING_WORDS = 16384, ZERO_RING_GRAIN = 16;
 
+void ecal_read_switches(ecal_switches &sw) {
+    auto on = [](const char *name) { return getenv(name) != nullptr; };
+    auto num = [](const char *name) -> long long {
+        const char *e = getenv(name);
+        return e ? atoll(e) : 0;
+    };
+    sw = ecal_switches();
+    sw.slice_no_pixel = on("ECAL_SLICE_NO_PIXEL");
+    sw.slice_sort_kernel = on("ECAL_SLICE_SORT_KERNEL");
+    sw.slice_no_second_pass = on("ECAL_SLICE_NO_SECOND_PASS");
+    sw.bounds_two_kernels = on("ECAL_BOUNDS_TWO_KERNELS");
+    sw.dbscan_no_pixel = on("ECAL_DBSCAN_NO_PIXEL");
+    sw.dbscan_no_second_pass = on("ECAL_DBSCAN_NO_SECOND_PASS");
+    sw.dbscan_generic_disc = on("ECAL_DBSCAN_GENERIC_DISC");
+    sw.extract_no_second_pass = on("ECAL_EXTRACT_NO_SECOND_PASS");
+    sw.no_fused_pass = on("ECAL_NO_FUSED_PASS");
+    sw.no_zero_ring = on("ECAL_NO_ZERO_RING");
+    sw.adaptive_trace = on("ECAL_ADAPTIVE_TRACE");
+    sw.grid_debug = on("ECAL_GRID_DEBUG");
+    sw.solver_device_linear_solve = on("ECAL_SOLVER_DEVICE_LINEAR_SOLVE");
+    sw.solver_trace = on("ECAL_SOLVER_TRACE");
+    sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
+    sw.adaptive_depth_max = (int) num("ECAL_ADAPTIVE_DEPTH_MAX");
+    sw.arrow_k = (int) num("ECAL_ARROW_K");
+    sw.bo_big_arena = (unsigned long long) num("ECAL_BO_BIG_ARENA");
+    if (const char *e = getenv("ECAL_GRID_TOL_PX")) sw.grid_tol_px = atof(e);
+}
+
+// tests: the switches again, after the environment changed under a live context
+extern "C" int ecal_debug_reload_env(ecal_ctx *ctx) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    ecal_read_switches(ctx->sw);
+    return ECAL_OK;
+}
+
 uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n) {
-    if (n > ZERO_RING_GRAIN || getenv("ECAL_NO_ZERO_RING")) return nullptr;
+    if (n > ZERO_RING_GRAIN || ctx->sw.no_zero_ring) return nullptr;
     ecal_ctx::zero_ring *r = nullptr;
     for (auto &c : ctx->zero_rings)
         if (c.used && c.stream == st) r = &c;
@@ -94,6 +129,7 @@ extern "C" int ecal_init(int device, ecal_ctx **out) {
         delete ctx;
         return ECAL_ERR_HIP;
     }
+    ecal_read_switches(ctx->sw);
     if (const char *e = getenv("ECAL_MEDIAN_TIES")) ctx->median_ties = atoi(e) ? ECAL_TIES_SMALLER_PID : ECAL_TIES_REFERENCE;   // debug switch
     if (const char *e = getenv("ECAL_TAIL_MODE")) ctx->tail_mode = atoi(e);   // debug switch (0 auto, 1 every tier, 2 lean)
     if (hipHostMalloc((void **) &ctx->tail_seen, ECAL_TAIL_SLOTS * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&

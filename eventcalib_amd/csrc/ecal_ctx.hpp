@@ -17,8 +17,24 @@ struct ecal_devbuf {
     size_t cap = 0;
 };
 
+// Debug / test switches, read from the environment ONCE per context (ecal_init) — not per call: getenv is not safe against a
+// concurrent setenv, and the entry points that consult these are the hot ones.  Tests that flip a switch on a live context call
+// ecal_debug_reload_env afterwards (eventcalib_amd.capi.sync_env does it for every live context).  None of them changes a
+// result, only which tier or routine produces it ("Environment switches").
+struct ecal_switches {
+    bool slice_no_pixel = false, slice_sort_kernel = false, slice_no_second_pass = false, bounds_two_kernels = false;
+    bool dbscan_no_pixel = false, dbscan_no_second_pass = false, dbscan_generic_disc = false;
+    bool extract_no_second_pass = false, no_fused_pass = false, no_zero_ring = false;
+    bool adaptive_trace = false, grid_debug = false, solver_device_linear_solve = false, solver_trace = false;
+    int adaptive_depth = 0, adaptive_depth_max = 0, arrow_k = 0;   // 0: not set
+    unsigned long long bo_big_arena = 0;                            // 0: not set
+    double grid_tol_px = 20.0;
+};
+void ecal_read_switches(ecal_switches &sw);
+
 struct ecal_ctx {
     int device = 0;
+    ecal_switches sw;
     hipStream_t stream = nullptr;
     std::string last_error;
     // grow-only device scratch (never shrinks; sized for 288 GB parts: keep and reuse)

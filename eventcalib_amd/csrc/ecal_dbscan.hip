@@ -310,12 +310,12 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
     hipStream_t st = (hipStream_t) stream;
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
     // (fused pass: its to-do list also holds the segments of windows the fused kernel did not slice, of any size)
-    const bool second_pass_wanted = (mx > (uint32_t) PX_CAP || ctx->fused_pass) && !getenv("ECAL_DBSCAN_NO_SECOND_PASS");  // debug switch
+    const bool second_pass_wanted = (mx > (uint32_t) PX_CAP || ctx->fused_pass) && !ctx->sw.dbscan_no_second_pass;  // debug switch
 
     // event pixels (integer coordinates, eps < 16): the lean pixel kernel takes every segment it can and lists
     // the others; the general tiers then work that list off with a small grid (it is normally empty)
     PxGeom geom;
-    const bool pixel = px_geometry(eps, &geom) && !getenv("ECAL_DBSCAN_NO_PIXEL");
+    const bool pixel = px_geometry(eps, &geom) && !ctx->sw.dbscan_no_pixel;
     const uint32_t *todo = nullptr, *todo_count = nullptr;
     uint32_t grid = S;
     // lean: what the pixel kernel lists (nothing, when this stage last ran) goes to ONE tail launch (dbscan_tail_kernel) instead
@@ -341,7 +341,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         cnt_a = cnt;
         cnt_b = second_pass ? cnt2 : nullptr;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
-        if (geom.e2i == 16 && !getenv("ECAL_DBSCAN_GENERIC_DISC")) {
+        if (geom.e2i == 16 && !ctx->sw.dbscan_generic_disc) {
             if (!fused) hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt);
             if (second_pass)

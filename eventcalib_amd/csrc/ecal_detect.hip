@@ -225,7 +225,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     // windows too large for the first pass's LDS staging but not for the second's are listed by the first pass
     if ((rc = ecal_ensure(ctx, ctx->det_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
     uint32_t *cnt = (uint32_t *) ctx->det_todo.ptr, *list = cnt + 4;
-    const bool second = !getenv("ECAL_EXTRACT_NO_SECOND_PASS");
+    const bool second = !ctx->sw.extract_no_second_pass;
     hipStream_t st = (hipStream_t) stream;
     // (fused pass, ecal_fused.hip: the fused kernel has extracted every window it carried through and listed the others)
     const bool fused = ctx->fused_pass && mode == 0;

@@ -917,7 +917,7 @@ extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, ui
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
     const uint32_t n_wg = (S + WB_T - 1) / WB_T;
-    uint32_t *ticket = getenv("ECAL_BOUNDS_TWO_KERNELS") ? nullptr : ecal_zero_words(ctx, st, 1);
+    uint32_t *ticket = ctx->sw.bounds_two_kernels ? nullptr : ecal_zero_words(ctx, st, 1);
     if (ticket && ctx->wb_status.cap < (size_t) n_wg * sizeof(unsigned long long)) {
         int rc;
         if ((rc = ecal_ensure(ctx, ctx->wb_status, (size_t) n_wg * sizeof(unsigned long long)))) return rc;
@@ -1052,7 +1052,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
     // (packed points: every segment starts as "doubles"; the pixel kernels mark the windows they pack.  The hash slicers — the
     // default — write the mark of EVERY window they look at, also of the ones they pass on: no wipe, one launch less per pass)
-    const bool hash_slicer = !getenv("ECAL_SLICE_NO_PIXEL") && (reforder || !getenv("ECAL_SLICE_SORT_KERNEL"));
+    const bool hash_slicer = !ctx->sw.slice_no_pixel && (reforder || !ctx->sw.slice_sort_kernel);
     if (sfmt && !(hash_slicer && !fused)) ECAL_HIP_TRY(ctx, hipMemsetAsync(sfmt, 0, 2 * (size_t) S * sizeof(uint32_t), st));
     const uint32_t mx = max_win_events ? max_win_events : 0xFFFFFFFFu;
     // pixel windows first; what they leave over (longer windows, non-integer coordinates) is listed for the general tiers
@@ -1062,7 +1062,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     // pass instead of four (ecal_ctx::tail_seen); only without size hints — a caller who names its sizes gets what it asks for
     const bool lean = hash_slicer && !fused && max_win_events == 0 && ecal_tail_lean(ctx, ECAL_TAIL_SLICE, 2);
     const uint32_t *cnt_a = nullptr, *cnt_b = nullptr;
-    if (!getenv("ECAL_SLICE_NO_PIXEL")) {
+    if (!ctx->sw.slice_no_pixel) {
         int rc;
         if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
         uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
@@ -1077,7 +1077,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         todo = list;
         todo_count = cnt;
         cnt_a = cnt;
-        if (reforder || !getenv("ECAL_SLICE_SORT_KERNEL")) {   // (debug switch: the counting-sort form, which also takes negative pixels)
+        if (reforder || !ctx->sw.slice_sort_kernel) {   // (debug switch: the counting-sort form, which also takes negative pixels)
             if (reforder) {
                 if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
                 if (!fused) hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
@@ -1088,7 +1088,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                 hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
                                    d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, xy16, sfmt);
             // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
-            if (!lean && (reforder || mx > PixHash<11>::CAP) && !getenv("ECAL_SLICE_NO_SECOND_PASS")) {
+            if (!lean && (reforder || mx > PixHash<11>::CAP) && !ctx->sw.slice_no_second_pass) {
                 cnt_b = cnt2;
                 const uint32_t grid2 = S < 768u ? S : 768u;
                 if (reforder)

@@ -148,7 +148,7 @@ extern "C" int ecal_detect_fused_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
     // the fused kernel is compiled for the shipped configuration: reference point order, pixel DBSCAN (eps < 16),
     // fitCircle == 0 (example.yaml); any other configuration runs the same stages as three kernels
     const bool fusable = ctx->point_order == ECAL_ORDER_REFERENCE && px_geometry(eps, &geom) && !fit_circle && cap_points &&
-                         !getenv("ECAL_NO_FUSED_PASS");
+                         !ctx->sw.no_fused_pass;
     if (fusable) {
         const size_t SS = 2 * (size_t) S;   // segments
         if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
@@ -205,7 +205,7 @@ extern "C" int ecal_detect_fused_dev(ecal_ctx *ctx, const uint8_t *d_events, uin
         a.sorted = (uint32_t *) ctx->det_sorted.ptr;
         a.norms = (double *) ctx->det_norms.ptr;
         a.det_cnt = (uint32_t *) ctx->det_todo.ptr;
-        a.det_list = getenv("ECAL_EXTRACT_NO_SECOND_PASS") ? nullptr : a.det_cnt + 4;
+        a.det_list = ctx->sw.extract_no_second_pass ? nullptr : a.det_cnt + 4;
         a.def_cnt = (uint32_t *) ctx->fused_def.ptr;
         a.def_list = a.def_cnt + 4;
         ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));

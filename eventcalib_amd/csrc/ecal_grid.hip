@@ -709,10 +709,9 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
         return ECAL_ERR_INVALID;
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const char *tol_env = getenv("ECAL_GRID_TOL_PX");   // debug switch (tests of the tolerance's effect); default = the reference's 20 px
-    const double tol_px = tol_env ? atof(tol_env) : 20.0;
+    const double tol_px = ctx->sw.grid_tol_px;   // (ECAL_GRID_TOL_PX, a debug switch for tests of the tolerance's effect; default = the reference's 20 px)
     hipLaunchKernelGGL(grid_order_kernel, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
-                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, getenv("ECAL_GRID_DEBUG") ? 1 : 0);
+                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, ctx->sw.grid_debug ? 1 : 0);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

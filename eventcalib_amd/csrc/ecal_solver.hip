@@ -1145,12 +1145,12 @@ struct DeviceLm {
     }
 };
 
-ArrowPlan make_arrow_plan(uint32_t n_cp) {
+ArrowPlan make_arrow_plan(uint32_t n_cp, int forced_k) {
     ArrowPlan pl;
     pl.n_cp = n_cp;
     // interiors cost ~6 K column steps each (in parallel), the separators' system 18 (P - 1) ~ 18 n_cp / K: balanced at K ~ sqrt(3 n_cp)
     pl.K = std::max<uint32_t>(21u, (uint32_t) std::sqrt(3.0 * (double) n_cp));
-    if (const char *k = getenv("ECAL_ARROW_K")) pl.K = std::max(3, atoi(k));   // debug switch (tests: many partitions on small problems)
+    if (forced_k > 0) pl.K = (uint32_t) std::max(3, forced_k);   // (ECAL_ARROW_K: debug switch; tests: many partitions on small problems)
     pl.P = std::max<uint32_t>(1u, n_cp / (pl.K + 3u));
     return pl;
 }
@@ -1180,7 +1180,7 @@ static int arrow_solve_dev(ecal_solver *s, DeviceLm &D, const double *d_acc, con
 static int device_lm_alloc(ecal_solver *s, DeviceLm &D) {
     ecal_ctx *ctx = s->ctx;
     D.ctx = ctx;
-    D.plan = make_arrow_plan(s->n_cp);
+    D.plan = make_arrow_plan(s->n_cp, s->ctx->sw.arrow_k);
     const size_t nc = 6 * (size_t) s->n_cp, np = s->n_params(), na = s->n_accum();
     auto get = [&](double **p, size_t n) -> bool {
         if (hipMalloc((void **) p, (n ? n : 1) * sizeof(double)) != hipSuccess) return false;
@@ -1343,7 +1343,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     // ECAL_SOLVER_DEVICE_LINEAR_SOLVE=1 (one rank): the whole iteration on the device (arrow_device.hpp) — correct and tested,
     // but measured SLOWER than the host factorisation on the benchmark problem (12 009 unknowns: 2.9 ms of device kernels per
     // linear solve against 1.3 ms on one host core + 0.5 ms of copies), so the host loop stays the default.
-    if (!opt.allreduce && getenv("ECAL_SOLVER_DEVICE_LINEAR_SOLVE")) {
+    if (!opt.allreduce && s->ctx->sw.solver_device_linear_solve) {
         const int rc_dev = device_lm_solve(s, params, opt, sum);
         if (rc_dev != ECAL_ERR_RANGE) return rc_dev;                     // (too large for the LDS-resident parts: host loop)
     }
@@ -1709,7 +1709,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     S.seconds_evaluate = t_eval;
     S.seconds_linear_solve = t_lin;
-    if (getenv("ECAL_SOLVER_TRACE"))
+    if (s->ctx->sw.solver_trace)
         fprintf(stderr, "ecal_solver_solve: total %.4f s | evaluate %.4f | linear solve %.4f (%d parts) | unpack %.4f | pool %.4f\n", S.seconds,
                 t_eval, t_lin, n_parts, t_unpack, t_pool);
     memcpy(params, x.data(), np * sizeof(double));

@@ -78,6 +78,7 @@ public:
         double K[4] = {0, 0, 0, 0};         // fx fy cx cy
         std::vector<double> distCoeffs;     // 8 (k1 k2 p1 p2 k3 k4 k5 k6) or 4 (fisheye k1..k4)
         double rms = 0;
+        int fisheyeStart = -1;   // Calibrate_UseFisheyeModel: 0 the reference's own start, 1 the radial guess was needed (ecal_calibrate_fisheye_views)
         std::vector<size_t> usedFrames;     // keyframes that entered the calibration
         std::vector<size_t> acceptedFrames; // keyframes that passed checkPose and rectifyFeatures, time order
         std::vector<FramePose> poses;       // one per keyframe (valid for every keyframe the PnP solved)
@@ -149,23 +150,15 @@ public:
         ecal_calib_result cr;
         int rc;
         if (cs.useFisheye) {
-            // cv::fisheye::calibrate starts from f = max(w, h) / pi (a lens that fills the sensor with ~180 degrees); for a lens
-            // far from that the first extrinsics' undistortion leaves its domain and the iteration fails.  The radial model's
-            // calibration of the same views gives the start (CALIB_USE_INTRINSIC_GUESS, as a user of the OpenCV call would).
-            ecal_calib_options po;
-            ecal_calib_default_options(&po);
-            po.model = 0;
-            po.flags = ECAL_CALIB_FIX_PRINCIPAL_POINT | ECAL_CALIB_ZERO_TANGENT_DIST | ECAL_CALIB_FIX_ASPECT_RATIO | ECAL_CALIB_FIX_K3 |
-                       ECAL_CALIB_FIX_K4 | ECAL_CALIB_FIX_K5 | ECAL_CALIB_FIX_K6;
-            po.aspect_ratio = 1.0;
-            ecal_calib_result pr;
-            rc = ecal_calibrate_views(ctx, obj.data(), n, img.data(), (uint32_t) use, width, height, &po, &pr, nullptr, nullptr, nullptr);
-            if (rc == ECAL_OK) {
-                for (int j = 0; j < 12; j++) cr.intr[j] = j < 4 ? pr.intr[j] : 0.0;
-                opt.flags |= ECAL_CALIB_USE_INTRINSIC_GUESS;
-            }
+            // the library's one start procedure (ecal_calibrate_fisheye_views): the reference's own start first, the radial
+            // model's focal lengths as a guess only when that fails; res.fisheyeStart says which
+            int start_used = 0;
+            rc = ecal_calibrate_fisheye_views(ctx, obj.data(), n, img.data(), (uint32_t) use, width, height, &opt, &cr, nullptr, nullptr,
+                                              nullptr, &start_used);
+            res.fisheyeStart = start_used;
+        } else {
+            rc = ecal_calibrate_views(ctx, obj.data(), n, img.data(), (uint32_t) use, width, height, &opt, &cr, nullptr, nullptr, nullptr);
         }
-        rc = ecal_calibrate_views(ctx, obj.data(), n, img.data(), (uint32_t) use, width, height, &opt, &cr, nullptr, nullptr, nullptr);
         if (rc == ECAL_ERR_INVALID) return false;  // degenerate views: what cv::calibrateCamera reports by throwing
         if (rc != ECAL_OK) throw std::runtime_error(std::string("ecal_calibrate_views: ") + ecal_last_error(ctx));
         bool ok = std::isfinite(cr.rms);

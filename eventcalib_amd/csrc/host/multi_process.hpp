@@ -88,7 +88,7 @@ inline bool orientation_gate(const KeyFrame &ref, const KeyFrame &cur, int rows,
     std::vector<double> theta;
     for (int i = 0; i < rows; i++) {
         const Vector2d a = row_direction(&ref.features[i * cols], cols), b = row_direction(&cur.features[i * cols], cols);
-        const double c = (a[0] * b[0] + a[1] * b[1]) / (std::hypot(a[0], a[1]) * std::hypot(b[0], b[1]));
+        const double c = (a[0] * b[0] + a[1] * b[1]) / (std::sqrt(a[0] * a[0] + a[1] * a[1]) * std::sqrt(b[0] * b[0] + b[1] * b[1]));   // Eigen's norm(), not hypot
         theta.push_back(std::acos(c));   // (not clamped, as the reference: a cosine rounded above 1 gives NaN)
     }
     // (with a NaN among the angles the result is whatever the library's loops leave at the position — on libstdc++ the very

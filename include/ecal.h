@@ -505,7 +505,10 @@ int ecal_associate_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events
                        uint32_t *d_count, void *stream);
 
 /* The same for ALL spline segments of a calibration in one pass over the stream: d_ranges [R][2] = (t_min, t_max) of segment r
- * (ascending, disjoint: EventCalibSpline.cpp:318-345 cuts the keyframes at gaps); an event inside range r that passes the two
+ * (REQUIRED ascending and disjoint — t_min[r] <= t_max[r] < t_min[r + 1]; EventCalibSpline.cpp:318-345 cuts the keyframes at
+ * gaps, so the reference's are —: the device finds an event's range by bisection and cannot report a violation from a device
+ * table; ecal_solver_create_from_stream, which takes the ranges from the host, checks and returns ECAL_ERR_INVALID);
+ * an event inside range r that passes the two
  * gates becomes a residual of segment r: d_seg_id[j] = r.  Outputs in event order = sorted by (segment, time), which is what
  * ecal_solver_create[_dev] takes; *d_count stays on the device (ecal_solver_create_dev reads it there). */
 int ecal_associate_ranges_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_kf_time,
@@ -733,6 +736,19 @@ int ecal_pnp_batch(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const doubl
 int ecal_calibrate_views(ecal_ctx *ctx, const double *obj /*[n_pts][3]*/, uint32_t n_pts, const double *img /*[V][n_pts][2]*/,
                          uint32_t n_views, double width, double height, const ecal_calib_options *opt, ecal_calib_result *res,
                          double *rvecs /*[V][3] or NULL*/, double *tvecs /*[V][3] or NULL*/, double *per_view_err /*[V] or NULL*/);
+
+/* The fisheye init calibration (cv::fisheye::calibrate at EventCalibIni.cpp:186-190) with ONE start procedure for every
+ * caller: the reference's own start first (principal point at the centre, f = max(w, h) / pi, no guess); only when that fails —
+ * ECAL_ERR_INVALID or a non-finite result — the radial model is calibrated on the same views with
+ * ECAL_CALIB_FISHEYE_PRECALIB_FLAGS and its fx, fy, cx, cy start the fisheye model (ECAL_CALIB_USE_INTRINSIC_GUESS).
+ * *start_used: 0 the reference's start, 1 the radial guess was needed, 2 the caller's own guess (opt->flags carries
+ * ECAL_CALIB_USE_INTRINSIC_GUESS, res->intr the guess).  opt->model is ignored (fisheye). */
+#define ECAL_CALIB_FISHEYE_PRECALIB_FLAGS                                                                                  \
+    (ECAL_CALIB_FIX_PRINCIPAL_POINT | ECAL_CALIB_ZERO_TANGENT_DIST | ECAL_CALIB_FIX_ASPECT_RATIO | ECAL_CALIB_FIX_K3 | ECAL_CALIB_FIX_K4 | \
+     ECAL_CALIB_FIX_K5 | ECAL_CALIB_FIX_K6)
+int ecal_calibrate_fisheye_views(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const double *img, uint32_t n_views, double width,
+                                 double height, const ecal_calib_options *opt, ecal_calib_result *res, double *rvecs, double *tvecs,
+                                 double *per_view_err, int *start_used);
 
 /* ---- initial spline fit + evaluation (host; no GPU involved) -------------------------------------------
  * ecal_spline_fit: BsplineReal<dim>(3, Q, controlPointsNum, u) (core/spline/include/opengv2/spline/

@@ -36,3 +36,16 @@ def _oracle_kd_backend(request):
     import oracle_lib as O
     O.set_kd_backend(request.node.get_closest_marker("gpu") is not None and O.have_ref_kdtree())
     yield
+
+
+@pytest.fixture(autouse=True)
+def _resync_library_switches():
+    """The library reads its ECAL_* debug switches once per context; a test that changed one (monkeypatch restores the
+    environment at teardown, before this fixture's) leaves no live context on a stale value."""
+    yield
+    mod = sys.modules.get("eventcalib_amd.capi")
+    if mod is not None and hasattr(mod, "sync_env"):
+        try:
+            mod.sync_env()
+        except Exception:
+            pass

@@ -27,8 +27,10 @@ def run(seeds, rates=RATES, pieces_list=PIECES, ctx=None, verbose=True, n=1_200_
             torch.cuda.synchronize()
             t_first, t_last = 5.0, 5.0 + (n - 1) / rate
             os.environ.pop("ECAL_ADAPTIVE_DEPTH", None); os.environ.pop("ECAL_ADAPTIVE_DEPTH_MAX", None)
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             a = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last)
             os.environ["ECAL_ADAPTIVE_DEPTH"] = "1"; os.environ["ECAL_ADAPTIVE_DEPTH_MAX"] = "1"
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             b = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last)
             for k in ("time", "duration", "events_num", "features"):
                 assert np.array_equal(a[k], b[k]), (seed, rate, pieces, k)
@@ -41,8 +43,10 @@ def run(seeds, rates=RATES, pieces_list=PIECES, ctx=None, verbose=True, n=1_200_
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
+                __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             else:
                 os.environ[k] = v
+                __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         if own:
             ctx.close()
     return dict(runs=n_ok, keyframes=n_kf)

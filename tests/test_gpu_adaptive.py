@@ -120,6 +120,7 @@ def test_look_ahead_does_not_change_the_keyframes(env, slots, chain, monkeypatch
     want = detect_keyframes_device(ctx, ev, 5e-4, 4000, 23, t_first, t_last)
     monkeypatch.setenv("ECAL_ADAPTIVE_DEPTH", str(slots))
     monkeypatch.setenv("ECAL_ADAPTIVE_DEPTH_MAX", str(chain))
+    __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     got = detect_keyframes_device(ctx, ev, 5e-4, 4000, 23, t_first, t_last)
     assert len(want["time"]) >= 20
     for k in ("time", "duration", "events_num", "features"):

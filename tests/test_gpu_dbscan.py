@@ -158,12 +158,15 @@ def test_pixel_and_general_kernels_agree(ctx):
     off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint32)
     for eps, minpts in ((4.0, 2), (3.0, 1), (5.0, 5), (4.5, 2), (15.0, 3), (16.0, 2)):
         os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+        __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         la, na = ctx.dbscan_batch(xy, off, eps, minpts)
         os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
+        __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             lb, nb = ctx.dbscan_batch(xy, off, eps, minpts)
         finally:
             os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         assert np.array_equal(la, lb) and np.array_equal(na, nb), (eps, minpts)
         ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)
         assert np.array_equal(la, ref_l) and np.array_equal(na, ref_n), (eps, minpts)
@@ -185,12 +188,15 @@ def test_compiled_and_generic_disc_agree(ctx):
     off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint32)
     for eps, minpts in ((4.0, 2), (4.0, 1), (4.0, 5), (4.1, 2)):
         os.environ.pop("ECAL_DBSCAN_GENERIC_DISC", None)
+        __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         la, na = ctx.dbscan_batch(xy, off, eps, minpts)
         os.environ["ECAL_DBSCAN_GENERIC_DISC"] = "1"
+        __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             lb, nb = ctx.dbscan_batch(xy, off, eps, minpts)
         finally:
             os.environ.pop("ECAL_DBSCAN_GENERIC_DISC", None)
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         assert np.array_equal(la, lb) and np.array_equal(na, nb), (eps, minpts)
         ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)
         assert np.array_equal(la, ref_l) and np.array_equal(na, ref_n), (eps, minpts)

@@ -258,6 +258,7 @@ def test_counter_words_from_the_ring_or_wiped_per_call(env, monkeypatch):
             for a, b in zip(snapshot(), want):
                 assert torch.equal(a, b)
     monkeypatch.setenv("ECAL_NO_ZERO_RING", "1")
+    __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     pipe.run(ev)
     for a, b in zip(snapshot(), want):
         assert torch.equal(a, b)

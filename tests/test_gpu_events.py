@@ -158,6 +158,7 @@ def test_pixel_and_general_slicers_agree(env, shift):
     for var in (None, "ECAL_SLICE_SORT_KERNEL", "ECAL_SLICE_NO_PIXEL"):
         if var:
             os.environ[var] = "1"
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             pipe.set_windows(t0, t1)
             pipe.run(d, slots=20000)
@@ -168,6 +169,7 @@ def test_pixel_and_general_slicers_agree(env, shift):
         finally:
             if var:
                 os.environ.pop(var, None)
+                __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     n_pts = int(outs[0][2].sum())
     for o in outs[1:]:
         assert np.array_equal(outs[0][2], o[2]) and np.array_equal(outs[0][1], o[1])
@@ -236,6 +238,7 @@ def test_single_odd_event_sends_the_window_to_the_general_slicer(env):
     for no_pixel in (False, True):
         if no_pixel:
             os.environ["ECAL_SLICE_NO_PIXEL"] = "1"
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             p = DetectPipeline(ctx)
             p.set_windows(t0, t1)
@@ -246,6 +249,7 @@ def test_single_odd_event_sends_the_window_to_the_general_slicer(env):
                          p.event_point[:60000].cpu().numpy().copy(), p.xy[:60000].cpu().numpy().copy()))
         finally:
             os.environ.pop("ECAL_SLICE_NO_PIXEL", None)
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     a, b = outs
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     used = np.zeros(60000, bool)
@@ -272,6 +276,7 @@ def test_hash_slicer_second_pass_equals_general_slicer(env):
     for no_pixel in (False, True):
         if no_pixel:
             os.environ["ECAL_SLICE_NO_PIXEL"] = "1"
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             p = DetectPipeline(ctx)
             p.set_windows(t0, t1)
@@ -284,6 +289,7 @@ def test_hash_slicer_second_pass_equals_general_slicer(env):
                          p.win_base[:S + 1].cpu().numpy().copy()))
         finally:
             os.environ.pop("ECAL_SLICE_NO_PIXEL", None)
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     a, b = outs
     assert int((a[1] - a[0]).max()) > 2048 and int((a[1] - a[0]).max()) < 4096
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])

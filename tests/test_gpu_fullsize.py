@@ -151,11 +151,13 @@ def test_pixel_kernel_equals_general_tiers_repeatedly(run):
     p2 = DetectPipeline(ctx)
     p2.set_windows(t0, t1)
     os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
+    __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     try:
         p2.run(ev, detect=False)
         torch.cuda.synchronize()
     finally:
         os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+        __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     ref_l, ref_n = p2.labels.clone(), p2.n_clusters[:2 * S].clone()
     off, cnt = p2.seg_off[:2 * S].long(), p2.seg_cnt[:2 * S].long()
     used = torch.repeat_interleave(off, cnt) + (torch.arange(int(cnt.sum()), device="cuda") -
@@ -234,8 +236,10 @@ def test_a_tie_pick_that_cannot_be_reproduced_is_flagged_not_silent(monkeypatch)
     for mode in ("exact", "exact_small_arena", "plain"):
         if mode == "exact_small_arena":
             monkeypatch.setenv("ECAL_BO_BIG_ARENA", "64")
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         else:
             monkeypatch.delenv("ECAL_BO_BIG_ARENA", raising=False)
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         ctx = eventcalib_amd.Context(0)
         try:
             pipe = DetectPipeline(ctx)

@@ -113,6 +113,7 @@ def test_lm_recovers_ground_truth_and_matches_reference_loop(ctx, device_solve, 
     from eventcalib_amd.capi import Solver
     if device_solve:
         monkeypatch.setenv("ECAL_SOLVER_DEVICE_LINEAR_SOLVE", "1")
+        __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     rng = np.random.default_rng(4)
     prob, x_gt = SV.make_problem(n_res, n_cp=n_cp, seed=4)
     x0 = SV.perturb(x_gt, n_cp, rng)
@@ -244,14 +245,17 @@ def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
         for parts in ([None] if n_cp >= 28 else []) + ([2, 3, 5, 8, 16] if n_cp >= 131 else []):
             if parts is None:
                 os.environ.pop("ECAL_HOST_ARROW_PARTS", None)
+                __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             else:
                 os.environ["ECAL_HOST_ARROW_PARTS"] = str(parts)
+                __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             try:
                 d = np.zeros(nt)
                 fail = ctypes.c_int(-1)
                 rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d.ctypes.data, ctypes.byref(fail), 2)
             finally:
                 os.environ.pop("ECAL_HOST_ARROW_PARTS", None)
+                __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             assert rc == 0 and fail.value == 0, (rc, fail.value, parts)
             assert np.abs(d - host).max() <= 1e-9 * np.abs(host).max(), (n_cp, parts, radius, np.abs(d - host).max(), np.abs(host).max())
         # and it solves the system: (S A S + D) y = -S g, checked densely for the small cases
