@@ -93,10 +93,13 @@ def check_pose(R_ref, twb_ref, t_ref, R_cur, twb_cur, t_cur, step):
 
 def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, frame_event_num_threshold=4000, piece_num=30,
                      frames_to_use=200, width=346.0, height=260.0, rows=9, cols=4, square=5.5, circle_radius=1.75,
-                     flags=None, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2, gate_mode=0,
-                     fisheye=False):
+                     flags=None, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2,
+                     gate_mode=capi.GATE_SHARED_MAP, fisheye=False):
     """events: uint8 CUDA tensor of packed 25-byte records.  Returns a dict with the initial calibration, the refined
     intrinsics [fx fy cx cy k1..k5 (inverse radial polynomial)] and the keyframe trajectory.
+    gate_mode: capi.GATE_SHARED_MAP (default: the reference's keyframe gate as its single-worker run computes it — one keyframe
+    map for all pieces) or capi.GATE_OWN_PIECE (the schedule-free own-piece gate: 2 - 3 x faster keyframe search, every piece's
+    first success ungated).
     fisheye (Calibrate_UseFisheyeModel: 1; BASELINE configs[4]): cv::fisheye::calibrate's model in the init stage
     (EventCalibIni.cpp:186-190), and — new: the reference stops at EventCalibSpline.cpp:97-99 — the Kannala-Brandt camera in
     the PnP, in rectifyFeatures' projections and in the spline solve (k1..k5 = the inverse angle polynomial)."""

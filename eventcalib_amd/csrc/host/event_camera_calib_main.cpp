@@ -58,8 +58,13 @@ int main(int argc, char **argv) {
     auto pattern = cs->circlePatternParameters;
     CirclesEventFrame::Params fp(fsSettings);                // :171
     int pieceNum = 30;                                       // (the reference: 5 * (hardware threads - 2), :172-173; the result
-    fsSettings["PieceNum"] >> pieceNum;                      //  of the build's own-piece gate depends on it, so the test pins it)
-    std::vector<KeyFrame> kfs = detect_keyframes_device(*container, pattern, fp, step, frameEventNumThreshold, pieceNum, startTime, endTime);
+    fsSettings["PieceNum"] >> pieceNum;                      //  depends on it, so the test pins it)
+    // GateMode (a key of this build, optional): 1 = ECAL_GATE_SHARED_MAP, the reference's semantics with one worker thread (the
+    // default: one keyframe map for all pieces, TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36); 0 = ECAL_GATE_OWN_PIECE, the
+    // faster schedule-free gate (every piece's first success ungated)
+    int gateMode = ECAL_GATE_SHARED_MAP;
+    fsSettings["GateMode"] >> gateMode;
+    std::vector<KeyFrame> kfs = detect_keyframes_device(*container, pattern, fp, step, frameEventNumThreshold, pieceNum, startTime, endTime, gateMode);
     std::printf("keyframes %zu\n", kfs.size());
     stage("keyframe_search");
     EventCalibIni ini(cs, step);

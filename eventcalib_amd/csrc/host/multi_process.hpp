@@ -184,7 +184,7 @@ inline std::vector<KeyFrame> detect_keyframes(EventContainer &container, CircleP
 inline std::vector<KeyFrame> detect_keyframes_device(EventContainer &container, CirclePatternParameters::Ptr pattern,
                                                      const CirclesEventFrame::Params &params, double motionTimeStep,
                                                      int frameEventNumThreshold, int pieceNum, double startTime, double endTime,
-                                                     int gateMode = ECAL_GATE_OWN_PIECE, int pieceFirst = 0, int pieceCount = 0) {
+                                                     int gateMode = ECAL_GATE_SHARED_MAP, int pieceFirst = 0, int pieceCount = 0) {
     // (pieceCount != 0: only the pieces pieceFirst .. pieceFirst + pieceCount - 1, with the bounds they have in the whole run —
     // the cut of one search over processes / GPUs; own-piece gate only)
     ecal_detect_params prm;

@@ -135,8 +135,8 @@ int main(int argc, char **argv) {
         std::printf("kf %.12f %.12f %d %.9f %.9f\n", kfs[k].duration.first, kfs[k].duration.second, kfs[k].eventsNum,
                     kfs[k].features[0].location[0], kfs[k].features[35].radius);
     }
-    // the same search with the policy on the device: identical keyframes
-    std::vector<KeyFrame> kfd = detect_keyframes_device(*container, pattern, fp, step, 4000, 4, t0, container->lastTime());
+    // the same search (the own-piece gate of detect_keyframes) with the policy on the device: identical keyframes
+    std::vector<KeyFrame> kfd = detect_keyframes_device(*container, pattern, fp, step, 4000, 4, t0, container->lastTime(), ECAL_GATE_OWN_PIECE);
     CHECK(kfd.size() == kfs.size());
     for (size_t k = 0; k < kfd.size() && k < kfs.size(); k++) {
         CHECK(kfd[k].timeStamp == kfs[k].timeStamp && kfd[k].duration == kfs[k].duration && kfd[k].eventsNum == kfs[k].eventsNum);
@@ -145,5 +145,10 @@ int main(int argc, char **argv) {
                   kfd[k].features[c].location[1] == kfs[k].features[c].location[1] && kfd[k].features[c].radius == kfs[k].features[c].radius);
     }
     std::printf("device policy: %zu keyframes, identical\n", kfd.size());
+    // the shim's default: the reference's single-worker gate (one keyframe map for all pieces) — only the run's very first
+    // success is ungated, so it never keeps more frames than the own-piece gate, and its first keyframe is the same one
+    std::vector<KeyFrame> kfm = detect_keyframes_device(*container, pattern, fp, step, 4000, 4, t0, container->lastTime());
+    CHECK(!kfm.empty() && kfm.size() <= kfs.size() && kfm[0].timeStamp == kfs[0].timeStamp);
+    std::printf("shared-map gate (default): %zu keyframes\n", kfm.size());
     return 0;
 }
