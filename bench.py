@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_EVENT = 29.0     # 25 B record read once + 4 B int32 label written once
-TRAFFIC_PROFILE = "r03c_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
+TRAFFIC_PROFILE = "r04_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -78,6 +78,9 @@ def main():
                     help="pieces of the adaptive-window policy P2 (SURVEY 8d) measured after M1 (0 = skip; -1 = the reference's "
                          "own choice on this host, 5 * (hardware threads - 2), and 4096)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe upload timing")
+    ap.add_argument("--no-fixed-cost", action="store_true",
+                    help="skip the pass_ms_fixed measurement (passes over S / 2 and S / 4 windows: under a profiler they would mix "
+                         "smaller launches into the kernels' average durations)")
     ap.add_argument("--event-point", action="store_true",
                     help="the timed passes also write the event -> point map (4 B per event; an output of this library's own that "
                          "only the association stage reads — the reference's EventFrame has no such member)")
@@ -257,7 +260,7 @@ def main():
     # bounds, per-kernel ramp-up): passes over the first S, S/2 and S/4 windows, straight line through the three times,
     # its value at zero windows.  At N = 8 a rank's pass is an eighth of the stream: this is what caps strong scaling.
     pass_ms_fixed = None
-    if rank == 0 and args.steps > 0 and S >= 64:
+    if rank == 0 and args.steps > 0 and S >= 64 and not args.no_fixed_cost:
         sizes, times = [S, S // 2, S // 4], []
         reps = max(10, args.steps)
         for Sw in sizes:
@@ -419,7 +422,7 @@ def main():
         if plain_extract_ms is not None:
             kernel_ms[3] = float(plain_extract_ms)
         dom = int(np.argmax(kernel_ms))
-        names = ["window_bounds_kernel", "slice_hash_ref_kernel", "dbscan_pixel_kernel", "extract_kernel"]   # reference point order (the default)
+        names = ["window_bounds_base_kernel", "slice_hash_ref_kernel", "dbscan_pixel_kernel", "extract_kernel"]   # reference point order (the default)
         achieved = ALGO_BYTES_PER_EVENT * n_covered / (kernel_ms[dom] * 1e-3) / 1e9      # rank 0's launch: the events of ITS windows
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
         # committed profile (tools/pmc_traffic.py over two rocprofv3 --pmc passes of this same command) is
@@ -430,7 +433,7 @@ def main():
             if tr.get("events") == n_events:
                 # the detection kernels of one timed pass: every kernel of the profile's passes (a pass = one launch of
                 # window_bounds_kernel) except the other legs' — the fused pass, the plain extraction (MODE 0), solver, calibration
-                passes = max(1, max(v.get("launches", 0) for k, v in tr["kernels"].items() if "window_bounds_kernel" in k))
+                passes = max(1, max(v.get("launches", 0) for k, v in tr["kernels"].items() if "window_bounds" in k))
                 skip = ("normal_eq", "reduce_heads", "calib_", "view_", "residual_rows", "arrow_", "lm_plus", "solver_", "bucket_table",
                         "associate", "scan_blocks", "detect_fused", "extract_kernel<false, 0>", "extract_list_kernel<false, 0>",
                         "extract_first_list_kernel<false, 0>", "grid_order", "adaptive_", "gather_features", "rectify", "pnp_", "sort_")
