@@ -473,9 +473,20 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
             else if (seed[lab[i]] == BO_NONE - 1u) order[base + i] = -2;
         // (a thread per small cluster; a wave per large one, its lanes taking one neighbour of the popped point each: the pops
         // of one cluster are a dependent chain, and in a lock-step pass of the adaptive policy that chain is the kernel's latency)
+        // Round 4: when FEW clusters are wanted — the exact extraction marks one or two per segment — every one of them gets a
+        // wave, whatever its size: a thread walks a popped point's ~10 neighbours one after the other (each a chain of four LDS
+        // operations), a wave takes them side by side; with one or two threads at work and 254 idle that walk was 43 % of
+        // the kernel (tools/phase_prof.py).
+        {
+            uint32_t mine = 0;
+            for (uint32_t c = tid; c < nc; c += BO_T) mine += seed[c] < BO_NONE - 1u ? 1u : 0u;
+            if (mine) atomicAdd(&red[6], mine);   // (red[6] = 0 since the segment's start)
+            __syncthreads();
+        }
+        const bool few_wanted = red[6] <= 2u * (BO_T / 64u);
         for (uint32_t c = tid; c < nc; c += BO_T) {
             const uint32_t qb = qbase[c], sd = seed[c];
-            if (sd >= BO_NONE - 1u || qbase[c + 1] - qb >= BO_WAVE_MIN) continue;   // not wanted (or, impossible, without members)
+            if (sd >= BO_NONE - 1u || qbase[c + 1] - qb >= BO_WAVE_MIN || few_wanted) continue;   // not wanted (or, impossible, without members)
             uint32_t head = 0, tail = 1;
             queue[qb] = (uint16_t) sd;
             atomicOr(&inq[sd >> 5], 1u << (sd & 31u));
@@ -500,7 +511,7 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
             const uint32_t lane = tid & 63u;
             for (uint32_t c = tid >> 6; c < nc; c += BO_T / 64u) {   // (uniform in the wave)
                 const uint32_t qb = qbase[c], sd = seed[c];
-                if (sd >= BO_NONE - 1u || qbase[c + 1] - qb < BO_WAVE_MIN) continue;
+                if (sd >= BO_NONE - 1u || (qbase[c + 1] - qb < BO_WAVE_MIN && !few_wanted)) continue;
                 uint32_t head = 0, tail = 1;
                 if (lane == 0) {
                     queue[qb] = (uint16_t) sd;
