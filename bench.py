@@ -78,6 +78,9 @@ def main():
                     help="pieces of the adaptive-window policy P2 (SURVEY 8d) measured after M1 (0 = skip; -1 = the reference's "
                          "own choice on this host, 5 * (hardware threads - 2), and 4096)")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe upload timing")
+    ap.add_argument("--profile", action="store_true",
+                    help="roctx ranges around the library's stage entry points (ecal_set_profile_ranges): run under `rocprofv3 "
+                         "--marker-trace --kernel-trace --stats -- python3 bench.py --profile ...`")
     ap.add_argument("--no-fixed-cost", action="store_true",
                     help="skip the pass_ms_fixed measurement (passes over S / 2 and S / 4 windows: under a profiler they would mix "
                          "smaller launches into the kernels' average durations)")
@@ -112,9 +115,19 @@ def main():
                "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
+    # Thread pools sized for the cores this process may actually use: the GPU box shows 256 hardware threads behind a cgroup
+    # quota of 16 CPUs, and a BLAS / OpenMP pool of 256 busy-waiting threads (numpy's polyfit, torch's CPU copies) gets the whole
+    # cgroup throttled for the next legs — the keyframe search, whose host side polls a counter per pass, then runs at a third
+    # of its speed (measured: 0.069 s against 0.235 s for the same search in the same process).
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ.setdefault(var, str(max(1, min(usable_cpus(), 16))))
     import numpy as np
     import torch
     import torch.distributed as dist
+    try:
+        torch.set_num_threads(max(1, min(usable_cpus(), 16)))
+    except RuntimeError:
+        pass
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,6 +162,8 @@ def main():
         dist.broadcast(idt, 0)
         ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
     pipe = DetectPipeline(ctx, dev)
+    if args.profile:
+        ctx.set_profile_ranges(True)
 
     # ---- synthetic input, resident in HBM before the timed region: ONE stream of --events events (seed 12345, from t = 5 s);
     # N ranks: cut into N contiguous ranges of whole windows, one per rank (tiled windows do not overlap; the adaptive policy's

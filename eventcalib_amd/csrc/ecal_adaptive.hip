@@ -470,6 +470,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
                                      const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                                      double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
                                      uint32_t *passes, uint64_t *windows) {
+    const ecal_range range__(ctx, "ecal_detect_keyframes");
     if (!ctx) return ECAL_ERR_INVALID;
     // the search's windows are three to ten steps long: second-tier work by design, so its passes launch every tier
     // (ecal_set_tail_mode; a context left in ECAL_TAIL_AUTO would spend the first pass finding that out)

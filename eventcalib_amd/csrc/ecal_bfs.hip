@@ -907,6 +907,7 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
                              uint32_t n_points, double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order,
                              uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
                              void *stream, const ecal_packed_points *pk) {
+    const ecal_range range__(ctx, "ecal_cluster_order");
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;

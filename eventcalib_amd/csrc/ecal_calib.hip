@@ -893,6 +893,7 @@ extern "C" void ecal_calib_default_options(ecal_calib_options *o) {
 extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const double *img, uint32_t n_views, double width,
                                     double height, const ecal_calib_options *opt_in, ecal_calib_result *res, double *rvecs, double *tvecs,
                                     double *per_view_err) {
+    const ecal_range range__(ctx, "ecal_calibrate_views");
     if (!ctx) return ECAL_ERR_INVALID;
     const ecal_calib_options *opt = opt_in;   // opt->allreduce == NULL: rank-local, always (ecal_comm_allreduce is explicit)
     if (!obj || (!img && n_views) || !opt || !res || n_pts < 4 || n_pts > CB_MAXPTS || (opt->model != 0 && opt->model != 1) ||

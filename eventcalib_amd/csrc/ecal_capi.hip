@@ -1,4 +1,5 @@
 // Context lifecycle and shared helpers of libecal.so.
+#include <dlfcn.h>
 #include "ecal_ctx.hpp"
 
 constexpr uint32_t ZERO_RING_WORDS = 16384, ZERO_RING_GRAIN = 16;
@@ -131,12 +132,14 @@ extern "C" int ecal_init(int device, ecal_ctx **out) {
     }
     ecal_read_switches(ctx->sw);
     if (const char *e = getenv("ECAL_MEDIAN_TIES")) ctx->median_ties = atoi(e) ? ECAL_TIES_SMALLER_PID : ECAL_TIES_REFERENCE;   // debug switch
+    if (getenv("ECAL_ROCTX")) (void) ecal_set_profile_ranges(ctx, 1);   // (no marker library: no ranges, not an error)
     if (const char *e = getenv("ECAL_TAIL_MODE")) ctx->tail_mode = atoi(e);   // debug switch (0 auto, 1 every tier, 2 lean)
     if (hipHostMalloc((void **) &ctx->tail_seen, ECAL_TAIL_SLOTS * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
         hipHostGetDevicePointer((void **) &ctx->tail_seen_dev, ctx->tail_seen, 0) == hipSuccess) {
         for (int k = 0; k < ECAL_TAIL_SLOTS; k++) ctx->tail_seen[k] = 0xFFFFFFFFu;
     } else {   // no mapped host memory: every tier every time
         if (ctx->tail_seen) (void) hipHostFree(ctx->tail_seen);
+    if (ctx->roctx_lib) (void) dlclose(ctx->roctx_lib);
         ctx->tail_seen = ctx->tail_seen_dev = nullptr;
         (void) hipGetLastError();
     }
@@ -172,6 +175,34 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     }
     for (ecal_devbuf *b : ctx->all_bufs()) release(*b);
     delete ctx;
+}
+
+extern "C" int ecal_set_profile_ranges(ecal_ctx *ctx, int on) {
+    if (!ctx) return ECAL_ERR_INVALID;
+    if (!on) {
+        ctx->roctx_push = nullptr;
+        ctx->roctx_pop = nullptr;
+        return ECAL_OK;
+    }
+    if (!ctx->roctx_lib) {
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            ctx->roctx_lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (ctx->roctx_lib) break;
+        }
+    }
+    if (!ctx->roctx_lib) {
+        ctx->last_error = "ecal_set_profile_ranges: no roctx library (librocprofiler-sdk-roctx.so / libroctx64.so) to be found";
+        return ECAL_ERR_INVALID;
+    }
+    ctx->roctx_push = (int (*)(const char *)) dlsym(ctx->roctx_lib, "roctxRangePushA");
+    ctx->roctx_pop = (int (*)()) dlsym(ctx->roctx_lib, "roctxRangePop");
+    if (!ctx->roctx_push || !ctx->roctx_pop) {
+        ctx->roctx_push = nullptr;
+        ctx->roctx_pop = nullptr;
+        ctx->last_error = "ecal_set_profile_ranges: roctxRangePushA / roctxRangePop not exported";
+        return ECAL_ERR_INVALID;
+    }
+    return ECAL_OK;
 }
 
 extern "C" int ecal_set_tail_mode(ecal_ctx *ctx, int mode) {

@@ -91,6 +91,12 @@ struct ecal_ctx {
     // every listed window / segment is processed: the choice moves time, never results.
     uint32_t *tail_seen = nullptr, *tail_seen_dev = nullptr;   // [ECAL_TAIL_SLOTS]; 0xFFFFFFFF = not known yet
     int tail_mode = 0;                                         // ECAL_TAIL_AUTO / _TIERED / _LEAN (ecal_set_tail_mode)
+    // roctx ranges around the stage entry points (ECAL_ROCTX=1 at ecal_init, or ecal_set_profile_ranges): the marker library
+    // (librocprofiler-sdk-roctx.so) is looked up at run time — no link-time dependency —, `rocprofv3 --marker-trace
+    // --kernel-trace` then shows which stage call every kernel belongs to (tracing)
+    int (*roctx_push)(const char *) = nullptr;
+    int (*roctx_pop)() = nullptr;
+    void *roctx_lib = nullptr;
     uint32_t n_cu = 256;  // compute units of the device (grid size of the persistent kernels)
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false, fused_attr_set = false, bfs_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
@@ -140,6 +146,18 @@ inline bool ecal_tail_lean(const ecal_ctx *ctx, int first, int n) {
         if (__atomic_load_n(ctx->tail_seen + first + k, __ATOMIC_RELAXED) != 0u) return false;
     return true;
 }
+// a roctx range for the lifetime of the object (nothing when the context has no marker library loaded)
+struct ecal_range {
+    const ecal_ctx *c;
+    ecal_range(const ecal_ctx *ctx, const char *name) : c(ctx && ctx->roctx_push ? ctx : nullptr) {
+        if (c) (void) c->roctx_push(name);
+    }
+    ~ecal_range() {
+        if (c && c->roctx_pop) (void) c->roctx_pop();
+    }
+    ecal_range(const ecal_range &) = delete;
+    ecal_range &operator=(const ecal_range &) = delete;
+};
 // n <= 16 words that are zero once everything enqueued on `st` so far has run, or nullptr (more streams than rings, no memory):
 // the caller then zeroes words of its own.  They stay the caller's for the next 512 calls on that stream at least.
 uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n);

@@ -288,6 +288,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
                                             const uint32_t *d_seg_cnt, uint32_t S, uint32_t n_points, uint32_t max_seg_points,
                                             double eps, uint32_t minpts, int32_t *d_labels, uint32_t *d_n_clusters,
                                             const ecal_packed_points *pk, void *stream) {
+    const ecal_range range__(ctx, "ecal_dbscan_batch");
     if (!ctx) return ECAL_ERR_INVALID;
     if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
     const uint32_t *const xy16 = pk ? pk->d_xy16 : nullptr, *const sfmt = pk ? pk->d_seg_fmt : nullptr;

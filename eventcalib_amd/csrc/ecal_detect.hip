@@ -373,6 +373,7 @@ int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                          uint32_t need_clusters, double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,
                          uint32_t *d_cand_pair, double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, void *stream,
                          const ecal_packed_points *pk) {
+    const ecal_range range__(ctx, "ecal_extract_batch");
     if (ctx && ctx->median_ties == ECAL_TIES_REFERENCE)
         return extract_exact(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, eps, cluster_min, need_clusters,
                              radius_threshold, fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, pk, stream);

@@ -904,6 +904,7 @@ static constexpr int SCAP0 = 2048, SCAP1 = 5120;
 extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_t0,
                                       const double *d_t1, uint32_t S, uint32_t *d_win_lo, uint32_t *d_win_hi,
                                       uint32_t *d_win_base, void *stream) {
+    const ecal_range range__(ctx, "ecal_window_bounds");
     if (!ctx) return ECAL_ERR_INVALID;
     if (n_events > 0xFFFFFFFFull) {
         ctx->last_error = "more than 2^32-1 events in one stream";
@@ -1020,6 +1021,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                                             uint32_t S, uint32_t max_win_events, uint32_t cap_points, double *d_xy,
                                             uint32_t *d_seg_off, uint32_t *d_seg_cnt, int32_t *d_event_point, int *d_overflow,
                                             const ecal_packed_points *pk, void *stream) {
+    const ecal_range range__(ctx, "ecal_slice_events");
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;

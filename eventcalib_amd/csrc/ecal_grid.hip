@@ -702,6 +702,7 @@ using namespace ecal;
 extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off,
                                    const double *d_cand_xyr, uint32_t S, uint32_t rows, uint32_t cols,
                                    int32_t *d_order, uint32_t *d_found, void *stream) {
+    const ecal_range range__(ctx, "ecal_grid_order");
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (!d_win_info || !d_seg_off || !d_cand_xyr || !d_order || !d_found || rows * cols < 4 || rows * cols > GR_MAXM) {

@@ -764,6 +764,7 @@ extern "C" uint64_t ecal_solver_num_residuals(const ecal_solver *s) { return s ?
 
 extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum,
                                         void *stream) {
+    const ecal_range range__(s ? s->ctx : nullptr, with_jacobian ? "ecal_solver_evaluate (normal equations)" : "ecal_solver_evaluate (cost)");
     if (!s || !d_params || !d_accum) return ECAL_ERR_INVALID;
     ecal_ctx *ctx = s->ctx;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1328,6 +1329,7 @@ static int device_lm_solve(ecal_solver *s, double *params, const ecal_lm_options
 
 extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_options *opt_in,
                                  ecal_lm_summary *sum) {
+    const ecal_range range__(s ? s->ctx : nullptr, "ecal_solver_solve");
     if (!s || !params) return ECAL_ERR_INVALID;
     ecal_lm_options opt;
     if (opt_in) opt = *opt_in; else ecal_lm_default_options(&opt);

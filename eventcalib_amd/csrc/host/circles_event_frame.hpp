@@ -75,6 +75,50 @@ public:
     }
     const std::vector<CalibCircle> &features() const { return features_; }
 
+    // CirclesEventFrame::image() as the reference's driver saves it (eventCameraCalib.cpp:214-227): black sensor-sized RGB
+    // raster; the kept clusters' pixels in the reference's colours (BGR (c / 256, c % 256, 200 | 100), c = 20 x cluster index,
+    // CirclesEventFrame.cpp:89-117); the candidate circles in green (:315-318) and the features of the grid in white (:626).
+    // cv::circle's rasterisation and drawChessboardCorners are OpenCV's: the outlines here are midpoint circles, the grid's
+    // row connections are left out — a diagnostic picture, not a parity item.
+    std::vector<uint8_t> image() {
+        ensure();
+        const int w = (int) container_->cameraSize[0], h = (int) container_->cameraSize[1];
+        std::vector<uint8_t> rgb((size_t) w * h * 3, 0);
+        auto put = [&](int x, int y, uint8_t r, uint8_t g, uint8_t b) {
+            if (x < 0 || y < 0 || x >= w || y >= h) return;
+            uint8_t *p = &rgb[3 * ((size_t) y * w + x)];
+            p[0] = r, p[1] = g, p[2] = b;
+        };
+        auto ring = [&](double cx, double cy, double rad, uint8_t r, uint8_t g, uint8_t b) {
+            const int x0 = (int) cx, y0 = (int) cy, R = (int) rad;   // cv::Point(double, double) / int radius truncate
+            int x = R, y = 0, err = 1 - R;
+            while (x >= y) {
+                const int px[8] = {x, y, -y, -x, -x, -y, y, x}, py[8] = {y, x, x, y, -y, -x, -x, -y};
+                for (int k = 0; k < 8; k++) put(x0 + px[k], y0 + py[k], r, g, b);
+                y++;
+                if (err < 0) err += 2 * y + 1;
+                else {
+                    x--;
+                    err += 2 * (y - x) + 1;
+                }
+            }
+        };
+        for (size_t i = 0; i < det_.positive.size(); i++)
+            if (i < det_.keptPos.size() && det_.keptPos[i] >= 0) {
+                const unsigned c = 20u * (unsigned) det_.keptPos[i];
+                put((int) det_.positive[i][0], (int) det_.positive[i][1], 200, (uint8_t) (c % 256), (uint8_t) (c / 256));   // BGR (c/256, c%256, 200)
+            }
+        for (size_t i = 0; i < det_.negative.size(); i++)
+            if (i < det_.keptNeg.size() && det_.keptNeg[i] >= 0) {
+                const unsigned c = 20u * (unsigned) det_.keptNeg[i];
+                put((int) det_.negative[i][0], (int) det_.negative[i][1], 100, (uint8_t) (c % 256), (uint8_t) (c / 256));
+            }
+        for (size_t i = 0; i < det_.candidateCenters.size(); i++)
+            ring(det_.candidateCenters[i][0], det_.candidateCenters[i][1], det_.candidatesRadius[i], 0, 255, 0);
+        for (const CalibCircle &f : features_) ring(f.location[0], f.location[1], f.radius, 255, 255, 255);
+        return rgb;
+    }
+
     // camera model rectifyFeatures projects with (the reference reads it from sensor_: PinholeCamera K, distCoeffs
     // k1 k2 p1 p2 k3 and size(), CirclesEventFrame.cpp:426-433)
     struct Camera {

@@ -8,7 +8,10 @@
 #include <chrono>
 #include <cstdio>
 
+#include <filesystem>
+
 #include "event_calib_spline.hpp"
+#include "png_writer.hpp"
 
 int main(int argc, char **argv) {
     using namespace opengv2;
@@ -161,5 +164,20 @@ int main(int argc, char **argv) {
     stage("spline_fit_association_lm");
     spline.saveKeyFrameTrajectoryTUM(std::string(argv[3]) + "/TrajectoryByEvent.txt");   // :212
     stage("save_trajectory");
+    if (!batch) {   // :214-227: saveDir/image/<std::to_string(time stamp)>.png of every keyframe in the map
+        const std::string dir = std::string(argv[3]) + "/image";
+        std::error_code ec;
+        std::filesystem::remove_all(dir, ec);
+        std::filesystem::create_directories(dir, ec);
+        size_t written = 0;
+        for (size_t f : res.acceptedFrames) {
+            CirclesEventFrame cf(container, kfs[f].duration, pattern, fp);
+            (void) cf.extractFeatures();
+            if (ecal_host::write_png_rgb(dir + "/" + std::to_string(kfs[f].timeStamp) + ".png", (int) container->cameraSize[0],
+                                         (int) container->cameraSize[1], cf.image()))
+                written++;
+        }
+        std::printf("images %zu\n", written);
+    }
     return 0;
 }

@@ -265,6 +265,12 @@ int ecal_get_median_ties(const ecal_ctx *ctx);
  * force one form (tests; the adaptive search forces TIERED for its passes: its windows are second-tier work by design).
  * The choice moves time only: every listed window is processed either way, results are bit-identical
  * (tests/test_gpu_tail_modes.py). */
+/* roctx ranges around the stage entry points (window bounds, slicing, DBSCAN, extraction, member order, grid ordering, keyframe
+ * search, init calibration, solver evaluations and solves): on != 0 looks the marker library up at run time
+ * (librocprofiler-sdk-roctx.so, else libroctx64.so; ECAL_ERR_INVALID when neither is there), `rocprofv3 --marker-trace
+ * --kernel-trace` then attributes every kernel to its stage call.  ECAL_ROCTX=1 in the environment at ecal_init does the same. */
+int ecal_set_profile_ranges(ecal_ctx *ctx, int on);
+
 #define ECAL_TAIL_AUTO 0
 #define ECAL_TAIL_TIERED 1
 #define ECAL_TAIL_LEAN 2

@@ -153,6 +153,20 @@ def test_cpp_driver_chain(tmp_path):
     traj = np.loadtxt(str(tmp_path / "TrajectoryByEvent.txt"))
     assert traj.shape[1] == 8 and len(traj) == len(py["trajectory"])
     assert np.abs(traj - py["trajectory"]).max() < 1e-3
+    # saveDir/image/<std::to_string(time stamp)>.png of every keyframe in the map (eventCameraCalib.cpp:214-227): sensor-sized RGB
+    # files a PNG decoder accepts, cluster pixels + green candidate circles + white features on black
+    import glob
+    import test_png_writer as TP
+    pngs = sorted(glob.glob(str(tmp_path / "image" / "*.png")))
+    assert len(pngs) == int(init[9]) and lines[3].split() == ["images", str(len(pngs))]
+    png_t = np.sort([float(os.path.basename(f)[:-4]) for f in pngs])
+    assert all(np.abs(png_t - t).min() < 1e-6 for t in traj[:, 0])        # (std::to_string keeps six decimals)
+    img = TP.decode_png(pngs[len(pngs) // 2])
+    assert img.shape == (260, 346, 3)
+    green = (img == [0, 255, 0]).all(axis=2).sum()
+    white = (img == [255, 255, 255]).all(axis=2).sum()
+    cluster = ((img[:, :, 0] == 200) | (img[:, :, 0] == 100)).sum()
+    assert green > 36 * 20 and white > 36 * 20 and cluster > 500 and (img.sum(axis=2) == 0).mean() > 0.8
     # "batch": rectifyFeatures of all keyframes in one device pass (ecal_rectify_keyframes), the file read in one piece —
     # the same chain, the same numbers, plus a time per stage (what bench.py's end_to_end leg runs at 50 M events)
     out2 = subprocess.run([exe, yamlf, binf, str(tmp_path), "batch"], capture_output=True, text=True, timeout=600)
