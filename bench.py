@@ -771,7 +771,7 @@ def cpp_chain(ev, n, rate, t_start, pieces, np):
         stages = {l.split()[1]: round(float(l.split()[2]), 4) for l in out.stdout.splitlines() if l.startswith("stage ")}
         lines = [l for l in out.stdout.splitlines() if not l.startswith("stage ")]
         ref = lines[2].split()
-        after = sum(v for k, v in stages.items() if k not in ("load_file", "upload"))
+        after = sum(v for k, v in stages.items() if k not in ("runtime_init", "load_file", "upload"))
         return {"process_wall_seconds": round(wall, 3), "stage_seconds": stages, "seconds_after_upload": round(after, 4),
                 "keyframes": int(lines[0].split()[1]), "refined_fx": float(ref[1]), "residuals": int(ref[11]),
                 "lm_iterations": int(ref[13]), "splines": int(ref[15]),
@@ -881,6 +881,7 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
     dev_solve = None
     if world == 1:
         os.environ["ECAL_SOLVER_DEVICE_LINEAR_SOLVE"] = "1"
+        ctx.reload_env()      # (the library reads its switches once per context)
         try:
             solver.solve(x0, opt)
             torch.cuda.synchronize(dev)
@@ -892,6 +893,7 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
                          "seconds": round(eld, 4), "final_cost_rel_diff_vs_host_solve": float(abs(sd.final_cost / summ.final_cost - 1))}
         finally:
             del os.environ["ECAL_SOLVER_DEVICE_LINEAR_SOLVE"]
+            ctx.reload_env()
     # SURVEY 8(d)'s ALGORITHMIC count per residual and Jacobian evaluation: ~0.7 kflop residual + analytic gradient, 561 FMA
     # for the upper J^T J, 33 FMA for J^T r = 1.9 kflop (the kernel executes ~2.1 kflop: 6 x 6 tiles pad 34 -> 36 columns)
     FLOP_JAC = 1900.0

@@ -178,7 +178,9 @@ __device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t
                                            const PxGeom &geom, uint32_t minpts, int32_t *__restrict__ labels,
                                            uint32_t *__restrict__ n_clusters, uint32_t *__restrict__ todo,
                                            uint32_t *__restrict__ todo_count, uint32_t known_cnt = 0, uint32_t known_off = 0,
-                                           const uint32_t *__restrict__ xy16 = nullptr, const uint32_t *__restrict__ seg_fmt = nullptr) {
+                                           const uint32_t *__restrict__ xy16 = nullptr, const uint32_t *__restrict__ seg_fmt = nullptr,
+                                           uint32_t *__restrict__ tree_out = nullptr, uint32_t *__restrict__ tree_flag = nullptr,
+                                           uint32_t tree_epoch = 0) {
     using L = PixelLayout<CAP>;
     using F = PxFmt<CAP>;
     using G = GeoI16;
@@ -440,6 +442,19 @@ __device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t
     ECAL_PHASE_MARK(0);
     ECAL_PHASE_COUNT(8, levels__);
     PX_STOP(3, sl[u] ^ (f[u] << 28));
+    // the finished tree goes out for the member-order kernel of the exact extraction (ecal_bfs.hip), which would otherwise
+    // replay these insertions for every segment it is given: child links as two u16 (0xFFFF = none) per point
+    if (tree_out) {
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const uint32_t i = tid + u * T;
+            if (i < n) {
+                const uint32_t l = slot[2 * i], r = slot[2 * i + 1];
+                tree_out[base + i] = (l == NONE32 ? 0xFFFFu : (l >> (2u * F::CB))) | ((r == NONE32 ? 0xFFFFu : (r >> (2u * F::CB))) << 16);
+            }
+        }
+        __syncthreads();   // (the bitmap below takes the child slots' place)
+    }
 
     // ---------------- bitmap of the points (the child slots are dead: same LDS) ----------------
     {   // 16 bytes per store (the region is 16-byte aligned and PX_WORDS + 4 words long: rounding up stays inside)
@@ -740,7 +755,10 @@ __device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t
         const uint32_t i = tid + u * T;
         if (i < n) out[i] = (root[u] == NONE32) ? -1 : (int32_t) rank[root[u]];
     }
-    if (tid == 0) n_clusters[s] = total;
+    if (tid == 0) {
+        n_clusters[s] = total;
+        if (tree_flag) tree_flag[s] = tree_epoch;   // (a segment that was bailed out of keeps an older call's number: no tree)
+    }
     ECAL_PHASE_MARK(4);
 #undef PX_BAIL
 #undef PX_STOP
@@ -756,9 +774,12 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                                                             uint32_t *__restrict__ n_clusters,
                                                             uint32_t *__restrict__ todo,
                                                             uint32_t *__restrict__ todo_count,
-                                                            const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt) {
+                                                            const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt,
+                                                            uint32_t *__restrict__ tree_out, uint32_t *__restrict__ tree_flag,
+                                                            uint32_t tree_epoch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
-    px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt);
+    px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt,
+                         tree_out, tree_flag, tree_epoch);
 }
 
 // second pass (CAP = PX_CAP2): the workgroups share the list of segments the first pass left over

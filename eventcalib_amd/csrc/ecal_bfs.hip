@@ -116,7 +116,9 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
                                                             const uint32_t *__restrict__ win_count,
                                                             uint32_t *__restrict__ defer_list, uint32_t *__restrict__ defer_cnt,
                                                             const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt,
-                                                            int lean /* TIER 2 only: this launch also takes the second launch's list (ecal_ctx::tail_seen) */) {
+                                                            int lean /* TIER 2 only: this launch also takes the second launch's list (ecal_ctx::tail_seen) */,
+                                                            const uint32_t *__restrict__ px_tree = nullptr /* TIER 0: the pixel DBSCAN kernel's trees */,
+                                                            const uint32_t *__restrict__ px_tree_flag = nullptr, uint32_t px_tree_epoch = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using Coord = typename std::conditional<BoLayout<CAP>::CB == 4, float, double>::type;
     Coord *const px = reinterpret_cast<Coord *>(smem + BoLayout<CAP>::px_off);
@@ -352,6 +354,16 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
         // child slot on its side — a slot of depth r + 1, which nobody can have filled before —; the winner is that node, the
         // others go on below it.  One barrier a round: the slots read after it (depth r + 1) are not the ones bid for next
         // (depth r + 2), and the "anybody still unplaced" vote rides on the same barrier (three rotating flag words).
+        // (Round 4: a segment whose tree the pixel DBSCAN kernel has just built — the same insertions, the same rule — gets its
+        // child links from there, 4 bytes per point, instead of replaying them: the build was a third of this kernel's time.)
+        const bool have_tree = TIER == 0 && px_tree && px_tree_flag[s] == px_tree_epoch;
+        if (have_tree) {
+            for (uint32_t i = tid; i < n; i += BO_T) {
+                const uint32_t w = px_tree[base + i], l = w & 0xFFFFu, r = w >> 16;
+                child[2 * i] = l == 0xFFFFu ? BO_NONE : l;
+                child[2 * i + 1] = r == 0xFFFFu ? BO_NONE : r;
+            }
+        }
         uint32_t cur[BO_PPT], dep[BO_PPT];
         bool placed[BO_PPT];
 #pragma unroll
@@ -359,9 +371,9 @@ __global__ __launch_bounds__(T, (T == BO_T1 ? 8 : 4)) void cluster_order_kernel(
             const uint32_t i = tid + u * BO_T;
             cur[u] = 0;
             dep[u] = 0;
-            placed[u] = i == 0 || i >= n;
+            placed[u] = i == 0 || i >= n || have_tree;
         }
-        for (uint32_t round = 0;; round++) {
+        for (uint32_t round = 0; !have_tree; round++) {
             uint32_t at[BO_PPT];
             bool active = false;
             if (tid == 0) red[(round + 1u) % 3u] = 0;
@@ -954,9 +966,13 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
     }
     // (The three launches are independent — a segment's size names its launch —, but starting the later ones on streams of
     // their own beside the first cost more in cross-stream waits than it saved: 0.74 against 0.65 ms per lock-step pass.)
+    // the trees of the pixel DBSCAN kernel, when these labels and segments are the ones its last call on this context produced
+    const bool trees = ctx->px_tree_labels && ctx->px_tree_labels == (const void *) d_labels && ctx->px_tree_seg_off == (const void *) d_seg_off &&
+                       ctx->px_tree_S == S;
     hipLaunchKernelGGL((cluster_order_kernel<BO_CAP1, BO_T1, 0>), dim3(grid1), dim3(BO_T1), BoLayout<BO_CAP1>::bytes, st, d_xy, d_seg_off,
                        d_seg_cnt, S, eps, d_labels, d_n_clusters, d_order, d_status, lists, cnt, only_tied_medians, d_win_list, d_win_count, dlist, dcnt,
-                       xy16, sfmt, 0);
+                       xy16, sfmt, 0, trees ? (const uint32_t *) ctx->px_tree.ptr : nullptr,
+                       trees ? (const uint32_t *) ctx->px_tree_flag.ptr : nullptr, ctx->px_tree_epoch);
     // lean (ecal_ctx::tail_seen: the first launch listed nothing when this stage last ran): the third launch takes the second's
     // list with its own, reading packed segments as they are, and the global-scratch launch unpacks what it is given — two
     // launches behind the first instead of six

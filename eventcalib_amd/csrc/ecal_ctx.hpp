@@ -41,6 +41,12 @@ struct ecal_ctx {
     ecal_devbuf in_xy, in_off, in_cnt, out_labels, out_ncl;  // staging for the host-pointer API
     ecal_devbuf big_slot, big_anc, big_cur, big_inv, big_cs, big_flags;    // global-scratch tier of DBSCAN
     ecal_devbuf pxs_todo;  // same for the pixel slicer
+    // the insertion-order kd-trees the pixel DBSCAN kernel built (child links, 4 B per point) for the member-order kernel of the
+    // exact extraction, which would otherwise build every listed segment's tree again (a third of its time): valid for the
+    // labels / segment arrays of the DBSCAN call numbered px_tree_epoch, per segment when px_tree_flag[s] carries that number
+    ecal_devbuf px_tree, px_tree_flag;
+    uint32_t px_tree_epoch = 0, px_tree_S = 0;
+    const void *px_tree_labels = nullptr, *px_tree_seg_off = nullptr;
     ecal_devbuf wb_status;  // ecal_window_bounds_dev: one word per workgroup of the look-back scan
     uint32_t wb_epoch = 0;  // ... and the number of the call that wrote it
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers
@@ -100,7 +106,7 @@ struct ecal_ctx {
     uint32_t n_cu = 256;  // compute units of the device (grid size of the persistent kernels)
     bool attrs_set = false, slice_attrs_set = false, det_attr_set = false, fused_attr_set = false, bfs_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
-        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &wb_status, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
+        return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &wb_status, &px_tree, &px_tree_flag, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos, &sl_order, &sl_order_big, &bucket_tab, &sort_scratch,
                 &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &fused_def, &bfs_lists, &bfs_defer, &bfs_big, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],

@@ -309,6 +309,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
     int rc = set_attrs(ctx);
     if (rc) return rc;
     hipStream_t st = (hipStream_t) stream;
+    ctx->px_tree_labels = nullptr;   // (whatever trees an earlier call left belong to ITS labels; set again below when this call exports its own)
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
     // (fused pass: its to-do list also holds the segments of windows the fused kernel did not slice, of any size)
     const bool second_pass_wanted = (mx > (uint32_t) PX_CAP || ctx->fused_pass) && !ctx->sw.dbscan_no_second_pass;  // debug switch
@@ -338,20 +339,38 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
             }
         }
         const uint32_t grid2 = std::min<uint32_t>(S, (uint32_t) ECAL_PX2_WG * ctx->n_cu);
+        // the trees the first pass builds go out for the exact extraction's member-order kernel (ecal_ctx::px_tree): 4 B per
+        // point, a flag word per segment that carries this call's number where the segment's tree is whole
+        uint32_t *tree = nullptr, *tflag = nullptr;
+        if (!fused && ctx->median_ties == ECAL_TIES_REFERENCE && n_points && PX_CAP <= 0xFFFE) {
+            const bool fresh = ctx->px_tree_flag.cap < (size_t) S * sizeof(uint32_t);
+            if (!ecal_ensure(ctx, ctx->px_tree, (size_t) n_points * sizeof(uint32_t)) &&
+                !ecal_ensure(ctx, ctx->px_tree_flag, (size_t) S * sizeof(uint32_t))) {
+                if (fresh) ECAL_HIP_TRY(ctx, hipMemsetAsync(ctx->px_tree_flag.ptr, 0, ctx->px_tree_flag.cap, st));   // (no stale numbers in fresh memory)
+                ctx->px_tree_epoch = ctx->px_tree_epoch == 0xFFFFFFFFu ? 1u : ctx->px_tree_epoch + 1u;
+                ctx->px_tree_labels = d_labels;
+                ctx->px_tree_seg_off = d_seg_off;
+                ctx->px_tree_S = S;
+                tree = (uint32_t *) ctx->px_tree.ptr;
+                tflag = (uint32_t *) ctx->px_tree_flag.ptr;
+            }
+        }
         const bool second_pass = second_pass_wanted && !lean;
         cnt_a = cnt;
         cnt_b = second_pass ? cnt2 : nullptr;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !ctx->sw.dbscan_generic_disc) {
             if (!fused) hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
-                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt);
+                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
+                               ctx->px_tree_epoch);
             if (second_pass)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<16, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
                                    (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt);
         } else {
             hipLaunchKernelGGL((dbscan_pixel_kernel<0, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
-                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt);
+                               d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
+                               ctx->px_tree_epoch);
             if (second_pass)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<0, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,

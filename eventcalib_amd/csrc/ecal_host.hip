@@ -144,13 +144,22 @@ extern "C" int ecal_stream_create_from_file(ecal_ctx *ctx, const char *path, dou
     constexpr int NT = 6;                                // reader threads = pinned buffers
     uint8_t *pin[NT] = {};
     hipEvent_t done[NT] = {};
+    const bool load_trace = getenv("ECAL_LOAD_TRACE") != nullptr;   // (debug: where the loader's time goes, on stderr)
+    const auto lt0 = std::chrono::steady_clock::now();
+    auto lt = [&](const char *what) {
+        if (load_trace)
+            fprintf(stderr, "ecal_stream_create_from_file: %-28s %.4f s\n", what,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - lt0).count());
+    };
     hipError_t e = hipMalloc((void **) &s->d_events, (size_t) n_file * 25 + 16);
+    lt("hipMalloc");
     const uint64_t n_chunks = (n_file + CH - 1) / CH;
     const int nt = (int) std::min<uint64_t>(NT, std::max<uint64_t>(n_chunks, 1));
     for (int b = 0; b < nt && e == hipSuccess; b++) {
         e = hipHostMalloc((void **) &pin[b], (size_t) std::min<uint64_t>(CH, std::max<uint64_t>(n_file, 1)) * 25, hipHostMallocDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
     }
+    lt("pinned buffers + events");
     auto cleanup = [&]() {
         for (int b = 0; b < NT; b++) {
             if (done[b]) (void) hipEventDestroy(done[b]);
@@ -231,8 +240,11 @@ extern "C" int ecal_stream_create_from_file(ecal_ctx *ctx, const char *path, dou
         if (nt > 0 && n_chunks > 0) reader(0);
         for (auto &t : th) t.join();
     }
+    lt("reads done, copies enqueued");
     const bool synced = hipStreamSynchronize(ctx->stream) == hipSuccess;
+    lt("copies done");
     cleanup();
+    lt("buffers released");
     if (io_error || !synced) {
         ctx->last_error = std::string("ecal_stream_create_from_file: read or copy failed for ") + path;
         (void) hipFree(s->d_events);

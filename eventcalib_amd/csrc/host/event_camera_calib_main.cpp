@@ -44,6 +44,8 @@ int main(int argc, char **argv) {
     container->cameraSize[0] = width;
     container->cameraSize[1] = height;
     if (batch) {   // the same loop as one call: file -> HBM, reads and upload overlapped (EventContainer::loadFile)
+        (void) ecal_host::thread_ctx();   // HIP runtime + context start-up (0.2 - 0.3 s in a cold process): a stage of its own,
+        stage("runtime_init");            // not part of reading the file
         es.close();
         container->loadFile(argv[2], startTime, customEnd, endTimeSetting);
     }
