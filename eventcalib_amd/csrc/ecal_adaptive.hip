@@ -28,6 +28,7 @@
 #include "ref_nth_element.hpp"
 
 #include <math.h>
+#include <chrono>
 
 #include <algorithm>
 #include <numeric>
@@ -603,7 +604,11 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // the lock-step passes of one set of runs: until no piece has a window left
     uint32_t deal = S;   // window slots dealt out per pass (all of them in the first set of runs)
     auto run_passes = [&]() -> int {
-        hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, deal, d_max, a, ap->motion_time_step, d_t0, d_t1);
+        // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
+        // kernels over the slots it deals out, not over all S: thousands of workgroups that find an empty window still cost
+        // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
+        const uint32_t Sr = deal < S ? deal : S;
+        hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1);
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
                 const uint32_t q = (pass - ahead) % 8u;
@@ -618,20 +623,20 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
             }
             n_passes++;
             AD_TRY(hip_rc(hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st), "hipMemsetAsync"));  // pieces active after this pass
-            AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, S, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
+            AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sr, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                           (uint32_t *) B[4].ptr, st));
-            AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, S, 0,
+            AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sr, 0,
                                          cap_points, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
                                          (int32_t *) B[8].ptr, (int *) B[16].ptr, st));
-            AD_TRY(ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * S, cap_points, 0,
+            AD_TRY(ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * Sr, cap_points, 0,
                                          prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, st));
             AD_TRY(ecal_extract_for_ctx(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
-                                        (uint32_t *) B[10].ptr, S, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
+                                        (uint32_t *) B[10].ptr, Sr, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
                                         prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st));
-            AD_TRY(ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, S, prm->rows, prm->cols,
+            AD_TRY(ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sr, prm->rows, prm->cols,
                                        (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st));
-            hipLaunchKernelGGL(adaptive_dir_kernel, dim3(S), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
+            hipLaunchKernelGGL(adaptive_dir_kernel, dim3(Sr), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
                                (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                                (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);
             hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, max_levels,
@@ -640,7 +645,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                                max_keys, d_kt, d_kd, d_ke, d_kf, d_kp, d_kg, d_t0, d_t1, (const int *) B[16].ptr,
                                (const double *) ctx->adaptive_dirs.ptr);
-            hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, S, deal, d_max, a, ap->motion_time_step, d_t0, d_t1);
+            hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1);
             AD_TRY(hip_rc(hipMemcpyAsync(ring + 4 * (pass % 8u), a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync"));
             AD_TRY(hip_rc(hipEventRecord(ctx->adaptive_ev[pass % 8u], st), "hipEventRecord"));
         }
@@ -667,12 +672,15 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
             if (h[8] == 0) break;
             if (h[1] > max_keys) break;   // the records have run over: reported below
             const uint32_t before = n_passes, again = h[8];
+            const auto t_round = std::chrono::steady_clock::now();
             // slots for the pieces that run again: as many per piece as the first runs had at the start, or what keeps the GPU
             // busy (measured at 1270 pieces: 0.266 -> 0.224 s for the whole search; 6 - 12 per piece and 512 - 3000 at least
             // all within 4 % of each other)
             deal = (uint32_t) std::min<uint64_t>(S, std::max<uint64_t>((uint64_t) again * D, 1536u));
             if ((rc = run_passes())) return rc;
-            if (trace) fprintf(stderr, "  round %u: %u pieces run again, %u passes\n", rounds, again, n_passes - before);
+            if (trace)
+                fprintf(stderr, "  round %u: %u pieces run again, %u passes, %u slots per pass, %.2f ms\n", rounds, again, n_passes - before, deal,
+                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_round).count());
         }
     }
 #undef AD_TRY
