@@ -106,6 +106,43 @@ __device__ __forceinline__ void ne_fma36(double (&acc)[36], const ne_v2d (&A)[3]
         for (int y = 0; y < 6; y++) acc[6 * x + y] += a[x] * b[y];
 }
 
+// A streamed evaluation (ecal_solver_solve, one rank, a long spline): the host factorises the interiors of its partition of the
+// control points (arrow_host_parts.hpp) WHILE the kernel is still accumulating the later ones.  The chunks are ordered by knot
+// span, i.e. by control point; group g = the chunks whose span's last control point lies in [cut[g], cut[g + 1]).  A chunk
+// with last control point s adds to the records s - 3 .. s, so the records of interior g ([cut[g], cut[g + 1] - 3)) are touched
+// by group g alone and the three records of the separator behind it by groups g and g + 1.  The workgroup that finishes a group
+// (a counter per group) copies the interior's records into the host's pinned buffer and raises the group's flag there; the
+// second of the two groups beside a separator to finish does the same for the separator's records.  The counters are restored
+// by the workgroup that zeroes them: nothing to prepare per launch.
+constexpr int NE_MAX_GROUPS = 32;
+struct NeProgress {
+    uint32_t n_groups, n_cp;
+    uint32_t cut[NE_MAX_GROUPS + 1];      // cut[n_groups] = n_cp
+    uint32_t init[2 * NE_MAX_GROUPS];     // [g]: chunks of group g; [NE_MAX_GROUPS + b]: groups with chunks beside separator b
+    uint32_t *left;                       // the running counters, same layout (device memory)
+    double *host_acc;                     // the pinned accumulation buffer as the device sees it
+    uint32_t *host_flag;                  // pinned; [g] / [NE_MAX_GROUPS + b] = number of the evaluation that delivered them
+};
+
+// records [r_lo, r_hi) of the accumulation buffer to the host's copy; the values were added by other workgroups' atomics on
+// any of the eight XCDs: agent-scope loads (a plain load could be served from this XCD's L2)
+__device__ __forceinline__ void ne_copy_records(const double *accum, double *host, uint32_t r_lo, uint32_t r_hi, int tid) {
+    const size_t lo = ACC_HEAD + ACC_PER_CP * (size_t) r_lo, hi = ACC_HEAD + ACC_PER_CP * (size_t) r_hi;
+    for (size_t i = lo + (size_t) tid; i < hi; i += 8 * (size_t) NE_T) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t k = i + (size_t) u * NE_T;
+            v[u] = k < hi ? __hip_atomic_load(accum + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const size_t k = i + (size_t) u * NE_T;
+            if (k < hi) host[k] = v[u];
+        }
+    }
+}
+
 // WITH_JAC = false: cost only (no rows, no LDS, no tiles) — its own, small instantiation (69 VGPRs against 233)
 template <bool SO3, bool WITH_JAC, bool FISHEYE = false>
 __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResRecord *__restrict__ rec,
@@ -116,7 +153,8 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
                                                          const double *__restrict__ params, uint32_t n_cp_total,
                                                          const double *__restrict__ landmarks, double radius,
                                                          double huber_a, double *__restrict__ accum,
-                                                         double *__restrict__ heads) {
+                                                         double *__restrict__ heads, const NeProgress *__restrict__ prog,
+                                                         uint32_t epoch) {
     constexpr bool with_jac = WITH_JAC;
     constexpr int NE_TW = SO3 ? 4 : 6;
     constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES, NE_GROUPS = NeTiles<NE_TW>::GROUPS;
@@ -323,6 +361,50 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             }
         }
     }
+    if (prog) {   // streamed evaluation: the group's (and its separators') records to the host when this chunk is the last one
+        __shared__ uint32_t fin[3];
+        __threadfence();
+        __syncthreads();   // every thread's adds are out
+        const uint32_t P = prog->n_groups;
+        if (tid == 0) {
+            const uint32_t sg = c0 + 3;
+            uint32_t g = 0;
+            while (g + 1 < P && prog->cut[g + 1] <= sg) g++;
+            uint32_t *left = prog->left;
+            const bool last = atomicSub(&left[g], 1u) == 1u;
+            fin[0] = last ? g + 1 : 0;
+            fin[1] = fin[2] = 0;
+            if (last) {
+                left[g] = prog->init[g];
+                if (g > 0 && atomicSub(&left[NE_MAX_GROUPS + g - 1], 1u) == 1u) {
+                    fin[1] = 1;
+                    left[NE_MAX_GROUPS + g - 1] = prog->init[NE_MAX_GROUPS + g - 1];
+                }
+                if (g + 1 < P && atomicSub(&left[NE_MAX_GROUPS + g], 1u) == 1u) {
+                    fin[2] = 1;
+                    left[NE_MAX_GROUPS + g] = prog->init[NE_MAX_GROUPS + g];
+                }
+            }
+        }
+        __syncthreads();
+        if (fin[0]) {
+            __threadfence();
+            const uint32_t g = fin[0] - 1;
+            const uint32_t c_lo = prog->cut[g], c_next = prog->cut[g + 1];
+            double *host = prog->host_acc;
+            ne_copy_records(accum, host, c_lo, g + 1 < P ? c_next - 3 : c_next, tid);
+            if (fin[1]) ne_copy_records(accum, host, c_lo - 3, c_lo, tid);
+            if (fin[2]) ne_copy_records(accum, host, c_next - 3, c_next, tid);
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t *flag = prog->host_flag;
+                __hip_atomic_store(&flag[g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (fin[1]) __hip_atomic_store(&flag[NE_MAX_GROUPS + g - 1], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (fin[2]) __hip_atomic_store(&flag[NE_MAX_GROUPS + g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // The Ceres CostFunction::Evaluate seam (EventCalibSpline.hpp:137-146,231-240 behind AutoDiffCostFunction<..., 1, 9, 4, 4, 4, 4,
@@ -398,6 +480,15 @@ struct ecal_solver {
     Chunk *d_chunks = nullptr;
     double *d_knots = nullptr, *d_landmarks = nullptr, *d_params = nullptr, *d_accum = nullptr, *d_heads = nullptr;
     uint32_t *d_knot_off = nullptr, *d_cp_off = nullptr;
+    // ecal_solver_solve's pinned staging (kept: pinning 3 MB per solve costs more than an LM iteration) and the streamed
+    // evaluation's progress block (NeProgress)
+    double *h_acc = nullptr, *h_x = nullptr;
+    uint32_t *h_flag = nullptr, *d_left = nullptr;
+    NeProgress *d_prog = nullptr;
+    NeProgress prog{};             // the host's copy (prog.n_groups = 0: not set up)
+    std::shared_ptr<void> host_pool;   // ecal_solver_solve's worker threads (HostPool), parked between solves
+    int host_pool_workers = -1;
+    uint32_t stream_epoch = 0;
     size_t n_params() const { return 9 + 7 * (size_t) n_cp; }
     size_t n_accum() const { return ACC_HEAD + ACC_PER_CP * (size_t) n_cp; }
 };
@@ -405,9 +496,13 @@ struct ecal_solver {
 extern "C" void ecal_solver_destroy(ecal_solver *s) {
     if (!s) return;
     (void) hipSetDevice(s->ctx->device);
-    void *ptrs[] = {s->d_rec, s->d_chunks, s->d_knots, s->d_landmarks, s->d_params, s->d_accum, s->d_heads, s->d_knot_off, s->d_cp_off};
+    void *ptrs[] = {s->d_rec, s->d_chunks, s->d_knots, s->d_landmarks, s->d_params, s->d_accum, s->d_heads, s->d_knot_off, s->d_cp_off,
+                    s->d_left, s->d_prog};
     for (void *p : ptrs)
         if (p) (void) hipFree(p);
+    void *pinned[] = {s->h_acc, s->h_x, s->h_flag};
+    for (void *p : pinned)
+        if (p) (void) hipHostFree(p);
     delete s;
 }
 
@@ -762,8 +857,15 @@ extern "C" int ecal_solver_create_dev(ecal_ctx *ctx, const ecal_spline_problem *
 
 extern "C" uint64_t ecal_solver_num_residuals(const ecal_solver *s) { return s ? s->n_res : 0; }
 
+static int solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum, void *stream,
+                               const NeProgress *d_prog, uint32_t epoch);
 extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum,
                                         void *stream) {
+    return solver_evaluate_dev(s, d_params, with_jacobian, d_accum, stream, nullptr, 0);
+}
+// d_prog (with_jacobian only): the streamed form — the records reach the host's pinned buffer group by group (NeProgress)
+static int solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_jacobian, double *d_accum, void *stream,
+                               const NeProgress *d_prog, uint32_t epoch) {
     const ecal_range range__(s ? s->ctx : nullptr, with_jacobian ? "ecal_solver_evaluate (normal equations)" : "ecal_solver_evaluate (cost)");
     if (!s || !d_params || !d_accum) return ECAL_ERR_INVALID;
     ecal_ctx *ctx = s->ctx;
@@ -775,7 +877,8 @@ extern "C" int ecal_solver_evaluate_dev(ecal_solver *s, const double *d_params, 
         const size_t lds = with_jacobian ? NE_T * NE_LD * sizeof(double) : 0;
 #define ECAL_NE_LAUNCH(SO3_, JAC_, FISH_)                                                                                          \
     hipLaunchKernelGGL((normal_eq_kernel<SO3_, JAC_, FISH_>), dim3(s->n_chunks), dim3(NE_T), lds, st, s->d_rec, s->d_chunks, s->d_knots, \
-                       s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads)
+                       s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads,   \
+                       with_jacobian ? d_prog : nullptr, epoch)
 #define ECAL_NE_LAUNCH2(SO3_, JAC_)                                       \
     do {                                                                  \
         if (s->fisheye) ECAL_NE_LAUNCH(SO3_, JAC_, true);                 \
@@ -1090,10 +1193,11 @@ void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd,
 }
 
 // x (+) delta: intrinsics and translations add, quaternions take exp(delta) (x) q
-void plus(const double *x, const std::vector<double> &d, uint32_t n_cp, bool so3, double *out) {
+void plus(const double *x, const std::vector<double> &d, uint32_t n_cp, bool so3, double *out, uint32_t c_lo = 0, uint32_t c_hi = 0xFFFFFFFFu) {
     const size_t nc = 6 * (size_t) n_cp;
-    for (int i = 0; i < 9; i++) out[i] = x[i] + d[nc + i];
-    for (uint32_t c = 0; c < n_cp; c++) {
+    if (c_lo == 0)
+        for (int i = 0; i < 9; i++) out[i] = x[i] + d[nc + i];
+    for (uint32_t c = c_lo; c < std::min(c_hi, n_cp); c++) {
         if (so3)
             so3_plus(x + 9 + 4 * (size_t) c, &d[6 * (size_t) c], out + 9 + 4 * (size_t) c);
         else
@@ -1354,20 +1458,10 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     ArrowSystem A;
     ArrowWorkspace ws;
     const auto t_begin = std::chrono::steady_clock::now();
-    // pinned staging: the 3 MB buffer comes back every evaluation
-    double *acc = nullptr, *xpin = nullptr;
-    ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &acc, na * sizeof(double), hipHostMallocDefault));
-    if (hipHostMalloc((void **) &xpin, np * sizeof(double), hipHostMallocDefault) != hipSuccess) {
-        (void) hipHostFree(acc);
-        return ECAL_ERR_NOMEM;
-    }
-    struct Free {
-        double *a, *b;
-        ~Free() {
-            (void) hipHostFree(a);
-            (void) hipHostFree(b);
-        }
-    } free_guard{acc, xpin};
+    // pinned staging (the solver keeps it): the 3 MB buffer comes back every evaluation
+    if (!s->h_acc) ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &s->h_acc, na * sizeof(double), hipHostMallocDefault));
+    if (!s->h_x) ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &s->h_x, np * sizeof(double), hipHostMallocDefault));
+    double *const acc = s->h_acc, *const xpin = s->h_x;
     double t_eval = 0, t_lin = 0;
     // Distributed segments (ecal_lm_options.distributed): every rank owns its own spline segments in its own
     // ecal_solver; only the 9 intrinsics are shared.  Per evaluation the 91-double head is all-reduced; per linear solve
@@ -1496,17 +1590,23 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         }
         return true;
     };
-    std::unique_ptr<HostPool> pool;
+    HostPool *pool = nullptr;   // (the solver keeps the threads: starting fifteen of them costs as much as a tenth of an iteration each)
     double t_unpack = 0, t_pool = 0;
-    if (n_parts > 1) {   // (the workers start while the GPU runs the first evaluation)
+    if (n_parts > 1) {
         const auto tp = now();
         const int hw = (int) std::max(1u, std::thread::hardware_concurrency());
-        try {
-            pool.reset(new HostPool(std::max(0, std::min(n_parts, hw) - 1)));
-        } catch (...) {   // no threads to be had: the sequential routines
-            pool.reset();
-            n_parts = 1;
+        const int workers = std::max(0, std::min(n_parts, hw) - 1);
+        if (!s->host_pool || s->host_pool_workers != workers) {
+            try {
+                s->host_pool = std::shared_ptr<void>(new HostPool(workers), [](void *q) { delete static_cast<HostPool *>(q); });
+                s->host_pool_workers = workers;
+            } catch (...) {   // no threads to be had: the sequential routines
+                s->host_pool.reset();
+                s->host_pool_workers = -1;
+                n_parts = 1;
+            }
         }
+        pool = static_cast<HostPool *>(s->host_pool.get());
         t_pool = secs(tp, now());
     }
     auto unpack_acc = [&]() {
@@ -1522,14 +1622,205 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         t_unpack += secs(tu, now());
     };
 
+    // Streamed evaluation (one rank, the multi-part host solve): NeProgress above — the kernel delivers the records group by
+    // group, the pool's threads unpack an interior's rows and, when the trust-region radius the next linear solve will use
+    // can be predicted, factorise it while the kernel is still busy with the later control points.  What is left behind the
+    // kernel: the last interior, the separators' rows, the reduced system, the back-substitution.
+    bool stream_ok = !opt.allreduce && pool && n_parts > 1 && parts_solve && n_parts <= NE_MAX_GROUPS && !ctx->sw.solver_no_stream &&
+                     s->n_chunks > 0;
+    std::vector<uint32_t> part_first, part_num;
+    if (stream_ok) {
+        arrow_partition_stream(s->n_cp, n_parts, part_first, part_num);
+        if (s->prog.n_groups != (uint32_t) n_parts) {   // first solve with this partition: the groups' chunk counts, the buffers
+            std::vector<Chunk> ch(s->n_chunks);
+            ECAL_HIP_TRY(ctx, hipMemcpy(ch.data(), s->d_chunks, ch.size() * sizeof(Chunk), hipMemcpyDeviceToHost));
+            NeProgress &pg = s->prog;
+            memset(&pg, 0, sizeof(pg));
+            pg.n_cp = s->n_cp;
+            for (int g = 0; g < n_parts; g++) pg.cut[g] = part_first[g];
+            pg.cut[n_parts] = s->n_cp;
+            for (const Chunk &c : ch) {
+                const uint32_t sg = s->cp_off[c.seg] + c.span;
+                uint32_t g = 0;
+                while (g + 1 < (uint32_t) n_parts && pg.cut[g + 1] <= sg) g++;
+                pg.init[g]++;
+            }
+            for (int b = 0; b + 1 < n_parts; b++) pg.init[NE_MAX_GROUPS + b] = (pg.init[b] ? 1u : 0u) + (pg.init[b + 1] ? 1u : 0u);
+            if (!s->h_flag) {
+                ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &s->h_flag, 2 * NE_MAX_GROUPS * sizeof(uint32_t), hipHostMallocDefault));
+                memset(s->h_flag, 0, 2 * NE_MAX_GROUPS * sizeof(uint32_t));
+            }
+            if (!s->d_left) ECAL_HIP_TRY(ctx, hipMalloc((void **) &s->d_left, 2 * NE_MAX_GROUPS * sizeof(uint32_t)));
+            if (!s->d_prog) ECAL_HIP_TRY(ctx, hipMalloc((void **) &s->d_prog, sizeof(NeProgress)));
+            ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+            ECAL_HIP_TRY(ctx, hipMemcpy(s->d_left, pg.init, 2 * NE_MAX_GROUPS * sizeof(uint32_t), hipMemcpyHostToDevice));
+            pg.left = s->d_left;
+            ECAL_HIP_TRY(ctx, hipHostGetDevicePointer((void **) &pg.host_acc, s->h_acc, 0));
+            ECAL_HIP_TRY(ctx, hipHostGetDevicePointer((void **) &pg.host_flag, s->h_flag, 0));
+            ECAL_HIP_TRY(ctx, hipMemcpy(s->d_prog, &pg, sizeof(pg), hipMemcpyHostToDevice));
+            pg.n_groups = (uint32_t) n_parts;
+            ECAL_HIP_TRY(ctx, hipMemcpy(s->d_prog, &pg, sizeof(pg), hipMemcpyHostToDevice));
+        }
+    }
+    const bool stream_partition = stream_ok;   // (kept for the whole solve, whatever becomes of the stream)
+    ArrowSystem A_next;
+    std::vector<double> dd_next(nt);
+    bool reduced_ok = false;   // a streamed evaluation with `factor`: every separator of the reduced system eliminated
+    std::vector<double> tl_arrive, tl_done;   // ECAL_SOLVER_TRACE: the last streamed evaluation's timeline (seconds from its start)
+    double tl_run = 0, tl_sync = 0;
+    double t_tail = 0;
+    // An: the system at xp.  factor: also arrow_part_factor of every interior, with the LM diagonal of trust-region radius
+    // r_fact (ws / parts then hold what arrow_parts_finish needs).  *streamed = false: the stream failed to deliver (nothing this
+    // code can name should make it) and the buffer was fetched and unpacked the plain way, nothing factorised.
+    auto evaluate_streamed = [&](const double *xp, ArrowSystem &An, bool factor, double r_fact, double *cost, bool *streamed,
+                                 const std::function<void()> *after_launch = nullptr) -> int {
+        const auto te = now();
+        const NeProgress &pg = s->prog;
+        const int P = n_parts;
+        memcpy(xpin, xp, np * sizeof(double));
+        if (hipMemcpyAsync(s->d_params, xpin, np * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) return ECAL_ERR_HIP;
+        const uint32_t epoch = ++s->stream_epoch;
+        // records that no chunk touches never arrive: they are zero
+        for (int g = 0; g < P; g++) {
+            if (!pg.init[g]) memset(acc + ACC_HEAD + ACC_PER_CP * (size_t) pg.cut[g], 0,
+                                    ACC_PER_CP * (size_t) ((g + 1 < P ? pg.cut[g + 1] - 3 : pg.cut[g + 1]) - pg.cut[g]) * sizeof(double));
+            if (g + 1 < P && !pg.init[NE_MAX_GROUPS + g]) memset(acc + ACC_HEAD + ACC_PER_CP * (size_t) (pg.cut[g + 1] - 3), 0, 3 * ACC_PER_CP * sizeof(double));
+        }
+        int rc2 = solver_evaluate_dev(s, s->d_params, 1, s->d_accum, st, s->d_prog, epoch);
+        if (rc2) return rc2;
+        if (hipMemcpyAsync(acc, s->d_accum, ACC_HEAD * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return ECAL_ERR_HIP;
+        if (after_launch) (*after_launch)();   // (host work of the caller that only has to be done by the time the kernel is)
+        unpack_alloc(s->n_cp, An);
+        if (factor) arrow_parts_setup(An.nc, P, ws, parts, true);
+        reduced_ok = false;
+        const bool trace_ev = ctx->sw.solver_trace;
+        tl_arrive.assign(P + 1, 0.0);
+        tl_done.assign(P + 1, 0.0);
+        std::atomic<bool> failed{false};
+        std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[P]);
+        for (int p = 0; p < P; p++) done[p].store(0);
+        volatile const uint32_t *flag = s->h_flag;
+        // A thread polls its flag only when its turn is near (the flag four groups earlier is up); before that it naps: sixteen
+        // polling threads for the length of a kernel are the machine's whole CPU allowance on a 16-CPU cgroup, and a throttled
+        // process loses milliseconds (measured: 290 -> 230 iterations/s in runs that hit the quota).
+        auto nap = [] {
+            timespec ts{0, 20000};
+            nanosleep(&ts, nullptr);
+        };
+        // a flag that does not come: after two seconds of waiting the stream is asked — still busy: wait on (a long kernel);
+        // finished or in error with the flag down: the stream has failed to deliver, every waiter gives up
+        auto overdue = [&](std::chrono::steady_clock::time_point &t0) -> bool {
+            if (failed.load()) return true;
+            if (secs(t0, now()) < 2.0) return false;
+            t0 = now();
+            if (hipStreamQuery(st) == hipErrorNotReady) return false;
+            return true;
+        };
+        auto wait_for = [&](uint32_t idx, int gate) {
+            auto t0 = now();
+            if (gate >= 0)
+                while (flag[gate] != epoch && flag[idx] != epoch) {
+                    nap();
+                    if (overdue(t0) && flag[idx] != epoch) {
+                        failed.store(true);
+                        return;
+                    }
+                }
+            for (uint32_t spin = 0; flag[idx] != epoch; spin++) {
+                for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+                if ((spin & 0xFFFu) == 0xFFFu && overdue(t0) && flag[idx] != epoch) {
+                    failed.store(true);
+                    return;
+                }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        };
+        // tasks 0 .. P-1: an interior each (taken in this order: a thread that waits, waits for the GPU alone); task P, with
+        // `factor`: the separators of the reduced system one after the other, each as soon as the interiors beside it are done
+        pool->run(factor ? P + 1 : P, [&](int p) {
+            if (p == P) {
+                bool good = true;
+                for (int sp = 0; sp + 1 < P && good; sp++) {
+                    for (uint32_t spin = 0; !(done[sp].load(std::memory_order_acquire) && done[sp + 1].load(std::memory_order_acquire)); spin++) {
+                        if (sp + 8 < P) nap();   // (the separators of the spline's last stretch are the ones to be prompt about)
+                        else
+                            for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+                        if ((spin & 0xFFu) == 0xFFu && failed.load()) return;
+                    }
+                    if (failed.load()) return;
+                    // the separator's own records are in (the interior behind it waited for them): its rows, its diagonal
+                    unpack_rows(acc, An, pg.cut[sp + 1] - 3, pg.cut[sp + 1]);
+                    for (size_t i = 6 * (size_t) (pg.cut[sp + 1] - 3); i < 6 * (size_t) pg.cut[sp + 1]; i++) {
+                        const double h = An.band[i * BW] * scale[i] * scale[i];
+                        dd_next[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / r_fact;
+                    }
+                    good = arrow_reduced_separator(An, scale.data(), dd_next.data(), parts, sp);
+                }
+                reduced_ok = good;
+                if (trace_ev) tl_done[P] = secs(te, now());
+                return;
+            }
+            if (pg.init[p]) wait_for((uint32_t) p, p >= 4 && pg.init[p - 4] ? p - 4 : -1);
+            if (p > 0 && pg.init[NE_MAX_GROUPS + p - 1]) wait_for((uint32_t) (NE_MAX_GROUPS + p - 1), -1);
+            if (p == P - 1 && factor) pool->nudge();   // the end is near: the threads that finished early are wanted for the back-substitution
+            if (trace_ev) tl_arrive[p] = secs(te, now());
+            if (!failed.load()) {
+                // rows of the interior and of the separator behind it (whose own records are not complete yet: those rows are
+                // unpacked again later; what the factorisation reads of them comes from the interior's records)
+                unpack_rows(acc, An, pg.cut[p], pg.cut[p + 1]);
+                if (factor) {
+                    for (size_t i = parts.a[p]; i < parts.a[p] + parts.n[p]; i++) {
+                        const double h = An.band[i * BW] * scale[i] * scale[i];
+                        dd_next[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / r_fact;
+                    }
+                    arrow_part_factor(An, scale.data(), dd_next.data(), ws, parts, p);
+                }
+            }
+            if (trace_ev) tl_done[p] = secs(te, now());
+            done[p].store(1, std::memory_order_release);
+        });
+        tl_run = secs(te, now());
+        const hipError_t e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("solver evaluate: ") + hipGetErrorString(e);
+            return ECAL_ERR_HIP;
+        }
+        const auto tt = now();
+        *streamed = !failed.load();
+        if (failed.load()) {
+            if (hipMemcpy(acc, s->d_accum, na * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ECAL_ERR_HIP;
+            unpack(acc, s->n_cp, An);
+        } else {
+            unpack_head(acc, An);
+            if (!factor)
+                for (int p = 0; p + 1 < P; p++) unpack_rows(acc, An, pg.cut[p + 1] - 3, pg.cut[p + 1]);
+        }
+        *cost = acc[0];
+        tl_sync = secs(te, tt);
+        t_tail += secs(tt, now());
+        t_eval += secs(te, now());
+        return ECAL_OK;
+    };
+
     ecal_lm_summary S;
     memset(&S, 0, sizeof(S));
     double cost = 0, radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
-    int rc = evaluate(x.data(), 1, &cost);
-    if (rc) return rc;
+    int rc;
+    bool fact_ready = false;      // ws / parts hold the interiors' factors for A with the diagonal of radius fact_radius
+    double fact_radius = 0;
+    int n_prefactored = 0;
+    if (stream_ok) {
+        bool streamed = false;
+        rc = evaluate_streamed(x.data(), A, false, 0.0, &cost, &streamed, nullptr);   // (the column scaling comes from this evaluation: nothing to factorise with yet)
+        if (rc) return rc;
+        if (!streamed) stream_ok = false;
+    } else {
+        rc = evaluate(x.data(), 1, &cost);
+        if (rc) return rc;
+        unpack_acc();
+    }
     S.jacobian_evaluations = 1;
     S.initial_cost = cost;
-    unpack_acc();
     if (opt.jacobi_scaling) {  // computed once from the initial Jacobian, as Ceres does
         for (size_t i = 0; i < nc; i++) scale[i] = 1.0 / (1.0 + std::sqrt(A.band[i * BW]));
         for (int i = 0; i < 9; i++) scale[nc + i] = 1.0 / (1.0 + std::sqrt(A.corner[10 * i]));
@@ -1564,19 +1855,53 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         };
     if (gmax() <= opt.gradient_tolerance) S.termination = 0;
     bool last_step_ok = true;
+    // the interiors factorised and the separators eliminated while the kernel ran: the intrinsics' corner and the way back
+    double t_fin_end = 0, t_fin_back = 0;
+    auto prefactored_finish = [&]() -> bool {
+        const auto ta = now();
+        if (!reduced_ok || !arrow_reduced_end(A, scale.data(), dd.data(), parts)) return false;
+        const auto tb = now();
+        arrow_parts_backsub(A.nc, delta, ws, parts, pool, n_parts);
+        t_fin_end += secs(ta, tb);
+        t_fin_back += secs(tb, now());
+        return true;
+    };
+    double t_dd = 0, t_fin = 0, t_quad = 0, t_plus = 0, t_book = 0;   // ECAL_SOLVER_TRACE: the host's share of an iteration, by item
     while (S.termination == 1 && S.iterations < opt.max_num_iterations) {
         S.iterations++;
-        // Levenberg-Marquardt diagonal on the scaled system
-        for (size_t i = 0; i < nt; i++) {
+        const auto t_it = now();
+        // Levenberg-Marquardt diagonal on the scaled system (the streamed evaluation left the control points' part behind when
+        // its radius is the one in force)
+        const bool prefactored = fact_ready && fact_radius == radius && reduced_ok;
+        if (prefactored) memcpy(dd.data(), dd_next.data(), nc * sizeof(double));
+        for (size_t i = prefactored ? nc : 0; i < nt; i++) {
             const double h = (i < nc ? A.band[i * BW] : A.corner[10 * (i - nc)]) * scale[i] * scale[i];
             dd[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / radius;
         }
         const auto tl = now();
+        t_dd += secs(t_it, tl);
         bool ok = ts_mode ? solve_arrow_parts(A, scale, dd, delta, ws, ts_parts, nullptr, world, my_rank, &ts_exchange)
-                  : (n_parts > 1 && parts_solve) ? solve_arrow_parts(A, scale, dd, delta, ws, parts, pool.get(), n_parts)
-                                                 : solve_arrow(A, scale, dd, delta, ws);
+                  : (n_parts > 1 && parts_solve)
+                      ? (fact_ready && fact_radius == radius ? prefactored_finish()   // (false when an interior or a separator was not positive definite)
+                                                             : solve_arrow_parts(A, scale, dd, delta, ws, parts, pool, n_parts, -1, nullptr, stream_partition))
+                      : solve_arrow(A, scale, dd, delta, ws);
+        if (fact_ready && fact_radius == radius) n_prefactored++;
+        fact_ready = false;
+        const auto t_q = now();
+        t_fin += secs(tl, t_q);
         double model_change = 0;
-        if (ok && ts_mode) {
+        // After a successful step the next one is usually successful too: evaluate the candidate WITH its normal
+        // equations in one pass (4.8 ms) instead of a cost-only pass (1.0 ms + a host round trip) followed, on
+        // acceptance, by the full pass at the same point.  After a rejected step fall back to the cost-only probe.
+        const bool speculate = last_step_ok;
+        // streamed evaluation ahead: the quadratic forms of the model are computed once the kernel is running (they gate the
+        // evaluation only when the step is no descent step of the model, which a positive definite system rules out up to rounding)
+        const bool defer_quad = ok && !dist_mode && speculate && stream_ok;
+        double gTd_late = 0, dHd_late = 0;
+        if (defer_quad) {
+            for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
+            model_change = 1.0;   // (placeholder until the forms are in)
+        } else if (ok && ts_mode) {
             // the step solves (H + D) y = -g exactly, so y^T H y = -g^T y - y^T D y and the model change -g^T y - y^T H y / 2 is
             // (y^T D y - g^T y) / 2: sums over unknowns — this rank's interior, rank 0 also the separators and the intrinsics
             // (every rank holds the same values for those)
@@ -1599,7 +1924,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         } else if (ok) {
             for (size_t i = 0; i < nt; i++) delta[i] *= scale[i];
             double gTd, dHd;
-            quad_forms(A, delta, &gTd, &dHd, dist_mode && my_rank != 0, pool.get(), n_parts);
+            quad_forms(A, delta, &gTd, &dHd, dist_mode && my_rank != 0, pool, n_parts);
             if (dist_mode) {
                 double two[2] = {gTd, dHd};
                 if (!reduce_small(two, 2)) return ECAL_ERR_HIP;
@@ -1610,20 +1935,41 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             ok = model_change > 0.0;
         }  // (a failed factorisation was agreed on through reduce_G: every rank skips the reduction above together)
         t_lin += secs(tl, now());
+        t_quad += secs(t_q, now());
         if (!ok) {  // invalid step: shrink the region
             radius /= decrease_factor;
             decrease_factor *= 2.0;
             S.unsuccessful_steps++;
             continue;
         }
-        plus(x.data(), delta, s->n_cp, s->use_so3, xc.data());
+        const auto t_p = now();
+        plus(x.data(), delta, s->n_cp, s->use_so3, xc.data());   // (on the pool's threads: measured slower, 47 against 28 us)
+        t_plus += secs(t_p, now());
         double new_cost;
-        // After a successful step the next one is usually successful too: evaluate the candidate WITH its normal
-        // equations in one pass (4.8 ms) instead of a cost-only pass (1.0 ms + a host round trip) followed, on
-        // acceptance, by the full pass at the same point.  After a rejected step fall back to the cost-only probe.
-        const bool speculate = last_step_ok;
-        rc = evaluate(xc.data(), speculate ? 1 : 0, &new_cost);
+        // streamed: the interiors are factorised for the radius a step with rel >= 0.937 leads to (the usual one while the
+        // model is good: radius / max(1/3, 1 - (2 rel - 1)^3) = 3 radius); any other verdict factorises again as before
+        const double r_pred = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 0.0));
+        bool cand_in_next = false, cand_factored = false;   // the candidate's system sits unpacked in A_next / its interiors are factorised
+        if (speculate && stream_ok) {
+            const std::function<void()> late = [&] { quad_forms(A, delta, &gTd_late, &dHd_late, false, pool, n_parts); };
+            rc = evaluate_streamed(xc.data(), A_next, true, r_pred, &new_cost, &cand_factored, defer_quad ? &late : nullptr);
+            cand_in_next = true;
+            if (!rc && !cand_factored) stream_ok = false;   // (fetched the plain way: carry on without the stream)
+        } else {
+            rc = evaluate(xc.data(), speculate ? 1 : 0, &new_cost);
+        }
         if (rc) return rc;
+        const auto t_b = now();
+        if (defer_quad) {
+            model_change = -gTd_late - 0.5 * dHd_late;
+            if (!(model_change > 0.0)) {   // invalid step after all: the evaluation is dropped, the region shrinks
+                S.jacobian_evaluations++;
+                radius /= decrease_factor;
+                decrease_factor *= 2.0;
+                S.unsuccessful_steps++;
+                continue;
+            }
+        }
         if (speculate) S.jacobian_evaluations++;
         else S.cost_evaluations++;
         const double rel = (cost - new_cost) / model_change;
@@ -1669,11 +2015,16 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
                 if (rc) return rc;
                 S.jacobian_evaluations++;
             }
-            unpack_acc();
+            if (cand_in_next) std::swap(A, A_next);   // (unpacked while the kernel ran)
+            else unpack_acc();
             S.successful_steps++;
             last_step_ok = true;
             const double t = 2.0 * rel - 1.0;
             radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+            if (cand_factored) {
+                fact_ready = true;
+                fact_radius = r_pred;
+            }
             decrease_factor = 2.0;
             if (gmax() <= opt.gradient_tolerance) S.termination = 0;
             else if (std::fabs(cost_change) <= opt.function_tolerance * prev) S.termination = 0;
@@ -1685,6 +2036,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         }
         if (S.termination == 1 && std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(x2) + opt.parameter_tolerance))
             S.termination = 0;
+        t_book += secs(t_b, now());
     }
     if (ts_mode) {
         // the solution put together: every rank contributes its interior, rank 0 the separators and the intrinsics (the one
@@ -1712,8 +2064,18 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     S.seconds_evaluate = t_eval;
     S.seconds_linear_solve = t_lin;
     if (s->ctx->sw.solver_trace)
-        fprintf(stderr, "ecal_solver_solve: total %.4f s | evaluate %.4f | linear solve %.4f (%d parts) | unpack %.4f | pool %.4f\n", S.seconds,
-                t_eval, t_lin, n_parts, t_unpack, t_pool);
+        fprintf(stderr, "ecal_solver_solve: total %.4f s | evaluate %.4f | linear solve %.4f (%d parts) | unpack %.4f | pool %.4f | streamed evaluations: "
+                        "%u, behind the kernel %.4f, %d of %d linear solves found their interiors factorised\n", S.seconds,
+                t_eval, t_lin, n_parts, t_unpack, t_pool, s->stream_epoch, t_tail, n_prefactored, S.iterations);
+    if (s->ctx->sw.solver_trace)
+        fprintf(stderr, "  host items, ms over the solve: LM diagonal %.3f | factorise / finish %.3f | scaling + quadratic forms %.3f | plus %.3f | "
+                        "verdict, norms, swap / unpack, gradient norm %.3f | of the finishes: corner %.3f, back-substitution %.3f\n", 1e3 * t_dd, 1e3 * t_fin,
+                1e3 * t_quad, 1e3 * t_plus, 1e3 * t_book, 1e3 * t_fin_end, 1e3 * t_fin_back);
+    if (s->ctx->sw.solver_trace && !tl_arrive.empty()) {
+        fprintf(stderr, "  last streamed evaluation, ms from its start: interiors arrived / factorised");
+        for (size_t p = 0; p + 1 < tl_arrive.size(); p++) fprintf(stderr, " %.2f/%.2f", 1e3 * tl_arrive[p], 1e3 * tl_done[p]);
+        fprintf(stderr, " | separators done %.2f | tasks joined %.2f | stream synchronised %.2f\n", 1e3 * tl_done.back(), 1e3 * tl_run, 1e3 * tl_sync);
+    }
     memcpy(params, x.data(), np * sizeof(double));
     if (sum) *sum = S;
     return ECAL_OK;
@@ -1745,36 +2107,79 @@ extern "C" void ecal_inverse_radial_distortion(const double *k4, double *b5) {
 // Test hook: one linear solve (S A S + D) y = -S g, delta = S y, for the normal equations `accum` (host, ecal_solver_normal_size
 // doubles) and the column scaling `scale` (host, 6 n_cp + 9) — on the device (arrow_device.hpp) or by the host routine the
 // sharded modes use.  tests/test_gpu_solver.py requires the two to agree.
+// The host's linear solves alone (no GPU involved): the accumulation buffer of n_cp control points (ecal_solver_normal_size
+// layout) -> the LM step.  mode 0: the sequential routine (solve_arrow); 2: the partitioned one (arrow_host_parts.hpp) with `parts`
+// interiors on a few threads; 3: the same on the streamed evaluation's partition (interiors shrinking towards the end).
+extern "C" int ecal_debug_arrow_solve_host(uint32_t n_cp, const double *accum, const double *scale, double radius, double min_diag,
+                                           double max_diag, double *delta_out, int *fail_out, int mode, int parts_wanted) {
+    if (!accum || !scale || !delta_out || !fail_out || n_cp < 1 || (mode != 0 && mode != 2 && mode != 3)) return ECAL_ERR_INVALID;
+    const size_t nc = 6 * (size_t) n_cp, nt = nc + 9;
+    ArrowSystem A;
+    ArrowWorkspace ws;
+    unpack(accum, n_cp, A);
+    std::vector<double> sc(scale, scale + nt), dd(nt), y;
+    for (size_t i = 0; i < nt; i++) {
+        const double h = (i < nc ? A.band[i * BW] : A.corner[10 * (i - nc)]) * sc[i] * sc[i];
+        dd[i] = std::min(std::max(h, min_diag), max_diag) / radius;
+    }
+    bool ok;
+    if (mode == 2 || mode == 3) {
+        ArrowParts parts;
+        int P = parts_wanted > 0 ? parts_wanted : arrow_parts_for(n_cp);
+        if (P < 2) P = 4;
+        if ((uint32_t) (7 * P) > n_cp) return ECAL_ERR_RANGE;
+        HostPool pool(3);
+        ok = solve_arrow_parts(A, sc, dd, y, ws, parts, &pool, P, -1, nullptr, mode == 3);
+        if (const char *e = getenv("ECAL_DEBUG_ARROW_TIME")) {   // tools: the factorisation of the largest interior alone, warm, on this thread
+            const int reps = std::max(1, atoi(e));
+            size_t big = 0;
+            for (int p = 0; p < P; p++)
+                if (parts.n[p] > parts.n[big]) big = p;
+#ifdef ECAL_ARROW_PROF
+            memset(g_arrow_prof, 0, sizeof(g_arrow_prof));
+#endif
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; r++) arrow_part_factor(A, sc.data(), dd.data(), ws, parts, (int) big);
+            const double us = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
+            std::vector<double> yy(nt);
+            const auto t1 = std::chrono::steady_clock::now();
+            for (int r = 0; r < reps; r++) arrow_part_backsub(ws, parts, (int) big, parts.yr.data(), yy.data());
+            const double us_b = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() / reps;
+#ifdef ECAL_ARROW_PROF
+            fprintf(stderr, "  cycles per control point: scaled entries %.0f | block factor %.0f | Gram %.0f | panel %.0f | trailing rows %.0f\n",
+                    g_arrow_prof[0] / (double) reps / (parts.n[big] / 6.0), g_arrow_prof[1] / (double) reps / (parts.n[big] / 6.0),
+                    g_arrow_prof[2] / (double) reps / (parts.n[big] / 6.0), g_arrow_prof[3] / (double) reps / (parts.n[big] / 6.0),
+                    g_arrow_prof[4] / (double) reps / (parts.n[big] / 6.0));
+#endif
+            fprintf(stderr, "arrow_part_factor: interior of %zu control points %.1f us (%.3f us per control point); back-substitution %.1f us\n",
+                    parts.n[big] / 6, us, us / (parts.n[big] / 6.0), us_b);
+        }
+    } else {
+        ok = solve_arrow(A, sc, dd, y, ws);
+    }
+    *fail_out = ok ? 0 : 1;
+    if (ok)
+        for (size_t i = 0; i < nt; i++) delta_out[i] = y[i] * sc[i];
+    return ECAL_OK;
+}
+
+// tests: the host solve's partitions (arrow_partition / arrow_partition_stream)
+extern "C" int ecal_debug_arrow_partition(uint32_t n_cp, int parts, int stream, uint32_t *first_cp, uint32_t *num_cp) {
+    if (!first_cp || !num_cp || parts < 1 || (uint32_t) (7 * parts) > n_cp) return ECAL_ERR_INVALID;
+    std::vector<uint32_t> f, m;
+    if (stream) arrow_partition_stream(n_cp, parts, f, m);
+    else arrow_partition(n_cp, parts, f, m);
+    memcpy(first_cp, f.data(), parts * sizeof(uint32_t));
+    memcpy(num_cp, m.data(), parts * sizeof(uint32_t));
+    return ECAL_OK;
+}
+
 extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const double *scale, double radius, double min_diag,
                                       double max_diag, double *delta_out, int *fail_out, int use_device) {
     if (!s || !accum || !scale || !delta_out || !fail_out) return ECAL_ERR_INVALID;
     ecal_ctx *ctx = s->ctx;
     const size_t nc = 6 * (size_t) s->n_cp, nt = nc + 9, na = s->n_accum();
-    if (use_device != 1) {
-        ArrowSystem A;
-        ArrowWorkspace ws;
-        unpack(accum, s->n_cp, A);
-        std::vector<double> sc(scale, scale + nt), dd(nt), y;
-        for (size_t i = 0; i < nt; i++) {
-            const double h = (i < nc ? A.band[i * BW] : A.corner[10 * (i - nc)]) * sc[i] * sc[i];
-            dd[i] = std::min(std::max(h, min_diag), max_diag) / radius;
-        }
-        bool ok;
-        if (use_device == 2) {   // the host routine's partitioned form (arrow_host_parts.hpp)
-            ArrowParts parts;
-            int P = arrow_parts_for(s->n_cp);
-            if (P < 2) P = 4;
-            if ((uint32_t) (7 * P) > s->n_cp) return ECAL_ERR_RANGE;
-            HostPool pool(3);
-            ok = solve_arrow_parts(A, sc, dd, y, ws, parts, &pool, P);
-        } else {
-            ok = solve_arrow(A, sc, dd, y, ws);
-        }
-        *fail_out = ok ? 0 : 1;
-        if (ok)
-            for (size_t i = 0; i < nt; i++) delta_out[i] = y[i] * sc[i];
-        return ECAL_OK;
-    }
+    if (use_device != 1) return ecal_debug_arrow_solve_host(s->n_cp, accum, scale, radius, min_diag, max_diag, delta_out, fail_out, use_device, 0);
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     DeviceLm D;

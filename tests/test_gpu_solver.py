@@ -253,6 +253,12 @@ def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
                 d = np.zeros(nt)
                 fail = ctypes.c_int(-1)
                 rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d.ctypes.data, ctypes.byref(fail), 2)
+                # mode 3: the partition of the streamed evaluation (interiors shrinking towards the end of the spline)
+                d3 = np.zeros(nt)
+                fail3 = ctypes.c_int(-1)
+                rc3 = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d3.ctypes.data, ctypes.byref(fail3), 3)
+                assert rc3 == 0 and fail3.value == 0, (rc3, fail3.value, parts)
+                assert np.abs(d3 - host).max() <= 1e-9 * np.abs(host).max(), (n_cp, parts, radius, np.abs(d3 - host).max(), np.abs(host).max())
             finally:
                 os.environ.pop("ECAL_HOST_ARROW_PARTS", None)
                 __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
@@ -347,3 +353,52 @@ def test_fisheye_rows_match_dual_numbers(ctx):
         worst_j = max(worst_j, np.abs(J[k] - J33).max() / max(1.0, np.abs(J33).max()))
     assert worst_r < 1e-11 and worst_j < 1e-10, (worst_r, worst_j)
     s.close()
+
+
+# ---- the streamed evaluation of ecal_solver_solve (the interiors of the host's partition are unpacked and factorised while the
+# kernel is still accumulating the later control points): same iterates as the plain form, with and without noise ----
+@pytest.mark.parametrize("n_cp,n_res,parts,noise", [(60, 30000, 3, 0.0), (131, 60000, 8, 0.3), (700, 200000, None, 0.3),
+                                                     (40, 20000, 5, 0.0), (300, 40, 16, 0.0)])
+def test_streamed_evaluation_gives_the_plain_solves_iterates(ctx, n_cp, n_res, parts, noise, monkeypatch, capfd):
+    """parts: ECAL_HOST_ARROW_PARTS (small problems take the sequential routine otherwise); (300, 40, 16): far fewer residuals than
+    knot spans — groups of the stream without a single chunk, records nobody writes (an underdetermined problem held by the LM
+    diagonal alone: compared to 1e-6).  The atomics' summation order differs from launch to launch, so
+    'same' is 1e-9 relative on the parameters and 1e-10 on the final cost, as for the other solver variants."""
+    from eventcalib_amd.capi import Solver, sync_env
+    rng = np.random.default_rng(n_cp)
+    prob, x_gt = SV.make_problem(n_res, n_cp=n_cp, seed=n_cp, pixel_noise=noise)
+    x0 = SV.perturb(x_gt, n_cp, rng)
+    if parts is not None:
+        monkeypatch.setenv("ECAL_HOST_ARROW_PARTS", str(parts))
+    monkeypatch.setenv("ECAL_SOLVER_TRACE", "1")
+    out = []
+    for plain in (False, True, False):
+        if plain:
+            monkeypatch.setenv("ECAL_SOLVER_NO_STREAM", "1")
+        else:
+            monkeypatch.delenv("ECAL_SOLVER_NO_STREAM", raising=False)
+        sync_env()
+        s = Solver(ctx, prob)
+        opt = s.default_options()
+        opt.max_num_iterations = 12
+        capfd.readouterr()
+        x, summ = s.solve(x0, opt)
+        x2, summ2 = s.solve(x0, opt)          # (again on the same solver: the group counters restore themselves)
+        err = capfd.readouterr().err
+        s.close()
+        assert abs(summ2.final_cost - summ.final_cost) <= (1e-7 if n_res < 1000 else 1e-10) * summ.final_cost + 1e-18
+        out.append((x, summ, err))
+    monkeypatch.delenv("ECAL_SOLVER_NO_STREAM", raising=False)
+    monkeypatch.delenv("ECAL_SOLVER_TRACE", raising=False)
+    sync_env()
+    (xs, ss, es), (xp, sp, ep), (xs2, ss2, _) = out
+    tol = 1e-6 if n_res < 1000 else 1e-9
+    # the streamed form ran (and the plain one did not): the trace counts the streamed evaluations
+    import re
+    n_stream = [int(m) for m in re.findall(r"streamed evaluations: (\d+)", es)]
+    n_plain = [int(m) for m in re.findall(r"streamed evaluations: (\d+)", ep)]
+    assert n_stream and n_stream[0] >= 2 and n_plain and n_plain[-1] == 0, (es, ep)
+    for x, summ in ((xs, ss), (xs2, ss2)):
+        assert summ.iterations == sp.iterations and summ.successful_steps == sp.successful_steps
+        assert abs(summ.final_cost - sp.final_cost) <= 0.1 * tol * sp.final_cost + 1e-18, (summ.final_cost, sp.final_cost)
+        assert np.abs(x - xp).max() <= tol * np.abs(xp).max()
