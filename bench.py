@@ -839,9 +839,28 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
         else:   # the library's RCCL communicator, asked for explicitly (a NULL all-reduce is a rank-local solve)
             opt.allreduce, opt.allreduce_user = ctx.comm_allreduce_fn()
         opt.distributed, opt.rank, opt.world_size = 1, rank, world
-    # warm-up: two iterations
-    opt.max_num_iterations = 2
+    # warm-up: one whole solve of the timed length, back to back with the timed ones (an LM run is 30 ms: after any pause the
+    # first solve runs on clocks that are still ramping — 275 against 295 - 300 iterations/s, profiles/r04_notes.md)
+    opt.max_num_iterations = args.solver_iters
     solver.solve(x0, opt)
+    # timed: three consecutive solves, the median counts (all three are in the line)
+    runs = []
+    for _ in range(3):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
+        x, summ = solver.solve(x0, opt)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - tb
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        runs.append(el)
+    el = sorted(runs)[1]
     # kernel-level timing of one Jacobian evaluation and one cost evaluation (HIP events on the launch stream)
     st = torch.cuda.current_stream(dev)
     d_x = torch.as_tensor(x0, device=dev)
@@ -860,23 +879,28 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
     torch.cuda.synchronize(dev)
     jac_ms = ev[0].elapsed_time(ev[1]) / reps
     cost_ms = ev[1].elapsed_time(ev[2]) / reps
-    # timed solve
-    opt.max_num_iterations = args.solver_iters
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    tb = time.perf_counter()
-    x, summ = solver.solve(x0, opt)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    el = time.perf_counter() - tb
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
     iters = int(summ.iterations)
     res_total = n_res * world
+    # the same solve with the evaluation fetched, unpacked and factorised AFTER the kernel (the form before round 4)
+    plain_solve = None
+    if world == 1:
+        os.environ["ECAL_SOLVER_NO_STREAM"] = "1"
+        ctx.reload_env()
+        try:
+            solver.solve(x0, opt)
+            pr = []
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                tb = time.perf_counter()
+                xp, sp = solver.solve(x0, opt)
+                torch.cuda.synchronize(dev)
+                pr.append(time.perf_counter() - tb)
+            plain_solve = {"value": round(int(sp.iterations) / sorted(pr)[1], 3), "unit": "iterations/s", "seconds": [round(r, 4) for r in pr],
+                           "final_cost_rel_diff_vs_streamed": float(abs(sp.final_cost / summ.final_cost - 1)),
+                           "note": "ECAL_SOLVER_NO_STREAM=1: the host fetches, unpacks and factorises after the kernel has finished"}
+        finally:
+            del os.environ["ECAL_SOLVER_NO_STREAM"]
+            ctx.reload_env()
     # the same solve with the linear algebra on the device (arrow_device.hpp: whole iteration in HBM, one 64-byte read-back)
     dev_solve = None
     if world == 1:
@@ -899,7 +923,8 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
     FLOP_JAC = 1900.0
     out = {
         "metric": "LM solver iterations/s", "value": round(iters / el, 3), "unit": "iterations/s",
-        "iterations": iters, "seconds": round(el, 4), "seconds_evaluate": round(float(summ.seconds_evaluate), 4),
+        "iterations": iters, "seconds": round(el, 4), "seconds_of_the_three_timed_solves": [round(r, 4) for r in runs],
+        "seconds_evaluate": round(float(summ.seconds_evaluate), 4),
         "seconds_linear_solve_host": round(float(summ.seconds_linear_solve), 4), "successful_steps": int(summ.successful_steps),
         "jacobian_evaluations": int(summ.jacobian_evaluations), "cost_evaluations": int(summ.cost_evaluations),
         "initial_cost": float(summ.initial_cost), "final_cost": float(summ.final_cost),
@@ -911,6 +936,9 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
         "roofline_fp64": {"kernel": "normal_eq_kernel", "flop_per_residual": FLOP_JAC,
                           "achieved_TFLOPs": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 1e12, 3), "peak_TFLOPs": 78.6,
                           "frac": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 78.6e12, 4)},
+        "evaluation": "streamed: the kernel delivers the accumulation buffer group by group, the host factorises under it (DESIGN.md 8)"
+                      if world == 1 else "plain",
+        "plain_evaluation": plain_solve,
         "device_linear_solve": dev_solve,
         "sharding": "one spline segment (time range) per GPU in its own solver, shared intrinsics: 91 doubles all-reduced per "
                     "evaluation, 101 + N per linear solve, 4 per step" if world > 1 else "single GPU",

@@ -22,7 +22,22 @@ rng = np.random.default_rng(99)
 x0 = x.copy()
 x0[:4] *= 1 + 0.01 * rng.uniform(-1, 1, 4)
 x0[4:9] += 0.01 * rng.uniform(-1, 1, 5)
-for mode in ("stream", "plain", "stream", "plain"):
+VAR = os.environ.get("PROBE_VARIANT", "")
+if "threads" in VAR:
+    torch.set_num_threads(16)
+    a = torch.randn(2000, 2000); (a @ a).sum().item()
+    np.polyfit(np.arange(3.0), np.arange(3.0), 1)
+if "pipe" in VAR:
+    import synth_stream as SS
+    from eventcalib_amd.pipeline import DetectPipeline
+    ev = SS.make_stream(50_000_000, device="cuda")
+    pipe = DetectPipeline(ctx)
+    t0w, t1w = SS.tiled_windows(5.0, 5.0 + (50_000_000 - 1) / 1e6)
+    pipe.set_windows(t0w, t1w)
+    for _ in range(3):
+        pipe.run(ev)
+    torch.cuda.synchronize()
+for mode in ("stream", "plain", "stream", "plain")[:int(os.environ.get("PROBE_MODES", "4"))]:
     if mode == "plain":
         os.environ["ECAL_SOLVER_NO_STREAM"] = "1"
     else:
@@ -35,6 +50,15 @@ for mode in ("stream", "plain", "stream", "plain"):
     s.solve(x0, opt)
     opt.max_num_iterations = iters
     for r in range(reps):
+        if "evals" in VAR:
+            d_x = torch.as_tensor(x0, device="cuda"); d_acc = torch.empty(s.n_normal, dtype=torch.float64, device="cuda")
+            st = torch.cuda.current_stream()
+            for _ in range(6):
+                s.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
+            for _ in range(5):
+                s.evaluate_dev(d_x.data_ptr(), 0, d_acc.data_ptr(), st.cuda_stream)
+        if "sleep" in VAR:
+            time.sleep(0.3)
         torch.cuda.synchronize(); t = time.perf_counter()
         xs, summ = s.solve(x0, opt)
         torch.cuda.synchronize(); el = time.perf_counter() - t
