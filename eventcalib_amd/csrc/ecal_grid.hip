@@ -53,6 +53,29 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return ((unsigned long long) hi << 32) | lo;
 }
 
+// minimum over a ROW of 16 lanes, in every lane of the row (four rotations): the wave as four independent searchers
+__device__ __forceinline__ unsigned long long row_min_u64(unsigned long long v) {
+#define ECAL_GR_ROW_STEP(ctrl)                                                                                        \
+    {                                                                                                                 \
+        const uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp(-1, (int) (uint32_t) v, ctrl, 0xF, 0xF, false);    \
+        const uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp(-1, (int) (uint32_t) (v >> 32), ctrl, 0xF, 0xF, false); \
+        const unsigned long long w = ((unsigned long long) hi << 32) | lo;                                             \
+        v = w < v ? w : v;                                                                                            \
+    }
+    ECAL_GR_ROW_STEP(0x128)   // row_ror:8
+    ECAL_GR_ROW_STEP(0x124)   // row_ror:4
+    ECAL_GR_ROW_STEP(0x122)   // row_ror:2
+    ECAL_GR_ROW_STEP(0x121)   // row_ror:1
+#undef ECAL_GR_ROW_STEP
+    return v;
+}
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long v, int src) {   // lane src's value, in a scalar register pair
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, src);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), src);
+    return ((unsigned long long) hi << 32) | lo;
+}
+__device__ __forceinline__ double lane_f64(double v, int src) { return __longlong_as_double((long long) lane_u64((unsigned long long) __double_as_longlong(v), src)); }
+
 __device__ __forceinline__ unsigned long long pack_key(double d2, uint32_t idx) {
     // non-negative doubles order like their bit patterns; low 8 bits carry the index (ties: smaller index)
     return (((unsigned long long) __double_as_longlong(d2)) & ~0xFFull) | (idx & 0xFFu);
@@ -60,6 +83,7 @@ __device__ __forceinline__ unsigned long long pack_key(double d2, uint32_t idx) 
 
 #ifdef ECAL_PHASE_PROF
 static __device__ unsigned long long g_gr_cycles[16];
+static __device__ unsigned long long g_gr_out[16];    // [o]: windows by outcome, [8 + o]: their cycles
 static __device__ unsigned long long g_gr_hist[32];   // [0..23]: windows by log2 of their cycles; [24]: max (cycles << 24 | n << 16 | nodes << 8 | sweeps)
 #define GR_MARK(i)                                                       \
     do {                                                                 \
@@ -112,17 +136,37 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     for (uint32_t k = lane; k < 4u * GR_NTF; k += GR_T) tf_sh[k] = GR_TF[k / 4u][k % 4u];
     __syncthreads();
 
-    // nearest candidate to (qx, qy) among those passing `want`; returns packed (dist^2, index)
-    auto nearest = [&](double qx, double qy, bool only_free, uint32_t skip) -> unsigned long long {
+    // The searches of the seed, the basis and the first walk run on REGISTERS: every row of 16 lanes holds all candidates
+    // (candidate gl + 16 k in lane gl's k-th register, the four rows alike), so a row answers a nearest-candidate query with
+    // eight distance keys per lane and four DPP rotations — no LDS, no barrier — and the wave answers four different queries
+    // at once (the four directions of a walk step).  The walk asked ~150 questions one after the other, each a trip through
+    // LDS, a six-step wave reduction and a barrier: half of this kernel's 250 us per window (profiles/r04_notes.md).
+    const uint32_t gl = lane & 15u, grp = lane >> 4;
+    double rx[8], ry[8];
+    uint32_t rvalid = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint32_t i = gl + 16u * (uint32_t) k;
+        rx[k] = i < n ? px[i] : 0.0;
+        ry[k] = i < n ? py[i] : 0.0;
+        rvalid |= i < n ? 1u << k : 0u;
+    }
+    // nearest candidate to (qx, qy) — per row: the rows may ask different questions — among this lane's candidates in `mask`
+    // with a key above `floor_key` (the k-th nearest = the nearest above the (k-1)-th's key: keys are unique, the index is in them)
+    const int rK = (int) ((n + 15u) / 16u);   // registers in use (the same in every lane)
+    auto row_nearest = [&](double qx, double qy, uint32_t mask, bool above, unsigned long long floor_key) __attribute__((always_inline)) -> unsigned long long {
         unsigned long long best = ~0ull;
-        for (uint32_t i = lane; i < n; i += GR_T) {
-            if (i == skip || (only_free && assigned[i])) continue;
-            const double dx = px[i] - qx, dy = py[i] - qy;
-            const unsigned long long k = pack_key(dx * dx + dy * dy, i);
-            best = k < best ? k : best;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k >= rK) break;
+            const double dx = rx[k] - qx, dy = ry[k] - qy;
+            const unsigned long long key = pack_key(dx * dx + dy * dy, gl + 16u * (uint32_t) k);
+            const bool take = ((mask >> k) & 1u) && (!above || key > floor_key) && key < best;
+            best = take ? key : best;
         }
-        return wave_min_u64(best);
+        return row_min_u64(best);
     };
+    auto bit_of = [&](uint32_t j) -> uint32_t { return (j & 15u) == gl ? 1u << (j >> 4) : 0u; };   // this lane's mask bit of candidate j
 
     // seed: the candidate closest to the centroid (an interior circle has all four diagonal neighbours)
     double sx = 0, sy = 0;
@@ -139,9 +183,13 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     const unsigned long long gr_t0__ = gr_t__;
     uint32_t gr_sweeps__ = 0;
     if (lane == 0) atomicAdd(&g_gr_cycles[15], 1ull);
+    uint32_t gr_outcome__ = 4;   // 0 / 1: found by the first start's walk / second attempt; 2 / 3: by a later start's; 4: not found
     auto gr_done__ = [&](uint32_t nodes) {
         if (lane == 0) {
             const unsigned long long cyc = __builtin_amdgcn_s_memtime() - gr_t0__;
+            const uint32_t oc = gr_outcome__ == 4u && n == M ? 5u : gr_outcome__;   // 5: not found with exactly M candidates
+            atomicAdd(&g_gr_out[oc], 1ull);
+            atomicAdd(&g_gr_out[8 + oc], cyc);
             atomicAdd(&g_gr_hist[63 - __clzll((long long) (cyc | 1ull)) < 23 ? 63 - __clzll((long long) (cyc | 1ull)) : 23], 1ull);
             atomicMax(&g_gr_hist[24], (cyc << 24) | ((unsigned long long) (n & 0xFFu) << 16) | ((unsigned long long) (nodes & 0xFFu) << 8) | (gr_sweeps__ & 0xFFu));
         }
@@ -160,60 +208,73 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     // first walk places two thirds of the pattern.  Then up to two more starts from the next such seeds, first walk only.  (Measured on the 50 M-event search, 1270 pieces: five extra starts
     // with second attempts cost 25 % of the search's time; tests/test_gpu_grid.py states the verdicts under clutter.)
     constexpr int GR_NB = 8, GR_SEEDS = 5, GR_EXTRA = 3;
-    uint32_t seeds[GR_SEEDS];
+    unsigned long long seeds_p = 0;   // the seeds, a byte each (an array indexed at run time would live in scratch memory)
+    auto seeds = [&](int q) -> uint32_t { return (uint32_t) (seeds_p >> (8 * q)) & 0xFFu; };
     int n_seeds = 0;
-    for (int st = 0; st < GR_SEEDS; st++) {   // the candidates nearest the centroid, nearest first
-        const unsigned long long rs = nearest(sx / n, sy / n, true, 0xFFFFFFFFu);
-        if (rs == ~0ull) break;
-        seeds[n_seeds++] = (uint32_t) (rs & 0xFFu);
-        if (lane == 0) assigned[seeds[st]] = 1;
-        __syncthreads();
+    {
+        unsigned long long floor_key = 0;
+        for (int st = 0; st < GR_SEEDS; st++) {   // the candidates nearest the centroid, nearest first
+            const unsigned long long rs = lane_u64(row_nearest(sx / n, sy / n, rvalid, st > 0, floor_key), 0);
+            if (rs == ~0ull) break;
+            seeds_p |= (rs & 0xFFull) << (8 * n_seeds);
+            n_seeds++;
+            floor_key = rs;
+        }
     }
-    if (lane == 0)
-        for (int q = 0; q < n_seeds; q++) assigned[seeds[q]] = 0;
-    __syncthreads();
     if (n_seeds == 0) return;
     // the two steps of a walk from `seed` (all candidates free on entry and on return); false: none
     // mode 0: the first start's rule (false: the seed has no two independent paired vectors — try the next seed);
     // mode 1: paired vectors only; mode 2: the plain rule whatever the pairs say
-    auto choose_basis = [&](uint32_t seed, int mode, double &ax, double &ay, double &bx, double &by) -> bool {
-        uint32_t nb[GR_NB];
-        for (int k = 0; k < GR_NB; k++) {   // the eight nearest neighbours, nearest first
-            const unsigned long long r = nearest(px[seed], py[seed], true, seed);
-            nb[k] = r == ~0ull ? seed : (uint32_t) (r & 0xFFu);
-            if (lane == 0 && r != ~0ull) assigned[nb[k]] = 1;
-            __syncthreads();
+    auto choose_basis = [&](uint32_t seed, int mode, double &ax, double &ay, double &bx, double &by) __attribute__((always_inline)) -> bool {
+        unsigned long long nb_p = 0;   // the neighbours, a byte each
+        auto nb = [&](int k) -> uint32_t { return (uint32_t) (nb_p >> (8 * k)) & 0xFFu; };
+        const uint32_t not_seed = rvalid & ~bit_of(seed);
+        {
+            unsigned long long floor_key = 0;
+            bool none = false;
+            for (int k = 0; k < GR_NB; k++) {   // the eight nearest neighbours, nearest first
+                const unsigned long long r = none ? ~0ull : lane_u64(row_nearest(px[seed], py[seed], not_seed, k > 0, floor_key), 0);
+                none = r == ~0ull;
+                nb_p |= (unsigned long long) (none ? seed : (uint32_t) (r & 0xFFu)) << (8 * k);
+                floor_key = r;
+            }
         }
-        if (lane == 0)
-            for (int k = 0; k < GR_NB; k++) assigned[nb[k]] = 0;
-        __syncthreads();
         // antipodal pairs: neighbour k counts when some other candidate sits at s - (p_k - s), within 0.3 of the step
+        // (four neighbours at a time: a row of lanes per question)
         uint32_t paired = 0;
         if (mode != 2)
-            for (int k = 0; k < GR_NB; k++) {
-                if (nb[k] == seed) break;
-                const double vx = px[nb[k]] - px[seed], vy = py[nb[k]] - py[seed];
-                const unsigned long long r = nearest(px[seed] - vx, py[seed] - vy, false, seed);
-                if (r == ~0ull) continue;
-                const uint32_t j = (uint32_t) (r & 0xFFu);
-                const double ex = px[j] - (px[seed] - vx), ey = py[j] - (py[seed] - vy);
-                if (j != nb[k] && ex * ex + ey * ey <= 0.09 * (vx * vx + vy * vy)) paired |= 1u << k;
+#pragma unroll
+            for (int k0 = 0; k0 < GR_NB; k0 += 4) {
+                const uint32_t nbk = nb(k0 + (int) grp);
+                const double vxr = px[nbk] - px[seed], vyr = py[nbk] - py[seed];
+                const unsigned long long rr = row_nearest(px[seed] - vxr, py[seed] - vyr, not_seed, false, 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = k0 + q;
+                    if (nb((int) (k)) == seed) continue;
+                    const unsigned long long r = lane_u64(rr, 16 * q);
+                    if (r == ~0ull) continue;
+                    const double vx = px[nb((int) (k))] - px[seed], vy = py[nb((int) (k))] - py[seed];
+                    const uint32_t j = (uint32_t) (r & 0xFFu);
+                    const double ex = px[j] - (px[seed] - vx), ey = py[j] - (py[seed] - vy);
+                    if (j != nb((int) (k)) && ex * ex + ey * ey <= 0.09 * (vx * vx + vy * vy)) paired |= 1u << k;
+                }
             }
         auto parallel = [&](uint32_t ka, uint32_t kb) -> bool {
-            const double ux = px[nb[ka]] - px[seed], uy = py[nb[ka]] - py[seed], dx = px[nb[kb]] - px[seed], dy = py[nb[kb]] - py[seed];
+            const double ux = px[nb((int) (ka))] - px[seed], uy = py[nb((int) (ka))] - py[seed], dx = px[nb((int) (kb))] - px[seed], dy = py[nb((int) (kb))] - py[seed];
             const double cr = fabs(ux * dy - uy * dx), nn = sqrt((ux * ux + uy * uy) * (dx * dx + dy * dy));
             return !(nn > 0 && cr / nn > 0.5);
         };
         auto short_enough = [&](uint32_t ka, uint32_t kb) -> bool {   // not longer than four times the first
-            const double ux = px[nb[ka]] - px[seed], uy = py[nb[ka]] - py[seed], dx = px[nb[kb]] - px[seed], dy = py[nb[kb]] - py[seed];
+            const double ux = px[nb((int) (ka))] - px[seed], uy = py[nb((int) (ka))] - py[seed], dx = px[nb((int) (kb))] - px[seed], dy = py[nb((int) (kb))] - py[seed];
             return (dx * dx + dy * dy) < 16.0 * (ux * ux + uy * uy);
         };
         // the plain rule: the nearest neighbour and the FIRST one not parallel to it (too long: no lattice here)
         int qa = -1, qb = -1;
-        if (nb[0] != seed) {
+        if (nb((int) (0)) != seed) {
             qa = 0;
             for (int k = 1; k < GR_NB; k++) {
-                if (nb[k] == seed) break;
+                if (nb((int) (k)) == seed) break;
                 if (!parallel(0u, (uint32_t) k)) {
                     if (short_enough(0u, (uint32_t) k)) qb = k;
                     break;
@@ -223,7 +284,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         // the paired rule: the shortest two independent paired vectors
         int ka = -1, kb = -1;
         for (int k = 0; k < GR_NB && kb < 0; k++) {
-            if (nb[k] == seed) break;
+            if (nb((int) (k)) == seed) break;
             if (!((paired >> k) & 1u)) continue;
             if (ka < 0) ka = k;
             else if (!parallel((uint32_t) ka, (uint32_t) k) && short_enough((uint32_t) ka, (uint32_t) k)) kb = k;
@@ -233,10 +294,10 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             kb = qb;
         }
         if (ka < 0 || kb < 0) return false;
-        ax = px[nb[ka]] - px[seed];
-        ay = py[nb[ka]] - py[seed];
-        bx = px[nb[kb]] - px[seed];
-        by = py[nb[kb]] - py[seed];
+        ax = px[nb((int) (ka))] - px[seed];
+        ay = py[nb((int) (ka))] - py[seed];
+        bx = px[nb((int) (kb))] - px[seed];
+        by = py[nb((int) (kb))] - py[seed];
         if (ax * by - ay * bx < 0) {  // right-handed (u, v) in image coordinates
             bx = -bx;
             by = -by;
@@ -246,7 +307,9 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     bool got = false;
     uint32_t qh = 0, qt = 0;
     // fit_h: the homography lattice (u, v) -> image through the placed nodes (inhomogeneous DLT, 8 x 8 normal equations)
-    auto fit_h = [&]() {
+    // (always_inline: a lambda the compiler leaves as a function takes its captures by address — `qt`, `lane`, … would live in
+    // scratch memory for the whole kernel, a trip to memory per use inside the walk)
+    auto fit_h = [&]() __attribute__((always_inline)) {
         // The normal equations of the node rows [u v 1 0 0 0 -ux -vx | x], [0 0 0 u v 1 -uy -vy | y] are made of 24 sums
         // S(a, b, g) = sum over the nodes of u^a v^b g with a + b <= 2 and g in {1, x, y, x^2 + y^2}: a lane per sum
         // (index 4 * m + g, m = 0..5 for u^a v^b = 1, u, v, u^2, u v, v^2), nodes in queue order.
@@ -334,26 +397,30 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         }
         __syncthreads();
     };
-    auto fit_all = [&]() { fit_h(); };
-    auto nearest_any = [&](double qx, double qy) -> unsigned long long { return nearest(qx, qy, false, 0xFFFFFFFFu); };
+    auto fit_all = [&]() __attribute__((always_inline)) { fit_h(); };
     int seed_at = 0;   // the next seed to look at
 #pragma nounroll
     for (int start = 0; start <= GR_EXTRA && !got; start++) {
     if (start > 0 && n <= M) break;   // (exactly the pattern's count of candidates: no clutter to have misled the first start)
-    uint32_t seed = seeds[0];
+    if (start > 0) {   // the previous start's walk is wiped
+        for (uint32_t i = lane; i < n; i += GR_T) assigned[i] = 0;
+        for (uint32_t k = lane; k < GR_L * GR_L; k += GR_T) occ[k] = 0;
+        __syncthreads();
+    }
+    uint32_t seed = seeds(0);
     double ax = 0, ay = 0, bx = 0, by = 0;
     bool have = false;
     if (start == 0) {          // the plain start, as it has always been: nothing that was found before round 4 is lost
         have = choose_basis(seed, 2, ax, ay, bx, by);
     } else if (start == 1) {   // the robust start: the first seed with two independent paired vectors, plain steps if THEY are paired
         for (int q = 0; q < n_seeds && !have; q++) {
-            seed = seeds[q];
+            seed = seeds(q);
             have = choose_basis(seed, 0, ax, ay, bx, by);
             seed_at = q + 1;
         }
     } else {                   // the next seeds, paired steps
         while (seed_at < n_seeds && !have) {
-            seed = seeds[seed_at++];
+            seed = seeds(seed_at++);
             have = choose_basis(seed, 1, ax, ay, bx, by);
         }
     }
@@ -361,11 +428,6 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         if (debug && lane == 0) out[8 + start] = -1000;
         if (start == 0) continue;
         break;
-    }
-    if (start > 0) {   // the previous start's walk is wiped
-        for (uint32_t i = lane; i < n; i += GR_T) assigned[i] = 0;
-        for (uint32_t k = lane; k < GR_L * GR_L; k += GR_T) occ[k] = 0;
-        __syncthreads();
     }
     GR_MARK(0);   // seed + basis
     // breadth-first walk
@@ -384,46 +446,101 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     }
     qt = 1;
     __syncthreads();
+    // a node's four directions at once, a row of lanes each; the candidates still free in `rfree` (this lane's)
+    uint32_t rfree = rvalid & ~bit_of(seed);
     while (qh < qt) {
         const uint32_t cur = queue[qh++];
         const int u0 = cu[cur], v0 = cv[cur];
         const double b1x = e1x[cur], b1y = e1y[cur], b2x = e2x[cur], b2y = e2y[cur];
-        for (int dir = 0; dir < 4; dir++) {
-            const int du = dir == 0 ? 1 : (dir == 1 ? -1 : 0), dv = dir == 2 ? 1 : (dir == 3 ? -1 : 0);
-            const int u = u0 + du, v = v0 + dv;
-            if (u < -GR_L / 2 || u >= GR_L / 2 || v < -GR_L / 2 || v >= GR_L / 2) continue;
-            if (occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)]) continue;
-            const double sxp = du * b1x + dv * b2x, syp = du * b1y + dv * b2y;
-            const double tx = px[cur] + sxp, ty = py[cur] + syp;
-            const unsigned long long r = nearest(tx, ty, true, 0xFFFFFFFFu);
-            if (r == ~0ull) continue;
-            const uint32_t j = (uint32_t) (r & 0xFFu);
-            const double ddx = px[j] - tx, ddy = py[j] - ty;
-            // the vendored finder takes the nearest keypoint within minDistanceToAddKeypoint = 20 px of (neighbour + basis
-            // vector) as the hole, else the line stays incomplete (circlesgrid.cpp:528,812-840,928-930: a synthetic
-            // keypoint earns no existingVertexGain); capped at tol_frac of the step for small apparent patterns
-            const double lim = fmin(tol_px * tol_px, tol_frac * tol_frac * (sxp * sxp + syp * syp));
-            if (ddx * ddx + ddy * ddy > lim) continue;
-            if (lane == 0) {
+        const double pcx = px[cur], pcy = py[cur];
+        const int du = grp == 0u ? 1 : (grp == 1u ? -1 : 0), dv = grp == 2u ? 1 : (grp == 3u ? -1 : 0);
+        const int u = u0 + du, v = v0 + dv;
+        const bool cell_ok = !(u < -GR_L / 2 || u >= GR_L / 2 || v < -GR_L / 2 || v >= GR_L / 2) && occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] == 0;
+        const double sxp = du * b1x + dv * b2x, syp = du * b1y + dv * b2y;
+        const double tx = pcx + sxp, ty = pcy + syp;
+        // the vendored finder takes the nearest keypoint within minDistanceToAddKeypoint = 20 px of (neighbour + basis
+        // vector) as the hole, else the line stays incomplete (circlesgrid.cpp:528,812-840,928-930: a synthetic
+        // keypoint earns no existingVertexGain); capped at tol_frac of the step for small apparent patterns
+        const double lim = fmin(tol_px * tol_px, tol_frac * tol_frac * (sxp * sxp + syp * syp));
+        unsigned long long r = row_nearest(tx, ty, rfree, false, 0);
+        // every row tests its own answer; the usual case — the accepted candidates are different ones — is written by the
+        // four rows at once.  Two directions that want the same candidate go through the one-after-the-other form below.
+        uint32_t jr = (uint32_t) (r & 0xFFu);
+        bool acc = false;
+        if (cell_ok && r != ~0ull) {
+            const double ddx = px[jr] - tx, ddy = py[jr] - ty;
+            acc = ddx * ddx + ddy * ddy <= lim;
+        }
+        const uint32_t a0 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 0), a1 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 16),
+                       a2 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 32), a3 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 48);
+        const uint32_t j0 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 0), j1 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 16),
+                       j2 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 32), j3 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 48);
+        const bool clash = (a0 && a1 && j0 == j1) || (a0 && a2 && j0 == j2) || (a0 && a3 && j0 == j3) || (a1 && a2 && j1 == j2) ||
+                           (a1 && a3 && j1 == j3) || (a2 && a3 && j2 == j3);
+        uint32_t n_new = 0;
+        if (!clash) {
+            const uint32_t before = grp == 0u ? 0u : (grp == 1u ? a0 : (grp == 2u ? a0 + a1 : a0 + a1 + a2));
+            n_new = a0 + a1 + a2 + a3;
+            rfree &= ~((a0 ? bit_of(j0) : 0u) | (a1 ? bit_of(j1) : 0u) | (a2 ? bit_of(j2) : 0u) | (a3 ? bit_of(j3) : 0u));
+            if (acc && gl == 0u) {
+                const uint32_t j = jr;
                 assigned[j] = 1;
                 cu[j] = (int8_t) u;
                 cv[j] = (int8_t) v;
                 // the step actually taken refreshes the matching basis vector (perspective / distortion drift)
-                const double mx = px[j] - px[cur], my = py[j] - py[cur];
+                const double mx = px[j] - pcx, my = py[j] - pcy;
                 e1x[j] = du ? du * mx : b1x;
                 e1y[j] = du ? du * my : b1y;
                 e2x[j] = dv ? dv * mx : b2x;
                 e2y[j] = dv ? dv * my : b2y;
                 occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] = (uint8_t) (j + 1);
-                queue[qt] = (uint8_t) j;
+                queue[qt + before] = (uint8_t) j;
             }
-            qt++;
-            __syncthreads();
+        } else {
+        uint32_t taken[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {   // in the order of the directions, as a walk that asks one question after the other
+            taken[d] = 0xFFFFFFFFu;
+            if (!__builtin_amdgcn_readlane((int) cell_ok, 16 * d)) continue;
+            unsigned long long rd = lane_u64(r, 16 * d);
+            if (rd == ~0ull) continue;
+            uint32_t j = (uint32_t) (rd & 0xFFu);
+            bool again = false;
+#pragma unroll
+            for (int e = 0; e < 4; e++) again = again || (e < d && taken[e] == j);
+            if (again) {   // an earlier direction of this node took that candidate: this row asks again
+                const unsigned long long r2 = row_nearest(tx, ty, rfree, false, 0);
+                if (grp == (uint32_t) d) r = r2;
+                rd = lane_u64(r2, 16 * d);
+                if (rd == ~0ull) continue;
+                j = (uint32_t) (rd & 0xFFu);
+            }
+            const double txd = lane_f64(tx, 16 * d), tyd = lane_f64(ty, 16 * d), limd = lane_f64(lim, 16 * d);
+            const double ddx = px[j] - txd, ddy = py[j] - tyd;
+            if (ddx * ddx + ddy * ddy > limd) continue;
+            taken[d] = j;
+            rfree &= ~bit_of(j);
+            if (lane == 16u * (uint32_t) d) {
+                assigned[j] = 1;
+                cu[j] = (int8_t) u;
+                cv[j] = (int8_t) v;
+                const double mx = px[j] - pcx, my = py[j] - pcy;
+                e1x[j] = du ? du * mx : b1x;
+                e1y[j] = du ? du * my : b1y;
+                e2x[j] = dv ? dv * mx : b2x;
+                e2y[j] = dv ? dv * my : b2y;
+                occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] = (uint8_t) (j + 1);
+                queue[qt + n_new] = (uint8_t) j;
+            }
+            n_new++;
         }
+        }
+        qt += n_new;
+        __syncthreads();
     }
     __syncthreads();
     GR_MARK(1);   // first walk
-    auto match_pattern = [&]() -> bool {
+    auto match_pattern = [&]() __attribute__((always_inline)) -> bool {
         if (qt < M) return false;
         // match the pattern: model point (x, y) = ((2j + i%2), i) has lattice coordinates U = (x+y)/2, V = (y-x)/2 in the
         // right-handed basis E1 = (1,1), E2 = (-1,1).  The walk's basis (two short independent steps around the seed) is SOME
@@ -499,6 +616,9 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
 
     };
     got = match_pattern();
+#ifdef ECAL_PHASE_PROF
+    if (got) gr_outcome__ = start == 0 ? 0u : 2u;
+#endif
     GR_MARK(2);   // first match
     // (the robust start gets its second attempt only when its first walk looks like the pattern's lattice: two thirds placed)
     if (!got && qt >= 4u && (start == 0 || (start == 1 && 3u * qt >= 2u * M))) {
@@ -621,6 +741,9 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             GR_MARK(5);   // sweeps' searches
             if (qt == qt_before) break;
             if (qt >= M) got = match_pattern();
+#ifdef ECAL_PHASE_PROF
+            if (got) gr_outcome__ = start == 0 ? 1u : 3u;
+#endif
             GR_MARK(6);   // matches after sweeps
         }
     }
@@ -637,13 +760,11 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
     // and every model point takes the candidate nearest to its prediction; twice.  Without clutter nothing changes.
     for (int it = 0; it < 2; it++) {
         __syncthreads();
-        if (lane == 0) {
-            for (uint32_t m = 0; m < M; m++) {
-                const uint32_t j = sel[m];
-                queue[m] = (uint8_t) j;
-                cu[j] = mU[m];
-                cv[j] = mV[m];
-            }
+        for (uint32_t m = lane; m < M; m += GR_T) {   // (the matched candidates are M different ones)
+            const uint32_t j = sel[m];
+            queue[m] = (uint8_t) j;
+            cu[j] = mU[m];
+            cv[j] = mV[m];
         }
         qt = M;
         __syncthreads();
@@ -658,26 +779,36 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             res[m] = dx * dx + dy * dy;
         }
         __syncthreads();
-        if (lane == 0) {
+        {   // a lane per model point counts the worse ones; the kept ones go to the queue in model order
             uint32_t keep = 0;
-            for (uint32_t m = 0; m < M; m++) {
+            for (uint32_t m0 = 0; m0 < M; m0 += GR_T) {
+                const uint32_t m = m0 + lane;
                 uint32_t worse = 0;   // model points with a larger residual (ties: larger index)
-                for (uint32_t q = 0; q < M; q++) worse += (res[q] > res[m] || (res[q] == res[m] && q > m)) ? 1u : 0u;
-                if (worse >= 6u || M <= 12u) queue[keep++] = sel[m];
+                if (m < M)
+                    for (uint32_t q = 0; q < M; q++) worse += (res[q] > res[m] || (res[q] == res[m] && q > m)) ? 1u : 0u;
+                const bool kept = m < M && (worse >= 6u || M <= 12u);
+                const unsigned long long km = __ballot(kept);
+                if (kept) queue[keep + (uint32_t) __popcll(km & ((1ull << lane) - 1ull))] = sel[m];
+                keep += (uint32_t) __popcll(km);
             }
-            sh_qt = keep;
+            qt = keep;
         }
         __syncthreads();
-        qt = sh_qt;
         fit_all();
         if (!(hh[0] == hh[0])) break;
         // nearest candidates to the predictions; taken only when they are M distinct candidates
         uint8_t *const pick = assigned;   // [M] (dead too)
         bool distinct = true;
-        for (uint32_t m = 0; m < M; m++) {
+        for (uint32_t m = lane; m < M; m += GR_T) {   // a lane per model point looks at every candidate (broadcast reads; the same order: distance, then index)
             const double u = mU[m], v = mV[m], wq = hh[6] * u + hh[7] * v + 1.0;
-            const unsigned long long r = nearest_any((hh[0] * u + hh[1] * v + hh[2]) / wq, (hh[3] * u + hh[4] * v + hh[5]) / wq);
-            if (lane == 0) pick[m] = (uint8_t) (r & 0xFFu);
+            const double qx = (hh[0] * u + hh[1] * v + hh[2]) / wq, qy = (hh[3] * u + hh[4] * v + hh[5]) / wq;
+            unsigned long long best = ~0ull;
+            for (uint32_t i = 0; i < n; i++) {
+                const double dx = px[i] - qx, dy = py[i] - qy;
+                const unsigned long long k = pack_key(dx * dx + dy * dy, i);
+                best = k < best ? k : best;
+            }
+            pick[m] = (uint8_t) (best & 0xFFu);
         }
         __syncthreads();
         for (uint32_t m = lane; m < M; m += GR_T)
@@ -720,6 +851,12 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
 #ifdef ECAL_PHASE_PROF
 extern "C" int ecal_debug_grid_cycles(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_gr_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset == 4) {   // the outcomes instead
+        if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_gr_out), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_gr_out), z, sizeof(z)) != hipSuccess) return -1;
+        return 0;
+    }
     if (reset >= 2) {   // the histogram instead
         unsigned long long hst[32];
         if (hipMemcpyFromSymbol(hst, HIP_SYMBOL(ecal::g_gr_hist), sizeof(hst)) != hipSuccess) return -1;

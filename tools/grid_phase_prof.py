@@ -21,6 +21,7 @@ b = (ctypes.c_ulonglong * 16)()
 detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, 5.0, 5.0 + (n - 1) / 1e6)
 L.ecal_debug_grid_cycles(b, 1)
 L.ecal_debug_grid_cycles(b, 3)
+L.ecal_debug_grid_cycles(b, 4)
 kf = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, 5.0, 5.0 + (n - 1) / 1e6)
 L.ecal_debug_grid_cycles(b, 0)
 v = list(b); w = max(v[15], 1); tot = sum(v[:7])
@@ -34,3 +35,11 @@ h = list(h)
 print("windows by cycles: " + "  ".join("2^%d: %d" % (i + 10, h[i]) for i in range(14) if h[i]))
 mx = h[14]
 print("slowest window: %d cycles, %d candidates, %d nodes at the end, %d sweeps" % (mx >> 24, (mx >> 16) & 255, (mx >> 8) & 255, mx & 255))
+
+o = (ctypes.c_ulonglong * 16)()
+L.ecal_debug_grid_cycles(o, 4)
+o = list(o)
+for i, nm in enumerate(["found: first start, first walk", "found: first start, second attempt", "found: later start, first walk", "found: later start, second attempt",
+                        "not found, more candidates than pattern points", "not found, exactly as many"]):
+    if o[i]:
+        print("  %-50s %6d windows, %8.0f cycles each, %5.1f %% of all cycles" % (nm, o[i], o[8 + i] / o[i], 100.0 * o[8 + i] / max(1, sum(o[8:14]))))
