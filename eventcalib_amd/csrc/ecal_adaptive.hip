@@ -28,6 +28,7 @@
 #include "ref_nth_element.hpp"
 
 #include <math.h>
+#include <atomic>
 #include <chrono>
 
 #include <algorithm>
@@ -181,8 +182,12 @@ __device__ __forceinline__ void write_chain(uint32_t D, double f, double s2, dou
 // average 83), so most passes see few pieces still at work: the B slots of a pass are dealt out evenly among THOSE, up to
 // d_max windows of chain each — the fewer pieces remain, the further each one looks ahead.  One workgroup.
 constexpr int AD_ALLOC_T = 1024;
+// report (pinned host memory, may be NULL) + seq: the pass that ends with this launch tells the host how it went — pieces still
+// active, keyframe records so far, capacity overflow, and LAST the pass's number, which the host polls for (a copy engine
+// transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
+// and takes the active-pieces counter back to zero for the next pass.
 __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t deal, uint32_t d_max, AdaptiveArrays st,
-                                                                    double mts, double *t0, double *t1) {
+                                                                    double mts, double *t0, double *t1, uint32_t *report, uint32_t seq) {
     __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
@@ -219,6 +224,15 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     for (uint32_t i = n_act * D + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
         t0[i] = INFINITY;
         t1[i] = -INFINITY;
+    }
+    if (report && tid == 0) {
+        const uint32_t active = st.counters[0];
+        st.counters[0] = 0;
+        __hip_atomic_store(&report[0], active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&report[1], st.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&report[3], st.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -580,9 +594,13 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // p - ahead left (a copy to pinned memory + an event behind every pass) — the device always has work queued, and at most
     // `ahead` passes run with nothing left to do.
     const uint32_t ahead = ap->check_every ? (ap->check_every < 8u ? ap->check_every : 8u) : 2u;
-    for (int i = 0; i < 8; i++)
-        if (!ctx->adaptive_ev[i]) ECAL_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->adaptive_ev[i], hipEventDisableTiming));
-    uint32_t *ring = h + 16;   // [8][4] counters as the passes left them
+    // [8][4] in pinned memory: what the last kernel of a pass reports (adaptive_alloc_kernel) — active pieces, records, the
+    // pass's number, overflow.  The host polls the number: no copy, no event between the kernels.
+    volatile uint32_t *ring = h + 16;
+    uint32_t *d_ring = nullptr;
+    ECAL_HIP_TRY(ctx, hipHostGetDevicePointer((void **) &d_ring, (void *) (h + 16), 0));
+    for (int i = 0; i < 32; i++) ring[i] = 0;
+    uint32_t seq = 0;   // passes enqueued in this call (over all its sets of runs): the number a pass reports
     // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
     // takes a piece through up to D of them
     const uint32_t max_levels = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
@@ -608,11 +626,25 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         // kernels over the slots it deals out, not over all S: thousands of workgroups that find an empty window still cost
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
-        hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1);
+        hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
+                           (uint32_t *) nullptr, 0u);
+        const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
-                const uint32_t q = (pass - ahead) % 8u;
-                AD_TRY(hip_rc(hipEventSynchronize(ctx->adaptive_ev[q]), "hipEventSynchronize"));
+                const uint32_t want = seq0 + pass - ahead + 1u, q = (want - 1u) % 8u;
+                auto t_wait = std::chrono::steady_clock::now();
+                for (uint32_t spin = 0; ring[4 * q + 2] != want; spin++) {
+                    for (int i = 0; i < 8; i++) __builtin_ia32_pause();
+                    if ((spin & 0x3FFFu) == 0x3FFFu && std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(2)) {
+                        // overdue: a stream that has stopped (an error) will never report
+                        const hipError_t qe = hipStreamQuery(st);
+                        if (qe != hipErrorNotReady && ring[4 * q + 2] != want) {
+                            AD_TRY(hip_rc(qe == hipSuccess ? hipErrorUnknown : qe, "a pass of the keyframe search did not report"));
+                        }
+                        t_wait = std::chrono::steady_clock::now();
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
                 if (ring[4 * q + 3]) {
                     (void) hipStreamSynchronize(st);
                     ctx->last_error = range_msg;
@@ -622,7 +654,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 if (ring[4 * q] == 0) break;   // (the passes enqueued since find nothing to do)
             }
             n_passes++;
-            AD_TRY(hip_rc(hipMemsetAsync(a.counters, 0, sizeof(uint32_t), st), "hipMemsetAsync"));  // pieces active after this pass
+            seq++;
             AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sr, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                           (uint32_t *) B[4].ptr, st));
             AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sr, 0,
@@ -645,9 +677,8 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                                max_keys, d_kt, d_kd, d_ke, d_kf, d_kp, d_kg, d_t0, d_t1, (const int *) B[16].ptr,
                                (const double *) ctx->adaptive_dirs.ptr);
-            hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1);
-            AD_TRY(hip_rc(hipMemcpyAsync(ring + 4 * (pass % 8u), a.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync"));
-            AD_TRY(hip_rc(hipEventRecord(ctx->adaptive_ev[pass % 8u], st), "hipEventRecord"));
+            hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
+                               d_ring + 4 * ((seq - 1u) % 8u), seq);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));
