@@ -26,6 +26,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.solver_device_linear_solve = on("ECAL_SOLVER_DEVICE_LINEAR_SOLVE");
     sw.solver_trace = on("ECAL_SOLVER_TRACE");
     sw.solver_no_stream = on("ECAL_SOLVER_NO_STREAM");
+    sw.solver_two_roles = on("ECAL_SOLVER_TWO_ROLES");
     sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
     sw.adaptive_depth_max = (int) num("ECAL_ADAPTIVE_DEPTH_MAX");
     sw.arrow_k = (int) num("ECAL_ARROW_K");

@@ -126,19 +126,67 @@ struct NeProgress {
 
 // records [r_lo, r_hi) of the accumulation buffer to the host's copy; the values were added by other workgroups' atomics on
 // any of the eight XCDs: agent-scope loads (a plain load could be served from this XCD's L2)
-__device__ __forceinline__ void ne_copy_records(const double *accum, double *host, uint32_t r_lo, uint32_t r_hi, int tid) {
+__device__ __forceinline__ void ne_copy_records(const double *accum, double *host, uint32_t r_lo, uint32_t r_hi, int tid, int nthreads) {
     const size_t lo = ACC_HEAD + ACC_PER_CP * (size_t) r_lo, hi = ACC_HEAD + ACC_PER_CP * (size_t) r_hi;
-    for (size_t i = lo + (size_t) tid; i < hi; i += 8 * (size_t) NE_T) {
+    for (size_t i = lo + (size_t) tid; i < hi; i += 8 * (size_t) nthreads) {
         double v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const size_t k = i + (size_t) u * NE_T;
+            const size_t k = i + (size_t) u * nthreads;
             v[u] = k < hi ? __hip_atomic_load(accum + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const size_t k = i + (size_t) u * NE_T;
+            const size_t k = i + (size_t) u * nthreads;
             if (k < hi) host[k] = v[u];
+        }
+    }
+}
+
+// the end of a chunk's workgroup in a streamed evaluation (NeProgress): the group's (and its separators') records to the host
+// when this chunk is the last one of the group.  Called by every thread of the workgroup (nthreads of them) after its adds.
+__device__ __forceinline__ void ne_publish_progress(const NeProgress *__restrict__ prog, uint32_t epoch, const double *accum, uint32_t c0, int tid,
+                                                    int nthreads) {
+    __shared__ uint32_t fin[3];
+    __threadfence();
+    __syncthreads();   // every thread's adds are out
+    const uint32_t P = prog->n_groups;
+    if (tid == 0) {
+        const uint32_t sg = c0 + 3;
+        uint32_t g = 0;
+        while (g + 1 < P && prog->cut[g + 1] <= sg) g++;
+        uint32_t *left = prog->left;
+        const bool last = atomicSub(&left[g], 1u) == 1u;
+        fin[0] = last ? g + 1 : 0;
+        fin[1] = fin[2] = 0;
+        if (last) {
+            left[g] = prog->init[g];
+            if (g > 0 && atomicSub(&left[NE_MAX_GROUPS + g - 1], 1u) == 1u) {
+                fin[1] = 1;
+                left[NE_MAX_GROUPS + g - 1] = prog->init[NE_MAX_GROUPS + g - 1];
+            }
+            if (g + 1 < P && atomicSub(&left[NE_MAX_GROUPS + g], 1u) == 1u) {
+                fin[2] = 1;
+                left[NE_MAX_GROUPS + g] = prog->init[NE_MAX_GROUPS + g];
+            }
+        }
+    }
+    __syncthreads();
+    if (fin[0]) {
+        __threadfence();
+        const uint32_t g = fin[0] - 1;
+        const uint32_t c_lo = prog->cut[g], c_next = prog->cut[g + 1];
+        double *host = prog->host_acc;
+        ne_copy_records(accum, host, c_lo, g + 1 < P ? c_next - 3 : c_next, tid, nthreads);
+        if (fin[1]) ne_copy_records(accum, host, c_lo - 3, c_lo, tid, nthreads);
+        if (fin[2]) ne_copy_records(accum, host, c_next - 3, c_next, tid, nthreads);
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t *flag = prog->host_flag;
+            __hip_atomic_store(&flag[g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (fin[1]) __hip_atomic_store(&flag[NE_MAX_GROUPS + g - 1], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (fin[2]) __hip_atomic_store(&flag[NE_MAX_GROUPS + g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -361,50 +409,197 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             }
         }
     }
-    if (prog) {   // streamed evaluation: the group's (and its separators') records to the host when this chunk is the last one
-        __shared__ uint32_t fin[3];
-        __threadfence();
-        __syncthreads();   // every thread's adds are out
-        const uint32_t P = prog->n_groups;
-        if (tid == 0) {
-            const uint32_t sg = c0 + 3;
-            uint32_t g = 0;
-            while (g + 1 < P && prog->cut[g + 1] <= sg) g++;
-            uint32_t *left = prog->left;
-            const bool last = atomicSub(&left[g], 1u) == 1u;
-            fin[0] = last ? g + 1 : 0;
-            fin[1] = fin[2] = 0;
-            if (last) {
-                left[g] = prog->init[g];
-                if (g > 0 && atomicSub(&left[NE_MAX_GROUPS + g - 1], 1u) == 1u) {
-                    fin[1] = 1;
-                    left[NE_MAX_GROUPS + g - 1] = prog->init[NE_MAX_GROUPS + g - 1];
+    if (prog) ne_publish_progress(prog, epoch, accum, c0, tid, NE_T);
+}
+
+// The same evaluation with the two phases of a batch on DIFFERENT waves (quaternion variant, round 4; ECAL_SOLVER_TWO_ROLES=1 —
+// measured: 2.26 ms per launch in either form on the benchmark problem, so the one-role kernel stays the default: both are at
+// ~70 % of the FP64 issue slots the two phases need together, which is what the other kernels of this library reach too).  In normal_eq_kernel every
+// wave evaluates 64 residuals (phase 1: ~700 flop of dependent spline arithmetic each, 241 VGPRs), waits at a barrier, and then
+// accumulates its Gram tiles over the batch's rows (phase 2: 36 FMAs per six 16-byte LDS reads), with the tiles' 72 accumulator
+// registers alive through phase 1 and the other workgroup of the CU as the only thing that may overlap the one phase with the
+// other.  Here a workgroup is 8 waves and owns the compute unit: waves 0-3 PRODUCE the rows of batch b + 1 into one half of a
+// double row buffer while waves 4-7 CONSUME batch b from the other half — one barrier per batch, a producer and a consumer wave on
+// every SIMD, so the SIMD's FP64 pipe always has the consumer's independent FMAs to issue under the producer's dependent chains
+// and the producer's arithmetic under the consumer's LDS waits.  Same arithmetic per residual and per tile as normal_eq_kernel
+// (the sums over rows are taken in the same order within a chunk); same chunk table; same flush.
+constexpr int NW_T = 512;
+constexpr size_t NW_LDS_BYTES = 2 * (size_t) NE_T * NE_LD * sizeof(double);
+template <bool FISHEYE>
+__global__ __launch_bounds__(NW_T, 1) void normal_eq_ws_kernel(const ResRecord *__restrict__ rec, const Chunk *__restrict__ chunks,
+                                                              const double *__restrict__ knots, const uint32_t *__restrict__ knot_off,
+                                                              const uint32_t *__restrict__ cp_off, const double *__restrict__ params,
+                                                              uint32_t n_cp_total, const double *__restrict__ landmarks, double radius,
+                                                              double huber_a, double *__restrict__ accum, double *__restrict__ heads,
+                                                              const NeProgress *__restrict__ prog, uint32_t epoch) {
+    constexpr int NE_TW = 6;
+    constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES, NE_GROUPS = NeTiles<NE_TW>::GROUPS;
+    extern __shared__ __attribute__((aligned(16))) double rows2[];   // [2][NE_T][NE_LD]
+    __shared__ double red[NE_T / 64];
+    const Chunk ch = chunks[blockIdx.x];
+    const int tid_all = threadIdx.x;
+    const bool producer = tid_all < NE_T;
+    const int tid = producer ? tid_all : tid_all - NE_T;   // index within the role
+    double *const head = heads + (size_t) (blockIdx.x % NE_REPL) * ACC_HEAD;
+    const uint32_t c0 = cp_off[ch.seg] + ch.span - 3;
+    const uint32_t nb = (ch.count + NE_T - 1) / NE_T;
+    double cost = 0.0;
+    double acc[NE_TW * NE_TW];
+#pragma unroll
+    for (int i = 0; i < NE_TW * NE_TW; i++) acc[i] = 0.0;
+    int ti = 0, tj = 0;
+    {
+        int rem = tid % NE_TILES;
+        for (ti = 0; ti < NE_TG; ti++) {
+            if (rem < NE_TG - ti) break;
+            rem -= NE_TG - ti;
+        }
+        tj = ti + rem;
+    }
+    const int grp = tid / NE_TILES;
+    if (producer) {
+        const double *kn = knots + knot_off[ch.seg];
+        const double *intr = params;
+        const double *qall = params + 9;
+        const double *tall = params + 9 + 4 * (size_t) n_cp_total;
+        double q[4][4], t[4][3], pin[9], binv[6];
+        for (int i = 0; i < 9; i++) pin[i] = intr[i];
+        spline_span_inverses(kn, ch.span, binv);
+        const double ifx = 1.0 / pin[0], ify = 1.0 / pin[1];
+        for (int j = 0; j < 4; j++) {
+            for (int k = 0; k < 4; k++) q[j][k] = qall[4 * (size_t) (c0 + j) + k];
+            for (int k = 0; k < 3; k++) t[j][k] = tall[3 * (size_t) (c0 + j) + k];
+        }
+        ResRecord e_next = rec[ch.start + min((uint32_t) tid, ch.count - 1u)];
+        for (uint32_t b = 0; b <= nb; b++) {   // iteration b: batch b's rows (b < nb); the consumers are on batch b - 1
+            if (b < nb) {
+                const uint32_t k = b * NE_T + (uint32_t) tid;
+                double J[RES_NJ];
+                double r = 0.0, sc = 0.0;
+                const ResRecord e = e_next;
+                e_next = rec[ch.start + min(k + (uint32_t) NE_T, ch.count - 1u)];
+                if (k < ch.count) {
+                    ResidualInput in;
+                    in.u = e.u;
+                    in.v = e.v;
+                    in.lmx = landmarks[3 * (size_t) e.lm];
+                    in.lmy = landmarks[3 * (size_t) e.lm + 1];
+                    in.lmz = landmarks[3 * (size_t) e.lm + 2];
+                    in.radius = radius;
+                    in.ifx = ifx;
+                    in.ify = ify;
+                    spline_basis_inv(kn, ch.span, binv, e.t, in.b);
+                    r = spline_residual<FISHEYE>(in, pin, q, t, J);
+                    double hr;
+                    sc = huber_scale(r, huber_a, &hr);
+                    cost += hr;
                 }
-                if (g + 1 < P && atomicSub(&left[NE_MAX_GROUPS + g], 1u) == 1u) {
-                    fin[2] = 1;
-                    left[NE_MAX_GROUPS + g] = prog->init[NE_MAX_GROUPS + g];
+                double *row = rows2 + ((size_t) (b & 1u) * NE_T + (size_t) tid) * NE_LD;
+                if (k < ch.count) {
+#pragma unroll
+                    for (int i = 0; i < RES_NJ; i++) row[i] = J[i] * sc;
+                    row[33] = r * sc;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 34; i++) row[i] = 0.0;
                 }
+                row[34] = 0.0;
+                row[35] = 0.0;
             }
+            __syncthreads();
+        }
+        for (int o = 32; o > 0; o >>= 1) cost += __shfl_down(cost, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = cost;
+    } else {
+        for (uint32_t b = 0; b <= nb; b++) {
+            if (b >= 1 && grp < NE_GROUPS) {
+                const uint32_t bp = b - 1u;
+                const uint32_t nrow = min((uint32_t) NE_T, ch.count - bp * NE_T);
+                const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) double *) (rows2 + (size_t) (bp & 1u) * NE_T * NE_LD);
+                const uint32_t a0 = lds0 + 8u * NE_TW * (uint32_t) ti, b0a = lds0 + 8u * NE_TW * (uint32_t) tj;
+                constexpr uint32_t ROWB = NE_LD * 8u;
+                ne_v2d A0[3], B0[3], A1[3], B1[3];
+                {
+                    const uint32_t o = min((uint32_t) grp, nrow - 1u) * ROWB;
+                    ne_lds_read6(a0 + o, b0a + o, A0, B0);
+                }
+                for (uint32_t rk = grp; rk < nrow; rk += 2 * NE_GROUPS) {
+                    const uint32_t r1 = rk + NE_GROUPS, r2 = rk + 2 * NE_GROUPS;
+                    const uint32_t o1 = min(r1, nrow - 1u) * ROWB, o2 = min(r2, nrow - 1u) * ROWB;
+                    ne_lds_read6(a0 + o1, b0a + o1, A1, B1);
+                    ne_lds_wait_but6(A0, B0);
+                    ne_fma36(acc, A0, B0);
+                    ne_lds_read6(a0 + o2, b0a + o2, A0, B0);
+                    ne_lds_wait_but6(A1, B1);
+                    if (r1 < nrow) ne_fma36(acc, A1, B1);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last (unused) prefetch, before the rows are rewritten
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid_all == 0) {
+        double c = 0;
+        for (int w = 0; w < NE_T / 64; w++) c += red[w];
+        atomicAdd(&head[0], c);
+    }
+    // the row groups' partial tiles summed in LDS (the row buffers are free now), then ONE flush per entry — by all 512 threads
+    {
+        constexpr int TSZ = NE_TW * NE_TW, NPART = NE_TILES * TSZ;
+        double *part = rows2;                        // [NE_GROUPS][NE_TILES * TSZ]
+        double *total = rows2;
+        static_assert((size_t) NE_GROUPS * NPART <= 2 * (size_t) NE_T * NE_LD, "the row buffers hold the partial tiles");
+        if (!producer && grp < NE_GROUPS) {
+#pragma unroll
+            for (int i = 0; i < TSZ; i++) part[(size_t) grp * NPART + (tid % NE_TILES) * TSZ + i] = acc[i];
         }
         __syncthreads();
-        if (fin[0]) {
-            __threadfence();
-            const uint32_t g = fin[0] - 1;
-            const uint32_t c_lo = prog->cut[g], c_next = prog->cut[g + 1];
-            double *host = prog->host_acc;
-            ne_copy_records(accum, host, c_lo, g + 1 < P ? c_next - 3 : c_next, tid);
-            if (fin[1]) ne_copy_records(accum, host, c_lo - 3, c_lo, tid);
-            if (fin[2]) ne_copy_records(accum, host, c_next - 3, c_next, tid);
-            __threadfence_system();
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t *flag = prog->host_flag;
-                __hip_atomic_store(&flag[g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (fin[1]) __hip_atomic_store(&flag[NE_MAX_GROUPS + g - 1], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (fin[2]) __hip_atomic_store(&flag[NE_MAX_GROUPS + g], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int e = tid_all; e < NPART; e += NW_T) {    // (in place of group 0's slice: entry e is read and written by ONE thread)
+            double v = 0.0;
+#pragma unroll
+            for (int g = 0; g < NE_GROUPS; g++) v += part[(size_t) g * NPART + e];
+            total[e] = v;
+        }
+        __syncthreads();
+        for (int e = tid_all; e < NPART; e += NW_T) {
+            const double v = total[e];
+            if (v == 0.0) continue;
+            const int tile = e / TSZ, x = (e % TSZ) / NE_TW, y = e % NE_TW;
+            int fi = 0, rem = tile;
+            for (fi = 0; fi < NE_TG; fi++) {
+                if (rem < NE_TG - fi) break;
+                rem -= NE_TG - fi;
+            }
+            const int fj = fi + rem;
+            const int li = NE_TW * fi + x, lj = NE_TW * fj + y;
+            if (li > lj || lj >= 34 || li >= 33) continue;
+            bool ia, ib;
+            uint32_t ca, ka, cb, kb;
+            local_to_unknown(li, c0, ia, ca, ka);
+            if (lj == 33) {  // gradient J^T r
+                if (ia) atomicAdd(&head[1 + ka], v);
+                else atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) ca + ka], v);
+                continue;
+            }
+            local_to_unknown(lj, c0, ib, cb, kb);
+            if (ia && ib) {
+                atomicAdd(&head[10 + 9 * ka + kb], v);
+            } else if (ia) {
+                atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) cb + 6 + 9 * kb + ka], v);
+            } else {
+                if (ca > cb || (ca == cb && ka > kb)) {
+                    const uint32_t tc = ca, tk = ka;
+                    ca = cb;
+                    ka = kb;
+                    cb = tc;
+                    kb = tk;
+                }
+                atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) ca + 60 + 36 * (cb - ca) + 6 * ka + kb], v);
             }
         }
     }
+    if (prog) ne_publish_progress(prog, epoch, accum, c0, tid_all, NW_T);
 }
 
 // The Ceres CostFunction::Evaluate seam (EventCalibSpline.hpp:137-146,231-240 behind AutoDiffCostFunction<..., 1, 9, 4, 4, 4, 4,
@@ -489,6 +684,7 @@ struct ecal_solver {
     std::shared_ptr<void> host_pool;   // ecal_solver_solve's worker threads (HostPool), parked between solves
     int host_pool_workers = -1;
     uint32_t stream_epoch = 0;
+    bool ws_attr_set = false;      // normal_eq_ws_kernel's dynamic LDS size registered
     size_t n_params() const { return 9 + 7 * (size_t) n_cp; }
     size_t n_accum() const { return ACC_HEAD + ACC_PER_CP * (size_t) n_cp; }
 };
@@ -886,6 +1082,22 @@ static int solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_
     } while (0)
         if (s->use_so3) {
             if (with_jacobian) ECAL_NE_LAUNCH2(true, true); else ECAL_NE_LAUNCH2(true, false);
+        } else if (with_jacobian && ctx->sw.solver_two_roles) {
+            // ECAL_SOLVER_TWO_ROLES=1: producer / consumer waves (normal_eq_ws_kernel) — built for the round-3 review, measured equal
+            // (2.26 ms both forms on the benchmark problem), kept behind the switch with its parity test
+            if (!s->ws_attr_set) {
+                ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_ws_kernel<false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) NW_LDS_BYTES));
+                ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_ws_kernel<true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) NW_LDS_BYTES));
+                s->ws_attr_set = true;
+            }
+            if (s->fisheye)
+                hipLaunchKernelGGL((normal_eq_ws_kernel<true>), dim3(s->n_chunks), dim3(NW_T), NW_LDS_BYTES, st, s->d_rec, s->d_chunks, s->d_knots,
+                                   s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads, d_prog, epoch);
+            else
+                hipLaunchKernelGGL((normal_eq_ws_kernel<false>), dim3(s->n_chunks), dim3(NW_T), NW_LDS_BYTES, st, s->d_rec, s->d_chunks, s->d_knots,
+                                   s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads, d_prog, epoch);
         } else {
             if (with_jacobian) ECAL_NE_LAUNCH2(false, true); else ECAL_NE_LAUNCH2(false, false);
         }
