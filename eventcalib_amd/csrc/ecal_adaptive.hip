@@ -487,13 +487,16 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
                                      uint32_t *passes, uint64_t *windows) {
     const ecal_range range__(ctx, "ecal_detect_keyframes");
     if (!ctx) return ECAL_ERR_INVALID;
-    // the search's windows are three to ten steps long: second-tier work by design, so its passes launch every tier
-    // (ecal_set_tail_mode; a context left in ECAL_TAIL_AUTO would spend the first pass finding that out)
+    // the search's windows are three to ten steps long: second-tier work by design — its passes never take the lean form of a
+    // stage (one slow general launch behind the first pass), but they do drop the tiers behind the second pass while those
+    // find nothing (ecal_tail_plan: eight launches of ~5 us + their gaps in a chain of ~27, every pass)
     const int was = ctx->tail_mode;
-    if (was == ECAL_TAIL_AUTO) ctx->tail_mode = ECAL_TAIL_TIERED;
+    const bool was_no_lean = ctx->tail_no_lean;
+    ctx->tail_no_lean = true;   // (AUTO stays AUTO: the tiers behind the second may still be dropped, ecal_tail_plan)
     const int rc = detect_keyframes_impl(ctx, d_events, n_events, ap, prm, cap_points, max_keyframes, kf_time, kf_duration, kf_events_num,
                                          kf_features, n_keyframes, passes, windows);
     ctx->tail_mode = was;
+    ctx->tail_no_lean = was_no_lean;
     return rc;
 }
 static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,

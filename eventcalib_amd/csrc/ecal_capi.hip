@@ -207,6 +207,13 @@ extern "C" int ecal_set_profile_ranges(ecal_ctx *ctx, int on) {
     return ECAL_OK;
 }
 
+// tests / tools: what the stages' last kernels reported (ecal_ctx::tail_seen, 16 words; 0xFFFFFFFF = nothing yet)
+extern "C" int ecal_debug_tail_seen(ecal_ctx *ctx, uint32_t *out16) {
+    if (!ctx || !out16 || !ctx->tail_seen) return ECAL_ERR_INVALID;
+    for (int k = 0; k < ECAL_TAIL_SLOTS; k++) out16[k] = __atomic_load_n(ctx->tail_seen + k, __ATOMIC_RELAXED);
+    return ECAL_OK;
+}
+
 extern "C" int ecal_set_tail_mode(ecal_ctx *ctx, int mode) {
     if (!ctx || mode < ECAL_TAIL_AUTO || mode > ECAL_TAIL_LEAN) return ECAL_ERR_INVALID;
     ctx->tail_mode = mode;

@@ -97,6 +97,9 @@ struct ecal_ctx {
     // every listed window / segment is processed: the choice moves time, never results.
     uint32_t *tail_seen = nullptr, *tail_seen_dev = nullptr;   // [ECAL_TAIL_SLOTS]; 0xFFFFFFFF = not known yet
     int tail_mode = 0;                                         // ECAL_TAIL_AUTO / _TIERED / _LEAN (ecal_set_tail_mode)
+    // a caller inside the library whose windows are second-tier ones by design (the keyframe search's adaptive windows): AUTO never
+    // goes lean for it (the lean tail is the slow general kernel), but may still drop the tiers BEHIND the second (ecal_tail_plan)
+    bool tail_no_lean = false;
     // roctx ranges around the stage entry points (ECAL_ROCTX=1 at ecal_init, or ecal_set_profile_ranges): the marker library
     // (librocprofiler-sdk-roctx.so) is looked up at run time — no link-time dependency —, `rocprofv3 --marker-trace
     // --kernel-trace` then shows which stage call every kernel belongs to (tracing)
@@ -151,6 +154,20 @@ inline bool ecal_tail_lean(const ecal_ctx *ctx, int first, int n) {
     for (int k = 0; k < n; k++)
         if (__atomic_load_n(ctx->tail_seen + first + k, __ATOMIC_RELAXED) != 0u) return false;
     return true;
+}
+// The plan of a stage whose to-do lists sit in slots first (what the first pass listed) and first + 1 (what the second pass left
+// of that): LEAN — one general launch behind the first pass; SEMI — first and second pass, then one general launch for whatever
+// the second pass leaves (normally nothing: the tiers behind it are three to five launches that find their list empty); TIERED —
+// every tier.  AUTO decides by what the stage's previous call on this context saw; whatever the plan, every listed window is
+// processed and the results are bit-identical (tests/test_gpu_tail_modes.py).
+enum { ECAL_PLAN_TIERED = 0, ECAL_PLAN_SEMI = 1, ECAL_PLAN_LEAN = 2 };
+inline int ecal_tail_plan(const ecal_ctx *ctx, int first) {
+    if (ctx->tail_mode == ECAL_TAIL_LEAN) return ECAL_PLAN_LEAN;
+    if (ctx->tail_mode == ECAL_TAIL_TIERED || !ctx->tail_seen) return ECAL_PLAN_TIERED;
+    const uint32_t a = __atomic_load_n(ctx->tail_seen + first, __ATOMIC_RELAXED), b = __atomic_load_n(ctx->tail_seen + first + 1, __ATOMIC_RELAXED);
+    if (a == 0u && b == 0u && !ctx->tail_no_lean) return ECAL_PLAN_LEAN;
+    if (a != 0xFFFFFFFFu && b == 0u) return ECAL_PLAN_SEMI;
+    return ECAL_PLAN_TIERED;
 }
 // a roctx range for the lifetime of the object (nothing when the context has no marker library loaded)
 struct ecal_range {

@@ -202,13 +202,14 @@ __global__ __launch_bounds__(BIG_T) void dbscan_tail_kernel(double *__restrict__
                                                             uint32_t *gslot, uint32_t *ganc, uint32_t *gcur, uint32_t *ginv, double2 *gcs,
                                                             uint8_t *gflags, const uint32_t *__restrict__ todo,
                                                             const uint32_t *__restrict__ todo_count, const uint32_t *__restrict__ xy16,
-                                                            uint32_t *__restrict__ fmt, uint32_t *seen) {
+                                                            uint32_t *__restrict__ fmt, uint32_t *seen,
+                                                            const uint32_t *__restrict__ first_count /* semi: the first pass's list, todo = the second's */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using L = TierLayout<4096>;
     const uint32_t n_work = *todo_count;
     if (seen && blockIdx.x == 0 && threadIdx.x == 0) {
-        seen[0] = n_work;
-        seen[1] = 0u;
+        seen[0] = first_count ? *first_count : n_work;
+        seen[1] = first_count ? n_work : 0u;
     }
     for (uint32_t kk = blockIdx.x; kk < n_work; kk += gridDim.x) {
         __syncthreads();
@@ -322,7 +323,11 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
     uint32_t grid = S;
     // lean: what the pixel kernel lists (nothing, when this stage last ran) goes to ONE tail launch (dbscan_tail_kernel) instead
     // of the second pixel pass, the unpacking and the four general tiers (ecal_ctx::tail_seen); only without a size hint
-    const bool lean = pixel && !ctx->fused_pass && max_seg_points == 0 && ecal_tail_lean(ctx, ECAL_TAIL_DBSCAN, 2);
+    const int plan = pixel && !ctx->fused_pass && max_seg_points == 0 ? ecal_tail_plan(ctx, ECAL_TAIL_DBSCAN) : ECAL_PLAN_TIERED;
+    const bool lean = plan == ECAL_PLAN_LEAN;
+    // semi: both pixel passes as always, then ONE tail launch for what the second leaves (nothing, when this stage last ran) instead
+    // of the unpacking + the three LDS tiers + the global-scratch tier
+    const bool semi = plan == ECAL_PLAN_SEMI && second_pass_wanted;
     const uint32_t *cnt_a = nullptr, *cnt_b = nullptr;
     if (pixel) {
         // two to-do lists: what the first pass (<= 1024 points) leaves, and what the second (<= 2048 points) leaves of that
@@ -386,7 +391,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         grid = S < 1024u ? S : 1024u;
     }
     uint32_t *const seen = pixel && !ctx->fused_pass && ctx->tail_seen_dev ? ctx->tail_seen_dev + ECAL_TAIL_DBSCAN : nullptr;
-    if (lean) {
+    if (lean || semi) {
         const size_t np = n_points;
         if ((rc = ecal_ensure(ctx, ctx->big_slot, (2 * np + 4 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
         if ((rc = ecal_ensure(ctx, ctx->big_inv, np * sizeof(uint32_t)))) return rc;
@@ -397,7 +402,8 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         hipLaunchKernelGGL(dbscan_tail_kernel, dim3(S < 256u ? S : 256u), dim3(BIG_T), TierLayout<CAP2>::bytes, st, d_xy, d_seg_off, d_seg_cnt, eps,
                            minpts, d_labels, d_n_clusters, (uint32_t *) ctx->big_slot.ptr, (uint32_t *) ctx->big_anc.ptr,
                            (uint32_t *) ctx->big_cur.ptr, (uint32_t *) ctx->big_inv.ptr, (double2 *) ctx->big_cs.ptr,
-                           (uint8_t *) ctx->big_flags.ptr, todo, todo_count, pk ? pk->d_xy16 : nullptr, pk ? pk->d_seg_fmt : nullptr, seen);
+                           (uint8_t *) ctx->big_flags.ptr, todo, todo_count, pk ? pk->d_xy16 : nullptr, pk ? pk->d_seg_fmt : nullptr, seen,
+                           semi ? cnt_a : (const uint32_t *) nullptr);
         ECAL_HIP_TRY(ctx, hipGetLastError());
         return ECAL_OK;
     }

@@ -1062,7 +1062,11 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     uint32_t grid = S;
     // lean: the listed windows (none, when this stage last ran) all go to the global-scratch tier, one launch behind the first
     // pass instead of four (ecal_ctx::tail_seen); only without size hints — a caller who names its sizes gets what it asks for
-    const bool lean = hash_slicer && !fused && max_win_events == 0 && ecal_tail_lean(ctx, ECAL_TAIL_SLICE, 2);
+    const int plan = hash_slicer && !fused && max_win_events == 0 ? ecal_tail_plan(ctx, ECAL_TAIL_SLICE) : ECAL_PLAN_TIERED;
+    const bool lean = plan == ECAL_PLAN_LEAN;
+    // semi: first and second pass as always, then the global-scratch tier alone for whatever the second pass leaves (nothing, when
+    // this stage last ran) instead of the two LDS tiers + it
+    const bool semi = plan == ECAL_PLAN_SEMI && reforder && !ctx->sw.slice_no_second_pass;
     const uint32_t *cnt_a = nullptr, *cnt_b = nullptr;
     if (!ctx->sw.slice_no_pixel) {
         int rc;
@@ -1118,11 +1122,11 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         if ((rc = ecal_ensure(ctx, ctx->sl_order, (size_t) grid * order_scratch_bytes(cap)))) return rc;
         ord_lds = (unsigned char *) ctx->sl_order.ptr;
     }
-    if (!lean)
+    if (!lean && !semi)
     hipLaunchKernelGGL((slice_lds_kernel<SCAP0, 2048, 256>), dim3(grid), dim3(256), SliceLayout<SCAP0>::bytes, st, d_events,
                        d_win_lo, d_win_hi, d_win_base, 0u, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point,
                        d_overflow, S, todo, todo_count, ord_lds);
-    if (!lean && mx > (uint32_t) SCAP0)
+    if (!lean && !semi && mx > (uint32_t) SCAP0)
         hipLaunchKernelGGL((slice_lds_kernel<SCAP1, 4096, 512>), dim3(grid), dim3(512), SliceLayout<SCAP1>::bytes, st,
                            d_events, d_win_lo, d_win_hi, d_win_base, (uint32_t) SCAP0, cap_points, d_xy, d_seg_off,
                            d_seg_cnt, d_event_point, d_overflow, S, todo, todo_count, ord_lds);
@@ -1140,7 +1144,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
             ord_big = (unsigned char *) ctx->sl_order_big.ptr;
         }
         hipLaunchKernelGGL(slice_big_kernel, dim3(S < 256u ? S : 256u), dim3(SLICE_BIG_T), 0, st, d_events, d_win_lo, d_win_hi, d_win_base,
-                           lean ? 0u : (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
+                           lean || semi ? 0u : (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
                            (double2 *) ctx->sl_pts.ptr, (uint8_t *) ctx->sl_pol.ptr, (uint32_t *) ctx->sl_bend.ptr,
                            (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr, ord_big, S, todo,
                            todo_count, hash_slicer && !fused ? ctx->tail_seen_dev + ECAL_TAIL_SLICE : nullptr, cnt_a, cnt_b);

@@ -135,3 +135,46 @@ def test_auto_goes_lean_after_an_empty_pass_and_back(env):
         for k in outs[i]:
             a, b = outs[i][k], outs[j][k]
             assert torch.equal(a.view(torch.int64) if a.dtype.is_floating_point else a, b.view(torch.int64) if b.dtype.is_floating_point else b), (i, j, k)
+
+
+def test_auto_drops_the_tiers_behind_the_second_pass_and_takes_them_back(env):
+    """The in-between plan (ecal_tail_plan: SEMI): after a pass whose FIRST-pass lists held work and whose second-pass lists were
+    empty (windows of 2 - 4 k events: the keyframe search's kind), slicing and DBSCAN run first pass + second pass + ONE general
+    launch.  The pass after that is scheduled from stale news: windows of 12 k events and windows with half-pixel coordinates then
+    go through that one launch — every array must equal the all-tiers form's, bit for bit."""
+    ctx, DetectPipeline, torch = env
+    n = 600_000
+    ev = SS.make_stream(n, rate=2.0e6, device="cuda", seed=12)
+    evh = ev.clone()
+    rec = evh.view(-1, 25)
+    xs = rec[:, 8:16].contiguous().view(torch.float64).view(-1)
+    sel = (torch.arange(n, device="cuda") // 3000) % 5 == 2
+    xs[sel] = xs[sel] + 0.5
+    rec[:, 8:16] = xs.view(-1, 1).view(torch.uint8)
+    c0, c1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 2.0e6, 1.5e-3)        # ~3000-event windows: second-pass work, nothing behind it
+    b0 = 5.0 + 0.02 * np.arange(10)
+    b1 = b0 + 6e-3                                                       # 12 k-event windows: work behind the second pass
+    seq = ((ev, c0, c1), (ev, c0, c1), (ev, b0, b1), (ev, c0, c1), (ev, c0, c1), (evh, c0, c1), (evh, c0, c1), (ev, c0, c1), (evh, b0, b1))
+
+    def run_all(mode):
+        ctx.set_tail_mode(mode)
+        outs = []
+        for (e, t0, t1) in seq:
+            pipe = DetectPipeline(ctx)
+            pipe.set_windows(t0, t1)
+            pipe.set_detect_params(5, 36, 15.511363636363637)
+            pipe.run(e, slots=n)
+            torch.cuda.synchronize()
+            assert not pipe.overflowed()
+            outs.append(TF._snapshot(pipe, len(t0), torch))
+        return outs
+    try:
+        tiered = run_all("tiered")
+        auto = run_all("auto")
+    finally:
+        ctx.set_tail_mode("auto")
+    assert int(tiered[0]["seg_cnt"].max()) > 768 and int(tiered[2]["seg_cnt"].max()) > 2048
+    for i, (a, b) in enumerate(zip(tiered, auto)):
+        for k in a:
+            x, y = a[k], b[k]
+            assert torch.equal(x.view(torch.int64) if x.dtype.is_floating_point else x, y.view(torch.int64) if y.dtype.is_floating_point else y), (i, k)
