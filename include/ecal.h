@@ -261,8 +261,10 @@ int ecal_get_median_ties(const ecal_ctx *ctx);
  * kernel that takes what the shipped configuration produces and lists the rest for tiers of growing capacity; on most data
  * those lists stay empty, and a launch that finds its list empty still costs ~5 us (twenty of them: 0.1 ms of every pass).
  * ECAL_TAIL_AUTO (default): a stage whose previous call on this context saw empty lists launches ONE kernel that takes
- * whatever is listed through its most general tier; a stage that saw work launches every tier.  ECAL_TAIL_TIERED / ECAL_TAIL_LEAN
- * force one form (tests; the adaptive search forces TIERED for its passes: its windows are second-tier work by design).
+ * whatever is listed through its most general tier; slicing and DBSCAN, when the first pass listed work but the second pass
+ * left none, run first pass + second pass + that one kernel; a stage that saw work behind the second pass launches every tier.
+ * ECAL_TAIL_TIERED / ECAL_TAIL_LEAN force one form (tests).  The adaptive search (ecal_detect_keyframes), whose windows are
+ * second-tier work by design, keeps AUTO but never takes the one-kernel form.
  * The choice moves time only: every listed window is processed either way, results are bit-identical
  * (tests/test_gpu_tail_modes.py). */
 /* roctx ranges around the stage entry points (window bounds, slicing, DBSCAN, extraction, member order, grid ordering, keyframe
