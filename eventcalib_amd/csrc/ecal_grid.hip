@@ -425,7 +425,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         }
     }
     if (!have) {
-        if (debug && lane == 0) out[8 + start] = -1000;
+        if ((debug & 1) && lane == 0) out[8 + start] = -1000;
         if (start == 0) continue;
         break;
     }
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                        a2 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 32), a3 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 48);
         const uint32_t j0 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 0), j1 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 16),
                        j2 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 32), j3 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 48);
-        const bool clash = (a0 && a1 && j0 == j1) || (a0 && a2 && j0 == j2) || (a0 && a3 && j0 == j3) || (a1 && a2 && j1 == j2) ||
+        const bool clash = (debug & 2) /* ECAL_GRID_SERIAL_WALK: always the one-after-the-other form */ || (a0 && a1 && j0 == j1) || (a0 && a2 && j0 == j2) || (a0 && a3 && j0 == j3) || (a1 && a2 && j1 == j2) ||
                            (a1 && a3 && j1 == j3) || (a2 && a3 && j2 == j3);
         uint32_t n_new = 0;
         if (!clash) {
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             GR_MARK(6);   // matches after sweeps
         }
     }
-    if (debug && !got && lane == 0) out[8 + start] = -2000 - (int32_t) qt;   // (ECAL_GRID_DEBUG: nodes placed by a start that failed)
+    if ((debug & 1) && !got && lane == 0) out[8 + start] = -2000 - (int32_t) qt;   // (ECAL_GRID_DEBUG: nodes placed by a start that failed)
     }   // (starts)
 #ifdef ECAL_PHASE_PROF
     gr_done__(qt);
@@ -843,7 +843,7 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const double tol_px = ctx->sw.grid_tol_px;   // (ECAL_GRID_TOL_PX, a debug switch for tests of the tolerance's effect; default = the reference's 20 px)
     hipLaunchKernelGGL(grid_order_kernel, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
-                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, ctx->sw.grid_debug ? 1 : 0);
+                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, (ctx->sw.grid_debug ? 1 : 0) | (ctx->sw.grid_serial_walk ? 2 : 0));
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

@@ -1,6 +1,8 @@
 """GPU: ordering of circle candidates into the 9x4 asymmetric grid vs synthetic ground truth
 (parity with OpenCV's randomised finder is unpinned; what is checked is the reference's output convention:
 grid index i*cols + j <-> model point ((2j + i%2) s, i s))."""
+import os
+
 import numpy as np
 import pytest
 
@@ -347,4 +349,51 @@ def test_grid_on_the_noise_streams_false_candidates():
     print("\n[grid] noise stream: %d windows hold the whole pattern + spurious candidates, %d of them lost" % (with_clutter, lost))
     assert with_clutter >= 8, with_clutter
     assert lost <= with_clutter // 4, "grids lost under clutter: %d of %d windows" % (lost, with_clutter)
+    ctx.close()
+
+
+def test_walk_four_directions_at_once_equals_one_after_the_other():
+    """The first walk asks a node's four neighbour cells at once (a row of lanes each) and falls back to the one-after-the-other
+    form when two directions want the same candidate; ECAL_GRID_SERIAL_WALK=1 takes that form always.  Same orders, same
+    verdicts: on cluttered patterns (where two directions do compete for a spurious candidate) and on the noise stream's own
+    candidate sets."""
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.capi import sync_env
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    rng = np.random.default_rng(77)
+    views = list(_project_centres(torch, np.linspace(5.0, 9.0, 40))) + _tilted_views(torch, [20, 35, 45, 55, 60] * 8, seed=4)
+    cases = []
+    for gt in views:
+        p = gt + rng.normal(0, 0.7, size=(36, 2))
+        k = int(rng.integers(0, 27))
+        step = np.sort(np.linalg.norm(p[:, None] - p[None], axis=2) + 1e9 * np.eye(36), axis=1)[:, 0].min()
+        clutter = _inside_hull_points(rng, p, k, p, 0.25 * step, on_edge=k // 3) if k else np.zeros((0, 2))
+        allp = np.concatenate([p, clutter])
+        cases.append(allp[rng.permutation(len(allp))])
+    pipe = DetectPipeline(ctx)
+    buf = SS.make_stream(1_500_000, rate=4.0e6, device="cuda", seed=8, noise_frac=0.5)
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (1_500_000 - 1) / 4.0e6)
+    pipe.set_windows(t0, t1)
+    pipe.run(buf)
+    out = {}
+    try:
+        for serial in (False, True):
+            if serial:
+                os.environ["ECAL_GRID_SERIAL_WALK"] = "1"
+            else:
+                os.environ.pop("ECAL_GRID_SERIAL_WALK", None)
+            sync_env()
+            o1, f1 = _run_grid(ctx, torch, cases)
+            o2, f2 = pipe.order_grid(9, 4)
+            torch.cuda.synchronize()
+            out[serial] = (np.array(o1), np.array(f1), o2.cpu().numpy().copy(), f2.cpu().numpy().copy())
+    finally:
+        os.environ.pop("ECAL_GRID_SERIAL_WALK", None)
+        sync_env()
+    a, b = out[False], out[True]
+    assert int(a[1].sum()) > 30 and int(a[3].sum()) > 50
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
     ctx.close()
