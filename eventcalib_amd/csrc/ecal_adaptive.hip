@@ -187,7 +187,7 @@ constexpr int AD_ALLOC_T = 1024;
 // transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
 // and takes the active-pieces counter back to zero for the next pass.
 __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t deal, uint32_t d_max, AdaptiveArrays st,
-                                                                    double mts, double *t0, double *t1, uint32_t *report, uint32_t seq) {
+                                                                    double mts, double *t0, double *t1, uint32_t *report, uint32_t seq, uint32_t live_base, uint32_t live_floor) {
     __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
@@ -208,6 +208,12 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     }
     // `deal` of the B slots are dealt out (a run of few pieces — a verification round of the shared-map gate — does not get
     // the whole pass: beyond what fills the GPU a pass's time grows with its windows, and most of a long look-ahead is thrown away)
+    // live_base (the live form of the shared-map search, where first runs and re-runs share the passes): as many slots per piece
+    // as the search starts with while the pieces fill the pass, never fewer than 1536 slots in all — what a set of re-runs got
+    if (live_base) {
+        const uint32_t want = n_act * live_base > live_floor ? n_act * live_base : live_floor;
+        deal = want < B ? want : B;
+    }
     uint32_t D = n_act ? (deal < n_act ? 1u : deal / n_act) : 0u;   // (B >= P: at least one)
     if (D > d_max) D = d_max;
     uint32_t at = pre + inc - mine;        // active pieces before this thread's
@@ -311,6 +317,55 @@ __global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, A
     st.rerun[k] = 0;
     st.gen[k]++;   // the keyframe records of the earlier runs of this piece are dead
     piece_start(k, P, rows, mts, st);
+    if (st.active[k]) atomicAdd(&st.counters[0], 1u);   // (the live form: the pass reports pieces with windows still to go)
+}
+
+// The verification of adaptive_verify_kernel after EVERY pass instead of after every set of runs (shared-map mode, the default
+// form): piece k is looked at as soon as the pieces between it and its nearest earlier keyframe have finished their runs, whether
+// k itself is finished or not — a set of runs lasts as long as its longest piece (16 passes where the average run takes 9), and
+// most re-runs can start long before that.  Same rule, same fixed point (the sequential run: the earliest unsettled piece is
+// settled by the time its predecessors are); what a piece is judged against is the state of FINISHED predecessors only, and a
+// predecessor that starts again later hands its successor a new frame when it is finished again.
+//   k finished, or running with its first acceptance behind it: as adaptive_verify_kernel (same verdicts -> the frame is noted,
+//   nothing else; different -> run again).
+//   k running, nothing accepted yet: the rejected successes so far must stay rejected (else: run again); then the run so far is
+//   the run it would have been with the new frame, and the frame becomes its reference for the successes to come.
+__global__ void adaptive_verify_live_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    uint32_t j = k + 1;
+    while (j < P) {
+        if (st.active[j]) return;   // not finished: its keyframes (or their absence) are not known yet
+        if (st.nacc[j] > 0) break;
+        j++;
+    }
+    const bool has = j < P;
+    const double r_t = has ? st.ref_t[j] : 0.0;
+    const double *r_dir = st.ref_dir + (size_t) (has ? j : 0) * rows * 2;
+    double *i_dir = st.init_dir + (size_t) k * rows * 2;
+    bool same = (st.init_has[k] != 0) == has;
+    if (same && has) {
+        same = st.init_t[k] == r_t;
+        for (uint32_t i = 0; i < 2 * rows && same; i++) same = i_dir[i] == r_dir[i];
+    }
+    if (same) return;
+    bool again = st.nrej[k] > AD_NREJ;   // more rejected successes than were kept: not decidable here
+    const uint32_t nr = st.nrej[k] < AD_NREJ ? st.nrej[k] : AD_NREJ;
+    for (uint32_t i = 0; i < nr && !again; i++)
+        again = !has || gate_accepts(r_dir, r_t, st.rej_dir + ((size_t) k * AD_NREJ + i) * rows * 2, st.rej_t[(size_t) k * AD_NREJ + i], rows, mts);
+    if (!again && st.nacc[k] > 0)
+        again = has && !gate_accepts(r_dir, r_t, st.facc_dir + (size_t) k * rows * 2, st.facc_t[k], rows, mts);
+    st.init_has[k] = has ? 1u : 0u;
+    st.init_t[k] = r_t;
+    for (uint32_t i = 0; i < 2 * rows; i++) i_dir[i] = has ? r_dir[i] : 0.0;
+    if (again) {
+        st.rerun[k] = 1;
+    } else if (st.active[k] && st.nacc[k] == 0) {   // still before its first acceptance: the new frame is what its successes meet from now on
+        st.have_ref[k] = has ? 1u : 0u;
+        st.ref_t[k] = r_t;
+        double *rd = st.ref_dir + (size_t) k * rows * 2;
+        for (uint32_t i = 0; i < 2 * rows; i++) rd[i] = has ? r_dir[i] : 0.0;
+    }
 }
 
 // The rows' line fits of every window of the pass that produced a grid (a 3 x 3 Jacobi eigen-decomposition per row: the bulk of
@@ -624,13 +679,17 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     };
     // the lock-step passes of one set of runs: until no piece has a window left
     uint32_t deal = S;   // window slots dealt out per pass (all of them in the first set of runs)
+    // shared-map gate: verification after every pass (default) or after every set of runs (ECAL_ADAPTIVE_ROUNDS=1: the form of
+    // rounds 2 - 3, kept for comparison; same keyframes)
+    const bool live = shared && !ctx->sw.adaptive_rounds;
+    const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1536u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
     auto run_passes = [&]() -> int {
         // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
         // kernels over the slots it deals out, not over all S: thousands of workgroups that find an empty window still cost
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u);
+                           (uint32_t *) nullptr, 0u, live ? D : 0u, live_floor);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
@@ -680,8 +739,12 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                                max_keys, d_kt, d_kd, d_ke, d_kf, d_kp, d_kg, d_t0, d_t1, (const int *) B[16].ptr,
                                (const double *) ctx->adaptive_dirs.ptr);
+            if (live) {   // shared-map gate: verification and restarts pass by pass (adaptive_verify_live_kernel)
+                hipLaunchKernelGGL(adaptive_verify_live_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
+                hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
+            }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq);
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, live ? D : 0u, live_floor);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));
@@ -695,7 +758,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     if ((rc = run_passes())) return rc;
     uint32_t rounds = 0;
     const bool trace = ctx->sw.adaptive_trace;
-    if (shared) {
+    if (shared && !live) {
         // verify every piece against the frame its predecessors now hand it; run the ones again whose verdicts change
         for (;; rounds++) {
             AD_TRY(hip_rc(hipMemsetAsync(a.counters + 8, 0, sizeof(uint32_t), st), "hipMemsetAsync"));

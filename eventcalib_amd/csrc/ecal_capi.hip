@@ -22,6 +22,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.no_fused_pass = on("ECAL_NO_FUSED_PASS");
     sw.no_zero_ring = on("ECAL_NO_ZERO_RING");
     sw.adaptive_trace = on("ECAL_ADAPTIVE_TRACE");
+    sw.adaptive_rounds = on("ECAL_ADAPTIVE_ROUNDS");
     sw.grid_debug = on("ECAL_GRID_DEBUG");
     sw.grid_serial_walk = on("ECAL_GRID_SERIAL_WALK");
     sw.solver_device_linear_solve = on("ECAL_SOLVER_DEVICE_LINEAR_SOLVE");
@@ -30,6 +31,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.solver_two_roles = on("ECAL_SOLVER_TWO_ROLES");
     sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
     sw.adaptive_depth_max = (int) num("ECAL_ADAPTIVE_DEPTH_MAX");
+    sw.adaptive_live_floor = (int) num("ECAL_ADAPTIVE_LIVE_FLOOR");
     sw.arrow_k = (int) num("ECAL_ARROW_K");
     sw.bo_big_arena = (unsigned long long) num("ECAL_BO_BIG_ARENA");
     if (const char *e = getenv("ECAL_GRID_TOL_PX")) sw.grid_tol_px = atof(e);

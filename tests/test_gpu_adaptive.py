@@ -146,12 +146,27 @@ def _same_keyframes(dev, ref):
         assert np.array_equal(dev[k], ref[k]), k
 
 
+def _in_rounds(ctx, ev, pieces, t_first, t_last):
+    """The shared-map search with the verification after every SET of runs (ECAL_ADAPTIVE_ROUNDS=1: the form before round 4's
+    pass-by-pass verification, kept behind the switch) — must give the same keyframes."""
+    import os
+    import eventcalib_amd.capi as capi
+    from eventcalib_amd.adaptive import detect_keyframes_device
+    os.environ["ECAL_ADAPTIVE_ROUNDS"] = "1"
+    capi.sync_env()
+    try:
+        return detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
+    finally:
+        del os.environ["ECAL_ADAPTIVE_ROUNDS"]
+        capi.sync_env()
+
+
 @pytest.mark.parametrize("pieces", [1, 6, 40])
 def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     """gate_mode = ECAL_GATE_SHARED_MAP against oracle/policy_oracle.cpp mode 1: ONE keyframe map for all pieces, pieces in the
     reference's pop_back order, only the very first frame ungated (TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36) — what the
-    reference computes with a single worker thread.  The product gets there by speculation + verification rounds
-    (ecal_adaptive.hip); keyframes, windows and counts must be the sequential run's."""
+    reference computes with a single worker thread.  The product gets there by speculation + verification, pass by pass
+    (ecal_adaptive.hip: adaptive_verify_live_kernel) or in rounds; keyframes, windows and counts must be the sequential run's."""
     import oracle_lib as O
     import eventcalib_amd.capi as capi
     from eventcalib_amd.adaptive import detect_keyframes_device
@@ -165,6 +180,7 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     dev = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
     assert len(ref["time"]) >= 20
     _same_keyframes(dev, ref)
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last), ref)
     if pieces == 1:
         _same_keyframes(dev, own)              # one piece: the two modes are the same run
     _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last), own)
@@ -193,6 +209,7 @@ def test_shared_map_gate_at_the_reference_s_piece_count():
         print("keyframes: shared map %d, own piece %d" % (len(ref["time"]), len(own["time"])))
         assert len(ref["time"]) >= 1000 and not np.array_equal(ref["time"], own["time"])   # the modes differ: the test bites
         _same_keyframes(dev, ref)
+        _same_keyframes(_in_rounds(ctx, ev, 1270, t_first, t_last), ref)
         _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, 1270, t_first, t_last), own)
     finally:
         ctx.close()
