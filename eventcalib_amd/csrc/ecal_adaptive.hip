@@ -95,6 +95,7 @@ struct AdaptiveArrays {
     double *first, *second, *bound_hi, *ref_t, *ref_dir;  // [P], [P], [P], [P], [P][rows][2]
     uint32_t *active, *have_ref, *levels;                 // [P]; levels: windows the piece has gone through
     uint32_t *slot0, *depth;                              // [P]: the piece's window slots of this pass (adaptive_alloc_kernel)
+    uint32_t *want;                                       // [P]: the chain length the piece asks for (live form: grows while its chains hold)
     uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: slots overflowed,
                          // 8: pieces to run again (shared-map verification)
     unsigned long long *windows;                          // windows evaluated
@@ -208,12 +209,66 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     }
     // `deal` of the B slots are dealt out (a run of few pieces — a verification round of the shared-map gate — does not get
     // the whole pass: beyond what fills the GPU a pass's time grows with its windows, and most of a long look-ahead is thrown away)
-    // live_base (the live form of the shared-map search, where first runs and re-runs share the passes): as many slots per piece
-    // as the search starts with while the pieces fill the pass, never fewer than 1536 slots in all — what a set of re-runs got
+    // live_base (the live form of the shared-map search, where first runs and re-runs share the passes): every piece gets the
+    // chain length it asks for (want: twice its last length while its chains hold, else the base), scaled down together when the
+    // pass cannot hold them all
     if (live_base) {
-        const uint32_t want = n_act * live_base > live_floor ? n_act * live_base : live_floor;
-        deal = want < B ? want : B;
-    }
+        __shared__ uint32_t red2[AD_ALLOC_T / 64 + 1];
+        const uint32_t share = n_act ? live_floor / n_act : 0u;   // few pieces at work: the pass has slots to spare for all of them
+        auto wanted = [&](uint32_t k) -> uint32_t {
+            uint32_t w = st.want[k] > live_base ? st.want[k] : live_base;
+            w = w > share ? w : share;
+            return w < d_max ? w : d_max;
+        };
+        uint32_t mw = 0;
+        for (uint32_t k = k0; k < k0 + per && k < P; k++) mw += st.active[k] ? wanted(k) : 0u;
+        uint32_t tw = mw;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) tw += __shfl_xor(tw, d, 64);
+        __syncthreads();
+        if (lane == 0) red2[wave] = tw;
+        __syncthreads();
+        uint32_t total_want = 0;
+        for (uint32_t w = 0; w < AD_ALLOC_T / 64; w++) total_want += red2[w];
+        auto depth_of = [&](uint32_t k) -> uint32_t {
+            const uint32_t w = wanted(k);
+            if (total_want <= B) return w;
+            // one slot each (B >= P), the rest in proportion to what is asked beyond that, rounded down: the sum stays within B
+            return 1u + (uint32_t) ((unsigned long long) (w - 1u) * (B - n_act) / (total_want - n_act));
+        };
+        uint32_t md = 0;
+        for (uint32_t k = k0; k < k0 + per && k < P; k++) md += st.active[k] ? depth_of(k) : 0u;
+        uint32_t incd = md;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incd, d, 64);
+            if ((int) lane >= d) incd += o;
+        }
+        __syncthreads();
+        if (lane == 63) red2[wave] = incd;
+        __syncthreads();
+        uint32_t pred = 0, total_depth = 0;
+        for (uint32_t w = 0; w < AD_ALLOC_T / 64; w++) {
+            if (w < wave) pred += red2[w];
+            total_depth += red2[w];
+        }
+        uint32_t at = pred + incd - md;   // slots before this thread's pieces
+        for (uint32_t k = k0; k < k0 + per && k < P; k++) {
+            if (st.active[k]) {
+                const uint32_t D = depth_of(k);
+                st.slot0[k] = at;
+                st.depth[k] = D;
+                write_chain(D, st.first[k], st.second[k], st.bound_hi[k], mts, t0 + at, t1 + at);
+                at += D;
+            } else {
+                st.depth[k] = 0;
+            }
+        }
+        for (uint32_t i = total_depth + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
+            t0[i] = INFINITY;
+            t1[i] = -INFINITY;
+        }
+    } else {
     uint32_t D = n_act ? (deal < n_act ? 1u : deal / n_act) : 0u;   // (B >= P: at least one)
     if (D > d_max) D = d_max;
     uint32_t at = pre + inc - mine;        // active pieces before this thread's
@@ -230,6 +285,7 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     for (uint32_t i = n_act * D + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
         t0[i] = INFINITY;
         t1[i] = -INFINITY;
+    }
     }
     if (report && tid == 0) {
         const uint32_t active = st.counters[0];
@@ -255,6 +311,7 @@ __device__ void piece_start(uint32_t k, uint32_t P, uint32_t rows, double mts, c
     st.levels[k] = 0;
     st.nacc[k] = 0;
     st.nrej[k] = 0;
+    st.want[k] = 0;   // (0: the base length)
     st.have_ref[k] = st.init_has[k];
     st.ref_t[k] = st.init_t[k];
     for (uint32_t i = 0; i < 2 * rows; i++) st.ref_dir[(size_t) k * rows * 2 + i] = st.init_dir[(size_t) k * rows * 2 + i];
@@ -413,7 +470,7 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
     }
     uint32_t w = st.slot0[k];   // slot of the window under evaluation
     const uint32_t D = st.depth[k];
-    bool act = true;
+    bool act = true, held = true;
     const uint32_t lev0 = st.levels[k];   // (max_levels: the caller's bound on the windows of a piece)
     const uint32_t n_levels = max_levels - lev0 < D ? max_levels - lev0 : D;
     if (n_levels == 0) return;
@@ -483,13 +540,19 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         }
         __syncthreads();
         act = sh_act != 0;
-        if (!act || sh_o != likely_outcome(f, s2, mts)) break;   // the chain evaluated ahead holds the likely successor only
+        if (!act || sh_o != likely_outcome(f, s2, mts)) {   // the chain evaluated ahead holds the likely successor only
+            held = false;
+            break;
+        }
         w++;
     }
     if (lane != 0) return;
     st.first[k] = sh_f;
     st.second[k] = sh_s2;
     st.active[k] = act ? 1u : 0u;
+    // a piece whose whole chain held asks for twice the length next time, one whose chain broke for the base length again (a
+    // stretch without the pattern is hundreds of windows whose verdicts are all the likely one: it is the search's longest path)
+    st.want[k] = held ? 2u * D : 0u;
     if (act && st.levels[k] < max_levels) atomicAdd(&st.counters[0], 1u);   // pieces with windows still to go
 }
 
@@ -591,7 +654,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
     // per piece: 7 doubles + (3 + AD_NREJ) x rows x 2 doubles of row directions + AD_NREJ doubles + 10 words
-    const size_t state_bytes = (size_t) P * (8 * (7 + AD_NREJ + 2 * (size_t) rows * (3 + AD_NREJ)) + 4 * 10) + 128;
+    const size_t state_bytes = (size_t) P * (8 * (7 + AD_NREJ + 2 * (size_t) rows * (3 + AD_NREJ)) + 4 * 11) + 128;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_dirs, (size_t) S * rows * 2 * sizeof(double)))) return rc;
     // keyframe records: in shared-map mode the pieces that run again leave dead records behind
@@ -635,6 +698,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         a.nrej = u, u += P;
         a.init_has = u, u += P;
         a.rerun = u, u += P;
+        a.want = u, u += P;
         a.start_time = ap->start_time;
         a.end_time = ap->end_time;
         a.p_total = ap->piece_num;
@@ -658,6 +722,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     uint32_t *d_ring = nullptr;
     ECAL_HIP_TRY(ctx, hipHostGetDevicePointer((void **) &d_ring, (void *) (h + 16), 0));
     for (int i = 0; i < 32; i++) ring[i] = 0;
+    std::vector<uint32_t> trace_active;   // ECAL_ADAPTIVE_TRACE: pieces still at work after every pass
     uint32_t seq = 0;   // passes enqueued in this call (over all its sets of runs): the number a pass reports
     // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
     // takes a piece through up to D of them
@@ -682,7 +747,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // shared-map gate: verification after every pass (default) or after every set of runs (ECAL_ADAPTIVE_ROUNDS=1: the form of
     // rounds 2 - 3, kept for comparison; same keyframes)
     const bool live = shared && !ctx->sw.adaptive_rounds;
-    const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1536u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
+    const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1024u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
     auto run_passes = [&]() -> int {
         // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
         // kernels over the slots it deals out, not over all S: thousands of workgroups that find an empty window still cost
@@ -707,6 +772,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                     }
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
+                if (ctx->sw.adaptive_trace) trace_active.push_back((uint32_t) ring[4 * q]);
                 if (ring[4 * q + 3]) {
                     (void) hipStreamSynchronize(st);
                     ctx->last_error = range_msg;
@@ -784,9 +850,13 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
 #ifdef ECAL_ADAPTIVE_STATS
     fprintf(stderr, "chain ends: keyframe %u, other verdict %u, chain used up %u, piece finished %u\n", h[4], h[5], h[6], h[7]);
 #endif
-    if (trace)
+    if (trace) {
         fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes, %u verification rounds\n", P, S,
                 d_max, n_passes, rounds);
+        fprintf(stderr, "  pieces at work after each pass:");
+        for (uint32_t v : trace_active) fprintf(stderr, " %u", v);
+        fprintf(stderr, "\n");
+    }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     // windows the rule was applied to / the longest chain of a piece: from the pieces' final runs
     std::vector<uint32_t> lev(P), gen(P);
