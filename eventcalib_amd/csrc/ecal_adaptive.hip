@@ -164,11 +164,34 @@ __device__ __forceinline__ int likely_outcome(double f, double s2, double mts) {
 
 // The chain of D windows that starts at the piece's current window (f, s2) and goes on as if every verdict were the likely
 // one, cut where it would end the piece (:50; the slots behind the cut stay empty: +inf, -inf, which every stage skips)
-__device__ __forceinline__ void write_chain(uint32_t D, double f, double s2, double hi, double mts, double *t0, double *t1) {
+// n_side > 0: behind the D windows, for each of the first n_side of them the chain of L windows that follows if THAT window is
+// accepted as a keyframe (for windows from .. from + n_side - 1: side chain i at t0 + D + (i - from) * L) — the one unlikely verdict that ends every chain sooner or later
+__device__ __forceinline__ void write_chain(uint32_t D, double f, double s2, double hi, double mts, double *t0, double *t1, uint32_t n_side = 0,
+                                            uint32_t L = 0, uint32_t from = 0) {
     bool act = true;
     for (uint32_t j = 0; j < D; j++) {
         t0[j] = act ? f : INFINITY;
         t1[j] = act ? s2 : -INFINITY;
+        if (j >= from && j < from + n_side) {
+            double af = 0, as = 0;
+            bool sact = act;
+            if (sact) {
+                next_window(0, f, s2, mts, af, as);
+                sact = as < hi;
+            }
+            double *s0 = t0 + D + (size_t) (j - from) * L, *s1 = t1 + D + (size_t) (j - from) * L;
+            for (uint32_t q = 0; q < L; q++) {
+                s0[q] = sact ? af : INFINITY;
+                s1[q] = sact ? as : -INFINITY;
+                if (sact) {
+                    double nf, ns;
+                    next_window(likely_outcome(af, as, mts), af, as, mts, nf, ns);
+                    af = nf;
+                    as = ns;
+                    sact = ns < hi;
+                }
+            }
+        }
         if (act) {
             double nf, ns;
             next_window(likely_outcome(f, s2, mts), f, s2, mts, nf, ns);
@@ -183,12 +206,20 @@ __device__ __forceinline__ void write_chain(uint32_t D, double f, double s2, dou
 // average 83), so most passes see few pieces still at work: the B slots of a pass are dealt out evenly among THOSE, up to
 // d_max windows of chain each — the fewer pieces remain, the further each one looks ahead.  One workgroup.
 constexpr int AD_ALLOC_T = 1024;
+// live form, few pieces at work: a main chain and side chains (write_chain): first main-chain window with one, how many, their
+// length, the main chain's length.  Measured (ECAL_ADAPTIVE_SIDE, tools/side_sweep.sh): 24 side chains of 12 behind a main chain
+// of 24 take the search from 108 to 79 passes at 1270 pieces, but the passes of the tail grow by what they save — 0.151 against
+// 0.159 s at 1270 pieces, 0.153 / 0.156 at 4096, 0.289 / 0.271 at 254; eight other layouts within 3 % of that — so the default
+// is none, and the form stays behind the switch with its test.
+constexpr uint32_t AD_SIDE_DEFAULT = 0u;
+constexpr uint32_t AD_SIDE_MEASURED = 0u | (24u << 8) | (12u << 16) | (24u << 24);
 // report (pinned host memory, may be NULL) + seq: the pass that ends with this launch tells the host how it went — pieces still
 // active, keyframe records so far, capacity overflow, and LAST the pass's number, which the host polls for (a copy engine
 // transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
 // and takes the active-pieces counter back to zero for the next pass.
 __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t deal, uint32_t d_max, AdaptiveArrays st,
-                                                                    double mts, double *t0, double *t1, uint32_t *report, uint32_t seq, uint32_t live_base, uint32_t live_floor) {
+                                                                    double mts, double *t0, double *t1, uint32_t *report, uint32_t seq, uint32_t live_base, uint32_t live_floor,
+                                                                    uint32_t side /* from | count << 8 | length << 16 | main chain << 24 */) {
     __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
@@ -213,12 +244,16 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     // chain length it asks for (want: twice its last length while its chains hold, else the base), scaled down together when the
     // pass cannot hold them all
     if (live_base) {
+        const uint32_t SF = side & 0xFFu, SC = (side >> 8) & 0xFFu, SL = (side >> 16) & 0xFFu, SM = side >> 24;
         __shared__ uint32_t red2[AD_ALLOC_T / 64 + 1];
         const uint32_t share = n_act ? live_floor / n_act : 0u;   // few pieces at work: the pass has slots to spare for all of them
+        // slots of a piece: a chain of up to d_max windows; with slots to spare beyond that (few pieces at work), a main chain
+        // of AD_SIDE_MAIN windows + side chains of AD_SIDE_LEN windows for as many of them as fit (write_chain)
         auto wanted = [&](uint32_t k) -> uint32_t {
             uint32_t w = st.want[k] > live_base ? st.want[k] : live_base;
             w = w > share ? w : share;
-            return w < d_max ? w : d_max;
+            const uint32_t cap = SC && share >= SM + 2u * SL ? SM + SC * SL : d_max;
+            return w < cap ? w : cap;
         };
         uint32_t mw = 0;
         for (uint32_t k = k0; k < k0 + per && k < P; k++) mw += st.active[k] ? wanted(k) : 0u;
@@ -255,11 +290,21 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
         uint32_t at = pred + incd - md;   // slots before this thread's pieces
         for (uint32_t k = k0; k < k0 + per && k < P; k++) {
             if (st.active[k]) {
-                const uint32_t D = depth_of(k);
+                const uint32_t slots = depth_of(k);
+                uint32_t D = slots, n_side = 0;
+                if (slots > d_max) {
+                    D = SM;
+                    n_side = (slots - D) / SL;
+                    n_side = n_side < SC ? n_side : SC;
+                }
                 st.slot0[k] = at;
-                st.depth[k] = D;
-                write_chain(D, st.first[k], st.second[k], st.bound_hi[k], mts, t0 + at, t1 + at);
-                at += D;
+                st.depth[k] = D | (n_side << 8) | (SF << 16) | (SL << 24);   // (D <= 48, n_side <= 24)
+                write_chain(D, st.first[k], st.second[k], st.bound_hi[k], mts, t0 + at, t1 + at, n_side, SL, SF);
+                for (uint32_t q = D + n_side * SL; q < slots; q++) {   // (the remainder of its slots)
+                    t0[at + q] = INFINITY;
+                    t1[at + q] = -INFINITY;
+                }
+                at += slots;
             } else {
                 st.depth[k] = 0;
             }
@@ -469,10 +514,14 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         sh_s2 = st.second[k];
     }
     uint32_t w = st.slot0[k];   // slot of the window under evaluation
-    const uint32_t D = st.depth[k];
+    const uint32_t D = st.depth[k] & 0xFFu, n_side = (st.depth[k] >> 8) & 0xFFu, side_from = (st.depth[k] >> 16) & 0xFFu,
+                   side_len = st.depth[k] >> 24;   // (adaptive_alloc_kernel's side chains, live form)
+    uint32_t pos = 0, chain_len = D;   // position in the chain being walked (the main one, then at most one side chain)
+    bool on_side = false;
     bool act = true, held = true;
     const uint32_t lev0 = st.levels[k];   // (max_levels: the caller's bound on the windows of a piece)
-    const uint32_t n_levels = max_levels - lev0 < D ? max_levels - lev0 : D;
+    const uint32_t d_all = D + (n_side ? side_len : 0u);
+    const uint32_t n_levels = max_levels - lev0 < d_all ? max_levels - lev0 : d_all;
     if (n_levels == 0) return;
     for (uint32_t level = 0; level < n_levels; level++) {
         __syncthreads();
@@ -540,11 +589,28 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         }
         __syncthreads();
         act = sh_act != 0;
-        if (!act || sh_o != likely_outcome(f, s2, mts)) {   // the chain evaluated ahead holds the likely successor only
+        if (!act) {
             held = false;
             break;
         }
-        w++;
+        if (sh_o == likely_outcome(f, s2, mts)) {   // the chain evaluated ahead holds the likely successor …
+            pos++;
+            if (pos >= chain_len) {
+                held = !on_side;
+                break;
+            }
+            w++;
+            continue;
+        }
+        if (sh_o == 0 && !on_side && pos >= side_from && pos < side_from + n_side) {   // … and, for n_side of the windows, what follows an acceptance
+            w = st.slot0[k] + D + (pos - side_from) * side_len;
+            on_side = true;
+            pos = 0;
+            chain_len = side_len;
+            continue;
+        }
+        held = false;
+        break;
     }
     if (lane != 0) return;
     st.first[k] = sh_f;
@@ -747,6 +813,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // shared-map gate: verification after every pass (default) or after every set of runs (ECAL_ADAPTIVE_ROUNDS=1: the form of
     // rounds 2 - 3, kept for comparison; same keyframes)
     const bool live = shared && !ctx->sw.adaptive_rounds;
+    const uint32_t live_side = ctx->sw.adaptive_side == 1 ? AD_SIDE_MEASURED : (ctx->sw.adaptive_side > 1 ? (uint32_t) ctx->sw.adaptive_side : AD_SIDE_DEFAULT);   // (ECAL_ADAPTIVE_SIDE: from | count << 8 | length << 16 | main << 24; 1 = the measured layout)
     const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1024u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
     auto run_passes = [&]() -> int {
         // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
@@ -754,7 +821,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u, live ? D : 0u, live_floor);
+                           (uint32_t *) nullptr, 0u, live ? D : 0u, live_floor, live_side);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
@@ -810,7 +877,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
             }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq, live ? D : 0u, live_floor);
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, live ? D : 0u, live_floor, live_side);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));

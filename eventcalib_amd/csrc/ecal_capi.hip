@@ -32,6 +32,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
     sw.adaptive_depth_max = (int) num("ECAL_ADAPTIVE_DEPTH_MAX");
     sw.adaptive_live_floor = (int) num("ECAL_ADAPTIVE_LIVE_FLOOR");
+    if (getenv("ECAL_ADAPTIVE_SIDE")) sw.adaptive_side = (int) num("ECAL_ADAPTIVE_SIDE");
     sw.arrow_k = (int) num("ECAL_ARROW_K");
     sw.bo_big_arena = (unsigned long long) num("ECAL_BO_BIG_ARENA");
     if (const char *e = getenv("ECAL_GRID_TOL_PX")) sw.grid_tol_px = atof(e);

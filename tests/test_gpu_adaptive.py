@@ -146,18 +146,19 @@ def _same_keyframes(dev, ref):
         assert np.array_equal(dev[k], ref[k]), k
 
 
-def _in_rounds(ctx, ev, pieces, t_first, t_last):
+def _in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_ROUNDS"):
     """The shared-map search with the verification after every SET of runs (ECAL_ADAPTIVE_ROUNDS=1: the form before round 4's
-    pass-by-pass verification, kept behind the switch) — must give the same keyframes."""
+    pass-by-pass verification, kept behind the switch) or with side chains behind accepted windows (ECAL_ADAPTIVE_SIDE=1: measured,
+    not the default) — must give the same keyframes."""
     import os
     import eventcalib_amd.capi as capi
     from eventcalib_amd.adaptive import detect_keyframes_device
-    os.environ["ECAL_ADAPTIVE_ROUNDS"] = "1"
+    os.environ[switch] = "1"
     capi.sync_env()
     try:
         return detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
     finally:
-        del os.environ["ECAL_ADAPTIVE_ROUNDS"]
+        del os.environ[switch]
         capi.sync_env()
 
 
@@ -181,6 +182,7 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     assert len(ref["time"]) >= 20
     _same_keyframes(dev, ref)
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last), ref)
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE"), ref)   # side chains behind accepted windows
     if pieces == 1:
         _same_keyframes(dev, own)              # one piece: the two modes are the same run
     _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last), own)
