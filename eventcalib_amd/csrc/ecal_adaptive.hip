@@ -813,6 +813,10 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // shared-map gate: verification after every pass (default) or after every set of runs (ECAL_ADAPTIVE_ROUNDS=1: the form of
     // rounds 2 - 3, kept for comparison; same keyframes)
     const bool live = shared && !ctx->sw.adaptive_rounds;
+    // slots dealt piece by piece (adaptive_alloc_kernel, live_base: a piece's chain doubles while it holds) — both gates; measured
+    // on the own-piece search against the same share for every piece at work (ECAL_ADAPTIVE_DEAL_UNIFORM=1): 0.059 / 0.065 s at
+    // 1270 pieces, 0.043 / 0.044 at 4096, 0.139 / 0.156 at 254; the set-by-set form of the shared-map gate keeps the uniform deal
+    const bool deal_by_piece = live || (!shared && !ctx->sw.adaptive_deal_uniform);
     const uint32_t live_side = ctx->sw.adaptive_side == 1 ? AD_SIDE_MEASURED : (ctx->sw.adaptive_side > 1 ? (uint32_t) ctx->sw.adaptive_side : AD_SIDE_DEFAULT);   // (ECAL_ADAPTIVE_SIDE: from | count << 8 | length << 16 | main << 24; 1 = the measured layout)
     const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1024u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
     auto run_passes = [&]() -> int {
@@ -821,7 +825,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u, live ? D : 0u, live_floor, live_side);
+                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
@@ -877,7 +881,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
             }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq, live ? D : 0u, live_floor, live_side);
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));

@@ -23,6 +23,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.no_zero_ring = on("ECAL_NO_ZERO_RING");
     sw.adaptive_trace = on("ECAL_ADAPTIVE_TRACE");
     sw.adaptive_rounds = on("ECAL_ADAPTIVE_ROUNDS");
+    sw.adaptive_deal_uniform = on("ECAL_ADAPTIVE_DEAL_UNIFORM");
     sw.grid_debug = on("ECAL_GRID_DEBUG");
     sw.grid_serial_walk = on("ECAL_GRID_SERIAL_WALK");
     sw.solver_device_linear_solve = on("ECAL_SOLVER_DEVICE_LINEAR_SOLVE");

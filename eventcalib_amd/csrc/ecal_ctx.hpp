@@ -25,7 +25,7 @@ struct ecal_switches {
     bool slice_no_pixel = false, slice_sort_kernel = false, slice_no_second_pass = false, bounds_two_kernels = false;
     bool dbscan_no_pixel = false, dbscan_no_second_pass = false, dbscan_generic_disc = false;
     bool extract_no_second_pass = false, no_fused_pass = false, no_zero_ring = false;
-    bool adaptive_trace = false, adaptive_rounds = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, solver_two_roles = false;
+    bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, solver_two_roles = false;
     int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_live_floor = 0, adaptive_side = -1, arrow_k = 0;   // 0: not set
     unsigned long long bo_big_arena = 0;                            // 0: not set
     double grid_tol_px = 20.0;
