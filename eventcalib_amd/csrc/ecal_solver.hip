@@ -1874,7 +1874,6 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             ECAL_HIP_TRY(ctx, hipMemcpy(s->d_prog, &pg, sizeof(pg), hipMemcpyHostToDevice));
         }
     }
-    const bool stream_partition = stream_ok;   // (kept for the whole solve, whatever becomes of the stream)
     ArrowSystem A_next;
     std::vector<double> dd_next(nt);
     bool reduced_ok = false;   // a streamed evaluation with `factor`: every separator of the reduced system eliminated
@@ -2095,7 +2094,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         bool ok = ts_mode ? solve_arrow_parts(A, scale, dd, delta, ws, ts_parts, nullptr, world, my_rank, &ts_exchange)
                   : (n_parts > 1 && parts_solve)
                       ? (fact_ready && fact_radius == radius ? prefactored_finish()   // (false when an interior or a separator was not positive definite)
-                                                             : solve_arrow_parts(A, scale, dd, delta, ws, parts, pool, n_parts, -1, nullptr, stream_partition))
+                                                             : solve_arrow_parts(A, scale, dd, delta, ws, parts, pool, n_parts))   // (a whole factorisation: the even partition — the streamed evaluation sets up its own)
                       : solve_arrow(A, scale, dd, delta, ws);
         if (fact_ready && fact_radius == radius) n_prefactored++;
         fact_ready = false;
