@@ -2374,6 +2374,41 @@ extern "C" int ecal_debug_arrow_solve_host(uint32_t n_cp, const double *accum, c
     return ECAL_OK;
 }
 
+// tests (no GPU involved): the solve's worker pool — `rounds` runs of 1 .. 40 tasks on `workers` threads, with pauses long enough for
+// the workers to go to sleep now and then, nudges from inside tasks (as the streamed evaluation's last interior does) and from the
+// caller; every task of every run must have run exactly once, in a run of its own.  Returns the number of violations.
+extern "C" int ecal_debug_host_pool_selftest(int workers, int rounds) {
+    if (workers < 0 || workers > 64 || rounds < 1) return -1;
+    HostPool pool(workers, 50);
+    std::vector<std::atomic<int>> hits(64);
+    int bad = 0;
+    uint64_t rng = 88172645463325252ull;
+    auto next = [&]() {
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        return rng;
+    };
+    std::atomic<int> in_run{0};
+    for (int r = 0; r < rounds; r++) {
+        const int n = 1 + (int) (next() % 40u);
+        for (auto &h : hits) h.store(0);
+        const int nudger = (int) (next() % (uint64_t) n);
+        if (next() % 4u == 0) std::this_thread::sleep_for(std::chrono::microseconds(120));   // (workers asleep by now)
+        if (next() % 3u == 0) pool.nudge();
+        in_run.store(r + 1);
+        pool.run(n, [&](int t) {
+            if (in_run.load() != r + 1) hits[63].fetch_add(1000);   // a task of another run
+            if (t == nudger) pool.nudge();
+            volatile double x = 0;
+            for (int i = 0; i < 200 + (t * 37) % 500; i++) x = x + i;
+            hits[t].fetch_add(1);
+        });
+        for (int t = 0; t < 64; t++) bad += hits[t].load() != (t < n ? 1 : 0);
+    }
+    return bad;
+}
+
 // tests: the host solve's partitions (arrow_partition / arrow_partition_stream)
 extern "C" int ecal_debug_arrow_partition(uint32_t n_cp, int parts, int stream, uint32_t *first_cp, uint32_t *num_cp) {
     if (!first_cp || !num_cp || parts < 1 || (uint32_t) (7 * parts) > n_cp) return ECAL_ERR_INVALID;

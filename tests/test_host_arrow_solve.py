@@ -115,3 +115,13 @@ def test_partitions_cover_the_control_points():
                 assert (np.diff(m.astype(np.int64)) <= 1).all()          # never growing towards the end
                 if n_cp >= 700:
                     assert m[-1] <= max(6, 0.007 * n_cp) + 1 and m[0] > 4 * m[-1]
+
+
+@pytest.mark.parametrize("workers", [0, 1, 3, 15])
+def test_the_worker_pool_runs_every_task_once(workers):
+    """HostPool (arrow_host_parts.hpp): runs of 1 - 40 tasks handed out among parked threads that poll, sleep and are nudged awake
+    — from the caller and from inside a task, as the streamed evaluation does — every task exactly once, none of another run."""
+    L = eventcalib_amd.load_library()
+    L.ecal_debug_host_pool_selftest.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.ecal_debug_host_pool_selftest.restype = ctypes.c_int
+    assert L.ecal_debug_host_pool_selftest(workers, 3000) == 0
