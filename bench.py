@@ -216,8 +216,9 @@ def main():
     c = ctx
     pipe.set_detect_params(5, 36, ctx.circle_radius_threshold(346, 260, 9, 4, True, 5.5, 1.75))
 
-    def staged_pass(n, Sw, marks=None):
+    def staged_pass(n, Sw, marks=None, event_point=None):
         """One pass of the hot path, stage by stage, on the launch stream; marks: five HIP events recorded around the stages."""
+        want_ep = args.event_point if event_point is None else event_point
         pk = pipe._pk()
         if marks:
             marks[0].record(st)
@@ -231,7 +232,7 @@ def main():
         # stage, the reference's EventFrame keeps none; the end-to-end leg, which associates, asks for it)
         c.slice_events_packed_dev(events.data_ptr(), n, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(), Sw, 0, n,
                                   pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(),
-                                  pipe.event_point.data_ptr() if args.event_point else 0, pipe.flags.data_ptr(), pk, st.cuda_stream)
+                                  pipe.event_point.data_ptr() if want_ep else 0, pipe.flags.data_ptr(), pk, st.cuda_stream)
         if marks:
             marks[2].record(st)
         c.dbscan_batch_packed_dev(pipe._xy.data_ptr(), pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), 2 * Sw, n, 0,
@@ -265,6 +266,7 @@ def main():
     else:
         covered_total = n_covered
 
+    ms_per_step_local = elapsed / max(args.steps, 1) * 1e3
     stage_ms = np.zeros(4)
     for k in range(args.steps):
         for j in range(4):
@@ -293,6 +295,29 @@ def main():
                          "passes_ms": {str(a): round(b, 4) for a, b in zip(sizes, times)},
                          "note": "intercept of pass time against window count (S, S/2, S/4 windows of the same stream)"}
         staged_pass(n_local, S)        # leave the arrays of the whole stream behind for the legs below
+        torch.cuda.synchronize(dev)
+
+    # the timed pass with the OTHER setting of the event -> point map (the library's DetectPipeline writes it by default, the
+    # timed pass does not unless --event-point): both figures side by side, so that `value` can be compared like for like
+    event_point_leg = None
+    if rank == 0 and args.steps > 0:
+        other = not args.event_point
+        for _ in range(2):
+            staged_pass(n_local, S, event_point=other)
+        fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        fe[0].record(st)
+        for _ in range(args.steps):
+            staged_pass(n_local, S, event_point=other)
+        fe[1].record(st)
+        torch.cuda.synchronize(dev)
+        other_ms = fe[0].elapsed_time(fe[1]) / args.steps
+        event_point_leg = {"timed_pass_writes_the_map": bool(args.event_point),
+                           "ms_per_step_with_the_map": round(ms_per_step_local if args.event_point else other_ms, 4),
+                           "ms_per_step_without_the_map": round(other_ms if args.event_point else ms_per_step_local, 4),
+                           "note": "d_event_point (event -> point index, 4 B per event) is this library's own output for the association "
+                                   "stage; the reference's EventFrame keeps none.  DetectPipeline's default writes it; `value` is the "
+                                   "setting named in config.event_point"}
+        staged_pass(n_local, S)
         torch.cuda.synchronize(dev)
 
     # the same pass as ONE call / one kernel per window (ecal_detect_fused_dev): measured beside the stage-by-stage form above,
@@ -371,7 +396,13 @@ def main():
             sharded_p2 = {"value": round(n_events / float(mx[0].item()) / 1e6, 1), "unit": "Mevents/s", "scaling": "strong", "pieces": P,
                           "pieces_per_gpu": p_hi - p_lo, "seconds": round(float(mx[0].item()), 4),
                           "keyframes": int(agg[0].item()), "windows_evaluated": int(agg[1].item()), "gate": "own piece",
-                          "note": "the pieces of one search cut over the ranks, every rank on its own time range of the stream"}
+                          "single_gpu_default_gate": "shared map",
+                          "note": "the pieces of one search cut over the ranks, every rank on its own time range of the stream.  "
+                                  "GATE: own piece (every piece's first success ungated) — NOT the single-GPU front ends' default: "
+                                  "the shared-map gate (the reference's single-worker semantics, EventCalibIni.cpp:26-36) hands a "
+                                  "piece its gate frame from the pieces before it and does not shard (ecal_detect_keyframes "
+                                  "refuses a subset of the pieces under it); compare this figure with policy_p2[gate = own piece] "
+                                  "of the 1-GPU line, not with its shared-map entry"}
             events = ev_p
         if args.scaling == "both":
             # weak scaling: every rank its OWN --events stream (its own time range of the motion), per-GPU work fixed
@@ -422,8 +453,11 @@ def main():
             "max_window_events": max_win, "max_segment_points": max_seg,
             "windows_reaching_pairing": n_ok, "circle_candidates": n_cand,
             "sharding": "time ranges of ONE stream, no data-path collective" if world > 1 else "single GPU",
+            "event_point": bool(args.event_point),
         },
     }
+    if event_point_leg is not None:
+        out["event_point_map"] = event_point_leg
     if weak is not None:
         out["weak_scaling"] = weak
     if sharded_p2 is not None:

@@ -6,8 +6,53 @@
 // unknowns), which one thread solves; the interiors are then back-substituted in parallel again.
 // Same algebra as arrow_device.hpp (the device form), same result as solve_arrow up to summation order.
 // Included by ecal_solver.hip inside its anonymous namespace (uses ArrowSystem, ArrowWorkspace, BW).
-// (<atomic>, <condition_variable>, <mutex>, <thread> are included by ecal_solver.hip at file scope)
+// (<atomic>, <condition_variable>, <mutex>, <thread>, <sched.h> are included by ecal_solver.hip at file scope)
 #pragma once
+
+// CPUs this process may keep busy: its affinity mask ∩ the cgroup's CPU quota (cpu.max of cgroup v2, cpu.cfs_quota_us of v1),
+// shared among the ranks of the node (LOCAL_WORLD_SIZE, as torch.distributed.run and the bench's launcher set it) — not
+// std::thread::hardware_concurrency(): the GPU box shows 256 hardware threads behind a quota of 16 CPUs, and eight ranks
+// with fifteen workers each would be 120 polling threads on 16 CPUs (a throttled cgroup loses milliseconds per iteration).
+// ECAL_HOST_THREADS overrides (tests, odd launchers).  quota_out (may be null): the node-wide figure before the division.
+inline int host_usable_cpus(int *quota_out = nullptr) {
+    long n = (long) std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = std::min<long>(n, CPU_COUNT(&set));
+    auto quota_of = [](const char *path_max, const char *path_q, const char *path_p) -> long {
+        if (path_max) {
+            if (FILE *f = fopen(path_max, "r")) {   // "max 100000" or "<quota> <period>"
+                char q[64] = {0};
+                long period = 0;
+                const int got = fscanf(f, "%63s %ld", q, &period);
+                fclose(f);
+                if (got == 2 && period > 0 && q[0] >= '0' && q[0] <= '9') return (atol(q) + period - 1) / period;
+            }
+            return 0;
+        }
+        long quota = -1, period = 0;
+        if (FILE *f = fopen(path_q, "r")) {
+            if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+            fclose(f);
+        }
+        if (FILE *f = fopen(path_p, "r")) {
+            if (fscanf(f, "%ld", &period) != 1) period = 0;
+            fclose(f);
+        }
+        return quota > 0 && period > 0 ? (quota + period - 1) / period : 0;
+    };
+    for (long q : {quota_of("/sys/fs/cgroup/cpu.max", nullptr, nullptr),
+                   quota_of(nullptr, "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"),
+                   quota_of(nullptr, "/sys/fs/cgroup/cpu,cpuacct/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu,cpuacct/cpu.cfs_period_us")})
+        if (q > 0) n = std::min(n, q);
+    if (quota_out) *quota_out = (int) n;
+    long ranks = 1;
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1L, atol(e));
+    n = std::max(1L, n / ranks);
+    if (const char *e = getenv("ECAL_HOST_THREADS"))
+        if (atol(e) >= 1) n = atol(e);
+    return (int) n;
+}
 
 // A few parked worker threads; run(n, fn) hands out tasks 0 .. n-1 (the caller works too) and returns when all are done.
 class HostPool {

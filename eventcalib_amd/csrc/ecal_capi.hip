@@ -146,7 +146,6 @@ extern "C" int ecal_init(int device, ecal_ctx **out) {
         for (int k = 0; k < ECAL_TAIL_SLOTS; k++) ctx->tail_seen[k] = 0xFFFFFFFFu;
     } else {   // no mapped host memory: every tier every time
         if (ctx->tail_seen) (void) hipHostFree(ctx->tail_seen);
-    if (ctx->roctx_lib) (void) dlclose(ctx->roctx_lib);
         ctx->tail_seen = ctx->tail_seen_dev = nullptr;
         (void) hipGetLastError();
     }
@@ -181,6 +180,9 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
         if (ctx->ev_consumed[k]) (void) hipEventDestroy(ctx->ev_consumed[k]);
     }
     for (ecal_devbuf *b : ctx->all_bufs()) release(*b);
+    ctx->roctx_push = nullptr;
+    ctx->roctx_pop = nullptr;
+    if (ctx->roctx_lib) (void) dlclose(ctx->roctx_lib);
     delete ctx;
 }
 

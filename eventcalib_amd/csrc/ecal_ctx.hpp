@@ -49,6 +49,8 @@ struct ecal_ctx {
     const void *px_tree_labels = nullptr, *px_tree_seg_off = nullptr;
     ecal_devbuf wb_status;  // ecal_window_bounds_dev: one word per workgroup of the look-back scan
     uint32_t wb_epoch = 0;  // ... and the number of the call that wrote it
+    hipStream_t wb_stream = nullptr;   // ... and the one stream whose calls use the table (others: the two-kernel form)
+    bool wb_stream_set = false;
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
     ecal_devbuf sort_scratch;  // ecal_sort_events_dev: keys, indices, radix-sort workspace

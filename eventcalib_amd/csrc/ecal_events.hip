@@ -918,7 +918,14 @@ extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, ui
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t) stream;
     const uint32_t n_wg = (S + WB_T - 1) / WB_T;
-    uint32_t *ticket = ctx->sw.bounds_two_kernels ? nullptr : ecal_zero_words(ctx, st, 1);
+    // the look-back table and its epoch belong to ONE stream of the context (the first that asks): calls in flight on two
+    // streams would overwrite each other's status words with another epoch and a workgroup looking back would wait for ever
+    // — a call on any other stream takes the two-kernel form, which uses no context scratch
+    if (!ctx->wb_stream_set) {
+        ctx->wb_stream = st;
+        ctx->wb_stream_set = true;
+    }
+    uint32_t *ticket = (ctx->sw.bounds_two_kernels || ctx->wb_stream != st) ? nullptr : ecal_zero_words(ctx, st, 1);
     if (ticket && ctx->wb_status.cap < (size_t) n_wg * sizeof(unsigned long long)) {
         int rc;
         if ((rc = ecal_ensure(ctx, ctx->wb_status, (size_t) n_wg * sizeof(unsigned long long)))) return rc;
@@ -1023,6 +1030,9 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                                             const ecal_packed_points *pk, void *stream) {
     const ecal_range range__(ctx, "ecal_slice_events");
     if (!ctx) return ECAL_ERR_INVALID;
+    // new points go into the segment arrays: the kd-trees the pixel DBSCAN kernel exported for the member-order kernel
+    // (ecal_ctx::px_tree) belong to the points of ITS call — the next DBSCAN call exports its own
+    ctx->px_tree_labels = nullptr;
     if (S == 0) return ECAL_OK;
     if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
     uint32_t *const xy16 = pk ? pk->d_xy16 : nullptr, *const sfmt = pk ? pk->d_seg_fmt : nullptr;

@@ -719,6 +719,7 @@ extern "C" int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events, ui
 extern "C" int ecal_copy_dev(ecal_ctx *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream, int sync) {
     if (!ctx || (bytes && (!d_dst || !d_src))) return ECAL_ERR_INVALID;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->px_tree_labels = nullptr;   // (the destination may be the arrays the exported kd-trees belong to: ecal_ctx::px_tree)
     if (bytes) ECAL_HIP_TRY(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t) stream));
     if (sync) ECAL_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t) stream));
     return ECAL_OK;

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <thread>
 #include <limits>
+#include <sched.h>
 #include "ecal_ctx.hpp"
 #include "spline_residual.hpp"
 #include "arrow_device.hpp"
@@ -1806,7 +1807,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     double t_unpack = 0, t_pool = 0;
     if (n_parts > 1) {
         const auto tp = now();
-        const int hw = (int) std::max(1u, std::thread::hardware_concurrency());
+        const int hw = host_usable_cpus();   // (affinity ∩ cgroup quota ÷ the node's ranks — not hardware_concurrency())
         const int workers = std::max(0, std::min(n_parts, hw) - 1);
         if (!s->host_pool || s->host_pool_workers != workers) {
             try {
@@ -1872,6 +1873,11 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             ECAL_HIP_TRY(ctx, hipMemcpy(s->d_prog, &pg, sizeof(pg), hipMemcpyHostToDevice));
             pg.n_groups = (uint32_t) n_parts;
             ECAL_HIP_TRY(ctx, hipMemcpy(s->d_prog, &pg, sizeof(pg), hipMemcpyHostToDevice));
+        } else {
+            // the kernel restores the groups' counters itself as it finishes each group — unless an earlier evaluation on this
+            // solver stopped half way (an error, a stream that failed to deliver): a solve starts from the full counts whatever
+            // the last one left behind (128 words; nothing of this solver is in flight here)
+            ECAL_HIP_TRY(ctx, hipMemcpyAsync(s->d_left, s->prog.init, 2 * NE_MAX_GROUPS * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         }
     }
     ArrowSystem A_next;
@@ -2373,6 +2379,10 @@ extern "C" int ecal_debug_arrow_solve_host(uint32_t n_cp, const double *accum, c
         for (size_t i = 0; i < nt; i++) delta_out[i] = y[i] * sc[i];
     return ECAL_OK;
 }
+
+// tests / bench: the CPUs the solver's worker pool is sized for (affinity ∩ cgroup quota ÷ LOCAL_WORLD_SIZE; ECAL_HOST_THREADS
+// overrides) and, in *node_quota, the figure before the division by the node's ranks.  No GPU involved.
+extern "C" int ecal_debug_host_usable_cpus(int *node_quota) { return host_usable_cpus(node_quota); }
 
 // tests (no GPU involved): the solve's worker pool — `rounds` runs of 1 .. 40 tasks on `workers` threads, with pauses long enough for
 // the workers to go to sleep now and then, nudges from inside tasks (as the streamed evaluation's last interior does) and from the

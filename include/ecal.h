@@ -90,7 +90,11 @@ int ecal_dbscan_batch_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_s
  * ecal_extract_batch_ordered_dev applies) —, the members of all other clusters get -2; segments without such a cluster do
  * not even have their tree rebuilt.  (only_tied_medians == 2, used by ecal_extract_batch_exact_dev: the caller has named
  * those clusters itself by storing -3 in d_order on the slot of one member of each.)
- * Four launches: segments of up to 768 points and 256 clusters, then up to 2048 points, then up to 4096, then the rest. */
+ * Four launches: segments of up to 768 points and 256 clusters, then up to 2048 points, then up to 4096, then the rest.
+ * Contract on the hand-over of kd-trees: the last ecal_dbscan_batch*_dev call of the context leaves the trees of its first-pass
+ * segments behind (4 bytes per point in context scratch); they are replayed here instead of being rebuilt when d_labels,
+ * d_seg_off and S are that call's.  Any slicing entry point and ecal_copy_dev on the context drop them; a caller that
+ * rewrites the points or labels of those buffers by other means must call ecal_dbscan_batch*_dev again before this. */
 int ecal_cluster_order_dev(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, uint32_t S,
                            double eps, const int32_t *d_labels, const uint32_t *d_n_clusters, int32_t *d_order /*[n_points]*/,
                            uint32_t *d_status /*[S]*/, int only_tied_medians, void *stream);
@@ -139,6 +143,8 @@ int ecal_get_point_order(const ecal_ctx *ctx);
 uint64_t ecal_ref_bucket_step(int epoch);
 uint64_t ecal_ref_pixel_hash(double x, double y);
 
+/* (One stream per context runs the single-launch form — the first stream that calls; calls on other streams of the same
+ * context are correct too but take two launches: the look-back table of the fused scan is context scratch.) */
 int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const double *d_t0,
                            const double *d_t1, uint32_t S, uint32_t *d_win_lo, uint32_t *d_win_hi,
                            uint32_t *d_win_base /*[S+1]*/, void *stream);

@@ -21,7 +21,7 @@
 //
 // Pinning status: the k-d tree part (insert + range query incl. result order) is checked
 // against the real reference kdtree.cpp compiled into oracle/_ref/libkdtree_ref.so
-// (tests/test_oracle_ref.py).  dbscan.h itself cannot be built in this image (it includes
+// (tests/test_oracle_dbscan.py).  dbscan.h itself cannot be built in this image (it includes
 // <Eigen/Eigen>, which is absent), so the Run()/expandCluster() driver is pinned only through
 // `oracle_dbscan_kdapi`, which runs this file's driver on top of the *reference's* kd_* C ABI
 // and must agree with the fully restated path, plus a scikit-learn cross-check on inputs where

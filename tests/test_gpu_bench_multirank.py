@@ -62,6 +62,12 @@ def test_two_ranks_match_one_rank():
     p2 = two["policy_p2_sharded"]
     assert p2["pieces"] == p1["pieces"] and p2["pieces_per_gpu"] <= (p1["pieces"] + 1) // 2
     assert p2["keyframes"] == p1["keyframes"] > 0 and p2["windows_evaluated"] == p1["windows_evaluated"]
+    # the sharded leg says which gate it ran (the shared-map gate, the single-GPU front ends' default, does not shard)
+    assert p2["gate"] == "own piece" and p2["single_gpu_default_gate"] == "shared map" and "does not shard" in p2["note"]
+    # the event -> point map: the line says whether the timed pass wrote it, and carries both figures
+    for r in (one, two):
+        assert r["config"]["event_point"] is False and r["event_point_map"]["timed_pass_writes_the_map"] is False
+        assert r["event_point_map"]["ms_per_step_with_the_map"] > 0 and r["event_point_map"]["ms_per_step_without_the_map"] > 0
     # the sharded init calibration lands on the single-rank answer (same 64 views, Schur records summed over ranks)
     c1, c2 = one["init_calibration"], two["init_calibration"]
     assert c1["views_per_gpu"] == 64 and c2["views_per_gpu"] == 32
