@@ -22,6 +22,7 @@
 #include <sched.h>
 #include "ecal_ctx.hpp"
 #include "spline_residual.hpp"
+#include "arrow_layout.hpp"
 #include "arrow_device.hpp"
 
 #include <algorithm>
@@ -53,9 +54,7 @@ struct NeTiles {
 constexpr uint32_t NE_CHUNK = 16384;  // residuals per workgroup (one span): few, long chunks keep the FP64 atomics rare
 constexpr uint32_t NE_REPL = 64;      // replicas of the shared head (cost, intrinsics block) that the chunks add into
 
-// accumulation buffer: [0] cost | [1..9] g_intr | [10..90] H_intr (9x9, upper) | per control point c at
-// 91 + 204 c: g_c[6] | H_c,intr[6][9] | H_c,c+d[4][6][6] (d = 0..3; d = 0 upper only)
-constexpr size_t ACC_HEAD = 91, ACC_PER_CP = 204;
+// (accumulation buffer layout: ACC_HEAD, ACC_PER_CP — arrow_layout.hpp)
 
 __device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_intr, uint32_t &cp, uint32_t &comp) {
     if (li < 9) {
@@ -115,7 +114,7 @@ __device__ __forceinline__ void ne_fma36(double (&acc)[36], const ne_v2d (&A)[3]
 // (a counter per group) copies the interior's records into the host's pinned buffer and raises the group's flag there; the
 // second of the two groups beside a separator to finish does the same for the separator's records.  The counters are restored
 // by the workgroup that zeroes them: nothing to prepare per launch.
-constexpr int NE_MAX_GROUPS = 32;
+// (NE_MAX_GROUPS: arrow_layout.hpp)
 struct NeProgress {
     uint32_t n_groups, n_cp;
     uint32_t cut[NE_MAX_GROUPS + 1];      // cut[n_groups] = n_cp
@@ -1186,224 +1185,7 @@ extern "C" int ecal_solver_evaluate(ecal_solver *s, const double *params, int wi
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int BW = 24;  // scalar half-bandwidth + 1 of the control-point part (4 blocks of 6)
-
-struct ArrowSystem {
-    size_t nc = 0;                // 6 * n_cp
-    std::vector<double> band;     // [nc][BW]: band[i][k] = A(i, i-k), lower band
-    std::vector<double> border;   // [nc][9]:  A(i, intr j)
-    double corner[81];            // A(intr, intr)
-    std::vector<double> gc;       // [nc]
-    double gi[9];
-};
-
-// unpack the accumulation buffer (upper blocks) into the symmetric arrow system
-void unpack_head(const double *acc, ArrowSystem &A) {
-    for (int i = 0; i < 9; i++) {
-        A.gi[i] = acc[1 + i];
-        for (int j = i; j < 9; j++) A.corner[9 * i + j] = A.corner[9 * j + i] = acc[10 + 9 * i + j];
-    }
-}
-// rows of control points [r_lo, r_hi): the band row of control point r = blocks (c, r) for c = r - 3 .. r, read from the column
-// owners' records — a range writes its own rows only, so ranges may run on different threads
-void unpack_rows(const double *acc, ArrowSystem &A, uint32_t r_lo, uint32_t r_hi) {
-    for (uint32_t r = r_lo; r < r_hi; r++) {
-        const double *b = acc + ACC_HEAD + ACC_PER_CP * (size_t) r;
-        for (int k = 0; k < 6; k++) {
-            A.gc[6 * r + k] = b[k];
-            for (int j = 0; j < 9; j++) A.border[(6 * (size_t) r + k) * 9 + j] = b[6 + 9 * k + j];
-            double *row = &A.band[(6 * (size_t) r + k) * BW];
-            for (int q = 0; q < BW; q++) row[q] = 0.0;
-        }
-        for (uint32_t d = 0; d < 4 && d <= r; d++) {
-            const uint32_t c = r - d;   // column owner: block (c, c + d) of its record
-            const double *blk = acc + ACC_HEAD + ACC_PER_CP * (size_t) c + 60 + 36 * d;
-            for (int ka = 0; ka < 6; ka++)
-                for (int kb = 0; kb < 6; kb++) {
-                    if (d == 0 && kb < ka) continue;  // diagonal block: upper stored
-                    const size_t row = 6 * (size_t) r + kb, col = 6 * (size_t) c + ka;  // row >= col
-                    A.band[row * BW + (row - col)] = blk[6 * ka + kb];
-                }
-        }
-    }
-}
-void unpack_alloc(uint32_t n_cp, ArrowSystem &A) {
-    A.nc = 6 * (size_t) n_cp;
-    A.band.resize(A.nc * BW);
-    A.border.resize(A.nc * 9);
-    A.gc.resize(A.nc);
-}
-void unpack(const double *acc, uint32_t n_cp, ArrowSystem &A) {
-    unpack_alloc(n_cp, A);
-    unpack_head(acc, A);
-    unpack_rows(acc, A, 0, n_cp);
-}
-
-// Solve (S A S + diag(dd)) y = -S g for the arrow system; returns false if not positive definite.
-// scale: Jacobi column scaling S (nc + 9); dd: LM diagonal added to the scaled system (nc + 9).
-// ws: caller-owned workspace (reused across iterations).  The border and the right-hand side are kept
-// as 10 contiguous columns so that the substitution loops vectorise.
-struct ArrowWorkspace {
-    std::vector<double> L, Z;  // [nc][BW] factor; [nc][10] = L^-1 [border | rhs]
-    double G[100];             // [Zb z]^T [Zb z]
-    std::function<bool(double *)> reduce_G;  // distributed mode: sums G over ranks in place; false = some rank failed
-};
-
-__attribute__((target("avx2,fma"))) bool solve_arrow(const ArrowSystem &A, const std::vector<double> &scale, const std::vector<double> &dd,
-                 std::vector<double> &y, ArrowWorkspace &ws) {
-    const size_t nc = A.nc;
-    ws.L.resize(nc * BW);
-    ws.Z.resize(nc * 10);
-    double *__restrict__ L = ws.L.data();
-    double *__restrict__ Z = ws.Z.data();
-    const double *__restrict__ sc = scale.data();
-    for (size_t i = 0; i < nc; i++) {
-        const double si = sc[i];
-        const size_t kmax = std::min<size_t>(BW - 1, i);
-        for (size_t k = 0; k <= kmax; k++) L[i * BW + k] = A.band[i * BW + k] * si * sc[i - k];
-        for (size_t k = kmax + 1; k < (size_t) BW; k++) L[i * BW + k] = 0.0;
-        L[i * BW] += dd[i];
-        for (int j = 0; j < 9; j++) Z[i * 10 + j] = A.border[i * 9 + j] * si * sc[nc + j];
-        Z[i * 10 + 9] = -A.gc[i] * si;
-    }
-    // banded Cholesky, right-looking: once column j is final, its rank-1 update goes into the (at most BW-1) rows
-    // below it and into their 10 border / right-hand-side columns.  The inner loops run over contiguous pieces of a
-    // row's band and of a small copy of the column, with fixed short trip counts: they vectorise (this function is
-    // compiled for AVX2 + FMA), which the row-wise dot-product form did not.
-    bool pd = true;
-    for (size_t j = 0; j < nc; j++) {
-        double d = L[j * BW];
-        if (!(d > 0.0)) {
-            pd = false;
-            break;
-        }
-        d = std::sqrt(d);
-        const double inv = 1.0 / d;
-        L[j * BW] = d;
-        double *__restrict__ Zj = Z + j * 10;
-        for (int c = 0; c < 10; c++) Zj[c] *= inv;
-        // the band is a BLOCK band (4 blocks of 6): column j of block column J reaches down to row 6 (J + 3) + 5 only, and
-        // Cholesky fill stays inside that envelope — the rows beyond hold exact zeros
-        const int rmax = (int) std::min<size_t>(BW - 1 - j % 6, nc - 1 - j);
-        double col[BW];  // col[r] = L(j + r, j)
-        for (int r = 1; r <= rmax; r++) {
-            col[r] = L[(j + r) * BW + r] * inv;
-            L[(j + r) * BW + r] = col[r];
-        }
-        for (int r = 1; r <= rmax; r++) {
-            const double lr = col[r];
-            double *__restrict__ Lr = L + (j + r) * BW;  // row j + r: entry (j + r, j + c) sits at band offset r - c
-            for (int c = 1; c <= r; c++) Lr[r - c] -= lr * col[c];
-            double *__restrict__ Zr = Z + (j + r) * 10;
-            for (int c = 0; c < 10; c++) Zr[c] -= lr * Zj[c];
-        }
-    }
-    // Schur complement on the 9 intrinsics: S = C - Zb^T Zb, b = -g_i - Zb^T z.  G = [Zb z]^T [Zb z] is a sum over the
-    // control-point rows: with the segments sharded over ranks it is the one thing the linear solve has to all-reduce.
-    double S[81], bvec[9];
-    double *G = ws.G;
-    for (int i = 0; i < 100; i++) G[i] = 0.0;
-    if (!pd) {
-        if (ws.reduce_G) {  // every rank must take part in the collective
-            G[99] = std::numeric_limits<double>::quiet_NaN();
-            (void) ws.reduce_G(G);
-        }
-        return false;
-    }
-    for (size_t r = 0; r < nc; r++) {
-        const double *__restrict__ z = Z + r * 10;
-        for (int i = 0; i < 10; i++) {
-            const double zi = z[i];
-            for (int j = i; j < 10; j++) G[10 * i + j] += zi * z[j];
-        }
-    }
-    if (ws.reduce_G && !ws.reduce_G(G)) return false;  // sum over ranks (also carries "some rank failed")
-    for (int i = 0; i < 9; i++) {
-        for (int j = 0; j < 9; j++) {
-            double v = A.corner[9 * i + j] * sc[nc + i] * sc[nc + j] - (i <= j ? G[10 * i + j] : G[10 * j + i]);
-            if (i == j) v += dd[nc + i];
-            S[9 * i + j] = v;
-        }
-        bvec[i] = -A.gi[i] * sc[nc + i] - G[10 * i + 9];
-    }
-    for (int i = 0; i < 9; i++) {  // dense Cholesky 9x9
-        for (int j = 0; j <= i; j++) {
-            double v = S[9 * i + j];
-            for (int k = 0; k < j; k++) v -= S[9 * i + k] * S[9 * j + k];
-            if (i == j) {
-                if (!(v > 0.0)) return false;
-                S[9 * i + i] = std::sqrt(v);
-            } else {
-                S[9 * i + j] = v / S[9 * j + j];
-            }
-        }
-    }
-    double yi[9];
-    for (int i = 0; i < 9; i++) {
-        double v = bvec[i];
-        for (int k = 0; k < i; k++) v -= S[9 * i + k] * yi[k];
-        yi[i] = v / S[9 * i + i];
-    }
-    for (int i = 8; i >= 0; i--) {
-        double v = yi[i];
-        for (int k = i + 1; k < 9; k++) v -= S[9 * k + i] * yi[k];
-        yi[i] = v / S[9 * i + i];
-    }
-    // back substitution for the control points: L^T y_c = z - Zb yi
-    y.assign(nc + 9, 0.0);
-    for (int j = 0; j < 9; j++) y[nc + j] = yi[j];
-    double *__restrict__ yc = y.data();
-    for (size_t ii = nc; ii-- > 0;) {
-        const double *__restrict__ z = Z + ii * 10;
-        double v = z[9];
-        for (int j = 0; j < 9; j++) v -= z[j] * yi[j];
-        const int kmax = (int) std::min<size_t>(BW - 1 - ii % 6, nc - 1 - ii);
-        for (int k = 1; k <= kmax; k++) v -= L[(ii + k) * BW + k] * yc[ii + k];
-        yc[ii] = v / L[ii * BW];
-    }
-    return true;
-}
-
-#include "arrow_host_parts.hpp"
-
-// y^T A y and g^T y on the unscaled system (for the model cost change)
-// skip_shared: distributed mode, ranks other than 0 — the intrinsics-only terms are counted once
-void quad_forms_rows(const ArrowSystem &A, const std::vector<double> &d, size_t lo, size_t hi, double *gTd, double *dHd) {
-    const size_t nc = A.nc;
-    double g = 0, h = 0;
-    for (size_t i = lo; i < hi; i++) {
-        g += A.gc[i] * d[i];
-        double row = A.band[i * BW] * d[i];
-        const int kmax = std::min<size_t>(BW - 1, i);
-        for (int k = 1; k <= kmax; k++) row += 2.0 * A.band[i * BW + k] * d[i - k];
-        h += d[i] * row;
-        for (int j = 0; j < 9; j++) h += 2.0 * d[i] * A.border[i * 9 + j] * d[nc + j];
-    }
-    *gTd = g;
-    *dHd = h;
-}
-void quad_forms(const ArrowSystem &A, const std::vector<double> &d, double *gTd, double *dHd, bool skip_shared = false, HostPool *pool = nullptr,
-                int tasks = 1) {
-    const size_t nc = A.nc;
-    double g = 0, h = 0;
-    if (pool && tasks > 1) {   // fixed ranges, partial sums added in range order: the result does not depend on the thread count
-        std::vector<double> part(2 * (size_t) tasks, 0.0);
-        const size_t per = (nc + tasks - 1) / tasks;
-        pool->run(tasks, [&](int t) { quad_forms_rows(A, d, std::min(nc, t * per), std::min(nc, (t + 1) * per), &part[2 * t], &part[2 * t + 1]); });
-        for (int t = 0; t < tasks; t++) {
-            g += part[2 * t];
-            h += part[2 * t + 1];
-        }
-    } else {
-        quad_forms_rows(A, d, 0, nc, &g, &h);
-    }
-    for (int i = 0; i < 9 && !skip_shared; i++) {
-        g += A.gi[i] * d[nc + i];
-        for (int j = 0; j < 9; j++) h += d[nc + i] * A.corner[9 * i + j] * d[nc + j];
-    }
-    *gTd = g;
-    *dHd = h;
-}
+#include "arrow_host.hpp"
 
 // x (+) delta: intrinsics and translations add, quaternions take exp(delta) (x) q
 void plus(const double *x, const std::vector<double> &d, uint32_t n_cp, bool so3, double *out, uint32_t c_lo = 0, uint32_t c_hi = 0xFFFFFFFFu) {
@@ -1913,89 +1695,16 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         const bool trace_ev = ctx->sw.solver_trace;
         tl_arrive.assign(P + 1, 0.0);
         tl_done.assign(P + 1, 0.0);
-        std::atomic<bool> failed{false};
-        std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[P]);
-        for (int p = 0; p < P; p++) done[p].store(0);
-        volatile const uint32_t *flag = s->h_flag;
-        // A thread polls its flag only when its turn is near (the flag four groups earlier is up); before that it naps: sixteen
-        // polling threads for the length of a kernel are the machine's whole CPU allowance on a 16-CPU cgroup, and a throttled
-        // process loses milliseconds (measured: 290 -> 230 iterations/s in runs that hit the quota).
-        auto nap = [] {
-            timespec ts{0, 20000};
-            nanosleep(&ts, nullptr);
-        };
-        // a flag that does not come: after two seconds of waiting the stream is asked — still busy: wait on (a long kernel);
-        // finished or in error with the flag down: the stream has failed to deliver, every waiter gives up
-        auto overdue = [&](std::chrono::steady_clock::time_point &t0) -> bool {
-            if (failed.load()) return true;
-            if (secs(t0, now()) < 2.0) return false;
-            t0 = now();
-            if (hipStreamQuery(st) == hipErrorNotReady) return false;
-            return true;
-        };
-        auto wait_for = [&](uint32_t idx, int gate) {
-            auto t0 = now();
-            if (gate >= 0)
-                while (flag[gate] != epoch && flag[idx] != epoch) {
-                    nap();
-                    if (overdue(t0) && flag[idx] != epoch) {
-                        failed.store(true);
-                        return;
-                    }
-                }
-            for (uint32_t spin = 0; flag[idx] != epoch; spin++) {
-                for (int i = 0; i < 16; i++) __builtin_ia32_pause();
-                if ((spin & 0xFFFu) == 0xFFFu && overdue(t0) && flag[idx] != epoch) {
-                    failed.store(true);
-                    return;
-                }
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
-        };
-        // tasks 0 .. P-1: an interior each (taken in this order: a thread that waits, waits for the GPU alone); task P, with
-        // `factor`: the separators of the reduced system one after the other, each as soon as the interiors beside it are done
-        pool->run(factor ? P + 1 : P, [&](int p) {
-            if (p == P) {
-                bool good = true;
-                for (int sp = 0; sp + 1 < P && good; sp++) {
-                    for (uint32_t spin = 0; !(done[sp].load(std::memory_order_acquire) && done[sp + 1].load(std::memory_order_acquire)); spin++) {
-                        if (sp + 8 < P) nap();   // (the separators of the spline's last stretch are the ones to be prompt about)
-                        else
-                            for (int i = 0; i < 16; i++) __builtin_ia32_pause();
-                        if ((spin & 0xFFu) == 0xFFu && failed.load()) return;
-                    }
-                    if (failed.load()) return;
-                    // the separator's own records are in (the interior behind it waited for them): its rows, its diagonal
-                    unpack_rows(acc, An, pg.cut[sp + 1] - 3, pg.cut[sp + 1]);
-                    for (size_t i = 6 * (size_t) (pg.cut[sp + 1] - 3); i < 6 * (size_t) pg.cut[sp + 1]; i++) {
-                        const double h = An.band[i * BW] * scale[i] * scale[i];
-                        dd_next[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / r_fact;
-                    }
-                    good = arrow_reduced_separator(An, scale.data(), dd_next.data(), parts, sp);
-                }
-                reduced_ok = good;
-                if (trace_ev) tl_done[P] = secs(te, now());
-                return;
-            }
-            if (pg.init[p]) wait_for((uint32_t) p, p >= 4 && pg.init[p - 4] ? p - 4 : -1);
-            if (p > 0 && pg.init[NE_MAX_GROUPS + p - 1]) wait_for((uint32_t) (NE_MAX_GROUPS + p - 1), -1);
-            if (p == P - 1 && factor) pool->nudge();   // the end is near: the threads that finished early are wanted for the back-substitution
-            if (trace_ev) tl_arrive[p] = secs(te, now());
-            if (!failed.load()) {
-                // rows of the interior and of the separator behind it (whose own records are not complete yet: those rows are
-                // unpacked again later; what the factorisation reads of them comes from the interior's records)
-                unpack_rows(acc, An, pg.cut[p], pg.cut[p + 1]);
-                if (factor) {
-                    for (size_t i = parts.a[p]; i < parts.a[p] + parts.n[p]; i++) {
-                        const double h = An.band[i * BW] * scale[i] * scale[i];
-                        dd_next[i] = std::min(std::max(h, opt.min_lm_diagonal), opt.max_lm_diagonal) / r_fact;
-                    }
-                    arrow_part_factor(An, scale.data(), dd_next.data(), ws, parts, p);
-                }
-            }
-            if (trace_ev) tl_done[p] = secs(te, now());
-            done[p].store(1, std::memory_order_release);
-        });
+        // the host tasks (arrow_host.hpp: an interior per task as its records arrive, the separators behind them)
+        StreamedSource src;
+        src.init = pg.init;
+        src.cut = pg.cut;
+        src.flag = s->h_flag;
+        src.epoch = epoch;
+        src.producer_gone = [&]() -> bool { return hipStreamQuery(st) != hipErrorNotReady; };
+        const bool delivered = arrow_streamed_tasks(pool, P, src, acc, An, factor, r_fact, scale.data(), dd_next.data(), opt.min_lm_diagonal,
+                                                    opt.max_lm_diagonal, ws, parts, &reduced_ok, trace_ev ? tl_arrive.data() : nullptr,
+                                                    trace_ev ? tl_done.data() : nullptr, te);
         tl_run = secs(te, now());
         const hipError_t e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
@@ -2003,8 +1712,8 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
             return ECAL_ERR_HIP;
         }
         const auto tt = now();
-        *streamed = !failed.load();
-        if (failed.load()) {
+        *streamed = delivered;
+        if (!delivered) {
             if (hipMemcpy(acc, s->d_accum, na * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return ECAL_ERR_HIP;
             unpack(acc, s->n_cp, An);
         } else {
@@ -2329,55 +2038,8 @@ extern "C" void ecal_inverse_radial_distortion(const double *k4, double *b5) {
 // interiors on a few threads; 3: the same on the streamed evaluation's partition (interiors shrinking towards the end).
 extern "C" int ecal_debug_arrow_solve_host(uint32_t n_cp, const double *accum, const double *scale, double radius, double min_diag,
                                            double max_diag, double *delta_out, int *fail_out, int mode, int parts_wanted) {
-    if (!accum || !scale || !delta_out || !fail_out || n_cp < 1 || (mode != 0 && mode != 2 && mode != 3)) return ECAL_ERR_INVALID;
-    const size_t nc = 6 * (size_t) n_cp, nt = nc + 9;
-    ArrowSystem A;
-    ArrowWorkspace ws;
-    unpack(accum, n_cp, A);
-    std::vector<double> sc(scale, scale + nt), dd(nt), y;
-    for (size_t i = 0; i < nt; i++) {
-        const double h = (i < nc ? A.band[i * BW] : A.corner[10 * (i - nc)]) * sc[i] * sc[i];
-        dd[i] = std::min(std::max(h, min_diag), max_diag) / radius;
-    }
-    bool ok;
-    if (mode == 2 || mode == 3) {
-        ArrowParts parts;
-        int P = parts_wanted > 0 ? parts_wanted : arrow_parts_for(n_cp);
-        if (P < 2) P = 4;
-        if ((uint32_t) (7 * P) > n_cp) return ECAL_ERR_RANGE;
-        HostPool pool(3);
-        ok = solve_arrow_parts(A, sc, dd, y, ws, parts, &pool, P, -1, nullptr, mode == 3);
-        if (const char *e = getenv("ECAL_DEBUG_ARROW_TIME")) {   // tools: the factorisation of the largest interior alone, warm, on this thread
-            const int reps = std::max(1, atoi(e));
-            size_t big = 0;
-            for (int p = 0; p < P; p++)
-                if (parts.n[p] > parts.n[big]) big = p;
-#ifdef ECAL_ARROW_PROF
-            memset(g_arrow_prof, 0, sizeof(g_arrow_prof));
-#endif
-            const auto t0 = std::chrono::steady_clock::now();
-            for (int r = 0; r < reps; r++) arrow_part_factor(A, sc.data(), dd.data(), ws, parts, (int) big);
-            const double us = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
-            std::vector<double> yy(nt);
-            const auto t1 = std::chrono::steady_clock::now();
-            for (int r = 0; r < reps; r++) arrow_part_backsub(ws, parts, (int) big, parts.yr.data(), yy.data());
-            const double us_b = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() / reps;
-#ifdef ECAL_ARROW_PROF
-            fprintf(stderr, "  cycles per control point: scaled entries %.0f | block factor %.0f | Gram %.0f | panel %.0f | trailing rows %.0f\n",
-                    g_arrow_prof[0] / (double) reps / (parts.n[big] / 6.0), g_arrow_prof[1] / (double) reps / (parts.n[big] / 6.0),
-                    g_arrow_prof[2] / (double) reps / (parts.n[big] / 6.0), g_arrow_prof[3] / (double) reps / (parts.n[big] / 6.0),
-                    g_arrow_prof[4] / (double) reps / (parts.n[big] / 6.0));
-#endif
-            fprintf(stderr, "arrow_part_factor: interior of %zu control points %.1f us (%.3f us per control point); back-substitution %.1f us\n",
-                    parts.n[big] / 6, us, us / (parts.n[big] / 6.0), us_b);
-        }
-    } else {
-        ok = solve_arrow(A, sc, dd, y, ws);
-    }
-    *fail_out = ok ? 0 : 1;
-    if (ok)
-        for (size_t i = 0; i < nt; i++) delta_out[i] = y[i] * sc[i];
-    return ECAL_OK;
+    const int rc = arrow_debug_solve_host(n_cp, accum, scale, radius, min_diag, max_diag, delta_out, fail_out, mode, parts_wanted);
+    return rc == -1 ? ECAL_ERR_INVALID : (rc == -6 ? ECAL_ERR_RANGE : ECAL_OK);
 }
 
 // tests / bench: the CPUs the solver's worker pool is sized for (affinity ∩ cgroup quota ÷ LOCAL_WORLD_SIZE; ECAL_HOST_THREADS
@@ -2387,37 +2049,7 @@ extern "C" int ecal_debug_host_usable_cpus(int *node_quota) { return host_usable
 // tests (no GPU involved): the solve's worker pool — `rounds` runs of 1 .. 40 tasks on `workers` threads, with pauses long enough for
 // the workers to go to sleep now and then, nudges from inside tasks (as the streamed evaluation's last interior does) and from the
 // caller; every task of every run must have run exactly once, in a run of its own.  Returns the number of violations.
-extern "C" int ecal_debug_host_pool_selftest(int workers, int rounds) {
-    if (workers < 0 || workers > 64 || rounds < 1) return -1;
-    HostPool pool(workers, 50);
-    std::vector<std::atomic<int>> hits(64);
-    int bad = 0;
-    uint64_t rng = 88172645463325252ull;
-    auto next = [&]() {
-        rng ^= rng << 13;
-        rng ^= rng >> 7;
-        rng ^= rng << 17;
-        return rng;
-    };
-    std::atomic<int> in_run{0};
-    for (int r = 0; r < rounds; r++) {
-        const int n = 1 + (int) (next() % 40u);
-        for (auto &h : hits) h.store(0);
-        const int nudger = (int) (next() % (uint64_t) n);
-        if (next() % 4u == 0) std::this_thread::sleep_for(std::chrono::microseconds(120));   // (workers asleep by now)
-        if (next() % 3u == 0) pool.nudge();
-        in_run.store(r + 1);
-        pool.run(n, [&](int t) {
-            if (in_run.load() != r + 1) hits[63].fetch_add(1000);   // a task of another run
-            if (t == nudger) pool.nudge();
-            volatile double x = 0;
-            for (int i = 0; i < 200 + (t * 37) % 500; i++) x = x + i;
-            hits[t].fetch_add(1);
-        });
-        for (int t = 0; t < 64; t++) bad += hits[t].load() != (t < n ? 1 : 0);
-    }
-    return bad;
-}
+extern "C" int ecal_debug_host_pool_selftest(int workers, int rounds) { return host_pool_selftest(workers, rounds); }
 
 // tests: the host solve's partitions (arrow_partition / arrow_partition_stream)
 extern "C" int ecal_debug_arrow_partition(uint32_t n_cp, int parts, int stream, uint32_t *first_cp, uint32_t *num_cp) {
