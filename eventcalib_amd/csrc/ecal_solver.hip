@@ -684,6 +684,7 @@ struct ecal_solver {
     std::shared_ptr<void> host_pool;   // ecal_solver_solve's worker threads (HostPool), parked between solves
     int host_pool_workers = -1;
     uint32_t stream_epoch = 0;
+    uint32_t last_solve[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ecal_debug_solver_last_solve: how the last ecal_solver_solve ran
     bool ws_attr_set = false;      // normal_eq_ws_kernel's dynamic LDS size registered
     size_t n_params() const { return 9 + 7 * (size_t) n_cp; }
     size_t n_accum() const { return ACC_HEAD + ACC_PER_CP * (size_t) n_cp; }
@@ -1585,6 +1586,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         }
         return true;
     };
+    const uint32_t epoch_at_start = s->stream_epoch;
     HostPool *pool = nullptr;   // (the solver keeps the threads: starting fifteen of them costs as much as a tenth of an iteration each)
     double t_unpack = 0, t_pool = 0;
     if (n_parts > 1) {
@@ -1989,6 +1991,13 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     S.seconds_evaluate = t_eval;
     S.seconds_linear_solve = t_lin;
+    s->last_solve[0] = (uint32_t) n_parts;
+    s->last_solve[1] = s->stream_epoch - epoch_at_start;
+    s->last_solve[2] = (uint32_t) n_prefactored;
+    s->last_solve[3] = pool ? (uint32_t) pool->workers() : 0u;
+    s->last_solve[4] = stream_ok ? 1u : 0u;
+    s->last_solve[5] = (uint32_t) S.iterations;
+    s->last_solve[6] = (uint32_t) dist_mode | (ts_mode ? 2u : 0u);
     if (s->ctx->sw.solver_trace)
         fprintf(stderr, "ecal_solver_solve: total %.4f s | evaluate %.4f | linear solve %.4f (%d parts) | unpack %.4f | pool %.4f | streamed evaluations: "
                         "%u, behind the kernel %.4f, %d of %d linear solves found their interiors factorised\n", S.seconds,
@@ -2040,6 +2049,15 @@ extern "C" int ecal_debug_arrow_solve_host(uint32_t n_cp, const double *accum, c
                                            double max_diag, double *delta_out, int *fail_out, int mode, int parts_wanted) {
     const int rc = arrow_debug_solve_host(n_cp, accum, scale, radius, min_diag, max_diag, delta_out, fail_out, mode, parts_wanted);
     return rc == -1 ? ECAL_ERR_INVALID : (rc == -6 ? ECAL_ERR_RANGE : ECAL_OK);
+}
+
+// tests: how the last ecal_solver_solve on this solver ran — [0] interiors of the host's partition, [1] streamed evaluations,
+// [2] linear solves that found their interiors factorised, [3] worker threads of the pool, [4] 1 = the streamed path was in force
+// at the end, [5] iterations, [6] bit 0 distributed, bit 1 time-sharded
+extern "C" int ecal_debug_solver_last_solve(const ecal_solver *s, uint32_t *out8) {
+    if (!s || !out8) return ECAL_ERR_INVALID;
+    memcpy(out8, s->last_solve, sizeof(s->last_solve));
+    return ECAL_OK;
 }
 
 // tests / bench: the CPUs the solver's worker pool is sized for (affinity ∩ cgroup quota ÷ LOCAL_WORLD_SIZE; ECAL_HOST_THREADS

@@ -399,7 +399,12 @@ def test_streamed_evaluation_gives_the_plain_solves_iterates(ctx, n_cp, n_res, p
     n_plain = [int(m) for m in re.findall(r"streamed evaluations: (\d+)", ep)]
     assert n_stream and n_stream[0] >= 2 and n_plain and n_plain[-1] == 0, (es, ep)
     for x, summ in ((xs, ss), (xs2, ss2)):
-        assert summ.iterations == sp.iterations and summ.successful_steps == sp.successful_steps
+        if noise == 0.0:
+            # noise-free: the cost goes to rounding level (1e-20), where the stop tests fire on the last bits of sums whose order
+            # differs from launch to launch — one iteration more or less, the same point (seen: 11 against 12)
+            assert abs(summ.iterations - sp.iterations) <= 1 and abs(summ.successful_steps - sp.successful_steps) <= 1
+        else:
+            assert summ.iterations == sp.iterations and summ.successful_steps == sp.successful_steps
         assert abs(summ.final_cost - sp.final_cost) <= 0.1 * tol * sp.final_cost + 1e-18, (summ.final_cost, sp.final_cost)
         assert np.abs(x - xp).max() <= tol * np.abs(xp).max()
 
