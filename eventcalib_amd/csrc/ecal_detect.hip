@@ -12,6 +12,7 @@
 #include "ecal_ctx.hpp"
 #include "block_utils.hpp"
 #include "extract_window.hpp"
+#include "dbscan_pixel.hpp"
 
 #pragma clang fp contract(off)
 
@@ -169,7 +170,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
                          double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info, uint32_t *d_cand_pair,
                          double *d_cand_xyr, int32_t *d_kept_labels, uint32_t *d_rep, int mode, const int32_t *d_order,
                          const uint32_t *d_in_list, const uint32_t *d_in_count, uint32_t *d_tie_list, uint32_t *d_tie_count, int32_t *d_tie_mark,
-                         void *stream, const ecal_packed_points *pk = nullptr) {
+                         void *stream, const ecal_packed_points *pk = nullptr, double tie_eps = 0.0 /* mode 2: the DBSCAN radius (0: no inline tie path) */) {
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
     if (pk && (!pk->d_xy16 || !pk->d_seg_fmt)) pk = nullptr;
@@ -203,6 +204,19 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
         ctx->last_error = "knn_num must be in 1..8 when fitCircle is set";
         return ECAL_ERR_INVALID;
     }
+    // the exact extraction's first pass resolves the ties of small clusters itself (resolve_ties_inline) when the kd-trees of
+    // these very labels and segments are at hand: the pixel DBSCAN kernel's last call on this context exported them
+    if (mode == 2 && tie_eps > 0.0 && !ctx->sw.extract_no_inline_ties && ctx->px_tree_labels && ctx->px_tree_labels == (const void *) d_labels &&
+        ctx->px_tree_seg_off == (const void *) d_seg_off && ctx->px_tree_S == 2 * S) {
+        PxGeom geom;
+        if (px_geometry(tie_eps, &geom)) {
+            prm.px_tree = (const uint32_t *) ctx->px_tree.ptr;
+            prm.px_tree_flag = (const uint32_t *) ctx->px_tree_flag.ptr;
+            prm.px_tree_epoch = ctx->px_tree_epoch;
+            prm.tie_e2i = geom.e2i;
+            prm.tie_prune = geom.eps_int ? geom.Rd - 1 : geom.Rd;   // |dx| < eps for integer dx (kdtree.cpp:169)
+        }
+    }
     if (!ctx->det_attr_set) {
 #define ECAL_DET_ATTR(K, BYTES)                                                                                        \
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int) (BYTES)))
@@ -213,7 +227,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     ECAL_DET_ATTR((K<true, 0>), BYTES);    \
     ECAL_DET_ATTR((K<true, 1>), BYTES);    \
     ECAL_DET_ATTR((K<true, 2>), BYTES)
-        ECAL_DET_ATTR3(extract_kernel, DET_LDS_BYTES);
+        ECAL_DET_ATTR3(extract_kernel, DET_LDS_BYTES + DET_TIE_INV_BYTES);
         ECAL_DET_ATTR3(extract_list_kernel, DET_LDS_BYTES2);
         ECAL_DET_ATTR((extract_first_list_kernel<false, 0>), DET_LDS_BYTES);
         ECAL_DET_ATTR((extract_first_list_kernel<false, 1>), DET_LDS_BYTES);
@@ -241,7 +255,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     // the device holds at once — six per CU
     const uint32_t gridf = S < 6u * ctx->n_cu ? S : 6u * ctx->n_cu;
 #define ECAL_DET_FIRST(FIT_, MODE_)                                                                                                  \
-    hipLaunchKernelGGL((extract_kernel<FIT_, MODE_>), dim3(S), dim3(DET_T), DET_LDS_BYTES, st, d_xy, d_seg_off, d_seg_cnt, d_labels,    \
+    hipLaunchKernelGGL((extract_kernel<FIT_, MODE_>), dim3(S), dim3(DET_T), DET_LDS_BYTES + (MODE_ == 2 ? DET_TIE_INV_BYTES : 0), st, d_xy, d_seg_off, d_seg_cnt, d_labels,    \
                        d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no,              \
                        second ? list : nullptr, cnt, d_order, d_tie_list, d_tie_count, d_tie_mark)
 #define ECAL_DET_FIRST_LIST(FIT_, MODE_, LIST_, COUNT_)                                                                              \
@@ -350,11 +364,12 @@ static int extract_exact(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     if (tcnt_zero) tcnt = tcnt_zero;
     int32_t *order = (int32_t *) ctx->tie_order.ptr;
     uint32_t *ostatus = (uint32_t *) (order + (size_t) n_points + 16);
+    ctx->tie_count_last = tcnt;   // (ecal_debug_tie_list_count)
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!tcnt_zero) ECAL_HIP_TRY(ctx, hipMemsetAsync(tcnt, 0, sizeof(uint32_t), (hipStream_t) stream));
     if ((rc = extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                             fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 2, nullptr, nullptr, nullptr, tlist,
-                            tcnt, order, stream, pk)))
+                            tcnt, order, stream, pk, eps)))
         return rc;
     // (only_tied_medians = 2: the tied clusters are the ones whose representative's slot the plain pass marked in `order`)
     if ((rc = ecal_cluster_order_sized(ctx, d_xy, d_seg_off, d_seg_cnt, 2 * S, n_points, eps, d_labels, d_n_clusters, order, ostatus, 2, tlist,
@@ -366,6 +381,16 @@ static int extract_exact(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     return extract_batch(ctx, d_xy, d_seg_off, d_seg_cnt, d_labels, d_n_clusters, S, n_points, cluster_min, need_clusters, radius_threshold,
                          fit_circle, knn_num, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, 1, order, tlist, tcnt, nullptr, nullptr,
                          nullptr, stream, pk);
+}
+
+// tests: the windows the last exact extraction on this context left on its list for the member-order launches (the ones its first
+// pass did not resolve itself: resolve_ties_inline); synchronises `stream`
+extern "C" int ecal_debug_tie_list_count(ecal_ctx *ctx, uint32_t *out, void *stream) {
+    if (!ctx || !out || !ctx->tie_count_last) return ECAL_ERR_INVALID;
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(out, ctx->tie_count_last, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t) stream));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize((hipStream_t) stream));
+    return ECAL_OK;
 }
 
 int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,

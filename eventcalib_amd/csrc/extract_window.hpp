@@ -5,6 +5,7 @@
 #include "ecal_ctx.hpp"
 #include "block_utils.hpp"
 #include "ref_nth_element.hpp"
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -47,7 +48,15 @@ struct DetectParams {
     uint32_t knn;            // Params::knn_num (<= DET_KNN_MAX)
     const uint32_t *xy16;    // packed points (ecal_packed_points) or null: windows marked seg_fmt & 1 are staged from these
     const uint32_t *seg_fmt; //   (a packed window that cannot be staged has had its doubles written before the launch)
+    // the exact extraction's first pass (TDET): the kd-trees the pixel DBSCAN kernel exported (ecal_ctx::px_tree: child links of
+    // point i of segment s at px_tree[seg_off[s] + i], valid where px_tree_flag[s] == px_tree_epoch) or null, and the range
+    // query's two tests for integer pixels: d2 <= eps^2 <=> d2 <= tie_e2i, |dx| < eps <=> |dx| <= tie_prune
+    const uint32_t *px_tree = nullptr, *px_tree_flag = nullptr;
+    uint32_t px_tree_epoch = 0;
+    int tie_e2i = 0, tie_prune = 0;
 };
+constexpr uint32_t DET_TIE_TREE_CAP = 768;   // points of a segment whose tree can be staged (the pixel DBSCAN kernel's first pass: PX_CAP)
+constexpr size_t DET_TIE_INV_BYTES = DET_TIE_TREE_CAP;   // u8 per point: its position in its cluster's ascending-pid member list
 constexpr uint32_t DET_KNN_MAX = 8;
 
 __device__ __forceinline__ double norm_of(double2 p) { return __dsqrt_rn(p.x * p.x + p.y * p.y); }  // Vector2d::norm()
@@ -243,6 +252,138 @@ __device__ __forceinline__ uint32_t ref_nth_member(const ST &st, uint32_t o, uin
     return a[nth];
 }
 
+// The tie path INSIDE the first extraction pass (round 5).  A window whose tied clusters are small used to leave this pass on a
+// list, have the member order of those clusters worked out by cluster_order_kernel (ecal_bfs.hip) and be extracted again from
+// the start — two more launches that stage the same window twice more (0.36 ms of the 2.75 ms pass for ties in 17 % of the
+// windows).  Here the workgroup that found the tie resolves it on the spot, a WAVE per tied cluster of <= 64 members:
+//   the polarity's kd-tree (dbscan_pixel_kernel's child links, 4 bytes per point) staged where csize / newid / coff lay (dead
+//   between the scatter and the pairing); a lane per member runs its range query — find_nearest's visiting order
+//   (kdtree.cpp:148-179), the pending far subtrees in a 192-bit shift register, integer arithmetic (exact for pixels) — and
+//   keeps the hits that are members of its own cluster, as positions in the cluster's ascending-pid list, in visiting order;
+//   the wave then simulates expandCluster's queue (dbscan.h:229-265; the result list is the hits in REVERSE visiting order,
+//   rlist_insert at the head, kdtree.cpp:469-486; a lane per hit of the popped member) and one lane runs libstdc++'s
+//   nth_element over the members in that order (CirclesEventFrame.cpp:136-147).
+// Scratch: members[] (free after the rank scan), 1408 bytes per wave.  Anything that does not fit — a cluster of more than 64
+// members, more same-cluster hits than the wave's list slots hold, more than twelve pending subtrees, no exported tree — fails
+// the whole window, which then goes on the list as before (nothing is committed until every tied cluster is resolved).
+// Returns true (uniform) when every tied cluster's representative is now the reference's pick (REP_TIE cleared).
+template <typename ST>
+__device__ __forceinline__ bool resolve_ties_inline(const ST &st, const uint32_t (&base)[2], const uint32_t (&kb)[2], const uint32_t (&n_pol)[2],
+                                                    const uint32_t (&nk)[2], uint32_t tied0, uint32_t tied1, const uint32_t *tree_g0,
+                                                    const uint32_t *tree_g1, int e2i, int prune, uint32_t *tree_lds, unsigned char *scratch,
+                                                    uint8_t *inv, uint32_t *fail_word) {
+    constexpr uint32_t WS = 1408, LIST_OFF = 200, LIST_BYTES = WS - LIST_OFF, NIL = 0xFFFFu;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned char *const ws = scratch + wave * WS;
+    uint16_t *const a = reinterpret_cast<uint16_t *>(ws);            // [64] the members in Clusters[c]'s order (polarity-local pids)
+    uint8_t *const queue = ws + 128;                                 // [64] positions in the ascending-pid member list
+    uint32_t *const inq = reinterpret_cast<uint32_t *>(ws + 192);    // [2] member is (or was) in the queue
+    uint8_t *const lists = ws + LIST_OFF;
+    if (tid == 0) *fail_word = 0;
+    for (int pol = 0; pol < 2; pol++) {
+        __syncthreads();   // the other polarity's tree is done with
+        if (!(pol ? tied1 : tied0)) continue;
+        const uint32_t o = base[pol];
+        const uint32_t *const tg = pol ? tree_g1 : tree_g0;   // (selects, not arrays indexed at run time: those would live in scratch memory)
+        for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) tree_lds[i] = tg[i];
+        __syncthreads();
+        for (uint32_t k = wave; k < nk[pol]; k += DET_T / 64) {   // (uniform in the wave)
+            const uint32_t rv = st.rep[kb[pol] + k];
+            if (!(rv & ST::REP_TIE)) continue;
+            const uint32_t m = st.ksize[kb[pol] + k], first = o + st.koff[kb[pol] + k];
+            if (m > 64u) {
+                if (lane == 0) *fail_word = 1;
+                continue;
+            }
+            const uint32_t slot = LIST_BYTES / m > 63u ? 63u : LIST_BYTES / m;
+            const uint32_t p = lane < m ? st.sorted[first + lane] : 0u;
+            if (lane < m) inv[p] = (uint8_t) lane;
+            if (lane < 2u) inq[lane] = lane == 0 ? 1u : 0u;   // the seed = the smallest pid = position 0 (dbscan.h:140-158)
+            if (lane == 0) queue[0] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- the members' range queries ----
+            uint32_t cnt = 0;
+            bool bad = false;
+            if (lane < m) {
+                const uint32_t pw = st.ipt(o + p);
+                const int qx = (int) (short) (pw & 0xFFFFu), qy = ((int) pw) >> 16;
+                uint8_t *const out = lists + lane * slot;
+                unsigned long long s0 = 0, s1 = 0, s2 = 0;   // pending far subtrees: twelve entries of node | dir << 15
+                uint32_t sp = 0, node = 0, dir = 0;
+                for (;;) {
+                    while (node != NIL) {
+                        const uint32_t nw = st.ipt(o + node);
+                        const int nx = (int) (short) (nw & 0xFFFFu), ny = ((int) nw) >> 16;
+                        const int ddx = nx - qx, ddy = ny - qy;
+                        if (ddx * ddx + ddy * ddy <= e2i && node != p && st.kept[o + node] == (int) k) {   // (regionQuery drops the query point, dbscan.h:218)
+                            if (cnt < slot) out[cnt] = inv[node];
+                            cnt++;
+                        }
+                        const int dx = dir ? (qy - ny) : (qx - nx);
+                        const uint32_t t = tree_lds[node], l = t & 0xFFFFu, r = t >> 16;
+                        const uint32_t nearc = dx <= 0 ? l : r, farc = dx <= 0 ? r : l;
+                        if ((dx < 0 ? -dx : dx) <= prune && farc != NIL) {
+                            if (sp < 12u) {
+                                s2 = (s2 << 16) | (s1 >> 48);
+                                s1 = (s1 << 16) | (s0 >> 48);
+                                s0 = (s0 << 16) | (farc | ((dir ^ 1u) << 15));
+                            }
+                            sp++;
+                        }
+                        node = nearc;
+                        dir ^= 1u;
+                    }
+                    if (sp == 0 || sp > 12u) break;
+                    sp--;
+                    const uint32_t e = (uint32_t) (s0 & 0xFFFFu);
+                    s0 = (s0 >> 16) | (s1 << 48);
+                    s1 = (s1 >> 16) | (s2 << 48);
+                    s2 >>= 16;
+                    node = e & 0x7FFFu;
+                    dir = e >> 15;
+                }
+                bad = cnt > slot || sp > 12u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- expandCluster's queue: a lane per hit of the popped member, the hits taken from the END of its list ----
+            uint32_t head = 0, tail = 1;
+            const bool any_bad = __any(bad);
+            while (!any_bad && head < tail) {
+                const uint32_t q = reinterpret_cast<volatile uint8_t *>(queue)[head];
+                head++;
+                const uint32_t mq = (uint32_t) __shfl((int) cnt, (int) q, 64);
+                bool take = false;
+                uint32_t j = 0;
+                if (lane < mq) {
+                    j = lists[q * slot + (mq - 1u - lane)];
+                    const uint32_t bit = 1u << (j & 31u);
+                    take = !(atomicOr(&inq[j >> 5], bit) & bit);   // (the hits of one query are distinct points)
+                }
+                const unsigned long long mask = __ballot(take);
+                if (take) queue[tail + __popcll(mask & ((1ull << lane) - 1ull))] = (uint8_t) j;
+                tail += (uint32_t) __popcll(mask);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (any_bad || tail != m) {   // (tail != m cannot happen with labels and tree of the same DBSCAN call: defensive)
+                if (lane == 0) *fail_word = 1;
+                continue;
+            }
+            if (lane < m) a[lane] = (uint16_t) st.sorted[first + queue[lane]];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                ecal::ref_nth_element(a, m, m / 2u, [&](uint16_t x, uint16_t y) { return st.key(o + x) < st.key(o + y); });
+                st.rep[kb[pol] + k] = (typename std::remove_reference<decltype(st.rep[0])>::type) (a[m / 2u] | ST::REP_TIE | ST::REP_BAD);   // resolved, not yet committed
+            }
+        }
+    }
+    __syncthreads();
+    return *fail_word == 0;
+}
+
 // ORD: ord0 / ord1 = the points' positions inside the reference's Clusters[label] (ecal_cluster_order_dev), per polarity:
 // the representative of a cluster whose median rank has an equal-norm rival is then the reference's own pick.
 // TDET (without ORD): the window is appended to tie_list when some kept cluster's median is tied — the representatives stay
@@ -255,7 +396,8 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                                                const uint32_t (&nc_pol)[2], const DetectParams &prm, uint32_t *csize,
                                                typename ST::CIdx *newid, typename ST::CIdx *coff,
                                                unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
-                                               uint32_t *cand_pair, double *cand_xyr) {
+                                               uint32_t *cand_pair, double *cand_xyr, const uint32_t *tie_tree0, const uint32_t *tie_tree1,
+                                               uint8_t *tie_inv) {
     const uint32_t tid = threadIdx.x;
     DET_T0();
     for (int pol = 0; pol < 2; pol++) {
@@ -363,30 +505,46 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
     __syncthreads();
     if constexpr (TDET && !ORD) {
         for (int pol = 0; pol < 2; pol++)
-            for (uint32_t k = tid; k < nk[pol]; k += DET_T) {
-                const uint32_t rv = st.rep[kb[pol] + k];
-                if (rv & ST::REP_TIE) {
-                    st.rep[kb[pol] + k] = rv & ~ST::REP_TIE;
-                    nk_sh[pol] |= 0x80000000u;   // (nk[] was read into registers above; every writer stores the same bit)
-                    // the cluster is named to ecal_cluster_order_list_dev by a mark on its representative's slot
-                    int32_t *mk = pol ? mark1 : mark0;
-                    if (mk) mk[rv & ~ST::REP_TIE] = -3;
-                }
-            }
+            for (uint32_t k = tid; k < nk[pol]; k += DET_T)
+                if (st.rep[kb[pol] + k] & ST::REP_TIE) nk_sh[pol] |= 0x80000000u;   // (nk[] was read into registers above; every writer stores the same bit)
         __syncthreads();
         const uint32_t tied0 = nk_sh[0] >> 31, tied1 = nk_sh[1] >> 31;
         const bool window_tied = (tied0 | tied1) != 0;
         __syncthreads();
-        if (tid == 0 && window_tied) {
+        if (tid == 0) {
             nk_sh[0] &= 0x7FFFFFFFu;
             nk_sh[1] &= 0x7FFFFFFFu;
+        }
+        bool resolved = false;
+        if constexpr (ST::INT_PIXELS) {   // staged integer pixels: the tied clusters' member order worked out here (resolve_ties_inline)
+            if (window_tied && tie_inv && (!tied0 || tie_tree0) && (!tied1 || tie_tree1) && 8u * ST::MAXC >= 4u * DET_TIE_TREE_CAP)
+                resolved = resolve_ties_inline(st, base, kb, n_pol, nk, tied0, tied1, tie_tree0, tie_tree1, prm.tie_e2i, prm.tie_prune, csize,
+                                               reinterpret_cast<unsigned char *>(st.members), tie_inv, &nk_sh[2]);
+        }
+        for (int pol = 0; pol < 2; pol++)
+            for (uint32_t k = tid; k < nk[pol]; k += DET_T) {
+                const uint32_t rv = st.rep[kb[pol] + k];
+                if (!(rv & ST::REP_TIE)) continue;
+                const uint32_t idx = rv & ~(ST::REP_TIE | ST::REP_BAD);
+                if (resolved) {
+                    st.rep[kb[pol] + k] = idx;    // the reference's pick
+                } else {
+                    // the window goes on the list: the smaller-pid member stays for now, and the cluster is named to
+                    // ecal_cluster_order_list_dev by a mark on the slot of one of its points (idx is one, resolved inline or not)
+                    st.rep[kb[pol] + k] = idx;
+                    int32_t *mk = pol ? mark1 : mark0;
+                    if (mk) mk[idx] = -3;
+                }
+            }
+        __syncthreads();
+        if (tid == 0 && window_tied && !resolved) {
             // the list entry: the window, bits 30 / 31 set = its + / - segment holds no tied cluster (ecal_cluster_order_list_dev skips it)
             if (tie_list) tie_list[atomicAdd(tie_count, 1u)] = tie_token | ((tied0 ^ 1u) << 30) | ((tied1 ^ 1u) << 31);
         }
         __syncthreads();
         // a listed window is extracted again from the start with the reference's picks (ORD): its pairing here would be
         // thrown away
-        if (window_tied && tie_list) return;
+        if (window_tied && !resolved && tie_list) return;
     }
     if constexpr (ORD) {
         // the flagged clusters: members into the reference's order (members[] is free from here on; a thread per POINT
@@ -830,11 +988,21 @@ __device__ __forceinline__ void extract_one(
         st.small = small_px;
         const uint32_t base[2] = {0u, n_pol[0]};
         const uint32_t kb[2] = {0u, MAXC};  // per-cluster arrays: one block of MAXC per polarity
+        // TDET, first pass: the kd-trees of the window's two segments, where the pixel DBSCAN kernel exported them (resolve_ties_inline)
+        const uint32_t *tie_tree0 = nullptr, *tie_tree1 = nullptr;
+        uint8_t *tie_inv = nullptr;
+        if constexpr (TDET && FIRST && !KNOWN) {
+            if (prm.px_tree) {
+                tie_inv = smem + (LL::bytes > 3 * DET_MAXC * sizeof(uint32_t) ? LL::bytes : 3 * DET_MAXC * sizeof(uint32_t));   // (behind DET_LDS_BYTES: the launch adds DET_TIE_INV_BYTES)
+                if (n_pol[0] <= DET_TIE_TREE_CAP && prm.px_tree_flag[2 * s] == prm.px_tree_epoch) tie_tree0 = prm.px_tree + o_pol[0];
+                if (n_pol[1] <= DET_TIE_TREE_CAP && prm.px_tree_flag[2 * s + 1] == prm.px_tree_epoch) tie_tree1 = prm.px_tree + o_pol[1];
+            }
+        }
         extract_window<FIT, ORD, TDET>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
                                        order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, tie_mark ? tie_mark + o_pol[0] : nullptr,
                                        tie_mark ? tie_mark + o_pol[1] : nullptr, nc_pol, prm, csize,
                        reinterpret_cast<uint16_t *>(smem + LL::newid_off), reinterpret_cast<uint16_t *>(smem + LL::coff_off), red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
-                       cand_xyr + 3 * (size_t) o_pol[0]);
+                       cand_xyr + 3 * (size_t) o_pol[0], tie_tree0, tie_tree1, tie_inv);
         __syncthreads();
 #ifdef ECAL_PHASE_PROF
         det_t__ = __builtin_readcyclecounter();
@@ -866,12 +1034,12 @@ __device__ __forceinline__ void extract_one(
                                        order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, tie_mark ? tie_mark + o_pol[0] : nullptr,
                                        tie_mark ? tie_mark + o_pol[1] : nullptr, nc_pol, prm, csize, csize + DET_MAXC,
                        csize + 2 * DET_MAXC, red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
-                       cand_xyr + 3 * (size_t) o_pol[0]);
+                       cand_xyr + 3 * (size_t) o_pol[0], nullptr, nullptr, nullptr);
     }
 }
 constexpr size_t DET_LDS_BYTES_GLOBAL = 3 * DET_MAXC * sizeof(uint32_t);
 constexpr size_t DET_LDS_BYTES_STAGED = DetLdsLayoutT<DET_LDS_PTS, DET_LDS_MAXC>::bytes;
-static_assert(DET_LDS_BYTES_STAGED + 64 <= 26624, "six workgroups per CU");
+static_assert(DET_LDS_BYTES_STAGED + DET_TIE_INV_BYTES + 64 <= 26624, "six workgroups per CU");
 constexpr size_t DET_LDS_BYTES2 = DetLdsLayoutT<DET_LDS_PTS2, DET_LDS_MAXC2>::bytes > DET_LDS_BYTES_GLOBAL
                                       ? DetLdsLayoutT<DET_LDS_PTS2, DET_LDS_MAXC2>::bytes : DET_LDS_BYTES_GLOBAL;
 constexpr size_t DET_LDS_BYTES = DET_LDS_BYTES_STAGED > DET_LDS_BYTES_GLOBAL ? DET_LDS_BYTES_STAGED : DET_LDS_BYTES_GLOBAL;

@@ -358,3 +358,65 @@ def test_packed_points_give_the_same_results_bit_for_bit(env):
             for h in (0, 1):
                 oo = a["off"][2 * s + h]
                 assert np.array_equal(a["rep"][oo:oo + a["info"][s, 1 + h]], b["rep"][oo:oo + b["info"][s, 1 + h]]), s
+
+
+def _tie_list_count(ctx, torch):
+    import ctypes
+    L = ctx._L
+    L.ecal_debug_tie_list_count.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.c_void_p]
+    L.ecal_debug_tie_list_count.restype = ctypes.c_int
+    out = ctypes.c_uint32(0xFFFFFFFF)
+    ctx._check(L.ecal_debug_tie_list_count(ctx._h, ctypes.byref(out), torch.cuda.current_stream().cuda_stream))
+    return out.value
+
+
+@pytest.mark.parametrize("rate", [1.0e6, 2.0e6])
+def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, monkeypatch):
+    """The exact extraction's first pass resolves the ties of small clusters itself (resolve_ties_inline: the DBSCAN kernel's
+    kd-trees, a wave per tied cluster) instead of leaving the window on a list for the member-order launches and a second
+    extraction.  Same picks either way — every output array equal to the listed form's (ECAL_EXTRACT_NO_INLINE_TIES=1) and to the
+    oracle's — and the list it leaves is (nearly) empty where the listed form's holds every tied window.  2 Mev/s: windows of
+    ~3000 events, segments beyond 768 points have no exported tree and stay on the list."""
+    ctx, _pipe, torch = env
+    from eventcalib_amd.capi import sync_env
+    from eventcalib_amd.pipeline import DetectPipeline
+    n = 300_000
+    buf = SS.make_stream(n, rate=rate, device="cpu", seed=77)
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / rate)
+    ev = buf.cuda()
+    S = len(t0)
+    outs, counts = [], []
+    for listed in (False, True):
+        if listed:
+            monkeypatch.setenv("ECAL_EXTRACT_NO_INLINE_TIES", "1")
+        else:
+            monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+        sync_env()
+        pipe = DetectPipeline(ctx)
+        pipe.set_windows(t0, t1)
+        pipe.set_detect_params(5, 36, THR)
+        pipe.run(ev)
+        torch.cuda.synchronize()
+        counts.append(_tie_list_count(ctx, torch))
+        outs.append({k: getattr(pipe, k)[:n].cpu().numpy().copy() for k in ("kept_labels", "rep", "cand_pair", "cand_xyr")})
+        outs[-1]["info"] = pipe.win_info[:S].cpu().numpy().copy()
+        if not listed:
+            exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)      # == the oracle, window by window
+    monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+    sync_env()
+    a, b = outs
+    off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
+    assert np.array_equal(a["info"], b["info"])
+    assert (a["info"][:, 3] & 0x100 == 0).all()                 # no window fell back to the smaller-pid pick
+    for s in range(S):
+        o, m = off[2 * s], a["info"][s, 0]
+        assert np.array_equal(a["cand_pair"][o:o + m], b["cand_pair"][o:o + m]) and np.array_equal(a["cand_xyr"][o:o + m], b["cand_xyr"][o:o + m]), s
+        if a["info"][s, 3] == 0:
+            for h in (0, 1):
+                oo = off[2 * s + h]
+                assert np.array_equal(a["rep"][oo:oo + a["info"][s, 1 + h]], b["rep"][oo:oo + b["info"][s, 1 + h]]), s
+    assert tied >= (10 if rate == 1.0e6 else 1) and counts[1] >= tied   # the listed form lists every tied window ...
+    if rate == 1.0e6:
+        assert counts[0] <= counts[1] // 10, counts             # ... the first pass leaves (nearly) none of them
+    else:
+        assert counts[0] <= counts[1], counts
