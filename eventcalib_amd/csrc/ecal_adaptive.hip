@@ -487,12 +487,16 @@ __global__ __launch_bounds__(64) void adaptive_dir_kernel(uint32_t rows, uint32_
     dirs[2 * ((size_t) w * rows + lane) + 1] = dy;
 }
 
-// One 64-lane workgroup per piece: verdict of the pass -> gate -> keyframe record -> next window, up to n_levels times: as long
-// as the verdict is the likely one, the next window is the next slot of the chain that this pass evaluated ahead of time.
+// One wave per piece: verdict of the pass -> gate -> keyframe record -> next window, up to n_levels times: as long as the
+// verdict is the likely one, the next window is the next slot of the chain that this pass evaluated ahead of time.
 // (A lock-step pass costs the latency of one workgroup through ~25 kernels plus the work of its windows — 0.63 ms for 1270
 // windows of ~6 steps, 0.84 ms for three times the events —, and a piece's windows are a dependent chain: 2.7 links per pass
 // at nine verdicts in ten as expected.)
-// (The rows' line fits come from adaptive_dir_kernel; lane 0 does the rest.)
+// Round 5: the walk along the chain is wave-uniform arithmetic on registers.  It used to be lane 0 alone, two workgroup barriers
+// and four dependent global reads per window (events of the window, status, grid found) — 100 - 140 us of every pass for chains
+// of up to 48 windows, nothing but memory latency.  Now lane l reads those words of the chain's l-th window up front (one round
+// trip for the whole chain) and every lane follows the same verdicts from them; the rare window that holds a grid (one in
+// thirteen) goes through the gate as before (the rows' line fits come from adaptive_dir_kernel), its circles copied a lane each.
 __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t rows, uint32_t cols, uint32_t max_levels,
                                      const uint32_t *__restrict__ win_info,
                                      const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
@@ -503,19 +507,17 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                                      uint32_t *__restrict__ kf_gen, double *__restrict__ t0,
                                      double *__restrict__ t1, const int *__restrict__ overflow, const double *__restrict__ dirs) {
     const uint32_t k = blockIdx.x, lane = threadIdx.x;
-    __shared__ double sh_f, sh_s2;
-    __shared__ int sh_act, sh_o;
     if (k == 0 && lane == 0 && *overflow) st.counters[3] = 1;  // the slicer clears its flag at every call: keep it until the host looks
     if (k >= P || !st.active[k]) return;
     const uint32_t M = rows * cols;
     const double ln = 3 * mts;
-    if (lane == 0) {
-        sh_f = st.first[k];
-        sh_s2 = st.second[k];
-    }
-    uint32_t w = st.slot0[k];   // slot of the window under evaluation
-    const uint32_t D = st.depth[k] & 0xFFu, n_side = (st.depth[k] >> 8) & 0xFFu, side_from = (st.depth[k] >> 16) & 0xFFu,
-                   side_len = st.depth[k] >> 24;   // (adaptive_alloc_kernel's side chains, live form)
+    double f = st.first[k], s2 = st.second[k];
+    const double hi = st.bound_hi[k];
+    const uint32_t slot0 = st.slot0[k];
+    uint32_t w = slot0;   // slot of the window under evaluation
+    const uint32_t dw = st.depth[k];
+    const uint32_t D = dw & 0xFFu, n_side = (dw >> 8) & 0xFFu, side_from = (dw >> 16) & 0xFFu,
+                   side_len = dw >> 24;   // (adaptive_alloc_kernel's side chains, live form)
     uint32_t pos = 0, chain_len = D;   // position in the chain being walked (the main one, then at most one side chain)
     bool on_side = false;
     bool act = true, held = true;
@@ -523,77 +525,97 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
     const uint32_t d_all = D + (n_side ? side_len : 0u);
     const uint32_t n_levels = max_levels - lev0 < d_all ? max_levels - lev0 : d_all;
     if (n_levels == 0) return;
+    // the main chain's windows, a lane each (D <= 48): events of the window (EventFrame::eventsNum()), extractFeatures() == true
+    uint32_t pre_cnt = 0, pre_ok = 0;
+    if (lane < D) {
+        const uint32_t wl = slot0 + lane;
+        pre_cnt = seg_cnt[2 * wl] + seg_cnt[2 * wl + 1];
+        pre_ok = (ECAL_WIN_STATUS(win_info[4 * wl + 3]) == 0 && found[wl]) ? 1u : 0u;
+    }
+    uint32_t have_ref = st.have_ref[k], nacc = st.nacc[k], nrej = st.nrej[k];
+    uint32_t levels_done = 0;
     for (uint32_t level = 0; level < n_levels; level++) {
-        __syncthreads();
-        const double f = sh_f, s2 = sh_s2;
-        const uint32_t cnt = seg_cnt[2 * w] + seg_cnt[2 * w + 1];  // EventFrame::eventsNum()
-        const bool ok = ECAL_WIN_STATUS(win_info[4 * w + 3]) == 0 && found[w];     // extractFeatures() == true
-        if (lane == 0) {
+        uint32_t cnt, okw;
+        if (!on_side) {
+            cnt = (uint32_t) __shfl((int) pre_cnt, (int) pos, 64);
+            okw = (uint32_t) __shfl((int) pre_ok, (int) pos, 64);
+        } else {   // (a side chain's windows: read where they are)
+            cnt = seg_cnt[2 * w] + seg_cnt[2 * w + 1];
+            okw = (ECAL_WIN_STATUS(win_info[4 * w + 3]) == 0 && found[w]) ? 1u : 0u;
+        }
+        bool accepted = false;
+        if (okw) {
             const double *dir = dirs + 2 * (size_t) w * rows;   // [rows][2]
-            bool accepted = false;
-            if (ok) {
-                const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
-                const int32_t *ord = order + (size_t) w * M;
-                const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
-                accepted = true;
-                if (st.have_ref[k])   // EventCalibIni::track: median row angle / time distance
-                    accepted = gate_accepts(st.ref_dir + (size_t) k * rows * 2, st.ref_t[k], dir, t_mid, rows, mts);
-                if (accepted) {
-                    const uint32_t at = atomicAdd(&st.counters[1], 1u);
-                    if (at < max_keys) {
+            const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
+            const int32_t *ord = order + (size_t) w * M;
+            const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
+            accepted = true;
+            if (have_ref)   // EventCalibIni::track: median row angle / time distance
+                accepted = gate_accepts(st.ref_dir + (size_t) k * rows * 2, st.ref_t[k], dir, t_mid, rows, mts);
+            if (accepted) {
+                uint32_t at = 0;
+                if (lane == 0) at = atomicAdd(&st.counters[1], 1u);
+                at = (uint32_t) __shfl((int) at, 0, 64);
+                if (at < max_keys) {
+                    if (lane == 0) {
                         kf_time[at] = t_mid;
                         kf_dur[2 * at] = f;
                         kf_dur[2 * at + 1] = s2;
                         kf_events[at] = (int32_t) cnt;
                         kf_piece[at] = k;
                         kf_gen[at] = st.gen[k];
-                        for (uint32_t c = 0; c < M; c++) {
-                            kf_feat[3 * ((size_t) at * M + c)] = xyr[3 * (size_t) ord[c]];
-                            kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[3 * (size_t) ord[c] + 1];
-                            kf_feat[3 * ((size_t) at * M + c) + 2] = xyr[3 * (size_t) ord[c] + 2];
-                        }
                     }
-                    st.have_ref[k] = 1;
-                    st.ref_t[k] = t_mid;
-                    double *rd = st.ref_dir + (size_t) k * rows * 2;
-                    for (uint32_t i = 0; i < 2 * rows; i++) rd[i] = dir[i];
-                    if (st.nacc[k] == 0) {   // the piece's first acceptance: what the shared-map verification looks at
-                        st.facc_t[k] = t_mid;
-                        for (uint32_t i = 0; i < 2 * rows; i++) st.facc_dir[(size_t) k * rows * 2 + i] = dir[i];
+                    for (uint32_t c = lane; c < M; c += 64) {
+                        kf_feat[3 * ((size_t) at * M + c)] = xyr[3 * (size_t) ord[c]];
+                        kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[3 * (size_t) ord[c] + 1];
+                        kf_feat[3 * ((size_t) at * M + c) + 2] = xyr[3 * (size_t) ord[c] + 2];
                     }
-                    st.nacc[k]++;
-                } else if (st.nacc[k] == 0) {   // a success rejected before the first acceptance
-                    const uint32_t r = st.nrej[k];
-                    if (r < AD_NREJ) {
-                        st.rej_t[(size_t) k * AD_NREJ + r] = t_mid;
-                        for (uint32_t i = 0; i < 2 * rows; i++) st.rej_dir[((size_t) k * AD_NREJ + r) * rows * 2 + i] = dir[i];
-                    }
-                    st.nrej[k] = r + 1;
                 }
+                // the new reference frame (and, for the piece's first acceptance, what the shared-map verification looks at):
+                // every lane has read the old frame in gate_accepts above — the wave's loads are complete before its stores
+                // are issued (the values went into the gate's arithmetic)
+                double *rd = st.ref_dir + (size_t) k * rows * 2;
+                for (uint32_t i = lane; i < 2 * rows; i += 64) {
+                    const double v = dir[i];
+                    rd[i] = v;
+                    if (nacc == 0) st.facc_dir[(size_t) k * rows * 2 + i] = v;
+                }
+                if (lane == 0) {
+                    st.ref_t[k] = t_mid;
+                    if (nacc == 0) st.facc_t[k] = t_mid;
+                }
+                __threadfence_block();   // the next gate of this wave reads the frame back
+                have_ref = 1;
+                nacc++;
+            } else if (nacc == 0) {   // a success rejected before the first acceptance
+                if (nrej < AD_NREJ) {
+                    if (lane == 0) st.rej_t[(size_t) k * AD_NREJ + nrej] = t_mid;
+                    for (uint32_t i = lane; i < 2 * rows; i += 64) st.rej_dir[((size_t) k * AD_NREJ + nrej) * rows * 2 + i] = dir[i];
+                }
+                nrej++;
             }
-            const int o = accepted ? 0 : ((cnt > thr_events || (s2 - f) > 3 * ln) ? 1 : 2);
-            double nf, ns;
-            next_window(o, f, s2, mts, nf, ns);
-            sh_f = nf;
-            sh_s2 = ns;
-            sh_o = o;
-            sh_act = ns < st.bound_hi[k] ? 1 : 0;  // :50
-#ifdef ECAL_ADAPTIVE_STATS
-            if (o == 0) atomicAdd(&st.counters[4], 1u);
-            else if (o != likely_outcome(f, s2, mts)) atomicAdd(&st.counters[5], 1u);
-            else if (level + 1 == n_levels) atomicAdd(&st.counters[6], 1u);
-            if (!sh_act) atomicAdd(&st.counters[7], 1u);
-#endif
-            st.levels[k] = lev0 + level + 1u;
-            atomicAdd(st.windows, 1ull);
         }
-        __syncthreads();
-        act = sh_act != 0;
+        const int o = accepted ? 0 : ((cnt > thr_events || (s2 - f) > 3 * ln) ? 1 : 2);
+        const int likely = likely_outcome(f, s2, mts);
+        double nf, ns;
+        next_window(o, f, s2, mts, nf, ns);
+        f = nf;
+        s2 = ns;
+        act = ns < hi;  // :50
+#ifdef ECAL_ADAPTIVE_STATS
+        if (lane == 0) {
+            if (o == 0) atomicAdd(&st.counters[4], 1u);
+            else if (o != likely) atomicAdd(&st.counters[5], 1u);
+            else if (level + 1 == n_levels) atomicAdd(&st.counters[6], 1u);
+            if (!act) atomicAdd(&st.counters[7], 1u);
+        }
+#endif
+        levels_done++;
         if (!act) {
             held = false;
             break;
         }
-        if (sh_o == likely_outcome(f, s2, mts)) {   // the chain evaluated ahead holds the likely successor …
+        if (o == likely) {   // the chain evaluated ahead holds the likely successor …
             pos++;
             if (pos >= chain_len) {
                 held = !on_side;
@@ -602,8 +624,8 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
             w++;
             continue;
         }
-        if (sh_o == 0 && !on_side && pos >= side_from && pos < side_from + n_side) {   // … and, for n_side of the windows, what follows an acceptance
-            w = st.slot0[k] + D + (pos - side_from) * side_len;
+        if (o == 0 && !on_side && pos >= side_from && pos < side_from + n_side) {   // … and, for n_side of the windows, what follows an acceptance
+            w = slot0 + D + (pos - side_from) * side_len;
             on_side = true;
             pos = 0;
             chain_len = side_len;
@@ -613,13 +635,18 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         break;
     }
     if (lane != 0) return;
-    st.first[k] = sh_f;
-    st.second[k] = sh_s2;
+    st.have_ref[k] = have_ref;
+    st.nacc[k] = nacc;
+    st.nrej[k] = nrej;
+    st.levels[k] = lev0 + levels_done;
+    atomicAdd(st.windows, (unsigned long long) levels_done);
+    st.first[k] = f;
+    st.second[k] = s2;
     st.active[k] = act ? 1u : 0u;
     // a piece whose whole chain held asks for twice the length next time, one whose chain broke for the base length again (a
     // stretch without the pattern is hundreds of windows whose verdicts are all the likely one: it is the search's longest path)
     st.want[k] = held ? 2u * D : 0u;
-    if (act && st.levels[k] < max_levels) atomicAdd(&st.counters[0], 1u);   // pieces with windows still to go
+    if (act && lev0 + levels_done < max_levels) atomicAdd(&st.counters[0], 1u);   // pieces with windows still to go
 }
 
 }  // namespace

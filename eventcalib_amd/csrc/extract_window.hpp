@@ -267,16 +267,39 @@ __device__ __forceinline__ uint32_t ref_nth_member(const ST &st, uint32_t o, uin
 // members, more same-cluster hits than the wave's list slots hold, more than twelve pending subtrees, no exported tree — fails
 // the whole window, which then goes on the list as before (nothing is committed until every tied cluster is resolved).
 // Returns true (uniform) when every tied cluster's representative is now the reference's pick (REP_TIE cleared).
+// an array of <= 64 words in the lanes of ONE vector register of the wave (element i in lane off + i), for ref_nth_element: the
+// loops run wave-uniformly, an element access is a v_readlane / a select on the lane id instead of a trip to LDS
+struct LaneArr {
+    using value_type = uint32_t;
+    uint32_t *v;
+    uint32_t off;
+    struct Ref {
+        uint32_t *v;
+        uint32_t lane;
+        __device__ __forceinline__ operator uint32_t() const { return (uint32_t) __builtin_amdgcn_readlane((int) *v, (int) lane); }
+        __device__ __forceinline__ Ref &operator=(uint32_t x) {   // (a compare + select: v_writelane_b32 has no builtin)
+            *v = (threadIdx.x & 63u) == lane ? x : *v;
+            return *this;
+        }
+        __device__ __forceinline__ Ref &operator=(const Ref &o) { return *this = (uint32_t) o; }
+    };
+    __device__ __forceinline__ Ref operator[](int64_t i) const { return Ref{v, (uint32_t) __builtin_amdgcn_readfirstlane((int) (off + (uint32_t) i))}; }
+    __device__ __forceinline__ LaneArr operator+(uint32_t d) const { return LaneArr{v, off + d}; }
+};
+
+// tree_win: the tree words of the window's points (px_tree + the window's first slot: a staged window's two segments are
+// contiguous).  Read HERE, by the windows that need them (17 % on the benchmark stream): asking for them at the head of the
+// kernel with the points — so that a tied window need not go back to memory, ~15 us at this point — was measured: 0.560 ->
+// 0.549 ms for the stage at 0.15 GB more traffic per pass, every window paying for the third load; not kept.
 template <typename ST>
 __device__ __forceinline__ bool resolve_ties_inline(const ST &st, const uint32_t (&base)[2], const uint32_t (&kb)[2], const uint32_t (&n_pol)[2],
-                                                    const uint32_t (&nk)[2], uint32_t tied0, uint32_t tied1, const uint32_t *tree_g0,
-                                                    const uint32_t *tree_g1, int e2i, int prune, uint32_t *tree_lds, unsigned char *scratch,
+                                                    const uint32_t (&nk)[2], uint32_t tied0, uint32_t tied1, const uint32_t *tree_win,
+                                                    int e2i, int prune, uint32_t *tree_lds, unsigned char *scratch,
                                                     uint8_t *inv, uint32_t *fail_word) {
     constexpr uint32_t WS = 1408, LIST_OFF = 200, LIST_BYTES = WS - LIST_OFF, NIL = 0xFFFFu;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     unsigned char *const ws = scratch + wave * WS;
-    uint16_t *const a = reinterpret_cast<uint16_t *>(ws);            // [64] the members in Clusters[c]'s order (polarity-local pids)
-    uint8_t *const queue = ws + 128;                                 // [64] positions in the ascending-pid member list
+    uint8_t *const queue = ws + 128;                                 // [64] positions in the ascending-pid member list, in Clusters[c]'s order
     uint32_t *const inq = reinterpret_cast<uint32_t *>(ws + 192);    // [2] member is (or was) in the queue
     uint8_t *const lists = ws + LIST_OFF;
     if (tid == 0) *fail_word = 0;
@@ -284,17 +307,32 @@ __device__ __forceinline__ bool resolve_ties_inline(const ST &st, const uint32_t
         __syncthreads();   // the other polarity's tree is done with
         if (!(pol ? tied1 : tied0)) continue;
         const uint32_t o = base[pol];
-        const uint32_t *const tg = pol ? tree_g1 : tree_g0;   // (selects, not arrays indexed at run time: those would live in scratch memory)
-        for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) tree_lds[i] = tg[i];
+#ifdef ECAL_PHASE_PROF
+        const unsigned long long tie_t0__ = __builtin_readcyclecounter();
+#endif
+        for (uint32_t i = tid; i < n_pol[pol]; i += DET_T) tree_lds[i] = tree_win[o + i];   // (staged windows: base = {0, n_pol[0]})
         __syncthreads();
+#ifdef ECAL_PHASE_PROF
+        if (tid == 0) atomicAdd(&g_det_cycles[9], __builtin_readcyclecounter() - tie_t0__);
+#endif
         for (uint32_t k = wave; k < nk[pol]; k += DET_T / 64) {   // (uniform in the wave)
             const uint32_t rv = st.rep[kb[pol] + k];
             if (!(rv & ST::REP_TIE)) continue;
             const uint32_t m = st.ksize[kb[pol] + k], first = o + st.koff[kb[pol] + k];
-            if (m > 64u) {
+            if (m > 64u || !st.composite()) {   // (composite member words: key << IDXB | index, what the nth_element below orders)
                 if (lane == 0) *fail_word = 1;
                 continue;
             }
+#ifdef ECAL_PHASE_PROF
+            unsigned long long tie_t__ = __builtin_readcyclecounter();
+#define TIE_MARK(i) do { if (lane == 0) { const unsigned long long n__ = __builtin_readcyclecounter(); atomicAdd(&g_det_cycles[i], n__ - tie_t__); tie_t__ = n__; } } while (0)
+            if (lane == 0) {
+                atomicAdd(&g_det_cycles[13], 1ull);
+                atomicAdd(&g_det_cycles[14], (unsigned long long) m);
+            }
+#else
+#define TIE_MARK(i) do { } while (0)
+#endif
             const uint32_t slot = LIST_BYTES / m > 63u ? 63u : LIST_BYTES / m;
             const uint32_t p = lane < m ? st.sorted[first + lane] : 0u;
             if (lane < m) inv[p] = (uint8_t) lane;
@@ -303,6 +341,10 @@ __device__ __forceinline__ bool resolve_ties_inline(const ST &st, const uint32_t
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // ---- the members' range queries ----
+            // (a cluster of <= 16 members — most are: half an arc of a circle's edge — keeps a member's hits in ONE 64-bit register,
+            // four bits a hit, and runs the queue below on scalars: no list in LDS, no atomics)
+            const bool tiny = m <= 16u;
+            unsigned long long hl = 0;
             uint32_t cnt = 0;
             bool bad = false;
             if (lane < m) {
@@ -317,7 +359,8 @@ __device__ __forceinline__ bool resolve_ties_inline(const ST &st, const uint32_t
                         const int nx = (int) (short) (nw & 0xFFFFu), ny = ((int) nw) >> 16;
                         const int ddx = nx - qx, ddy = ny - qy;
                         if (ddx * ddx + ddy * ddy <= e2i && node != p && st.kept[o + node] == (int) k) {   // (regionQuery drops the query point, dbscan.h:218)
-                            if (cnt < slot) out[cnt] = inv[node];
+                            if (tiny) hl |= (unsigned long long) inv[node] << (4u * cnt);   // (at most 15 other members)
+                            else if (cnt < slot) out[cnt] = inv[node];
                             cnt++;
                         }
                         const int dx = dir ? (qy - ny) : (qx - nx);
@@ -343,14 +386,35 @@ __device__ __forceinline__ bool resolve_ties_inline(const ST &st, const uint32_t
                     node = e & 0x7FFFu;
                     dir = e >> 15;
                 }
-                bad = cnt > slot || sp > 12u;
+                bad = (!tiny && cnt > slot) || sp > 12u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            TIE_MARK(10);
             // ---- expandCluster's queue: a lane per hit of the popped member, the hits taken from the END of its list ----
             uint32_t head = 0, tail = 1;
             const bool any_bad = __any(bad);
-            while (!any_bad && head < tail) {
+            unsigned long long qv = 0;   // tiny: the queue, four bits a member (the seed, position 0, first)
+            if (tiny && !any_bad) {
+                uint32_t inqm = 1u;
+                while (head < tail) {
+                    const int q = __builtin_amdgcn_readfirstlane((int) ((qv >> (4u * head)) & 15u));
+                    head++;
+                    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) hl, q);
+                    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (hl >> 32), q);
+                    const unsigned long long hq = ((unsigned long long) hi << 32) | lo;
+                    const uint32_t mq = (uint32_t) __builtin_amdgcn_readlane((int) cnt, q);
+                    for (uint32_t t = mq; t-- > 0;) {   // the result list = the hits in REVERSE visiting order
+                        const uint32_t j = (uint32_t) (hq >> (4u * t)) & 15u;
+                        if (!((inqm >> j) & 1u)) {
+                            inqm |= 1u << j;
+                            qv |= (unsigned long long) j << (4u * tail);
+                            tail++;
+                        }
+                    }
+                }
+            }
+            while (!tiny && !any_bad && head < tail) {
                 const uint32_t q = reinterpret_cast<volatile uint8_t *>(queue)[head];
                 head++;
                 const uint32_t mq = (uint32_t) __shfl((int) cnt, (int) q, 64);
@@ -371,13 +435,21 @@ __device__ __forceinline__ bool resolve_ties_inline(const ST &st, const uint32_t
                 if (lane == 0) *fail_word = 1;
                 continue;
             }
-            if (lane < m) a[lane] = (uint16_t) st.sorted[first + queue[lane]];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                ecal::ref_nth_element(a, m, m / 2u, [&](uint16_t x, uint16_t y) { return st.key(o + x) < st.key(o + y); });
-                st.rep[kb[pol] + k] = (typename std::remove_reference<decltype(st.rep[0])>::type) (a[m / 2u] | ST::REP_TIE | ST::REP_BAD);   // resolved, not yet committed
+            TIE_MARK(11);
+            // the members in Clusters[c]'s order, one per lane, as key << IDXB | point index; libstdc++'s nth_element by the whole
+            // wave on that register (the comparison looks at the key alone: members of equal norm are equivalent, and which of
+            // them ends up in the middle is the library's data movement)
+            uint32_t aw = 0;
+            if (lane < m) {
+                const uint32_t pid = st.sorted[first + (tiny ? (uint32_t) (qv >> (4u * lane)) & 15u : (uint32_t) queue[lane])];
+                aw = st.member_word(o + pid, pid);
             }
+            ecal::ref_nth_element(LaneArr{&aw, 0u}, m, m / 2u, [](uint32_t x, uint32_t y) { return (x >> ST::IDXB) < (y >> ST::IDXB); });
+            const uint32_t pick = (uint32_t) __builtin_amdgcn_readlane((int) aw, (int) (m / 2u)) & ST::IDX_MASK;
+            if (lane == 0)
+                st.rep[kb[pol] + k] = (typename std::remove_reference<decltype(st.rep[0])>::type) (pick | ST::REP_TIE | ST::REP_BAD);   // resolved, not yet committed
+            TIE_MARK(12);
+#undef TIE_MARK
         }
     }
     __syncthreads();
@@ -396,7 +468,7 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
                                                const uint32_t (&nc_pol)[2], const DetectParams &prm, uint32_t *csize,
                                                typename ST::CIdx *newid, typename ST::CIdx *coff,
                                                unsigned long long *red, uint32_t *nk_sh, uint32_t *info,
-                                               uint32_t *cand_pair, double *cand_xyr, const uint32_t *tie_tree0, const uint32_t *tie_tree1,
+                                               uint32_t *cand_pair, double *cand_xyr, const uint32_t *tie_tree, const uint32_t *tie_flags,
                                                uint8_t *tie_inv) {
     const uint32_t tid = threadIdx.x;
     DET_T0();
@@ -517,9 +589,14 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         }
         bool resolved = false;
         if constexpr (ST::INT_PIXELS) {   // staged integer pixels: the tied clusters' member order worked out here (resolve_ties_inline)
-            if (window_tied && tie_inv && (!tied0 || tie_tree0) && (!tied1 || tie_tree1) && 8u * ST::MAXC >= 4u * DET_TIE_TREE_CAP)
-                resolved = resolve_ties_inline(st, base, kb, n_pol, nk, tied0, tied1, tie_tree0, tie_tree1, prm.tie_e2i, prm.tie_prune, csize,
-                                               reinterpret_cast<unsigned char *>(st.members), tie_inv, &nk_sh[2]);
+            if (window_tied && tie_inv && 8u * ST::MAXC >= 4u * DET_TIE_TREE_CAP) {
+                // the trees of the tied polarities must be at hand: segments of the pixel DBSCAN kernel's first pass, flagged with its call's number
+                const bool ok0 = !tied0 || (n_pol[0] <= DET_TIE_TREE_CAP && tie_flags[0] == prm.px_tree_epoch);
+                const bool ok1 = !tied1 || (n_pol[1] <= DET_TIE_TREE_CAP && tie_flags[1] == prm.px_tree_epoch);
+                if (ok0 && ok1)
+                    resolved = resolve_ties_inline(st, base, kb, n_pol, nk, tied0, tied1, tie_tree, prm.tie_e2i, prm.tie_prune, csize,
+                                                   reinterpret_cast<unsigned char *>(st.members), tie_inv, &nk_sh[2]);
+            }
         }
         for (int pol = 0; pol < 2; pol++)
             for (uint32_t k = tid; k < nk[pol]; k += DET_T) {
@@ -989,20 +1066,21 @@ __device__ __forceinline__ void extract_one(
         const uint32_t base[2] = {0u, n_pol[0]};
         const uint32_t kb[2] = {0u, MAXC};  // per-cluster arrays: one block of MAXC per polarity
         // TDET, first pass: the kd-trees of the window's two segments, where the pixel DBSCAN kernel exported them (resolve_ties_inline)
-        const uint32_t *tie_tree0 = nullptr, *tie_tree1 = nullptr;
+        // TDET, first pass: where the pixel DBSCAN kernel exported the kd-trees of the window's two segments (resolve_ties_inline)
         uint8_t *tie_inv = nullptr;
+        const uint32_t *tie_tree = nullptr, *tie_flags = nullptr;
         if constexpr (TDET && FIRST && !KNOWN) {
             if (prm.px_tree) {
                 tie_inv = smem + (LL::bytes > 3 * DET_MAXC * sizeof(uint32_t) ? LL::bytes : 3 * DET_MAXC * sizeof(uint32_t));   // (behind DET_LDS_BYTES: the launch adds DET_TIE_INV_BYTES)
-                if (n_pol[0] <= DET_TIE_TREE_CAP && prm.px_tree_flag[2 * s] == prm.px_tree_epoch) tie_tree0 = prm.px_tree + o_pol[0];
-                if (n_pol[1] <= DET_TIE_TREE_CAP && prm.px_tree_flag[2 * s + 1] == prm.px_tree_epoch) tie_tree1 = prm.px_tree + o_pol[1];
+                tie_tree = prm.px_tree + o_pol[0];
+                tie_flags = prm.px_tree_flag + 2 * (size_t) s;
             }
         }
         extract_window<FIT, ORD, TDET>(st, base, kb, n_pol, labels + o_pol[0], labels + o_pol[1], order ? order + o_pol[0] : nullptr,
                                        order ? order + o_pol[1] : nullptr, tie_list, tie_count, s, tie_mark ? tie_mark + o_pol[0] : nullptr,
                                        tie_mark ? tie_mark + o_pol[1] : nullptr, nc_pol, prm, csize,
                        reinterpret_cast<uint16_t *>(smem + LL::newid_off), reinterpret_cast<uint16_t *>(smem + LL::coff_off), red, nk_sh, info, cand_pair + 2 * (size_t) o_pol[0],
-                       cand_xyr + 3 * (size_t) o_pol[0], tie_tree0, tie_tree1, tie_inv);
+                       cand_xyr + 3 * (size_t) o_pol[0], tie_tree, tie_flags, tie_inv);
         __syncthreads();
 #ifdef ECAL_PHASE_PROF
         det_t__ = __builtin_readcyclecounter();

@@ -22,8 +22,14 @@
 
 namespace ecal {
 
-template <typename T, typename Less>
-ECAL_HD void ref_push_heap(T *first, int64_t hole, int64_t top, T value, Less less) {   // std::__push_heap
+// The array the routines work on: a pointer, or any accessor with operator[] (a reference-like proxy), operator+ (an offset
+// view) and value_type — the extraction's tie path keeps the members of a small cluster in the LANES of one vector register
+// and runs these loops wave-uniformly on v_readlane / v_writelane (extract_window.hpp, LaneArr).
+template <typename A> struct ref_arr_traits { using value_type = typename A::value_type; };
+template <typename T> struct ref_arr_traits<T *> { using value_type = T; };
+
+template <typename A, typename T, typename Less>
+ECAL_HD void ref_push_heap(A first, int64_t hole, int64_t top, T value, Less less) {   // std::__push_heap
     int64_t parent = (hole - 1) / 2;
     while (hole > top && less(first[parent], value)) {
         first[hole] = first[parent];
@@ -33,8 +39,8 @@ ECAL_HD void ref_push_heap(T *first, int64_t hole, int64_t top, T value, Less le
     first[hole] = value;
 }
 
-template <typename T, typename Less>
-ECAL_HD void ref_adjust_heap(T *first, int64_t hole, int64_t len, T value, Less less) {   // std::__adjust_heap
+template <typename A, typename T, typename Less>
+ECAL_HD void ref_adjust_heap(A first, int64_t hole, int64_t len, T value, Less less) {   // std::__adjust_heap
     const int64_t top = hole;
     int64_t second = hole;
     while (second < (len - 1) / 2) {
@@ -51,8 +57,9 @@ ECAL_HD void ref_adjust_heap(T *first, int64_t hole, int64_t len, T value, Less 
     ref_push_heap(first, hole, top, value, less);
 }
 
-template <typename T, typename Less>
-ECAL_HD void ref_heap_select(T *first, int64_t middle, int64_t last, Less less) {   // std::__heap_select(first, first + middle, first + last)
+template <typename A, typename Less>
+ECAL_HD void ref_heap_select(A first, int64_t middle, int64_t last, Less less) {   // std::__heap_select(first, first + middle, first + last)
+    using T = typename ref_arr_traits<A>::value_type;
     if (middle >= 2) {   // std::__make_heap(first, middle)
         for (int64_t parent = (middle - 2) / 2;; parent--) {
             const T value = first[parent];
@@ -69,8 +76,9 @@ ECAL_HD void ref_heap_select(T *first, int64_t middle, int64_t last, Less less) 
 }
 
 // std::nth_element(a, a + nth, a + m, less); nth < m
-template <typename T, typename Less>
-ECAL_HD void ref_nth_element(T *a, uint32_t m, uint32_t nth, Less less) {
+template <typename A, typename Less>
+ECAL_HD void ref_nth_element(A a, uint32_t m, uint32_t nth, Less less) {
+    using T = typename ref_arr_traits<A>::value_type;
     if (m == 0 || nth >= m) return;
     auto swp = [&](uint32_t i, uint32_t j) {
         const T t = a[i];

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstddef>
 #include <cmath>
+#include <thread>
 #include <vector>
 #include <algorithm>
 
@@ -392,6 +393,75 @@ double oracle_evaluate_mode(const double *intr, uint32_t n_cp, const double *q, 
         if (H) for (int i = 0; i < 33; i++) for (int j = 0; j < 33; j++) H[idx[i] * N + idx[j]] += J[i] * J[j];
     }
     return cost;
+}
+
+// The normal equations of a one-segment problem of ANY size, in the product's accumulation-buffer layout (the checker of the
+// GPU normal equations at benchmark size: oracle_evaluate_mode's dense H is (9 + 6 n_cp)^2 doubles).  acc[91 + 204 n_cp]:
+// [0] cost = sum rho / 2 | [1..9] g_intr | [10 + 9 i + j], j >= i: H_intr upper | per control point c at 91 + 204 c:
+// g_c[6] (rot 3, trans 3) | H_c,intr[6][9] | H_c,c+d[6][6] for d = 0..3 (d = 0: upper triangle only) — the sums Ceres'
+// normal-equation build forms from the autodiff rows (EventCalibSpline.cpp:196-247), here from the dual-number rows above.
+// n_threads workers over contiguous ranges of the residuals, each into its own buffer, added in thread order.
+void oracle_evaluate_arrow_mt(const double *intr, uint32_t n_cp, const double *q, const double *t, const double *knots,
+                              uint64_t M, const double *obs, const double *time, const uint32_t *lm_id, const double *landmarks,
+                              double radius, double huber_a, int mode, int n_threads, double *acc) {
+    const size_t HEAD = 91, PER = 204, N = HEAD + PER * (size_t) n_cp;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::vector<double>> part((size_t) n_threads);
+    auto work = [&](int w) {
+        std::vector<double> &a = part[(size_t) w];
+        a.assign(N, 0.0);
+        const uint64_t lo = M * (uint64_t) w / (uint64_t) n_threads, hi = M * (uint64_t) (w + 1) / (uint64_t) n_threads;
+        for (uint64_t m = lo; m < hi; m++) {
+            const double u = time[m];
+            const uint32_t span = oracle_find_span(knots, n_cp, u);
+            double b[4], J[33];
+            oracle_basis(knots, span, u, b);
+            const uint32_t c0 = span - 3;
+            double r = ((mode & 1) ? oracle_residual_so3_cam : oracle_residual_cam)(intr, q + 4 * (size_t) c0, t + 3 * (size_t) c0, b, obs + 2 * m,
+                                                                                    landmarks + 3 * (size_t) lm_id[m], radius, nullptr, J,
+                                                                                    (mode >> 1) & 1);
+            const double s = r * r, a2 = huber_a * huber_a;   // HuberLoss + Corrector, as oracle_evaluate_mode
+            double rho, scale;
+            if (s <= a2) {
+                rho = s;
+                scale = 1.0;
+            } else {
+                const double rt = std::sqrt(s);
+                rho = 2 * huber_a * rt - a2;
+                scale = std::sqrt(huber_a / rt);
+            }
+            a[0] += 0.5 * rho;
+            r *= scale;
+            for (int i = 0; i < 33; i++) J[i] *= scale;
+            for (int i = 0; i < 9; i++) {
+                a[1 + i] += J[i] * r;
+                for (int j = i; j < 9; j++) a[10 + 9 * i + j] += J[i] * J[j];
+            }
+            double v[4][6];   // the row's entries of control point c0 + j: rotation tangent, translation
+            for (int j = 0; j < 4; j++)
+                for (int k = 0; k < 3; k++) {
+                    v[j][k] = J[9 + 3 * j + k];
+                    v[j][3 + k] = J[21 + 3 * j + k];
+                }
+            for (int j = 0; j < 4; j++) {
+                double *rec = a.data() + HEAD + PER * (size_t) (c0 + j);
+                for (int k = 0; k < 6; k++) {
+                    rec[k] += v[j][k] * r;
+                    for (int i = 0; i < 9; i++) rec[6 + 9 * k + i] += v[j][k] * J[i];
+                }
+                for (int d = 0; j + d < 4; d++)
+                    for (int ka = 0; ka < 6; ka++)
+                        for (int kb = (d == 0 ? ka : 0); kb < 6; kb++) rec[60 + 36 * d + 6 * ka + kb] += v[j][ka] * v[j + d][kb];
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < n_threads; w++) th.emplace_back(work, w);
+    work(0);
+    for (auto &x : th) x.join();
+    std::fill(acc, acc + N, 0.0);
+    for (int w = 0; w < n_threads; w++)
+        for (size_t i = 0; i < N; i++) acc[i] += part[(size_t) w][i];
 }
 
 }  // extern "C"

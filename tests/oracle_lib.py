@@ -379,6 +379,33 @@ def solver_evaluate(problem, x, want_H=True):
     return cost, g, H
 
 
+def solver_evaluate_arrow(problem, x, n_threads=1):
+    """The normal equations of a one-segment problem of any size in the product's accumulation-buffer layout
+    (oracle_evaluate_arrow_mt: [0] cost | g_intr 9 | H_intr 81 (upper) | per control point 204: g 6, H_c,intr 54, H_c,c+d 4 x 36),
+    on n_threads host threads."""
+    L = lib()
+    L.oracle_evaluate_arrow_mt.argtypes = [_dp, ctypes.c_uint32, _dp, _dp, _dp, ctypes.c_uint64, _dp, _dp, _u32p, _dp,
+                                           ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, _dp]
+    L.oracle_evaluate_arrow_mt.restype = None
+    n_cp = int(problem["seg_cp_off"][-1])
+    assert len(problem["seg_cp_off"]) == 2, "one segment"
+    x = np.ascontiguousarray(x, np.float64)
+    intr = x[:9].copy()
+    q = x[9:9 + 4 * n_cp].copy()
+    t = x[9 + 4 * n_cp:].copy()
+    kn = np.ascontiguousarray(problem["knots"], np.float64)
+    obs = np.ascontiguousarray(problem["obs"], np.float64)
+    tm = np.ascontiguousarray(problem["time"], np.float64)
+    lm = np.ascontiguousarray(problem["lm_id"], np.uint32)
+    lms = np.ascontiguousarray(problem["landmarks"], np.float64)
+    acc = np.zeros(91 + 204 * n_cp)
+    L.oracle_evaluate_arrow_mt(_p(intr, _dp), n_cp, _p(q, _dp), _p(t, _dp), _p(kn, _dp), tm.shape[0], _p(obs, _dp), _p(tm, _dp),
+                               _p(lm, _u32p), _p(lms, _dp), float(problem["circle_radius"]), float(problem["huber_a"]),
+                               int(bool(problem.get("use_so3", False))) | (2 if problem.get("fisheye", False) else 0), int(n_threads),
+                               _p(acc, _dp))
+    return acc
+
+
 def inverse_radial(k4):
     L = lib()
     L.oracle_inverse_radial.argtypes = [_dp, _dp]

@@ -47,3 +47,44 @@ def test_product_residual_header_matches_oracle(tmp_path):
                            "-L" + O.ORACLE_DIR, "-loracle", "-Wl,-rpath," + O.ORACLE_DIR])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def _dense_from_acc(acc, n_cp):
+    """the accumulation-buffer layout (arrow_layout.hpp) back to cost, gradient and the dense symmetric matrix in the oracle's
+    tangent order [intr 9 | (rot 3, trans 3) per control point]"""
+    N = 9 + 6 * n_cp
+    g = np.zeros(N)
+    H = np.zeros((N, N))
+    g[:9] = acc[1:10]
+    for i in range(9):
+        for j in range(i, 9):
+            H[i, j] = H[j, i] = acc[10 + 9 * i + j]
+    for c in range(n_cp):
+        rec = acc[91 + 204 * c: 91 + 204 * (c + 1)]
+        g[9 + 6 * c: 15 + 6 * c] = rec[:6]
+        H[9 + 6 * c: 15 + 6 * c, :9] = rec[6:60].reshape(6, 9)
+        H[:9, 9 + 6 * c: 15 + 6 * c] = rec[6:60].reshape(6, 9).T
+        for d in range(4):
+            if c + d >= n_cp:
+                break
+            blk = rec[60 + 36 * d: 96 + 36 * d].reshape(6, 6)
+            if d == 0:
+                blk = np.triu(blk) + np.triu(blk, 1).T
+            H[9 + 6 * c: 15 + 6 * c, 9 + 6 * (c + d): 15 + 6 * (c + d)] = blk
+            H[9 + 6 * (c + d): 15 + 6 * (c + d), 9 + 6 * c: 15 + 6 * c] = blk.T
+    return acc[0], g, H
+
+
+def test_arrow_layout_evaluation_equals_the_dense_one():
+    """oracle_evaluate_arrow_mt (the checker of the GPU normal equations at benchmark size, any thread count) == the dense
+    oracle_evaluate_mode it restates in the accumulation buffer's layout: radial and fisheye camera, both rotation variants"""
+    rng = np.random.default_rng(5)
+    for kw in ({}, {"fisheye": True}, {"use_so3": True}):
+        prob, x = SV.make_problem(3000, n_cp=11, seed=7, pixel_noise=0.4, **kw)
+        y = SV.perturb(x, 11, rng, intr_rel=0.01, rot=0.004, trans=0.1)
+        cost, g, H = O.solver_evaluate(prob, y)
+        for threads in (1, 3, 8):
+            c2, g2, H2 = _dense_from_acc(O.solver_evaluate_arrow(prob, y, threads), 11)
+            assert abs(c2 - cost) <= 1e-12 * cost
+            assert np.abs(g2 - g).max() <= 1e-11 * np.abs(g).max()
+            assert np.abs(H2 - H).max() <= 1e-11 * np.abs(H).max()
