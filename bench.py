@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--profile", action="store_true",
                     help="roctx ranges around the library's stage entry points (ecal_set_profile_ranges): run under `rocprofv3 "
                          "--marker-trace --kernel-trace --stats -- python3 bench.py --profile ...`")
+    ap.add_argument("--device-solve", action="store_true",
+                    help="also time the LM solve with the linear algebra on the device (ECAL_SOLVER_DEVICE_LINEAR_SOLVE=1: the slower option)")
     ap.add_argument("--no-fixed-cost", action="store_true",
                     help="skip the pass_ms_fixed measurement (passes over S / 2 and S / 4 windows: under a profiler they would mix "
                          "smaller launches into the kernels' average durations)")
@@ -796,10 +798,25 @@ def cpp_chain(ev, n, rate, t_start, pieces, np):
                 return {"error": "make driver: " + (cc.stdout + cc.stderr)[-300:]}
         ev.cpu().numpy().tofile(os.path.join(tmp, "events.bin"))
         open(os.path.join(tmp, "settings.yaml"), "w").write(CHAIN_YAML % dict(start=t_start, pieces=pieces))
+        def throttled():
+            # the cgroup's CPU-quota statistics (v2: cpu.stat throttled_usec; v1: cpu/cpu.stat throttled_time in ns): a child that
+            # shares a throttled cgroup with this process's thread pools loses wall time that is not its own
+            for path, key, div in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e3), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e6),
+                                   ("/sys/fs/cgroup/cpu,cpuacct/cpu.stat", "throttled_time", 1e6)):
+                try:
+                    for ln in open(path):
+                        if ln.startswith(key):
+                            return float(ln.split()[1]) / div
+                except OSError:
+                    pass
+            return None
+        time.sleep(float(os.environ.get("ECAL_BENCH_CHAIN_SETTLE", "0.3")))   # (this process's worker pools go to sleep: OpenMP / BLAS threads spin for a while after their last region)
+        thr0 = throttled()
         t0 = time.perf_counter()
         out = subprocess.run([exe, os.path.join(tmp, "settings.yaml"), os.path.join(tmp, "events.bin"), tmp, "batch"],
                              capture_output=True, text=True, timeout=900)
         wall = time.perf_counter() - t0
+        thr1 = throttled()
         if out.returncode != 0:
             return {"error": (out.stdout + out.stderr)[-400:]}
         stages = {l.split()[1]: round(float(l.split()[2]), 4) for l in out.stdout.splitlines() if l.startswith("stage ")}
@@ -809,6 +826,8 @@ def cpp_chain(ev, n, rate, t_start, pieces, np):
         return {"process_wall_seconds": round(wall, 3), "stage_seconds": stages, "seconds_after_upload": round(after, 4),
                 "keyframes": int(lines[0].split()[1]), "refined_fx": float(ref[1]), "residuals": int(ref[11]),
                 "lm_iterations": int(ref[13]), "splines": int(ref[15]),
+                "cgroup_throttled_ms_during_the_run": None if thr0 is None or thr1 is None else round(thr1 - thr0, 1),
+                "load_average": [round(v, 1) for v in os.getloadavg()],
                 "note": "process start to exit incl. HIP runtime initialisation and EventContainer::loadFile (ecal_stream_create_from_file: 1.25 GB from a RAM-backed file, chunked reads overlapped with the upload)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -935,9 +954,11 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
         finally:
             del os.environ["ECAL_SOLVER_NO_STREAM"]
             ctx.reload_env()
-    # the same solve with the linear algebra on the device (arrow_device.hpp: whole iteration in HBM, one 64-byte read-back)
+    # the same solve with the linear algebra on the device (arrow_device.hpp: whole iteration in HBM, one 64-byte read-back): 2 x
+    # slower than the host path (its reduced system is a chain of sequential separator steps), kept in the library
+    # and its tests, out of the default line since round 5 (--device-solve puts it back)
     dev_solve = None
-    if world == 1:
+    if world == 1 and args.device_solve:
         os.environ["ECAL_SOLVER_DEVICE_LINEAR_SOLVE"] = "1"
         ctx.reload_env()      # (the library reads its switches once per context)
         try:

@@ -797,11 +797,15 @@ __global__ __launch_bounds__(PX_T, ECAL_PX2_WG) void dbscan_pixel_list_kernel(co
                                                                  uint32_t *__restrict__ todo_count,
                                                                  const uint32_t *__restrict__ in_list,
                                                                  const uint32_t *__restrict__ in_count,
-                                                                 const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt) {
+                                                                 const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt,
+                                                                 uint32_t *__restrict__ tree_out = nullptr, uint32_t *__restrict__ tree_flag = nullptr,
+                                                                 uint32_t tree_epoch = 0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
     const uint32_t count = *in_count;
     for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
-        px_segment<E2I, CAP>(px_smem, in_list[k], xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt);
+        // (the trees go out as the first pass's do: the exact extraction's second pass resolves its ties on them, extract_window.hpp)
+        px_segment<E2I, CAP>(px_smem, in_list[k], xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt,
+                             tree_out, tree_flag, tree_epoch);
         __syncthreads();
     }
 }

@@ -371,7 +371,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
             if (second_pass)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<16, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
-                                   (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt);
+                                   (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt, tree, tflag, ctx->px_tree_epoch);
         } else {
             hipLaunchKernelGGL((dbscan_pixel_kernel<0, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
@@ -379,7 +379,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
             if (second_pass)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<0, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
-                                   (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt);
+                                   (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt, tree, tflag, ctx->px_tree_epoch);
         }
         if (second_pass) {
             todo = list2;

@@ -589,13 +589,23 @@ __device__ __forceinline__ void extract_window(const ST &st, const uint32_t (&ba
         }
         bool resolved = false;
         if constexpr (ST::INT_PIXELS) {   // staged integer pixels: the tied clusters' member order worked out here (resolve_ties_inline)
-            if (window_tied && tie_inv && 8u * ST::MAXC >= 4u * DET_TIE_TREE_CAP) {
-                // the trees of the tied polarities must be at hand: segments of the pixel DBSCAN kernel's first pass, flagged with its call's number
-                const bool ok0 = !tied0 || (n_pol[0] <= DET_TIE_TREE_CAP && tie_flags[0] == prm.px_tree_epoch);
-                const bool ok1 = !tied1 || (n_pol[1] <= DET_TIE_TREE_CAP && tie_flags[1] == prm.px_tree_epoch);
-                if (ok0 && ok1)
-                    resolved = resolve_ties_inline(st, base, kb, n_pol, nk, tied0, tied1, tie_tree, prm.tie_e2i, prm.tie_prune, csize,
-                                                   reinterpret_cast<unsigned char *>(st.members), tie_inv, &nk_sh[2]);
+            if (window_tied && tie_tree) {
+                // First pass (<= 1408 points, 384 clusters): the tree goes where csize / newid / coff lay (768 words: the pixel DBSCAN
+                // kernel's first-pass segments), the members' positions behind the staging (DET_TIE_INV_BYTES, added by the launch).
+                // Second pass (<= 2816 points): the waves' scratch takes the first half of members[], the tree its second half
+                // (1408 words), the positions the place of csize — segments of up to 1408 points, whose trees the DBSCAN kernel's
+                // second pass exports.
+                constexpr bool FIRST_LAYOUT = ST::IDXB == 11u;   // (the 1408-point staging; the second pass's 2816 points take 12 index bits)
+                constexpr uint32_t TREE_CAP = FIRST_LAYOUT ? DET_TIE_TREE_CAP : 1408u;
+                static_assert(FIRST_LAYOUT ? 8u * ST::MAXC >= 4u * DET_TIE_TREE_CAP : 8u * ST::MAXC >= 1408u, "the tree / the positions fit where csize, newid and coff lay");
+                uint32_t *const tree_lds = FIRST_LAYOUT ? csize : st.members + 1408;
+                uint8_t *const inv = FIRST_LAYOUT ? tie_inv : reinterpret_cast<uint8_t *>(csize);
+                // the trees of the tied polarities must be at hand: flagged with the DBSCAN call's number
+                const bool ok0 = !tied0 || (n_pol[0] <= TREE_CAP && tie_flags[0] == prm.px_tree_epoch);
+                const bool ok1 = !tied1 || (n_pol[1] <= TREE_CAP && tie_flags[1] == prm.px_tree_epoch);
+                if (ok0 && ok1 && inv)
+                    resolved = resolve_ties_inline(st, base, kb, n_pol, nk, tied0, tied1, tie_tree, prm.tie_e2i, prm.tie_prune, tree_lds,
+                                                   reinterpret_cast<unsigned char *>(st.members), inv, &nk_sh[2]);
             }
         }
         for (int pol = 0; pol < 2; pol++)
@@ -1069,9 +1079,9 @@ __device__ __forceinline__ void extract_one(
         // TDET, first pass: where the pixel DBSCAN kernel exported the kd-trees of the window's two segments (resolve_ties_inline)
         uint8_t *tie_inv = nullptr;
         const uint32_t *tie_tree = nullptr, *tie_flags = nullptr;
-        if constexpr (TDET && FIRST && !KNOWN) {
+        if constexpr (TDET && !KNOWN) {
             if (prm.px_tree) {
-                tie_inv = smem + (LL::bytes > 3 * DET_MAXC * sizeof(uint32_t) ? LL::bytes : 3 * DET_MAXC * sizeof(uint32_t));   // (behind DET_LDS_BYTES: the launch adds DET_TIE_INV_BYTES)
+                if constexpr (FIRST) tie_inv = smem + (LL::bytes > 3 * DET_MAXC * sizeof(uint32_t) ? LL::bytes : 3 * DET_MAXC * sizeof(uint32_t));   // (behind DET_LDS_BYTES: the launch adds DET_TIE_INV_BYTES)
                 tie_tree = prm.px_tree + o_pol[0];
                 tie_flags = prm.px_tree_flag + 2 * (size_t) s;
             }

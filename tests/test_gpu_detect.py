@@ -376,7 +376,8 @@ def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, mo
     kd-trees, a wave per tied cluster) instead of leaving the window on a list for the member-order launches and a second
     extraction.  Same picks either way — every output array equal to the listed form's (ECAL_EXTRACT_NO_INLINE_TIES=1) and to the
     oracle's — and the list it leaves is (nearly) empty where the listed form's holds every tied window.  2 Mev/s: windows of
-    ~3000 events, segments beyond 768 points have no exported tree and stay on the list."""
+    ~3000 events — the second extraction pass, which resolves its ties the same way on the trees the DBSCAN kernel's second
+    pass exports (segments of up to 1408 points)."""
     ctx, _pipe, torch = env
     from eventcalib_amd.capi import sync_env
     from eventcalib_amd.pipeline import DetectPipeline
@@ -386,6 +387,7 @@ def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, mo
     ev = buf.cuda()
     S = len(t0)
     outs, counts = [], []
+    ctx.set_tail_mode("tiered")      # (every size tier launched: the lean form's one tail launch per stage exports no trees)
     for listed in (False, True):
         if listed:
             monkeypatch.setenv("ECAL_EXTRACT_NO_INLINE_TIES", "1")
@@ -404,6 +406,7 @@ def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, mo
             exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)      # == the oracle, window by window
     monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
     sync_env()
+    ctx.set_tail_mode("auto")
     a, b = outs
     off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
     assert np.array_equal(a["info"], b["info"])
@@ -419,4 +422,4 @@ def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, mo
     if rate == 1.0e6:
         assert counts[0] <= counts[1] // 10, counts             # ... the first pass leaves (nearly) none of them
     else:
-        assert counts[0] <= counts[1], counts
+        assert counts[0] <= counts[1] // 2, counts              # (second pass: segments of up to 1408 points, trees from the DBSCAN kernel's second pass)
