@@ -211,8 +211,12 @@ constexpr int AD_ALLOC_T = 1024;
 // of 24 take the search from 108 to 79 passes at 1270 pieces, but the passes of the tail grow by what they save — 0.151 against
 // 0.159 s at 1270 pieces, 0.153 / 0.156 at 4096, 0.289 / 0.271 at 254; eight other layouts within 3 % of that — so the default
 // is none, and the form stays behind the switch with its test.
-constexpr uint32_t AD_SIDE_DEFAULT = 0u;
+constexpr uint32_t AD_SIDE_NONE = 0u;
 constexpr uint32_t AD_SIDE_MEASURED = 0u | (24u << 8) | (12u << 16) | (24u << 24);
+// Round 5: with the passes cheaper (ties resolved inside the extraction passes, the step kernel's chain walk on registers) the
+// saved passes now outweigh the wider ones — shared-map gate 0.145 -> 0.138 s at 1270 pieces, 0.148 -> 0.137 s at 4096 — and the
+// measured layout is the default (ECAL_ADAPTIVE_SIDE=0: none).
+constexpr uint32_t AD_SIDE_DEFAULT = AD_SIDE_MEASURED;
 // report (pinned host memory, may be NULL) + seq: the pass that ends with this launch tells the host how it went — pieces still
 // active, keyframe records so far, capacity overflow, and LAST the pass's number, which the host polls for (a copy engine
 // transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
@@ -844,7 +848,10 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // on the own-piece search against the same share for every piece at work (ECAL_ADAPTIVE_DEAL_UNIFORM=1): 0.059 / 0.065 s at
     // 1270 pieces, 0.043 / 0.044 at 4096, 0.139 / 0.156 at 254; the set-by-set form of the shared-map gate keeps the uniform deal
     const bool deal_by_piece = live || (!shared && !ctx->sw.adaptive_deal_uniform);
-    const uint32_t live_side = ctx->sw.adaptive_side == 1 ? AD_SIDE_MEASURED : (ctx->sw.adaptive_side > 1 ? (uint32_t) ctx->sw.adaptive_side : AD_SIDE_DEFAULT);   // (ECAL_ADAPTIVE_SIDE: from | count << 8 | length << 16 | main << 24; 1 = the measured layout)
+    const uint32_t live_side = ctx->sw.adaptive_side < 0 ? AD_SIDE_DEFAULT : (ctx->sw.adaptive_side == 0 ? AD_SIDE_NONE : (ctx->sw.adaptive_side == 1 ? AD_SIDE_MEASURED : (uint32_t) ctx->sw.adaptive_side));   // (ECAL_ADAPTIVE_SIDE: from | count << 8 | length << 16 | main << 24; 1 = the measured layout, 0 = none, unset = the default)
+    // (side chains hang behind a main chain of (live_side >> 24) windows: a search whose chains are capped below that — the debug
+    // switch ECAL_ADAPTIVE_DEPTH_MAX — runs without them)
+    const uint32_t live_side_eff = d_max >= (live_side >> 24) ? live_side : AD_SIDE_NONE;
     const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1024u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
     auto run_passes = [&]() -> int {
         // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
@@ -852,7 +859,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side);
+                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side_eff);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
@@ -908,7 +915,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
             }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side);
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side_eff);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));

@@ -146,14 +146,14 @@ def _same_keyframes(dev, ref):
         assert np.array_equal(dev[k], ref[k]), k
 
 
-def _in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_ROUNDS"):
+def _in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_ROUNDS", value="1"):
     """The shared-map search with the verification after every SET of runs (ECAL_ADAPTIVE_ROUNDS=1: the form before round 4's
-    pass-by-pass verification, kept behind the switch) or with side chains behind accepted windows (ECAL_ADAPTIVE_SIDE=1: measured,
-    not the default) — must give the same keyframes."""
+    pass-by-pass verification, kept behind the switch) or WITHOUT the side chains behind accepted windows (ECAL_ADAPTIVE_SIDE=0;
+    with them is the default since round 5) — must give the same keyframes."""
     import os
     import eventcalib_amd.capi as capi
     from eventcalib_amd.adaptive import detect_keyframes_device
-    os.environ[switch] = "1"
+    os.environ[switch] = value
     capi.sync_env()
     try:
         return detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
@@ -182,7 +182,8 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     assert len(ref["time"]) >= 20
     _same_keyframes(dev, ref)
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last), ref)
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE"), ref)   # side chains behind accepted windows
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="0"), ref)   # without the side chains behind accepted windows
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="1"), ref)   # the measured layout, named
     if pieces == 1:
         _same_keyframes(dev, own)              # one piece: the two modes are the same run
     _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last), own)

@@ -23,8 +23,8 @@ try:
         print("run %d: wall %.3f | %s" % (r, wall, st), flush=True)
         if out.returncode:
             print(out.stdout[-300:], out.stderr[-300:])
-        err = [l for l in out.stderr.splitlines() if "ecal" in l]
-        for l in err[:12]:
+        err = [l for l in out.stderr.splitlines() if "ecal" in l or "finish_stream" in l or "EventContainer" in l]
+        for l in err[:24]:
             print("   ", l)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
