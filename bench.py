@@ -134,6 +134,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.e2e_events > 0 and not os.environ.get("ECAL_BENCH_NO_CPP_CHAIN"):
+        # the C++ driver as a cold process on a GPU nobody else holds: before this process creates its HIP context
+        global _CPP_CHAIN_IDLE
+        try:
+            _CPP_CHAIN_IDLE = cpp_chain_on_an_idle_gpu(args.e2e_events, 1.0e6, 5.0, 5 * max(1, (os.cpu_count() or 3) - 2))
+        except Exception as e:      # (reported in the line; the legs below still run)
+            _CPP_CHAIN_IDLE = {"error": repr(e)[:300]}
     # test hooks (never set by the driver): run the N > 1 code paths on a one-GPU box
     backend = os.environ.get("ECAL_BENCH_BACKEND", "nccl")          # "gloo" stages collectives through the host
     if os.environ.get("ECAL_BENCH_SINGLE_DEVICE"):
@@ -710,7 +717,8 @@ def e2e_leg(args, ctx, dev, torch, np):
            "keyframe_search_seconds": round(rs["stage_seconds"]["keyframe_search"], 4),
            "refined_fx_rel_err": float(abs(rs["intrinsics"][0] / SS.FX - 1)), "lm_iterations": rs["spline"]["iterations"],
            "gate": "own piece (every piece's first success ungated: schedule-free, not what a run of the reference computes)"}
-    cpp = cpp_chain(ev, n, rate, t_start, pieces, np) if not os.environ.get("ECAL_BENCH_NO_CPP_CHAIN") else None
+    cpp_beside = cpp_chain(ev, n, rate, t_start, pieces, np) if not os.environ.get("ECAL_BENCH_NO_CPP_CHAIN") else None
+    cpp = _CPP_CHAIN_IDLE if _CPP_CHAIN_IDLE is not None else cpp_beside
     # configs[4]'s camera through the same chain: Kannala-Brandt stream, fisheye init calibration / PnP / rectify / spline residual
     del ev
     SS.TRAJECTORY, SS.CAMERA = "orbit", "fisheye"
@@ -735,7 +743,7 @@ def e2e_leg(args, ctx, dev, torch, np):
             "stage_seconds": {k: round(v, 4) for k, v in rf["stage_seconds"].items()},
             "note": "Kannala-Brandt stream (k = 0.05, -0.01, 0.002, 0); fisheye model in the init calibration (started from the radial "
                     "model's focal length), PnP, rectifyFeatures' projections and the spline residual (new functionality)"}
-    return {"cpp_chain": cpp, "fisheye": fish, "own_piece_gate": own, "gate": "shared map, single worker (TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36): the front ends' default", "events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
+    return {"cpp_chain": cpp, "cpp_chain_beside_this_process": cpp_beside, "fisheye": fish, "own_piece_gate": own, "gate": "shared map, single worker (TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36): the front ends' default", "events": n, "keyframes": r["keyframes"], "init_fx_rel_err": float(abs(r["init"]["intr"][0] / SS.FX - 1)),
             "residuals_from_association": sp["residuals"], "unknowns": sp["unknowns"], "splines": sp["splines"],
             "lm_iterations": sp["iterations"], "lm_seconds": round(sp["seconds"], 4),
             "lm_iterations_per_s": round(sp["iterations"] / max(sp["seconds"], 1e-9), 2),
@@ -779,56 +787,109 @@ PieceNum: %(pieces)d
 """
 
 
-def cpp_chain(ev, n, rate, t_start, pieces, np):
-    """The drop-in itself: eventcalib_amd/unit_test_eventCameraCalib (host/event_camera_calib_main.cpp: the reference driver's main on the
-    C++ shims of eventcalib_amd/csrc/host, argv = settings.yaml events.bin saveDir as eventCameraCalib.cpp:105-110) run on the same
-    stream written as a .bin file; its own per-stage seconds.  The stream is a file here, so loading and uploading it are stages
-    of their own; `seconds_after_upload` is what compares with the Python chain's wall time."""
+def _run_driver(tmp, exe, note):
+    """One cold run of the C++ driver on tmp/events.bin + tmp/settings.yaml: wall seconds of the process, its own stage seconds."""
+    import subprocess
+
+    def throttled():
+        # the cgroup's CPU-quota statistics (v2: cpu.stat throttled_usec; v1: cpu/cpu.stat throttled_time in ns): a child that
+        # shares a throttled cgroup with this process's thread pools loses wall time that is not its own
+        for path, key, div in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e3), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e6),
+                               ("/sys/fs/cgroup/cpu,cpuacct/cpu.stat", "throttled_time", 1e6)):
+            try:
+                for ln in open(path):
+                    if ln.startswith(key):
+                        return float(ln.split()[1]) / div
+            except OSError:
+                pass
+        return None
+    thr0 = throttled()
+    t0 = time.perf_counter()
+    out = subprocess.run([exe, os.path.join(tmp, "settings.yaml"), os.path.join(tmp, "events.bin"), tmp, "batch"],
+                         capture_output=True, text=True, timeout=900)
+    wall = time.perf_counter() - t0
+    thr1 = throttled()
+    if out.returncode != 0:
+        return {"error": (out.stdout + out.stderr)[-400:]}
+    stages = {l.split()[1]: round(float(l.split()[2]), 4) for l in out.stdout.splitlines() if l.startswith("stage ")}
+    lines = [l for l in out.stdout.splitlines() if not l.startswith("stage ")]
+    ref = lines[2].split()
+    after = sum(v for k, v in stages.items() if k not in ("runtime_init", "load_file", "upload"))
+    return {"process_wall_seconds": round(wall, 3), "stage_seconds": stages, "seconds_after_upload": round(after, 4),
+            "keyframes": int(lines[0].split()[1]), "refined_fx": float(ref[1]), "residuals": int(ref[11]),
+            "lm_iterations": int(ref[13]), "splines": int(ref[15]),
+            "cgroup_throttled_ms_during_the_run": None if thr0 is None or thr1 is None else round(thr1 - thr0, 1),
+            "load_average": [round(v, 1) for v in os.getloadavg()], "note": note}
+
+
+def _driver_exe():
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    # the product's executable, built with the library (eventcalib_amd/csrc/Makefile, target `driver`)
+    exe = os.path.join(root, "eventcalib_amd", "unit_test_eventCameraCalib")
+    if not os.path.exists(exe):      # (it travels to the GPU box prebuilt, like libecal.so)
+        cc = subprocess.run(["make", "-s", "-C", os.path.join(root, "eventcalib_amd", "csrc"), "driver"], capture_output=True, text=True)
+        if cc.returncode != 0 or not os.path.exists(exe):
+            return None, "make driver: " + (cc.stdout + cc.stderr)[-300:]
+    return exe, None
+
+
+_CPP_CHAIN_IDLE = None
+
+
+def cpp_chain_on_an_idle_gpu(n, rate, t_start, pieces):
+    """The drop-in as a user runs it: eventcalib_amd/unit_test_eventCameraCalib (host/event_camera_calib_main.cpp: the reference
+    driver's main on the C++ shims, argv = settings.yaml events.bin saveDir as eventCameraCalib.cpp:105-110) as a cold process on a
+    GPU NO OTHER PROCESS HOLDS.  Called at the very start of this benchmark, before this process creates its own HIP context: the
+    stream file is written by a helper process that exits (the same generator, the same seed as the end-to-end leg's stream), then
+    the driver runs twice (the first run of a binary on a box also pays for its page faults).  Beside a process that keeps a
+    context with many queues alive — this benchmark, later — the driver's launch-bound stages take twice as long (the GPU's
+    scheduler shares the queues of both processes): that figure is reported too (cpp_chain_beside_this_process)."""
     import shutil
     import subprocess
     import tempfile
+    exe, err = _driver_exe()
+    if exe is None:
+        return {"error": err}
     root = os.path.dirname(os.path.abspath(__file__))
     tmp = tempfile.mkdtemp(prefix="ecal_chain_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)   # the stream: a RAM-backed file
     try:
-        # the product's executable, built with the library (eventcalib_amd/csrc/Makefile, target `driver`)
-        exe = os.path.join(root, "eventcalib_amd", "unit_test_eventCameraCalib")
-        if not os.path.exists(exe):      # (it travels to the GPU box prebuilt, like libecal.so)
-            cc = subprocess.run(["make", "-s", "-C", os.path.join(root, "eventcalib_amd", "csrc"), "driver"], capture_output=True, text=True)
-            if cc.returncode != 0 or not os.path.exists(exe):
-                return {"error": "make driver: " + (cc.stdout + cc.stderr)[-300:]}
+        helper = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import synth_stream as SS; SS.TRAJECTORY = 'orbit'; "
+                  "ev = SS.make_stream(%d, rate=%r, t_start=%r, device='cuda', seed=21); ev.cpu().numpy().tofile(%r)"
+                  % (root, os.path.join(root, "tests"), n, rate, t_start, os.path.join(tmp, "events.bin")))
+        h = subprocess.run([sys.executable, "-c", helper], capture_output=True, text=True, timeout=900)
+        if h.returncode != 0:
+            return {"error": "stream helper: " + (h.stdout + h.stderr)[-300:]}
+        open(os.path.join(tmp, "settings.yaml"), "w").write(CHAIN_YAML % dict(start=t_start, pieces=pieces))
+        note = ("process start to exit incl. HIP runtime initialisation and EventContainer::loadFile (ecal_stream_create_from_file: "
+                "1.25 GB from a RAM-backed file, chunked reads overlapped with the upload); no other process on the GPU")
+        first = _run_driver(tmp, exe, note)
+        second = _run_driver(tmp, exe, note)
+        if "error" in first or "error" in second:
+            return first if "error" in first else second
+        best = dict(second)
+        best["first_run_on_this_box"] = {"process_wall_seconds": first["process_wall_seconds"], "stage_seconds": first["stage_seconds"]}
+        return best
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpp_chain(ev, n, rate, t_start, pieces, np):
+    """The same executable on the same stream while THIS process is alive with its HIP context, streams and worker pools (what
+    earlier rounds reported as the cold process): its own per-stage seconds.  The stream is a file here, so loading and uploading
+    it are stages of their own; `seconds_after_upload` is what compares with the Python chain's wall time."""
+    import shutil
+    import tempfile
+    exe, err = _driver_exe()
+    if exe is None:
+        return {"error": err}
+    tmp = tempfile.mkdtemp(prefix="ecal_chain_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)   # the stream: a RAM-backed file
+    try:
         ev.cpu().numpy().tofile(os.path.join(tmp, "events.bin"))
         open(os.path.join(tmp, "settings.yaml"), "w").write(CHAIN_YAML % dict(start=t_start, pieces=pieces))
-        def throttled():
-            # the cgroup's CPU-quota statistics (v2: cpu.stat throttled_usec; v1: cpu/cpu.stat throttled_time in ns): a child that
-            # shares a throttled cgroup with this process's thread pools loses wall time that is not its own
-            for path, key, div in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e3), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e6),
-                                   ("/sys/fs/cgroup/cpu,cpuacct/cpu.stat", "throttled_time", 1e6)):
-                try:
-                    for ln in open(path):
-                        if ln.startswith(key):
-                            return float(ln.split()[1]) / div
-                except OSError:
-                    pass
-            return None
         time.sleep(float(os.environ.get("ECAL_BENCH_CHAIN_SETTLE", "0.3")))   # (this process's worker pools go to sleep: OpenMP / BLAS threads spin for a while after their last region)
-        thr0 = throttled()
-        t0 = time.perf_counter()
-        out = subprocess.run([exe, os.path.join(tmp, "settings.yaml"), os.path.join(tmp, "events.bin"), tmp, "batch"],
-                             capture_output=True, text=True, timeout=900)
-        wall = time.perf_counter() - t0
-        thr1 = throttled()
-        if out.returncode != 0:
-            return {"error": (out.stdout + out.stderr)[-400:]}
-        stages = {l.split()[1]: round(float(l.split()[2]), 4) for l in out.stdout.splitlines() if l.startswith("stage ")}
-        lines = [l for l in out.stdout.splitlines() if not l.startswith("stage ")]
-        ref = lines[2].split()
-        after = sum(v for k, v in stages.items() if k not in ("runtime_init", "load_file", "upload"))
-        return {"process_wall_seconds": round(wall, 3), "stage_seconds": stages, "seconds_after_upload": round(after, 4),
-                "keyframes": int(lines[0].split()[1]), "refined_fx": float(ref[1]), "residuals": int(ref[11]),
-                "lm_iterations": int(ref[13]), "splines": int(ref[15]),
-                "cgroup_throttled_ms_during_the_run": None if thr0 is None or thr1 is None else round(thr1 - thr0, 1),
-                "load_average": [round(v, 1) for v in os.getloadavg()],
-                "note": "process start to exit incl. HIP runtime initialisation and EventContainer::loadFile (ecal_stream_create_from_file: 1.25 GB from a RAM-backed file, chunked reads overlapped with the upload)"}
+        return _run_driver(tmp, exe, "process start to exit, beside the benchmark process (which keeps its HIP context, streams and the "
+                                     "stream's 1.25 GB alive): the GPU's scheduler shares the queues of both processes")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -148,6 +148,7 @@ __device__ __forceinline__ void next_window(int o, double f, double s2, double m
 // of the finished pieces going to the others: 6 slots per piece and chains of <= 12: 533 / 922, <= 24: 592 / 943,
 // <= 48: 633 / 962, <= 64: 626 / 973; 4, 5, 8 slots per piece (<= 64, <= 48, <= 64): 559 / 1001, 582 / 1017, 541 / 823.
 constexpr uint32_t AD_DEPTH_MAX = 48;
+XX
 static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
     if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_DEPTH: debug / measurement switch; the result does not depend on it)
     return pieces <= 2048u ? 6u : (pieces <= 8192u ? 5u : (pieces <= 32768u ? 3u : 1u));   // (many pieces fill the GPU by themselves)
@@ -821,6 +822,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     for (int i = 0; i < 32; i++) ring[i] = 0;
     std::vector<uint32_t> trace_active;   // ECAL_ADAPTIVE_TRACE: pieces still at work after every pass
     uint32_t seq = 0;   // passes enqueued in this call (over all its sets of runs): the number a pass reports
+    uint32_t last_active = P;   // pieces at work after the last pass that has reported
     // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
     // takes a piece through up to D of them
     const uint32_t max_levels = ap->max_passes ? ap->max_passes : 0xFFFFFFFFu;
@@ -877,6 +879,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                     }
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
+                last_active = (uint32_t) ring[4 * q];
                 if (ctx->sw.adaptive_trace) trace_active.push_back((uint32_t) ring[4 * q]);
                 if (ring[4 * q + 3]) {
                     (void) hipStreamSynchronize(st);
@@ -899,8 +902,12 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                         (uint32_t *) B[10].ptr, Sr, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
                                         prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st));
-            AD_TRY(ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sr, prm->rows, prm->cols,
-                                       (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st));
+            // (few pieces still at work — known two passes late —: the grid finder's latency form, a wave per start, ecal_grid.hip)
+            ctx->grid_hint_windows = last_active <= (ctx->sw.adaptive_grid_pieces > 0 ? (uint32_t) ctx->sw.adaptive_grid_pieces : AD_GRID_LATENCY_PIECES) ? 1u : Sr;   // (ECAL_ADAPTIVE_GRID_PIECES: measurement switch)
+            rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sr, prm->rows, prm->cols,
+                                     (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st);
+            ctx->grid_hint_windows = 0;
+            AD_TRY(rc);
             hipLaunchKernelGGL(adaptive_dir_kernel, dim3(Sr), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
                                (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                                (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);

@@ -27,6 +27,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.adaptive_deal_uniform = on("ECAL_ADAPTIVE_DEAL_UNIFORM");
     sw.grid_debug = on("ECAL_GRID_DEBUG");
     sw.grid_serial_walk = on("ECAL_GRID_SERIAL_WALK");
+    sw.grid_one_wave = on("ECAL_GRID_ONE_WAVE");
     sw.solver_device_linear_solve = on("ECAL_SOLVER_DEVICE_LINEAR_SOLVE");
     sw.solver_trace = on("ECAL_SOLVER_TRACE");
     sw.solver_no_stream = on("ECAL_SOLVER_NO_STREAM");
@@ -34,6 +35,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
     sw.adaptive_depth_max = (int) num("ECAL_ADAPTIVE_DEPTH_MAX");
     sw.adaptive_live_floor = (int) num("ECAL_ADAPTIVE_LIVE_FLOOR");
+    sw.adaptive_grid_pieces = (int) num("ECAL_ADAPTIVE_GRID_PIECES");
     if (getenv("ECAL_ADAPTIVE_SIDE")) sw.adaptive_side = (int) num("ECAL_ADAPTIVE_SIDE");
     sw.arrow_k = (int) num("ECAL_ARROW_K");
     sw.bo_big_arena = (unsigned long long) num("ECAL_BO_BIG_ARENA");

@@ -25,8 +25,9 @@ struct ecal_switches {
     bool slice_no_pixel = false, slice_sort_kernel = false, slice_no_second_pass = false, bounds_two_kernels = false;
     bool dbscan_no_pixel = false, dbscan_no_second_pass = false, dbscan_generic_disc = false;
     bool extract_no_second_pass = false, extract_no_inline_ties = false, no_fused_pass = false, no_zero_ring = false;
+    bool grid_one_wave = false;
     bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, solver_two_roles = false;
-    int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_live_floor = 0, adaptive_side = -1, arrow_k = 0;   // 0: not set
+    int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_live_floor = 0, adaptive_side = -1, adaptive_grid_pieces = 0, arrow_k = 0;   // 0: not set
     unsigned long long bo_big_arena = 0;                            // 0: not set
     double grid_tol_px = 20.0;
 };
@@ -50,6 +51,7 @@ struct ecal_ctx {
     ecal_devbuf wb_status;  // ecal_window_bounds_dev: one word per workgroup of the look-back scan
     uint32_t wb_epoch = 0;  // ... and the number of the call that wrote it
     const uint32_t *tie_count_last = nullptr;   // the exact extraction's list counter of the last call (a zero-ring word or tie_list's own)
+    uint32_t grid_hint_windows = 0;   // ecal_grid_order_dev: windows that hold work in the next launch, by the caller's knowledge (0: the launch's size)
     hipStream_t wb_stream = nullptr;   // ... and the one stream whose calls use the table (others: the two-kernel form)
     bool wb_stream_set = false;
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers

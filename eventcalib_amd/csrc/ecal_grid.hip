@@ -24,6 +24,7 @@ constexpr int GR_T = 64;
 constexpr uint32_t GR_MAXC = 128;  // candidates per window handled
 constexpr int GR_L = 32;           // lattice coordinate window (u, v in [-16, 15])
 constexpr uint32_t GR_MAXM = 128;  // pattern points handled (rows * cols)
+constexpr uint32_t GR_PARALLEL_MAX = 1024;   // windows at work up to which the launch takes the latency form (a wave per start)
 
 // the changes of lattice basis the pattern is matched through: the four rotations, then the other integer matrices
 // (a b; c d) of determinant + 1 with entries in [-2, 2], in ascending order of (a + 2) + 5 (b + 2) + 25 (c + 2) + 125 (d + 2)
@@ -97,24 +98,49 @@ static __device__ unsigned long long g_gr_hist[32];   // [0..23]: windows by log
 #define GR_MARK(i)
 #endif
 
-__global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__restrict__ win_info,
+// NW = 1: one wave per window, the starts one after the other (the throughput form: a pass of thousands of windows).
+// NW = 4 (round 5): the LATENCY form for passes of few windows — the keyframe search's tail, where this kernel's time is the time
+// of its slowest window, one that goes through every start and fails (1.16 M cycles against 0.3 M for a window found at once).
+// The starts are independent of each other (every one wipes the previous walk; which seed a later start takes follows from the
+// basis searches of the earlier ones alone), so wave w runs start w with a working set of its own — replaying the earlier starts'
+// basis searches for its seed —, a start that finds the grid tells the later ones to stop, and the lowest successful start's
+// result is the window's: the same result as the sequential form (tests/test_gpu_grid.py runs the two against each other).
+template <int NW>
+__global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *__restrict__ win_info,
                                                           const uint32_t *__restrict__ seg_off,
                                                           const double *__restrict__ cand_xyr, uint32_t rows,
                                                           uint32_t cols, double tol_frac, double tol_px, int32_t *__restrict__ order,
                                                           uint32_t *__restrict__ found, int debug) {
-    __shared__ double px[GR_MAXC], py[GR_MAXC];
-    __shared__ double e1x[GR_MAXC], e1y[GR_MAXC], e2x[GR_MAXC], e2y[GR_MAXC];  // local lattice basis per node
-    __shared__ int8_t cu[GR_MAXC], cv[GR_MAXC];
-    __shared__ uint8_t assigned[GR_MAXC], queue[GR_MAXC];
-    __shared__ uint8_t occ[GR_L * GR_L];  // lattice cell -> candidate index + 1
-    __shared__ double hm[24];             // moment sums of the partial grid's homography fit (second attempt)
-    __shared__ double hh[8];
-    __shared__ uint32_t sh_qt;
-    __shared__ int sh_box[4];                       // box of the visited lattice cells (match_pattern)
-    __shared__ int8_t mU[GR_MAXM], mV[GR_MAXM];     // lattice coordinates of the model points relative to model point 0
-    __shared__ int8_t tf_sh[4 * GR_NTF];            // the table of basis changes
-    __shared__ uint8_t sel[GR_MAXM];                // the matched candidate of every model point
-    const uint32_t s = blockIdx.x, lane = threadIdx.x;
+    __shared__ double px_a[NW][GR_MAXC], py_a[NW][GR_MAXC];
+    __shared__ double e1x_a[NW][GR_MAXC], e1y_a[NW][GR_MAXC], e2x_a[NW][GR_MAXC], e2y_a[NW][GR_MAXC];  // local lattice basis per node
+    __shared__ int8_t cu_a[NW][GR_MAXC], cv_a[NW][GR_MAXC];
+    __shared__ uint8_t assigned_a[NW][GR_MAXC], queue_a[NW][GR_MAXC];
+    __shared__ uint8_t occ_a[NW][GR_L * GR_L];  // lattice cell -> candidate index + 1
+    __shared__ double hm_a[NW][24];             // moment sums of the partial grid's homography fit (second attempt)
+    __shared__ double hh_a[NW][8];
+    __shared__ uint32_t sh_qt_a[NW];
+    __shared__ int sh_box_a[NW][4];                       // box of the visited lattice cells (match_pattern)
+    __shared__ int8_t mU_a[NW][GR_MAXM], mV_a[NW][GR_MAXM];     // lattice coordinates of the model points relative to model point 0
+    __shared__ int8_t tf_sh_a[NW][4 * GR_NTF];            // the table of basis changes
+    __shared__ uint8_t sel_a[NW][GR_MAXM];                // the matched candidate of every model point
+    __shared__ uint32_t best_start_sh;                    // NW > 1: the lowest start that has found the grid (255: none yet)
+    const uint32_t s = blockIdx.x, lane = threadIdx.x & 63u, wv = NW > 1 ? threadIdx.x >> 6 : 0u;
+    double *const px = px_a[wv], *const py = py_a[wv], *const e1x = e1x_a[wv], *const e1y = e1y_a[wv], *const e2x = e2x_a[wv], *const e2y = e2y_a[wv];
+    int8_t *const cu = cu_a[wv], *const cv = cv_a[wv], *const mU = mU_a[wv], *const mV = mV_a[wv], *const tf_sh = tf_sh_a[wv];
+    uint8_t *const assigned = assigned_a[wv], *const queue = queue_a[wv], *const occ = occ_a[wv], *const sel = sel_a[wv];
+    double *const hm = hm_a[wv], *const hh = hh_a[wv];
+    uint32_t &sh_qt = sh_qt_a[wv];
+    int *const sh_box = sh_box_a[wv];
+    // (every wave works on arrays of its own: a wave-level barrier orders its LDS traffic; NW = 1 keeps the workgroup barrier)
+#define GR_SYNC()                                                        \
+    do {                                                                 \
+        if constexpr (NW == 1) {                                         \
+            __syncthreads();                                             \
+        } else {                                                         \
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");       \
+            __builtin_amdgcn_wave_barrier();                             \
+        }                                                                \
+    } while (0)
     const uint32_t n = win_info[4 * (size_t) s], M = rows * cols;
     int32_t *out = order + (size_t) s * M;
     for (uint32_t m = lane; m < M; m += GR_T) out[m] = -1;
@@ -134,7 +160,11 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         mV[m] = (int8_t) ((y - x) / 2);
     }
     for (uint32_t k = lane; k < 4u * GR_NTF; k += GR_T) tf_sh[k] = GR_TF[k / 4u][k % 4u];
-    __syncthreads();
+    if constexpr (NW > 1) {
+        if (threadIdx.x == 0) best_start_sh = 255u;
+        __syncthreads();   // (every wave of the window is here: the conditions of the returns above are the window's)
+    }
+    GR_SYNC();
 
     // The searches of the seed, the basis and the first walk run on REGISTERS: every row of 16 lanes holds all candidates
     // (candidate gl + 16 k in lane gl's k-th register, the four rows alike), so a row answers a nearest-candidate query with
@@ -325,7 +355,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             }
             hm[lane] = acc;
         }
-        __syncthreads();
+        GR_SYNC();
         // row r of the 8 x 9 system in lane r's registers.  S1(p, q) = sum of t_p t_q g for t = (u, v, 1)
         auto S = [&](uint32_t p, uint32_t q, uint32_t g) -> double {   // p, q in {0: u, 1: v, 2: 1}
             const uint32_t lo = p < q ? p : q, hi = p < q ? q : p;
@@ -395,17 +425,39 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
 #pragma unroll
             for (int c = 0; c < 8; c++) hh[c] = okh ? x[c] : NAN;
         }
-        __syncthreads();
+        GR_SYNC();
     };
     auto fit_all = [&]() __attribute__((always_inline)) { fit_h(); };
     int seed_at = 0;   // the next seed to look at
+    // NW > 1: this wave's start alone — after the basis searches of the starts before it, which say where its seed search
+    // begins (a start without a basis ends the sequence: then this wave has no start to run)
+    bool runnable = true;
+    if constexpr (NW > 1) {
+        if (wv > 0u && n <= M) runnable = false;
+        double t0_, t1_, t2_, t3_;
+        if (runnable && wv >= 2u) {   // start 1's seed search
+            bool have1 = false;
+            for (int q = 0; q < n_seeds && !have1; q++) {
+                have1 = choose_basis(seeds(q), 0, t0_, t1_, t2_, t3_);
+                seed_at = q + 1;
+            }
+            runnable = have1;
+        }
+        if (runnable && wv >= 3u) {   // start 2's
+            bool have2 = false;
+            while (seed_at < n_seeds && !have2) have2 = choose_basis(seeds(seed_at++), 1, t0_, t1_, t2_, t3_);
+            runnable = have2;
+        }
+    }
+    // a later start stops when an earlier one has found the grid (its result could not be the window's)
+#define GR_CANCELLED(start_) (NW > 1 && *reinterpret_cast<volatile uint32_t *>(&best_start_sh) < (uint32_t) (start_))
 #pragma nounroll
-    for (int start = 0; start <= GR_EXTRA && !got; start++) {
+    for (int start = (NW > 1 ? (int) wv : 0); start <= (NW > 1 ? (int) wv : GR_EXTRA) && !got && runnable; start++) {
     if (start > 0 && n <= M) break;   // (exactly the pattern's count of candidates: no clutter to have misled the first start)
     if (start > 0) {   // the previous start's walk is wiped
         for (uint32_t i = lane; i < n; i += GR_T) assigned[i] = 0;
         for (uint32_t k = lane; k < GR_L * GR_L; k += GR_T) occ[k] = 0;
-        __syncthreads();
+        GR_SYNC();
     }
     uint32_t seed = seeds(0);
     double ax = 0, ay = 0, bx = 0, by = 0;
@@ -445,10 +497,10 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         queue[0] = (uint8_t) seed;
     }
     qt = 1;
-    __syncthreads();
+    GR_SYNC();
     // a node's four directions at once, a row of lanes each; the candidates still free in `rfree` (this lane's)
     uint32_t rfree = rvalid & ~bit_of(seed);
-    while (qh < qt) {
+    while (qh < qt && !GR_CANCELLED(start)) {
         const uint32_t cur = queue[qh++];
         const int u0 = cu[cur], v0 = cv[cur];
         const double b1x = e1x[cur], b1y = e1y[cur], b2x = e2x[cur], b2y = e2y[cur];
@@ -536,9 +588,9 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         }
         }
         qt += n_new;
-        __syncthreads();
+        GR_SYNC();
     }
-    __syncthreads();
+    GR_SYNC();
     GR_MARK(1);   // first walk
     auto match_pattern = [&]() __attribute__((always_inline)) -> bool {
         if (qt < M) return false;
@@ -558,7 +610,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             sh_box[0] = sh_box[2] = 127;
             sh_box[1] = sh_box[3] = -128;
         }
-        __syncthreads();
+        GR_SYNC();
         for (uint32_t k = lane; k < qt; k += GR_T) {
             const uint32_t j = queue[k];
             atomicMin(&sh_box[0], (int) cu[j]);
@@ -566,11 +618,11 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             atomicMin(&sh_box[2], (int) cv[j]);
             atomicMax(&sh_box[3], (int) cv[j]);
         }
-        __syncthreads();
+        GR_SYNC();
         const int box_u = sh_box[1] - sh_box[0], box_v = sh_box[3] - sh_box[2];
         const uint32_t corner[3] = {cols - 1u, M - cols, M - 1u};
         uint32_t win_t = 0xFFFFFFFFu, win_anchor = 0;
-        for (uint32_t t = 0; t < GR_NTF && win_t == 0xFFFFFFFFu; t++) {   // (in order: the first match wins, rotations first)
+        for (uint32_t t = 0; t < GR_NTF && win_t == 0xFFFFFFFFu && !GR_CANCELLED(start); t++) {   // (in order: the first match wins, rotations first)
             const int a = tf_sh[4 * t], b = tf_sh[4 * t + 1], c = tf_sh[4 * t + 2], d = tf_sh[4 * t + 3];
             int ulo = 0, uhi = 0, vlo = 0, vhi = 0;   // (model point 0 sits at the anchor)
 #pragma unroll
@@ -608,7 +660,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             const int a = tf_sh[4 * win_t], b = tf_sh[4 * win_t + 1], c = tf_sh[4 * win_t + 2], d = tf_sh[4 * win_t + 3];
             for (uint32_t m = lane; m < M; m += GR_T) {
                 const int u = cu[win_anchor] + a * mU[m] + b * mV[m], v = cv[win_anchor] + c * mU[m] + d * mV[m];
-                out[m] = (int32_t) occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1;
+                if constexpr (NW == 1) out[m] = (int32_t) occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1;   // (NW > 1: the winning start's wave writes it)
                 sel[m] = (uint8_t) (occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)] - 1);
             }
         }
@@ -643,9 +695,9 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             }
             sh_qt = keep;
         }
-        __syncthreads();
+        GR_SYNC();
         qt = sh_qt;
-        for (int sweep = 0; sweep < 20 && !got && qt >= 4u; sweep++) {
+        for (int sweep = 0; sweep < 20 && !got && qt >= 4u && !GR_CANCELLED(start); sweep++) {
             GR_MARK(3);   // (restart, loop overhead)
 #ifdef ECAL_PHASE_PROF
             gr_sweeps__++;
@@ -666,7 +718,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                 sh_box[1] = sh_box[3] = -128;
             }
             for (uint32_t i = lane; i < n; i += GR_T) claim[i] = ~0ull;
-            __syncthreads();
+            GR_SYNC();
             for (uint32_t k = lane; k < qt; k += GR_T) {
                 const uint32_t j = queue[k];
                 atomicMin(&sh_box[0], (int) cu[j]);
@@ -674,7 +726,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                 atomicMin(&sh_box[2], (int) cv[j]);
                 atomicMax(&sh_box[3], (int) cv[j]);
             }
-            __syncthreads();
+            GR_SYNC();
             const int vlo = max(sh_box[2] - 1, -GR_L / 2), vhi = min(sh_box[3] + 1, GR_L / 2 - 1);
             auto visited = [&](int u, int v) -> uint32_t {   // candidate index + 1 of the cell, 0: open or outside
                 return (u < -GR_L / 2 || u >= GR_L / 2 || v < -GR_L / 2 || v >= GR_L / 2) ? 0u : occ[(v + GR_L / 2) * GR_L + (u + GR_L / 2)];
@@ -693,7 +745,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                 nf += (uint32_t) __popcll(m);
             }
             nf = nf < 512u ? nf : 512u;
-            __syncthreads();
+            GR_SYNC();
             for (uint32_t k0 = 0; k0 < nf; k0 += GR_T) {
                 const uint32_t k = k0 + lane;
                 const bool mine = k < nf;
@@ -724,7 +776,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                 // (distances order like their bit patterns; the low bits carry the cell: ties go to the earlier one)
                 const unsigned long long key = (((unsigned long long) __double_as_longlong(best)) & ~0x3FFull) | (unsigned long long) k;
                 if (want) atomicMin(&claim[bj], key);
-                __syncthreads();
+                GR_SYNC();
                 const bool won = want && claim[bj] == key;
                 const unsigned long long wm = __ballot(won);
                 if (won) {
@@ -736,7 +788,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
                     queue[at] = (uint8_t) bj;
                 }
                 qt += (uint32_t) __popcll(wm);
-                __syncthreads();
+                GR_SYNC();
             }
             GR_MARK(5);   // sweeps' searches
             if (qt == qt_before) break;
@@ -748,18 +800,29 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         }
     }
     if ((debug & 1) && !got && lane == 0) out[8 + start] = -2000 - (int32_t) qt;   // (ECAL_GRID_DEBUG: nodes placed by a start that failed)
+    if constexpr (NW > 1) {
+        if (got && lane == 0) atomicMin(&best_start_sh, (uint32_t) start);
+    }
     }   // (starts)
+#undef GR_CANCELLED
 #ifdef ECAL_PHASE_PROF
     gr_done__(qt);
 #endif
-    if (!got) return;
+    if constexpr (NW > 1) {
+        __syncthreads();   // every wave is through its start
+        const uint32_t win = best_start_sh;
+        if (win == 255u || wv != win) return;   // (the lowest successful start's wave goes on: its `got` is true, its arrays hold the grid)
+        for (uint32_t m = lane; m < M; m += GR_T) out[m] = (int32_t) sel[m];
+    } else {
+        if (!got) return;
+    }
     // The holes, as the reference takes them: CirclesEventFrame.cpp:340-353 looks up the candidate nearest to every centre the
     // finder returns, and the finder's centres under clutter are the keypoints nearest the positions its basis predicts.  Here:
     // the homography model lattice -> image through the 36 matched candidates, refitted without the six worst (a hole a spurious
     // candidate took during the walk — its step predictions drift, a spurious point can be the nearer one — is among them),
     // and every model point takes the candidate nearest to its prediction; twice.  Without clutter nothing changes.
     for (int it = 0; it < 2; it++) {
-        __syncthreads();
+        GR_SYNC();
         for (uint32_t m = lane; m < M; m += GR_T) {   // (the matched candidates are M different ones)
             const uint32_t j = sel[m];
             queue[m] = (uint8_t) j;
@@ -767,7 +830,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             cv[j] = mV[m];
         }
         qt = M;
-        __syncthreads();
+        GR_SYNC();
         fit_all();
         if (!(hh[0] == hh[0])) break;
         // residuals; the M - 6 best stay in the fit
@@ -778,7 +841,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             const double dx = (hh[0] * u + hh[1] * v + hh[2]) / wq - px[j], dy = (hh[3] * u + hh[4] * v + hh[5]) / wq - py[j];
             res[m] = dx * dx + dy * dy;
         }
-        __syncthreads();
+        GR_SYNC();
         {   // a lane per model point counts the worse ones; the kept ones go to the queue in model order
             uint32_t keep = 0;
             for (uint32_t m0 = 0; m0 < M; m0 += GR_T) {
@@ -793,7 +856,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             }
             qt = keep;
         }
-        __syncthreads();
+        GR_SYNC();
         fit_all();
         if (!(hh[0] == hh[0])) break;
         // nearest candidates to the predictions; taken only when they are M distinct candidates
@@ -810,7 +873,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
             }
             pick[m] = (uint8_t) (best & 0xFFu);
         }
-        __syncthreads();
+        GR_SYNC();
         for (uint32_t m = lane; m < M; m += GR_T)
             for (uint32_t q = 0; q < m; q++)
                 if (pick[q] == pick[m]) distinct = false;
@@ -824,6 +887,7 @@ __global__ __launch_bounds__(GR_T) void grid_order_kernel(const uint32_t *__rest
         if (__ballot(changed) == 0ull) break;
     }
     if (lane == 0) found[s] = 1;
+#undef GR_SYNC
 }
 
 }  // namespace ecal
@@ -842,8 +906,16 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     const double tol_px = ctx->sw.grid_tol_px;   // (ECAL_GRID_TOL_PX, a debug switch for tests of the tolerance's effect; default = the reference's 20 px)
-    hipLaunchKernelGGL(grid_order_kernel, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
-                       d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, (ctx->sw.grid_debug ? 1 : 0) | (ctx->sw.grid_serial_walk ? 2 : 0));
+    const int dbg = (ctx->sw.grid_debug ? 1 : 0) | (ctx->sw.grid_serial_walk ? 2 : 0);
+    // few windows at work (the caller's word, ecal_ctx::grid_hint_windows — the keyframe search knows how many pieces are still
+    // active —, else the launch's size): the latency form, a wave per start; ECAL_GRID_ONE_WAVE=1 keeps the one-wave form
+    const uint32_t at_work = ctx->grid_hint_windows ? ctx->grid_hint_windows : S;
+    if (at_work <= GR_PARALLEL_MAX && !ctx->sw.grid_one_wave && !ctx->sw.grid_debug)
+        hipLaunchKernelGGL(grid_order_kernel<4>, dim3(S), dim3(GR_T * 4), 0, (hipStream_t) stream, d_win_info, d_seg_off,
+                           d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, dbg);
+    else
+        hipLaunchKernelGGL(grid_order_kernel<1>, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
+                           d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, dbg);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

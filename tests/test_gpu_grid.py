@@ -397,3 +397,53 @@ def test_walk_four_directions_at_once_equals_one_after_the_other():
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     ctx.close()
+
+
+def test_a_wave_per_start_equals_the_starts_one_after_the_other():
+    """ecal_grid_order_dev takes its latency form for launches of few windows (round 5: a wave per start — the plain start, the
+    robust one and the two extra seeds side by side, the lowest successful start's result kept); ECAL_GRID_ONE_WAVE=1 keeps the
+    one-wave form, the starts one after the other.  Same verdicts and the same orders: on clean and cluttered patterns (where the
+    later starts are the ones that find the grid) and on the noise stream's own candidate sets."""
+    import torch
+    import eventcalib_amd
+    from eventcalib_amd.capi import sync_env
+    from eventcalib_amd.pipeline import DetectPipeline
+    ctx = eventcalib_amd.Context(0)
+    rng = np.random.default_rng(78)
+    views = list(_project_centres(torch, np.linspace(5.0, 9.0, 60))) + _tilted_views(torch, [20, 30, 40, 45, 50, 55, 60] * 12, seed=5)
+    cases = []
+    for gt in views:
+        p = gt + rng.normal(0, 0.7, size=(36, 2))
+        k = int(rng.integers(0, 27))
+        step = np.sort(np.linalg.norm(p[:, None] - p[None], axis=2) + 1e9 * np.eye(36), axis=1)[:, 0].min()
+        clutter = _inside_hull_points(rng, p, k, p, 0.25 * step, on_edge=k // 3) if k else np.zeros((0, 2))
+        allp = np.concatenate([p, clutter])
+        if rng.integers(0, 6) == 0:
+            allp = allp[rng.permutation(len(allp))[: max(30, len(allp) - int(rng.integers(1, 8)))]]   # some with circles missing: nothing to find
+        cases.append(allp[rng.permutation(len(allp))])
+    pipe = DetectPipeline(ctx)
+    n = 700_000                                            # 117 windows: a launch the latency form takes
+    buf = SS.make_stream(n, rate=4.0e6, device="cuda", seed=8, noise_frac=0.5)
+    t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 4.0e6)
+    pipe.set_windows(t0, t1)
+    pipe.run(buf)
+    out = {}
+    try:
+        for one_wave in (False, True):
+            if one_wave:
+                os.environ["ECAL_GRID_ONE_WAVE"] = "1"
+            else:
+                os.environ.pop("ECAL_GRID_ONE_WAVE", None)
+            sync_env()
+            o1, f1 = _run_grid(ctx, torch, cases)
+            o2, f2 = pipe.order_grid(9, 4)
+            torch.cuda.synchronize()
+            out[one_wave] = (np.array(o1), np.array(f1), o2.cpu().numpy().copy(), f2.cpu().numpy().copy())
+    finally:
+        os.environ.pop("ECAL_GRID_ONE_WAVE", None)
+        sync_env()
+    a, b = out[False], out[True]
+    assert int(a[1].sum()) > 60 and int((~a[1].astype(bool)).sum()) > 5 and int(a[3].sum()) > 20
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ctx.close()
