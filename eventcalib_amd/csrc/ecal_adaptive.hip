@@ -148,7 +148,10 @@ __device__ __forceinline__ void next_window(int o, double f, double s2, double m
 // of the finished pieces going to the others: 6 slots per piece and chains of <= 12: 533 / 922, <= 24: 592 / 943,
 // <= 48: 633 / 962, <= 64: 626 / 973; 4, 5, 8 slots per piece (<= 64, <= 48, <= 64): 559 / 1001, 582 / 1017, 541 / 823.
 constexpr uint32_t AD_DEPTH_MAX = 48;
-XX
+// pieces at work up to which a pass's grid finder runs in its latency form (a wave per start, ecal_grid.hip).  Measured, shared-map
+// gate, seconds at 1270 / 4096 pieces: never 0.137 / 0.132; 32: 0.133 / 0.133; 64: 0.133 / 0.135; 128: 0.132 / 0.130; 256: 0.131 /
+// 0.122; 512: 0.132 / 0.128
+constexpr uint32_t AD_GRID_LATENCY_PIECES = 256;
 static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
     if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_DEPTH: debug / measurement switch; the result does not depend on it)
     return pieces <= 2048u ? 6u : (pieces <= 8192u ? 5u : (pieces <= 32768u ? 3u : 1u));   // (many pieces fill the GPU by themselves)
