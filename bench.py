@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_EVENT = 29.0     # 25 B record read once + 4 B int32 label written once
-TRAFFIC_PROFILE = "r04_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
+TRAFFIC_PROFILE = "r05_traffic.json"   # tools/profile_round.sh: PMC passes of this same command
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 
 
@@ -474,8 +474,8 @@ def main():
     if pass_ms_fixed is not None:
         out["pass_ms_fixed"] = pass_ms_fixed
     if rank == 0:
-        # the dominant KERNEL: the extraction stage is three launches (plain pass, member order, listed windows again), of
-        # which the plain pass — timed alone below the stage — is the longest
+        # the dominant KERNEL: the extraction stage is its first pass (which resolves the ties of small clusters itself since round 5)
+        # + the launches of the listed path for what that leaves; the plain pass — timed alone below the stage — stands for it
         kernel_ms = [float(x) for x in stage_ms]
         if plain_extract_ms is not None:
             kernel_ms[3] = float(plain_extract_ms)

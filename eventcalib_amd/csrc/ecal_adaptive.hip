@@ -124,6 +124,45 @@ __device__ bool gate_accepts(const double *rd, double ref_t, const double *dir, 
     return theta[rows / 2u] / fabs(t_mid - ref_t) < (5e-4 * M_PI) / mts;
 }
 
+// The same test by a whole wave (adaptive_step_kernel): lane i computes row i's angle, the library's nth_element runs wave-uniformly
+// on the LANES of that register (an element access is two v_readlane / a select on the lane id) — the same operations on the same
+// values in the same order as gate_accepts, whose angle array lives in scratch memory (a trip to memory per access of the
+// selection: with a gate per grid-bearing window of a chain that was most of the step kernel's 100 us per pass).
+struct LaneArrF64 {
+    using value_type = double;
+    double *v;
+    uint32_t off;
+    struct Ref {
+        double *v;
+        uint32_t lane;
+        __device__ __forceinline__ operator double() const {
+            const unsigned long long b = (unsigned long long) __double_as_longlong(*v);
+            const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b, (int) lane);
+            const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (b >> 32), (int) lane);
+            return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+        }
+        __device__ __forceinline__ Ref &operator=(double x) {
+            *v = (threadIdx.x & 63u) == lane ? x : *v;
+            return *this;
+        }
+        __device__ __forceinline__ Ref &operator=(const Ref &o) { return *this = (double) o; }
+    };
+    __device__ __forceinline__ Ref operator[](int64_t i) const { return Ref{v, (uint32_t) __builtin_amdgcn_readfirstlane((int) (off + (uint32_t) i))}; }
+    __device__ __forceinline__ LaneArrF64 operator+(uint32_t d) const { return LaneArrF64{v, off + d}; }
+};
+__device__ __forceinline__ bool gate_accepts_wave(const double *rd, double ref_t, const double *dir, double t_mid, uint32_t rows, double mts) {
+    const uint32_t i = threadIdx.x & 63u;
+    double theta = 0.0;
+    if (i < rows) {
+        const double c = (rd[2 * i] * dir[2 * i] + rd[2 * i + 1] * dir[2 * i + 1]) /
+                         (sqrt(rd[2 * i] * rd[2 * i] + rd[2 * i + 1] * rd[2 * i + 1]) * sqrt(dir[2 * i] * dir[2 * i] + dir[2 * i + 1] * dir[2 * i + 1]));
+        theta = acos(c);
+    }
+    ecal::ref_nth_element(LaneArrF64{&theta, 0u}, rows, rows / 2u, [](double x, double y) { return x < y; });
+    const double med = (double) LaneArrF64{&theta, 0u}[rows / 2u];
+    return med / fabs(t_mid - ref_t) < (5e-4 * M_PI) / mts;
+}
+
 // The window that follows (f, s2) under outcome o of eventCameraCalib.cpp:61-62 (0: keyframe accepted), :67-69,75-77 (1: slide),
 // :70-71,78-79 (2: grow) — the ONE place these sums are written, so that a window evaluated ahead of time is bit for bit the
 // window the policy arrives at.
@@ -559,7 +598,7 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
             const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
             accepted = true;
             if (have_ref)   // EventCalibIni::track: median row angle / time distance
-                accepted = gate_accepts(st.ref_dir + (size_t) k * rows * 2, st.ref_t[k], dir, t_mid, rows, mts);
+                accepted = gate_accepts_wave(st.ref_dir + (size_t) k * rows * 2, st.ref_t[k], dir, t_mid, rows, mts);
             if (accepted) {
                 uint32_t at = 0;
                 if (lane == 0) at = atomicAdd(&st.counters[1], 1u);
