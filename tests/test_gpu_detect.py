@@ -423,3 +423,92 @@ def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, mo
         assert counts[0] <= counts[1] // 10, counts             # ... the first pass leaves (nearly) none of them
     else:
         assert counts[0] <= counts[1] // 2, counts              # (second pass: segments of up to 1408 points, trees from the DBSCAN kernel's second pass)
+
+
+@pytest.mark.parametrize("eps", [4.0, 3.0, 4.5])
+def test_tie_paths_by_cluster_size_against_the_oracle(env, eps, monkeypatch):
+    """The tie resolution inside the extraction pass by the size of the tied cluster: <= 16 members (hits in one register, queue
+    on scalars), 17 - 64 (lists in LDS, a lane per hit), beyond 64 (the window goes down the listed path) — windows of dense
+    blobs of 6 - 100 pixels centred on the diagonal x = y (a pixel and its mirror image share their norm: most medians are tied), at the shipped radius, a smaller
+    integral one and a non-integral one (no pruning quirk, other disc).  Representatives, pairs and circles == the oracle's
+    (the reference's nth_element over its BFS member order), == the listed form's."""
+    ctx, _pipe, torch = env
+    from eventcalib_amd.capi import sync_env
+    from eventcalib_amd.pipeline import DetectPipeline
+    rng = np.random.default_rng(int(eps * 10))
+    S, win = 48, 1.5e-3
+    ts, xs, ps = [], [], []
+    sizes = []
+    for s in range(S):
+        k = 0
+        pts = []
+        for pol in (0, 1):
+            n_blobs = int(rng.integers(4, 9))
+            for b in range(n_blobs):
+                # blob centres ON THE DIAGONAL x = y: a pixel (a, b) of a blob and its mirror (b, a) have the same norm, so the
+                # median rank of most clusters has an equal-norm rival; the two polarities' blobs alternate along it (they pair)
+                cx = cy = 20 + 30 * b + (14 if pol else 0)
+                m = int(rng.choice([6, 9, 12, 16, 20, 30, 45, 64, 70, 100]))
+                rad = 1.2 + 0.55 * np.sqrt(m)
+                cand = [(cx + dx, cy + dy) for dx in range(-12, 13) for dy in range(-12, 13) if dx * dx + dy * dy <= rad * rad]
+                rng.shuffle(cand)
+                for (x, y) in cand[:m]:
+                    pts.append((x, y, pol))
+                sizes.append(min(m, len(cand)))
+        rng.shuffle(pts)
+        t = 5.0 + s * win + np.sort(rng.uniform(0.0, win * 0.98, len(pts)))
+        ts.append(t)
+        xs.append(np.array([(p[0], p[1]) for p in pts], float))
+        ps.append(np.array([p[2] for p in pts], np.uint8))
+    t = torch.tensor(np.concatenate(ts))
+    xy = torch.tensor(np.concatenate(xs))
+    pol = torch.tensor(np.concatenate(ps))
+    buf = SS.pack_records(t, xy, pol)
+    t0 = 5.0 + win * np.arange(S)
+    t1 = np.nextafter(5.0 + win * np.arange(1, S + 1), -np.inf)
+    ev = buf.cuda()
+    n = t.shape[0]
+    cluster_min, need, thr = 5, 3, 40.0
+    outs, counts = [], []
+    ctx.set_tail_mode("tiered")
+    for listed in (False, True):
+        if listed:
+            monkeypatch.setenv("ECAL_EXTRACT_NO_INLINE_TIES", "1")
+        else:
+            monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+        sync_env()
+        pipe = DetectPipeline(ctx)
+        pipe.set_windows(t0, t1)
+        pipe.set_detect_params(cluster_min, need, thr)
+        pipe.run(ev, eps, 2)
+        torch.cuda.synchronize()
+        counts.append(_tie_list_count(ctx, torch))
+        outs.append({k: getattr(pipe, k)[:n].cpu().numpy().copy() for k in ("kept_labels", "rep", "cand_pair", "cand_xyr")})
+        outs[-1]["info"] = pipe.win_info[:S].cpu().numpy().copy()
+        if not listed:
+            info = outs[-1]["info"].astype(np.int64)
+            off = pipe.seg_off[:2 * S].cpu().numpy().astype(np.int64)
+            cnt = pipe.seg_cnt[:2 * S].cpu().numpy().astype(np.int64)
+            pxy = pipe.xy.cpu().numpy()
+            tied = big_tied = 0
+            for s in range(S):
+                op, on = off[2 * s], off[2 * s + 1]
+                ref = O.extract_candidates(pxy[op:op + cnt[2 * s]], pxy[on:on + cnt[2 * s + 1]], eps, 2, cluster_min, need, thr)
+                assert (info[s, 3] & 0xFF) == ref["status"] and (info[s, 3] & 0x100) == 0, s
+                if ref["status"]:
+                    continue
+                tied += int(ref["tie"])
+                assert np.array_equal(outs[-1]["rep"][op:op + ref["nk_pos"]], ref["rep_pos"]), "window %d rep +" % s
+                assert np.array_equal(outs[-1]["rep"][on:on + ref["nk_neg"]], ref["rep_neg"]), "window %d rep -" % s
+                assert info[s, 0] == ref["n"] and np.array_equal(outs[-1]["cand_pair"][op:op + ref["n"]], ref["pair"]), s
+                assert np.array_equal(outs[-1]["cand_xyr"][op:op + ref["n"]], ref["xyr"]), s
+    monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+    sync_env()
+    ctx.set_tail_mode("auto")
+    a, b = outs
+    for k in ("info", "rep", "cand_pair", "cand_xyr"):
+        if k == "info":
+            assert np.array_equal(a[k], b[k])
+    assert tied >= S // 2, tied                                   # most windows hold tied clusters ...
+    assert max(sizes) > 64 and min(sizes) <= 16                   # ... of every size class
+    assert 0 < counts[0] < counts[1], counts                      # windows with a tied cluster beyond 64 members stay on the list, the others do not
