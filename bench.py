@@ -97,7 +97,9 @@ def main():
                     help="events of the double-buffered ingest leg (configs[4]; host-resident stream; 0 = skip)")
     ap.add_argument("--calib-views", type=int, default=64,
                     help="views of the init calibration leg (configs[3]: 64 views sharded over the GPUs; 0 = skip)")
-    ap.add_argument("--calib-cpu-views", type=int, default=8, help="views timed on the numpy oracle (0 = skip)")
+    ap.add_argument("--calib-cpu-views", type=int, default=32,
+                    help="views timed on the numpy oracle (0 = skip); its dense (12 + 6V)^2 solve makes the time grow with V^2 - V^3: 32 views "
+                         "are ~10 - 15 s, all 64 would be ~45 s")
     ap.add_argument("--e2e-events", type=int, default=50_000_000,
                     help="events of the end-to-end leg: one stream with tilted views through keyframe search -> init calibration -> "
                          "rectify -> splines -> ecal_associate_dev -> the spline solve fed by THAT association (0 = skip)")
