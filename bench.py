@@ -1096,6 +1096,28 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
     solver.close()
     return out
 
+def host_threads_of_the_last_solve(ctx, solver, world, dist, torch, dev):
+    """Threads the solver's host half used on this rank in its last solve (its pool's workers + the calling thread:
+    ecal_debug_solver_last_solve), summed over the ranks, beside the CPUs the node's processes may use (affinity mask and cgroup
+    quota: ecal_debug_host_usable_cpus) — N ranks on one node must share that quota, not take hardware_concurrency() each."""
+    import ctypes
+    L = ctx._L
+    L.ecal_debug_solver_last_solve.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+    L.ecal_debug_host_usable_cpus.argtypes = [ctypes.POINTER(ctypes.c_int)]
+    how = (ctypes.c_uint32 * 8)()
+    ctx._check(L.ecal_debug_solver_last_solve(solver._h, how))
+    quota = ctypes.c_int(0)
+    per_rank = int(L.ecal_debug_host_usable_cpus(ctypes.byref(quota)))
+    mine = int(how[3]) + 1
+    total = mine
+    if world > 1:
+        tt = torch.tensor([float(mine)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        total = int(tt.item())
+    return {"this_rank": mine, "all_ranks": total, "node_cpu_quota": int(quota.value), "cpus_per_rank": per_rank,
+            "local_world_size": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))}
+
+
 def time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, duration, hook):
     """THE spline of configs[2] (n_cp control points over the stream's duration, n_res residuals — the same
     problem whatever the number of ranks) whose residuals are cut by time into one range per rank
@@ -1150,6 +1172,9 @@ def time_shard_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, du
            "allreduce_doubles": {"per_jacobian_evaluation": 91 + 612 * (world - 1), "per_linear_solve": 1082 * world, "per_step": 4,
                                  "once_at_the_end": int(9 + 7 * C)},
            "residuals_per_gpu_rank0": mine,
+           "evaluation": "plain (a rank owns ONE interior of the partition, factorised behind the separators' all-reduce: the streamed "
+                         "evaluation, which factorises under the kernel, is the single-rank path)",
+           "host_threads": host_threads_of_the_last_solve(ctx, solver, world, dist, torch, dev),
            "sharding": "ONE spline (the single-GPU problem), residuals cut by time at %d knots (3-control-point separators)" % (world - 1)}
     if os.environ.get("ECAL_BENCH_SOLVER_CHECK") and rank == 0:
         # test hook: the same problem in ONE solver, solved by rank 0 alone

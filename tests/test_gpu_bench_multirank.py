@@ -85,6 +85,11 @@ def test_two_ranks_match_one_rank():
     assert tc["iterations"][0] == tc["iterations"][1]
     assert tc["intrinsics_rel_diff"] < 1e-8 and tc["final_cost_rel_diff"] < 1e-9 and tc["control_points_abs_diff"] < 1e-6
     assert s2["allreduce_doubles"]["per_jacobian_evaluation"] == 91 + 612
+    # two ranks on one box share the CPUs the node's processes may use (affinity mask and cgroup quota over LOCAL_WORLD_SIZE): the
+    # solver's worker pools together stay within it — not hardware_concurrency() threads per rank
+    ht = s2["host_threads"]
+    assert ht["local_world_size"] == 2 and ht["cpus_per_rank"] == max(1, ht["node_cpu_quota"] // 2)
+    assert ht["all_ranks"] <= max(2, ht["node_cpu_quota"]) and ht["this_rank"] <= ht["cpus_per_rank"]
     # ... beside it, one spline segment per rank (weak): distributed segments (each rank factorises its own band, 91 / 101 + N /
     # 4 doubles exchanged) == one solver over both segments: same iterates up to the summation order
     wk = s2["weak_segments_per_rank"]
