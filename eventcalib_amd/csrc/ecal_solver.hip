@@ -413,8 +413,9 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
 }
 
 // The same evaluation with the two phases of a batch on DIFFERENT waves (quaternion variant, round 4; ECAL_SOLVER_TWO_ROLES=1 —
-// measured: 2.26 ms per launch in either form on the benchmark problem, so the one-role kernel stays the default: both are at
-// ~70 % of the FP64 issue slots the two phases need together, which is what the other kernels of this library reach too).  In normal_eq_kernel every
+// measured in round 5: 2.70 ms per launch against 2.32 – 2.37 ms for the one-role kernel on the benchmark problem — round 4's
+// "equal" timed this kernel twice, profiles/r05_notes.md item 12 — so the one-role kernel is the default; it runs at ~70 % of
+// the FP64 issue slots the two phases need together).  In normal_eq_kernel every
 // wave evaluates 64 residuals (phase 1: ~700 flop of dependent spline arithmetic each, 241 VGPRs), waits at a barrier, and then
 // accumulates its Gram tiles over the batch's rows (phase 2: 36 FMAs per six 16-byte LDS reads), with the tiles' 72 accumulator
 // registers alive through phase 1 and the other workgroup of the CU as the only thing that may overlap the one phase with the
@@ -1084,8 +1085,8 @@ static int solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_
         if (s->use_so3) {
             if (with_jacobian) ECAL_NE_LAUNCH2(true, true); else ECAL_NE_LAUNCH2(true, false);
         } else if (with_jacobian && ctx->sw.solver_two_roles) {
-            // ECAL_SOLVER_TWO_ROLES=1: producer / consumer waves (normal_eq_ws_kernel) — built for the round-3 review, measured equal
-            // (2.26 ms both forms on the benchmark problem), kept behind the switch with its parity test
+            // ECAL_SOLVER_TWO_ROLES=1: producer / consumer waves (normal_eq_ws_kernel) — built for the round-3 review, measured 15 % slower
+            // (2.70 against 2.35 ms on the benchmark problem), kept behind the switch with its parity test
             if (!s->ws_attr_set) {
                 ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_ws_kernel<false>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) NW_LDS_BYTES));

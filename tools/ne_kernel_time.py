@@ -16,7 +16,10 @@ st = torch.cuda.current_stream()
 d_x = torch.as_tensor(x, device="cuda"); d_acc = torch.empty(s.n_normal, dtype=torch.float64, device="cuda")
 for rnd in range(3):
     for mode in ("0", "1"):
-        os.environ["ECAL_SOLVER_TWO_ROLES"] = mode
+        if mode == "1":
+            os.environ["ECAL_SOLVER_TWO_ROLES"] = "1"   # the switch is "set or not set"
+        else:
+            os.environ.pop("ECAL_SOLVER_TWO_ROLES", None)
         ctx.reload_env()
         for _ in range(3):
             s.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
