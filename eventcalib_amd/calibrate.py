@@ -165,6 +165,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     # rectifyFeatures for all keyframes at once: their windows go through the detection pipeline again
     pipe.set_windows(kf["duration"][:, 0], kf["duration"][:, 1])
     pipe.run(events, eps, minpts)
+    mark("rectify_detection")
     prm = capi.RectifyParams()
     prm.fx, prm.fy, prm.cx, prm.cy = intr0[:4]
     for i in range(5):
