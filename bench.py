@@ -586,7 +586,9 @@ def main():
             out["policy_p2"] = []
             for pieces in runs:
                 nth = 2   # more host threads do not help: a pass is bound by the GPU-side chain of its largest window
-                detect_keyframes(pipe, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts, n_threads=nth)   # warm-up
+                # (warm-ups over the WHOLE stream: a context sizes its scratch buffers by the call, and on a box whose memory another
+                # process has just given back a first full-size call has been seen to spend 0.15 - 0.9 s in its allocations)
+                detect_keyframes(pipe, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, n_threads=nth)   # warm-up
                 torch.cuda.synchronize(dev)
                 tp = time.perf_counter()
                 kf = detect_keyframes(pipe, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts, n_threads=nth)
@@ -600,7 +602,7 @@ def main():
                                                  "bounds and one D2H of verdicts + ordered circles per pass)"})
                 # the same policy with the rule on the device (ecal_detect_keyframes): no per-pass host round trip
                 from eventcalib_amd import capi as _capi
-                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts,
+                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts,
                                         gate_mode=_capi.GATE_OWN_PIECE)   # warm-up
                 torch.cuda.synchronize(dev)
                 tp = time.perf_counter()
@@ -619,7 +621,7 @@ def main():
                 # ... and with the reference's own gate semantics: ONE keyframe map, single-worker order (ECAL_GATE_SHARED_MAP ==
                 # oracle/policy_oracle.cpp mode 1): speculation as above + verification rounds across the piece boundaries
                 from eventcalib_amd import capi as _capi
-                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, min(t_last, t_first + 1.0), eps, minpts,
+                detect_keyframes_device(ctx, events, 5e-4, 4000, pieces, t_first, t_last, eps, minpts,
                                         gate_mode=_capi.GATE_SHARED_MAP)   # warm-up, as the two timings above (first-call allocations)
                 torch.cuda.synchronize(dev)
                 tp = time.perf_counter()
