@@ -26,6 +26,7 @@
 //                         round, so the result is the sequential single-worker run's; on the benchmark stream a few rounds.
 #include "ecal_ctx.hpp"
 #include "ref_nth_element.hpp"
+#include "row_direction.hpp"
 
 #include <math.h>
 #include <atomic>
@@ -38,57 +39,7 @@ namespace {
 
 constexpr int AD_MAX_ROWS = 32;
 
-// direction (B, -A) of the total-least-squares line A x + B y + C = 0 through the row's circle centres: eigenvector of the
-// 3x3 Gram matrix of [x y 1] with the smallest eigenvalue (= the right singular vector of EventCalibIni.cpp:46-57), cyclic
-// Jacobi as in host/multi_process.hpp; oriented from the first to the last circle
-__device__ void row_direction(const double *xyr, const int32_t *order, uint32_t cols, double &dx_out, double &dy_out) {
-    double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (uint32_t j = 0; j < cols; j++) {
-        const double r[3] = {xyr[3 * (size_t) order[j]], xyr[3 * (size_t) order[j] + 1], 1.0};
-        for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) M[a][b] += r[a] * r[b];
-    }
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0;
-        for (int a = 0; a < 3; a++)
-            for (int b = a + 1; b < 3; b++) off += M[a][b] * M[a][b];
-        if (off < 1e-300) break;
-        for (int a = 0; a < 3; a++)
-            for (int b = a + 1; b < 3; b++) {
-                if (M[a][b] == 0.0) continue;
-                const double th = 0.5 * atan2(2 * M[a][b], M[b][b] - M[a][a]);
-                const double c = cos(th), s = sin(th);
-                for (int k = 0; k < 3; k++) {
-                    const double mka = M[k][a], mkb = M[k][b];
-                    M[k][a] = c * mka - s * mkb;
-                    M[k][b] = s * mka + c * mkb;
-                }
-                for (int k = 0; k < 3; k++) {
-                    const double mak = M[a][k], mbk = M[b][k];
-                    M[a][k] = c * mak - s * mbk;
-                    M[b][k] = s * mak + c * mbk;
-                }
-                for (int k = 0; k < 3; k++) {
-                    const double vka = V[k][a], vkb = V[k][b];
-                    V[k][a] = c * vka - s * vkb;
-                    V[k][b] = s * vka + c * vkb;
-                }
-            }
-    }
-    int m = 0;
-    for (int a = 1; a < 3; a++)
-        if (M[a][a] < M[m][m]) m = a;
-    double dx = V[1][m], dy = -V[0][m];
-    const double sx = xyr[3 * (size_t) order[cols - 1]] - xyr[3 * (size_t) order[0]];
-    const double sy = xyr[3 * (size_t) order[cols - 1] + 1] - xyr[3 * (size_t) order[0] + 1];
-    if (dx * sx + dy * sy < 0) {
-        dx = -dx;
-        dy = -dy;
-    }
-    dx_out = dx;
-    dy_out = dy;
-}
+using ecal::row_direction;   // (row_direction.hpp: shared with the grid finder's epilogue)
 
 constexpr uint32_t AD_NREJ = 4;   // successes rejected before a piece's first acceptance that are kept for the verification
 struct AdaptiveArrays {
@@ -150,12 +101,13 @@ struct LaneArrF64 {
     __device__ __forceinline__ Ref operator[](int64_t i) const { return Ref{v, (uint32_t) __builtin_amdgcn_readfirstlane((int) (off + (uint32_t) i))}; }
     __device__ __forceinline__ LaneArrF64 operator+(uint32_t d) const { return LaneArrF64{v, off + d}; }
 };
-__device__ __forceinline__ bool gate_accepts_wave(const double *rd, double ref_t, const double *dir, double t_mid, uint32_t rows, double mts) {
+// Both frames on registers: lane i holds row i of the reference frame (rx, ry) and of the window's (dx, dy); the same expression,
+// operand for operand, as gate_accepts.
+__device__ __forceinline__ bool gate_accepts_regs(double rx, double ry, double ref_t, double dx, double dy, double t_mid, uint32_t rows, double mts) {
     const uint32_t i = threadIdx.x & 63u;
     double theta = 0.0;
     if (i < rows) {
-        const double c = (rd[2 * i] * dir[2 * i] + rd[2 * i + 1] * dir[2 * i + 1]) /
-                         (sqrt(rd[2 * i] * rd[2 * i] + rd[2 * i + 1] * rd[2 * i + 1]) * sqrt(dir[2 * i] * dir[2 * i] + dir[2 * i + 1] * dir[2 * i + 1]));
+        const double c = (rx * dx + ry * dy) / (sqrt(rx * rx + ry * ry) * sqrt(dx * dx + dy * dy));
         theta = acos(c);
     }
     ecal::ref_nth_element(LaneArrF64{&theta, 0u}, rows, rows / 2u, [](double x, double y) { return x < y; });
@@ -580,6 +532,37 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         pre_ok = (ECAL_WIN_STATUS(win_info[4 * wl + 3]) == 0 && found[wl]) ? 1u : 0u;
     }
     uint32_t have_ref = st.have_ref[k], nacc = st.nacc[k], nrej = st.nrej[k];
+    // the reference frame on registers (lane i: row i) for the whole walk — it used to be read back from memory at every gate and
+    // written at every acceptance; the first AD_STEP_PF grid-bearing windows' line fits with it, in the same round trip
+    double rx = 0.0, ry = 0.0, ref_t = st.ref_t[k];
+    if (lane < rows) {
+        rx = st.ref_dir[(size_t) k * rows * 2 + 2 * lane];
+        ry = st.ref_dir[(size_t) k * rows * 2 + 2 * lane + 1];
+    }
+    constexpr int AD_STEP_PF = 4;
+    const unsigned long long okmask = __ballot(pre_ok != 0u);
+    double pfx[AD_STEP_PF], pfy[AD_STEP_PF];
+    {
+        unsigned long long m = okmask;
+#pragma unroll
+        for (int j = 0; j < AD_STEP_PF; j++) {
+            pfx[j] = pfy[j] = 0.0;
+            if (m) {
+                const uint32_t p = (uint32_t) __builtin_ctzll(m);
+                m &= m - 1ull;
+                if (lane < rows) {
+                    pfx[j] = dirs[2 * ((size_t) (slot0 + p) * rows + lane)];
+                    pfy[j] = dirs[2 * ((size_t) (slot0 + p) * rows + lane) + 1];
+                }
+            }
+        }
+    }
+    // the accepted windows of this walk: their keyframe records are written behind it, all at once (an atomic with a return
+    // value and two dependent reads per record were on the walk's path)
+    constexpr uint32_t ACC_CAP = 96;
+    __shared__ uint32_t acc_w[ACC_CAP], acc_cnt[ACC_CAP];
+    __shared__ double acc_f[ACC_CAP], acc_s[ACC_CAP];
+    uint32_t n_new = 0;
     uint32_t levels_done = 0;
     for (uint32_t level = 0; level < n_levels; level++) {
         uint32_t cnt, okw;
@@ -592,52 +575,51 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         }
         bool accepted = false;
         if (okw) {
-            const double *dir = dirs + 2 * (size_t) w * rows;   // [rows][2]
-            const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * w];
-            const int32_t *ord = order + (size_t) w * M;
+            double dx = 0.0, dy = 0.0;   // lane i: row i of this window's line fits
+            const uint32_t nth_ok = on_side ? (uint32_t) AD_STEP_PF : (uint32_t) __popcll(okmask & ((1ull << pos) - 1ull));
+            if (nth_ok < (uint32_t) AD_STEP_PF) {
+#pragma unroll
+                for (int j = 0; j < AD_STEP_PF; j++)
+                    if (nth_ok == (uint32_t) j) {
+                        dx = pfx[j];
+                        dy = pfy[j];
+                    }
+            } else if (lane < rows) {
+                dx = dirs[2 * ((size_t) w * rows + lane)];
+                dy = dirs[2 * ((size_t) w * rows + lane) + 1];
+            }
             const double t_mid = (f + s2) / 2;  // eventCameraCalib.cpp:58
             accepted = true;
             if (have_ref)   // EventCalibIni::track: median row angle / time distance
-                accepted = gate_accepts_wave(st.ref_dir + (size_t) k * rows * 2, st.ref_t[k], dir, t_mid, rows, mts);
+                accepted = gate_accepts_regs(rx, ry, ref_t, dx, dy, t_mid, rows, mts);
             if (accepted) {
-                uint32_t at = 0;
-                if (lane == 0) at = atomicAdd(&st.counters[1], 1u);
-                at = (uint32_t) __shfl((int) at, 0, 64);
-                if (at < max_keys) {
-                    if (lane == 0) {
-                        kf_time[at] = t_mid;
-                        kf_dur[2 * at] = f;
-                        kf_dur[2 * at + 1] = s2;
-                        kf_events[at] = (int32_t) cnt;
-                        kf_piece[at] = k;
-                        kf_gen[at] = st.gen[k];
-                    }
-                    for (uint32_t c = lane; c < M; c += 64) {
-                        kf_feat[3 * ((size_t) at * M + c)] = xyr[3 * (size_t) ord[c]];
-                        kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[3 * (size_t) ord[c] + 1];
-                        kf_feat[3 * ((size_t) at * M + c) + 2] = xyr[3 * (size_t) ord[c] + 2];
-                    }
-                }
-                // the new reference frame (and, for the piece's first acceptance, what the shared-map verification looks at):
-                // every lane has read the old frame in gate_accepts above — the wave's loads are complete before its stores
-                // are issued (the values went into the gate's arithmetic)
-                double *rd = st.ref_dir + (size_t) k * rows * 2;
-                for (uint32_t i = lane; i < 2 * rows; i += 64) {
-                    const double v = dir[i];
-                    rd[i] = v;
-                    if (nacc == 0) st.facc_dir[(size_t) k * rows * 2 + i] = v;
-                }
                 if (lane == 0) {
-                    st.ref_t[k] = t_mid;
-                    if (nacc == 0) st.facc_t[k] = t_mid;
+                    acc_w[n_new] = w;
+                    acc_cnt[n_new] = cnt;
+                    acc_f[n_new] = f;
+                    acc_s[n_new] = s2;
                 }
-                __threadfence_block();   // the next gate of this wave reads the frame back
+                n_new++;
+                // the new reference frame (and, for the piece's first acceptance, what the shared-map verification looks at)
+                rx = dx;
+                ry = dy;
+                ref_t = t_mid;
+                if (nacc == 0) {
+                    if (lane < rows) {
+                        st.facc_dir[(size_t) k * rows * 2 + 2 * lane] = dx;
+                        st.facc_dir[(size_t) k * rows * 2 + 2 * lane + 1] = dy;
+                    }
+                    if (lane == 0) st.facc_t[k] = t_mid;
+                }
                 have_ref = 1;
                 nacc++;
             } else if (nacc == 0) {   // a success rejected before the first acceptance
                 if (nrej < AD_NREJ) {
                     if (lane == 0) st.rej_t[(size_t) k * AD_NREJ + nrej] = t_mid;
-                    for (uint32_t i = lane; i < 2 * rows; i += 64) st.rej_dir[((size_t) k * AD_NREJ + nrej) * rows * 2 + i] = dir[i];
+                    if (lane < rows) {
+                        st.rej_dir[((size_t) k * AD_NREJ + nrej) * rows * 2 + 2 * lane] = dx;
+                        st.rej_dir[((size_t) k * AD_NREJ + nrej) * rows * 2 + 2 * lane + 1] = dy;
+                    }
                 }
                 nrej++;
             }
@@ -662,6 +644,10 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
             held = false;
             break;
         }
+        if (n_new == ACC_CAP) {   // (the list is full: the piece goes on from here in the next pass)
+            held = false;
+            break;
+        }
         if (o == likely) {   // the chain evaluated ahead holds the likely successor …
             pos++;
             if (pos >= chain_len) {
@@ -680,6 +666,43 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         }
         held = false;
         break;
+    }
+    if (n_new) {
+        // the frame the piece goes on with, and the walk's keyframe records: one reservation, the circles of all of them side by side
+        if (lane < rows) {
+            st.ref_dir[(size_t) k * rows * 2 + 2 * lane] = rx;
+            st.ref_dir[(size_t) k * rows * 2 + 2 * lane + 1] = ry;
+        }
+        uint32_t base = 0;
+        if (lane == 0) {
+            st.ref_t[k] = ref_t;
+            base = atomicAdd(&st.counters[1], n_new);
+        }
+        base = (uint32_t) __shfl((int) base, 0, 64);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (lane 0's list, read by the others)
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t gen = st.gen[k];
+        for (uint32_t a = lane; a < n_new; a += 64) {
+            const uint32_t at = base + a;
+            if (at < max_keys) {
+                kf_time[at] = (acc_f[a] + acc_s[a]) / 2;
+                kf_dur[2 * at] = acc_f[a];
+                kf_dur[2 * at + 1] = acc_s[a];
+                kf_events[at] = (int32_t) acc_cnt[a];
+                kf_piece[at] = k;
+                kf_gen[at] = gen;
+            }
+        }
+        for (uint32_t i = lane; i < n_new * M; i += 64) {
+            const uint32_t a = i / M, c = i - a * M, at = base + a;
+            if (at >= max_keys) continue;
+            const uint32_t wa = acc_w[a];
+            const double *xyr = cand_xyr + 3 * (size_t) seg_off[2 * wa];
+            const size_t src = 3 * (size_t) order[(size_t) wa * M + c];
+            kf_feat[3 * ((size_t) at * M + c)] = xyr[src];
+            kf_feat[3 * ((size_t) at * M + c) + 1] = xyr[src + 1];
+            kf_feat[3 * ((size_t) at * M + c) + 2] = xyr[src + 2];
+        }
     }
     if (lane != 0) return;
     st.have_ref[k] = have_ref;
@@ -946,13 +969,18 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st));
             // (few pieces still at work — known two passes late —: the grid finder's latency form, a wave per start, ecal_grid.hip)
             ctx->grid_hint_windows = last_active <= (ctx->sw.adaptive_grid_pieces > 0 ? (uint32_t) ctx->sw.adaptive_grid_pieces : AD_GRID_LATENCY_PIECES) ? 1u : Sr;   // (ECAL_ADAPTIVE_GRID_PIECES: measurement switch)
-            rc = ecal_grid_order_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sr, prm->rows, prm->cols,
-                                     (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st);
+            // (the rows' line fits of the windows that hold a grid: by the grid finder's own workgroups, under the launch's slowest
+            // failing window; ECAL_ADAPTIVE_DIR_KERNEL=1: by adaptive_dir_kernel behind it, the form up to round 5 — same values)
+            const bool dirs_in_grid = !ctx->sw.adaptive_dir_kernel && prm->rows <= 64;
+            rc = ecal_grid_order_dirs_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sr, prm->rows, prm->cols,
+                                          (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr,
+                                          dirs_in_grid ? (double *) ctx->adaptive_dirs.ptr : nullptr, st);
             ctx->grid_hint_windows = 0;
             AD_TRY(rc);
-            hipLaunchKernelGGL(adaptive_dir_kernel, dim3(Sr), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
-                               (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
-                               (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);
+            if (!dirs_in_grid)
+                hipLaunchKernelGGL(adaptive_dir_kernel, dim3(Sr), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
+                                   (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
+                                   (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);
             hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, max_levels,
                                (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const uint32_t *) B[7].ptr,
                                (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,

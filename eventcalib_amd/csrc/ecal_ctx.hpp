@@ -26,7 +26,7 @@ struct ecal_switches {
     bool dbscan_no_pixel = false, dbscan_no_second_pass = false, dbscan_generic_disc = false;
     bool extract_no_second_pass = false, extract_no_inline_ties = false, no_fused_pass = false, no_zero_ring = false;
     bool grid_one_wave = false;
-    bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, solver_two_roles = false;
+    bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, solver_two_roles = false, adaptive_dir_kernel = false;
     int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_live_floor = 0, adaptive_side = -1, adaptive_grid_pieces = 0, arrow_k = 0;   // 0: not set
     unsigned long long bo_big_arena = 0;                            // 0: not set
     double grid_tol_px = 20.0;
@@ -144,6 +144,9 @@ int ecal_cluster_order_sized(ecal_ctx *ctx, const double *d_xy, const uint32_t *
                              uint32_t *d_status, int only_tied_medians, const uint32_t *d_win_list, const uint32_t *d_win_count,
                              void *stream, const ecal_packed_points *pk = nullptr);
 // extraction as the context's ecal_set_median_ties setting wants it (ecal_detect.hip): the exact form needs the DBSCAN radius
+// ecal_grid_order_dev + the found grids' row directions (row_direction.hpp) into d_dirs[S][rows][2] (NULL: none)
+int ecal_grid_order_dirs_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off, const double *d_cand_xyr, uint32_t S,
+                             uint32_t rows, uint32_t cols, int32_t *d_order, uint32_t *d_found, double *d_dirs, void *stream);
 int ecal_extract_for_ctx(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_seg_off, const uint32_t *d_seg_cnt, const int32_t *d_labels,
                          const uint32_t *d_n_clusters, uint32_t S, uint32_t n_points, double eps, uint32_t cluster_min,
                          uint32_t need_clusters, double radius_threshold, int fit_circle, uint32_t knn_num, uint32_t *d_win_info,

@@ -15,6 +15,7 @@
 // One wave (64 lanes) per window: lanes share the nearest-candidate searches, lane-uniform control flow
 // does the breadth-first walk over the centred-square lattice (neighbours along the two diagonals).
 #include "ecal_ctx.hpp"
+#include "row_direction.hpp"
 
 #pragma clang fp contract(off)
 
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *_
                                                           const uint32_t *__restrict__ seg_off,
                                                           const double *__restrict__ cand_xyr, uint32_t rows,
                                                           uint32_t cols, double tol_frac, double tol_px, int32_t *__restrict__ order,
-                                                          uint32_t *__restrict__ found, int debug) {
+                                                          uint32_t *__restrict__ found, int debug,
+                                                          double *__restrict__ dirs /* [S][rows][2] or NULL: see the end */) {
     __shared__ double px_a[NW][GR_MAXC], py_a[NW][GR_MAXC];
     __shared__ double e1x_a[NW][GR_MAXC], e1y_a[NW][GR_MAXC], e2x_a[NW][GR_MAXC], e2y_a[NW][GR_MAXC];  // local lattice basis per node
     __shared__ int8_t cu_a[NW][GR_MAXC], cv_a[NW][GR_MAXC];
@@ -887,6 +889,18 @@ __global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *_
         if (__ballot(changed) == 0ull) break;
     }
     if (lane == 0) found[s] = 1;
+    // The keyframe search's next step — the rows' line fits of a window that holds a grid, the keyframe gate's input — here, by
+    // the wave that has the grid (a lane per row, the same routine on the same values as the policy's own kernel): a kernel of
+    // its own cost the search ~70 us of latency in every pass, while this launch lasts as long as its slowest FAILING window.
+    if (dirs && rows <= GR_T) {
+        GR_SYNC();
+        if (lane < rows) {
+            double dx, dy;
+            row_direction(c, sel + lane * cols, cols, dx, dy);
+            dirs[2 * ((size_t) s * rows + lane)] = dx;
+            dirs[2 * ((size_t) s * rows + lane) + 1] = dy;
+        }
+    }
 #undef GR_SYNC
 }
 
@@ -897,6 +911,12 @@ using namespace ecal;
 extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off,
                                    const double *d_cand_xyr, uint32_t S, uint32_t rows, uint32_t cols,
                                    int32_t *d_order, uint32_t *d_found, void *stream) {
+    return ecal_grid_order_dirs_dev(ctx, d_win_info, d_seg_off, d_cand_xyr, S, rows, cols, d_order, d_found, nullptr, stream);
+}
+
+// the same, and the found grids' row directions into d_dirs[S][rows][2] (may be NULL; ecal_adaptive.hip's passes)
+int ecal_grid_order_dirs_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off, const double *d_cand_xyr, uint32_t S,
+                             uint32_t rows, uint32_t cols, int32_t *d_order, uint32_t *d_found, double *d_dirs, void *stream) {
     const ecal_range range__(ctx, "ecal_grid_order");
     if (!ctx) return ECAL_ERR_INVALID;
     if (S == 0) return ECAL_OK;
@@ -912,10 +932,10 @@ extern "C" int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, co
     const uint32_t at_work = ctx->grid_hint_windows ? ctx->grid_hint_windows : S;
     if (at_work <= GR_PARALLEL_MAX && !ctx->sw.grid_one_wave && !ctx->sw.grid_debug)
         hipLaunchKernelGGL(grid_order_kernel<4>, dim3(S), dim3(GR_T * 4), 0, (hipStream_t) stream, d_win_info, d_seg_off,
-                           d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, dbg);
+                           d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, dbg, d_dirs);
     else
         hipLaunchKernelGGL(grid_order_kernel<1>, dim3(S), dim3(GR_T), 0, (hipStream_t) stream, d_win_info, d_seg_off,
-                           d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, dbg);
+                           d_cand_xyr, rows, cols, 0.7, tol_px, d_order, d_found, dbg, d_dirs);
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
 }

@@ -149,7 +149,8 @@ def _same_keyframes(dev, ref):
 def _in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_ROUNDS", value="1"):
     """The shared-map search with the verification after every SET of runs (ECAL_ADAPTIVE_ROUNDS=1: the form before round 4's
     pass-by-pass verification, kept behind the switch) or WITHOUT the side chains behind accepted windows (ECAL_ADAPTIVE_SIDE=0;
-    with them is the default since round 5) — must give the same keyframes."""
+    with them is the default since round 5), or with the rows' line fits in adaptive_dir_kernel instead of the grid finder's epilogue
+    (ECAL_ADAPTIVE_DIR_KERNEL=1) — must give the same keyframes."""
     import os
     import eventcalib_amd.capi as capi
     from eventcalib_amd.adaptive import detect_keyframes_device
@@ -184,6 +185,7 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last), ref)
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="0"), ref)   # without the side chains behind accepted windows
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="1"), ref)   # the measured layout, named
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_DIR_KERNEL", value="1"), ref)   # the rows' line fits by a kernel of their own (default: in the grid finder's epilogue)
     if pieces == 1:
         _same_keyframes(dev, own)              # one piece: the two modes are the same run
     _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last), own)
