@@ -45,7 +45,7 @@ constexpr uint32_t AD_NREJ = 4;   // successes rejected before a piece's first a
 struct AdaptiveArrays {
     double *first, *second, *bound_hi, *ref_t, *ref_dir;  // [P], [P], [P], [P], [P][rows][2]
     uint32_t *active, *have_ref, *levels;                 // [P]; levels: windows the piece has gone through
-    uint32_t *slot0, *depth;                              // [P]: the piece's window slots of this pass (adaptive_alloc_kernel)
+    uint32_t *slot0, *depth, *lay;                        // [P]: the piece's window slots of this pass (adaptive_alloc_kernel): first slot, ChainTree's two words
     uint32_t *want;                                       // [P]: the chain length the piece asks for (live form: grows while its chains hold)
     uint32_t *counters;  // 0: pieces active after this pass, 1: keyframes, 2: passes that evaluated a window, 3: slots overflowed,
                          // 8: pieces to run again (shared-map verification)
@@ -197,6 +197,88 @@ __device__ __forceinline__ void write_chain(uint32_t D, double f, double s2, dou
     }
 }
 
+// A piece's window slots as a TREE of chains (round 5).  The verdicts that do not accept are predictable (likely_outcome: on the
+// benchmark stream without a miss), so a chain only ever ends at an ACCEPTANCE or at its last slot — and where a window is
+// accepted cannot be known ahead: 4 to 10 steps long, most often 5.  Level 0 is the main chain (len0 windows from the piece's
+// current one, every verdict the likely one).  Behind positions [a1, a1 + c1) of it hang the c1 chains of level 1 — what follows
+// if THAT window is accepted, len1 windows —, behind positions [a2, a2 + c2) of every level-1 chain the chains of level 2, and so
+// on: a walk goes down one level per keyframe.  Slots: level 0, then the chains of level 1 in the order of their positions, then
+// level 2 (chain i of level 1, position q: number i * c2 + (q - a2)), then level 3.  c1 = 0: a chain; c2 = 0: the main chain
+// and side chains of round 4.
+struct ChainTree {
+    uint32_t len0, len1, len2, len3, a1, a2, a3, c1, c2, c3;
+    __device__ __forceinline__ uint32_t off1() const { return len0; }
+    __device__ __forceinline__ uint32_t off2() const { return len0 + c1 * len1; }
+    __device__ __forceinline__ uint32_t off3() const { return len0 + c1 * len1 + c1 * c2 * len2; }
+    __device__ __forceinline__ uint32_t slots() const { return len0 + c1 * (len1 + c2 * (len2 + c3 * len3)); }
+    __device__ __forceinline__ uint32_t longest_walk() const { return len0 + (c1 ? len1 : 0u) + (c2 ? len2 : 0u) + (c3 ? len3 : 0u); }
+    // the two words a piece's layout is kept in (AdaptiveArrays::depth, ::lay)
+    __device__ __forceinline__ uint32_t word0() const { return len0 | (c1 << 8) | (a1 << 16) | (len1 << 24); }   // (len0 <= 255, c1 <= 255)
+    __device__ __forceinline__ uint32_t word1() const { return a2 | (c2 << 4) | (len2 << 8) | (a3 << 16) | (c3 << 20) | (len3 << 24); }
+    __device__ __forceinline__ static ChainTree unpack(uint32_t w0, uint32_t w1) {
+        ChainTree y;
+        y.len0 = w0 & 0xFFu, y.c1 = (w0 >> 8) & 0xFFu, y.a1 = (w0 >> 16) & 0xFFu, y.len1 = w0 >> 24;
+        y.a2 = w1 & 0xFu, y.c2 = (w1 >> 4) & 0xFu, y.len2 = (w1 >> 8) & 0xFFu, y.a3 = (w1 >> 16) & 0xFu, y.c3 = (w1 >> 20) & 0xFu, y.len3 = w1 >> 24;
+        return y;
+    }
+};
+// The tree a piece gets in the regime where keyframes are to be expected (its last chain ended at one, or it starts): `tree` =
+// main | len << 8 | c1 << 16 | c2 << 20 | c3 << 24 | from << 28 at most, as much of it as `slots` hold — level by level, every
+// chain of a level or none.  Fewer than main + len slots: no tree (c1 = 0, the caller's chain).
+__device__ __forceinline__ ChainTree tree_for(uint32_t slots, uint32_t tree) {
+    ChainTree y = {};
+    const uint32_t TM = tree & 0xFFu, TL = (tree >> 8) & 0xFFu, C1 = (tree >> 16) & 0xFu, C2 = (tree >> 20) & 0xFu, C3 = (tree >> 24) & 0xFu, TF = tree >> 28;
+    if (!tree || TL == 0 || slots < TM + TL) return y;
+    y.len0 = TM;
+    y.len1 = y.len2 = y.len3 = TL;
+    y.a1 = y.a2 = y.a3 = TF;
+    uint32_t used = TM;
+    y.c1 = (slots - used) / TL;
+    y.c1 = y.c1 < C1 ? y.c1 : C1;
+    used += y.c1 * TL;
+    y.c2 = y.c1 ? (slots - used) / (y.c1 * TL) : 0u;
+    y.c2 = y.c2 < C2 ? y.c2 : C2;
+    used += y.c1 * y.c2 * TL;
+    y.c3 = y.c2 ? (slots - used) / (y.c1 * y.c2 * TL) : 0u;
+    y.c3 = y.c3 < C3 ? y.c3 : C3;
+    return y;
+}
+__device__ __forceinline__ uint32_t tree_slots_max(uint32_t tree) {
+    const uint32_t TM = tree & 0xFFu, TL = (tree >> 8) & 0xFFu, C1 = (tree >> 16) & 0xFu, C2 = (tree >> 20) & 0xFu, C3 = (tree >> 24) & 0xFu;
+    return TM + TL * C1 * (1u + C2 * (1u + C3));
+}
+// chain `idx` of level LV: its windows from (f, s2) on as if every verdict were the likely one (empty behind the piece's end, as
+// write_chain), and below the positions that carry them the chains of the next level, from the window that follows an acceptance
+template <int LV>
+__device__ __forceinline__ void write_tree_level(const ChainTree &y, uint32_t idx, double f, double s2, bool act, double hi, double mts, double *t0, double *t1) {
+    const uint32_t len = LV == 0 ? y.len0 : (LV == 1 ? y.len1 : (LV == 2 ? y.len2 : y.len3));
+    const uint32_t off = LV == 0 ? 0u : (LV == 1 ? y.off1() : (LV == 2 ? y.off2() : y.off3()));
+    const uint32_t ca = LV == 0 ? y.a1 : (LV == 1 ? y.a2 : y.a3), cc = LV == 0 ? y.c1 : (LV == 1 ? y.c2 : (LV == 2 ? y.c3 : 0u));
+    double *c0 = t0 + off + (size_t) idx * len, *c1 = t1 + off + (size_t) idx * len;
+    for (uint32_t q = 0; q < len; q++) {
+        c0[q] = act ? f : INFINITY;
+        c1[q] = act ? s2 : -INFINITY;
+        if constexpr (LV < 3) {
+            if (q >= ca && q < ca + cc) {
+                double af = 0, as = 0;
+                bool sact = act;
+                if (sact) {
+                    next_window(0, f, s2, mts, af, as);
+                    sact = as < hi;
+                }
+                write_tree_level<LV + 1>(y, idx * cc + (q - ca), af, as, sact, hi, mts, t0, t1);
+            }
+        }
+        if (act) {
+            double nf, ns;
+            next_window(likely_outcome(f, s2, mts), f, s2, mts, nf, ns);
+            f = nf;
+            s2 = ns;
+            act = ns < hi;
+        }
+    }
+}
+
 // The window slots of the next pass.  The pieces' chains differ a lot in length (the benchmark's longest has 559 windows, the
 // average 83), so most passes see few pieces still at work: the B slots of a pass are dealt out evenly among THOSE, up to
 // d_max windows of chain each — the fewer pieces remain, the further each one looks ahead.  One workgroup.
@@ -212,13 +294,17 @@ constexpr uint32_t AD_SIDE_MEASURED = 0u | (24u << 8) | (12u << 16) | (24u << 24
 // saved passes now outweigh the wider ones — shared-map gate 0.145 -> 0.138 s at 1270 pieces, 0.148 -> 0.137 s at 4096 — and the
 // measured layout is the default (ECAL_ADAPTIVE_SIDE=0: none).
 constexpr uint32_t AD_SIDE_DEFAULT = AD_SIDE_MEASURED;
+// tree_for's word: main chain 8, chains of 8 behind positions 1 .. 5 / 1 .. 4 / 1 .. 3 of the levels above (a keyframe's window is
+// 4 - 10 steps long, position = steps - 3 after a fresh start: 5 steps 32 %, 4: 21 %, 6: 20 %, 7: 12 %, 8: 8 %)
+constexpr uint32_t AD_TREE_DEFAULT = 8u | (8u << 8) | (5u << 16) | (4u << 20) | (3u << 24) | (1u << 28);
 // report (pinned host memory, may be NULL) + seq: the pass that ends with this launch tells the host how it went — pieces still
 // active, keyframe records so far, capacity overflow, and LAST the pass's number, which the host polls for (a copy engine
 // transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
 // and takes the active-pieces counter back to zero for the next pass.
 __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t deal, uint32_t d_max, AdaptiveArrays st,
                                                                     double mts, double *t0, double *t1, uint32_t *report, uint32_t seq, uint32_t live_base, uint32_t live_floor,
-                                                                    uint32_t side /* from | count << 8 | length << 16 | main chain << 24 */) {
+                                                                    uint32_t side /* from | count << 8 | length << 16 | main chain << 24 */,
+                                                                    uint32_t tree /* tree_for's word; 0: no trees */) {
     __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
@@ -248,9 +334,13 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
         const uint32_t share = n_act ? live_floor / n_act : 0u;   // few pieces at work: the pass has slots to spare for all of them
         // slots of a piece: a chain of up to d_max windows; with slots to spare beyond that (few pieces at work), a main chain
         // of AD_SIDE_MAIN windows + side chains of AD_SIDE_LEN windows for as many of them as fit (write_chain)
+        // a piece whose last chain ended at a keyframe (or that starts) is where keyframes are to be expected: its slots are a tree
+        // (tree_for) as far as the share goes; one whose chains hold — a stretch without the pattern — asks for a chain as before
+        const uint32_t tree_max = tree ? tree_slots_max(tree) : 0u;
         auto wanted = [&](uint32_t k) -> uint32_t {
             uint32_t w = st.want[k] > live_base ? st.want[k] : live_base;
             w = w > share ? w : share;
+            if (tree && st.want[k] == 0u && share >= (tree & 0xFFu) + ((tree >> 8) & 0xFFu)) return w < tree_max ? w : tree_max;
             const uint32_t cap = SC && share >= SM + 2u * SL ? SM + SC * SL : d_max;
             return w < cap ? w : cap;
         };
@@ -290,22 +380,31 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
         for (uint32_t k = k0; k < k0 + per && k < P; k++) {
             if (st.active[k]) {
                 const uint32_t slots = depth_of(k);
-                uint32_t D = slots, n_side = 0;
-                if (slots > d_max) {
-                    D = SM;
-                    n_side = (slots - D) / SL;
-                    n_side = n_side < SC ? n_side : SC;
+                ChainTree y = {};
+                if (tree && st.want[k] == 0u && share >= (tree & 0xFFu) + ((tree >> 8) & 0xFFu)) y = tree_for(slots, tree);
+                if (y.c1 == 0u) {   // a chain, with round 4's side chains when there are slots for them
+                    y = ChainTree{};
+                    y.len0 = slots < d_max ? slots : d_max;
+                    if (slots > d_max && SC) {
+                        y.len0 = SM;
+                        y.c1 = (slots - SM) / SL;
+                        y.c1 = y.c1 < SC ? y.c1 : SC;
+                        y.a1 = SF;
+                        y.len1 = SL;
+                    }
                 }
                 st.slot0[k] = at;
-                st.depth[k] = D | (n_side << 8) | (SF << 16) | (SL << 24);   // (D <= 48, n_side <= 24)
-                write_chain(D, st.first[k], st.second[k], st.bound_hi[k], mts, t0 + at, t1 + at, n_side, SL, SF);
-                for (uint32_t q = D + n_side * SL; q < slots; q++) {   // (the remainder of its slots)
+                st.depth[k] = y.word0();
+                st.lay[k] = y.word1();
+                write_tree_level<0>(y, 0u, st.first[k], st.second[k], true, st.bound_hi[k], mts, t0 + at, t1 + at);
+                for (uint32_t q = y.slots(); q < slots; q++) {   // (the remainder of its slots)
                     t0[at + q] = INFINITY;
                     t1[at + q] = -INFINITY;
                 }
                 at += slots;
             } else {
                 st.depth[k] = 0;
+                st.lay[k] = 0;
             }
         }
         for (uint32_t i = total_depth + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
@@ -320,10 +419,12 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
         if (st.active[k]) {
             st.slot0[k] = at * D;
             st.depth[k] = D;
+            st.lay[k] = 0;
             write_chain(D, st.first[k], st.second[k], st.bound_hi[k], mts, t0 + (size_t) at * D, t1 + (size_t) at * D);
             at++;
         } else {
             st.depth[k] = 0;
+            st.lay[k] = 0;
         }
     }
     for (uint32_t i = n_act * D + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
@@ -335,7 +436,7 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
         const uint32_t active = st.counters[0];
         st.counters[0] = 0;
         __hip_atomic_store(&report[0], active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&report[1], st.counters[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&report[1], (uint32_t) *st.windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (windows the rule has been applied to so far: the trace's)
         __hip_atomic_store(&report[3], st.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
         __hip_atomic_store(&report[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -514,22 +615,29 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
     const double hi = st.bound_hi[k];
     const uint32_t slot0 = st.slot0[k];
     uint32_t w = slot0;   // slot of the window under evaluation
-    const uint32_t dw = st.depth[k];
-    const uint32_t D = dw & 0xFFu, n_side = (dw >> 8) & 0xFFu, side_from = (dw >> 16) & 0xFFu,
-                   side_len = dw >> 24;   // (adaptive_alloc_kernel's side chains, live form)
-    uint32_t pos = 0, chain_len = D;   // position in the chain being walked (the main one, then at most one side chain)
-    bool on_side = false;
+    // the piece's slots of this pass: a tree of chains (ChainTree; adaptive_alloc_kernel) — the walk starts on the main chain and goes
+    // down a level at every acceptance that has a chain behind it
+    const ChainTree y = ChainTree::unpack(st.depth[k], st.lay[k]);
+    const uint32_t D = y.len0;
+    uint32_t lv = 0, cidx = 0, cbase = 0;   // level, number (within its level) and first slot (within the piece's) of the chain being walked
+    uint32_t pos = 0, chain_len = D;   // position in that chain
     bool act = true, held = true;
     const uint32_t lev0 = st.levels[k];   // (max_levels: the caller's bound on the windows of a piece)
-    const uint32_t d_all = D + (n_side ? side_len : 0u);
+    const uint32_t d_all = y.longest_walk();
     const uint32_t n_levels = max_levels - lev0 < d_all ? max_levels - lev0 : d_all;
     if (n_levels == 0) return;
-    // the main chain's windows, a lane each (D <= 48): events of the window (EventFrame::eventsNum()), extractFeatures() == true
-    uint32_t pre_cnt = 0, pre_ok = 0;
-    if (lane < D) {
-        const uint32_t wl = slot0 + lane;
-        pre_cnt = seg_cnt[2 * wl] + seg_cnt[2 * wl + 1];
-        pre_ok = (ECAL_WIN_STATUS(win_info[4 * wl + 3]) == 0 && found[wl]) ? 1u : 0u;
+    // every slot's verdict words into LDS, all lanes at once (one round trip for the whole tree): events of the window
+    // (EventFrame::eventsNum()) and bit 31 = extractFeatures() == true
+    constexpr uint32_t AD_STEP_SLOTS = 1024;
+    __shared__ uint32_t vw[AD_STEP_SLOTS];
+    const uint32_t n_slots = y.slots() < AD_STEP_SLOTS ? y.slots() : AD_STEP_SLOTS;
+    uint32_t pre_ok = 0;   // (this lane's main-chain window: D <= 48)
+    for (uint32_t i = lane; i < n_slots; i += 64) {
+        const uint32_t wl = slot0 + i;
+        const uint32_t c_ = seg_cnt[2 * wl] + seg_cnt[2 * wl + 1];
+        const uint32_t ok_ = (ECAL_WIN_STATUS(win_info[4 * wl + 3]) == 0 && found[wl]) ? 1u : 0u;
+        vw[i] = (c_ & 0x7FFFFFFFu) | (ok_ << 31);
+        if (i == lane && lane < D) pre_ok = ok_;
     }
     uint32_t have_ref = st.have_ref[k], nacc = st.nacc[k], nrej = st.nrej[k];
     // the reference frame on registers (lane i: row i) for the whole walk — it used to be read back from memory at every gate and
@@ -565,18 +673,16 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
     uint32_t n_new = 0;
     uint32_t levels_done = 0;
     for (uint32_t level = 0; level < n_levels; level++) {
-        uint32_t cnt, okw;
-        if (!on_side) {
-            cnt = (uint32_t) __shfl((int) pre_cnt, (int) pos, 64);
-            okw = (uint32_t) __shfl((int) pre_ok, (int) pos, 64);
-        } else {   // (a side chain's windows: read where they are)
-            cnt = seg_cnt[2 * w] + seg_cnt[2 * w + 1];
-            okw = (ECAL_WIN_STATUS(win_info[4 * w + 3]) == 0 && found[w]) ? 1u : 0u;
+        if (cbase + pos >= AD_STEP_SLOTS) {   // (beyond what was staged: cannot happen with the layouts adaptive_alloc_kernel writes)
+            held = false;
+            break;
         }
+        const uint32_t vword = vw[cbase + pos];
+        const uint32_t cnt = vword & 0x7FFFFFFFu, okw = vword >> 31;
         bool accepted = false;
         if (okw) {
             double dx = 0.0, dy = 0.0;   // lane i: row i of this window's line fits
-            const uint32_t nth_ok = on_side ? (uint32_t) AD_STEP_PF : (uint32_t) __popcll(okmask & ((1ull << pos) - 1ull));
+            const uint32_t nth_ok = lv ? (uint32_t) AD_STEP_PF : (uint32_t) __popcll(okmask & ((1ull << pos) - 1ull));
             if (nth_ok < (uint32_t) AD_STEP_PF) {
 #pragma unroll
                 for (int j = 0; j < AD_STEP_PF; j++)
@@ -651,18 +757,25 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
         if (o == likely) {   // the chain evaluated ahead holds the likely successor …
             pos++;
             if (pos >= chain_len) {
-                held = !on_side;
+                held = lv == 0u;
                 break;
             }
             w++;
             continue;
         }
-        if (o == 0 && !on_side && pos >= side_from && pos < side_from + n_side) {   // … and, for n_side of the windows, what follows an acceptance
-            w = slot0 + D + (pos - side_from) * side_len;
-            on_side = true;
-            pos = 0;
-            chain_len = side_len;
-            continue;
+        if (o == 0 && lv < 3u) {   // … and, behind some of its windows, the chain of the next level: what follows an acceptance
+            const uint32_t ca = lv == 0u ? y.a1 : (lv == 1u ? y.a2 : y.a3), cc = lv == 0u ? y.c1 : (lv == 1u ? y.c2 : y.c3);
+            if (pos >= ca && pos < ca + cc) {
+                const uint32_t nlen = lv == 0u ? y.len1 : (lv == 1u ? y.len2 : y.len3);
+                const uint32_t noff = lv == 0u ? y.off1() : (lv == 1u ? y.off2() : y.off3());
+                cidx = cidx * cc + (pos - ca);
+                cbase = noff + cidx * nlen;
+                w = slot0 + cbase;
+                lv++;
+                pos = 0;
+                chain_len = nlen;
+                continue;
+            }
         }
         held = false;
         break;
@@ -817,7 +930,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
     // per piece: 7 doubles + (3 + AD_NREJ) x rows x 2 doubles of row directions + AD_NREJ doubles + 10 words
-    const size_t state_bytes = (size_t) P * (8 * (7 + AD_NREJ + 2 * (size_t) rows * (3 + AD_NREJ)) + 4 * 11) + 128;
+    const size_t state_bytes = (size_t) P * (8 * (7 + AD_NREJ + 2 * (size_t) rows * (3 + AD_NREJ)) + 4 * 12) + 128;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_dirs, (size_t) S * rows * 2 * sizeof(double)))) return rc;
     // keyframe records: in shared-map mode the pieces that run again leave dead records behind
@@ -856,6 +969,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         a.levels = u, u += P;
         a.slot0 = u, u += P;
         a.depth = u, u += P;
+        a.lay = u, u += P;
         a.gen = u, u += P;
         a.nacc = u, u += P;
         a.nrej = u, u += P;
@@ -885,7 +999,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     uint32_t *d_ring = nullptr;
     ECAL_HIP_TRY(ctx, hipHostGetDevicePointer((void **) &d_ring, (void *) (h + 16), 0));
     for (int i = 0; i < 32; i++) ring[i] = 0;
-    std::vector<uint32_t> trace_active;   // ECAL_ADAPTIVE_TRACE: pieces still at work after every pass
+    std::vector<uint32_t> trace_active, trace_windows;   // ECAL_ADAPTIVE_TRACE: pieces still at work after every pass, windows gone through so far
     uint32_t seq = 0;   // passes enqueued in this call (over all its sets of runs): the number a pass reports
     uint32_t last_active = P;   // pieces at work after the last pass that has reported
     // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
@@ -919,6 +1033,9 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // (side chains hang behind a main chain of (live_side >> 24) windows: a search whose chains are capped below that — the debug
     // switch ECAL_ADAPTIVE_DEPTH_MAX — runs without them)
     const uint32_t live_side_eff = d_max >= (live_side >> 24) ? live_side : AD_SIDE_NONE;
+    // the tree of chains a piece gets where keyframes are to be expected (tree_for; ECAL_ADAPTIVE_TREE: 0 = none, else the word)
+    const uint32_t live_tree_asked = ctx->sw.adaptive_tree < 0 ? AD_TREE_DEFAULT : (uint32_t) ctx->sw.adaptive_tree;
+    const uint32_t live_tree = d_max >= (live_tree_asked & 0xFFu) ? live_tree_asked : 0u;   // (as the side chains: not under a chain cap below its main chain)
     const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1024u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
     auto run_passes = [&]() -> int {
         // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
@@ -926,7 +1043,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side_eff);
+                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
@@ -945,7 +1062,10 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
                 last_active = (uint32_t) ring[4 * q];
-                if (ctx->sw.adaptive_trace) trace_active.push_back((uint32_t) ring[4 * q]);
+                if (ctx->sw.adaptive_trace) {
+                    trace_active.push_back((uint32_t) ring[4 * q]);
+                    trace_windows.push_back((uint32_t) ring[4 * q + 1]);
+                }
                 if (ring[4 * q + 3]) {
                     (void) hipStreamSynchronize(st);
                     ctx->last_error = range_msg;
@@ -992,7 +1112,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
             }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side_eff);
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));
@@ -1037,6 +1157,8 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                 d_max, n_passes, rounds);
         fprintf(stderr, "  pieces at work after each pass:");
         for (uint32_t v : trace_active) fprintf(stderr, " %u", v);
+        fprintf(stderr, "\n  windows gone through in each pass:");
+        for (size_t i = 0; i < trace_windows.size(); i++) fprintf(stderr, " %u", trace_windows[i] - (i ? trace_windows[i - 1] : 0u));
         fprintf(stderr, "\n");
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());

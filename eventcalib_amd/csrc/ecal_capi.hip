@@ -38,6 +38,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.adaptive_live_floor = (int) num("ECAL_ADAPTIVE_LIVE_FLOOR");
     sw.adaptive_grid_pieces = (int) num("ECAL_ADAPTIVE_GRID_PIECES");
     if (getenv("ECAL_ADAPTIVE_SIDE")) sw.adaptive_side = (int) num("ECAL_ADAPTIVE_SIDE");
+    if (getenv("ECAL_ADAPTIVE_TREE")) sw.adaptive_tree = (int) num("ECAL_ADAPTIVE_TREE");
     sw.arrow_k = (int) num("ECAL_ARROW_K");
     sw.bo_big_arena = (unsigned long long) num("ECAL_BO_BIG_ARENA");
     if (const char *e = getenv("ECAL_GRID_TOL_PX")) sw.grid_tol_px = atof(e);

@@ -150,7 +150,8 @@ def _in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_ROUNDS", 
     """The shared-map search with the verification after every SET of runs (ECAL_ADAPTIVE_ROUNDS=1: the form before round 4's
     pass-by-pass verification, kept behind the switch) or WITHOUT the side chains behind accepted windows (ECAL_ADAPTIVE_SIDE=0;
     with them is the default since round 5), or with the rows' line fits in adaptive_dir_kernel instead of the grid finder's epilogue
-    (ECAL_ADAPTIVE_DIR_KERNEL=1) — must give the same keyframes."""
+    (ECAL_ADAPTIVE_DIR_KERNEL=1), or with another shape of the tree of chains a piece's window slots form (ECAL_ADAPTIVE_TREE; 0: none)
+    — must give the same keyframes."""
     import os
     import eventcalib_amd.capi as capi
     from eventcalib_amd.adaptive import detect_keyframes_device
@@ -185,6 +186,9 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last), ref)
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="0"), ref)   # without the side chains behind accepted windows
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="1"), ref)   # the measured layout, named
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value="0"), ref)   # chains and side chains only (no tree of chains behind acceptances)
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value=str(4 | (4 << 8) | (2 << 16) | (2 << 20) | (2 << 24) | (1 << 28))), ref)   # a small tree: chains that end early, three levels
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value=str(12 | (10 << 8) | (6 << 16) | (5 << 20) | (0 << 24) | (0 << 28))), ref)   # a wide one from position 0, two levels
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_DIR_KERNEL", value="1"), ref)   # the rows' line fits by a kernel of their own (default: in the grid finder's epilogue)
     if pieces == 1:
         _same_keyframes(dev, own)              # one piece: the two modes are the same run
