@@ -301,12 +301,24 @@ constexpr uint32_t AD_TREE_DEFAULT = 8u | (8u << 8) | (5u << 16) | (4u << 20) | 
 // active, keyframe records so far, capacity overflow, and LAST the pass's number, which the host polls for (a copy engine
 // transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
 // and takes the active-pieces counter back to zero for the next pass.
+__device__ void verify_live_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st);
+__device__ void restart_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st);
 __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t deal, uint32_t d_max, AdaptiveArrays st,
                                                                     double mts, double *t0, double *t1, uint32_t *report, uint32_t seq, uint32_t live_base, uint32_t live_floor,
                                                                     uint32_t side /* from | count << 8 | length << 16 | main chain << 24 */,
-                                                                    uint32_t tree /* tree_for's word; 0: no trees */) {
+                                                                    uint32_t tree /* tree_for's word; 0: no trees */,
+                                                                    uint32_t verify_rows /* > 0: the shared-map gate's pass-by-pass verification first */) {
     __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // shared-map gate, live form, ECAL_ADAPTIVE_VERIFY_IN_ALLOC=1: the verification of the pass that has just ended and the restarts
+    // it asks for, by this one workgroup instead of adaptive_verify_live_kernel and adaptive_restart_kernel in front of it (a piece
+    // is read by other pieces' verifications only in a state its own restart does not touch before the barrier) — measured slower
+    if (verify_rows) {
+        for (uint32_t k = tid; k < P; k += AD_ALLOC_T) verify_live_piece(k, P, verify_rows, mts, st);
+        __syncthreads();
+        for (uint32_t k = tid; k < P; k += AD_ALLOC_T) restart_piece(k, P, verify_rows, mts, st);
+        __syncthreads();
+    }
     const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
     uint32_t mine = 0;
     for (uint32_t k = k0; k < k0 + per && k < P; k++) mine += st.active[k] ? 1u : 0u;
@@ -513,13 +525,16 @@ __global__ void adaptive_verify_kernel(uint32_t P, uint32_t rows, double mts, Ad
     }
 }
 
-__global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P || !st.rerun[k]) return;
+__device__ void restart_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st) {
+    if (!st.rerun[k]) return;
     st.rerun[k] = 0;
     st.gen[k]++;   // the keyframe records of the earlier runs of this piece are dead
     piece_start(k, P, rows, mts, st);
     if (st.active[k]) atomicAdd(&st.counters[0], 1u);   // (the live form: the pass reports pieces with windows still to go)
+}
+__global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < P) restart_piece(k, P, rows, mts, st);
 }
 
 // The verification of adaptive_verify_kernel after EVERY pass instead of after every set of runs (shared-map mode, the default
@@ -532,9 +547,7 @@ __global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, A
 //   nothing else; different -> run again).
 //   k running, nothing accepted yet: the rejected successes so far must stay rejected (else: run again); then the run so far is
 //   the run it would have been with the new frame, and the frame becomes its reference for the successes to come.
-__global__ void adaptive_verify_live_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P) return;
+__device__ void verify_live_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st) {
     uint32_t j = k + 1;
     while (j < P) {
         if (st.active[j]) return;   // not finished: its keyframes (or their absence) are not known yet
@@ -568,6 +581,10 @@ __global__ void adaptive_verify_live_kernel(uint32_t P, uint32_t rows, double mt
         double *rd = st.ref_dir + (size_t) k * rows * 2;
         for (uint32_t i = 0; i < 2 * rows; i++) rd[i] = has ? r_dir[i] : 0.0;
     }
+}
+__global__ void adaptive_verify_live_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < P) verify_live_piece(k, P, rows, mts, st);
 }
 
 // The rows' line fits of every window of the pass that produced a grid (a 3 x 3 Jacobi eigen-decomposition per row: the bulk of
@@ -1043,7 +1060,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree);
+                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree, 0u);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
@@ -1107,12 +1124,17 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                                max_keys, d_kt, d_kd, d_ke, d_kf, d_kp, d_kg, d_t0, d_t1, (const int *) B[16].ptr,
                                (const double *) ctx->adaptive_dirs.ptr);
-            if (live) {   // shared-map gate: verification and restarts pass by pass (adaptive_verify_live_kernel)
+            // shared-map gate: verification and restarts pass by pass (adaptive_verify_live_kernel, adaptive_restart_kernel).
+            // ECAL_ADAPTIVE_VERIFY_IN_ALLOC=1: in front of the next pass's slots in adaptive_alloc_kernel's launch instead — two
+            // launches less, measured SLOWER (0.118 - 0.125 against 0.116 - 0.118 s at 1270 pieces: one workgroup's threads take
+            // two to four pieces each through scans of dependent reads that the two kernels spread over the chip)
+            const bool verify_in_alloc = live && ctx->sw.adaptive_verify_in_alloc;
+            if (live && !verify_in_alloc) {
                 hipLaunchKernelGGL(adaptive_verify_live_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
                 hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
             }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree);
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree, verify_in_alloc ? rows : 0u);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));

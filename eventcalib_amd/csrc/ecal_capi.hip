@@ -33,6 +33,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.solver_no_stream = on("ECAL_SOLVER_NO_STREAM");
     sw.solver_two_roles = on("ECAL_SOLVER_TWO_ROLES");
     sw.adaptive_dir_kernel = on("ECAL_ADAPTIVE_DIR_KERNEL");
+    sw.adaptive_verify_in_alloc = on("ECAL_ADAPTIVE_VERIFY_IN_ALLOC");
     sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
     sw.adaptive_depth_max = (int) num("ECAL_ADAPTIVE_DEPTH_MAX");
     sw.adaptive_live_floor = (int) num("ECAL_ADAPTIVE_LIVE_FLOOR");

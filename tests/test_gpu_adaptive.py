@@ -189,6 +189,7 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value="0"), ref)   # chains and side chains only (no tree of chains behind acceptances)
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value=str(4 | (4 << 8) | (2 << 16) | (2 << 20) | (2 << 24) | (1 << 28))), ref)   # a small tree: chains that end early, three levels
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value=str(12 | (10 << 8) | (6 << 16) | (5 << 20) | (0 << 24) | (0 << 28))), ref)   # a wide one from position 0, two levels
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_VERIFY_IN_ALLOC", value="1"), ref)   # verification and restarts in front of the slot allocation, one launch (default: launches of their own)
     _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_DIR_KERNEL", value="1"), ref)   # the rows' line fits by a kernel of their own (default: in the grid finder's epilogue)
     if pieces == 1:
         _same_keyframes(dev, own)              # one piece: the two modes are the same run
