@@ -549,10 +549,22 @@ __global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, A
 //   the run it would have been with the new frame, and the frame becomes its reference for the successes to come.
 __device__ void verify_live_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st) {
     uint32_t j = k + 1;
-    while (j < P) {
-        if (st.active[j]) return;   // not finished: its keyframes (or their absence) are not known yet
-        if (st.nacc[j] > 0) break;
-        j++;
+    // (four pieces' words per round trip: the scan is a chain of dependent reads, and this kernel sits in every pass)
+    for (bool found_it = false; j < P && !found_it;) {
+        uint32_t a[4], n[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t ju = j + (uint32_t) u < P ? j + (uint32_t) u : P - 1u;
+            a[u] = st.active[ju];
+            n[u] = st.nacc[ju];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (found_it || j >= P) continue;
+            if (a[u]) return;   // not finished: its keyframes (or their absence) are not known yet
+            if (n[u] > 0) found_it = true;
+            else j++;
+        }
     }
     const bool has = j < P;
     const double r_t = has ? st.ref_t[j] : 0.0;
@@ -582,9 +594,79 @@ __device__ void verify_live_piece(uint32_t k, uint32_t P, uint32_t rows, double 
         for (uint32_t i = 0; i < 2 * rows; i++) rd[i] = has ? r_dir[i] : 0.0;
     }
 }
-__global__ void adaptive_verify_live_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < P) verify_live_piece(k, P, rows, mts, st);
+// the same by a WAVE per piece (the default's kernel): the scan for the predecessor 64 pieces at a time, the frames a lane per row,
+// the gate on registers (gate_accepts_regs) — a thread per piece went through the scan, the comparison and up to five gates
+// with their angle arrays in scratch memory as chains of dependent reads: 36 us of every pass
+__global__ __launch_bounds__(256) void adaptive_verify_live_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
+    const uint32_t k = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (k >= P) return;
+    uint32_t j = k + 1;
+    bool has = false;
+    while (j < P) {
+        const uint32_t jl = j + lane;
+        const uint32_t a = jl < P ? st.active[jl] : 0u, n = jl < P ? st.nacc[jl] : 0u;
+        const unsigned long long hit = __ballot(a != 0u || n > 0u);
+        if (hit) {
+            const uint32_t first = (uint32_t) __builtin_ctzll(hit);
+            if (__shfl((int) a, (int) first, 64)) return;   // not finished: its keyframes (or their absence) are not known yet
+            j += first;
+            has = true;
+            break;
+        }
+        j += 64u;
+    }
+    const double r_t = has ? st.ref_t[j] : 0.0;
+    double rx = 0.0, ry = 0.0, ix = 0.0, iy = 0.0;
+    if (lane < rows) {
+        if (has) {
+            rx = st.ref_dir[((size_t) j * rows + lane) * 2];
+            ry = st.ref_dir[((size_t) j * rows + lane) * 2 + 1];
+        }
+        ix = st.init_dir[((size_t) k * rows + lane) * 2];
+        iy = st.init_dir[((size_t) k * rows + lane) * 2 + 1];
+    }
+    bool same = (st.init_has[k] != 0) == has;
+    if (same && has) same = st.init_t[k] == r_t && __ballot(lane < rows && !(ix == rx && iy == ry)) == 0ull;
+    if (same) return;
+    const uint32_t nrej_k = st.nrej[k], nacc_k = st.nacc[k];
+    bool again = nrej_k > AD_NREJ;   // more rejected successes than were kept: not decidable here
+    const uint32_t nr = nrej_k < AD_NREJ ? nrej_k : AD_NREJ;
+    for (uint32_t i = 0; i < nr && !again; i++) {
+        double dx = 0.0, dy = 0.0;
+        if (lane < rows) {
+            dx = st.rej_dir[(((size_t) k * AD_NREJ + i) * rows + lane) * 2];
+            dy = st.rej_dir[(((size_t) k * AD_NREJ + i) * rows + lane) * 2 + 1];
+        }
+        again = !has || gate_accepts_regs(rx, ry, r_t, dx, dy, st.rej_t[(size_t) k * AD_NREJ + i], rows, mts);
+    }
+    if (!again && nacc_k > 0) {
+        double dx = 0.0, dy = 0.0;
+        if (lane < rows) {
+            dx = st.facc_dir[((size_t) k * rows + lane) * 2];
+            dy = st.facc_dir[((size_t) k * rows + lane) * 2 + 1];
+        }
+        again = has && !gate_accepts_regs(rx, ry, r_t, dx, dy, st.facc_t[k], rows, mts);
+    }
+    if (lane == 0) {
+        st.init_has[k] = has ? 1u : 0u;   // (the frame the piece's results are now known to be right for)
+        st.init_t[k] = r_t;
+    }
+    if (lane < rows) {
+        st.init_dir[((size_t) k * rows + lane) * 2] = rx;   // (0 without a frame)
+        st.init_dir[((size_t) k * rows + lane) * 2 + 1] = ry;
+    }
+    if (again) {
+        if (lane == 0) st.rerun[k] = 1;
+    } else if (st.active[k] && nacc_k == 0) {   // still before its first acceptance: the new frame is what its successes meet from now on
+        if (lane == 0) {
+            st.have_ref[k] = has ? 1u : 0u;
+            st.ref_t[k] = r_t;
+        }
+        if (lane < rows) {
+            st.ref_dir[((size_t) k * rows + lane) * 2] = rx;
+            st.ref_dir[((size_t) k * rows + lane) * 2 + 1] = ry;
+        }
+    }
 }
 
 // The rows' line fits of every window of the pass that produced a grid (a 3 x 3 Jacobi eigen-decomposition per row: the bulk of
@@ -1130,7 +1212,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
             // two to four pieces each through scans of dependent reads that the two kernels spread over the chip)
             const bool verify_in_alloc = live && ctx->sw.adaptive_verify_in_alloc;
             if (live && !verify_in_alloc) {
-                hipLaunchKernelGGL(adaptive_verify_live_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
+                hipLaunchKernelGGL(adaptive_verify_live_kernel, dim3((P + 3) / 4), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
                 hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
             }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
