@@ -200,6 +200,25 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     regular = ok & pair_ok & rect_ok
     irregular = np.flatnonzero(~regular)
     ok_l, rect_l, pair_l = ok.tolist(), rect_ok.tolist(), pair_ok.tolist()
+    # (the scalar test below runs once per frame behind a rejection — thousands of times on a long stream —: rotations, positions
+    # and times as Python lists, converted once)
+    import math
+    R_l, tw_l, kt_l = Rsw.reshape(K, 9).tolist(), twb.tolist(), kt.tolist()
+    lim_t, lim_r = (2.5e-1 / step) * 2, (5e-4 * math.pi) * 2 / step
+
+    def pose_ok(last, f):   # check_pose(Rsw[last], twb[last], kt[last], Rsw[f], twb[f], kt[f], step), the same operations
+        dt = kt_l[f] - kt_l[last]
+        a, b = tw_l[f], tw_l[last]
+        d0, d1, d2 = a[0] - b[0], a[1] - b[1], a[2] - b[2]
+        v_t = math.sqrt(d0 * d0 + d1 * d1 + d2 * d2) / dt
+        ra, rb = R_l[f], R_l[last]
+        tr = 0.0
+        for i in range(9):
+            tr += ra[i] * rb[i]
+        c = (tr - 1) * 0.5
+        v_r = abs(math.acos(min(1.0, max(-1.0, c))) / dt)
+        return v_t < lim_t and v_r < lim_r
+
     f = 0
     while f < K:
         if last == f - 1 and last >= 0 and regular[f]:
@@ -208,8 +227,7 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
             last = g - 1
             f = g
             continue
-        if not ok_l[f] or (last >= 0 and not (pair_l[f] if last == f - 1 else
-                                              check_pose(Rsw[last], twb[last], kt[last], Rsw[f], twb[f], kt[f], step))):
+        if not ok_l[f] or (last >= 0 and not (pair_l[f] if last == f - 1 else pose_ok(last, f))):
             n_check += 1
         elif not rect_l[f]:
             n_rect += 1

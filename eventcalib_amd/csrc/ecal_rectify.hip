@@ -86,6 +86,20 @@ __device__ __forceinline__ void solve3(double (&A)[3][4], double (&x)[3]) {
     x[0] = (A[0][3] - A[0][1] * x[1] - A[0][2] * x[2]) / A[0][0];
 }
 
+// a point of the window as every lane needs it: lane j of the wave has loaded point i0 + j (one coalesced load for 64 points
+// instead of a broadcast load per point), the walk reads them lane by lane (v_readlane: wave-uniform values)
+__device__ __forceinline__ double rc_lane_f64(double v, uint32_t j) {
+    const unsigned long long b = (unsigned long long) __double_as_longlong(v);
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b, (int) j);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (b >> 32), (int) j);
+    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+
+// WORDS = flag words per polarity and lane: the launch with RC_WORDS_SMALL (256 kept clusters per polarity: 4 KB of LDS, so that
+// the compute unit holds waves enough to hide the walk's latencies) takes the frames that fit, the one with RC_WORDS (32 KB:
+// five waves per compute unit) the others; a frame is worked on by exactly one of the two.
+constexpr uint32_t RC_WORDS_SMALL = 8;
+template <uint32_t WORDS>
 __global__ __launch_bounds__(RC_T) void rectify_kernel(const double2 *__restrict__ xy,
                                                        const uint32_t *__restrict__ seg_off,
                                                        const uint32_t *__restrict__ seg_cnt,
@@ -96,13 +110,18 @@ __global__ __launch_bounds__(RC_T) void rectify_kernel(const double2 *__restrict
                                                        const double *__restrict__ landmarks, RectifyConst prm,
                                                        double *__restrict__ feat_xyr, uint32_t *__restrict__ feat_valid,
                                                        uint32_t *__restrict__ frame_info) {
-    __shared__ uint32_t flags[2 * RC_WORDS * RC_T];  // [pol][word][lane]
+    __shared__ uint32_t flags[2 * WORDS * RC_T];  // [pol][word][lane]
     __shared__ uint8_t valid_sh[RC_MAXN];
     const uint32_t f = blockIdx.x, lane = threadIdx.x;
     const uint32_t s = frame_window[f], n = prm.rows * prm.cols;
     const uint32_t base[2] = {seg_off[2 * s], seg_off[2 * s + 1]}, cnt[2] = {seg_cnt[2 * s], seg_cnt[2 * s + 1]};
     const uint32_t nk[2] = {win_info[4 * (size_t) s + 1], win_info[4 * (size_t) s + 2]};
     const bool unsupported = ECAL_WIN_STATUS(win_info[4 * (size_t) s + 3]) == 4 || nk[0] > RC_MAXK || nk[1] > RC_MAXK;
+    {   // (the other launch's frame?)
+        const bool small_fits = nk[0] <= 32u * RC_WORDS_SMALL && nk[1] <= 32u * RC_WORDS_SMALL;
+        if ((WORDS == RC_WORDS_SMALL) != small_fits) return;
+    }
+    const uint32_t words_used = unsupported ? 0u : ((nk[0] > nk[1] ? nk[0] : nk[1]) + 31u) / 32u;   // (labels of kept clusters are < nk)
     double R[9], t[3];
 #pragma unroll
     for (int i = 0; i < 9; i++) R[i] = pose[12 * (size_t) f + i];
@@ -135,14 +154,22 @@ __global__ __launch_bounds__(RC_T) void rectify_kernel(const double2 *__restrict
             }
             search = (max_radius + inlier) * (max_radius + inlier);
         }
-        for (uint32_t w = 0; w < 2 * RC_WORDS; w++) flags[w * RC_T + lane] = 0;
+        for (uint32_t pw = 0; pw < 2; pw++)
+            for (uint32_t w = 0; w < words_used; w++) flags[(pw * WORDS + w) * RC_T + lane] = 0;
         // inliers -> clusters.  The trip counts are wave-uniform; a lane without a circle just does not mark.
         for (int pol = 0; pol < 2; pol++) {
             const double2 *pts = xy + base[pol];
             const int32_t *lab = kept_labels + base[pol];
-            for (uint32_t i = 0; i < cnt[pol]; i++) {
-                const double2 e = pts[i];
-                const int32_t l = lab[i];
+            for (uint32_t i0 = 0; i0 < cnt[pol]; i0 += RC_T) {
+              const uint32_t mine = i0 + lane < cnt[pol] ? i0 + lane : cnt[pol] - 1u;
+              const double2 e_my = pts[mine];
+              const int32_t l_my = lab[mine];
+              const uint32_t nj = cnt[pol] - i0 < (uint32_t) RC_T ? cnt[pol] - i0 : (uint32_t) RC_T;
+              for (uint32_t j = 0; j < nj; j++) {
+                double2 e;
+                e.x = rc_lane_f64(e_my.x, j);
+                e.y = rc_lane_f64(e_my.y, j);
+                const int32_t l = __builtin_amdgcn_readlane(l_my, (int) j);
                 const double dx = e.x - cx, dy = e.y - cy;
                 const double d2 = dx * dx + dy * dy;
                 if (!ok || l < 0 || !(d2 < search)) continue;
@@ -154,7 +181,8 @@ __global__ __launch_bounds__(RC_T) void rectify_kernel(const double2 *__restrict
                 else if (dx <= 0 && dy >= 0) idx = 3;
                 const double rq = idx == 0 ? radius[0] : idx == 1 ? radius[1] : idx == 2 ? radius[2] : radius[3];
                 if (fabs(distance - rq) <= inlier)
-                    flags[((uint32_t) pol * RC_WORDS + ((uint32_t) l >> 5)) * RC_T + lane] |= 1u << (l & 31);
+                    flags[((uint32_t) pol * WORDS + ((uint32_t) l >> 5)) * RC_T + lane] |= 1u << (l & 31);
+              }
             }
         }
         // whole clusters -> the nine sums of fitCircle
@@ -164,11 +192,18 @@ __global__ __launch_bounds__(RC_T) void rectify_kernel(const double2 *__restrict
             const double2 *pts = xy + base[pol];
             const int32_t *lab = kept_labels + base[pol];
             uint32_t m = 0;
-            for (uint32_t i = 0; i < cnt[pol]; i++) {
-                const double2 e = pts[i];
-                const int32_t l = lab[i];
+            for (uint32_t i0 = 0; i0 < cnt[pol]; i0 += RC_T) {
+              const uint32_t mine = i0 + lane < cnt[pol] ? i0 + lane : cnt[pol] - 1u;
+              const double2 e_my = pts[mine];
+              const int32_t l_my = lab[mine];
+              const uint32_t nj = cnt[pol] - i0 < (uint32_t) RC_T ? cnt[pol] - i0 : (uint32_t) RC_T;
+              for (uint32_t j = 0; j < nj; j++) {
+                double2 e;
+                e.x = rc_lane_f64(e_my.x, j);
+                e.y = rc_lane_f64(e_my.y, j);
+                const int32_t l = __builtin_amdgcn_readlane(l_my, (int) j);
                 if (!ok || l < 0) continue;
-                if (!((flags[((uint32_t) pol * RC_WORDS + ((uint32_t) l >> 5)) * RC_T + lane] >> (l & 31)) & 1u)) continue;
+                if (!((flags[((uint32_t) pol * WORDS + ((uint32_t) l >> 5)) * RC_T + lane] >> (l & 31)) & 1u)) continue;
                 m++;
                 sx += e.x;
                 sy += e.y;
@@ -180,6 +215,7 @@ __global__ __launch_bounds__(RC_T) void rectify_kernel(const double2 *__restrict
                 syyy += yy * e.y;
                 sxyy += xyv * e.y;
                 sxxy += e.x * xyv;
+              }
             }
             members[pol] = m;
         }
@@ -267,7 +303,10 @@ extern "C" int ecal_rectify_batch_dev(ecal_ctx *ctx, const double *d_xy, const u
     c.rows = prm->rows, c.cols = prm->cols, c.asymmetric = prm->asymmetric, c.fit_circle = prm->fit_circle;
     c.model = prm->model == 1 ? 1 : 0;
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(rectify_kernel, dim3(F), dim3(RC_T), 0, (hipStream_t) stream, (const double2 *) d_xy, d_seg_off,
+    hipLaunchKernelGGL(rectify_kernel<RC_WORDS_SMALL>, dim3(F), dim3(RC_T), 0, (hipStream_t) stream, (const double2 *) d_xy, d_seg_off,
+                       d_seg_cnt, d_kept_labels, d_win_info, d_frame_window, d_pose, d_landmarks, c, d_feat_xyr,
+                       d_feat_valid, d_frame_info);
+    hipLaunchKernelGGL(rectify_kernel<RC_WORDS>, dim3(F), dim3(RC_T), 0, (hipStream_t) stream, (const double2 *) d_xy, d_seg_off,
                        d_seg_cnt, d_kept_labels, d_win_info, d_frame_window, d_pose, d_landmarks, c, d_feat_xyr,
                        d_feat_valid, d_frame_info);
     ECAL_HIP_TRY(ctx, hipGetLastError());
