@@ -8,6 +8,6 @@ import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n=r["Name"]
-    if any(k in n for k in ("rectify","pnp","associate","spline","calib","normal_eq","solver","arrow","reduce_heads","gather","index")):
+    if int(r["Calls"]) <= 8 and float(r["TotalDurationNs"]) > 2e5 or any(k in n for k in ("rectify","pnp","associate","normal_eq")):
         print("%-70s calls %5s total_ms %8.2f avg_us %9.1f" % (n.split("(")[0][-70:], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3))
 PY
