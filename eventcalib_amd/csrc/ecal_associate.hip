@@ -67,6 +67,62 @@ __device__ __forceinline__ int associate_one(double t, double x, double y, const
     return (fabs(dis - c[3 * bi + 2]) < edge_tol) ? bi : -1;
 }
 
+// The same with the keyframes a block's events can meet staged in LDS (associate_kernel): kt / circ hold the keyframes
+// k_first .. k_first + n_st - 1, the first index with kf_time >= t lies in [a_lo, a_hi] (the block's own events bound it).
+// Same comparisons on the same values as associate_one.
+__device__ __forceinline__ int associate_one_staged(double t, double x, double y, const double *kt, const double *circ, uint32_t K,
+                                                    uint32_t n_circ, uint32_t k_first, uint32_t a_lo, uint32_t a_hi, double t_min,
+                                                    double t_max, double max_dt2, double edge_tol) {
+    if (!(t >= t_min && t <= t_max) || K == 0) return -1;
+    uint32_t a = a_lo;
+    while (a < a_hi && kt[a - k_first] < t) a++;
+    uint32_t k = a;
+    if (a == K) k = K - 1;
+    else if (a > 0) {
+        const double d0 = t - kt[a - 1 - k_first], d1 = kt[a - k_first] - t;
+        if (d0 * d0 <= d1 * d1) k = a - 1;
+    }
+    const double dt = t - kt[k - k_first];
+    if (!(dt * dt < max_dt2)) return -1;
+    const double *c = circ + 3 * (size_t) (k - k_first) * n_circ;
+    double best = 1.79769313486231570e308;
+    int bi = -1;
+    for (uint32_t i = 0; i < n_circ; i++) {
+        const double dx = x - c[3 * i], dy = y - c[3 * i + 1];
+        const double d2 = dx * dx + dy * dy;
+        if (d2 < best) {
+            best = d2;
+            bi = (int) i;
+        }
+    }
+    if (bi < 0) return -1;
+    const double dis = __dsqrt_rn(best);
+    return (fabs(dis - c[3 * bi + 2]) < edge_tol) ? bi : -1;
+}
+
+// first index in [0, K] whose kf_time is not below t, by one wave: 64 probes a round (three rounds for thousands of keyframes
+// where a thread's bisection takes thirteen dependent loads)
+__device__ __forceinline__ uint32_t wave_lower_bound(const double *kf_time, uint32_t K, double t) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lo = 0, hi = K;   // every index below lo is < t, every index from hi on is >= t
+    while (lo < hi) {
+        const uint32_t span = hi - lo, step = (span + 63u) / 64u;
+        const uint32_t idx = lo + lane * step;
+        const bool less = idx < hi && kf_time[idx] < t;
+        const uint32_t c = (uint32_t) __popcll(__ballot(less));   // ascending times: the probes below t come first
+        if (c == 0) {
+            hi = lo;
+        } else {
+            const uint32_t nhi = lo + c * step < hi ? lo + c * step : hi;
+            lo = lo + (c - 1u) * step + 1u;
+            hi = nhi;
+        }
+    }
+    return lo;
+}
+
+constexpr uint32_t AS_KF_LDS = 6, AS_CIRC_LDS = 64, AS_RNG_LDS = 32;   // keyframes / circles per keyframe / time ranges a block stages
+
 template <bool WRITE>
 __global__ __launch_bounds__(AS_T) void associate_kernel(const uint8_t *__restrict__ rec, uint64_t n,
                                                          const double *__restrict__ kf_time,
@@ -78,26 +134,89 @@ __global__ __launch_bounds__(AS_T) void associate_kernel(const uint8_t *__restri
                                                          uint32_t *__restrict__ lm, const double *__restrict__ ranges,
                                                          uint32_t n_ranges, uint32_t *__restrict__ seg) {
     __shared__ uint32_t wsum[AS_T / 64];
+    __shared__ double s_kt[AS_KF_LDS], s_circ[AS_KF_LDS * 3 * AS_CIRC_LDS], s_rng[2 * AS_RNG_LDS], s_tmm[2 * (AS_T / 64)];
+    __shared__ uint32_t s_plan[4];   // staged?, k_first, a_lo, a_hi
     const uint64_t base = (uint64_t) blockIdx.x * (AS_T * AS_PER) + (uint64_t) threadIdx.x * AS_PER;
     int hit[AS_PER], rng[AS_PER];
     double tt[AS_PER], xx[AS_PER], yy[AS_PER];
     uint32_t mine = 0;
+    double tmn = 1.79769313486231570e308, tmx = -1.79769313486231570e308;
 #pragma unroll
     for (int e = 0; e < AS_PER; e++) {
         hit[e] = -1;
         rng[e] = 0;
+        tt[e] = xx[e] = yy[e] = 0.0;
         const uint64_t i = base + e;
         if (i < n) {
             const uint8_t *r = rec + i * 25;
             tt[e] = load_f64_u(r);
             xx[e] = load_f64_u(r + 8);
             yy[e] = load_f64_u(r + 16);
+            tmn = tt[e] < tmn ? tt[e] : tmn;
+            tmx = tt[e] > tmx ? tt[e] : tmx;
+        }
+    }
+    // The keyframes this block's 1024 events can meet: the events lie close together in time (the stream is in time order: a
+    // millisecond a block), so the nearest keyframe of every one of them is among the few around the block's own time span —
+    // found once per block (a wave's 64-ary search) and staged in LDS with their circles, instead of a thirteen-step bisection
+    // through global memory and 108 global loads of circle data PER EVENT.  Any order of events is taken (the span is the
+    // block's minimum and maximum); a block whose span meets more than AS_KF_LDS keyframes goes the plain way.
+    {
+        const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+        for (int o = 32; o > 0; o >>= 1) {
+            const double a = __shfl_xor(tmn, o, 64), b = __shfl_xor(tmx, o, 64);
+            tmn = a < tmn ? a : tmn;
+            tmx = b > tmx ? b : tmx;
+        }
+        if (lane_ == 0) {
+            s_tmm[2 * wave_] = tmn;
+            s_tmm[2 * wave_ + 1] = tmx;
+        }
+        if (ranges && n_ranges <= AS_RNG_LDS && threadIdx.x < 2 * n_ranges) s_rng[threadIdx.x] = ranges[threadIdx.x];
+        __syncthreads();
+        if (wave_ == 0) {
+            double bmn = s_tmm[0], bmx = s_tmm[1];
+            for (int w = 1; w < AS_T / 64; w++) {
+                bmn = s_tmm[2 * w] < bmn ? s_tmm[2 * w] : bmn;
+                bmx = s_tmm[2 * w + 1] > bmx ? s_tmm[2 * w + 1] : bmx;
+            }
+            uint32_t staged = 0, k_first = 0, a_lo = 0, a_hi = 0;
+            if (K > 0 && n_circ <= AS_CIRC_LDS && bmn <= bmx) {
+                a_lo = wave_lower_bound(kf_time, K, bmn);
+                a_hi = wave_lower_bound(kf_time, K, bmx);
+                k_first = a_lo > 0 ? a_lo - 1 : 0;
+                const uint32_t k_last = a_hi < K ? a_hi : K - 1;
+                if (k_last - k_first + 1 <= AS_KF_LDS) {
+                    staged = 1;
+                    const uint32_t n_st = k_last - k_first + 1;
+                    if ((uint32_t) lane_ < n_st) s_kt[lane_] = kf_time[k_first + lane_];
+                    for (uint32_t i = lane_; i < n_st * 3 * n_circ; i += 64) s_circ[i] = circles[3 * (size_t) k_first * n_circ + i];
+                }
+            }
+            if (lane_ == 0) {
+                s_plan[0] = staged;
+                s_plan[1] = k_first;
+                s_plan[2] = a_lo;
+                s_plan[3] = a_hi;
+            }
+        }
+        __syncthreads();
+    }
+    const bool staged = s_plan[0] != 0;
+    const uint32_t k_first = s_plan[1], a_lo = s_plan[2], a_hi = s_plan[3];
+    const double *const rng_tab = ranges && n_ranges <= AS_RNG_LDS ? s_rng : ranges;
+#pragma unroll
+    for (int e = 0; e < AS_PER; e++) {
+        const uint64_t i = base + e;
+        if (i < n) {
             if (ranges) {   // all spline segments in one pass: the event's range, if any, names its segment
-                rng[e] = range_of(tt[e], ranges, n_ranges);
+                rng[e] = range_of(tt[e], rng_tab, n_ranges);
                 if (rng[e] >= 0)
-                    hit[e] = associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, tt[e], tt[e], max_dt2, edge_tol);
+                    hit[e] = staged ? associate_one_staged(tt[e], xx[e], yy[e], s_kt, s_circ, K, n_circ, k_first, a_lo, a_hi, tt[e], tt[e], max_dt2, edge_tol)
+                                    : associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, tt[e], tt[e], max_dt2, edge_tol);
             } else {
-                hit[e] = associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, t_min, t_max, max_dt2, edge_tol);
+                hit[e] = staged ? associate_one_staged(tt[e], xx[e], yy[e], s_kt, s_circ, K, n_circ, k_first, a_lo, a_hi, t_min, t_max, max_dt2, edge_tol)
+                                : associate_one(tt[e], xx[e], yy[e], kf_time, circles, K, n_circ, t_min, t_max, max_dt2, edge_tol);
             }
             mine += hit[e] >= 0 ? 1u : 0u;
         }
