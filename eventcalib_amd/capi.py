@@ -170,6 +170,7 @@ class Context:
             self._check(self._L.ecal_debug_reload_env(self._h))
 
     def close(self):
+        self._calibrate_pipe = None   # (calibrate.calibrate_stream keeps its detection pipeline's arrays with the context)
         if getattr(self, "_h", None):
             _live_contexts.discard(self)
             self._L.ecal_destroy(self._h)

@@ -403,7 +403,14 @@ extern "C" int ecal_rectify_keyframes(ecal_ctx *ctx, const ecal_stream *es, cons
     dp.rows = dp.cols = 0;   // (no grid ordering: rectifyFeatures works on the clusters)
     ecal_detect_result none;
     memset(&none, 0, sizeof(none));
-    if ((rc = ecal_detect_batch(ctx, es, t0.data(), t1.data(), F, &dp, total + 64u, &none))) return rc;
+    // every size tier at work: a keyframe's window is 4 - 10 steps long (second- and third-tier work by construction), and what
+    // the stages' previous call saw — the keyframe search's last pass, with next to nothing in its lists — says nothing about
+    // this one: left to the automatic plan the whole batch went through the one slow general launch (9.4 ms instead of 3)
+    const int was_mode = ctx->tail_mode;
+    ctx->tail_mode = ECAL_TAIL_TIERED;
+    rc = ecal_detect_batch(ctx, es, t0.data(), t1.data(), F, &dp, total + 64u, &none);
+    ctx->tail_mode = was_mode;
+    if (rc) return rc;
     const uint32_t n = rprm->rows * rprm->cols;
     ecal_devbuf *R = ctx->host_rect;
     const size_t rs[6] = {(size_t) F * 12 * 8, (size_t) n * 3 * 8, (size_t) F * 4, (size_t) F * n * 24, (size_t) F * n * 4, (size_t) F * 8};
