@@ -1022,6 +1022,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     const uint32_t S = D * P;   // window slots per pass, dealt out among the pieces still at work: the current window and the likely chain after it
     const size_t cap = (size_t) cap_points + 16;
     ecal_devbuf *B = ctx->host_pipe;  // roles as in ecal_detect_pass; 0 holds t0 and t1 back to back
+    const auto t_scratch0 = std::chrono::steady_clock::now();
     const size_t sizes[17] = {2ul * S * sizeof(double), 16, S * 4ul, S * 4ul, (S + 1) * 4ul, cap * 16, 2ul * S * 4, 2ul * S * 4, cap * 4,
                               cap * 4, 2ul * S * 4, cap * 4, cap * 4, 4ul * S * 4, cap * 8, cap * 24, 16};
     for (int i = 0; i < 17; i++)
@@ -1044,6 +1045,9 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &ctx->pass_pinned, 4096, hipHostMallocDefault));
         ctx->pass_pinned_cap = 4096;
     }
+    if (ctx->sw.adaptive_trace)
+        fprintf(stderr, "ecal_detect_keyframes: scratch buffers ready after %.4f s (cap_points %u)\n",
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_scratch0).count(), cap_points);
     AdaptiveArrays a;
     {
         unsigned char *p = (unsigned char *) ctx->adaptive_state.ptr;
