@@ -197,62 +197,12 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
                           d_feat.data_ptr(), d_valid.data_ptr(), d_info.data_ptr(), st)
     rect_ok = d_info[:, 0].cpu().numpy().astype(bool)
     mark("rectify")
-    # the sequential gates of EventCalibIni.cpp:281-302 (checkPose against the last accepted keyframe, then rectify).  The
-    # test against the PREVIOUS keyframe is worked out for all keyframes at once; the loop falls back to the scalar test only
-    # where the last accepted keyframe is not the previous one (a rejection in between)
+    # the sequential gates of EventCalibIni.cpp:281-302 (checkPose against the last accepted keyframe, then rectify): the loop
+    # carries a dependence from frame to frame — host code of the library (ecal_pose_gates), the same operations as
+    # EventCalibIni::checkPose in the shim (host/event_calib_ini.hpp); 6 ms as a Python loop on 9227 keyframes
     kt = kf["time"]
-    pair_ok = np.zeros(K, bool)
-    if K > 1:
-        dt = kt[1:] - kt[:-1]
-        v_t = np.linalg.norm(twb[1:] - twb[:-1], axis=1) / dt
-        c = (np.einsum("nij,nij->n", Rsw[1:], Rsw[:-1]) - 1) * 0.5          # trace(R_cur R_ref^T)
-        v_r = np.abs(np.arccos(np.minimum(1.0, np.maximum(-1.0, c))) / dt)
-        pair_ok[1:] = (v_t < (2.5e-1 / step) * 2) & (v_r < (5e-4 * np.pi) * 2 / step)
-    acc, last, n_check, n_rect = [], -1, 0, 0
-    # a keyframe that passes all three precomputed tests right after an accepted one is accepted: such runs are taken in one
-    # piece, the loop below only walks the frames around a rejection
-    regular = ok & pair_ok & rect_ok
-    irregular = np.flatnonzero(~regular)
-    ok_l, rect_l, pair_l = ok.tolist(), rect_ok.tolist(), pair_ok.tolist()
-    # (the scalar test below runs once per frame behind a rejection — thousands of times on a long stream —: rotations, positions
-    # and times as Python lists, converted once)
-    import math
-    # (ONE flat list each: thousands of small lists kept alive push the interpreter's collector into full collections — 6 ms
-    # in a fresh process, 56 ms at the end of bench.py's)
-    R_l, tw_l, kt_l = Rsw.reshape(-1).tolist(), twb.reshape(-1).tolist(), kt.tolist()
-    lim_t, lim_r = (2.5e-1 / step) * 2, (5e-4 * math.pi) * 2 / step
-
-    def pose_ok(last, f):   # check_pose(Rsw[last], twb[last], kt[last], Rsw[f], twb[f], kt[f], step), the same operations
-        dt = kt_l[f] - kt_l[last]
-        a, b = 3 * f, 3 * last
-        d0, d1, d2 = tw_l[a] - tw_l[b], tw_l[a + 1] - tw_l[b + 1], tw_l[a + 2] - tw_l[b + 2]
-        v_t = math.sqrt(d0 * d0 + d1 * d1 + d2 * d2) / dt
-        ra, rb = 9 * f, 9 * last
-        tr = 0.0
-        for i in range(9):
-            tr += R_l[ra + i] * R_l[rb + i]
-        c = (tr - 1) * 0.5
-        v_r = abs(math.acos(min(1.0, max(-1.0, c))) / dt)
-        return v_t < lim_t and v_r < lim_r
-
-    f = 0
-    while f < K:
-        if last == f - 1 and last >= 0 and regular[f]:
-            g = int(irregular[np.searchsorted(irregular, f)]) if len(irregular) and irregular[-1] > f else K   # next frame that is not
-            acc.extend(range(f, g))
-            last = g - 1
-            f = g
-            continue
-        if not ok_l[f] or (last >= 0 and not (pair_l[f] if last == f - 1 else pose_ok(last, f))):
-            n_check += 1
-        elif not rect_l[f]:
-            n_rect += 1
-        else:
-            acc.append(f)
-            last = f
-        f += 1
+    acc, n_check, n_rect = capi.pose_gates(Rsw, twb, kt, ok, rect_ok, step)
     out["init"].update(accepted=len(acc), discarded_by_check_pose=n_check, discarded_by_rectify=n_rect)
-    acc = np.array(acc, np.int64)
     mark("check_pose_gates")
     if len(acc) <= 10:
         raise RuntimeError("too few frames in the map.")     # EventCalibSpline.cpp:26-28

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "ecal_solver_solve", "ecal_inverse_radial_distortion", "ecal_solver_create_dev", "ecal_solver_num_residuals",
     "ecal_associate_ranges_dev", "ecal_ref_nth_element_f64", "ecal_solver_create_from_stream", "ecal_rectify_keyframes", "ecal_solver_time_shard_cuts",
     "ecal_slice_events_packed_dev", "ecal_dbscan_batch_packed_dev", "ecal_extract_batch_packed_dev", "ecal_unpack_points_dev",
-    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval", "ecal_spline_so3_refine",
+    "ecal_calib_default_options", "ecal_calib_view_blocks_dev", "ecal_pnp_batch_dev", "ecal_pnp_batch", "ecal_pose_gates", "ecal_calibrate_views", "ecal_spline_fit", "ecal_spline_eval", "ecal_spline_so3_refine",
 ]
 
 
@@ -526,6 +526,29 @@ def time_shard_cuts(knots, n_cp, world_size):
     if rc:
         raise EcalError(rc, "ecal_solver_time_shard_cuts")
     return out[:world_size - 1]
+
+
+def pose_gates(Rsw, twb, time, pnp_ok, rect_ok, motion_time_step):
+    """ecal_pose_gates: the sequential keyframe gates of EventCalibIni::cvCalibration (EventCalibIni.cpp:281-302) on per-frame
+    results known for all frames.  Returns (accepted indices int64, discarded by checkPose, discarded by rectify)."""
+    L = load_library()
+    u8p, u32p, f64p = ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_double)
+    L.ecal_pose_gates.argtypes = [ctypes.c_uint32, f64p, f64p, f64p, u8p, u8p, ctypes.c_double, u32p, u32p, u32p, u32p]
+    L.ecal_pose_gates.restype = ctypes.c_int
+    R = np.ascontiguousarray(Rsw, np.float64).reshape(-1, 9)
+    K = R.shape[0]
+    tw = np.ascontiguousarray(twb, np.float64).reshape(K, 3)
+    tt = np.ascontiguousarray(time, np.float64).reshape(K)
+    a = np.ascontiguousarray(pnp_ok, np.uint8).reshape(K)
+    b = np.ascontiguousarray(rect_ok, np.uint8).reshape(K)
+    acc = np.zeros(max(K, 1), np.uint32)
+    n = (ctypes.c_uint32 * 3)()
+    rc = L.ecal_pose_gates(K, R.ctypes.data_as(f64p), tw.ctypes.data_as(f64p), tt.ctypes.data_as(f64p), a.ctypes.data_as(u8p),
+                           b.ctypes.data_as(u8p), float(motion_time_step), acc.ctypes.data_as(u32p),
+                           ctypes.cast(ctypes.byref(n, 0), u32p), ctypes.cast(ctypes.byref(n, 4), u32p), ctypes.cast(ctypes.byref(n, 8), u32p))
+    if rc:
+        raise EcalError(rc, "ecal_pose_gates: invalid arguments")
+    return acc[:n[0]].astype(np.int64), int(n[1]), int(n[2])
 
 
 def inverse_radial_distortion(k4):

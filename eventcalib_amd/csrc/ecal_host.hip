@@ -785,3 +785,38 @@ extern "C" int ecal_rectify_batch(ecal_ctx *ctx, const double *xy, const uint32_
     ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
     return ECAL_OK;
 }
+
+// ---- the sequential keyframe gates of the init stage (host only) ------------------------------------------------------------
+extern "C" int ecal_pose_gates(uint32_t n_frames, const double *Rsw, const double *twb, const double *time, const uint8_t *pnp_ok,
+                               const uint8_t *rect_ok, double motion_time_step, uint32_t *accepted, uint32_t *n_accepted,
+                               uint32_t *n_discarded_by_check_pose, uint32_t *n_discarded_by_rectify) {
+    if (!n_accepted || (n_frames && (!Rsw || !twb || !time || !pnp_ok || !rect_ok || !accepted)) || !(motion_time_step > 0)) return ECAL_ERR_INVALID;
+    const double lim_t = (2.5e-1 / motion_time_step) * 2, lim_r = (5e-4 * M_PI) * 2 / motion_time_step;
+    uint32_t na = 0, nc = 0, nr = 0;
+    long last = -1;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        bool pose = pnp_ok[f] != 0;
+        if (pose && last >= 0) {   // EventCalibIni::checkPose against the last accepted frame
+            const double dt = time[f] - time[last];
+            const double d0 = twb[3 * f] - twb[3 * last], d1 = twb[3 * f + 1] - twb[3 * last + 1], d2 = twb[3 * f + 2] - twb[3 * last + 2];
+            const double v_t = std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) / dt;
+            double tr = 0.0;
+            for (int i = 0; i < 9; i++) tr += Rsw[9 * (size_t) f + i] * Rsw[9 * (size_t) last + i];
+            const double c = (tr - 1) * 0.5;
+            const double v_r = std::fabs(std::acos(std::min(1.0, std::max(-1.0, c))) / dt);
+            pose = v_t < lim_t && v_r < lim_r;
+        }
+        if (!pose) {
+            nc++;
+        } else if (!rect_ok[f]) {
+            nr++;
+        } else {
+            accepted[na++] = f;
+            last = (long) f;
+        }
+    }
+    *n_accepted = na;
+    if (n_discarded_by_check_pose) *n_discarded_by_check_pose = nc;
+    if (n_discarded_by_rectify) *n_discarded_by_rectify = nr;
+    return ECAL_OK;
+}

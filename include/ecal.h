@@ -747,6 +747,16 @@ int ecal_pnp_batch_dev(ecal_ctx *ctx, const double *d_obj, uint32_t n_pts, const
 int ecal_pnp_batch(ecal_ctx *ctx, const double *obj, uint32_t n_pts, const double *img, const uint32_t *valid /*or NULL*/,
                    uint32_t n_frames, int model, const double *intr /*[12]*/, double reproj_thresh, int rounds, int refine_iters,
                    double *pose /*[F][6]*/, uint32_t *inlier /*or NULL*/, double *err /*or NULL*/, uint32_t *ok /*or NULL*/);
+/* The sequential keyframe gates of EventCalibIni::cvCalibration (event_camera_calib/src/EventCalibIni.cpp:281-302) on results that
+ * are known for all keyframes at once (ecal_pnp_batch, ecal_rectify_keyframes): frame f, in time order, is discarded when its PnP
+ * failed or EventCalibIni::checkPose (:327-347: translational speed |twb_f - twb_last| / dt below (0.25 / step) * 2 and angular
+ * speed |acos((trace(Rsw_f Rsw_last^T) - 1) / 2)| / dt below (5e-4 pi) * 2 / step) fails against the LAST ACCEPTED frame (the first
+ * accepted frame has none to be checked against), then when its rectification failed; otherwise it is accepted.  Host code, no
+ * context: the loop carries a dependence from frame to frame.  accepted[0 .. *n_accepted) = the accepted frames' indices. */
+int ecal_pose_gates(uint32_t n_frames, const double *Rsw /*[F][9] row-major*/, const double *twb /*[F][3]*/, const double *time /*[F]*/,
+                    const uint8_t *pnp_ok /*[F]*/, const uint8_t *rect_ok /*[F]*/, double motion_time_step,
+                    uint32_t *accepted /*[F]*/, uint32_t *n_accepted, uint32_t *n_discarded_by_check_pose,
+                    uint32_t *n_discarded_by_rectify);
 int ecal_calibrate_views(ecal_ctx *ctx, const double *obj /*[n_pts][3]*/, uint32_t n_pts, const double *img /*[V][n_pts][2]*/,
                          uint32_t n_views, double width, double height, const ecal_calib_options *opt, ecal_calib_result *res,
                          double *rvecs /*[V][3] or NULL*/, double *tvecs /*[V][3] or NULL*/, double *per_view_err /*[V] or NULL*/);
