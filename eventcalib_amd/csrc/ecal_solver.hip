@@ -77,6 +77,14 @@ __device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_i
 // will not keep a second row in flight).  These helpers issue a row's reads and wait for the reads issued BEFORE the last
 // six: the loop keeps one row in flight behind the row it is multiplying.  (LDS operations of a wave complete in order.)
 typedef double ne_v2d __attribute__((ext_vector_type(2)));
+// The Gram accumulation on the matrix cores (v_mfma_f64_4x4x4_4b_f64, 16 rows per instruction round) unless built with
+// -DECAL_NE_FMA_TILES (the register-tiled v_fma_f64 form of rounds 2 - 5, kept for the A/B of profiles/r06_notes.md)
+#ifdef ECAL_NE_FMA_TILES
+constexpr bool NE_USE_MFMA = false;
+#else
+constexpr bool NE_USE_MFMA = true;
+#endif
+__host__ __device__ constexpr int ne_swz(int c) { return 16 * (c & 1) ^ 2 * ((c >> 1) & 1); }
 // (profiling builds: -DECAL_NE_SKIP_P1 / -DECAL_NE_SKIP_P2 drop the residual code / the Gram accumulation, -DECAL_NE_P2_NOLDS /
 // -DECAL_NE_P2_NOFMA keep the accumulation's FMAs without its LDS reads / its reads without the FMAs: the phase split of
 // profiles/r02_notes.md.  Results are meaningless in those builds.)
@@ -204,9 +212,12 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
                                                          double *__restrict__ heads, const NeProgress *__restrict__ prog,
                                                          uint32_t epoch) {
     constexpr bool with_jac = WITH_JAC;
-    constexpr int NE_TW = SO3 ? 4 : 6;
-    constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES, NE_GROUPS = NeTiles<NE_TW>::GROUPS;
-    extern __shared__ __attribute__((aligned(16))) double rows[];  // [NE_T][NE_LD] when with_jac
+    constexpr bool MFMA = NE_USE_MFMA;
+    constexpr int NE_TW = (SO3 || MFMA) ? 4 : 6;
+    constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES;
+    constexpr int NE_GROUPS = MFMA ? NE_T / 64 : NeTiles<NE_TW>::GROUPS;   // MFMA: a wave is a row group
+    constexpr int NE_NACC = MFMA ? NE_TILES : NE_TW * NE_TW;               // MFMA: one D entry per lane and tile pair
+    extern __shared__ __attribute__((aligned(16))) double rows[];  // [NE_T][NE_LD] when with_jac (MFMA: [4 waves][NE_LD columns][64 rows])
     __shared__ double red[NE_T / 64];
     const Chunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x;
@@ -235,11 +246,23 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
         }
         tj = ti + rem;
     }
-    const int grp = tid / NE_TILES;
-    double acc[NE_TW * NE_TW];
+    const int grp = MFMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / NE_TILES;
+    double acc[NE_NACC];
 #pragma unroll
-    for (int i = 0; i < NE_TW * NE_TW; i++) acc[i] = 0.0;
+    for (int i = 0; i < NE_NACC; i++) acc[i] = 0.0;
     double cost = 0.0;
+    // MFMA form: this wave's slab of the row buffer, column-major ([column][row of the wave's 64]) with the row index XOR-ed by
+    // ne_swz(column): lane l WRITES its row's entry of column c at c * 64 + (l ^ swz(c)) — a permutation of 64 consecutive
+    // doubles, conflict-free — and lane (x, blk, k) = (l & 3, (l >> 2) & 3, l >> 4) READS entry [row 16 s + 4 blk + k][column
+    // 4 t + x], the operand of v_mfma_f64_4x4x4_4b for column tile t in the 16-row step s: A[blk][i = x][k] as the left tile,
+    // B[blk][k][j = x] as the right one — the same register (profiles/r05_mfma_f64_probe.txt).  swz(c) = 16 (c & 1) ^ 2 (c & 2 ? 1 : 0)
+    // puts the 32 lanes of either half-wave on 32 different 8-byte bank pairs.
+    double *const slab = rows + (size_t) grp * (NE_LD * 64);
+    const int lane = tid & 63;
+    if constexpr (MFMA && with_jac) {
+        slab[34 * 64 + lane] = 0.0;     // the two padding columns of tile 8: written once
+        slab[35 * 64 + lane] = 0.0;
+    }
 
     // the record of the NEXT batch is asked for before this batch's residual is evaluated: its trip to HBM (the only one a
     // batch makes) runs behind ~2000 cycles of arithmetic instead of in front of them
@@ -277,7 +300,38 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             sc = huber_scale(r, huber_a, &hr);
             cost += hr;
         }
-        if (with_jac) {
+        if constexpr (with_jac && MFMA) {
+            const bool live = k < ch.count;
+#pragma unroll
+            for (int i = 0; i < RES_NJ; i++) slab[i * 64 + (lane ^ ne_swz(i))] = live ? J[i] * sc : 0.0;
+            slab[33 * 64 + (lane ^ ne_swz(33))] = live ? r * sc : 0.0;
+            // the slab is this wave's alone: no workgroup barrier.  A wave's LDS operations complete in order; the fence keeps the
+            // compiler from moving the reads above the writes (other lanes' data) or the next batch's writes above these reads.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#ifndef ECAL_NE_SKIP_P2
+            const uint32_t nrow = min((uint32_t) NE_T, ch.count - b0);
+            const int x = lane & 3, r0 = ((lane >> 2) & 3) * 4 + (lane >> 4);
+            const int pb = x * 64 + (r0 ^ (x & 2));                   // (row ^ swz) = 16 (s ^ (x & 1)) + (r0 ^ (x & 2))
+            const double *const base_e = slab + pb + 16 * (x & 1);      // even steps (s = 0, 2): + 32 (s >> 1)
+            const double *const base_o = slab + pb + 16 * (1 - (x & 1));  // odd steps
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                if ((uint32_t) (64 * grp + 16 * s4) >= nrow) break;     // wave-uniform: only the chunk's last batch
+                const double *const bs = ((s4 & 1) ? base_o : base_e) + 32 * (s4 >> 1);
+                double R[NE_TG];
+#pragma unroll
+                for (int t9 = 0; t9 < NE_TG; t9++) R[t9] = bs[t9 * 256];
+                int p = 0;
+#pragma unroll
+                for (int ta = 0; ta < NE_TG; ta++)
+#pragma unroll
+                    for (int tb = ta; tb < NE_TG; tb++, p++) acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(R[ta], R[tb], acc[p], 0, 0, 0);
+            }
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else if constexpr (with_jac) {
             double *row = rows + (size_t) tid * NE_LD;
             if (k < ch.count) {
 #pragma unroll
@@ -359,7 +413,17 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
         double *total = rows;                        // (in place of group 0's slice: entry e is read and written by ONE thread)
         static_assert(NE_GROUPS * NPART <= NE_T * NE_LD, "the row buffer holds the partial tiles");
         __syncthreads();
-        if (grp < NE_GROUPS) {
+        if constexpr (MFMA) {
+            // D[blk][i][j] of tile pair p sits in lane j + 4 blk + 16 i: the four blocks (this wave's rows 4 blk + k of every step)
+            // are summed across lane bits 2-3, block 0's lanes store entry (i, j) of the wave's partial tile
+#pragma unroll
+            for (int p = 0; p < NE_TILES; p++) {
+                double v = acc[p];
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                if ((lane & 12) == 0) part[(size_t) grp * NPART + p * TSZ + 4 * (lane >> 4) + (lane & 3)] = v;
+            }
+        } else if (grp < NE_GROUPS) {
 #pragma unroll
             for (int i = 0; i < TSZ; i++) part[(size_t) grp * NPART + (tid % NE_TILES) * TSZ + i] = acc[i];
         }
