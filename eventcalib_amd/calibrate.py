@@ -94,7 +94,7 @@ def check_pose(R_ref, twb_ref, t_ref, R_cur, twb_cur, t_cur, step):
 def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, frame_event_num_threshold=4000, piece_num=30,
                      frames_to_use=200, width=346.0, height=260.0, rows=9, cols=4, square=5.5, circle_radius=1.75,
                      flags=None, aspect_ratio=1.0, use_so3=False, max_num_iterations=50, eps=4.0, minpts=2,
-                     gate_mode=capi.GATE_SHARED_MAP, fisheye=False):
+                     gate_mode=capi.GATE_SHARED_MAP, fisheye=False, tables=False):
     """events: uint8 CUDA tensor of packed 25-byte records.  Returns a dict with the initial calibration, the refined
     intrinsics [fx fy cx cy k1..k5 (inverse radial polynomial)] and the keyframe trajectory.
     gate_mode: capi.GATE_SHARED_MAP (default: the reference's keyframe gate as its single-worker run computes it — one keyframe
@@ -102,7 +102,9 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     first success ungated).
     fisheye (Calibrate_UseFisheyeModel: 1; BASELINE configs[4]): cv::fisheye::calibrate's model in the init stage
     (EventCalibIni.cpp:186-190), and — new: the reference stops at EventCalibSpline.cpp:97-99 — the Kannala-Brandt camera in
-    the PnP, in rectifyFeatures' projections and in the spline solve (k1..k5 = the inverse angle polynomial)."""
+    the PnP, in rectifyFeatures' projections and in the spline solve (k1..k5 = the inverse angle polynomial).
+    tables: also return the per-stage tables (keyframe records, PnP poses and verdicts, rectified circles, accepted frames, the
+    spline's start) that tests/test_gpu_oracle_chain.py compares with the CPU oracle chain."""
     if flags is None:
         flags = EXAMPLE_FLAGS_FISHEYE if fisheye else EXAMPLE_FLAGS
     model = 1 if fisheye else 0
@@ -174,11 +176,12 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     pipe.set_windows(kf["duration"][:, 0], kf["duration"][:, 1])
     # (every size tier at work: these windows are 4 - 10 steps long, and what the stages' previous call saw — the search's last
     # pass, its lists all but empty — would send the whole batch through the one slow general launch: 9.4 ms instead of 3)
+    was_mode = ctx.get_tail_mode()      # (the caller's choice comes back afterwards, as in ecal_rectify_keyframes)
     ctx.set_tail_mode("tiered")
     try:
         pipe.run(events, eps, minpts)
     finally:
-        ctx.set_tail_mode("auto")
+        ctx.set_tail_mode(was_mode)
     mark("rectify_detection")
     prm = capi.RectifyParams()
     prm.fx, prm.fy, prm.cx, prm.cy = intr0[:4]
@@ -203,6 +206,10 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     kt = kf["time"]
     acc, n_check, n_rect = capi.pose_gates(Rsw, twb, kt, ok, rect_ok, step)
     out["init"].update(accepted=len(acc), discarded_by_check_pose=n_check, discarded_by_rectify=n_rect)
+    if tables:
+        out["kf"] = kf
+        out["pose"] = dict(Rsw=Rsw, tsw=tsw, ok=ok, rect_ok=rect_ok, rect=d_feat.cpu().numpy())
+        out["accepted"] = np.asarray(acc)
     mark("check_pose_gates")
     if len(acc) <= 10:
         raise RuntimeError("too few frames in the map.")     # EventCalibSpline.cpp:26-28
@@ -274,6 +281,10 @@ def calibrate_stream(ctx, events, t_first, t_last, *, motion_time_step=5e-4, fra
     solver = capi.Solver(ctx, prob, device_arrays=(d_o.data_ptr(), d_t.data_ptr(), d_l.data_ptr(), d_s.data_ptr(), n_events,
                                                    d_c.data_ptr()), stream=st)
     n_res = solver.n_res
+    if tables:
+        m = int(d_c.item())
+        out["spline_start"] = dict(knots=prob["knots"], x0=x0, residuals=m, obs=d_o[:m].cpu().numpy(), time=d_t[:m].cpu().numpy(),
+                                   lm_id=d_l[:m].cpu().numpy())
     del d_o, d_t, d_l, d_s
     mark("solver_setup")
     opt = solver.default_options()

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "ecal_window_bounds_dev", "ecal_check_sorted_dev", "ecal_sort_events_dev", "ecal_slice_events_dev",
     "ecal_set_point_order", "ecal_get_point_order", "ecal_ref_bucket_step", "ecal_ref_pixel_hash",
     "ecal_comm_unique_id", "ecal_comm_init", "ecal_comm_destroy", "ecal_comm_size", "ecal_comm_rank", "ecal_comm_allreduce_sum_dev", "ecal_comm_allreduce",
-    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_set_median_ties", "ecal_set_tail_mode", "ecal_calibrate_fisheye_views", "ecal_set_profile_ranges",
+    "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_set_median_ties", "ecal_set_tail_mode", "ecal_get_tail_mode", "ecal_calibrate_fisheye_views", "ecal_set_profile_ranges",
     "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
@@ -269,6 +269,15 @@ class Context:
         code = {"auto": 0, "tiered": 1, "lean": 2, 0: 0, 1: 1, 2: 2}[mode]
         self._L.ecal_set_tail_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
         self._check(self._L.ecal_set_tail_mode(self._h, code))
+
+    def get_tail_mode(self):
+        """The mode in force as its number (TAIL_AUTO / TAIL_TIERED / TAIL_LEAN): set_tail_mode takes it back."""
+        self._L.ecal_get_tail_mode.argtypes = [ctypes.c_void_p]
+        self._L.ecal_get_tail_mode.restype = ctypes.c_int
+        mode = self._L.ecal_get_tail_mode(self._h)
+        if mode < 0:
+            self._check(mode)
+        return mode
 
     def set_profile_ranges(self, on=True):
         """roctx ranges around the stage entry points (ecal_set_profile_ranges) for `rocprofv3 --marker-trace --kernel-trace`."""

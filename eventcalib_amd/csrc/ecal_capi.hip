@@ -31,7 +31,6 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.solver_device_linear_solve = on("ECAL_SOLVER_DEVICE_LINEAR_SOLVE");
     sw.solver_trace = on("ECAL_SOLVER_TRACE");
     sw.solver_no_stream = on("ECAL_SOLVER_NO_STREAM");
-    sw.solver_two_roles = on("ECAL_SOLVER_TWO_ROLES");
     sw.adaptive_dir_kernel = on("ECAL_ADAPTIVE_DIR_KERNEL");
     sw.adaptive_verify_in_alloc = on("ECAL_ADAPTIVE_VERIFY_IN_ALLOC");
     sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
@@ -227,6 +226,7 @@ extern "C" int ecal_debug_tail_seen(ecal_ctx *ctx, uint32_t *out16) {
     return ECAL_OK;
 }
 
+extern "C" int ecal_get_tail_mode(const ecal_ctx *ctx) { return ctx ? ctx->tail_mode : ECAL_ERR_INVALID; }
 extern "C" int ecal_set_tail_mode(ecal_ctx *ctx, int mode) {
     if (!ctx || mode < ECAL_TAIL_AUTO || mode > ECAL_TAIL_LEAN) return ECAL_ERR_INVALID;
     ctx->tail_mode = mode;

@@ -26,7 +26,7 @@ struct ecal_switches {
     bool dbscan_no_pixel = false, dbscan_no_second_pass = false, dbscan_generic_disc = false;
     bool extract_no_second_pass = false, extract_no_inline_ties = false, no_fused_pass = false, no_zero_ring = false;
     bool grid_one_wave = false;
-    bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, solver_two_roles = false, adaptive_dir_kernel = false, adaptive_verify_in_alloc = false;
+    bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, adaptive_dir_kernel = false, adaptive_verify_in_alloc = false;
     int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_live_floor = 0, adaptive_side = -1, adaptive_tree = -1, adaptive_grid_pieces = 0, arrow_k = 0;   // 0: not set
     unsigned long long bo_big_arena = 0;                            // 0: not set
     double grid_tol_px = 20.0;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *_
     // no such pairs, and a spurious neighbour of a true point has no antipode.  The FIRST start is the plain one, as it has
     // always been — the candidate nearest the centroid, its nearest neighbour and the nearest one not parallel to it, both
     // attempts —, so nothing that was found before is lost and a window that is found at once costs what it did.  When it finds
-    // no grid although there are more candidates than pattern points (clutter), a ROBUST start follows: the seed is the
+    // no grid (round 4: only with more candidates than pattern points; round 6: always), a ROBUST start follows: the seed is the
     // candidate nearest the centroid that has two independent PAIRED neighbour vectors (GR_SEEDS are looked at), its steps the
     // plain rule's when both of those are paired, else the shortest two independent paired vectors; both attempts when the
     // first walk places two thirds of the pattern.  Then up to two more starts from the next such seeds, first walk only.  (Measured on the 50 M-event search, 1270 pieces: five extra starts
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *_
     // begins (a start without a basis ends the sequence: then this wave has no start to run)
     bool runnable = true;
     if constexpr (NW > 1) {
-        if (wv > 0u && n <= M) runnable = false;
+        if (wv > 0u && n < M) runnable = false;
         double t0_, t1_, t2_, t3_;
         if (runnable && wv >= 2u) {   // start 1's seed search
             bool have1 = false;
@@ -455,7 +455,11 @@ __global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *_
 #define GR_CANCELLED(start_) (NW > 1 && *reinterpret_cast<volatile uint32_t *>(&best_start_sh) < (uint32_t) (start_))
 #pragma nounroll
     for (int start = (NW > 1 ? (int) wv : 0); start <= (NW > 1 ? (int) wv : GR_EXTRA) && !got && runnable; start++) {
-    if (start > 0 && n <= M) break;   // (exactly the pattern's count of candidates: no clutter to have misled the first start)
+    // (round 6: the later starts run for windows with EXACTLY the pattern's count of candidates too — until then "no clutter to have
+    // misled the first start" ended them here; the midpoint circles of a 4 - 6 step window are up to 8 px off their centres, and the
+    // plain start lost 9 of 723 such windows of tests/test_gpu_oracle_chain.py's search that hold the 36 circles and nothing else:
+    // 2 of 725 now, the 1270-piece search's time unchanged)
+    if (start > 0 && n < M) break;
     if (start > 0) {   // the previous start's walk is wiped
         for (uint32_t i = lane; i < n; i += GR_T) assigned[i] = 0;
         for (uint32_t k = lane; k < GR_L * GR_L; k += GR_T) occ[k] = 0;

@@ -8,10 +8,12 @@
 //   CalibReprojectionError::operator() (EventCalibSpline.hpp:158-229) — see spline_residual.hpp.
 // Residuals are sorted by (segment, time); a "chunk" is a run of residuals inside one knot span, so all
 // its rows share the same 33 columns and J^T J of the chunk is one dense 34x34 (33 + residual) Gram
-// matrix.  It is accumulated with register-tiled FP64 FMAs (6x6 tiles).  The matrix cores were tried and measured
-// (profiles/experiments/r02_normal_eq_mfma_f64.patch): v_mfma_f64_16x16x4_f64 pads 34 columns to 48 (six 16x16 tiles,
-// 2x the multiply-adds) and runs at 46 - 50 TFLOP/s on this part against 65 - 72 for plain v_fma_f64
-// (profiles/experiments/r02_fp64_*_rate.hip): 4.63 ms per evaluation against 3.59.
+// matrix: a genuine dense contraction, accumulated on the matrix cores with v_mfma_f64_4x4x4_4b_f64 (nine 4-column tiles of
+// the padded 36 columns, 45 tile pairs, 16 rows per round — see normal_eq_kernel).  History of the alternatives, each with its
+// measurement: v_mfma_f64_16x16x4_f64 (34 -> 48 columns, 2x the multiply-adds: 4.63 ms per evaluation against 3.59,
+// profiles/experiments/r02_normal_eq_mfma_f64.patch); register-tiled v_fma_f64 (6x6 tiles, rounds 2 - 5: 2.28 ms) and
+// producer / consumer waves on those tiles (2.70 ms) against this kernel's 1.71 ms at 45 M residuals
+// (profiles/experiments/r06_normal_eq_fma_tiles_and_two_roles.patch, profiles/r06_ne_mfma_vs_fma.txt).
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -42,15 +44,8 @@ struct Chunk {
 
 constexpr int NE_T = 256;   // threads per workgroup = rows per batch
 constexpr int NE_LD = 36;   // padded row: 33 Jacobian entries, the residual, 2 zeros
-// Register tiles of the Gram accumulation: TW x TW doubles per thread over the padded 36 columns.  TW = 6 (21 tiles of
-// the upper triangle x 12 row groups = 252 threads, 2.7 LDS bytes per FMA) for the quaternion variant; the SO3 variant's
-// residual code needs the registers, so it keeps TW = 4 (45 tiles x 5 row groups = 225 threads, 4 bytes per FMA).
-template <int TW>
-struct NeTiles {
-    static constexpr int TG = NE_LD / TW;
-    static constexpr int TILES = TG * (TG + 1) / 2;
-    static constexpr int GROUPS = NE_T / TILES;
-};
+// Gram accumulation: 4-column tiles of the padded row (v_mfma_f64_4x4x4_4b_f64 multiplies four 4x4 blocks per instruction)
+constexpr int NE_TW = 4, NE_TG = NE_LD / NE_TW, NE_TILES = NE_TG * (NE_TG + 1) / 2, NE_WAVES = NE_T / 64;
 constexpr uint32_t NE_CHUNK = 16384;  // residuals per workgroup (one span): few, long chunks keep the FP64 atomics rare
 constexpr uint32_t NE_REPL = 64;      // replicas of the shared head (cost, intrinsics block) that the chunks add into
 
@@ -72,47 +67,10 @@ __device__ __forceinline__ void local_to_unknown(int li, uint32_t c0, bool &is_i
     }
 }
 
-// The Gram accumulation reads two tile slices of a row (six 16-byte LDS reads) per 36 FMAs.  Left to the compiler every row's
-// reads sit at the top of their own iteration and their latency opens it (the kernel is at the register limit: the scheduler
-// will not keep a second row in flight).  These helpers issue a row's reads and wait for the reads issued BEFORE the last
-// six: the loop keeps one row in flight behind the row it is multiplying.  (LDS operations of a wave complete in order.)
-typedef double ne_v2d __attribute__((ext_vector_type(2)));
-// The Gram accumulation on the matrix cores (v_mfma_f64_4x4x4_4b_f64, 16 rows per instruction round) unless built with
-// -DECAL_NE_FMA_TILES (the register-tiled v_fma_f64 form of rounds 2 - 5, kept for the A/B of profiles/r06_notes.md)
-#ifdef ECAL_NE_FMA_TILES
-constexpr bool NE_USE_MFMA = false;
-#else
-constexpr bool NE_USE_MFMA = true;
-#endif
+// (profiling builds: -DECAL_NE_SKIP_P1 / -DECAL_NE_SKIP_P2 drop the residual code / the Gram accumulation: the phase split of
+// profiles/r06_notes.md.  Results are meaningless in those builds.)
+// Row index swizzle of the wave's column-major slab (see normal_eq_kernel)
 __host__ __device__ constexpr int ne_swz(int c) { return 16 * (c & 1) ^ 2 * ((c >> 1) & 1); }
-// (profiling builds: -DECAL_NE_SKIP_P1 / -DECAL_NE_SKIP_P2 drop the residual code / the Gram accumulation, -DECAL_NE_P2_NOLDS /
-// -DECAL_NE_P2_NOFMA keep the accumulation's FMAs without its LDS reads / its reads without the FMAs: the phase split of
-// profiles/r02_notes.md.  Results are meaningless in those builds.)
-__device__ __forceinline__ void ne_lds_read6(uint32_t a_addr, uint32_t b_addr, ne_v2d (&A)[3], ne_v2d (&B)[3]) {
-#ifdef ECAL_NE_P2_NOLDS
-    asm volatile("" : "=v"(A[0]), "=v"(A[1]), "=v"(A[2]), "=v"(B[0]), "=v"(B[1]), "=v"(B[2]) : "v"(a_addr), "v"(b_addr));
-    return;
-#endif
-    asm volatile(
-        "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
-        "ds_read_b128 %3, %7\n\tds_read_b128 %4, %7 offset:16\n\tds_read_b128 %5, %7 offset:32"
-        : "=&v"(A[0]), "=&v"(A[1]), "=&v"(A[2]), "=&v"(B[0]), "=&v"(B[1]), "=&v"(B[2])
-        : "v"(a_addr), "v"(b_addr));
-}
-__device__ __forceinline__ void ne_lds_wait_but6(ne_v2d (&A)[3], ne_v2d (&B)[3]) {
-    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]));
-}
-__device__ __forceinline__ void ne_fma36(double (&acc)[36], const ne_v2d (&A)[3], const ne_v2d (&B)[3]) {
-#ifdef ECAL_NE_P2_NOFMA
-    acc[0] += A[0].x + A[1].x + A[2].x + B[0].x + B[1].x + B[2].x;
-    return;
-#endif
-    const double a[6] = {A[0].x, A[0].y, A[1].x, A[1].y, A[2].x, A[2].y}, b[6] = {B[0].x, B[0].y, B[1].x, B[1].y, B[2].x, B[2].y};
-#pragma unroll
-    for (int x = 0; x < 6; x++)
-#pragma unroll
-        for (int y = 0; y < 6; y++) acc[6 * x + y] += a[x] * b[y];
-}
 
 // A streamed evaluation (ecal_solver_solve, one rank, a long spline): the host factorises the interiors of its partition of the
 // control points (arrow_host_parts.hpp) WHILE the kernel is still accumulating the later ones.  The chunks are ordered by knot
@@ -212,12 +170,7 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
                                                          double *__restrict__ heads, const NeProgress *__restrict__ prog,
                                                          uint32_t epoch) {
     constexpr bool with_jac = WITH_JAC;
-    constexpr bool MFMA = NE_USE_MFMA;
-    constexpr int NE_TW = (SO3 || MFMA) ? 4 : 6;
-    constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES;
-    constexpr int NE_GROUPS = MFMA ? NE_T / 64 : NeTiles<NE_TW>::GROUPS;   // MFMA: a wave is a row group
-    constexpr int NE_NACC = MFMA ? NE_TILES : NE_TW * NE_TW;               // MFMA: one D entry per lane and tile pair
-    extern __shared__ __attribute__((aligned(16))) double rows[];  // [NE_T][NE_LD] when with_jac (MFMA: [4 waves][NE_LD columns][64 rows])
+    extern __shared__ __attribute__((aligned(16))) double rows[];  // with_jac: [NE_WAVES][NE_LD columns][64 rows]
     __shared__ double red[NE_T / 64];
     const Chunk ch = chunks[blockIdx.x];
     const int tid = threadIdx.x;
@@ -236,30 +189,23 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
         for (int k = 0; k < 4; k++) q[j][k] = qall[4 * (size_t) (c0 + j) + k];
         for (int k = 0; k < 3; k++) t[j][k] = tall[3 * (size_t) (c0 + j) + k];
     }
-    // tile owned by this thread in the accumulation phase
-    int ti = 0, tj = 0;
-    {
-        int rem = tid % NE_TILES;
-        for (ti = 0; ti < NE_TG; ti++) {
-            if (rem < NE_TG - ti) break;
-            rem -= NE_TG - ti;
-        }
-        tj = ti + rem;
-    }
-    const int grp = MFMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid / NE_TILES;
-    double acc[NE_NACC];
+    // Gram accumulation on the matrix cores.  v_mfma_f64_4x4x4_4b_f64 multiplies four independent 4x4x4 blocks: block blk takes
+    // rows 4 blk .. 4 blk + 3 of a 16-row step, and all four blocks multiply the same pair of column tiles (ta, tb), so lane
+    // (x, blk, k) = (l & 3, (l >> 2) & 3, l >> 4) supplies J[row 4 blk + k][column 4 ta + x] as A[blk][i = x][k] and
+    // J[row 4 blk + k][4 tb + x] as B[blk][k][j = x]: ONE register per column tile serves as the left and as the right operand
+    // (lane maps: profiles/r05_mfma_f64_probe.txt).  Nine 8-byte LDS reads per lane and 45 instructions per 16 rows; 45
+    // accumulators per lane (D[blk][i][j] of pair p in lane j + 4 blk + 16 i), summed over blk at the end of the chunk.
+    // The rows go through THIS WAVE's slab of the row buffer, column-major ([column][row of the wave's 64]) with the row index
+    // XOR-ed by ne_swz(column): lane l writes its row's entry of column c at c * 64 + (l ^ swz(c)) — a permutation of 64
+    // consecutive doubles, conflict-free — and the operand read above puts the 32 lanes of either half-wave on 32 different
+    // 8-byte bank pairs.  No other wave touches the slab: the batch loop has no workgroup barrier.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    double acc[NE_TILES];
 #pragma unroll
-    for (int i = 0; i < NE_NACC; i++) acc[i] = 0.0;
+    for (int i = 0; i < NE_TILES; i++) acc[i] = 0.0;
     double cost = 0.0;
-    // MFMA form: this wave's slab of the row buffer, column-major ([column][row of the wave's 64]) with the row index XOR-ed by
-    // ne_swz(column): lane l WRITES its row's entry of column c at c * 64 + (l ^ swz(c)) — a permutation of 64 consecutive
-    // doubles, conflict-free — and lane (x, blk, k) = (l & 3, (l >> 2) & 3, l >> 4) READS entry [row 16 s + 4 blk + k][column
-    // 4 t + x], the operand of v_mfma_f64_4x4x4_4b for column tile t in the 16-row step s: A[blk][i = x][k] as the left tile,
-    // B[blk][k][j = x] as the right one — the same register (profiles/r05_mfma_f64_probe.txt).  swz(c) = 16 (c & 1) ^ 2 (c & 2 ? 1 : 0)
-    // puts the 32 lanes of either half-wave on 32 different 8-byte bank pairs.
-    double *const slab = rows + (size_t) grp * (NE_LD * 64);
-    const int lane = tid & 63;
-    if constexpr (MFMA && with_jac) {
+    double *const slab = rows + (size_t) wave * (NE_LD * 64);
+    if constexpr (with_jac) {
         slab[34 * 64 + lane] = 0.0;     // the two padding columns of tile 8: written once
         slab[35 * 64 + lane] = 0.0;
     }
@@ -300,7 +246,7 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             sc = huber_scale(r, huber_a, &hr);
             cost += hr;
         }
-        if constexpr (with_jac && MFMA) {
+        if constexpr (with_jac) {
             const bool live = k < ch.count;
 #pragma unroll
             for (int i = 0; i < RES_NJ; i++) slab[i * 64 + (lane ^ ne_swz(i))] = live ? J[i] * sc : 0.0;
@@ -317,7 +263,7 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             const double *const base_o = slab + pb + 16 * (1 - (x & 1));  // odd steps
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
-                if ((uint32_t) (64 * grp + 16 * s4) >= nrow) break;     // wave-uniform: only the chunk's last batch
+                if ((uint32_t) (64 * wave + 16 * s4) >= nrow) break;     // wave-uniform: only the chunk's last batch
                 const double *const bs = ((s4 & 1) ? base_o : base_e) + 32 * (s4 >> 1);
                 double R[NE_TG];
 #pragma unroll
@@ -331,68 +277,6 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-        } else if constexpr (with_jac) {
-            double *row = rows + (size_t) tid * NE_LD;
-            if (k < ch.count) {
-#pragma unroll
-                for (int i = 0; i < RES_NJ; i++) row[i] = J[i] * sc;
-                row[33] = r * sc;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 34; i++) row[i] = 0.0;
-            }
-            row[34] = 0.0;
-            row[35] = 0.0;
-            __syncthreads();
-#ifdef ECAL_NE_SKIP_P2
-            if (false) {
-#else
-            if (grp < NE_GROUPS) {
-#endif
-                const uint32_t nrow = min((uint32_t) NE_T, ch.count - b0);
-                if constexpr (NE_TW == 6) {
-                    // one row in flight behind the row being multiplied (see ne_lds_read6); rows past the end are clamped reads
-                    // whose values are dropped
-                    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) double *) rows;
-                    const uint32_t a0 = lds0 + 8u * NE_TW * (uint32_t) ti, b0a = lds0 + 8u * NE_TW * (uint32_t) tj;
-                    constexpr uint32_t ROWB = NE_LD * 8u;
-                    ne_v2d A0[3], B0[3], A1[3], B1[3];
-                    {
-                        const uint32_t o = min((uint32_t) grp, nrow - 1u) * ROWB;
-                        ne_lds_read6(a0 + o, b0a + o, A0, B0);
-                    }
-                    for (uint32_t rk = grp; rk < nrow; rk += 2 * NE_GROUPS) {
-                        const uint32_t r1 = rk + NE_GROUPS, r2 = rk + 2 * NE_GROUPS;
-                        const uint32_t o1 = min(r1, nrow - 1u) * ROWB, o2 = min(r2, nrow - 1u) * ROWB;
-                        ne_lds_read6(a0 + o1, b0a + o1, A1, B1);
-                        ne_lds_wait_but6(A0, B0);
-                        ne_fma36(acc, A0, B0);
-                        ne_lds_read6(a0 + o2, b0a + o2, A0, B0);
-                        ne_lds_wait_but6(A1, B1);
-                        if (r1 < nrow) ne_fma36(acc, A1, B1);
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last (unused) prefetch, before the rows are rewritten
-                } else {
-                    for (uint32_t rk = grp; rk < nrow; rk += NE_GROUPS) {
-                        const double *rw = rows + (size_t) rk * NE_LD;
-                        double a[NE_TW], bb[NE_TW];
-#pragma unroll
-                        for (int x = 0; x < NE_TW; x += 2) {  // 16-byte LDS reads (tile starts are 48-byte aligned)
-                            const double2 av = *reinterpret_cast<const double2 *>(rw + NE_TW * ti + x);
-                            const double2 bv = *reinterpret_cast<const double2 *>(rw + NE_TW * tj + x);
-                            a[x] = av.x;
-                            a[x + 1] = av.y;
-                            bb[x] = bv.x;
-                            bb[x + 1] = bv.y;
-                        }
-#pragma unroll
-                        for (int x = 0; x < NE_TW; x++)
-#pragma unroll
-                            for (int y = 0; y < NE_TW; y++) acc[NE_TW * x + y] += a[x] * bb[y];
-                    }
-                }
-            }
-            __syncthreads();
         }
     }
     // cost: block reduction, one atomic per workgroup
@@ -405,33 +289,28 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
         atomicAdd(&head[0], c);
     }
     if (!with_jac) return;
-    // the row groups' partial tiles are summed in LDS (the row buffer is free now) so that ONE group flushes: the
-    // FP64 atomics of a chunk drop from NE_GROUPS x ~600 to ~600 (they were 0.67 GB of write traffic per launch)
+    // the waves' partial tiles are summed in LDS (the row buffer is free now) so that ONE set of FP64 atomics per chunk goes out
+    // (~600 instead of 4 x ~600)
     {
         constexpr int TSZ = NE_TW * NE_TW, NPART = NE_TILES * TSZ;
-        double *part = rows;                         // [NE_GROUPS][NE_TILES * TSZ]
-        double *total = rows;                        // (in place of group 0's slice: entry e is read and written by ONE thread)
-        static_assert(NE_GROUPS * NPART <= NE_T * NE_LD, "the row buffer holds the partial tiles");
+        double *part = rows;                         // [NE_WAVES][NE_TILES * TSZ]
+        double *total = rows;                        // (in place of wave 0's slice: entry e is read and written by ONE thread)
+        static_assert(NE_WAVES * NPART <= NE_T * NE_LD, "the row buffer holds the partial tiles");
         __syncthreads();
-        if constexpr (MFMA) {
-            // D[blk][i][j] of tile pair p sits in lane j + 4 blk + 16 i: the four blocks (this wave's rows 4 blk + k of every step)
-            // are summed across lane bits 2-3, block 0's lanes store entry (i, j) of the wave's partial tile
+        // D[blk][i][j] of tile pair p sits in lane j + 4 blk + 16 i: the four blocks (this wave's rows 4 blk + k of every step)
+        // are summed across lane bits 2-3, block 0's lanes store entry (i, j) of the wave's partial tile
 #pragma unroll
-            for (int p = 0; p < NE_TILES; p++) {
-                double v = acc[p];
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
-                if ((lane & 12) == 0) part[(size_t) grp * NPART + p * TSZ + 4 * (lane >> 4) + (lane & 3)] = v;
-            }
-        } else if (grp < NE_GROUPS) {
-#pragma unroll
-            for (int i = 0; i < TSZ; i++) part[(size_t) grp * NPART + (tid % NE_TILES) * TSZ + i] = acc[i];
+        for (int p = 0; p < NE_TILES; p++) {
+            double v = acc[p];
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            if ((lane & 12) == 0) part[(size_t) wave * NPART + p * TSZ + 4 * (lane >> 4) + (lane & 3)] = v;
         }
         __syncthreads();
         for (int e = tid; e < NPART; e += NE_T) {    // every thread sums a few entries over the groups
             double v = 0.0;
 #pragma unroll
-            for (int g = 0; g < NE_GROUPS; g++) v += part[(size_t) g * NPART + e];
+            for (int g = 0; g < NE_WAVES; g++) v += part[(size_t) g * NPART + e];
             total[e] = v;
         }
         __syncthreads();
@@ -476,201 +355,6 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
     if (prog) ne_publish_progress(prog, epoch, accum, c0, tid, NE_T);
 }
 
-// The same evaluation with the two phases of a batch on DIFFERENT waves (quaternion variant, round 4; ECAL_SOLVER_TWO_ROLES=1 —
-// measured in round 5: 2.70 ms per launch against 2.32 – 2.37 ms for the one-role kernel on the benchmark problem — round 4's
-// "equal" timed this kernel twice, profiles/r05_notes.md item 12 — so the one-role kernel is the default; it runs at ~70 % of
-// the FP64 issue slots the two phases need together).  In normal_eq_kernel every
-// wave evaluates 64 residuals (phase 1: ~700 flop of dependent spline arithmetic each, 241 VGPRs), waits at a barrier, and then
-// accumulates its Gram tiles over the batch's rows (phase 2: 36 FMAs per six 16-byte LDS reads), with the tiles' 72 accumulator
-// registers alive through phase 1 and the other workgroup of the CU as the only thing that may overlap the one phase with the
-// other.  Here a workgroup is 8 waves and owns the compute unit: waves 0-3 PRODUCE the rows of batch b + 1 into one half of a
-// double row buffer while waves 4-7 CONSUME batch b from the other half — one barrier per batch, a producer and a consumer wave on
-// every SIMD, so the SIMD's FP64 pipe always has the consumer's independent FMAs to issue under the producer's dependent chains
-// and the producer's arithmetic under the consumer's LDS waits.  Same arithmetic per residual and per tile as normal_eq_kernel
-// (the sums over rows are taken in the same order within a chunk); same chunk table; same flush.
-constexpr int NW_T = 512;
-constexpr size_t NW_LDS_BYTES = 2 * (size_t) NE_T * NE_LD * sizeof(double);
-template <bool FISHEYE>
-__global__ __launch_bounds__(NW_T, 1) void normal_eq_ws_kernel(const ResRecord *__restrict__ rec, const Chunk *__restrict__ chunks,
-                                                              const double *__restrict__ knots, const uint32_t *__restrict__ knot_off,
-                                                              const uint32_t *__restrict__ cp_off, const double *__restrict__ params,
-                                                              uint32_t n_cp_total, const double *__restrict__ landmarks, double radius,
-                                                              double huber_a, double *__restrict__ accum, double *__restrict__ heads,
-                                                              const NeProgress *__restrict__ prog, uint32_t epoch) {
-    constexpr int NE_TW = 6;
-    constexpr int NE_TG = NeTiles<NE_TW>::TG, NE_TILES = NeTiles<NE_TW>::TILES, NE_GROUPS = NeTiles<NE_TW>::GROUPS;
-    extern __shared__ __attribute__((aligned(16))) double rows2[];   // [2][NE_T][NE_LD]
-    __shared__ double red[NE_T / 64];
-    const Chunk ch = chunks[blockIdx.x];
-    const int tid_all = threadIdx.x;
-    const bool producer = tid_all < NE_T;
-    const int tid = producer ? tid_all : tid_all - NE_T;   // index within the role
-    double *const head = heads + (size_t) (blockIdx.x % NE_REPL) * ACC_HEAD;
-    const uint32_t c0 = cp_off[ch.seg] + ch.span - 3;
-    const uint32_t nb = (ch.count + NE_T - 1) / NE_T;
-    double cost = 0.0;
-    double acc[NE_TW * NE_TW];
-#pragma unroll
-    for (int i = 0; i < NE_TW * NE_TW; i++) acc[i] = 0.0;
-    int ti = 0, tj = 0;
-    {
-        int rem = tid % NE_TILES;
-        for (ti = 0; ti < NE_TG; ti++) {
-            if (rem < NE_TG - ti) break;
-            rem -= NE_TG - ti;
-        }
-        tj = ti + rem;
-    }
-    const int grp = tid / NE_TILES;
-    if (producer) {
-        const double *kn = knots + knot_off[ch.seg];
-        const double *intr = params;
-        const double *qall = params + 9;
-        const double *tall = params + 9 + 4 * (size_t) n_cp_total;
-        double q[4][4], t[4][3], pin[9], binv[6];
-        for (int i = 0; i < 9; i++) pin[i] = intr[i];
-        spline_span_inverses(kn, ch.span, binv);
-        const double ifx = 1.0 / pin[0], ify = 1.0 / pin[1];
-        for (int j = 0; j < 4; j++) {
-            for (int k = 0; k < 4; k++) q[j][k] = qall[4 * (size_t) (c0 + j) + k];
-            for (int k = 0; k < 3; k++) t[j][k] = tall[3 * (size_t) (c0 + j) + k];
-        }
-        ResRecord e_next = rec[ch.start + min((uint32_t) tid, ch.count - 1u)];
-        for (uint32_t b = 0; b <= nb; b++) {   // iteration b: batch b's rows (b < nb); the consumers are on batch b - 1
-            if (b < nb) {
-                const uint32_t k = b * NE_T + (uint32_t) tid;
-                double J[RES_NJ];
-                double r = 0.0, sc = 0.0;
-                const ResRecord e = e_next;
-                e_next = rec[ch.start + min(k + (uint32_t) NE_T, ch.count - 1u)];
-                if (k < ch.count) {
-                    ResidualInput in;
-                    in.u = e.u;
-                    in.v = e.v;
-                    in.lmx = landmarks[3 * (size_t) e.lm];
-                    in.lmy = landmarks[3 * (size_t) e.lm + 1];
-                    in.lmz = landmarks[3 * (size_t) e.lm + 2];
-                    in.radius = radius;
-                    in.ifx = ifx;
-                    in.ify = ify;
-                    spline_basis_inv(kn, ch.span, binv, e.t, in.b);
-                    r = spline_residual<FISHEYE>(in, pin, q, t, J);
-                    double hr;
-                    sc = huber_scale(r, huber_a, &hr);
-                    cost += hr;
-                }
-                double *row = rows2 + ((size_t) (b & 1u) * NE_T + (size_t) tid) * NE_LD;
-                if (k < ch.count) {
-#pragma unroll
-                    for (int i = 0; i < RES_NJ; i++) row[i] = J[i] * sc;
-                    row[33] = r * sc;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 34; i++) row[i] = 0.0;
-                }
-                row[34] = 0.0;
-                row[35] = 0.0;
-            }
-            __syncthreads();
-        }
-        for (int o = 32; o > 0; o >>= 1) cost += __shfl_down(cost, o, 64);
-        if ((tid & 63) == 0) red[tid >> 6] = cost;
-    } else {
-        for (uint32_t b = 0; b <= nb; b++) {
-            if (b >= 1 && grp < NE_GROUPS) {
-                const uint32_t bp = b - 1u;
-                const uint32_t nrow = min((uint32_t) NE_T, ch.count - bp * NE_T);
-                const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) double *) (rows2 + (size_t) (bp & 1u) * NE_T * NE_LD);
-                const uint32_t a0 = lds0 + 8u * NE_TW * (uint32_t) ti, b0a = lds0 + 8u * NE_TW * (uint32_t) tj;
-                constexpr uint32_t ROWB = NE_LD * 8u;
-                ne_v2d A0[3], B0[3], A1[3], B1[3];
-                {
-                    const uint32_t o = min((uint32_t) grp, nrow - 1u) * ROWB;
-                    ne_lds_read6(a0 + o, b0a + o, A0, B0);
-                }
-                for (uint32_t rk = grp; rk < nrow; rk += 2 * NE_GROUPS) {
-                    const uint32_t r1 = rk + NE_GROUPS, r2 = rk + 2 * NE_GROUPS;
-                    const uint32_t o1 = min(r1, nrow - 1u) * ROWB, o2 = min(r2, nrow - 1u) * ROWB;
-                    ne_lds_read6(a0 + o1, b0a + o1, A1, B1);
-                    ne_lds_wait_but6(A0, B0);
-                    ne_fma36(acc, A0, B0);
-                    ne_lds_read6(a0 + o2, b0a + o2, A0, B0);
-                    ne_lds_wait_but6(A1, B1);
-                    if (r1 < nrow) ne_fma36(acc, A1, B1);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the last (unused) prefetch, before the rows are rewritten
-            }
-            __syncthreads();
-        }
-    }
-    __syncthreads();
-    if (tid_all == 0) {
-        double c = 0;
-        for (int w = 0; w < NE_T / 64; w++) c += red[w];
-        atomicAdd(&head[0], c);
-    }
-    // the row groups' partial tiles summed in LDS (the row buffers are free now), then ONE flush per entry — by all 512 threads
-    {
-        constexpr int TSZ = NE_TW * NE_TW, NPART = NE_TILES * TSZ;
-        double *part = rows2;                        // [NE_GROUPS][NE_TILES * TSZ]
-        double *total = rows2;
-        static_assert((size_t) NE_GROUPS * NPART <= 2 * (size_t) NE_T * NE_LD, "the row buffers hold the partial tiles");
-        if (!producer && grp < NE_GROUPS) {
-#pragma unroll
-            for (int i = 0; i < TSZ; i++) part[(size_t) grp * NPART + (tid % NE_TILES) * TSZ + i] = acc[i];
-        }
-        __syncthreads();
-        for (int e = tid_all; e < NPART; e += NW_T) {    // (in place of group 0's slice: entry e is read and written by ONE thread)
-            double v = 0.0;
-#pragma unroll
-            for (int g = 0; g < NE_GROUPS; g++) v += part[(size_t) g * NPART + e];
-            total[e] = v;
-        }
-        __syncthreads();
-        for (int e = tid_all; e < NPART; e += NW_T) {
-            const double v = total[e];
-            if (v == 0.0) continue;
-            const int tile = e / TSZ, x = (e % TSZ) / NE_TW, y = e % NE_TW;
-            int fi = 0, rem = tile;
-            for (fi = 0; fi < NE_TG; fi++) {
-                if (rem < NE_TG - fi) break;
-                rem -= NE_TG - fi;
-            }
-            const int fj = fi + rem;
-            const int li = NE_TW * fi + x, lj = NE_TW * fj + y;
-            if (li > lj || lj >= 34 || li >= 33) continue;
-            bool ia, ib;
-            uint32_t ca, ka, cb, kb;
-            local_to_unknown(li, c0, ia, ca, ka);
-            if (lj == 33) {  // gradient J^T r
-                if (ia) atomicAdd(&head[1 + ka], v);
-                else atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) ca + ka], v);
-                continue;
-            }
-            local_to_unknown(lj, c0, ib, cb, kb);
-            if (ia && ib) {
-                atomicAdd(&head[10 + 9 * ka + kb], v);
-            } else if (ia) {
-                atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) cb + 6 + 9 * kb + ka], v);
-            } else {
-                if (ca > cb || (ca == cb && ka > kb)) {
-                    const uint32_t tc = ca, tk = ka;
-                    ca = cb;
-                    ka = kb;
-                    cb = tc;
-                    kb = tk;
-                }
-                atomicAdd(&accum[ACC_HEAD + ACC_PER_CP * (size_t) ca + 60 + 36 * (cb - ca) + 6 * ka + kb], v);
-            }
-        }
-    }
-    if (prog) ne_publish_progress(prog, epoch, accum, c0, tid_all, NW_T);
-}
-
-// The Ceres CostFunction::Evaluate seam (EventCalibSpline.hpp:137-146,231-240 behind AutoDiffCostFunction<..., 1, 9, 4, 4, 4, 4,
-// 3, 3, 3, 3> and the local parameterisations): per residual its raw value (no loss function) and the raw 1 x 33 row of the
-// tangent-space Jacobian, columns [ intrinsics 9 | rotation tangent of control points cp0 .. cp0+3 (3 each) | translation of
-// cp0 .. cp0+3 (3 each) ].  One thread per residual, chunks as in normal_eq_kernel.
 template <bool SO3, bool FISHEYE = false>
 __global__ __launch_bounds__(NE_T) void residual_rows_kernel(const ResRecord *__restrict__ rec, const Chunk *__restrict__ chunks,
                                                             const double *__restrict__ knots, const uint32_t *__restrict__ knot_off,
@@ -750,7 +434,6 @@ struct ecal_solver {
     int host_pool_workers = -1;
     uint32_t stream_epoch = 0;
     uint32_t last_solve[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ecal_debug_solver_last_solve: how the last ecal_solver_solve ran
-    bool ws_attr_set = false;      // normal_eq_ws_kernel's dynamic LDS size registered
     size_t n_params() const { return 9 + 7 * (size_t) n_cp; }
     size_t n_accum() const { return ACC_HEAD + ACC_PER_CP * (size_t) n_cp; }
 };
@@ -1148,22 +831,6 @@ static int solver_evaluate_dev(ecal_solver *s, const double *d_params, int with_
     } while (0)
         if (s->use_so3) {
             if (with_jacobian) ECAL_NE_LAUNCH2(true, true); else ECAL_NE_LAUNCH2(true, false);
-        } else if (with_jacobian && ctx->sw.solver_two_roles) {
-            // ECAL_SOLVER_TWO_ROLES=1: producer / consumer waves (normal_eq_ws_kernel) — built for the round-3 review, measured 15 % slower
-            // (2.70 against 2.35 ms on the benchmark problem), kept behind the switch with its parity test
-            if (!s->ws_attr_set) {
-                ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_ws_kernel<false>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) NW_LDS_BYTES));
-                ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&normal_eq_ws_kernel<true>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) NW_LDS_BYTES));
-                s->ws_attr_set = true;
-            }
-            if (s->fisheye)
-                hipLaunchKernelGGL((normal_eq_ws_kernel<true>), dim3(s->n_chunks), dim3(NW_T), NW_LDS_BYTES, st, s->d_rec, s->d_chunks, s->d_knots,
-                                   s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads, d_prog, epoch);
-            else
-                hipLaunchKernelGGL((normal_eq_ws_kernel<false>), dim3(s->n_chunks), dim3(NW_T), NW_LDS_BYTES, st, s->d_rec, s->d_chunks, s->d_knots,
-                                   s->d_knot_off, s->d_cp_off, d_params, s->n_cp, s->d_landmarks, s->radius, s->huber_a, d_accum, s->d_heads, d_prog, epoch);
         } else {
             if (with_jacobian) ECAL_NE_LAUNCH2(false, true); else ECAL_NE_LAUNCH2(false, false);
         }

@@ -283,6 +283,8 @@ int ecal_set_profile_ranges(ecal_ctx *ctx, int on);
 #define ECAL_TAIL_TIERED 1
 #define ECAL_TAIL_LEAN 2
 int ecal_set_tail_mode(ecal_ctx *ctx, int mode);
+/* the mode in force (ECAL_TAIL_*), or ECAL_ERR_INVALID: lets a caller that switches modes for one stage put back what it found */
+int ecal_get_tail_mode(const ecal_ctx *ctx);
 
 /* ecal_extract_batch_exact_dev: the exact extraction in one call (eps = the DBSCAN radius the labels were made with): the plain
  * pass lists the windows in which some kept cluster's median is tied in norm (a third of them on recorded-like data, all of

@@ -1,4 +1,4 @@
-"""The normal-equations launch alone, both kernel forms (ECAL_SOLVER_TWO_ROLES), on the benchmark's spline problem."""
+"""The normal-equations launch alone (memsets + normal_eq_kernel + head reduction) on the benchmark's spline problem."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,19 +15,13 @@ s = Solver(ctx, prob)
 st = torch.cuda.current_stream()
 d_x = torch.as_tensor(x, device="cuda"); d_acc = torch.empty(s.n_normal, dtype=torch.float64, device="cuda")
 for rnd in range(3):
-    for mode in ("0", "1"):
-        if mode == "1":
-            os.environ["ECAL_SOLVER_TWO_ROLES"] = "1"   # the switch is "set or not set"
-        else:
-            os.environ.pop("ECAL_SOLVER_TWO_ROLES", None)
-        ctx.reload_env()
-        for _ in range(3):
-            s.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(10):
-            s.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
-        e1.record(st)
-        torch.cuda.synchronize()
-        print("two roles" if mode == "1" else "one role", "%.4f ms per evaluation" % (e0.elapsed_time(e1) / 10), flush=True)
+    for _ in range(3):
+        s.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(10):
+        s.evaluate_dev(d_x.data_ptr(), 1, d_acc.data_ptr(), st.cuda_stream)
+    e1.record(st)
+    torch.cuda.synchronize()
+    print("one role", "%.4f ms per evaluation" % (e0.elapsed_time(e1) / 10), flush=True)
