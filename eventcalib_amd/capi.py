@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "ecal_circle_radius_threshold", "ecal_extract_batch_dev", "ecal_extract_batch_ordered_dev", "ecal_extract_batch_exact_dev", "ecal_cluster_order_list_dev", "ecal_set_median_ties", "ecal_set_tail_mode", "ecal_get_tail_mode", "ecal_calibrate_fisheye_views", "ecal_set_profile_ranges",
     "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
-    "ecal_grid_order_dev", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
+    "ecal_grid_order_dev", "ecal_grid_order", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
     "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_detect_keyframes_cap_hint", "ecal_detect_keyframes_cap_hint_dev", "ecal_stream_create_from_file", "ecal_stream_times", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",

@@ -944,6 +944,37 @@ int ecal_grid_order_dirs_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const ui
     return ECAL_OK;
 }
 
+// Host-buffer form for ONE candidate list: what cv::findCirclesGrid(points, Size(cols, rows), centers, flags) is called with at
+// CirclesEventFrame.cpp:332-336 (the shim host/cv_calib.hpp sits on this).  order[rows * cols] = candidate index per pattern point.
+extern "C" int ecal_grid_order(ecal_ctx *ctx, const double *cand_xyr, uint32_t n, uint32_t rows, uint32_t cols, int32_t *order,
+                               uint32_t *found) {
+    if (!ctx || !order || !found || (n && !cand_xyr) || rows * cols < 4 || rows * cols > GR_MAXM) return ECAL_ERR_INVALID;
+    const uint32_t M = rows * cols;
+    *found = 0;
+    for (uint32_t m = 0; m < M; m++) order[m] = -1;
+    if (n < M || n > GR_MAXC) return ECAL_OK;      // (the kernel's own rule: fewer candidates than pattern points, or more than it handles)
+    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    ecal_devbuf *B = ctx->host_pipe;   // roles as in ecal_detect_pass: 13 win_info, 6 seg_off, 15 candidates
+    int rc;
+    if ((rc = ecal_ensure(ctx, B[13], 4 * sizeof(uint32_t))) || (rc = ecal_ensure(ctx, B[6], 2 * sizeof(uint32_t))) ||
+        (rc = ecal_ensure(ctx, B[15], (size_t) n * 3 * sizeof(double))) || (rc = ecal_ensure(ctx, ctx->host_grid_order, M * sizeof(int32_t))) ||
+        (rc = ecal_ensure(ctx, ctx->host_grid_found, sizeof(uint32_t))))
+        return rc;
+    const uint32_t info[4] = {n, 0, 0, 0}, off[2] = {0, 0};
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(B[13].ptr, info, sizeof(info), hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(B[6].ptr, off, sizeof(off), hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(B[15].ptr, cand_xyr, (size_t) n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));   // (the sources are the caller's pageable memory and this frame's locals)
+    if ((rc = ecal_grid_order_dev(ctx, (const uint32_t *) B[13].ptr, (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, 1, rows, cols,
+                                  (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr, st)))
+        return rc;
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(order, ctx->host_grid_order.ptr, M * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipMemcpyAsync(found, ctx->host_grid_found.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
+    return ECAL_OK;
+}
+
 #ifdef ECAL_PHASE_PROF
 extern "C" int ecal_debug_grid_cycles(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ecal::g_gr_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;

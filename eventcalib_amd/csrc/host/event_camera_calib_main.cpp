@@ -9,6 +9,8 @@
 #include <cstdio>
 
 #include <filesystem>
+#include <thread>
+#include <algorithm>
 
 #include "event_calib_spline.hpp"
 #include "png_writer.hpp"
@@ -62,8 +64,11 @@ int main(int argc, char **argv) {
     const int frameEventNumThreshold = fsSettings["FrameEventNumThreshold"];   // :168
     auto pattern = cs->circlePatternParameters;
     CirclesEventFrame::Params fp(fsSettings);                // :171
-    int pieceNum = 30;                                       // (the reference: 5 * (hardware threads - 2), :172-173; the result
-    fsSettings["PieceNum"] >> pieceNum;                      //  depends on it, so the test pins it)
+    // the reference's piece count (:172-173): 5 * (std::thread::hardware_concurrency() - 2) — the keyframe set depends on it (the
+    // pieces' boundaries), so the same binary on the same box gives what the reference would; PieceNum (a key of this build,
+    // optional) pins it where a result must not depend on the host (the tests do)
+    int pieceNum = 5 * std::max(1, (int) std::thread::hardware_concurrency() - 2);
+    fsSettings["PieceNum"] >> pieceNum;
     // GateMode (a key of this build, optional): 1 = ECAL_GATE_SHARED_MAP, the reference's semantics with one worker thread (the
     // default: one keyframe map for all pieces, TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36); 0 = ECAL_GATE_OWN_PIECE, the
     // faster schedule-free gate (every piece's first success ungated)

@@ -131,7 +131,7 @@ int ecal_cluster_order(ecal_ctx *ctx, const double *xy, const uint32_t *slice_of
  *   max_win_events: upper bound on any window size, 0 = unknown.
  */
 /* Element order of the pixel sets every slicing entry point of this context emits (ecal_slice_events_dev and everything
- * built on it: ecal_detect_*, ecal_slice_events).  ECAL_ORDER_REFERENCE (default): positiveEvents_ / negativeEvents_ exactly
+ * built on it: ecal_detect_fused_dev, ecal_detect_batch, ecal_detect_pass, ecal_detect_keyframes, ecal_detect_stream_tiled).  ECAL_ORDER_REFERENCE (default): positiveEvents_ / negativeEvents_ exactly
  * as the reference's EventFrame constructor leaves them on libstdc++ — same `.bin` => same point order => same DBSCAN
  * labels as the reference.  ECAL_ORDER_FIRST_OCCURRENCE: ascending first occurrence of the pixel inside the window (the
  * same sets, a cheaper order; labels then equal the reference's only up to the order-dependent effects). */
@@ -459,6 +459,11 @@ int ecal_detect_stream_tiled(ecal_ctx *ctx, const uint8_t *events /*host*/, uint
 int ecal_grid_order_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const uint32_t *d_seg_off, const double *d_cand_xyr,
                         uint32_t S, uint32_t rows, uint32_t cols, int32_t *d_order /*[S][rows*cols]*/,
                         uint32_t *d_found /*[S]*/, void *stream);
+/* Host-buffer form for one candidate list — the call cv::findCirclesGrid(points, Size(cols, rows), centers,
+ * CALIB_CB_ASYMMETRIC_GRID [| CALIB_CB_CLUSTERING]) of CirclesEventFrame.cpp:332-336 (cv_calib/include/cv_calib.hpp:19-21):
+ * cand_xyr [n][3] (x, y, radius; the radius is not used), order [rows * cols] = candidate index of every pattern point
+ * (-1 when *found == 0).  eventcalib_amd/csrc/host/cv_calib.hpp wraps it in that very signature.  Synchronous. */
+int ecal_grid_order(ecal_ctx *ctx, const double *cand_xyr, uint32_t n, uint32_t rows, uint32_t cols, int32_t *order, uint32_t *found);
 
 /* ---- re-detection of the circles around their predicted projections ---------------------------------
  * Replaces CirclesEventFrame::rectifyFeatures(outlierIdxs, Rcw, tcw) (event_camera_calib/src/

@@ -175,3 +175,24 @@ def tiled_windows(t_first, t_last, length=1.5e-3):
     t0 = t_first + length * np.arange(n, dtype=np.float64)
     t1 = np.nextafter(t_first + length * np.arange(1, n + 1, dtype=np.float64), -np.inf)
     return t0, t1
+
+
+def undistortion_error_px(intr, radius=0.30):
+    """Max error, in pixels of the generating camera, of a refined camera's pixel -> undistorted-ray map
+    (EventCalibSpline.hpp:194-204: x = (u - cx) / fx, X = x (1 + k1 r^2 + .. + k5 r^10)) against the generating radial model,
+    over the rays within `radius` (tan of the angle to the optical axis; 0.30 = 108 px around the principal point: where the
+    board's circles are seen — beyond it the five-term polynomial extrapolates, as the reference's would).  The events are floored
+    to integer pixels, so a generated point observed at pixel p is p - 0.5 to the estimator (the principal point comes back 0.5
+    low)."""
+    import numpy as np
+    xn, yn = np.meshgrid(np.linspace(-radius, radius, 121), np.linspace(-radius, radius, 121))
+    r2 = xn * xn + yn * yn
+    d = 1 + K1 * r2 + K2 * r2 * r2 + K3 * r2 * r2 * r2
+    u, v = FX * xn * d + CX - 0.5, FY * yn * d + CY - 0.5
+    keep = (u >= 0) & (u <= SENSOR_W - 1) & (v >= 0) & (v <= SENSOR_H - 1) & (r2 <= radius * radius)
+    fx, fy, cx, cy = intr[:4]
+    x, y = (u - cx) / fx, (v - cy) / fy
+    q2 = x * x + y * y
+    c = 1 + q2 * (intr[4] + q2 * (intr[5] + q2 * (intr[6] + q2 * (intr[7] + q2 * intr[8]))))
+    err = FX * np.hypot(x * c - xn, y * c - yn)
+    return float(err[keep].max())

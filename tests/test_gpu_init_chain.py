@@ -52,6 +52,11 @@ def test_refined_intrinsics_and_trajectory(result, so3):
     fx, fy, cx, cy = r["intrinsics"][:4]
     assert abs(fx / SS.FX - 1) < 2e-3 and abs(fy / SS.FY - 1) < 2e-3
     assert abs(cx - (SS.CX - 0.5)) < 0.3 and abs(cy - (SS.CY - 0.5)) < 0.3
+    # the distortion itself: the refined k1..k5 (inverse radial polynomial) against the generating (k1, k2, k3), as the pixel ->
+    # undistorted-ray map over the rays within 0.30 of the optical axis (108 px around the principal point: where the circles are seen), in pixels
+    und = SS.undistortion_error_px(r["intrinsics"])
+    print("\n[init chain] so3=%s undistortion map max error %.3f px" % (so3, und))
+    assert und < 0.5
     assert r["spline"]["final_cost"] < r["spline"]["initial_cost"] and r["spline"]["residuals"] > 1_000_000
     # trajectory: camera centres within 3 mm of the generating motion (the PnP initialisation is centimetres off)
     tr, ini = r["trajectory"], r["init_trajectory"]

@@ -179,3 +179,38 @@ def test_cpp_driver_chain(tmp_path):
     stages = dict(l.split()[1:3] for l in out2.stdout.splitlines() if l.startswith("stage "))
     assert set(stages) == {"runtime_init", "load_file", "upload", "keyframe_search", "init_calibration_pnp_rectify", "spline_fit_association_lm",
                            "save_trajectory"}
+
+
+def test_cv_find_circles_grid_shim(tmp_path):
+    """host/cv_calib.hpp: cv::findCirclesGrid(points, Size(cols, rows), centers, CALIB_CB_ASYMMETRIC_GRID [| CLUSTERING]) in the
+    signature of the reference's vendored finder (cv_calib/include/cv_calib.hpp:19-21), called as CirclesEventFrame.cpp:332-353
+    calls it: projected circle centres in shuffled order (+ noise, + a spurious point outside the pattern) come back ordered row
+    by row — index i * cols + j = model point ((2 j + i % 2) s, i s) —, an incomplete list gives false."""
+    import numpy as np
+    import torch
+    exe = str(tmp_path / "test_cv_calib_shim")
+    lib_dir = os.path.join(ROOT, "eventcalib_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_cv_calib_shim.cpp"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + lib_dir, "-lecal", "-Wl,-rpath," + lib_dir, "-lpthread"])
+    rng = np.random.default_rng(5)
+    lm = SS.landmarks()
+    text, want = [], []
+    for k, t in enumerate(np.linspace(5.0, 8.0, 12)):
+        R, C = SS.pose(torch.tensor([t], dtype=torch.float64))
+        gt = SS.project(lm, R.expand(36, 3, 3), C.expand(36, 3)).numpy() + rng.normal(0, 0.7, size=(36, 2))
+        pts = gt.copy()
+        if k % 3 == 1:
+            pts = np.vstack([pts, [[8.0, 8.0]]])                 # a spurious candidate in the image corner
+        if k % 3 == 2:
+            pts = np.delete(pts, 17, axis=0)                      # a circle missing: no grid
+        perm = rng.permutation(len(pts))
+        pts = pts[perm]
+        text.append("%d\n%s\n" % (len(pts), "\n".join("%.6f %.6f" % (x, y) for x, y in pts)))
+        want.append(None if k % 3 == 2 else [int(np.flatnonzero(perm == m)[0]) for m in range(36)])
+    out = subprocess.run([exe], input="".join(text), capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(want)
+    for line, w in zip(out, want):
+        if w is None:
+            assert line == "none"
+        else:
+            assert line.split()[0] == "found" and [int(v) for v in line.split()[1:]] == w
