@@ -16,11 +16,8 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.slice_no_second_pass = on("ECAL_SLICE_NO_SECOND_PASS");
     sw.bounds_two_kernels = on("ECAL_BOUNDS_TWO_KERNELS");
     sw.dbscan_no_pixel = on("ECAL_DBSCAN_NO_PIXEL");
-    sw.dbscan_no_second_pass = on("ECAL_DBSCAN_NO_SECOND_PASS");
     sw.dbscan_generic_disc = on("ECAL_DBSCAN_GENERIC_DISC");
-    sw.extract_no_second_pass = on("ECAL_EXTRACT_NO_SECOND_PASS");
     sw.extract_no_inline_ties = on("ECAL_EXTRACT_NO_INLINE_TIES");
-    sw.no_fused_pass = on("ECAL_NO_FUSED_PASS");
     sw.no_zero_ring = on("ECAL_NO_ZERO_RING");
     sw.adaptive_trace = on("ECAL_ADAPTIVE_TRACE");
     sw.adaptive_rounds = on("ECAL_ADAPTIVE_ROUNDS");

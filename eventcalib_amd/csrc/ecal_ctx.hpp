@@ -23,8 +23,8 @@ struct ecal_devbuf {
 // result, only which tier or routine produces it ("Environment switches").
 struct ecal_switches {
     bool slice_no_pixel = false, slice_sort_kernel = false, slice_no_second_pass = false, bounds_two_kernels = false;
-    bool dbscan_no_pixel = false, dbscan_no_second_pass = false, dbscan_generic_disc = false;
-    bool extract_no_second_pass = false, extract_no_inline_ties = false, no_fused_pass = false, no_zero_ring = false;
+    bool dbscan_no_pixel = false, dbscan_generic_disc = false;
+    bool extract_no_inline_ties = false, no_zero_ring = false;
     bool grid_one_wave = false;
     bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, adaptive_dir_kernel = false, adaptive_verify_in_alloc = false;
     int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_live_floor = 0, adaptive_side = -1, adaptive_tree = -1, adaptive_grid_pieces = 0, arrow_k = 0;   // 0: not set
@@ -69,8 +69,6 @@ struct ecal_ctx {
     ecal_devbuf bfs_lists;  // ecal_cluster_order_dev: neighbour lists of the range queries, one slice per workgroup
     ecal_devbuf bfs_defer;  // ecal_cluster_order_dev: the segments the first launch leaves to the later ones
     ecal_devbuf bfs_big;    // ecal_cluster_order_dev: workspace + hit-list arena of the global-scratch launch
-    ecal_devbuf fused_def;  // [4 + S] u32: count, then the windows the fused pass (ecal_fused.hip) did not carry to the end
-    bool fused_pass = false;  // set by ecal_detect_fused_dev around its calls of the three stage functions: their first passes have run
     ecal_devbuf as_cnt, as_off;  // association: per-block counts / offsets
     ecal_devbuf as_host;         // staging of ecal_associate
     ecal_devbuf ingest_ev[2], ingest_feat;  // ecal_detect_stream_tiled: ping-pong event chunks, gathered features
@@ -112,11 +110,11 @@ struct ecal_ctx {
     int (*roctx_pop)() = nullptr;
     void *roctx_lib = nullptr;
     uint32_t n_cu = 256;  // compute units of the device (grid size of the persistent kernels)
-    bool attrs_set = false, slice_attrs_set = false, det_attr_set = false, fused_attr_set = false, bfs_attr_set = false;
+    bool attrs_set = false, slice_attrs_set = false, det_attr_set = false, bfs_attr_set = false;
     std::vector<ecal_devbuf *> all_bufs() {
         return {&in_xy, &in_off, &in_cnt, &out_labels, &out_ncl, &px_todo, &pxs_todo, &wb_status, &px_tree, &px_tree_flag, &big_slot, &big_anc, &big_cur, &big_inv, &big_cs, &big_flags,
                 &sl_pts, &sl_pol, &sl_bend, &sl_sorted, &sl_rep, &sl_pos, &sl_order, &sl_order_big, &bucket_tab, &sort_scratch,
-                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &fused_def, &bfs_lists, &bfs_defer, &bfs_big, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
+                &det_members, &det_koff, &det_ksize, &det_sorted, &det_norms, &det_todo, &bfs_lists, &bfs_defer, &bfs_big, &bfs_host, &tie_list, &tie_order, &as_cnt, &as_off,
                 &host_rect[0], &host_rect[1], &host_rect[2], &host_rect[3], &host_rect[4], &host_rect[5], &host_rect[6],
                 &host_rect[7], &host_rect[8], &host_rect[9], &host_rect[10],
                 &host_pipe[0], &host_pipe[1], &host_pipe[2], &host_pipe[3], &host_pipe[4], &host_pipe[5],

@@ -312,8 +312,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
     hipStream_t st = (hipStream_t) stream;
     ctx->px_tree_labels = nullptr;   // (whatever trees an earlier call left belong to ITS labels; set again below when this call exports its own)
     const uint32_t mx = max_seg_points ? max_seg_points : 0xFFFFFFFFu;
-    // (fused pass: its to-do list also holds the segments of windows the fused kernel did not slice, of any size)
-    const bool second_pass_wanted = (mx > (uint32_t) PX_CAP || ctx->fused_pass) && !ctx->sw.dbscan_no_second_pass;  // debug switch
+    const bool second_pass_wanted = mx > (uint32_t) PX_CAP;
 
     // event pixels (integer coordinates, eps < 16): the lean pixel kernel takes every segment it can and lists
     // the others; the general tiers then work that list off with a small grid (it is normally empty)
@@ -323,7 +322,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
     uint32_t grid = S;
     // lean: what the pixel kernel lists (nothing, when this stage last ran) goes to ONE tail launch (dbscan_tail_kernel) instead
     // of the second pixel pass, the unpacking and the four general tiers (ecal_ctx::tail_seen); only without a size hint
-    const int plan = pixel && !ctx->fused_pass && max_seg_points == 0 ? ecal_tail_plan(ctx, ECAL_TAIL_DBSCAN) : ECAL_PLAN_TIERED;
+    const int plan = pixel && max_seg_points == 0 ? ecal_tail_plan(ctx, ECAL_TAIL_DBSCAN) : ECAL_PLAN_TIERED;
     const bool lean = plan == ECAL_PLAN_LEAN;
     // semi: both pixel passes as always, then ONE tail launch for what the second leaves (nothing, when this stage last ran) instead
     // of the unpacking + the three LDS tiers + the global-scratch tier
@@ -333,21 +332,18 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         // two to-do lists: what the first pass (<= 1024 points) leaves, and what the second (<= 2048 points) leaves of that
         if ((rc = ecal_ensure(ctx, ctx->px_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
         uint32_t *cnt = (uint32_t *) ctx->px_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
-        // (fused pass, ecal_fused.hip: the first pass has run inside the fused kernel and has filled the first to-do list)
-        const bool fused = ctx->fused_pass;
-        if (!fused) {   // the lists' counters: words that are zero already, else two wiped now
-            if (uint32_t *z = ecal_zero_words(ctx, st, 2)) {
-                cnt = z;
-                cnt2 = z + 1;
-            } else {
-                ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
-            }
+        // the lists' counters: words that are zero already, else two wiped now
+        if (uint32_t *z = ecal_zero_words(ctx, st, 2)) {
+            cnt = z;
+            cnt2 = z + 1;
+        } else {
+            ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
         }
         const uint32_t grid2 = std::min<uint32_t>(S, (uint32_t) ECAL_PX2_WG * ctx->n_cu);
         // the trees the first pass builds go out for the exact extraction's member-order kernel (ecal_ctx::px_tree): 4 B per
         // point, a flag word per segment that carries this call's number where the segment's tree is whole
         uint32_t *tree = nullptr, *tflag = nullptr;
-        if (!fused && ctx->median_ties == ECAL_TIES_REFERENCE && n_points && PX_CAP <= 0xFFFE) {
+        if (ctx->median_ties == ECAL_TIES_REFERENCE && n_points && PX_CAP <= 0xFFFE) {
             const bool fresh = ctx->px_tree_flag.cap < (size_t) S * sizeof(uint32_t);
             if (!ecal_ensure(ctx, ctx->px_tree, (size_t) n_points * sizeof(uint32_t)) &&
                 !ecal_ensure(ctx, ctx->px_tree_flag, (size_t) S * sizeof(uint32_t))) {
@@ -365,7 +361,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         cnt_b = second_pass ? cnt2 : nullptr;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !ctx->sw.dbscan_generic_disc) {
-            if (!fused) hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
+            hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
                                ctx->px_tree_epoch);
             if (second_pass)
@@ -390,7 +386,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         }
         grid = S < 1024u ? S : 1024u;
     }
-    uint32_t *const seen = pixel && !ctx->fused_pass && ctx->tail_seen_dev ? ctx->tail_seen_dev + ECAL_TAIL_DBSCAN : nullptr;
+    uint32_t *const seen = pixel && ctx->tail_seen_dev ? ctx->tail_seen_dev + ECAL_TAIL_DBSCAN : nullptr;
     if (lean || semi) {
         const size_t np = n_points;
         if ((rc = ecal_ensure(ctx, ctx->big_slot, (2 * np + 4 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;

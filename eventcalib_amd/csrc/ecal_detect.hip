@@ -39,7 +39,7 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
         members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order, tie_list, tie_count, tie_mark);
 }
 
-// the first pass over a list: the windows the fused detection pass (ecal_fused.hip) did not carry through to extraction
+// the first pass over a list of windows (the exact extraction's tied windows: ecal_extract_batch_exact_dev)
 template <bool FIT, int MODE = 0>
 #ifndef ECAL_EFL_WAVES
 #define ECAL_EFL_WAVES 6
@@ -229,7 +229,6 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     ECAL_DET_ATTR((K<true, 2>), BYTES)
         ECAL_DET_ATTR3(extract_kernel, DET_LDS_BYTES + DET_TIE_INV_BYTES);
         ECAL_DET_ATTR3(extract_list_kernel, DET_LDS_BYTES2);
-        ECAL_DET_ATTR((extract_first_list_kernel<false, 0>), DET_LDS_BYTES);
         ECAL_DET_ATTR((extract_first_list_kernel<false, 1>), DET_LDS_BYTES);
         ECAL_DET_ATTR((extract_first_list_kernel<true, 1>), DET_LDS_BYTES);
 #undef ECAL_DET_ATTR3
@@ -239,14 +238,11 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     // windows too large for the first pass's LDS staging but not for the second's are listed by the first pass
     if ((rc = ecal_ensure(ctx, ctx->det_todo, ((size_t) S + 4) * sizeof(uint32_t)))) return rc;
     uint32_t *cnt = (uint32_t *) ctx->det_todo.ptr, *list = cnt + 4;
-    const bool second = !ctx->sw.extract_no_second_pass;
+    const bool second = true;
     hipStream_t st = (hipStream_t) stream;
-    // (fused pass, ecal_fused.hip: the fused kernel has extracted every window it carried through and listed the others)
-    const bool fused = ctx->fused_pass && mode == 0;
-    if (!fused) {   // the list's counter: a word that is zero already, else one wiped now
-        if (uint32_t *z = ecal_zero_words(ctx, st, 1)) cnt = z;
-        else ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
-    }
+    // the list's counter: a word that is zero already, else one wiped now
+    if (uint32_t *z = ecal_zero_words(ctx, st, 1)) cnt = z;
+    else ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
     uint32_t *mem = (uint32_t *) ctx->det_members.ptr, *ko = (uint32_t *) ctx->det_koff.ptr, *ks = (uint32_t *) ctx->det_ksize.ptr,
              *so = (uint32_t *) ctx->det_sorted.ptr;
     double *no = (double *) ctx->det_norms.ptr;
@@ -271,10 +267,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
         hipLaunchKernelGGL(unpack_unstaged_windows_kernel, dim3((S + 255u) / 256u < 1024u ? (S + 255u) / 256u : 1024u), dim3(256), 0, st, S, second ? DET_LDS_PTS2 : DET_LDS_PTS,
                            second ? DET_LDS_MAXC2 : DET_LDS_MAXC, d_seg_off, d_seg_cnt, d_n_clusters, (const uint32_t *) pk->d_xy16,
                            pk->d_seg_fmt, const_cast<double *>(d_xy));
-    if (fused && !fit) {
-        const uint32_t *dcnt = (const uint32_t *) ctx->fused_def.ptr, *dlist = dcnt + 4;
-        ECAL_DET_FIRST_LIST(false, 0, dlist, dcnt);
-    } else if (mode == 1 && d_in_list) {
+    if (mode == 1 && d_in_list) {
         if (fit) ECAL_DET_FIRST_LIST(true, 1, d_in_list, d_in_count); else ECAL_DET_FIRST_LIST(false, 1, d_in_list, d_in_count);
     } else if (mode == 1) {
         if (fit) ECAL_DET_FIRST(true, 1); else ECAL_DET_FIRST(false, 1);

@@ -1059,20 +1059,18 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) H12));
         ctx->slice_attrs_set = true;
     }
-    // (fused pass, ecal_fused.hip: the first pass has run inside the fused kernel and has filled the first to-do list)
-    const bool fused = ctx->fused_pass;
-    if (!fused) ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
+    ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
     // (packed points: every segment starts as "doubles"; the pixel kernels mark the windows they pack.  The hash slicers — the
     // default — write the mark of EVERY window they look at, also of the ones they pass on: no wipe, one launch less per pass)
     const bool hash_slicer = !ctx->sw.slice_no_pixel && (reforder || !ctx->sw.slice_sort_kernel);
-    if (sfmt && !(hash_slicer && !fused)) ECAL_HIP_TRY(ctx, hipMemsetAsync(sfmt, 0, 2 * (size_t) S * sizeof(uint32_t), st));
+    if (sfmt && !hash_slicer) ECAL_HIP_TRY(ctx, hipMemsetAsync(sfmt, 0, 2 * (size_t) S * sizeof(uint32_t), st));
     const uint32_t mx = max_win_events ? max_win_events : 0xFFFFFFFFu;
     // pixel windows first; what they leave over (longer windows, non-integer coordinates) is listed for the general tiers
     const uint32_t *todo = nullptr, *todo_count = nullptr;
     uint32_t grid = S;
     // lean: the listed windows (none, when this stage last ran) all go to the global-scratch tier, one launch behind the first
     // pass instead of four (ecal_ctx::tail_seen); only without size hints — a caller who names its sizes gets what it asks for
-    const int plan = hash_slicer && !fused && max_win_events == 0 ? ecal_tail_plan(ctx, ECAL_TAIL_SLICE) : ECAL_PLAN_TIERED;
+    const int plan = hash_slicer && max_win_events == 0 ? ecal_tail_plan(ctx, ECAL_TAIL_SLICE) : ECAL_PLAN_TIERED;
     const bool lean = plan == ECAL_PLAN_LEAN;
     // semi: first and second pass as always, then the global-scratch tier alone for whatever the second pass leaves (nothing, when
     // this stage last ran) instead of the two LDS tiers + it
@@ -1082,13 +1080,12 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         int rc;
         if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
         uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
-        if (!fused) {   // the lists' counters: words that are zero already, else two wiped now
-            if (uint32_t *z = ecal_zero_words(ctx, st, 2)) {
-                cnt = z;
-                cnt2 = z + 1;
-            } else {
-                ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
-            }
+        // the lists' counters: words that are zero already, else two wiped now
+        if (uint32_t *z = ecal_zero_words(ctx, st, 2)) {
+            cnt = z;
+            cnt2 = z + 1;
+        } else {
+            ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
         }
         todo = list;
         todo_count = cnt;
@@ -1096,7 +1093,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         if (reforder || !ctx->sw.slice_sort_kernel) {   // (debug switch: the counting-sort form, which also takes negative pixels)
             if (reforder) {
                 if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
-                if (!fused) hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
+                hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
                                    d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt,
                                    (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
             }
@@ -1157,7 +1154,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                            lean || semi ? 0u : (uint32_t) SCAP1, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow,
                            (double2 *) ctx->sl_pts.ptr, (uint8_t *) ctx->sl_pol.ptr, (uint32_t *) ctx->sl_bend.ptr,
                            (uint32_t *) ctx->sl_sorted.ptr, (uint32_t *) ctx->sl_rep.ptr, (uint32_t *) ctx->sl_pos.ptr, ord_big, S, todo,
-                           todo_count, hash_slicer && !fused ? ctx->tail_seen_dev + ECAL_TAIL_SLICE : nullptr, cnt_a, cnt_b);
+                           todo_count, hash_slicer ? ctx->tail_seen_dev + ECAL_TAIL_SLICE : nullptr, cnt_a, cnt_b);
     }
     ECAL_HIP_TRY(ctx, hipGetLastError());
     return ECAL_OK;
