@@ -81,8 +81,6 @@ def main():
     ap.add_argument("--profile", action="store_true",
                     help="roctx ranges around the library's stage entry points (ecal_set_profile_ranges): run under `rocprofv3 "
                          "--marker-trace --kernel-trace --stats -- python3 bench.py --profile ...`")
-    ap.add_argument("--device-solve", action="store_true",
-                    help="also time the LM solve with the linear algebra on the device (ECAL_SOLVER_DEVICE_LINEAR_SOLVE=1: the slower option)")
     ap.add_argument("--no-fixed-cost", action="store_true",
                     help="skip the pass_ms_fixed measurement (passes over S / 2 and S / 4 windows: under a profiler they would mix "
                          "smaller launches into the kernels' average durations)")
@@ -331,26 +329,9 @@ def main():
         staged_pass(n_local, S)
         torch.cuda.synchronize(dev)
 
-    # the same pass as ONE call / one kernel per window (ecal_detect_fused_dev): measured beside the stage-by-stage form above,
-    # outside the timed region; identical results (tests/test_gpu_fused.py).  The faster form is not assumed: both are reported.
-    fused_ms = plain_extract_ms = None
+    plain_extract_ms = None
     if rank == 0 and args.steps > 0:
-        def fused_step():
-            c.detect_fused_dev(events.data_ptr(), n_local, pipe.win_lo.data_ptr(), pipe.win_hi.data_ptr(), pipe.win_base.data_ptr(),
-                               S, 0, 0, n_local, eps, minpts, pipe.det[0], pipe.det[1], pipe.det[2], pipe._xy.data_ptr(),
-                               pipe.seg_off.data_ptr(), pipe.seg_cnt.data_ptr(), pipe.event_point.data_ptr(), pipe.flags.data_ptr(),
-                               pipe.labels.data_ptr(), pipe.n_clusters.data_ptr(), pipe.win_info.data_ptr(), pipe.cand_pair.data_ptr(),
-                               pipe.cand_xyr.data_ptr(), pipe.kept_labels.data_ptr(), pipe.rep.data_ptr(), st.cuda_stream,
-                               fit_circle=pipe.det[3], knn_num=pipe.det[4])
-        for _ in range(2):
-            fused_step()
         fe = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        fe[0].record(st)
-        for _ in range(args.steps):
-            fused_step()
-        fe[1].record(st)
-        torch.cuda.synchronize(dev)
-        fused_ms = fe[0].elapsed_time(fe[1]) / args.steps
         # the plain extraction (smaller pid at tied medians: ecal_extract_batch_dev alone), for comparison
         def plain_extract():
             c.set_median_ties(1)       # ECAL_TIES_SMALLER_PID: the plain extraction, same packed points
@@ -495,7 +476,7 @@ def main():
                 # window_bounds_kernel) except the other legs' — the fused pass, the plain extraction (MODE 0), solver, calibration
                 passes = max(1, max(v.get("launches", 0) for k, v in tr["kernels"].items() if "window_bounds" in k))
                 skip = ("normal_eq", "reduce_heads", "calib_", "view_", "residual_rows", "arrow_", "lm_plus", "solver_", "bucket_table",
-                        "associate", "scan_blocks", "detect_fused", "extract_kernel<false, 0>", "extract_list_kernel<false, 0>",
+                        "associate", "scan_blocks", "extract_kernel<false, 0>", "extract_list_kernel<false, 0>",
                         "extract_first_list_kernel<false, 0>", "grid_order", "adaptive_", "gather_features", "rectify", "pnp_", "sort_")
                 pass_traffic = sum(v["hbm_bytes_per_launch"] * min(1.0, v.get("launches", passes) / passes) for k, v in tr["kernels"].items()
                                    if not any(x in k for x in skip))
@@ -523,11 +504,6 @@ def main():
             out["median_ties"] = {"timed": "reference (std::nth_element over the reference's cluster member order where a median is tied)",
                                   "extract_ms_exact": round(float(stage_ms[3]), 4), "extract_ms_smaller_pid_rule": round(float(plain_extract_ms), 4),
                                   "pass_ms_smaller_pid_rule": round(float(stage_ms[0] + stage_ms[1] + stage_ms[2] + plain_extract_ms), 4)}
-        if fused_ms is not None:
-            out["fused_pass"] = {"ms_slice_dbscan_extract": round(float(fused_ms), 4),
-                                 "staged_ms_slice_dbscan_extract": round(float(stage_ms[1] + stage_ms[2] + plain_extract_ms), 4),
-                                 "note": "ecal_detect_fused_dev: one kernel carries a window through slicing, both DBSCAN runs and "
-                                         "extraction (plain tie rule); same results as the three plain stage calls; not the timed path (the stage-by-stage form is faster, profiles/r02_notes.md)"}
         if args.cpu_sample > 0 and world == 1:
             with leg(out, "cpu_baseline"):
                 import oracle_lib as O
@@ -1020,7 +996,7 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
     # the same solve with the evaluation fetched, unpacked and factorised AFTER the kernel (the form before round 4)
     plain_solve = None
     if world == 1:
-        os.environ["ECAL_SOLVER_NO_STREAM"] = "1"
+        os.environ["ECAL_FORCE"] = "solver_no_stream"
         ctx.reload_env()
         try:
             solver.solve(x0, opt)
@@ -1033,28 +1009,9 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
                 pr.append(time.perf_counter() - tb)
             plain_solve = {"value": round(int(sp.iterations) / sorted(pr)[1], 3), "unit": "iterations/s", "seconds": [round(r, 4) for r in pr],
                            "final_cost_rel_diff_vs_streamed": float(abs(sp.final_cost / summ.final_cost - 1)),
-                           "note": "ECAL_SOLVER_NO_STREAM=1: the host fetches, unpacks and factorises after the kernel has finished"}
+                           "note": "ECAL_FORCE=solver_no_stream: the host fetches, unpacks and factorises after the kernel has finished"}
         finally:
-            del os.environ["ECAL_SOLVER_NO_STREAM"]
-            ctx.reload_env()
-    # the same solve with the linear algebra on the device (arrow_device.hpp: whole iteration in HBM, one 64-byte read-back): 2 x
-    # slower than the host path (its reduced system is a chain of sequential separator steps), kept in the library
-    # and its tests, out of the default line since round 5 (--device-solve puts it back)
-    dev_solve = None
-    if world == 1 and args.device_solve:
-        os.environ["ECAL_SOLVER_DEVICE_LINEAR_SOLVE"] = "1"
-        ctx.reload_env()      # (the library reads its switches once per context)
-        try:
-            solver.solve(x0, opt)
-            torch.cuda.synchronize(dev)
-            tb = time.perf_counter()
-            xd, sd = solver.solve(x0, opt)
-            torch.cuda.synchronize(dev)
-            eld = time.perf_counter() - tb
-            dev_solve = {"value": round(int(sd.iterations) / eld, 3), "unit": "iterations/s", "iterations": int(sd.iterations),
-                         "seconds": round(eld, 4), "final_cost_rel_diff_vs_host_solve": float(abs(sd.final_cost / summ.final_cost - 1))}
-        finally:
-            del os.environ["ECAL_SOLVER_DEVICE_LINEAR_SOLVE"]
+            del os.environ["ECAL_FORCE"]
             ctx.reload_env()
     # SURVEY 8(d)'s ALGORITHMIC count per residual and Jacobian evaluation: ~0.7 kflop residual + analytic gradient, 561 FMA
     # for the upper J^T J, 33 FMA for J^T r = 1.9 kflop (the kernel executes ~2.1 kflop: 45 matrix-core products of 4 x 4 x 4 x 4
@@ -1083,7 +1040,6 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
         "evaluation": "streamed: the kernel delivers the accumulation buffer group by group, the host factorises under it (DESIGN.md 8)"
                       if world == 1 else "plain",
         "plain_evaluation": plain_solve,
-        "device_linear_solve": dev_solve,
         "sharding": "one spline segment (time range) per GPU in its own solver, shared intrinsics: 91 doubles all-reduced per "
                     "evaluation, 101 + N per linear solve, 4 per step" if world > 1 else "single GPU",
     }

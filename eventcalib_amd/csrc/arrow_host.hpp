@@ -364,30 +364,6 @@ inline int arrow_debug_solve_host(uint32_t n_cp, const double *accum, const doub
         if ((uint32_t) (7 * P) > n_cp) return -6;   // ECAL_ERR_RANGE
         HostPool pool(pool_workers);
         ok = solve_arrow_parts(A, sc, dd, y, ws, parts, &pool, P, -1, nullptr, mode == 3);
-        if (const char *e = getenv("ECAL_DEBUG_ARROW_TIME")) {   // tools: the factorisation of the largest interior alone, warm, on this thread
-            const int reps = std::max(1, atoi(e));
-            size_t big = 0;
-            for (int p = 0; p < P; p++)
-                if (parts.n[p] > parts.n[big]) big = p;
-#ifdef ECAL_ARROW_PROF
-            memset(g_arrow_prof, 0, sizeof(g_arrow_prof));
-#endif
-            const auto t0 = std::chrono::steady_clock::now();
-            for (int r = 0; r < reps; r++) arrow_part_factor(A, sc.data(), dd.data(), ws, parts, (int) big);
-            const double us = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / reps;
-            std::vector<double> yy(nt);
-            const auto t1 = std::chrono::steady_clock::now();
-            for (int r = 0; r < reps; r++) arrow_part_backsub(ws, parts, (int) big, parts.yr.data(), yy.data());
-            const double us_b = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() / reps;
-#ifdef ECAL_ARROW_PROF
-            fprintf(stderr, "  cycles per control point: scaled entries %.0f | block factor %.0f | Gram %.0f | panel %.0f | trailing rows %.0f\n",
-                    g_arrow_prof[0] / (double) reps / (parts.n[big] / 6.0), g_arrow_prof[1] / (double) reps / (parts.n[big] / 6.0),
-                    g_arrow_prof[2] / (double) reps / (parts.n[big] / 6.0), g_arrow_prof[3] / (double) reps / (parts.n[big] / 6.0),
-                    g_arrow_prof[4] / (double) reps / (parts.n[big] / 6.0));
-#endif
-            fprintf(stderr, "arrow_part_factor: interior of %zu control points %.1f us (%.3f us per control point); back-substitution %.1f us\n",
-                    parts.n[big] / 6, us, us / (parts.n[big] / 6.0), us_b);
-        }
     } else {
         ok = solve_arrow(A, sc, dd, y, ws);
     }

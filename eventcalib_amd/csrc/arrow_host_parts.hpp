@@ -4,7 +4,8 @@
 // columns instead of 10: [left separator 18 | intrinsics 9 | rhs | right separator 18] — and contributes a 46 x 46 Gram
 // block to the reduced system over the separators and the intrinsics (block tridiagonal + dense border, a few hundred
 // unknowns), which one thread solves; the interiors are then back-substituted in parallel again.
-// Same algebra as arrow_device.hpp (the device form), same result as solve_arrow up to summation order.
+// Same result as solve_arrow up to summation order.  (A device form of the same algebra — interiors in LDS, one workgroup each — ran
+// 2.9 ms per solve against this file's 0.6 ms on the benchmark problem: profiles/experiments/r06_device_linear_solve.patch.)
 // Included by ecal_solver.hip inside its anonymous namespace (uses ArrowSystem, ArrowWorkspace, BW).
 // (<atomic>, <condition_variable>, <mutex>, <thread>, <sched.h> are included by ecal_solver.hip at file scope)
 #pragma once
@@ -58,7 +59,6 @@ inline int host_usable_cpus(int *quota_out = nullptr) {
 class HostPool {
 public:
     explicit HostPool(int workers, int spin_us = 400) : spin_us_(spin_us) {
-        if (const char *e = getenv("ECAL_HOST_POOL_SPIN_US")) spin_us_ = atoi(e);   // debug switch
         for (int i = 0; i < workers; i++) th_.emplace_back([this] { loop(); });
     }
     ~HostPool() {

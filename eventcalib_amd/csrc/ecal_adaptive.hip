@@ -61,24 +61,12 @@ struct AdaptiveArrays {
 
 // EventCalibIni::track's test (EventCalibIni.cpp:73-82): the median — what libstdc++'s std::nth_element leaves at position
 // rows / 2, NaNs included: an angle is NaN when the cosine rounds above 1 (no clamp in the reference) — of the angles between
-// corresponding pattern rows, over the time distance, below (5e-4 pi) / MotionTimeStep
-__device__ bool gate_accepts(const double *rd, double ref_t, const double *dir, double t_mid, uint32_t rows, double mts) {
-    double theta[AD_MAX_ROWS];
-    for (uint32_t i = 0; i < rows; i++) {
-        // (Eigen's norm() = sqrt of the sum of squares, EventCalibIni.cpp:73-77 — not hypot(): one ulp in the norm decides
-        // whether a cosine of near-parallel rows rounds above 1, i.e. whether the angle is 0 or NaN, and the NaN is kept)
-        const double c = (rd[2 * i] * dir[2 * i] + rd[2 * i + 1] * dir[2 * i + 1]) /
-                         (sqrt(rd[2 * i] * rd[2 * i] + rd[2 * i + 1] * rd[2 * i + 1]) * sqrt(dir[2 * i] * dir[2 * i] + dir[2 * i + 1] * dir[2 * i + 1]));
-        theta[i] = acos(c);
-    }
-    ecal::ref_nth_element(theta, rows, rows / 2u, [](double x, double y) { return x < y; });
-    return theta[rows / 2u] / fabs(t_mid - ref_t) < (5e-4 * M_PI) / mts;
-}
-
-// The same test by a whole wave (adaptive_step_kernel): lane i computes row i's angle, the library's nth_element runs wave-uniformly
-// on the LANES of that register (an element access is two v_readlane / a select on the lane id) — the same operations on the same
-// values in the same order as gate_accepts, whose angle array lives in scratch memory (a trip to memory per access of the
-// selection: with a gate per grid-bearing window of a chain that was most of the step kernel's 100 us per pass).
+// corresponding pattern rows, over the time distance, below (5e-4 pi) / MotionTimeStep.  (Eigen's norm() = sqrt of the sum of
+// squares, EventCalibIni.cpp:73-77 — not hypot(): one ulp in the norm decides whether a cosine of near-parallel rows rounds above
+// 1, i.e. whether the angle is 0 or NaN, and the NaN is kept.)
+// By a whole wave: lane i computes row i's angle, the library's nth_element runs wave-uniformly on the LANES of that register (an
+// element access is two v_readlane / a select on the lane id) — the same operations on the same values in the same order as a
+// thread with the angle array in scratch memory, without a trip to memory per access of the selection.
 struct LaneArrF64 {
     using value_type = double;
     double *v;
@@ -144,11 +132,11 @@ constexpr uint32_t AD_DEPTH_MAX = 48;
 // 0.122; 512: 0.132 / 0.128
 constexpr uint32_t AD_GRID_LATENCY_PIECES = 256;
 static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
-    if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_DEPTH: debug / measurement switch; the result does not depend on it)
+    if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_SHAPE depth: debug / measurement switch; the result does not depend on it)
     return pieces <= 2048u ? 6u : (pieces <= 8192u ? 5u : (pieces <= 32768u ? 3u : 1u));   // (many pieces fill the GPU by themselves)
 }
 static uint32_t adaptive_depth_max(int forced = 0) {
-    if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_DEPTH_MAX: debug / measurement switch)
+    if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_SHAPE depth_max: debug / measurement switch)
     return AD_DEPTH_MAX;
 }
 
@@ -157,45 +145,6 @@ static uint32_t adaptive_depth_max(int forced = 0) {
 // grows unless it holds more than the event threshold, which is rare).
 __device__ __forceinline__ int likely_outcome(double f, double s2, double mts) { return (s2 - f) > 3 * (3 * mts) ? 1 : 2; }
 
-// The chain of D windows that starts at the piece's current window (f, s2) and goes on as if every verdict were the likely
-// one, cut where it would end the piece (:50; the slots behind the cut stay empty: +inf, -inf, which every stage skips)
-// n_side > 0: behind the D windows, for each of the first n_side of them the chain of L windows that follows if THAT window is
-// accepted as a keyframe (for windows from .. from + n_side - 1: side chain i at t0 + D + (i - from) * L) — the one unlikely verdict that ends every chain sooner or later
-__device__ __forceinline__ void write_chain(uint32_t D, double f, double s2, double hi, double mts, double *t0, double *t1, uint32_t n_side = 0,
-                                            uint32_t L = 0, uint32_t from = 0) {
-    bool act = true;
-    for (uint32_t j = 0; j < D; j++) {
-        t0[j] = act ? f : INFINITY;
-        t1[j] = act ? s2 : -INFINITY;
-        if (j >= from && j < from + n_side) {
-            double af = 0, as = 0;
-            bool sact = act;
-            if (sact) {
-                next_window(0, f, s2, mts, af, as);
-                sact = as < hi;
-            }
-            double *s0 = t0 + D + (size_t) (j - from) * L, *s1 = t1 + D + (size_t) (j - from) * L;
-            for (uint32_t q = 0; q < L; q++) {
-                s0[q] = sact ? af : INFINITY;
-                s1[q] = sact ? as : -INFINITY;
-                if (sact) {
-                    double nf, ns;
-                    next_window(likely_outcome(af, as, mts), af, as, mts, nf, ns);
-                    af = nf;
-                    as = ns;
-                    sact = ns < hi;
-                }
-            }
-        }
-        if (act) {
-            double nf, ns;
-            next_window(likely_outcome(f, s2, mts), f, s2, mts, nf, ns);
-            f = nf;
-            s2 = ns;
-            act = ns < hi;
-        }
-    }
-}
 
 // A piece's window slots as a TREE of chains (round 5).  The verdicts that do not accept are predictable (likely_outcome: on the
 // benchmark stream without a miss), so a chain only ever ends at an ACCEPTANCE or at its last slot — and where a window is
@@ -284,7 +233,7 @@ __device__ __forceinline__ void write_tree_level(const ChainTree &y, uint32_t id
 // d_max windows of chain each — the fewer pieces remain, the further each one looks ahead.  One workgroup.
 constexpr int AD_ALLOC_T = 1024;
 // live form, few pieces at work: a main chain and side chains (write_chain): first main-chain window with one, how many, their
-// length, the main chain's length.  Measured (ECAL_ADAPTIVE_SIDE, tools/side_sweep.sh): 24 side chains of 12 behind a main chain
+// length, the main chain's length.  Measured (ECAL_ADAPTIVE_SHAPE side, tools/side_sweep.sh): 24 side chains of 12 behind a main chain
 // of 24 take the search from 108 to 79 passes at 1270 pieces, but the passes of the tail grow by what they save — 0.151 against
 // 0.159 s at 1270 pieces, 0.153 / 0.156 at 4096, 0.289 / 0.271 at 254; eight other layouts within 3 % of that — so the default
 // is none, and the form stays behind the switch with its test.
@@ -292,7 +241,7 @@ constexpr uint32_t AD_SIDE_NONE = 0u;
 constexpr uint32_t AD_SIDE_MEASURED = 0u | (24u << 8) | (12u << 16) | (24u << 24);
 // Round 5: with the passes cheaper (ties resolved inside the extraction passes, the step kernel's chain walk on registers) the
 // saved passes now outweigh the wider ones — shared-map gate 0.145 -> 0.138 s at 1270 pieces, 0.148 -> 0.137 s at 4096 — and the
-// measured layout is the default (ECAL_ADAPTIVE_SIDE=0: none).
+// measured layout is the default (ECAL_ADAPTIVE_SHAPE side=0: none).
 constexpr uint32_t AD_SIDE_DEFAULT = AD_SIDE_MEASURED;
 // tree_for's word: main chain 8, chains of 8 behind positions 1 .. 5 / 1 .. 4 / 1 .. 3 of the levels above (a keyframe's window is
 // 4 - 10 steps long, position = steps - 3 after a fresh start: 5 steps 32 %, 4: 21 %, 6: 20 %, 7: 12 %, 8: 8 %)
@@ -301,24 +250,12 @@ constexpr uint32_t AD_TREE_DEFAULT = 8u | (8u << 8) | (5u << 16) | (4u << 20) | 
 // active, keyframe records so far, capacity overflow, and LAST the pass's number, which the host polls for (a copy engine
 // transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
 // and takes the active-pieces counter back to zero for the next pass.
-__device__ void verify_live_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st);
-__device__ void restart_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st);
 __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t deal, uint32_t d_max, AdaptiveArrays st,
                                                                     double mts, double *t0, double *t1, uint32_t *report, uint32_t seq, uint32_t live_base, uint32_t live_floor,
                                                                     uint32_t side /* from | count << 8 | length << 16 | main chain << 24 */,
-                                                                    uint32_t tree /* tree_for's word; 0: no trees */,
-                                                                    uint32_t verify_rows /* > 0: the shared-map gate's pass-by-pass verification first */) {
+                                                                    uint32_t tree /* tree_for's word; 0: no trees */) {
     __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // shared-map gate, live form, ECAL_ADAPTIVE_VERIFY_IN_ALLOC=1: the verification of the pass that has just ended and the restarts
-    // it asks for, by this one workgroup instead of adaptive_verify_live_kernel and adaptive_restart_kernel in front of it (a piece
-    // is read by other pieces' verifications only in a state its own restart does not touch before the barrier) — measured slower
-    if (verify_rows) {
-        for (uint32_t k = tid; k < P; k += AD_ALLOC_T) verify_live_piece(k, P, verify_rows, mts, st);
-        __syncthreads();
-        for (uint32_t k = tid; k < P; k += AD_ALLOC_T) restart_piece(k, P, verify_rows, mts, st);
-        __syncthreads();
-    }
     const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
     uint32_t mine = 0;
     for (uint32_t k = k0; k < k0 + per && k < P; k++) mine += st.active[k] ? 1u : 0u;
@@ -330,9 +267,8 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     }
     if (lane == 63) red[wave] = inc;
     __syncthreads();
-    uint32_t pre = 0, n_act = 0;
+    uint32_t n_act = 0;
     for (uint32_t w = 0; w < AD_ALLOC_T / 64; w++) {
-        if (w < wave) pre += red[w];
         n_act += red[w];
     }
     // `deal` of the B slots are dealt out (a run of few pieces — a verification round of the shared-map gate — does not get
@@ -340,7 +276,7 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     // live_base (the live form of the shared-map search, where first runs and re-runs share the passes): every piece gets the
     // chain length it asks for (want: twice its last length while its chains hold, else the base), scaled down together when the
     // pass cannot hold them all
-    if (live_base) {
+    {
         const uint32_t SF = side & 0xFFu, SC = (side >> 8) & 0xFFu, SL = (side >> 16) & 0xFFu, SM = side >> 24;
         __shared__ uint32_t red2[AD_ALLOC_T / 64 + 1];
         const uint32_t share = n_act ? live_floor / n_act : 0u;   // few pieces at work: the pass has slots to spare for all of them
@@ -423,26 +359,6 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
             t0[i] = INFINITY;
             t1[i] = -INFINITY;
         }
-    } else {
-    uint32_t D = n_act ? (deal < n_act ? 1u : deal / n_act) : 0u;   // (B >= P: at least one)
-    if (D > d_max) D = d_max;
-    uint32_t at = pre + inc - mine;        // active pieces before this thread's
-    for (uint32_t k = k0; k < k0 + per && k < P; k++) {
-        if (st.active[k]) {
-            st.slot0[k] = at * D;
-            st.depth[k] = D;
-            st.lay[k] = 0;
-            write_chain(D, st.first[k], st.second[k], st.bound_hi[k], mts, t0 + (size_t) at * D, t1 + (size_t) at * D);
-            at++;
-        } else {
-            st.depth[k] = 0;
-            st.lay[k] = 0;
-        }
-    }
-    for (uint32_t i = n_act * D + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
-        t0[i] = INFINITY;
-        t1[i] = -INFINITY;
-    }
     }
     if (report && tid == 0) {
         const uint32_t active = st.counters[0];
@@ -489,42 +405,6 @@ __global__ void adaptive_init_kernel(uint32_t P, uint32_t rows, double mts, Adap
     piece_start(k, P, rows, mts, st);
 }
 
-// Shared-map mode, after a set of runs has finished: does piece k's result stand with the reference frame its predecessors
-// NOW hand it — R = the last keyframe of the nearest earlier piece (larger index: piece 0 is the last in time) that has one?
-// It does iff the verdicts on its successes up to the first acceptance come out the same: every recorded rejected one is
-// rejected against R too, the first accepted one accepted (no R: the run's very first success, ungated).  Otherwise the piece
-// is marked, R becomes its initial reference and adaptive_restart_kernel starts it again.  (Reads other pieces' ref_*,
-// writes only its own init_* and mark: the restart is a kernel of its own.)
-__global__ void adaptive_verify_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P) return;
-    uint32_t j = k + 1;
-    while (j < P && st.nacc[j] == 0) j++;
-    const bool has = j < P;
-    const double r_t = has ? st.ref_t[j] : 0.0;
-    const double *r_dir = st.ref_dir + (size_t) (has ? j : 0) * rows * 2;
-    double *i_dir = st.init_dir + (size_t) k * rows * 2;
-    bool same = (st.init_has[k] != 0) == has;
-    if (same && has) {
-        same = st.init_t[k] == r_t;
-        for (uint32_t i = 0; i < 2 * rows && same; i++) same = i_dir[i] == r_dir[i];
-    }
-    if (same) return;
-    bool again = st.nrej[k] > AD_NREJ;   // more rejected successes than were kept: not decidable here
-    const uint32_t nr = st.nrej[k] < AD_NREJ ? st.nrej[k] : AD_NREJ;
-    for (uint32_t i = 0; i < nr && !again; i++)
-        again = !has || gate_accepts(r_dir, r_t, st.rej_dir + ((size_t) k * AD_NREJ + i) * rows * 2, st.rej_t[(size_t) k * AD_NREJ + i], rows, mts);
-    if (!again && st.nacc[k] > 0)
-        again = has && !gate_accepts(r_dir, r_t, st.facc_dir + (size_t) k * rows * 2, st.facc_t[k], rows, mts);
-    st.init_has[k] = has ? 1u : 0u;   // (the frame the piece's results are now known to be right for)
-    st.init_t[k] = r_t;
-    for (uint32_t i = 0; i < 2 * rows; i++) i_dir[i] = has ? r_dir[i] : 0.0;
-    if (again) {
-        st.rerun[k] = 1;
-        atomicAdd(&st.counters[8], 1u);
-    }
-}
-
 __device__ void restart_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st) {
     if (!st.rerun[k]) return;
     st.rerun[k] = 0;
@@ -547,53 +427,6 @@ __global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, A
 //   nothing else; different -> run again).
 //   k running, nothing accepted yet: the rejected successes so far must stay rejected (else: run again); then the run so far is
 //   the run it would have been with the new frame, and the frame becomes its reference for the successes to come.
-__device__ void verify_live_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st) {
-    uint32_t j = k + 1;
-    // (four pieces' words per round trip: the scan is a chain of dependent reads, and this kernel sits in every pass)
-    for (bool found_it = false; j < P && !found_it;) {
-        uint32_t a[4], n[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t ju = j + (uint32_t) u < P ? j + (uint32_t) u : P - 1u;
-            a[u] = st.active[ju];
-            n[u] = st.nacc[ju];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (found_it || j >= P) continue;
-            if (a[u]) return;   // not finished: its keyframes (or their absence) are not known yet
-            if (n[u] > 0) found_it = true;
-            else j++;
-        }
-    }
-    const bool has = j < P;
-    const double r_t = has ? st.ref_t[j] : 0.0;
-    const double *r_dir = st.ref_dir + (size_t) (has ? j : 0) * rows * 2;
-    double *i_dir = st.init_dir + (size_t) k * rows * 2;
-    bool same = (st.init_has[k] != 0) == has;
-    if (same && has) {
-        same = st.init_t[k] == r_t;
-        for (uint32_t i = 0; i < 2 * rows && same; i++) same = i_dir[i] == r_dir[i];
-    }
-    if (same) return;
-    bool again = st.nrej[k] > AD_NREJ;   // more rejected successes than were kept: not decidable here
-    const uint32_t nr = st.nrej[k] < AD_NREJ ? st.nrej[k] : AD_NREJ;
-    for (uint32_t i = 0; i < nr && !again; i++)
-        again = !has || gate_accepts(r_dir, r_t, st.rej_dir + ((size_t) k * AD_NREJ + i) * rows * 2, st.rej_t[(size_t) k * AD_NREJ + i], rows, mts);
-    if (!again && st.nacc[k] > 0)
-        again = has && !gate_accepts(r_dir, r_t, st.facc_dir + (size_t) k * rows * 2, st.facc_t[k], rows, mts);
-    st.init_has[k] = has ? 1u : 0u;
-    st.init_t[k] = r_t;
-    for (uint32_t i = 0; i < 2 * rows; i++) i_dir[i] = has ? r_dir[i] : 0.0;
-    if (again) {
-        st.rerun[k] = 1;
-    } else if (st.active[k] && st.nacc[k] == 0) {   // still before its first acceptance: the new frame is what its successes meet from now on
-        st.have_ref[k] = has ? 1u : 0u;
-        st.ref_t[k] = r_t;
-        double *rd = st.ref_dir + (size_t) k * rows * 2;
-        for (uint32_t i = 0; i < 2 * rows; i++) rd[i] = has ? r_dir[i] : 0.0;
-    }
-}
 // the same by a WAVE per piece (the default's kernel): the scan for the predecessor 64 pieces at a time, the frames a lane per row,
 // the gate on registers (gate_accepts_regs) — a thread per piece went through the scan, the comparison and up to five gates
 // with their angle arrays in scratch memory as chains of dependent reads: 36 us of every pass
@@ -1102,7 +935,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     uint32_t *d_ring = nullptr;
     ECAL_HIP_TRY(ctx, hipHostGetDevicePointer((void **) &d_ring, (void *) (h + 16), 0));
     for (int i = 0; i < 32; i++) ring[i] = 0;
-    std::vector<uint32_t> trace_active, trace_windows;   // ECAL_ADAPTIVE_TRACE: pieces still at work after every pass, windows gone through so far
+    std::vector<uint32_t> trace_active, trace_windows;   // ECAL_TRACE=adaptive: pieces still at work after every pass, windows gone through so far
     uint32_t seq = 0;   // passes enqueued in this call (over all its sets of runs): the number a pass reports
     uint32_t last_active = P;   // pieces at work after the last pass that has reported
     // max_passes bounds the windows a piece goes through (the lock-step passes of the one-window-per-pass form); a pass here
@@ -1125,28 +958,25 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     };
     // the lock-step passes of one set of runs: until no piece has a window left
     uint32_t deal = S;   // window slots dealt out per pass (all of them in the first set of runs)
-    // shared-map gate: verification after every pass (default) or after every set of runs (ECAL_ADAPTIVE_ROUNDS=1: the form of
-    // rounds 2 - 3, kept for comparison; same keyframes)
-    const bool live = shared && !ctx->sw.adaptive_rounds;
-    // slots dealt piece by piece (adaptive_alloc_kernel, live_base: a piece's chain doubles while it holds) — both gates; measured
-    // on the own-piece search against the same share for every piece at work (ECAL_ADAPTIVE_DEAL_UNIFORM=1): 0.059 / 0.065 s at
-    // 1270 pieces, 0.043 / 0.044 at 4096, 0.139 / 0.156 at 254; the set-by-set form of the shared-map gate keeps the uniform deal
-    const bool deal_by_piece = live || (!shared && !ctx->sw.adaptive_deal_uniform);
-    const uint32_t live_side = ctx->sw.adaptive_side < 0 ? AD_SIDE_DEFAULT : (ctx->sw.adaptive_side == 0 ? AD_SIDE_NONE : (ctx->sw.adaptive_side == 1 ? AD_SIDE_MEASURED : (uint32_t) ctx->sw.adaptive_side));   // (ECAL_ADAPTIVE_SIDE: from | count << 8 | length << 16 | main << 24; 1 = the measured layout, 0 = none, unset = the default)
+    // shared-map gate: the verification runs after every pass (adaptive_verify_live_kernel).  Slots are dealt piece by piece
+    // (adaptive_alloc_kernel: a piece's chain doubles while it holds) under both gates.  (Until round 5 the library also kept the
+    // verification after every SET of runs and a uniform deal behind switches: 0.164 against 0.116 s, 0.065 against 0.059 s at 1270
+    // pieces — profiles/experiments/r06_adaptive_alternatives.patch.)
+    const uint32_t live_side = ctx->sw.adaptive_side < 0 ? AD_SIDE_DEFAULT : (ctx->sw.adaptive_side == 0 ? AD_SIDE_NONE : (ctx->sw.adaptive_side == 1 ? AD_SIDE_MEASURED : (uint32_t) ctx->sw.adaptive_side));   // (ECAL_ADAPTIVE_SHAPE side: from | count << 8 | length << 16 | main << 24; 1 = the measured layout, 0 = none, unset = the default)
     // (side chains hang behind a main chain of (live_side >> 24) windows: a search whose chains are capped below that — the debug
-    // switch ECAL_ADAPTIVE_DEPTH_MAX — runs without them)
+    // switch ECAL_ADAPTIVE_SHAPE depth_max — runs without them)
     const uint32_t live_side_eff = d_max >= (live_side >> 24) ? live_side : AD_SIDE_NONE;
-    // the tree of chains a piece gets where keyframes are to be expected (tree_for; ECAL_ADAPTIVE_TREE: 0 = none, else the word)
+    // the tree of chains a piece gets where keyframes are to be expected (tree_for; ECAL_ADAPTIVE_SHAPE tree: 0 = none, else the word)
     const uint32_t live_tree_asked = ctx->sw.adaptive_tree < 0 ? AD_TREE_DEFAULT : (uint32_t) ctx->sw.adaptive_tree;
     const uint32_t live_tree = d_max >= (live_tree_asked & 0xFFu) ? live_tree_asked : 0u;   // (as the side chains: not under a chain cap below its main chain)
-    const uint32_t live_floor = ctx->sw.adaptive_live_floor > 0 ? (uint32_t) ctx->sw.adaptive_live_floor : 1024u;   // (ECAL_ADAPTIVE_LIVE_FLOOR: measurement switch)
+    const uint32_t live_floor = 1024u;   // (slots a pass has to spare for few pieces at work; swept in round 5, profiles/r05_notes.md)
     auto run_passes = [&]() -> int {
         // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
         // kernels over the slots it deals out, not over all S: thousands of workgroups that find an empty window still cost
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree, 0u);
+                           (uint32_t *) nullptr, 0u, D, live_floor, live_side_eff, live_tree);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
@@ -1191,10 +1021,10 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                         prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st));
             // (few pieces still at work — known two passes late —: the grid finder's latency form, a wave per start, ecal_grid.hip)
-            ctx->grid_hint_windows = last_active <= (ctx->sw.adaptive_grid_pieces > 0 ? (uint32_t) ctx->sw.adaptive_grid_pieces : AD_GRID_LATENCY_PIECES) ? 1u : Sr;   // (ECAL_ADAPTIVE_GRID_PIECES: measurement switch)
+            ctx->grid_hint_windows = last_active <= AD_GRID_LATENCY_PIECES ? 1u : Sr;
             // (the rows' line fits of the windows that hold a grid: by the grid finder's own workgroups, under the launch's slowest
-            // failing window; ECAL_ADAPTIVE_DIR_KERNEL=1: by adaptive_dir_kernel behind it, the form up to round 5 — same values)
-            const bool dirs_in_grid = !ctx->sw.adaptive_dir_kernel && prm->rows <= 64;
+            // failing window; patterns of more than 64 rows: by adaptive_dir_kernel behind it — same values)
+            const bool dirs_in_grid = prm->rows <= 64;
             rc = ecal_grid_order_dirs_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sr, prm->rows, prm->cols,
                                           (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr,
                                           dirs_in_grid ? (double *) ctx->adaptive_dirs.ptr : nullptr, st);
@@ -1210,17 +1040,13 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                (const uint32_t *) ctx->host_grid_found.ptr, a, ap->motion_time_step, ap->frame_event_num_threshold,
                                max_keys, d_kt, d_kd, d_ke, d_kf, d_kp, d_kg, d_t0, d_t1, (const int *) B[16].ptr,
                                (const double *) ctx->adaptive_dirs.ptr);
-            // shared-map gate: verification and restarts pass by pass (adaptive_verify_live_kernel, adaptive_restart_kernel).
-            // ECAL_ADAPTIVE_VERIFY_IN_ALLOC=1: in front of the next pass's slots in adaptive_alloc_kernel's launch instead — two
-            // launches less, measured SLOWER (0.118 - 0.125 against 0.116 - 0.118 s at 1270 pieces: one workgroup's threads take
-            // two to four pieces each through scans of dependent reads that the two kernels spread over the chip)
-            const bool verify_in_alloc = live && ctx->sw.adaptive_verify_in_alloc;
-            if (live && !verify_in_alloc) {
+            // shared-map gate: verification and restarts pass by pass
+            if (shared) {
                 hipLaunchKernelGGL(adaptive_verify_live_kernel, dim3((P + 3) / 4), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
                 hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
             }
             hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq, deal_by_piece ? D : 0u, live_floor, live_side_eff, live_tree, verify_in_alloc ? rows : 0u);
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, D, live_floor, live_side_eff, live_tree);
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));
@@ -1232,37 +1058,14 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         return ECAL_OK;
     };
     if ((rc = run_passes())) return rc;
-    uint32_t rounds = 0;
     const bool trace = ctx->sw.adaptive_trace;
-    if (shared && !live) {
-        // verify every piece against the frame its predecessors now hand it; run the ones again whose verdicts change
-        for (;; rounds++) {
-            AD_TRY(hip_rc(hipMemsetAsync(a.counters + 8, 0, sizeof(uint32_t), st), "hipMemsetAsync"));
-            hipLaunchKernelGGL(adaptive_verify_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
-            hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
-            AD_TRY(hip_rc(hipMemcpyAsync(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st), "hipMemcpyAsync"));
-            AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
-            if (h[8] == 0) break;
-            if (h[1] > max_keys) break;   // the records have run over: reported below
-            const uint32_t before = n_passes, again = h[8];
-            const auto t_round = std::chrono::steady_clock::now();
-            // slots for the pieces that run again: as many per piece as the first runs had at the start, or what keeps the GPU
-            // busy (measured at 1270 pieces: 0.266 -> 0.224 s for the whole search; 6 - 12 per piece and 512 - 3000 at least
-            // all within 4 % of each other)
-            deal = (uint32_t) std::min<uint64_t>(S, std::max<uint64_t>((uint64_t) again * D, 1536u));
-            if ((rc = run_passes())) return rc;
-            if (trace)
-                fprintf(stderr, "  round %u: %u pieces run again, %u passes, %u slots per pass, %.2f ms\n", rounds, again, n_passes - before, deal,
-                        1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_round).count());
-        }
-    }
 #undef AD_TRY
 #ifdef ECAL_ADAPTIVE_STATS
     fprintf(stderr, "chain ends: keyframe %u, other verdict %u, chain used up %u, piece finished %u\n", h[4], h[5], h[6], h[7]);
 #endif
     if (trace) {
-        fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes, %u verification rounds\n", P, S,
-                d_max, n_passes, rounds);
+        fprintf(stderr, "ecal_detect_keyframes: %u pieces, %u window slots per pass (chains of <= %u), %u passes\n", P, S,
+                d_max, n_passes);
         fprintf(stderr, "  pieces at work after each pass:");
         for (uint32_t v : trace_active) fprintf(stderr, " %u", v);
         fprintf(stderr, "\n  windows gone through in each pass:");

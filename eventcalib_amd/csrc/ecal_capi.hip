@@ -1,43 +1,68 @@
 // Context lifecycle and shared helpers of libecal.so.
 #include <dlfcn.h>
+#include <cstring>
 #include "ecal_ctx.hpp"
 
 constexpr uint32_t ZERO_RING_WORDS = 16384, ZERO_RING_GRAIN = 16;
 
+// The environment of the library, read once per context (ecal_init; ecal_debug_reload_env for tests):
+//   ECAL_FORCE          test knobs, comma-separated: which tier / routine produces a result, never what the result is —
+//                       slice_general, dbscan_general, dbscan_generic_disc, extract_no_inline_ties, bounds_two_kernels, grid_one_wave,
+//                       grid_serial_walk, solver_no_stream (the parity tests run the forms against each other)
+//   ECAL_TRACE          stderr traces, comma-separated: adaptive, grid, solver, load
+//   ECAL_ADAPTIVE_SHAPE the look-ahead of the keyframe search, comma-separated key=value: depth, depth_max, side, tree (any shape
+//                       gives the same keyframes: tests/test_gpu_adaptive.py)
+//   ECAL_GRID_TOL_PX    the grid finder's hole tolerance (default: the reference's 20 px); ECAL_BO_BIG_ARENA: bytes of the member-order
+//                       kernel's global arena (tests of its overflow path)
+//   ECAL_MEDIAN_TIES, ECAL_TAIL_MODE, ECAL_ROCTX (ecal_init: the defaults of ecal_set_median_ties / ecal_set_tail_mode /
+//   ecal_set_profile_ranges); ECAL_HOST_THREADS, ECAL_HOST_ARROW_PARTS (arrow_host_parts.hpp: the solver's host half)
 void ecal_read_switches(ecal_switches &sw) {
-    auto on = [](const char *name) { return getenv(name) != nullptr; };
-    auto num = [](const char *name) -> long long {
-        const char *e = getenv(name);
-        return e ? atoll(e) : 0;
+    auto has = [](const char *var, const char *word) -> bool {      // `word` is an element of the comma-separated list in `var`
+        const char *e = getenv(var);
+        if (!e) return false;
+        const size_t n = strlen(word);
+        for (const char *p = e; *p;) {
+            const char *q = strchr(p, ',');
+            const size_t len = q ? (size_t) (q - p) : strlen(p);
+            if (len == n && strncmp(p, word, n) == 0) return true;
+            p += len + (q ? 1 : 0);
+        }
+        return false;
+    };
+    auto value = [](const char *var, const char *key, long long &out) -> bool {   // key=value in the comma-separated list
+        const char *e = getenv(var);
+        if (!e) return false;
+        const size_t n = strlen(key);
+        for (const char *p = e; *p;) {
+            const char *q = strchr(p, ',');
+            const size_t len = q ? (size_t) (q - p) : strlen(p);
+            if (len > n + 1 && strncmp(p, key, n) == 0 && p[n] == '=') {
+                out = atoll(p + n + 1);
+                return true;
+            }
+            p += len + (q ? 1 : 0);
+        }
+        return false;
     };
     sw = ecal_switches();
-    sw.slice_no_pixel = on("ECAL_SLICE_NO_PIXEL");
-    sw.slice_sort_kernel = on("ECAL_SLICE_SORT_KERNEL");
-    sw.slice_no_second_pass = on("ECAL_SLICE_NO_SECOND_PASS");
-    sw.bounds_two_kernels = on("ECAL_BOUNDS_TWO_KERNELS");
-    sw.dbscan_no_pixel = on("ECAL_DBSCAN_NO_PIXEL");
-    sw.dbscan_generic_disc = on("ECAL_DBSCAN_GENERIC_DISC");
-    sw.extract_no_inline_ties = on("ECAL_EXTRACT_NO_INLINE_TIES");
-    sw.no_zero_ring = on("ECAL_NO_ZERO_RING");
-    sw.adaptive_trace = on("ECAL_ADAPTIVE_TRACE");
-    sw.adaptive_rounds = on("ECAL_ADAPTIVE_ROUNDS");
-    sw.adaptive_deal_uniform = on("ECAL_ADAPTIVE_DEAL_UNIFORM");
-    sw.grid_debug = on("ECAL_GRID_DEBUG");
-    sw.grid_serial_walk = on("ECAL_GRID_SERIAL_WALK");
-    sw.grid_one_wave = on("ECAL_GRID_ONE_WAVE");
-    sw.solver_device_linear_solve = on("ECAL_SOLVER_DEVICE_LINEAR_SOLVE");
-    sw.solver_trace = on("ECAL_SOLVER_TRACE");
-    sw.solver_no_stream = on("ECAL_SOLVER_NO_STREAM");
-    sw.adaptive_dir_kernel = on("ECAL_ADAPTIVE_DIR_KERNEL");
-    sw.adaptive_verify_in_alloc = on("ECAL_ADAPTIVE_VERIFY_IN_ALLOC");
-    sw.adaptive_depth = (int) num("ECAL_ADAPTIVE_DEPTH");
-    sw.adaptive_depth_max = (int) num("ECAL_ADAPTIVE_DEPTH_MAX");
-    sw.adaptive_live_floor = (int) num("ECAL_ADAPTIVE_LIVE_FLOOR");
-    sw.adaptive_grid_pieces = (int) num("ECAL_ADAPTIVE_GRID_PIECES");
-    if (getenv("ECAL_ADAPTIVE_SIDE")) sw.adaptive_side = (int) num("ECAL_ADAPTIVE_SIDE");
-    if (getenv("ECAL_ADAPTIVE_TREE")) sw.adaptive_tree = (int) num("ECAL_ADAPTIVE_TREE");
-    sw.arrow_k = (int) num("ECAL_ARROW_K");
-    sw.bo_big_arena = (unsigned long long) num("ECAL_BO_BIG_ARENA");
+    sw.slice_no_pixel = has("ECAL_FORCE", "slice_general");
+    sw.dbscan_no_pixel = has("ECAL_FORCE", "dbscan_general");
+    sw.dbscan_generic_disc = has("ECAL_FORCE", "dbscan_generic_disc");
+    sw.extract_no_inline_ties = has("ECAL_FORCE", "extract_no_inline_ties");
+    sw.bounds_two_kernels = has("ECAL_FORCE", "bounds_two_kernels");
+    sw.grid_one_wave = has("ECAL_FORCE", "grid_one_wave");
+    sw.grid_serial_walk = has("ECAL_FORCE", "grid_serial_walk");
+    sw.solver_no_stream = has("ECAL_FORCE", "solver_no_stream");
+    sw.adaptive_trace = has("ECAL_TRACE", "adaptive");
+    sw.grid_debug = has("ECAL_TRACE", "grid");
+    sw.solver_trace = has("ECAL_TRACE", "solver");
+    sw.load_trace = has("ECAL_TRACE", "load");
+    long long v;
+    if (value("ECAL_ADAPTIVE_SHAPE", "depth", v)) sw.adaptive_depth = (int) v;
+    if (value("ECAL_ADAPTIVE_SHAPE", "depth_max", v)) sw.adaptive_depth_max = (int) v;
+    if (value("ECAL_ADAPTIVE_SHAPE", "side", v)) sw.adaptive_side = (int) v;
+    if (value("ECAL_ADAPTIVE_SHAPE", "tree", v)) sw.adaptive_tree = (int) v;
+    if (const char *e = getenv("ECAL_BO_BIG_ARENA")) sw.bo_big_arena = (unsigned long long) atoll(e);
     if (const char *e = getenv("ECAL_GRID_TOL_PX")) sw.grid_tol_px = atof(e);
 }
 
@@ -49,7 +74,7 @@ extern "C" int ecal_debug_reload_env(ecal_ctx *ctx) {
 }
 
 uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n) {
-    if (n > ZERO_RING_GRAIN || ctx->sw.no_zero_ring) return nullptr;
+    if (n > ZERO_RING_GRAIN) return nullptr;
     ecal_ctx::zero_ring *r = nullptr;
     for (auto &c : ctx->zero_rings)
         if (c.used && c.stream == st) r = &c;

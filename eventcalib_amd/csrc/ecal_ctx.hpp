@@ -17,17 +17,18 @@ struct ecal_devbuf {
     size_t cap = 0;
 };
 
-// Debug / test switches, read from the environment ONCE per context (ecal_init) — not per call: getenv is not safe against a
+// Debug / test switches (ECAL_FORCE, ECAL_TRACE, ECAL_ADAPTIVE_SHAPE, …: ecal_capi.hip), read from the environment ONCE per context (ecal_init) — not per call: getenv is not safe against a
 // concurrent setenv, and the entry points that consult these are the hot ones.  Tests that flip a switch on a live context call
 // ecal_debug_reload_env afterwards (eventcalib_amd.capi.sync_env does it for every live context).  None of them changes a
 // result, only which tier or routine produces it ("Environment switches").
 struct ecal_switches {
-    bool slice_no_pixel = false, slice_sort_kernel = false, slice_no_second_pass = false, bounds_two_kernels = false;
-    bool dbscan_no_pixel = false, dbscan_generic_disc = false;
-    bool extract_no_inline_ties = false, no_zero_ring = false;
-    bool grid_one_wave = false;
-    bool adaptive_trace = false, adaptive_rounds = false, adaptive_deal_uniform = false, grid_debug = false, grid_serial_walk = false, solver_device_linear_solve = false, solver_trace = false, solver_no_stream = false, adaptive_dir_kernel = false, adaptive_verify_in_alloc = false;
-    int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_live_floor = 0, adaptive_side = -1, adaptive_tree = -1, adaptive_grid_pieces = 0, arrow_k = 0;   // 0: not set
+    // which tier / routine produces a result (parity tests run the tiers against each other)
+    bool slice_no_pixel = false, dbscan_no_pixel = false, dbscan_generic_disc = false, extract_no_inline_ties = false;
+    bool bounds_two_kernels = false, grid_one_wave = false, grid_serial_walk = false, solver_no_stream = false;
+    // traces (stderr)
+    bool adaptive_trace = false, grid_debug = false, solver_trace = false, load_trace = false;
+    // shape of the keyframe search's look-ahead (tests: any shape gives the same keyframes); 0 / -1: not set
+    int adaptive_depth = 0, adaptive_depth_max = 0, adaptive_side = -1, adaptive_tree = -1;
     unsigned long long bo_big_arena = 0;                            // 0: not set
     double grid_tol_px = 20.0;
 };

@@ -241,26 +241,16 @@ using namespace ecal;
 // general size tiers: capacity CAP points, CAP/4 threads; LDS ~36 B/point -> 4 / 2 / 1 workgroups per CU
 static constexpr int CAP0 = 1024, CAP1 = 2048, CAP2 = 4096;
 
-// profiling knobs only (tools/occupancy_probe.sh): ECAL_DBSCAN_LDS_PAD = extra dynamic LDS of the pixel kernel, to lower
-// its occupancy; ECAL_DBSCAN_NO_PIXEL = general kernels only
-static size_t tier0_pad() {
-    static const size_t pad = [] {
-        const char *e = getenv("ECAL_DBSCAN_LDS_PAD");
-        return e ? (size_t) strtoul(e, nullptr, 10) : (size_t) 0;
-    }();
-    return pad;
-}
-
 static int set_attrs(ecal_ctx *ctx) {
     if (ctx->attrs_set) return ECAL_OK;
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP0, CAP0 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP0>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<0, PX_CAP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int) (PixelLayout<PX_CAP>::bytes + tier0_pad())));
+                                          (int) (PixelLayout<PX_CAP>::bytes)));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_kernel<16, PX_CAP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int) (PixelLayout<PX_CAP>::bytes + tier0_pad())));
+                                          (int) (PixelLayout<PX_CAP>::bytes)));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_list_kernel<0, PX_CAP2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixelLayout<PX_CAP2>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_list_kernel<16, PX_CAP2>),
@@ -361,7 +351,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         cnt_b = second_pass ? cnt2 : nullptr;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !ctx->sw.dbscan_generic_disc) {
-            hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
+            hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes, st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
                                ctx->px_tree_epoch);
             if (second_pass)
@@ -369,7 +359,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
                                    (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt, tree, tflag, ctx->px_tree_epoch);
         } else {
-            hipLaunchKernelGGL((dbscan_pixel_kernel<0, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes + tier0_pad(), st,
+            hipLaunchKernelGGL((dbscan_pixel_kernel<0, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes, st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
                                ctx->px_tree_epoch);
             if (second_pass)

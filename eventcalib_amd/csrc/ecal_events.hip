@@ -563,180 +563,6 @@ __global__ __launch_bounds__(T) void slice_lds_kernel(const uint8_t *__restrict_
     }
 }
 
-// ---------------- pixel windows: the hot path ------------------------------------------------------------------
-// Same EventFrame semantics for windows of <= 2048 events whose coordinates are integers with |v| <= 16383 (event
-// pixels; -0.0 == +0.0 as operator== has it): an event is one 31-bit key (x 15 | y 15 | polarity), the workspace is
-// 24 KB of LDS instead of 58 KB, so a CU holds six windows instead of two — the kernel is a chain of dependent LDS
-// operations (latency bound), throughput follows the workgroups in flight.  Anything else goes to the to-do list.
-constexpr int PXS_T = 256;
-constexpr int PXS_CAP = 2048;
-constexpr uint32_t PXS_NB_LOG = 11;
-
-struct PixSliceLayout {
-    static constexpr size_t key_off = 0;                                          // u32[2048]
-    static constexpr size_t bend_off = key_off + 4 * PXS_CAP;                     // u32[2048 + 4]; later pos u16[2048]
-    static constexpr size_t sorted_off = bend_off + 4 * ((1u << PXS_NB_LOG) + 4); // u16[2048]
-    static constexpr size_t rep_off = sorted_off + 2 * PXS_CAP;                   // u16[2048]
-    static constexpr size_t red_off = rep_off + 2 * PXS_CAP;                      // 16 x u64 + 4 x u32 flags
-    static constexpr size_t bytes = red_off + 16 * 8 + 16;
-};
-
-__device__ __forceinline__ uint32_t pix_bucket(uint32_t key) {
-    return ((key & 0x3FFFFFFFu) * 0x9E3779B1u) >> (32u - PXS_NB_LOG);
-}
-
-__global__ __launch_bounds__(PXS_T) void slice_pixel_kernel(const uint8_t *__restrict__ rec,
-                                                            const uint32_t *__restrict__ win_lo,
-                                                            const uint32_t *__restrict__ win_hi,
-                                                            const uint32_t *__restrict__ win_base, uint32_t cap_points,
-                                                            double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
-                                                            uint32_t *__restrict__ seg_cnt,
-                                                            int32_t *__restrict__ event_point, int *overflow,
-                                                            uint32_t *__restrict__ todo,
-                                                            uint32_t *__restrict__ todo_count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using L = PixSliceLayout;
-    constexpr int T = PXS_T;
-    constexpr uint32_t NONE = 0xFFFFu, NB = 1u << PXS_NB_LOG;
-    const uint32_t s = blockIdx.x, tid = threadIdx.x;
-    const uint32_t lo = win_lo[s], n = win_hi[s] - lo, base = win_base[s];
-    if (n == 0) {
-        if (tid == 0) {
-            seg_off[2 * s] = base < cap_points ? base : 0;
-            seg_off[2 * s + 1] = seg_off[2 * s];
-            seg_cnt[2 * s] = 0;
-            seg_cnt[2 * s + 1] = 0;
-        }
-        return;
-    }
-    if (n > (uint32_t) PXS_CAP) {
-        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
-        return;
-    }
-    if ((uint64_t) base + n > cap_points) {  // caller's buffers too small: report, emit empty segments
-        if (tid == 0) {
-            *overflow = 1;
-            seg_off[2 * s] = seg_off[2 * s + 1] = 0;
-            seg_cnt[2 * s] = seg_cnt[2 * s + 1] = 0;
-        }
-        return;
-    }
-    uint32_t *const key = reinterpret_cast<uint32_t *>(smem + L::key_off);
-    uint32_t *const bend = reinterpret_cast<uint32_t *>(smem + L::bend_off);
-    uint16_t *const pos = reinterpret_cast<uint16_t *>(smem + L::bend_off);
-    uint16_t *const sorted = reinterpret_cast<uint16_t *>(smem + L::sorted_off);
-    uint16_t *const rep = reinterpret_cast<uint16_t *>(smem + L::rep_off);
-    uint32_t *const red = reinterpret_cast<uint32_t *>(smem + L::red_off);
-    uint32_t *const badf = red + 32;
-
-    // a. decode (Event.hpp:41-47) into keys
-    for (uint32_t b = tid; b <= NB; b += T) bend[b] = 0;
-    if (tid == 0) badf[0] = 0;
-    bool bad = false;
-    for (uint32_t k = tid; k < n; k += T) {
-        const uint8_t *r = rec + (uint64_t) (lo + k) * RECORD_BYTES;
-        const double x = load_f64_unaligned(r + 8), y = load_f64_unaligned(r + 16);
-        // (-0.0 is a valid pixel for operator==, but the emitted element keeps its sign bit: general path)
-        bad = bad || !(x == floor(x) && y == floor(y) && fabs(x) <= 16383.0 && fabs(y) <= 16383.0) ||
-              __double_as_longlong(x) == (long long) 0x8000000000000000ull ||
-              __double_as_longlong(y) == (long long) 0x8000000000000000ull;
-        const uint32_t kx = (uint32_t) (int) x & 0x7FFFu, ky = (uint32_t) (int) y & 0x7FFFu;
-        key[k] = kx | (ky << 15) | (r[24] ? 0x40000000u : 0u);
-    }
-    __syncthreads();
-    if (__any(bad) && (tid & 63) == 0) badf[0] = 1;
-    // b/c. counting sort of the events by pixel-hash bucket
-    for (uint32_t k = tid; k < n; k += T) atomicAdd(&bend[pix_bucket(key[k])], 1u);
-    __syncthreads();
-    if (badf[0]) {
-        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
-        return;
-    }
-    if (ECAL_SL_STOP == 1) return;
-    {
-        constexpr uint32_t per = NB / T;
-        const uint32_t b0 = tid * per;
-        uint32_t c[per], sum = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < per; b++) {
-            c[b] = bend[b0 + b];
-            sum += c[b];
-        }
-        uint32_t ex, dummy0, tot, dummy1;
-        block_exscan2<T>(sum, 0u, red, &ex, &dummy0, &tot, &dummy1);
-#pragma unroll
-        for (uint32_t b = 0; b < per; b++) {
-            bend[b0 + b] = ex;
-            ex += c[b];
-        }
-    }
-    __syncthreads();
-    for (uint32_t k = tid; k < n; k += T) {
-        const uint32_t at = atomicAdd(&bend[pix_bucket(key[k])], 1u);
-        sorted[at] = (uint16_t) k;
-    }
-    __syncthreads();
-    if (ECAL_SL_STOP == 2) return;
-    // d. first occurrence per (pixel, polarity); erase pixels that fired with both polarities (EventFrame.cpp:24-32)
-    for (uint32_t k = tid; k < n; k += T) {
-        const uint32_t p = key[k];
-        const uint32_t b = pix_bucket(p);
-        uint32_t m = b ? bend[b - 1] : 0u;
-        const uint32_t e = bend[b];
-        uint32_t minP = NONE, minN = NONE;
-        for (; m < e; m++) {
-            const uint32_t j = sorted[m];
-            const uint32_t q = key[j];
-            if (((q ^ p) & 0x3FFFFFFFu) == 0u) {
-                if (q & 0x40000000u) minP = min(minP, j); else minN = min(minN, j);
-            }
-        }
-        const bool erased = (minP != NONE) && (minN != NONE);
-        rep[k] = (uint16_t) (erased ? NONE : ((p & 0x40000000u) ? minP : minN));
-    }
-    __syncthreads();  // bend is dead from here: pos takes its place
-    if (ECAL_SL_STOP == 3) return;
-    // e. ranks of the representatives in event order (blocked ownership: contiguous k per thread)
-    const uint32_t per = (n + T - 1) / T, k0 = tid * per;
-    uint32_t cntP = 0, cntN = 0;
-    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if (rep[k] == k) { if (key[k] & 0x40000000u) cntP++; else cntN++; }
-    }
-    uint32_t exP, exN, nP, nN;
-    block_exscan2<T>(cntP, cntN, red, &exP, &exN, &nP, &nN);
-    for (uint32_t k = k0; k < k0 + per && k < n; k++) {
-        if (rep[k] == k) pos[k] = (uint16_t) ((key[k] & 0x40000000u) ? exP++ : exN++);
-    }
-    __syncthreads();
-    if (ECAL_SL_STOP == 4) return;
-    // f. outputs: positives first, then negatives (canonical order = first occurrence)
-    double2 *out2 = reinterpret_cast<double2 *>(xy_out) + base;
-    int32_t *ep = event_point ? event_point + base : nullptr;
-    for (uint32_t k = tid; k < n; k += T) {
-        const uint32_t r = rep[k];
-        if (r == NONE) {
-            if (ep) ep[k] = -1;
-        } else {
-            const uint32_t at = pos[r];
-            if (ep) ep[k] = (int32_t) at;
-            if (r == k) {
-                const uint32_t p = key[k];
-                double2 v;
-                v.x = (double) (((int) (p << 17)) >> 17);
-                v.y = (double) (((int) (p << 2)) >> 17);
-                out2[(p & 0x40000000u) ? at : nP + at] = v;
-            }
-        }
-    }
-    if (tid == 0) {
-        seg_off[2 * s] = base;
-        seg_cnt[2 * s] = nP;
-        seg_off[2 * s + 1] = base + nP;
-        seg_cnt[2 * s + 1] = nN;
-    }
-}
-
-
 // Bucket numbers of every sensor pixel the first pass can see (x <= 2047, y <= 1023), for the seven bucket counts a set of
 // up to 1109 keys goes through: [pix = x << 10 | y] -> { epochs 4, 5, 6 packed 9 + 10 + 11 bits, epochs 0 .. 3 packed
 // 4 + 5 + 6 + 7 bits }.  Built once per context (16 MB); the slicer then needs ONE 8-byte gather per key instead of the
@@ -1062,7 +888,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
     // (packed points: every segment starts as "doubles"; the pixel kernels mark the windows they pack.  The hash slicers — the
     // default — write the mark of EVERY window they look at, also of the ones they pass on: no wipe, one launch less per pass)
-    const bool hash_slicer = !ctx->sw.slice_no_pixel && (reforder || !ctx->sw.slice_sort_kernel);
+    const bool hash_slicer = !ctx->sw.slice_no_pixel;
     if (sfmt && !hash_slicer) ECAL_HIP_TRY(ctx, hipMemsetAsync(sfmt, 0, 2 * (size_t) S * sizeof(uint32_t), st));
     const uint32_t mx = max_win_events ? max_win_events : 0xFFFFFFFFu;
     // pixel windows first; what they leave over (longer windows, non-integer coordinates) is listed for the general tiers
@@ -1074,7 +900,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     const bool lean = plan == ECAL_PLAN_LEAN;
     // semi: first and second pass as always, then the global-scratch tier alone for whatever the second pass leaves (nothing, when
     // this stage last ran) instead of the two LDS tiers + it
-    const bool semi = plan == ECAL_PLAN_SEMI && reforder && !ctx->sw.slice_no_second_pass;
+    const bool semi = plan == ECAL_PLAN_SEMI && reforder;
     const uint32_t *cnt_a = nullptr, *cnt_b = nullptr;
     if (!ctx->sw.slice_no_pixel) {
         int rc;
@@ -1090,34 +916,29 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         todo = list;
         todo_count = cnt;
         cnt_a = cnt;
-        if (reforder || !ctx->sw.slice_sort_kernel) {   // (debug switch: the counting-sort form, which also takes negative pixels)
-            if (reforder) {
-                if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
-                hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
-                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt,
-                                   (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
-            }
+        if (reforder) {
+            if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
+            hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
+                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt,
+                               (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
+        }
+        else
+            hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
+                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, xy16, sfmt);
+        // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
+        if (!lean && (reforder || mx > PixHash<11>::CAP)) {
+            cnt_b = cnt2;
+            const uint32_t grid2 = S < 768u ? S : 768u;
+            if (reforder)
+                hipLaunchKernelGGL(slice_hash_list_kernel<true>, dim3(grid2), dim3(PXH_T), H12, st, d_events, d_win_lo,
+                                   d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
+                                   cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
             else
-                hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
-                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, xy16, sfmt);
-            // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
-            if (!lean && (reforder || mx > PixHash<11>::CAP) && !ctx->sw.slice_no_second_pass) {
-                cnt_b = cnt2;
-                const uint32_t grid2 = S < 768u ? S : 768u;
-                if (reforder)
-                    hipLaunchKernelGGL(slice_hash_list_kernel<true>, dim3(grid2), dim3(PXH_T), H12, st, d_events, d_win_lo,
-                                       d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
-                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
-                else
-                    hipLaunchKernelGGL(slice_hash_list_kernel<false>, dim3(grid2), dim3(PXH_T), PixHash<12>::bytes, st, d_events, d_win_lo,
-                                       d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
-                                       cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) nullptr, xy16, sfmt);
-                todo = list2;
-                todo_count = cnt2;
-            }
-        } else {
-            hipLaunchKernelGGL(slice_pixel_kernel, dim3(S), dim3(PXS_T), PixSliceLayout::bytes, st, d_events, d_win_lo, d_win_hi,
-                               d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt);
+                hipLaunchKernelGGL(slice_hash_list_kernel<false>, dim3(grid2), dim3(PXH_T), PixHash<12>::bytes, st, d_events, d_win_lo,
+                                   d_win_hi, d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list2,
+                                   cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) nullptr, xy16, sfmt);
+            todo = list2;
+            todo_count = cnt2;
         }
         grid = S < 512u ? S : 512u;
     }

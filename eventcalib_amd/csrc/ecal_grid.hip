@@ -533,7 +533,7 @@ __global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *_
                        a2 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 32), a3 = (uint32_t) __builtin_amdgcn_readlane((int) acc, 48);
         const uint32_t j0 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 0), j1 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 16),
                        j2 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 32), j3 = (uint32_t) __builtin_amdgcn_readlane((int) jr, 48);
-        const bool clash = (debug & 2) /* ECAL_GRID_SERIAL_WALK: always the one-after-the-other form */ || (a0 && a1 && j0 == j1) || (a0 && a2 && j0 == j2) || (a0 && a3 && j0 == j3) || (a1 && a2 && j1 == j2) ||
+        const bool clash = (debug & 2) /* ECAL_FORCE=grid_serial_walk: always the one-after-the-other form */ || (a0 && a1 && j0 == j1) || (a0 && a2 && j0 == j2) || (a0 && a3 && j0 == j3) || (a1 && a2 && j1 == j2) ||
                            (a1 && a3 && j1 == j3) || (a2 && a3 && j2 == j3);
         uint32_t n_new = 0;
         if (!clash) {
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(GR_T * NW) void grid_order_kernel(const uint32_t *_
             GR_MARK(6);   // matches after sweeps
         }
     }
-    if ((debug & 1) && !got && lane == 0) out[8 + start] = -2000 - (int32_t) qt;   // (ECAL_GRID_DEBUG: nodes placed by a start that failed)
+    if ((debug & 1) && !got && lane == 0) out[8 + start] = -2000 - (int32_t) qt;   // (ECAL_TRACE=grid: nodes placed by a start that failed)
     if constexpr (NW > 1) {
         if (got && lane == 0) atomicMin(&best_start_sh, (uint32_t) start);
     }
@@ -932,7 +932,7 @@ int ecal_grid_order_dirs_dev(ecal_ctx *ctx, const uint32_t *d_win_info, const ui
     const double tol_px = ctx->sw.grid_tol_px;   // (ECAL_GRID_TOL_PX, a debug switch for tests of the tolerance's effect; default = the reference's 20 px)
     const int dbg = (ctx->sw.grid_debug ? 1 : 0) | (ctx->sw.grid_serial_walk ? 2 : 0);
     // few windows at work (the caller's word, ecal_ctx::grid_hint_windows — the keyframe search knows how many pieces are still
-    // active —, else the launch's size): the latency form, a wave per start; ECAL_GRID_ONE_WAVE=1 keeps the one-wave form
+    // active —, else the launch's size): the latency form, a wave per start; ECAL_FORCE=grid_one_wave keeps the one-wave form
     const uint32_t at_work = ctx->grid_hint_windows ? ctx->grid_hint_windows : S;
     if (at_work <= GR_PARALLEL_MAX && !ctx->sw.grid_one_wave && !ctx->sw.grid_debug)
         hipLaunchKernelGGL(grid_order_kernel<4>, dim3(S), dim3(GR_T * 4), 0, (hipStream_t) stream, d_win_info, d_seg_off,

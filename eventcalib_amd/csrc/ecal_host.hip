@@ -144,7 +144,7 @@ extern "C" int ecal_stream_create_from_file(ecal_ctx *ctx, const char *path, dou
     constexpr int NT = 6;                                // reader threads = pinned buffers
     uint8_t *pin[NT] = {};
     hipEvent_t done[NT] = {};
-    const bool load_trace = getenv("ECAL_LOAD_TRACE") != nullptr;   // (debug: where the loader's time goes, on stderr)
+    const bool load_trace = ctx->sw.load_trace;   // (ECAL_TRACE=load: where the loader's time goes, on stderr)
     const auto lt0 = std::chrono::steady_clock::now();
     auto lt = [&](const char *what) {
         if (load_trace)

@@ -25,7 +25,6 @@
 #include "ecal_ctx.hpp"
 #include "spline_residual.hpp"
 #include "arrow_layout.hpp"
-#include "arrow_device.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -956,209 +955,6 @@ extern "C" void ecal_lm_default_options(ecal_lm_options *o) {
     o->world_size = 1;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Levenberg-Marquardt with the linear algebra on the device (arrow_device.hpp): per iteration the host reads back ONE
-// 64-byte record (failure flag, g^T d, d^T A d, |d|^2, |x|^2, the candidate's cost and gradient max-norm) and decides;
-// parameters, normal equations, factors and the step never leave HBM.  Same control flow as the host loop below
-// (Ceres' trust-region minimiser restated); used on one rank, the host loop serves the sharded modes.
-// ------------------------------------------------------------------------------------------------
-namespace {
-
-struct DeviceLm {
-    ecal_ctx *ctx;
-    ArrowPlan plan;
-    double *x[2] = {nullptr, nullptr}, *acc[2] = {nullptr, nullptr};
-    double *scale = nullptr, *delta = nullptr, *Lfac = nullptr, *Zfac = nullptr, *Gp = nullptr, *Lred = nullptr, *Zred = nullptr,
-           *Gtot = nullptr, *yred = nullptr, *sc = nullptr;   // sc: [0..3] sums, [4] fail (int), [5] gmax bits, [6] cost
-    double *h_sc = nullptr;
-    std::vector<void *> owned;
-    ~DeviceLm() {
-        for (void *p : owned) (void) hipFree(p);
-        if (h_sc) (void) hipHostFree(h_sc);
-    }
-};
-
-ArrowPlan make_arrow_plan(uint32_t n_cp, int forced_k) {
-    ArrowPlan pl;
-    pl.n_cp = n_cp;
-    // interiors cost ~6 K column steps each (in parallel), the separators' system 18 (P - 1) ~ 18 n_cp / K: balanced at K ~ sqrt(3 n_cp)
-    pl.K = std::max<uint32_t>(21u, (uint32_t) std::sqrt(3.0 * (double) n_cp));
-    if (forced_k > 0) pl.K = (uint32_t) std::max(3, forced_k);   // (ECAL_ARROW_K: debug switch; tests: many partitions on small problems)
-    pl.P = std::max<uint32_t>(1u, n_cp / (pl.K + 3u));
-    return pl;
-}
-
-}  // namespace
-
-// (S A S + D) y = -S g on the device for the normal equations in d_accum; d_delta [6 n_cp + 9] = S y.  Exposed for the
-// tests (the host solve is the checker); *fail_out = 1 when the matrix is not positive definite.
-extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const double *scale, double radius, double min_diag,
-                                      double max_diag, double *delta_out, int *fail_out, int use_device);
-
-static int arrow_solve_dev(ecal_solver *s, DeviceLm &D, const double *d_acc, const ArrowLm lm, hipStream_t st) {
-    const ArrowPlan &pl = D.plan;
-    int *fail = reinterpret_cast<int *>(D.sc + 4);
-    hipLaunchKernelGGL(arrow_interior_kernel, dim3(pl.P), dim3(64), 0, st, d_acc, (const double *) D.scale, pl, lm, D.Lfac, D.Zfac, fail);
-    hipLaunchKernelGGL(arrow_gram_kernel, dim3(pl.P), dim3(256), 0, st, pl, (const double *) D.Zfac, D.Gp);
-    hipLaunchKernelGGL(arrow_reduced_kernel, dim3(1), dim3(64), 0, st, d_acc, (const double *) D.scale, pl, lm, (const double *) D.Gp, D.Lred,
-                       D.Zred, D.Gtot, fail);
-    hipLaunchKernelGGL(arrow_corner_kernel, dim3(1), dim3(64), (pl.n_red() + 1) * sizeof(double), st, d_acc, (const double *) D.scale, pl, lm,
-                       (const double *) D.Gtot, (const double *) D.Lred, (const double *) D.Zred, D.yred, fail, 1);
-    hipLaunchKernelGGL(arrow_backsub_kernel, dim3(pl.P), dim3(64), (size_t) 6 * (2 * pl.K + 6) * sizeof(double), st, (const double *) D.scale, pl,
-                       (const double *) D.Lfac, (const double *) D.Zfac, (const double *) D.yred, D.delta);
-    (void) s;
-    return hipGetLastError() == hipSuccess ? ECAL_OK : ECAL_ERR_HIP;
-}
-
-static int device_lm_alloc(ecal_solver *s, DeviceLm &D) {
-    ecal_ctx *ctx = s->ctx;
-    D.ctx = ctx;
-    D.plan = make_arrow_plan(s->n_cp, s->ctx->sw.arrow_k);
-    const size_t nc = 6 * (size_t) s->n_cp, np = s->n_params(), na = s->n_accum();
-    auto get = [&](double **p, size_t n) -> bool {
-        if (hipMalloc((void **) p, (n ? n : 1) * sizeof(double)) != hipSuccess) return false;
-        D.owned.push_back(*p);
-        return true;
-    };
-    const size_t P = D.plan.P, nred = D.plan.n_red();
-    bool ok = get(&D.x[1], np) && get(&D.acc[1], na) && get(&D.scale, nc + 9) && get(&D.delta, nc + 9) && get(&D.Lfac, nc * AR_BW) &&
-              get(&D.Zfac, nc * AR_NB) && get(&D.Gp, P * AR_NB * AR_NB) && get(&D.Lred, (nred + 1) * AR_RBW) &&
-              get(&D.Zred, (nred + 1) * AR_RNB) && get(&D.Gtot, 100) && get(&D.yred, nred + 9) && get(&D.sc, 8);
-    if (ok && hipHostMalloc((void **) &D.h_sc, 8 * sizeof(double), hipHostMallocDefault) != hipSuccess) ok = false;
-    if (!ok) {
-        ctx->last_error = "device LM: out of memory";
-        return ECAL_ERR_NOMEM;
-    }
-    D.x[0] = s->d_params;
-    D.acc[0] = s->d_accum;
-    if (6 * (2 * (size_t) D.plan.K + 6) * sizeof(double) > 60000 || (nred + 1) * sizeof(double) > 60000) {
-        ctx->last_error = "device LM: problem too large for the LDS-resident back substitutions";
-        return ECAL_ERR_RANGE;
-    }
-    return ECAL_OK;
-}
-
-static int device_lm_solve(ecal_solver *s, double *params, const ecal_lm_options &opt, ecal_lm_summary *sum) {
-    ecal_ctx *ctx = s->ctx;
-    hipStream_t st = ctx->stream;
-    const size_t np = s->n_params(), nc = 6 * (size_t) s->n_cp, nt = nc + 9;
-    DeviceLm D;
-    int rc = device_lm_alloc(s, D);
-    if (rc) return rc;
-    const auto t_begin = std::chrono::steady_clock::now();
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double>(b - a).count();
-    };
-    double t_eval = 0, t_lin = 0;
-    int cur = 0;   // x[cur], acc[cur]: the current point and its normal equations
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(D.x[0], params, np * sizeof(double), hipMemcpyHostToDevice, st));
-    const uint32_t gblocks = (uint32_t) ((nt + 255) / 256), pblocks = (uint32_t) ((std::max(nt, np) + 255) / 256);
-    auto eval = [&](int which, int with_jac) -> int {   // normal equations (or the cost alone) of x[which] into acc[which]; gmax with them
-        int r = ecal_solver_evaluate_dev(s, D.x[which], with_jac, D.acc[which], st);
-        if (r) return r;
-        if (hipMemsetAsync(D.sc + 5, 0, sizeof(double), st) != hipSuccess) return ECAL_ERR_HIP;
-        if (with_jac) hipLaunchKernelGGL(arrow_gmax_kernel, dim3(gblocks), dim3(256), 0, st, (const double *) D.acc[which], s->n_cp,
-                                         reinterpret_cast<unsigned long long *>(D.sc + 5));
-        if (hipMemcpyAsync(D.sc + 6, D.acc[which], sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess) return ECAL_ERR_HIP;
-        return ECAL_OK;
-    };
-    auto fetch = [&]() -> int {   // the one host round trip of an iteration
-        if (hipMemcpyAsync(D.h_sc, D.sc, 8 * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return ECAL_ERR_HIP;
-        if (hipStreamSynchronize(st) != hipSuccess) return ECAL_ERR_HIP;
-        return ECAL_OK;
-    };
-    ecal_lm_summary S;
-    memset(&S, 0, sizeof(S));
-    double radius = opt.initial_trust_region_radius, decrease_factor = 2.0;
-    auto te = now();
-    if ((rc = eval(0, 1)) || (rc = fetch())) return rc;
-    t_eval += secs(te, now());
-    double cost = D.h_sc[6], gmax = D.h_sc[5];
-    S.jacobian_evaluations = 1;
-    S.initial_cost = cost;
-    hipLaunchKernelGGL(arrow_scale_kernel, dim3(gblocks), dim3(256), 0, st, (const double *) D.acc[0], s->n_cp, opt.jacobi_scaling, D.scale);
-    S.termination = 1;
-    if (gmax <= opt.gradient_tolerance) S.termination = 0;
-    bool last_step_ok = true;
-    while (S.termination == 1 && S.iterations < opt.max_num_iterations) {
-        S.iterations++;
-        const int cand = cur ^ 1;
-        const ArrowLm lm{radius, opt.min_lm_diagonal, opt.max_lm_diagonal};
-        const bool speculate = last_step_ok;
-        const auto tl = now();
-        ECAL_HIP_TRY(ctx, hipMemsetAsync(D.sc, 0, 5 * sizeof(double), st));
-        if ((rc = arrow_solve_dev(s, D, D.acc[cur], lm, st))) return rc;
-        hipLaunchKernelGGL(arrow_quad_kernel, dim3(pblocks), dim3(256), 0, st, (const double *) D.acc[cur], (const double *) D.delta,
-                           (const double *) D.x[cur], s->n_cp, (uint32_t) np, D.sc);
-        if (s->use_so3)
-            hipLaunchKernelGGL(lm_plus_kernel<true>, dim3((s->n_cp + 9 + 255) / 256), dim3(256), 0, st, (const double *) D.x[cur],
-                               (const double *) D.delta, s->n_cp, D.x[cand]);
-        else
-            hipLaunchKernelGGL(lm_plus_kernel<false>, dim3((s->n_cp + 9 + 255) / 256), dim3(256), 0, st, (const double *) D.x[cur],
-                               (const double *) D.delta, s->n_cp, D.x[cand]);
-        // the candidate is evaluated before the host knows whether the step is valid: invalid steps are rare and cost one
-        // wasted pass, every other iteration saves a round trip
-        if ((rc = eval(cand, speculate ? 1 : 0)) || (rc = fetch())) return rc;
-        const double spent = secs(tl, now());
-        t_lin += 0.0;   // (the device passes are not timed apart; seconds_evaluate carries the iteration)
-        t_eval += spent;
-        int fail_flag;
-        memcpy(&fail_flag, &D.h_sc[4], sizeof(int));
-        const double gTd = D.h_sc[0], dHd = D.h_sc[1], step2 = D.h_sc[2], x2 = D.h_sc[3], new_cost = D.h_sc[6], new_gmax = D.h_sc[5];
-        const double model_change = -gTd - 0.5 * dHd;
-        const bool ok = !fail_flag && model_change > 0.0 && std::isfinite(new_cost);
-        if (!ok) {   // invalid step: shrink the region
-            radius /= decrease_factor;
-            decrease_factor *= 2.0;
-            S.unsuccessful_steps++;
-            continue;
-        }
-        if (speculate) S.jacobian_evaluations++;
-        else S.cost_evaluations++;
-        const double rel = (cost - new_cost) / model_change;
-        if (rel > opt.min_relative_decrease) {
-            const double cost_change = cost - new_cost, prev = cost;
-            cur = cand;
-            double g_here = new_gmax;
-            if (speculate) {
-                cost = new_cost;
-            } else {   // the probe carried the cost only: the normal equations at the accepted point
-                te = now();
-                if ((rc = eval(cur, 1)) || (rc = fetch())) return rc;
-                t_eval += secs(te, now());
-                cost = D.h_sc[6];
-                g_here = D.h_sc[5];
-                S.jacobian_evaluations++;
-            }
-            S.successful_steps++;
-            last_step_ok = true;
-            const double t = 2.0 * rel - 1.0;
-            radius = std::min(opt.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
-            decrease_factor = 2.0;
-            if (g_here <= opt.gradient_tolerance) S.termination = 0;
-            else if (std::fabs(cost_change) <= opt.function_tolerance * prev) S.termination = 0;
-        } else {
-            radius /= decrease_factor;
-            decrease_factor *= 2.0;
-            S.unsuccessful_steps++;
-            last_step_ok = false;
-        }
-        if (S.termination == 1 && std::sqrt(step2) <= opt.parameter_tolerance * (std::sqrt(x2) + opt.parameter_tolerance)) S.termination = 0;
-    }
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(params, D.x[cur], np * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (cur != 0) {   // the solver's own buffers hold the solution state again
-        ECAL_HIP_TRY(ctx, hipMemcpyAsync(s->d_params, D.x[cur], np * sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
-    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
-    S.final_cost = cost;
-    S.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    S.seconds_evaluate = t_eval;
-    S.seconds_linear_solve = t_lin;
-    if (sum) *sum = S;
-    return ECAL_OK;
-}
-
 extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_options *opt_in,
                                  ecal_lm_summary *sum) {
     const ecal_range range__(s ? s->ctx : nullptr, "ecal_solver_solve");
@@ -1174,13 +970,6 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     }
     ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    // ECAL_SOLVER_DEVICE_LINEAR_SOLVE=1 (one rank): the whole iteration on the device (arrow_device.hpp) — correct and tested,
-    // but measured SLOWER than the host factorisation on the benchmark problem (12 009 unknowns: 2.9 ms of device kernels per
-    // linear solve against 1.3 ms on one host core + 0.5 ms of copies), so the host loop stays the default.
-    if (!opt.allreduce && s->ctx->sw.solver_device_linear_solve) {
-        const int rc_dev = device_lm_solve(s, params, opt, sum);
-        if (rc_dev != ECAL_ERR_RANGE) return rc_dev;                     // (too large for the LDS-resident parts: host loop)
-    }
     const size_t np = s->n_params(), na = s->n_accum(), nc = 6 * (size_t) s->n_cp, nt = nc + 9;
     std::vector<double> x(params, params + np), xc(np), delta, scale(nt, 1.0), dd(nt);
     ArrowSystem A;
@@ -1399,7 +1188,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
     ArrowSystem A_next;
     std::vector<double> dd_next(nt);
     bool reduced_ok = false;   // a streamed evaluation with `factor`: every separator of the reduced system eliminated
-    std::vector<double> tl_arrive, tl_done;   // ECAL_SOLVER_TRACE: the last streamed evaluation's timeline (seconds from its start)
+    std::vector<double> tl_arrive, tl_done;   // ECAL_TRACE=solver: the last streamed evaluation's timeline (seconds from its start)
     double tl_run = 0, tl_sync = 0;
     double t_tail = 0;
     // An: the system at xp.  factor: also arrow_part_factor of every interior, with the LM diagonal of trust-region radius
@@ -1526,7 +1315,7 @@ extern "C" int ecal_solver_solve(ecal_solver *s, double *params, const ecal_lm_o
         t_fin_back += secs(tb, now());
         return true;
     };
-    double t_dd = 0, t_fin = 0, t_quad = 0, t_plus = 0, t_book = 0;   // ECAL_SOLVER_TRACE: the host's share of an iteration, by item
+    double t_dd = 0, t_fin = 0, t_quad = 0, t_plus = 0, t_book = 0;   // ECAL_TRACE=solver: the host's share of an iteration, by item
     while (S.termination == 1 && S.iterations < opt.max_num_iterations) {
         S.iterations++;
         const auto t_it = now();
@@ -1772,8 +1561,8 @@ extern "C" void ecal_inverse_radial_distortion(const double *k4, double *b5) {
 }
 
 // Test hook: one linear solve (S A S + D) y = -S g, delta = S y, for the normal equations `accum` (host, ecal_solver_normal_size
-// doubles) and the column scaling `scale` (host, 6 n_cp + 9) — on the device (arrow_device.hpp) or by the host routine the
-// sharded modes use.  tests/test_gpu_solver.py requires the two to agree.
+// doubles) and the column scaling `scale` (host, 6 n_cp + 9) by the host routines (sequential, partitioned, the streamed
+// evaluation's partition); tests/test_gpu_solver.py requires them to agree.
 // The host's linear solves alone (no GPU involved): the accumulation buffer of n_cp control points (ecal_solver_normal_size
 // layout) -> the LM step.  mode 0: the sequential routine (solve_arrow); 2: the partitioned one (arrow_host_parts.hpp) with `parts`
 // interiors on a few threads; 3: the same on the streamed evaluation's partition (interiors shrinking towards the end).
@@ -1813,27 +1602,9 @@ extern "C" int ecal_debug_arrow_partition(uint32_t n_cp, int parts, int stream, 
 }
 
 extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const double *scale, double radius, double min_diag,
-                                      double max_diag, double *delta_out, int *fail_out, int use_device) {
-    if (!s || !accum || !scale || !delta_out || !fail_out) return ECAL_ERR_INVALID;
-    ecal_ctx *ctx = s->ctx;
-    const size_t nc = 6 * (size_t) s->n_cp, nt = nc + 9, na = s->n_accum();
-    if (use_device != 1) return ecal_debug_arrow_solve_host(s->n_cp, accum, scale, radius, min_diag, max_diag, delta_out, fail_out, use_device, 0);
-    ECAL_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    DeviceLm D;
-    int rc = device_lm_alloc(s, D);
-    if (rc) return rc;
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(D.acc[1], accum, na * sizeof(double), hipMemcpyHostToDevice, st));
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(D.scale, scale, nt * sizeof(double), hipMemcpyHostToDevice, st));
-    ECAL_HIP_TRY(ctx, hipMemsetAsync(D.sc, 0, 8 * sizeof(double), st));
-    ECAL_HIP_TRY(ctx, hipMemsetAsync(D.delta, 0, nt * sizeof(double), st));
-    const ArrowLm lm{radius, min_diag, max_diag};
-    if ((rc = arrow_solve_dev(s, D, D.acc[1], lm, st))) return rc;
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(delta_out, D.delta, nt * sizeof(double), hipMemcpyDeviceToHost, st));
-    ECAL_HIP_TRY(ctx, hipMemcpyAsync(D.h_sc, D.sc, 8 * sizeof(double), hipMemcpyDeviceToHost, st));
-    ECAL_HIP_TRY(ctx, hipStreamSynchronize(st));
-    memcpy(fail_out, &D.h_sc[4], sizeof(int));
-    return ECAL_OK;
+                                      double max_diag, double *delta_out, int *fail_out, int mode) {
+    if (!s || !accum || !scale || !delta_out || !fail_out || mode == 1) return ECAL_ERR_INVALID;   // (1 was the device form, round 3 - 5)
+    return ecal_debug_arrow_solve_host(s->n_cp, accum, scale, radius, min_diag, max_diag, delta_out, fail_out, mode, 0);
 }
 
 #ifdef ECAL_PHASE_PROF

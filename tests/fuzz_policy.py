@@ -1,5 +1,5 @@
 """The device policy's look-ahead (ecal_detect_keyframes follows every piece's likely chain of windows) against the
-same call with one window per piece and pass (ECAL_ADAPTIVE_DEPTH=1: the reference's loop as it stands, which the tests pin
+same call with one window per piece and pass (ECAL_ADAPTIVE_SHAPE=depth=1,depth_max=1: the reference's loop as it stands, which the tests pin
 on the policy oracle) over random streams, rates and piece counts: same keyframes, same windows.
 `python tests/fuzz_policy.py N` runs N seeds; tests/test_gpu_fuzz.py runs a bounded, fixed-seed sweep as a -m gpu test."""
 import os, sys, itertools
@@ -20,16 +20,16 @@ def run(seeds, rates=RATES, pieces_list=PIECES, ctx=None, verbose=True, n=1_200_
     if own:
         ctx = eventcalib_amd.Context(0)
     n_ok = n_kf = 0
-    saved = {k: os.environ.get(k) for k in ("ECAL_ADAPTIVE_DEPTH", "ECAL_ADAPTIVE_DEPTH_MAX")}
+    saved = {k: os.environ.get(k) for k in ("ECAL_ADAPTIVE_SHAPE",)}
     try:
         for seed, rate, pieces in itertools.product(seeds, rates, pieces_list):
             ev = SS.make_stream(n, rate=rate, device="cuda", seed=500 + seed, noise_frac=0.05 + 0.05 * (seed % 6))
             torch.cuda.synchronize()
             t_first, t_last = 5.0, 5.0 + (n - 1) / rate
-            os.environ.pop("ECAL_ADAPTIVE_DEPTH", None); os.environ.pop("ECAL_ADAPTIVE_DEPTH_MAX", None)
+            os.environ.pop("ECAL_ADAPTIVE_SHAPE", None)
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             a = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last)
-            os.environ["ECAL_ADAPTIVE_DEPTH"] = "1"; os.environ["ECAL_ADAPTIVE_DEPTH_MAX"] = "1"
+            os.environ["ECAL_ADAPTIVE_SHAPE"] = "depth=1,depth_max=1"
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
             b = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last)
             for k in ("time", "duration", "events_num", "features"):

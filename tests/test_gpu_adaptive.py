@@ -118,8 +118,7 @@ def test_look_ahead_does_not_change_the_keyframes(env, slots, chain, monkeypatch
     ctx, pipe, ev, torch = env
     t_first, t_last = 5.0, 5.0 + 0.4
     want = detect_keyframes_device(ctx, ev, 5e-4, 4000, 23, t_first, t_last)
-    monkeypatch.setenv("ECAL_ADAPTIVE_DEPTH", str(slots))
-    monkeypatch.setenv("ECAL_ADAPTIVE_DEPTH_MAX", str(chain))
+    monkeypatch.setenv("ECAL_ADAPTIVE_SHAPE", "depth=%d,depth_max=%d" % (slots, chain))
     __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     got = detect_keyframes_device(ctx, ev, 5e-4, 4000, 23, t_first, t_last)
     assert len(want["time"]) >= 20
@@ -146,21 +145,19 @@ def _same_keyframes(dev, ref):
         assert np.array_equal(dev[k], ref[k]), k
 
 
-def _in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_ROUNDS", value="1"):
-    """The shared-map search with the verification after every SET of runs (ECAL_ADAPTIVE_ROUNDS=1: the form before round 4's
-    pass-by-pass verification, kept behind the switch) or WITHOUT the side chains behind accepted windows (ECAL_ADAPTIVE_SIDE=0;
-    with them is the default since round 5), or with the rows' line fits in adaptive_dir_kernel instead of the grid finder's epilogue
-    (ECAL_ADAPTIVE_DIR_KERNEL=1), or with another shape of the tree of chains a piece's window slots form (ECAL_ADAPTIVE_TREE; 0: none)
-    — must give the same keyframes."""
+def _in_rounds(ctx, ev, pieces, t_first, t_last, switch, value):
+    """The shared-map search WITHOUT the side chains behind accepted windows (ECAL_ADAPTIVE_SHAPE side=0; with them is the default since
+    round 5), or with another shape of the tree of chains a piece's window slots form (ECAL_ADAPTIVE_SHAPE tree=…; 0: none) — must give the
+    same keyframes."""
     import os
     import eventcalib_amd.capi as capi
     from eventcalib_amd.adaptive import detect_keyframes_device
-    os.environ[switch] = value
+    os.environ["ECAL_ADAPTIVE_SHAPE"] = "%s=%s" % (switch, value)
     capi.sync_env()
     try:
         return detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
     finally:
-        del os.environ[switch]
+        del os.environ["ECAL_ADAPTIVE_SHAPE"]
         capi.sync_env()
 
 
@@ -169,7 +166,7 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     """gate_mode = ECAL_GATE_SHARED_MAP against oracle/policy_oracle.cpp mode 1: ONE keyframe map for all pieces, pieces in the
     reference's pop_back order, only the very first frame ungated (TrackingBase.cpp:16-46, EventCalibIni.cpp:26-36) — what the
     reference computes with a single worker thread.  The product gets there by speculation + verification, pass by pass
-    (ecal_adaptive.hip: adaptive_verify_live_kernel) or in rounds; keyframes, windows and counts must be the sequential run's."""
+    (ecal_adaptive.hip: adaptive_verify_live_kernel); keyframes, windows and counts must be the sequential run's."""
     import oracle_lib as O
     import eventcalib_amd.capi as capi
     from eventcalib_amd.adaptive import detect_keyframes_device
@@ -183,14 +180,11 @@ def test_shared_map_gate_equals_the_single_worker_reference(env, pieces):
     dev = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
     assert len(ref["time"]) >= 20
     _same_keyframes(dev, ref)
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last), ref)
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="0"), ref)   # without the side chains behind accepted windows
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_SIDE", value="1"), ref)   # the measured layout, named
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value="0"), ref)   # chains and side chains only (no tree of chains behind acceptances)
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value=str(4 | (4 << 8) | (2 << 16) | (2 << 20) | (2 << 24) | (1 << 28))), ref)   # a small tree: chains that end early, three levels
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_TREE", value=str(12 | (10 << 8) | (6 << 16) | (5 << 20) | (0 << 24) | (0 << 28))), ref)   # a wide one from position 0, two levels
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_VERIFY_IN_ALLOC", value="1"), ref)   # verification and restarts in front of the slot allocation, one launch (default: launches of their own)
-    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="ECAL_ADAPTIVE_DIR_KERNEL", value="1"), ref)   # the rows' line fits by a kernel of their own (default: in the grid finder's epilogue)
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="side", value="0"), ref)   # without the side chains behind accepted windows
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="side", value="1"), ref)   # the measured layout, named
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="tree", value="0"), ref)   # chains and side chains only (no tree of chains behind acceptances)
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="tree", value=str(4 | (4 << 8) | (2 << 16) | (2 << 20) | (2 << 24) | (1 << 28))), ref)   # a small tree: chains that end early, three levels
+    _same_keyframes(_in_rounds(ctx, ev, pieces, t_first, t_last, switch="tree", value=str(12 | (10 << 8) | (6 << 16) | (5 << 20) | (0 << 24) | (0 << 28))), ref)   # a wide one from position 0, two levels
     if pieces == 1:
         _same_keyframes(dev, own)              # one piece: the two modes are the same run
     _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last), own)
@@ -219,7 +213,7 @@ def test_shared_map_gate_at_the_reference_s_piece_count():
         print("keyframes: shared map %d, own piece %d" % (len(ref["time"]), len(own["time"])))
         assert len(ref["time"]) >= 1000 and not np.array_equal(ref["time"], own["time"])   # the modes differ: the test bites
         _same_keyframes(dev, ref)
-        _same_keyframes(_in_rounds(ctx, ev, 1270, t_first, t_last), ref)
+        _same_keyframes(_in_rounds(ctx, ev, 1270, t_first, t_last, switch="tree", value="0"), ref)
         _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, 1270, t_first, t_last), own)
     finally:
         ctx.close()

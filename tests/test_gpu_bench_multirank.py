@@ -100,3 +100,27 @@ def test_two_ranks_match_one_rank():
     # the ingest leg (configs[4]): the host-resident events split into one time range per rank
     assert one["ingest"]["events"] == two["ingest"]["events"] == 1000000 and two["ingest"]["events_per_gpu"] == 500000
     assert one["ingest"]["value"] > 0 and two["ingest"]["value"] > 0
+
+
+def test_eight_ranks_match_one_rank():
+    """The 8-way partitions of `bench.py --gpus 8` (what the driver launches on the 8-GPU node), executed here with eight ranks on
+    ONE GPU over gloo: 8 time ranges of the detection stream, the keyframe search's pieces cut over 8 ranks, 64 calibration views
+    8 per rank, the spline's time cut into 8 shards (distributed = 2) — each against the single-rank result.  No scaling figure is
+    read off this (eight contexts share one device); it shows that the partitions and the exchange are right at N = 8."""
+    one = _bench(1, ["--p2-pieces", "40"])
+    eight = _bench(8, ["--p2-pieces", "40"])
+    assert eight["n_gpus"] == 8 and eight["failed_legs"] == []
+    assert eight["config"]["events_covered_by_the_ranks_windows"] == 2000000 == eight["config"]["events_total"]
+    assert eight["config"]["windows_total"] == one["config"]["windows_total"]
+    assert eight["config"]["windows_per_gpu"] <= one["config"]["windows_per_gpu"] // 8 + 1
+    p1 = [p for p in one["policy_p2"] if p.get("driver") == "device" and p.get("gate") == "own piece"][0]
+    p8 = eight["policy_p2_sharded"]
+    assert p8["pieces"] == p1["pieces"] and p8["keyframes"] == p1["keyframes"] > 0 and p8["windows_evaluated"] == p1["windows_evaluated"]
+    c1, c8 = one["init_calibration"], eight["init_calibration"]
+    assert c8["views_per_gpu"] == 8 and abs(c1["rms_px"] - c8["rms_px"]) < 1e-9 and abs(c1["lm_iterations"] - c8["lm_iterations"]) <= 1
+    s1, s8 = one["solver"], eight["solver"]
+    assert s8["scaling"] == "strong" and s8["residuals"] == s1["residuals"] and s8["unknowns"] == s1["unknowns"]
+    tc = s8["check_vs_single_solver"]
+    assert tc["iterations"][0] == tc["iterations"][1]
+    assert tc["intrinsics_rel_diff"] < 1e-8 and tc["final_cost_rel_diff"] < 1e-9 and tc["control_points_abs_diff"] < 1e-6
+    assert eight["ingest"]["events_per_gpu"] == 125000

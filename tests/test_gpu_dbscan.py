@@ -136,7 +136,7 @@ def test_invalid_arguments(ctx):
 
 
 def test_pixel_and_general_kernels_agree(ctx):
-    """Integer pixel segments take the lean pixel kernel (dbscan_pixel.hpp); with ECAL_DBSCAN_NO_PIXEL the general
+    """Integer pixel segments take the lean pixel kernel (dbscan_pixel.hpp); with ECAL_FORCE=dbscan_general the general
     tiers do the same segments.  Both must equal the oracle — including the pruning quirk (integral eps), duplicate
     pixels (pixel kernel bails), a bounding box too large for its bitmap, and segments above its 1024-point capacity."""
     rng = np.random.default_rng(77)
@@ -157,15 +157,15 @@ def test_pixel_and_general_kernels_agree(ctx):
     xy = np.concatenate(segs)
     off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint32)
     for eps, minpts in ((4.0, 2), (3.0, 1), (5.0, 5), (4.5, 2), (15.0, 3), (16.0, 2)):
-        os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+        os.environ.pop("ECAL_FORCE", None)
         __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         la, na = ctx.dbscan_batch(xy, off, eps, minpts)
-        os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
+        os.environ["ECAL_FORCE"] = "dbscan_general"
         __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             lb, nb = ctx.dbscan_batch(xy, off, eps, minpts)
         finally:
-            os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+            os.environ.pop("ECAL_FORCE", None)
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         assert np.array_equal(la, lb) and np.array_equal(na, nb), (eps, minpts)
         ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)
@@ -174,7 +174,7 @@ def test_pixel_and_general_kernels_agree(ctx):
 
 def test_compiled_and_generic_disc_agree(ctx):
     """floor(eps^2) == 16 (the shipped eps = 4) runs the pixel kernel with the disc compiled in (packed half-disc word,
-    multiply-free anchor test); ECAL_DBSCAN_GENERIC_DISC forces the run-time disc on the same input.  Sparse noise
+    multiply-free anchor test); ECAL_FORCE=dbscan_generic_disc forces the run-time disc on the same input.  Sparse noise
     around dense arcs gives core points with non-core neighbours; eps = 4.1 has the same disc without the quirk."""
     rng = np.random.default_rng(5)
     segs = []
@@ -187,15 +187,15 @@ def test_compiled_and_generic_disc_agree(ctx):
     xy = np.concatenate(segs)
     off = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.uint32)
     for eps, minpts in ((4.0, 2), (4.0, 1), (4.0, 5), (4.1, 2)):
-        os.environ.pop("ECAL_DBSCAN_GENERIC_DISC", None)
+        os.environ.pop("ECAL_FORCE", None)
         __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         la, na = ctx.dbscan_batch(xy, off, eps, minpts)
-        os.environ["ECAL_DBSCAN_GENERIC_DISC"] = "1"
+        os.environ["ECAL_FORCE"] = "dbscan_generic_disc"
         __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             lb, nb = ctx.dbscan_batch(xy, off, eps, minpts)
         finally:
-            os.environ.pop("ECAL_DBSCAN_GENERIC_DISC", None)
+            os.environ.pop("ECAL_FORCE", None)
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         assert np.array_equal(la, lb) and np.array_equal(na, nb), (eps, minpts)
         ref_l, ref_n = O.dbscan_batch(xy, off[:-1], np.diff(off).astype(np.uint32), eps, minpts)

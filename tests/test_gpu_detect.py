@@ -229,7 +229,7 @@ def test_smaller_pid_rule_of_the_plain_primitive(env):
 
 def test_counter_words_from_the_ring_or_wiped_per_call(env, monkeypatch):
     """The to-do counters of the stage calls come from a per-stream ring of zeroed words (ecal_zero_words) or, without one —
-    ECAL_NO_ZERO_RING, or a fifth stream on one context —, from words wiped per call: same results, also across the ring's
+    a fifth stream on one context —, from words wiped per call: same results, also across the ring's
     half-by-half wipes (600 passes = 3 600 counter words on one stream)."""
     ctx, pipe, torch = env
     n = 200_000
@@ -257,11 +257,7 @@ def test_counter_words_from_the_ring_or_wiped_per_call(env, monkeypatch):
             pipe.run(ev)
             for a, b in zip(snapshot(), want):
                 assert torch.equal(a, b)
-    monkeypatch.setenv("ECAL_NO_ZERO_RING", "1")
-    __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
-    pipe.run(ev)
-    for a, b in zip(snapshot(), want):
-        assert torch.equal(a, b)
+
 
 
 def test_records_to_candidates_with_no_gpu_array_in_between(env):
@@ -374,7 +370,7 @@ def _tie_list_count(ctx, torch):
 def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, monkeypatch):
     """The exact extraction's first pass resolves the ties of small clusters itself (resolve_ties_inline: the DBSCAN kernel's
     kd-trees, a wave per tied cluster) instead of leaving the window on a list for the member-order launches and a second
-    extraction.  Same picks either way — every output array equal to the listed form's (ECAL_EXTRACT_NO_INLINE_TIES=1) and to the
+    extraction.  Same picks either way — every output array equal to the listed form's (ECAL_FORCE=extract_no_inline_ties) and to the
     oracle's — and the list it leaves is (nearly) empty where the listed form's holds every tied window.  2 Mev/s: windows of
     ~3000 events — the second extraction pass, which resolves its ties the same way on the trees the DBSCAN kernel's second
     pass exports (segments of up to 1408 points)."""
@@ -390,9 +386,9 @@ def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, mo
     ctx.set_tail_mode("tiered")      # (every size tier launched: the lean form's one tail launch per stage exports no trees)
     for listed in (False, True):
         if listed:
-            monkeypatch.setenv("ECAL_EXTRACT_NO_INLINE_TIES", "1")
+            monkeypatch.setenv("ECAL_FORCE", "extract_no_inline_ties")
         else:
-            monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+            monkeypatch.delenv("ECAL_FORCE", raising=False)
         sync_env()
         pipe = DetectPipeline(ctx)
         pipe.set_windows(t0, t1)
@@ -404,7 +400,7 @@ def test_ties_resolved_inside_the_first_pass_equal_the_listed_form(env, rate, mo
         outs[-1]["info"] = pipe.win_info[:S].cpu().numpy().copy()
         if not listed:
             exact, tied = _check_windows(pipe, torch, buf.numpy(), t0, t1, 5, 36, THR)      # == the oracle, window by window
-    monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+    monkeypatch.delenv("ECAL_FORCE", raising=False)
     sync_env()
     ctx.set_tail_mode("auto")
     a, b = outs
@@ -473,9 +469,9 @@ def test_tie_paths_by_cluster_size_against_the_oracle(env, eps, monkeypatch):
     ctx.set_tail_mode("tiered")
     for listed in (False, True):
         if listed:
-            monkeypatch.setenv("ECAL_EXTRACT_NO_INLINE_TIES", "1")
+            monkeypatch.setenv("ECAL_FORCE", "extract_no_inline_ties")
         else:
-            monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+            monkeypatch.delenv("ECAL_FORCE", raising=False)
         sync_env()
         pipe = DetectPipeline(ctx)
         pipe.set_windows(t0, t1)
@@ -502,7 +498,7 @@ def test_tie_paths_by_cluster_size_against_the_oracle(env, eps, monkeypatch):
                 assert np.array_equal(outs[-1]["rep"][on:on + ref["nk_neg"]], ref["rep_neg"]), "window %d rep -" % s
                 assert info[s, 0] == ref["n"] and np.array_equal(outs[-1]["cand_pair"][op:op + ref["n"]], ref["pair"]), s
                 assert np.array_equal(outs[-1]["cand_xyr"][op:op + ref["n"]], ref["xyr"]), s
-    monkeypatch.delenv("ECAL_EXTRACT_NO_INLINE_TIES", raising=False)
+    monkeypatch.delenv("ECAL_FORCE", raising=False)
     sync_env()
     ctx.set_tail_mode("auto")
     a, b = outs

@@ -133,10 +133,9 @@ def test_check_sorted(env):
 
 @pytest.mark.parametrize("shift", [0.0, 25.0])
 def test_pixel_and_general_slicers_agree(env, shift):
-    """Sensor-pixel windows take slice_hash_kernel (its second pass above 2047 events); ECAL_SLICE_SORT_KERNEL selects the
-    counting-sort pixel kernel instead (it also takes negative pixels), ECAL_SLICE_NO_PIXEL sends everything through the
-    general tiers.  Same outputs, and all equal the oracle.  shift = 0: negative coordinates and -0.0 (hash kernel bails,
-    sort kernel does not); shift = 25: all coordinates >= 0.  Both: both-polarity cancellation, a window with one
+    """Sensor-pixel windows take the hash slicer (its second pass above 2047 events); ECAL_FORCE=slice_general sends everything through
+    the general tiers.  Same outputs, and both equal the oracle.  shift = 0: negative coordinates and -0.0 (the hash kernel hands
+    those windows to the general tiers); shift = 25: all coordinates >= 0.  Both: both-polarity cancellation, a window with one
     non-integer coordinate, a window above the first pass's capacity."""
     import os
     ctx, pipe, torch = env
@@ -155,9 +154,9 @@ def test_pixel_and_general_slicers_agree(env, shift):
     t1 = [t[b - 1] for b in cuts[1:]]
     d = torch.from_numpy(rec).cuda()
     outs = []
-    for var in (None, "ECAL_SLICE_SORT_KERNEL", "ECAL_SLICE_NO_PIXEL"):
+    for var in (None, "ECAL_FORCE"):
         if var:
-            os.environ[var] = "1"
+            os.environ[var] = "slice_general"
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             pipe.set_windows(t0, t1)
@@ -237,7 +236,7 @@ def test_single_odd_event_sends_the_window_to_the_general_slicer(env):
     outs = []
     for no_pixel in (False, True):
         if no_pixel:
-            os.environ["ECAL_SLICE_NO_PIXEL"] = "1"
+            os.environ["ECAL_FORCE"] = "slice_general"
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             p = DetectPipeline(ctx)
@@ -248,7 +247,7 @@ def test_single_odd_event_sends_the_window_to_the_general_slicer(env):
             outs.append((p.seg_off[:2 * S].cpu().numpy().copy(), p.seg_cnt[:2 * S].cpu().numpy().copy(),
                          p.event_point[:60000].cpu().numpy().copy(), p.xy[:60000].cpu().numpy().copy()))
         finally:
-            os.environ.pop("ECAL_SLICE_NO_PIXEL", None)
+            os.environ.pop("ECAL_FORCE", None)
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     a, b = outs
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
@@ -275,7 +274,7 @@ def test_hash_slicer_second_pass_equals_general_slicer(env):
     outs = []
     for no_pixel in (False, True):
         if no_pixel:
-            os.environ["ECAL_SLICE_NO_PIXEL"] = "1"
+            os.environ["ECAL_FORCE"] = "slice_general"
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
         try:
             p = DetectPipeline(ctx)
@@ -288,7 +287,7 @@ def test_hash_slicer_second_pass_equals_general_slicer(env):
                          p.seg_cnt[:2 * S].cpu().numpy().copy(), p.event_point.cpu().numpy().copy(), p.xy.cpu().numpy().copy(),
                          p.win_base[:S + 1].cpu().numpy().copy()))
         finally:
-            os.environ.pop("ECAL_SLICE_NO_PIXEL", None)
+            os.environ.pop("ECAL_FORCE", None)
             __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     a, b = outs
     assert int((a[1] - a[0]).max()) > 2048 and int((a[1] - a[0]).max()) < 4096

@@ -141,7 +141,7 @@ def test_every_window_of_the_10M_stream_equals_the_oracle(run):
 
 
 def test_pixel_kernel_equals_general_tiers_repeatedly(run):
-    """The pixel DBSCAN kernel against the general tiers (ECAL_DBSCAN_NO_PIXEL) on every segment of the stream, eight
+    """The pixel DBSCAN kernel against the general tiers (ECAL_FORCE=dbscan_general) on every segment of the stream, eight
     runs: 13 k segments x 8 is what it takes to see a one-in-10^5 ordering race between workgroup threads (the
     flatten pass once lost a root to a concurrent path-halving store)."""
     import os
@@ -150,13 +150,13 @@ def test_pixel_kernel_equals_general_tiers_repeatedly(run):
     S = len(t0)
     p2 = DetectPipeline(ctx)
     p2.set_windows(t0, t1)
-    os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
+    os.environ["ECAL_FORCE"] = "dbscan_general"
     __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     try:
         p2.run(ev, detect=False)
         torch.cuda.synchronize()
     finally:
-        os.environ.pop("ECAL_DBSCAN_NO_PIXEL", None)
+        os.environ.pop("ECAL_FORCE", None)
         __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     ref_l, ref_n = p2.labels.clone(), p2.n_clusters[:2 * S].clone()
     off, cnt = p2.seg_off[:2 * S].long(), p2.seg_cnt[:2 * S].long()

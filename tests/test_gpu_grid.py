@@ -354,7 +354,7 @@ def test_grid_on_the_noise_streams_false_candidates():
 
 def test_walk_four_directions_at_once_equals_one_after_the_other():
     """The first walk asks a node's four neighbour cells at once (a row of lanes each) and falls back to the one-after-the-other
-    form when two directions want the same candidate; ECAL_GRID_SERIAL_WALK=1 takes that form always.  Same orders, same
+    form when two directions want the same candidate; ECAL_FORCE=grid_serial_walk takes that form always.  Same orders, same
     verdicts: on cluttered patterns (where two directions do compete for a spurious candidate) and on the noise stream's own
     candidate sets."""
     import torch
@@ -381,16 +381,16 @@ def test_walk_four_directions_at_once_equals_one_after_the_other():
     try:
         for serial in (False, True):
             if serial:
-                os.environ["ECAL_GRID_SERIAL_WALK"] = "1"
+                os.environ["ECAL_FORCE"] = "grid_serial_walk"
             else:
-                os.environ.pop("ECAL_GRID_SERIAL_WALK", None)
+                os.environ.pop("ECAL_FORCE", None)
             sync_env()
             o1, f1 = _run_grid(ctx, torch, cases)
             o2, f2 = pipe.order_grid(9, 4)
             torch.cuda.synchronize()
             out[serial] = (np.array(o1), np.array(f1), o2.cpu().numpy().copy(), f2.cpu().numpy().copy())
     finally:
-        os.environ.pop("ECAL_GRID_SERIAL_WALK", None)
+        os.environ.pop("ECAL_FORCE", None)
         sync_env()
     a, b = out[False], out[True]
     assert int(a[1].sum()) > 30 and int(a[3].sum()) > 50
@@ -401,7 +401,7 @@ def test_walk_four_directions_at_once_equals_one_after_the_other():
 
 def test_a_wave_per_start_equals_the_starts_one_after_the_other():
     """ecal_grid_order_dev takes its latency form for launches of few windows (round 5: a wave per start — the plain start, the
-    robust one and the two extra seeds side by side, the lowest successful start's result kept); ECAL_GRID_ONE_WAVE=1 keeps the
+    robust one and the two extra seeds side by side, the lowest successful start's result kept); ECAL_FORCE=grid_one_wave keeps the
     one-wave form, the starts one after the other.  Same verdicts and the same orders: on clean and cluttered patterns (where the
     later starts are the ones that find the grid) and on the noise stream's own candidate sets."""
     import torch
@@ -431,16 +431,16 @@ def test_a_wave_per_start_equals_the_starts_one_after_the_other():
     try:
         for one_wave in (False, True):
             if one_wave:
-                os.environ["ECAL_GRID_ONE_WAVE"] = "1"
+                os.environ["ECAL_FORCE"] = "grid_one_wave"
             else:
-                os.environ.pop("ECAL_GRID_ONE_WAVE", None)
+                os.environ.pop("ECAL_FORCE", None)
             sync_env()
             o1, f1 = _run_grid(ctx, torch, cases)
             o2, f2 = pipe.order_grid(9, 4)
             torch.cuda.synchronize()
             out[one_wave] = (np.array(o1), np.array(f1), o2.cpu().numpy().copy(), f2.cpu().numpy().copy())
     finally:
-        os.environ.pop("ECAL_GRID_ONE_WAVE", None)
+        os.environ.pop("ECAL_FORCE", None)
         sync_env()
     a, b = out[False], out[True]
     assert int(a[1].sum()) > 60 and int((~a[1].astype(bool)).sum()) > 5 and int(a[3].sum()) > 20

@@ -24,11 +24,16 @@ def exe(tmp_path_factory):
     obj, img, rv, tv = SC.make_views(24, 0, seed=5, noise_px=0.05)
     vf = str(d / "views.bin")
     np.concatenate([[24, obj.shape[0], 0], img.ravel()]).astype(np.float64).tofile(vf)
+    # BASELINE configs[3]'s shape: 64 calibration views, 8 per rank on 8 ranks
+    obj, img, rv, tv = SC.make_views(64, 0, seed=7, noise_px=0.05)
+    np.concatenate([[64, obj.shape[0], 0], img.ravel()]).astype(np.float64).tofile(str(d / "views64.bin"))
     return out, vf, str(d)
 
 
-def _run(exe, mode, world):
+def _run(exe, mode, world, views=None):
     out, vf, d = exe
+    if views:
+        vf = os.path.join(d, views)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([out, mode, str(world), vf, d], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -39,6 +44,17 @@ def _run(exe, mode, world):
 def test_callback_allreduce_two_ranks_on_one_gpu(exe):
     out = _run(exe, "shm", 2)
     assert "rank 0/2" in out and "rank 1/2" in out
+
+
+def test_configs3_partition_eight_ranks_on_one_gpu(exe):
+    """BASELINE configs[3] as it will be partitioned on the 8-GPU node — 64 calibration views, 8 per rank, the per-view blocks
+    summed over the ranks by the all-reduce seam — executed here with EIGHT processes on one GPU over the shared-memory callback
+    (RCCL refuses several ranks per device; the 8-GPU RCCL run is the driver's): every rank's sharded result == the unsharded
+    calibration of all 64 views (1e-7 relative on the twelve intrinsics, rms 1e-9)."""
+    out = _run(exe, "shm", 8, views="views64.bin")
+    for r in range(8):
+        assert "rank %d/8" % r in out
+    assert "views [56, 64)" in out and "views [0, 8)" in out
 
 
 def test_rccl_communicator_in_the_library(exe):

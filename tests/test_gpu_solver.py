@@ -106,14 +106,9 @@ def test_two_segments(ctx):
     s.close()
 
 
-@pytest.mark.parametrize("device_solve,n_cp,n_res", [(False, 8, 4000), (True, 8, 4000), (True, 60, 30000)])
-def test_lm_recovers_ground_truth_and_matches_reference_loop(ctx, device_solve, n_cp, n_res, monkeypatch):
-    """device_solve: the whole LM iteration on the device (ECAL_SOLVER_DEVICE_LINEAR_SOLVE: partitioned arrow Cholesky, step,
-    acceptance sums; one 64-byte read-back per iteration) — same minimiser, same iterates as the host loop."""
+@pytest.mark.parametrize("n_cp,n_res", [(8, 4000), (60, 30000)])
+def test_lm_recovers_ground_truth_and_matches_reference_loop(ctx, n_cp, n_res, monkeypatch):
     from eventcalib_amd.capi import Solver
-    if device_solve:
-        monkeypatch.setenv("ECAL_SOLVER_DEVICE_LINEAR_SOLVE", "1")
-        __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
     rng = np.random.default_rng(4)
     prob, x_gt = SV.make_problem(n_res, n_cp=n_cp, seed=4)
     x0 = SV.perturb(x_gt, n_cp, rng)
@@ -207,10 +202,11 @@ def test_per_residual_rows_match_dual_numbers(ctx, use_so3):
 
 
 @pytest.mark.parametrize("n_cp,n_res", [(4, 2000), (9, 3000), (27, 6000), (28, 6000), (50, 12000), (131, 30000), (700, 150000)])
-def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
-    """The partitioned banded-arrow Cholesky on the device (arrow_device.hpp: interiors in parallel, separators' reduced
-    system, intrinsics, back substitution) against the sequential host factorisation of the same scaled, damped system:
-    f64, different elimination order -> relative 1e-8 on the step."""
+def test_partitioned_arrow_solves_match_the_sequential_solve(ctx, n_cp, n_res):
+    """The host's partitioned banded-arrow Cholesky (arrow_host_parts.hpp: interiors in parallel, separators' reduced system,
+    intrinsics, back substitution; the plain partition and the streamed evaluation's) against the sequential factorisation of
+    the same scaled, damped system built from the GPU's normal equations: f64, different elimination order -> relative 1e-9 on
+    the step; and the step solves the system (dense check)."""
     import ctypes
     from eventcalib_amd.capi import Solver
     rng = np.random.default_rng(n_cp)
@@ -229,16 +225,11 @@ def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
     diag = np.concatenate([np.diag(H)[9:], np.diag(H)[:9]])
     scale = np.ascontiguousarray(1.0 / (1.0 + np.sqrt(diag)))
     for radius in (1e4, 3.0):
-        out = []
-        for dev in (0, 1):
-            d = np.zeros(nt)
-            fail = ctypes.c_int(-1)
-            rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, d.ctypes.data, ctypes.byref(fail), dev)
-            assert rc == 0 and fail.value == 0, (rc, fail.value, dev)
-            out.append(d)
-        host, devd = out
+        host = np.zeros(nt)
+        fail = ctypes.c_int(-1)
+        rc = L.ecal_debug_arrow_solve(s._h, acc.ctypes.data, scale.ctypes.data, radius, 1e-6, 1e32, host.ctypes.data, ctypes.byref(fail), 0)
+        assert rc == 0 and fail.value == 0, (rc, fail.value)
         assert np.abs(host).max() > 0
-        assert np.abs(devd - host).max() <= 1e-8 * np.abs(host).max(), (n_cp, radius, np.abs(devd - host).max(), np.abs(host).max())
         # the host routine's own partitioned form (arrow_host_parts.hpp: interiors on several cores, separators' reduced system):
         # mode 2 of the hook, 4 interiors here, what ecal_solver_solve uses on long splines
         import os
@@ -272,7 +263,7 @@ def test_device_arrow_solve_matches_host_solve(ctx, n_cp, n_res):
             As = A * scale[:, None] * scale[None, :]
             D = np.clip(np.diag(As), 1e-6, 1e32) / radius
             yy = np.linalg.solve(As + np.diag(D), -gg * scale)
-            assert np.abs(devd - yy * scale).max() <= 1e-7 * np.abs(yy * scale).max()
+            assert np.abs(host - yy * scale).max() <= 1e-7 * np.abs(yy * scale).max()
     s.close()
 
 
@@ -370,13 +361,13 @@ def test_streamed_evaluation_gives_the_plain_solves_iterates(ctx, n_cp, n_res, p
     x0 = SV.perturb(x_gt, n_cp, rng)
     if parts is not None:
         monkeypatch.setenv("ECAL_HOST_ARROW_PARTS", str(parts))
-    monkeypatch.setenv("ECAL_SOLVER_TRACE", "1")
+    monkeypatch.setenv("ECAL_TRACE", "solver")
     out = []
     for plain in (False, True, False):
         if plain:
-            monkeypatch.setenv("ECAL_SOLVER_NO_STREAM", "1")
+            monkeypatch.setenv("ECAL_FORCE", "solver_no_stream")
         else:
-            monkeypatch.delenv("ECAL_SOLVER_NO_STREAM", raising=False)
+            monkeypatch.delenv("ECAL_FORCE", raising=False)
         sync_env()
         s = Solver(ctx, prob)
         opt = s.default_options()
@@ -388,8 +379,8 @@ def test_streamed_evaluation_gives_the_plain_solves_iterates(ctx, n_cp, n_res, p
         s.close()
         assert abs(summ2.final_cost - summ.final_cost) <= (1e-7 if n_res < 1000 else 1e-10) * summ.final_cost + 1e-18
         out.append((x, summ, err))
-    monkeypatch.delenv("ECAL_SOLVER_NO_STREAM", raising=False)
-    monkeypatch.delenv("ECAL_SOLVER_TRACE", raising=False)
+    monkeypatch.delenv("ECAL_FORCE", raising=False)
+    monkeypatch.delenv("ECAL_TRACE", raising=False)
     sync_env()
     (xs, ss, es), (xp, sp, ep), (xs2, ss2, _) = out
     tol = 1e-6 if n_res < 1000 else 1e-9
@@ -452,8 +443,8 @@ def test_benchmark_size_solve_against_the_oracle(ctx, monkeypatch):
     (1) the kernel's normal equations == the oracle's dual-number rows summed on all host threads (oracle_evaluate_arrow_mt,
         ~12 s on the box's 16 CPUs), every defined entry, 1e-9 of the largest entry of its kind (sums of ~22 500 terms per
         control point in another order; measured ~1e-12);
-    (2) the LM iterates of the three solve paths — streamed evaluation (the host factorises under the kernel), plain evaluation
-        (ECAL_SOLVER_NO_STREAM=1), device linear solve (ECAL_SOLVER_DEVICE_LINEAR_SOLVE=1) — agree to 1e-9 after bench.py's eight
+    (2) the LM iterates of the two solve paths — streamed evaluation (the host factorises under the kernel) and plain evaluation
+        (ECAL_FORCE=solver_no_stream) — agree to 1e-9 after bench.py's eight
         iterations, with the same iteration and step counts;
     (3) the streamed path is the one that ran: 16 interiors, streamed evaluations > 0, interiors found factorised."""
     import ctypes
@@ -487,9 +478,9 @@ def test_benchmark_size_solve_against_the_oracle(ctx, monkeypatch):
     opt = s.default_options()
     opt.max_num_iterations = 8
     runs = {}
-    for name, var in (("streamed", None), ("plain", "ECAL_SOLVER_NO_STREAM"), ("device", "ECAL_SOLVER_DEVICE_LINEAR_SOLVE")):
+    for name, var in (("streamed", None), ("plain", "ECAL_FORCE")):
         if var:
-            monkeypatch.setenv(var, "1")
+            monkeypatch.setenv(var, "solver_no_stream")
         sync_env()
         try:
             x, summ = s.solve(x0, opt)
@@ -505,7 +496,7 @@ def test_benchmark_size_solve_against_the_oracle(ctx, monkeypatch):
     assert hs[0] == 16 and hs[1] >= 2 and hs[2] > 0 and hs[4] == 1 and hs[5] == ss.iterations, hs     # 16 interiors, streamed evaluations, interiors found factorised
     assert runs["plain"][2][0] == 16 and runs["plain"][2][1] == 0, runs["plain"][2]
     assert ss.final_cost < ss.initial_cost and np.abs(xs[:4] / x_gt[:4] - 1).max() < 8e-3
-    for name in ("plain", "device"):
+    for name in ("plain",):
         x, summ, _ = runs[name]
         assert summ.iterations == ss.iterations and summ.successful_steps == ss.successful_steps, name
         assert abs(summ.final_cost - ss.final_cost) <= 1e-10 * ss.final_cost, name

@@ -14,10 +14,10 @@ ev = SS.make_stream(n, rate=rate, device="cuda")
 t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / rate, wlen)
 pipe.set_windows(t0, t1)
 S = len(t0)
-os.environ["ECAL_DBSCAN_NO_PIXEL"] = "1"
+os.environ["ECAL_FORCE"] = "dbscan_general"
 pipe.run(ev, detect=False); torch.cuda.synchronize()
 ref_l = pipe.labels.clone(); ref_n = pipe.n_clusters.clone()
-os.environ.pop("ECAL_DBSCAN_NO_PIXEL")
+os.environ.pop("ECAL_FORCE", None)
 off = pipe.seg_off[:2 * S].long().cpu().numpy(); cnt = pipe.seg_cnt[:2 * S].long().cpu().numpy()
 o_t, c_t = pipe.seg_off[:2 * S].long(), pipe.seg_cnt[:2 * S].long()
 used = torch.repeat_interleave(o_t, c_t) + (torch.arange(int(c_t.sum()), device="cuda") - torch.repeat_interleave(torch.cumsum(c_t, 0) - c_t, c_t))

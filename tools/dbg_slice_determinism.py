@@ -13,9 +13,9 @@ ev = SS.make_stream(n, device="cuda")
 t0, t1 = SS.tiled_windows(5.0, 5.0 + (n - 1) / 1e6)
 pipe.set_windows(t0, t1)
 S = len(t0)
-os.environ["ECAL_SLICE_NO_PIXEL"] = "1"
+os.environ["ECAL_FORCE"] = "slice_general"
 pipe.run(ev, slice_only=True); torch.cuda.synchronize()
-os.environ.pop("ECAL_SLICE_NO_PIXEL")
+os.environ.pop("ECAL_FORCE", None)
 ref = [x.clone() for x in (pipe.seg_off[:2 * S], pipe.seg_cnt[:2 * S], pipe.event_point[:n], pipe.xy[:n])]
 used = torch.zeros(n, dtype=torch.bool, device="cuda")
 o, c = ref[0].long(), ref[1].long()

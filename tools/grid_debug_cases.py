@@ -1,5 +1,5 @@
 import sys, os
-os.environ["ECAL_GRID_DEBUG"] = "1"
+os.environ["ECAL_TRACE"] = "grid"
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np, torch
 import eventcalib_amd

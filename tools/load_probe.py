@@ -1,8 +1,8 @@
-"""Debug: where ecal_stream_create_from_file spends its time (ECAL_LOAD_TRACE=1) on a 1.25 GB file in /dev/shm."""
+"""Debug: where ecal_stream_create_from_file spends its time (ECAL_TRACE=load) on a 1.25 GB file in /dev/shm."""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["ECAL_LOAD_TRACE"] = "1"
+os.environ["ECAL_TRACE"] = "load"
 import numpy as np, torch
 import eventcalib_amd, synth_stream as SS
 n = 50_000_000

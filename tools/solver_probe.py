@@ -1,5 +1,5 @@
 """M2 alone: the benchmark's spline problem (45 M residuals, 2000 control points), ecal_solver_solve timed with its trace —
-streamed evaluation (default) and ECAL_SOLVER_NO_STREAM=1 side by side.  `python tools/solver_probe.py [n_events] [iters] [reps]`"""
+streamed evaluation (default) and ECAL_FORCE=solver_no_stream side by side.  `python tools/solver_probe.py [n_events] [iters] [reps]`"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -39,10 +39,10 @@ if "pipe" in VAR:
     torch.cuda.synchronize()
 for mode in ("stream", "plain", "stream", "plain")[:int(os.environ.get("PROBE_MODES", "4"))]:
     if mode == "plain":
-        os.environ["ECAL_SOLVER_NO_STREAM"] = "1"
+        os.environ["ECAL_FORCE"] = "solver_no_stream"
     else:
-        os.environ.pop("ECAL_SOLVER_NO_STREAM", None)
-    os.environ["ECAL_SOLVER_TRACE"] = "1" if os.environ.get("TRACE", "1") == "1" else "0"
+        os.environ.pop("ECAL_FORCE", None)
+    os.environ["ECAL_TRACE"] = "solver"
     ctx.reload_env()
     s = Solver(ctx, prob)
     opt = s.default_options()

@@ -15,10 +15,10 @@ for (n_cp, n_res, noise) in ((700, 200000, 0.3), (520, 60000, 0.0), (1500, 40000
     rng = np.random.default_rng(n_cp)
     prob, x_gt = SV.make_problem(n_res, n_cp=n_cp, seed=n_cp, pixel_noise=noise)
     x0 = SV.perturb(x_gt, n_cp, rng)
-    os.environ["ECAL_SOLVER_NO_STREAM"] = "1"; ctx.reload_env()
+    os.environ["ECAL_FORCE"] = "solver_no_stream"; ctx.reload_env()
     s = Solver(ctx, prob); opt = s.default_options(); opt.max_num_iterations = 10
     xp, sp = s.solve(x0, opt); s.close()
-    os.environ.pop("ECAL_SOLVER_NO_STREAM"); ctx.reload_env()
+    os.environ.pop("ECAL_FORCE", None); ctx.reload_env()
     probs.append((prob, x0, sp.final_cost, sp.iterations, Solver(ctx, prob), sp.initial_cost))
 worst = [0.0] * len(probs); tot = [0.0] * len(probs); n = [0] * len(probs)
 for r in range(rounds):
