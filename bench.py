@@ -359,10 +359,14 @@ def main():
     sharded_p2 = weak = None
     if world > 1 and args.steps > 0:
         if args.p2_pieces != 0:
-            # the reference driver's adaptive-window search (policy P2) over the same stream: its pieces are independent time
-            # ranges (own-piece gate), so rank r searches the pieces [P r / N, P (r + 1) / N) — with the bounds they have in
-            # the whole run (ecal_adaptive_params.piece_first / piece_count) — on its own range of the stream; no collective
-            from eventcalib_amd.adaptive import detect_keyframes_device
+            # the reference driver's adaptive-window search (policy P2) over the same stream: rank r searches the pieces
+            # [P r / N, P (r + 1) / N) — with the bounds they have in the whole run (ecal_adaptive_params.piece_first / piece_count) —
+            # on its own range of the stream.  With the reference's gate (one keyframe map, single-worker order: the 1-GPU front
+            # ends' default) a rank needs ONE frame from the ranks before it in time: a chain of N - 1 messages of 66 doubles
+            # (ecal_detect_keyframes_sharded, DistHandover), its pieces running as a speculation until the frame arrives — the
+            # ranks' keyframes together are the single-GPU search's, record for record.  The own-piece gate (no exchange at all)
+            # is timed beside it.
+            from eventcalib_amd.adaptive import detect_keyframes_device, DistHandover
             from eventcalib_amd import capi as _capi
             P = 5 * max(1, (os.cpu_count() or 3) - 2) if args.p2_pieces < 0 else args.p2_pieces
             P = max(P, world)
@@ -374,27 +378,40 @@ def main():
             del events
             torch.cuda.empty_cache()
             ev_p = SS.make_stream(q_hi - q_lo, rate=rate, t_start=t_start, seed=12345, device=dev, k_offset=q_lo, total=n_events)
-            kw = dict(piece_first=p_lo, piece_count=p_hi - p_lo, gate_mode=_capi.GATE_OWN_PIECE)
-            detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, **kw)   # warm-up
-            barrier()
-            tb = time.perf_counter()
-            kp = detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, **kw)
-            barrier()
-            el_p = time.perf_counter() - tb
-            agg = torch.tensor([float(len(kp["time"])), float(kp["windows"])], dtype=torch.float64, device=dev)
-            dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-            mx = torch.tensor([el_p], dtype=torch.float64, device=dev)
-            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-            sharded_p2 = {"value": round(n_events / float(mx[0].item()) / 1e6, 1), "unit": "Mevents/s", "scaling": "strong", "pieces": P,
-                          "pieces_per_gpu": p_hi - p_lo, "seconds": round(float(mx[0].item()), 4),
-                          "keyframes": int(agg[0].item()), "windows_evaluated": int(agg[1].item()), "gate": "own piece",
-                          "single_gpu_default_gate": "shared map",
-                          "note": "the pieces of one search cut over the ranks, every rank on its own time range of the stream.  "
-                                  "GATE: own piece (every piece's first success ungated) — NOT the single-GPU front ends' default: "
-                                  "the shared-map gate (the reference's single-worker semantics, EventCalibIni.cpp:26-36) hands a "
-                                  "piece its gate frame from the pieces before it and does not shard (ecal_detect_keyframes "
-                                  "refuses a subset of the pieces under it); compare this figure with policy_p2[gate = own piece] "
-                                  "of the 1-GPU line, not with its shared-map entry"}
+            def sharded_search(gate, tag):
+                # (rank r holds pieces [p_lo, p_hi): piece 0 is the LAST in time, so the rank before r in time is r + 1)
+                def once(t):
+                    ho = DistHandover(rank + 1 if rank + 1 < world else None, rank - 1 if rank > 0 else None, tag=t) if gate == _capi.GATE_SHARED_MAP else None
+                    return detect_keyframes_device(ctx, ev_p, 5e-4, 4000, P, tf, tl, eps, minpts, piece_first=p_lo, piece_count=p_hi - p_lo,
+                                                   gate_mode=gate, handover=ho)
+                once(tag)   # warm-up
+                barrier()
+                tb = time.perf_counter()
+                kp = once(tag + 1)
+                barrier()
+                el_p = time.perf_counter() - tb
+                agg = torch.tensor([float(len(kp["time"])), float(kp["windows"])], dtype=torch.float64, device=dev)
+                dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+                mx = torch.tensor([el_p], dtype=torch.float64, device=dev)
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                every = [None] * world
+                dist.all_gather_object(every, kp["time"].tobytes())
+                import hashlib
+                digest = hashlib.sha1(np.sort(np.frombuffer(b"".join(every), np.float64)).tobytes()).hexdigest()[:16]
+                return {"value": round(n_events / float(mx[0].item()) / 1e6, 1), "unit": "Mevents/s", "scaling": "strong", "pieces": P,
+                        "pieces_per_gpu": p_hi - p_lo, "seconds": round(float(mx[0].item()), 4), "keyframes": int(agg[0].item()),
+                        "windows_evaluated": int(agg[1].item()), "keyframe_times_sha1_16": digest}
+            sharded_p2 = sharded_search(_capi.GATE_SHARED_MAP, 100)
+            sharded_p2.update({"gate": "shared map, single worker (the single-GPU front ends' default; the reference's TrackingBase / "
+                                       "EventCalibIni::track semantics)",
+                               "exchange": "%d messages of 66 doubles per search: the frame behind a rank's pieces (last keyframe's time stamp + "
+                                           "row directions) to the next rank in time; pieces run speculatively until it arrives" % (world - 1),
+                               "note": "the pieces of one search cut over the ranks, every rank on its own time range of the stream; the "
+                                       "ranks' keyframes together == the 1-GPU line's policy_p2[gate = shared map] at the same piece count "
+                                       "(keyframe_times_sha1_16 there)"})
+            sharded_p2["own_piece_gate"] = sharded_search(_capi.GATE_OWN_PIECE, 200)
+            sharded_p2["own_piece_gate"]["note"] = ("every piece's first success ungated: no exchange at all, not what a run of the "
+                                                    "reference computes; compare with policy_p2[gate = own piece] of the 1-GPU line")
             events = ev_p
         if args.scaling == "both":
             # weak scaling: every rank its OWN --events stream (its own time range of the motion), per-GPU work fixed
@@ -624,6 +641,7 @@ def main():
                 out["policy_p2"].append({"value": round(n_events / p2s_s / 1e6, 1), "unit": "Mevents/s", "seconds": round(p2s_s, 4),
                                          "pieces": pieces, "host_threads": 1, "longest_window_chain": ks["steps"],
                                          "windows_evaluated": ks["windows"], "keyframes": int(len(ks["time"])), "driver": "device",
+                                         "keyframe_times_sha1_16": __import__("hashlib").sha1(np.sort(ks["time"]).tobytes()).hexdigest()[:16],
                                          "gate": "shared map, single worker (the reference's TrackingBase / EventCalibIni::track semantics)"})
             pipe.set_windows(t0, t1)
     # ------------------------------------------------------------------------------------------

@@ -99,7 +99,7 @@ def detect_keyframes(pipe: DetectPipeline, events, motion_time_step, frame_event
 
 def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps=4.0,
                             minpts=2, rows=9, cols=4, max_passes=0, gate_mode=0, n_threads=1, contexts=None, piece_first=0,
-                            piece_count=0):
+                            piece_count=0, handover=None):
     """Same result as detect_keyframes, with the policy on the device (ecal_detect_keyframes): no per-pass host round trip.
     gate_mode = capi.GATE_SHARED_MAP: the reference's single-worker run (one keyframe map for all pieces) instead of the
     own-piece gate.  Slots and the keyframe capacity are estimated and doubled when the library reports them too small.
@@ -111,13 +111,14 @@ def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_thres
     calls: their scratch buffers stay allocated), else created and closed here.
 
     piece_count != 0: only the pieces piece_first .. piece_first + piece_count - 1 (one rank's share of a search cut over
-    GPUs; `events` then only has to hold those pieces' time range)."""
+    GPUs; `events` then only has to hold those pieces' time range).  Under capi.GATE_SHARED_MAP such a share needs the frame of
+    the pieces before it: handover (DistHandover below; ecal_detect_keyframes_sharded)."""
     torch.cuda.synchronize(events.device)   # the passes run on the contexts' own streams: `events` must be complete
     n_ev = events.numel() // 25
     n_threads = max(1, min(int(n_threads), int(piece_num)))
     if n_threads == 1 or gate_mode != 0 or piece_count:
         return _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps, minpts,
-                             rows, cols, max_passes, gate_mode, piece_first, piece_count)
+                             rows, cols, max_passes, gate_mode, piece_first, piece_count, handover)
     import threading
     from .capi import Context
     own = contexts is None
@@ -150,8 +151,44 @@ def detect_keyframes_device(ctx, events, motion_time_step, frame_event_num_thres
                 windows=sum(o["windows"] for o in outs))
 
 
+class DistHandover:
+    """The frame hand-over of a shared-map search cut over torch.distributed ranks in time (ecal_detect_keyframes_sharded): `src` =
+    the rank that holds the pieces BEFORE this rank's in time (None: this rank holds the run's first piece), `dst` = the rank that
+    holds the pieces after (None: the last).  One message of 2 + 64 doubles per boundary; the received frame is kept, so a call
+    repeated with more capacity (ECAL_ERR_RANGE) finds it again and sends its own only once."""
+
+    def __init__(self, src, dst, tag=0):
+        import torch.distributed as dist
+        self.dist, self.src, self.dst, self.tag = dist, src, dst, tag
+        self.dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        self.frame = self.work = self.buf = None
+        self.sent = False
+
+    def recv(self, wait):
+        if self.frame is None:
+            if self.src is None:
+                return (0, 0.0, [0.0] * 64)
+            if self.work is None:
+                self.buf = torch.zeros(66, dtype=torch.float64, device=self.dev)
+                self.work = self.dist.irecv(self.buf, src=self.src, tag=self.tag)
+            if wait:
+                self.work.wait()
+            elif not self.work.is_completed():
+                return None
+            b = self.buf.cpu().tolist()
+            self.frame = (int(b[0]), b[1], b[2:])
+        return self.frame
+
+    def send(self, has, time, dirs):
+        if self.sent or self.dst is None:
+            return
+        self.sent = True
+        t = torch.tensor([float(has), float(time)] + list(dirs) + [0.0] * (64 - len(dirs)), dtype=torch.float64, device=self.dev)
+        self.dist.send(t, dst=self.dst, tag=self.tag)
+
+
 def _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold, piece_num, start_time, end_time, eps, minpts, rows,
-                  cols, max_passes, gate_mode, piece_first, piece_count):
+                  cols, max_passes, gate_mode, piece_first, piece_count, handover=None):
     span = max(end_time - start_time, 1e-9)
     n_mine = piece_count if piece_count else piece_num
     # a pass covers a chain of windows per piece: the library's own estimate, doubled whenever it reports it too small
@@ -167,7 +204,7 @@ def _detect_group(ctx, events, n_ev, motion_time_step, frame_event_num_threshold
                                                                     frame_event_num_threshold, piece_num, start_time, end_time, cap,
                                                                     max_keys, eps, minpts, 5, rows, cols, max_passes=max_passes,
                                                                     gate_mode=gate_mode, piece_first=piece_first,
-                                                                    piece_count=piece_count)
+                                                                    piece_count=piece_count, handover=handover)
             break
         except capi.EcalError as err:
             if err.status != -6:

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "ecal_get_median_ties", "ecal_detect_fused_dev", "ecal_cluster_order_dev", "ecal_cluster_order",
     "ecal_stream_create", "ecal_stream_destroy", "ecal_stream_size", "ecal_stream_data", "ecal_detect_batch", "ecal_copy_dev",
     "ecal_grid_order_dev", "ecal_grid_order", "ecal_associate_dev", "ecal_associate", "ecal_pin_host", "ecal_unpin_host",
-    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_detect_keyframes_cap_hint", "ecal_detect_keyframes_cap_hint_dev", "ecal_stream_create_from_file", "ecal_stream_times", "ecal_rectify_batch_dev", "ecal_rectify_batch",
+    "ecal_detect_stream_tiled", "ecal_gather_features_dev", "ecal_detect_pass", "ecal_detect_keyframes", "ecal_detect_keyframes_sharded", "ecal_detect_keyframes_cap_hint", "ecal_detect_keyframes_cap_hint_dev", "ecal_stream_create_from_file", "ecal_stream_times", "ecal_rectify_batch_dev", "ecal_rectify_batch",
     "ecal_solver_create", "ecal_solver_destroy", "ecal_solver_param_size", "ecal_solver_normal_size",
     "ecal_solver_num_chunks", "ecal_solver_evaluate_dev", "ecal_solver_evaluate", "ecal_residuals_dev", "ecal_residuals", "ecal_lm_default_options",
     "ecal_solver_solve", "ecal_inverse_radial_distortion", "ecal_solver_create_dev", "ecal_solver_num_residuals",
@@ -942,12 +942,28 @@ def detect_keyframes_cap_hint_dev(ctx: Context, d_events, n_events, motion_time_
     return int(L.ecal_detect_keyframes_cap_hint_dev(ctx._h, d_events, int(n_events), ctypes.byref(ap)))
 
 
+class KeyframeFrame(ctypes.Structure):   # ecal_keyframe_frame
+    _fields_ = [("has", ctypes.c_int), ("time", ctypes.c_double), ("dir", ctypes.c_double * 64)]
+
+
+_FRAME_RECV = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(KeyframeFrame), ctypes.c_int)
+_FRAME_SEND = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(KeyframeFrame))
+
+
+class AdaptiveHandover(ctypes.Structure):   # ecal_adaptive_handover
+    _fields_ = [("recv", _FRAME_RECV), ("send", _FRAME_SEND), ("user", ctypes.c_void_p)]
+
+
 def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, frame_event_num_threshold, piece_num, start_time,
                          end_time, cap_points, max_keyframes, eps=4.0, minpts=2, cluster_min=5, rows=9, cols=4,
-                         radius_threshold=15.511363636363637, max_passes=0, check_every=0, gate_mode=0, piece_first=0, piece_count=0):
+                         radius_threshold=15.511363636363637, max_passes=0, check_every=0, gate_mode=0, piece_first=0, piece_count=0,
+                         handover=None):
     """ecal_detect_keyframes (policy on the device; gate_mode: GATE_OWN_PIECE / GATE_SHARED_MAP; piece_count != 0: only the pieces
     piece_first .. piece_first + piece_count - 1 of the piece_num).  Returns (time [K], duration [K,2], events_num [K], features [K, rows cols, 3],
-    passes, windows); raises EcalError(-6) when cap_points or max_keyframes is too small."""
+    passes, windows); raises EcalError(-6) when cap_points or max_keyframes is too small.
+    handover (ecal_detect_keyframes_sharded: a subset of the pieces under GATE_SHARED_MAP): an object with recv(wait) -> None (not there
+    yet; only when wait is false) or (has, time, dir [2 rows]) = the frame behind the pieces before this subset, and send(has, time,
+    dir) for the frame behind this subset's pieces."""
     L = ctx._L
     vp, u32 = ctypes.c_void_p, ctypes.c_uint32
     L.ecal_detect_keyframes.argtypes = [vp, vp, ctypes.c_uint64, ctypes.POINTER(AdaptiveParams), ctypes.POINTER(DetectParams), u32, u32,
@@ -963,9 +979,42 @@ def detect_keyframes_dev(ctx: Context, d_events, n_events, motion_time_step, fra
     f = np.empty((max_keyframes, M, 3))
     nk, ps, nw = u32(0), u32(0), ctypes.c_uint64(0)
     try:
-        ctx._check(L.ecal_detect_keyframes(ctx._h, d_events, int(n_events), ctypes.byref(ap), ctypes.byref(prm), int(cap_points),
-                                           int(max_keyframes), _ptr(t), _ptr(d), _ptr(e), _ptr(f), ctypes.byref(nk), ctypes.byref(ps),
-                                           ctypes.byref(nw)))
+        if handover is None:
+            ctx._check(L.ecal_detect_keyframes(ctx._h, d_events, int(n_events), ctypes.byref(ap), ctypes.byref(prm), int(cap_points),
+                                               int(max_keyframes), _ptr(t), _ptr(d), _ptr(e), _ptr(f), ctypes.byref(nk), ctypes.byref(ps),
+                                               ctypes.byref(nw)))
+        else:
+            errs = []
+
+            def recv(user, frame, wait):
+                try:
+                    got = handover.recv(bool(wait))
+                    if got is None:
+                        return 0
+                    frame[0].has, frame[0].time = int(bool(got[0])), float(got[1])
+                    for i, v in enumerate(got[2][: 2 * rows]):
+                        frame[0].dir[i] = float(v)
+                    return 1
+                except BaseException as ex:   # noqa: BLE001 — never let an exception cross the C frame
+                    errs.append(ex)
+                    return -1
+
+            def send(user, frame):
+                try:
+                    handover.send(int(frame[0].has), float(frame[0].time), [float(frame[0].dir[i]) for i in range(2 * rows)])
+                    return 0
+                except BaseException as ex:   # noqa: BLE001
+                    errs.append(ex)
+                    return -1
+            ho = AdaptiveHandover(_FRAME_RECV(recv), _FRAME_SEND(send), None)
+            L.ecal_detect_keyframes_sharded.argtypes = L.ecal_detect_keyframes.argtypes + [ctypes.POINTER(AdaptiveHandover)]
+            L.ecal_detect_keyframes_sharded.restype = ctypes.c_int
+            st = L.ecal_detect_keyframes_sharded(ctx._h, d_events, int(n_events), ctypes.byref(ap), ctypes.byref(prm), int(cap_points),
+                                                 int(max_keyframes), _ptr(t), _ptr(d), _ptr(e), _ptr(f), ctypes.byref(nk), ctypes.byref(ps),
+                                                 ctypes.byref(nw), ctypes.byref(ho))
+            if errs:
+                raise errs[0]
+            ctx._check(st)
     except EcalError as err:
         err.n_keyframes = int(nk.value)     # ECAL_ERR_RANGE with a count beyond max_keyframes: the keyframe capacity was short
         raise

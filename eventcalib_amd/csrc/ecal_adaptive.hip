@@ -57,6 +57,11 @@ struct AdaptiveArrays {
     double *rej_t, *rej_dir;                              // [P][AD_NREJ], [P][AD_NREJ][rows][2]: the rejected ones before it
     double start_time, end_time;
     uint32_t p_total, p_first;   // the pieces at work are p_first .. p_first + P - 1 of the p_total pieces of [start_time, end_time]
+    // a search over a SUBSET of the pieces under the shared-map gate (ecal_detect_keyframes_sharded): the frame the pieces before the
+    // subset (larger indices: earlier in time, another rank's) hand over — ext[0] = 0: not known yet, 1: known, there is none,
+    // 2: known; ext_frame = its time stamp, then its row directions [rows][2].  NULL: the subset starts the run (no predecessor)
+    const uint32_t *ext;
+    const double *ext_frame;
 };
 
 // EventCalibIni::track's test (EventCalibIni.cpp:73-82): the median — what libstdc++'s std::nth_element leaves at position
@@ -448,12 +453,20 @@ __global__ __launch_bounds__(256) void adaptive_verify_live_kernel(uint32_t P, u
         }
         j += 64u;
     }
-    const double r_t = has ? st.ref_t[j] : 0.0;
+    // no keyframe in the pieces before k that this call runs: the frame comes from the pieces before THEM (another rank's) — not
+    // decidable until that frame has arrived (k's results stand as a speculation with "none" till then)
+    bool from_ext = false;
+    if (!has && st.ext) {
+        const uint32_t es = __hip_atomic_load(st.ext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (es == 0u) return;
+        from_ext = has = es == 2u;
+    }
+    const double r_t = has ? (from_ext ? st.ext_frame[0] : st.ref_t[j]) : 0.0;
     double rx = 0.0, ry = 0.0, ix = 0.0, iy = 0.0;
     if (lane < rows) {
         if (has) {
-            rx = st.ref_dir[((size_t) j * rows + lane) * 2];
-            ry = st.ref_dir[((size_t) j * rows + lane) * 2 + 1];
+            rx = from_ext ? st.ext_frame[1 + 2 * lane] : st.ref_dir[((size_t) j * rows + lane) * 2];
+            ry = from_ext ? st.ext_frame[2 + 2 * lane] : st.ref_dir[((size_t) j * rows + lane) * 2 + 1];
         }
         ix = st.init_dir[((size_t) k * rows + lane) * 2];
         iy = st.init_dir[((size_t) k * rows + lane) * 2 + 1];
@@ -806,11 +819,40 @@ extern "C" uint64_t ecal_detect_keyframes_cap_hint_dev(ecal_ctx *ctx, const uint
 static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                                  const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                                  double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
-                                 uint32_t *passes, uint64_t *windows);
+                                 uint32_t *passes, uint64_t *windows, const ecal_adaptive_handover *ho);
+static int detect_keyframes_entry(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                                  const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                                  double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                                  uint32_t *passes, uint64_t *windows, const ecal_adaptive_handover *ho);
 extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                                      const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                                      double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
                                      uint32_t *passes, uint64_t *windows) {
+    return detect_keyframes_entry(ctx, d_events, n_events, ap, prm, cap_points, max_keyframes, kf_time, kf_duration, kf_events_num,
+                                  kf_features, n_keyframes, passes, windows, nullptr);
+}
+// The shared-map search of ONE stream cut over several callers (ranks): this call runs the pieces ap->piece_first ..
+// piece_first + piece_count - 1 (contiguous in time; piece 0 is the last in time) with the gate of the reference's single-worker
+// run.  What those pieces need from the pieces before them (larger indices, earlier in time: another caller's) is ONE frame — the
+// last keyframe's time stamp and row directions (EventCalibIni.cpp:26-36: the map's last keyframe) —, so the callers form a chain in
+// time: ho->recv delivers the frame of everything before this call's pieces (polled between passes with wait = 0, then waited
+// for; never called when the subset holds the run's first piece), ho->send passes on the frame behind this call's pieces (its own
+// last keyframe, else the received frame) once it is final.  Until the frame arrives the pieces run as a speculation without one;
+// the pass-by-pass verification (adaptive_verify_live_kernel) then re-runs exactly the pieces whose verdicts it changes — as it
+// does for the pieces of one call.  The union of the callers' keyframes is the single call's over all pieces, record for record
+// (tests/test_gpu_bench_multirank.py).
+extern "C" int ecal_detect_keyframes_sharded(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                                             const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                                             double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                                             uint32_t *passes, uint64_t *windows, const ecal_adaptive_handover *ho) {
+    if (!ho || !ho->send || !ho->recv || !ap || ap->gate_mode != ECAL_GATE_SHARED_MAP || ap->piece_count == 0) return ECAL_ERR_INVALID;
+    return detect_keyframes_entry(ctx, d_events, n_events, ap, prm, cap_points, max_keyframes, kf_time, kf_duration, kf_events_num,
+                                  kf_features, n_keyframes, passes, windows, ho);
+}
+static int detect_keyframes_entry(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                                     const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                                     double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                                  uint32_t *passes, uint64_t *windows, const ecal_adaptive_handover *ho) {
     const ecal_range range__(ctx, "ecal_detect_keyframes");
     if (!ctx) return ECAL_ERR_INVALID;
     // the search's windows are three to ten steps long: second-tier work by design — its passes never take the lean form of a
@@ -820,7 +862,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
     const bool was_no_lean = ctx->tail_no_lean;
     ctx->tail_no_lean = true;   // (AUTO stays AUTO: the tiers behind the second may still be dropped, ecal_tail_plan)
     const int rc = detect_keyframes_impl(ctx, d_events, n_events, ap, prm, cap_points, max_keyframes, kf_time, kf_duration, kf_events_num,
-                                         kf_features, n_keyframes, passes, windows);
+                                         kf_features, n_keyframes, passes, windows, ho);
     ctx->tail_mode = was;
     ctx->tail_no_lean = was_no_lean;
     return rc;
@@ -828,7 +870,7 @@ extern "C" int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uin
 static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
                                  const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                                  double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
-                                 uint32_t *passes, uint64_t *windows) {
+                                 uint32_t *passes, uint64_t *windows, const ecal_adaptive_handover *ho) {
     if (!ctx || !ap || !prm || !n_keyframes || (n_events && !d_events)) return ECAL_ERR_INVALID;
     *n_keyframes = 0;
     if (passes) *passes = 0;
@@ -836,9 +878,9 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     const uint32_t P = ap->piece_count ? ap->piece_count : ap->piece_num, M = prm->rows * prm->cols, rows = prm->rows;
     const bool subset = ap->piece_count != 0 && ap->piece_count != ap->piece_num;
     if ((uint64_t) ap->piece_first + ap->piece_count > ap->piece_num || (!ap->piece_count && ap->piece_first) ||
-        (subset && ap->gate_mode == ECAL_GATE_SHARED_MAP)) {
+        (subset && ap->gate_mode == ECAL_GATE_SHARED_MAP && !ho)) {
         ctx->last_error = "ecal_detect_keyframes: piece_first + piece_count beyond piece_num, or a subset of the pieces under the shared-map gate "
-                          "(a piece's gate frame comes from the pieces before it)";
+                          "(a piece's gate frame comes from the pieces before it: ecal_detect_keyframes_sharded hands it over)";
         return ECAL_ERR_INVALID;
     }
     if (P == 0 || M == 0 || M > 128 || prm->rows > (uint32_t) AD_MAX_ROWS || !(ap->motion_time_step > 0) ||
@@ -863,7 +905,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     if ((rc = ecal_ensure(ctx, ctx->host_grid_order, (size_t) S * M * sizeof(int32_t)))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->host_grid_found, (size_t) S * sizeof(uint32_t)))) return rc;
     // per piece: 7 doubles + (3 + AD_NREJ) x rows x 2 doubles of row directions + AD_NREJ doubles + 10 words
-    const size_t state_bytes = (size_t) P * (8 * (7 + AD_NREJ + 2 * (size_t) rows * (3 + AD_NREJ)) + 4 * 12) + 128;
+    const size_t state_bytes = (size_t) P * (8 * (7 + AD_NREJ + 2 * (size_t) rows * (3 + AD_NREJ)) + 4 * 12) + 128 + 8 * (2 + 2 * (size_t) AD_MAX_ROWS);
     if ((rc = ecal_ensure(ctx, ctx->adaptive_state, state_bytes))) return rc;
     if ((rc = ecal_ensure(ctx, ctx->adaptive_dirs, (size_t) S * rows * 2 * sizeof(double)))) return rc;
     // keyframe records: in shared-map mode the pieces that run again leave dead records behind
@@ -912,6 +954,11 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         a.init_has = u, u += P;
         a.rerun = u, u += P;
         a.want = u, u += P;
+        // (the handed-over frame behind everything else, 8-byte aligned: P words x 12 are a multiple of 8 bytes only for even P)
+        double *xf = (double *) (((uintptr_t) u + 7u) & ~(uintptr_t) 7u);
+        const bool has_pred = ho && (uint64_t) ap->piece_first + ap->piece_count < ap->piece_num;
+        a.ext = has_pred ? (const uint32_t *) xf : nullptr;
+        a.ext_frame = has_pred ? xf + 1 : nullptr;
         a.start_time = ap->start_time;
         a.end_time = ap->end_time;
         a.p_total = ap->piece_num;
@@ -924,6 +971,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
     hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
     ECAL_HIP_TRY(ctx, hipMemsetAsync(B[16].ptr, 0, sizeof(int), st));
+    if (a.ext) ECAL_HIP_TRY(ctx, hipMemsetAsync((void *) a.ext, 0, 8 * (2 + 2 * (size_t) AD_MAX_ROWS), st));   // (the frame from before: not known yet)
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..15] counters
     // The host runs `ahead` passes ahead of the device's counters: before it enqueues pass p it waits for the counters that pass
     // p - ahead left (a copy to pinned memory + an event behind every pass) — the device always has work queued, and at most
@@ -955,6 +1003,37 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         if (e == hipSuccess) return ECAL_OK;
         ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? ECAL_ERR_NOMEM : ECAL_ERR_HIP;
+    };
+    // the frame handed over from the pieces before this call's (ecal_detect_keyframes_sharded): asked for between the passes, staged
+    // in pinned memory, copied in on the search's stream — a pass sees all of it or none of it
+    bool ext_known = a.ext == nullptr;
+    ecal_keyframe_frame ext_f;
+    memset(&ext_f, 0, sizeof(ext_f));
+    // the first pass that sees the frame: a report "no piece at work" from an EARLIER pass does not end the search — the frame may
+    // start pieces again that had finished (without it such a report is final: nothing restarts a search whose pieces are all
+    // finished and verified)
+    uint32_t ext_first_pass = 0;
+    auto take_ext = [&](int wait, uint32_t next_pass) -> int {
+        if (ext_known) return ECAL_OK;
+        ecal_keyframe_frame f;
+        memset(&f, 0, sizeof(f));
+        const int r = ho->recv(ho->user, &f, wait);
+        if (r < 0) {
+            ctx->last_error = "ecal_detect_keyframes_sharded: the recv callback failed";
+            return ECAL_ERR_INVALID;
+        }
+        if (r == 0) return ECAL_OK;
+        double *stage = reinterpret_cast<double *>(ctx->pass_pinned) + 64;   // (bytes 512 ..: behind the counters and the report ring)
+        const uint32_t word[2] = {f.has ? 2u : 1u, 0u};
+        memcpy(stage, word, sizeof(word));
+        stage[1] = f.time;
+        for (uint32_t i = 0; i < 2 * rows; i++) stage[2 + i] = f.dir[i];
+        const hipError_t e = hipMemcpyAsync((void *) a.ext, stage, 8 * (2 + 2 * (size_t) rows), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return hip_rc(e, "hipMemcpyAsync");
+        ext_f = f;
+        ext_known = true;
+        ext_first_pass = next_pass;
+        return ECAL_OK;
     };
     // the lock-step passes of one set of runs: until no piece has a window left
     uint32_t deal = S;   // window slots dealt out per pass (all of them in the first set of runs)
@@ -1005,10 +1084,11 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                     if (ctx->sw.adaptive_trace) fprintf(stderr, "ecal_detect_keyframes: cap_points %u too small after %u passes\n", cap_points, n_passes);
                     return ECAL_ERR_RANGE;
                 }
-                if (ring[4 * q] == 0) break;   // (the passes enqueued since find nothing to do)
+                if (ring[4 * q] == 0 && want >= ext_first_pass) break;   // (the passes enqueued since find nothing to do)
             }
             n_passes++;
             seq++;
+            AD_TRY(take_ext(0, seq));
             AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sr, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                           (uint32_t *) B[4].ptr, st));
             AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sr, 0,
@@ -1058,6 +1138,16 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         return ECAL_OK;
     };
     if ((rc = run_passes())) return rc;
+    if (!ext_known) {
+        // every piece has run to its end on the speculation that nothing comes before it: now the frame is needed.  With it the
+        // verification of the next pass re-runs the pieces whose verdicts it changes (usually the first one or two in time)
+        AD_TRY(take_ext(1, seq + 1u));
+        if (!ext_known) {
+            ctx->last_error = "ecal_detect_keyframes_sharded: recv(wait = 1) returned without a frame";
+            return ECAL_ERR_INVALID;
+        }
+        if ((rc = run_passes())) return rc;
+    }
     const bool trace = ctx->sw.adaptive_trace;
 #undef AD_TRY
 #ifdef ECAL_ADAPTIVE_STATS
@@ -1085,6 +1175,24 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     }
     if (passes) *passes = longest;
     if (windows) *windows = nwin;
+    if (ho) {
+        // the frame behind this call's pieces: the last keyframe of its latest piece (smallest index) that has one, else the frame
+        // it was handed
+        std::vector<uint32_t> nacc(P);
+        ECAL_HIP_TRY(ctx, hipMemcpy(nacc.data(), a.nacc, (size_t) P * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        ecal_keyframe_frame out = ext_f;
+        for (uint32_t k = 0; k < P; k++)
+            if (nacc[k] > 0) {
+                out.has = 1;
+                ECAL_HIP_TRY(ctx, hipMemcpy(&out.time, a.ref_t + k, sizeof(double), hipMemcpyDeviceToHost));
+                ECAL_HIP_TRY(ctx, hipMemcpy(out.dir, a.ref_dir + (size_t) k * rows * 2, 2 * (size_t) rows * sizeof(double), hipMemcpyDeviceToHost));
+                break;
+            }
+        if (ho->send(ho->user, &out) < 0) {
+            ctx->last_error = "ecal_detect_keyframes_sharded: the send callback failed";
+            return ECAL_ERR_INVALID;
+        }
+    }
     const uint32_t K_all = h[1];   // records written, dead ones included
     if (K_all > max_keys) {
         *n_keyframes = K_all;

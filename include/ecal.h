@@ -412,7 +412,8 @@ typedef struct ecal_adaptive_params {
     /* piece_count != 0: only the pieces piece_first .. piece_first + piece_count - 1 of the piece_num pieces (piece 0 is the last
      * in time, eventCameraCalib.cpp:172-179), with exactly the bounds they have in the whole run.  Pieces are independent under
      * ECAL_GATE_OWN_PIECE, so several calls — one context and host thread each — share one search: their kernels overlap on the
-     * GPU (a lock-step pass is latency bound) and the union of their keyframes is the whole run's.  Not with ECAL_GATE_SHARED_MAP. */
+     * GPU (a lock-step pass is latency bound) and the union of their keyframes is the whole run's.  With ECAL_GATE_SHARED_MAP a
+     * subset needs the frame of the pieces before it: ecal_detect_keyframes_sharded. */
     uint32_t piece_first, piece_count;
 } ecal_adaptive_params;
 /* Which keyframe a successful window is gated against (EventCalibIni::track, EventCalibIni.cpp:26-36: the map's
@@ -432,6 +433,32 @@ int ecal_detect_keyframes(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
                           const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
                           double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
                           uint32_t *passes, uint64_t *windows);
+/* ecal_detect_keyframes_sharded: the shared-map search of ONE stream cut over several callers (one per GPU): this call runs the
+ * pieces ap->piece_first .. piece_first + piece_count - 1 (contiguous in time) under ECAL_GATE_SHARED_MAP.  What they need from
+ * the pieces before them (larger indices = earlier in time, another caller's) is one frame — the map's last keyframe as
+ * EventCalibIni::track reads it (EventCalibIni.cpp:26-36): time stamp + the pattern rows' line directions —, so the callers form
+ * a chain in time: recv delivers the frame behind all earlier pieces (return 1: *frame filled — has = 0: no keyframe before —,
+ * 0: not there yet (only when wait == 0), < 0: error; polled between passes, then waited for; never called by the caller that
+ * holds the run's first piece), send is called once with the frame behind this caller's pieces (return < 0: error).  The union
+ * of the callers' keyframes == ecal_detect_keyframes over all pieces, record for record.  N - 1 messages of 8 (2 + 2 rows)
+ * bytes per search; a caller's pieces run speculatively until its frame arrives (docs: design/11_keyframe_gate.md). */
+#define ECAL_FRAME_MAX_ROWS 32
+typedef struct ecal_keyframe_frame {
+    int has;                              /* 0: no keyframe */
+    double time;                          /* KeyFrame time stamp */
+    double dir[2 * ECAL_FRAME_MAX_ROWS];  /* [rows][2]: direction of the line fitted to every pattern row (EventCalibIni.cpp:46-57) */
+} ecal_keyframe_frame;
+typedef int (*ecal_frame_recv_fn)(void *user, ecal_keyframe_frame *frame, int wait);
+typedef int (*ecal_frame_send_fn)(void *user, const ecal_keyframe_frame *frame);
+typedef struct ecal_adaptive_handover {
+    ecal_frame_recv_fn recv;
+    ecal_frame_send_fn send;
+    void *user;
+} ecal_adaptive_handover;
+int ecal_detect_keyframes_sharded(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
+                                  const ecal_detect_params *prm, uint32_t cap_points, uint32_t max_keyframes, double *kf_time,
+                                  double *kf_duration, int32_t *kf_events_num, double *kf_features, uint32_t *n_keyframes,
+                                  uint32_t *passes, uint64_t *windows, const ecal_adaptive_handover *ho);
 /* a cap_points that ecal_detect_keyframes will usually find sufficient for a stream of n_events events (0: invalid
  * parameters); ECAL_ERR_RANGE still says when it was not — double it and call again */
 uint64_t ecal_detect_keyframes_cap_hint(const ecal_adaptive_params *ap, uint64_t n_events);

@@ -217,3 +217,56 @@ def test_shared_map_gate_at_the_reference_s_piece_count():
         _same_keyframes(detect_keyframes_device(ctx, ev, 5e-4, 4000, 1270, t_first, t_last), own)
     finally:
         ctx.close()
+
+
+class _ChainHandover:
+    """In-process stand-in for the ranks' frame hand-over: the shards run one after the other, earliest in time first; `delay` =
+    polls (wait = False) answered "not there yet" before the frame is handed out (None: only a waiting recv gets it)."""
+
+    def __init__(self, frame_in, delay):
+        self.frame_in, self.delay, self.polls, self.frame_out = frame_in, delay, 0, None
+
+    def recv(self, wait):
+        if wait or (self.delay is not None and self.polls >= self.delay):
+            return self.frame_in
+        self.polls += 1
+        return None
+
+    def send(self, has, time, dirs):
+        self.frame_out = (has, time, dirs)
+
+
+@pytest.mark.parametrize("pieces,shards,delay", [(40, 4, 0), (40, 4, 3), (40, 8, None), (23, 2, 1), (40, 40, 2)])
+def test_sharded_shared_map_search_equals_the_single_call(env, pieces, shards, delay):
+    """ecal_detect_keyframes_sharded: the pieces of ONE shared-map search cut into `shards` contiguous groups (as `bench.py --gpus N`
+    cuts them over the ranks), every group a call of its own that gets the frame behind the earlier groups through the hand-over
+    callbacks — immediately, after a few passes (the group has been running as a speculation without a frame: the pass-by-pass
+    verification re-runs what the frame changes), or only when it has nothing left to do and waits.  The union of the groups'
+    keyframes == the single call over all pieces == the sequential oracle (test_shared_map_gate_equals_the_single_worker_reference)."""
+    import eventcalib_amd.capi as capi
+    from eventcalib_amd.adaptive import detect_keyframes_device
+    ctx, pipe, ev, torch = env
+    t_first, t_last = 5.0, 5.0 + 0.4
+    want = detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP)
+    assert len(want["time"]) >= 20
+    frame = (0, 0.0, [0.0] * 64)
+    parts = []
+    for g in reversed(range(shards)):               # group `shards - 1` holds the largest piece indices = the earliest pieces
+        lo, hi = pieces * g // shards, pieces * (g + 1) // shards
+        ho = _ChainHandover(frame, delay)
+        parts.append(detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP,
+                                             piece_first=lo, piece_count=hi - lo, handover=ho))
+        assert ho.frame_out is not None
+        if hi < pieces and delay is not None and delay > 0:
+            assert ho.polls == delay                 # (the frame was withheld for that many passes)
+        frame = ho.frame_out
+    got = {k: np.concatenate([p[k] for p in parts]) for k in ("time", "duration", "events_num", "features")}
+    order = np.argsort(got["time"], kind="stable")
+    for k in ("time", "duration", "events_num", "features"):
+        assert np.array_equal(got[k][order], want[k]), k
+    assert sum(p["windows"] for p in parts) == want["windows"]
+    # the frame behind the whole run = the last keyframe's time stamp
+    assert frame[0] == 1 and frame[1] == want["time"][-1]
+    # a subset without the hand-over stays refused
+    with pytest.raises(capi.EcalError):
+        detect_keyframes_device(ctx, ev, 5e-4, 4000, pieces, t_first, t_last, gate_mode=capi.GATE_SHARED_MAP, piece_first=0, piece_count=1)

@@ -59,11 +59,16 @@ def test_two_ranks_match_one_rank():
     # ... and the adaptive-window search of that stream with its pieces cut over the ranks: the keyframes and windows of the
     # single-rank search (own-piece gate, same piece count)
     p1 = [p for p in one["policy_p2"] if p.get("driver") == "device" and p.get("gate") == "own piece"][0]
-    p2 = two["policy_p2_sharded"]
+    p2 = two["policy_p2_sharded"]["own_piece_gate"]
     assert p2["pieces"] == p1["pieces"] and p2["pieces_per_gpu"] <= (p1["pieces"] + 1) // 2
     assert p2["keyframes"] == p1["keyframes"] > 0 and p2["windows_evaluated"] == p1["windows_evaluated"]
-    # the sharded leg says which gate it ran (the shared-map gate, the single-GPU front ends' default, does not shard)
-    assert p2["gate"] == "own piece" and p2["single_gpu_default_gate"] == "shared map" and "does not shard" in p2["note"]
+    # ... and with the reference's gate — the single-GPU front ends' default — through the frame hand-over between the ranks
+    # (ecal_detect_keyframes_sharded): the very keyframes of the single-rank shared-map search
+    s1 = [p for p in one["policy_p2"] if p.get("driver") == "device" and p.get("gate", "").startswith("shared map")][0]
+    s2 = two["policy_p2_sharded"]
+    assert s2["gate"].startswith("shared map") and s2["pieces"] == s1["pieces"]
+    assert s2["keyframes"] == s1["keyframes"] > 0 and s2["windows_evaluated"] == s1["windows_evaluated"]
+    assert s2["keyframe_times_sha1_16"] == s1["keyframe_times_sha1_16"] and s2["keyframe_times_sha1_16"] != p2["keyframe_times_sha1_16"]
     # the event -> point map: the line says whether the timed pass wrote it, and carries both figures
     for r in (one, two):
         assert r["config"]["event_point"] is False and r["event_point_map"]["timed_pass_writes_the_map"] is False
@@ -114,8 +119,12 @@ def test_eight_ranks_match_one_rank():
     assert eight["config"]["windows_total"] == one["config"]["windows_total"]
     assert eight["config"]["windows_per_gpu"] <= one["config"]["windows_per_gpu"] // 8 + 1
     p1 = [p for p in one["policy_p2"] if p.get("driver") == "device" and p.get("gate") == "own piece"][0]
-    p8 = eight["policy_p2_sharded"]
+    p8 = eight["policy_p2_sharded"]["own_piece_gate"]
     assert p8["pieces"] == p1["pieces"] and p8["keyframes"] == p1["keyframes"] > 0 and p8["windows_evaluated"] == p1["windows_evaluated"]
+    s1 = [p for p in one["policy_p2"] if p.get("driver") == "device" and p.get("gate", "").startswith("shared map")][0]
+    s8 = eight["policy_p2_sharded"]
+    assert s8["gate"].startswith("shared map") and s8["keyframes"] == s1["keyframes"] > 0
+    assert s8["windows_evaluated"] == s1["windows_evaluated"] and s8["keyframe_times_sha1_16"] == s1["keyframe_times_sha1_16"]
     c1, c8 = one["init_calibration"], eight["init_calibration"]
     assert c8["views_per_gpu"] == 8 and abs(c1["rms_px"] - c8["rms_px"]) < 1e-9 and abs(c1["lm_iterations"] - c8["lm_iterations"]) <= 1
     s1, s8 = one["solver"], eight["solver"]
