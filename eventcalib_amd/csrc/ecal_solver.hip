@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
     double q[4][4], t[4][3], pin[9], binv[6];
     for (int i = 0; i < 9; i++) pin[i] = intr[i];
     spline_span_inverses(kn, ch.span, binv);           // uniform over the chunk: 6 + 2 divisions per thread, not per residual
-    const double ifx = 1.0 / pin[0], ify = 1.0 / pin[1];
+    const double ifx = 1.0 / pin[0], ify = 1.0 / pin[1], inv_huber_a = 1.0 / huber_a;
     for (int j = 0; j < 4; j++) {
         for (int k = 0; k < 4; k++) q[j][k] = qall[4 * (size_t) (c0 + j) + k];
         for (int k = 0; k < 3; k++) t[j][k] = tall[3 * (size_t) (c0 + j) + k];
@@ -218,16 +218,19 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
         double r = 0.0, sc = 0.0;
         const ResRecord e = e_next;
         e_next = rec[ch.start + min(k + (uint32_t) NE_T, ch.count - 1u)];
+        // (no branch around the residual code: a lane past the chunk's end — the last batch only — evaluates the chunk's last
+        // record again, which it holds anyway (clamped load), and its row is scaled by zero: the row's 34 stores need no selects)
+        const bool live = k < ch.count;
 #ifdef ECAL_NE_SKIP_P1
-        if (k < ch.count) {
+        {
             r = e.u;
-            sc = e.v;
+            sc = live ? e.v : 0.0;
             for (int i = 0; i < RES_NJ; i++) J[i] = e.t + i;
-            cost += r;
+            cost += live ? r : 0.0;
         }
         if (false) {
 #else
-        if (k < ch.count) {
+        {
 #endif
             ResidualInput in;
             in.u = e.u;
@@ -239,17 +242,23 @@ __global__ __launch_bounds__(NE_T, SO3 ? 1 : 2) void normal_eq_kernel(const ResR
             in.ifx = ifx;
             in.ify = ify;
             spline_basis_inv(kn, ch.span, binv, e.t, in.b);
+            double hr = 0.0;
+            if constexpr (with_jac) {   // the row comes out scaled by sqrt(rho') (ResidualInput)
+                in.huber_a = huber_a;
+                in.dead = !live;
+                in.inv_huber_a = inv_huber_a;
+                in.sc_out = &sc;
+                in.half_rho_out = &hr;
+            }
             r = SO3 ? spline_residual_so3<FISHEYE>(in, pin, q, t, with_jac ? J : nullptr)
                     : spline_residual<FISHEYE>(in, pin, q, t, with_jac ? J : nullptr);
-            double hr;
-            sc = huber_scale(r, huber_a, &hr);
-            cost += hr;
+            if constexpr (!with_jac) sc = huber_scale(r, huber_a, &hr, inv_huber_a);
+            cost += live ? hr : 0.0;
         }
         if constexpr (with_jac) {
-            const bool live = k < ch.count;
 #pragma unroll
-            for (int i = 0; i < RES_NJ; i++) slab[i * 64 + (lane ^ ne_swz(i))] = live ? J[i] * sc : 0.0;
-            slab[33 * 64 + (lane ^ ne_swz(33))] = live ? r * sc : 0.0;
+            for (int i = 0; i < RES_NJ; i++) slab[i * 64 + (lane ^ ne_swz(i))] = J[i];
+            slab[33 * 64 + (lane ^ ne_swz(33))] = r * sc;
             // the slab is this wave's alone: no workgroup barrier.  A wave's LDS operations complete in order; the fence keeps the
             // compiler from moving the reads above the writes (other lanes' data) or the next batch's writes above these reads.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

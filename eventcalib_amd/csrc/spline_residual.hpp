@@ -34,6 +34,16 @@ namespace ecal {
 
 constexpr int RES_NJ = 33;  // tangent-space width of one residual's Jacobian row
 
+// 1 / sqrt(x): on the device the reciprocal square root (v_rsq_f64 + refinement, ~1 ulp) instead of a square root AND a division
+// (~27 FP64 instructions of the ~440 a batch of residuals costs; the kernel is bound by FP64 issue, design/08_solver.md)
+ECAL_HD double res_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return rsqrt(x);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 // knot span index for u in a clamped knot vector with n_cp control points, degree 3
 // (BsplineReal.hpp:208-231; u == last knot -> last span)
 ECAL_HD uint32_t spline_find_span(const double *knots, uint32_t n_cp, double u) {
@@ -92,7 +102,15 @@ ECAL_HD void spline_basis_inv(const double *knots, uint32_t span, const double i
     for (int j = 0; j <= 3; j++) b[j] = N[j];
 }
 
+ECAL_HD double huber_scale(double r, double a, double *half_rho, double inv_a);
+
 struct ResidualInput {
+    // sc_out != nullptr: the core applies the robust loss (Huber, huber_a) itself — *sc_out = sqrt(rho') and *half_rho_out = rho / 2 of the residual it
+    // returns, and the Jacobian row comes out ALREADY scaled by sqrt(rho') (the row is linear in d res / d Xw, which is scaled at
+    // its root: three multiplications instead of 33 on the finished row)
+    double huber_a = 0.0, inv_huber_a = 0.0;
+    double *sc_out = nullptr, *half_rho_out = nullptr;
+    bool dead = false;    // (with sc_out) a row that must come out as zeros: *sc_out = 0 (a lane past the end of its chunk)
     double u, v;          // observed pixel
     double lmx, lmy, lmz; // landmark (circle centre on the board, z = 0)
     double radius;        // circle radius (world units)
@@ -131,12 +149,19 @@ ECAL_HD double residual_core(const ResidualInput &in, const double *intr, double
     const double s = -T[2] * iY2;  // depth
     const double Xw0 = T[0] + s * Y0, Xw1 = T[1] + s * Y1, Xw2 = T[2] + s * Y2;
     const double d0 = Xw0 - in.lmx, d1 = Xw1 - in.lmy, d2 = Xw2 - in.lmz;
-    const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const double dd = d0 * d0 + d1 * d1 + d2 * d2;
+    const double idist = res_rsqrt(dd);
+    const double dist = dd * idist;
     const double res = dist - in.radius;
     if (!J) return res;
 
-    const double idist = 1.0 / dist;
-    const double e0 = d0 * idist, e1 = d1 * idist, e2 = d2 * idist;  // d res / d Xw
+    double esc = idist;
+    if (in.sc_out) {
+        const double sc = in.dead ? 0.0 : huber_scale(res, in.huber_a, in.half_rho_out, in.inv_huber_a);
+        *in.sc_out = sc;
+        esc = idist * sc;
+    }
+    const double e0 = d0 * esc, e1 = d1 * esc, e2 = d2 * esc;  // d res / d Xw (times sqrt(rho') under the robust loss)
     const double eY = e0 * Y0 + e1 * Y1 + e2 * Y2;
     // Xw = T - T_z Y / Y_z
     gT[0] = e0;
@@ -188,8 +213,7 @@ ECAL_HD double spline_residual(const ResidualInput &in, const double *intr, cons
         for (int k = 0; k < 4; k++) vq[k] += in.b[j] * q[j][k];
         for (int k = 0; k < 3; k++) T[k] += in.b[j] * t[j][k];
     }
-    const double vn = sqrt(vq[0] * vq[0] + vq[1] * vq[1] + vq[2] * vq[2] + vq[3] * vq[3]);
-    const double ivn = 1.0 / vn;
+    const double ivn = res_rsqrt(vq[0] * vq[0] + vq[1] * vq[1] + vq[2] * vq[2] + vq[3] * vq[3]);
     const double ux = vq[0] * ivn, uy = vq[1] * ivn, uz = vq[2] * ivn, w = vq[3] * ivn;
     double gq[4], gT[3];
     const double res = residual_core<FISHEYE>(in, intr, ux, uy, uz, w, T, J, gq, gT);
@@ -373,16 +397,13 @@ ECAL_HD double spline_residual_so3(const ResidualInput &in, const double *intr, 
 // ceres::HuberLoss(a) + Corrector for a scalar residual (Ceres 1.x loss_function.cc / corrector.cc):
 // s = r^2; rho(s) = s (s <= a^2) or 2 a sqrt(s) - a^2; rho'' <= 0, so residual and Jacobian row are
 // both scaled by sqrt(rho'); cost contribution = rho / 2.
-ECAL_HD double huber_scale(double r, double a, double *half_rho) {
-    const double s = r * r, b = a * a;
-    if (s <= b) {
-        *half_rho = 0.5 * s;
-        return 1.0;
-    }
-    const double rt = sqrt(s);
-    *half_rho = 0.5 * (2.0 * a * rt - b);
-    const double rho1 = a / rt;
-    return sqrt(rho1 > 0 ? rho1 : 0.0);  // max(min, a / r), Ceres clamps with DBL_MIN
+// Branch-free: |r| is sqrt(s), and sqrt(a / |r|) one reciprocal square root of |r| / a (inv_a = 1 / a: a constant of the call).
+ECAL_HD double huber_scale(double r, double a, double *half_rho, double inv_a) {
+    const double s = r * r, b = a * a, rt = fabs(r);
+    const bool tail = !(s <= b);
+    *half_rho = tail ? a * rt - 0.5 * b : 0.5 * s;
+    const double q = rt * (inv_a != 0.0 ? inv_a : 1.0 / a);
+    return tail ? res_rsqrt(q > 0 ? q : 1.0) : 1.0;   // (tail implies |r| > a >= 0: q > 0; Ceres clamps a / |r| with DBL_MIN)
 }
 
 // q <- q (x) exp(delta)   (LocalParameterizationSO3::Plus, BsplineSO3.hpp:196-203)

@@ -157,3 +157,55 @@ def test_world_size_2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _handover_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from eventcalib_amd.adaptive import DistHandover
+        # the chain in time of `bench.py --gpus N`'s sharded shared-map search: rank r holds pieces later in time than rank r + 1
+        ho = DistHandover(rank + 1 if rank + 1 < world else None, rank - 1 if rank > 0 else None, tag=7)
+        if rank + 1 == world:
+            got = (0, 0.0, [0.0] * 64)              # holds the run's first piece: the library never asks it to receive
+        else:
+            polls = 0
+            got = ho.recv(False)
+            while got is None and polls < 200000:   # between passes: "not there yet" until the predecessor is done
+                polls += 1
+                got = ho.recv(False)
+            if got is None:
+                got = ho.recv(True)
+            assert ho.recv(False) == got and ho.recv(True) == got    # kept: a repeated call finds it again
+        has, t, dirs = got
+        assert len(dirs) == 64
+        mine = (1, t + 10.0 + rank, [float(rank)] * 18 + [0.0] * 46) if rank % 2 == 0 else got   # odd ranks: no keyframe of their own
+        ho.send(*mine)
+        ho.send(1, -1.0, [9.0] * 64)                 # a second send (a call repeated with more capacity) is a no-op
+        q.put((rank, got[0], got[1], list(got[2][:2]), None))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, None, None, None, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_3_gloo_keyframe_frame_handover():
+    """DistHandover (eventcalib_amd/adaptive.py), the transport of ecal_detect_keyframes_sharded's frame hand-over: a chain of
+    world - 1 point-to-point messages from the rank that is earliest in time to the latest; polling receive, the frame kept for
+    repeated calls, one send per rank; a rank without a keyframe of its own passes on what it received."""
+    world, port = 3, 29771 + os.getpid() % 100
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    ps = [ctxm.Process(target=_handover_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+    assert all(r[4] is None for r in res), res
+    # rank 2 (earliest): nothing before it, sends (1, 12, [2, 2, ..]); rank 1 (odd) passes it on; rank 0 receives rank 2's frame
+    assert res[2][1:4] == (0, 0.0, [0.0, 0.0])
+    assert res[1][1:4] == (1, 12.0, [2.0, 2.0])
+    assert res[0][1:4] == (1, 12.0, [2.0, 2.0])
