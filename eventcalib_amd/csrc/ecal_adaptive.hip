@@ -182,19 +182,26 @@ struct ChainTree {
 __device__ __forceinline__ ChainTree tree_for(uint32_t slots, uint32_t tree) {
     ChainTree y = {};
     const uint32_t TM = tree & 0xFFu, TL = (tree >> 8) & 0xFFu, C1 = (tree >> 16) & 0xFu, C2 = (tree >> 20) & 0xFu, C3 = (tree >> 24) & 0xFu, TF = tree >> 28;
-    if (!tree || TL == 0 || slots < TM + TL) return y;
+    // (a level's chains hang below positions TF .. TF + c - 1 of the chain above: a word whose hang positions run past that chain —
+    // only reachable through ECAL_ADAPTIVE_SHAPE tree= — is clamped; write_tree_level writes child chains for positions < len only,
+    // and a counted but unwritten chain would keep the previous pass's windows)
+    if (!tree || TL == 0 || slots < TM + TL || TF >= TM) return y;
+    const uint32_t cap1 = TM - TF, cap23 = TF < TL ? TL - TF : 0u;
     y.len0 = TM;
     y.len1 = y.len2 = y.len3 = TL;
     y.a1 = y.a2 = y.a3 = TF;
     uint32_t used = TM;
     y.c1 = (slots - used) / TL;
     y.c1 = y.c1 < C1 ? y.c1 : C1;
+    y.c1 = y.c1 < cap1 ? y.c1 : cap1;
     used += y.c1 * TL;
     y.c2 = y.c1 ? (slots - used) / (y.c1 * TL) : 0u;
     y.c2 = y.c2 < C2 ? y.c2 : C2;
+    y.c2 = y.c2 < cap23 ? y.c2 : cap23;
     used += y.c1 * y.c2 * TL;
     y.c3 = y.c2 ? (slots - used) / (y.c1 * y.c2 * TL) : 0u;
     y.c3 = y.c3 < C3 ? y.c3 : C3;
+    y.c3 = y.c3 < cap23 ? y.c3 : cap23;
     return y;
 }
 __device__ __forceinline__ uint32_t tree_slots_max(uint32_t tree) {

@@ -202,6 +202,7 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     for (auto &e : ctx->adaptive_ev)
         if (e) (void) hipEventDestroy(e);
     if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
+    if (ctx->wb_done) (void) hipEventDestroy(ctx->wb_done);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_uploaded[k]) (void) hipEventDestroy(ctx->ev_uploaded[k]);
         if (ctx->ev_consumed[k]) (void) hipEventDestroy(ctx->ev_consumed[k]);

@@ -55,6 +55,7 @@ struct ecal_ctx {
     uint32_t grid_hint_windows = 0;   // ecal_grid_order_dev: windows that hold work in the next launch, by the caller's knowledge (0: the launch's size)
     hipStream_t wb_stream = nullptr;   // ... and the one stream whose calls use the table (others: the two-kernel form)
     bool wb_stream_set = false;
+    hipEvent_t wb_done = nullptr;      // recorded behind every fused call of the owner: another stream takes the table over once it has fired
     ecal_devbuf px_todo;  // [4 + S] u32: count, then the segments the pixel kernel left to the general tiers
     ecal_devbuf sl_pts, sl_pol, sl_bend, sl_sorted, sl_rep, sl_pos;  // global-scratch tier of the slicer
     ecal_devbuf sort_scratch;  // ecal_sort_events_dev: keys, indices, radix-sort workspace

@@ -747,9 +747,13 @@ extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, ui
     // the look-back table and its epoch belong to ONE stream of the context (the first that asks): calls in flight on two
     // streams would overwrite each other's status words with another epoch and a workgroup looking back would wait for ever
     // — a call on any other stream takes the two-kernel form, which uses no context scratch
+    // The binding moves when the caller's stream changes and the owner has nothing in flight (an event behind every fused call):
+    // a context whose first call came from a warm-up stream is not stuck on the two-kernel form for life.
     if (!ctx->wb_stream_set) {
         ctx->wb_stream = st;
         ctx->wb_stream_set = true;
+    } else if (ctx->wb_stream != st && ctx->wb_done && hipEventQuery(ctx->wb_done) == hipSuccess) {
+        ctx->wb_stream = st;
     }
     uint32_t *ticket = (ctx->sw.bounds_two_kernels || ctx->wb_stream != st) ? nullptr : ecal_zero_words(ctx, st, 1);
     if (ticket && ctx->wb_status.cap < (size_t) n_wg * sizeof(unsigned long long)) {
@@ -762,6 +766,8 @@ extern "C" int ecal_window_bounds_dev(ecal_ctx *ctx, const uint8_t *d_events, ui
         ctx->wb_epoch = (ctx->wb_epoch % 0x3FFFFFFFu) + 1u;       // 1 .. 2^30 - 1, never the wiped table's 0
         hipLaunchKernelGGL(window_bounds_base_kernel, dim3(n_wg), dim3(WB_T), 0, st, d_events, n_events, d_t0, d_t1, S, d_win_lo, d_win_hi,
                            d_win_base, (unsigned long long *) ctx->wb_status.ptr, ctx->wb_epoch, ticket);
+        if (!ctx->wb_done && hipEventCreateWithFlags(&ctx->wb_done, hipEventDisableTiming) != hipSuccess) ctx->wb_done = nullptr;
+        if (ctx->wb_done) (void) hipEventRecord(ctx->wb_done, st);
     } else {   // (no zeroed word to be had, or the debug switch: the search and the scan as two launches)
         hipLaunchKernelGGL(window_bounds_kernel, dim3((S + 255) / 256), dim3(256), 0, st, d_events, n_events, d_t0, d_t1, S,
                            d_win_lo, d_win_hi);
