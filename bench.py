@@ -719,7 +719,7 @@ def e2e_leg(args, ctx, dev, torch, np):
     calibrate_stream(ctx, ev, t_start, t_start + (n - 1) / rate, piece_num=pieces)   # warm-up (as the timed loop's): scratch of the context at its final sizes; the C++ chain below is the cold process
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    # the front ends' default: the reference's single-worker keyframe gate (one keyframe map for all pieces)
+    # the front ends' default: the reference's single-worker keyframe gate (one keyframe map for all pieces, design/11_keyframe_gate.md)
     r = calibrate_stream(ctx, ev, t_start, t_start + (n - 1) / rate, piece_num=pieces)
     wall = time.perf_counter() - t0
     sp = r["spline"]
@@ -1060,7 +1060,7 @@ def segments_leg(args, ctx, dev, world, rank, dist, torch, np, n_res, n_cp, dura
         "roofline_fp64": {"kernel": "normal_eq_kernel", "flop_per_residual": FLOP_JAC,
                           "achieved_TFLOPs": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 1e12, 3), "peak_TFLOPs": 78.6,
                           "frac": round(FLOP_JAC * n_res / (jac_ms * 1e-3) / 78.6e12, 4)},
-        "evaluation": "streamed: the kernel delivers the accumulation buffer group by group, the host factorises under it (DESIGN.md 8)"
+        "evaluation": "streamed: the kernel delivers the accumulation buffer group by group, the host factorises under it (design/08_solver.md)"
                       if world == 1 else "plain",
         "plain_evaluation": plain_solve,
         "sharding": "one spline segment (time range) per GPU in its own solver, shared intrinsics: 91 doubles all-reduced per "

@@ -3,7 +3,7 @@
 // Replaces the sequential reference pair
 //   dbscan/include/dbscan.h:115-177,198-265  (Run / regionQuery / expandCluster)
 //   dbscan/src/kdtree.cpp:106-179            (insertion-order kd-tree, range query)
-// with a data-parallel formulation that yields the same labels bit for bit:
+// with a data-parallel formulation that yields the same labels bit for bit (design/03_dbscan.md):
 //   B. kd-cell bounds: a level-synchronous replay of kd_insert gives every point the deepest
 //      ancestor per dimension whose right (lo) / left (hi) subtree contains it;
 //   C. torus cell hash (cell edge >= eps); points counting-sorted by bucket, their coordinates
@@ -16,7 +16,7 @@
 // own double arithmetic; GeoI16 is taken (per segment, decided on the device) when every
 // coordinate is an integer of magnitude <= 16383 — event pixels — and evaluates the SAME
 // predicates in exact 32-bit integer arithmetic (double arithmetic on such values is exact, so
-// every comparison has the identical outcome).
+// every comparison has the identical outcome; design/03_dbscan.md).
 // Arithmetic of the ball predicate is the reference's: (xj-xi)^2 + (yj-yi)^2 <= eps*eps with
 // separate mul/add (kdtree.cpp:155-159) — this translation unit must be built -ffp-contract=off.
 #pragma once
@@ -213,7 +213,7 @@ __device__ __forceinline__ bool pruned_dim(const typename G::Store *cs, const Id
 // coordinate, bit2/bit3 = its hi_x/hi_y ancestor within eps*2^-30 above.  pruned_dim(.., j, d, ..)
 // can only fire through an ancestor whose bit is set: the pruning ancestor's coordinate and j's
 // both round to a difference of exactly eps from the query, so they are within one ulp(eps) of
-// each other.  For pixel data the bit simply says "an ancestor shares my x (y)".
+// each other (design/03_dbscan.md).  For pixel data the bit simply says "an ancestor shares my x (y)".
 template <typename G, typename Idx>
 __device__ __forceinline__ uint32_t point_flags(const typename G::Store *p, typename G::Store self, uint32_t lox,
                                                 uint32_t loy, uint32_t hix, uint32_t hiy, double tol) {
@@ -352,7 +352,7 @@ __device__ __forceinline__ bool kd_level_settle(uint32_t *slot, uint32_t i, type
     using R = IdxBits<uint32_t>;
     const uint32_t a = st & R::MASK;
     const uint32_t d = (st & R::DIR) ? 1u : 0u;
-    // deepest ancestor wins; value selects keep the four ids in registers
+    // deepest ancestor wins (design/03_dbscan.md); value selects keep the four ids in registers
     const bool right = (st & R::SIDE) != 0;
     lox = (right && !d) ? a : lox;
     loy = (right && d) ? a : loy;

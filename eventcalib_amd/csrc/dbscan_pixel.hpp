@@ -11,7 +11,7 @@
 // (tools/occupancy_probe.sh, profiles/r01_notes.md) — so throughput is proportional to the workgroups a CU can
 // hold, i.e. to 160 KB / LDS per workgroup (capacity 768 points instead of 1024: 22.1 KB, 7 instead of 6 workgroups,
 // 1.157 -> 1.033 ms on the benchmark stream whose segments hold <= 666 points).  For integer pixels the
-// closed form of the pruning quirk collapses to two bits per point,
+// closed form of the pruning quirk (design/03_dbscan.md) collapses to two bits per point,
 //     f_d(j) = "an ancestor of j in the insertion-order kd-tree splits on d at j's own d-coordinate",
 // and  i -> j is pruned  <=>  j = i + eps * e_d exactly  and  f_d(j)   (integral eps only),
 // so the replay of kd_insert (phase B) only has to produce those bits: no ancestor tables, no f64 replay.

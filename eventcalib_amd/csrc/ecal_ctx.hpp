@@ -20,7 +20,7 @@ struct ecal_devbuf {
 // Debug / test switches (ECAL_FORCE, ECAL_TRACE, ECAL_ADAPTIVE_SHAPE, …: ecal_capi.hip), read from the environment ONCE per context (ecal_init) — not per call: getenv is not safe against a
 // concurrent setenv, and the entry points that consult these are the hot ones.  Tests that flip a switch on a live context call
 // ecal_debug_reload_env afterwards (eventcalib_amd.capi.sync_env does it for every live context).  None of them changes a
-// result, only which tier or routine produces it ("Environment switches").
+// result, only which tier or routine produces it.
 struct ecal_switches {
     // which tier / routine produces a result (parity tests run the tiers against each other)
     bool slice_no_pixel = false, dbscan_no_pixel = false, dbscan_generic_disc = false, extract_no_inline_ties = false;

@@ -5,7 +5,7 @@
 // findCirclesGrid call (event_camera_calib/src/CirclesEventFrame.cpp:89-312, fitCircle == 0 path
 // :283-311) and the radius gate of :16-33.  One workgroup owns one window.
 //
-// Order conventions: a cluster's members are processed in ascending pid; its
+// Order conventions (design/04_slicing_extraction.md): a cluster's members are processed in ascending pid; its
 // representative is the member of rank size/2 in the order (norm, pid) — the reference takes
 // std::nth_element by norm over its BFS member order, which picks the same pixel unless two members
 // tie in norm at that rank; 1-NN ties go to the smallest cluster index.

@@ -1,5 +1,5 @@
 """Numpy restatement of the *data-parallel* DBSCAN formulation the HIP kernel implements
-(DESIGN.md §DBSCAN): kd-cell bounds lo/hi from the insertion-order tree, the directed
+(design/03_dbscan.md): kd-cell bounds lo/hi from the insertion-order tree, the directed
 neighbour relation "in ball and not pruned", and min-seed reachability labels.
 
 Test infrastructure only: it lets the CPU suite prove that the closed form is equivalent to the
