@@ -782,6 +782,29 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
                          tree_out, tree_flag, tree_epoch);
 }
 
+// The LATENCY form of the two passes (ecal_ctx::latency_pass: few windows hold work — the tail of the keyframe search, where a
+// pass's time is the SUM of its launches' single-workgroup latencies): workgroup b takes segment b through the pass its size asks
+// for, so a segment of 769 .. CAP2 points does not wait for the first pass's launch to drain before the second one starts.  Same
+// device code per segment, same results; what the first-pass code cannot take for another reason still goes to ITS list (the
+// second pass behind this launch finds it), what the second-pass code cannot take to todo2.
+template <int E2I, int CAP, int CAP2>
+__global__ __launch_bounds__(PX_T) void dbscan_pixel_both_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
+                                                                 const uint32_t *__restrict__ seg_cnt, const PxGeom geom, uint32_t minpts,
+                                                                 int32_t *__restrict__ labels, uint32_t *__restrict__ n_clusters,
+                                                                 uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
+                                                                 uint32_t *__restrict__ todo2, uint32_t *__restrict__ todo2_count,
+                                                                 const uint32_t *__restrict__ xy16, const uint32_t *__restrict__ seg_fmt,
+                                                                 uint32_t *__restrict__ tree_out, uint32_t *__restrict__ tree_flag,
+                                                                 uint32_t tree_epoch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
+    if (seg_cnt[blockIdx.x] <= (uint32_t) CAP)
+        px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt,
+                             tree_out, tree_flag, tree_epoch);
+    else
+        px_segment<E2I, CAP2>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo2, todo2_count, 0, 0, xy16,
+                              seg_fmt, tree_out, tree_flag, tree_epoch);
+}
+
 // second pass (CAP = PX_CAP2): the workgroups share the list of segments the first pass left over
 // (in_list[0 .. *in_count)); what this pass cannot take either goes to todo / todo_count for the general tiers
 template <int E2I, int CAP>

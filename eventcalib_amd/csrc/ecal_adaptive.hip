@@ -872,6 +872,7 @@ static int detect_keyframes_entry(ecal_ctx *ctx, const uint8_t *d_events, uint64
                                          kf_features, n_keyframes, passes, windows, ho);
     ctx->tail_mode = was;
     ctx->tail_no_lean = was_no_lean;
+    ctx->latency_pass = false;
     return rc;
 }
 static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
@@ -1096,6 +1097,8 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
             n_passes++;
             seq++;
             AD_TRY(take_ext(0, seq));
+            // (few pieces still at work — known two passes late —: the stages' latency forms, ecal_ctx::latency_pass)
+            ctx->latency_pass = last_active <= AD_GRID_LATENCY_PIECES;
             AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sr, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                           (uint32_t *) B[4].ptr, st));
             AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sr, 0,

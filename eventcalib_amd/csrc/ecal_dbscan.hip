@@ -255,6 +255,8 @@ static int set_attrs(ecal_ctx *ctx) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixelLayout<PX_CAP2>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_list_kernel<16, PX_CAP2>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixelLayout<PX_CAP2>::bytes));
+    ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_pixel_both_kernel<16, PX_CAP, PX_CAP2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixelLayout<PX_CAP2>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP1, CAP1 / 4>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) TierLayout<CAP1>::bytes));
     ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&dbscan_lds_kernel<CAP2, CAP2 / 4>),
@@ -351,6 +353,11 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         cnt_b = second_pass ? cnt2 : nullptr;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !ctx->sw.dbscan_generic_disc) {
+            if (ctx->latency_pass && second_pass)   // (few windows at work: a segment goes through the pass its size asks for in ONE launch)
+                hipLaunchKernelGGL((dbscan_pixel_both_kernel<16, PX_CAP, PX_CAP2>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st,
+                                   d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, list2, cnt2, xy16, sfmt, tree,
+                                   tflag, ctx->px_tree_epoch);
+            else
             hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes, st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
                                ctx->px_tree_epoch);

@@ -18,6 +18,8 @@
 
 namespace ecal {
 
+constexpr size_t DET_LDS_BOTH = DET_LDS_BYTES + DET_TIE_INV_BYTES > DET_LDS_BYTES2 ? DET_LDS_BYTES + DET_TIE_INV_BYTES : DET_LDS_BYTES2;
+
 
 // FIT = Params::fitCircle: the algebraic-fit pairing keeps two 3x4 systems in registers; compiled apart so that the default
 // path (fitCircle == 0) stays below 72 VGPRs.  First pass: workgroup b takes window b.
@@ -37,6 +39,38 @@ __global__ __launch_bounds__(DET_T) void extract_kernel(
     extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, MODE == 1, MODE == 2>(
         smem, red, nk_sh, blockIdx.x, xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
         members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order, tie_list, tie_count, tie_mark);
+}
+
+// The LATENCY form of the two staged passes (ecal_ctx::latency_pass: few windows hold work): workgroup b takes window b through the
+// pass its size asks for — the first pass's staging (<= DET_LDS_PTS points, <= DET_LDS_MAXC clusters per polarity) or, for a window
+// the first pass would LIST for the second, the second pass's (<= DET_LDS_PTS2, <= DET_LDS_MAXC2) right away; anything else is the
+// first-pass code's (its global path).  Same device code per window, same results.
+template <bool FIT, int MODE>
+__global__ __launch_bounds__(DET_T) void extract_both_kernel(
+    const double *__restrict__ xy, const uint32_t *__restrict__ seg_off, const uint32_t *__restrict__ seg_cnt,
+    const int32_t *__restrict__ labels, const uint32_t *__restrict__ n_clusters, DetectParams prm,
+    uint32_t *__restrict__ win_info, uint32_t *__restrict__ cand_pair, double *__restrict__ cand_xyr,
+    int32_t *__restrict__ kept_labels, uint32_t *__restrict__ rep, uint32_t *__restrict__ members,
+    uint32_t *__restrict__ koff, uint32_t *__restrict__ ksize, uint32_t *__restrict__ sorted,
+    double *__restrict__ norms, uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count, const int32_t *__restrict__ order,
+    uint32_t *__restrict__ tie_list, uint32_t *__restrict__ tie_count, int32_t *__restrict__ tie_mark) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long red[DET_T / 64];
+    __shared__ uint32_t nk_sh[4];
+    const uint32_t s = blockIdx.x;
+    const uint32_t oP = seg_off[2 * s], oN = seg_off[2 * s + 1], nP = seg_cnt[2 * s], nN = seg_cnt[2 * s + 1];
+    const uint32_t cP = n_clusters[2 * s], cN = n_clusters[2 * s + 1], n_all = nP + nN;
+    // (extract_one's own test: what the first pass stages, and what it would hand to the second)
+    const bool first_stages = oN == oP + nP && n_all <= DET_LDS_PTS && cP <= DET_LDS_MAXC && cN <= DET_LDS_MAXC;
+    const bool second_stages = oN == oP + nP && n_all <= DET_LDS_PTS2 && cP <= DET_LDS_MAXC2 && cN <= DET_LDS_MAXC2;
+    if (first_stages || !second_stages || nP == 0 || nN == 0)
+        extract_one<FIT, DET_LDS_PTS, DET_LDS_MAXC, true, false, MODE == 1, MODE == 2>(
+            smem, red, nk_sh, s, xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
+            members, koff, ksize, sorted, norms, todo, todo_count, nullptr, order, tie_list, tie_count, tie_mark);
+    else
+        extract_one<FIT, DET_LDS_PTS2, DET_LDS_MAXC2, false, false, MODE == 1, MODE == 2>(
+            smem, red, nk_sh, s, xy, seg_off, seg_cnt, labels, n_clusters, prm, win_info, cand_pair, cand_xyr, kept_labels, rep,
+            members, koff, ksize, sorted, norms, nullptr, nullptr, nullptr, order, tie_list, tie_count, tie_mark);
 }
 
 // the first pass over a list of windows (the exact extraction's tied windows: ecal_extract_batch_exact_dev)
@@ -229,6 +263,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     ECAL_DET_ATTR((K<true, 2>), BYTES)
         ECAL_DET_ATTR3(extract_kernel, DET_LDS_BYTES + DET_TIE_INV_BYTES);
         ECAL_DET_ATTR3(extract_list_kernel, DET_LDS_BYTES2);
+        ECAL_DET_ATTR((extract_both_kernel<false, 2>), DET_LDS_BOTH);
         ECAL_DET_ATTR((extract_first_list_kernel<false, 1>), DET_LDS_BYTES);
         ECAL_DET_ATTR((extract_first_list_kernel<true, 1>), DET_LDS_BYTES);
 #undef ECAL_DET_ATTR3
@@ -272,7 +307,12 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
     } else if (mode == 1) {
         if (fit) ECAL_DET_FIRST(true, 1); else ECAL_DET_FIRST(false, 1);
     } else if (mode == 2) {
-        if (fit) ECAL_DET_FIRST(true, 2); else ECAL_DET_FIRST(false, 2);
+        if (fit) ECAL_DET_FIRST(true, 2);
+        else if (ctx->latency_pass)   // (few windows at work: a window goes through the pass its size asks for in ONE launch)
+            hipLaunchKernelGGL((extract_both_kernel<false, 2>), dim3(S), dim3(DET_T), DET_LDS_BOTH, st, d_xy, d_seg_off, d_seg_cnt, d_labels,
+                               d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no, list, cnt,
+                               d_order, d_tie_list, d_tie_count, d_tie_mark);
+        else ECAL_DET_FIRST(false, 2);
     } else {
         if (fit) ECAL_DET_FIRST(true, 0); else ECAL_DET_FIRST(false, 0);
     }

@@ -618,6 +618,29 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
                                  todo, todo_count, nullptr, xy16, seg_fmt);
 }
 
+// The LATENCY form of the two hash passes in the reference order (ecal_ctx::latency_pass: few windows hold work, a pass's time is
+// the sum of its launches' single-workgroup latencies): workgroup b takes window b through the pass its event count asks for —
+// a window of 2048 .. 4095 events does not wait for the first pass's launch to drain.  Same device code per window, same results;
+// a window the first-pass code cannot take for another reason (more than 1109 keys of a polarity, a non-pixel coordinate) still
+// goes to ITS list, which the second pass behind this launch works off.
+__global__ __launch_bounds__(PXH_T) void slice_hash_ref_both_kernel(const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo,
+                                                                    const uint32_t *__restrict__ win_hi, const uint32_t *__restrict__ win_base,
+                                                                    uint32_t cap_points, double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
+                                                                    uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
+                                                                    uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
+                                                                    uint32_t *__restrict__ todo2, uint32_t *__restrict__ todo2_count,
+                                                                    const uint2 *__restrict__ bucket_tab, uint32_t *__restrict__ xy16,
+                                                                    uint32_t *__restrict__ seg_fmt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t s = blockIdx.x;
+    if (win_hi[s] - win_lo[s] <= PixHash<11>::CAP)
+        slice_hash_window<11, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo,
+                                    todo_count, bucket_tab, xy16, seg_fmt);
+    else
+        slice_hash_window<12, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo2,
+                                    todo2_count, bucket_tab, xy16, seg_fmt);
+}
+
 // second pass: the workgroups share the list the first pass left (in_list[0 .. *in_count)); windows of up to 4095 events
 template <bool REFORDER>
 #ifndef ECAL_SL2_WAVES
@@ -889,6 +912,8 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixHash<12>::bytes));
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_list_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) H12));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_ref_both_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) H12));
         ctx->slice_attrs_set = true;
     }
     ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
@@ -924,6 +949,11 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
         cnt_a = cnt;
         if (reforder) {
             if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
+            if (ctx->latency_pass && !lean)   // (few windows at work: a window goes through the pass its size asks for in ONE launch)
+                hipLaunchKernelGGL(slice_hash_ref_both_kernel, dim3(S), dim3(PXH_T), H12, st, d_events, d_win_lo, d_win_hi, d_win_base,
+                                   cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, list2, cnt2,
+                                   (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
+            else
             hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
                                d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt,
                                (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
