@@ -136,6 +136,15 @@ constexpr uint32_t AD_DEPTH_MAX = 48;
 // gate, seconds at 1270 / 4096 pieces: never 0.137 / 0.132; 32: 0.133 / 0.133; 64: 0.133 / 0.135; 128: 0.132 / 0.130; 256: 0.131 /
 // 0.122; 512: 0.132 / 0.128
 constexpr uint32_t AD_GRID_LATENCY_PIECES = 256;
+#ifndef ECAL_AD_STAGE_LATENCY_PIECES
+#define ECAL_AD_STAGE_LATENCY_PIECES 2048
+#endif
+// Pieces at work up to which the stages take their latency forms (ecal_ctx::latency_pass): one launch per stage takes a window through
+// the tier its size asks for — no to-do list, no second pass.  Measured at 1270 pieces (shared-map search, 3 runs each, s):
+// 96: 0.112 - 0.113 | 256: 0.109 - 0.110 | 640: 0.108 | 1100: 0.107 | always: 0.105; at 4096 pieces 0.116 - 0.137 for every value
+// (run-to-run noise is larger than the differences) — the forms stay off above 2048 windows, where the first pass's small blocks fill
+// the chip and the occupancy of the wide forms starts to cost.
+constexpr uint32_t AD_STAGE_LATENCY_PIECES = ECAL_AD_STAGE_LATENCY_PIECES;
 static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
     if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_SHAPE depth: debug / measurement switch; the result does not depend on it)
     return pieces <= 2048u ? 6u : (pieces <= 8192u ? 5u : (pieces <= 32768u ? 3u : 1u));   // (many pieces fill the GPU by themselves)
@@ -1098,7 +1107,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
             seq++;
             AD_TRY(take_ext(0, seq));
             // (few pieces still at work — known two passes late —: the stages' latency forms, ecal_ctx::latency_pass)
-            ctx->latency_pass = last_active <= AD_GRID_LATENCY_PIECES;
+            ctx->latency_pass = last_active <= AD_STAGE_LATENCY_PIECES;
             AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sr, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                           (uint32_t *) B[4].ptr, st));
             AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sr, 0,
