@@ -145,9 +145,15 @@ constexpr uint32_t AD_GRID_LATENCY_PIECES = 256;
 // (run-to-run noise is larger than the differences) — the forms stay off above 2048 windows, where the first pass's small blocks fill
 // the chip and the occupancy of the wide forms starts to cost.
 constexpr uint32_t AD_STAGE_LATENCY_PIECES = ECAL_AD_STAGE_LATENCY_PIECES;
+// the search's tail: with at most AD_TAIL_PIECES pieces at work a pass is launched over AD_TAIL_SLOTS window slots (run_passes)
+constexpr uint32_t AD_TAIL_PIECES = 64, AD_TAIL_SLOTS = 4096;
 static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
     if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_SHAPE depth: debug / measurement switch; the result does not depend on it)
-    return pieces <= 2048u ? 6u : (pieces <= 8192u ? 5u : (pieces <= 32768u ? 3u : 1u));   // (many pieces fill the GPU by themselves)
+    // (many pieces fill the GPU by themselves.  Round 6, with the passes' fixed cost down: a pass of 8 - 16 thousand slots is the
+    // optimum — shared-map search, s, at slots per piece 1 / 2 / 3 / 4 / 5 / 6: 2048 pieces - / - / 0.119-0.129 / 0.116-0.122 / 0.123-0.127 /
+    // 0.124-0.133; 4096 pieces 0.103 / 0.099 / 0.120 / - / 0.114-0.127 / -; 8192 pieces 0.086-0.096 / 0.065 / 0.086-0.092 / 0.090-0.097 /
+    // 0.094-0.098 / -; 16384 pieces 0.152 / 0.168-0.179 / 0.165; 1270 pieces 5 / 6 / 7: 0.107 / 0.105 / 0.104 — tools/depth_sweep.sh)
+    return pieces <= 1536u ? 6u : (pieces <= 2560u ? 4u : (pieces <= 8192u ? 2u : 1u));
 }
 static uint32_t adaptive_depth_max(int forced = 0) {
     if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_SHAPE depth_max: debug / measurement switch)
@@ -174,6 +180,7 @@ struct ChainTree {
     __device__ __forceinline__ uint32_t off2() const { return len0 + c1 * len1; }
     __device__ __forceinline__ uint32_t off3() const { return len0 + c1 * len1 + c1 * c2 * len2; }
     __device__ __forceinline__ uint32_t slots() const { return len0 + c1 * (len1 + c2 * (len2 + c3 * len3)); }
+    __device__ __forceinline__ uint32_t chains() const { return 1u + c1 * (1u + c2 * (1u + c3)); }
     __device__ __forceinline__ uint32_t longest_walk() const { return len0 + (c1 ? len1 : 0u) + (c2 ? len2 : 0u) + (c3 ? len3 : 0u); }
     // the two words a piece's layout is kept in (AdaptiveArrays::depth, ::lay)
     __device__ __forceinline__ uint32_t word0() const { return len0 | (c1 << 8) | (a1 << 16) | (len1 << 24); }   // (len0 <= 255, c1 <= 255)
@@ -249,10 +256,62 @@ __device__ __forceinline__ void write_tree_level(const ChainTree &y, uint32_t id
     }
 }
 
+// ONE chain of the tree — number c in the order level 0, the chains of level 1, of level 2, of level 3 — written by itself: its first
+// window follows from the piece's current one by the walk down to it (the likely verdicts along each chain above, an acceptance
+// at the position it hangs below: the very sequence of next_window calls write_tree_level makes on its way there, so the same
+// doubles), then its windows as write_tree_level writes them.
+__device__ __forceinline__ void write_tree_chain(const ChainTree &y, uint32_t c, double f, double s2, double hi, double mts, double *t0, double *t1) {
+    uint32_t lv = 0, idx = 0;
+    if (c >= 1u) {
+        if (c < 1u + y.c1) lv = 1u, idx = c - 1u;
+        else if (c < 1u + y.c1 + y.c1 * y.c2) lv = 2u, idx = c - 1u - y.c1;
+        else lv = 3u, idx = c - 1u - y.c1 - y.c1 * y.c2;
+    }
+    // positions of the descents: in the main chain, in the level-1 chain, in the level-2 chain
+    uint32_t p[3] = {0u, 0u, 0u};
+    if (lv == 1u) p[0] = y.a1 + idx;
+    else if (lv == 2u) p[0] = y.a1 + idx / y.c2, p[1] = y.a2 + idx % y.c2;
+    else if (lv == 3u) p[0] = y.a1 + (idx / y.c3) / y.c2, p[1] = y.a2 + (idx / y.c3) % y.c2, p[2] = y.a3 + idx % y.c3;
+    bool act = true;
+    for (uint32_t m = 0; m < lv; m++) {
+        for (uint32_t q = 0; q < p[m]; q++)
+            if (act) {
+                double nf, ns;
+                next_window(likely_outcome(f, s2, mts), f, s2, mts, nf, ns);
+                f = nf;
+                s2 = ns;
+                act = ns < hi;
+            }
+        if (act) {
+            double af, as;
+            next_window(0, f, s2, mts, af, as);
+            f = af;
+            s2 = as;
+            act = as < hi;
+        }
+    }
+    const uint32_t len = lv == 0u ? y.len0 : (lv == 1u ? y.len1 : (lv == 2u ? y.len2 : y.len3));
+    const uint32_t off = lv == 0u ? 0u : (lv == 1u ? y.off1() : (lv == 2u ? y.off2() : y.off3()));
+    double *c0 = t0 + off + (size_t) idx * len, *c1 = t1 + off + (size_t) idx * len;
+    for (uint32_t q = 0; q < len; q++) {
+        c0[q] = act ? f : INFINITY;
+        c1[q] = act ? s2 : -INFINITY;
+        if (act) {
+            double nf, ns;
+            next_window(likely_outcome(f, s2, mts), f, s2, mts, nf, ns);
+            f = nf;
+            s2 = ns;
+            act = ns < hi;
+        }
+    }
+}
+
 // The window slots of the next pass.  The pieces' chains differ a lot in length (the benchmark's longest has 559 windows, the
 // average 83), so most passes see few pieces still at work: the B slots of a pass are dealt out evenly among THOSE, up to
 // d_max windows of chain each — the fewer pieces remain, the further each one looks ahead.  One workgroup.
+__device__ void restart_piece(uint32_t k, uint32_t P, uint32_t rows, double mts, const AdaptiveArrays &st);
 constexpr int AD_ALLOC_T = 1024;
+constexpr int AD_ALLOC_TAB = 2 * AD_ALLOC_T;   // pieces at work up to which adaptive_alloc_kernel writes the slots a chain per thread
 // live form, few pieces at work: a main chain and side chains (write_chain): first main-chain window with one, how many, their
 // length, the main chain's length.  Measured (ECAL_ADAPTIVE_SHAPE side, tools/side_sweep.sh): 24 side chains of 12 behind a main chain
 // of 24 take the search from 108 to 79 passes at 1270 pieces, but the passes of the tail grow by what they save — 0.151 against
@@ -274,12 +333,42 @@ constexpr uint32_t AD_TREE_DEFAULT = 8u | (8u << 8) | (5u << 16) | (4u << 20) | 
 __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, uint32_t B, uint32_t deal, uint32_t d_max, AdaptiveArrays st,
                                                                     double mts, double *t0, double *t1, uint32_t *report, uint32_t seq, uint32_t live_base, uint32_t live_floor,
                                                                     uint32_t side /* from | count << 8 | length << 16 | main chain << 24 */,
-                                                                    uint32_t tree /* tree_for's word; 0: no trees */) {
+                                                                    uint32_t tree /* tree_for's word; 0: no trees */,
+                                                                    uint32_t restart_rows /* > 0: restart_piece first (the shared-map gate's re-runs; the pattern's rows) */) {
     __shared__ uint32_t red[AD_ALLOC_T / 64 + 1];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t per = (P + AD_ALLOC_T - 1) / AD_ALLOC_T, k0 = tid * per;
+    // (the re-runs the verification asked for start here: a launch of its own cost 6 us of every pass)
+    if (restart_rows)
+        for (uint32_t k = k0; k < k0 + per && k < P; k++) restart_piece(k, P, restart_rows, mts, st);
+    // this thread's pieces' words, read once (up to AD_ALLOC_REG pieces a thread — 4096 pieces — on registers; beyond: from memory
+    // at every use, as it used to be for all: a chain of dependent reads through the three sums below)
+    constexpr uint32_t AD_ALLOC_REG = 4;
+    uint32_t r_act[AD_ALLOC_REG], r_want[AD_ALLOC_REG];
+    const bool regs = per <= AD_ALLOC_REG;
+#pragma unroll
+    for (uint32_t i = 0; i < AD_ALLOC_REG; i++) {
+        const uint32_t k = k0 + i;
+        const bool in = regs && i < per && k < P;
+        r_act[i] = in ? st.active[k] : 0u;
+        r_want[i] = in ? st.want[k] : 0u;
+    }
+    auto active_of = [&](uint32_t k) -> uint32_t {
+        if (!regs) return st.active[k];
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < AD_ALLOC_REG; i++) v = k - k0 == i ? r_act[i] : v;
+        return v;
+    };
+    auto want_of = [&](uint32_t k) -> uint32_t {
+        if (!regs) return st.want[k];
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < AD_ALLOC_REG; i++) v = k - k0 == i ? r_want[i] : v;
+        return v;
+    };
     uint32_t mine = 0;
-    for (uint32_t k = k0; k < k0 + per && k < P; k++) mine += st.active[k] ? 1u : 0u;
+    for (uint32_t k = k0; k < k0 + per && k < P; k++) mine += active_of(k) ? 1u : 0u;
     uint32_t inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -288,9 +377,10 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
     }
     if (lane == 63) red[wave] = inc;
     __syncthreads();
-    uint32_t n_act = 0;
+    uint32_t n_act = 0, j0 = inc - mine;   // j0: active pieces before this thread's
     for (uint32_t w = 0; w < AD_ALLOC_T / 64; w++) {
         n_act += red[w];
+        if (w < wave) j0 += red[w];
     }
     // `deal` of the B slots are dealt out (a run of few pieces — a verification round of the shared-map gate — does not get
     // the whole pass: beyond what fills the GPU a pass's time grows with its windows, and most of a long look-ahead is thrown away)
@@ -307,14 +397,14 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
         // (tree_for) as far as the share goes; one whose chains hold — a stretch without the pattern — asks for a chain as before
         const uint32_t tree_max = tree ? tree_slots_max(tree) : 0u;
         auto wanted = [&](uint32_t k) -> uint32_t {
-            uint32_t w = st.want[k] > live_base ? st.want[k] : live_base;
+            uint32_t w = want_of(k) > live_base ? want_of(k) : live_base;
             w = w > share ? w : share;
-            if (tree && st.want[k] == 0u && share >= (tree & 0xFFu) + ((tree >> 8) & 0xFFu)) return w < tree_max ? w : tree_max;
+            if (tree && want_of(k) == 0u && share >= (tree & 0xFFu) + ((tree >> 8) & 0xFFu)) return w < tree_max ? w : tree_max;
             const uint32_t cap = SC && share >= SM + 2u * SL ? SM + SC * SL : d_max;
             return w < cap ? w : cap;
         };
         uint32_t mw = 0;
-        for (uint32_t k = k0; k < k0 + per && k < P; k++) mw += st.active[k] ? wanted(k) : 0u;
+        for (uint32_t k = k0; k < k0 + per && k < P; k++) mw += active_of(k) ? wanted(k) : 0u;
         uint32_t tw = mw;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) tw += __shfl_xor(tw, d, 64);
@@ -330,7 +420,7 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
             return 1u + (uint32_t) ((unsigned long long) (w - 1u) * (B - n_act) / (total_want - n_act));
         };
         uint32_t md = 0;
-        for (uint32_t k = k0; k < k0 + per && k < P; k++) md += st.active[k] ? depth_of(k) : 0u;
+        for (uint32_t k = k0; k < k0 + per && k < P; k++) md += active_of(k) ? depth_of(k) : 0u;
         uint32_t incd = md;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -345,12 +435,19 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
             if (w < wave) pred += red2[w];
             total_depth += red2[w];
         }
+        // The windows of the slots are written by ALL threads, a chain of a piece's tree each (a tree has up to 86 chains, 688
+        // slots: a thread per PIECE walked them one after the other — 40 to 90 us of every pass of the search's tail, where few
+        // pieces hold deep trees).  The pieces' layouts go through LDS for that; more pieces at work than the table holds (their
+        // chains are short then): a thread per piece as before.
+        __shared__ uint32_t pk_k[AD_ALLOC_TAB], pk_at[AD_ALLOC_TAB], pk_slots[AD_ALLOC_TAB], pk_w0[AD_ALLOC_TAB], pk_w1[AD_ALLOC_TAB], pk_off[AD_ALLOC_TAB + 1];
+        const bool tabled = n_act <= AD_ALLOC_TAB;
         uint32_t at = pred + incd - md;   // slots before this thread's pieces
+        uint32_t j = j0;
         for (uint32_t k = k0; k < k0 + per && k < P; k++) {
-            if (st.active[k]) {
+            if (active_of(k)) {
                 const uint32_t slots = depth_of(k);
                 ChainTree y = {};
-                if (tree && st.want[k] == 0u && share >= (tree & 0xFFu) + ((tree >> 8) & 0xFFu)) y = tree_for(slots, tree);
+                if (tree && want_of(k) == 0u && share >= (tree & 0xFFu) + ((tree >> 8) & 0xFFu)) y = tree_for(slots, tree);
                 if (y.c1 == 0u) {   // a chain, with round 4's side chains when there are slots for them
                     y = ChainTree{};
                     y.len0 = slots < d_max ? slots : d_max;
@@ -365,10 +462,19 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
                 st.slot0[k] = at;
                 st.depth[k] = y.word0();
                 st.lay[k] = y.word1();
-                write_tree_level<0>(y, 0u, st.first[k], st.second[k], true, st.bound_hi[k], mts, t0 + at, t1 + at);
-                for (uint32_t q = y.slots(); q < slots; q++) {   // (the remainder of its slots)
-                    t0[at + q] = INFINITY;
-                    t1[at + q] = -INFINITY;
+                if (tabled) {
+                    pk_k[j] = k;
+                    pk_at[j] = at;
+                    pk_slots[j] = slots;
+                    pk_w0[j] = y.word0();
+                    pk_w1[j] = y.word1();
+                    j++;
+                } else {
+                    write_tree_level<0>(y, 0u, st.first[k], st.second[k], true, st.bound_hi[k], mts, t0 + at, t1 + at);
+                    for (uint32_t q = y.slots(); q < slots; q++) {   // (the remainder of its slots)
+                        t0[at + q] = INFINITY;
+                        t1[at + q] = -INFINITY;
+                    }
                 }
                 at += slots;
             } else {
@@ -376,13 +482,58 @@ __global__ __launch_bounds__(AD_ALLOC_T) void adaptive_alloc_kernel(uint32_t P, 
                 st.lay[k] = 0;
             }
         }
+        if (tabled) {
+            __syncthreads();
+            // chains before table entry e: entries 2 tid, 2 tid + 1 by thread tid, then the scan over the threads
+            static_assert(AD_ALLOC_TAB == 2 * AD_ALLOC_T, "two table entries per thread");
+            uint32_t c2[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const uint32_t e = 2u * tid + (uint32_t) i;
+                c2[i] = e < n_act ? ChainTree::unpack(pk_w0[e], pk_w1[e]).chains() : 0u;
+            }
+            uint32_t incc = c2[0] + c2[1];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incc, d, 64);
+                if ((int) lane >= d) incc += o;
+            }
+            if (lane == 63) red2[wave] = incc;
+            __syncthreads();
+            uint32_t before = incc - (c2[0] + c2[1]), n_tasks = 0;
+            for (uint32_t w = 0; w < AD_ALLOC_T / 64; w++) {
+                if (w < wave) before += red2[w];
+                n_tasks += red2[w];
+            }
+            pk_off[2u * tid] = before;
+            pk_off[2u * tid + 1u] = before + c2[0];
+            if (tid == 0) pk_off[AD_ALLOC_TAB] = n_tasks;
+            __syncthreads();
+            for (uint32_t t = tid; t < n_tasks; t += AD_ALLOC_T) {
+                uint32_t lo = 0, hi_e = n_act;   // the entry whose chains hold task t: pk_off[e] <= t < pk_off[e + 1]
+                while (hi_e - lo > 1u) {
+                    const uint32_t mid = (lo + hi_e) / 2u;
+                    if (pk_off[mid] <= t) lo = mid;
+                    else hi_e = mid;
+                }
+                const uint32_t e = lo, k = pk_k[e], pat = pk_at[e];
+                const ChainTree y = ChainTree::unpack(pk_w0[e], pk_w1[e]);
+                write_tree_chain(y, t - pk_off[e], st.first[k], st.second[k], st.bound_hi[k], mts, t0 + pat, t1 + pat);
+                if (t == pk_off[e])
+                    for (uint32_t q = y.slots(); q < pk_slots[e]; q++) {   // (the remainder of the piece's slots)
+                        t0[pat + q] = INFINITY;
+                        t1[pat + q] = -INFINITY;
+                    }
+            }
+        }
         for (uint32_t i = total_depth + tid; i < B; i += AD_ALLOC_T) {   // slots nobody got
             t0[i] = INFINITY;
             t1[i] = -INFINITY;
         }
     }
+    __syncthreads();   // (the restarts' additions to the counter)
     if (report && tid == 0) {
-        const uint32_t active = st.counters[0];
+        const uint32_t active = __hip_atomic_load(&st.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         st.counters[0] = 0;
         __hip_atomic_store(&report[0], active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&report[1], (uint32_t) *st.windows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (windows the rule has been applied to so far: the trace's)
@@ -432,10 +583,6 @@ __device__ void restart_piece(uint32_t k, uint32_t P, uint32_t rows, double mts,
     st.gen[k]++;   // the keyframe records of the earlier runs of this piece are dead
     piece_start(k, P, rows, mts, st);
     if (st.active[k]) atomicAdd(&st.counters[0], 1u);   // (the live form: the pass reports pieces with windows still to go)
-}
-__global__ void adaptive_restart_kernel(uint32_t P, uint32_t rows, double mts, AdaptiveArrays st) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < P) restart_piece(k, P, rows, mts, st);
 }
 
 // The verification of adaptive_verify_kernel after EVERY pass instead of after every set of runs (shared-map mode, the default
@@ -568,7 +715,7 @@ __global__ __launch_bounds__(64) void adaptive_step_kernel(uint32_t P, uint32_t 
                                      uint32_t *__restrict__ kf_gen, double *__restrict__ t0,
                                      double *__restrict__ t1, const int *__restrict__ overflow, const double *__restrict__ dirs) {
     const uint32_t k = blockIdx.x, lane = threadIdx.x;
-    if (k == 0 && lane == 0 && *overflow) st.counters[3] = 1;  // the slicer clears its flag at every call: keep it until the host looks
+    if (k == 0 && lane == 0 && *overflow) st.counters[3] = 1;  // keep it until the host looks
     if (k >= P || !st.active[k]) return;
     const uint32_t M = rows * cols;
     const double ln = 3 * mts;
@@ -882,6 +1029,7 @@ static int detect_keyframes_entry(ecal_ctx *ctx, const uint8_t *d_events, uint64
     ctx->tail_mode = was;
     ctx->tail_no_lean = was_no_lean;
     ctx->latency_pass = false;
+    ctx->overflow_sticky = nullptr;
     return rc;
 }
 static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_events, const ecal_adaptive_params *ap,
@@ -988,6 +1136,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     double *d_t0 = (double *) B[0].ptr, *d_t1 = d_t0 + S;
     hipLaunchKernelGGL(adaptive_init_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
     ECAL_HIP_TRY(ctx, hipMemsetAsync(B[16].ptr, 0, sizeof(int), st));
+    ctx->overflow_sticky = (const int *) B[16].ptr;   // (wiped here, once: the passes' slicing calls leave it alone)
     if (a.ext) ECAL_HIP_TRY(ctx, hipMemsetAsync((void *) a.ext, 0, 8 * (2 + 2 * (size_t) AD_MAX_ROWS), st));   // (the frame from before: not known yet)
     uint32_t *h = reinterpret_cast<uint32_t *>(ctx->pass_pinned);  // [0..15] counters
     // The host runs `ahead` passes ahead of the device's counters: before it enqueues pass p it waits for the counters that pass
@@ -1072,8 +1221,12 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
         // tens of microseconds per kernel, and a round is a chain of ~10 passes of ~25 kernels)
         const uint32_t Sr = deal < S ? deal : S;
         hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                           (uint32_t *) nullptr, 0u, D, live_floor, live_side_eff, live_tree);
+                           (uint32_t *) nullptr, 0u, D, live_floor, live_side_eff, live_tree, 0u);
         const uint32_t seq0 = seq;   // this set's pass `pass` reports seq0 + pass + 1 into slot (seq0 + pass) % 8
+        // the slots of the pass being enqueued: all of them, or AD_TAIL_SLOTS in the search's tail — a launch over 7620 window slots
+        // of which a few hundred hold a window still pays for the empty workgroups (~1 us per thousand and kernel), and the few
+        // pieces at work there cannot ask for more slots than that (adaptive_alloc_kernel: live_floor shared out, trees of <= 688)
+        uint32_t Sw = Sr;
         for (uint32_t pass = 0; pass < max_levels; pass++) {
             if (pass >= ahead) {
                 const uint32_t want = seq0 + pass - ahead + 1u, q = (want - 1u) % 8u;
@@ -1108,29 +1261,29 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
             AD_TRY(take_ext(0, seq));
             // (few pieces still at work — known two passes late —: the stages' latency forms, ecal_ctx::latency_pass)
             ctx->latency_pass = last_active <= AD_STAGE_LATENCY_PIECES;
-            AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sr, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
+            AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sw, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                           (uint32_t *) B[4].ptr, st));
-            AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sr, 0,
+            AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sw, 0,
                                          cap_points, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr,
                                          (int32_t *) B[8].ptr, (int *) B[16].ptr, st));
-            AD_TRY(ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * Sr, cap_points, 0,
+            AD_TRY(ecal_dbscan_batch_dev(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, 2 * Sw, cap_points, 0,
                                          prm->dbscan_eps, prm->dbscan_min_samples, (int32_t *) B[9].ptr, (uint32_t *) B[10].ptr, st));
             AD_TRY(ecal_extract_for_ctx(ctx, (double *) B[5].ptr, (uint32_t *) B[6].ptr, (uint32_t *) B[7].ptr, (int32_t *) B[9].ptr,
-                                        (uint32_t *) B[10].ptr, Sr, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
+                                        (uint32_t *) B[10].ptr, Sw, cap_points, prm->dbscan_eps, prm->cluster_min_sample, prm->need_clusters,
                                         prm->circle_radius_threshold, prm->fit_circle, prm->knn_num, (uint32_t *) B[13].ptr,
                                         (uint32_t *) B[14].ptr, (double *) B[15].ptr, (int32_t *) B[11].ptr, (uint32_t *) B[12].ptr, st));
             // (few pieces still at work — known two passes late —: the grid finder's latency form, a wave per start, ecal_grid.hip)
-            ctx->grid_hint_windows = last_active <= AD_GRID_LATENCY_PIECES ? 1u : Sr;
+            ctx->grid_hint_windows = last_active <= AD_GRID_LATENCY_PIECES ? 1u : Sw;
             // (the rows' line fits of the windows that hold a grid: by the grid finder's own workgroups, under the launch's slowest
             // failing window; patterns of more than 64 rows: by adaptive_dir_kernel behind it — same values)
             const bool dirs_in_grid = prm->rows <= 64;
-            rc = ecal_grid_order_dirs_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sr, prm->rows, prm->cols,
+            rc = ecal_grid_order_dirs_dev(ctx, (uint32_t *) B[13].ptr, (uint32_t *) B[6].ptr, (double *) B[15].ptr, Sw, prm->rows, prm->cols,
                                           (int32_t *) ctx->host_grid_order.ptr, (uint32_t *) ctx->host_grid_found.ptr,
                                           dirs_in_grid ? (double *) ctx->adaptive_dirs.ptr : nullptr, st);
             ctx->grid_hint_windows = 0;
             AD_TRY(rc);
             if (!dirs_in_grid)
-                hipLaunchKernelGGL(adaptive_dir_kernel, dim3(Sr), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
+                hipLaunchKernelGGL(adaptive_dir_kernel, dim3(Sw), dim3(64), 0, st, prm->rows, prm->cols, (const uint32_t *) B[13].ptr,
                                    (const uint32_t *) B[6].ptr, (const double *) B[15].ptr, (const int32_t *) ctx->host_grid_order.ptr,
                                    (const uint32_t *) ctx->host_grid_found.ptr, (double *) ctx->adaptive_dirs.ptr);
             hipLaunchKernelGGL(adaptive_step_kernel, dim3(P), dim3(64), 0, st, P, prm->rows, prm->cols, max_levels,
@@ -1140,12 +1293,13 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
                                max_keys, d_kt, d_kd, d_ke, d_kf, d_kp, d_kg, d_t0, d_t1, (const int *) B[16].ptr,
                                (const double *) ctx->adaptive_dirs.ptr);
             // shared-map gate: verification and restarts pass by pass
-            if (shared) {
+            // (... and the re-runs start inside the slot allocation's launch: restart_piece)
+            if (shared)
                 hipLaunchKernelGGL(adaptive_verify_live_kernel, dim3((P + 3) / 4), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
-                hipLaunchKernelGGL(adaptive_restart_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, rows, ap->motion_time_step, a);
-            }
-            hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sr, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
-                               d_ring + 4 * ((seq - 1u) % 8u), seq, D, live_floor, live_side_eff, live_tree);
+            const uint32_t Sn = last_active <= AD_TAIL_PIECES && Sr > AD_TAIL_SLOTS ? AD_TAIL_SLOTS : Sr;   // (the next pass's slots)
+            hipLaunchKernelGGL(adaptive_alloc_kernel, dim3(1), dim3(AD_ALLOC_T), 0, st, P, Sn, deal, d_max, a, ap->motion_time_step, d_t0, d_t1,
+                               d_ring + 4 * ((seq - 1u) % 8u), seq, D, live_floor, live_side_eff, live_tree, shared ? rows : 0u);
+            Sw = Sn;
         }
         AD_TRY(hip_rc(hipStreamSynchronize(st), "hipStreamSynchronize"));
         AD_TRY(hip_rc(hipMemcpy(h, a.counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost), "hipMemcpy"));

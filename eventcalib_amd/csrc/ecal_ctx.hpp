@@ -53,6 +53,7 @@ struct ecal_ctx {
     uint32_t wb_epoch = 0;  // ... and the number of the call that wrote it
     const uint32_t *tie_count_last = nullptr;   // the exact extraction's list counter of the last call (a zero-ring word or tie_list's own)
     bool latency_pass = false;        // the caller's word (the keyframe search's tail): few of the launch's windows hold work — the stages take the forms that cost least LATENCY (a window through the tier it needs in one launch)
+    const int *overflow_sticky = nullptr;   // the caller's word: this overflow flag is zero and may STAY set once set — ecal_slice_events_dev does not wipe it (the keyframe search's passes: a memset between the kernels of a pass costs ~20 us with its gaps, and an overflow ends the search anyway)
     uint32_t grid_hint_windows = 0;   // ecal_grid_order_dev: windows that hold work in the next launch, by the caller's knowledge (0: the launch's size)
     hipStream_t wb_stream = nullptr;   // ... and the one stream whose calls use the table (others: the two-kernel form)
     bool wb_stream_set = false;

@@ -916,7 +916,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) H12));
         ctx->slice_attrs_set = true;
     }
-    ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));
+    if (d_overflow != ctx->overflow_sticky) ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));   // (ecal_ctx::overflow_sticky)
     // (packed points: every segment starts as "doubles"; the pixel kernels mark the windows they pack.  The hash slicers — the
     // default — write the mark of EVERY window they look at, also of the ones they pass on: no wipe, one launch less per pass)
     const bool hash_slicer = !ctx->sw.slice_no_pixel;

@@ -1,7 +1,12 @@
 #!/bin/bash
-# the shared-map search against the window slots per piece and pass (ECAL_ADAPTIVE_SHAPE depth=)
+# Run on the GPU box: the shared-map keyframe search under different window slots per piece (ECAL_ADAPTIVE_SHAPE depth=; the result
+# does not depend on it).  usage: bash tools/depth_sweep.sh "<pieces>:<depth> <depth> ..." ...   (depth 0 = the library's choice)
 for rep in 1 2; do
-for d in ${DEPTHS:-4 5 6 8}; do
-  echo -n "slots per piece $d: "
-  for p in 1270 4096; do ECAL_ADAPTIVE_SHAPE=depth=$d python tools/p2_probe.py 50000000 $p 1 shared 2>&1 | tail -1 | awk '{printf "%s pieces %s s | ", $6, $8}'; done; echo
+for spec in "$@"; do
+  p=${spec%%:*}
+  for d in ${spec#*:}; do
+    if [ "$d" = 0 ]; then unset ECAL_ADAPTIVE_SHAPE; else export ECAL_ADAPTIVE_SHAPE=depth=$d; fi
+    echo -n "pieces $p depth=$d: "
+    python tools/p2_probe.py 50000000 $p 1 shared 2>&1 | tail -2 | tr '\n' ' ' | awk '{printf "%s %s s %s passes\n", $3, $11, $13}'
+  done
 done; done
