@@ -152,8 +152,10 @@ static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
     // (many pieces fill the GPU by themselves.  Round 6, with the passes' fixed cost down: a pass of 8 - 16 thousand slots is the
     // optimum — shared-map search, s, at slots per piece 1 / 2 / 3 / 4 / 5 / 6: 2048 pieces - / - / 0.119-0.129 / 0.116-0.122 / 0.123-0.127 /
     // 0.124-0.133; 4096 pieces 0.103 / 0.099 / 0.120 / - / 0.114-0.127 / -; 8192 pieces 0.086-0.096 / 0.065 / 0.086-0.092 / 0.090-0.097 /
-    // 0.094-0.098 / -; 16384 pieces 0.152 / 0.168-0.179 / 0.165; 1270 pieces 5 / 6 / 7: 0.107 / 0.105 / 0.104 — tools/depth_sweep.sh)
-    return pieces <= 1536u ? 6u : (pieces <= 2560u ? 4u : (pieces <= 8192u ? 2u : 1u));
+    // 0.094-0.098 / -; 16384 pieces 0.152 / 0.168-0.179 / 0.165; 1270 pieces 5 / 6 / 7: 0.107 / 0.105 / 0.104; a second box: 1800 pieces
+    // 4 / 6: 0.123-0.131 / 0.140; 2300 pieces 4 / 5 / 6: 0.132-0.135 / 0.122-0.128 / 0.150; 3000 pieces 2 / 4: 0.121-0.148 / 0.108 —
+    // tools/depth_sweep.sh; the boxes differ by more than neighbouring settings do)
+    return pieces <= 1536u ? 6u : (pieces <= 3500u ? 4u : (pieces <= 8192u ? 2u : 1u));
 }
 static uint32_t adaptive_depth_max(int forced = 0) {
     if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_SHAPE depth_max: debug / measurement switch)
