@@ -145,6 +145,11 @@ constexpr uint32_t AD_GRID_LATENCY_PIECES = 256;
 // (run-to-run noise is larger than the differences) — the forms stay off above 2048 windows, where the first pass's small blocks fill
 // the chip and the occupancy of the wide forms starts to cost.
 constexpr uint32_t AD_STAGE_LATENCY_PIECES = ECAL_AD_STAGE_LATENCY_PIECES;
+// pieces at work up to which the slicer's latency form takes the third pass's windows (4096 .. 5119 events) in its one launch too
+#ifndef ECAL_AD_THIRD_IN_ONE_PIECES
+#define ECAL_AD_THIRD_IN_ONE_PIECES 256
+#endif
+constexpr uint32_t AD_THIRD_IN_ONE_PIECES = ECAL_AD_THIRD_IN_ONE_PIECES;
 // the search's tail: with at most AD_TAIL_PIECES pieces at work a pass is launched over AD_TAIL_SLOTS window slots (run_passes)
 constexpr uint32_t AD_TAIL_PIECES = 64, AD_TAIL_SLOTS = 4096;
 static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
@@ -1030,7 +1035,7 @@ static int detect_keyframes_entry(ecal_ctx *ctx, const uint8_t *d_events, uint64
                                          kf_features, n_keyframes, passes, windows, ho);
     ctx->tail_mode = was;
     ctx->tail_no_lean = was_no_lean;
-    ctx->latency_pass = false;
+    ctx->latency_pass = 0;
     ctx->overflow_sticky = nullptr;
     return rc;
 }
@@ -1262,7 +1267,7 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
             seq++;
             AD_TRY(take_ext(0, seq));
             // (few pieces still at work — known two passes late —: the stages' latency forms, ecal_ctx::latency_pass)
-            ctx->latency_pass = last_active <= AD_STAGE_LATENCY_PIECES;
+            ctx->latency_pass = last_active <= AD_THIRD_IN_ONE_PIECES ? 2 : (last_active <= AD_STAGE_LATENCY_PIECES ? 1 : 0);
             AD_TRY(ecal_window_bounds_dev(ctx, d_events, n_events, d_t0, d_t1, Sw, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr,
                                           (uint32_t *) B[4].ptr, st));
             AD_TRY(ecal_slice_events_dev(ctx, d_events, n_events, (uint32_t *) B[2].ptr, (uint32_t *) B[3].ptr, (uint32_t *) B[4].ptr, Sw, 0,

@@ -52,7 +52,7 @@ struct ecal_ctx {
     ecal_devbuf wb_status;  // ecal_window_bounds_dev: one word per workgroup of the look-back scan
     uint32_t wb_epoch = 0;  // ... and the number of the call that wrote it
     const uint32_t *tie_count_last = nullptr;   // the exact extraction's list counter of the last call (a zero-ring word or tie_list's own)
-    bool latency_pass = false;        // the caller's word (the keyframe search's tail): few of the launch's windows hold work — the stages take the forms that cost least LATENCY (a window through the tier it needs in one launch)
+    int latency_pass = 0;             // the caller's word (the keyframe search): few of the launch's windows hold work — the stages take the forms that cost least LATENCY (1: a window through the tier it needs in one launch; 2, the search's tail: the slicer's third pass in that launch too)
     const int *overflow_sticky = nullptr;   // the caller's word: this overflow flag is zero and may STAY set once set — ecal_slice_events_dev does not wipe it (the keyframe search's passes: a memset between the kernels of a pass costs ~20 us with its gaps, and an overflow ends the search anyway)
     uint32_t grid_hint_windows = 0;   // ecal_grid_order_dev: windows that hold work in the next launch, by the caller's knowledge (0: the launch's size)
     hipStream_t wb_stream = nullptr;   // ... and the one stream whose calls use the table (others: the two-kernel form)

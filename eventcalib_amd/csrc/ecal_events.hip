@@ -622,23 +622,49 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
 // the sum of its launches' single-workgroup latencies): workgroup b takes window b through the pass its event count asks for —
 // a window of 2048 .. 4095 events does not wait for the first pass's launch to drain.  Same device code per window, same results;
 // a window the first-pass code cannot take for another reason (more than 1109 keys of a polarity, a non-pixel coordinate) still
-// goes to ITS list, which the second pass behind this launch works off.
+// goes to ITS list, which the second pass behind this launch works off (and the second pass's leftovers the third).
+template <bool THIRD /* windows of 4096 .. 5119 events go through the third pass's code in this launch too */>
 __global__ __launch_bounds__(PXH_T) void slice_hash_ref_both_kernel(const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo,
                                                                     const uint32_t *__restrict__ win_hi, const uint32_t *__restrict__ win_base,
                                                                     uint32_t cap_points, double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
                                                                     uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
                                                                     uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
                                                                     uint32_t *__restrict__ todo2, uint32_t *__restrict__ todo2_count,
+                                                                    uint32_t *__restrict__ todo3, uint32_t *__restrict__ todo3_count,
                                                                     const uint2 *__restrict__ bucket_tab, uint32_t *__restrict__ xy16,
                                                                     uint32_t *__restrict__ seg_fmt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t s = blockIdx.x;
-    if (win_hi[s] - win_lo[s] <= PixHash<11>::CAP)
+    const uint32_t n = win_hi[s] - win_lo[s];
+    if (n <= PixHash<11>::CAP)
         slice_hash_window<11, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo,
                                     todo_count, bucket_tab, xy16, seg_fmt);
-    else
+    else if (!THIRD || n <= PixHash<12>::CAP)
         slice_hash_window<12, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo2,
                                     todo2_count, bucket_tab, xy16, seg_fmt);
+    else
+        slice_hash_window<13, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo3,
+                                    todo3_count, bucket_tab, xy16, seg_fmt);
+}
+
+// third pass (reference order): the workgroups share the list the second pass left (windows of more than 4095 events, sets of more
+// than 2048 keys); what it cannot take either (more than 5119 events, a set beyond the eighth epoch's 2357 buckets, a non-pixel
+// coordinate) goes on to the general tiers' list
+__global__ __launch_bounds__(PXH_T) __attribute__((amdgpu_waves_per_eu(2, 2))) void slice_hash_third_kernel(const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo,
+                                                                 const uint32_t *__restrict__ win_hi, const uint32_t *__restrict__ win_base,
+                                                                 uint32_t cap_points, double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
+                                                                 uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
+                                                                 uint32_t *__restrict__ todo, uint32_t *__restrict__ todo_count,
+                                                                 const uint32_t *__restrict__ in_list, const uint32_t *__restrict__ in_count,
+                                                                 const uint2 *__restrict__ bucket_tab, uint32_t *__restrict__ xy16,
+                                                                 uint32_t *__restrict__ seg_fmt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t count = *in_count;
+    for (uint32_t k = blockIdx.x; k < count; k += gridDim.x) {
+        slice_hash_window<13, true>(smem, in_list[k], rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point,
+                                    overflow, todo, todo_count, bucket_tab, xy16, seg_fmt);
+        __syncthreads();
+    }
 }
 
 // second pass: the workgroups share the list the first pass left (in_list[0 .. *in_count)); windows of up to 4095 events
@@ -901,6 +927,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     const bool reforder = ctx->point_order == ECAL_ORDER_REFERENCE;
     constexpr size_t H11 = PixHash<11>::bytes > PixHash<11>::obytes ? PixHash<11>::bytes : PixHash<11>::obytes;
     constexpr size_t H12 = PixHash<12>::bytes > PixHash<12>::obytes ? PixHash<12>::bytes : PixHash<12>::obytes;
+    constexpr size_t H13 = PixHash<13>::bytes > PixHash<13>::obytes ? PixHash<13>::bytes : PixHash<13>::obytes;
     if (!ctx->slice_attrs_set) {
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_lds_kernel<SCAP0, 2048, 256>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -912,8 +939,12 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) PixHash<12>::bytes));
         ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_list_kernel<true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) H12));
-        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_ref_both_kernel),
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_ref_both_kernel<false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int) H12));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_ref_both_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) H13));
+        ECAL_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&slice_hash_third_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) H13));
         ctx->slice_attrs_set = true;
     }
     if (d_overflow != ctx->overflow_sticky) ECAL_HIP_TRY(ctx, hipMemsetAsync(d_overflow, 0, sizeof(int), st));   // (ecal_ctx::overflow_sticky)
@@ -935,23 +966,30 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
     const uint32_t *cnt_a = nullptr, *cnt_b = nullptr;
     if (!ctx->sw.slice_no_pixel) {
         int rc;
-        if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (2 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
-        uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S;
-        // the lists' counters: words that are zero already, else two wiped now
-        if (uint32_t *z = ecal_zero_words(ctx, st, 2)) {
+        if ((rc = ecal_ensure(ctx, ctx->pxs_todo, (3 * (size_t) S + 8) * sizeof(uint32_t)))) return rc;
+        uint32_t *cnt = (uint32_t *) ctx->pxs_todo.ptr, *list = cnt + 8, *cnt2 = cnt + 1, *list2 = list + S, *cnt3 = cnt + 2, *list3 = list2 + S;
+        // the lists' counters: words that are zero already, else three wiped now
+        if (uint32_t *z = ecal_zero_words(ctx, st, 3)) {
             cnt = z;
             cnt2 = z + 1;
+            cnt3 = z + 2;
         } else {
-            ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 2 * sizeof(uint32_t), st));
+            ECAL_HIP_TRY(ctx, hipMemsetAsync(cnt, 0, 3 * sizeof(uint32_t), st));
         }
         todo = list;
         todo_count = cnt;
         cnt_a = cnt;
         if (reforder) {
             if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
-            if (ctx->latency_pass && !lean)   // (few windows at work: a window goes through the pass its size asks for in ONE launch)
-                hipLaunchKernelGGL(slice_hash_ref_both_kernel, dim3(S), dim3(PXH_T), H12, st, d_events, d_win_lo, d_win_hi, d_win_base,
-                                   cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, list2, cnt2,
+            // (few windows at work: a window goes through the pass its size asks for in ONE launch; very few — latency_pass 2, the
+            // tail of the keyframe search —: the third pass's windows as well, in workgroups of 66 KB instead of 52)
+            if (ctx->latency_pass >= 2 && !lean)
+                hipLaunchKernelGGL(slice_hash_ref_both_kernel<true>, dim3(S), dim3(PXH_T), H13, st, d_events, d_win_lo, d_win_hi, d_win_base,
+                                   cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, list2, cnt2, list3, cnt3,
+                                   (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
+            else if (ctx->latency_pass && !lean)
+                hipLaunchKernelGGL(slice_hash_ref_both_kernel<false>, dim3(S), dim3(PXH_T), H12, st, d_events, d_win_lo, d_win_hi, d_win_base,
+                                   cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, list2, cnt2, list3, cnt3,
                                    (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
             else
             hipLaunchKernelGGL(slice_hash_ref_kernel, dim3(S), dim3(PXH_T), H11, st, d_events, d_win_lo, d_win_hi,
@@ -975,6 +1013,14 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
                                    cnt2, (const uint32_t *) list, (const uint32_t *) cnt, (const uint2 *) nullptr, xy16, sfmt);
             todo = list2;
             todo_count = cnt2;
+            if (reforder) {   // the third pass: what the second one leaves that is still a pixel window
+                hipLaunchKernelGGL(slice_hash_third_kernel, dim3(S < 512u ? S : 512u), dim3(PXH_T), H13, st, d_events, d_win_lo, d_win_hi,
+                                   d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list3, cnt3,
+                                   (const uint32_t *) list2, (const uint32_t *) cnt2, (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
+                cnt_b = cnt3;
+                todo = list3;
+                todo_count = cnt3;
+            }
         }
         grid = S < 512u ? S : 512u;
     }

@@ -48,12 +48,17 @@ static __device__ unsigned long long g_ro_cycles[16];
 // from decode to output: the tables are all the LDS there is (16 KB).
 // LOGC = 11: the first pass (<= 2047 events, x <= 2047, y <= 1023; 24 KB of LDS, six windows per CU);
 // LOGC = 12: the second pass over the windows the first one lists (<= 4095 events, x, y <= 1023; 49 KB, three per CU).
+// LOGC = 13 (round 6): the third pass, reference order only (<= 5119 events, x <= 511, y <= 1023; 66 KB, two per CU) — the
+// keyframe search grows its windows to nine and ten steps (eventCameraCalib.cpp:57-95), 4500 - 5000 events on the benchmark
+// stream: one window in eight went to the general tier (a 512-thread kernel with 120 KB of LDS, one workgroup per CU).
 constexpr int PXH_T = 256;
 template <int LOGC>
 struct PixHash {
     static constexpr uint32_t SLOTS = 1u << LOGC;        // per polarity
-    static constexpr uint32_t CAP = SLOTS - 1u;          // events per window: indices 0 .. CAP - 1, CAP = "erased"
-    static constexpr int PER = (int) (SLOTS / PXH_T);    // events per thread at most
+    // events per thread at most (LOGC = 13, the third pass: 20 — windows of up to 5119 events, what the keyframe search's windows
+    // of nine and ten steps hold; the tables' 8192 slots give the event indices their 13 bits)
+    static constexpr int PER = LOGC == 13 ? 20 : (int) (SLOTS / PXH_T);
+    static constexpr uint32_t CAP = (uint32_t) PER * PXH_T - 1u;   // events per window: indices 0 .. CAP - 1, CAP = "erased"
     static constexpr uint32_t PIXB = 32u - LOGC;         // pixel bits: x << 10 | y
     static constexpr double XMAX = (double) ((1u << (PIXB - 10u)) - 1u), YMAX = 1023.0;
     static constexpr size_t tab_off = 0;                                   // u32[2][SLOTS]; later pos u16[SLOTS] + batch counts
@@ -80,7 +85,8 @@ struct PixHash {
     // keys per thread of a pair: 1152 >= 1109 in the first pass; the second pass takes sets of up to 2048 keys (19 would hold
     // the 2357 of its last epoch, but with 16 the layout is 52 KB instead of 60: three windows per CU instead of two — a
     // window of 4095 events has ~1600 keys per polarity; the rare larger set goes to the general tier)
-    static constexpr int NI = LOGC == 11 ? ECAL_RO_NI : ECAL_RO_NI2;
+    // (the third pass: 19 = 2432 keys, every set that stays within the 2357 buckets of the eighth epoch)
+    static constexpr int NI = LOGC == 11 ? ECAL_RO_NI : (LOGC == 12 ? ECAL_RO_NI2 : 19);
     static constexpr int MAX_EPOCHS = LOGC == 11 ? 7 : 8;             // bucket counts up to 1109 / 2357
     static constexpr uint32_t NOFF = 128u * NI, PSL = 2u * NOFF;
 #ifndef ECAL_RO_FA
@@ -252,7 +258,10 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
 #ifdef ECAL_PHASE_PROF
     unsigned long long ro_t__ = __builtin_amdgcn_s_memtime();
 #endif
-    constexpr uint32_t PXH_CAP = L::CAP, PXH_SLOTS = L::SLOTS, IDXM = L::CAP, PIXB = L::PIXB;
+    constexpr uint32_t PXH_CAP = L::CAP, PXH_SLOTS = L::SLOTS, IDXM = L::SLOTS - 1u, PIXB = L::PIXB;
+    // the per-event word of the reference-order block: first occurrence (MB bits) | erased | polarity | key | rank << 16
+    constexpr uint32_t MB = LOGC <= 12 ? 12u : 13u, M_IDX = (1u << MB) - 1u, M_ER = 1u << MB, M_POL = 2u << MB, M_KEY = 4u << MB;
+    static_assert(MB + 3u <= 16u && L::CAP <= M_IDX, "the word's fields");
     constexpr int PXH_PER = L::PER;
     constexpr uint32_t NONE = L::CAP, EMPTY = 0xFFFFFFFFu;
     const uint32_t tid = threadIdx.x;
@@ -439,22 +448,36 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             const unsigned long long lower = (1ull << lane) - 1ull;
             const uint32_t below = (uint32_t) __popcll((vp[j] ? mP : mN) & lower);
             if (lane == 0) bcnt[j * (T / 64) + wave] = (uint32_t) __popcll(mP) | ((uint32_t) __popcll(mN) << 16);
-            meta[j] = k < n ? ((firstk[j] & 0xFFFu) | ((firstk[j] & 0x8000u) ? 0x1000u : 0u) | (vp[j] ? 0x2000u : 0u) |
-                               (isu ? 0x4000u : 0u) | (below << 16))
-                            : 0x1000u;   // (no event: "erased", not a key)
+            meta[j] = k < n ? ((firstk[j] & M_IDX) | ((firstk[j] & 0x8000u) ? M_ER : 0u) | (vp[j] ? M_POL : 0u) |
+                               (isu ? M_KEY : 0u) | (below << 16))
+                            : M_ER;   // (no event: "erased", not a key)
         }
         if constexpr (EARLY_GATHER) lds_barrier(); else __syncthreads();
     RO_MARK(2);
         if (tid < 64u) {
-            const uint32_t v = tid < NBATCH ? bcnt[tid] : 0u;
-            uint32_t inc = v;
+            if constexpr (NBATCH <= 64u) {
+                const uint32_t v = tid < NBATCH ? bcnt[tid] : 0u;
+                uint32_t inc = v;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(inc, d, 64);
-                if (lane >= (uint32_t) d) inc += o;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d, 64);
+                    if (lane >= (uint32_t) d) inc += o;
+                }
+                if (tid < NBATCH) bcnt[tid] = inc - v;
+                if (tid == 63u) bcnt[NBATCH] = inc;
+            } else {   // (the third pass: up to 128 batches, two a lane; the packed fields stay below 2^16: <= 5119 events)
+                static_assert(NBATCH <= 128u, "two batches per lane");
+                const uint32_t v0 = 2u * tid < NBATCH ? bcnt[2u * tid] : 0u, v1 = 2u * tid + 1u < NBATCH ? bcnt[2u * tid + 1u] : 0u;
+                uint32_t inc = v0 + v1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(inc, d, 64);
+                    if (lane >= (uint32_t) d) inc += o;
+                }
+                if (2u * tid < NBATCH) bcnt[2u * tid] = inc - v0 - v1;
+                if (2u * tid + 1u < NBATCH) bcnt[2u * tid + 1u] = inc - v1;
+                if (tid == 63u) bcnt[NBATCH] = inc;
             }
-            if (tid < NBATCH) bcnt[tid] = inc - v;
-            if (tid == 63u) bcnt[NBATCH] = inc;
         }
         if constexpr (EARLY_GATHER) lds_barrier(); else __syncthreads();
     RO_MARK(3);
@@ -479,11 +502,11 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
 #pragma unroll
                 for (int j = 0; j < PXH_PER; j++) {
                     const uint32_t ex = bcnt[j * (T / 64) + wave];
-                    meta[j] += ((meta[j] & 0x2000u) ? (ex & 0xFFFFu) : (ex >> 16)) << 16;
-                    if (meta[j] & 0x4000u) {
+                    meta[j] += ((meta[j] & M_POL) ? (ex & 0xFFFFu) : (ex >> 16)) << 16;
+                    if (meta[j] & M_KEY) {
                         const uint32_t rank = meta[j] >> 16;
-                        const bool pos_ = (meta[j] & 0x2000u) != 0;
-                        W[(pos_ ? 0u : L::NOFF) + rank] = bw[j].x | ((meta[j] & 0x1000u) ? 0x80000000u : 0u);
+                        const bool pos_ = (meta[j] & M_POL) != 0;
+                        W[(pos_ ? 0u : L::NOFF) + rank] = bw[j].x | ((meta[j] & M_ER) ? 0x80000000u : 0u);
                         if (rank < N_EARLY) fa[(pos_ ? 0u : faN) + rank] = bw[j].y;
                         if (L::MAX_EPOCHS > 7 && (pos_ ? EP : EN) > 7)   // (second pass, a set of more than 1109 keys)
                             region[(pos_ ? 0u : L::NOFF) + rank] =
@@ -659,8 +682,8 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             if (want_ep) {
 #pragma unroll
                 for (int j = 0; j < PXH_PER; j++) {
-                    if ((meta[j] & 0x5000u) == 0x4000u)   // a key, and not erased
-                        posE[meta[j] & 0xFFFu] = cur[((meta[j] & 0x2000u) ? 0u : L::NOFF) + (meta[j] >> 16)];
+                    if ((meta[j] & (M_KEY | M_ER)) == M_KEY)   // a key, and not erased
+                        posE[meta[j] & M_IDX] = cur[((meta[j] & M_POL) ? 0u : L::NOFF) + (meta[j] >> 16)];
                 }
                 __syncthreads();
             }
@@ -671,14 +694,14 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             for (int j = 0; j < PXH_PER; j++) {
                 const uint32_t k = tid + j * T;
                 if (k < n) {
-                    if (meta[j] & 0x1000u) {
+                    if (meta[j] & M_ER) {
                         if (want_ep) ep[k] = -1;
-                    } else if (want_ep || (meta[j] & 0x4000u)) {
-                        const uint32_t at = want_ep ? posE[meta[j] & 0xFFFu]
-                                                    : (uint32_t) cur[((meta[j] & 0x2000u) ? 0u : L::NOFF) + (meta[j] >> 16)];
+                    } else if (want_ep || (meta[j] & M_KEY)) {
+                        const uint32_t at = want_ep ? posE[meta[j] & M_IDX]
+                                                    : (uint32_t) cur[((meta[j] & M_POL) ? 0u : L::NOFF) + (meta[j] >> 16)];
                         if (want_ep) ep[k] = (int32_t) at;
-                        if (meta[j] & 0x4000u) {
-                            const uint32_t slot = (meta[j] & 0x2000u) ? at : nP + at;
+                        if (meta[j] & M_KEY) {
+                            const uint32_t slot = (meta[j] & M_POL) ? at : nP + at;
                             if (xy16) {
                                 xy16[base + slot] = (pix[j] >> 10) | ((pix[j] & 0x3FFu) << 16);
                             } else {
@@ -707,6 +730,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
     // event index: rank = representatives of the same polarity in the batches before + on the lanes below (ballots; the
     // per-batch counts, both polarities packed in one word, are scanned by wave 0).
     constexpr uint32_t NBATCH = (uint32_t) PXH_PER * (T / 64);
+    static_assert(REFORDER || NBATCH <= 64u, "the canonical-order form scans one batch per lane (first and second pass only)");
     uint32_t *const bcnt = tab + PXH_SLOTS;  // [NBATCH] counts, then exclusive prefixes; [NBATCH]: totals (the tables are dead)
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t below[PXH_PER];

@@ -300,6 +300,59 @@ def test_hash_slicer_second_pass_equals_general_slicer(env):
             assert np.array_equal(a[5][o:o + c], b[5][o:o + c]), (s, pol)
 
 
+def test_hash_slicer_third_pass_equals_general_slicer(env):
+    """Windows of 4096 ... 5119 events (what the keyframe search's windows of nine and ten steps hold) are taken by the THIRD pass of
+    the hash-table slicer (8192-slot tables, 13-bit event indices, sets of up to 2357 keys per polarity); longer ones and sets
+    beyond that go on to the general tiers.  Points, their order, the segments and the event -> point map must equal the general
+    slicer's on every window (which tests above pin to the oracle)."""
+    import os
+    import torch
+    ctx = env[0]
+    from eventcalib_amd.pipeline import DetectPipeline
+    n = 200000
+    buf = SS.make_stream(n, rate=2.0e6, device="cpu", seed=33)
+    t, _, _ = SS.unpack_records(buf)
+    t0a, t1a = SS.tiled_windows(float(t[0]), float(t[-1]), 2.2e-3)      # ~4400 events
+    t0b, t1b = SS.tiled_windows(float(t[0]), float(t[-1]), 2.5e-3)      # ~5000 events: some beyond 5119
+    t0c, t1c = SS.tiled_windows(float(t[0]), float(t[-1]), 3.2e-3)      # ~6400 events: the general tiers'
+    t0d, t1d = SS.tiled_windows(float(t[0]), float(t[-1]), 1.0e-3)      # ~2000 events: first and second pass beside them
+    t0, t1 = np.concatenate([t0a, t0b, t0c, t0d]), np.concatenate([t1a, t1b, t1c, t1d])
+    ev = buf.cuda()
+    outs = []
+    for no_pixel in (False, True):
+        if no_pixel:
+            os.environ["ECAL_FORCE"] = "slice_general"
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
+        try:
+            p = DetectPipeline(ctx)
+            p.set_windows(t0, t1)
+            p.run(ev, slots=int(4.2 * n) + 8192, slice_only=True)
+            torch.cuda.synchronize()
+            S = len(t0)
+            assert not p.overflowed()
+            fmt = p.seg_fmt[:2 * S].cpu().numpy().copy()   # (1: the window's points went out packed, i.e. through a hash pass)
+            outs.append((p.win_lo[:S].cpu().numpy().copy(), p.win_hi[:S].cpu().numpy().copy(), p.seg_off[:2 * S].cpu().numpy().copy(),
+                         p.seg_cnt[:2 * S].cpu().numpy().copy(), p.event_point.cpu().numpy().copy(), p.xy.cpu().numpy().copy(),
+                         p.win_base[:S + 1].cpu().numpy().copy(), fmt))
+        finally:
+            os.environ.pop("ECAL_FORCE", None)
+            __import__("eventcalib_amd.capi", fromlist=["sync_env"]).sync_env()   # (the switches are read once per context)
+    a, b = outs
+    sizes = a[1] - a[0]
+    third = (sizes > 4095) & (sizes <= 5119)
+    if ctx.point_order() == "reference":   # the third pass took its windows (a set of > 2357 keys may go on); first-occurrence order has none
+        assert a[7][0::2][third].mean() > 0.9
+    assert not a[7][0::2][sizes > 5119].any() and not b[7].any()
+    assert int(((sizes > 4095) & (sizes <= 5119)).sum()) >= 40 and int((sizes > 5119).sum()) >= 10 and int((sizes <= 4095).sum()) >= 40
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for s in range(len(t0)):
+        lo, hi, base = int(a[0][s]), int(a[1][s]), int(a[6][s])
+        assert np.array_equal(a[4][base:base + hi - lo], b[4][base:base + hi - lo]), s
+        for pol in range(2):
+            o, c = int(a[2][2 * s + pol]), int(a[3][2 * s + pol])
+            assert np.array_equal(a[5][o:o + c], b[5][o:o + c]), (s, pol)
+
+
 def test_golden_eventframe_order_fixtures(env):
     """`.bin` records -> the reference's point order -> DBSCAN labels, against the committed fixtures
     (tests/golden/eventframe_order_*.npz: real std::unordered_set + the reference's kd-tree, made in the build container)."""
