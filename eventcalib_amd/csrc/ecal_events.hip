@@ -636,15 +636,32 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_ref_both_kernel(const uint8_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t s = blockIdx.x;
     const uint32_t n = win_hi[s] - win_lo[s];
+    if constexpr (THIRD) {
+        // ONE launch for all three passes: a window the pass of its size cannot take (a set of more keys than that pass holds) goes
+        // straight on to the next pass in this workgroup; only what the third cannot take either is listed (for the general tiers) —
+        // the lists of the first two stay empty and their launches are not made
+        bool done = false;
+        if (n <= PixHash<11>::CAP)
+            done = slice_hash_window<11, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
+                                               nullptr, nullptr, bucket_tab, xy16, seg_fmt);
+        if (!done && n <= PixHash<12>::CAP) {
+            __syncthreads();
+            done = slice_hash_window<12, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow,
+                                               nullptr, nullptr, bucket_tab, xy16, seg_fmt);
+        }
+        if (!done) {
+            __syncthreads();
+            slice_hash_window<13, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo3,
+                                        todo3_count, bucket_tab, xy16, seg_fmt);
+        }
+        return;
+    }
     if (n <= PixHash<11>::CAP)
         slice_hash_window<11, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo,
                                     todo_count, bucket_tab, xy16, seg_fmt);
-    else if (!THIRD || n <= PixHash<12>::CAP)
+    else
         slice_hash_window<12, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo2,
                                     todo2_count, bucket_tab, xy16, seg_fmt);
-    else
-        slice_hash_window<13, true>(smem, s, rec, win_lo, win_hi, win_base, cap_points, xy_out, seg_off, seg_cnt, event_point, overflow, todo3,
-                                    todo3_count, bucket_tab, xy16, seg_fmt);
 }
 
 // third pass (reference order): the workgroups share the list the second pass left (windows of more than 4095 events, sets of more
@@ -1000,7 +1017,11 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
             hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
                                d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, xy16, sfmt);
         // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
-        if (!lean && (reforder || mx > PixHash<11>::CAP)) {
+        if (reforder && !lean && ctx->latency_pass >= 2) {   // (all three passes were that one launch: its only list is the general tiers')
+            cnt_b = cnt3;
+            todo = list3;
+            todo_count = cnt3;
+        } else if (!lean && (reforder || mx > PixHash<11>::CAP)) {
             cnt_b = cnt2;
             const uint32_t grid2 = S < 768u ? S : 768u;
             if (reforder)

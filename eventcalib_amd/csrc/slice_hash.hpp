@@ -52,12 +52,15 @@ static __device__ unsigned long long g_ro_cycles[16];
 // keyframe search grows its windows to nine and ten steps (eventCameraCalib.cpp:57-95), 4500 - 5000 events on the benchmark
 // stream: one window in eight went to the general tier (a 512-thread kernel with 120 KB of LDS, one workgroup per CU).
 constexpr int PXH_T = 256;
+#ifndef ECAL_PXH13_PER
+#define ECAL_PXH13_PER 20
+#endif
 template <int LOGC>
 struct PixHash {
     static constexpr uint32_t SLOTS = 1u << LOGC;        // per polarity
     // events per thread at most (LOGC = 13, the third pass: 20 — windows of up to 5119 events, what the keyframe search's windows
     // of nine and ten steps hold; the tables' 8192 slots give the event indices their 13 bits)
-    static constexpr int PER = LOGC == 13 ? 20 : (int) (SLOTS / PXH_T);
+    static constexpr int PER = LOGC == 13 ? ECAL_PXH13_PER : (int) (SLOTS / PXH_T);
     static constexpr uint32_t CAP = (uint32_t) PER * PXH_T - 1u;   // events per window: indices 0 .. CAP - 1, CAP = "erased"
     static constexpr uint32_t PIXB = 32u - LOGC;         // pixel bits: x << 10 | y
     static constexpr double XMAX = (double) ((1u << (PIXB - 10u)) - 1u), YMAX = 1023.0;
@@ -242,6 +245,8 @@ __device__ __forceinline__ void early_epochs_packed(uint32_t m, uint32_t *fa, ui
         if (lane + 64u * i < m_e) cur_out[lane + 64u * i] = (uint16_t) cur[i];
 }
 
+// Returns false when the window is not this pass's (too many events or keys, a non-pixel coordinate): it is then put on `todo`, or —
+// todo == nullptr — left to the caller (nothing has been written for it yet except, with seg_fmt, its "doubles" mark).
 template <int LOGC, bool REFORDER>
 __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uint32_t s, const uint8_t *__restrict__ rec,
                                                   const uint32_t *__restrict__ win_lo, const uint32_t *__restrict__ win_hi,
@@ -278,7 +283,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
     }
     if (n > PXH_CAP) {
         if (tid == 0) {
-            todo[atomicAdd(todo_count, 1u)] = s;
+            if (todo) todo[atomicAdd(todo_count, 1u)] = s;   // (null: the caller takes the window on itself — false comes back)
             if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
         }
         return false;
@@ -335,7 +340,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
     __syncthreads();
     if (badf[0] | badf[1] | badf[2] | badf[3]) {
         if (tid == 0) {
-            todo[atomicAdd(todo_count, 1u)] = s;
+            if (todo) todo[atomicAdd(todo_count, 1u)] = s;   // (null: the caller takes the window on itself — false comes back)
             if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
         }
         return false;
@@ -488,7 +493,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             if (need > L::FA_CAP || EP > L::MAX_EPOCHS || EN > L::MAX_EPOCHS || mP > 128u * (uint32_t) L::NI ||
                 mN > 128u * (uint32_t) L::NI) {   // more keys than the bucket tables / the pair's registers hold: next tier
                 if (tid == 0) {
-            todo[atomicAdd(todo_count, 1u)] = s;
+            if (todo) todo[atomicAdd(todo_count, 1u)] = s;   // (null: the caller takes the window on itself — false comes back)
             if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
         }
                 return false;
@@ -642,7 +647,7 @@ __device__ __forceinline__ bool slice_hash_window(unsigned char *smem, const uin
             if (ECAL_RO_STOP == 4) return true;
             if (ored[10]) {
                 if (tid == 0) {
-            todo[atomicAdd(todo_count, 1u)] = s;
+            if (todo) todo[atomicAdd(todo_count, 1u)] = s;   // (null: the caller takes the window on itself — false comes back)
             if (seg_fmt) seg_fmt[2 * s] = seg_fmt[2 * s + 1] = 0u;   // (whoever takes the window later writes doubles)
         }
                 return false;

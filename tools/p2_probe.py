@@ -29,4 +29,4 @@ kf = run(5.0, 5.0 + (n - 1) / 1e6)
 torch.cuda.synchronize(); el = time.perf_counter() - t
 import hashlib
 print("keyframes sha", hashlib.sha1(kf["time"].tobytes() + kf["features"].tobytes()).hexdigest()[:12])
-print("threads %d " % nth + "P2: %d events, %d pieces, %.3f s, %d passes (%.3f ms each), %d windows, %d keyframes" % (n, pieces, el, kf["steps"], el / kf["steps"] * 1e3, kf["windows"], len(kf["time"])))
+print("threads %d " % nth + "P2: %d events, %d pieces, %.4f s, %d passes (%.3f ms each), %d windows, %d keyframes" % (n, pieces, el, kf["steps"], el / kf["steps"] * 1e3, kf["windows"], len(kf["time"])))
