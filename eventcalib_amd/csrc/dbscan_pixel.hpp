@@ -198,7 +198,7 @@ __device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t
         return 0;
     }
     if (n > (uint32_t) CAP) {
-        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;
+        if (tid == 0 && todo) todo[atomicAdd(todo_count, 1u)] = s;   // (todo == nullptr: the caller takes the segment on itself — -1 comes back)
         return -1;
     }
     // E2I > 0: the disc is a compile-time constant (masks become literals, the row loops unroll)
@@ -235,7 +235,7 @@ __device__ __forceinline__ int px_segment(unsigned char *px_smem, const uint32_t
 #endif
 #define PX_BAIL()                                                  \
     do {                                                           \
-        if (tid == 0) todo[atomicAdd(todo_count, 1u)] = s;         \
+        if (tid == 0 && todo) todo[atomicAdd(todo_count, 1u)] = s; \
         return -1;                                                \
     } while (0)
     // debug builds (-DECAL_PX_STOP=k, tools/px_stop_probe.sh): leave after phase k with the phase's results written
@@ -785,8 +785,7 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_kernel(const double *__rest
 // The LATENCY form of the two passes (ecal_ctx::latency_pass: few windows hold work — the tail of the keyframe search, where a
 // pass's time is the SUM of its launches' single-workgroup latencies): workgroup b takes segment b through the pass its size asks
 // for, so a segment of 769 .. CAP2 points does not wait for the first pass's launch to drain before the second one starts.  Same
-// device code per segment, same results; what the first-pass code cannot take for another reason still goes to ITS list (the
-// second pass behind this launch finds it), what the second-pass code cannot take to todo2.
+// device code per segment, same results; what the second-pass code cannot take goes to todo2 (the general tiers').
 template <int E2I, int CAP, int CAP2>
 __global__ __launch_bounds__(PX_T) void dbscan_pixel_both_kernel(const double *__restrict__ xy, const uint32_t *__restrict__ seg_off,
                                                                  const uint32_t *__restrict__ seg_cnt, const PxGeom geom, uint32_t minpts,
@@ -797,12 +796,17 @@ __global__ __launch_bounds__(PX_T) void dbscan_pixel_both_kernel(const double *_
                                                                  uint32_t *__restrict__ tree_out, uint32_t *__restrict__ tree_flag,
                                                                  uint32_t tree_epoch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char px_smem[];
+    // (a segment the first pass's code bails out of — its box of pixels larger than that pass's bitmap, more one-way edges than its
+    // list holds — goes on to the second pass's code in this workgroup: the first pass's list stays empty, its launch is not made)
+    int r = -1;
     if (seg_cnt[blockIdx.x] <= (uint32_t) CAP)
-        px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo, todo_count, 0, 0, xy16, seg_fmt,
-                             tree_out, tree_flag, tree_epoch);
-    else
+        r = px_segment<E2I, CAP>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, nullptr, nullptr, 0, 0, xy16, seg_fmt,
+                                 tree_out, tree_flag, tree_epoch);
+    if (r == -1) {
+        __syncthreads();
         px_segment<E2I, CAP2>(px_smem, blockIdx.x, xy, seg_off, seg_cnt, geom, minpts, labels, n_clusters, todo2, todo2_count, 0, 0, xy16,
                               seg_fmt, tree_out, tree_flag, tree_epoch);
+    }
 }
 
 // second pass (CAP = PX_CAP2): the workgroups share the list of segments the first pass left over

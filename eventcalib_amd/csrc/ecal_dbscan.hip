@@ -361,7 +361,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
             hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes, st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
                                ctx->px_tree_epoch);
-            if (second_pass)
+            if (second_pass && !ctx->latency_pass)   // (latency form: both passes were that one launch, the first pass's list is empty)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<16, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
                                    (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt, tree, tflag, ctx->px_tree_epoch);

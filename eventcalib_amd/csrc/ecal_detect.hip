@@ -320,7 +320,8 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
         if (mode == 1) {
             if (fit) ECAL_DET_SECOND(true, 1); else ECAL_DET_SECOND(false, 1);
         } else if (mode == 2) {
-            if (fit) ECAL_DET_SECOND(true, 2); else ECAL_DET_SECOND(false, 2);
+            // (latency form: extract_both_kernel took the second pass's windows itself and lists none)
+            if (fit) ECAL_DET_SECOND(true, 2); else if (!ctx->latency_pass) ECAL_DET_SECOND(false, 2);
         } else {
             if (fit) ECAL_DET_SECOND(true, 0); else ECAL_DET_SECOND(false, 0);
         }
