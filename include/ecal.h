@@ -163,7 +163,8 @@ int ecal_slice_events_dev(ecal_ctx *ctx, const uint8_t *d_events, uint64_t n_eve
  * Event pixels are small integers: between the stages a point needs 4 bytes (x | y << 16, two's complement int16 each), not
  * the 16 of the reference's Vector2d.  The *_packed_dev forms of the three stage entry points take an ecal_packed_points
  * (caller-owned device buffers: d_xy16 [cap_points], d_seg_fmt [2S]; NULL = the plain forms): the slicer writes the windows
- * its pixel kernels take (sensor pixels 0 <= x <= 2047, 0 <= y <= 1023, up to 4095 events) to d_xy16 only and marks their two
+ * its pixel kernels take (sensor pixels 0 <= x <= 2047, 0 <= y <= 1023, up to 2047 events; x <= 1023 up to 4095 events; in
+ * reference order x <= 511 up to 5119 events) to d_xy16 only and marks their two
  * segments d_seg_fmt = 1; every other window goes to d_xy as doubles (d_seg_fmt = 0).  DBSCAN and the extraction read
  * whichever form a segment has (and write its doubles themselves, d_seg_fmt 1 -> 3, before a segment goes to one of their
  * general tiers); results are bit for bit those of the plain forms.  ecal_unpack_points_dev writes the doubles of every
@@ -267,8 +268,8 @@ int ecal_get_median_ties(const ecal_ctx *ctx);
  * kernel that takes what the shipped configuration produces and lists the rest for tiers of growing capacity; on most data
  * those lists stay empty, and a launch that finds its list empty still costs ~5 us (twenty of them: 0.1 ms of every pass).
  * ECAL_TAIL_AUTO (default): a stage whose previous call on this context saw empty lists launches ONE kernel that takes
- * whatever is listed through its most general tier; slicing and DBSCAN, when the first pass listed work but the second pass
- * left none, run first pass + second pass + that one kernel; a stage that saw work behind the second pass launches every tier.
+ * whatever is listed through its most general tier; slicing and DBSCAN, when the first pass listed work but the later hash /
+ * pixel passes left none, run those passes + that one kernel; a stage that saw work behind the second pass launches every tier.
  * ECAL_TAIL_TIERED / ECAL_TAIL_LEAN force one form (tests).  The adaptive search (ecal_detect_keyframes), whose windows are
  * second-tier work by design, keeps AUTO but never takes the one-kernel form.
  * The choice moves time only: every listed window is processed either way, results are bit-identical
