@@ -332,7 +332,9 @@ constexpr uint32_t AD_SIDE_MEASURED = 0u | (24u << 8) | (12u << 16) | (24u << 24
 constexpr uint32_t AD_SIDE_DEFAULT = AD_SIDE_MEASURED;
 // tree_for's word: main chain 8, chains of 8 behind positions 1 .. 5 / 1 .. 4 / 1 .. 3 of the levels above (a keyframe's window is
 // 4 - 10 steps long, position = steps - 3 after a fresh start: 5 steps 32 %, 4: 21 %, 6: 20 %, 7: 12 %, 8: 8 %)
-constexpr uint32_t AD_TREE_DEFAULT = 8u | (8u << 8) | (5u << 16) | (4u << 20) | (3u << 24) | (1u << 28);
+// Round 6 (cheaper passes; tools/tree_ab.sh, shared-map search at 1270 pieces, s): chains of 8 / 5 / 4 / 3 as above 0.0903 - 0.0906;
+// chains of 7: 0.0890; 7 with 5 / 5 / 3 chains: 0.0884 - 0.0885; 6 / 4 / 3, 5 / 4 / 4 and others within 0.001 of those
+constexpr uint32_t AD_TREE_DEFAULT = 8u | (7u << 8) | (5u << 16) | (5u << 20) | (3u << 24) | (1u << 28);
 // report (pinned host memory, may be NULL) + seq: the pass that ends with this launch tells the host how it went — pieces still
 // active, keyframe records so far, capacity overflow, and LAST the pass's number, which the host polls for (a copy engine
 // transfer + an event per pass between the kernels of a launch-bound chain cost more than the kernels they sat between) —
@@ -1221,7 +1223,14 @@ static int detect_keyframes_impl(ecal_ctx *ctx, const uint8_t *d_events, uint64_
     // the tree of chains a piece gets where keyframes are to be expected (tree_for; ECAL_ADAPTIVE_SHAPE tree: 0 = none, else the word)
     const uint32_t live_tree_asked = ctx->sw.adaptive_tree < 0 ? AD_TREE_DEFAULT : (uint32_t) ctx->sw.adaptive_tree;
     const uint32_t live_tree = d_max >= (live_tree_asked & 0xFFu) ? live_tree_asked : 0u;   // (as the side chains: not under a chain cap below its main chain)
-    const uint32_t live_floor = 1024u;   // (slots a pass has to spare for few pieces at work; swept in round 5, profiles/r05_notes.md)
+#ifndef ECAL_AD_LIVE_FLOOR
+#define ECAL_AD_LIVE_FLOOR 640u
+#endif
+    // slots a pass has to spare for few pieces at work.  1024 until round 6 (swept in round 5, profiles/r05_notes.md); with the passes
+    // of round 6 (s at 1270 / 4096 pieces, the tree above): 384: 0.0877 / 0.112 - 0.118; 512: 0.0864 - 0.0867 / 0.0875 - 0.0893;
+    // 640: 0.0864 / 0.0855 - 0.0859; 768: 0.0866 - 0.0870 / 0.0862; 1024: 0.0885 / 0.086; 1536, 2048: 0.093 - 0.094 — a tail pass's time
+    // is the sum over the stages of their SLOWEST window, and every window more is another draw
+    const uint32_t live_floor = ECAL_AD_LIVE_FLOOR;
     auto run_passes = [&]() -> int {
         // the window slots of this set of runs: `deal` of the S there are (a verification round of a few pieces launches its
         // kernels over the slots it deals out, not over all S: thousands of workgroups that find an empty window still cost

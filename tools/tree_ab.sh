@@ -1,8 +1,10 @@
 #!/bin/bash
-# A/B of the tree of chains (ECAL_ADAPTIVE_SHAPE=tree=0: chains and side chains only), both gates, same box, alternating
-for rep in 1 2 3; do
-for t in on off; do
-  if [ $t = off ]; then export ECAL_ADAPTIVE_SHAPE=tree=0; else unset ECAL_ADAPTIVE_SHAPE; fi
-  echo -n "tree $t: "
-  for p in 1270 4096; do for g in shared dev; do python tools/p2_probe.py 50000000 $p 1 $g 2>&1 | tail -1 | awk -v g=$g '{printf "%s %s pieces %s s (%s passes) | ", g, $6, $8, $10}'; done; done; echo
+# Run on the GPU box: the shared-map search at 1270 pieces under other shapes of the tree of chains (ECAL_ADAPTIVE_SHAPE tree=<word>:
+# main | len << 8 | c1 << 16 | c2 << 20 | c3 << 24 | from << 28; the result does not depend on it) and other builds (ab_libs/*.so)
+w() { echo $(( $1 | ($2 << 8) | ($3 << 16) | ($4 << 20) | ($5 << 24) | ($6 << 28) )); }
+for rep in 1 2; do
+for spec in "default" ${TREES:-"tree=$(w 8 7 5 4 3 1)" "tree=$(w 8 7 5 4 4 1)" "tree=$(w 8 6 5 4 3 1)" "tree=$(w 7 7 5 4 3 1)" "tree=$(w 8 7 6 4 3 1)" "tree=$(w 8 7 5 5 3 1)" "tree=$(w 8 6 5 4 4 1)" "tree=$(w 8 7 4 4 4 1)"} "$@"; do
+  unset ECAL_ADAPTIVE_SHAPE ECAL_AB_LIB
+  case "$spec" in default) ;; tree=*) export ECAL_ADAPTIVE_SHAPE=$spec ;; *) export ECAL_AB_LIB=$spec ;; esac
+  echo -n "$spec: "; python tools/p2_probe.py 50000000 1270 1 shared 2>&1 | tail -2 | tr '\n' ' ' | awk '{printf "%s %s s\n", $3, $11}'
 done; done
