@@ -147,7 +147,7 @@ constexpr uint32_t AD_GRID_LATENCY_PIECES = 256;
 constexpr uint32_t AD_STAGE_LATENCY_PIECES = ECAL_AD_STAGE_LATENCY_PIECES;
 // pieces at work up to which the slicer's latency form takes the third pass's windows (4096 .. 5119 events) in its one launch too
 #ifndef ECAL_AD_THIRD_IN_ONE_PIECES
-#define ECAL_AD_THIRD_IN_ONE_PIECES 2048   // (64 / 256 / 700 / always: 0.093 - 0.094 / 0.092 / 0.092 / 0.090 - 0.091 s at 1270 pieces, 0.088 - 0.091 / 0.087 / 0.086 - 0.087 / 0.084 - 0.085 at 4096)
+#define ECAL_AD_THIRD_IN_ONE_PIECES 600    // (with the two-pass form at two workgroups per CU — 64 / 256 / 700 / always: 0.093 - 0.094 / 0.092 / 0.092 / 0.090 - 0.091 s at 1270 pieces; with it compiled for three: 600 / 1000 / always: 0.0850 - 0.0852 / 0.0854 - 0.0856 / 0.0862 - 0.0865)
 #endif
 constexpr uint32_t AD_THIRD_IN_ONE_PIECES = ECAL_AD_THIRD_IN_ONE_PIECES;
 // the search's tail: with at most AD_TAIL_PIECES pieces at work a pass is launched over AD_TAIL_SLOTS window slots (run_passes)

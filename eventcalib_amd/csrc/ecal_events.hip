@@ -623,8 +623,10 @@ __global__ __launch_bounds__(PXH_T) void slice_hash_kernel(const uint8_t *__rest
 // a window of 2048 .. 4095 events does not wait for the first pass's launch to drain.  Same device code per window, same results;
 // a window the first-pass code cannot take for another reason (more than 1109 keys of a polarity, a non-pixel coordinate) still
 // goes to ITS list, which the second pass behind this launch works off (and the second pass's leftovers the third).
+// (THIRD = false is the form of the search's EARLY passes — thousands of windows, throughput again —: compiled for three workgroups
+// per CU, which its 52 KB of LDS allow; the third pass's windows then go through slice_hash_third_kernel behind it)
 template <bool THIRD /* windows of 4096 .. 5119 events go through the third pass's code in this launch too */>
-__global__ __launch_bounds__(PXH_T) void slice_hash_ref_both_kernel(const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo,
+__global__ __launch_bounds__(PXH_T) __attribute__((amdgpu_waves_per_eu(THIRD ? 2 : 3, THIRD ? 2 : 3))) void slice_hash_ref_both_kernel(const uint8_t *__restrict__ rec, const uint32_t *__restrict__ win_lo,
                                                                     const uint32_t *__restrict__ win_hi, const uint32_t *__restrict__ win_base,
                                                                     uint32_t cap_points, double *__restrict__ xy_out, uint32_t *__restrict__ seg_off,
                                                                     uint32_t *__restrict__ seg_cnt, int32_t *__restrict__ event_point, int *overflow,
