@@ -353,6 +353,54 @@ def test_hash_slicer_third_pass_equals_general_slicer(env):
             assert np.array_equal(a[5][o:o + c], b[5][o:o + c]), (s, pol)
 
 
+def test_third_pass_edges_equal_the_oracle(env):
+    """The third hash pass at its limits, every window against the ORACLE (real std::unordered_set order): exactly 4096 / 5119 / 5120
+    events; a set of exactly 2357 keys (the eighth epoch's bucket count: the last the pass holds) and of 2358 (a ninth epoch: the
+    general tiers'); all events one pixel; x beyond the pass's 511 (general tiers); heavy +/- cancellation."""
+    ctx, pipe, torch = env
+    rng = np.random.default_rng(77)
+    recs, bounds = [], []
+    t_at = [0.0]
+
+    def window(x, y, p):
+        n = len(x)
+        t = t_at[0] + 1e-6 * (1 + np.arange(n))
+        recs.append(O.pack_events(t, np.asarray(x, np.float64), np.asarray(y, np.float64), np.asarray(p, np.uint8)))
+        bounds.append((t[0], t[-1]))
+        t_at[0] = t[-1] + 1e-3
+
+    def distinct(n_keys, n_events, pol):   # n_keys distinct pixels (x <= 511), the rest duplicates of them
+        pix = rng.choice(512 * 300, n_keys, replace=False)
+        idx = np.concatenate([np.arange(n_keys), rng.integers(0, n_keys, n_events - n_keys)])
+        idx[n_keys:] = idx[n_keys:][rng.permutation(n_events - n_keys)]
+        return pix[idx] // 300, pix[idx] % 300, np.full(n_events, pol)
+
+    for n in (4096, 5119, 5120):   # (a 60 x 50 patch: ~1700 keys per polarity, within the pass's 2357)
+        window(rng.integers(100, 160, n), rng.integers(100, 150, n), rng.integers(0, 2, n))
+    for keys in (2357, 2358):
+        x, y, p = distinct(keys, 4500, 1)
+        window(x, y, p)
+        xa, ya, pa = distinct(keys, 2400, 0)
+        xb, yb, pb = distinct(1500, 2300, 1)
+        window(np.concatenate([xa, xb]), np.concatenate([ya, yb]), np.concatenate([pa, pb]))
+    window(np.full(4700, 17), np.full(4700, 3), rng.integers(0, 2, 4700))
+    x = rng.integers(0, 346, 4600)
+    x[1234] = 600
+    window(x, rng.integers(0, 260, 4600), rng.integers(0, 2, 4600))
+    window(rng.integers(0, 40, 5000), rng.integers(0, 30, 5000), rng.integers(0, 2, 5000))
+    rec = np.concatenate(recs)
+    t0 = [b[0] for b in bounds]
+    t1 = [b[1] + 5e-7 for b in bounds]
+    pipe.set_windows(t0, t1)
+    pipe.run(torch.from_numpy(rec).cuda(), slots=rec.size // 25 + 64)
+    torch.cuda.synchronize()
+    _compare(pipe, torch, rec, t0, t1, check_labels=False)
+    if ctx.point_order() == "reference":
+        fmt = pipe.seg_fmt[:2 * len(t0)].cpu().numpy()[0::2]
+        # packed = taken by a hash pass: 4096, 5119 yes, 5120 no; 2357 keys yes (both windows), 2358 no; one pixel yes; x = 600 no; the last yes
+        assert [int(v != 0) for v in fmt] == [1, 1, 0, 1, 1, 0, 0, 1, 0, 1]
+
+
 def test_golden_eventframe_order_fixtures(env):
     """`.bin` records -> the reference's point order -> DBSCAN labels, against the committed fixtures
     (tests/golden/eventframe_order_*.npz: real std::unordered_set + the reference's kd-tree, made in the build container)."""
