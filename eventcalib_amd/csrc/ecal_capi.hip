@@ -8,7 +8,7 @@ constexpr uint32_t ZERO_RING_WORDS = 16384, ZERO_RING_GRAIN = 16;
 // The environment of the library, read once per context (ecal_init; ecal_debug_reload_env for tests):
 //   ECAL_FORCE          test knobs, comma-separated: which tier / routine produces a result, never what the result is —
 //                       slice_general, dbscan_general, dbscan_generic_disc, extract_no_inline_ties, bounds_two_kernels, grid_one_wave,
-//                       grid_serial_walk, solver_no_stream (the parity tests run the forms against each other)
+//                       grid_serial_walk, solver_no_stream, latency_two_pass, latency_forms (the parity tests run the forms against each other)
 //   ECAL_TRACE          stderr traces, comma-separated: adaptive, grid, solver, load
 //   ECAL_ADAPTIVE_SHAPE the look-ahead of the keyframe search, comma-separated key=value: depth, depth_max, side, tree (any shape
 //                       gives the same keyframes: tests/test_gpu_adaptive.py)
@@ -53,6 +53,7 @@ void ecal_read_switches(ecal_switches &sw) {
     sw.grid_one_wave = has("ECAL_FORCE", "grid_one_wave");
     sw.grid_serial_walk = has("ECAL_FORCE", "grid_serial_walk");
     sw.solver_no_stream = has("ECAL_FORCE", "solver_no_stream");
+    sw.latency_forms = has("ECAL_FORCE", "latency_forms") ? 2 : (has("ECAL_FORCE", "latency_two_pass") ? 1 : 0);
     sw.adaptive_trace = has("ECAL_TRACE", "adaptive");
     sw.grid_debug = has("ECAL_TRACE", "grid");
     sw.solver_trace = has("ECAL_TRACE", "solver");

@@ -25,6 +25,7 @@ struct ecal_switches {
     // which tier / routine produces a result (parity tests run the tiers against each other)
     bool slice_no_pixel = false, dbscan_no_pixel = false, dbscan_generic_disc = false, extract_no_inline_ties = false;
     bool bounds_two_kernels = false, grid_one_wave = false, grid_serial_walk = false, solver_no_stream = false;
+    int latency_forms = 0;   // ECAL_FORCE=latency_two_pass / latency_forms: 1 / 2 (ecal_latency_level)
     // traces (stderr)
     bool adaptive_trace = false, grid_debug = false, solver_trace = false, load_trace = false;
     // shape of the keyframe search's look-ahead (tests: any shape gives the same keyframes); 0 / -1: not set
@@ -179,6 +180,9 @@ inline int ecal_tail_plan(const ecal_ctx *ctx, int first) {
     if (a != 0xFFFFFFFFu && b == 0u) return ECAL_PLAN_SEMI;
     return ECAL_PLAN_TIERED;
 }
+// the latency forms' level of a stage call: the caller's word (ecal_ctx::latency_pass), or 1 / 2 under ECAL_FORCE=latency_two_pass /
+// latency_forms (tests: the forms against the staged passes outside the keyframe search)
+inline int ecal_latency_level(const ecal_ctx *ctx) { return ctx->sw.latency_forms ? ctx->sw.latency_forms : ctx->latency_pass; }
 // a roctx range for the lifetime of the object (nothing when the context has no marker library loaded)
 struct ecal_range {
     const ecal_ctx *c;

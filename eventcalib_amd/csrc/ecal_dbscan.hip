@@ -353,7 +353,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
         cnt_b = second_pass ? cnt2 : nullptr;
         // floor(eps^2) == 16 (the shipped eps = 4): the disc is compiled in; any other radius takes the generic form
         if (geom.e2i == 16 && !ctx->sw.dbscan_generic_disc) {
-            if (ctx->latency_pass && second_pass)   // (few windows at work: a segment goes through the pass its size asks for in ONE launch)
+            if (ecal_latency_level(ctx) && second_pass)   // (few windows at work: a segment goes through the pass its size asks for in ONE launch)
                 hipLaunchKernelGGL((dbscan_pixel_both_kernel<16, PX_CAP, PX_CAP2>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st,
                                    d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, list2, cnt2, xy16, sfmt, tree,
                                    tflag, ctx->px_tree_epoch);
@@ -361,7 +361,7 @@ extern "C" int ecal_dbscan_batch_packed_dev(ecal_ctx *ctx, double *d_xy, const u
             hipLaunchKernelGGL((dbscan_pixel_kernel<16, PX_CAP>), dim3(S), dim3(PX_T), PixelLayout<PX_CAP>::bytes, st,
                                d_xy, d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list, cnt, xy16, sfmt, tree, tflag,
                                ctx->px_tree_epoch);
-            if (second_pass && !ctx->latency_pass)   // (latency form: both passes were that one launch, the first pass's list is empty)
+            if (second_pass && !ecal_latency_level(ctx))   // (latency form: both passes were that one launch, the first pass's list is empty)
                 hipLaunchKernelGGL((dbscan_pixel_list_kernel<16, PX_CAP2>), dim3(grid2), dim3(PX_T), PixelLayout<PX_CAP2>::bytes, st, d_xy,
                                    d_seg_off, d_seg_cnt, geom, minpts, d_labels, d_n_clusters, list2, cnt2,
                                    (const uint32_t *) list, (const uint32_t *) cnt, xy16, sfmt, tree, tflag, ctx->px_tree_epoch);

@@ -308,7 +308,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
         if (fit) ECAL_DET_FIRST(true, 1); else ECAL_DET_FIRST(false, 1);
     } else if (mode == 2) {
         if (fit) ECAL_DET_FIRST(true, 2);
-        else if (ctx->latency_pass)   // (few windows at work: a window goes through the pass its size asks for in ONE launch)
+        else if (ecal_latency_level(ctx))   // (few windows at work: a window goes through the pass its size asks for in ONE launch)
             hipLaunchKernelGGL((extract_both_kernel<false, 2>), dim3(S), dim3(DET_T), DET_LDS_BOTH, st, d_xy, d_seg_off, d_seg_cnt, d_labels,
                                d_n_clusters, prm, d_win_info, d_cand_pair, d_cand_xyr, d_kept_labels, d_rep, mem, ko, ks, so, no, list, cnt,
                                d_order, d_tie_list, d_tie_count, d_tie_mark);
@@ -321,7 +321,7 @@ static int extract_batch(ecal_ctx *ctx, const double *d_xy, const uint32_t *d_se
             if (fit) ECAL_DET_SECOND(true, 1); else ECAL_DET_SECOND(false, 1);
         } else if (mode == 2) {
             // (latency form: extract_both_kernel took the second pass's windows itself and lists none)
-            if (fit) ECAL_DET_SECOND(true, 2); else if (!ctx->latency_pass) ECAL_DET_SECOND(false, 2);
+            if (fit) ECAL_DET_SECOND(true, 2); else if (!ecal_latency_level(ctx)) ECAL_DET_SECOND(false, 2);
         } else {
             if (fit) ECAL_DET_SECOND(true, 0); else ECAL_DET_SECOND(false, 0);
         }

@@ -1002,11 +1002,11 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
             if ((rc = ecal_ensure_bucket_table(ctx, st))) return rc;
             // (few windows at work: a window goes through the pass its size asks for in ONE launch; very few — latency_pass 2, the
             // tail of the keyframe search —: the third pass's windows as well, in workgroups of 66 KB instead of 52)
-            if (ctx->latency_pass >= 2 && !lean)
+            if (ecal_latency_level(ctx) >= 2 && !lean)
                 hipLaunchKernelGGL(slice_hash_ref_both_kernel<true>, dim3(S), dim3(PXH_T), H13, st, d_events, d_win_lo, d_win_hi, d_win_base,
                                    cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, list2, cnt2, list3, cnt3,
                                    (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
-            else if (ctx->latency_pass && !lean)
+            else if (ecal_latency_level(ctx) && !lean)
                 hipLaunchKernelGGL(slice_hash_ref_both_kernel<false>, dim3(S), dim3(PXH_T), H12, st, d_events, d_win_lo, d_win_hi, d_win_base,
                                    cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, list2, cnt2, list3, cnt3,
                                    (const uint2 *) ctx->bucket_tab.ptr, xy16, sfmt);
@@ -1019,7 +1019,7 @@ extern "C" int ecal_slice_events_packed_dev(ecal_ctx *ctx, const uint8_t *d_even
             hipLaunchKernelGGL(slice_hash_kernel, dim3(S), dim3(PXH_T), PixHash<11>::bytes, st, d_events, d_win_lo, d_win_hi,
                                d_win_base, cap_points, d_xy, d_seg_off, d_seg_cnt, d_event_point, d_overflow, list, cnt, xy16, sfmt);
         // (reference order: the second pass also takes the windows whose sets outgrow the first pass's bucket tables)
-        if (reforder && !lean && ctx->latency_pass >= 2) {   // (all three passes were that one launch: its only list is the general tiers')
+        if (reforder && !lean && ecal_latency_level(ctx) >= 2) {   // (all three passes were that one launch: its only list is the general tiers')
             cnt_b = cnt3;
             todo = list3;
             todo_count = cnt3;
