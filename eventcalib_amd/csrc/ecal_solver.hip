@@ -1616,13 +1616,3 @@ extern "C" int ecal_debug_arrow_solve(ecal_solver *s, const double *accum, const
     return ecal_debug_arrow_solve_host(s->n_cp, accum, scale, radius, min_diag, max_diag, delta_out, fail_out, mode, 0);
 }
 
-#ifdef ECAL_PHASE_PROF
-extern "C" int ecal_debug_ar_cycles(unsigned long long *out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(ecal::g_ar_cycles), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(ecal::g_ar_cycles), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
