@@ -160,7 +160,9 @@ static uint32_t adaptive_slots_per_piece(uint32_t pieces, int forced = 0) {
     // 0.094-0.098 / -; 16384 pieces 0.152 / 0.168-0.179 / 0.165; 1270 pieces 5 / 6 / 7: 0.107 / 0.105 / 0.104; a second box: 1800 pieces
     // 4 / 6: 0.123-0.131 / 0.140; 2300 pieces 4 / 5 / 6: 0.132-0.135 / 0.122-0.128 / 0.150; 3000 pieces 2 / 4: 0.121-0.148 / 0.108 —
     // tools/depth_sweep.sh; the boxes differ by more than neighbouring settings do)
-    return pieces <= 1536u ? 6u : (pieces <= 3500u ? 4u : (pieces <= 8192u ? 2u : 1u));
+    // (with the third hash pass and the look-ahead of round 6's end, 1270 pieces 6 / 7 / 8 / 9: 0.0848 - 0.0856 / 0.0839 - 0.0840 / 0.0877 /
+    // 0.0966: seven where that makes a pass of 8 - 9 thousand slots)
+    return pieces <= 1100u ? 6u : (pieces <= 1400u ? 7u : (pieces <= 1536u ? 6u : (pieces <= 3500u ? 4u : (pieces <= 8192u ? 2u : 1u))));
 }
 static uint32_t adaptive_depth_max(int forced = 0) {
     if (forced >= 1 && forced <= 64) return (uint32_t) forced;   // (ECAL_ADAPTIVE_SHAPE depth_max: debug / measurement switch)
