@@ -104,6 +104,21 @@ uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n) {
     return p;
 }
 
+unsigned char *ecal_fetch_pinned(ecal_ctx *ctx, size_t bytes) {
+    if (ctx->fetch_pinned_cap >= bytes) return ctx->fetch_pinned;
+    if (ctx->fetch_pinned) (void) hipHostFree(ctx->fetch_pinned);
+    ctx->fetch_pinned = nullptr;
+    ctx->fetch_pinned_cap = 0;
+    const size_t want = (bytes + bytes / 4 + 4095) & ~(size_t) 4095;
+    if (hipHostMalloc((void **) &ctx->fetch_pinned, want, hipHostMallocDefault) != hipSuccess) {
+        (void) hipGetLastError();
+        ctx->fetch_pinned = nullptr;
+        return nullptr;
+    }
+    ctx->fetch_pinned_cap = want;
+    return ctx->fetch_pinned;
+}
+
 int ecal_ensure(ecal_ctx *ctx, ecal_devbuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return ECAL_OK;
@@ -203,6 +218,7 @@ extern "C" void ecal_destroy(ecal_ctx *ctx) {
     for (auto &e : ctx->adaptive_ev)
         if (e) (void) hipEventDestroy(e);
     if (ctx->pass_pinned) (void) hipHostFree(ctx->pass_pinned);
+    if (ctx->fetch_pinned) (void) hipHostFree(ctx->fetch_pinned);
     if (ctx->wb_done) (void) hipEventDestroy(ctx->wb_done);
     for (int k = 0; k < 2; k++) {
         if (ctx->ev_uploaded[k]) (void) hipEventDestroy(ctx->ev_uploaded[k]);

@@ -80,6 +80,8 @@ struct ecal_ctx {
     hipStream_t copy_stream = nullptr;      // uploads of the double-buffered ingest
     double *pass_pinned = nullptr;          // ecal_detect_pass: pinned window bounds in, packed verdicts out
     size_t pass_pinned_cap = 0;
+    unsigned char *fetch_pinned = nullptr;  // ecal_fetch_pinned: pinned staging of the larger result downloads (a hipMemcpy into pageable memory the runtime has not seen before runs at ~0.3 GB/s: 25 - 30 ms for the keyframe search's 8 MB in the first calls of a process)
+    size_t fetch_pinned_cap = 0;
     hipEvent_t ev_uploaded[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
     ecal_devbuf host_pipe[17];  // staging of ecal_detect_batch
     ecal_devbuf host_grid_order, host_grid_found;
@@ -198,5 +200,7 @@ struct ecal_range {
 // n <= 16 words that are zero once everything enqueued on `st` so far has run, or nullptr (more streams than rings, no memory):
 // the caller then zeroes words of its own.  They stay the caller's for the next 512 calls on that stream at least.
 uint32_t *ecal_zero_words(ecal_ctx *ctx, hipStream_t st, uint32_t n);
+// pinned host staging of at least `bytes` (grow-only, contents NOT preserved; nullptr: no memory — the caller copies the slow way)
+unsigned char *ecal_fetch_pinned(ecal_ctx *ctx, size_t bytes);
 // ensure a scratch buffer of at least `bytes` (contents are NOT preserved)
 int ecal_ensure(ecal_ctx *ctx, ecal_devbuf &b, size_t bytes);
