@@ -717,12 +717,28 @@ struct CalibWork {
     uint32_t V, n;
     double *d_obj, *d_img, *d_intr, *d_view[2], *d_blocks[2], *d_view_red, *d_red, *d_xi;
     double *h_red;  // pinned
+    // pinned staging of the small uploads (the intrinsics of an evaluation, two slots in turn; the reduced step): a hipMemcpyAsync
+    // from the caller's stack goes through the runtime's pageable path — a staging copy and a wait of its own, three to four times
+    // per LM iteration, each as long as the kernels it sits between
+    double *h_intr[2], *h_xi;
+    int intr_slot = 0;
+    // the two view-parameter arrays of the step test (accepted state, candidate) ride on the NEXT reduce_to_host's synchronisation
+    // when the caller asks for them here (a download + wait of their own was a third of an LM iteration's round trips)
+    double *fetch_views[2] = {nullptr, nullptr};
+    int fetch_from[2] = {0, 0};
     const ecal_calib_options *opt;
     int jac_evals = 0, err_evals = 0;
 };
 
+// (every use of a slot is followed by a synchronisation of the stream before the slot comes round again: cost_of / reduced_step)
+static const double *stage_intr(CalibWork &w, const double *intr) {
+    double *h = w.h_intr[w.intr_slot ^= 1];
+    for (int j = 0; j < CB_NI; j++) h[j] = intr[j];
+    return h;
+}
+
 int launch_eval(CalibWork &w, const double *intr, int which_view, int which_blocks, int with_jac) {
-    ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.d_intr, intr, CB_NI * sizeof(double), hipMemcpyHostToDevice, w.st));
+    ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.d_intr, stage_intr(w, intr), CB_NI * sizeof(double), hipMemcpyHostToDevice, w.st));
     if (w.V) hipLaunchKernelGGL(calib_eval_kernel, dim3(w.V), dim3(CBK_T), 0, w.st, w.d_obj, w.n, w.d_img, w.cc, w.d_intr,
                        w.d_view[which_view], with_jac, w.d_blocks[which_blocks]);
     if (with_jac) w.jac_evals++;
@@ -740,6 +756,11 @@ int reduce_to_host(CalibWork &w) {
         }
     }
     ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.h_red, w.d_red, CB_RED * sizeof(double), hipMemcpyDeviceToHost, w.st));
+    if (w.fetch_views[0] && w.V) {
+        for (int k = 0; k < 2; k++)
+            ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.fetch_views[k], w.d_view[w.fetch_from[k]], 6 * (size_t) w.V * sizeof(double), hipMemcpyDeviceToHost, w.st));
+    }
+    w.fetch_views[0] = w.fetch_views[1] = nullptr;
     ECAL_HIP_TRY(w.ctx, hipStreamSynchronize(w.st));
     return ECAL_OK;
 }
@@ -785,7 +806,8 @@ int reduced_step(CalibWork &w, int which_blocks, double lambda, double *x_i) {
 }
 
 int launch_update(CalibWork &w, int which_blocks, double lambda, const double *x_i, double scale, int from_view, int to_view) {
-    ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.d_xi, x_i, CB_NI * sizeof(double), hipMemcpyHostToDevice, w.st));
+    for (int j = 0; j < CB_NI; j++) w.h_xi[j] = x_i[j];
+    ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.d_xi, w.h_xi, CB_NI * sizeof(double), hipMemcpyHostToDevice, w.st));
     if (w.V) hipLaunchKernelGGL(calib_update_kernel, dim3(w.V), dim3(CBK_T), 0, w.st, w.d_blocks[which_blocks], lambda, w.d_xi, scale,
                        w.d_view[from_view], w.d_view[to_view]);
     return ECAL_OK;
@@ -793,7 +815,7 @@ int launch_update(CalibWork &w, int which_blocks, double lambda, const double *x
 
 int launch_pose(CalibWork &w, const double *intr, int which_view, const uint32_t *d_valid, double thresh, int rounds, int refine_iters,
                 uint32_t *d_inl, double *d_err, uint32_t *d_ok) {
-    ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.d_intr, intr, CB_NI * sizeof(double), hipMemcpyHostToDevice, w.st));
+    ECAL_HIP_TRY(w.ctx, hipMemcpyAsync(w.d_intr, stage_intr(w, intr), CB_NI * sizeof(double), hipMemcpyHostToDevice, w.st));
     if (w.V) hipLaunchKernelGGL(view_pose_kernel, dim3(w.V), dim3(CBK_T), 0, w.st, w.d_obj, w.n, w.d_img, d_valid, w.cc, w.d_intr, thresh,
                        rounds, refine_iters, (double) FLT_EPSILON, w.d_view[which_view], d_inl, d_err, d_ok);
     return ECAL_OK;
@@ -946,8 +968,11 @@ extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n
     w.d_xi = base + o_xi;
     double *d_H = base + o_H, *d_err = base + o_err;
     uint32_t *d_ok = (uint32_t *) (base + o_ok);
-    if (!ctx->calib_pinned) ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &ctx->calib_pinned, CB_RED_STRIDE * sizeof(double), hipHostMallocDefault));
+    if (!ctx->calib_pinned) ECAL_HIP_TRY(ctx, hipHostMalloc((void **) &ctx->calib_pinned, (CB_RED_STRIDE + 48) * sizeof(double), hipHostMallocDefault));
     w.h_red = ctx->calib_pinned;
+    w.h_intr[0] = ctx->calib_pinned + CB_RED_STRIDE;
+    w.h_intr[1] = w.h_intr[0] + 16;
+    w.h_xi = w.h_intr[1] + 16;
     ECAL_HIP_TRY(ctx, hipMemcpyAsync(w.d_obj, obj, 3 * (size_t) n_pts * sizeof(double), hipMemcpyHostToDevice, w.st));
     if (n_views) ECAL_HIP_TRY(ctx, hipMemcpyAsync(w.d_img, img, 2 * (size_t) n_pts * n_views * sizeof(double), hipMemcpyHostToDevice, w.st));
 
@@ -1052,6 +1077,13 @@ extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n
     if (opt->model == 0) {
         // CvLevMarq::updateAlt (see oracle/calib_oracle.py::levmarq)
         int lam_lg10 = -3;
+        std::vector<double> view_pageable;
+        double *view_a = reinterpret_cast<double *>(ecal_fetch_pinned(ctx, 12 * (size_t) Va * sizeof(double)));   // (pinned: see CalibWork::h_intr)
+        if (!view_a) {
+            view_pageable.resize(12 * (size_t) Va);
+            view_a = view_pageable.data();
+        }
+        double *const view_b = view_a + 6 * (size_t) Va;
         if ((rc = launch_eval(w, intr, cur, cur, 1))) return rc;
         if ((rc = cost_of(w, cur, &err, &npts))) return rc;
         for (;;) {
@@ -1064,6 +1096,12 @@ extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n
                 if (w.cc.fix_aspect) cand[0] = cand[1] * opt->aspect_ratio;
                 if ((rc = launch_update(w, cur, lam, x_i, 1.0, cur, cur ^ 1))) return rc;
                 if ((rc = launch_eval(w, cand, cur ^ 1, cur ^ 1, 1))) return rc;
+                if (view_a) {   // (the step test below wants both states' view parameters: with this cost's download)
+                    w.fetch_views[0] = view_a;
+                    w.fetch_views[1] = view_b;
+                    w.fetch_from[0] = cur;
+                    w.fetch_from[1] = cur ^ 1;
+                }
                 if ((rc = cost_of(w, cur ^ 1, &err, nullptr))) return rc;
                 if (!(err <= prev_err)) {
                     if (++lam_lg10 <= 16) continue;
@@ -1075,11 +1113,8 @@ extern "C" int ecal_calibrate_views(ecal_ctx *ctx, const double *obj, uint32_t n
             // relative parameter change over the whole vector: the view part comes from the device
             double dn = 0, pn = 0;
             {
-                std::vector<double> a(6 * (size_t) Va), b(6 * (size_t) Va);
+                const double *const a = view_a, *const b = view_b;   // (arrived with the last cost: the accepted state's and the candidate's)
                 if (n_views) {
-                    ECAL_HIP_TRY(ctx, hipMemcpyAsync(a.data(), w.d_view[cur], 6 * (size_t) n_views * sizeof(double), hipMemcpyDeviceToHost, w.st));
-                    ECAL_HIP_TRY(ctx, hipMemcpyAsync(b.data(), w.d_view[cur ^ 1], 6 * (size_t) n_views * sizeof(double), hipMemcpyDeviceToHost, w.st));
-                    ECAL_HIP_TRY(ctx, hipStreamSynchronize(w.st));
                     for (size_t k = 0; k < 6 * (size_t) n_views; k++) {
                         dn += (b[k] - a[k]) * (b[k] - a[k]);
                         pn += a[k] * a[k];
